@@ -1,0 +1,94 @@
+"""ctypes binding of ``libpup_hip.so`` (C ABI declared in ``include/pup_hip.h``).
+
+This is the ONLY way the Python host layer reaches the HIP kernels.  There is no CPU fallback:
+if the shared library is missing the import of :func:`lib` fails loudly, and if no GPU is visible
+``pup_create`` fails with the HIP error text.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpup_hip.so")
+
+# mode bits (mirror include/pup_hip.h)
+MODE_OOE = 0x01
+MODE_EXPECTED = 0x02
+MODE_COV = 0x04
+MODE_TRANSPOSE = 0x08
+MODE_DEVPTR = 0x10
+
+PUP_OK = 0
+ERROR_NAMES = {
+    -1: "PUP_EINVAL", -2: "PUP_ENOMEM", -3: "PUP_EHIP", -4: "PUP_ESTATE", -5: "PUP_ERANGE", -6: "PUP_ENOTSUP",
+}
+
+
+class PupStats(C.Structure):
+    _fields_ = [
+        ("k1_ms", C.c_double),
+        ("reduce_ms", C.c_double),
+        ("k1_launches", C.c_int64),
+        ("snippets", C.c_int64),
+        ("pixels_in_windows", C.c_int64),
+        ("probe_loads", C.c_int64),
+    ]
+
+
+class PupError(RuntimeError):
+    """A libpup_hip call returned a negative code."""
+
+    def __init__(self, code, msg):
+        self.code = code
+        super().__init__(f"{ERROR_NAMES.get(code, code)}: {msg}")
+
+
+# every symbol include/pup_hip.h declares, with its signature
+_SIGNATURES = {
+    "pup_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "pup_destroy": (None, [C.c_void_p]),
+    "pup_last_error": (C.c_char_p, [C.c_void_p]),
+    "pup_version": (C.c_int, []),
+    "pup_device_count": (C.c_int, []),
+    "pup_load_pixels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64]),
+    "pup_load_bins": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pup_set_expected": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "pup_reset": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "pup_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                 C.c_int32, C.c_uint32]),
+    "pup_sync": (C.c_int, [C.c_void_p]),
+    "pup_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pup_packed_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "pup_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pup_import": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pup_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "pup_get_stats": (C.c_int, [C.c_void_p, C.POINTER(PupStats)]),
+    "pup_clear_stats": (C.c_int, [C.c_void_p]),
+    "pup_event_record": (C.c_int, [C.c_void_p, C.c_int]),
+    "pup_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "pup_set_tuning": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP extension was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or coolpuppy_amd.build.build_hip()). "
+                "There is no CPU fallback."
+            )
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)   # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def declared_symbols():
+    return sorted(_SIGNATURES)

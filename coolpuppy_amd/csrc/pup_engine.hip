@@ -1,0 +1,550 @@
+// pup_engine.hip — C ABI (include/pup_hip.h) over the gfx950 pile-up kernels.
+//
+// Host-side responsibilities: device residency of the pixel table / bin vectors / expected,
+// chunking of tile-grouped snippets, kernel launches on one HIP stream, deterministic two-level
+// reduction of per-chunk partial tiles into the running accumulators, HIP-event timing.
+// Replaces the data handling of PileUpper.get_data / _stream_snips / accumulate_stream
+// (reference coolpuppy/coolpup.py:1024-1057, 1059-1191, 1236-1283) — see the header for the map.
+#include "../../include/pup_hip.h"
+#include "pup_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error = "";
+
+template <typename T>
+struct DevBuf {           // grow-only device buffer
+    T* p = nullptr;
+    size_t cap = 0;       // elements
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = n + n / 4 + 16;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
+        if (e != hipSuccess) { p = nullptr; cap = 0; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct pup_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // resident tables
+    DevBuf<long long> indptr;
+    DevBuf<int2> px;
+    DevBuf<double> weight, cov, expv;
+    bool have_px = false, have_weight = false, have_cov = false;
+    long long nbins = 0, nnz = 0, nexp = 0;
+    // accumulators (packed layout of the header)
+    DevBuf<double> acc_f64;
+    DevBuf<long long> acc_i64;
+    int T = 0, pad = 0, W = 0;
+    // workspaces
+    DevBuf<int> d_r0, d_c0;
+    DevBuf<unsigned char> d_flip;
+    DevBuf<long long> d_chunk_begin, d_chunk_end, d_seg1, d_seg2, d_dn;
+    DevBuf<double> part_f64, slice_f64;
+    DevBuf<unsigned> part_num;
+    DevBuf<long long> slice_num;
+    DevBuf<unsigned long long> counters;   // [2]
+    DevBuf<int> d_err;
+    // stats / timing
+    bool profiling = false;
+    pup_stats stats{};
+    struct EvTriple { hipEvent_t a, b, c; };   // K1 = a..b, reduction = b..c
+    std::vector<EvTriple> pending;             // awaiting a stream sync
+    hipEvent_t slots[8] = {};
+    int chunk_snippets = 0, variant = 0;
+    int max_lds = 0, n_cu = 0;
+};
+
+namespace {
+
+int fail(pup_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                  \
+    do { hipError_t e_ = (expr);                                                           \
+         if (e_ != hipSuccess)                                                             \
+             return fail((ctx), e_ == hipErrorOutOfMemory ? PUP_ENOMEM : PUP_EHIP,         \
+                         "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+int bind(pup_ctx* c) {
+    HIPCHK(c, hipSetDevice(c->device));
+    return PUP_OK;
+}
+
+// drain finished event triples into the stats (after a stream sync)
+void collect_events(pup_ctx* c) {
+    for (auto& p : c->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { c->stats.k1_ms += ms; c->stats.k1_launches += 1; }
+        if (hipEventElapsedTime(&ms, p.b, p.c) == hipSuccess) c->stats.reduce_ms += ms;
+        (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); (void)hipEventDestroy(p.c);
+    }
+    c->pending.clear();
+}
+
+int check_async_error(pup_ctx* c) {
+    if (!c->d_err.p) return PUP_OK;
+    int h = 0;
+    HIPCHK(c, hipMemcpy(&h, c->d_err.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (h) {
+        int zero = 0;
+        HIPCHK(c, hipMemcpy(c->d_err.p, &zero, sizeof(int), hipMemcpyHostToDevice));
+        return fail(c, PUP_ERANGE, "a snippet window leaves the bin table [0, %lld)", c->nbins);
+    }
+    return PUP_OK;
+}
+
+template <int WT>
+void launch_k1(const pup::K1Args& a, int nchunks, size_t lds, hipStream_t s) {
+    hipLaunchKernelGGL(pup::pileup_chunk_kernel<WT>, dim3(nchunks), dim3(pup::kWave), lds, s, a);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pup_version(void) { return 100; }
+
+int pup_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { g_create_error = hipGetErrorString(e); return PUP_EHIP; }
+    return n;
+}
+
+const char* pup_last_error(const pup_ctx* ctx) {
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int pup_create(int device_id, pup_ctx** out) {
+    if (!out) return fail(nullptr, PUP_EINVAL, "pup_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, PUP_EHIP, "pup_create: no HIP device available (%s)",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device_id < 0 || device_id >= n)
+        return fail(nullptr, PUP_EINVAL, "pup_create: device_id %d out of range [0,%d)", device_id, n);
+    pup_ctx* c = new (std::nothrow) pup_ctx();
+    if (!c) return fail(nullptr, PUP_ENOMEM, "pup_create: out of host memory");
+    c->device = device_id;
+    if ((e = hipSetDevice(device_id)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+        delete c;
+        return fail(nullptr, PUP_EHIP, "pup_create: %s", hipGetErrorString(e));
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
+        c->max_lds = (int)prop.sharedMemPerBlock;
+        c->n_cu = prop.multiProcessorCount;
+    } else { c->max_lds = 64 * 1024; c->n_cu = 256; }
+    for (auto& s : c->slots) (void)hipEventCreate(&s);
+    if (c->counters.reserve(2) != hipSuccess || c->d_err.reserve(1) != hipSuccess) {
+        pup_destroy(c);
+        return fail(nullptr, PUP_ENOMEM, "pup_create: device allocation failed");
+    }
+    (void)hipMemset(c->counters.p, 0, 2 * sizeof(unsigned long long));
+    (void)hipMemset(c->d_err.p, 0, sizeof(int));
+    *out = c;
+    return PUP_OK;
+}
+
+void pup_destroy(pup_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    collect_events(c);
+    c->indptr.release(); c->px.release(); c->weight.release(); c->cov.release(); c->expv.release();
+    c->acc_f64.release(); c->acc_i64.release();
+    c->d_r0.release(); c->d_c0.release(); c->d_flip.release();
+    c->d_chunk_begin.release(); c->d_chunk_end.release(); c->d_seg1.release(); c->d_seg2.release();
+    c->d_dn.release();
+    c->part_f64.release(); c->slice_f64.release(); c->part_num.release(); c->slice_num.release();
+    c->counters.release(); c->d_err.release();
+    for (auto& s : c->slots) if (s) (void)hipEventDestroy(s);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int pup_load_pixels(pup_ctx* c, const int64_t* bin1_offset, const void* bin2_id, int bin2_bytes,
+                    const int32_t* count, int64_t nbins, int64_t nnz) {
+    if (!c) return PUP_EINVAL;
+    if (!bin1_offset || nbins <= 0 || nnz < 0 || (nnz > 0 && (!bin2_id || !count)))
+        return fail(c, PUP_EINVAL, "pup_load_pixels: NULL table or bad sizes (nbins=%lld nnz=%lld)",
+                    (long long)nbins, (long long)nnz);
+    if (bin2_bytes != 4 && bin2_bytes != 8)
+        return fail(c, PUP_EINVAL, "pup_load_pixels: bin2_bytes must be 4 or 8, got %d", bin2_bytes);
+    if (nbins > 0x7fffffffLL - 4096)
+        return fail(c, PUP_ENOTSUP, "pup_load_pixels: nbins %lld does not fit int32 bin ids", (long long)nbins);
+    if (bin1_offset[0] != 0 || bin1_offset[nbins] != nnz)
+        return fail(c, PUP_EINVAL, "pup_load_pixels: bin1_offset[0]=%lld, bin1_offset[nbins]=%lld, expected 0 and nnz=%lld",
+                    (long long)bin1_offset[0], (long long)bin1_offset[nbins], (long long)nnz);
+    int rc = bind(c); if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_px = false;
+    HIPCHK(c, c->indptr.reserve((size_t)nbins + 1));
+    HIPCHK(c, c->px.reserve((size_t)std::max<int64_t>(nnz, 1)));
+    HIPCHK(c, hipMemcpy(c->indptr.p, bin1_offset, ((size_t)nbins + 1) * sizeof(long long), hipMemcpyHostToDevice));
+    // stage bin2/count through a bounded device staging area and interleave on device
+    const size_t slab = (size_t)1 << 26;   // 64 Mi pixels per slab
+    void* d_col = nullptr; int* d_cnt = nullptr;
+    const size_t slab_n = (size_t)std::min<int64_t>(nnz, (int64_t)slab);
+    if (nnz > 0) {
+        HIPCHK(c, hipMalloc(&d_col, slab_n * (size_t)bin2_bytes));
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_cnt), slab_n * sizeof(int));
+        if (e != hipSuccess) { (void)hipFree(d_col); return fail(c, PUP_ENOMEM, "pup_load_pixels: staging alloc failed"); }
+    }
+    int status = PUP_OK;
+    for (int64_t off = 0; off < nnz && status == PUP_OK; off += (int64_t)slab) {
+        const size_t m = (size_t)std::min<int64_t>((int64_t)slab, nnz - off);
+        hipError_t e = hipMemcpy(d_col, static_cast<const char*>(bin2_id) + (size_t)off * bin2_bytes,
+                                 m * (size_t)bin2_bytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_cnt, count + off, m * sizeof(int), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            const int blocks = (int)std::min<size_t>((m + 255) / 256, 65536);
+            if (bin2_bytes == 8)
+                hipLaunchKernelGGL(pup::pack_pixels_kernel<long long>, dim3(blocks), dim3(256), 0, c->stream,
+                                   static_cast<const long long*>(d_col), d_cnt, c->px.p + off, (long long)m);
+            else
+                hipLaunchKernelGGL(pup::pack_pixels_kernel<int>, dim3(blocks), dim3(256), 0, c->stream,
+                                   static_cast<const int*>(d_col), d_cnt, c->px.p + off, (long long)m);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        }
+        if (e != hipSuccess) status = fail(c, PUP_EHIP, "pup_load_pixels: upload failed: %s", hipGetErrorString(e));
+    }
+    if (d_col) (void)hipFree(d_col);
+    if (d_cnt) (void)hipFree(d_cnt);
+    if (status != PUP_OK) return status;
+    c->nbins = nbins; c->nnz = nnz; c->have_px = true;
+    c->have_weight = c->have_cov = false;
+    return PUP_OK;
+}
+
+int pup_load_bins(pup_ctx* c, const double* weight, const double* cov) {
+    if (!c) return PUP_EINVAL;
+    if (!c->have_px) return fail(c, PUP_ESTATE, "pup_load_bins: call pup_load_pixels first");
+    int rc = bind(c); if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_weight = c->have_cov = false;
+    if (weight) {
+        HIPCHK(c, c->weight.reserve((size_t)c->nbins));
+        HIPCHK(c, hipMemcpy(c->weight.p, weight, (size_t)c->nbins * sizeof(double), hipMemcpyHostToDevice));
+        c->have_weight = true;
+    }
+    if (cov) {
+        HIPCHK(c, c->cov.reserve((size_t)c->nbins));
+        HIPCHK(c, hipMemcpy(c->cov.p, cov, (size_t)c->nbins * sizeof(double), hipMemcpyHostToDevice));
+        c->have_cov = true;
+    }
+    return PUP_OK;
+}
+
+int pup_set_expected(pup_ctx* c, const double* expected, int64_t n) {
+    if (!c) return PUP_EINVAL;
+    if (n < 0 || (n > 0 && !expected)) return fail(c, PUP_EINVAL, "pup_set_expected: bad arguments");
+    int rc = bind(c); if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // earlier launches may still read the old vector
+    c->nexp = 0;
+    if (n > 0) {
+        HIPCHK(c, c->expv.reserve((size_t)n));
+        HIPCHK(c, hipMemcpy(c->expv.p, expected, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+        c->nexp = n;
+    }
+    return PUP_OK;
+}
+
+int pup_reset(pup_ctx* c, int32_t n_tiles, int32_t pad) {
+    if (!c) return PUP_EINVAL;
+    if (n_tiles <= 0 || pad < 0) return fail(c, PUP_EINVAL, "pup_reset: n_tiles=%d pad=%d", n_tiles, pad);
+    const int W = 2 * pad + 1;
+    if (pup::k1_lds_bytes(W) > (size_t)c->max_lds)
+        return fail(c, PUP_ENOTSUP, "pup_reset: window %dx%d needs %zu B of LDS per wave, device offers %d",
+                    W, W, pup::k1_lds_bytes(W), c->max_lds);
+    int rc = bind(c); if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t W2 = (size_t)W * W;
+    const size_t nf = (size_t)n_tiles * (W2 + 2 * (size_t)W), ni = (size_t)n_tiles * (W2 + 1);
+    HIPCHK(c, c->acc_f64.reserve(nf));
+    HIPCHK(c, c->acc_i64.reserve(ni));
+    HIPCHK(c, hipMemsetAsync(c->acc_f64.p, 0, nf * sizeof(double), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->acc_i64.p, 0, ni * sizeof(long long), c->stream));
+    c->T = n_tiles; c->pad = pad; c->W = W;
+    return PUP_OK;
+}
+
+int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, const uint8_t* flip,
+                   int64_t n, const int64_t* tile_ptr, int32_t ignore_diags, uint32_t mode) {
+    if (!c) return PUP_EINVAL;
+    if (!c->have_px) return fail(c, PUP_ESTATE, "pup_accumulate: no pixel table loaded");
+    if (c->T <= 0) return fail(c, PUP_ESTATE, "pup_accumulate: call pup_reset first");
+    if (n < 0 || !tile_ptr || (n > 0 && (!r0 || !c0)))
+        return fail(c, PUP_EINVAL, "pup_accumulate: NULL snippet arrays or negative n");
+    if (tile_ptr[0] != 0 || tile_ptr[c->T] != n)
+        return fail(c, PUP_EINVAL, "pup_accumulate: tile_ptr must run from 0 to n=%lld (got %lld..%lld)",
+                    (long long)n, (long long)tile_ptr[0], (long long)tile_ptr[c->T]);
+    for (int t = 0; t < c->T; ++t)
+        if (tile_ptr[t + 1] < tile_ptr[t])
+            return fail(c, PUP_EINVAL, "pup_accumulate: tile_ptr decreases at tile %d", t);
+    const bool m_ooe = mode & PUP_MODE_OOE, m_exp = mode & PUP_MODE_EXPECTED;
+    if ((m_ooe || m_exp) && c->nexp == 0)
+        return fail(c, PUP_ESTATE, "pup_accumulate: OOE/EXPECTED mode without pup_set_expected");
+    if (m_ooe && m_exp) return fail(c, PUP_EINVAL, "pup_accumulate: OOE and EXPECTED are exclusive");
+    if ((mode & PUP_MODE_COV) && !c->have_cov)
+        return fail(c, PUP_ESTATE, "pup_accumulate: COV mode without a coverage vector");
+    if (n == 0) return PUP_OK;
+    int rc = bind(c); if (rc) return rc;
+
+    const int W = c->W;
+    const size_t W2 = (size_t)W * W, Lf = W2 + 2 * (size_t)W;
+
+    // ---- snippets to device ----------------------------------------------------------------------
+    const int *dr0, *dc0; const unsigned char* dfl = nullptr;
+    if (mode & PUP_MODE_DEVPTR) { dr0 = r0; dc0 = c0; dfl = flip; }
+    else {
+        // earlier launches may still read the staging buffers
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, c->d_r0.reserve((size_t)n)); HIPCHK(c, c->d_c0.reserve((size_t)n));
+        HIPCHK(c, hipMemcpy(c->d_r0.p, r0, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_c0.p, c0, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+        dr0 = c->d_r0.p; dc0 = c->d_c0.p;
+        if (flip) {
+            HIPCHK(c, c->d_flip.reserve((size_t)n));
+            HIPCHK(c, hipMemcpy(c->d_flip.p, flip, (size_t)n, hipMemcpyHostToDevice));
+            dfl = c->d_flip.p;
+        }
+    }
+
+    // ---- chunk table: equal snippet counts, cut at tile boundaries -------------------------------
+    long long C = c->chunk_snippets;
+    if (C <= 0) {
+        const long long target = (long long)std::max(c->n_cu, 64) * 32 * 4;   // ~4 chunks per wave slot
+        C = std::max<long long>(16, (n + target - 1) / target);
+    }
+    std::vector<long long> cb, ce, tile_chunk_ptr((size_t)c->T + 1, 0), dn((size_t)c->T);
+    for (int t = 0; t < c->T; ++t) {
+        const long long b = tile_ptr[t], e = tile_ptr[t + 1];
+        dn[(size_t)t] = e - b;
+        for (long long s = b; s < e; s += C) { cb.push_back(s); ce.push_back(std::min(e, s + C)); }
+        tile_chunk_ptr[(size_t)t + 1] = (long long)cb.size();
+    }
+    const long long nchunks = (long long)cb.size();
+    if (nchunks > 0x7fffffffLL) return fail(c, PUP_ENOTSUP, "pup_accumulate: too many chunks");
+    if (C > 0xffffffffLL) return fail(c, PUP_ENOTSUP, "pup_accumulate: chunk too long for 32-bit num partials");
+
+    // two-level reduction plan: chunks -> slices of <= S chunks (within a tile) -> tiles
+    const long long S = 64;
+    long long max_per_tile = 0;
+    for (int t = 0; t < c->T; ++t)
+        max_per_tile = std::max(max_per_tile, tile_chunk_ptr[(size_t)t + 1] - tile_chunk_ptr[(size_t)t]);
+    const bool two_level = max_per_tile > 2 * S;
+    std::vector<long long> seg1, seg2;   // seg1: slice -> chunk range; seg2: tile -> slice (or chunk) range
+    if (two_level) {
+        seg2.assign((size_t)c->T + 1, 0);
+        seg1.push_back(0);
+        for (int t = 0; t < c->T; ++t) {
+            const long long b = tile_chunk_ptr[(size_t)t], e = tile_chunk_ptr[(size_t)t + 1];
+            for (long long k = b; k < e; k += S) seg1.push_back(std::min(e, k + S));
+            seg2[(size_t)t + 1] = (long long)seg1.size() - 1;
+        }
+    } else seg2 = tile_chunk_ptr;
+    const long long nslices = two_level ? (long long)seg1.size() - 1 : 0;
+
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // chunk/segment tables of the previous call are free now
+    HIPCHK(c, c->d_chunk_begin.reserve((size_t)nchunks)); HIPCHK(c, c->d_chunk_end.reserve((size_t)nchunks));
+    HIPCHK(c, c->d_seg2.reserve(seg2.size())); HIPCHK(c, c->d_dn.reserve((size_t)c->T));
+    HIPCHK(c, c->part_f64.reserve((size_t)nchunks * Lf)); HIPCHK(c, c->part_num.reserve((size_t)nchunks * W2));
+    HIPCHK(c, hipMemcpy(c->d_chunk_begin.p, cb.data(), (size_t)nchunks * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_chunk_end.p, ce.data(), (size_t)nchunks * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_seg2.p, seg2.data(), seg2.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_dn.p, dn.data(), (size_t)c->T * 8, hipMemcpyHostToDevice));
+    if (two_level) {
+        HIPCHK(c, c->d_seg1.reserve(seg1.size()));
+        HIPCHK(c, hipMemcpy(c->d_seg1.p, seg1.data(), seg1.size() * 8, hipMemcpyHostToDevice));
+        HIPCHK(c, c->slice_f64.reserve((size_t)nslices * Lf)); HIPCHK(c, c->slice_num.reserve((size_t)nslices * W2));
+    }
+
+    // ---- K1 ---------------------------------------------------------------------------------------
+    pup::K1Args a{};
+    a.indptr = c->indptr.p; a.px = c->px.p;
+    a.weight = c->have_weight ? c->weight.p : nullptr;
+    a.cov = c->have_cov ? c->cov.p : nullptr;
+    a.expv = c->nexp > 0 ? c->expv.p : nullptr; a.nexp = c->nexp; a.nbins = c->nbins;
+    a.r0 = dr0; a.c0 = dc0; a.flip = dfl;
+    a.chunk_begin = c->d_chunk_begin.p; a.chunk_end = c->d_chunk_end.p;
+    a.part_f64 = c->part_f64.p; a.part_num = c->part_num.p;
+    a.counters = c->counters.p; a.err = c->d_err.p;
+    a.W = W; a.ignore_diags = ignore_diags; a.mode = mode;
+    const size_t lds = pup::k1_lds_bytes(W);
+
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    if (c->profiling) {
+        HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1)); HIPCHK(c, hipEventCreate(&e2));
+        HIPCHK(c, hipEventRecord(e0, c->stream));
+    }
+    switch (W) {
+        case 21: launch_k1<21>(a, (int)nchunks, lds, c->stream); break;
+        case 51: launch_k1<51>(a, (int)nchunks, lds, c->stream); break;
+        default: launch_k1<0>(a, (int)nchunks, lds, c->stream); break;
+    }
+    HIPCHK(c, hipGetLastError());
+    if (c->profiling) HIPCHK(c, hipEventRecord(e1, c->stream));
+
+    // ---- K2: partials -> (slices ->) accumulators ---------------------------------------------------
+    const int Li = (int)W2;
+    const dim3 rb(256), rg1((unsigned)((Lf + Li + 255) / 256), (unsigned)std::max<long long>(nslices, 1));
+    const dim3 rg2((unsigned)((Lf + Li + 255) / 256), (unsigned)c->T);
+    if (two_level) {
+        hipLaunchKernelGGL((pup::reduce_partials_kernel<unsigned, false>), rg1, rb, 0, c->stream,
+                           c->part_f64.p, c->part_num.p, c->d_seg1.p, (int)Lf, Li, c->slice_f64.p, c->slice_num.p);
+        hipLaunchKernelGGL((pup::reduce_partials_kernel<long long, true>), rg2, rb, 0, c->stream,
+                           c->slice_f64.p, c->slice_num.p, c->d_seg2.p, (int)Lf, Li, c->acc_f64.p, c->acc_i64.p);
+    } else {
+        hipLaunchKernelGGL((pup::reduce_partials_kernel<unsigned, true>), rg2, rb, 0, c->stream,
+                           c->part_f64.p, c->part_num.p, c->d_seg2.p, (int)Lf, Li, c->acc_f64.p, c->acc_i64.p);
+    }
+    hipLaunchKernelGGL(pup::add_counts_kernel, dim3((unsigned)((c->T + 255) / 256)), dim3(256), 0, c->stream,
+                       c->acc_i64.p + (size_t)c->T * W2, c->d_dn.p, c->T);
+    HIPCHK(c, hipGetLastError());
+    if (c->profiling) {
+        HIPCHK(c, hipEventRecord(e2, c->stream));
+        c->pending.push_back({e0, e1, e2});
+    }
+    c->stats.snippets += n;
+    return PUP_OK;
+}
+
+int pup_sync(pup_ctx* c) {
+    if (!c) return PUP_EINVAL;
+    int rc = bind(c); if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    collect_events(c);
+    return check_async_error(c);
+}
+
+int pup_fetch(pup_ctx* c, double* sum, int64_t* num, int64_t* n, double* cov_start, double* cov_end) {
+    if (!c) return PUP_EINVAL;
+    if (c->T <= 0) return fail(c, PUP_ESTATE, "pup_fetch: call pup_reset first");
+    int rc = pup_sync(c); if (rc) return rc;
+    const int W = c->W; const size_t W2 = (size_t)W * W, Lf = W2 + 2 * (size_t)W, T = (size_t)c->T;
+    if (sum || cov_start || cov_end) {
+        std::vector<double> h(T * Lf);
+        HIPCHK(c, hipMemcpy(h.data(), c->acc_f64.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t t = 0; t < T; ++t) {
+            const double* rec = h.data() + t * Lf;
+            if (sum) std::memcpy(sum + t * W2, rec, W2 * sizeof(double));
+            if (cov_start) std::memcpy(cov_start + t * W, rec + W2, (size_t)W * sizeof(double));
+            if (cov_end) std::memcpy(cov_end + t * W, rec + W2 + W, (size_t)W * sizeof(double));
+        }
+    }
+    if (num) HIPCHK(c, hipMemcpy(num, c->acc_i64.p, T * W2 * sizeof(long long), hipMemcpyDeviceToHost));
+    if (n) HIPCHK(c, hipMemcpy(n, c->acc_i64.p + T * W2, T * sizeof(long long), hipMemcpyDeviceToHost));
+    return PUP_OK;
+}
+
+int pup_packed_sizes(pup_ctx* c, int64_t* n_f64, int64_t* n_i64) {
+    if (!c) return PUP_EINVAL;
+    if (c->T <= 0) return fail(c, PUP_ESTATE, "pup_packed_sizes: call pup_reset first");
+    const int64_t W2 = (int64_t)c->W * c->W;
+    if (n_f64) *n_f64 = (int64_t)c->T * (W2 + 2 * c->W);
+    if (n_i64) *n_i64 = (int64_t)c->T * (W2 + 1);
+    return PUP_OK;
+}
+
+int pup_export(pup_ctx* c, void* dev_f64, void* dev_i64) {
+    if (!c) return PUP_EINVAL;
+    if (c->T <= 0) return fail(c, PUP_ESTATE, "pup_export: call pup_reset first");
+    if (!dev_f64 || !dev_i64) return fail(c, PUP_EINVAL, "pup_export: NULL destination");
+    int rc = pup_sync(c); if (rc) return rc;
+    int64_t nf, ni; pup_packed_sizes(c, &nf, &ni);
+    HIPCHK(c, hipMemcpy(dev_f64, c->acc_f64.p, (size_t)nf * 8, hipMemcpyDeviceToDevice));
+    HIPCHK(c, hipMemcpy(dev_i64, c->acc_i64.p, (size_t)ni * 8, hipMemcpyDeviceToDevice));
+    HIPCHK(c, hipDeviceSynchronize());
+    return PUP_OK;
+}
+
+int pup_import(pup_ctx* c, const void* dev_f64, const void* dev_i64) {
+    if (!c) return PUP_EINVAL;
+    if (c->T <= 0) return fail(c, PUP_ESTATE, "pup_import: call pup_reset first");
+    if (!dev_f64 || !dev_i64) return fail(c, PUP_EINVAL, "pup_import: NULL source");
+    int rc = pup_sync(c); if (rc) return rc;
+    int64_t nf, ni; pup_packed_sizes(c, &nf, &ni);
+    HIPCHK(c, hipMemcpy(c->acc_f64.p, dev_f64, (size_t)nf * 8, hipMemcpyDeviceToDevice));
+    HIPCHK(c, hipMemcpy(c->acc_i64.p, dev_i64, (size_t)ni * 8, hipMemcpyDeviceToDevice));
+    HIPCHK(c, hipDeviceSynchronize());
+    return PUP_OK;
+}
+
+int pup_set_profiling(pup_ctx* c, int enabled) {
+    if (!c) return PUP_EINVAL;
+    c->profiling = enabled != 0;
+    return PUP_OK;
+}
+
+int pup_get_stats(pup_ctx* c, pup_stats* out) {
+    if (!c || !out) return PUP_EINVAL;
+    int rc = pup_sync(c); if (rc) return rc;
+    unsigned long long h[2] = {0, 0};
+    HIPCHK(c, hipMemcpy(h, c->counters.p, sizeof h, hipMemcpyDeviceToHost));
+    c->stats.pixels_in_windows = (int64_t)h[0];
+    c->stats.probe_loads = (int64_t)h[1];
+    *out = c->stats;
+    return PUP_OK;
+}
+
+int pup_clear_stats(pup_ctx* c) {
+    if (!c) return PUP_EINVAL;
+    int rc = pup_sync(c); if (rc) return rc;
+    c->stats = pup_stats{};
+    HIPCHK(c, hipMemset(c->counters.p, 0, 2 * sizeof(unsigned long long)));
+    return PUP_OK;
+}
+
+int pup_event_record(pup_ctx* c, int slot) {
+    if (!c) return PUP_EINVAL;
+    if (slot < 0 || slot >= 8) return fail(c, PUP_EINVAL, "pup_event_record: slot %d out of [0,8)", slot);
+    int rc = bind(c); if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->slots[slot], c->stream));
+    return PUP_OK;
+}
+
+int pup_event_elapsed_ms(pup_ctx* c, int a, int b, float* ms) {
+    if (!c || !ms) return PUP_EINVAL;
+    if (a < 0 || a >= 8 || b < 0 || b >= 8) return fail(c, PUP_EINVAL, "pup_event_elapsed_ms: bad slot");
+    int rc = bind(c); if (rc) return rc;
+    HIPCHK(c, hipEventSynchronize(c->slots[b]));
+    HIPCHK(c, hipEventElapsedTime(ms, c->slots[a], c->slots[b]));
+    return PUP_OK;
+}
+
+int pup_set_tuning(pup_ctx* c, int32_t chunk_snippets, int32_t variant) {
+    if (!c) return PUP_EINVAL;
+    if (chunk_snippets < 0) return fail(c, PUP_EINVAL, "pup_set_tuning: negative chunk size");
+    c->chunk_snippets = chunk_snippets; c->variant = variant;
+    return PUP_OK;
+}
+
+}  // extern "C"

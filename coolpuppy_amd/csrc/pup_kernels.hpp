@@ -1,0 +1,251 @@
+// pup_kernels.hpp — CDNA4 (gfx950) kernels of the pile-up engine.
+//
+// K1  pileup_chunk_kernel   one wavefront (64 lanes) per chunk of same-tile snippets:
+//                           per snippet, lanes = window rows run a lower_bound on the row's column
+//                           segment (HBM/L2 probes), then lanes = window slots gather the contiguous
+//                           {col,count} run of each row, apply weight outer product / diagonal mask /
+//                           expected, and add into a per-wave LDS tile (sum f64, num u32, cov f64).
+//                           The tile is written out once per chunk as a partial.
+// K2  reduce_partials_kernel deterministic segmented reduction of partial tiles (fixed order), used
+//                           twice (chunks -> slices -> running accumulators).
+//
+// What the arithmetic restates (reference = open2c/coolpuppy, paths relative to its tree):
+//   window extraction, NaN rows/cols, diagonal mask, expected, coverage   coolpuppy/coolpup.py:1104-1157
+//   nansum / isfinite / n accumulation                                    coolpuppy/lib/puputils.py:12-41
+//   anti-transpose for flipped snippets                                    coolpuppy/coolpup.py:128-131
+// No MFMA: this is a gather/reduce bounded by memory latency and bandwidth, not a contraction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pup {
+
+constexpr int kWave = 64;
+
+struct K1Args {
+    // resident tables
+    const long long* indptr;   // [nbins+1]
+    const int2*      px;       // [nnz] {col, count}
+    const double*    weight;   // [nbins] or nullptr (raw)
+    const double*    cov;      // [nbins] or nullptr
+    const double*    expv;     // [nexp] or nullptr
+    long long        nexp;
+    long long        nbins;
+    // snippets (device)
+    const int*           r0;
+    const int*           c0;
+    const unsigned char* flip;     // nullable
+    // chunk table (device)
+    const long long* chunk_begin;  // [nchunks]
+    const long long* chunk_end;    // [nchunks]
+    // per-chunk partial outputs
+    double*   part_f64;   // [nchunks][W2 + 2W]   (sum | cov_start | cov_end)
+    unsigned* part_num;   // [nchunks][W2]
+    // diagnostics
+    unsigned long long* counters;  // [0] pixels inside windows, [1] search probes
+    int*                err;       // set to 1 when a window leaves the bin table
+    int      W;
+    int      ignore_diags;         // < 0: no diagonal mask
+    unsigned mode;                 // PUP_MODE_* bits
+};
+
+// LDS bytes one wave needs for window width W
+__host__ __device__ inline size_t k1_lds_bytes(int W) {
+    size_t W2 = (size_t)W * W;
+    // f64: tile sum W2 | cov_s W | cov_e W | wr W | wc W | ex 2W ; i64: st W | hi W ; u32: num W2
+    return 8 * (W2 + 6 * (size_t)W) + 16 * (size_t)W + 4 * W2;
+}
+
+__device__ __forceinline__ void lds_add_f64(double* p, double v) {
+    // fire-and-forget LDS f64 add (ds_add_f64); cells within one snippet are distinct,
+    // the atomic form is used because it is a single no-return instruction.
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int WT>
+__global__ __launch_bounds__(kWave) void pileup_chunk_kernel(K1Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int W  = WT ? WT : a.W;
+    const int W2 = W * W;
+    const int lane = threadIdx.x;
+
+    double*    tsum = reinterpret_cast<double*>(smem_raw);
+    double*    covs = tsum + W2;
+    double*    cove = covs + W;
+    double*    wr   = cove + W;
+    double*    wc   = wr + W;
+    double*    ex   = wc + W;                       // 2W slots (2W-1 used)
+    long long* st   = reinterpret_cast<long long*>(ex + 2 * W);
+    long long* hi   = st + W;
+    unsigned*  tnum = reinterpret_cast<unsigned*>(hi + W);
+
+    const bool m_ooe   = a.mode & 0x01u;
+    const bool m_exp   = a.mode & 0x02u;
+    const bool m_cov   = (a.mode & 0x04u) && a.cov != nullptr;
+    const bool m_tr    = a.mode & 0x08u;
+    const bool use_exp = (m_ooe || m_exp) && a.expv != nullptr && a.nexp > 0;
+    const int  igd     = a.ignore_diags;
+
+    for (int t = lane; t < W2; t += kWave) { tsum[t] = 0.0; tnum[t] = 0u; }
+    for (int t = lane; t < 2 * W; t += kWave) covs[t] = 0.0;   // covs and cove are contiguous
+    __syncthreads();
+
+    const long long cb = a.chunk_begin[blockIdx.x];
+    const long long ce = a.chunk_end[blockIdx.x];
+    unsigned long long npix = 0, nprobe = 0;
+
+    for (long long s = cb; s < ce; ++s) {
+        const int r0s = __builtin_amdgcn_readfirstlane(a.r0[s]);
+        const int c0s = __builtin_amdgcn_readfirstlane(a.c0[s]);
+        const int fl  = a.flip ? __builtin_amdgcn_readfirstlane((int)a.flip[s]) : 0;
+        if (r0s < 0 || c0s < 0 || (long long)r0s + W > a.nbins || (long long)c0s + W > a.nbins) {
+            if (lane == 0) atomicExch(a.err, 1);
+            continue;   // wave-uniform
+        }
+        // ---- phase A: per-row search + per-snippet vectors ------------------------------------
+        if (!m_exp) {
+            for (int p = lane; p < W; p += kWave) {
+                const int r = r0s + p;
+                long long lo = a.indptr[r];
+                const long long h = a.indptr[r + 1];
+                long long b = h;
+                while (lo < b) {                       // lower_bound(col >= c0s)
+                    const long long m = (lo + b) >> 1;
+                    if (a.px[m].x < c0s) lo = m + 1; else b = m;
+                    ++nprobe;
+                }
+                st[p] = lo;
+                hi[p] = h;
+                wr[p] = a.weight ? a.weight[r] : 1.0;
+                wc[p] = a.weight ? a.weight[c0s + p] : 1.0;
+                if (m_cov) {
+                    const double cr = a.cov[r], cc = a.cov[c0s + p];
+                    // reference: cov_start follows the snippet's rows, cov_end its columns
+                    // (coolpup.py:1151-1153); under TRANSPOSE the kernel's rows are the reference's columns
+                    const double vs = m_tr ? cc : cr, ve = m_tr ? cr : cc;
+                    if (vs == vs) covs[p] += vs;       // nansum: NaN coverage adds 0
+                    if (ve == ve) cove[p] += ve;
+                }
+            }
+        }
+        if (use_exp) {
+            const int dmin = (c0s - r0s) - (W - 1);
+            for (int i = lane; i < 2 * W - 1; i += kWave) {
+                long long ad = dmin + i; if (ad < 0) ad = -ad;
+                double e;
+                if (a.nexp == 1) e = a.expv[0];        // trans scalar
+                else e = ad < a.nexp ? a.expv[ad] : __builtin_nan("");
+                ex[i] = e;
+            }
+        }
+        __syncthreads();
+        // ---- phase B: slots (p, j) = cell (p, q=j) for num, j-th pixel of row p for sum -----------
+        for (int t = lane; t < W2; t += kWave) {
+            const int p = t / W;
+            const int j = t - p * W;
+            if (m_exp) {
+                // expected-as-control: the Toeplitz window itself, no masks (coolpup.py:1135-1139)
+                const double e = use_exp ? ex[j - p + W - 1] : __builtin_nan("");
+                int pp = m_tr ? j : p, qq = m_tr ? p : j;
+                if (fl) { const int tp = W - 1 - qq; qq = W - 1 - pp; pp = tp; }
+                const int cell = pp * W + qq;
+                if (e == e) {
+                    lds_add_f64(&tsum[cell], e);
+                    if (!__builtin_isinf(e)) atomicAdd(&tnum[cell], 1u);
+                }
+                continue;
+            }
+            const double wrp = wr[p];
+            {   // validity of cell (p, j): masks only, independent of the pixel table
+                const double wcq = wc[j];
+                const int d = (c0s + j) - (r0s + p);
+                bool ok = (wrp == wrp) && (wcq == wcq) && (igd < 0 || d >= igd);
+                if (m_ooe) { const double e = use_exp ? ex[j - p + W - 1] : __builtin_nan("");
+                             ok = ok && (e == e) && (e != 0.0); }
+                if (ok) {
+                    int pp = m_tr ? j : p, qq = m_tr ? p : j;
+                    if (fl) { const int tp = W - 1 - qq; qq = W - 1 - pp; pp = tp; }
+                    atomicAdd(&tnum[pp * W + qq], 1u);
+                }
+            }
+            const long long pos = st[p] + j;
+            if (pos < hi[p]) {
+                const int2 e2 = a.px[pos];
+                const int q = e2.x - c0s;              // >= 0 by lower_bound
+                if (q < W) {
+                    ++npix;
+                    double val = (double)e2.y * wrp * wc[q];
+                    const int d = (c0s + q) - (r0s + p);
+                    bool ok = (val == val) && (igd < 0 || d >= igd);
+                    if (m_ooe) { val = val / (use_exp ? ex[q - p + W - 1] : __builtin_nan("")); ok = ok && (val == val); }
+                    if (ok) {
+                        int pp = m_tr ? q : p, qq = m_tr ? p : q;
+                        if (fl) { const int tp = W - 1 - qq; qq = W - 1 - pp; pp = tp; }
+                        lds_add_f64(&tsum[pp * W + qq], val);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- flush the chunk's partial tile ---------------------------------------------------------
+    const size_t L = (size_t)W2 + 2 * (size_t)W;
+    double*   of = a.part_f64 + (size_t)blockIdx.x * L;
+    unsigned* on = a.part_num + (size_t)blockIdx.x * W2;
+    for (int t = lane; t < W2; t += kWave) { of[t] = tsum[t]; on[t] = tnum[t]; }
+    for (int t = lane; t < 2 * W; t += kWave) of[W2 + t] = covs[t];
+    // wave-reduce diagnostics, one atomic per chunk
+    for (int off = 32; off > 0; off >>= 1) {
+        npix   += __shfl_down(npix, off);
+        nprobe += __shfl_down(nprobe, off);
+    }
+    if (lane == 0 && a.counters) {
+        atomicAdd(&a.counters[0], npix);
+        atomicAdd(&a.counters[1], nprobe);
+    }
+}
+
+// Segmented, order-fixed reduction of partial records.
+//   f64 record length Lf, integer record length Li.  Output segment g sums input records
+//   [seg_ptr[g], seg_ptr[g+1]).  ACCUM: add into the output instead of overwriting, and route
+//   record g to output record out_index[g] (running accumulators, one per tile).
+template <typename NumIn, bool ACCUM>
+__global__ __launch_bounds__(256) void reduce_partials_kernel(
+        const double* __restrict__ in_f64, const NumIn* __restrict__ in_num,
+        const long long* __restrict__ seg_ptr, int Lf, int Li,
+        double* out_f64, long long* out_num) {
+    const int g = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Lf + Li) return;
+    const long long b = seg_ptr[g], e = seg_ptr[g + 1];
+    if (idx < Lf) {
+        double acc = 0.0;
+        for (long long c = b; c < e; ++c) acc += in_f64[(size_t)c * Lf + idx];
+        double* o = out_f64 + (size_t)g * Lf + idx;
+        if (ACCUM) *o += acc; else *o = acc;
+    } else {
+        const int k = idx - Lf;
+        long long acc = 0;
+        for (long long c = b; c < e; ++c) acc += (long long)in_num[(size_t)c * Li + k];
+        long long* o = out_num + (size_t)g * Li + k;
+        if (ACCUM) *o += acc; else *o = acc;
+    }
+}
+
+// n[t] += dn[t]
+__global__ void add_counts_kernel(long long* n, const long long* dn, int T) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < T) n[t] += dn[t];
+}
+
+// interleave bin2/count into {col,count} pairs (upload helper), 64-bit or 32-bit column ids
+template <typename ColT>
+__global__ void pack_pixels_kernel(const ColT* __restrict__ col, const int* __restrict__ cnt,
+                                   int2* __restrict__ out, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = make_int2((int)col[i], cnt[i]);
+}
+
+}  // namespace pup

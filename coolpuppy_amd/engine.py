@@ -1,0 +1,183 @@
+"""Python face of the HIP pile-up engine: one :class:`PileupEngine` per GPU.
+
+Thin, numpy-in / numpy-out wrapper over the C ABI (``include/pup_hip.h``).  It owns no algorithm:
+everything that touches pixels runs in ``libpup_hip.so``.  What it replaces in the reference is the
+inner part of ``PileUpper.pileup_region`` — ``get_data`` + ``_stream_snips`` + ``accumulate_stream``
+(reference coolpuppy/coolpup.py:1024-1057, 1059-1191, 1236-1283).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import MODE_COV, MODE_DEVPTR, MODE_EXPECTED, MODE_OOE, MODE_TRANSPOSE, PupError  # noqa: F401
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _as(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class PileupEngine:
+    """Device-resident pixel table + running (kind, group) accumulators on one MI355X."""
+
+    def __init__(self, device_id=0):
+        self._lib = _ffi.lib()
+        h = C.c_void_p()
+        rc = self._lib.pup_create(int(device_id), C.byref(h))
+        if rc != 0:
+            raise PupError(rc, self._lib.pup_last_error(None).decode())
+        self._h = h
+        self.device_id = int(device_id)
+        self.n_tiles = 0
+        self.pad = 0
+        self.nbins = 0
+        self.nnz = 0
+
+    # -- plumbing -------------------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise PupError(rc, self._lib.pup_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pup_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def W(self):
+        return 2 * self.pad + 1
+
+    # -- inputs ---------------------------------------------------------------------------------------
+    def load_pixels(self, bin1_offset, bin2_id, count):
+        """Upper-triangular pixel table as stored in a .cool (indexes/bin1_offset, pixels/bin2_id, pixels/count)."""
+        bin1_offset = _as(bin1_offset, np.int64)
+        bin2_id = np.ascontiguousarray(bin2_id)
+        if bin2_id.dtype not in (np.dtype(np.int32), np.dtype(np.int64)):
+            bin2_id = bin2_id.astype(np.int64)
+        count = np.ascontiguousarray(count)
+        if count.dtype != np.int32:
+            if not np.issubdtype(count.dtype, np.integer):
+                raise PupError(-6, f"pixel counts of dtype {count.dtype} are not supported (int32 expected)")
+            count = count.astype(np.int32)
+        nbins = bin1_offset.shape[0] - 1
+        nnz = bin2_id.shape[0]
+        if count.shape[0] != nnz:
+            raise ValueError("bin2_id and count differ in length")
+        self._check(self._lib.pup_load_pixels(self._h, _ptr(bin1_offset), _ptr(bin2_id), bin2_id.dtype.itemsize,
+                                              _ptr(count), nbins, nnz))
+        self.nbins, self.nnz = nbins, nnz
+
+    def load_bins(self, weight=None, cov=None):
+        """Per-bin float64 vectors: balancing weights (NaN = masked; None = raw) and coverage (None = unused)."""
+        w = None if weight is None else _as(weight, np.float64)
+        c = None if cov is None else _as(cov, np.float64)
+        for v in (w, c):
+            if v is not None and v.shape[0] != self.nbins:
+                raise ValueError(f"bin vector has {v.shape[0]} entries, table has {self.nbins} bins")
+        self._check(self._lib.pup_load_bins(self._h, _ptr(w), _ptr(c)))
+
+    def set_expected(self, expected=None):
+        """By-diagonal expected vector (cis), a scalar (trans) or None."""
+        if expected is None:
+            self._check(self._lib.pup_set_expected(self._h, None, 0))
+            return
+        e = np.atleast_1d(_as(expected, np.float64))
+        self._check(self._lib.pup_set_expected(self._h, _ptr(e), e.shape[0]))
+
+    # -- accumulators -----------------------------------------------------------------------------------
+    def reset(self, n_tiles, pad):
+        self._check(self._lib.pup_reset(self._h, int(n_tiles), int(pad)))
+        self.n_tiles, self.pad = int(n_tiles), int(pad)
+
+    def accumulate(self, r0, c0, tile_ptr, *, flip=None, ignore_diags=2, mode=0):
+        """Accumulate tile-grouped snippets given by their top-left GLOBAL bins (host arrays)."""
+        r0 = _as(r0, np.int32)
+        c0 = _as(c0, np.int32)
+        tile_ptr = _as(tile_ptr, np.int64)
+        if tile_ptr.shape[0] != self.n_tiles + 1:
+            raise ValueError(f"tile_ptr needs {self.n_tiles + 1} entries")
+        f = None if flip is None else _as(flip, np.uint8)
+        self._check(self._lib.pup_accumulate(self._h, _ptr(r0), _ptr(c0), _ptr(f), r0.shape[0], _ptr(tile_ptr),
+                                             int(ignore_diags), int(mode) & ~MODE_DEVPTR))
+
+    def accumulate_device(self, r0_ptr, c0_ptr, n, tile_ptr, *, flip_ptr=None, ignore_diags=2, mode=0):
+        """Same, with r0/c0/flip already resident in HBM (raw device addresses, e.g. tensor.data_ptr())."""
+        tile_ptr = _as(tile_ptr, np.int64)
+        self._check(self._lib.pup_accumulate(self._h, C.c_void_p(r0_ptr), C.c_void_p(c0_ptr),
+                                             C.c_void_p(flip_ptr) if flip_ptr else None, int(n), _ptr(tile_ptr),
+                                             int(ignore_diags), int(mode) | MODE_DEVPTR))
+
+    def sync(self):
+        self._check(self._lib.pup_sync(self._h))
+
+    def fetch(self):
+        """dict(sum [T,W,W] f64, num [T,W,W] i64, n [T] i64, cov_start [T,W], cov_end [T,W])."""
+        T, W = self.n_tiles, self.W
+        out = {
+            "sum": np.empty((T, W, W), np.float64),
+            "num": np.empty((T, W, W), np.int64),
+            "n": np.empty((T,), np.int64),
+            "cov_start": np.empty((T, W), np.float64),
+            "cov_end": np.empty((T, W), np.float64),
+        }
+        self._check(self._lib.pup_fetch(self._h, _ptr(out["sum"]), _ptr(out["num"]), _ptr(out["n"]),
+                                        _ptr(out["cov_start"]), _ptr(out["cov_end"])))
+        return out
+
+    # -- cross-GPU ----------------------------------------------------------------------------------------
+    def packed_sizes(self):
+        a, b = C.c_int64(), C.c_int64()
+        self._check(self._lib.pup_packed_sizes(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def export_to(self, dev_f64_ptr, dev_i64_ptr):
+        self._check(self._lib.pup_export(self._h, C.c_void_p(dev_f64_ptr), C.c_void_p(dev_i64_ptr)))
+
+    def import_from(self, dev_f64_ptr, dev_i64_ptr):
+        self._check(self._lib.pup_import(self._h, C.c_void_p(dev_f64_ptr), C.c_void_p(dev_i64_ptr)))
+
+    # -- measurement --------------------------------------------------------------------------------------
+    def set_profiling(self, enabled=True):
+        self._check(self._lib.pup_set_profiling(self._h, int(bool(enabled))))
+
+    def set_tuning(self, chunk_snippets=0, variant=0):
+        self._check(self._lib.pup_set_tuning(self._h, int(chunk_snippets), int(variant)))
+
+    def stats(self):
+        s = _ffi.PupStats()
+        self._check(self._lib.pup_get_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in _ffi.PupStats._fields_}
+
+    def clear_stats(self):
+        self._check(self._lib.pup_clear_stats(self._h))
+
+    def event_record(self, slot):
+        self._check(self._lib.pup_event_record(self._h, int(slot)))
+
+    def event_elapsed_ms(self, a, b):
+        ms = C.c_float()
+        self._check(self._lib.pup_event_elapsed_ms(self._h, int(a), int(b), C.byref(ms)))
+        return ms.value
+
+
+def device_count():
+    n = _ffi.lib().pup_device_count()
+    if n < 0:
+        raise PupError(n, _ffi.lib().pup_last_error(None).decode())
+    return n

@@ -1,0 +1,156 @@
+/*
+ * pup_hip.h — C ABI of the MI355X (gfx950) pile-up engine, libpup_hip.so.
+ *
+ * This is the drop-in boundary for ONE hot path of open2c/coolpuppy: the
+ * per-region "slice a (2*pad+1)^2 window out of the chromosome CSR -> mask ->
+ * normalise -> accumulate sum/num" loop.  The reference has no FFI of its own
+ * (it is pure Python); each entry point below names the reference code it
+ * replaces (paths are relative to the coolpuppy source tree):
+ *
+ *   pup_load_pixels / pup_load_bins   <- PileUpper.get_data            coolpuppy/coolpup.py:1024-1057
+ *                                        + weight / coverage columns   coolpuppy/coolpup.py:1081-1098
+ *   pup_set_expected                  <- expected_selections / get_expected_trans
+ *                                                                      coolpuppy/coolpup.py:907-916, 999-1005
+ *   pup_reset                         <- make_outmap / empty_pup       coolpuppy/coolpup.py:986-997, 1007-1022
+ *   pup_accumulate                    <- _stream_snips + accumulate_stream + _add_snip
+ *                                                                      coolpuppy/coolpup.py:1059-1191, 1236-1283
+ *                                                                      coolpuppy/lib/puputils.py:12-41
+ *                                        (flip bit: flip_snip_func     coolpuppy/coolpup.py:128-147)
+ *   pup_fetch / pup_export / pup_import
+ *                                     <- sum_pups cross-region merge   coolpuppy/lib/puputils.py:88-113
+ *                                        and the reduce at             coolpuppy/coolpup.py:1511-1531
+ *
+ * Conventions
+ *   - plain C: pointers + sizes only; no C++/torch types cross this line.
+ *   - every function returns 0 on success or a negative PUP_E* code; the text
+ *     of the last failure is available from pup_last_error().  Nothing throws.
+ *   - all host buffers are caller-owned; the library copies what it needs.
+ *   - one context per GPU; calls on one context must be serialised by the
+ *     caller; different contexts are independent.
+ *   - "bin" always means a GLOBAL bin id of the cooler bin table (chromosome
+ *     offset already added).  "tile" = one (kind, group) accumulator: a WxW
+ *     sum (f64), a WxW num (i64), cov_start/cov_end (f64[W]) and n (i64).
+ */
+#ifndef PUP_HIP_H
+#define PUP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pup_ctx pup_ctx;
+
+/* error codes */
+#define PUP_OK          0
+#define PUP_EINVAL     -1   /* bad argument */
+#define PUP_ENOMEM     -2   /* host or device allocation failed */
+#define PUP_EHIP       -3   /* a HIP runtime call failed */
+#define PUP_ESTATE     -4   /* call order violated (e.g. accumulate before load) */
+#define PUP_ERANGE     -5   /* a snippet window leaves the bin table (caught on device) */
+#define PUP_ENOTSUP    -6   /* valid request the engine cannot serve (e.g. window too large for LDS) */
+
+/* mode bits for pup_accumulate */
+#define PUP_MODE_OOE        0x01u  /* divide each value by expected before summing (ooe=True) */
+#define PUP_MODE_EXPECTED   0x02u  /* accumulate the EXPECTED window itself, unmasked (the
+                                      "control"-kind snippet of expected & !ooe, coolpup.py:1135-1139);
+                                      the pixel table is not read */
+#define PUP_MODE_COV        0x04u  /* accumulate cov_start / cov_end (coverage_norm) */
+#define PUP_MODE_TRANSPOSE  0x08u  /* (r0,c0) were swapped by the caller so that r0's region precedes
+                                      c0's in the upper-triangular table; cells are stored transposed */
+#define PUP_MODE_DEVPTR     0x10u  /* r0 / c0 / flip are DEVICE pointers (already resident in HBM) */
+
+/* lifetime ---------------------------------------------------------------------------------------- */
+int  pup_create(int device_id, pup_ctx** out);
+void pup_destroy(pup_ctx* ctx);
+/* last error text of this context (or of pup_create when ctx == NULL); never NULL */
+const char* pup_last_error(const pup_ctx* ctx);
+/* library/ABI version: major*10000 + minor*100 + patch */
+int  pup_version(void);
+/* number of HIP devices visible, or a negative error */
+int  pup_device_count(void);
+
+/* inputs ------------------------------------------------------------------------------------------ */
+/*
+ * Upper-triangular pixel table exactly as a .cool stores it: bin1_offset = indexes/bin1_offset
+ * (CSR row pointer, int64[nbins+1]), bin2_id = pixels/bin2_id (int32 when bin2_bytes == 4, int64 when 8),
+ * count = pixels/count (int32).  Rows sorted, columns sorted within a row, bin2 >= bin1.
+ * Stored on device as int64 indptr + interleaved {int32 col, int32 count} pairs (8 B per pixel).
+ */
+int pup_load_pixels(pup_ctx* ctx, const int64_t* bin1_offset, const void* bin2_id, int bin2_bytes,
+                    const int32_t* count, int64_t nbins, int64_t nnz);
+/*
+ * Per-bin vectors (float64[nbins]).  weight: balancing weights, NaN = masked bin; NULL = raw counts
+ * (clr_weight_name falsy: no bin is masked).  cov: coverage column for coverage_norm; NULL = none.
+ */
+int pup_load_bins(pup_ctx* ctx, const double* weight, const double* cov);
+/*
+ * Expected for the region (pair) the next pup_accumulate calls belong to.
+ *   n >= 2 : cis, by-diagonal vector, value for a cell = expected[|col - row|]
+ *   n == 1 : trans, one scalar for the whole block
+ *   n == 0 : none
+ */
+int pup_set_expected(pup_ctx* ctx, const double* expected, int64_t n);
+
+/* accumulators ------------------------------------------------------------------------------------ */
+/* (re)allocate and zero n_tiles accumulators for windows of W = 2*pad+1 bins */
+int pup_reset(pup_ctx* ctx, int32_t n_tiles, int32_t pad);
+
+/*
+ * Accumulate n snippets.  Snippet s covers rows [r0[s], r0[s]+W) and columns [c0[s], c0[s]+W) of the
+ * global bin table; the caller has already dropped windows that leave their region
+ * (coolpup.py:1111-1114).  Snippets MUST be grouped by tile: tile_ptr[t]..tile_ptr[t+1] (host array,
+ * int64[n_tiles+1], non-decreasing, tile_ptr[0] == 0, tile_ptr[n_tiles] == n) are the snippets of tile t.
+ * flip (nullable, uint8[n]): non-zero = anti-transpose the snippet before adding (flip_snip_func).
+ * ignore_diags: cis: cells with (col - row) < ignore_diags are masked (must be >= 0: the table is
+ * upper-triangular); pass a negative value for trans (no diagonal mask).
+ * Asynchronous with respect to the host; results are ordered on the context's stream.
+ */
+int pup_accumulate(pup_ctx* ctx, const int32_t* r0, const int32_t* c0, const uint8_t* flip,
+                   int64_t n, const int64_t* tile_ptr, int32_t ignore_diags, uint32_t mode);
+
+/* wait for all queued work; surfaces asynchronous errors (PUP_ERANGE, PUP_EHIP) */
+int pup_sync(pup_ctx* ctx);
+
+/*
+ * Copy the accumulators to host memory (any pointer may be NULL to skip it):
+ *   sum [n_tiles][W][W] f64, num [n_tiles][W][W] i64, n [n_tiles] i64,
+ *   cov_start [n_tiles][W] f64, cov_end [n_tiles][W] f64.     Implies pup_sync.
+ */
+int pup_fetch(pup_ctx* ctx, double* sum, int64_t* num, int64_t* n, double* cov_start, double* cov_end);
+
+/*
+ * Packed accumulator image for cross-GPU reduction (the caller all-reduces it with RCCL, op = sum):
+ *   f64 part: n_tiles records of [sum W*W | cov_start W | cov_end W]   = n_tiles*(W*W + 2*W) doubles
+ *   i64 part: num [n_tiles][W*W] followed by n [n_tiles]               = n_tiles*(W*W + 1)   int64s
+ * pup_packed_sizes reports the two element counts; pup_export copies device->device into
+ * caller-provided DEVICE buffers, pup_import overwrites the accumulators from them.
+ */
+int pup_packed_sizes(pup_ctx* ctx, int64_t* n_f64, int64_t* n_i64);
+int pup_export(pup_ctx* ctx, void* dev_f64, void* dev_i64);
+int pup_import(pup_ctx* ctx, const void* dev_f64, const void* dev_i64);
+
+/* measurement ------------------------------------------------------------------------------------- */
+typedef struct pup_stats {
+    double  k1_ms;          /* total device time of the pile-up kernel (HIP events), ms */
+    double  reduce_ms;      /* total device time of the partial-tile reduction kernel, ms */
+    int64_t k1_launches;
+    int64_t snippets;       /* snippets accumulated */
+    int64_t pixels_in_windows; /* sum over snippets of nnz inside the window (counted on device) */
+    int64_t probe_loads;    /* binary-search probes issued (counted on device) */
+} pup_stats;
+/* profiling on: every kernel launch is bracketed by HIP events on the context's stream */
+int pup_set_profiling(pup_ctx* ctx, int enabled);
+int pup_get_stats(pup_ctx* ctx, pup_stats* out);   /* implies pup_sync */
+int pup_clear_stats(pup_ctx* ctx);
+/* generic stream timer: record slot (0..7) on the context's stream; elapsed between two slots */
+int pup_event_record(pup_ctx* ctx, int slot);
+int pup_event_elapsed_ms(pup_ctx* ctx, int slot_begin, int slot_end, float* ms);
+/* tuning knobs (0 = library default): snippets per chunk and kernel variant */
+int pup_set_tuning(pup_ctx* ctx, int32_t chunk_snippets, int32_t variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PUP_HIP_H */

@@ -1,0 +1,144 @@
+"""TEST INFRASTRUCTURE, NOT PRODUCT CODE — CPU restatements of coolpuppy's per-snippet hot path.
+
+Two independent restatements of the same reference steps (reference = open2c/coolpuppy):
+
+* :func:`pileup_c`      — ctypes call into ``oracle/liboracle.so`` (``pileup_oracle.c``), dense WxW
+  window per snippet, symmetric pixel lookup, single-threaded.
+* :func:`pileup_scipy`  — the reference's own operation sequence on a scipy CSR: symmetric
+  ``count*w_i*w_j`` region matrix (coolpup.py:1053-1057), ``[r0:r1, c0:c1].toarray()`` (:1115-1121),
+  NaN rows/cols (:1122-1123), Toeplitz expected (:1125-1133), diagonal mask (:1141-1149),
+  ``data/exp`` (:1154-1156), ``rot90(flipud())`` (:128-131), then ``_add_snip``'s nansum / isfinite
+  (lib/puputils.py:12-41).  Slow, used on small inputs and as the "reference-algorithm" CPU baseline.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+Parity pinning: both are checked against tests/golden/*.npz, which were produced by importing the
+reference's unchanged coolpup.py (see oracle/make_golden.py).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SRC = os.path.join(_HERE, "pileup_oracle.c")
+_SO = os.path.join(_HERE, "liboracle.so")
+
+MODE_OOE, MODE_EXPECTED, MODE_COV, MODE_TRANSPOSE = 0x01, 0x02, 0x04, 0x08
+
+_lib = None
+
+
+def build(force=False):
+    """gcc -O2 the C restatement into oracle/liboracle.so."""
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
+        subprocess.run(["gcc", "-O2", "-Wall", "-shared", "-fPIC", _SRC, "-o", _SO, "-lm"], check=True)
+    return _SO
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.oracle_pileup.restype = C.c_int
+        _lib.oracle_pileup.argtypes = [C.c_void_p] * 3 + [C.c_int64] + [C.c_void_p] * 3 + [C.c_int64] + \
+            [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_int32, C.c_uint32] + [C.c_void_p] * 5
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def empty_acc(n_tiles, pad):
+    W = 2 * pad + 1
+    return {
+        "sum": np.zeros((n_tiles, W, W)), "num": np.zeros((n_tiles, W, W), np.int64),
+        "n": np.zeros(n_tiles, np.int64), "cov_start": np.zeros((n_tiles, W)), "cov_end": np.zeros((n_tiles, W)),
+    }
+
+
+def pileup_c(indptr, col, cnt, weight, cov, expv, r0, c0, flip, tile, n_tiles, pad, ignore_diags, mode, acc=None):
+    """Accumulate into ``acc`` (created when None) with the C restatement; returns acc."""
+    lib = _load()
+    indptr = np.ascontiguousarray(indptr, np.int64)
+    col = np.ascontiguousarray(col, np.int32)
+    cnt = np.ascontiguousarray(cnt, np.int32)
+    weight = None if weight is None else np.ascontiguousarray(weight, np.float64)
+    cov = None if cov is None else np.ascontiguousarray(cov, np.float64)
+    expv = None if expv is None else np.atleast_1d(np.ascontiguousarray(expv, np.float64))
+    r0 = np.ascontiguousarray(r0, np.int32)
+    c0 = np.ascontiguousarray(c0, np.int32)
+    flip = None if flip is None else np.ascontiguousarray(flip, np.uint8)
+    tile = np.ascontiguousarray(tile, np.int32)
+    if acc is None:
+        acc = empty_acc(n_tiles, pad)
+    rc = lib.oracle_pileup(_p(indptr), _p(col), _p(cnt), indptr.shape[0] - 1, _p(weight), _p(cov), _p(expv),
+                           0 if expv is None else expv.shape[0], _p(r0), _p(c0), _p(flip), _p(tile), r0.shape[0],
+                           pad, ignore_diags, mode, _p(acc["sum"]), _p(acc["num"]), _p(acc["n"]),
+                           _p(acc["cov_start"]), _p(acc["cov_end"]))
+    if rc != 0:
+        raise RuntimeError(f"oracle_pileup failed with {rc}")
+    return acc
+
+
+def symmetric_csr(indptr, col, cnt, weight, lo1, hi1, lo2, hi2):
+    """cooler's ``matrix(sparse=True, balance=w).fetch(r1, r2).tocsr()`` for global bin ranges
+    [lo1,hi1) x [lo2,hi2) of an upper-triangular pixel table: both triangles, value = count*w_i*w_j."""
+    import scipy.sparse as sp
+    nb = indptr.shape[0] - 1
+    rows = np.repeat(np.arange(nb, dtype=np.int64), np.diff(indptr))
+    cols = col.astype(np.int64)
+    vals = cnt.astype(np.float64)
+    if weight is not None:
+        vals = vals * weight[rows] * weight[cols]
+    # mirror, without doubling the main diagonal
+    off = rows != cols
+    R = np.concatenate([rows, cols[off]])
+    Cc = np.concatenate([cols, rows[off]])
+    V = np.concatenate([vals, vals[off]])
+    keep = (R >= lo1) & (R < hi1) & (Cc >= lo2) & (Cc < hi2)
+    return sp.coo_matrix((V[keep], (R[keep] - lo1, Cc[keep] - lo2)), shape=(hi1 - lo1, hi2 - lo2)).tocsr()
+
+
+def pileup_scipy(bigdata, lo1, lo2, weight, cov, expv, r0, c0, flip, tile, n_tiles, pad, ignore_diags, mode,
+                 acc=None):
+    """Reference operation sequence on a region CSR ``bigdata`` (rows from global bin lo1, cols from lo2)."""
+    W = 2 * pad + 1
+    if acc is None:
+        acc = empty_acc(n_tiles, pad)
+    ar = np.arange(W)
+    for s in range(len(r0)):
+        rs, cs = (c0[s], r0[s]) if mode & MODE_TRANSPOSE else (r0[s], c0[s])
+        t = tile[s]
+        have_exp = (mode & (MODE_OOE | MODE_EXPECTED)) and expv is not None
+        if have_exp:
+            ev = np.atleast_1d(expv)
+            if ev.shape[0] == 1:
+                exp_data = np.full((W, W), ev[0])
+            else:
+                d = np.abs((cs + ar)[None, :] - (rs + ar)[:, None])
+                exp_data = np.where(d < ev.shape[0], ev[np.minimum(d, ev.shape[0] - 1)], np.nan)
+        if mode & MODE_EXPECTED:
+            data = exp_data.astype(float)
+        else:
+            data = bigdata[rs - lo1:rs - lo1 + W, cs - lo2:cs - lo2 + W].toarray().astype(float)
+            if weight is not None:
+                data[np.isnan(weight[rs:rs + W]), :] = np.nan
+                data[:, np.isnan(weight[cs:cs + W])] = np.nan
+            if ignore_diags >= 0:
+                D = ((cs + ar)[None, :] - (rs + ar)[:, None]) < ignore_diags
+                data[D] = np.nan
+            if (mode & MODE_COV) and cov is not None:
+                acc["cov_start"][t] = np.nansum([acc["cov_start"][t], cov[rs:rs + W]], axis=0)
+                acc["cov_end"][t] = np.nansum([acc["cov_end"][t], cov[cs:cs + W]], axis=0)
+            if mode & MODE_OOE:
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    data = data / (exp_data if have_exp else np.nan)
+        if flip is not None and flip[s]:
+            data = np.rot90(np.flipud(data))
+        acc["sum"][t] = np.nansum([acc["sum"][t], data], axis=0)
+        acc["num"][t] += np.isfinite(data).astype(int)
+        acc["n"][t] += 1
+    return acc
