@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""bench.py — pile-up hot path on N MI355X GPUs (one process per GPU).
+
+Workload (BASELINE.json configs[2], the configuration the north-star target is quoted on):
+synthetic human-scale 10 kb pixel table (hg38 chr1-22,X, ~3e8 upper-triangular nnz, balanced with
+2 % masked bins) + 1e6 random cis BEDPE pairs, pad=10 (21x21 windows), nshifts=10 random-shift
+controls (seed 0) => ~1.1e7 snippets per step.  A "step" = one full pass: zero the accumulators,
+pile up every snippet (ROI + controls) of this rank's shard from HBM-resident inputs, and (N>1)
+all-reduce the packed sum/num/n/cov accumulators over RCCL.
+
+Scaling is STRONG: the same 1e6 pairs are split over the ranks (contiguous genome slices of the
+sorted snippet list; the pixel table is replicated — 2.4 GB of 288 GB).
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (K1 kernel,
+HIP-event timed inside this process) and `cpu_baseline` (the C oracle on a bounded sample, N=1 only).
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from coolpuppy_amd import synth  # noqa: E402  (numpy only; torch is imported after generation)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=1_000_000)
+    ap.add_argument("--nshifts", type=int, default=10)
+    ap.add_argument("--pad", type=int, default=10)
+    ap.add_argument("--lam", type=float, default=4200.0, help="Poisson contacts drawn per row before de-duplication")
+    ap.add_argument("--chroms", type=int, default=23, help="use the first K hg38 chromosomes (23 = all)")
+    ap.add_argument("--cpu-sample", type=int, default=150_000, help="snippets timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-cache", action="store_true")
+    return ap.parse_args()
+
+
+# ----------------------------------------------------------------------------------------------------
+# workload
+# ----------------------------------------------------------------------------------------------------
+def _cache_path(a):
+    key = f"v3|{a.chroms}|{a.lam}|{a.pairs}|{a.nshifts}|{a.pad}"
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), "coolpuppy_amd_bench_" +
+                        hashlib.sha1(key.encode()).hexdigest()[:12] + ".npz")
+
+
+def build_workload(a):
+    """Returns dict(bin1_offset, bin2_id, count, weight, r0, c0, n_roi, chrom_offset)."""
+    names = list(synth.HG38)[: a.chroms]
+    clr = synth.make_cooler({c: synth.HG38[c] for c in names}, binsize=10_000, lam=a.lam, seed=1000,
+                            name="synthetic_hg38_10kb", parallel=True)
+    # feature pairs and windows: host-side coordinate generation (CoordCreator semantics)
+    from coolpuppy_amd.coolpup import CoordCreator, snippet_batches
+    pairs = synth.random_cis_pairs(clr, a.pairs, min_sep=230_000, max_sep=5_000_000, seed=42)
+    np.random.seed(0)
+    cc = CoordCreator(pairs, clr.binsize, features_format="bedpe", flank=a.pad * clr.binsize,
+                      nshifts=a.nshifts, mindist="auto")
+    r0, c0, kind = snippet_batches(cc, clr, control=a.nshifts > 0)
+    order = np.lexsort((c0, r0, kind))
+    r0, c0, kind = r0[order], c0[order], kind[order]
+    bin1_offset, bin2_id, count = clr.pixel_table()
+    return {
+        "bin1_offset": bin1_offset, "bin2_id": bin2_id, "count": count,
+        "weight": clr.bins()["weight"][:].values, "r0": r0.astype(np.int32), "c0": c0.astype(np.int32),
+        "n_roi": np.int64((kind == 0).sum()), "chrom_offset": clr.chrom_offset,
+    }
+
+
+def load_or_build(a, rank, barrier):
+    path = _cache_path(a)
+    if rank == 0 and (a.no_cache or not os.path.exists(path)):
+        t = time.time()
+        wl = build_workload(a)
+        tmp = path + f".tmp{os.getpid()}.npz"
+        np.savez(tmp, **wl)
+        os.replace(tmp, path)
+        print(f"[bench] workload built in {time.time()-t:.1f}s -> {path}", file=sys.stderr, flush=True)
+    barrier()
+    z = np.load(path)
+    return {k: z[k] for k in z.files}
+
+
+# ----------------------------------------------------------------------------------------------------
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        a.gpus = world
+
+    # stage 0: rank 0 builds the workload BEFORE any GPU runtime is initialised (it may fork workers);
+    # the other ranks wait on a file barrier, so torch/RCCL init never overlaps the fork.
+    path = _cache_path(a)
+    if rank == 0:
+        wl = load_or_build(a, 0, lambda: None)
+    else:
+        while not os.path.exists(path):
+            time.sleep(0.5)
+        time.sleep(0.5)
+        wl = load_or_build(a, rank, lambda: None)
+
+    import torch
+    import torch.distributed as dist
+    from coolpuppy_amd.build import build_hip
+    from coolpuppy_amd.engine import PileupEngine, MODE_DEVPTR  # noqa: F401
+
+    if rank == 0:
+        build_hip()          # no-op when the in-tree .so is current
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    W = 2 * a.pad + 1
+    n_all = int(wl["r0"].shape[0])
+    n_roi = int(wl["n_roi"])
+    # strong-scaling shard: contiguous slice of each tile's (sorted) snippet range
+    def part(lo, hi):
+        m = hi - lo
+        return lo + (m * rank) // world, lo + (m * (rank + 1)) // world
+    a0, a1 = part(0, n_roi)
+    b0, b1 = part(n_roi, n_all)
+    r0 = np.concatenate([wl["r0"][a0:a1], wl["r0"][b0:b1]])
+    c0 = np.concatenate([wl["c0"][a0:a1], wl["c0"][b0:b1]])
+    tile_ptr = np.array([0, a1 - a0, (a1 - a0) + (b1 - b0)], np.int64)
+    n_local = int(tile_ptr[-1])
+
+    eng = PileupEngine(local_rank)
+    t_h2d = time.time()
+    eng.load_pixels(wl["bin1_offset"], wl["bin2_id"], wl["count"])
+    eng.load_bins(wl["weight"], None)
+    eng.sync()
+    t_h2d = time.time() - t_h2d
+    eng.reset(2, a.pad)
+    d_r0 = torch.from_numpy(r0).cuda()
+    d_c0 = torch.from_numpy(c0).cuda()
+    nf, ni = eng.packed_sizes()
+    buf_f = torch.zeros(nf, dtype=torch.float64, device="cuda")
+    buf_i = torch.zeros(ni, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+
+    def step():
+        eng.reset(2, a.pad)
+        eng.accumulate_device(d_r0.data_ptr(), d_c0.data_ptr(), n_local, tile_ptr, ignore_diags=2, mode=0)
+        if world > 1:
+            eng.export_to(buf_f.data_ptr(), buf_i.data_ptr())
+            dist.all_reduce(buf_f)
+            dist.all_reduce(buf_i)
+            torch.cuda.synchronize()
+            eng.import_from(buf_f.data_ptr(), buf_i.data_ptr())
+        else:
+            eng.sync()
+
+    for _ in range(a.warmup):
+        step()
+    eng.set_profiling(True)
+    eng.clear_stats()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    st = eng.stats()
+    eng.set_profiling(False)
+
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        agg = torch.tensor([st["k1_ms"], float(st["pixels_in_windows"]), float(st["snippets"])],
+                           dtype=torch.float64, device="cuda")
+        mx = agg.clone()
+        dist.all_reduce(agg)                      # sums over ranks
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        k1_ms_max = float(mx[0].item())
+        pix_total, snip_total = float(agg[1].item()), float(agg[2].item())
+    else:
+        k1_ms_max = st["k1_ms"]
+        pix_total, snip_total = float(st["pixels_in_windows"]), float(st["snippets"])
+
+    out = eng.fetch()
+
+    if rank == 0:
+        ms_per_step = dt / a.steps * 1e3
+        value = n_all * a.steps / dt
+        # ---- roofline of the dominant kernel (K1), per launch -----------------------------------------
+        # algorithmic bytes per snippet: 8(W+1) indptr + 8*nnz_win pixels + 16W weights + 12
+        launches = max(int(st["k1_launches"]), 1)
+        alg_bytes_total = snip_total * (8 * (W + 1) + 16 * W + 12) + 8.0 * pix_total     # all ranks, all steps
+        k1_ms_per_launch = k1_ms_max / launches                                           # slowest rank
+        achieved = alg_bytes_total / a.steps / (k1_ms_per_launch * 1e-3) / 1e9             # GB/s, whole job
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("workload_key") == os.path.basename(_cache_path(a)) and a.gpus == 1:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {
+            "bound": "hbm", "kernel": "pileup_chunk_kernel<21>", "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBPS * a.gpus, "unit": "GB/s", "frac": round(achieved / (HBM_PEAK_GBPS * a.gpus), 4),
+            "traffic": traffic, "kernel_ms_per_launch": round(k1_ms_per_launch, 4),
+            "algorithmic_bytes_per_launch": round(alg_bytes_total / a.steps / a.gpus),
+            "nnz_win_mean": round(pix_total / max(snip_total, 1), 1),
+        }
+        # ---- CPU baseline + same-run parity on a bounded sample (N=1 only) ------------------------------
+        cpu = None
+        if a.gpus == 1 and a.cpu_sample > 0:
+            from oracle import pileup_oracle as po
+            po.build()
+            m = min(a.cpu_sample, n_all)
+            idx = np.linspace(0, n_all - 1, m).astype(np.int64)
+            sr0, sc0 = wl["r0"][idx], wl["c0"][idx]
+            stile = (idx >= n_roi).astype(np.int32)
+            t = time.perf_counter()
+            want = po.pileup_c(wl["bin1_offset"], wl["bin2_id"], wl["count"], wl["weight"], None, None,
+                               sr0, sc0, None, stile, 2, a.pad, 2, 0)
+            cpu_s = time.perf_counter() - t
+            sptr = np.array([0, int((stile == 0).sum()), m], np.int64)
+            eng.reset(2, a.pad)
+            eng.accumulate(sr0, sc0, sptr, ignore_diags=2, mode=0)
+            got = eng.fetch()
+            ok = (np.array_equal(got["n"], want["n"]) and np.array_equal(got["num"], want["num"])
+                  and np.allclose(got["sum"], want["sum"], rtol=1e-6, atol=0, equal_nan=True))
+            cpu = {"value": round(m / cpu_s, 1), "unit": "snippets/s", "cores": 1, "kind": "port",
+                   "sample": f"{m} snippets strided over the {n_all} of this workload, C oracle (oracle/pileup_oracle.c), "
+                             f"{cpu_s:.1f}s", "gpu_matches_oracle_on_sample": bool(ok)}
+            if not ok:
+                print("[bench] PARITY FAILURE against the oracle on the sample", file=sys.stderr)
+        line = {
+            "metric": "snippets/sec (21x21 windows @10kb, ROI + control snippets accumulated)",
+            "value": round(value, 1), "unit": "snippets/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[2]: synthetic hg38 10kb CSR + 1e6 random cis BEDPE pairs, pad=10, "
+                            "nshifts=10, balanced, ignore_diags=2",
+                "nnz": int(wl["bin2_id"].shape[0]), "nbins": int(wl["bin1_offset"].shape[0] - 1),
+                "pairs": a.pairs, "nshifts": a.nshifts, "pad": a.pad, "snippets_per_step": n_all,
+                "parallelism": f"snippet-sharded x{a.gpus}, pixel table replicated, RCCL all-reduce of tiles",
+            },
+            "roofline": roofline, "cpu_baseline": cpu,
+            "h2d_pixel_table_s": round(t_h2d, 3),
+            "check": {"n": [int(x) for x in out["n"]],
+                      "center_roi_over_ctrl": float((out["sum"][0, a.pad, a.pad] / out["num"][0, a.pad, a.pad]) /
+                                                    (out["sum"][1, a.pad, a.pad] / out["num"][1, a.pad, a.pad]))},
+        }
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,1178 @@
+"""Host-side mirror of coolpuppy's pile-up API on top of the MI355X engine.
+
+Same public names, arguments, defaults, error behaviour and returned DataFrame layout as the
+reference's ``coolpuppy/coolpup.py`` (``CoordCreator`` :150-749, ``PileUpper`` :752-1919,
+``pileup`` :1922-2279) — so code written against coolpuppy keeps working — but the work is organised
+for a GPU instead of a per-snippet Python loop:
+
+* coordinates are generated as numpy column tables per region (not one dict per snippet); the
+  random-shift controls issue the SAME ``np.random`` legacy calls in the SAME order as the
+  reference (``_control_regions`` :387-453), so control windows are bit-identical for ``nproc=1``;
+* every snippet becomes (r0, c0, tile, flip): top-left GLOBAL bins + accumulator index; the whole
+  per-snippet extract/mask/normalise/accumulate loop (``_stream_snips`` :1059-1191,
+  ``accumulate_stream`` :1236-1283, ``_add_snip`` lib/puputils.py:12-41) runs in ``libpup_hip.so``;
+* the tail of ``pileupsWithControl`` (:1511-1654) — merge, coverage normalisation, ROI/control ratio,
+  inf→NaN, symmetrisation, annotation — is restated with pandas on the fetched tiles.
+
+Not implemented (raise ``NotImplementedError``): rescaled pile-ups, stored stripes, by-window
+pile-ups and per-snippet Python callbacks (``postprocess_func`` / ``extra_sum_funcs``) — SURVEY.md §8(f).
+"""
+import itertools
+import logging
+import os
+import re
+import warnings
+from functools import partial
+
+import numpy as np
+import pandas as pd
+
+from .cooler_lite import as_array_cooler
+from .lib.puputils import finalize_pileups
+
+logger = logging.getLogger("coolpuppy")
+
+KIND_ROI, KIND_CONTROL = 0, 1
+_DEFAULT_EDGES = "default"
+
+
+# ------------------------------------------------------------------------------------------------------
+# small helpers
+# ------------------------------------------------------------------------------------------------------
+def natsorted(seq):
+    """Natural sort ("chr2" < "chr10"), the ordering the reference gets from ``natsort.natsorted``."""
+    def key(s):
+        return [(0, int(t), "") if t.isdigit() else (1, 0, t) for t in re.split(r"(\d+)", str(s)) if t != ""]
+    return sorted(seq, key=key)
+
+
+def _default_band_edges():
+    return np.append([0], 50000 * 2 ** np.arange(30))
+
+
+def bin_distance_intervals(intervals, band_edges="default"):
+    """Annotate a DataFrame that has a 'distance' column with a 'distance_band' tuple column
+    (reference coolpup.py:28-51): band = (edges[i-1], edges[i]) with i = searchsorted(edges, d, 'right')."""
+    if isinstance(band_edges, str) and band_edges == "default":
+        band_edges = _default_band_edges()
+    ids = np.searchsorted(band_edges, intervals["distance"], side="right")
+    lut = {i: tuple(band_edges[i - 1:i + 1]) for i in np.unique(ids)}   # i == 0 (negative distance) -> ()
+    intervals["distance_band"] = [lut[i] for i in ids]
+    return intervals
+
+
+def assign_groups(intervals, groupby=[]):
+    """'group' column: "all", or the list of the groupby values of each row (reference :54-75)."""
+    if not groupby:
+        intervals["group"] = "all"
+    else:
+        intervals["group"] = list(intervals[groupby].values)
+    return intervals
+
+
+def expand(intervals, flank, resolution, rescale_flank=None):
+    """Window of one feature: the bin holding its centre, +- flank (reference :78-91)."""
+    if rescale_flank is not None:
+        raise NotImplementedError("rescale_flank (rescaled pile-ups) is not implemented in coolpuppy_amd")
+    out = intervals.copy()
+    cbin_start = np.floor(out["center"] / resolution) * resolution
+    out["exp_start"] = cbin_start - flank
+    out["exp_end"] = np.floor(out["center"] / resolution + 1) * resolution + flank
+    return out
+
+
+def expand2D(intervals, flank, resolution, rescale_flank=None):
+    """Two-sided version of :func:`expand` (reference :94-115)."""
+    if rescale_flank is not None:
+        raise NotImplementedError("rescale_flank (rescaled pile-ups) is not implemented in coolpuppy_amd")
+    for side in ("1", "2"):
+        c = intervals["center" + side]
+        intervals["exp_start" + side] = np.floor(c // resolution) * resolution - flank
+        intervals["exp_end" + side] = np.floor(c / resolution + 1) * resolution + flank
+    return intervals
+
+
+def flip_mark_intervals_func(intervals, flipby, flip_negative_strand, extra_func=None):
+    """'flip' column: negative strand of side 1, or flipby1 > flipby2 (reference :118-125)."""
+    if flip_negative_strand:
+        intervals["flip"] = np.where(intervals["strand1"] == "-", True, False)
+    else:
+        intervals["flip"] = intervals[f"{flipby}1"] > intervals[f"{flipby}2"]
+    if extra_func is not None:
+        intervals = extra_func(intervals)
+    return intervals
+
+
+class _Cols(dict):
+    """A column table: name -> 1-D numpy array, all of one length."""
+
+    def __len__(self):
+        for v in self.values():
+            return int(v.shape[0])
+        return 0
+
+    def take(self, sel):
+        return _Cols({k: v[sel] for k, v in self.items()})
+
+    def tiled(self, k):
+        return _Cols({name: np.tile(v, k) for name, v in self.items()})
+
+    @staticmethod
+    def concat(a, b):
+        return _Cols({k: np.concatenate([a[k], b[k]]) for k in a})
+
+    def frame(self):
+        return pd.DataFrame({k: v for k, v in self.items()})
+
+    @staticmethod
+    def from_frame(df):
+        return _Cols({c: df[c].values for c in df.columns})
+
+
+# ------------------------------------------------------------------------------------------------------
+# CoordCreator
+# ------------------------------------------------------------------------------------------------------
+class CoordCreator:
+    """Turns BED / BEDPE features into pile-up windows in bin units (reference coolpup.py:150-749).
+
+    Same constructor and attributes as the reference.  Window streams are exposed as column tables
+    (:meth:`region_table`) rather than per-snippet dicts; :attr:`pos_stream` still yields dict rows for
+    code that iterates it.
+    """
+
+    def __init__(self, features, resolution, *, features_format="auto", flank=100000, rescale_flank=None,
+                 chroms="all", minshift=10**5, maxshift=10**6, nshifts=10, mindist="auto", maxdist=None,
+                 local=False, subset=0, trans=False, seed=None):
+        self.intervals = features.copy()
+        self.resolution = resolution
+        self.features_format = features_format
+        self.flank = flank
+        self.rescale_flank = rescale_flank
+        self.chroms = chroms
+        self.minshift = minshift
+        self.maxshift = maxshift
+        self.nshifts = nshifts
+        self.trans = trans
+        if mindist == "auto":
+            self.mindist = 2 * self.flank + 2 * self.resolution
+        else:
+            self.mindist = mindist
+            if self.trans:
+                warnings.warn("Ignoring mindist when using trans", stacklevel=2)
+                self.mindist = 0
+        if maxdist is None:
+            self.maxdist = np.inf
+        else:
+            self.maxdist = maxdist
+            if self.trans:
+                warnings.warn("Ignoring maxdist when using trans", stacklevel=2)
+                self.maxdist = np.inf
+        self.local = local
+        self.subset = subset
+        self.seed = seed
+        self.process()
+
+    # -- construction-time processing (reference :259-385) -------------------------------------------
+    def process(self):
+        bedpe_cols = ["chrom1", "start1", "end1", "chrom2", "start2", "end2"]
+        bed_cols = ["chrom", "start", "end"]
+        have = set(self.intervals.columns)
+        if self.features_format is None or self.features_format == "auto":
+            if have.issuperset(bedpe_cols):
+                self.kind = "bedpe"
+            elif have.issuperset(bed_cols):
+                self.kind = "bed"
+            else:
+                raise ValueError(
+                    "Can't determine kind of input, please specify and/or name columns correctly:"
+                    "'chrom1', 'start1', 'end1', 'chrom2', 'start2', 'end2' for bedpe kind"
+                    "'chrom', 'start', 'end' for bed kind"
+                )
+        else:
+            self.kind = self.features_format
+        if self.kind not in ("bed", "bedpe"):
+            raise ValueError('kind can only be "bed" or "bedpe"')
+        if self.rescale_flank is not None:
+            raise NotImplementedError("rescale_flank (rescaled pile-ups) is not implemented in coolpuppy_amd")
+        if self.flank % self.resolution != 0:
+            raise ValueError(
+                f"flank ({self.flank}) must be a multiple of the resolution ({self.resolution}): the window "
+                "would not be 2*(flank//resolution)+1 bins wide")
+
+        if self.subset > 0:
+            self.intervals = self._subset(self.intervals)
+
+        iv = self.intervals
+        if self.kind == "bed":
+            assert have.issuperset(bed_cols), "Column names must include chrom, start, and end"
+            iv["chrom"] = iv["chrom"].astype(str)
+            iv["center"] = (iv["start"] + iv["end"]) / 2
+            iv = expand(iv, self.flank, self.resolution, self.rescale_flank)
+        else:
+            assert have.issuperset(bedpe_cols), \
+                "Column names must include chrom1, start1, end1, chrom2, start2, and end2"
+            iv[["chrom1", "chrom2"]] = iv[["chrom1", "chrom2"]].astype(str)
+            iv["center1"] = (iv["start1"] + iv["end1"]) / 2
+            iv["center2"] = (iv["start2"] + iv["end2"]) / 2
+            iv["distance"] = iv["center2"] - iv["center1"]
+            absd = iv["distance"].abs()
+            iv = iv[(self.mindist <= absd) & (absd <= self.maxdist)].reset_index(drop=True)
+            iv = expand2D(iv, self.flank, self.resolution, self.rescale_flank)
+        self.intervals = iv
+
+        if iv.shape[0] == 0:
+            warnings.warn("No regions in features (maybe all below mindist?), returning empty output", stacklevel=2)
+            self.pos_stream = self.empty_stream
+            self.final_chroms = []
+            return
+
+        if self.nshifts > 0 and self.kind == "bedpe":
+            self.intervals = self._control_regions(self.intervals)   # nshifts=0: only tags kind="ROI"
+
+        if self.kind == "bed":
+            base = set(self.intervals["chrom"])
+        else:
+            if self.local:
+                raise ValueError("Can't make local with both sides of loops defined")
+            if self.trans:
+                base = set(self.intervals["chrom1"].unique().tolist() + self.intervals["chrom2"].unique().tolist())
+            else:
+                base = set(self.intervals["chrom1"]).intersection(set(self.intervals["chrom2"]))
+        self.basechroms = natsorted(list(base))
+        if isinstance(self.chroms, str) and self.chroms == "all":
+            self.final_chroms = natsorted(list(base))
+        else:
+            self.final_chroms = natsorted(list(set(self.chroms).intersection(set(self.basechroms))))
+        if len(self.final_chroms) == 0:
+            raise ValueError(
+                """No chromosomes are in common between the coordinate
+                   file and the cooler file. Are they in the same
+                   format, e.g. starting with "chr"?
+                   """
+            )
+
+        self.intervals = self._binnify(self.intervals)
+
+        keys = ["stBin", "endBin"] if self.kind == "bed" else ["stBin1", "endBin1", "stBin2", "endBin2"]
+        dups = self.intervals.duplicated(subset=keys)
+        if dups.any():
+            logger.debug(f"{dups.mean() * 100:.2f}% of intervals fall within the same bin as another interval. "
+                         "These are all included in the pileup.")
+
+        if self.trans & self.local:
+            raise ValueError("Cannot do local with trans=True")
+
+        self.pos_stream = self.get_combinations if self.kind == "bed" else self.get_intervals_stream
+
+    def _subset(self, df):
+        if self.seed is not None:
+            np.random.seed(self.seed)
+        if 0 < self.subset < len(df):
+            return df.sample(self.subset)
+        return df
+
+    def _binnify(self, intervals):
+        """Sort and convert expanded coordinates to bins (reference :489-527). pandas does the sort so the
+        row order (hence the control-shift assignment) is the reference's."""
+        res = self.resolution
+        if self.kind == "bed":
+            intervals = intervals.sort_values(["chrom", "start"])
+            sides = [""]
+        else:
+            intervals = intervals.sort_values(["chrom1", "chrom2", "start1", "start2"])
+            sides = ["1", "2"]
+        for s in sides:
+            intervals["stBin" + s] = np.floor(intervals["exp_start" + s] / res).astype(int)
+            intervals["endBin" + s] = np.ceil(intervals["exp_end" + s] / res).astype(int)
+            intervals["exp_start" + s] = intervals["stBin" + s] * res
+            intervals["exp_end" + s] = intervals["endBin" + s] * res
+        return intervals
+
+    # -- random-shift controls (reference :387-453) -----------------------------------------------------
+    def _control_regions(self, intervals2d, nshifts=0):
+        """DataFrame form (API compatibility).  Issues exactly the reference's RNG calls."""
+        if nshifts <= 0:
+            intervals2d["kind"] = "ROI"
+            return intervals2d
+        cols = _Cols.from_frame(intervals2d)
+        out = self._control_cols(cols, nshifts)
+        df = out.frame()
+        df["kind"] = np.where(out["kind"] == KIND_ROI, "ROI", "control")
+        return df
+
+    def _control_cols(self, cols, nshifts):
+        """Column-table form: returns ROI rows followed by nshifts shifted copies, with an int8 'kind'."""
+        n = len(cols)
+        if nshifts <= 0:
+            out = _Cols(cols)
+            out["kind"] = np.full(n, KIND_ROI, np.int8)
+            return out
+        ctrl = cols.tiled(nshifts)
+        m = n * nshifts
+        shift = np.random.randint(self.minshift, self.maxshift, m)
+        sign = np.random.choice([-1, 1], m)
+        shift *= sign
+        if self.trans:   # the two sides move independently in bp ...
+            shift2 = np.random.randint(self.minshift, self.maxshift, m)
+            sign2 = np.random.choice([-1, 1], m)
+            shift2 = shift2 * sign2
+        else:
+            shift2 = shift
+        for name in ("exp_start1", "exp_end1", "center1"):
+            if name in ctrl:
+                ctrl[name] = ctrl[name] + shift
+        for name in ("exp_start2", "exp_end2", "center2"):
+            if name in ctrl:
+                ctrl[name] = ctrl[name] + shift2
+        # ... but the BINS of both sides move by `shift` (reference :442-445)
+        dbin = np.round(shift / self.resolution).astype(int)
+        for name in ("stBin1", "endBin1", "stBin2", "endBin2"):
+            ctrl[name] = ctrl[name] + dbin
+        roi = _Cols(cols)
+        roi["kind"] = np.full(n, KIND_ROI, np.int8)
+        ctrl["kind"] = np.full(m, KIND_CONTROL, np.int8)
+        return _Cols.concat(roi, ctrl)
+
+    # -- region filters (reference :529-596) --------------------------------------------------------------
+    def filter_func_all(self, intervals):
+        return intervals
+
+    def _filter_func_chrom(self, intervals, chrom):
+        return intervals[intervals["chrom"] == chrom].reset_index(drop=True)
+
+    def _filter_func_pairs_chrom(self, intervals, chrom):
+        return intervals[(intervals["chrom1"] == chrom) & (intervals["chrom2"] == chrom)].reset_index(drop=True)
+
+    def filter_func_chrom(self, chrom):
+        f = self._filter_func_chrom if self.kind == "bed" else self._filter_func_pairs_chrom
+        return partial(f, chrom=chrom)
+
+    def _filter_func_region(self, intervals, region):
+        chrom, start, end = region
+        keep = (intervals["chrom"] == chrom) & (intervals["start"] >= start) & (intervals["end"] < end)
+        return intervals[keep].reset_index(drop=True)
+
+    def _filter_func_pairs_region(self, intervals, region):
+        chrom, start, end = region
+        keep = ((intervals["chrom1"] == chrom) & (intervals["chrom2"] == chrom)
+                & (intervals["start1"] >= start) & (intervals["end1"] < end)
+                & (intervals["start2"] >= start) & (intervals["end2"] < end))
+        return intervals[keep].reset_index(drop=True)
+
+    def _filter_func_trans_pairs(self, intervals, region1, region2):
+        c1, s1, e1 = region1
+        c2, s2, e2 = region2
+        fwd = ((intervals["chrom1"] == c1) & (intervals["chrom2"] == c2)
+               & (intervals["start1"] >= s1) & (intervals["end1"] < e1)
+               & (intervals["start2"] >= s2) & (intervals["end2"] < e2))
+        rev = ((intervals["chrom2"] == c1) & (intervals["chrom1"] == c2)
+               & (intervals["start2"] >= s1) & (intervals["end2"] < e1)
+               & (intervals["start1"] >= s2) & (intervals["end1"] < e2))
+        # rows in the opposite chromosome order are selected but NOT swapped (reference :578-585)
+        return pd.concat([intervals[fwd].reset_index(drop=True), intervals[rev].reset_index(drop=True)])
+
+    def filter_func_trans_pairs(self, region1, region2):
+        return partial(self._filter_func_trans_pairs, region1=region1, region2=region2)
+
+    def filter_func_region(self, region):
+        f = self._filter_func_region if self.kind == "bed" else self._filter_func_pairs_region
+        return partial(f, region=region)
+
+    # -- column-table window generation ---------------------------------------------------------------------
+    def _needed(self, want):
+        """Columns to carry per snippet: bins + what grouping/flipping asks for (None = everything)."""
+        if want is None:
+            return None
+        base = ["stBin1", "endBin1", "stBin2", "endBin2"]
+        return base + [c for c in want if c not in base]
+
+    def region_table(self, region1, region2=None, control=False, columns=()):
+        """All windows of one region (pair) as a column table with 'kind' (0 ROI / 1 control).
+
+        region1/region2: (chrom, start, end).  ``columns``: extra columns to carry (e.g. 'distance',
+        'strand1'); None carries every column.  Equivalent of running ``pos_stream`` for the region
+        (reference get_intervals_stream :716-746 / get_combinations :598-714) up to, not including,
+        ``modify_2Dintervals_func`` and ``assign_groups``.
+        """
+        if len(self.intervals) == 0 or not hasattr(self, "kind") or self.pos_stream == self.empty_stream:
+            return None
+        nshifts = self.nshifts * bool(control)
+        if self.kind == "bedpe":
+            if self.trans:
+                sub = self._filter_func_trans_pairs(self.intervals, tuple(region1), tuple(region2))
+            else:
+                sub = self._filter_func_pairs_region(self.intervals, tuple(region1))
+            keep = self._needed(columns)
+            cols = _Cols.from_frame(sub if keep is None else sub[[c for c in keep if c in sub.columns]])
+            out = self._control_cols(cols, nshifts)
+            return out if len(sub) >= 1 else None
+        # ---- bed: combinations ----
+        left = self._filter_func_region(self.intervals, tuple(region1))
+        right = left if region2 is None or tuple(region2) == tuple(region1) else \
+            self._filter_func_region(self.intervals, tuple(region2))
+        want = None if columns is None else set(columns) | {"center1", "center2"}
+
+        def side(df, s):
+            names = list(df.columns) if want is None else \
+                [c for c in df.columns if c + s in want or c in ("stBin", "endBin", "center")]
+            return {c + s: df[c].values for c in names}
+
+        L, R = side(left, "1"), side(right, "2")
+        if self.local:
+            tbl = _Cols({**L, **{k[:-1] + "2": v for k, v in L.items()}})
+            return self._control_cols(tbl, nshifts)
+        parts = []
+        if self.trans:
+            nl, nr = len(left), len(right)
+            if nshifts == 0:
+                x = np.repeat(np.arange(nl), nr)
+                y = np.tile(np.arange(nr), nl)
+                tbl = _Cols({**{k: v[x] for k, v in L.items()}, **{k: v[y] for k, v in R.items()}})
+                return self._control_cols(tbl, 0) if len(tbl) else None
+            for x, y in itertools.product(range(nl), range(nr)):   # one RNG draw set per pair, as the reference
+                tbl = _Cols({**{k: v[x:x + 1] for k, v in L.items()}, **{k: v[y:y + 1] for k, v in R.items()}})
+                parts.append(self._control_cols(tbl, nshifts))
+        else:
+            m = len(left)                      # cis: right is left (reference :614-615)
+            c1, c2 = L["center1"], R["center2"]
+            # the reference loops offsets up to the TOTAL number of features (:682); offsets >= m select
+            # nothing and draw nothing
+            for i in range(1, min(self.intervals.shape[0], m)):
+                k = m - i
+                dist = c2[i:i + k] - c1[:k]
+                ok = (self.mindist <= np.abs(dist)) & (np.abs(dist) <= self.maxdist)
+                a = np.flatnonzero(ok)
+                if len(a) == 0:
+                    continue                   # size-0 RNG draws do not advance the generator
+                tbl = _Cols({**{kk: v[a] for kk, v in L.items()}, **{kk: v[a + i] for kk, v in R.items()}})
+                tbl["distance"] = dist[a]
+                parts.append(self._control_cols(tbl, nshifts))
+        parts = [p for p in parts if len(p)]
+        if not parts:
+            return None
+        out = _Cols({k: np.concatenate([p[k] for p in parts]) for k in parts[0]})
+        return out
+
+    # -- dict-row streams kept for API compatibility (reference :598-749) -----------------------------------
+    def get_intervals_stream(self, filter_func1, filter_func2=None, intervals=None, control=False, groupby=[],
+                             modify_2Dintervals_func=None):
+        """Per-snippet dict rows, as the reference yields them (bedpe). Slow path; the engine uses region_table."""
+        if intervals is None:
+            intervals = self.intervals
+        intervals = filter_func1(intervals)
+        intervals = self._control_regions(intervals, self.nshifts * control)
+        if modify_2Dintervals_func is not None:
+            intervals = modify_2Dintervals_func(intervals)
+        intervals = assign_groups(intervals, groupby)
+        if not len(intervals) >= 1:
+            logger.debug("Empty selection")
+            yield None
+        for row in intervals.to_dict(orient="records"):
+            yield row
+
+    def get_combinations(self, filter_func1, filter_func2=None, intervals=None, control=False, groupby=[],
+                         modify_2Dintervals_func=None):
+        raise NotImplementedError(
+            "coolpuppy_amd generates bed combinations as column tables: use CoordCreator.region_table()")
+
+    def empty_stream(self, *args, **kwargs):
+        yield from ()
+
+
+# ------------------------------------------------------------------------------------------------------
+# PileUpper
+# ------------------------------------------------------------------------------------------------------
+def _make_cooler_view(clr):
+    """cooltools.lib.common.make_cooler_view: one whole-chromosome region per chromosome."""
+    return pd.DataFrame({"chrom": list(clr.chromnames), "start": 0,
+                         "end": [int(clr.chromsizes[c]) for c in clr.chromnames], "name": list(clr.chromnames)})
+
+
+def _make_viewframe(view_df, chromsizes):
+    """bioframe.make_viewframe for the DataFrame case: chrom/start/end[/name], bounds-checked."""
+    df = pd.DataFrame(view_df).copy()
+    if "chrom" not in df.columns:
+        df.columns = ["chrom", "start", "end", "name"][: df.shape[1]] + list(df.columns[4:])
+    if "name" not in df.columns:
+        df["name"] = df["chrom"].astype(str)
+    df["chrom"] = df["chrom"].astype(str)
+    df = df[["chrom", "start", "end", "name"]].reset_index(drop=True)
+    if df["name"].duplicated().any():
+        raise ValueError("view_df is not a valid viewframe: region names are not unique")
+    for _, r in df.iterrows():
+        if r["chrom"] not in chromsizes.index or r["start"] < 0 or r["end"] > int(chromsizes[r["chrom"]]) \
+                or r["start"] >= r["end"]:
+            raise ValueError(f"view_df is not a valid viewframe or incompatible: region {tuple(r)} out of bounds")
+    return df
+
+
+_ENGINES = {}
+
+
+def _engine_for(clr, device_id):
+    """One resident pixel table per (cooler object, device): repeated pile-ups skip the upload."""
+    from .engine import PileupEngine
+    key = (id(clr), device_id)
+    hit = _ENGINES.get(key)
+    if hit is not None and hit[0] is clr:
+        return hit[1]
+    for k in [k for k, v in _ENGINES.items() if k[1] == device_id]:   # one table per device at a time
+        _ENGINES.pop(k)[1].close()
+    eng = PileupEngine(device_id)
+    eng.load_pixels(*clr.pixel_table())
+    _ENGINES[key] = (clr, eng)
+    return eng
+
+
+class PileUpper:
+    """Creates pile-ups (reference coolpup.py:752-1919) with the per-snippet work on the GPU."""
+
+    def __init__(self, clr, CC, *, view_df=None, clr_weight_name="weight", expected=False,
+                 expected_value_col="balanced.avg", ooe=True, control=False, coverage_norm=False, rescale=False,
+                 rescale_size=99, flip_negative_strand=False, ignore_diags=2, store_stripes=False, nproc=1):
+        self.clr = clr
+        self._aclr = as_array_cooler(clr)
+        self.resolution = self.clr.binsize
+        self.CC = CC
+        assert self.resolution == self.CC.resolution
+        self.__dict__.update(self.CC.__dict__)
+        self.clr_weight_name = clr_weight_name
+        self.expected = expected
+        self.expected_value_col = expected_value_col
+        self.ooe = ooe
+        self.control = control
+        self.pad_bins = self.CC.flank // self.resolution
+        self.coverage_norm = coverage_norm
+        self.rescale = rescale
+        self.rescale_size = rescale_size
+        self.flip_negative_strand = flip_negative_strand
+        self.ignore_diags = ignore_diags
+        self.store_stripes = store_stripes
+        self.nproc = nproc
+
+        if view_df is None:
+            self.view_df = _make_cooler_view(clr)
+        else:
+            self.view_df = _make_viewframe(view_df, clr.chromsizes)
+        self._expected_vectors = {}
+        if self.expected is not None and self.expected is not False:
+            exp = self.expected
+            need = {"region1", "region2", self.expected_value_col}
+            if not isinstance(exp, pd.DataFrame) or not need.issubset(exp.columns):
+                raise ValueError("provided expected is not valid")
+            exp = exp[exp["region1"].isin(self.view_df["name"]) & exp["region2"].isin(self.view_df["name"])] \
+                .reset_index(drop=True)
+            if self.control:
+                warnings.warn("Can't do both expected and control shifts; defaulting to expected", stacklevel=2)
+                self.control = False
+            if self.trans:
+                if (exp["region1"] == exp["region2"]).all() and len(exp):
+                    raise ValueError("provided expected is not valid")
+                self.expected_df = exp
+            else:
+                exp = exp[exp["region1"] == exp["region2"]].reset_index(drop=True)
+                if "dist" not in exp.columns:
+                    raise ValueError("provided expected is not valid")
+                for name in self.view_df["name"]:
+                    rows = exp[exp["region1"] == name]
+                    if len(rows) == 0:
+                        raise ValueError("provided expected is not valid")
+                    # by-diagonal vector in table order (ExpectedSnipper.select -> LazyToeplitz)
+                    self._expected_vectors[name] = rows[self.expected_value_col].values.astype(np.float64)
+                self.expected_df = exp
+            self.expected = True
+        self.view_df = self.view_df.set_index("name")
+        self.view_df_extents = {}
+        self._global_extents = {}
+        for region_name, region in self.view_df.iterrows():
+            lo, hi = self._aclr.extent((region["chrom"], region["start"], region["end"]))
+            chroffset = self._aclr.offset(region["chrom"])
+            self.view_df_extents[region_name] = lo - chroffset, hi - chroffset
+            self._global_extents[region_name] = (lo, hi, chroffset)
+
+        self.chroms = natsorted(list(set(self.CC.final_chroms) & set(self.clr.chromnames)))
+        self.view_df = self.view_df[self.view_df["chrom"].isin(self.chroms)]
+        if self.view_df["chrom"].unique().shape[0] == 0:
+            raise ValueError(
+                """No chromosomes are in common between the coordinate
+                   file and the cooler file. Are they in the same
+                   format, e.g. starting with "chr"?
+                   """
+            )
+        if self.trans and self.view_df["chrom"].unique().shape[0] < 2:
+            raise ValueError("Trying to do trans with fewer than two chromosomes")
+
+        bins_columns = list(self.clr.bins().columns)
+        if self.coverage_norm is True:
+            self.coverage_norm = "cov_tot_raw"
+        elif self.coverage_norm == "cis":
+            self.coverage_norm = "cov_cis_raw"
+        elif self.coverage_norm == "total":
+            self.coverage_norm = "cov_tot_raw"
+        elif self.coverage_norm and self.coverage_norm not in bins_columns:
+            raise ValueError(f"coverage_norm {self.coverage_norm} not found in cooler bins")
+        if self.coverage_norm in ["cov_cis_raw", "cov_tot_raw"] and self.coverage_norm not in bins_columns:
+            raise NotImplementedError(
+                f"the cooler has no {self.coverage_norm!r} column; computing coverage (cooltools.coverage, "
+                "reference coolpup.py:955-963) is not implemented here yet — store the column first")
+        if self.coverage_norm and self.clr_weight_name:
+            raise ValueError("Can't do coverage normalization when clr_weight_name is provided")
+        if self.rescale:
+            if self.rescale_flank is None:
+                raise ValueError("Cannot use rescale without setting rescale_flank")
+            elif self.rescale_size % 2 == 0:
+                raise ValueError("Please provide an odd rescale_size")
+            raise NotImplementedError("rescaled pile-ups are not implemented in coolpuppy_amd")
+        if self.store_stripes:
+            raise NotImplementedError("store_stripes is not implemented in coolpuppy_amd")
+        if self.ignore_diags is None or self.ignore_diags < 0:
+            raise ValueError("ignore_diags must be >= 0 (the engine reads the upper-triangular pixel table)")
+
+        self.empty_outmap = self.make_outmap()
+        self.empty_pup = {
+            "data": self.empty_outmap, "horizontal_stripe": [], "vertical_stripe": [], "n": 0,
+            "num": self.empty_outmap, "cov_start": np.zeros((self.empty_outmap.shape[0])),
+            "cov_end": np.zeros((self.empty_outmap.shape[1])), "coordinates": [],
+        }
+
+    # -- small pieces kept from the reference API ------------------------------------------------------------
+    def get_expected_trans(self, region1, region2):
+        sel = (self.expected_df["region1"] == region1) & (self.expected_df["region2"] == region2)
+        return self.expected_df.loc[sel, self.expected_value_col].item()
+
+    def make_outmap(self):
+        n = self.rescale_size if self.rescale else 2 * self.pad_bins + 1
+        return np.zeros((n, n))
+
+    # -- host side of pileup_region: windows of one region (pair) as engine inputs ----------------------------
+    def _region_pairs(self):
+        if self.trans:
+            r1, r2 = [], []
+            for a, b in itertools.combinations(self.view_df.index, 2):
+                if self.view_df.loc[a, "chrom"] != self.view_df.loc[b, "chrom"]:
+                    r1.append(a)
+                    r2.append(b)
+            return list(zip(r1, r2))
+        return [(r, r) for r in self.view_df.index]
+
+    def region_snippets(self, region1, region2=None, groupby=[], modify_2Dintervals_func=None, columns=()):
+        """Host half of ``pileup_region`` (reference :1285-1358 down to the skip test :1105-1114).
+
+        Returns None when the region has no feature, else a dict with the accepted windows:
+        r0, c0 (global top-left bins, int64), kind (int8), flip (bool), group_codes (int64, -1 when
+        ungrouped), group_keys (list of tuples in first-appearance order), transpose (bool).
+        """
+        if region2 is None:
+            region2 = region1
+        reg1 = tuple(self.view_df.loc[region1, ["chrom", "start", "end"]])
+        reg2 = tuple(self.view_df.loc[region2, ["chrom", "start", "end"]])
+        carry = columns
+        if carry is not None:
+            carry = list(carry) + [c for c in groupby if c != "distance_band"]
+            if modify_2Dintervals_func is not None and not _is_builtin_modify(modify_2Dintervals_func):
+                carry = None          # a user function may read any column
+        tbl = self.CC.region_table(reg1, None if region2 == region1 else reg2, control=self.control, columns=carry)
+        if tbl is None or len(tbl) == 0:
+            return None
+        decoders = {}
+        if modify_2Dintervals_func is not None:
+            if _is_builtin_modify(modify_2Dintervals_func):
+                tbl, decoders = _apply_builtin_modify(tbl, modify_2Dintervals_func)
+            else:
+                tbl = _Cols.from_frame(modify_2Dintervals_func(tbl.frame()))
+        lo1, hi1, off1 = self._global_extents[region1]
+        lo2, hi2, off2 = self._global_extents[region2]
+        W = 2 * self.pad_bins + 1
+        if not (np.all(tbl["endBin1"] - tbl["stBin1"] == W) and np.all(tbl["endBin2"] - tbl["stBin2"] == W)):
+            raise ValueError("window size differs from 2*pad_bins+1; rescaled windows are not supported")
+        r0 = tbl["stBin1"].astype(np.int64) + off1
+        c0 = tbl["stBin2"].astype(np.int64) + off2
+        ok = (r0 >= lo1) & (r0 + W <= hi1) & (c0 >= lo2) & (c0 + W <= hi2)     # reference :1111-1114
+        tbl = tbl.take(ok)
+        r0, c0 = r0[ok], c0[ok]
+        n = len(r0)
+        flip = tbl["flip"].astype(bool) if "flip" in tbl else np.zeros(n, bool)
+        if groupby:
+            keycols = []
+            for g in groupby:
+                v = tbl[g]
+                if self.ignore_group_order and flip.any():
+                    # flipped snippets swap every paired column X1<->X2 before grouping (reference :131-144)
+                    partner = g[:-1] + ("2" if g.endswith("1") else "1") if g[-1:] in "12" else None
+                    if partner is not None and partner in tbl:
+                        v = np.where(flip, tbl[partner], v)
+                keycols.append(v)
+            codes, keys = _factorize_rows(keycols, [decoders.get(g) for g in groupby])
+        else:
+            codes, keys = np.full(n, -1, np.int64), []
+        return {"r0": r0, "c0": c0, "kind": tbl["kind"].astype(np.int8), "flip": flip, "group_codes": codes,
+                "group_keys": keys, "n": n}
+
+    # -- the pile-up -------------------------------------------------------------------------------------------
+    def pileupsWithControl(self, nproc=None, groupby=[], ignore_group_order=False, modify_2Dintervals_func=None,
+                           postprocess_func=None, extra_sum_funcs=None, _columns=()):
+        """All regions -> normalised pile-ups DataFrame (reference :1360-1654)."""
+        self.ignore_group_order = ignore_group_order
+        if postprocess_func is not None or extra_sum_funcs:
+            raise NotImplementedError(
+                "per-snippet Python callbacks (postprocess_func / extra_sum_funcs) cannot run on the GPU engine")
+        if nproc is None:
+            nproc = self.nproc
+        if len(self.chroms) == 0:
+            return self.make_outmap(), 0
+
+        columns = list(_columns) if _columns is not None else None
+        flipby = None
+        if self.flip_negative_strand:
+            flipby = "strand"
+            if self.ignore_group_order:
+                if self.local:
+                    raise ValueError("ignore_group_order doesn't make sense for local pileups")
+                elif self.kind == "bedpe":
+                    raise ValueError("ignore_group_order doesn't make sense for bedpe files")
+                elif groupby:
+                    warnings.warn(
+                        "flip_negative_strand and ignore_group_order leads to combining strands, not other groups")
+        elif self.ignore_group_order and groupby:
+            if self.local:
+                raise ValueError("ignore_group_order doesn't make sense for local pileups")
+            if self.kind == "bedpe":
+                raise ValueError("ignore_group_order doesn't make sense for bedpe files")
+            groups = np.array(groupby)
+            paired = [f"{g[:-1]}1" in groups and f"{g[:-1]}2" in groups for g in groups]
+            groups_filtered = np.sort(groups[paired])
+            if self.ignore_group_order is True:
+                flipby = list(set(g[:-1] for g in groups_filtered))
+            elif isinstance(self.ignore_group_order, str):
+                flipby = [self.ignore_group_order]
+            elif len(self.ignore_group_order) == 1:
+                flipby = self.ignore_group_order
+            elif len(self.ignore_group_order) > 1:
+                flipby = list(set(g[:-1] for g in self.ignore_group_order))
+            if len(flipby) == 1 and f"{flipby[0]}1" in groups_filtered:
+                flipby = flipby[0]
+            else:
+                raise ValueError(
+                    "Ambiguous ignore_group_order, please provide str or list of two strings which are in groupby")
+        elif self.ignore_group_order and not groupby:
+            warnings.warn("Need to specify groupby for ignore_group_order")
+
+        modify = modify_2Dintervals_func
+        if self.flip_negative_strand or (self.ignore_group_order and groupby):
+            modify = partial(flip_mark_intervals_func, flipby=flipby,
+                             flip_negative_strand=self.flip_negative_strand, extra_func=modify_2Dintervals_func)
+            if columns is not None:
+                columns += ["strand1"] if self.flip_negative_strand else [f"{flipby}1", f"{flipby}2"]
+        batches = []
+        for region1, region2 in self._region_pairs():
+            b = self.region_snippets(region1, region2, groupby=groupby, modify_2Dintervals_func=modify,
+                                     columns=columns)
+            batches.append((region1, region2, b))
+            if b is not None and b["n"] > 0:
+                logger.info(f"{region1, region2}: {int((b['kind'] == KIND_ROI).sum())}")
+
+        return self._pile_and_finalize(batches, groupby)
+
+    def make_plan(self, batches, groupby):
+        """Turn per-region window tables into a declarative list of engine calls plus the group bookkeeping
+        the finaliser needs.  Pure host code (no GPU): tests replay a plan on the CPU oracle."""
+        from .engine import MODE_COV, MODE_EXPECTED, MODE_OOE, MODE_TRANSPOSE
+        # global group table in the reference's first-appearance order: regions in order, each region's
+        # groups in snippet order, then "all" (coolpup.py:1263-1283, 1511-1531)
+        exp_as_control = bool(self.expected) and not self.ooe
+        want_control = bool(self.control) or exp_as_control
+        order = {KIND_ROI: [], KIND_CONTROL: []}
+        seen = {KIND_ROI: set(), KIND_CONTROL: set()}
+        contrib = {KIND_ROI: {}, KIND_CONTROL: {}}     # key -> number of regions holding it (sum_pups quirks)
+
+        def note(kind, key):
+            if key not in seen[kind]:
+                seen[kind].add(key)
+                order[kind].append(key)
+            contrib[kind][key] = contrib[kind].get(key, 0) + 1
+
+        for _, _, b in batches:
+            if b is not None and b["n"] > 0 and groupby:
+                for kind in (KIND_ROI, KIND_CONTROL):
+                    # with expected & !ooe every ROI snippet also emits an expected ("control") snippet
+                    sel = b["kind"] == (KIND_ROI if (exp_as_control and kind == KIND_CONTROL) else kind)
+                    if kind == KIND_CONTROL and not want_control:
+                        continue
+                    for c in pd.unique(b["group_codes"][sel]):
+                        note(kind, b["group_keys"][c])
+            note(KIND_ROI, "all")
+            if want_control:
+                note(KIND_CONTROL, "all")
+        keys_all = list(dict.fromkeys(order[KIND_ROI] + order[KIND_CONTROL]))
+        gid = {k: i for i, k in enumerate(keys_all)}
+        G = len(keys_all)
+        T = 2 * G
+        calls = []
+        for region1, region2, b in batches:
+            if b is None or b["n"] == 0:
+                continue
+            if groupby:
+                g = np.array([gid[k] for k in b["group_keys"]], np.int64)[b["group_codes"]]
+            else:
+                g = np.zeros(b["n"], np.int64)
+            expected = None
+            if self.expected:
+                expected = np.array([self.get_expected_trans(region1, region2)], np.float64) if self.trans \
+                    else self._expected_vectors[region1]
+            igd = -1 if self.trans else int(self.ignore_diags)
+            # engine rows must come from the earlier region of the upper-triangular table
+            transpose = self._global_extents[region1][0] > self._global_extents[region2][0]
+            r0, c0 = (b["c0"], b["r0"]) if transpose else (b["r0"], b["c0"])
+            tr = MODE_TRANSPOSE if transpose else 0
+            mode = (MODE_OOE if (self.expected and self.ooe) else 0) | (MODE_COV if self.coverage_norm else 0) | tr
+            calls.append(_engine_call(region1, region2, expected, r0, c0, b["flip"],
+                                      b["kind"].astype(np.int64) * G + g, T, igd, mode))
+            if exp_as_control:
+                roi = b["kind"] == KIND_ROI
+                calls.append(_engine_call(region1, region2, expected, r0[roi], c0[roi], b["flip"][roi],
+                                          G + g[roi], T, igd, MODE_EXPECTED | tr))
+        return {"T": T, "G": G, "gid": gid, "order": order, "contrib": contrib, "want_control": want_control,
+                "groupby": list(groupby), "calls": calls, "pad": self.pad_bins, "n_regions": len(batches),
+                "weight_name": self.clr_weight_name if self.clr_weight_name else None,
+                "cov_name": self.coverage_norm if self.coverage_norm else None}
+
+    def run_plan(self, plan):
+        """Execute a plan on this process's GPU (calls sharded over ranks when torch.distributed is
+        initialised, then one all-reduce of the packed accumulators) and fetch the tiles."""
+        from . import dist as _dist
+        eng = _engine_for(self._aclr, _dist.local_device())
+        bins = self.clr.bins()
+        eng.load_bins(bins[plan["weight_name"]][:].values if plan["weight_name"] else None,
+                      bins[plan["cov_name"]][:].values if plan["cov_name"] else None)
+        eng.reset(plan["T"], plan["pad"])
+        mine = _dist.shard(len(plan["calls"]), weights=[len(c["r0"]) for c in plan["calls"]])
+        for i, c in enumerate(plan["calls"]):
+            if i not in mine:
+                continue
+            eng.set_expected(c["expected"])
+            eng.accumulate(c["r0"], c["c0"], c["tile_ptr"], flip=c["flip"], ignore_diags=c["ignore_diags"],
+                           mode=c["mode"])
+        _dist.allreduce_engine(eng)
+        return eng.fetch()
+
+    def finalize_plan(self, plan, acc):
+        """Fetched tiles -> the reference's output DataFrame."""
+        G, gid, order = plan["G"], plan["gid"], plan["order"]
+        if plan["groupby"]:   # "all" of a grouped pile-up = sum of its groups (reference :1271-1282)
+            for kind in (KIND_ROI, KIND_CONTROL):
+                members = [kind * G + gid[k] for k in order[kind] if not (isinstance(k, str) and k == "all")]
+                if members:
+                    a = kind * G + gid["all"]
+                    for name in ("sum", "num", "n", "cov_start", "cov_end"):
+                        acc[name][a] = acc[name][members].sum(axis=0)
+        return finalize_pileups(self, acc, order, plan["contrib"], gid, G, plan["groupby"], plan["want_control"],
+                                n_regions=plan["n_regions"])
+
+    def _pile_and_finalize(self, batches, groupby):
+        plan = self.make_plan(batches, groupby)
+        return self.finalize_plan(plan, self.run_plan(plan))
+
+    def pileup_region(self, region1, region2=None, groupby=[], modify_2Dintervals_func=None, postprocess_func=None,
+                      extra_sum_funcs=None):
+        """One region (pair) -> {"ROI": {group: pup}, "control": {group: pup}} with summed, un-normalised
+        tiles (reference :1285-1358): pup = data (sum), num, n, cov_start, cov_end."""
+        if postprocess_func is not None or extra_sum_funcs:
+            raise NotImplementedError("per-snippet Python callbacks cannot run on the GPU engine")
+        if region2 is None:
+            region2 = region1
+        if not hasattr(self, "ignore_group_order"):
+            self.ignore_group_order = False
+        b = self.region_snippets(region1, region2, groupby=groupby, modify_2Dintervals_func=modify_2Dintervals_func,
+                                 columns=None)
+        plan = self.make_plan([(region1, region2, b)], groupby)
+        acc = self.run_plan(plan)
+        return _tiles_to_pups(plan, acc)
+
+    # -- by-X wrappers (reference :1656-1919) ---------------------------------------------------------------------
+    def pileupsByStrandWithControl(self, nproc=None, groupby=[], ignore_group_order=False):
+        if nproc is None:
+            nproc = self.nproc
+        pups = self.pileupsWithControl(nproc=nproc, groupby=["strand1", "strand2"] + groupby,
+                                       ignore_group_order=ignore_group_order)
+        pups.insert(0, "orientation", (pups["strand1"] + pups["strand2"]).replace({"allall": "all"}))
+        return pups
+
+    def pileupsByWindowWithControl(self, nproc=None):
+        if self.local:
+            raise ValueError("Cannot do by-window pileups for local")
+        raise NotImplementedError("by-window pile-ups are not implemented in coolpuppy_amd (SURVEY.md §8(f))")
+
+    def _distance_edges(self, distance_edges):
+        if not (isinstance(distance_edges, str) and distance_edges == "default"):
+            if not all(isinstance(n, (int, np.integer)) for n in distance_edges):
+                raise ValueError("Distance edges must be integers")
+            distance_edges = list(np.sort(distance_edges))
+            for _ in range(len(distance_edges)):
+                if np.min(distance_edges) < self.mindist:
+                    distance_edges[np.argmin(distance_edges)] = self.mindist
+                else:
+                    break
+        return distance_edges
+
+    @staticmethod
+    def _separation_labels(pups):
+        def label(x):
+            if isinstance(x, str) and x == "all":
+                return x
+            if len(x) == 2:
+                return f"{x[0] / 1000000}Mb-\n{x[1] / 1000000}Mb"
+            return f"{x[0] / 1000000}Mb+"
+        return pups["distance_band"].apply(label)
+
+    def pileupsByDistanceWithControl(self, nproc=None, distance_edges="default", groupby=[],
+                                     ignore_group_order=False):
+        if nproc is None:
+            nproc = self.nproc
+        if self.trans:
+            raise ValueError("Cannot do by-distance pileups for trans")
+        elif self.local:
+            raise ValueError("Cannot do by-distance pileups for local")
+        distance_edges = self._distance_edges(distance_edges)
+        bin_func = partial(bin_distance_intervals, band_edges=distance_edges)
+        pups = self.pileupsWithControl(nproc=nproc, modify_2Dintervals_func=bin_func,
+                                       groupby=["distance_band"] + groupby, ignore_group_order=ignore_group_order,
+                                       _columns=("distance",))
+        pups = pups.loc[pups["distance_band"] != (), :].reset_index(drop=True)
+        pups.insert(0, "separation", self._separation_labels(pups))
+        i = np.where(pups["separation"] == "all")[0]
+        pups = pd.concat([pups.drop(i).sort_values("distance_band"), pups.iloc[i, :]],
+                         ignore_index=True).reset_index(drop=True)
+        return pups
+
+    def pileupsByStrandByDistanceWithControl(self, nproc=None, distance_edges="default", groupby=[],
+                                             ignore_group_order=False):
+        if nproc is None:
+            nproc = self.nproc
+        if self.trans:
+            raise ValueError("Cannot do by-distance pileups for trans")
+        distance_edges = self._distance_edges(distance_edges)
+        bin_func = partial(bin_distance_intervals, band_edges=distance_edges)
+        pups = self.pileupsWithControl(nproc=nproc, modify_2Dintervals_func=bin_func,
+                                       groupby=["strand1", "strand2", "distance_band"] + groupby,
+                                       ignore_group_order=ignore_group_order, _columns=("distance",))
+        pups.insert(0, "orientation", (pups["strand1"] + pups["strand2"]).replace({"allall": "all"}))
+        pups = pups.loc[pups["distance_band"] != (), :].reset_index(drop=True)
+        pups.insert(0, "separation", self._separation_labels(pups))
+        i = np.where(pups["separation"] == "all")[0]
+        pups = pd.concat([pups.drop(i).sort_values(["orientation", "distance_band"]), pups.iloc[i, :]],
+                         ignore_index=True).reset_index(drop=True)
+        return pups
+
+
+def _engine_call(region1, region2, expected, r0, c0, flip, tile, T, igd, mode):
+    """One pup_accumulate call: snippets grouped by tile (stable: genome order is kept inside a tile)."""
+    if len(tile) > 1 and not np.all(tile[1:] >= tile[:-1]):
+        o = np.argsort(tile, kind="stable")
+        r0, c0, flip, tile = r0[o], c0[o], flip[o], tile[o]
+    tile_ptr = np.concatenate([[0], np.cumsum(np.bincount(tile, minlength=T))]).astype(np.int64)
+    return {"region1": region1, "region2": region2, "expected": expected,
+            "r0": np.ascontiguousarray(r0, np.int32), "c0": np.ascontiguousarray(c0, np.int32),
+            "flip": np.ascontiguousarray(flip, np.uint8) if flip is not None and flip.any() else None,
+            "tile": np.ascontiguousarray(tile, np.int32), "tile_ptr": tile_ptr, "ignore_diags": igd, "mode": mode}
+
+
+def _tiles_to_pups(plan, acc):
+    G, gid, order = plan["G"], plan["gid"], plan["order"]
+    if plan["groupby"]:
+        for kind in (KIND_ROI, KIND_CONTROL):
+            members = [kind * G + gid[k] for k in order[kind] if not (isinstance(k, str) and k == "all")]
+            if members:
+                a = kind * G + gid["all"]
+                for name in ("sum", "num", "n", "cov_start", "cov_end"):
+                    acc[name][a] = acc[name][members].sum(axis=0)
+    out = {"ROI": {}, "control": {}}
+    for kind, label in ((KIND_ROI, "ROI"), (KIND_CONTROL, "control")):
+        for key in order[kind]:
+            t = kind * G + gid[key]
+            out[label][key] = {"data": acc["sum"][t].copy(), "num": acc["num"][t].copy(), "n": int(acc["n"][t]),
+                               "cov_start": acc["cov_start"][t].copy(), "cov_end": acc["cov_end"][t].copy(),
+                               "horizontal_stripe": [], "vertical_stripe": [], "coordinates": []}
+    return out
+
+
+def _factorize_rows(cols, decoders=None):
+    """Row-wise factorisation of several columns: (codes int64, keys = list of tuples in first-appearance
+    order).  decoders[j], when given, maps the stored value of column j to the value shown in the key."""
+    decoders = decoders or [None] * len(cols)
+    per = [pd.factorize(c, sort=False) for c in cols]
+    radix = 1
+    for _, uniq in per:
+        radix *= len(uniq) + 1
+    if radix < 2 ** 62:
+        combined = np.zeros(len(cols[0]), np.int64)
+        for codes, uniq in per:
+            combined = combined * (len(uniq) + 1) + codes
+    else:   # too many distinct values for a mixed-radix code: factorize tuples
+        combined = pd.factorize(pd.Series(list(zip(*[codes for codes, _ in per]))), sort=False)[0]
+    codes, _ = pd.factorize(combined, sort=False)
+    _, first_rows = np.unique(codes, return_index=True)
+    keys = []
+    for r in first_rows:
+        vals = []
+        for j, (cj, uj) in enumerate(per):
+            v = uj[cj[r]]
+            vals.append(decoders[j](v) if decoders[j] is not None else v)
+        keys.append(tuple(vals))
+    return codes.astype(np.int64), keys
+
+
+def _is_builtin_modify(func):
+    """True for (compositions of) this module's own bin_distance_intervals / flip_mark_intervals_func."""
+    if isinstance(func, partial):
+        if func.func is flip_mark_intervals_func:
+            inner = func.keywords.get("extra_func")
+            return inner is None or _is_builtin_modify(inner)
+        return func.func is bin_distance_intervals
+    return func is bin_distance_intervals
+
+
+def _apply_builtin_modify(tbl, func):
+    """Column-table versions of flip_mark_intervals_func / bin_distance_intervals (no per-row Python objects).
+    Returns (table, decoders): 'distance_band' is stored as the searchsorted id and decoded to the band tuple."""
+    decoders = {}
+    kw = func.keywords if isinstance(func, partial) else {}
+    base = func.func if isinstance(func, partial) else func
+    if base is flip_mark_intervals_func:
+        if kw.get("flip_negative_strand"):
+            tbl["flip"] = tbl["strand1"] == "-"
+        else:
+            fb = kw["flipby"]
+            tbl["flip"] = np.asarray(tbl[f"{fb}1"] > tbl[f"{fb}2"], dtype=bool)
+        inner = kw.get("extra_func")
+        if inner is not None:
+            tbl, decoders = _apply_builtin_modify(tbl, inner)
+        return tbl, decoders
+    edges = kw.get("band_edges", "default")
+    if isinstance(edges, str) and edges == "default":
+        edges = _default_band_edges()
+    tbl["distance_band"] = np.searchsorted(edges, tbl["distance"], side="right")
+    decoders["distance_band"] = lambda i, e=edges: tuple(e[i - 1:i + 1])
+    return tbl, decoders
+
+
+# ------------------------------------------------------------------------------------------------------
+# pileup()
+# ------------------------------------------------------------------------------------------------------
+def pileup(clr, features, features_format="bed", view_df=None, expected_df=None, expected_value_col="balanced.avg",
+           clr_weight_name="weight", flank=100000, minshift=10**5, maxshift=10**6, nshifts=0, ooe=True,
+           mindist="auto", maxdist=None, min_diag=2, subset=0, by_window=False, by_strand=False, by_distance=False,
+           groupby=[], ignore_group_order=False, flip_negative_strand=False, local=False, coverage_norm=False,
+           trans=False, rescale=False, rescale_flank=1, rescale_size=99, store_stripes=False, nproc=1, seed=None):
+    """Create pile-ups — same signature, defaults and returned columns as the reference's ``pileup``
+    (coolpup.py:1922-2279)."""
+    if by_distance is not False:
+        if local:
+            raise ValueError("Can't do local pileups by distance, please specify only one of those arguments")
+        if isinstance(by_distance, np.ndarray):
+            try:
+                distance_edges = [int(i) for i in by_distance]
+            except Exception as e:
+                raise ValueError(
+                    "Distance bin edges have to be an iterable of integers or convertable to integers") from e
+            by_distance = True
+        elif by_distance is True or (isinstance(by_distance, str) and by_distance == "default"):
+            distance_edges = "default"
+            by_distance = True
+        else:
+            raise ValueError("Invalid by_distance value, should be either True, 'default' or a list of integers")
+
+    if not rescale:
+        rescale_flank = None
+    if seed is not None:
+        np.random.seed(seed)
+    if nproc == 0:
+        nproc = -1
+    if view_df is None:
+        view_df = _make_cooler_view(clr)
+    else:
+        try:
+            view_df = _make_viewframe(view_df, clr.chromsizes).reset_index(drop=True)
+            pos = [list(clr.chromnames).index(c) for c in view_df["chrom"]]
+            keyed = list(zip(pos, view_df["start"]))
+            if keyed != sorted(keyed):
+                raise ValueError("view is not sorted by chromosome order and start")
+        except Exception as e:
+            raise ValueError("view_df is not a valid viewframe or incompatible") from e
+    control = nshifts > 0
+    if expected_df is None:
+        expected_value_col = None
+    if mindist is None:
+        mindist = "auto"
+    if maxdist is None:
+        maxdist = np.inf
+    if rescale and rescale_size % 2 == 0:
+        raise ValueError("Please provide an odd rescale_size")
+    chroms = list(view_df["chrom"].unique())
+    if by_window:
+        if features_format != "bed":
+            raise ValueError("Can't make by-window pileups without making combinations")
+        if local:
+            raise ValueError("Can't make local by-window pileups")
+
+    CC = CoordCreator(features=features, resolution=clr.binsize, features_format=features_format, flank=flank,
+                      rescale_flank=rescale_flank, chroms=chroms, minshift=minshift, maxshift=maxshift,
+                      nshifts=nshifts, mindist=mindist, maxdist=maxdist, local=local, subset=subset, seed=seed,
+                      trans=trans)
+    PU = PileUpper(clr=clr, CC=CC, view_df=view_df, clr_weight_name=clr_weight_name, expected=expected_df,
+                   expected_value_col=expected_value_col, ooe=ooe, control=control, coverage_norm=coverage_norm,
+                   rescale=rescale, rescale_size=rescale_size, flip_negative_strand=flip_negative_strand,
+                   ignore_diags=min_diag, store_stripes=store_stripes, nproc=nproc)
+
+    if by_window:
+        pups = PU.pileupsByWindowWithControl()
+        flags = (True, False, False)
+        if groupby:
+            warnings.warn("by-window not compatible with additional groupby")
+    elif by_strand and by_distance:
+        pups = PU.pileupsByStrandByDistanceWithControl(nproc=nproc, distance_edges=distance_edges, groupby=groupby,
+                                                       ignore_group_order=ignore_group_order)
+        flags = (False, True, True)
+    elif by_strand:
+        pups = PU.pileupsByStrandWithControl(groupby=groupby, ignore_group_order=ignore_group_order)
+        flags = (False, True, False)
+    elif by_distance:
+        pups = PU.pileupsByDistanceWithControl(nproc=nproc, distance_edges=distance_edges, groupby=groupby,
+                                               ignore_group_order=ignore_group_order)
+        flags = (False, False, True)
+    else:
+        pups = PU.pileupsWithControl(groupby=groupby, ignore_group_order=ignore_group_order)
+        flags = (False, False, False)
+    pups["by_window"], pups["by_strand"], pups["by_distance"] = flags
+    pups["groupby"] = [groupby] * pups.shape[0]
+    pups["expected"] = pups["expected"].fillna(False)
+    pups["cooler"] = os.path.splitext(os.path.basename(clr.filename))[0]
+    return pups
+
+
+def snippet_batches(cc, clr, control=False, view_df=None):
+    """Engine inputs for an ungrouped pile-up of every view region: (r0, c0, kind) global-bin arrays, regions
+    concatenated in view order.  Host-only (no GPU); used by the benchmark and by the coordinate tests."""
+    pu = PileUpper.__new__(PileUpper)
+    pu.clr = clr
+    pu._aclr = as_array_cooler(clr)
+    pu.CC = cc
+    pu.__dict__.update(cc.__dict__)
+    pu.control = control
+    pu.pad_bins = cc.flank // cc.resolution
+    pu.ignore_group_order = False
+    vd = _make_cooler_view(clr) if view_df is None else _make_viewframe(view_df, clr.chromsizes)
+    pu.view_df = vd.set_index("name")
+    pu._global_extents = {}
+    for name, r in pu.view_df.iterrows():
+        lo, hi = pu._aclr.extent((r["chrom"], r["start"], r["end"]))
+        pu._global_extents[name] = (lo, hi, pu._aclr.offset(r["chrom"]))
+    pu.chroms = natsorted(list(set(cc.final_chroms) & set(clr.chromnames)))
+    pu.view_df = pu.view_df[pu.view_df["chrom"].isin(pu.chroms)]
+    r0s, c0s, ks = [], [], []
+    for region1, region2 in pu._region_pairs():
+        b = pu.region_snippets(region1, region2)
+        if b is not None and b["n"]:
+            r0s.append(b["r0"]); c0s.append(b["c0"]); ks.append(b["kind"])
+    if not r0s:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.int8)
+    return np.concatenate(r0s), np.concatenate(c0s), np.concatenate(ks)

@@ -1,0 +1,93 @@
+"""Multi-GPU plumbing: one process per GPU, regions sharded, one RCCL all-reduce of the packed tiles.
+
+The reference parallelises with ``multiprocessing.Pool`` over regions and merges per-region dicts with
+``reduce(sum_pups)`` on the host (coolpuppy/coolpup.py:1495-1531).  Here each rank piles up its share of
+the regions on its own GPU and the (kind, group) accumulators — additive by construction — are summed
+across ranks with ``torch.distributed.all_reduce`` (backend "nccl" = RCCL over xGMI; "gloo" on CPU for
+tests).  Message: n_tiles*(W*W+2W) float64 + n_tiles*(W*W+1) int64, ~1 MB at most outside by-window mode,
+so the collective is latency-bound and a single flat all-reduce per dtype is the right shape.
+
+torch is imported lazily and only when a process group exists: single-GPU use has no torch dependency.
+"""
+import os
+
+import numpy as np
+
+
+def _dist():
+    try:
+        import torch.distributed as dist
+    except Exception:
+        return None
+    if dist.is_available() and dist.is_initialized():
+        return dist
+    return None
+
+
+def world():
+    d = _dist()
+    return (d.get_rank(), d.get_world_size()) if d is not None else (0, 1)
+
+
+def local_device():
+    """GPU index of this process: COOLPUPPY_AMD_DEVICE, else LOCAL_RANK, else 0."""
+    for var in ("COOLPUPPY_AMD_DEVICE", "LOCAL_RANK"):
+        if os.environ.get(var, "") != "":
+            return int(os.environ[var])
+    return 0
+
+
+def shard(n_units, weights=None, rank=None, world_size=None):
+    """Indices of the units (regions / region pairs) this rank piles up.
+
+    Longest-processing-time assignment on ``weights`` (snippets per unit): deterministic, identical on
+    every rank, no communication.  Returns a set.
+    """
+    if rank is None or world_size is None:
+        rank, world_size = world()
+    if world_size == 1:
+        return set(range(n_units))
+    w = np.ones(n_units) if weights is None else np.asarray(weights, dtype=np.float64)
+    load = np.zeros(world_size)
+    mine = set()
+    for i in np.argsort(-w, kind="stable"):
+        r = int(np.argmin(load))
+        load[r] += w[i]
+        if r == rank:
+            mine.add(int(i))
+    return mine
+
+
+def allreduce_arrays(f64, i64):
+    """Sum a float64 and an int64 numpy array over all ranks (in place where possible); returns both."""
+    d = _dist()
+    if d is None or d.get_world_size() == 1:
+        return f64, i64
+    import torch
+    backend = d.get_backend()
+    dev = torch.device("cuda", local_device()) if backend == "nccl" else torch.device("cpu")
+    tf = torch.from_numpy(np.ascontiguousarray(f64)).to(dev)
+    ti = torch.from_numpy(np.ascontiguousarray(i64)).to(dev)
+    d.all_reduce(tf)
+    d.all_reduce(ti)
+    return tf.cpu().numpy(), ti.cpu().numpy()
+
+
+def allreduce_engine(eng):
+    """All-reduce the engine's packed accumulators across ranks, device to device (no host round trip)."""
+    d = _dist()
+    if d is None or d.get_world_size() == 1:
+        return
+    import torch
+    if d.get_backend() != "nccl":
+        raise RuntimeError("allreduce_engine needs the nccl (RCCL) backend: accumulators live in HBM")
+    nf, ni = eng.packed_sizes()
+    dev = torch.device("cuda", eng.device_id)
+    bf = torch.empty(nf, dtype=torch.float64, device=dev)
+    bi = torch.empty(ni, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize(dev)
+    eng.export_to(bf.data_ptr(), bi.data_ptr())
+    d.all_reduce(bf)
+    d.all_reduce(bi)
+    torch.cuda.synchronize(dev)
+    eng.import_from(bf.data_ptr(), bi.data_ptr())

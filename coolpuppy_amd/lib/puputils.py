@@ -1,0 +1,120 @@
+"""Host-side merge / normalisation of fetched pile-up tiles.
+
+Restates, on whole (kind, group) tiles instead of per-snippet dicts, what the reference does after the
+per-region loops: ``sum_pups`` (coolpuppy/lib/puputils.py:88-113), ``norm_coverage`` (:168-190) and the
+tail of ``PileUpper.pileupsWithControl`` (coolpuppy/coolpup.py:1511-1654).  All of it is O(groups * W^2).
+"""
+import os
+
+import numpy as np
+import pandas as pd
+
+KIND_ROI, KIND_CONTROL = 0, 1
+
+# scalar attributes copied into every output row, in the reference's column order
+# (PileUpper.__dict__ iteration minus its exclude list, coolpup.py:1628-1653)
+_ANNOTATION_ATTRS = [
+    "clr", "resolution", "flank", "rescale_flank", "chroms", "minshift", "maxshift", "nshifts", "trans", "mindist",
+    "maxdist", "local", "subset", "seed", "clr_weight_name", "expected", "expected_value_col", "ooe", "control",
+    "pad_bins", "coverage_norm", "rescale", "rescale_size", "flip_negative_strand", "ignore_diags", "store_stripes",
+    "nproc", "ignore_group_order",
+]
+
+
+def sum_pups(pup1, pup2, extra_funcs={}):
+    """Sum two pile-up dicts (data, num, n, cov_start, cov_end); NaN/inf in data are replaced first,
+    exactly like the reference's ``np.nan_to_num`` (lib/puputils.py:97-98)."""
+    d1, d2 = np.nan_to_num(pup1["data"]), np.nan_to_num(pup2["data"])
+    out = {
+        "data": d1 + d2,
+        "cov_start": pup1["cov_start"] + pup2["cov_start"],
+        "cov_end": pup1["cov_end"] + pup2["cov_end"],
+        "n": pup1.get("n", 1) + pup2.get("n", 1),
+        "num": pup1.get("num", np.isfinite(d1).astype(int)) + pup2.get("num", np.isfinite(d2).astype(int)),
+        "horizontal_stripe": list(pup1.get("horizontal_stripe", [])) + list(pup2.get("horizontal_stripe", [])),
+        "vertical_stripe": list(pup1.get("vertical_stripe", [])) + list(pup2.get("vertical_stripe", [])),
+        "coordinates": list(pup1.get("coordinates", [])) + list(pup2.get("coordinates", [])),
+    }
+    return pd.Series(out)
+
+
+def norm_coverage(snip):
+    """data /= outer(cov_start, cov_end) / nanmean(...) ; NaN -> 0 (reference lib/puputils.py:168-190)."""
+    coverage = np.outer(snip["cov_start"], snip["cov_end"])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        coverage = coverage / np.nanmean(coverage)
+        snip["data"] = snip["data"] / coverage
+    snip["data"][np.isnan(snip["data"])] = 0
+    return snip
+
+
+def _tile_frame(acc, kind, order, contrib, gid, G, grouped):
+    """DataFrame indexed by group key (first-appearance order) with the summed tile of each group."""
+    rows = {}
+    for key in order[kind]:
+        t = kind * G + gid[key]
+        data = acc["sum"][t].copy()
+        # sum_pups() passes data through nan_to_num whenever >= 2 pile-ups are merged: +inf becomes the
+        # largest double (lib/puputils.py:97-98).  A group held by a single region is never merged; the
+        # "all" row of a grouped pile-up always is (coolpup.py:1271-1282).
+        merged = contrib[kind].get(key, 0) >= 2 or (grouped and key == "all" and acc["n"][t] > 0)
+        if merged:
+            data = np.nan_to_num(data)
+        rows[key] = {"data": data, "num": acc["num"][t].copy(), "n": int(acc["n"][t]),
+                     "cov_start": acc["cov_start"][t].copy(), "cov_end": acc["cov_end"][t].copy()}
+    df = pd.DataFrame(list(rows.values()), columns=["data", "num", "n", "cov_start", "cov_end"])
+    df.index = pd.Index(list(rows.keys()), tupleize_cols=False)
+    return df
+
+
+def finalize_pileups(pu, acc, order, contrib, gid, G, groupby, want_control, n_regions):
+    """Tail of pileupsWithControl (coolpup.py:1533-1654) on summed tiles -> annotated DataFrame."""
+    import warnings
+    grouped = bool(groupby)
+    roi = _tile_frame(acc, KIND_ROI, order, contrib, gid, G, grouped)
+    ctrl = _tile_frame(acc, KIND_CONTROL, order, contrib, gid, G, grouped) if want_control else None
+
+    if pu.coverage_norm:
+        roi = roi.apply(norm_coverage, axis=1)
+        if pu.control:
+            ctrl = ctrl.apply(norm_coverage, axis=1)
+        elif pu.expected:
+            warnings.warn("Expected can not be normalized to coverage", stacklevel=2)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        normalized_roi = pd.DataFrame(roi["data"] / roi["num"], columns=["data"])
+        if want_control:
+            normalized_control = pd.DataFrame(ctrl["data"] / ctrl["num"], columns=["data"])
+            normalized_roi = normalized_roi / normalized_control
+            normalized_roi["control_n"] = ctrl["n"]
+            normalized_roi["control_num"] = ctrl["num"]
+    normalized_roi["data"] = normalized_roi["data"].apply(lambda x: np.where(x == np.inf, np.nan, x))
+    normalized_roi["n"] = roi["n"]
+    normalized_roi["num"] = roi["num"]
+
+    if pu.local:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", category=RuntimeWarning)
+            normalized_roi["data"] = normalized_roi["data"].apply(lambda x: np.nanmean(np.dstack((x, x.T)), 2))
+    n = normalized_roi.loc["all", "n"]
+    normalized_roi = normalized_roi.reset_index().rename(columns={"index": "group"})
+    if groupby:
+        normalized_roi[groupby] = pd.DataFrame(
+            [("all",) * len(groupby) if (isinstance(i, str) and i == "all") else i
+             for i in normalized_roi["group"].to_list()],
+            columns=groupby,
+        )
+        for val in groupby:
+            normalized_roi.insert(0, val, normalized_roi.pop(val))
+    import logging
+    logging.getLogger("coolpuppy").info(f"Total number of piled up windows: {int(n)}")
+
+    for name in _ANNOTATION_ATTRS:
+        if not hasattr(pu, name):
+            continue
+        attr = getattr(pu, name)
+        if isinstance(attr, list):
+            attr = str(attr)
+        if name == "clr":
+            attr = os.path.abspath(attr.filename)
+        normalized_roi[name] = attr
+    return normalized_roi

@@ -40,21 +40,34 @@ def _chrom_block(nb, lam, max_log10, rng):
     return row, col, cnt
 
 
+def _chrom_job(args):
+    nb, lam, max_log10, seed = args
+    return _chrom_block(nb, lam, max_log10, np.random.Generator(np.random.PCG64(seed)))
+
+
 def make_cooler(chromsizes, binsize=10_000, lam=120.0, max_log10=3.5, nan_frac=0.02, seed=1000,
-                trans_nnz=0, name="synthetic"):
+                trans_nnz=0, name="synthetic", parallel=False):
     """Build an :class:`ArrayCooler` with ``weight`` (NaN for masked bins) and ``cov_tot_raw`` / ``cov_cis_raw``.
 
     chromsizes: mapping name -> length (bp).  Per-chromosome RNG = PCG64(seed + chrom index).
     trans_nnz > 0 adds that many uniformly placed inter-chromosomal pixels (chrom i < chrom j).
+    parallel=True generates chromosomes in forked worker processes (same result).
     """
     names = list(chromsizes)
     nb = np.array([-(-int(chromsizes[c]) // binsize) for c in names], dtype=np.int64)
     off = np.concatenate([[0], np.cumsum(nb)])
     nbins = int(off[-1])
     rows, cols, cnts = [], [], []
-    for i, _ in enumerate(names):
-        rng = np.random.Generator(np.random.PCG64(seed + i))
-        r, c, k = _chrom_block(int(nb[i]), lam, max_log10, rng)
+    jobs = [(int(nb[i]), lam, max_log10, seed + i) for i in range(len(names))]
+    if parallel and len(jobs) > 1:
+        # one worker per chromosome (fork: call this before any GPU runtime is initialised in the process)
+        import multiprocessing as mp
+        import os
+        with mp.get_context("fork").Pool(min(len(jobs), max(1, (os.cpu_count() or 2) // 2))) as pool:
+            blocks = pool.map(_chrom_job, jobs, chunksize=1)
+    else:
+        blocks = [_chrom_job(j) for j in jobs]
+    for i, (r, c, k) in enumerate(blocks):
         rows.append(r + off[i]); cols.append(c + off[i]); cnts.append(k)
     if trans_nnz > 0:
         rng = np.random.Generator(np.random.PCG64(seed + 10_000))

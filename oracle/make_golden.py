@@ -1,0 +1,337 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE — generate tests/golden/*.npz by running the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference).  The reference's coolpuppy/coolpup.py is imported
+unchanged under the stand-ins of oracle/refshim.py, fed synthetic in-memory coolers, and its own
+``pileup()`` / ``PileUpper`` outputs are recorded together with every input needed to replay them:
+
+    python -m oracle.make_golden            # rewrites tests/golden/
+
+Each scenario file holds: meta (JSON: pileup kwargs, features / view / expected as CSV text, cooler name),
+and the reference's output rows (group keys, data, n, num[, control_n, control_num]).  ``coolers.npz`` holds
+the pixel tables; ``streams.npz`` the reference's window streams (stBin1, stBin2, kind per region) that pin
+the control-shift RNG sequence; ``regions.npz`` raw per-region tiles from the reference's pileup_region.
+Nothing of the reference's source is stored — inputs and outputs only.
+"""
+import io
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+import pandas as pd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from coolpuppy_amd import synth  # noqa: E402
+from coolpuppy_amd.cooler_lite import ArrayCooler  # noqa: E402
+from oracle import refshim  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+REF_TESTS = "/root/reference/tests"
+
+
+# ---------------------------------------------------------------------------------------------------------
+# inputs
+# ---------------------------------------------------------------------------------------------------------
+def small_cooler():
+    return synth.make_cooler({"chrA": 22_000_000, "chrB": 16_000_000, "chrC": 9_500_000}, binsize=10_000,
+                             lam=40, nan_frac=0.03, seed=2024, trans_nnz=30_000, name="small")
+
+
+def toy_cooler():
+    """mm9 chr1/chr2 at 1 Mb — the frame of the reference's own tests (tests/test_coolpup.py)."""
+    return synth.make_cooler({"chr1": 197195432, "chr2": 181748087}, binsize=1_000_000, lam=60, max_log10=2.0,
+                             nan_frac=0.02, seed=77, name="toy_mm9_1Mb")
+
+
+def bedpe_features(clr, n=420, seed=5):
+    rng = np.random.default_rng(seed)
+    df = synth.random_cis_pairs(clr, n, min_sep=150_000, max_sep=3_000_000, seed=seed, strands=True)
+    # windows that leave the chromosome at either end, a negative-distance pair, duplicates, multi-bin anchors
+    extra = pd.DataFrame({
+        "chrom1": ["chrA", "chrA", "chrB", "chrC", "chrA", "chrA"],
+        "start1": [20_000, 21_700_000, 3_000_000, 60_000, 5_000_000, 5_000_000],
+        "end1": [30_000, 21_710_000, 3_010_000, 70_000, 5_030_000, 5_030_000],
+        "chrom2": ["chrA", "chrA", "chrB", "chrC", "chrA", "chrA"],
+        "start2": [900_000, 21_990_000, 1_000_000, 9_400_000, 6_200_000, 6_200_000],
+        "end2": [910_000, 22_000_000, 1_010_000, 9_410_000, 6_215_000, 6_215_000],
+        "strand1": ["+", "-", "+", "-", "+", "+"], "strand2": ["-", "-", "+", "+", "-", "-"],
+    })
+    df = pd.concat([df, extra], ignore_index=True)
+    return df.iloc[rng.permutation(len(df))].reset_index(drop=True)
+
+
+def bed_features(clr, per_chrom=28, seed=9):
+    rng = np.random.default_rng(seed)
+    rows = []
+    for c in clr.chromnames:
+        L = int(clr.chromsizes[c])
+        st = np.sort(rng.integers(0, L - 40_000, per_chrom))
+        ln = rng.integers(200, 30_000, per_chrom)
+        for s, l in zip(st, ln):
+            rows.append((c, int(s), int(s + l), "f", 0, rng.choice(["+", "-"])))
+    return pd.DataFrame(rows, columns=["chrom", "start", "end", "name", "score", "strand"])
+
+
+def trans_bedpe(clr, n=300, seed=12):
+    df = synth.random_trans_pairs(clr, n, seed=seed)
+    # one row in the opposite chromosome order documents the un-swapped-coordinates quirk (coolpup.py:578-585)
+    swapped = pd.DataFrame({"chrom1": ["chrB"], "start1": [2_000_000], "end1": [2_010_000],
+                            "chrom2": ["chrA"], "start2": [7_000_000], "end2": [7_010_000]})
+    return pd.concat([df, swapped], ignore_index=True)
+
+
+def trans_expected(clr, view):
+    rows = []
+    names = list(view["name"])
+    rng = np.random.default_rng(3)
+    for i in range(len(names)):
+        for j in range(i + 1, len(names)):
+            rows.append((names[i], names[j], 1, float(rng.uniform(1e-4, 5e-4))))
+    return pd.DataFrame(rows, columns=["region1", "region2", "n_valid", "balanced.avg"])
+
+
+def csv_text(df):
+    return None if df is None else df.to_csv(index=False)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# scenarios
+# ---------------------------------------------------------------------------------------------------------
+def scenarios():
+    clr = small_cooler()
+    toy = toy_cooler()
+    bedpe = bedpe_features(clr)
+    bed = bed_features(clr)
+    view_sub = pd.DataFrame({"chrom": ["chrA", "chrA", "chrB", "chrC"], "start": [0, 11_000_000, 0, 1_000_000],
+                             "end": [11_000_000, 22_000_000, 16_000_000, 9_500_000],
+                             "name": ["A_left", "A_right", "B", "C_part"]})
+    exp_chrom = synth.cis_expected(clr)
+    # expected for the sub-chromosomal view: per-region vectors cut from the chromosome ones
+    parts = []
+    for _, r in view_sub.iterrows():
+        e = exp_chrom[exp_chrom.region1 == r["chrom"]].copy()
+        nb = -(-(r["end"] - r["start"]) // clr.binsize)
+        e = e.iloc[:nb].copy()
+        e["region1"] = e["region2"] = r["name"]
+        parts.append(e)
+    exp_view = pd.concat(parts, ignore_index=True)
+    exp_zero = exp_chrom.copy()
+    exp_zero.loc[(exp_zero.region1 == "chrA") & (exp_zero.dist == 40), "balanced.avg"] = 0.0   # exp == 0 -> inf
+    view_chrom = pd.DataFrame({"chrom": clr.chromnames, "start": 0,
+                               "end": [int(clr.chromsizes[c]) for c in clr.chromnames], "name": clr.chromnames})
+    tr_exp = trans_expected(clr, view_chrom)
+
+    toy_feat = pd.read_csv(f"{REF_TESTS}/data/toy_features.bed", sep="\t", header=None,
+                           names=["chrom", "start", "end", "name", "score", "strand"])
+    toy_view = pd.read_csv(f"{REF_TESTS}/data/CN.mm9.toy_regions.bed", sep="\t", header=None,
+                           names=["chrom", "start", "end", "name"])
+    toy_exp = pd.read_csv(f"{REF_TESTS}/data/CN.mm9.toy_expected.tsv", sep="\t")
+
+    S = []
+
+    def add(name, cooler, features, view=None, expected=None, **kw):
+        S.append({"name": name, "cooler": cooler, "features": features, "view": view, "expected": expected, "kw": kw})
+
+    base = dict(features_format="bedpe", flank=100_000)
+    add("G1_bedpe_balanced", "small", bedpe, **base)
+    add("G1b_bedpe_view", "small", bedpe, view=view_sub, **base)
+    add("G2_raw_covnorm", "small", bedpe, clr_weight_name=None, coverage_norm="total", **base)
+    add("G2b_raw_covnorm_controls", "small", bedpe, clr_weight_name=None, coverage_norm=True, nshifts=2, seed=3,
+        min_diag=0, **base)
+    add("G3_nshifts3", "small", bedpe, nshifts=3, seed=0, **base)
+    add("G3b_nshifts10_view", "small", bedpe, view=view_sub, nshifts=10, seed=11, minshift=50_000,
+        maxshift=400_000, **base)
+    add("G4_expected_ooe", "small", bedpe, expected=exp_chrom, **base)
+    add("G4b_expected_not_ooe", "small", bedpe, expected=exp_chrom, ooe=False, **base)
+    add("G4c_expected_view_ooe", "small", bedpe, view=view_sub, expected=exp_view, **base)
+    add("G5_local_expected_diag2", "small", bed, features_format="bed", local=True, expected=exp_chrom,
+        flank=100_000)
+    add("G5b_local_diag0", "small", bed, features_format="bed", local=True, min_diag=0, flank=100_000)
+    add("G5c_local_controls", "small", bed, features_format="bed", local=True, nshifts=2, seed=4, flank=50_000)
+    add("G6_by_distance", "small", bedpe, by_distance=True, **base)
+    add("G6b_by_strand", "small", bedpe, by_strand=True, **base)
+    add("G6c_by_strand_distance_controls", "small", bedpe, by_strand=True, by_distance=True, nshifts=2, seed=5,
+        **base)
+    add("G6d_by_distance_edges", "small", bedpe, by_distance=[0, 300_000, 700_000, 1_500_000], mindist=0, **base)
+    add("G6e_groupby_extra", "small", bedpe, groupby=["strand1"], nshifts=1, seed=8, **base)
+    add("G7_trans_bedpe_expected", "small", trans_bedpe(clr), features_format="bedpe", trans=True,
+        expected=tr_exp, flank=250_000)
+    add("G7b_trans_bed_product", "small", bed.groupby("chrom").head(7), features_format="bed", trans=True,
+        flank=100_000)
+    add("G7c_trans_bedpe_controls", "small", trans_bedpe(clr, 120, 13), features_format="bedpe", trans=True,
+        nshifts=2, seed=6, flank=100_000)
+    add("G8_exp_zero_inf", "small", bedpe, expected=exp_zero, **base)
+    add("G8b_pad3_mindist0", "small", bedpe, features_format="bedpe", flank=30_000, mindist=0, maxdist=2_000_000)
+    add("G9_bed_combinations", "small", bed, features_format="bed", flank=100_000, mindist=300_000,
+        maxdist=2_500_000)
+    add("G9b_bed_combinations_controls_strand", "small", bed, features_format="bed", flank=100_000, nshifts=2,
+        seed=9, by_strand=True, maxdist=3_000_000)
+    add("G9c_bed_flip_negative_strand", "small", bed, features_format="bed", flank=100_000,
+        flip_negative_strand=True, by_strand=True, maxdist=3_000_000)
+    add("G9d_bed_ignore_group_order", "small", bed, features_format="bed", flank=100_000, by_strand=True,
+        ignore_group_order=True, flip_negative_strand=True, maxdist=3_000_000)
+    # known-answer tests of the reference's own test-suite (tests/test_coolpup.py), n depends on coordinates only
+    toy_kw = dict(features_format="bed", flank=2_000_000, mindist=0)
+    add("KAT_bystrand_expected_ooe", "toy", toy_feat, view=toy_view, expected=toy_exp, by_strand=True, **toy_kw)
+    add("KAT_bystrand_expected_not_ooe", "toy", toy_feat, view=toy_view, expected=toy_exp, by_strand=True,
+        ooe=False, **toy_kw)
+    add("KAT_bystrand_no_expected", "toy", toy_feat, by_strand=True, **toy_kw)
+    add("KAT_bystrand_covnorm", "toy", toy_feat, by_strand=True, clr_weight_name=None, coverage_norm=True, **toy_kw)
+    add("KAT_bystrand_ignore_group_order", "toy", toy_feat, by_strand=True, ignore_group_order=True, **toy_kw)
+    add("KAT_bystrand_controls", "toy", toy_feat, view=toy_view, by_strand=True, nshifts=10, seed=1, **toy_kw)
+    add("KAT_bystrand_bydistance_controls", "toy", toy_feat, view=toy_view, by_strand=True, by_distance=True,
+        nshifts=1, seed=2, **toy_kw)
+    return {"small": clr, "toy": toy}, S
+
+
+# ---------------------------------------------------------------------------------------------------------
+def key_repr(k):
+    if isinstance(k, str):
+        return k
+    out = []
+    for v in k:
+        if isinstance(v, tuple):
+            out.append([int(x) for x in v])
+        elif isinstance(v, (np.integer, int)):
+            out.append(int(v))
+        else:
+            out.append(str(v))
+    return out
+
+
+def record(df, W):
+    rows = len(df)
+    rec = {
+        "group": json.dumps([key_repr(g) for g in df["group"]]),
+        "data": np.stack([np.asarray(x, float).reshape(W, W) for x in df["data"]]),
+        "n": df["n"].values.astype(np.float64),
+        "num": np.stack([np.asarray(x).reshape(W, W) for x in df["num"]]).astype(np.int64),
+    }
+    if "control_n" in df.columns:
+        rec["control_n"] = df["control_n"].values.astype(np.float64)
+        rec["control_num"] = np.stack([np.asarray(x).reshape(W, W) if np.ndim(x) == 2 else np.full((W, W), -1)
+                                       for x in df["control_num"]]).astype(np.int64)
+    for c in ("orientation", "separation"):
+        if c in df.columns:
+            rec[c] = json.dumps([str(x) for x in df[c]])
+    if "distance_band" in df.columns:
+        rec["distance_band"] = json.dumps([key_repr((b,))[0] if not isinstance(b, str) else b
+                                           for b in df["distance_band"]])
+    scalars = {}
+    for c in df.columns:
+        v = df[c].iloc[0]
+        if isinstance(v, (str, bool, int, float, np.integer, np.floating, np.bool_)) or v is None:
+            scalars[c] = v if not isinstance(v, (np.integer, np.floating, np.bool_)) else v.item()
+    rec["columns"] = json.dumps(list(df.columns))
+    rec["scalars"] = json.dumps(scalars, default=str)
+    assert rec["data"].shape[0] == rows
+    return rec
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    ref = refshim.import_reference()
+    coolers, S = scenarios()
+    # ---- coolers ------------------------------------------------------------------------------------------
+    blob = {}
+    for name, c in coolers.items():
+        blob[f"{name}__chromnames"] = np.array(c.chromnames)
+        blob[f"{name}__chromsizes"] = c.chromsizes.values
+        blob[f"{name}__binsize"] = np.int64(c.binsize)
+        blob[f"{name}__bin1_offset"] = c.bin1_offset
+        blob[f"{name}__bin2_id"] = c.bin2_id.astype(np.int32)
+        blob[f"{name}__count"] = c.count.astype(np.int32)
+        for col in ("weight", "cov_tot_raw", "cov_cis_raw"):
+            blob[f"{name}__{col}"] = c.bins()[col][:].values
+        blob[f"{name}__filename"] = np.array(c.filename)
+    np.savez_compressed(os.path.join(GOLD, "coolers.npz"), **blob)
+
+    streams, index = {}, []
+    for sc in S:
+        clr = refshim.ShimCooler(coolers[sc["cooler"]])
+        kw = dict(sc["kw"])
+        if isinstance(kw.get("by_distance"), list):
+            kw["by_distance"] = np.array(kw["by_distance"])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            df = ref.pileup(clr, sc["features"].copy(), view_df=None if sc["view"] is None else sc["view"].copy(),
+                            expected_df=None if sc["expected"] is None else sc["expected"].copy(), **kw)
+        W = 2 * (kw["flank"] // clr.binsize) + 1
+        rec = record(df, W)
+        meta = {"name": sc["name"], "cooler": sc["cooler"], "kw": sc["kw"], "features": csv_text(sc["features"]),
+                "view": csv_text(sc["view"]), "expected": csv_text(sc["expected"])}
+        rec["meta"] = json.dumps(meta)
+        np.savez_compressed(os.path.join(GOLD, sc["name"] + ".npz"), **rec)
+        index.append(sc["name"])
+        print(f"{sc['name']:45s} rows={len(df):3d} n_all={int(df.loc[df['group'].astype(str) == 'all', 'n'].iloc[0])}")
+
+        # ---- window streams of the reference (pins filtering, ordering and the control-shift RNG) ------------
+        if sc["name"] in ("G3_nshifts3", "G3b_nshifts10_view", "G9b_bed_combinations_controls_strand",
+                          "G7c_trans_bedpe_controls", "G5c_local_controls", "G1_bedpe_balanced",
+                          "G9_bed_combinations", "G7b_trans_bed_product"):
+            kw2 = dict(sc["kw"])
+            seed = kw2.get("seed")
+            if seed is not None:
+                np.random.seed(seed)
+            view = ref.common.make_cooler_view(clr) if sc["view"] is None else sc["view"].copy()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                cc = ref.CoordCreator(sc["features"].copy(), clr.binsize, features_format=kw2["features_format"],
+                                      flank=kw2["flank"], chroms=list(view["chrom"].unique()),
+                                      minshift=kw2.get("minshift", 10**5), maxshift=kw2.get("maxshift", 10**6),
+                                      nshifts=kw2.get("nshifts", 0), mindist=kw2.get("mindist", "auto"),
+                                      maxdist=kw2.get("maxdist", None), local=kw2.get("local", False),
+                                      trans=kw2.get("trans", False), seed=seed)
+                pu = ref.PileUpper(clr, cc, view_df=view, control=kw2.get("nshifts", 0) > 0,
+                                   ignore_diags=kw2.get("min_diag", 2))
+            pairs = []
+            if kw2.get("trans"):
+                import itertools
+                for a, b in itertools.combinations(pu.view_df.index, 2):
+                    if pu.view_df.loc[a, "chrom"] != pu.view_df.loc[b, "chrom"]:
+                        pairs.append((a, b))
+            else:
+                pairs = [(r, r) for r in pu.view_df.index]
+            for r1, r2 in pairs:
+                c1, c2 = pu.view_df.loc[r1], pu.view_df.loc[r2]
+                if cc.kind == "bedpe" and cc.trans:
+                    f1, f2 = cc.filter_func_trans_pairs(region1=c1, region2=c2), None
+                else:
+                    f1 = cc.filter_func_region(region=c1)
+                    f2 = None if r1 == r2 else cc.filter_func_region(region=c2)
+                rows = [r for r in cc.pos_stream(f1, f2, control=pu.control) if r is not None]
+                arr = np.array([[r["stBin1"], r["stBin2"], 0 if r["kind"] == "ROI" else 1] for r in rows],
+                               dtype=np.int64).reshape(-1, 3)
+                streams[f"{sc['name']}|{r1}|{r2}"] = arr
+    np.savez_compressed(os.path.join(GOLD, "streams.npz"), **streams)
+
+    # ---- raw per-region tiles from the reference's pileup_region (un-normalised sums) --------------------------
+    sc = next(s for s in S if s["name"] == "G3_nshifts3")
+    clr = refshim.ShimCooler(coolers["small"])
+    np.random.seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cc = ref.CoordCreator(sc["features"].copy(), clr.binsize, features_format="bedpe", flank=100_000,
+                              chroms=list(clr.chromnames), nshifts=3, seed=0)
+        pu = ref.PileUpper(clr, cc, control=True)
+        regions = {}
+        for r in pu.view_df.index:
+            out = pu.pileup_region(r)
+            for kind in ("ROI", "control"):
+                p = out[kind]["all"]
+                regions[f"{r}|{kind}|data"] = np.nan_to_num(np.asarray(p["data"], float))
+                regions[f"{r}|{kind}|num"] = np.asarray(p["num"]).astype(np.int64)
+                regions[f"{r}|{kind}|n"] = np.int64(p["n"])
+    np.savez_compressed(os.path.join(GOLD, "regions.npz"), **regions)
+    with open(os.path.join(GOLD, "index.json"), "w") as f:
+        json.dump(index, f, indent=0)
+    # the reference's own small test data files (data, not source) used by the KAT scenarios
+    print("wrote", len(index), "scenarios to", GOLD)
+
+
+if __name__ == "__main__":
+    main()

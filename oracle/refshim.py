@@ -1,0 +1,170 @@
+"""TEST INFRASTRUCTURE — stand-ins for the third-party packages the reference imports but this image lacks.
+
+Purpose: let ``/root/reference/coolpuppy/coolpup.py`` (+ ``lib/puputils.py``, ``lib/numutils.py``) be
+imported UNCHANGED in the build container so that its own ``pileup()`` / ``PileUpper`` produce golden
+vectors (oracle/make_golden.py).  Nothing here is product code and nothing here travels as a dependency of
+the product; the reference itself is never copied.
+
+What is substituted (all absent here: cooler, cooltools, bioframe, natsort, more_itertools,
+multiprocessing_logging) and the upstream behaviour each stand-in restates:
+
+* ``cooler.api.Cooler``       -> :class:`ShimCooler` over an in-memory pixel table.  ``matrix(sparse=True,
+  balance=name).fetch(r1, r2)`` returns the region block as scipy COO with BOTH triangles filled for a cis
+  block and value = count * w[bin1] * w[bin2] (NaN where a weight is NaN); ``balance`` falsy -> raw counts.
+  ``extent(region)`` = (offset + start//binsize, offset + ceil(end/binsize)); ``offset(chrom)`` = first bin.
+* ``cooltools.numutils.LazyToeplitz(c, r)``: T[i, j] = c[i-j] for i >= j else r[j-i]; 2-D slice -> dense.
+* ``cooltools.api.snipping.ExpectedSnipper.select(r, r)`` -> LazyToeplitz(expected rows of (r, r) in table order).
+* ``cooltools.lib.common.make_cooler_view``: one whole-chromosome row per chromosome, name = chrom.
+* ``cooltools.lib.checks.is_valid_expected / is_compatible_viewframe``: accept (return True).
+* ``bioframe.make_viewframe``: chrom/start/end/name frame; name defaults to the chromosome.
+* ``natsort.natsorted``, ``more_itertools.collapse(it, base_type=dict)``.
+
+Because these restate third-party behaviour from documentation/knowledge (their source is not on disk),
+parity with a real cooler/cooltools install is UNPINNED; what the goldens pin is everything the
+reference's own code computes downstream of a given (pixel table, weights, expected, coverage) tuple.
+"""
+import re
+import sys
+import types
+
+import numpy as np
+import pandas as pd
+
+from . import pileup_oracle as po
+
+
+# ---------------------------------------------------------------------------------------------------------
+class LazyToeplitz:
+    def __init__(self, c, r=None):
+        self._c = np.asarray(c)
+        self._r = self._c if r is None else np.asarray(r)
+
+    def __getitem__(self, key):
+        si, sj = key
+        i = np.arange(si.start, si.stop)[:, None]
+        j = np.arange(sj.start, sj.stop)[None, :]
+        d = i - j
+        lower = self._c[np.clip(d, 0, len(self._c) - 1)]
+        upper = self._r[np.clip(-d, 0, len(self._r) - 1)]
+        return np.where(d >= 0, lower, upper)
+
+
+class _MatrixSelector:
+    def __init__(self, clr, balance):
+        self._clr, self._balance = clr, balance
+
+    def fetch(self, region1, region2=None):
+        c = self._clr
+        if region2 is None:
+            region2 = region1
+        lo1, hi1 = c.extent(region1)
+        lo2, hi2 = c.extent(region2)
+        w = c.arr.bins()[self._balance][:].values if self._balance else None
+        indptr, col, cnt = c.arr.pixel_table()
+        return po.symmetric_csr(indptr, col, cnt, w, lo1, hi1, lo2, hi2).tocoo()
+
+
+class ShimCooler:
+    """Looks like cooler.Cooler for the calls coolpup.py makes; wraps coolpuppy_amd.cooler_lite.ArrayCooler."""
+
+    def __init__(self, arr):
+        self.arr = arr
+        self.binsize = arr.binsize
+        self.chromsizes = arr.chromsizes
+        self.chromnames = arr.chromnames
+        self.filename = arr.filename
+
+    def offset(self, region):
+        return self.arr.offset(region)
+
+    def extent(self, region):
+        return self.arr.extent(region)
+
+    def bins(self):
+        return self.arr.bins()
+
+    def matrix(self, sparse=True, balance=True, **kw):
+        if balance is True:
+            balance = "weight"
+        return _MatrixSelector(self, balance)
+
+
+class ExpectedSnipper:
+    def __init__(self, clr, expected, view_df=None, min_diag=2, expected_value_col="balanced.avg"):
+        self.clr, self.expected, self.view_df, self.col = clr, expected, view_df, expected_value_col
+
+    def select(self, region1, region2):
+        assert region1 == region2
+        e = self.expected
+        rows = e[(e["region1"] == region1) & (e["region2"] == region2)]
+        return LazyToeplitz(rows[self.col].values)
+
+
+def make_cooler_view(clr):
+    return pd.DataFrame({"chrom": list(clr.chromnames), "start": 0,
+                         "end": [int(clr.chromsizes[c]) for c in clr.chromnames], "name": list(clr.chromnames)})
+
+
+def make_viewframe(view_df, check_bounds=None, **kw):
+    df = pd.DataFrame(view_df).copy()
+    if "chrom" not in df.columns:
+        df.columns = ["chrom", "start", "end", "name"][: df.shape[1]]
+    if "name" not in df.columns:
+        df["name"] = df["chrom"]
+    return df[["chrom", "start", "end", "name"]].reset_index(drop=True)
+
+
+def natsorted(seq):
+    def key(s):
+        return [int(t) if t.isdigit() else t.lower() for t in re.split(r"(\d+)", str(s))]
+    return sorted(seq, key=key)
+
+
+def collapse(iterable, base_type=None, levels=None):
+    def walk(node):
+        if isinstance(node, (str, bytes)) or (base_type is not None and isinstance(node, base_type)):
+            yield node
+            return
+        try:
+            it = iter(node)
+        except TypeError:
+            yield node
+            return
+        for child in it:
+            yield from walk(child)
+    yield from walk(iterable)
+
+
+def install():
+    """Register the stand-ins in sys.modules (idempotent)."""
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    mod("natsort", natsorted=natsorted)
+    mod("more_itertools", collapse=collapse)
+    mod("bioframe", make_viewframe=make_viewframe)
+    api = mod("cooler.api", Cooler=ShimCooler)
+    mod("cooler", api=api, Cooler=ShimCooler)
+    numutils = mod("cooltools.numutils", LazyToeplitz=LazyToeplitz)
+    common = mod("cooltools.lib.common", make_cooler_view=make_cooler_view)
+    checks = mod("cooltools.lib.checks", is_valid_expected=lambda *a, **k: True,
+                 is_compatible_viewframe=lambda *a, **k: True)
+    lib = mod("cooltools.lib", common=common, checks=checks)
+    snipping = mod("cooltools.api.snipping", ExpectedSnipper=ExpectedSnipper)
+    coverage = mod("cooltools.api.coverage")
+    capi = mod("cooltools.api", snipping=snipping, coverage=coverage)
+    mod("cooltools", numutils=numutils, lib=lib, api=capi)
+    mod("multiprocessing_logging", install_mp_handler=lambda: None, uninstall_mp_handler=lambda: None)
+
+
+def import_reference(path="/root/reference"):
+    """Import the reference's coolpup module, unchanged, without writing bytecode into its tree."""
+    install()
+    sys.dont_write_bytecode = True
+    if path not in sys.path:
+        sys.path.insert(0, path)
+    import importlib
+    return importlib.import_module("coolpuppy.coolpup")

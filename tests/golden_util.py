@@ -1,0 +1,102 @@
+"""Helpers shared by the golden-vector tests: rebuild the inputs stored in tests/golden/*.npz, run this
+build's pileup(), compare with what the reference produced (oracle/make_golden.py)."""
+import io
+import json
+import os
+import warnings
+
+import numpy as np
+import pandas as pd
+
+from coolpuppy_amd.cooler_lite import ArrayCooler
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SCENARIOS = json.load(open(os.path.join(GOLD, "index.json")))
+
+_coolers = {}
+
+
+def cooler(name):
+    if name not in _coolers:
+        z = np.load(os.path.join(GOLD, "coolers.npz"))
+        sizes = pd.Series(z[f"{name}__chromsizes"], index=[str(c) for c in z[f"{name}__chromnames"]])
+        _coolers[name] = ArrayCooler(
+            sizes, int(z[f"{name}__binsize"]), z[f"{name}__bin1_offset"], z[f"{name}__bin2_id"], z[f"{name}__count"],
+            bins={c: z[f"{name}__{c}"] for c in ("weight", "cov_tot_raw", "cov_cis_raw")},
+            filename=str(z[f"{name}__filename"]))
+    return _coolers[name]
+
+
+def load(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    meta = json.loads(str(z["meta"]))
+    rd = lambda txt: None if txt is None else pd.read_csv(io.StringIO(txt))   # noqa: E731
+    kw = dict(meta["kw"])
+    if isinstance(kw.get("by_distance"), list):
+        kw["by_distance"] = np.array(kw["by_distance"])
+    return z, meta, rd(meta["features"]), rd(meta["view"]), rd(meta["expected"]), kw
+
+
+def key_repr(k):
+    if isinstance(k, str):
+        return k
+    out = []
+    for v in k:
+        if isinstance(v, tuple):
+            out.append([int(x) for x in v])
+        elif isinstance(v, (np.integer, int)):
+            out.append(int(v))
+        else:
+            out.append(str(v))
+    return out
+
+
+def run(name, pileup_func):
+    z, meta, features, view, expected, kw = load(name)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        df = pileup_func(cooler(meta["cooler"]), features, view_df=view, expected_df=expected, **kw)
+    return z, df
+
+
+def compare(z, df, rtol):
+    want_groups = json.loads(str(z["group"]))
+    got_groups = [key_repr(g) for g in df["group"]]
+    assert got_groups == want_groups, f"group rows/order differ: {got_groups} vs {want_groups}"
+    W = z["data"].shape[1]
+    got = np.stack([np.asarray(x, float).reshape(W, W) for x in df["data"]])
+    np.testing.assert_allclose(got, z["data"], rtol=rtol, atol=0, equal_nan=True)
+    np.testing.assert_array_equal(df["n"].values.astype(float), z["n"])
+    np.testing.assert_array_equal(np.stack([np.asarray(x) for x in df["num"]]), z["num"])
+    if "control_n" in z.files:
+        np.testing.assert_array_equal(df["control_n"].values.astype(float), z["control_n"])
+        got_cn = np.stack([np.asarray(x) if np.ndim(x) == 2 else np.full((W, W), -1) for x in df["control_num"]])
+        np.testing.assert_array_equal(got_cn, z["control_num"])
+    for c in ("orientation", "separation"):
+        if c in z.files:
+            assert [str(x) for x in df[c]] == json.loads(str(z[c])), c
+    assert list(df.columns) == json.loads(str(z["columns"])), "output columns differ from the reference's"
+    scal = json.loads(str(z["scalars"]))
+    for c, v in scal.items():
+        if c in ("clr",):
+            continue
+        g = df[c].iloc[0]
+        g = g.item() if isinstance(g, (np.integer, np.floating, np.bool_)) else g
+        if isinstance(v, float) and np.isnan(v):
+            assert g is None or (isinstance(g, float) and np.isnan(g)), (c, g, v)
+        else:
+            assert str(g) == str(v), f"column {c}: {g!r} != {v!r}"
+
+
+def oracle_run_plan(pu, plan):
+    """Replay a plan (list of engine calls) on the CPU oracle — CPU stand-in for PileUpper.run_plan in tests."""
+    from oracle import pileup_oracle as po
+    indptr, col, cnt = pu._aclr.pixel_table()
+    bins = pu.clr.bins()
+    weight = bins[plan["weight_name"]][:].values if plan["weight_name"] else None
+    cov = bins[plan["cov_name"]][:].values if plan["cov_name"] else None
+    acc = po.empty_acc(plan["T"], plan["pad"])
+    for c in plan["calls"]:
+        po.pileup_c(indptr, col, cnt, weight, cov, c["expected"], c["r0"], c["c0"], c["flip"], c["tile"],
+                    plan["T"], plan["pad"], c["ignore_diags"], c["mode"], acc=acc)
+    return acc

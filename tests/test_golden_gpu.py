@@ -1,0 +1,19 @@
+"""GPU tests: pileup() through the real HIP engine reproduces the reference's outputs (tests/golden)."""
+import pytest
+
+import golden_util as gu
+from coolpuppy_amd import coolpup
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", gu.SCENARIOS)
+def test_reference_golden_on_gpu(name, hip_lib):
+    z, df = gu.run(name, coolpup.pileup)
+    gu.compare(z, df, rtol=1e-6)   # north-star tolerance; integers are compared exactly
+
+
+def test_native_library_is_what_ran(hip_lib):
+    """The HIP shared object is loaded in this process (no silent fallback exists)."""
+    loaded = open("/proc/self/maps").read()
+    assert "libpup_hip.so" in loaded
