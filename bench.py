@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--pad", type=int, default=10)
     ap.add_argument("--lam", type=float, default=4200.0, help="Poisson contacts drawn per row before de-duplication")
     ap.add_argument("--chroms", type=int, default=23, help="use the first K hg38 chromosomes (23 = all)")
-    ap.add_argument("--cpu-sample", type=int, default=150_000, help="snippets timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="snippets timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-cache", action="store_true")
     return ap.parse_args()
 

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Dev tool (run on the GPU box through gpurun): rocprofv3 passes over bench.py.
+#   pass 1: --kernel-trace --stats   -> per-kernel time summary
+#   pass 2..: --pmc <counters>       -> HBM traffic / L2 hit counters (separate passes, as the guide prescribes)
+set -u
+REPO="${GRAFT_REPO_ROOT:-/root/repo}"
+OUT="$REPO/gpurun_out/prof"
+ARGS="${BENCH_ARGS:---steps 5 --warmup 1 --cpu-sample 0}"
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+python "$REPO/bench.py" --steps 1 --warmup 0 --cpu-sample 0 > /dev/null 2>&1   # build the workload cache once
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python "$REPO/bench.py" $ARGS > "$OUT/stats_bench.json" 2> "$OUT/stats.err"
+for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  tag=$(echo "$C" | tr ' ' '_')
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$tag" -- python "$REPO/bench.py" $ARGS > "$OUT/pmc_${tag}_bench.json" 2> "$OUT/pmc_$tag.err"
+done
+find "$OUT" -name "*.csv" | head -50
+du -sh "$OUT"
