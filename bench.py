@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--chroms", type=int, default=23, help="use the first K hg38 chromosomes (23 = all)")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="snippets timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-cache", action="store_true")
+    ap.add_argument("--no-index", action="store_true", help="binary search only (skip the rank-bitmap index)")
     return ap.parse_args()
 
 
@@ -153,6 +154,9 @@ def main():
     eng.load_bins(wl["weight"], None)
     eng.sync()
     t_h2d = time.time() - t_h2d
+    t_idx = time.time()
+    have_index = eng.build_index(wl["chrom_offset"]) if not a.no_index else False
+    t_idx = time.time() - t_idx
     eng.reset(2, a.pad)
     d_r0 = torch.from_numpy(r0).cuda()
     d_c0 = torch.from_numpy(c0).cuda()
@@ -265,7 +269,8 @@ def main():
                 "parallelism": f"snippet-sharded x{a.gpus}, pixel table replicated, RCCL all-reduce of tiles",
             },
             "roofline": roofline, "cpu_baseline": cpu,
-            "h2d_pixel_table_s": round(t_h2d, 3),
+            "h2d_pixel_table_s": round(t_h2d, 3), "rank_bitmap_index": bool(have_index),
+            "index_build_s": round(t_idx, 3),
             "check": {"n": [int(x) for x in out["n"]],
                       "center_roi_over_ctrl": float((out["sum"][0, a.pad, a.pad] / out["num"][0, a.pad, a.pad]) /
                                                     (out["sum"][1, a.pad, a.pad] / out["num"][1, a.pad, a.pad]))},

@@ -50,6 +50,7 @@ _SIGNATURES = {
     "pup_version": (C.c_int, []),
     "pup_device_count": (C.c_int, []),
     "pup_load_pixels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64]),
+    "pup_build_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64]),
     "pup_load_bins": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pup_set_expected": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "pup_reset": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),

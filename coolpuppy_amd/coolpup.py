@@ -520,6 +520,7 @@ def _engine_for(clr, device_id):
         _ENGINES.pop(k)[1].close()
     eng = PileupEngine(device_id)
     eng.load_pixels(*clr.pixel_table())
+    eng.build_index(clr.chrom_offset)      # optional accelerator; False (too large) just means binary search
     _ENGINES[key] = (clr, eng)
     return eng
 

@@ -47,6 +47,12 @@ struct pup_ctx {
     // resident tables
     DevBuf<long long> indptr;
     DevBuf<int2> px;
+    DevBuf<int> cnt32;
+    DevBuf<pup::IdxBlock> idx;
+    DevBuf<pup::IdxChrom> idx_chrom;
+    int n_chrom = 0;
+    bool have_idx = false;
+    long long idx_bytes = 0;
     DevBuf<double> weight, cov, expv;
     bool have_px = false, have_weight = false, have_cov = false;
     long long nbins = 0, nnz = 0, nexp = 0;
@@ -177,7 +183,7 @@ void pup_destroy(pup_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     collect_events(c);
-    c->indptr.release(); c->px.release(); c->weight.release(); c->cov.release(); c->expv.release();
+    c->indptr.release(); c->px.release(); c->cnt32.release(); c->idx.release(); c->idx_chrom.release(); c->weight.release(); c->cov.release(); c->expv.release();
     c->acc_f64.release(); c->acc_i64.release();
     c->d_r0.release(); c->d_c0.release(); c->d_flip.release();
     c->d_chunk_begin.release(); c->d_chunk_end.release(); c->d_seg1.release(); c->d_seg2.release();
@@ -204,9 +210,10 @@ int pup_load_pixels(pup_ctx* c, const int64_t* bin1_offset, const void* bin2_id,
                     (long long)bin1_offset[0], (long long)bin1_offset[nbins], (long long)nnz);
     int rc = bind(c); if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->have_px = false;
+    c->have_px = false; c->have_idx = false;
     HIPCHK(c, c->indptr.reserve((size_t)nbins + 1));
     HIPCHK(c, c->px.reserve((size_t)std::max<int64_t>(nnz, 1)));
+    HIPCHK(c, c->cnt32.reserve((size_t)std::max<int64_t>(nnz, 1)));
     HIPCHK(c, hipMemcpy(c->indptr.p, bin1_offset, ((size_t)nbins + 1) * sizeof(long long), hipMemcpyHostToDevice));
     // stage bin2/count through a bounded device staging area and interleave on device
     const size_t slab = (size_t)1 << 26;   // 64 Mi pixels per slab
@@ -227,10 +234,10 @@ int pup_load_pixels(pup_ctx* c, const int64_t* bin1_offset, const void* bin2_id,
             const int blocks = (int)std::min<size_t>((m + 255) / 256, 65536);
             if (bin2_bytes == 8)
                 hipLaunchKernelGGL(pup::pack_pixels_kernel<long long>, dim3(blocks), dim3(256), 0, c->stream,
-                                   static_cast<const long long*>(d_col), d_cnt, c->px.p + off, (long long)m);
+                                   static_cast<const long long*>(d_col), d_cnt, c->px.p + off, c->cnt32.p + off, (long long)m);
             else
                 hipLaunchKernelGGL(pup::pack_pixels_kernel<int>, dim3(blocks), dim3(256), 0, c->stream,
-                                   static_cast<const int*>(d_col), d_cnt, c->px.p + off, (long long)m);
+                                   static_cast<const int*>(d_col), d_cnt, c->px.p + off, c->cnt32.p + off, (long long)m);
             e = hipGetLastError();
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         }
@@ -241,6 +248,49 @@ int pup_load_pixels(pup_ctx* c, const int64_t* bin1_offset, const void* bin2_id,
     if (status != PUP_OK) return status;
     c->nbins = nbins; c->nnz = nnz; c->have_px = true;
     c->have_weight = c->have_cov = false;
+    return PUP_OK;
+}
+
+int pup_build_index(pup_ctx* c, const int64_t* chrom_offset, int32_t n_chroms, int64_t max_bytes) {
+    if (!c) return PUP_EINVAL;
+    if (!c->have_px) return fail(c, PUP_ESTATE, "pup_build_index: call pup_load_pixels first");
+    if (!chrom_offset || n_chroms <= 0) return fail(c, PUP_EINVAL, "pup_build_index: NULL chrom_offset or n_chroms <= 0");
+    if (chrom_offset[0] != 0 || chrom_offset[n_chroms] != c->nbins)
+        return fail(c, PUP_EINVAL, "pup_build_index: chrom_offset must run from 0 to nbins=%lld", c->nbins);
+    std::vector<pup::IdxChrom> tab((size_t)n_chroms);
+    long long nblocks = 0;
+    for (int k = 0; k < n_chroms; ++k) {
+        const long long lo = chrom_offset[k], hi = chrom_offset[k + 1];
+        if (hi < lo) return fail(c, PUP_EINVAL, "pup_build_index: chrom_offset decreases at %d", k);
+        const long long nb = hi - lo;
+        tab[(size_t)k].start = (int)lo; tab[(size_t)k].end = (int)hi;
+        tab[(size_t)k].nblk = (int)((nb + pup::kIdxCols - 1) / pup::kIdxCols);
+        tab[(size_t)k].pad_ = 0;
+        tab[(size_t)k].blk_base = nblocks;
+        nblocks += nb * tab[(size_t)k].nblk;
+    }
+    const long long bytes = nblocks * (long long)sizeof(pup::IdxBlock);
+    int rc = bind(c); if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_idx = false;
+    if (max_bytes > 0 && bytes > max_bytes)
+        return fail(c, PUP_ENOMEM, "pup_build_index: index needs %lld bytes, limit is %lld", bytes, (long long)max_bytes);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)bytes + ((size_t)1 << 30) > free_b + c->idx.cap * sizeof(pup::IdxBlock))
+        return fail(c, PUP_ENOMEM, "pup_build_index: index needs %lld bytes, only %zu free on the device", bytes, free_b);
+    HIPCHK(c, c->idx.reserve((size_t)std::max<long long>(nblocks, 1)));
+    HIPCHK(c, c->idx_chrom.reserve((size_t)n_chroms));
+    HIPCHK(c, hipMemcpy(c->idx_chrom.p, tab.data(), tab.size() * sizeof(pup::IdxChrom), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemsetAsync(c->idx.p, 0, (size_t)nblocks * sizeof(pup::IdxBlock), c->stream));
+    const int rows_per_block = 4;
+    const unsigned g1 = (unsigned)std::min<long long>((c->nbins + rows_per_block - 1) / rows_per_block, 1 << 20);
+    hipLaunchKernelGGL(pup::index_fill_kernel, dim3(g1), dim3(64 * rows_per_block), 0, c->stream,
+                       c->indptr.p, c->px.p, c->idx_chrom.p, n_chroms, c->idx.p, c->nbins);
+    hipLaunchKernelGGL(pup::index_rank_kernel, dim3((unsigned)((c->nbins + 255) / 256)), dim3(256), 0, c->stream,
+                       c->indptr.p, c->idx_chrom.p, n_chroms, c->idx.p, c->nbins);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->n_chrom = n_chroms; c->have_idx = true; c->idx_bytes = bytes;
     return PUP_OK;
 }
 
@@ -389,7 +439,10 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, const uint8
 
     // ---- K1 ---------------------------------------------------------------------------------------
     pup::K1Args a{};
-    a.indptr = c->indptr.p; a.px = c->px.p;
+    a.indptr = c->indptr.p; a.px = c->px.p; a.cnt32 = c->cnt32.p;
+    const bool use_idx = c->have_idx && c->variant != 1;
+    a.idx = use_idx ? c->idx.p : nullptr; a.idx_chrom = use_idx ? c->idx_chrom.p : nullptr;
+    a.n_chrom = use_idx ? c->n_chrom : 0;
     a.weight = c->have_weight ? c->weight.p : nullptr;
     a.cov = c->have_cov ? c->cov.p : nullptr;
     a.expv = c->nexp > 0 ? c->expv.p : nullptr; a.nexp = c->nexp; a.nbins = c->nbins;

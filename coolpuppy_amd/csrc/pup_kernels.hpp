@@ -6,6 +6,10 @@
 //                           {col,count} run of each row, apply weight outer product / diagonal mask /
 //                           expected, and add into a per-wave LDS tile (sum f64, num u32, cov f64).
 //                           The tile is written out once per chunk as a partial.
+//                           Two ways to find a row's pixels: (a) rank-bitmap index (one 64-B block holds
+//                           the absolute position of its first pixel + 448 presence bits: one cache line
+//                           replaces a ~10-probe binary search, popcounts give every pixel's position),
+//                           built once per table for cis windows; (b) binary search, any window.
 // K2  reduce_partials_kernel deterministic segmented reduction of partial tiles (fixed order), used
 //                           twice (chunks -> slices -> running accumulators).
 //
@@ -22,10 +26,32 @@ namespace pup {
 
 constexpr int kWave = 64;
 
+// ---- rank-bitmap index ---------------------------------------------------------------------------------
+// One 64-byte block covers kIdxCols consecutive columns of one row: pos = absolute index (into the pixel
+// arrays) of the first pixel of the row at or after the block's first column; bits[w] bit b set <=> the
+// row has a pixel at column (block_first_col + 64*w + b).  Row r of chromosome k owns nblk[k] blocks
+// covering that chromosome's columns; only cis pixels are indexed.
+constexpr int kIdxCols = 448;
+struct __attribute__((aligned(64))) IdxBlock {
+    unsigned long long pos;
+    unsigned long long bits[7];
+};
+struct IdxChrom {             // per chromosome (device table, sorted by start)
+    int       start;          // first global bin
+    int       end;            // one past the last global bin
+    int       nblk;           // blocks per row
+    int       pad_;
+    long long blk_base;       // index of the first block of the chromosome's first row
+};
+
 struct K1Args {
     // resident tables
     const long long* indptr;   // [nbins+1]
     const int2*      px;       // [nnz] {col, count}
+    const int*       cnt32;    // [nnz] counts only (indexed path reads 4 B per pixel)
+    const IdxBlock*  idx;      // rank-bitmap index or nullptr
+    const IdxChrom*  idx_chrom;
+    int              n_chrom;
     const double*    weight;   // [nbins] or nullptr (raw)
     const double*    cov;      // [nbins] or nullptr
     const double*    expv;     // [nexp] or nullptr
@@ -62,6 +88,39 @@ __device__ __forceinline__ void lds_add_f64(double* p, double v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// cell of the accumulator a window cell (p, q) lands in: TRANSPOSE first (back to the reference's frame),
+// then the reference's flip = anti-transpose (coolpup.py:128-131)
+__device__ __forceinline__ int map_cell(int p, int q, int W, bool tr, int fl) {
+    int pp = tr ? q : p, qq = tr ? p : q;
+    if (fl) { const int tp = W - 1 - qq; qq = W - 1 - pp; pp = tp; }
+    return pp * W + qq;
+}
+
+// rank-bitmap lookup for one row: position of the first pixel with column >= the window start, and the
+// presence bits of the W (<= 64) window columns.  rel_c = window start column relative to the chromosome.
+__device__ __forceinline__ void idx_lookup(const IdxBlock* __restrict__ rowblk, int nblk, int rel_c, int W,
+                                           long long& pos, unsigned long long& wbits) {
+    const int b  = rel_c / kIdxCols;
+    const int o  = rel_c - b * kIdxCols;
+    const int ws = o >> 6, sh = o & 63;
+    const ulonglong2* q = reinterpret_cast<const ulonglong2*>(rowblk + b);
+    const ulonglong2 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];     // one 64-byte line
+    const unsigned long long w[7] = {v0.y, v1.x, v1.y, v2.x, v2.y, v3.x, v3.y};
+    unsigned long long rank = 0, cur = 0, nxt = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        rank += (k < ws) ? (unsigned long long)__popcll(w[k]) : 0ull;
+        cur = (k == ws) ? w[k] : cur;
+        nxt = (k == ws + 1) ? w[k] : nxt;
+    }
+    if (ws == 6 && sh + W > 64 && b + 1 < nblk) nxt = rowblk[b + 1].bits[0];   // window crosses into the next block
+    rank += (unsigned long long)__popcll(cur & ((1ull << sh) - 1ull));
+    unsigned long long bits = cur >> sh;
+    if (sh) bits |= nxt << (64 - sh);
+    wbits = (W < 64) ? (bits & ((1ull << W) - 1ull)) : bits;
+    pos = (long long)(v0.x + rank);
+}
+
 template <int WT>
 __global__ __launch_bounds__(kWave) void pileup_chunk_kernel(K1Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -76,7 +135,8 @@ __global__ __launch_bounds__(kWave) void pileup_chunk_kernel(K1Args a) {
     double*    wc   = wr + W;
     double*    ex   = wc + W;                       // 2W slots (2W-1 used)
     long long* st   = reinterpret_cast<long long*>(ex + 2 * W);
-    long long* hi   = st + W;
+    long long* hi   = st + W;                       // search path: row end; indexed path: window bits
+    unsigned long long* wbv = reinterpret_cast<unsigned long long*>(hi);
     unsigned*  tnum = reinterpret_cast<unsigned*>(hi + W);
 
     const bool m_ooe   = a.mode & 0x01u;
@@ -85,6 +145,7 @@ __global__ __launch_bounds__(kWave) void pileup_chunk_kernel(K1Args a) {
     const bool m_tr    = a.mode & 0x08u;
     const bool use_exp = (m_ooe || m_exp) && a.expv != nullptr && a.nexp > 0;
     const int  igd     = a.ignore_diags;
+    const bool have_idx = a.idx != nullptr && W <= 64;
 
     for (int t = lane; t < W2; t += kWave) { tsum[t] = 0.0; tnum[t] = 0u; }
     for (int t = lane; t < 2 * W; t += kWave) covs[t] = 0.0;   // covs and cove are contiguous
@@ -93,6 +154,8 @@ __global__ __launch_bounds__(kWave) void pileup_chunk_kernel(K1Args a) {
     const long long cb = a.chunk_begin[blockIdx.x];
     const long long ce = a.chunk_end[blockIdx.x];
     unsigned long long npix = 0, nprobe = 0;
+    // chromosome of the previous snippet (snippets arrive sorted: the lookup is almost always a hit)
+    int ch_start = 0, ch_end = -1, ch_nblk = 0; long long ch_base = 0;
 
     for (long long s = cb; s < ce; ++s) {
         const int r0s = __builtin_amdgcn_readfirstlane(a.r0[s]);
@@ -102,20 +165,39 @@ __global__ __launch_bounds__(kWave) void pileup_chunk_kernel(K1Args a) {
             if (lane == 0) atomicExch(a.err, 1);
             continue;   // wave-uniform
         }
-        // ---- phase A: per-row search + per-snippet vectors ------------------------------------
+        // indexed path only when rows and columns of the window lie in ONE chromosome (cis window)
+        bool indexed = false;
+        if (have_idx && !m_exp) {
+            if (!(r0s >= ch_start && r0s < ch_end)) {          // wave-uniform re-lookup
+                int lo = 0, hi_k = a.n_chrom;
+                while (lo < hi_k) { const int m = (lo + hi_k) >> 1; if (a.idx_chrom[m].end <= r0s) lo = m + 1; else hi_k = m; }
+                if (lo < a.n_chrom) {
+                    const IdxChrom c = a.idx_chrom[lo];
+                    ch_start = c.start; ch_end = c.end; ch_nblk = c.nblk; ch_base = c.blk_base;
+                } else { ch_start = 0; ch_end = -1; }
+            }
+            indexed = r0s >= ch_start && r0s + W <= ch_end && c0s >= ch_start && c0s + W <= ch_end;
+        }
+        // ---- phase A: locate each row's pixels + per-snippet vectors -----------------------------
         if (!m_exp) {
             for (int p = lane; p < W; p += kWave) {
                 const int r = r0s + p;
-                long long lo = a.indptr[r];
-                const long long h = a.indptr[r + 1];
-                long long b = h;
-                while (lo < b) {                       // lower_bound(col >= c0s)
-                    const long long m = (lo + b) >> 1;
-                    if (a.px[m].x < c0s) lo = m + 1; else b = m;
-                    ++nprobe;
+                if (indexed) {
+                    const IdxBlock* rowblk = a.idx + ch_base + (long long)(r - ch_start) * ch_nblk;
+                    long long pos; unsigned long long bits;
+                    idx_lookup(rowblk, ch_nblk, c0s - ch_start, W, pos, bits);
+                    st[p] = pos; wbv[p] = bits;
+                } else {
+                    long long lo = a.indptr[r];
+                    const long long h = a.indptr[r + 1];
+                    long long b = h;
+                    while (lo < b) {                       // lower_bound(col >= c0s)
+                        const long long m = (lo + b) >> 1;
+                        if (a.px[m].x < c0s) lo = m + 1; else b = m;
+                        ++nprobe;
+                    }
+                    st[p] = lo; hi[p] = h;
                 }
-                st[p] = lo;
-                hi[p] = h;
                 wr[p] = a.weight ? a.weight[r] : 1.0;
                 wc[p] = a.weight ? a.weight[c0s + p] : 1.0;
                 if (m_cov) {
@@ -139,16 +221,14 @@ __global__ __launch_bounds__(kWave) void pileup_chunk_kernel(K1Args a) {
             }
         }
         __syncthreads();
-        // ---- phase B: slots (p, j) = cell (p, q=j) for num, j-th pixel of row p for sum -----------
+        // ---- phase B: lanes = window cells --------------------------------------------------------
         for (int t = lane; t < W2; t += kWave) {
             const int p = t / W;
             const int j = t - p * W;
             if (m_exp) {
                 // expected-as-control: the Toeplitz window itself, no masks (coolpup.py:1135-1139)
                 const double e = use_exp ? ex[j - p + W - 1] : __builtin_nan("");
-                int pp = m_tr ? j : p, qq = m_tr ? p : j;
-                if (fl) { const int tp = W - 1 - qq; qq = W - 1 - pp; pp = tp; }
-                const int cell = pp * W + qq;
+                const int cell = map_cell(p, j, W, m_tr, fl);
                 if (e == e) {
                     lds_add_f64(&tsum[cell], e);
                     if (!__builtin_isinf(e)) atomicAdd(&tnum[cell], 1u);
@@ -156,32 +236,39 @@ __global__ __launch_bounds__(kWave) void pileup_chunk_kernel(K1Args a) {
                 continue;
             }
             const double wrp = wr[p];
-            {   // validity of cell (p, j): masks only, independent of the pixel table
-                const double wcq = wc[j];
-                const int d = (c0s + j) - (r0s + p);
-                bool ok = (wrp == wrp) && (wcq == wcq) && (igd < 0 || d >= igd);
-                if (m_ooe) { const double e = use_exp ? ex[j - p + W - 1] : __builtin_nan("");
-                             ok = ok && (e == e) && (e != 0.0); }
-                if (ok) {
-                    int pp = m_tr ? j : p, qq = m_tr ? p : j;
-                    if (fl) { const int tp = W - 1 - qq; qq = W - 1 - pp; pp = tp; }
-                    atomicAdd(&tnum[pp * W + qq], 1u);
-                }
-            }
-            const long long pos = st[p] + j;
-            if (pos < hi[p]) {
-                const int2 e2 = a.px[pos];
-                const int q = e2.x - c0s;              // >= 0 by lower_bound
-                if (q < W) {
+            const double wcj = wc[j];
+            const int dj = (c0s + j) - (r0s + p);
+            // validity of cell (p, j): masks only, independent of the pixel table
+            bool ok = (wrp == wrp) && (wcj == wcj) && (igd < 0 || dj >= igd);
+            double ej = 1.0;
+            if (m_ooe) { ej = use_exp ? ex[j - p + W - 1] : __builtin_nan(""); ok = ok && (ej == ej) && (ej != 0.0); }
+            const int cell = map_cell(p, j, W, m_tr, fl);
+            if (ok) atomicAdd(&tnum[cell], 1u);
+            if (indexed) {
+                // cell (p, j) holds a pixel iff bit j of the row's window bits is set; its position in the
+                // pixel arrays is the row's start + the number of set bits below j
+                const unsigned long long bits = wbv[p];
+                if ((bits >> j) & 1ull) {
                     ++npix;
-                    double val = (double)e2.y * wrp * wc[q];
-                    const int d = (c0s + q) - (r0s + p);
-                    bool ok = (val == val) && (igd < 0 || d >= igd);
-                    if (m_ooe) { val = val / (use_exp ? ex[q - p + W - 1] : __builtin_nan("")); ok = ok && (val == val); }
-                    if (ok) {
-                        int pp = m_tr ? q : p, qq = m_tr ? p : q;
-                        if (fl) { const int tp = W - 1 - qq; qq = W - 1 - pp; pp = tp; }
-                        lds_add_f64(&tsum[pp * W + qq], val);
+                    const long long pos = st[p] + __popcll(bits & ((1ull << j) - 1ull));
+                    double val = (double)a.cnt32[pos] * wrp * wcj;
+                    bool okv = (val == val) && (igd < 0 || dj >= igd);
+                    if (m_ooe) { val = val / ej; okv = okv && (val == val); }
+                    if (okv) lds_add_f64(&tsum[cell], val);
+                }
+            } else {
+                // j-th pixel of row p at or after the window start
+                const long long pos = st[p] + j;
+                if (pos < hi[p]) {
+                    const int2 e2 = a.px[pos];
+                    const int q = e2.x - c0s;              // >= 0 by lower_bound
+                    if (q < W) {
+                        ++npix;
+                        double val = (double)e2.y * wrp * wc[q];
+                        const int d = (c0s + q) - (r0s + p);
+                        bool okv = (val == val) && (igd < 0 || d >= igd);
+                        if (m_ooe) { val = val / (use_exp ? ex[q - p + W - 1] : __builtin_nan("")); okv = okv && (val == val); }
+                        if (okv) lds_add_f64(&tsum[map_cell(p, q, W, m_tr, fl)], val);
                     }
                 }
             }
@@ -203,6 +290,52 @@ __global__ __launch_bounds__(kWave) void pileup_chunk_kernel(K1Args a) {
     if (lane == 0 && a.counters) {
         atomicAdd(&a.counters[0], npix);
         atomicAdd(&a.counters[1], nprobe);
+    }
+}
+
+// ---- index construction (once per pixel table) ---------------------------------------------------------
+// one wave per row: set the presence bit of every cis pixel of the row
+__global__ __launch_bounds__(256) void index_fill_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
+                                                         const IdxChrom* __restrict__ chroms, int n_chrom,
+                                                         IdxBlock* __restrict__ idx, long long nbins) {
+    const int lane = threadIdx.x & 63;
+    long long r = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long stride = (long long)gridDim.x * (blockDim.x >> 6);
+    for (; r < nbins; r += stride) {
+        int lo = 0, hi = n_chrom;
+        while (lo < hi) { const int m = (lo + hi) >> 1; if (chroms[m].end <= r) lo = m + 1; else hi = m; }
+        if (lo >= n_chrom) continue;
+        const IdxChrom c = chroms[lo];
+        if (r < c.start) continue;
+        unsigned long long* rowbits = reinterpret_cast<unsigned long long*>(idx + c.blk_base + (r - c.start) * c.nblk);
+        const long long b = indptr[r], e = indptr[r + 1];
+        for (long long k = b + lane; k < e; k += 64) {
+            const int col = px[k].x;
+            if (col >= c.end) continue;              // trans pixel: not indexed
+            const int rel = col - c.start;
+            const int blk = rel / kIdxCols, o = rel - blk * kIdxCols;
+            atomicOr(rowbits + (size_t)blk * 8 + 1 + (o >> 6), 1ull << (o & 63));
+        }
+    }
+}
+
+// one thread per row: absolute position of each block's first pixel (running popcount)
+__global__ __launch_bounds__(256) void index_rank_kernel(const long long* __restrict__ indptr,
+                                                         const IdxChrom* __restrict__ chroms, int n_chrom,
+                                                         IdxBlock* __restrict__ idx, long long nbins) {
+    long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nbins) return;
+    int lo = 0, hi = n_chrom;
+    while (lo < hi) { const int m = (lo + hi) >> 1; if (chroms[m].end <= r) lo = m + 1; else hi = m; }
+    if (lo >= n_chrom) return;
+    const IdxChrom c = chroms[lo];
+    if (r < c.start) return;
+    IdxBlock* row = idx + c.blk_base + (r - c.start) * c.nblk;
+    unsigned long long pos = (unsigned long long)indptr[r];
+    for (int b = 0; b < c.nblk; ++b) {
+        row[b].pos = pos;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) pos += (unsigned long long)__popcll(row[b].bits[k]);
     }
 }
 
@@ -242,10 +375,10 @@ __global__ void add_counts_kernel(long long* n, const long long* dn, int T) {
 // interleave bin2/count into {col,count} pairs (upload helper), 64-bit or 32-bit column ids
 template <typename ColT>
 __global__ void pack_pixels_kernel(const ColT* __restrict__ col, const int* __restrict__ cnt,
-                                   int2* __restrict__ out, long long n) {
+                                   int2* __restrict__ out, int* __restrict__ out_cnt, long long n) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) out[i] = make_int2((int)col[i], cnt[i]);
+    for (; i < n; i += stride) { const int c = cnt[i]; out[i] = make_int2((int)col[i], c); out_cnt[i] = c; }
 }
 
 }  // namespace pup

@@ -83,6 +83,16 @@ class PileupEngine:
                                               _ptr(count), nbins, nnz))
         self.nbins, self.nnz = nbins, nnz
 
+    def build_index(self, chrom_offset, max_bytes=0):
+        """Rank-bitmap index over the cis part of the table (chrom_offset = the cooler's indexes/chrom_offset).
+        Returns True when built, False when it does not fit (the engine then keeps using binary search)."""
+        co = _as(chrom_offset, np.int64)
+        rc = self._lib.pup_build_index(self._h, _ptr(co), co.shape[0] - 1, int(max_bytes))
+        if rc == -2:          # PUP_ENOMEM: optional structure, not an error for the caller
+            return False
+        self._check(rc)
+        return True
+
     def load_bins(self, weight=None, cov=None):
         """Per-bin float64 vectors: balancing weights (NaN = masked; None = raw) and coverage (None = unused)."""
         w = None if weight is None else _as(weight, np.float64)

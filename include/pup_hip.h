@@ -9,6 +9,9 @@
  *
  *   pup_load_pixels / pup_load_bins   <- PileUpper.get_data            coolpuppy/coolpup.py:1024-1057
  *                                        + weight / coverage columns   coolpuppy/coolpup.py:1081-1098
+ *   pup_build_index                   <- (no counterpart: device-side search structure over the same table;
+ *                                        chromosome partition = cooler's indexes/chrom_offset, the extents the
+ *                                        reference takes from clr.extent / clr.offset,     coolpuppy/coolpup.py:922-925)
  *   pup_set_expected                  <- expected_selections / get_expected_trans
  *                                                                      coolpuppy/coolpup.py:907-916, 999-1005
  *   pup_reset                         <- make_outmap / empty_pup       coolpuppy/coolpup.py:986-997, 1007-1022
@@ -86,6 +89,17 @@ int pup_load_pixels(pup_ctx* ctx, const int64_t* bin1_offset, const void* bin2_i
  */
 int pup_load_bins(pup_ctx* ctx, const double* weight, const double* cov);
 /*
+ * Optional accelerator: build a rank-bitmap index over the cis part of the loaded table (one 64-byte block
+ * per 448 columns per row: first-pixel position + presence bits).  chrom_offset = indexes/chrom_offset
+ * (int64[n_chroms+1], chrom_offset[0] == 0, chrom_offset[n_chroms] == nbins).  Windows whose rows and columns
+ * lie inside one chromosome then cost one cache line per row instead of a binary search; all other windows
+ * (trans) keep using the binary search.  Memory: sum_k nb_k * ceil(nb_k/448) * 64 bytes; returns PUP_ENOMEM
+ * (and leaves the engine usable without index) when that exceeds max_bytes (0 = no limit).
+ * Results never depend on whether the index exists.
+ */
+int pup_build_index(pup_ctx* ctx, const int64_t* chrom_offset, int32_t n_chroms, int64_t max_bytes);
+
+/*
  * Expected for the region (pair) the next pup_accumulate calls belong to.
  *   n >= 2 : cis, by-diagonal vector, value for a cell = expected[|col - row|]
  *   n == 1 : trans, one scalar for the whole block
@@ -147,7 +161,7 @@ int pup_clear_stats(pup_ctx* ctx);
 /* generic stream timer: record slot (0..7) on the context's stream; elapsed between two slots */
 int pup_event_record(pup_ctx* ctx, int slot);
 int pup_event_elapsed_ms(pup_ctx* ctx, int slot_begin, int slot_end, float* ms);
-/* tuning knobs (0 = library default): snippets per chunk and kernel variant */
+/* tuning knobs (0 = library default): snippets per chunk; variant 1 = ignore the index (binary search only) */
 int pup_set_tuning(pup_ctx* ctx, int32_t chunk_snippets, int32_t variant);
 
 #ifdef __cplusplus

@@ -16,11 +16,16 @@ def small_clr():
                              trans_nnz=40_000)
 
 
-@pytest.fixture(scope="module")
-def engine(hip_lib, small_clr):
+@pytest.fixture(scope="module", params=["indexed", "search"])
+def engine(hip_lib, small_clr, request):
+    """Both ways of locating a row's pixels must give identical results: the rank-bitmap index
+    (cis windows) and the binary search (index ignored: variant 1)."""
     from coolpuppy_amd.engine import PileupEngine
     eng = PileupEngine(0)
     eng.load_pixels(*small_clr.pixel_table())
+    assert eng.build_index(small_clr.chrom_offset)
+    eng._variant = 1 if request.param == "search" else 0
+    eng.set_tuning(0, eng._variant)
     yield eng
     eng.close()
 
@@ -133,13 +138,13 @@ def test_many_chunks_two_level_reduction(engine, small_clr, oracle_mod):
     engine.set_expected(None)
     outs = []
     for chunk in (1, 7, 16, 0):
-        engine.set_tuning(chunk_snippets=chunk)
+        engine.set_tuning(chunk, engine._variant)
         engine.reset(T, pad)
         engine.accumulate(r0, c0, tile_ptr, ignore_diags=2, mode=0)
         got = engine.fetch()
         _compare(got, want)
         outs.append(got["sum"].copy())
-    engine.set_tuning(0)
+    engine.set_tuning(0, engine._variant)
     # determinism: same chunking twice -> bit-identical sums
     engine.reset(T, pad)
     engine.accumulate(r0, c0, tile_ptr, ignore_diags=2, mode=0)
@@ -163,3 +168,63 @@ def test_errors_are_loud(engine, small_clr):
     engine.fetch()                         # error state cleared
     with pytest.raises(PupError):          # window too large for LDS
         engine.reset(1, 400)
+
+
+def test_index_block_boundaries(engine, small_clr, oracle_mod):
+    """Windows starting at every column phase around the 448-column index block edges and 64-bit word edges."""
+    po = oracle_mod
+    clr = small_clr
+    indptr, col, cnt = clr.pixel_table()
+    w = clr.bins()["weight"][:].values
+    lo, hi = clr.extent("chrA")
+    pad, T = 10, 1
+    W = 2 * pad + 1
+    starts = []
+    for edge in (448, 896, 1344, 64, 128, 448 + 384):
+        for d in range(-W - 2, 3):
+            starts.append(edge + d)
+    c0 = np.array(sorted(set(s for s in starts if s >= 0)), np.int64) + lo
+    r0 = np.maximum(c0 - 30, lo)
+    r0 = np.concatenate([r0, c0])            # also on-diagonal windows
+    c0 = np.concatenate([c0, c0])
+    ok = (c0 + W <= hi) & (r0 + W <= hi)
+    r0, c0 = r0[ok].astype(np.int32), c0[ok].astype(np.int32)
+    tile = np.zeros(len(r0), np.int32)
+    tile_ptr = np.array([0, len(r0)], np.int64)
+    want = po.pileup_c(indptr, col, cnt, w, None, None, r0, c0, None, tile, T, pad, 0, 0)
+    engine.load_bins(w, None)
+    engine.set_expected(None)
+    engine.reset(T, pad)
+    engine.accumulate(r0, c0, tile_ptr, ignore_diags=0, mode=0)
+    _compare(engine.fetch(), want)
+    # W = 64: the widest window the index serves (pad 31 is not expressible -> use per-snippet check at pad=31: W=63)
+    pad = 31
+    W = 2 * pad + 1
+    r0b = np.arange(lo, lo + 700, 7, dtype=np.int32)
+    c0b = (r0b + 385).astype(np.int32)
+    want = po.pileup_c(indptr, col, cnt, w, None, None, r0b, c0b, None, np.zeros(len(r0b), np.int32), 1, pad, 2, 0)
+    engine.reset(1, pad)
+    engine.accumulate(r0b, c0b, np.array([0, len(r0b)], np.int64), ignore_diags=2, mode=0)
+    _compare(engine.fetch(), want)
+
+
+def test_cis_windows_near_chromosome_ends_and_trans_fallback(engine, small_clr, oracle_mod):
+    """Windows touching the last bins of a chromosome (index tail block) and windows whose columns sit in
+    another chromosome (must take the search path even when the index exists)."""
+    po = oracle_mod
+    clr = small_clr
+    indptr, col, cnt = clr.pixel_table()
+    w = clr.bins()["weight"][:].values
+    pad = 10
+    W = 21
+    loA, hiA = clr.extent("chrA")
+    loB, hiB = clr.extent("chrB")
+    r0 = np.array([hiA - W, hiA - W - 1, hiA - W, loA, hiA - W - 5, hiA - 30], np.int32)
+    c0 = np.array([hiA - W, hiA - W, hiA - W - 3, loA, loB, loB + 2], np.int32)   # last two: trans windows
+    tile = np.zeros(len(r0), np.int32)
+    want = po.pileup_c(indptr, col, cnt, w, None, None, r0, c0, None, tile, 1, pad, -1, 0)
+    engine.load_bins(w, None)
+    engine.set_expected(None)
+    engine.reset(1, pad)
+    engine.accumulate(r0, c0, np.array([0, len(r0)], np.int64), ignore_diags=-1, mode=0)
+    _compare(engine.fetch(), want)

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--sort", type=int, default=1)
+    ap.add_argument("--variant", type=int, default=0, help="1 = ignore the rank-bitmap index")
     a = ap.parse_args()
     names = list(synth.HG38)[: a.chroms]
     t = time.time()
@@ -51,9 +52,10 @@ def main():
     print(f"snippets: {len(r)}", flush=True)
     eng = PileupEngine(0)
     t = time.time(); eng.load_pixels(*clr.pixel_table()); print(f"H2D pixels {time.time()-t:.2f}s")
+    t = time.time(); ok = eng.build_index(clr.chrom_offset); print(f"index built={ok} {time.time()-t:.3f}s")
     eng.load_bins(clr.bins()["weight"][:].values, None)
     eng.set_profiling(True)
-    eng.set_tuning(a.chunk)
+    eng.set_tuning(a.chunk, a.variant)
     eng.reset(2, a.pad)
     for rep in range(a.reps):
         eng.clear_stats()
