@@ -54,7 +54,7 @@ _SIGNATURES = {
     "pup_load_bins": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pup_set_expected": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "pup_reset": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
-    "pup_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+    "pup_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                  C.c_int32, C.c_uint32]),
     "pup_sync": (C.c_int, [C.c_void_p]),
     "pup_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -851,8 +851,8 @@ class PileUpper:
             if i not in mine:
                 continue
             eng.set_expected(c["expected"])
-            eng.accumulate(c["r0"], c["c0"], c["tile_ptr"], flip=c["flip"], ignore_diags=c["ignore_diags"],
-                           mode=c["mode"])
+            eng.accumulate(c["r0"], c["c0"], c["tile_ptr"], flip_from=c["flip_from"],
+                           ignore_diags=c["ignore_diags"], mode=c["mode"])
         _dist.allreduce_engine(eng)
         return eng.fetch()
 
@@ -966,15 +966,22 @@ class PileUpper:
 
 
 def _engine_call(region1, region2, expected, r0, c0, flip, tile, T, igd, mode):
-    """One pup_accumulate call: snippets grouped by tile (stable: genome order is kept inside a tile)."""
-    if len(tile) > 1 and not np.all(tile[1:] >= tile[:-1]):
-        o = np.argsort(tile, kind="stable")
+    """One pup_accumulate call: snippets grouped by (tile, flip) — stable, so genome order is kept inside a
+    group; within a tile the anti-transposed snippets come last (flip_from marks where they start)."""
+    flip = np.zeros(len(tile), bool) if flip is None else np.asarray(flip, bool)
+    key = tile.astype(np.int64) * 2 + flip
+    if len(key) > 1 and not np.all(key[1:] >= key[:-1]):
+        o = np.argsort(key, kind="stable")
         r0, c0, flip, tile = r0[o], c0[o], flip[o], tile[o]
     tile_ptr = np.concatenate([[0], np.cumsum(np.bincount(tile, minlength=T))]).astype(np.int64)
+    flip_from = None
+    if flip.any():
+        flip_from = tile_ptr[1:] - np.bincount(tile[flip], minlength=T)
     return {"region1": region1, "region2": region2, "expected": expected,
             "r0": np.ascontiguousarray(r0, np.int32), "c0": np.ascontiguousarray(c0, np.int32),
-            "flip": np.ascontiguousarray(flip, np.uint8) if flip is not None and flip.any() else None,
-            "tile": np.ascontiguousarray(tile, np.int32), "tile_ptr": tile_ptr, "ignore_diags": igd, "mode": mode}
+            "flip": np.ascontiguousarray(flip, np.uint8) if flip_from is not None else None,
+            "flip_from": flip_from, "tile": np.ascontiguousarray(tile, np.int32), "tile_ptr": tile_ptr,
+            "ignore_diags": igd, "mode": mode}
 
 
 def _tiles_to_pups(plan, acc):

@@ -62,7 +62,7 @@ struct pup_ctx {
     int T = 0, pad = 0, W = 0;
     // workspaces
     DevBuf<int> d_r0, d_c0;
-    DevBuf<unsigned char> d_flip;
+    DevBuf<unsigned char> d_chunk_flip;
     DevBuf<long long> d_chunk_begin, d_chunk_end, d_seg1, d_seg2, d_dn;
     DevBuf<double> part_f64, slice_f64;
     DevBuf<unsigned> part_num;
@@ -127,6 +127,33 @@ void launch_k1(const pup::K1Args& a, int nchunks, size_t lds, hipStream_t s) {
     hipLaunchKernelGGL(pup::pileup_chunk_kernel<WT>, dim3(nchunks), dim3(pup::kWave), lds, s, a);
 }
 
+template <int W>
+void launch_k1r(const pup::K1Args& a, int nchunks, hipStream_t s) {
+    hipLaunchKernelGGL(pup::pileup_regtile_kernel<W>, dim3(nchunks), dim3(pup::kWave), 0, s, a);
+}
+
+// window widths the register-tile kernel is instantiated for (pad 1..15 -> W = 3..31)
+bool launch_regtile(int W, const pup::K1Args& a, int nchunks, hipStream_t s) {
+    switch (W) {
+        case 3:  launch_k1r<3>(a, nchunks, s);  return true;
+        case 5:  launch_k1r<5>(a, nchunks, s);  return true;
+        case 7:  launch_k1r<7>(a, nchunks, s);  return true;
+        case 9:  launch_k1r<9>(a, nchunks, s);  return true;
+        case 11: launch_k1r<11>(a, nchunks, s); return true;
+        case 13: launch_k1r<13>(a, nchunks, s); return true;
+        case 15: launch_k1r<15>(a, nchunks, s); return true;
+        case 17: launch_k1r<17>(a, nchunks, s); return true;
+        case 19: launch_k1r<19>(a, nchunks, s); return true;
+        case 21: launch_k1r<21>(a, nchunks, s); return true;
+        case 23: launch_k1r<23>(a, nchunks, s); return true;
+        case 25: launch_k1r<25>(a, nchunks, s); return true;
+        case 27: launch_k1r<27>(a, nchunks, s); return true;
+        case 29: launch_k1r<29>(a, nchunks, s); return true;
+        case 31: launch_k1r<31>(a, nchunks, s); return true;
+        default: return false;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -185,7 +212,7 @@ void pup_destroy(pup_ctx* c) {
     collect_events(c);
     c->indptr.release(); c->px.release(); c->cnt32.release(); c->idx.release(); c->idx_chrom.release(); c->weight.release(); c->cov.release(); c->expv.release();
     c->acc_f64.release(); c->acc_i64.release();
-    c->d_r0.release(); c->d_c0.release(); c->d_flip.release();
+    c->d_r0.release(); c->d_c0.release(); c->d_chunk_flip.release();
     c->d_chunk_begin.release(); c->d_chunk_end.release(); c->d_seg1.release(); c->d_seg2.release();
     c->d_dn.release();
     c->part_f64.release(); c->slice_f64.release(); c->part_num.release(); c->slice_num.release();
@@ -346,8 +373,8 @@ int pup_reset(pup_ctx* c, int32_t n_tiles, int32_t pad) {
     return PUP_OK;
 }
 
-int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, const uint8_t* flip,
-                   int64_t n, const int64_t* tile_ptr, int32_t ignore_diags, uint32_t mode) {
+int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, const int64_t* tile_ptr,
+                   const int64_t* flip_from, int32_t ignore_diags, uint32_t mode) {
     if (!c) return PUP_EINVAL;
     if (!c->have_px) return fail(c, PUP_ESTATE, "pup_accumulate: no pixel table loaded");
     if (c->T <= 0) return fail(c, PUP_ESTATE, "pup_accumulate: call pup_reset first");
@@ -356,9 +383,13 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, const uint8
     if (tile_ptr[0] != 0 || tile_ptr[c->T] != n)
         return fail(c, PUP_EINVAL, "pup_accumulate: tile_ptr must run from 0 to n=%lld (got %lld..%lld)",
                     (long long)n, (long long)tile_ptr[0], (long long)tile_ptr[c->T]);
-    for (int t = 0; t < c->T; ++t)
+    for (int t = 0; t < c->T; ++t) {
         if (tile_ptr[t + 1] < tile_ptr[t])
             return fail(c, PUP_EINVAL, "pup_accumulate: tile_ptr decreases at tile %d", t);
+        if (flip_from && (flip_from[t] < tile_ptr[t] || flip_from[t] > tile_ptr[t + 1]))
+            return fail(c, PUP_EINVAL, "pup_accumulate: flip_from[%d]=%lld outside its tile [%lld, %lld]", t,
+                        (long long)flip_from[t], (long long)tile_ptr[t], (long long)tile_ptr[t + 1]);
+    }
     const bool m_ooe = mode & PUP_MODE_OOE, m_exp = mode & PUP_MODE_EXPECTED;
     if ((m_ooe || m_exp) && c->nexp == 0)
         return fail(c, PUP_ESTATE, "pup_accumulate: OOE/EXPECTED mode without pup_set_expected");
@@ -372,8 +403,8 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, const uint8
     const size_t W2 = (size_t)W * W, Lf = W2 + 2 * (size_t)W;
 
     // ---- snippets to device ----------------------------------------------------------------------
-    const int *dr0, *dc0; const unsigned char* dfl = nullptr;
-    if (mode & PUP_MODE_DEVPTR) { dr0 = r0; dc0 = c0; dfl = flip; }
+    const int *dr0, *dc0;
+    if (mode & PUP_MODE_DEVPTR) { dr0 = r0; dc0 = c0; }
     else {
         // earlier launches may still read the staging buffers
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -381,11 +412,6 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, const uint8
         HIPCHK(c, hipMemcpy(c->d_r0.p, r0, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(c->d_c0.p, c0, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
         dr0 = c->d_r0.p; dc0 = c->d_c0.p;
-        if (flip) {
-            HIPCHK(c, c->d_flip.reserve((size_t)n));
-            HIPCHK(c, hipMemcpy(c->d_flip.p, flip, (size_t)n, hipMemcpyHostToDevice));
-            dfl = c->d_flip.p;
-        }
     }
 
     // ---- chunk table: equal snippet counts, cut at tile boundaries -------------------------------
@@ -395,10 +421,13 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, const uint8
         C = std::max<long long>(16, (n + target - 1) / target);
     }
     std::vector<long long> cb, ce, tile_chunk_ptr((size_t)c->T + 1, 0), dn((size_t)c->T);
+    std::vector<unsigned char> cf;
     for (int t = 0; t < c->T; ++t) {
         const long long b = tile_ptr[t], e = tile_ptr[t + 1];
+        const long long f = flip_from ? flip_from[t] : e;          // [b, f) as is, [f, e) flipped
         dn[(size_t)t] = e - b;
-        for (long long s = b; s < e; s += C) { cb.push_back(s); ce.push_back(std::min(e, s + C)); }
+        for (long long s = b; s < f; s += C) { cb.push_back(s); ce.push_back(std::min(f, s + C)); cf.push_back(0); }
+        for (long long s = f; s < e; s += C) { cb.push_back(s); ce.push_back(std::min(e, s + C)); cf.push_back(1); }
         tile_chunk_ptr[(size_t)t + 1] = (long long)cb.size();
     }
     const long long nchunks = (long long)cb.size();
@@ -429,6 +458,8 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, const uint8
     HIPCHK(c, c->part_f64.reserve((size_t)nchunks * Lf)); HIPCHK(c, c->part_num.reserve((size_t)nchunks * W2));
     HIPCHK(c, hipMemcpy(c->d_chunk_begin.p, cb.data(), (size_t)nchunks * 8, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_chunk_end.p, ce.data(), (size_t)nchunks * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, c->d_chunk_flip.reserve((size_t)nchunks));
+    HIPCHK(c, hipMemcpy(c->d_chunk_flip.p, cf.data(), (size_t)nchunks, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_seg2.p, seg2.data(), seg2.size() * 8, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_dn.p, dn.data(), (size_t)c->T * 8, hipMemcpyHostToDevice));
     if (two_level) {
@@ -440,14 +471,14 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, const uint8
     // ---- K1 ---------------------------------------------------------------------------------------
     pup::K1Args a{};
     a.indptr = c->indptr.p; a.px = c->px.p; a.cnt32 = c->cnt32.p;
-    const bool use_idx = c->have_idx && c->variant != 1;
+    const bool use_idx = c->have_idx && !(c->variant & 1);
     a.idx = use_idx ? c->idx.p : nullptr; a.idx_chrom = use_idx ? c->idx_chrom.p : nullptr;
     a.n_chrom = use_idx ? c->n_chrom : 0;
     a.weight = c->have_weight ? c->weight.p : nullptr;
     a.cov = c->have_cov ? c->cov.p : nullptr;
     a.expv = c->nexp > 0 ? c->expv.p : nullptr; a.nexp = c->nexp; a.nbins = c->nbins;
-    a.r0 = dr0; a.c0 = dc0; a.flip = dfl;
-    a.chunk_begin = c->d_chunk_begin.p; a.chunk_end = c->d_chunk_end.p;
+    a.r0 = dr0; a.c0 = dc0;
+    a.chunk_begin = c->d_chunk_begin.p; a.chunk_end = c->d_chunk_end.p; a.chunk_flip = c->d_chunk_flip.p;
     a.part_f64 = c->part_f64.p; a.part_num = c->part_num.p;
     a.counters = c->counters.p; a.err = c->d_err.p;
     a.W = W; a.ignore_diags = ignore_diags; a.mode = mode;
@@ -458,10 +489,14 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, const uint8
         HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1)); HIPCHK(c, hipEventCreate(&e2));
         HIPCHK(c, hipEventRecord(e0, c->stream));
     }
-    switch (W) {
-        case 21: launch_k1<21>(a, (int)nchunks, lds, c->stream); break;
-        case 51: launch_k1<51>(a, (int)nchunks, lds, c->stream); break;
-        default: launch_k1<0>(a, (int)nchunks, lds, c->stream); break;
+    // small windows: register-tile kernel; EXPECTED-only passes, wide windows and variant&2: LDS-tile kernel
+    const bool regtile = !m_exp && !(c->variant & 2) && launch_regtile(W, a, (int)nchunks, c->stream);
+    if (!regtile) {
+        switch (W) {
+            case 21: launch_k1<21>(a, (int)nchunks, lds, c->stream); break;
+            case 51: launch_k1<51>(a, (int)nchunks, lds, c->stream); break;
+            default: launch_k1<0>(a, (int)nchunks, lds, c->stream); break;
+        }
     }
     HIPCHK(c, hipGetLastError());
     if (c->profiling) HIPCHK(c, hipEventRecord(e1, c->stream));

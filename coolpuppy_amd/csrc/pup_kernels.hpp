@@ -60,10 +60,10 @@ struct K1Args {
     // snippets (device)
     const int*           r0;
     const int*           c0;
-    const unsigned char* flip;     // nullable
-    // chunk table (device)
+    // chunk table (device): a chunk holds snippets of ONE tile and ONE flip state
     const long long* chunk_begin;  // [nchunks]
     const long long* chunk_end;    // [nchunks]
+    const unsigned char* chunk_flip;  // [nchunks] non-zero: anti-transpose these snippets (flip_snip_func)
     // per-chunk partial outputs
     double*   part_f64;   // [nchunks][W2 + 2W]   (sum | cov_start | cov_end)
     unsigned* part_num;   // [nchunks][W2]
@@ -153,6 +153,7 @@ __global__ __launch_bounds__(kWave) void pileup_chunk_kernel(K1Args a) {
 
     const long long cb = a.chunk_begin[blockIdx.x];
     const long long ce = a.chunk_end[blockIdx.x];
+    const int fl = a.chunk_flip[blockIdx.x];
     unsigned long long npix = 0, nprobe = 0;
     // chromosome of the previous snippet (snippets arrive sorted: the lookup is almost always a hit)
     int ch_start = 0, ch_end = -1, ch_nblk = 0; long long ch_base = 0;
@@ -160,7 +161,6 @@ __global__ __launch_bounds__(kWave) void pileup_chunk_kernel(K1Args a) {
     for (long long s = cb; s < ce; ++s) {
         const int r0s = __builtin_amdgcn_readfirstlane(a.r0[s]);
         const int c0s = __builtin_amdgcn_readfirstlane(a.c0[s]);
-        const int fl  = a.flip ? __builtin_amdgcn_readfirstlane((int)a.flip[s]) : 0;
         if (r0s < 0 || c0s < 0 || (long long)r0s + W > a.nbins || (long long)c0s + W > a.nbins) {
             if (lane == 0) atomicExch(a.err, 1);
             continue;   // wave-uniform
@@ -283,6 +283,229 @@ __global__ __launch_bounds__(kWave) void pileup_chunk_kernel(K1Args a) {
     for (int t = lane; t < W2; t += kWave) { of[t] = tsum[t]; on[t] = tnum[t]; }
     for (int t = lane; t < 2 * W; t += kWave) of[W2 + t] = covs[t];
     // wave-reduce diagnostics, one atomic per chunk
+    for (int off = 32; off > 0; off >>= 1) {
+        npix   += __shfl_down(npix, off);
+        nprobe += __shfl_down(nprobe, off);
+    }
+    if (lane == 0 && a.counters) {
+        atomicAdd(&a.counters[0], npix);
+        atomicAdd(&a.counters[1], nprobe);
+    }
+}
+
+// ---- K1r: register-tile variant for small windows (W <= 32) ----------------------------------------------
+// Lane (p, k) owns the CH = ceil(W / NCH) cells of window row p, columns [k*CH, (k+1)*CH), NCH = 64 / W, for
+// EVERY snippet of the chunk: sum (f64) and num (u32) of those cells live in registers, so the hot loop has no
+// LDS traffic, no atomics and no barrier.  Per snippet a lane (1) reads ONE 64-byte index block of its row
+// (or binary-searches the row when the window is not cis / no index) to get the position of the first pixel
+// of its column chunk and the chunk's presence bits, (2) issues one 4-byte count load per set bit, all
+// independent, (3) applies weights / masks / expected in registers.  The next snippet's index block and
+// weights are requested before the current snippet's arithmetic (software pipelining across snippets).
+// The flip / transpose cell mapping is applied once, when the chunk's partial tile is written.
+struct RowLoc { long long pos; unsigned bits; };
+
+template <int CHW>
+__device__ __forceinline__ RowLoc search_row_chunk(const K1Args& a, int r, int c_first, unsigned long long& nprobe) {
+    // binary search for the first pixel with column >= c_first, then presence bits of the CHW columns
+    long long lo = a.indptr[r];
+    const long long h = a.indptr[r + 1];
+    long long b = h;
+    while (lo < b) {
+        const long long m = (lo + b) >> 1;
+        if (a.px[m].x < c_first) lo = m + 1; else b = m;
+        ++nprobe;
+    }
+    unsigned bits = 0;
+#pragma unroll
+    for (int i = 0; i < CHW; ++i) {
+        if (lo + i < h) {
+            const int d = a.px[lo + i].x - c_first;
+            if (d < CHW) bits |= 1u << d;
+        }
+    }
+    return {lo, bits};
+}
+
+template <int W>
+__global__ __launch_bounds__(kWave) void pileup_regtile_kernel(K1Args a) {
+    static_assert(W >= 1 && W <= 32, "register-tile kernel serves windows up to 32 bins");
+    constexpr int NCH = kWave / W;
+    constexpr int CH  = (W + NCH - 1) / NCH;
+    constexpr int W2  = W * W;
+    __shared__ double cov_lds[2 * W];
+    const int lane = threadIdx.x;
+    const int p  = lane / NCH;
+    const int k  = lane - p * NCH;
+    const int q0 = k * CH;
+    const bool active = (p < W) && (q0 < W);
+    const int chw = active ? ((W - q0) < CH ? (W - q0) : CH) : 0;     // columns this lane really owns
+
+    const bool m_ooe   = a.mode & 0x01u;
+    const bool m_cov   = (a.mode & 0x04u) && a.cov != nullptr;
+    const bool m_tr    = a.mode & 0x08u;
+    const bool use_exp = m_ooe && a.expv != nullptr && a.nexp > 0;
+    const int  igd     = a.ignore_diags;
+    const bool have_idx = a.idx != nullptr;
+
+    double   sum[CH];
+    unsigned num[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { sum[i] = 0.0; num[i] = 0u; }
+    if (m_cov) {
+        for (int t = lane; t < 2 * W; t += kWave) cov_lds[t] = 0.0;
+        __syncthreads();
+    }
+
+    const long long cb = a.chunk_begin[blockIdx.x];
+    const long long ce = a.chunk_end[blockIdx.x];
+    const int fl = a.chunk_flip[blockIdx.x];
+    unsigned long long npix = 0, nprobe = 0;
+    int ch_start = 0, ch_end = -1, ch_nblk = 0; long long ch_base = 0;
+
+    // ---- software pipeline state: raw index line + weights of the snippet about to be processed ----------
+    ulonglong2 nb0 = {0, 0}, nb1 = {0, 0}, nb2 = {0, 0}, nb3 = {0, 0};
+    double n_wr = 1.0; double n_wc[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) n_wc[i] = 1.0;
+    int n_r0 = 0, n_c0 = 0; bool n_valid = false, n_indexed = false; int n_o = 0, n_b = 0;
+    const IdxBlock* n_rowblk = nullptr;
+
+    auto issue = [&](long long s) {
+        n_valid = false; n_indexed = false;
+        if (s >= ce) return;
+        n_r0 = __builtin_amdgcn_readfirstlane(a.r0[s]);
+        n_c0 = __builtin_amdgcn_readfirstlane(a.c0[s]);
+        if (n_r0 < 0 || n_c0 < 0 || (long long)n_r0 + W > a.nbins || (long long)n_c0 + W > a.nbins) {
+            if (lane == 0) atomicExch(a.err, 1);
+            return;
+        }
+        n_valid = true;
+        if (have_idx) {
+            if (!(n_r0 >= ch_start && n_r0 < ch_end)) {
+                int lo = 0, hi_k = a.n_chrom;
+                while (lo < hi_k) { const int m = (lo + hi_k) >> 1; if (a.idx_chrom[m].end <= n_r0) lo = m + 1; else hi_k = m; }
+                if (lo < a.n_chrom) {
+                    const IdxChrom c = a.idx_chrom[lo];
+                    ch_start = c.start; ch_end = c.end; ch_nblk = c.nblk; ch_base = c.blk_base;
+                } else { ch_start = 0; ch_end = -1; }
+            }
+            n_indexed = n_r0 >= ch_start && n_r0 + W <= ch_end && n_c0 >= ch_start && n_c0 + W <= ch_end;
+        }
+        if (active) {
+            const int r = n_r0 + p;
+            if (n_indexed) {
+                const int rel = (n_c0 - ch_start) + q0;
+                n_b = rel / kIdxCols; n_o = rel - n_b * kIdxCols;
+                n_rowblk = a.idx + ch_base + (long long)(r - ch_start) * ch_nblk;
+                const ulonglong2* q = reinterpret_cast<const ulonglong2*>(n_rowblk + n_b);
+                nb0 = q[0]; nb1 = q[1]; nb2 = q[2]; nb3 = q[3];
+            }
+            if (a.weight) {
+                n_wr = a.weight[r];
+#pragma unroll
+                for (int i = 0; i < CH; ++i) if (i < chw) n_wc[i] = a.weight[n_c0 + q0 + i];
+            }
+        }
+    };
+
+    issue(cb);
+    for (long long s = cb; s < ce; ++s) {
+        // ---- take over the prefetched snippet -------------------------------------------------------------
+        const bool valid = n_valid, indexed = n_indexed;
+        const int r0s = n_r0, c0s = n_c0;
+        const double wrp = n_wr;
+        double wc[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) wc[i] = n_wc[i];
+        RowLoc loc = {0, 0u};
+        if (valid && active) {
+            if (indexed) {
+                const unsigned long long w[7] = {nb0.y, nb1.x, nb1.y, nb2.x, nb2.y, nb3.x, nb3.y};
+                const int ws = n_o >> 6, sh = n_o & 63;
+                unsigned long long rank = 0, cur = 0, nxt = 0;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) {
+                    rank += (i < ws) ? (unsigned long long)__popcll(w[i]) : 0ull;
+                    cur = (i == ws) ? w[i] : cur;
+                    nxt = (i == ws + 1) ? w[i] : nxt;
+                }
+                if (ws == 6 && sh + chw > 64 && n_b + 1 < ch_nblk) nxt = n_rowblk[n_b + 1].bits[0];
+                rank += (unsigned long long)__popcll(cur & ((1ull << sh) - 1ull));
+                unsigned long long bits = cur >> sh;
+                if (sh) bits |= nxt << (64 - sh);
+                loc.bits = (unsigned)(bits & ((1ull << chw) - 1ull));
+                loc.pos = (long long)(nb0.x + rank);
+            } else {
+                loc = search_row_chunk<CH>(a, r0s + p, c0s + q0, nprobe);
+                loc.bits &= (chw < 32) ? ((1u << chw) - 1u) : 0xffffffffu;
+            }
+        }
+        // ---- request the next snippet's index line and weights before doing this one's arithmetic ---------
+        issue(s + 1);
+        if (!valid) continue;                                        // wave-uniform
+        if (m_cov) {
+            if (active && k == 0) {
+                const double cr = a.cov[r0s + p], cc = a.cov[c0s + p];
+                const double vs = m_tr ? cc : cr, ve = m_tr ? cr : cc;
+                if (vs == vs) cov_lds[p] += vs;                      // one lane per element: no race
+                if (ve == ve) cov_lds[W + p] += ve;
+            }
+        }
+        if (active) {
+            // all count loads of this lane are independent: issue them together
+            int cnt[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                cnt[i] = 0;
+                if ((loc.bits >> i) & 1u) cnt[i] = a.cnt32[loc.pos + __popc(loc.bits & ((1u << i) - 1u))];
+            }
+            double ev[CH];
+            if (m_ooe) {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    ev[i] = __builtin_nan("");
+                    if (use_exp && i < chw) {
+                        long long ad = (long long)(c0s + q0 + i) - (r0s + p); if (ad < 0) ad = -ad;
+                        ev[i] = (a.nexp == 1) ? a.expv[0] : (ad < a.nexp ? a.expv[ad] : __builtin_nan(""));
+                    }
+                }
+            }
+            npix += (unsigned long long)__popc(loc.bits);
+            const bool rowok = (wrp == wrp);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                if (i < chw) {
+                    const int dj = (c0s + q0 + i) - (r0s + p);
+                    bool ok = rowok && (wc[i] == wc[i]) && (igd < 0 || dj >= igd);
+                    if (m_ooe) ok = ok && (ev[i] == ev[i]) && (ev[i] != 0.0);
+                    num[i] += ok ? 1u : 0u;
+                    if ((loc.bits >> i) & 1u) {
+                        double val = (double)cnt[i] * wrp * wc[i];
+                        bool okv = (val == val) && (igd < 0 || dj >= igd);
+                        if (m_ooe) { val = val / ev[i]; okv = okv && (val == val); }
+                        if (okv) sum[i] += val;
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- flush: window frame -> accumulator frame (transpose, then anti-transpose when flipped) ----------
+    if (m_cov) __syncthreads();
+    const size_t L = (size_t)W2 + 2 * (size_t)W;
+    double*   of = a.part_f64 + (size_t)blockIdx.x * L;
+    unsigned* on = a.part_num + (size_t)blockIdx.x * W2;
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            if (i < chw) {
+                const int cell = map_cell(p, q0 + i, W, m_tr, fl);
+                of[cell] = sum[i];
+                on[cell] = num[i];
+            }
+        }
+    }
+    for (int t = lane; t < 2 * W; t += kWave) of[W2 + t] = m_cov ? cov_lds[t] : 0.0;
     for (int off = 32; off > 0; off >>= 1) {
         npix   += __shfl_down(npix, off);
         nprobe += __shfl_down(nprobe, off);

@@ -115,23 +115,26 @@ class PileupEngine:
         self._check(self._lib.pup_reset(self._h, int(n_tiles), int(pad)))
         self.n_tiles, self.pad = int(n_tiles), int(pad)
 
-    def accumulate(self, r0, c0, tile_ptr, *, flip=None, ignore_diags=2, mode=0):
-        """Accumulate tile-grouped snippets given by their top-left GLOBAL bins (host arrays)."""
+    def accumulate(self, r0, c0, tile_ptr, *, flip_from=None, ignore_diags=2, mode=0):
+        """Accumulate tile-grouped snippets given by their top-left GLOBAL bins (host arrays).
+        flip_from[t] (optional): first anti-transposed snippet of tile t (flipped ones come last in a tile)."""
         r0 = _as(r0, np.int32)
         c0 = _as(c0, np.int32)
         tile_ptr = _as(tile_ptr, np.int64)
         if tile_ptr.shape[0] != self.n_tiles + 1:
             raise ValueError(f"tile_ptr needs {self.n_tiles + 1} entries")
-        f = None if flip is None else _as(flip, np.uint8)
-        self._check(self._lib.pup_accumulate(self._h, _ptr(r0), _ptr(c0), _ptr(f), r0.shape[0], _ptr(tile_ptr),
+        ff = None if flip_from is None else _as(flip_from, np.int64)
+        if ff is not None and ff.shape[0] != self.n_tiles:
+            raise ValueError(f"flip_from needs {self.n_tiles} entries")
+        self._check(self._lib.pup_accumulate(self._h, _ptr(r0), _ptr(c0), r0.shape[0], _ptr(tile_ptr), _ptr(ff),
                                              int(ignore_diags), int(mode) & ~MODE_DEVPTR))
 
-    def accumulate_device(self, r0_ptr, c0_ptr, n, tile_ptr, *, flip_ptr=None, ignore_diags=2, mode=0):
-        """Same, with r0/c0/flip already resident in HBM (raw device addresses, e.g. tensor.data_ptr())."""
+    def accumulate_device(self, r0_ptr, c0_ptr, n, tile_ptr, *, flip_from=None, ignore_diags=2, mode=0):
+        """Same, with r0/c0 already resident in HBM (raw device addresses, e.g. tensor.data_ptr())."""
         tile_ptr = _as(tile_ptr, np.int64)
-        self._check(self._lib.pup_accumulate(self._h, C.c_void_p(r0_ptr), C.c_void_p(c0_ptr),
-                                             C.c_void_p(flip_ptr) if flip_ptr else None, int(n), _ptr(tile_ptr),
-                                             int(ignore_diags), int(mode) | MODE_DEVPTR))
+        ff = None if flip_from is None else _as(flip_from, np.int64)
+        self._check(self._lib.pup_accumulate(self._h, C.c_void_p(r0_ptr), C.c_void_p(c0_ptr), int(n),
+                                             _ptr(tile_ptr), _ptr(ff), int(ignore_diags), int(mode) | MODE_DEVPTR))
 
     def sync(self):
         self._check(self._lib.pup_sync(self._h))

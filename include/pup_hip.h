@@ -62,7 +62,7 @@ typedef struct pup_ctx pup_ctx;
 #define PUP_MODE_COV        0x04u  /* accumulate cov_start / cov_end (coverage_norm) */
 #define PUP_MODE_TRANSPOSE  0x08u  /* (r0,c0) were swapped by the caller so that r0's region precedes
                                       c0's in the upper-triangular table; cells are stored transposed */
-#define PUP_MODE_DEVPTR     0x10u  /* r0 / c0 / flip are DEVICE pointers (already resident in HBM) */
+#define PUP_MODE_DEVPTR     0x10u  /* r0 / c0 are DEVICE pointers (already resident in HBM) */
 
 /* lifetime ---------------------------------------------------------------------------------------- */
 int  pup_create(int device_id, pup_ctx** out);
@@ -116,13 +116,14 @@ int pup_reset(pup_ctx* ctx, int32_t n_tiles, int32_t pad);
  * global bin table; the caller has already dropped windows that leave their region
  * (coolpup.py:1111-1114).  Snippets MUST be grouped by tile: tile_ptr[t]..tile_ptr[t+1] (host array,
  * int64[n_tiles+1], non-decreasing, tile_ptr[0] == 0, tile_ptr[n_tiles] == n) are the snippets of tile t.
- * flip (nullable, uint8[n]): non-zero = anti-transpose the snippet before adding (flip_snip_func).
+ * flip_from (nullable, host int64[n_tiles]): inside tile t the snippets [tile_ptr[t], flip_from[t]) are added as
+ * they are and [flip_from[t], tile_ptr[t+1]) are anti-transposed first (flip_snip_func); NULL = no flips.
  * ignore_diags: cis: cells with (col - row) < ignore_diags are masked (must be >= 0: the table is
  * upper-triangular); pass a negative value for trans (no diagonal mask).
  * Asynchronous with respect to the host; results are ordered on the context's stream.
  */
-int pup_accumulate(pup_ctx* ctx, const int32_t* r0, const int32_t* c0, const uint8_t* flip,
-                   int64_t n, const int64_t* tile_ptr, int32_t ignore_diags, uint32_t mode);
+int pup_accumulate(pup_ctx* ctx, const int32_t* r0, const int32_t* c0, int64_t n, const int64_t* tile_ptr,
+                   const int64_t* flip_from, int32_t ignore_diags, uint32_t mode);
 
 /* wait for all queued work; surfaces asynchronous errors (PUP_ERANGE, PUP_EHIP) */
 int pup_sync(pup_ctx* ctx);

@@ -42,9 +42,17 @@ def _snippets(clr, n, pad, rng, lo, hi, near=True):
 
 
 def _group(r0, c0, flip, tile, n_tiles):
-    order = np.argsort(tile, kind="stable")
+    """Sort by (tile, flip); returns (..., tile_ptr) — use _flip_from() for the engine's flip argument."""
+    key = tile.astype(np.int64) * 2 + (0 if flip is None else flip.astype(np.int64))
+    order = np.argsort(key, kind="stable")
     tile_ptr = np.concatenate([[0], np.cumsum(np.bincount(tile, minlength=n_tiles))]).astype(np.int64)
     return r0[order], c0[order], (None if flip is None else flip[order]), tile[order], tile_ptr
+
+
+def _flip_from(flip, tile, tile_ptr):
+    if flip is None:
+        return None
+    return tile_ptr[1:] - np.bincount(tile[flip.astype(bool)], minlength=len(tile_ptr) - 1)
 
 
 def _compare(got, want):
@@ -84,11 +92,12 @@ def test_cis_parity(engine, small_clr, oracle_mod, pad, scenario):
     engine.load_bins(weight, covv)
     engine.set_expected(expv)
     engine.reset(T, pad)
-    engine.accumulate(r0, c0, tile_ptr, flip=flip, ignore_diags=igd, mode=mode)
+    ff = _flip_from(flip, tile, tile_ptr)
+    engine.accumulate(r0, c0, tile_ptr, flip_from=ff, ignore_diags=igd, mode=mode)
     got = engine.fetch()
     _compare(got, want)
     # running accumulation: a second identical call doubles everything exactly for integers
-    engine.accumulate(r0, c0, tile_ptr, flip=flip, ignore_diags=igd, mode=mode)
+    engine.accumulate(r0, c0, tile_ptr, flip_from=ff, ignore_diags=igd, mode=mode)
     got2 = engine.fetch()
     np.testing.assert_array_equal(got2["num"], 2 * want["num"])
     np.testing.assert_array_equal(got2["n"], 2 * want["n"])
@@ -219,12 +228,21 @@ def test_cis_windows_near_chromosome_ends_and_trans_fallback(engine, small_clr, 
     W = 21
     loA, hiA = clr.extent("chrA")
     loB, hiB = clr.extent("chrB")
-    r0 = np.array([hiA - W, hiA - W - 1, hiA - W, loA, hiA - W - 5, hiA - 30], np.int32)
-    c0 = np.array([hiA - W, hiA - W, hiA - W - 3, loA, loB, loB + 2], np.int32)   # last two: trans windows
-    tile = np.zeros(len(r0), np.int32)
-    want = po.pileup_c(indptr, col, cnt, w, None, None, r0, c0, None, tile, 1, pad, -1, 0)
     engine.load_bins(w, None)
     engine.set_expected(None)
+    # cis windows on the chromosome's last bins (diagonal mask 0: the engine reads the upper triangle only)
+    r0 = np.array([hiA - W, hiA - W - 1, hiA - W - 3, loA, hiA - W - 40], np.int32)
+    c0 = np.array([hiA - W, hiA - W, hiA - W, loA, hiA - W], np.int32)
+    tile = np.zeros(len(r0), np.int32)
+    want = po.pileup_c(indptr, col, cnt, w, None, None, r0, c0, None, tile, 1, pad, 0, 0)
+    engine.reset(1, pad)
+    engine.accumulate(r0, c0, np.array([0, len(r0)], np.int64), ignore_diags=0, mode=0)
+    _compare(engine.fetch(), want)
+    # trans windows (rows in chrA, columns in chrB), including ones hugging both chromosome edges
+    r0 = np.array([hiA - W, hiA - W - 5, loA, hiA - 30], np.int32)
+    c0 = np.array([loB, loB + 2, hiB - W, loB + 700], np.int32)
+    tile = np.zeros(len(r0), np.int32)
+    want = po.pileup_c(indptr, col, cnt, w, None, None, r0, c0, None, tile, 1, pad, -1, 0)
     engine.reset(1, pad)
     engine.accumulate(r0, c0, np.array([0, len(r0)], np.int64), ignore_diags=-1, mode=0)
     _compare(engine.fetch(), want)
