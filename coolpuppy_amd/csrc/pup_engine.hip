@@ -129,7 +129,10 @@ void launch_k1(const pup::K1Args& a, int nchunks, size_t lds, hipStream_t s) {
 
 template <int W>
 void launch_k1r(const pup::K1Args& a, int nchunks, hipStream_t s) {
-    hipLaunchKernelGGL(pup::pileup_regtile_kernel<W>, dim3(nchunks), dim3(pup::kWave), 0, s, a);
+    if (a.mode & PUP_MODE_OOE)
+        hipLaunchKernelGGL((pup::pileup_regtile_kernel<W, true>), dim3(nchunks), dim3(pup::kWave), 0, s, a);
+    else
+        hipLaunchKernelGGL((pup::pileup_regtile_kernel<W, false>), dim3(nchunks), dim3(pup::kWave), 0, s, a);
 }
 
 // window widths the register-tile kernel is instantiated for (pad 1..15 -> W = 3..31)
@@ -240,7 +243,8 @@ int pup_load_pixels(pup_ctx* c, const int64_t* bin1_offset, const void* bin2_id,
     c->have_px = false; c->have_idx = false;
     HIPCHK(c, c->indptr.reserve((size_t)nbins + 1));
     HIPCHK(c, c->px.reserve((size_t)std::max<int64_t>(nnz, 1)));
-    HIPCHK(c, c->cnt32.reserve((size_t)std::max<int64_t>(nnz, 1)));
+    HIPCHK(c, c->cnt32.reserve((size_t)nnz + 64));     // +64: the register-tile kernel loads counts unconditionally
+    HIPCHK(c, hipMemset(c->cnt32.p + nnz, 0, 64 * sizeof(int)));
     HIPCHK(c, hipMemcpy(c->indptr.p, bin1_offset, ((size_t)nbins + 1) * sizeof(long long), hipMemcpyHostToDevice));
     // stage bin2/count through a bounded device staging area and interleave on device
     const size_t slab = (size_t)1 << 26;   // 64 Mi pixels per slab

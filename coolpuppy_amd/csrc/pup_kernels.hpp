@@ -27,15 +27,23 @@ namespace pup {
 constexpr int kWave = 64;
 
 // ---- rank-bitmap index ---------------------------------------------------------------------------------
-// One 64-byte block covers kIdxCols consecutive columns of one row: pos = absolute index (into the pixel
-// arrays) of the first pixel of the row at or after the block's first column; bits[w] bit b set <=> the
-// row has a pixel at column (block_first_col + 64*w + b).  Row r of chromosome k owns nblk[k] blocks
-// covering that chromosome's columns; only cis pixels are indexed.
-constexpr int kIdxCols = 448;
+// One 64-byte block (= one cache line) covers kIdxCols consecutive columns of one row:
+//   pos      absolute index (into the pixel arrays) of the row's first pixel at or after the block's first
+//            column (< 2^48: its top 16 bits double as cum[0] == 0)
+//   cum[w-1] number of pixels in words 0..w-1 of this block (w = 1..4)
+//   bits[w]  bit b set <=> the row has a pixel at column block_first_col + 64*w + b
+//   next0    copy of the NEXT block's bits[0] (0 for the row's last block): a window that starts in word 4
+//            never needs a second line
+// A lookup is three loads from one line: pos, cum[word], and the 16 bytes {word, word+1}.
+// Row r of chromosome k owns nblk[k] blocks covering that chromosome's columns; only cis pixels are indexed.
+constexpr int kIdxCols = 320;
 struct __attribute__((aligned(64))) IdxBlock {
     unsigned long long pos;
-    unsigned long long bits[7];
+    unsigned short     cum[4];
+    unsigned long long bits[5];
+    unsigned long long next0;
 };
+static_assert(sizeof(IdxBlock) == 64, "index block must be one 64-byte line");
 struct IdxChrom {             // per chromosome (device table, sorted by start)
     int       start;          // first global bin
     int       end;            // one past the last global bin
@@ -96,29 +104,25 @@ __device__ __forceinline__ int map_cell(int p, int q, int W, bool tr, int fl) {
     return pp * W + qq;
 }
 
-// rank-bitmap lookup for one row: position of the first pixel with column >= the window start, and the
-// presence bits of the W (<= 64) window columns.  rel_c = window start column relative to the chromosome.
-__device__ __forceinline__ void idx_lookup(const IdxBlock* __restrict__ rowblk, int nblk, int rel_c, int W,
-                                           long long& pos, unsigned long long& wbits) {
+// rank-bitmap lookup: position of the row's first pixel with column >= the window start and the presence
+// bits of the next 64 columns.  rel_c = window start column relative to the chromosome.
+__device__ __forceinline__ void idx_lookup64(const IdxBlock* __restrict__ rowblk, int rel_c,
+                                             long long& pos, unsigned long long& bits) {
     const int b  = rel_c / kIdxCols;
     const int o  = rel_c - b * kIdxCols;
     const int ws = o >> 6, sh = o & 63;
-    const ulonglong2* q = reinterpret_cast<const ulonglong2*>(rowblk + b);
-    const ulonglong2 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];     // one 64-byte line
-    const unsigned long long w[7] = {v0.y, v1.x, v1.y, v2.x, v2.y, v3.x, v3.y};
-    unsigned long long rank = 0, cur = 0, nxt = 0;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        rank += (k < ws) ? (unsigned long long)__popcll(w[k]) : 0ull;
-        cur = (k == ws) ? w[k] : cur;
-        nxt = (k == ws + 1) ? w[k] : nxt;
+    const char* base = reinterpret_cast<const char*>(rowblk + b);
+    const unsigned long long p0 = *reinterpret_cast<const unsigned long long*>(base);
+    const unsigned cum = *reinterpret_cast<const unsigned short*>(base + 6 + 2 * ws);   // ws == 0 reads pos[63:48] == 0
+    unsigned long long cur, nxt;
+    {   // {bits[ws], bits[ws+1] or next0}: 16 bytes at an 8-byte aligned address of the same line
+        const unsigned long long* w = reinterpret_cast<const unsigned long long*>(base + 16 + 8 * ws);
+        cur = w[0]; nxt = w[1];
     }
-    if (ws == 6 && sh + W > 64 && b + 1 < nblk) nxt = rowblk[b + 1].bits[0];   // window crosses into the next block
-    rank += (unsigned long long)__popcll(cur & ((1ull << sh) - 1ull));
-    unsigned long long bits = cur >> sh;
+    const unsigned long long below = cur & ((1ull << sh) - 1ull);
+    bits = cur >> sh;
     if (sh) bits |= nxt << (64 - sh);
-    wbits = (W < 64) ? (bits & ((1ull << W) - 1ull)) : bits;
-    pos = (long long)(v0.x + rank);
+    pos = (long long)(p0 + cum + (unsigned long long)__popcll(below));
 }
 
 template <int WT>
@@ -185,8 +189,8 @@ __global__ __launch_bounds__(kWave) void pileup_chunk_kernel(K1Args a) {
                 if (indexed) {
                     const IdxBlock* rowblk = a.idx + ch_base + (long long)(r - ch_start) * ch_nblk;
                     long long pos; unsigned long long bits;
-                    idx_lookup(rowblk, ch_nblk, c0s - ch_start, W, pos, bits);
-                    st[p] = pos; wbv[p] = bits;
+                    idx_lookup64(rowblk, c0s - ch_start, pos, bits);
+                    st[p] = pos; wbv[p] = (W < 64) ? (bits & ((1ull << W) - 1ull)) : bits;
                 } else {
                     long long lo = a.indptr[r];
                     const long long h = a.indptr[r + 1];
@@ -293,20 +297,11 @@ __global__ __launch_bounds__(kWave) void pileup_chunk_kernel(K1Args a) {
     }
 }
 
-// ---- K1r: register-tile variant for small windows (W <= 32) ----------------------------------------------
-// Lane (p, k) owns the CH = ceil(W / NCH) cells of window row p, columns [k*CH, (k+1)*CH), NCH = 64 / W, for
-// EVERY snippet of the chunk: sum (f64) and num (u32) of those cells live in registers, so the hot loop has no
-// LDS traffic, no atomics and no barrier.  Per snippet a lane (1) reads ONE 64-byte index block of its row
-// (or binary-searches the row when the window is not cis / no index) to get the position of the first pixel
-// of its column chunk and the chunk's presence bits, (2) issues one 4-byte count load per set bit, all
-// independent, (3) applies weights / masks / expected in registers.  The next snippet's index block and
-// weights are requested before the current snippet's arithmetic (software pipelining across snippets).
-// The flip / transpose cell mapping is applied once, when the chunk's partial tile is written.
 struct RowLoc { long long pos; unsigned bits; };
 
+// binary search for a row's first pixel with column >= c_first, then the presence bits of CHW columns
 template <int CHW>
 __device__ __forceinline__ RowLoc search_row_chunk(const K1Args& a, int r, int c_first, unsigned long long& nprobe) {
-    // binary search for the first pixel with column >= c_first, then presence bits of the CHW columns
     long long lo = a.indptr[r];
     const long long h = a.indptr[r + 1];
     long long b = h;
@@ -326,7 +321,30 @@ __device__ __forceinline__ RowLoc search_row_chunk(const K1Args& a, int r, int c
     return {lo, bits};
 }
 
-template <int W>
+// ---- K1r: register-tile variant for small windows (W <= 32) ----------------------------------------------
+// Lane (p, k) owns the CH = ceil(W / NCH) cells of window row p, columns [k*CH, (k+1)*CH), NCH = 64 / W, for
+// EVERY snippet of the chunk: sum (f64) and num (u32) of those cells live in registers, so the hot loop has no
+// LDS traffic, no atomics and no barrier.  Per snippet a lane (1) reads ONE 64-byte index line of its row
+// (or binary-searches the row when the window is not cis / no index) to get the position of the first pixel
+// of its column chunk and the chunk's presence bits, (2) issues one 4-byte count load per owned cell, all
+// independent and unconditional, (3) applies weights / masks / expected in registers with selects (the loop
+// body is straight-line: no per-lane branches).  The next snippet's index line and weights are requested
+// before the current snippet's arithmetic; the loop is unrolled x2 over two register sets so the pipeline
+// needs no register copies.  The flip / transpose cell mapping is applied once, at the chunk's flush.
+template <int CH>
+struct RtStage {
+    unsigned long long p0, cur, nxt;   // raw index words
+    unsigned           cum;
+    int                sh;             // bit offset of the lane's chunk inside `cur`
+    double             wr;
+    double             wc[CH];
+    long long          spos;           // search path: position / bits already resolved
+    unsigned           sbits;
+    int                r0, c0;         // wave-uniform
+    bool               valid, indexed; // wave-uniform
+};
+
+template <int W, bool OOE>
 __global__ __launch_bounds__(kWave) void pileup_regtile_kernel(K1Args a) {
     static_assert(W >= 1 && W <= 32, "register-tile kernel serves windows up to 32 bins");
     constexpr int NCH = kWave / W;
@@ -334,23 +352,30 @@ __global__ __launch_bounds__(kWave) void pileup_regtile_kernel(K1Args a) {
     constexpr int W2  = W * W;
     __shared__ double cov_lds[2 * W];
     const int lane = threadIdx.x;
-    const int p  = lane / NCH;
-    const int k  = lane - p * NCH;
+    const int p_raw = lane / NCH;
+    const int k  = lane - p_raw * NCH;
     const int q0 = k * CH;
-    const bool active = (p < W) && (q0 < W);
-    const int chw = active ? ((W - q0) < CH ? (W - q0) : CH) : 0;     // columns this lane really owns
+    const bool lane_ok = (p_raw < W) && (q0 < W);
+    const int p  = p_raw < W ? p_raw : W - 1;                         // idle lanes shadow the last row, add nothing
+    const int chw = lane_ok ? ((W - q0) < CH ? (W - q0) : CH) : 0;    // cells this lane really owns
+    const unsigned chmask = chw >= 32 ? 0xffffffffu : ((1u << chw) - 1u);
+    const int qs = q0 < W ? q0 : 0;                                   // column chunk actually addressed
 
-    const bool m_ooe   = a.mode & 0x01u;
     const bool m_cov   = (a.mode & 0x04u) && a.cov != nullptr;
     const bool m_tr    = a.mode & 0x08u;
-    const bool use_exp = m_ooe && a.expv != nullptr && a.nexp > 0;
+    const bool use_exp = OOE && a.expv != nullptr && a.nexp > 0;
     const int  igd     = a.ignore_diags;
     const bool have_idx = a.idx != nullptr;
+    const double qnan = __builtin_nan("");
 
     double   sum[CH];
     unsigned num[CH];
+    int      thr[CH];        // cell i passes the diagonal mask iff (c0 - r0) >= thr[i]
 #pragma unroll
-    for (int i = 0; i < CH; ++i) { sum[i] = 0.0; num[i] = 0u; }
+    for (int i = 0; i < CH; ++i) {
+        sum[i] = 0.0; num[i] = 0u;
+        thr[i] = igd < 0 ? (int)0x80000000 : igd - (qs + i - p);
+    }
     if (m_cov) {
         for (int t = lane; t < 2 * W; t += kWave) cov_lds[t] = 0.0;
         __syncthreads();
@@ -362,132 +387,112 @@ __global__ __launch_bounds__(kWave) void pileup_regtile_kernel(K1Args a) {
     unsigned long long npix = 0, nprobe = 0;
     int ch_start = 0, ch_end = -1, ch_nblk = 0; long long ch_base = 0;
 
-    // ---- software pipeline state: raw index line + weights of the snippet about to be processed ----------
-    ulonglong2 nb0 = {0, 0}, nb1 = {0, 0}, nb2 = {0, 0}, nb3 = {0, 0};
-    double n_wr = 1.0; double n_wc[CH];
-#pragma unroll
-    for (int i = 0; i < CH; ++i) n_wc[i] = 1.0;
-    int n_r0 = 0, n_c0 = 0; bool n_valid = false, n_indexed = false; int n_o = 0, n_b = 0;
-    const IdxBlock* n_rowblk = nullptr;
-
-    auto issue = [&](long long s) {
-        n_valid = false; n_indexed = false;
+    // request everything snippet s needs that does not depend on other loads
+    auto issue = [&](RtStage<CH>& g, long long s) __attribute__((always_inline)) {
+        g.valid = false; g.indexed = false;
         if (s >= ce) return;
-        n_r0 = __builtin_amdgcn_readfirstlane(a.r0[s]);
-        n_c0 = __builtin_amdgcn_readfirstlane(a.c0[s]);
-        if (n_r0 < 0 || n_c0 < 0 || (long long)n_r0 + W > a.nbins || (long long)n_c0 + W > a.nbins) {
+        g.r0 = __builtin_amdgcn_readfirstlane(a.r0[s]);
+        g.c0 = __builtin_amdgcn_readfirstlane(a.c0[s]);
+        if (g.r0 < 0 || g.c0 < 0 || (long long)g.r0 + W > a.nbins || (long long)g.c0 + W > a.nbins) {
             if (lane == 0) atomicExch(a.err, 1);
             return;
         }
-        n_valid = true;
+        g.valid = true;
         if (have_idx) {
-            if (!(n_r0 >= ch_start && n_r0 < ch_end)) {
+            if (!(g.r0 >= ch_start && g.r0 < ch_end)) {               // snippets arrive sorted: rare
                 int lo = 0, hi_k = a.n_chrom;
-                while (lo < hi_k) { const int m = (lo + hi_k) >> 1; if (a.idx_chrom[m].end <= n_r0) lo = m + 1; else hi_k = m; }
+                while (lo < hi_k) { const int m = (lo + hi_k) >> 1; if (a.idx_chrom[m].end <= g.r0) lo = m + 1; else hi_k = m; }
                 if (lo < a.n_chrom) {
                     const IdxChrom c = a.idx_chrom[lo];
                     ch_start = c.start; ch_end = c.end; ch_nblk = c.nblk; ch_base = c.blk_base;
                 } else { ch_start = 0; ch_end = -1; }
             }
-            n_indexed = n_r0 >= ch_start && n_r0 + W <= ch_end && n_c0 >= ch_start && n_c0 + W <= ch_end;
+            g.indexed = g.r0 >= ch_start && g.r0 + W <= ch_end && g.c0 >= ch_start && g.c0 + W <= ch_end;
         }
-        if (active) {
-            const int r = n_r0 + p;
-            if (n_indexed) {
-                const int rel = (n_c0 - ch_start) + q0;
-                n_b = rel / kIdxCols; n_o = rel - n_b * kIdxCols;
-                n_rowblk = a.idx + ch_base + (long long)(r - ch_start) * ch_nblk;
-                const ulonglong2* q = reinterpret_cast<const ulonglong2*>(n_rowblk + n_b);
-                nb0 = q[0]; nb1 = q[1]; nb2 = q[2]; nb3 = q[3];
-            }
-            if (a.weight) {
-                n_wr = a.weight[r];
+        const int r = g.r0 + p;
+        if (g.indexed) {
+            const int rel = (g.c0 - ch_start) + qs;
+            const int b = rel / kIdxCols, o = rel - b * kIdxCols;
+            const int ws = o >> 6;
+            g.sh = o & 63;
+            const char* base = reinterpret_cast<const char*>(a.idx + ch_base + (long long)(r - ch_start) * ch_nblk + b);
+            g.p0  = *reinterpret_cast<const unsigned long long*>(base);
+            g.cum = *reinterpret_cast<const unsigned short*>(base + 6 + 2 * ws);
+            const unsigned long long* w = reinterpret_cast<const unsigned long long*>(base + 16 + 8 * ws);
+            g.cur = w[0]; g.nxt = w[1];
+        } else {
+            const RowLoc loc = search_row_chunk<CH>(a, r, g.c0 + qs, nprobe);
+            g.spos = loc.pos; g.sbits = loc.bits;
+        }
+        if (a.weight) {
+            g.wr = a.weight[r];
 #pragma unroll
-                for (int i = 0; i < CH; ++i) if (i < chw) n_wc[i] = a.weight[n_c0 + q0 + i];
+            for (int i = 0; i < CH; ++i) {
+                const int c = g.c0 + qs + i;
+                g.wc[i] = a.weight[c < a.nbins ? c : (int)a.nbins - 1];
             }
+        } else {
+            g.wr = 1.0;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) g.wc[i] = 1.0;
         }
     };
 
-    issue(cb);
-    for (long long s = cb; s < ce; ++s) {
-        // ---- take over the prefetched snippet -------------------------------------------------------------
-        const bool valid = n_valid, indexed = n_indexed;
-        const int r0s = n_r0, c0s = n_c0;
-        const double wrp = n_wr;
-        double wc[CH];
+    auto process = [&](const RtStage<CH>& g) __attribute__((always_inline)) {
+        if (!g.valid) return;                                          // wave-uniform
+        long long pos; unsigned bits;
+        if (g.indexed) {
+            unsigned long long b64 = g.cur >> g.sh;
+            if (g.sh) b64 |= g.nxt << (64 - g.sh);
+            bits = (unsigned)b64 & chmask;
+            pos = (long long)(g.p0 + g.cum + (unsigned long long)__popcll(g.cur & ((1ull << g.sh) - 1ull)));
+        } else { pos = g.spos; bits = g.sbits & chmask; }
+        // one count load per cell, addresses known up front (cnt32 is padded: a cell without a pixel reads a
+        // neighbouring count that is then discarded)
+        int cnt[CH];
 #pragma unroll
-        for (int i = 0; i < CH; ++i) wc[i] = n_wc[i];
-        RowLoc loc = {0, 0u};
-        if (valid && active) {
-            if (indexed) {
-                const unsigned long long w[7] = {nb0.y, nb1.x, nb1.y, nb2.x, nb2.y, nb3.x, nb3.y};
-                const int ws = n_o >> 6, sh = n_o & 63;
-                unsigned long long rank = 0, cur = 0, nxt = 0;
+        for (int i = 0; i < CH; ++i) cnt[i] = a.cnt32[pos + __popc(bits & ((1u << i) - 1u))];
+        double ev[CH];
+        if (OOE) {
 #pragma unroll
-                for (int i = 0; i < 7; ++i) {
-                    rank += (i < ws) ? (unsigned long long)__popcll(w[i]) : 0ull;
-                    cur = (i == ws) ? w[i] : cur;
-                    nxt = (i == ws + 1) ? w[i] : nxt;
-                }
-                if (ws == 6 && sh + chw > 64 && n_b + 1 < ch_nblk) nxt = n_rowblk[n_b + 1].bits[0];
-                rank += (unsigned long long)__popcll(cur & ((1ull << sh) - 1ull));
-                unsigned long long bits = cur >> sh;
-                if (sh) bits |= nxt << (64 - sh);
-                loc.bits = (unsigned)(bits & ((1ull << chw) - 1ull));
-                loc.pos = (long long)(nb0.x + rank);
-            } else {
-                loc = search_row_chunk<CH>(a, r0s + p, c0s + q0, nprobe);
-                loc.bits &= (chw < 32) ? ((1u << chw) - 1u) : 0xffffffffu;
+            for (int i = 0; i < CH; ++i) {
+                long long ad = (long long)(g.c0 + qs + i) - (g.r0 + p); if (ad < 0) ad = -ad;
+                const long long ai = (a.nexp == 1) ? 0 : (ad < a.nexp ? ad : 0);
+                const double e = use_exp ? a.expv[ai] : qnan;
+                ev[i] = (a.nexp == 1 || ad < a.nexp) ? e : qnan;
             }
         }
-        // ---- request the next snippet's index line and weights before doing this one's arithmetic ---------
-        issue(s + 1);
-        if (!valid) continue;                                        // wave-uniform
         if (m_cov) {
-            if (active && k == 0) {
-                const double cr = a.cov[r0s + p], cc = a.cov[c0s + p];
+            if (lane_ok && k == 0) {
+                const double cr = a.cov[g.r0 + p], cc = a.cov[g.c0 + p];
                 const double vs = m_tr ? cc : cr, ve = m_tr ? cr : cc;
-                if (vs == vs) cov_lds[p] += vs;                      // one lane per element: no race
+                if (vs == vs) cov_lds[p] += vs;                        // one lane per element: no race
                 if (ve == ve) cov_lds[W + p] += ve;
             }
         }
-        if (active) {
-            // all count loads of this lane are independent: issue them together
-            int cnt[CH];
+        npix += (unsigned long long)__popc(bits);
+        const int D = g.c0 - g.r0;
+        const bool rowok = (g.wr == g.wr);
 #pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                cnt[i] = 0;
-                if ((loc.bits >> i) & 1u) cnt[i] = a.cnt32[loc.pos + __popc(loc.bits & ((1u << i) - 1u))];
-            }
-            double ev[CH];
-            if (m_ooe) {
-#pragma unroll
-                for (int i = 0; i < CH; ++i) {
-                    ev[i] = __builtin_nan("");
-                    if (use_exp && i < chw) {
-                        long long ad = (long long)(c0s + q0 + i) - (r0s + p); if (ad < 0) ad = -ad;
-                        ev[i] = (a.nexp == 1) ? a.expv[0] : (ad < a.nexp ? a.expv[ad] : __builtin_nan(""));
-                    }
-                }
-            }
-            npix += (unsigned long long)__popc(loc.bits);
-            const bool rowok = (wrp == wrp);
-#pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                if (i < chw) {
-                    const int dj = (c0s + q0 + i) - (r0s + p);
-                    bool ok = rowok && (wc[i] == wc[i]) && (igd < 0 || dj >= igd);
-                    if (m_ooe) ok = ok && (ev[i] == ev[i]) && (ev[i] != 0.0);
-                    num[i] += ok ? 1u : 0u;
-                    if ((loc.bits >> i) & 1u) {
-                        double val = (double)cnt[i] * wrp * wc[i];
-                        bool okv = (val == val) && (igd < 0 || dj >= igd);
-                        if (m_ooe) { val = val / ev[i]; okv = okv && (val == val); }
-                        if (okv) sum[i] += val;
-                    }
-                }
-            }
+        for (int i = 0; i < CH; ++i) {
+            const bool cell = (chmask >> i) & 1u;                       // lane-constant
+            bool ok = cell && rowok && (g.wc[i] == g.wc[i]) && (D >= thr[i]);
+            double val = (double)cnt[i] * g.wr * g.wc[i];
+            if (OOE) { ok = ok && (ev[i] == ev[i]) && (ev[i] != 0.0); val = val / ev[i]; }
+            num[i] += ok ? 1u : 0u;
+            // nansum semantics: add unless NaN (masked cells are NaN by construction: diagonal mask / NaN weight)
+            const bool add = ((bits >> i) & 1u) && (val == val) && (D >= thr[i]);
+            sum[i] += add ? val : 0.0;
         }
+    };
+
+    RtStage<CH> A, B;
+    issue(A, cb);
+    for (long long s = cb; s < ce; s += 2) {
+        issue(B, s + 1);
+        process(A);
+        issue(A, s + 2);
+        process(B);
     }
 
     // ---- flush: window frame -> accumulator frame (transpose, then anti-transpose when flipped) ----------
@@ -495,14 +500,12 @@ __global__ __launch_bounds__(kWave) void pileup_regtile_kernel(K1Args a) {
     const size_t L = (size_t)W2 + 2 * (size_t)W;
     double*   of = a.part_f64 + (size_t)blockIdx.x * L;
     unsigned* on = a.part_num + (size_t)blockIdx.x * W2;
-    if (active) {
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            if (i < chw) {
-                const int cell = map_cell(p, q0 + i, W, m_tr, fl);
-                of[cell] = sum[i];
-                on[cell] = num[i];
-            }
+    for (int i = 0; i < CH; ++i) {
+        if ((chmask >> i) & 1u) {
+            const int cell = map_cell(p, q0 + i, W, m_tr, fl);
+            of[cell] = sum[i];
+            on[cell] = num[i];
         }
     }
     for (int t = lane; t < 2 * W; t += kWave) of[W2 + t] = m_cov ? cov_lds[t] : 0.0;
@@ -530,19 +533,20 @@ __global__ __launch_bounds__(256) void index_fill_kernel(const long long* __rest
         if (lo >= n_chrom) continue;
         const IdxChrom c = chroms[lo];
         if (r < c.start) continue;
-        unsigned long long* rowbits = reinterpret_cast<unsigned long long*>(idx + c.blk_base + (r - c.start) * c.nblk);
+        unsigned long long* rowwords = reinterpret_cast<unsigned long long*>(idx + c.blk_base + (r - c.start) * c.nblk);
         const long long b = indptr[r], e = indptr[r + 1];
         for (long long k = b + lane; k < e; k += 64) {
             const int col = px[k].x;
             if (col >= c.end) continue;              // trans pixel: not indexed
             const int rel = col - c.start;
             const int blk = rel / kIdxCols, o = rel - blk * kIdxCols;
-            atomicOr(rowbits + (size_t)blk * 8 + 1 + (o >> 6), 1ull << (o & 63));
+            atomicOr(rowwords + (size_t)blk * 8 + 2 + (o >> 6), 1ull << (o & 63));   // words: pos, cum, bits[0..4], next0
         }
     }
 }
 
-// one thread per row: absolute position of each block's first pixel (running popcount)
+// one thread per row: per block the absolute position of its first pixel, the in-block cumulative counts,
+// and the copy of the following block's first word
 __global__ __launch_bounds__(256) void index_rank_kernel(const long long* __restrict__ indptr,
                                                          const IdxChrom* __restrict__ chroms, int n_chrom,
                                                          IdxBlock* __restrict__ idx, long long nbins) {
@@ -557,8 +561,14 @@ __global__ __launch_bounds__(256) void index_rank_kernel(const long long* __rest
     unsigned long long pos = (unsigned long long)indptr[r];
     for (int b = 0; b < c.nblk; ++b) {
         row[b].pos = pos;
+        unsigned run = 0;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) pos += (unsigned long long)__popcll(row[b].bits[k]);
+        for (int k = 0; k < 5; ++k) {
+            if (k > 0) row[b].cum[k - 1] = (unsigned short)run;
+            run += (unsigned)__popcll(row[b].bits[k]);
+        }
+        pos += run;
+        row[b].next0 = (b + 1 < c.nblk) ? row[b + 1].bits[0] : 0ull;
     }
 }
 

@@ -14,6 +14,6 @@ done
 python - <<PY
 import pandas as pd, glob
 for f in sorted(glob.glob("$OUT/p*/*/*_counter_collection.csv")):
-    d=pd.read_csv(f); k=d[d.Kernel_Name.str.contains("pileup_chunk")]
+    d=pd.read_csv(f); k=d[d.Kernel_Name.str.contains("pileup_")]
     print(k.groupby("Counter_Name").Counter_Value.mean().to_string())
 PY
