@@ -48,6 +48,9 @@ struct pup_ctx {
     DevBuf<long long> indptr;
     DevBuf<int2> px;
     DevBuf<int> cnt32;
+    DevBuf<double> bal;
+    DevBuf<unsigned long long> badbits;
+    bool have_bal = false;
     DevBuf<pup::IdxBlock> idx;
     DevBuf<pup::IdxChrom> idx_chrom;
     int n_chrom = 0;
@@ -213,7 +216,7 @@ void pup_destroy(pup_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     collect_events(c);
-    c->indptr.release(); c->px.release(); c->cnt32.release(); c->idx.release(); c->idx_chrom.release(); c->weight.release(); c->cov.release(); c->expv.release();
+    c->indptr.release(); c->px.release(); c->cnt32.release(); c->bal.release(); c->badbits.release(); c->idx.release(); c->idx_chrom.release(); c->weight.release(); c->cov.release(); c->expv.release();
     c->acc_f64.release(); c->acc_i64.release();
     c->d_r0.release(); c->d_c0.release(); c->d_chunk_flip.release();
     c->d_chunk_begin.release(); c->d_chunk_end.release(); c->d_seg1.release(); c->d_seg2.release();
@@ -278,7 +281,7 @@ int pup_load_pixels(pup_ctx* c, const int64_t* bin1_offset, const void* bin2_id,
     if (d_cnt) (void)hipFree(d_cnt);
     if (status != PUP_OK) return status;
     c->nbins = nbins; c->nnz = nnz; c->have_px = true;
-    c->have_weight = c->have_cov = false;
+    c->have_weight = c->have_cov = false; c->have_bal = false;
     return PUP_OK;
 }
 
@@ -330,7 +333,7 @@ int pup_load_bins(pup_ctx* c, const double* weight, const double* cov) {
     if (!c->have_px) return fail(c, PUP_ESTATE, "pup_load_bins: call pup_load_pixels first");
     int rc = bind(c); if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->have_weight = c->have_cov = false;
+    c->have_weight = c->have_cov = false; c->have_bal = false;
     if (weight) {
         HIPCHK(c, c->weight.reserve((size_t)c->nbins));
         HIPCHK(c, hipMemcpy(c->weight.p, weight, (size_t)c->nbins * sizeof(double), hipMemcpyHostToDevice));
@@ -341,6 +344,20 @@ int pup_load_bins(pup_ctx* c, const double* weight, const double* cov) {
         HIPCHK(c, hipMemcpy(c->cov.p, cov, (size_t)c->nbins * sizeof(double), hipMemcpyHostToDevice));
         c->have_cov = true;
     }
+    // per (table, weight column): balanced pixel values + masked-bin bitmap for the register-tile kernel
+    const long long nwords = c->nbins / 64 + 3;
+    HIPCHK(c, c->bal.reserve((size_t)c->nnz + 64));
+    HIPCHK(c, c->badbits.reserve((size_t)nwords));
+    HIPCHK(c, hipMemsetAsync(c->bal.p + c->nnz, 0, 64 * sizeof(double), c->stream));
+    const double* dw = c->have_weight ? c->weight.p : nullptr;
+    const unsigned gb = (unsigned)std::min<long long>((c->nbins + 3) / 4, 1 << 20);
+    hipLaunchKernelGGL(pup::balance_pixels_kernel, dim3(gb), dim3(256), 0, c->stream,
+                       c->indptr.p, c->px.p, dw, c->bal.p, c->nbins);
+    hipLaunchKernelGGL(pup::badbits_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, c->stream,
+                       dw, c->badbits.p, c->nbins, nwords);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_bal = true;
     return PUP_OK;
 }
 
@@ -381,6 +398,7 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, 
                    const int64_t* flip_from, int32_t ignore_diags, uint32_t mode) {
     if (!c) return PUP_EINVAL;
     if (!c->have_px) return fail(c, PUP_ESTATE, "pup_accumulate: no pixel table loaded");
+    if (!c->have_bal) return fail(c, PUP_ESTATE, "pup_accumulate: call pup_load_bins first (weights or NULL for raw)");
     if (c->T <= 0) return fail(c, PUP_ESTATE, "pup_accumulate: call pup_reset first");
     if (n < 0 || !tile_ptr || (n > 0 && (!r0 || !c0)))
         return fail(c, PUP_EINVAL, "pup_accumulate: NULL snippet arrays or negative n");
@@ -475,6 +493,7 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, 
     // ---- K1 ---------------------------------------------------------------------------------------
     pup::K1Args a{};
     a.indptr = c->indptr.p; a.px = c->px.p; a.cnt32 = c->cnt32.p;
+    a.bal = c->bal.p; a.badbits = c->badbits.p;
     const bool use_idx = c->have_idx && !(c->variant & 1);
     a.idx = use_idx ? c->idx.p : nullptr; a.idx_chrom = use_idx ? c->idx_chrom.p : nullptr;
     a.n_chrom = use_idx ? c->n_chrom : 0;

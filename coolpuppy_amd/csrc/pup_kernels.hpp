@@ -56,7 +56,11 @@ struct K1Args {
     // resident tables
     const long long* indptr;   // [nbins+1]
     const int2*      px;       // [nnz] {col, count}
-    const int*       cnt32;    // [nnz] counts only (indexed path reads 4 B per pixel)
+    const int*       cnt32;    // [nnz+64] counts only (LDS-tile kernel, indexed path)
+    const double*    bal;      // [nnz+64] balanced value of every pixel, count*w[row]*w[col] (0 where a weight is
+                               //          NaN; plain count when raw) — what get_data() yields, computed once per
+                               //          (table, weight column); read by the register-tile kernel
+    const unsigned long long* badbits;  // [nbins/64 + 3] bit b of word k set <=> bin 64k+b has a NaN weight
     const IdxBlock*  idx;      // rank-bitmap index or nullptr
     const IdxChrom*  idx_chrom;
     int              n_chrom;
@@ -324,20 +328,21 @@ __device__ __forceinline__ RowLoc search_row_chunk(const K1Args& a, int r, int c
 // ---- K1r: register-tile variant for small windows (W <= 32) ----------------------------------------------
 // Lane (p, k) owns the CH = ceil(W / NCH) cells of window row p, columns [k*CH, (k+1)*CH), NCH = 64 / W, for
 // EVERY snippet of the chunk: sum (f64) and num (u32) of those cells live in registers, so the hot loop has no
-// LDS traffic, no atomics and no barrier.  Per snippet a lane (1) reads ONE 64-byte index line of its row
-// (or binary-searches the row when the window is not cis / no index) to get the position of the first pixel
-// of its column chunk and the chunk's presence bits, (2) issues one 4-byte count load per owned cell, all
-// independent and unconditional, (3) applies weights / masks / expected in registers with selects (the loop
-// body is straight-line: no per-lane branches).  The next snippet's index line and weights are requested
-// before the current snippet's arithmetic; the loop is unrolled x2 over two register sets so the pipeline
-// needs no register copies.  The flip / transpose cell mapping is applied once, at the chunk's flush.
-template <int CH>
+// LDS traffic, no atomics and no barrier.  Per snippet a lane
+//   (1) reads ONE 64-byte index line of its row (or binary-searches the row when the window is not cis / there
+//       is no index) -> position of the first pixel of its column chunk + the chunk's presence bits,
+//   (2) reads the masked-bin bits of its row and of its columns (one word + one word pair),
+//   (3) issues one 8-byte load per owned cell of the pre-balanced pixel value (count*w_row*w_col, exactly the
+//       product the reference forms once per region in get_data), all independent and unconditional,
+//   (4) adds with selects: the loop body is straight-line, no per-lane branches.
+// The next snippet's index line and mask words are requested before the current snippet's arithmetic; the loop
+// is unrolled x2 over two register sets so the pipeline needs no register copies.  The flip / transpose cell
+// mapping is applied once, at the chunk's flush.
 struct RtStage {
     unsigned long long p0, cur, nxt;   // raw index words
+    unsigned long long rw, cw0, cw1;   // masked-bin words: row, columns
     unsigned           cum;
     int                sh;             // bit offset of the lane's chunk inside `cur`
-    double             wr;
-    double             wc[CH];
     long long          spos;           // search path: position / bits already resolved
     unsigned           sbits;
     int                r0, c0;         // wave-uniform
@@ -370,12 +375,8 @@ __global__ __launch_bounds__(kWave) void pileup_regtile_kernel(K1Args a) {
 
     double   sum[CH];
     unsigned num[CH];
-    int      thr[CH];        // cell i passes the diagonal mask iff (c0 - r0) >= thr[i]
 #pragma unroll
-    for (int i = 0; i < CH; ++i) {
-        sum[i] = 0.0; num[i] = 0u;
-        thr[i] = igd < 0 ? (int)0x80000000 : igd - (qs + i - p);
-    }
+    for (int i = 0; i < CH; ++i) { sum[i] = 0.0; num[i] = 0u; }
     if (m_cov) {
         for (int t = lane; t < 2 * W; t += kWave) cov_lds[t] = 0.0;
         __syncthreads();
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(kWave) void pileup_regtile_kernel(K1Args a) {
     int ch_start = 0, ch_end = -1, ch_nblk = 0; long long ch_base = 0;
 
     // request everything snippet s needs that does not depend on other loads
-    auto issue = [&](RtStage<CH>& g, long long s) __attribute__((always_inline)) {
+    auto issue = [&](RtStage& g, long long s) __attribute__((always_inline)) {
         g.valid = false; g.indexed = false;
         if (s >= ce) return;
         g.r0 = __builtin_amdgcn_readfirstlane(a.r0[s]);
@@ -424,21 +425,12 @@ __global__ __launch_bounds__(kWave) void pileup_regtile_kernel(K1Args a) {
             const RowLoc loc = search_row_chunk<CH>(a, r, g.c0 + qs, nprobe);
             g.spos = loc.pos; g.sbits = loc.bits;
         }
-        if (a.weight) {
-            g.wr = a.weight[r];
-#pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                const int c = g.c0 + qs + i;
-                g.wc[i] = a.weight[c < a.nbins ? c : (int)a.nbins - 1];
-            }
-        } else {
-            g.wr = 1.0;
-#pragma unroll
-            for (int i = 0; i < CH; ++i) g.wc[i] = 1.0;
-        }
+        g.rw = a.badbits[r >> 6];
+        const unsigned long long* bw = a.badbits + ((g.c0 + qs) >> 6);
+        g.cw0 = bw[0]; g.cw1 = bw[1];
     };
 
-    auto process = [&](const RtStage<CH>& g) __attribute__((always_inline)) {
+    auto process = [&](const RtStage& g) __attribute__((always_inline)) {
         if (!g.valid) return;                                          // wave-uniform
         long long pos; unsigned bits;
         if (g.indexed) {
@@ -447,16 +439,29 @@ __global__ __launch_bounds__(kWave) void pileup_regtile_kernel(K1Args a) {
             bits = (unsigned)b64 & chmask;
             pos = (long long)(g.p0 + g.cum + (unsigned long long)__popcll(g.cur & ((1ull << g.sh) - 1ull)));
         } else { pos = g.spos; bits = g.sbits & chmask; }
-        // one count load per cell, addresses known up front (cnt32 is padded: a cell without a pixel reads a
-        // neighbouring count that is then discarded)
-        int cnt[CH];
+        // one value load per cell, addresses known up front (bal is padded: a cell without a pixel reads a
+        // neighbouring value that is then discarded)
+        double v[CH];
 #pragma unroll
-        for (int i = 0; i < CH; ++i) cnt[i] = a.cnt32[pos + __popc(bits & ((1u << i) - 1u))];
+        for (int i = 0; i < CH; ++i) v[i] = a.bal[pos + __popc(bits & ((1u << i) - 1u))];
+        // validity of the lane's cells as a bit mask: bin masks, diagonal mask
+        const int r = g.r0 + p, cc = g.c0 + qs;
+        const unsigned rowbad = (unsigned)(g.rw >> (r & 63)) & 1u;
+        const int csh = cc & 63;
+        unsigned long long cb64 = g.cw0 >> csh;
+        if (csh) cb64 |= g.cw1 << (64 - csh);
+        unsigned ok = chmask & ~(unsigned)cb64;
+        if (rowbad) ok = 0u;
+        if (igd >= 0) {
+            // cell i is on or above the first kept diagonal iff (c0+qs+i) - (r0+p) >= igd  <=>  i >= t0
+            const int t0 = igd - (cc - r);
+            ok &= t0 <= 0 ? 0xffffffffu : (t0 >= 32 ? 0u : ~((1u << t0) - 1u));
+        }
         double ev[CH];
         if (OOE) {
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
-                long long ad = (long long)(g.c0 + qs + i) - (g.r0 + p); if (ad < 0) ad = -ad;
+                long long ad = (long long)(cc + i) - r; if (ad < 0) ad = -ad;
                 const long long ai = (a.nexp == 1) ? 0 : (ad < a.nexp ? ad : 0);
                 const double e = use_exp ? a.expv[ai] : qnan;
                 ev[i] = (a.nexp == 1 || ad < a.nexp) ? e : qnan;
@@ -464,29 +469,30 @@ __global__ __launch_bounds__(kWave) void pileup_regtile_kernel(K1Args a) {
         }
         if (m_cov) {
             if (lane_ok && k == 0) {
-                const double cr = a.cov[g.r0 + p], cc = a.cov[g.c0 + p];
-                const double vs = m_tr ? cc : cr, ve = m_tr ? cr : cc;
+                const double cr = a.cov[g.r0 + p], cv = a.cov[g.c0 + p];
+                const double vs = m_tr ? cv : cr, ve = m_tr ? cr : cv;
                 if (vs == vs) cov_lds[p] += vs;                        // one lane per element: no race
                 if (ve == ve) cov_lds[W + p] += ve;
             }
         }
         npix += (unsigned long long)__popc(bits);
-        const int D = g.c0 - g.r0;
-        const bool rowok = (g.wr == g.wr);
+        const unsigned addm = ok & bits;                                // cells that hold a pixel and are unmasked
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            const bool cell = (chmask >> i) & 1u;                       // lane-constant
-            bool ok = cell && rowok && (g.wc[i] == g.wc[i]) && (D >= thr[i]);
-            double val = (double)cnt[i] * g.wr * g.wc[i];
-            if (OOE) { ok = ok && (ev[i] == ev[i]) && (ev[i] != 0.0); val = val / ev[i]; }
-            num[i] += ok ? 1u : 0u;
-            // nansum semantics: add unless NaN (masked cells are NaN by construction: diagonal mask / NaN weight)
-            const bool add = ((bits >> i) & 1u) && (val == val) && (D >= thr[i]);
-            sum[i] += add ? val : 0.0;
+            if (OOE) {
+                // reference: data / exp; NaN results (exp NaN, 0/0) are skipped, inf is kept by nansum
+                const double q = v[i] / ev[i];
+                const bool okn = ((ok >> i) & 1u) && (ev[i] == ev[i]) && (ev[i] != 0.0);
+                num[i] += okn ? 1u : 0u;
+                sum[i] += (((addm >> i) & 1u) && (q == q)) ? q : 0.0;
+            } else {
+                num[i] += (ok >> i) & 1u;
+                sum[i] += ((addm >> i) & 1u) ? v[i] : 0.0;
+            }
         }
     };
 
-    RtStage<CH> A, B;
+    RtStage A, B;
     issue(A, cb);
     for (long long s = cb; s < ce; s += 2) {
         issue(B, s + 1);
@@ -517,6 +523,41 @@ __global__ __launch_bounds__(kWave) void pileup_regtile_kernel(K1Args a) {
         atomicAdd(&a.counters[0], npix);
         atomicAdd(&a.counters[1], nprobe);
     }
+}
+
+// ---- per (table, weight column) precomputation ---------------------------------------------------------------
+// balanced value of every pixel (one wave per row) — the product PileUpper.get_data() obtains from
+// cooler's matrix(balance=w) once per region (coolpup.py:1053-1055), evaluated in the same order
+// (count * w[row]) * w[col]; NaN (masked bin) is stored as 0 and masked through badbits instead
+__global__ __launch_bounds__(256) void balance_pixels_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
+                                                             const double* __restrict__ weight, double* __restrict__ bal,
+                                                             long long nbins) {
+    const int lane = threadIdx.x & 63;
+    long long r = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long stride = (long long)gridDim.x * (blockDim.x >> 6);
+    for (; r < nbins; r += stride) {
+        const double wr = weight ? weight[r] : 1.0;
+        const long long b = indptr[r], e = indptr[r + 1];
+        for (long long k = b + lane; k < e; k += 64) {
+            const int2 pc = px[k];
+            double v = (double)pc.y;
+            if (weight) { v = v * wr * weight[pc.x]; if (!(v == v)) v = 0.0; }
+            bal[k] = v;
+        }
+    }
+}
+
+__global__ void badbits_kernel(const double* __restrict__ weight, unsigned long long* __restrict__ badbits,
+                               long long nbins, long long nwords) {
+    const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwords) return;
+    unsigned long long m = 0;
+    if (weight)
+        for (int b = 0; b < 64; ++b) {
+            const long long i = w * 64 + b;
+            if (i < nbins && !(weight[i] == weight[i])) m |= 1ull << b;
+        }
+    badbits[w] = m;
 }
 
 // ---- index construction (once per pixel table) ---------------------------------------------------------
