@@ -1,0 +1,53 @@
+"""CPU tests of the drop-in boundary: the shared library loads and exports every symbol include/pup_hip.h
+declares, the Python binding covers exactly that set, and argument errors are reported without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "pup_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pup_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound(hip_lib):
+    from coolpuppy_amd import _ffi
+    declared = _declared()
+    assert len(declared) >= 20
+    assert declared == _ffi.declared_symbols(), "ctypes binding and header disagree"
+    raw = C.CDLL(_ffi.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} is declared in include/pup_hip.h but not exported by libpup_hip.so"
+
+
+def test_version_and_null_handling(hip_lib):
+    assert hip_lib.pup_version() >= 100
+    assert isinstance(hip_lib.pup_last_error(None), bytes)
+    # NULL context: every entry point must return PUP_EINVAL, never crash
+    assert hip_lib.pup_sync(None) == -1
+    assert hip_lib.pup_reset(None, 1, 1) == -1
+    assert hip_lib.pup_create(0, None) == -1
+
+
+def test_no_cpu_fallback_in_product():
+    """The product package never imports the oracle (a fallback would void the parity claims)."""
+    pkg = os.path.join(ROOT, "coolpuppy_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f"{f} references the oracle"
+                assert "liboracle" not in src, f
+
+
+def test_missing_library_is_loud(monkeypatch, tmp_path):
+    from coolpuppy_amd import _ffi
+    monkeypatch.setattr(_ffi, "_lib", None)
+    monkeypatch.setattr(_ffi, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="not found"):
+        _ffi.lib()
