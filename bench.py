@@ -226,7 +226,9 @@ def main():
             except Exception:
                 traffic = None
         roofline = {
-            "bound": "hbm", "kernel": "pileup_chunk_kernel<21>", "achieved": round(achieved, 1),
+            "bound": "hbm",
+            "kernel": (f"pup::pileup_regtile_kernel<{W}, false>" if W <= 31 else f"pup::pileup_chunk_kernel<{W}>"),
+            "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBPS * a.gpus, "unit": "GB/s", "frac": round(achieved / (HBM_PEAK_GBPS * a.gpus), 4),
             "traffic": traffic, "kernel_ms_per_launch": round(k1_ms_per_launch, 4),
             "algorithmic_bytes_per_launch": round(alg_bytes_total / a.steps / a.gpus),

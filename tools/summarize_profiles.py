@@ -1,0 +1,79 @@
+"""Dev tool: condense gpurun_out/prof (rocprofv3 passes of bench.py, see tools/profile_bench.sh) into profiles/.
+
+Writes profiles/<tag>_kernel_stats.csv (the --stats summary), profiles/<tag>_pmc_summary.json (per-kernel
+counter means) and profiles/traffic.json (HBM bytes per K1 launch, used by bench.py's roofline.traffic).
+FETCH_SIZE calibration: balance_pixels_kernel streams a KNOWN byte count (8 B/pixel read, 8 B/pixel written)
+in the same runs, so its counters give the bytes-per-count factor for this access width on this machine.
+"""
+import glob
+import json
+import os
+import shutil
+import sys
+
+import pandas as pd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+prof = os.path.join(ROOT, "gpurun_out", "prof")
+out = os.path.join(ROOT, "profiles")
+os.makedirs(out, exist_ok=True)
+
+stats = glob.glob(os.path.join(prof, "stats", "*", "*_kernel_stats.csv"))[0]
+shutil.copy(stats, os.path.join(out, f"{tag}_kernel_stats.csv"))
+bench = json.loads(open(os.path.join(prof, "stats_bench.json")).read().strip().splitlines()[-1])
+nnz = bench["config"]["nnz"]
+
+summary = {}
+for d in sorted(glob.glob(os.path.join(prof, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    f = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+    if not f:
+        continue
+    df = pd.read_csv(f[0])
+    tr = pd.read_csv(glob.glob(os.path.join(d, "*", "*_kernel_trace.csv"))[0])
+    tr["ms"] = (tr.End_Timestamp - tr.Start_Timestamp) / 1e6
+    for kname, g in df.groupby("Kernel_Name"):
+        if "pup::" not in kname:
+            continue
+        short = kname.split("(")[0].replace("void ", "")
+        e = summary.setdefault(short, {"counters": {}})
+        for cname, gg in g.groupby("Counter_Name"):
+            e["counters"][cname] = {"mean_per_launch": float(gg.Counter_Value.mean()), "launches": int(len(gg))}
+        e["ms_per_launch_under_pmc"] = float(tr[tr.Kernel_Name == kname].ms.mean())
+        e["vgpr"] = int(g.VGPR_Count.iloc[0]); e["agpr"] = int(g.Accum_VGPR_Count.iloc[0])
+        e["lds_bytes"] = int(g.LDS_Block_Size.iloc[0])
+
+k1 = next(k for k in summary if "pileup_" in k)
+cal = next((k for k in summary if "balance_pixels" in k), None)
+doc = {"bench_line_under_rocprof": bench, "kernels": summary,
+       "units": "FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB"}
+fetch_kib = summary[k1]["counters"]["FETCH_SIZE"]["mean_per_launch"]
+write_kib = summary[k1]["counters"]["WRITE_SIZE"]["mean_per_launch"]
+factor = 2.0      # MI355X_MICROARCH.md: gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced reads
+if cal:
+    known_read = nnz * 8.0
+    cal_fetch = summary[cal]["counters"]["FETCH_SIZE"]["mean_per_launch"] * 1024
+    cal_write = summary[cal]["counters"]["WRITE_SIZE"]["mean_per_launch"] * 1024
+    doc["calibration"] = {"kernel": cal, "known_read_bytes": known_read, "known_write_bytes": nnz * 8.0,
+                          "FETCH_SIZE_bytes": cal_fetch, "WRITE_SIZE_bytes": cal_write,
+                          "read_bytes_per_counted_byte": known_read / cal_fetch,
+                          "write_bytes_per_counted_byte": nnz * 8.0 / cal_write}
+    factor = known_read / cal_fetch
+hbm = fetch_kib * 1024 * factor + write_kib * 1024
+doc["k1"] = {"kernel": k1, "FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib, "fetch_correction_factor": factor,
+             "hbm_bytes_per_launch": hbm,
+             "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"]}
+json.dump(doc, open(os.path.join(out, f"{tag}_pmc_summary.json"), "w"), indent=1)
+key = None
+import hashlib
+c = bench["config"]
+# must match bench._cache_path(): v3|chroms|lam|pairs|nshifts|pad  (defaults: 23 chroms, lam 4200)
+key = "coolpuppy_amd_bench_" + hashlib.sha1(f"v3|23|4200.0|{c['pairs']}|{c['nshifts']}|{c['pad']}".encode()).hexdigest()[:12] + ".npz"
+json.dump({"workload_key": key, "hbm_bytes_per_launch": hbm, "kernel": k1, "source": f"profiles/{tag}_pmc_summary.json",
+           "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB->bytes, FETCH_SIZE x calibration "
+                     "factor measured on balance_pixels_kernel (known 8 B/pixel stream) in the same run"},
+          open(os.path.join(out, "traffic.json"), "w"), indent=1)
+print(json.dumps(doc["k1"], indent=1)); print(json.dumps(doc.get("calibration"), indent=1))
+print(open(os.path.join(out, f"{tag}_kernel_stats.csv")).read()[:1500])
