@@ -66,6 +66,7 @@ struct pup_ctx {
     // workspaces
     DevBuf<int> d_r0, d_c0;
     DevBuf<unsigned char> d_chunk_flip;
+    DevBuf<int> d_chunk_stride, d_block_chunk;
     DevBuf<long long> d_chunk_begin, d_chunk_end, d_seg1, d_seg2, d_dn;
     DevBuf<double> part_f64, slice_f64;
     DevBuf<unsigned> part_num;
@@ -78,7 +79,7 @@ struct pup_ctx {
     struct EvTriple { hipEvent_t a, b, c; };   // K1 = a..b, reduction = b..c
     std::vector<EvTriple> pending;             // awaiting a stream sync
     hipEvent_t slots[8] = {};
-    int chunk_snippets = 0, variant = 0;
+    int chunk_snippets = 0, variant = 0, group_waves = 0;
     int max_lds = 0, n_cu = 0;
 };
 
@@ -218,7 +219,7 @@ void pup_destroy(pup_ctx* c) {
     collect_events(c);
     c->indptr.release(); c->px.release(); c->cnt32.release(); c->bal.release(); c->badbits.release(); c->idx.release(); c->idx_chrom.release(); c->weight.release(); c->cov.release(); c->expv.release();
     c->acc_f64.release(); c->acc_i64.release();
-    c->d_r0.release(); c->d_c0.release(); c->d_chunk_flip.release();
+    c->d_r0.release(); c->d_c0.release(); c->d_chunk_flip.release(); c->d_chunk_stride.release(); c->d_block_chunk.release();
     c->d_chunk_begin.release(); c->d_chunk_end.release(); c->d_seg1.release(); c->d_seg2.release();
     c->d_dn.release();
     c->part_f64.release(); c->slice_f64.release(); c->part_num.release(); c->slice_num.release();
@@ -436,39 +437,66 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, 
         dr0 = c->d_r0.p; dc0 = c->d_c0.p;
     }
 
-    // ---- chunk table: equal snippet counts, cut at tile boundaries -------------------------------
+    // ---- chunk table -------------------------------------------------------------------------------------
+    // A chunk = the snippets one wave accumulates (one tile, one flip state).  Chunks come in GROUPS: a group
+    // owns a contiguous range of the (position-sorted) snippets and its S chunks interleave over it (chunk j
+    // takes range[j], range[j+S], ...), so the waves of a group walk the same few matrix rows together and
+    // the rows stay in the XCD's L2.  Groups are dealt round-robin to the 8 XCDs; workgroup b runs on XCD
+    // b % 8 (observed dispatch rule, used for speed only), so a group's chunks get ids b = xcd + 8*i.
     long long C = c->chunk_snippets;
     if (C <= 0) {
         const long long target = (long long)std::max(c->n_cu, 64) * 32 * 4;   // ~4 chunks per wave slot
         C = std::max<long long>(16, (n + target - 1) / target);
     }
+    const int S = c->group_waves > 0 ? c->group_waves : 128;
+    const int n_xcd = 8;
     std::vector<long long> cb, ce, tile_chunk_ptr((size_t)c->T + 1, 0), dn((size_t)c->T);
     std::vector<unsigned char> cf;
+    std::vector<int> cs;
+    std::vector<std::vector<int>> xcd_list((size_t)n_xcd);
+    long long group_no = 0;
+    auto add_run = [&](long long b, long long e, unsigned char flip) {
+        for (long long g0 = b; g0 < e; g0 += (long long)S * C) {
+            const long long g1 = std::min(e, g0 + (long long)S * C);
+            const int waves = (int)std::min<long long>(S, std::max<long long>(1, (g1 - g0 + 15) / 16));
+            auto& lst = xcd_list[(size_t)(group_no++ % n_xcd)];
+            for (int j = 0; j < waves; ++j) {
+                lst.push_back((int)cb.size());
+                cb.push_back(g0 + j); ce.push_back(g1); cs.push_back(waves); cf.push_back(flip);
+            }
+        }
+    };
     for (int t = 0; t < c->T; ++t) {
         const long long b = tile_ptr[t], e = tile_ptr[t + 1];
         const long long f = flip_from ? flip_from[t] : e;          // [b, f) as is, [f, e) flipped
         dn[(size_t)t] = e - b;
-        for (long long s = b; s < f; s += C) { cb.push_back(s); ce.push_back(std::min(f, s + C)); cf.push_back(0); }
-        for (long long s = f; s < e; s += C) { cb.push_back(s); ce.push_back(std::min(e, s + C)); cf.push_back(1); }
+        add_run(b, f, 0);
+        add_run(f, e, 1);
         tile_chunk_ptr[(size_t)t + 1] = (long long)cb.size();
     }
+    size_t per_xcd = 0;
+    for (auto& l : xcd_list) per_xcd = std::max(per_xcd, l.size());
+    std::vector<int> block_chunk(per_xcd * (size_t)n_xcd, -1);
+    for (int x = 0; x < n_xcd; ++x)
+        for (size_t i = 0; i < xcd_list[(size_t)x].size(); ++i) block_chunk[i * (size_t)n_xcd + (size_t)x] = xcd_list[(size_t)x][i];
+    const long long nblocks = (long long)block_chunk.size();
     const long long nchunks = (long long)cb.size();
-    if (nchunks > 0x7fffffffLL) return fail(c, PUP_ENOTSUP, "pup_accumulate: too many chunks");
+    if (nchunks > 0x7fffffffLL || nblocks > 0x7fffffffLL) return fail(c, PUP_ENOTSUP, "pup_accumulate: too many chunks");
     if (C > 0xffffffffLL) return fail(c, PUP_ENOTSUP, "pup_accumulate: chunk too long for 32-bit num partials");
 
     // two-level reduction plan: chunks -> slices of <= S chunks (within a tile) -> tiles
-    const long long S = 64;
+    const long long SL = 64;
     long long max_per_tile = 0;
     for (int t = 0; t < c->T; ++t)
         max_per_tile = std::max(max_per_tile, tile_chunk_ptr[(size_t)t + 1] - tile_chunk_ptr[(size_t)t]);
-    const bool two_level = max_per_tile > 2 * S;
+    const bool two_level = max_per_tile > 2 * SL;
     std::vector<long long> seg1, seg2;   // seg1: slice -> chunk range; seg2: tile -> slice (or chunk) range
     if (two_level) {
         seg2.assign((size_t)c->T + 1, 0);
         seg1.push_back(0);
         for (int t = 0; t < c->T; ++t) {
             const long long b = tile_chunk_ptr[(size_t)t], e = tile_chunk_ptr[(size_t)t + 1];
-            for (long long k = b; k < e; k += S) seg1.push_back(std::min(e, k + S));
+            for (long long k = b; k < e; k += SL) seg1.push_back(std::min(e, k + SL));
             seg2[(size_t)t + 1] = (long long)seg1.size() - 1;
         }
     } else seg2 = tile_chunk_ptr;
@@ -482,6 +510,10 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, 
     HIPCHK(c, hipMemcpy(c->d_chunk_end.p, ce.data(), (size_t)nchunks * 8, hipMemcpyHostToDevice));
     HIPCHK(c, c->d_chunk_flip.reserve((size_t)nchunks));
     HIPCHK(c, hipMemcpy(c->d_chunk_flip.p, cf.data(), (size_t)nchunks, hipMemcpyHostToDevice));
+    HIPCHK(c, c->d_chunk_stride.reserve((size_t)nchunks));
+    HIPCHK(c, hipMemcpy(c->d_chunk_stride.p, cs.data(), (size_t)nchunks * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, c->d_block_chunk.reserve((size_t)nblocks));
+    HIPCHK(c, hipMemcpy(c->d_block_chunk.p, block_chunk.data(), (size_t)nblocks * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_seg2.p, seg2.data(), seg2.size() * 8, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_dn.p, dn.data(), (size_t)c->T * 8, hipMemcpyHostToDevice));
     if (two_level) {
@@ -502,6 +534,7 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, 
     a.expv = c->nexp > 0 ? c->expv.p : nullptr; a.nexp = c->nexp; a.nbins = c->nbins;
     a.r0 = dr0; a.c0 = dc0;
     a.chunk_begin = c->d_chunk_begin.p; a.chunk_end = c->d_chunk_end.p; a.chunk_flip = c->d_chunk_flip.p;
+    a.chunk_stride = c->d_chunk_stride.p; a.block_chunk = c->d_block_chunk.p;
     a.part_f64 = c->part_f64.p; a.part_num = c->part_num.p;
     a.counters = c->counters.p; a.err = c->d_err.p;
     a.W = W; a.ignore_diags = ignore_diags; a.mode = mode;
@@ -513,12 +546,12 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, 
         HIPCHK(c, hipEventRecord(e0, c->stream));
     }
     // small windows: register-tile kernel; EXPECTED-only passes, wide windows and variant&2: LDS-tile kernel
-    const bool regtile = !m_exp && !(c->variant & 2) && launch_regtile(W, a, (int)nchunks, c->stream);
+    const bool regtile = !m_exp && !(c->variant & 2) && launch_regtile(W, a, (int)nblocks, c->stream);
     if (!regtile) {
         switch (W) {
-            case 21: launch_k1<21>(a, (int)nchunks, lds, c->stream); break;
-            case 51: launch_k1<51>(a, (int)nchunks, lds, c->stream); break;
-            default: launch_k1<0>(a, (int)nchunks, lds, c->stream); break;
+            case 21: launch_k1<21>(a, (int)nblocks, lds, c->stream); break;
+            case 51: launch_k1<51>(a, (int)nblocks, lds, c->stream); break;
+            default: launch_k1<0>(a, (int)nblocks, lds, c->stream); break;
         }
     }
     HIPCHK(c, hipGetLastError());
@@ -654,7 +687,7 @@ int pup_event_elapsed_ms(pup_ctx* c, int a, int b, float* ms) {
 int pup_set_tuning(pup_ctx* c, int32_t chunk_snippets, int32_t variant) {
     if (!c) return PUP_EINVAL;
     if (chunk_snippets < 0) return fail(c, PUP_EINVAL, "pup_set_tuning: negative chunk size");
-    c->chunk_snippets = chunk_snippets; c->variant = variant;
+    c->chunk_snippets = chunk_snippets; c->variant = variant & 0xff; c->group_waves = (variant >> 8) & 0xffff;
     return PUP_OK;
 }
 

@@ -76,6 +76,11 @@ struct K1Args {
     const long long* chunk_begin;  // [nchunks]
     const long long* chunk_end;    // [nchunks]
     const unsigned char* chunk_flip;  // [nchunks] non-zero: anti-transpose these snippets (flip_snip_func)
+    const int*       chunk_stride; // [nchunks] the chunk takes snippets begin, begin+stride, ... < end: the waves of
+                                   //           one group interleave over a contiguous snippet range so that what an
+                                   //           XCD works on at any moment is a few consecutive rows (L2-resident)
+    const int*       block_chunk;  // [gridDim.x] chunk executed by each workgroup (-1: none); groups are laid out
+                                   //           so that workgroups b, b+8, b+16, ... (one XCD) share a group
     // per-chunk partial outputs
     double*   part_f64;   // [nchunks][W2 + 2W]   (sum | cov_start | cov_end)
     unsigned* part_num;   // [nchunks][W2]
@@ -155,18 +160,21 @@ __global__ __launch_bounds__(kWave) void pileup_chunk_kernel(K1Args a) {
     const int  igd     = a.ignore_diags;
     const bool have_idx = a.idx != nullptr && W <= 64;
 
+    const int ck = a.block_chunk[blockIdx.x];
+    if (ck < 0) return;                                          // padding workgroup (wave-uniform)
     for (int t = lane; t < W2; t += kWave) { tsum[t] = 0.0; tnum[t] = 0u; }
     for (int t = lane; t < 2 * W; t += kWave) covs[t] = 0.0;   // covs and cove are contiguous
     __syncthreads();
 
-    const long long cb = a.chunk_begin[blockIdx.x];
-    const long long ce = a.chunk_end[blockIdx.x];
-    const int fl = a.chunk_flip[blockIdx.x];
+    const long long cb = a.chunk_begin[ck];
+    const long long ce = a.chunk_end[ck];
+    const long long cstep = a.chunk_stride[ck];
+    const int fl = a.chunk_flip[ck];
     unsigned long long npix = 0, nprobe = 0;
     // chromosome of the previous snippet (snippets arrive sorted: the lookup is almost always a hit)
     int ch_start = 0, ch_end = -1, ch_nblk = 0; long long ch_base = 0;
 
-    for (long long s = cb; s < ce; ++s) {
+    for (long long s = cb; s < ce; s += cstep) {
         const int r0s = __builtin_amdgcn_readfirstlane(a.r0[s]);
         const int c0s = __builtin_amdgcn_readfirstlane(a.c0[s]);
         if (r0s < 0 || c0s < 0 || (long long)r0s + W > a.nbins || (long long)c0s + W > a.nbins) {
@@ -286,8 +294,8 @@ __global__ __launch_bounds__(kWave) void pileup_chunk_kernel(K1Args a) {
 
     // ---- flush the chunk's partial tile ---------------------------------------------------------
     const size_t L = (size_t)W2 + 2 * (size_t)W;
-    double*   of = a.part_f64 + (size_t)blockIdx.x * L;
-    unsigned* on = a.part_num + (size_t)blockIdx.x * W2;
+    double*   of = a.part_f64 + (size_t)ck * L;
+    unsigned* on = a.part_num + (size_t)ck * W2;
     for (int t = lane; t < W2; t += kWave) { of[t] = tsum[t]; on[t] = tnum[t]; }
     for (int t = lane; t < 2 * W; t += kWave) of[W2 + t] = covs[t];
     // wave-reduce diagnostics, one atomic per chunk
@@ -373,6 +381,8 @@ __global__ __launch_bounds__(kWave) void pileup_regtile_kernel(K1Args a) {
     const bool have_idx = a.idx != nullptr;
     const double qnan = __builtin_nan("");
 
+    const int ck = a.block_chunk[blockIdx.x];
+    if (ck < 0) return;                                               // padding workgroup (wave-uniform)
     double   sum[CH];
     unsigned num[CH];
 #pragma unroll
@@ -382,9 +392,10 @@ __global__ __launch_bounds__(kWave) void pileup_regtile_kernel(K1Args a) {
         __syncthreads();
     }
 
-    const long long cb = a.chunk_begin[blockIdx.x];
-    const long long ce = a.chunk_end[blockIdx.x];
-    const int fl = a.chunk_flip[blockIdx.x];
+    const long long cb = a.chunk_begin[ck];
+    const long long ce = a.chunk_end[ck];
+    const long long cstep = a.chunk_stride[ck];
+    const int fl = a.chunk_flip[ck];
     unsigned long long npix = 0, nprobe = 0;
     int ch_start = 0, ch_end = -1, ch_nblk = 0; long long ch_base = 0;
 
@@ -494,18 +505,18 @@ __global__ __launch_bounds__(kWave) void pileup_regtile_kernel(K1Args a) {
 
     RtStage A, B;
     issue(A, cb);
-    for (long long s = cb; s < ce; s += 2) {
-        issue(B, s + 1);
+    for (long long s = cb; s < ce; s += 2 * cstep) {
+        issue(B, s + cstep);
         process(A);
-        issue(A, s + 2);
+        issue(A, s + 2 * cstep);
         process(B);
     }
 
     // ---- flush: window frame -> accumulator frame (transpose, then anti-transpose when flipped) ----------
     if (m_cov) __syncthreads();
     const size_t L = (size_t)W2 + 2 * (size_t)W;
-    double*   of = a.part_f64 + (size_t)blockIdx.x * L;
-    unsigned* on = a.part_num + (size_t)blockIdx.x * W2;
+    double*   of = a.part_f64 + (size_t)ck * L;
+    unsigned* on = a.part_num + (size_t)ck * W2;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
         if ((chmask >> i) & 1u) {

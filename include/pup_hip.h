@@ -162,7 +162,8 @@ int pup_clear_stats(pup_ctx* ctx);
 /* generic stream timer: record slot (0..7) on the context's stream; elapsed between two slots */
 int pup_event_record(pup_ctx* ctx, int slot);
 int pup_event_elapsed_ms(pup_ctx* ctx, int slot_begin, int slot_end, float* ms);
-/* tuning knobs (0 = library default): snippets per chunk; variant 1 = ignore the index (binary search only) */
+/* tuning knobs (0 = library default): snippets per chunk (per wave); variant bit 0 = ignore the index (binary
+ * search only), bit 1 = LDS-tile kernel for every width, bits 8..23 = waves per interleaved group */
 int pup_set_tuning(pup_ctx* ctx, int32_t chunk_snippets, int32_t variant);
 
 #ifdef __cplusplus

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--sort", type=int, default=1)
     ap.add_argument("--variant", type=int, default=0, help="1 = ignore the rank-bitmap index")
+    ap.add_argument("--group", type=str, default="0", help="comma list of waves-per-group values to sweep")
     a = ap.parse_args()
     names = list(synth.HG38)[: a.chroms]
     t = time.time()
@@ -55,23 +56,25 @@ def main():
     t = time.time(); ok = eng.build_index(clr.chrom_offset); print(f"index built={ok} {time.time()-t:.3f}s")
     eng.load_bins(clr.bins()["weight"][:].values, None)
     eng.set_profiling(True)
-    eng.set_tuning(a.chunk, a.variant)
-    eng.reset(2, a.pad)
-    for rep in range(a.reps):
-        eng.clear_stats()
-        t = time.time()
-        eng.accumulate(r, c, tile_ptr, ignore_diags=2, mode=0)
-        eng.sync()
-        wall = time.time() - t
-        st = eng.stats()
-        n = len(r)
-        alg_bytes = n * (8 * (W + 1) + 16 * W + 12) + 8 * st["pixels_in_windows"]
-        print(json.dumps({"rep": rep, "wall_s": round(wall, 4), "k1_ms": round(st["k1_ms"], 3),
-                          "reduce_ms": round(st["reduce_ms"], 3),
-                          "snips_per_s_k1": round(n / (st["k1_ms"] * 1e-3)),
-                          "nnz_win_mean": round(st["pixels_in_windows"] / n, 1),
-                          "probes_per_snip": round(st["probe_loads"] / n, 1),
-                          "alg_GBps": round(alg_bytes / (st["k1_ms"] * 1e-3) / 1e9, 1)}), flush=True)
+    for grp in [int(x) for x in a.group.split(",")]:
+      eng.set_tuning(a.chunk, a.variant | (grp << 8))
+      eng.reset(2, a.pad)
+      print("group_waves", grp, flush=True)
+      for rep in range(a.reps):
+          eng.clear_stats()
+          t = time.time()
+          eng.accumulate(r, c, tile_ptr, ignore_diags=2, mode=0)
+          eng.sync()
+          wall = time.time() - t
+          st = eng.stats()
+          n = len(r)
+          alg_bytes = n * (8 * (W + 1) + 16 * W + 12) + 8 * st["pixels_in_windows"]
+          print(json.dumps({"rep": rep, "wall_s": round(wall, 4), "k1_ms": round(st["k1_ms"], 3),
+                            "reduce_ms": round(st["reduce_ms"], 3),
+                            "snips_per_s_k1": round(n / (st["k1_ms"] * 1e-3)),
+                            "nnz_win_mean": round(st["pixels_in_windows"] / n, 1),
+                            "probes_per_snip": round(st["probe_loads"] / n, 1),
+                            "alg_GBps": round(alg_bytes / (st["k1_ms"] * 1e-3) / 1e9, 1)}), flush=True)
     out = eng.fetch()
     print("n", out["n"], "center", out["sum"][:, a.pad, a.pad] / np.maximum(out["num"][:, a.pad, a.pad], 1))
 
