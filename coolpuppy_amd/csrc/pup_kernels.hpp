@@ -310,6 +310,9 @@ __global__ __launch_bounds__(kWave) void pileup_chunk_kernel(K1Args a) {
 }
 
 struct RowLoc { long long pos; unsigned bits; };
+// 16-byte loads at 8-byte aligned addresses (global_load_dwordx4 needs dword alignment only)
+struct __attribute__((packed, aligned(8))) U64x2 { unsigned long long a, b; };
+struct __attribute__((packed, aligned(8))) F64x2 { double a, b; };
 
 // binary search for a row's first pixel with column >= c_first, then the presence bits of CHW columns
 template <int CHW>
@@ -347,10 +350,9 @@ __device__ __forceinline__ RowLoc search_row_chunk(const K1Args& a, int r, int c
 // is unrolled x2 over two register sets so the pipeline needs no register copies.  The flip / transpose cell
 // mapping is applied once, at the chunk's flush.
 struct RtStage {
-    unsigned long long p0, cur, nxt;   // raw index words
-    unsigned long long rw, cw0, cw1;   // masked-bin words: row, columns
-    unsigned           cum;
-    int                sh;             // bit offset of the lane's chunk inside `cur`
+    unsigned long long p0, cums, cur, nxt;   // raw index words: position, packed cum[4], {word, word+1}
+    unsigned           rowbad, colbad; // wave-uniform: masked-bin bits of the window's W rows / W columns
+    int                ws, sh;         // word and bit offset of the lane's chunk inside the index line
     long long          spos;           // search path: position / bits already resolved
     unsigned           sbits;
     int                r0, c0;         // wave-uniform
@@ -425,20 +427,28 @@ __global__ __launch_bounds__(kWave) void pileup_regtile_kernel(K1Args a) {
         if (g.indexed) {
             const int rel = (g.c0 - ch_start) + qs;
             const int b = rel / kIdxCols, o = rel - b * kIdxCols;
-            const int ws = o >> 6;
+            g.ws = o >> 6;
             g.sh = o & 63;
-            const char* base = reinterpret_cast<const char*>(a.idx + ch_base + (long long)(r - ch_start) * ch_nblk + b);
-            g.p0  = *reinterpret_cast<const unsigned long long*>(base);
-            g.cum = *reinterpret_cast<const unsigned short*>(base + 6 + 2 * ws);
-            const unsigned long long* w = reinterpret_cast<const unsigned long long*>(base + 16 + 8 * ws);
-            g.cur = w[0]; g.nxt = w[1];
+            // two 16-byte loads from one 64-byte line: {pos, cum[4]} and {bits[ws], bits[ws+1] | next0}
+            const U64x2* base = reinterpret_cast<const U64x2*>(a.idx + ch_base + (long long)(r - ch_start) * ch_nblk + b);
+            const U64x2 h = base[0];
+            g.p0 = h.a; g.cums = h.b;
+            const U64x2 w = *reinterpret_cast<const U64x2*>(reinterpret_cast<const char*>(base) + 16 + 8 * g.ws);
+            g.cur = w.a; g.nxt = w.b;
         } else {
             const RowLoc loc = search_row_chunk<CH>(a, r, g.c0 + qs, nprobe);
             g.spos = loc.pos; g.sbits = loc.bits;
         }
-        g.rw = a.badbits[r >> 6];
-        const unsigned long long* bw = a.badbits + ((g.c0 + qs) >> 6);
-        g.cw0 = bw[0]; g.cw1 = bw[1];
+        // masked-bin bits of the window's rows and columns: wave-uniform -> scalar loads and scalar shifts
+        {
+            const unsigned long long* rw = a.badbits + (g.r0 >> 6);
+            const unsigned long long* cw = a.badbits + (g.c0 >> 6);
+            const int rs = g.r0 & 63, cs = g.c0 & 63;
+            unsigned long long rb = rw[0] >> rs, cbm = cw[0] >> cs;
+            if (rs) rb |= rw[1] << (64 - rs);
+            if (cs) cbm |= cw[1] << (64 - cs);
+            g.rowbad = (unsigned)rb; g.colbad = (unsigned)cbm;       // W <= 32 bits are used
+        }
     };
 
     auto process = [&](const RtStage& g) __attribute__((always_inline)) {
@@ -448,21 +458,24 @@ __global__ __launch_bounds__(kWave) void pileup_regtile_kernel(K1Args a) {
             unsigned long long b64 = g.cur >> g.sh;
             if (g.sh) b64 |= g.nxt << (64 - g.sh);
             bits = (unsigned)b64 & chmask;
-            pos = (long long)(g.p0 + g.cum + (unsigned long long)__popcll(g.cur & ((1ull << g.sh) - 1ull)));
+            const unsigned cum = g.ws ? (unsigned)(g.cums >> ((g.ws - 1) * 16)) & 0xffffu : 0u;
+            pos = (long long)(g.p0 + cum + (unsigned long long)__popcll(g.cur & ((1ull << g.sh) - 1ull)));
         } else { pos = g.spos; bits = g.sbits & chmask; }
-        // one value load per cell, addresses known up front (bal is padded: a cell without a pixel reads a
-        // neighbouring value that is then discarded)
+        // values of the lane's cells: one 16-byte load per PAIR of cells.  The pixel of cell i sits at
+        // pos + popc(bits below i); the pair load at that address returns it and its successor, which is cell
+        // i+1's pixel when cell i holds one (otherwise cell i+1's pixel is the first value itself).  bal is
+        // padded, so a cell without a pixel harmlessly reads a neighbour that is then discarded.
         double v[CH];
 #pragma unroll
-        for (int i = 0; i < CH; ++i) v[i] = a.bal[pos + __popc(bits & ((1u << i) - 1u))];
+        for (int i = 0; i < CH; i += 2) {
+            const F64x2 pr = *reinterpret_cast<const F64x2*>(a.bal + pos + __popc(bits & ((1u << i) - 1u)));
+            v[i] = pr.a;
+            if (i + 1 < CH) v[i + 1] = ((bits >> i) & 1u) ? pr.b : pr.a;
+        }
         // validity of the lane's cells as a bit mask: bin masks, diagonal mask
         const int r = g.r0 + p, cc = g.c0 + qs;
-        const unsigned rowbad = (unsigned)(g.rw >> (r & 63)) & 1u;
-        const int csh = cc & 63;
-        unsigned long long cb64 = g.cw0 >> csh;
-        if (csh) cb64 |= g.cw1 << (64 - csh);
-        unsigned ok = chmask & ~(unsigned)cb64;
-        if (rowbad) ok = 0u;
+        unsigned ok = chmask & ~(g.colbad >> qs);
+        if ((g.rowbad >> p) & 1u) ok = 0u;
         if (igd >= 0) {
             // cell i is on or above the first kept diagonal iff (c0+qs+i) - (r0+p) >= igd  <=>  i >= t0
             const int t0 = igd - (cc - r);
