@@ -1,0 +1,103 @@
+"""GPU tests at sizes the CPU oracle cannot reach in seconds: size-independent properties of the pile-up.
+
+Linearity over snippet sets, independence from how a row's pixels are located (rank-bitmap index vs binary
+search) and from which kernel accumulates (register tile vs LDS tile), invariance to snippet order and chunking,
+the flip (anti-transpose) and transpose identities, and agreement with the oracle on a strided sample."""
+import numpy as np
+import pytest
+
+from coolpuppy_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+PAD, W = 10, 21
+
+
+@pytest.fixture(scope="module")
+def big():
+    clr = synth.make_cooler({c: synth.HG38[c] for c in ("chr20", "chr21", "chr22")}, lam=1500, seed=1000)
+    rng = np.random.default_rng(123)
+    n = 300_000
+    lo = np.array([clr.extent(c)[0] for c in clr.chromnames])
+    hi = np.array([clr.extent(c)[1] for c in clr.chromnames])
+    k = rng.integers(0, 3, n)
+    r0 = lo[k] + (rng.random(n) * (hi[k] - lo[k] - 600)).astype(np.int64)
+    c0 = r0 + rng.integers(-5, 520, n)
+    c0 = np.minimum(c0, hi[k] - W)
+    order = np.lexsort((c0, r0))
+    return clr, r0[order].astype(np.int32), c0[order].astype(np.int32)
+
+
+@pytest.fixture(scope="module")
+def eng(hip_lib, big):
+    from coolpuppy_amd.engine import PileupEngine
+    clr = big[0]
+    e = PileupEngine(0)
+    e.load_pixels(*clr.pixel_table())
+    assert e.build_index(clr.chrom_offset)
+    e.load_bins(clr.bins()["weight"][:].values, clr.bins()["cov_tot_raw"][:].values)
+    yield e
+    e.close()
+
+
+def run(eng, r0, c0, variant=0, chunk=0, group=0, mode=0, igd=2, flip_all=False):
+    eng.set_tuning(chunk, variant | (group << 8))
+    eng.reset(1, PAD)
+    n = len(r0)
+    eng.accumulate(r0, c0, np.array([0, n]), flip_from=np.array([0]) if flip_all else None, ignore_diags=igd, mode=mode)
+    out = eng.fetch()
+    eng.set_tuning(0, 0)
+    return out
+
+
+def test_linearity_and_order_invariance(eng, big):
+    _, r0, c0 = big
+    full = run(eng, r0, c0)
+    half = len(r0) // 3
+    a, b = run(eng, r0[:half], c0[:half]), run(eng, r0[half:], c0[half:])
+    np.testing.assert_array_equal(a["num"] + b["num"], full["num"])
+    np.testing.assert_array_equal(a["n"] + b["n"], full["n"])
+    np.testing.assert_allclose(a["sum"] + b["sum"], full["sum"], rtol=1e-11, atol=0)
+    perm = np.random.default_rng(1).permutation(len(r0))
+    shuf = run(eng, r0[perm], c0[perm])
+    np.testing.assert_array_equal(shuf["num"], full["num"])
+    np.testing.assert_allclose(shuf["sum"], full["sum"], rtol=1e-11, atol=0)
+
+
+def test_index_vs_search_vs_lds_kernel(eng, big):
+    _, r0, c0 = big
+    ref = run(eng, r0, c0)
+    for variant in (1, 2, 3):      # 1: binary search only, 2: LDS-tile kernel, 3: both
+        other = run(eng, r0, c0, variant=variant)
+        np.testing.assert_array_equal(other["num"], ref["num"])
+        np.testing.assert_allclose(other["sum"], ref["sum"], rtol=1e-11, atol=0)
+    for chunk, group in ((16, 4), (1000, 1), (77, 512)):
+        other = run(eng, r0, c0, chunk=chunk, group=group)
+        np.testing.assert_array_equal(other["num"], ref["num"])
+        np.testing.assert_allclose(other["sum"], ref["sum"], rtol=1e-11, atol=0)
+    again = run(eng, r0, c0)
+    np.testing.assert_array_equal(again["sum"], ref["sum"])        # same configuration -> bit-identical
+
+
+def test_flip_is_antitranspose(eng, big):
+    _, r0, c0 = big
+    ref = run(eng, r0, c0, mode=0x04)
+    fl = run(eng, r0, c0, mode=0x04, flip_all=True)
+    np.testing.assert_array_equal(fl["num"][0], np.rot90(np.flipud(ref["num"][0])))
+    np.testing.assert_array_equal(fl["sum"][0], np.rot90(np.flipud(ref["sum"][0])))
+    np.testing.assert_array_equal(fl["cov_start"], ref["cov_start"])   # the reference flips data only
+
+
+def test_oracle_on_strided_sample(eng, big, oracle_mod):
+    clr, r0, c0 = big
+    idx = np.arange(0, len(r0), 97)
+    indptr, col, cnt = clr.pixel_table()
+    w = clr.bins()["weight"][:].values
+    cov = clr.bins()["cov_tot_raw"][:].values
+    want = oracle_mod.pileup_c(indptr, col, cnt, w, cov, None, r0[idx], c0[idx], None,
+                               np.zeros(len(idx), np.int32), 1, PAD, 2, 0x04)
+    got = run(eng, r0[idx], c0[idx], mode=0x04)
+    np.testing.assert_array_equal(got["num"], want["num"])
+    np.testing.assert_allclose(got["sum"], want["sum"], rtol=1e-6, atol=0)
+    np.testing.assert_allclose(got["cov_start"], want["cov_start"], rtol=1e-12)
+    np.testing.assert_allclose(got["cov_end"], want["cov_end"], rtol=1e-12)
