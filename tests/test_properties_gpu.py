@@ -23,7 +23,7 @@ def big():
     k = rng.integers(0, 3, n)
     r0 = lo[k] + (rng.random(n) * (hi[k] - lo[k] - 600)).astype(np.int64)
     c0 = r0 + rng.integers(-5, 520, n)
-    c0 = np.minimum(c0, hi[k] - W)
+    c0 = np.clip(c0, lo[k], hi[k] - W)
     order = np.lexsort((c0, r0))
     return clr, r0[order].astype(np.int32), c0[order].astype(np.int32)
 
