@@ -378,6 +378,87 @@ class CoordCreator:
         f = self._filter_func_region if self.kind == "bed" else self._filter_func_pairs_region
         return partial(f, region=region)
 
+    # -- cached numpy views for fast region selection / grouping -------------------------------------------------
+    def _cache(self):
+        """Integer chromosome codes and coordinate arrays of self.intervals (rebuilt if the frame is replaced)."""
+        c = getattr(self, "_fc", None)
+        if c is not None and c["id"] is self.intervals:
+            return c
+        iv = self.intervals
+        c = {"id": iv, "cols": {}, "gc": {}}
+        if self.kind == "bedpe":
+            n = len(iv)
+            codes, uniq = pd.factorize(np.concatenate([iv["chrom1"].values, iv["chrom2"].values]))
+            c["chrom_code"] = {str(u): i for i, u in enumerate(uniq)}
+            c["c1"], c["c2"] = codes[:n], codes[n:]
+            for k in ("start1", "end1", "start2", "end2"):
+                c[k] = iv[k].values
+        else:
+            codes, uniq = pd.factorize(iv["chrom"].values)
+            c["chrom_code"] = {str(u): i for i, u in enumerate(uniq)}
+            c["c"] = codes
+            c["start"], c["end"] = iv["start"].values, iv["end"].values
+        self._fc = c
+        return c
+
+    def _col(self, name):
+        c = self._cache()
+        if name not in c["cols"]:
+            c["cols"][name] = self.intervals[name].values
+        return c["cols"][name]
+
+    def group_codes(self, name):
+        """(int codes over self.intervals rows, uniques) of a grouping column.  Paired bedpe columns X1 / X2 share
+        one dictionary (needed when flipped snippets swap them); bed column X serves X1 and X2."""
+        c = self._cache()
+        if name in c["gc"]:
+            return c["gc"][name]
+        iv = self.intervals
+        if self.kind == "bedpe" and name[-1:] in "12" and (name[:-1] + "1") in iv.columns and (name[:-1] + "2") in iv.columns:
+            a, b = iv[name[:-1] + "1"].values, iv[name[:-1] + "2"].values
+            codes, uniq = pd.factorize(np.concatenate([a, b]))
+            c["gc"][name[:-1] + "1"] = (codes[:len(a)].astype(np.int64), uniq)
+            c["gc"][name[:-1] + "2"] = (codes[len(a):].astype(np.int64), uniq)
+        else:
+            codes, uniq = pd.factorize(iv[name].values)
+            c["gc"][name] = (codes.astype(np.int64), uniq)
+        return c["gc"][name]
+
+    def _rows_pairs_region(self, region):
+        chrom, start, end = region
+        c = self._cache()
+        k = c["chrom_code"].get(str(chrom), -1)
+        m = ((c["c1"] == k) & (c["c2"] == k) & (c["start1"] >= start) & (c["end1"] < end)
+             & (c["start2"] >= start) & (c["end2"] < end))
+        return np.flatnonzero(m)
+
+    def _rows_trans_pairs(self, region1, region2):
+        c1n, s1, e1 = region1
+        c2n, s2, e2 = region2
+        c = self._cache()
+        k1, k2 = c["chrom_code"].get(str(c1n), -1), c["chrom_code"].get(str(c2n), -1)
+        fwd = ((c["c1"] == k1) & (c["c2"] == k2) & (c["start1"] >= s1) & (c["end1"] < e1)
+               & (c["start2"] >= s2) & (c["end2"] < e2))
+        rev = ((c["c2"] == k1) & (c["c1"] == k2) & (c["start2"] >= s1) & (c["end2"] < e1)
+               & (c["start1"] >= s2) & (c["end1"] < e2))
+        return np.concatenate([np.flatnonzero(fwd), np.flatnonzero(rev)])      # same order as the reference's concat
+
+    def _rows_region(self, region):
+        chrom, start, end = region
+        c = self._cache()
+        k = c["chrom_code"].get(str(chrom), -1)
+        return np.flatnonzero((c["c"] == k) & (c["start"] >= start) & (c["end"] < end))
+
+    def _take(self, rows, names, suffix=""):
+        """Column table of the given rows. '_gc_X' names yield the integer group codes of column X."""
+        out = {}
+        for name in names:
+            if name.startswith("_gc_"):
+                out[name + suffix] = self.group_codes(name[4:])[0][rows]
+            else:
+                out[name + suffix] = self._col(name)[rows]
+        return out
+
     # -- column-table window generation ---------------------------------------------------------------------
     def _needed(self, want):
         """Columns to carry per snippet: bins + what grouping/flipping asks for (None = everything)."""
@@ -397,26 +478,30 @@ class CoordCreator:
         if len(self.intervals) == 0 or not hasattr(self, "kind") or self.pos_stream == self.empty_stream:
             return None
         nshifts = self.nshifts * bool(control)
+        have = set(self.intervals.columns)
         if self.kind == "bedpe":
-            if self.trans:
-                sub = self._filter_func_trans_pairs(self.intervals, tuple(region1), tuple(region2))
-            else:
-                sub = self._filter_func_pairs_region(self.intervals, tuple(region1))
+            rows = self._rows_trans_pairs(tuple(region1), tuple(region2)) if self.trans \
+                else self._rows_pairs_region(tuple(region1))
+            if len(rows) == 0:
+                return None
             keep = self._needed(columns)
-            cols = _Cols.from_frame(sub if keep is None else sub[[c for c in keep if c in sub.columns]])
-            out = self._control_cols(cols, nshifts)
-            return out if len(sub) >= 1 else None
+            names = list(self.intervals.columns) if keep is None else \
+                [c for c in keep if c in have or (c.startswith("_gc_") and c[4:] in have)]
+            return self._control_cols(_Cols(self._take(rows, names)), nshifts)
         # ---- bed: combinations ----
-        left = self._filter_func_region(self.intervals, tuple(region1))
-        right = left if region2 is None or tuple(region2) == tuple(region1) else \
-            self._filter_func_region(self.intervals, tuple(region2))
+        rows_l = self._rows_region(tuple(region1))
+        rows_r = rows_l if region2 is None or tuple(region2) == tuple(region1) else self._rows_region(tuple(region2))
         want = None if columns is None else set(columns) | {"center1", "center2"}
 
-        def side(df, s):
-            names = list(df.columns) if want is None else \
-                [c for c in df.columns if c + s in want or c in ("stBin", "endBin", "center")]
-            return {c + s: df[c].values for c in names}
+        def side(rows, s):
+            if want is None:
+                names = list(self.intervals.columns)
+            else:
+                names = [c for c in self.intervals.columns if c + s in want or c in ("stBin", "endBin", "center")]
+                names += ["_gc_" + w[4:-1] for w in want if w.startswith("_gc_") and w.endswith(s) and w[4:-1] in have]
+            return self._take(rows, names, suffix=s)
 
+        left, right = rows_l, rows_r
         L, R = side(left, "1"), side(right, "2")
         if self.local:
             tbl = _Cols({**L, **{k[:-1] + "2": v for k, v in L.items()}})
@@ -656,6 +741,16 @@ class PileUpper:
             return list(zip(r1, r2))
         return [(r, r) for r in self.view_df.index]
 
+    def _group_source(self, g):
+        """Column to carry for grouping by g: integer codes ('_gc_' + g) for string-like feature columns, the
+        column itself otherwise; plus the decoder that turns a stored value back into the key element."""
+        iv = self.CC.intervals
+        base = g if self.CC.kind == "bedpe" else g[:-1]
+        if base in iv.columns and iv[base].dtype == object:
+            uniq = self.CC.group_codes(g if self.CC.kind == "bedpe" else base)[1]
+            return "_gc_" + g, (lambda i, u=uniq: u[i])
+        return g, None
+
     def region_snippets(self, region1, region2=None, groupby=[], modify_2Dintervals_func=None, columns=()):
         """Host half of ``pileup_region`` (reference :1285-1358 down to the skip test :1105-1114).
 
@@ -668,10 +763,21 @@ class PileUpper:
         reg1 = tuple(self.view_df.loc[region1, ["chrom", "start", "end"]])
         reg2 = tuple(self.view_df.loc[region2, ["chrom", "start", "end"]])
         carry = columns
-        if carry is not None:
-            carry = list(carry) + [c for c in groupby if c != "distance_band"]
-            if modify_2Dintervals_func is not None and not _is_builtin_modify(modify_2Dintervals_func):
-                carry = None          # a user function may read any column
+        builtin = modify_2Dintervals_func is None or _is_builtin_modify(modify_2Dintervals_func)
+        src = {}                       # groupby column -> (carried column, decoder)
+        if carry is not None and builtin:
+            carry = list(carry)
+            for g in groupby:
+                src[g] = self._group_source(g)
+                if g != "distance_band":
+                    carry.append(src[g][0])
+            if getattr(self, "ignore_group_order", False):
+                for g in groupby:      # flipped snippets swap X1 <-> X2: the partner's codes are needed as well
+                    name = src[g][0]
+                    if name[-1:] in "12":
+                        carry.append(name[:-1] + ("2" if name.endswith("1") else "1"))
+        else:
+            carry = None               # a user function may read any column
         tbl = self.CC.region_table(reg1, None if region2 == region1 else reg2, control=self.control, columns=carry)
         if tbl is None or len(tbl) == 0:
             return None
@@ -694,16 +800,20 @@ class PileUpper:
         n = len(r0)
         flip = tbl["flip"].astype(bool) if "flip" in tbl else np.zeros(n, bool)
         if groupby:
-            keycols = []
+            keycols, decs = [], []
             for g in groupby:
-                v = tbl[g]
+                name, dec = src.get(g, (g, None))
+                if g == "distance_band":
+                    name, dec = g, decoders.get(g)
+                v = tbl[name]
                 if self.ignore_group_order and flip.any():
                     # flipped snippets swap every paired column X1<->X2 before grouping (reference :131-144)
-                    partner = g[:-1] + ("2" if g.endswith("1") else "1") if g[-1:] in "12" else None
+                    partner = name[:-1] + ("2" if name.endswith("1") else "1") if name[-1:] in "12" else None
                     if partner is not None and partner in tbl:
                         v = np.where(flip, tbl[partner], v)
                 keycols.append(v)
-            codes, keys = _factorize_rows(keycols, [decoders.get(g) for g in groupby])
+                decs.append(dec)
+            codes, keys = _factorize_rows(keycols, decs)
         else:
             codes, keys = np.full(n, -1, np.int64), []
         return {"r0": r0, "c0": c0, "kind": tbl["kind"].astype(np.int8), "flip": flip, "group_codes": codes,
@@ -808,7 +918,7 @@ class PileUpper:
         gid = {k: i for i, k in enumerate(keys_all)}
         G = len(keys_all)
         T = 2 * G
-        calls = []
+        raw = []
         for region1, region2, b in batches:
             if b is None or b["n"] == 0:
                 continue
@@ -826,12 +936,24 @@ class PileUpper:
             r0, c0 = (b["c0"], b["r0"]) if transpose else (b["r0"], b["c0"])
             tr = MODE_TRANSPOSE if transpose else 0
             mode = (MODE_OOE if (self.expected and self.ooe) else 0) | (MODE_COV if self.coverage_norm else 0) | tr
-            calls.append(_engine_call(region1, region2, expected, r0, c0, b["flip"],
-                                      b["kind"].astype(np.int64) * G + g, T, igd, mode))
+            raw.append((region1, region2, expected, r0, c0, b["flip"], b["kind"].astype(np.int64) * G + g, igd, mode))
             if exp_as_control:
                 roi = b["kind"] == KIND_ROI
-                calls.append(_engine_call(region1, region2, expected, r0[roi], c0[roi], b["flip"][roi],
-                                          G + g[roi], T, igd, MODE_EXPECTED | tr))
+                raw.append((region1, region2, expected, r0[roi], c0[roi], b["flip"][roi], G + g[roi], igd,
+                            MODE_EXPECTED | tr))
+        # regions that need no per-region state (no expected vector) and share mode / diagonal mask go to the
+        # engine as ONE call: fewer launches, and the engine's interleaved groups span region boundaries
+        merged = []                     # [head item, [parts of fields 3..6]]
+        for item in raw:
+            prev = merged[-1][0] if merged else None
+            if prev is not None and item[2] is None and prev[2] is None and item[7] == prev[7] and item[8] == prev[8]:
+                merged[-1][1].append(item[3:7])
+            else:
+                merged.append([item, [item[3:7]]])
+        calls = []
+        for head, parts in merged:
+            f = [np.concatenate([p[k] for p in parts]) if len(parts) > 1 else parts[0][k] for k in range(4)]
+            calls.append(_engine_call(head[0], head[1], head[2], f[0], f[1], f[2], f[3], T, head[7], head[8]))
         return {"T": T, "G": G, "gid": gid, "order": order, "contrib": contrib, "want_control": want_control,
                 "groupby": list(groupby), "calls": calls, "pad": self.pad_bins, "n_regions": len(batches),
                 "weight_name": self.clr_weight_name if self.clr_weight_name else None,
@@ -846,9 +968,10 @@ class PileUpper:
         eng.load_bins(bins[plan["weight_name"]][:].values if plan["weight_name"] else None,
                       bins[plan["cov_name"]][:].values if plan["cov_name"] else None)
         eng.reset(plan["T"], plan["pad"])
-        mine = _dist.shard(len(plan["calls"]), weights=[len(c["r0"]) for c in plan["calls"]])
-        for i, c in enumerate(plan["calls"]):
-            if i not in mine:
+        rank, world = _dist.world()
+        for c in plan["calls"]:
+            c = _dist.slice_call(c, rank, world)          # every rank takes an even share of every tile segment
+            if len(c["r0"]) == 0:
                 continue
             eng.set_expected(c["expected"])
             eng.accumulate(c["r0"], c["c0"], c["tile_ptr"], flip_from=c["flip_from"],
@@ -970,6 +1093,8 @@ def _engine_call(region1, region2, expected, r0, c0, flip, tile, T, igd, mode):
     group; within a tile the anti-transposed snippets come last (flip_from marks where they start)."""
     flip = np.zeros(len(tile), bool) if flip is None else np.asarray(flip, bool)
     key = tile.astype(np.int64) * 2 + flip
+    if 2 * T < 65536:
+        key = key.astype(np.uint16)            # numpy's stable sort of 16-bit keys is a radix sort: O(n)
     if len(key) > 1 and not np.all(key[1:] >= key[:-1]):
         o = np.argsort(key, kind="stable")
         r0, c0, flip, tile = r0[o], c0[o], flip[o], tile[o]
@@ -1017,8 +1142,10 @@ def _factorize_rows(cols, decoders=None):
             combined = combined * (len(uniq) + 1) + codes
     else:   # too many distinct values for a mixed-radix code: factorize tuples
         combined = pd.factorize(pd.Series(list(zip(*[codes for codes, _ in per]))), sort=False)[0]
-    codes, _ = pd.factorize(combined, sort=False)
-    _, first_rows = np.unique(codes, return_index=True)
+    codes, uniq = pd.factorize(combined, sort=False)
+    n = len(codes)
+    first_rows = np.empty(len(uniq), np.int64)
+    first_rows[codes[::-1]] = np.arange(n - 1, -1, -1)       # reversed writes: the first occurrence wins
     keys = []
     for r in first_rows:
         vals = []

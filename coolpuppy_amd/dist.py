@@ -58,6 +58,38 @@ def shard(n_units, weights=None, rank=None, world_size=None):
     return mine
 
 
+def slice_call(call, rank, world_size):
+    """This rank's share of one engine call: an even, contiguous slice of every (tile, flip) segment of the
+    call's tile-grouped snippets (deterministic, no communication).  Returns a call dict of the same shape."""
+    if world_size == 1:
+        return call
+    tp = np.asarray(call["tile_ptr"], np.int64)
+    T = len(tp) - 1
+    ff = tp[1:] if call.get("flip_from") is None else np.asarray(call["flip_from"], np.int64)
+    # segment boundaries: [tp[t], ff[t]) as is, [ff[t], tp[t+1]) flipped
+    a = np.stack([tp[:-1], ff], axis=1).ravel()
+    b = np.stack([ff, tp[1:]], axis=1).ravel()
+    n = b - a
+    lo = a + (n * rank) // world_size
+    hi = a + (n * (rank + 1)) // world_size
+    cnt = hi - lo
+    total = int(cnt.sum())
+    if total:
+        starts = np.repeat(lo - np.concatenate([[0], np.cumsum(cnt)[:-1]]), cnt)
+        idx = starts + np.arange(total)
+    else:
+        idx = np.zeros(0, np.int64)
+    per_tile = cnt.reshape(T, 2)
+    new_tp = np.concatenate([[0], np.cumsum(per_tile.sum(axis=1))]).astype(np.int64)
+    out = dict(call)
+    for k in ("r0", "c0", "tile", "flip"):
+        if call.get(k) is not None:
+            out[k] = np.ascontiguousarray(call[k][idx])
+    out["tile_ptr"] = new_tp
+    out["flip_from"] = None if call.get("flip_from") is None else (new_tp[:-1] + per_tile[:, 0]).astype(np.int64)
+    return out
+
+
 def allreduce_arrays(f64, i64):
     """Sum a float64 and an int64 numpy array over all ranks (in place where possible); returns both."""
     d = _dist()
