@@ -485,7 +485,7 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, 
     if (C > 0xffffffffLL) return fail(c, PUP_ENOTSUP, "pup_accumulate: chunk too long for 32-bit num partials");
 
     // two-level reduction plan: chunks -> slices of <= S chunks (within a tile) -> tiles
-    const long long SL = 64;
+    const long long SL = 256;
     long long max_per_tile = 0;
     for (int t = 0; t < c->T; ++t)
         max_per_tile = std::max(max_per_tile, tile_chunk_ptr[(size_t)t + 1] - tile_chunk_ptr[(size_t)t]);
@@ -559,8 +559,8 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, 
 
     // ---- K2: partials -> (slices ->) accumulators ---------------------------------------------------
     const int Li = (int)W2;
-    const dim3 rb(256), rg1((unsigned)((Lf + Li + 255) / 256), (unsigned)std::max<long long>(nslices, 1));
-    const dim3 rg2((unsigned)((Lf + Li + 255) / 256), (unsigned)c->T);
+    const dim3 rb(64, pup::kRedParts), rg1((unsigned)((Lf + Li + 63) / 64), (unsigned)std::max<long long>(nslices, 1));
+    const dim3 rg2((unsigned)((Lf + Li + 63) / 64), (unsigned)c->T);
     if (two_level) {
         hipLaunchKernelGGL((pup::reduce_partials_kernel<unsigned, false>), rg1, rb, 0, c->stream,
                            c->part_f64.p, c->part_num.p, c->d_seg1.p, (int)Lf, Li, c->slice_f64.p, c->slice_num.p);

@@ -642,29 +642,44 @@ __global__ __launch_bounds__(256) void index_rank_kernel(const long long* __rest
 }
 
 // Segmented, order-fixed reduction of partial records.
-//   f64 record length Lf, integer record length Li.  Output segment g sums input records
-//   [seg_ptr[g], seg_ptr[g+1]).  ACCUM: add into the output instead of overwriting, and route
-//   record g to output record out_index[g] (running accumulators, one per tile).
+//   f64 record length Lf, integer record length Li.  Output record g sums input records
+//   [seg_ptr[g], seg_ptr[g+1]).  A workgroup = 64 record elements x kRedParts interleaved partial sums
+//   (part y adds records b+y, b+y+kRedParts, ...), combined in the fixed order y = 0..kRedParts-1:
+//   parallel, yet the summation order never depends on timing.  ACCUM: add into the output (running accumulators).
+constexpr int kRedParts = 16;
 template <typename NumIn, bool ACCUM>
-__global__ __launch_bounds__(256) void reduce_partials_kernel(
+__global__ __launch_bounds__(64 * kRedParts) void reduce_partials_kernel(
         const double* __restrict__ in_f64, const NumIn* __restrict__ in_num,
         const long long* __restrict__ seg_ptr, int Lf, int Li,
         double* out_f64, long long* out_num) {
+    __shared__ double    sf[kRedParts][64];
+    __shared__ long long si[kRedParts][64];
     const int g = blockIdx.y;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= Lf + Li) return;
+    const int cx = threadIdx.x, py = threadIdx.y;
+    const int idx = blockIdx.x * 64 + cx;
     const long long b = seg_ptr[g], e = seg_ptr[g + 1];
+    double accf = 0.0; long long acci = 0;
     if (idx < Lf) {
-        double acc = 0.0;
-        for (long long c = b; c < e; ++c) acc += in_f64[(size_t)c * Lf + idx];
-        double* o = out_f64 + (size_t)g * Lf + idx;
-        if (ACCUM) *o += acc; else *o = acc;
-    } else {
+        for (long long c = b + py; c < e; c += kRedParts) accf += in_f64[(size_t)c * Lf + idx];
+    } else if (idx < Lf + Li) {
         const int k = idx - Lf;
-        long long acc = 0;
-        for (long long c = b; c < e; ++c) acc += (long long)in_num[(size_t)c * Li + k];
-        long long* o = out_num + (size_t)g * Li + k;
-        if (ACCUM) *o += acc; else *o = acc;
+        for (long long c = b + py; c < e; c += kRedParts) acci += (long long)in_num[(size_t)c * Li + k];
+    }
+    sf[py][cx] = accf; si[py][cx] = acci;
+    __syncthreads();
+    if (py != 0 || idx >= Lf + Li) return;
+    if (idx < Lf) {
+        double t = 0.0;
+#pragma unroll
+        for (int y = 0; y < kRedParts; ++y) t += sf[y][cx];
+        double* o = out_f64 + (size_t)g * Lf + idx;
+        if (ACCUM) *o += t; else *o = t;
+    } else {
+        long long t = 0;
+#pragma unroll
+        for (int y = 0; y < kRedParts; ++y) t += si[y][cx];
+        long long* o = out_num + (size_t)g * Li + (idx - Lf);
+        if (ACCUM) *o += t; else *o = t;
     }
 }
 
