@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="snippets timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-cache", action="store_true")
     ap.add_argument("--no-index", action="store_true", help="binary search only (skip the rank-bitmap index)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo (+ COOLPUPPY_AMD_BENCH_DEVICE=0) lets several ranks share ONE GPU "
+                         "to smoke-test the N>1 code path on a single-GPU box")
     return ap.parse_args()
 
 
@@ -123,11 +126,25 @@ def main():
         build_hip()          # no-op when the in-tree .so is current
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    if os.environ.get("COOLPUPPY_AMD_BENCH_DEVICE", "") != "":
+        local_rank = int(os.environ["COOLPUPPY_AMD_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def allreduce(t, op=None):
+        """all-reduce a CUDA tensor in place (through host memory when the backend is gloo)."""
+        kw = {} if op is None else {"op": op}
+        if a.backend == "nccl":
+            dist.all_reduce(t, **kw)
+        else:
+            h = t.cpu()
+            dist.all_reduce(h, **kw)
+            t.copy_(h)
 
     def barrier():
         if world > 1:
@@ -170,8 +187,8 @@ def main():
         eng.accumulate_device(d_r0.data_ptr(), d_c0.data_ptr(), n_local, tile_ptr, ignore_diags=2, mode=0)
         if world > 1:
             eng.export_to(buf_f.data_ptr(), buf_i.data_ptr())
-            dist.all_reduce(buf_f)
-            dist.all_reduce(buf_i)
+            allreduce(buf_f)
+            allreduce(buf_i)
             torch.cuda.synchronize()
             eng.import_from(buf_f.data_ptr(), buf_i.data_ptr())
         else:
@@ -192,13 +209,13 @@ def main():
 
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        allreduce(tt, dist.ReduceOp.MAX)
         dt = float(tt.item())
         agg = torch.tensor([st["k1_ms"], float(st["pixels_in_windows"]), float(st["snippets"])],
                            dtype=torch.float64, device="cuda")
         mx = agg.clone()
-        dist.all_reduce(agg)                      # sums over ranks
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        allreduce(agg)                            # sums over ranks
+        allreduce(mx, dist.ReduceOp.MAX)
         k1_ms_max = float(mx[0].item())
         pix_total, snip_total = float(agg[1].item()), float(agg[2].item())
     else:
