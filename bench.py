@@ -8,8 +8,10 @@ controls (seed 0) => ~1.1e7 snippets per step.  A "step" = one full pass: zero t
 pile up every snippet (ROI + controls) of this rank's shard from HBM-resident inputs, and (N>1)
 all-reduce the packed sum/num/n/cov accumulators over RCCL.
 
-Scaling is STRONG: the same 1e6 pairs are split over the ranks (contiguous genome slices of the
-sorted snippet list; the pixel table is replicated — 2.4 GB of 288 GB).
+Scaling (default WEAK, per-GPU work fixed): the pixel table is replicated on every GPU (2.7 GB of 288 GB) and
+every rank piles up its OWN set of 1e6 pairs (pair seed 42+rank, control seed rank); the step ends with the real
+exchange of the path — one all-reduce of the packed tiles — so the job's result is the pile-up over all N sets.
+`--scaling strong` splits ONE 1e6-pair set over the ranks instead (contiguous slices of the sorted snippets).
 
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (K1 kernel,
 HIP-event timed inside this process) and `cpu_baseline` (the C oracle on a bounded sample, N=1 only).
@@ -43,6 +45,9 @@ def parse():
     ap.add_argument("--chroms", type=int, default=23, help="use the first K hg38 chromosomes (23 = all)")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="snippets timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-cache", action="store_true")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank piles up its own set of --pairs pairs on the shared table; "
+                         "strong: the ranks split ONE set")
     ap.add_argument("--no-index", action="store_true", help="binary search only (skip the rank-bitmap index)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo (+ COOLPUPPY_AMD_BENCH_DEVICE=0) lets several ranks share ONE GPU "
@@ -51,48 +56,84 @@ def parse():
 
 
 # ----------------------------------------------------------------------------------------------------
-# workload
+# workload (cached under $TMPDIR so that back-to-back runs at N = 1, 2, 4, 8 do not regenerate it)
 # ----------------------------------------------------------------------------------------------------
-def _cache_path(a):
-    key = f"v3|{a.chroms}|{a.lam}|{a.pairs}|{a.nshifts}|{a.pad}"
-    return os.path.join(os.environ.get("TMPDIR", "/tmp"), "coolpuppy_amd_bench_" +
-                        hashlib.sha1(key.encode()).hexdigest()[:12] + ".npz")
+def _tmp(name):
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), name)
 
 
-def build_workload(a):
-    """Returns dict(bin1_offset, bin2_id, count, weight, r0, c0, n_roi, chrom_offset)."""
-    names = list(synth.HG38)[: a.chroms]
-    clr = synth.make_cooler({c: synth.HG38[c] for c in names}, binsize=10_000, lam=a.lam, seed=1000,
-                            name="synthetic_hg38_10kb", parallel=True)
-    # feature pairs and windows: host-side coordinate generation (CoordCreator semantics)
+def workload_key(a):
+    return hashlib.sha1(f"w4|{a.chroms}|{a.lam}|{a.pairs}|{a.nshifts}|{a.pad}".encode()).hexdigest()[:12]
+
+
+def cooler_path(a):
+    return _tmp("coolpuppy_amd_bench_cooler_" + hashlib.sha1(f"c4|{a.chroms}|{a.lam}".encode()).hexdigest()[:12] + ".npz")
+
+
+def snippets_path(a, k):
+    return _tmp(f"coolpuppy_amd_bench_snips_{workload_key(a)}_{k}.npz")
+
+
+def _save(path, **arrays):
+    tmp = path + f".tmp{os.getpid()}.npz"
+    np.savez(tmp, **arrays)
+    os.replace(tmp, path)
+
+
+def _chromsizes(a):
+    return {c: synth.HG38[c] for c in list(synth.HG38)[: a.chroms]}
+
+
+def build_cooler(a):
+    clr = synth.make_cooler(_chromsizes(a), binsize=10_000, lam=a.lam, seed=1000, name="synthetic_hg38_10kb",
+                            parallel=True)
+    bin1_offset, bin2_id, count = clr.pixel_table()
+    return {"bin1_offset": bin1_offset, "bin2_id": bin2_id, "count": count,
+            "weight": clr.bins()["weight"][:].values, "chrom_offset": clr.chrom_offset}
+
+
+def build_snippets(a, cool, k):
+    """Snippet set k: a.pairs random cis BEDPE pairs (pair seed 42+k) through the host-side coordinate layer
+    (CoordCreator semantics, control-shift RNG seed k) -> position-sorted (r0, c0) with ROI first."""
+    from coolpuppy_amd.cooler_lite import ArrayCooler
     from coolpuppy_amd.coolpup import CoordCreator, snippet_batches
-    pairs = synth.random_cis_pairs(clr, a.pairs, min_sep=230_000, max_sep=5_000_000, seed=42)
-    np.random.seed(0)
+    clr = ArrayCooler(_chromsizes(a), 10_000, cool["bin1_offset"], cool["bin2_id"], cool["count"],
+                      bins={"weight": cool["weight"]}, filename="synthetic_hg38_10kb.cool")
+    pairs = synth.random_cis_pairs(clr, a.pairs, min_sep=230_000, max_sep=5_000_000, seed=42 + k)
+    np.random.seed(k)
     cc = CoordCreator(pairs, clr.binsize, features_format="bedpe", flank=a.pad * clr.binsize,
                       nshifts=a.nshifts, mindist="auto")
     r0, c0, kind = snippet_batches(cc, clr, control=a.nshifts > 0)
     order = np.lexsort((c0, r0, kind))
-    r0, c0, kind = r0[order], c0[order], kind[order]
-    bin1_offset, bin2_id, count = clr.pixel_table()
-    return {
-        "bin1_offset": bin1_offset, "bin2_id": bin2_id, "count": count,
-        "weight": clr.bins()["weight"][:].values, "r0": r0.astype(np.int32), "c0": c0.astype(np.int32),
-        "n_roi": np.int64((kind == 0).sum()), "chrom_offset": clr.chrom_offset,
-    }
+    return {"r0": r0[order].astype(np.int32), "c0": c0[order].astype(np.int32), "n_roi": np.int64((kind == 0).sum())}
 
 
-def load_or_build(a, rank, barrier):
-    path = _cache_path(a)
-    if rank == 0 and (a.no_cache or not os.path.exists(path)):
+def _wait_for(path):
+    while not os.path.exists(path):
+        time.sleep(0.5)
+    time.sleep(0.3)
+
+
+def load_workload(a, rank, world):
+    """Everything happens BEFORE any GPU runtime is initialised in this process (the generator forks workers)."""
+    cpath = cooler_path(a)
+    if rank == 0 and (a.no_cache or not os.path.exists(cpath)):
         t = time.time()
-        wl = build_workload(a)
-        tmp = path + f".tmp{os.getpid()}.npz"
-        np.savez(tmp, **wl)
-        os.replace(tmp, path)
-        print(f"[bench] workload built in {time.time()-t:.1f}s -> {path}", file=sys.stderr, flush=True)
-    barrier()
-    z = np.load(path)
-    return {k: z[k] for k in z.files}
+        _save(cpath, **build_cooler(a))
+        print(f"[bench] cooler built in {time.time()-t:.1f}s -> {cpath}", file=sys.stderr, flush=True)
+    _wait_for(cpath)
+    z = np.load(cpath)
+    cool = {k: z[k] for k in z.files}
+    k = rank if a.scaling == "weak" else 0
+    spath = snippets_path(a, k)
+    if (rank == k or a.scaling == "weak") and (a.no_cache and rank == k or not os.path.exists(spath)):
+        t = time.time()
+        _save(spath, **build_snippets(a, cool, k))
+        print(f"[bench] rank {rank}: snippet set {k} built in {time.time()-t:.1f}s", file=sys.stderr, flush=True)
+    _wait_for(spath)
+    z = np.load(spath)
+    cool.update({kk: z[kk] for kk in z.files})
+    return cool
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -106,16 +147,7 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         a.gpus = world
 
-    # stage 0: rank 0 builds the workload BEFORE any GPU runtime is initialised (it may fork workers);
-    # the other ranks wait on a file barrier, so torch/RCCL init never overlaps the fork.
-    path = _cache_path(a)
-    if rank == 0:
-        wl = load_or_build(a, 0, lambda: None)
-    else:
-        while not os.path.exists(path):
-            time.sleep(0.5)
-        time.sleep(0.5)
-        wl = load_or_build(a, rank, lambda: None)
+    wl = load_workload(a, rank, world)
 
     import torch
     import torch.distributed as dist
@@ -152,17 +184,22 @@ def main():
         torch.cuda.synchronize()
 
     W = 2 * a.pad + 1
-    n_all = int(wl["r0"].shape[0])
+    n_set = int(wl["r0"].shape[0])
     n_roi = int(wl["n_roi"])
-    # strong-scaling shard: contiguous slice of each tile's (sorted) snippet range
-    def part(lo, hi):
-        m = hi - lo
-        return lo + (m * rank) // world, lo + (m * (rank + 1)) // world
-    a0, a1 = part(0, n_roi)
-    b0, b1 = part(n_roi, n_all)
-    r0 = np.concatenate([wl["r0"][a0:a1], wl["r0"][b0:b1]])
-    c0 = np.concatenate([wl["c0"][a0:a1], wl["c0"][b0:b1]])
-    tile_ptr = np.array([0, a1 - a0, (a1 - a0) + (b1 - b0)], np.int64)
+    if a.scaling == "weak":
+        # every rank owns a full workload (its own pairs / control shifts) on the replicated table
+        r0, c0 = wl["r0"], wl["c0"]
+        tile_ptr = np.array([0, n_roi, n_set], np.int64)
+    else:
+        # strong: contiguous slice of each tile's (sorted) snippet range of the one shared set
+        def part(lo, hi):
+            m = hi - lo
+            return lo + (m * rank) // world, lo + (m * (rank + 1)) // world
+        a0, a1 = part(0, n_roi)
+        b0, b1 = part(n_roi, n_set)
+        r0 = np.concatenate([wl["r0"][a0:a1], wl["r0"][b0:b1]])
+        c0 = np.concatenate([wl["c0"][a0:a1], wl["c0"][b0:b1]])
+        tile_ptr = np.array([0, a1 - a0, (a1 - a0) + (b1 - b0)], np.int64)
     n_local = int(tile_ptr[-1])
 
     eng = PileupEngine(local_rank)
@@ -207,7 +244,11 @@ def main():
     st = eng.stats()
     eng.set_profiling(False)
 
+    n_all = n_local
     if world > 1:
+        nn = torch.tensor([float(n_local)], dtype=torch.float64, device="cuda")
+        allreduce(nn)
+        n_all = int(nn.item())
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         allreduce(tt, dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -238,7 +279,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("workload_key") == os.path.basename(_cache_path(a)) and a.gpus == 1:
+                if tj.get("workload_key") == workload_key(a) and a.gpus == 1:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -256,8 +297,8 @@ def main():
         if a.gpus == 1 and a.cpu_sample > 0:
             from oracle import pileup_oracle as po
             po.build()
-            m = min(a.cpu_sample, n_all)
-            idx = np.linspace(0, n_all - 1, m).astype(np.int64)
+            m = min(a.cpu_sample, n_set)
+            idx = np.linspace(0, n_set - 1, m).astype(np.int64)
             sr0, sc0 = wl["r0"][idx], wl["c0"][idx]
             stile = (idx >= n_roi).astype(np.int32)
             t = time.perf_counter()
@@ -271,21 +312,24 @@ def main():
             ok = (np.array_equal(got["n"], want["n"]) and np.array_equal(got["num"], want["num"])
                   and np.allclose(got["sum"], want["sum"], rtol=1e-6, atol=0, equal_nan=True))
             cpu = {"value": round(m / cpu_s, 1), "unit": "snippets/s", "cores": 1, "kind": "port",
-                   "sample": f"{m} snippets strided over the {n_all} of this workload, C oracle (oracle/pileup_oracle.c), "
+                   "sample": f"{m} snippets strided over the {n_set} of this workload, C oracle (oracle/pileup_oracle.c), "
                              f"{cpu_s:.1f}s", "gpu_matches_oracle_on_sample": bool(ok)}
             if not ok:
                 print("[bench] PARITY FAILURE against the oracle on the sample", file=sys.stderr)
         line = {
             "metric": "snippets/sec (21x21 windows @10kb, ROI + control snippets accumulated)",
             "value": round(value, 1), "unit": "snippets/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": "BASELINE configs[2]: synthetic hg38 10kb CSR + 1e6 random cis BEDPE pairs, pad=10, "
                             "nshifts=10, balanced, ignore_diags=2",
                 "nnz": int(wl["bin2_id"].shape[0]), "nbins": int(wl["bin1_offset"].shape[0] - 1),
                 "pairs": a.pairs, "nshifts": a.nshifts, "pad": a.pad, "snippets_per_step": n_all,
-                "parallelism": f"snippet-sharded x{a.gpus}, pixel table replicated, RCCL all-reduce of tiles",
+                "parallelism": (f"{a.gpus} rank(s), pixel table replicated; " +
+                                ("each rank piles up its own 1e6-pair set" if a.scaling == "weak"
+                                 else "one snippet set split evenly over the ranks") +
+                                "; RCCL all-reduce of the packed tiles every step"),
             },
             "roofline": roofline, "cpu_baseline": cpu,
             "h2d_pixel_table_s": round(t_h2d, 3), "rank_bitmap_index": bool(have_index),

@@ -66,11 +66,10 @@ doc["k1"] = {"kernel": k1, "FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_
              "hbm_bytes_per_launch": hbm,
              "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"]}
 json.dump(doc, open(os.path.join(out, f"{tag}_pmc_summary.json"), "w"), indent=1)
-key = None
 import hashlib
 c = bench["config"]
-# must match bench._cache_path(): v3|chroms|lam|pairs|nshifts|pad  (defaults: 23 chroms, lam 4200)
-key = "coolpuppy_amd_bench_" + hashlib.sha1(f"v3|23|4200.0|{c['pairs']}|{c['nshifts']}|{c['pad']}".encode()).hexdigest()[:12] + ".npz"
+# must match bench.workload_key(): w4|chroms|lam|pairs|nshifts|pad  (defaults: 23 chroms, lam 4200)
+key = hashlib.sha1(f"w4|23|4200.0|{c['pairs']}|{c['nshifts']}|{c['pad']}".encode()).hexdigest()[:12]
 json.dump({"workload_key": key, "hbm_bytes_per_launch": hbm, "kernel": k1, "source": f"profiles/{tag}_pmc_summary.json",
            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB->bytes, FETCH_SIZE x calibration "
                      "factor measured on balance_pixels_kernel (known 8 B/pixel stream) in the same run"},
