@@ -80,6 +80,9 @@ struct pup_ctx {
     std::vector<EvTriple> pending;             // awaiting a stream sync
     hipEvent_t slots[8] = {};
     int chunk_snippets = 0, variant = 0, group_waves = 0;
+    std::vector<long long> geom_key;            // launch-geometry cache (see pup_accumulate)
+    long long g_nchunks = 0, g_nblocks = 0, g_nslices = 0;
+    bool g_two_level = false;
     int max_lds = 0, n_cu = 0;
 };
 
@@ -437,6 +440,18 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, 
         dr0 = c->d_r0.p; dc0 = c->d_c0.p;
     }
 
+    // launch geometry (chunk / group / reduction tables) depends only on the snippet COUNTS per tile and on
+    // the tuning: when it repeats (steady-state loops, benchmarks) the device tables of the last call are reused
+    std::vector<long long> gkey;
+    gkey.reserve(8 + 2 * (size_t)c->T);
+    gkey.push_back(n); gkey.push_back(c->T); gkey.push_back(c->W); gkey.push_back(c->chunk_snippets);
+    gkey.push_back(c->group_waves); gkey.push_back(c->variant & 2); gkey.push_back((mode & PUP_MODE_EXPECTED) ? 1 : 0);
+    gkey.push_back(flip_from ? 1 : 0);
+    for (int t = 0; t <= c->T; ++t) gkey.push_back(tile_ptr[t]);
+    if (flip_from) for (int t = 0; t < c->T; ++t) gkey.push_back(flip_from[t]);
+    const bool geom_hit = (gkey == c->geom_key);
+    if (!geom_hit) {
+    c->geom_key.clear();
     // ---- chunk table -------------------------------------------------------------------------------------
     // A chunk = the snippets one wave accumulates (one tile, one flip state).  Chunks come in GROUPS: a group
     // owns a contiguous range of the (position-sorted) snippets and its S chunks interleave over it (chunk j
@@ -521,6 +536,12 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, 
         HIPCHK(c, hipMemcpy(c->d_seg1.p, seg1.data(), seg1.size() * 8, hipMemcpyHostToDevice));
         HIPCHK(c, c->slice_f64.reserve((size_t)nslices * Lf)); HIPCHK(c, c->slice_num.reserve((size_t)nslices * W2));
     }
+    c->g_nchunks = nchunks; c->g_nblocks = nblocks; c->g_two_level = two_level; c->g_nslices = nslices;
+    c->geom_key = gkey;
+    }   // !geom_hit
+    const long long nchunks = c->g_nchunks, nblocks = c->g_nblocks, nslices = c->g_nslices;
+    const bool two_level = c->g_two_level;
+    (void)nchunks;
 
     // ---- K1 ---------------------------------------------------------------------------------------
     pup::K1Args a{};
