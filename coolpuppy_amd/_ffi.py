@@ -31,6 +31,7 @@ class PupStats(C.Structure):
         ("snippets", C.c_int64),
         ("pixels_in_windows", C.c_int64),
         ("probe_loads", C.c_int64),
+        ("coverage_ms", C.c_double),
     ]
 
 
@@ -51,6 +52,7 @@ _SIGNATURES = {
     "pup_device_count": (C.c_int, []),
     "pup_load_pixels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64]),
     "pup_build_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64]),
+    "pup_coverage": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "pup_load_bins": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pup_set_expected": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "pup_reset": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),

@@ -698,9 +698,15 @@ class PileUpper:
         elif self.coverage_norm and self.coverage_norm not in bins_columns:
             raise ValueError(f"coverage_norm {self.coverage_norm} not found in cooler bins")
         if self.coverage_norm in ["cov_cis_raw", "cov_tot_raw"] and self.coverage_norm not in bins_columns:
-            raise NotImplementedError(
-                f"the cooler has no {self.coverage_norm!r} column; computing coverage (cooltools.coverage, "
-                "reference coolpup.py:955-963) is not implemented here yet — store the column first")
+            # the reference computes both columns with cooltools' coverage() and STORES them in the cooler
+            # (coolpup.py:955-963); here the GPU computes them (K3) and they are kept in the cooler object
+            from . import dist as _dist
+            if not hasattr(self._aclr, "set_bins_column"):
+                raise ValueError(f"cannot store the computed {self.coverage_norm!r} column in this cooler object")
+            eng = _engine_for(self._aclr, _dist.local_device())
+            cis, tot = eng.coverage(self._aclr.chrom_offset, ignore_diags=self.ignore_diags)
+            self._aclr.set_bins_column("cov_cis_raw", cis)
+            self._aclr.set_bins_column("cov_tot_raw", tot)
         if self.coverage_norm and self.clr_weight_name:
             raise ValueError("Can't do coverage normalization when clr_weight_name is provided")
         if self.rescale:

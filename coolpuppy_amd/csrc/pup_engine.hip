@@ -84,6 +84,7 @@ struct pup_ctx {
     long long g_nchunks = 0, g_nblocks = 0, g_nslices = 0;
     bool g_two_level = false;
     int max_lds = 0, n_cu = 0;
+    float last_coverage_ms = 0.f;
 };
 
 namespace {
@@ -329,6 +330,53 @@ int pup_build_index(pup_ctx* c, const int64_t* chrom_offset, int32_t n_chroms, i
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->n_chrom = n_chroms; c->have_idx = true; c->idx_bytes = bytes;
+    return PUP_OK;
+}
+
+int pup_coverage(pup_ctx* c, const int64_t* chrom_offset, int32_t n_chroms, int32_t ignore_diags,
+                 double* cov_cis, double* cov_tot) {
+    if (!c) return PUP_EINVAL;
+    if (!c->have_px) return fail(c, PUP_ESTATE, "pup_coverage: call pup_load_pixels first");
+    if (!chrom_offset || n_chroms <= 0) return fail(c, PUP_EINVAL, "pup_coverage: NULL chrom_offset or n_chroms <= 0");
+    if (chrom_offset[0] != 0 || chrom_offset[n_chroms] != c->nbins)
+        return fail(c, PUP_EINVAL, "pup_coverage: chrom_offset must run from 0 to nbins=%lld", c->nbins);
+    if (ignore_diags < 0) return fail(c, PUP_EINVAL, "pup_coverage: ignore_diags must be >= 0");
+    int rc = bind(c); if (rc) return rc;
+    std::vector<pup::IdxChrom> tab((size_t)n_chroms);
+    for (int k = 0; k < n_chroms; ++k) {
+        if (chrom_offset[k + 1] < chrom_offset[k]) return fail(c, PUP_EINVAL, "pup_coverage: chrom_offset decreases at %d", k);
+        tab[(size_t)k] = pup::IdxChrom{(int)chrom_offset[k], (int)chrom_offset[k + 1], 0, 0, 0};
+    }
+    DevBuf<pup::IdxChrom> d_tab; DevBuf<unsigned long long> d_cov;
+    const size_t nb = (size_t)c->nbins;
+    hipError_t e = d_tab.reserve((size_t)n_chroms);
+    if (e == hipSuccess) e = d_cov.reserve(2 * nb);
+    if (e != hipSuccess) { d_tab.release(); d_cov.release(); return fail(c, PUP_ENOMEM, "pup_coverage: device allocation failed"); }
+    int status = PUP_OK;
+    std::vector<unsigned long long> h(2 * nb);
+    e = hipMemcpy(d_tab.p, tab.data(), tab.size() * sizeof(pup::IdxChrom), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemsetAsync(d_cov.p, 0, 2 * nb * sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, c->stream);
+        hipLaunchKernelGGL(pup::coverage_kernel, dim3((unsigned)((c->nbins + pup::kCovRows - 1) / pup::kCovRows)), dim3(256), 0,
+                           c->stream, c->indptr.p, c->px.p, d_tab.p, n_chroms, ignore_diags, d_cov.p, d_cov.p + nb, c->nbins);
+        (void)hipEventRecord(e1, c->stream);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        float ms = 0.f;
+        if (e == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) c->last_coverage_ms = ms;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    if (e == hipSuccess) e = hipMemcpy(h.data(), d_cov.p, 2 * nb * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) status = fail(c, PUP_EHIP, "pup_coverage: %s", hipGetErrorString(e));
+    d_tab.release(); d_cov.release();
+    if (status != PUP_OK) return status;
+    for (size_t i = 0; i < nb; ++i) {
+        if (cov_cis) cov_cis[i] = (double)(h[nb + i] - h[i]);      // total minus inter-chromosomal
+        if (cov_tot) cov_tot[i] = (double)h[nb + i];
+    }
     return PUP_OK;
 }
 
@@ -676,6 +724,7 @@ int pup_get_stats(pup_ctx* c, pup_stats* out) {
     HIPCHK(c, hipMemcpy(h, c->counters.p, sizeof h, hipMemcpyDeviceToHost));
     c->stats.pixels_in_windows = (int64_t)h[0];
     c->stats.probe_loads = (int64_t)h[1];
+    c->stats.coverage_ms = c->last_coverage_ms;
     *out = c->stats;
     return PUP_OK;
 }

@@ -683,6 +683,55 @@ __global__ __launch_bounds__(64 * kRedParts) void reduce_partials_kernel(
     }
 }
 
+// ---- K3: per-bin coverage (marginal sums of raw counts) ------------------------------------------------------
+// What coolpuppy obtains from cooltools.api.coverage.coverage(clr, ignore_diags=..., store=True) when the bins
+// table lacks cov_cis_raw / cov_tot_raw (coolpup.py:955-963): every pixel adds its count to BOTH of its bins
+// (a main-diagonal pixel therefore twice), pixels with |bin2 - bin1| < ignore_diags count as 0, the cis variant
+// only uses pixels whose bins share a chromosome.  One streaming pass over the pixel table (8 B per pixel):
+// a workgroup owns kCovRows consecutive rows; row sums are wave-reduced, column sums go to an LDS histogram over
+// the kCovCols columns following the block's first row (where almost all cis mass lies) and to global integer
+// atomics beyond it.  Integer (u64) accumulation: exact and order-independent.
+constexpr int kCovRows = 32;
+constexpr int kCovCols = 4096;
+// cov_tot accumulates every pixel; cov_trans only inter-chromosomal pixels (rare): cov_cis = cov_tot - cov_trans
+__global__ __launch_bounds__(256) void coverage_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
+                                                       const IdxChrom* __restrict__ chroms, int n_chrom, int ignore_diags,
+                                                       unsigned long long* cov_trans, unsigned long long* cov_tot,
+                                                       long long nbins) {
+    __shared__ unsigned long long h_tot[kCovCols];
+    const long long row0 = (long long)blockIdx.x * kCovRows;
+    for (int t = threadIdx.x; t < kCovCols; t += blockDim.x) h_tot[t] = 0ull;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    for (long long r = row0 + wave; r < row0 + kCovRows && r < nbins; r += nwave) {
+        int lo = 0, hi = n_chrom;
+        while (lo < hi) { const int m = (lo + hi) >> 1; if (chroms[m].end <= r) lo = m + 1; else hi = m; }
+        const long long chrom_end = lo < n_chrom ? chroms[lo].end : nbins;
+        unsigned long long s_trans = 0, s_tot = 0;
+        const long long b = indptr[r], e = indptr[r + 1];
+        for (long long k = b + lane; k < e; k += 64) {
+            const int2 pc = px[k];
+            const long long d = (long long)pc.x - r;
+            const unsigned long long w = ((d < 0 ? -d : d) < ignore_diags) ? 0ull : (unsigned long long)(unsigned)pc.y;
+            s_tot += w;
+            if (pc.x >= chrom_end) { s_trans += w; atomicAdd(&cov_trans[pc.x], w); }
+            const long long rel = (long long)pc.x - row0;
+            if (rel < kCovCols) atomicAdd(&h_tot[rel], w);
+            else atomicAdd(&cov_tot[pc.x], w);
+        }
+        for (int off = 32; off > 0; off >>= 1) { s_trans += __shfl_down(s_trans, off); s_tot += __shfl_down(s_tot, off); }
+        if (lane == 0) {
+            atomicAdd(&h_tot[r - row0], s_tot);
+            if (s_trans) atomicAdd(&cov_trans[r], s_trans);
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < kCovCols; t += blockDim.x) {
+        const long long c = row0 + t;
+        if (c < nbins && h_tot[t]) atomicAdd(&cov_tot[c], h_tot[t]);
+    }
+}
+
 // n[t] += dn[t]
 __global__ void add_counts_kernel(long long* n, const long long* dn, int T) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -93,6 +93,14 @@ class PileupEngine:
         self._check(rc)
         return True
 
+    def coverage(self, chrom_offset, ignore_diags=2):
+        """(cov_cis_raw, cov_tot_raw) of the loaded table — cooltools.coverage semantics, see pup_coverage."""
+        co = _as(chrom_offset, np.int64)
+        cis = np.empty(self.nbins, np.float64)
+        tot = np.empty(self.nbins, np.float64)
+        self._check(self._lib.pup_coverage(self._h, _ptr(co), co.shape[0] - 1, int(ignore_diags), _ptr(cis), _ptr(tot)))
+        return cis, tot
+
     def load_bins(self, weight=None, cov=None):
         """Per-bin float64 vectors: balancing weights (NaN = masked; None = raw) and coverage (None = unused)."""
         w = None if weight is None else _as(weight, np.float64)

@@ -19,6 +19,8 @@
  *                                                                      coolpuppy/coolpup.py:1059-1191, 1236-1283
  *                                                                      coolpuppy/lib/puputils.py:12-41
  *                                        (flip bit: flip_snip_func     coolpuppy/coolpup.py:128-147)
+ *   pup_coverage                      <- cooltools.api.coverage.coverage(clr, ignore_diags=..., store=True), called by
+ *                                        PileUpper.__init__ when cov_*_raw is missing     coolpuppy/coolpup.py:955-963
  *   pup_fetch / pup_export / pup_import
  *                                     <- sum_pups cross-region merge   coolpuppy/lib/puputils.py:88-113
  *                                        and the reduce at             coolpuppy/coolpup.py:1511-1531
@@ -107,6 +109,15 @@ int pup_build_index(pup_ctx* ctx, const int64_t* chrom_offset, int32_t n_chroms,
  */
 int pup_set_expected(pup_ctx* ctx, const double* expected, int64_t n);
 
+/*
+ * Per-bin coverage of the loaded table (K3), cooltools semantics: every pixel adds its raw count to BOTH of its
+ * bins (a main-diagonal pixel twice); pixels with |bin2 - bin1| < ignore_diags count as 0; cov_cis only uses
+ * pixels whose two bins share a chromosome (chrom_offset = indexes/chrom_offset, int64[n_chroms+1]).
+ * Outputs: host float64[nbins] (integers, exact); either may be NULL.  Synchronous.
+ */
+int pup_coverage(pup_ctx* ctx, const int64_t* chrom_offset, int32_t n_chroms, int32_t ignore_diags,
+                 double* cov_cis, double* cov_tot);
+
 /* accumulators ------------------------------------------------------------------------------------ */
 /* (re)allocate and zero n_tiles accumulators for windows of W = 2*pad+1 bins */
 int pup_reset(pup_ctx* ctx, int32_t n_tiles, int32_t pad);
@@ -154,6 +165,7 @@ typedef struct pup_stats {
     int64_t snippets;       /* snippets accumulated */
     int64_t pixels_in_windows; /* sum over snippets of nnz inside the window (counted on device) */
     int64_t probe_loads;    /* binary-search probes issued (counted on device) */
+    double  coverage_ms;    /* device time of the last pup_coverage kernel, ms */
 } pup_stats;
 /* profiling on: every kernel launch is bracketed by HIP events on the context's stream */
 int pup_set_profiling(pup_ctx* ctx, int enabled);

@@ -1,0 +1,43 @@
+"""K3 (pup_coverage) vs the numpy restatement of cooltools' coverage — exact (integer sums)."""
+import numpy as np
+import pytest
+
+from coolpuppy_amd import coolpup, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("ignore_diags", [0, 2, 5])
+def test_coverage_exact(hip_lib, oracle_mod, ignore_diags):
+    from coolpuppy_amd.engine import PileupEngine
+    clr = synth.make_cooler({"chrA": 60_000_000, "chrB": 23_000_000, "chrC": 9_000_000}, lam=300, seed=4,
+                            trans_nnz=200_000)
+    indptr, col, cnt = clr.pixel_table()
+    want_cis, want_tot = oracle_mod.coverage_numpy(indptr, col, cnt, clr.chrom_offset, ignore_diags)
+    with PileupEngine(0) as eng:
+        eng.load_pixels(indptr, col, cnt)
+        cis, tot = eng.coverage(clr.chrom_offset, ignore_diags=ignore_diags)
+    np.testing.assert_array_equal(cis, want_cis)
+    np.testing.assert_array_equal(tot, want_tot)
+    if ignore_diags == 0:   # the generator's own columns use the same convention
+        np.testing.assert_array_equal(tot, clr.bins()["cov_tot_raw"][:].values)
+        np.testing.assert_array_equal(cis, clr.bins()["cov_cis_raw"][:].values)
+
+
+def test_pileup_computes_missing_coverage_column(hip_lib, oracle_mod):
+    """coverage_norm=True on a cooler without cov_tot_raw: the column is computed (K3) and stored, and the
+    pile-up equals the one obtained with the column supplied up front."""
+    from coolpuppy_amd.cooler_lite import ArrayCooler
+    full = synth.make_cooler({"chrA": 30_000_000, "chrB": 12_000_000}, lam=80, seed=9)
+    indptr, col, cnt = full.pixel_table()
+    _, tot = oracle_mod.coverage_numpy(indptr, col, cnt, full.chrom_offset, 2)
+    bare = ArrayCooler(full.chromsizes, full.binsize, indptr, col, cnt, bins={"weight": full.bins()["weight"][:].values},
+                       filename="bare.cool")
+    given = ArrayCooler(full.chromsizes, full.binsize, indptr, col, cnt, bins={"cov_tot_raw": tot}, filename="given.cool")
+    pairs = synth.random_cis_pairs(full, 3000, min_sep=230_000, max_sep=2_000_000, seed=2)
+    kw = dict(features_format="bedpe", flank=100_000, clr_weight_name=None, coverage_norm=True)
+    a = coolpup.pileup(bare, pairs, **kw)
+    b = coolpup.pileup(given, pairs, **kw)
+    assert "cov_tot_raw" in bare.bins().columns
+    np.testing.assert_allclose(a["data"].iloc[0], b["data"].iloc[0], rtol=1e-12, equal_nan=True)
+    np.testing.assert_array_equal(a["num"].iloc[0], b["num"].iloc[0])
