@@ -55,6 +55,8 @@ _SIGNATURES = {
     "pup_coverage": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "pup_load_bins": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pup_set_expected": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "pup_set_expected_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                         C.c_void_p, C.c_int64, C.c_void_p]),
     "pup_reset": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "pup_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                  C.c_int32, C.c_uint32]),

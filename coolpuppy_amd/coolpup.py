@@ -924,6 +924,24 @@ class PileUpper:
         gid = {k: i for i, k in enumerate(keys_all)}
         G = len(keys_all)
         T = 2 * G
+        # expected of every view region in ONE device table, so that a single engine call can span regions
+        exp_table = None
+        if self.expected:
+            names = sorted(self._global_extents, key=lambda k: self._global_extents[k][0])
+            names = [k for k in names if k in self.view_df.index]
+            starts = np.array([self._global_extents[k][0] for k in names], np.int64)
+            ends = np.array([self._global_extents[k][1] for k in names], np.int64)
+            if len(names) and np.all(starts[1:] >= ends[:-1]):          # disjoint regions (overlap: per-region calls)
+                if self.trans:
+                    pos = {k: i for i, k in enumerate(names)}
+                    pair = np.full((len(names), len(names)), np.nan)
+                    for r1, r2 in self._region_pairs():
+                        v = self.get_expected_trans(r1, r2)
+                        pair[pos[r1], pos[r2]] = pair[pos[r2], pos[r1]] = v
+                    exp_table = {"names": names, "start": starts, "end": ends, "pair": pair, "vectors": None}
+                else:
+                    exp_table = {"names": names, "start": starts, "end": ends, "pair": None,
+                                 "vectors": [self._expected_vectors[k] for k in names]}
         raw = []
         for region1, region2, b in batches:
             if b is None or b["n"] == 0:
@@ -934,8 +952,11 @@ class PileUpper:
                 g = np.zeros(b["n"], np.int64)
             expected = None
             if self.expected:
-                expected = np.array([self.get_expected_trans(region1, region2)], np.float64) if self.trans \
-                    else self._expected_vectors[region1]
+                if exp_table is not None:
+                    expected = "table"
+                else:
+                    expected = np.array([self.get_expected_trans(region1, region2)], np.float64) if self.trans \
+                        else self._expected_vectors[region1]
             igd = -1 if self.trans else int(self.ignore_diags)
             # engine rows must come from the earlier region of the upper-triangular table
             transpose = self._global_extents[region1][0] > self._global_extents[region2][0]
@@ -952,7 +973,9 @@ class PileUpper:
         merged = []                     # [head item, [parts of fields 3..6]]
         for item in raw:
             prev = merged[-1][0] if merged else None
-            if prev is not None and item[2] is None and prev[2] is None and item[7] == prev[7] and item[8] == prev[8]:
+            same_exp = (item[2] is None and prev is not None and prev[2] is None) or \
+                (isinstance(item[2], str) and prev is not None and isinstance(prev[2], str))
+            if prev is not None and same_exp and item[7] == prev[7] and item[8] == prev[8]:
                 merged[-1][1].append(item[3:7])
             else:
                 merged.append([item, [item[3:7]]])
@@ -962,6 +985,7 @@ class PileUpper:
             calls.append(_engine_call(head[0], head[1], head[2], f[0], f[1], f[2], f[3], T, head[7], head[8]))
         return {"T": T, "G": G, "gid": gid, "order": order, "contrib": contrib, "want_control": want_control,
                 "groupby": list(groupby), "calls": calls, "pad": self.pad_bins, "n_regions": len(batches),
+                "expected_table": exp_table,
                 "weight_name": self.clr_weight_name if self.clr_weight_name else None,
                 "cov_name": self.coverage_norm if self.coverage_norm else None}
 
@@ -975,11 +999,19 @@ class PileUpper:
                       bins[plan["cov_name"]][:].values if plan["cov_name"] else None)
         eng.reset(plan["T"], plan["pad"])
         rank, world = _dist.world()
+        et = plan.get("expected_table")
+        table_set = False
         for c in plan["calls"]:
             c = _dist.slice_call(c, rank, world)          # every rank takes an even share of every tile segment
             if len(c["r0"]) == 0:
                 continue
-            eng.set_expected(c["expected"])
+            if isinstance(c["expected"], str):
+                if not table_set:
+                    eng.set_expected_table(et["start"], et["end"], vectors=et["vectors"], pair=et["pair"])
+                    table_set = True
+            else:
+                eng.set_expected(c["expected"])
+                table_set = False
             eng.accumulate(c["r0"], c["c0"], c["tile_ptr"], flip_from=c["flip_from"],
                            ignore_diags=c["ignore_diags"], mode=c["mode"])
         _dist.allreduce_engine(eng)
@@ -1113,6 +1145,38 @@ def _engine_call(region1, region2, expected, r0, c0, flip, tile, T, igd, mode):
             "flip": np.ascontiguousarray(flip, np.uint8) if flip_from is not None else None,
             "flip_from": flip_from, "tile": np.ascontiguousarray(tile, np.int32), "tile_ptr": tile_ptr,
             "ignore_diags": igd, "mode": mode}
+
+
+def iter_expected_subcalls(plan, call):
+    """Split an engine call that uses the plan's expected TABLE into (expected, sub-call) pieces that each use one
+    plain expected vector / scalar (what pup_set_expected takes).  Host-only helper for replaying a plan on
+    back-ends that have no table support (the test oracle)."""
+    if not isinstance(call["expected"], str):
+        yield call["expected"], call
+        return
+    et = plan["expected_table"]
+    transpose = bool(call["mode"] & 0x08)
+    rr = np.searchsorted(et["end"], call["r0"], side="right")
+    cc = np.searchsorted(et["end"], call["c0"], side="right")
+    key = rr * (len(et["end"]) + 1) + (cc if et["pair"] is not None else 0)
+    for kval in np.unique(key):
+        sel = np.flatnonzero(key == kval)
+        i = int(rr[sel[0]]); j = int(cc[sel[0]])
+        if et["pair"] is not None:
+            expected = np.array([et["pair"][i, j] if i < len(et["end"]) and j < len(et["end"]) else np.nan])
+        else:
+            expected = et["vectors"][i] if i < len(et["end"]) else np.array([np.nan, np.nan])
+        sub = dict(call)
+        for name in ("r0", "c0", "tile", "flip"):
+            if call.get(name) is not None:
+                sub[name] = call[name][sel]
+        T = len(call["tile_ptr"]) - 1
+        sub["tile_ptr"] = np.concatenate([[0], np.cumsum(np.bincount(sub["tile"], minlength=T))]).astype(np.int64)
+        sub["flip_from"] = None if sub.get("flip") is None else \
+            sub["tile_ptr"][1:] - np.bincount(sub["tile"][sub["flip"].astype(bool)], minlength=T)
+        sub["expected"] = expected
+        yield expected, sub
+    del transpose
 
 
 def _tiles_to_pups(plan, acc):

@@ -56,7 +56,9 @@ struct pup_ctx {
     int n_chrom = 0;
     bool have_idx = false;
     long long idx_bytes = 0;
-    DevBuf<double> weight, cov, expv;
+    DevBuf<double> weight, cov, expv, exp_pair;
+    DevBuf<pup::ExpRegion> exp_regions;
+    int n_exp_regions = 0; bool have_exp_pair = false;
     bool have_px = false, have_weight = false, have_cov = false;
     long long nbins = 0, nnz = 0, nexp = 0;
     // accumulators (packed layout of the header)
@@ -221,7 +223,7 @@ void pup_destroy(pup_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     collect_events(c);
-    c->indptr.release(); c->px.release(); c->cnt32.release(); c->bal.release(); c->badbits.release(); c->idx.release(); c->idx_chrom.release(); c->weight.release(); c->cov.release(); c->expv.release();
+    c->indptr.release(); c->px.release(); c->cnt32.release(); c->bal.release(); c->badbits.release(); c->idx.release(); c->idx_chrom.release(); c->weight.release(); c->cov.release(); c->expv.release(); c->exp_pair.release(); c->exp_regions.release();
     c->acc_f64.release(); c->acc_i64.release();
     c->d_r0.release(); c->d_c0.release(); c->d_chunk_flip.release(); c->d_chunk_stride.release(); c->d_block_chunk.release();
     c->d_chunk_begin.release(); c->d_chunk_end.release(); c->d_seg1.release(); c->d_seg2.release();
@@ -418,12 +420,45 @@ int pup_set_expected(pup_ctx* c, const double* expected, int64_t n) {
     if (n < 0 || (n > 0 && !expected)) return fail(c, PUP_EINVAL, "pup_set_expected: bad arguments");
     int rc = bind(c); if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));   // earlier launches may still read the old vector
-    c->nexp = 0;
+    c->nexp = 0; c->n_exp_regions = 0; c->have_exp_pair = false;
     if (n > 0) {
         HIPCHK(c, c->expv.reserve((size_t)n));
         HIPCHK(c, hipMemcpy(c->expv.p, expected, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
         c->nexp = n;
     }
+    return PUP_OK;
+}
+
+int pup_set_expected_table(pup_ctx* c, const int32_t* start, const int32_t* end, const int64_t* offset,
+                           const int64_t* length, int32_t n_regions, const double* values, int64_t n_values,
+                           const double* pair) {
+    if (!c) return PUP_EINVAL;
+    if (n_regions <= 0 || !start || !end) return fail(c, PUP_EINVAL, "pup_set_expected_table: no regions");
+    if (!pair && (!offset || !length || !values || n_values <= 0))
+        return fail(c, PUP_EINVAL, "pup_set_expected_table: cis table needs offset/length/values");
+    std::vector<pup::ExpRegion> tab((size_t)n_regions);
+    for (int r = 0; r < n_regions; ++r) {
+        if (end[r] < start[r] || (r > 0 && start[r] < end[r - 1]))
+            return fail(c, PUP_EINVAL, "pup_set_expected_table: regions must be sorted by start and disjoint (region %d)", r);
+        const long long off = pair ? 0 : offset[r], len = pair ? 0 : length[r];
+        if (off < 0 || len < 0 || off + len > n_values)
+            if (!pair) return fail(c, PUP_EINVAL, "pup_set_expected_table: vector of region %d leaves values[]", r);
+        tab[(size_t)r] = pup::ExpRegion{start[r], end[r], off, len};
+    }
+    int rc = bind(c); if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->nexp = 0; c->n_exp_regions = 0; c->have_exp_pair = false;
+    HIPCHK(c, c->exp_regions.reserve((size_t)n_regions));
+    HIPCHK(c, hipMemcpy(c->exp_regions.p, tab.data(), tab.size() * sizeof(pup::ExpRegion), hipMemcpyHostToDevice));
+    if (pair) {
+        HIPCHK(c, c->exp_pair.reserve((size_t)n_regions * n_regions));
+        HIPCHK(c, hipMemcpy(c->exp_pair.p, pair, (size_t)n_regions * n_regions * sizeof(double), hipMemcpyHostToDevice));
+        c->have_exp_pair = true;
+    } else {
+        HIPCHK(c, c->expv.reserve((size_t)n_values));
+        HIPCHK(c, hipMemcpy(c->expv.p, values, (size_t)n_values * sizeof(double), hipMemcpyHostToDevice));
+    }
+    c->n_exp_regions = n_regions;
     return PUP_OK;
 }
 
@@ -465,7 +500,7 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, 
                         (long long)flip_from[t], (long long)tile_ptr[t], (long long)tile_ptr[t + 1]);
     }
     const bool m_ooe = mode & PUP_MODE_OOE, m_exp = mode & PUP_MODE_EXPECTED;
-    if ((m_ooe || m_exp) && c->nexp == 0)
+    if ((m_ooe || m_exp) && c->nexp == 0 && c->n_exp_regions == 0)
         return fail(c, PUP_ESTATE, "pup_accumulate: OOE/EXPECTED mode without pup_set_expected");
     if (m_ooe && m_exp) return fail(c, PUP_EINVAL, "pup_accumulate: OOE and EXPECTED are exclusive");
     if ((mode & PUP_MODE_COV) && !c->have_cov)
@@ -600,7 +635,10 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, 
     a.n_chrom = use_idx ? c->n_chrom : 0;
     a.weight = c->have_weight ? c->weight.p : nullptr;
     a.cov = c->have_cov ? c->cov.p : nullptr;
-    a.expv = c->nexp > 0 ? c->expv.p : nullptr; a.nexp = c->nexp; a.nbins = c->nbins;
+    a.expv = (c->nexp > 0 || (c->n_exp_regions > 0 && !c->have_exp_pair)) ? c->expv.p : nullptr;
+    a.nexp = c->nexp; a.nbins = c->nbins;
+    a.exp_regions = c->n_exp_regions > 0 ? c->exp_regions.p : nullptr; a.n_exp_regions = c->n_exp_regions;
+    a.exp_pair = c->have_exp_pair ? c->exp_pair.p : nullptr;
     a.r0 = dr0; a.c0 = dc0;
     a.chunk_begin = c->d_chunk_begin.p; a.chunk_end = c->d_chunk_end.p; a.chunk_flip = c->d_chunk_flip.p;
     a.chunk_stride = c->d_chunk_stride.p; a.block_chunk = c->d_block_chunk.p;

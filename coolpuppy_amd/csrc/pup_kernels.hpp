@@ -52,6 +52,18 @@ struct IdxChrom {             // per chromosome (device table, sorted by start)
     long long blk_base;       // index of the first block of the chromosome's first row
 };
 
+// expected for many regions in one call: region = global bins [start, end), by-diagonal vector at expv[off .. off+len)
+struct ExpRegion { int start, end; long long off, len; };
+
+// what one snippet divides by: a by-diagonal vector (value = base[|col-row|], NaN beyond len) or one scalar
+struct ExpSel {
+    const double* base; long long len; double scalar; bool is_scalar;
+    __device__ __forceinline__ double at(long long ad) const {
+        if (is_scalar) return scalar;
+        return ad < len ? base[ad] : __builtin_nan("");
+    }
+};
+
 struct K1Args {
     // resident tables
     const long long* indptr;   // [nbins+1]
@@ -66,8 +78,11 @@ struct K1Args {
     int              n_chrom;
     const double*    weight;   // [nbins] or nullptr (raw)
     const double*    cov;      // [nbins] or nullptr
-    const double*    expv;     // [nexp] or nullptr
+    const double*    expv;     // [nexp] or nullptr: ONE by-diagonal vector (nexp >= 2) or ONE scalar (nexp == 1) ...
     long long        nexp;
+    const ExpRegion* exp_regions;  // ... or, when n_exp_regions > 0, a table of regions: expv holds their vectors
+    int              n_exp_regions;
+    const double*    exp_pair;     // [n_exp_regions^2] trans: scalar expected of block (region of r0, region of c0), or nullptr
     long long        nbins;
     // snippets (device)
     const int*           r0;
@@ -103,6 +118,48 @@ __device__ __forceinline__ void lds_add_f64(double* p, double v) {
     // fire-and-forget LDS f64 add (ds_add_f64); cells within one snippet are distinct,
     // the atomic form is used because it is a single no-return instruction.
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// region lookup for the expected table (regions sorted by start, disjoint); -1 when the bin is in no region
+__device__ __forceinline__ int find_exp_region(const ExpRegion* __restrict__ regs, int n, int bin) {
+    int lo = 0, hi = n;
+    while (lo < hi) { const int m = (lo + hi) >> 1; if (regs[m].end <= bin) lo = m + 1; else hi = m; }
+    return (lo < n && regs[lo].start <= bin) ? lo : -1;
+}
+
+struct ExpCache { int r_idx = -1, r_start = 0, r_end = -1; long long r_off = 0, r_len = 0; int c_idx = -1, c_start = 0, c_end = -1; };
+
+// expected of the snippet at (r0, c0): legacy single vector / scalar, or the region table (cis: the vector of the
+// region holding r0; trans: the pair scalar of (region of r0, region of c0)).  All wave-uniform.
+__device__ __forceinline__ ExpSel select_expected(const K1Args& a, ExpCache& ec, int r0, int c0) {
+    ExpSel e;
+    const double qn = __builtin_nan("");
+    if (a.n_exp_regions <= 0) {
+        e.base = a.expv; e.len = a.nexp; e.is_scalar = (a.nexp == 1);
+        e.scalar = (a.nexp == 1 && a.expv) ? a.expv[0] : qn;
+        if (!a.expv || a.nexp <= 0) { e.is_scalar = true; e.scalar = qn; }
+        return e;
+    }
+    if (!(r0 >= ec.r_start && r0 < ec.r_end)) {
+        ec.r_idx = find_exp_region(a.exp_regions, a.n_exp_regions, r0);
+        if (ec.r_idx >= 0) { const ExpRegion g = a.exp_regions[ec.r_idx]; ec.r_start = g.start; ec.r_end = g.end; ec.r_off = g.off; ec.r_len = g.len; }
+        else { ec.r_start = 0; ec.r_end = -1; }
+    }
+    if (a.exp_pair) {
+        if (!(c0 >= ec.c_start && c0 < ec.c_end)) {
+            ec.c_idx = find_exp_region(a.exp_regions, a.n_exp_regions, c0);
+            if (ec.c_idx >= 0) { const ExpRegion g = a.exp_regions[ec.c_idx]; ec.c_start = g.start; ec.c_end = g.end; }
+            else { ec.c_start = 0; ec.c_end = -1; }
+        }
+        e.is_scalar = true; e.base = nullptr; e.len = 0;
+        e.scalar = (ec.r_idx >= 0 && ec.r_end > r0 && ec.c_idx >= 0 && ec.c_end > c0)
+                       ? a.exp_pair[(long long)ec.r_idx * a.n_exp_regions + ec.c_idx] : qn;
+        return e;
+    }
+    e.is_scalar = false; e.scalar = qn;
+    if (ec.r_idx >= 0 && r0 < ec.r_end) { e.base = a.expv + ec.r_off; e.len = ec.r_len; }
+    else { e.base = a.expv; e.len = 0; }
+    return e;
 }
 
 // cell of the accumulator a window cell (p, q) lands in: TRANSPOSE first (back to the reference's frame),
@@ -156,9 +213,10 @@ __global__ __launch_bounds__(kWave) void pileup_chunk_kernel(K1Args a) {
     const bool m_exp   = a.mode & 0x02u;
     const bool m_cov   = (a.mode & 0x04u) && a.cov != nullptr;
     const bool m_tr    = a.mode & 0x08u;
-    const bool use_exp = (m_ooe || m_exp) && a.expv != nullptr && a.nexp > 0;
+    const bool use_exp = (m_ooe || m_exp) && ((a.expv != nullptr && a.nexp > 0) || a.n_exp_regions > 0);
     const int  igd     = a.ignore_diags;
     const bool have_idx = a.idx != nullptr && W <= 64;
+    ExpCache ecache;
 
     const int ck = a.block_chunk[blockIdx.x];
     if (ck < 0) return;                                          // padding workgroup (wave-uniform)
@@ -227,13 +285,11 @@ __global__ __launch_bounds__(kWave) void pileup_chunk_kernel(K1Args a) {
             }
         }
         if (use_exp) {
+            const ExpSel es = select_expected(a, ecache, r0s, c0s);
             const int dmin = (c0s - r0s) - (W - 1);
             for (int i = lane; i < 2 * W - 1; i += kWave) {
                 long long ad = dmin + i; if (ad < 0) ad = -ad;
-                double e;
-                if (a.nexp == 1) e = a.expv[0];        // trans scalar
-                else e = ad < a.nexp ? a.expv[ad] : __builtin_nan("");
-                ex[i] = e;
+                ex[i] = es.at(ad);
             }
         }
         __syncthreads();
@@ -382,10 +438,11 @@ __global__ __launch_bounds__(kWave, rt_min_waves(W)) void pileup_regtile_kernel(
 
     const bool m_cov   = (a.mode & 0x04u) && a.cov != nullptr;
     const bool m_tr    = a.mode & 0x08u;
-    const bool use_exp = OOE && a.expv != nullptr && a.nexp > 0;
+    const bool use_exp = OOE && ((a.expv != nullptr && a.nexp > 0) || a.n_exp_regions > 0);
     const int  igd     = a.ignore_diags;
     const bool have_idx = a.idx != nullptr;
     const double qnan = __builtin_nan("");
+    ExpCache ecache;
 
     const int ck = a.block_chunk[blockIdx.x];
     if (ck < 0) return;                                               // padding workgroup (wave-uniform)
@@ -487,12 +544,13 @@ __global__ __launch_bounds__(kWave, rt_min_waves(W)) void pileup_regtile_kernel(
         }
         double ev[CH];
         if (OOE) {
+            ExpSel es; es.base = a.expv; es.len = 0; es.scalar = qnan; es.is_scalar = true;
+            if (use_exp) es = select_expected(a, ecache, g.r0, g.c0);
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
                 long long ad = (long long)(cc + i) - r; if (ad < 0) ad = -ad;
-                const long long ai = (a.nexp == 1) ? 0 : (ad < a.nexp ? ad : 0);
-                const double e = use_exp ? a.expv[ai] : qnan;
-                ev[i] = (a.nexp == 1 || ad < a.nexp) ? e : qnan;
+                const double e = es.is_scalar ? es.scalar : es.base[ad < es.len ? ad : 0];   // unconditional load
+                ev[i] = (es.is_scalar || ad < es.len) ? e : qnan;
             }
         }
         if (m_cov) {

@@ -118,6 +118,21 @@ class PileupEngine:
         e = np.atleast_1d(_as(expected, np.float64))
         self._check(self._lib.pup_set_expected(self._h, _ptr(e), e.shape[0]))
 
+    def set_expected_table(self, start, end, vectors=None, pair=None):
+        """Expected of many regions at once. start/end: global bin ranges (sorted, disjoint).
+        vectors: list of by-diagonal vectors, one per region (cis);  pair: [n, n] matrix of scalars (trans)."""
+        start, end = _as(start, np.int32), _as(end, np.int32)
+        n = start.shape[0]
+        if pair is not None:
+            pm = _as(pair, np.float64).reshape(n, n)
+            self._check(self._lib.pup_set_expected_table(self._h, _ptr(start), _ptr(end), None, None, n, None, 0, _ptr(pm)))
+            return
+        lens = np.array([len(v) for v in vectors], np.int64)
+        offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+        vals = _as(np.concatenate([np.asarray(v, np.float64) for v in vectors]) if n else np.zeros(1), np.float64)
+        self._check(self._lib.pup_set_expected_table(self._h, _ptr(start), _ptr(end), _ptr(offs), _ptr(lens), n,
+                                                     _ptr(vals), vals.shape[0], None))
+
     # -- accumulators -----------------------------------------------------------------------------------
     def reset(self, n_tiles, pad):
         self._check(self._lib.pup_reset(self._h, int(n_tiles), int(pad)))

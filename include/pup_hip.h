@@ -12,7 +12,7 @@
  *   pup_build_index                   <- (no counterpart: device-side search structure over the same table;
  *                                        chromosome partition = cooler's indexes/chrom_offset, the extents the
  *                                        reference takes from clr.extent / clr.offset,     coolpuppy/coolpup.py:922-925)
- *   pup_set_expected                  <- expected_selections / get_expected_trans
+ *   pup_set_expected[_table]          <- expected_selections / get_expected_trans
  *                                                                      coolpuppy/coolpup.py:907-916, 999-1005
  *   pup_reset                         <- make_outmap / empty_pup       coolpuppy/coolpup.py:986-997, 1007-1022
  *   pup_accumulate                    <- _stream_snips + accumulate_stream + _add_snip
@@ -108,6 +108,18 @@ int pup_build_index(pup_ctx* ctx, const int64_t* chrom_offset, int32_t n_chroms,
  *   n == 0 : none
  */
 int pup_set_expected(pup_ctx* ctx, const double* expected, int64_t n);
+/*
+ * Expected for MANY regions at once, so that one pup_accumulate call can span regions (replaces the state set
+ * by pup_set_expected).  Regions r = 0..n_regions-1 cover global bins [start[r], end[r]), sorted and disjoint.
+ *   cis   (pair == NULL): the by-diagonal vector of region r is values[offset[r] .. offset[r]+length[r]); a
+ *         snippet uses the vector of the region holding its first row (expected_selections, coolpup.py:913-916)
+ *   trans (pair != NULL): pair[r1*n_regions + r2] is the scalar expected of the block with rows in region r1
+ *         and columns in region r2 (get_expected_trans, coolpup.py:999-1005); values/offset/length are ignored
+ * A snippet outside every region sees NaN expected (all of its cells are invalid).
+ */
+int pup_set_expected_table(pup_ctx* ctx, const int32_t* start, const int32_t* end, const int64_t* offset,
+                           const int64_t* length, int32_t n_regions, const double* values, int64_t n_values,
+                           const double* pair);
 
 /*
  * Per-bin coverage of the loaded table (K3), cooltools semantics: every pixel adds its raw count to BOTH of its

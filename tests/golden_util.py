@@ -96,7 +96,9 @@ def oracle_run_plan(pu, plan):
     weight = bins[plan["weight_name"]][:].values if plan["weight_name"] else None
     cov = bins[plan["cov_name"]][:].values if plan["cov_name"] else None
     acc = po.empty_acc(plan["T"], plan["pad"])
-    for c in plan["calls"]:
-        po.pileup_c(indptr, col, cnt, weight, cov, c["expected"], c["r0"], c["c0"], c["flip"], c["tile"],
-                    plan["T"], plan["pad"], c["ignore_diags"], c["mode"], acc=acc)
+    from coolpuppy_amd.coolpup import iter_expected_subcalls
+    for call in plan["calls"]:
+        for expected, c in iter_expected_subcalls(plan, call):
+            po.pileup_c(indptr, col, cnt, weight, cov, expected, c["r0"], c["c0"], c["flip"], c["tile"],
+                        plan["T"], plan["pad"], c["ignore_diags"], c["mode"], acc=acc)
     return acc

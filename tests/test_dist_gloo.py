@@ -42,8 +42,9 @@ def run_plan_sharded(pu, plan):
                 k = int(c["flip_from"][t] - c["tile_ptr"][t])
                 assert not seg[:k].any() and seg[k:].all()
         if len(c["r0"]):
-            po.pileup_c(indptr, col, cnt, weight, cov, c["expected"], c["r0"], c["c0"], c["flip"], c["tile"],
-                        plan["T"], plan["pad"], c["ignore_diags"], c["mode"], acc=acc)
+            for expected, sc in coolpup.iter_expected_subcalls(plan, c):
+                po.pileup_c(indptr, col, cnt, weight, cov, expected, sc["r0"], sc["c0"], sc["flip"], sc["tile"],
+                            plan["T"], plan["pad"], sc["ignore_diags"], sc["mode"], acc=acc)
     T, W = plan["T"], 2 * plan["pad"] + 1
     f64 = np.concatenate([acc["sum"].ravel(), acc["cov_start"].ravel(), acc["cov_end"].ravel()])
     i64 = np.concatenate([acc["num"].ravel(), acc["n"].ravel()])

@@ -23,8 +23,12 @@ def timed_plan(pu, plan, reps=3):
         eng.clear_stats()
         t = time.time()
         eng.reset(plan["T"], plan["pad"])
+        et = plan.get("expected_table")
         for c in plan["calls"]:
-            eng.set_expected(c["expected"])
+            if isinstance(c["expected"], str):
+                eng.set_expected_table(et["start"], et["end"], vectors=et["vectors"], pair=et["pair"])
+            else:
+                eng.set_expected(c["expected"])
             eng.accumulate(c["r0"], c["c0"], c["tile_ptr"], flip_from=c["flip_from"], ignore_diags=c["ignore_diags"],
                            mode=c["mode"])
         eng.sync()

@@ -38,8 +38,12 @@ def engine_time(pu, plan, reps=3):
         eng.clear_stats()
         t = time.time()
         eng.reset(plan["T"], plan["pad"])
+        et = plan.get("expected_table")
         for c in plan["calls"]:
-            eng.set_expected(c["expected"])
+            if isinstance(c["expected"], str):
+                eng.set_expected_table(et["start"], et["end"], vectors=et["vectors"], pair=et["pair"])
+            else:
+                eng.set_expected(c["expected"])
             eng.accumulate(c["r0"], c["c0"], c["tile_ptr"], flip_from=c["flip_from"], ignore_diags=c["ignore_diags"],
                            mode=c["mode"])
         eng.sync()
@@ -66,6 +70,7 @@ def oracle_check(pu, plan, got, max_snips=60_000):
     eng.reset(plan["T"], plan["pad"])
     acc = po.empty_acc(plan["T"], plan["pad"])
     n_s = 0
+    et = plan.get("expected_table")
     for c in plan["calls"]:
         idx = np.arange(0, len(c["r0"]), step)
         if len(idx) == 0:
@@ -75,11 +80,15 @@ def oracle_check(pu, plan, got, max_snips=60_000):
         call = coolpup._engine_call(c["region1"], c["region2"], c["expected"], c["r0"][idx].astype(np.int64),
                                     c["c0"][idx].astype(np.int64), flip, tile.astype(np.int64), plan["T"],
                                     c["ignore_diags"], c["mode"])
-        eng.set_expected(call["expected"])
+        if isinstance(call["expected"], str):
+            eng.set_expected_table(et["start"], et["end"], vectors=et["vectors"], pair=et["pair"])
+        else:
+            eng.set_expected(call["expected"])
         eng.accumulate(call["r0"], call["c0"], call["tile_ptr"], flip_from=call["flip_from"],
                        ignore_diags=call["ignore_diags"], mode=call["mode"])
-        po.pileup_c(indptr, col, cnt, weight, cov, call["expected"], call["r0"], call["c0"], call["flip"], call["tile"],
-                    plan["T"], plan["pad"], call["ignore_diags"], call["mode"], acc=acc)
+        for expected, sc in coolpup.iter_expected_subcalls(plan, call):
+            po.pileup_c(indptr, col, cnt, weight, cov, expected, sc["r0"], sc["c0"], sc["flip"], sc["tile"],
+                        plan["T"], plan["pad"], sc["ignore_diags"], sc["mode"], acc=acc)
         n_s += len(idx)
     g = eng.fetch()
     ok = (np.array_equal(g["n"], acc["n"]) and np.array_equal(g["num"], acc["num"])
