@@ -757,7 +757,8 @@ class PileUpper:
             return "_gc_" + g, (lambda i, u=uniq: u[i])
         return g, None
 
-    def region_snippets(self, region1, region2=None, groupby=[], modify_2Dintervals_func=None, columns=()):
+    def region_snippets(self, region1, region2=None, groupby=[], modify_2Dintervals_func=None, columns=(),
+                        by_window=False):
         """Host half of ``pileup_region`` (reference :1285-1358 down to the skip test :1105-1114).
 
         Returns None when the region has no feature, else a dict with the accepted windows:
@@ -773,6 +774,8 @@ class PileUpper:
         src = {}                       # groupby column -> (carried column, decoder)
         if carry is not None and builtin:
             carry = list(carry)
+            if by_window:
+                carry += ["_gc_chrom1", "start1", "end1", "_gc_chrom2", "start2", "end2"]
             for g in groupby:
                 src[g] = self._group_source(g)
                 if g != "distance_band":
@@ -820,6 +823,17 @@ class PileUpper:
                 keycols.append(v)
                 decs.append(dec)
             codes, keys = _factorize_rows(keycols, decs)
+        elif by_window:
+            # every snippet is counted once for the feature on each side (group_by_region, lib/puputils.py:218-223):
+            # emit it twice, side 1 then side 2, keyed by (chrom, start, end) of that side's feature
+            chrom_u = self.CC.group_codes("chrom")[1]
+            two = lambda a, b: np.stack([a, b], axis=1).ravel()      # noqa: E731  interleave side 1 / side 2
+            kc = [two(tbl["_gc_chrom1"], tbl["_gc_chrom2"]), two(tbl["start1"], tbl["start2"]),
+                  two(tbl["end1"], tbl["end2"])]
+            codes, keys = _factorize_rows(kc, [lambda i, u=chrom_u: u[i], None, None])
+            dup = np.repeat(np.arange(n), 2)
+            return {"r0": r0[dup], "c0": c0[dup], "kind": tbl["kind"].astype(np.int8)[dup], "flip": flip[dup],
+                    "group_codes": codes, "group_keys": keys, "n": 2 * n}
         else:
             codes, keys = np.full(n, -1, np.int64), []
         return {"r0": r0, "c0": c0, "kind": tbl["kind"].astype(np.int8), "flip": flip, "group_codes": codes,
@@ -827,7 +841,7 @@ class PileUpper:
 
     # -- the pile-up -------------------------------------------------------------------------------------------
     def pileupsWithControl(self, nproc=None, groupby=[], ignore_group_order=False, modify_2Dintervals_func=None,
-                           postprocess_func=None, extra_sum_funcs=None, _columns=()):
+                           postprocess_func=None, extra_sum_funcs=None, _columns=(), _by_window=False):
         """All regions -> normalised pile-ups DataFrame (reference :1360-1654)."""
         self.ignore_group_order = ignore_group_order
         if postprocess_func is not None or extra_sum_funcs:
@@ -883,17 +897,19 @@ class PileUpper:
         batches = []
         for region1, region2 in self._region_pairs():
             b = self.region_snippets(region1, region2, groupby=groupby, modify_2Dintervals_func=modify,
-                                     columns=columns)
+                                     columns=columns, by_window=_by_window)
             batches.append((region1, region2, b))
             if b is not None and b["n"] > 0:
                 logger.info(f"{region1, region2}: {int((b['kind'] == KIND_ROI).sum())}")
 
-        return self._pile_and_finalize(batches, groupby)
+        return self._pile_and_finalize(batches, groupby, grouped=bool(groupby) or _by_window)
 
-    def make_plan(self, batches, groupby):
+    def make_plan(self, batches, groupby, grouped=None):
         """Turn per-region window tables into a declarative list of engine calls plus the group bookkeeping
         the finaliser needs.  Pure host code (no GPU): tests replay a plan on the CPU oracle."""
         from .engine import MODE_COV, MODE_EXPECTED, MODE_OOE, MODE_TRANSPOSE
+        if grouped is None:
+            grouped = bool(groupby)
         # global group table in the reference's first-appearance order: regions in order, each region's
         # groups in snippet order, then "all" (coolpup.py:1263-1283, 1511-1531)
         exp_as_control = bool(self.expected) and not self.ooe
@@ -909,7 +925,7 @@ class PileUpper:
             contrib[kind][key] = contrib[kind].get(key, 0) + 1
 
         for _, _, b in batches:
-            if b is not None and b["n"] > 0 and groupby:
+            if b is not None and b["n"] > 0 and grouped:
                 for kind in (KIND_ROI, KIND_CONTROL):
                     # with expected & !ooe every ROI snippet also emits an expected ("control") snippet
                     sel = b["kind"] == (KIND_ROI if (exp_as_control and kind == KIND_CONTROL) else kind)
@@ -946,7 +962,7 @@ class PileUpper:
         for region1, region2, b in batches:
             if b is None or b["n"] == 0:
                 continue
-            if groupby:
+            if grouped:
                 g = np.array([gid[k] for k in b["group_keys"]], np.int64)[b["group_codes"]]
             else:
                 g = np.zeros(b["n"], np.int64)
@@ -984,7 +1000,8 @@ class PileUpper:
             f = [np.concatenate([p[k] for p in parts]) if len(parts) > 1 else parts[0][k] for k in range(4)]
             calls.append(_engine_call(head[0], head[1], head[2], f[0], f[1], f[2], f[3], T, head[7], head[8]))
         return {"T": T, "G": G, "gid": gid, "order": order, "contrib": contrib, "want_control": want_control,
-                "groupby": list(groupby), "calls": calls, "pad": self.pad_bins, "n_regions": len(batches),
+                "groupby": list(groupby), "grouped": bool(grouped), "calls": calls, "pad": self.pad_bins,
+                "n_regions": len(batches),
                 "expected_table": exp_table,
                 "weight_name": self.clr_weight_name if self.clr_weight_name else None,
                 "cov_name": self.coverage_norm if self.coverage_norm else None}
@@ -1020,7 +1037,7 @@ class PileUpper:
     def finalize_plan(self, plan, acc):
         """Fetched tiles -> the reference's output DataFrame."""
         G, gid, order = plan["G"], plan["gid"], plan["order"]
-        if plan["groupby"]:   # "all" of a grouped pile-up = sum of its groups (reference :1271-1282)
+        if plan["grouped"]:   # "all" of a grouped pile-up = sum of its groups (reference :1271-1282)
             for kind in (KIND_ROI, KIND_CONTROL):
                 members = [kind * G + gid[k] for k in order[kind] if not (isinstance(k, str) and k == "all")]
                 if members:
@@ -1028,10 +1045,10 @@ class PileUpper:
                     for name in ("sum", "num", "n", "cov_start", "cov_end"):
                         acc[name][a] = acc[name][members].sum(axis=0)
         return finalize_pileups(self, acc, order, plan["contrib"], gid, G, plan["groupby"], plan["want_control"],
-                                n_regions=plan["n_regions"])
+                                n_regions=plan["n_regions"], grouped=plan["grouped"])
 
-    def _pile_and_finalize(self, batches, groupby):
-        plan = self.make_plan(batches, groupby)
+    def _pile_and_finalize(self, batches, groupby, grouped=None):
+        plan = self.make_plan(batches, groupby, grouped=grouped)
         return self.finalize_plan(plan, self.run_plan(plan))
 
     def pileup_region(self, region1, region2=None, groupby=[], modify_2Dintervals_func=None, postprocess_func=None,
@@ -1060,9 +1077,27 @@ class PileUpper:
         return pups
 
     def pileupsByWindowWithControl(self, nproc=None):
+        """One pile-up per feature: every pair is counted for both of its features (reference :1696-1755)."""
+        if nproc is None:
+            nproc = self.nproc
         if self.local:
             raise ValueError("Cannot do by-window pileups for local")
-        raise NotImplementedError("by-window pile-ups are not implemented in coolpuppy_amd (SURVEY.md §8(f))")
+        if self.kind != "bed":
+            raise ValueError("Can't make by-window pileups without making combinations")
+        pups = self.pileupsWithControl(nproc=nproc, _by_window=True)
+        is_all = pups["group"].apply(lambda g: isinstance(g, str) and g == "all")
+        coords = pd.DataFrame([("all", -1, -1) if a else tuple(g) for a, g in zip(is_all, pups["group"])],
+                              index=pups.index, columns=["chrom", "start", "end"])
+        pups = pd.concat([coords, pups], axis=1)
+        pups[["start", "end"]] = pups[["start", "end"]].astype(int)
+        pups = pups.drop(columns="group")
+        # bioframe.sort_bedframe(df, view_df): by the view's chromosome order, then start, end; "all" (not in the
+        # view) lands at the end
+        view_chroms = list(dict.fromkeys(self.view_df["chrom"]))
+        rank = {c: i for i, c in enumerate(view_chroms)}
+        key = pups["chrom"].map(lambda c: rank.get(c, len(rank)))
+        pups = pups.assign(_k=key).sort_values(["_k", "start", "end"], kind="stable").drop(columns="_k")
+        return pups.reset_index(drop=True)
 
     def _distance_edges(self, distance_edges):
         if not (isinstance(distance_edges, str) and distance_edges == "default"):
@@ -1181,7 +1216,7 @@ def iter_expected_subcalls(plan, call):
 
 def _tiles_to_pups(plan, acc):
     G, gid, order = plan["G"], plan["gid"], plan["order"]
-    if plan["groupby"]:
+    if plan["grouped"]:
         for kind in (KIND_ROI, KIND_CONTROL):
             members = [kind * G + gid[k] for k in order[kind] if not (isinstance(k, str) and k == "all")]
             if members:

@@ -63,14 +63,16 @@ def _tile_frame(acc, kind, order, contrib, gid, G, grouped):
         rows[key] = {"data": data, "num": acc["num"][t].copy(), "n": int(acc["n"][t]),
                      "cov_start": acc["cov_start"][t].copy(), "cov_end": acc["cov_end"][t].copy()}
     df = pd.DataFrame(list(rows.values()), columns=["data", "num", "n", "cov_start", "cov_end"])
+    df["n"] = df["n"].astype(object)     # the reference's frames hold Python ints in object columns
     df.index = pd.Index(list(rows.keys()), tupleize_cols=False)
     return df
 
 
-def finalize_pileups(pu, acc, order, contrib, gid, G, groupby, want_control, n_regions):
+def finalize_pileups(pu, acc, order, contrib, gid, G, groupby, want_control, n_regions, grouped=None):
     """Tail of pileupsWithControl (coolpup.py:1533-1654) on summed tiles -> annotated DataFrame."""
     import warnings
-    grouped = bool(groupby)
+    if grouped is None:
+        grouped = bool(groupby)
     roi = _tile_frame(acc, KIND_ROI, order, contrib, gid, G, grouped)
     ctrl = _tile_frame(acc, KIND_CONTROL, order, contrib, gid, G, grouped) if want_control else None
 

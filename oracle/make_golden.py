@@ -174,6 +174,10 @@ def scenarios():
         flip_negative_strand=True, by_strand=True, maxdist=3_000_000)
     add("G9d_bed_ignore_group_order", "small", bed, features_format="bed", flank=100_000, by_strand=True,
         ignore_group_order=True, flip_negative_strand=True, maxdist=3_000_000)
+    add("G10_by_window", "small", bed, features_format="bed", flank=100_000, by_window=True, mindist=300_000,
+        maxdist=2_000_000)
+    add("G10b_by_window_controls", "small", bed.groupby("chrom").head(12), features_format="bed", flank=50_000,
+        by_window=True, nshifts=2, seed=10, maxdist=4_000_000)
     # known-answer tests of the reference's own test-suite (tests/test_coolpup.py), n depends on coordinates only
     toy_kw = dict(features_format="bed", flank=2_000_000, mindist=0)
     add("KAT_bystrand_expected_ooe", "toy", toy_feat, view=toy_view, expected=toy_exp, by_strand=True, **toy_kw)
@@ -203,13 +207,23 @@ def key_repr(k):
     return out
 
 
+def group_list(df):
+    if "group" in df.columns:
+        return [key_repr(g) for g in df["group"]]
+    # by-window output: the group is spelled out as chrom / start / end columns
+    return [("all" if c == "all" else [str(c), int(s), int(e)]) for c, s, e in zip(df["chrom"], df["start"], df["end"])]
+
+
 def record(df, W):
     rows = len(df)
     rec = {
-        "group": json.dumps([key_repr(g) for g in df["group"]]),
-        "data": np.stack([np.asarray(x, float).reshape(W, W) for x in df["data"]]),
+        "group": json.dumps(group_list(df)),
+        # a group seen only among the controls has no ROI tile: the reference leaves scalar NaN there
+        "data": np.stack([np.asarray(x, float).reshape(W, W) if np.ndim(x) == 2 else np.full((W, W), np.nan)
+                          for x in df["data"]]),
         "n": df["n"].values.astype(np.float64),
-        "num": np.stack([np.asarray(x).reshape(W, W) for x in df["num"]]).astype(np.int64),
+        "num": np.stack([np.asarray(x).reshape(W, W) if np.ndim(x) == 2 else np.full((W, W), -1)
+                         for x in df["num"]]).astype(np.int64),
     }
     if "control_n" in df.columns:
         rec["control_n"] = df["control_n"].values.astype(np.float64)
@@ -267,7 +281,8 @@ def main():
         rec["meta"] = json.dumps(meta)
         np.savez_compressed(os.path.join(GOLD, sc["name"] + ".npz"), **rec)
         index.append(sc["name"])
-        print(f"{sc['name']:45s} rows={len(df):3d} n_all={int(df.loc[df['group'].astype(str) == 'all', 'n'].iloc[0])}")
+        gl = group_list(df)
+        print(f"{sc['name']:45s} rows={len(df):3d} n_all={int(df['n'].iloc[gl.index('all')])}")
 
         # ---- window streams of the reference (pins filtering, ordering and the control-shift RNG) ------------
         if sc["name"] in ("G3_nshifts3", "G3b_nshifts10_view", "G9b_bed_combinations_controls_strand",

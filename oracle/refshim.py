@@ -17,6 +17,7 @@ multiprocessing_logging) and the upstream behaviour each stand-in restates:
 * ``cooltools.lib.common.make_cooler_view``: one whole-chromosome row per chromosome, name = chrom.
 * ``cooltools.lib.checks.is_valid_expected / is_compatible_viewframe``: accept (return True).
 * ``bioframe.make_viewframe``: chrom/start/end/name frame; name defaults to the chromosome.
+  ``bioframe.sort_bedframe(df, view_df)``: view chromosome order, then start, end.
 * ``natsort.natsorted``, ``more_itertools.collapse(it, base_type=dict)``.
 
 Because these restate third-party behaviour from documentation/knowledge (their source is not on disk),
@@ -114,6 +115,18 @@ def make_viewframe(view_df, check_bounds=None, **kw):
     return df[["chrom", "start", "end", "name"]].reset_index(drop=True)
 
 
+def sort_bedframe(df, view_df=None, reset_index=True, df_view_col=None, view_name_col="name", cols=None,
+                  cols_view=None):
+    """bioframe.sort_bedframe restated: order rows by the view's chromosome order, then start, end; rows whose
+    chromosome is not in the view go last."""
+    out = df.copy()
+    chroms = list(dict.fromkeys(view_df["chrom"])) if view_df is not None else sorted(set(out["chrom"]))
+    rank = {c: i for i, c in enumerate(chroms)}
+    out["_k"] = out["chrom"].map(lambda c: rank.get(c, len(rank)))
+    out = out.sort_values(["_k", "start", "end"], kind="stable").drop(columns="_k")
+    return out.reset_index(drop=True) if reset_index else out
+
+
 def natsorted(seq):
     def key(s):
         return [int(t) if t.isdigit() else t.lower() for t in re.split(r"(\d+)", str(s))]
@@ -145,7 +158,7 @@ def install():
 
     mod("natsort", natsorted=natsorted)
     mod("more_itertools", collapse=collapse)
-    mod("bioframe", make_viewframe=make_viewframe)
+    mod("bioframe", make_viewframe=make_viewframe, sort_bedframe=sort_bedframe)
     api = mod("cooler.api", Cooler=ShimCooler)
     mod("cooler", api=api, Cooler=ShimCooler)
     numutils = mod("cooltools.numutils", LazyToeplitz=LazyToeplitz)
