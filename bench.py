@@ -43,7 +43,8 @@ def parse():
     ap.add_argument("--pad", type=int, default=10)
     ap.add_argument("--lam", type=float, default=4200.0, help="Poisson contacts drawn per row before de-duplication")
     ap.add_argument("--chroms", type=int, default=23, help="use the first K hg38 chromosomes (23 = all)")
-    ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="snippets timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="snippets timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all cores, capped at 64)")
     ap.add_argument("--no-cache", action="store_true")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank piles up its own set of --pairs pairs on the shared table; "
@@ -301,19 +302,40 @@ def main():
             idx = np.linspace(0, n_set - 1, m).astype(np.int64)
             sr0, sc0 = wl["r0"][idx], wl["c0"][idx]
             stile = (idx >= n_roi).astype(np.int32)
+            # (1) one core: the scalar port as is, on a quarter of the sample
+            m1 = max(1, m // 4)
             t = time.perf_counter()
-            want = po.pileup_c(wl["bin1_offset"], wl["bin2_id"], wl["count"], wl["weight"], None, None,
-                               sr0, sc0, None, stile, 2, a.pad, 2, 0)
+            po.pileup_c(wl["bin1_offset"], wl["bin2_id"], wl["count"], wl["weight"], None, None,
+                        sr0[:m1], sc0[:m1], None, stile[:m1], 2, a.pad, 2, 0)
+            one_core = m1 / (time.perf_counter() - t)
+            # (2) all host cores (capped): the same C function on C threads (ctypes releases the GIL), each with its
+            #     own accumulators, summed afterwards — the reference's own grain is one region per process
+            from concurrent.futures import ThreadPoolExecutor
+            C_thr = max(1, min(a.cpu_threads if a.cpu_threads > 0 else (os.cpu_count() or 1), 64))
+            cuts = np.linspace(0, m, C_thr + 1).astype(np.int64)
+            arrs = [np.ascontiguousarray(x) for x in (wl["bin1_offset"], wl["bin2_id"], wl["count"], wl["weight"])]
+
+            def work(k):
+                lo_, hi_ = int(cuts[k]), int(cuts[k + 1])
+                return po.pileup_c(arrs[0], arrs[1], arrs[2], arrs[3], None, None, sr0[lo_:hi_], sc0[lo_:hi_], None,
+                                   stile[lo_:hi_], 2, a.pad, 2, 0)
+            po._load()
+            t = time.perf_counter()
+            with ThreadPoolExecutor(C_thr) as ex:
+                parts = list(ex.map(work, range(C_thr)))
             cpu_s = time.perf_counter() - t
+            want = {k: sum(p[k] for p in parts) for k in ("sum", "num", "n")}
             sptr = np.array([0, int((stile == 0).sum()), m], np.int64)
             eng.reset(2, a.pad)
             eng.accumulate(sr0, sc0, sptr, ignore_diags=2, mode=0)
             got = eng.fetch()
             ok = (np.array_equal(got["n"], want["n"]) and np.array_equal(got["num"], want["num"])
                   and np.allclose(got["sum"], want["sum"], rtol=1e-6, atol=0, equal_nan=True))
-            cpu = {"value": round(m / cpu_s, 1), "unit": "snippets/s", "cores": 1, "kind": "port",
-                   "sample": f"{m} snippets strided over the {n_set} of this workload, C oracle (oracle/pileup_oracle.c), "
-                             f"{cpu_s:.1f}s", "gpu_matches_oracle_on_sample": bool(ok)}
+            cpu = {"value": round(m / cpu_s, 1), "unit": "snippets/s", "cores": C_thr, "kind": "port",
+                   "sample": f"{m} snippets strided over the {n_set} of this workload, C oracle (oracle/pileup_oracle.c) "
+                             f"on {C_thr} threads, {cpu_s:.1f}s; one thread: {one_core:.0f} snippets/s",
+                   "single_core_value": round(one_core, 1), "host_cpu_count": os.cpu_count(),
+                   "gpu_matches_oracle_on_sample": bool(ok)}
             if not ok:
                 print("[bench] PARITY FAILURE against the oracle on the sample", file=sys.stderr)
         line = {
