@@ -715,8 +715,6 @@ class PileUpper:
             elif self.rescale_size % 2 == 0:
                 raise ValueError("Please provide an odd rescale_size")
             raise NotImplementedError("rescaled pile-ups are not implemented in coolpuppy_amd")
-        if self.store_stripes:
-            raise NotImplementedError("store_stripes is not implemented in coolpuppy_amd")
         if self.ignore_diags is None or self.ignore_diags < 0:
             raise ValueError("ignore_diags must be >= 0 (the engine reads the upper-triangular pixel table)")
 
@@ -776,6 +774,8 @@ class PileUpper:
             carry = list(carry)
             if by_window:
                 carry += ["_gc_chrom1", "start1", "end1", "_gc_chrom2", "start2", "end2"]
+            if self.store_stripes:
+                carry += ["chrom1", "start1", "end1", "chrom2", "start2", "end2"]
             for g in groupby:
                 src[g] = self._group_source(g)
                 if g != "distance_band":
@@ -808,6 +808,13 @@ class PileUpper:
         r0, c0 = r0[ok], c0[ok]
         n = len(r0)
         flip = tbl["flip"].astype(bool) if "flip" in tbl else np.zeros(n, bool)
+        coords = None
+        if self.store_stripes:
+            if by_window:
+                raise NotImplementedError("store_stripes together with by-window pile-ups is not implemented")
+            # str() of each coordinate, as the reference joins and re-splits them (coolpup.py:1170-1182, 1557-1560)
+            coords = np.stack([np.asarray(tbl[c]).astype(str) for c in
+                               ("chrom1", "start1", "end1", "chrom2", "start2", "end2")], axis=1)
         if groupby:
             keycols, decs = [], []
             for g in groupby:
@@ -837,7 +844,7 @@ class PileUpper:
         else:
             codes, keys = np.full(n, -1, np.int64), []
         return {"r0": r0, "c0": c0, "kind": tbl["kind"].astype(np.int8), "flip": flip, "group_codes": codes,
-                "group_keys": keys, "n": n}
+                "group_keys": keys, "n": n, "coords": coords}
 
     # -- the pile-up -------------------------------------------------------------------------------------------
     def pileupsWithControl(self, nproc=None, groupby=[], ignore_group_order=False, modify_2Dintervals_func=None,
@@ -986,6 +993,27 @@ class PileUpper:
                             MODE_EXPECTED | tr))
         # regions that need no per-region state (no expected vector) and share mode / diagonal mask go to the
         # engine as ONE call: fewer launches, and the engine's interleaved groups span region boundaries
+        stripe_jobs = []
+        if self.store_stripes:
+            for region1, region2, b in batches:
+                if b is None or b["n"] == 0:
+                    continue
+                roi = np.flatnonzero(b["kind"] == KIND_ROI)
+                if len(roi) == 0:
+                    continue
+                gk = np.array([gid[k] for k in b["group_keys"]], np.int64)[b["group_codes"][roi]] if grouped \
+                    else np.full(len(roi), gid["all"], np.int64)
+                transpose = self._global_extents[region1][0] > self._global_extents[region2][0]
+                r0, c0 = (b["c0"][roi], b["r0"][roi]) if transpose else (b["r0"][roi], b["c0"][roi])
+                expected = None
+                if self.expected and self.ooe:
+                    expected = "table" if exp_table is not None else (
+                        np.array([self.get_expected_trans(region1, region2)], np.float64) if self.trans
+                        else self._expected_vectors[region1])
+                stripe_jobs.append({"expected": expected, "ignore_diags": -1 if self.trans else int(self.ignore_diags),
+                                    "mode": (MODE_OOE if (self.expected and self.ooe) else 0) | (MODE_TRANSPOSE if transpose else 0),
+                                    "r0": r0.astype(np.int32), "c0": c0.astype(np.int32), "gid": gk,
+                                    "coords": b["coords"][roi]})
         merged = []                     # [head item, [parts of fields 3..6]]
         for item in raw:
             prev = merged[-1][0] if merged else None
@@ -1002,7 +1030,7 @@ class PileUpper:
         return {"T": T, "G": G, "gid": gid, "order": order, "contrib": contrib, "want_control": want_control,
                 "groupby": list(groupby), "grouped": bool(grouped), "calls": calls, "pad": self.pad_bins,
                 "n_regions": len(batches),
-                "expected_table": exp_table,
+                "expected_table": exp_table, "stripe_jobs": stripe_jobs,
                 "weight_name": self.clr_weight_name if self.clr_weight_name else None,
                 "cov_name": self.coverage_norm if self.coverage_norm else None}
 
@@ -1032,7 +1060,19 @@ class PileUpper:
             eng.accumulate(c["r0"], c["c0"], c["tile_ptr"], flip_from=c["flip_from"],
                            ignore_diags=c["ignore_diags"], mode=c["mode"])
         _dist.allreduce_engine(eng)
-        return eng.fetch()
+        acc = eng.fetch()
+        if plan.get("stripe_jobs"):
+            # O(n*W) per-snippet output, not a reduction: every rank computes all of it (cheap) so that every rank
+            # ends with the complete result, like the reduced tiles
+            acc["stripes"] = []
+            for job in plan["stripe_jobs"]:
+                if isinstance(job["expected"], str):
+                    eng.set_expected_table(et["start"], et["end"], vectors=et["vectors"], pair=et["pair"])
+                else:
+                    eng.set_expected(job["expected"])
+                acc["stripes"].append(eng.stripes(job["r0"], job["c0"], plan["pad"], ignore_diags=job["ignore_diags"],
+                                                  mode=job["mode"]))
+        return acc
 
     def finalize_plan(self, plan, acc):
         """Fetched tiles -> the reference's output DataFrame."""
@@ -1044,8 +1084,9 @@ class PileUpper:
                     a = kind * G + gid["all"]
                     for name in ("sum", "num", "n", "cov_start", "cov_end"):
                         acc[name][a] = acc[name][members].sum(axis=0)
+        stripes = _collect_stripes(plan, acc) if plan.get("stripe_jobs") else None
         return finalize_pileups(self, acc, order, plan["contrib"], gid, G, plan["groupby"], plan["want_control"],
-                                n_regions=plan["n_regions"], grouped=plan["grouped"])
+                                n_regions=plan["n_regions"], grouped=plan["grouped"], stripes=stripes)
 
     def _pile_and_finalize(self, batches, groupby, grouped=None):
         plan = self.make_plan(batches, groupby, grouped=grouped)
@@ -1180,6 +1221,28 @@ def _engine_call(region1, region2, expected, r0, c0, flip, tile, T, igd, mode):
             "flip": np.ascontiguousarray(flip, np.uint8) if flip_from is not None else None,
             "flip_from": flip_from, "tile": np.ascontiguousarray(tile, np.int32), "tile_ptr": tile_ptr,
             "ignore_diags": igd, "mode": mode}
+
+
+def _collect_stripes(plan, acc):
+    """Per group key: (coordinates [n,6] str, horizontal [n,W], vertical [n,W]) in the reference's accumulation
+    order — regions in order, snippets in stream order; the "all" row of a grouped pile-up concatenates, region by
+    region, the groups in their order of first appearance in that region (reduce(sum_pups), coolpup.py:1271-1282)."""
+    gid = plan["gid"]
+    inv = {v: k for k, v in gid.items()}
+    per = {}
+    def push(key, co, h, v):
+        e = per.setdefault(key, ([], [], []))
+        e[0].append(co); e[1].append(h); e[2].append(v)
+    for job, (h, v) in zip(plan["stripe_jobs"], acc["stripes"]):
+        g = job["gid"]
+        if plan["grouped"]:
+            for code in pd.unique(g):                       # first-appearance order within the region
+                sel = np.flatnonzero(g == code)
+                push(inv[int(code)], job["coords"][sel], h[sel], v[sel])
+                push("all", job["coords"][sel], h[sel], v[sel])
+        else:
+            push("all", job["coords"], h, v)
+    return {k: (np.concatenate(e[0]), np.concatenate(e[1]), np.concatenate(e[2])) for k, e in per.items()}
 
 
 def iter_expected_subcalls(plan, call):

@@ -688,6 +688,48 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, 
     return PUP_OK;
 }
 
+int pup_stripes(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, int32_t pad, int32_t ignore_diags,
+                uint32_t mode, double* horizontal, double* vertical) {
+    if (!c) return PUP_EINVAL;
+    if (!c->have_px) return fail(c, PUP_ESTATE, "pup_stripes: no pixel table loaded");
+    if (!c->have_bal) return fail(c, PUP_ESTATE, "pup_stripes: call pup_load_bins first (weights or NULL for raw)");
+    if (n < 0 || pad < 0 || (n > 0 && (!r0 || !c0 || !horizontal || !vertical)))
+        return fail(c, PUP_EINVAL, "pup_stripes: NULL arrays or negative sizes");
+    if ((mode & PUP_MODE_OOE) && c->nexp == 0 && c->n_exp_regions == 0)
+        return fail(c, PUP_ESTATE, "pup_stripes: OOE mode without expected");
+    if (mode & (PUP_MODE_EXPECTED | PUP_MODE_DEVPTR)) return fail(c, PUP_EINVAL, "pup_stripes: unsupported mode bits");
+    if (n == 0) return PUP_OK;
+    int rc = bind(c); if (rc) return rc;
+    const int W = 2 * pad + 1;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    DevBuf<double> d_out;
+    HIPCHK(c, c->d_r0.reserve((size_t)n)); HIPCHK(c, c->d_c0.reserve((size_t)n));
+    HIPCHK(c, d_out.reserve((size_t)n * W * 2));
+    hipError_t e = hipMemcpy(c->d_r0.p, r0, (size_t)n * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(c->d_c0.p, c0, (size_t)n * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        pup::K1Args a{};
+        a.indptr = c->indptr.p; a.px = c->px.p;
+        a.weight = c->have_weight ? c->weight.p : nullptr;
+        a.expv = (c->nexp > 0 || (c->n_exp_regions > 0 && !c->have_exp_pair)) ? c->expv.p : nullptr;
+        a.nexp = c->nexp; a.nbins = c->nbins;
+        a.exp_regions = c->n_exp_regions > 0 ? c->exp_regions.p : nullptr; a.n_exp_regions = c->n_exp_regions;
+        a.exp_pair = c->have_exp_pair ? c->exp_pair.p : nullptr;
+        a.r0 = c->d_r0.p; a.c0 = c->d_c0.p; a.err = c->d_err.p;
+        a.W = W; a.ignore_diags = ignore_diags; a.mode = mode;
+        const unsigned grid = (unsigned)std::min<int64_t>(n, 65536);
+        hipLaunchKernelGGL(pup::stripes_kernel, dim3(grid), dim3(pup::kWave), 0, c->stream, a, (long long)n,
+                           d_out.p, d_out.p + (size_t)n * W);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(horizontal, d_out.p, (size_t)n * W * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(vertical, d_out.p + (size_t)n * W, (size_t)n * W * sizeof(double), hipMemcpyDeviceToHost);
+    d_out.release();
+    if (e != hipSuccess) return fail(c, PUP_EHIP, "pup_stripes: %s", hipGetErrorString(e));
+    return check_async_error(c);
+}
+
 int pup_sync(pup_ctx* c) {
     if (!c) return PUP_EINVAL;
     int rc = bind(c); if (rc) return rc;

@@ -790,6 +790,55 @@ __global__ __launch_bounds__(256) void coverage_kernel(const long long* __restri
     }
 }
 
+// ---- K4: per-snippet stripes (store_stripes) ---------------------------------------------------------------
+// The centre row and the centre column of every snippet, masked and normalised exactly like the window itself
+// (coolpup.py:1164-1169): horizontal = data[pad, :], vertical = data[:, pad][::-1].  Output is O(n*W), not a
+// reduction: one wave per snippet, lanes 0..W-1 look up the row cells, lanes W..2W-1 the column cells, each by a
+// binary search of its matrix row (2W cells per snippet: the index would save nothing worth its code here).
+__device__ __forceinline__ int find_count(const K1Args& a, int row, int col) {
+    long long lo = a.indptr[row], hi = a.indptr[row + 1];
+    const long long end = hi;
+    while (lo < hi) { const long long m = (lo + hi) >> 1; if (a.px[m].x < col) lo = m + 1; else hi = m; }
+    return (lo < end && a.px[lo].x == col) ? a.px[lo].y : 0;
+}
+
+__global__ __launch_bounds__(kWave) void stripes_kernel(K1Args a, long long n, double* __restrict__ h_out,
+                                                       double* __restrict__ v_out) {
+    const int W = a.W, pad = W / 2;
+    const int lane = threadIdx.x;
+    const bool m_ooe = a.mode & 0x01u, m_tr = a.mode & 0x08u;
+    const bool use_exp = m_ooe && ((a.expv != nullptr && a.nexp > 0) || a.n_exp_regions > 0);
+    const double qn = __builtin_nan("");
+    ExpCache ecache;
+    for (long long s = blockIdx.x; s < n; s += gridDim.x) {
+        const int r0s = a.r0[s], c0s = a.c0[s];
+        if (r0s < 0 || c0s < 0 || (long long)r0s + W > a.nbins || (long long)c0s + W > a.nbins) {
+            if (lane == 0) atomicExch(a.err, 1);
+            continue;
+        }
+        ExpSel es; es.base = a.expv; es.len = 0; es.scalar = qn; es.is_scalar = true;
+        if (use_exp) es = select_expected(a, ecache, r0s, c0s);
+        for (int t = lane; t < 2 * W; t += kWave) {
+            // engine frame: rows from r0s, columns from c0s.  In the reference's frame (after undoing TRANSPOSE)
+            // the horizontal stripe runs along its columns and the vertical one, reversed, along its rows.
+            const bool horiz = t < W;
+            const int i = horiz ? t : t - W;
+            int p, q;
+            if (!m_tr) { p = horiz ? pad : (W - 1 - i); q = horiz ? i : pad; }
+            else       { p = horiz ? i : pad;           q = horiz ? pad : (W - 1 - i); }
+            const int row = r0s + p, col = c0s + q;
+            double v = (double)find_count(a, row, col);
+            if (a.weight) {
+                const double wr = a.weight[row], wc = a.weight[col];
+                v = (wr == wr && wc == wc) ? (v != 0.0 ? v * wr * wc : 0.0) : qn;
+            }
+            if (a.ignore_diags >= 0 && (col - row) < a.ignore_diags) v = qn;
+            if (m_ooe) { long long ad = (long long)col - row; if (ad < 0) ad = -ad; v = v / es.at(ad); }
+            (horiz ? h_out : v_out)[s * W + i] = v;
+        }
+    }
+}
+
 // n[t] += dn[t]
 __global__ void add_counts_kernel(long long* n, const long long* dn, int T) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -159,6 +159,17 @@ class PileupEngine:
         self._check(self._lib.pup_accumulate(self._h, C.c_void_p(r0_ptr), C.c_void_p(c0_ptr), int(n),
                                              _ptr(tile_ptr), _ptr(ff), int(ignore_diags), int(mode) | MODE_DEVPTR))
 
+    def stripes(self, r0, c0, pad, *, ignore_diags=2, mode=0):
+        """(horizontal [n,W], vertical [n,W]) centre row / reversed centre column of every snippet (store_stripes)."""
+        r0 = _as(r0, np.int32)
+        c0 = _as(c0, np.int32)
+        W = 2 * int(pad) + 1
+        h = np.empty((r0.shape[0], W), np.float64)
+        v = np.empty((r0.shape[0], W), np.float64)
+        self._check(self._lib.pup_stripes(self._h, _ptr(r0), _ptr(c0), r0.shape[0], int(pad), int(ignore_diags),
+                                          int(mode), _ptr(h), _ptr(v)))
+        return h, v
+
     def sync(self):
         self._check(self._lib.pup_sync(self._h))
 

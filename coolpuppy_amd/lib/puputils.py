@@ -68,7 +68,14 @@ def _tile_frame(acc, kind, order, contrib, gid, G, grouped):
     return df
 
 
-def finalize_pileups(pu, acc, order, contrib, gid, G, groupby, want_control, n_regions, grouped=None):
+def _copy_array_halves(x):
+    """Mirror the right half of each stripe onto the left (reference lib/numutils.py:6-9)."""
+    cntr = int(np.floor(x.shape[1] / 2))
+    x[:, : (cntr + 1)] = np.fliplr(x[:, cntr:])
+    return x
+
+
+def finalize_pileups(pu, acc, order, contrib, gid, G, groupby, want_control, n_regions, grouped=None, stripes=None):
     """Tail of pileupsWithControl (coolpup.py:1533-1654) on summed tiles -> annotated DataFrame."""
     import warnings
     if grouped is None:
@@ -92,6 +99,26 @@ def finalize_pileups(pu, acc, order, contrib, gid, G, groupby, want_control, n_r
     normalized_roi["data"] = normalized_roi["data"].apply(lambda x: np.where(x == np.inf, np.nan, x))
     normalized_roi["n"] = roi["n"]
     normalized_roi["num"] = roi["num"]
+    if stripes is not None:
+        # per-snippet centre row / column and coordinates of the ROI snippets (coolpup.py:1556-1600)
+        keys = list(roi.index)
+        co = pd.Series([stripes[k][0] if k in stripes else np.nan for k in keys], index=roi.index, dtype=object)
+        hs = pd.Series([stripes[k][1] if k in stripes else np.nan for k in keys], index=roi.index, dtype=object)
+        vs = pd.Series([stripes[k][2] if k in stripes else np.nan for k in keys], index=roi.index, dtype=object)
+        normalized_roi["coordinates"] = co
+        normalized_roi["horizontal_stripe"] = hs
+        normalized_roi["vertical_stripe"] = vs
+        if want_control:
+            ctrl_all = normalized_control["data"]["all"]
+            cntr = int(np.floor(ctrl_all.shape[0] / 2))
+            ch = np.array(ctrl_all[cntr, :], dtype=float)
+            cv = np.array(ctrl_all[:, cntr][::-1], dtype=float)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                normalized_roi["horizontal_stripe"] = normalized_roi["horizontal_stripe"].apply(lambda x: np.divide(x, ch))
+                normalized_roi["vertical_stripe"] = normalized_roi["vertical_stripe"].apply(lambda x: np.divide(x, cv))
+        if pu.local:
+            for c in ("vertical_stripe", "horizontal_stripe"):
+                normalized_roi[c] = normalized_roi[c].apply(lambda x: _copy_array_halves(np.array(x, dtype=float)))
 
     if pu.local:
         with warnings.catch_warnings():

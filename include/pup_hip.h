@@ -21,6 +21,7 @@
  *                                        (flip bit: flip_snip_func     coolpuppy/coolpup.py:128-147)
  *   pup_coverage                      <- cooltools.api.coverage.coverage(clr, ignore_diags=..., store=True), called by
  *                                        PileUpper.__init__ when cov_*_raw is missing     coolpuppy/coolpup.py:955-963
+ *   pup_stripes                       <- the store_stripes branch of _stream_snips   coolpuppy/coolpup.py:1164-1182
  *   pup_fetch / pup_export / pup_import
  *                                     <- sum_pups cross-region merge   coolpuppy/lib/puputils.py:88-113
  *                                        and the reduce at             coolpuppy/coolpup.py:1511-1531
@@ -147,6 +148,15 @@ int pup_reset(pup_ctx* ctx, int32_t n_tiles, int32_t pad);
  */
 int pup_accumulate(pup_ctx* ctx, const int32_t* r0, const int32_t* c0, int64_t n, const int64_t* tile_ptr,
                    const int64_t* flip_from, int32_t ignore_diags, uint32_t mode);
+
+/*
+ * Per-snippet stripes (store_stripes, coolpup.py:1164-1169): for each of the n snippets the centre row
+ * (horizontal[s][0..W)) and the centre column reversed (vertical[s][i] = data[W-1-i][pad]) of the masked /
+ * normalised window — NaN where the window is masked.  Uses the current weights and expected state; mode accepts
+ * PUP_MODE_OOE and PUP_MODE_TRANSPOSE.  Host arrays in, host arrays out ([n][W] float64 each); synchronous.
+ */
+int pup_stripes(pup_ctx* ctx, const int32_t* r0, const int32_t* c0, int64_t n, int32_t pad, int32_t ignore_diags,
+                uint32_t mode, double* horizontal, double* vertical);
 
 /* wait for all queued work; surfaces asynchronous errors (PUP_ERANGE, PUP_EHIP) */
 int pup_sync(pup_ctx* ctx);

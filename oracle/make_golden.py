@@ -178,8 +178,16 @@ def scenarios():
         maxdist=2_000_000)
     add("G10b_by_window_controls", "small", bed.groupby("chrom").head(12), features_format="bed", flank=50_000,
         by_window=True, nshifts=2, seed=10, maxdist=4_000_000)
+    add("G11_stripes_raw", "small", bedpe, store_stripes=True, clr_weight_name=None, min_diag=0, **base)
+    add("G11b_stripes_controls_strand", "small", bedpe, store_stripes=True, nshifts=2, seed=12, by_strand=True, **base)
+    add("G11c_stripes_expected_ooe_view", "small", bedpe, view=view_sub, expected=exp_view, store_stripes=True, **base)
+    add("G11d_stripes_local", "small", bed, features_format="bed", local=True, store_stripes=True, flank=100_000)
+    add("G11e_stripes_trans", "small", trans_bedpe(clr, 80, 14), features_format="bedpe", trans=True,
+        store_stripes=True, flank=100_000)
+    # the reference's own stripe test (tests/test_coolpup.py:143-172): raw counts, ignore_diags=0, first coordinates row
     # known-answer tests of the reference's own test-suite (tests/test_coolpup.py), n depends on coordinates only
     toy_kw = dict(features_format="bed", flank=2_000_000, mindist=0)
+    add("KAT_stripes", "toy", toy_feat, view=toy_view, store_stripes=True, clr_weight_name=None, min_diag=0, **toy_kw)
     add("KAT_bystrand_expected_ooe", "toy", toy_feat, view=toy_view, expected=toy_exp, by_strand=True, **toy_kw)
     add("KAT_bystrand_expected_not_ooe", "toy", toy_feat, view=toy_view, expected=toy_exp, by_strand=True,
         ooe=False, **toy_kw)
@@ -229,6 +237,16 @@ def record(df, W):
         rec["control_n"] = df["control_n"].values.astype(np.float64)
         rec["control_num"] = np.stack([np.asarray(x).reshape(W, W) if np.ndim(x) == 2 else np.full((W, W), -1)
                                        for x in df["control_num"]]).astype(np.int64)
+    if "horizontal_stripe" in df.columns:
+        ptr, hs, vs, co = [0], [], [], []
+        for h, v, c in zip(df["horizontal_stripe"], df["vertical_stripe"], df["coordinates"]):
+            if np.ndim(h) == 2:
+                hs.append(np.asarray(h, float)); vs.append(np.asarray(v, float)); co.append(np.asarray(c).astype(str))
+                ptr.append(ptr[-1] + len(h))
+            else:
+                ptr.append(ptr[-1])
+        rec["stripe_ptr"] = np.array(ptr, np.int64)
+        rec["hstripe"] = np.concatenate(hs); rec["vstripe"] = np.concatenate(vs); rec["coords"] = np.concatenate(co)
     for c in ("orientation", "separation"):
         if c in df.columns:
             rec[c] = json.dumps([str(x) for x in df[c]])

@@ -160,3 +160,21 @@ def coverage_numpy(indptr, col, cnt, chrom_offset, ignore_diags):
     cov_cis = np.bincount(row, weights=w * cis, minlength=nb) + np.bincount(c, weights=w * cis, minlength=nb)
     cov_tot = np.bincount(row, weights=w, minlength=nb) + np.bincount(c, weights=w, minlength=nb)
     return cov_cis, cov_tot
+
+
+def stripes_c(indptr, col, cnt, weight, expv, r0, c0, pad, ignore_diags, mode):
+    """Centre row and reversed centre column of every snippet's masked / normalised window (the store_stripes
+    branch, coolpup.py:1164-1169), obtained from the C restatement one snippet at a time: for a single snippet
+    sum == data with NaN replaced by 0 and num == isfinite(data)."""
+    W = 2 * pad + 1
+    n = len(r0)
+    h = np.empty((n, W))
+    v = np.empty((n, W))
+    tile = np.zeros(1, np.int32)
+    for s in range(n):
+        acc = pileup_c(indptr, col, cnt, weight, None, expv, r0[s:s + 1], c0[s:s + 1], None, tile, 1, pad,
+                       ignore_diags, mode & ~MODE_COV)
+        data = np.where(acc["num"][0] == 1, acc["sum"][0], np.where(np.isinf(acc["sum"][0]), acc["sum"][0], np.nan))
+        h[s] = data[pad, :]
+        v[s] = data[:, pad][::-1]
+    return h, v

@@ -78,6 +78,17 @@ def compare(z, df, rtol):
         np.testing.assert_array_equal(df["control_n"].values.astype(float), z["control_n"])
         got_cn = np.stack([np.asarray(x) if np.ndim(x) == 2 else np.full((W, W), -1) for x in df["control_num"]])
         np.testing.assert_array_equal(got_cn, z["control_num"])
+    if "stripe_ptr" in z.files:
+        ptr = z["stripe_ptr"]
+        for i in range(len(df)):
+            a, b = int(ptr[i]), int(ptr[i + 1])
+            if b == a:
+                continue
+            np.testing.assert_array_equal(np.asarray(df["coordinates"].iloc[i]).astype(str), z["coords"][a:b])
+            np.testing.assert_allclose(np.asarray(df["horizontal_stripe"].iloc[i], float), z["hstripe"][a:b],
+                                       rtol=rtol, atol=0, equal_nan=True)
+            np.testing.assert_allclose(np.asarray(df["vertical_stripe"].iloc[i], float), z["vstripe"][a:b],
+                                       rtol=rtol, atol=0, equal_nan=True)
     for c in ("orientation", "separation"):
         if c in z.files:
             assert [str(x) for x in df[c]] == json.loads(str(z[c])), c
@@ -107,4 +118,20 @@ def oracle_run_plan(pu, plan):
         for expected, c in iter_expected_subcalls(plan, call):
             po.pileup_c(indptr, col, cnt, weight, cov, expected, c["r0"], c["c0"], c["flip"], c["tile"],
                         plan["T"], plan["pad"], c["ignore_diags"], c["mode"], acc=acc)
+    if plan.get("stripe_jobs"):
+        acc["stripes"] = []
+        for job in plan["stripe_jobs"]:
+            fake = {"expected": job["expected"], "r0": job["r0"], "c0": job["c0"], "mode": job["mode"],
+                    "tile": np.zeros(len(job["r0"]), np.int32), "flip": None, "tile_ptr": np.array([0, len(job["r0"])])}
+            W = 2 * plan["pad"] + 1
+            h = np.empty((len(job["r0"]), W)); v = np.empty((len(job["r0"]), W))
+            pos = {int(a) * (1 << 32) + int(b): i for i, (a, b) in enumerate(zip(job["r0"], job["c0"]))}
+            for expected, sc in iter_expected_subcalls(plan, fake):
+                hh, vv = po.stripes_c(indptr, col, cnt, weight, expected, sc["r0"], sc["c0"], plan["pad"],
+                                      job["ignore_diags"], sc["mode"])
+                for k in range(len(sc["r0"])):      # sub-calls permute the snippets: put them back by position
+                    sel = np.flatnonzero((job["r0"] == sc["r0"][k]) & (job["c0"] == sc["c0"][k]))
+                    h[sel] = hh[k]; v[sel] = vv[k]
+            del pos
+            acc["stripes"].append((h, v))
     return acc
