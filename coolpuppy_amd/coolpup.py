@@ -1463,6 +1463,8 @@ def snippet_batches(cc, clr, control=False, view_df=None):
     pu.control = control
     pu.pad_bins = cc.flank // cc.resolution
     pu.ignore_group_order = False
+    pu.store_stripes = False
+    pu.flip_negative_strand = False
     vd = _make_cooler_view(clr) if view_df is None else _make_viewframe(view_df, clr.chromsizes)
     pu.view_df = vd.set_index("name")
     pu._global_extents = {}
