@@ -1205,22 +1205,29 @@ class PileUpper:
 def _engine_call(region1, region2, expected, r0, c0, flip, tile, T, igd, mode):
     """One pup_accumulate call: snippets grouped by (tile, flip) — stable, so genome order is kept inside a
     group; within a tile the anti-transposed snippets come last (flip_from marks where they start)."""
-    flip = np.zeros(len(tile), bool) if flip is None else np.asarray(flip, bool)
-    key = tile.astype(np.int64) * 2 + flip
-    if 2 * T < 65536:
-        key = key.astype(np.uint16)            # numpy's stable sort of 16-bit keys is a radix sort: O(n)
-    if len(key) > 1 and not np.all(key[1:] >= key[:-1]):
-        o = np.argsort(key, kind="stable")
-        r0, c0, flip, tile = r0[o], c0[o], flip[o], tile[o]
-    tile_ptr = np.concatenate([[0], np.cumsum(np.bincount(tile, minlength=T))]).astype(np.int64)
-    flip_from = None
-    if flip.any():
-        flip_from = tile_ptr[1:] - np.bincount(tile[flip], minlength=T)
+    n = len(tile)
+    r0 = np.asarray(r0).astype(np.int32, copy=False)            # narrow BEFORE permuting: half the bytes to move
+    c0 = np.asarray(c0).astype(np.int32, copy=False)
+    any_flip = flip is not None and bool(np.any(flip))
+    key = np.asarray(tile).astype(np.int64, copy=False) * 2
+    if any_flip:
+        key = key + np.asarray(flip, bool)
+    counts = np.bincount(key, minlength=2 * T)                   # per (tile, flip) segment
+    if n > 1 and not np.all(key[1:] >= key[:-1]):
+        if 2 * T < 65536:
+            o = np.argsort(key.astype(np.uint16), kind="stable")   # 16-bit keys: numpy uses a radix sort, O(n)
+        else:
+            o = np.argsort(key, kind="stable")
+        r0, c0 = r0[o], c0[o]
+    per_tile = counts.reshape(T, 2)
+    tile_ptr = np.concatenate([[0], np.cumsum(per_tile.sum(axis=1))]).astype(np.int64)
+    flip_from = (tile_ptr[:-1] + per_tile[:, 0]).astype(np.int64) if any_flip else None
+    # after the grouping the tile / flip of every snippet follow from the segment sizes
+    tile_sorted = np.repeat(np.arange(T, dtype=np.int32), per_tile.sum(axis=1))
+    flip_sorted = np.repeat(np.tile(np.array([0, 1], np.uint8), T), counts) if any_flip else None
     return {"region1": region1, "region2": region2, "expected": expected,
-            "r0": np.ascontiguousarray(r0, np.int32), "c0": np.ascontiguousarray(c0, np.int32),
-            "flip": np.ascontiguousarray(flip, np.uint8) if flip_from is not None else None,
-            "flip_from": flip_from, "tile": np.ascontiguousarray(tile, np.int32), "tile_ptr": tile_ptr,
-            "ignore_diags": igd, "mode": mode}
+            "r0": np.ascontiguousarray(r0), "c0": np.ascontiguousarray(c0), "flip": flip_sorted,
+            "flip_from": flip_from, "tile": tile_sorted, "tile_ptr": tile_ptr, "ignore_diags": igd, "mode": mode}
 
 
 def _collect_stripes(plan, acc):
