@@ -1,0 +1,218 @@
+"""Read a ``.cool`` file into an :class:`~coolpuppy_amd.cooler_lite.ArrayCooler` (host I/O).
+
+The reference opens coolers through the ``cooler`` package (``cooler.Cooler(path)``, coolpuppy/CLI.py:406), which
+reads HDF5 through h5py.  Neither is guaranteed here, so this reader goes to libhdf5 directly via ctypes (h5py is
+used when importable).  It reads exactly the datasets the pile-up path consumes — the cooler schema's
+
+    chroms/{name,length}   bins/{chrom,start,end,weight,...}   pixels/{bin1_id,bin2_id,count}
+    indexes/{bin1_offset,chrom_offset}                          attrs: bin-size
+
+— and nothing is transformed: ``indexes/bin1_offset`` IS the CSR row pointer of the upper-triangular pixel table
+the GPU engine loads (``pixels/bin1_id`` is not even read).  Multi-resolution files: pass ``group="resolutions/10000"``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pandas as pd
+
+from .cooler_lite import ArrayCooler
+
+_H5F_ACC_RDONLY = 0
+_H5P_DEFAULT = 0
+_H5S_ALL = 0
+_H5T_INTEGER, _H5T_FLOAT, _H5T_STRING, _H5T_ENUM = 0, 1, 3, 8
+
+_lib = None
+
+
+def _hdf5():
+    global _lib
+    if _lib is not None:
+        return _lib
+    cands = [os.environ.get("COOLPUPPY_AMD_LIBHDF5", ""), "libhdf5.so", "libhdf5_serial.so", "/opt/conda/lib/libhdf5.so",
+             "/usr/lib/x86_64-linux-gnu/libhdf5_serial.so", "/usr/lib/x86_64-linux-gnu/hdf5/serial/libhdf5.so"]
+    last = None
+    for c in cands:
+        if not c:
+            continue
+        try:
+            lib = C.CDLL(c)
+            break
+        except OSError as e:
+            last = e
+    else:
+        raise RuntimeError(f"libhdf5 not found (set COOLPUPPY_AMD_LIBHDF5 to its path): {last}")
+    hid = C.c_int64
+    lib.H5open.restype = C.c_int
+    lib.H5Fopen.restype = hid; lib.H5Fopen.argtypes = [C.c_char_p, C.c_uint, hid]
+    lib.H5Fclose.argtypes = [hid]
+    lib.H5Dopen2.restype = hid; lib.H5Dopen2.argtypes = [hid, C.c_char_p, hid]
+    lib.H5Dclose.argtypes = [hid]
+    lib.H5Dget_space.restype = hid; lib.H5Dget_space.argtypes = [hid]
+    lib.H5Dget_type.restype = hid; lib.H5Dget_type.argtypes = [hid]
+    lib.H5Sget_simple_extent_npoints.restype = C.c_int64; lib.H5Sget_simple_extent_npoints.argtypes = [hid]
+    lib.H5Sclose.argtypes = [hid]
+    lib.H5Tget_class.restype = C.c_int; lib.H5Tget_class.argtypes = [hid]
+    lib.H5Tget_size.restype = C.c_size_t; lib.H5Tget_size.argtypes = [hid]
+    lib.H5Tget_sign.restype = C.c_int; lib.H5Tget_sign.argtypes = [hid]
+    lib.H5Tget_super.restype = hid; lib.H5Tget_super.argtypes = [hid]
+    lib.H5Tget_nmembers.restype = C.c_int; lib.H5Tget_nmembers.argtypes = [hid]
+    lib.H5Tget_member_name.restype = C.c_void_p; lib.H5Tget_member_name.argtypes = [hid, C.c_uint]
+    lib.H5Tget_member_value.argtypes = [hid, C.c_uint, C.c_void_p]
+    lib.H5Tis_variable_str.restype = C.c_int; lib.H5Tis_variable_str.argtypes = [hid]
+    lib.H5Tcopy.restype = hid; lib.H5Tcopy.argtypes = [hid]
+    lib.H5Tclose.argtypes = [hid]
+    lib.H5free_memory.argtypes = [C.c_void_p]
+    lib.H5Dread.restype = C.c_int; lib.H5Dread.argtypes = [hid, hid, hid, hid, hid, C.c_void_p]
+    lib.H5Lexists.restype = C.c_int; lib.H5Lexists.argtypes = [hid, C.c_char_p, hid]
+    lib.H5Aopen_by_name.restype = hid; lib.H5Aopen_by_name.argtypes = [hid, C.c_char_p, C.c_char_p, hid, hid]
+    lib.H5Aread.restype = C.c_int; lib.H5Aread.argtypes = [hid, hid, C.c_void_p]
+    lib.H5Aclose.argtypes = [hid]
+    lib.H5Gopen2.restype = hid; lib.H5Gopen2.argtypes = [hid, C.c_char_p, hid]
+    lib.H5Gclose.argtypes = [hid]
+    lib.H5Literate.restype = C.c_int
+    lib.H5Eset_auto2.argtypes = [hid, C.c_void_p, C.c_void_p]
+    lib.H5open()
+    lib.H5Eset_auto2(0, None, None)          # errors are reported through return codes, not stderr spam
+    _lib = lib
+    return lib
+
+
+def _native(lib, name):
+    return C.c_int64.in_dll(lib, name).value
+
+
+class _File:
+    def __init__(self, path):
+        self.lib = _hdf5()
+        self.fid = self.lib.H5Fopen(os.fsencode(path), _H5F_ACC_RDONLY, _H5P_DEFAULT)
+        if self.fid < 0:
+            raise OSError(f"cannot open {path!r} as HDF5")
+
+    def close(self):
+        if self.fid >= 0:
+            self.lib.H5Fclose(self.fid)
+            self.fid = -1
+
+    def exists(self, name):
+        parts = name.strip("/").split("/")
+        cur = ""
+        for p in parts:
+            cur += "/" + p
+            if self.lib.H5Lexists(self.fid, cur.encode(), _H5P_DEFAULT) <= 0:
+                return False
+        return True
+
+    def read(self, name):
+        """Dataset -> numpy array (integers, floats, fixed-length strings, integer-backed enums)."""
+        lib = self.lib
+        did = lib.H5Dopen2(self.fid, name.encode(), _H5P_DEFAULT)
+        if did < 0:
+            raise KeyError(f"dataset {name!r} not found")
+        try:
+            sid = lib.H5Dget_space(did)
+            n = lib.H5Sget_simple_extent_npoints(sid)
+            lib.H5Sclose(sid)
+            tid = lib.H5Dget_type(did)
+            cls, size = lib.H5Tget_class(tid), lib.H5Tget_size(tid)
+            labels = None
+            if cls == _H5T_ENUM:
+                nm = lib.H5Tget_nmembers(tid)
+                sup = lib.H5Tget_super(tid)
+                bsize = lib.H5Tget_size(sup)
+                lib.H5Tclose(sup)
+                labels = {}
+                for i in range(nm):
+                    p = lib.H5Tget_member_name(tid, i)
+                    nm_s = C.string_at(p).decode()
+                    lib.H5free_memory(p)
+                    val = C.c_int64(0)
+                    lib.H5Tget_member_value(tid, i, C.byref(val))
+                    labels[int(np.frombuffer(bytes(val)[:bsize], dtype=f"<i{bsize}")[0])] = nm_s
+                dtype, mem, size = np.dtype(f"<i{bsize}"), tid, bsize
+            elif cls == _H5T_INTEGER:
+                signed = lib.H5Tget_sign(tid) != 0
+                dtype = np.dtype(f"<{'i' if signed else 'u'}{size}")
+                mem = _native(lib, {(1, True): "H5T_NATIVE_INT8_g", (2, True): "H5T_NATIVE_INT16_g",
+                                    (4, True): "H5T_NATIVE_INT32_g", (8, True): "H5T_NATIVE_INT64_g",
+                                    (1, False): "H5T_NATIVE_UINT8_g", (2, False): "H5T_NATIVE_UINT16_g",
+                                    (4, False): "H5T_NATIVE_UINT32_g", (8, False): "H5T_NATIVE_UINT64_g"}[(size, signed)])
+            elif cls == _H5T_FLOAT:
+                dtype = np.dtype(f"<f{size}")
+                mem = _native(lib, "H5T_NATIVE_DOUBLE_g" if size == 8 else "H5T_NATIVE_FLOAT_g")
+            elif cls == _H5T_STRING:
+                if lib.H5Tis_variable_str(tid) > 0:
+                    raise NotImplementedError(f"{name}: variable-length strings are not supported")
+                dtype, mem = np.dtype(f"S{size}"), tid
+            else:
+                raise NotImplementedError(f"{name}: HDF5 type class {cls} is not supported")
+            out = np.empty(int(n), dtype=dtype)
+            if n > 0 and lib.H5Dread(did, mem, _H5S_ALL, _H5S_ALL, _H5P_DEFAULT, out.ctypes.data_as(C.c_void_p)) < 0:
+                raise OSError(f"H5Dread failed for {name!r}")
+            lib.H5Tclose(tid)
+            if labels is not None:
+                lut = np.array([labels[i] for i in range(max(labels) + 1)], dtype=object)
+                return lut[out]
+            return out
+        finally:
+            lib.H5Dclose(did)
+
+    def attr_int(self, obj, name):
+        lib = self.lib
+        aid = lib.H5Aopen_by_name(self.fid, obj.encode(), name.encode(), _H5P_DEFAULT, _H5P_DEFAULT)
+        if aid < 0:
+            raise KeyError(f"attribute {name!r} not found on {obj!r}")
+        v = C.c_int64(0)
+        rc = lib.H5Aread(aid, _native(lib, "H5T_NATIVE_INT64_g"), C.byref(v))
+        lib.H5Aclose(aid)
+        if rc < 0:
+            raise OSError(f"cannot read attribute {name!r}")
+        return int(v.value)
+
+
+def read_cool(path, group="/", extra_bins=None):
+    """Open ``path`` (optionally a ``group`` inside a multi-resolution file) and return an ArrayCooler.
+
+    Every numeric column of ``bins/`` listed in ``extra_bins`` (default: weight, cov_cis_raw, cov_tot_raw when
+    present) is loaded; the whole pixel table is read into host memory (the engine keeps it in HBM afterwards)."""
+    try:
+        import h5py  # noqa: F401
+        return _read_cool_h5py(path, group, extra_bins)
+    except ImportError:
+        pass
+    g = "/" + group.strip("/")
+    g = "" if g == "/" else g
+    f = _File(path)
+    try:
+        names = [x.decode() if isinstance(x, bytes) else str(x) for x in f.read(f"{g}/chroms/name")]
+        names = [x.rstrip("\x00") for x in names]
+        lengths = f.read(f"{g}/chroms/length").astype(np.int64)
+        binsize = f.attr_int(g or "/", "bin-size")
+        bin1_offset = f.read(f"{g}/indexes/bin1_offset").astype(np.int64)
+        bin2_id = f.read(f"{g}/pixels/bin2_id")
+        count = f.read(f"{g}/pixels/count")
+        cols = {}
+        want = extra_bins if extra_bins is not None else ["weight", "cov_cis_raw", "cov_tot_raw"]
+        for c in want:
+            if f.exists(f"{g}/bins/{c}"):
+                cols[c] = f.read(f"{g}/bins/{c}")
+    finally:
+        f.close()
+    if not np.issubdtype(count.dtype, np.integer):
+        raise NotImplementedError("coolers with non-integer pixel counts are not supported by the GPU engine")
+    return ArrayCooler(pd.Series(lengths, index=names), binsize, bin1_offset, bin2_id, count.astype(np.int32), bins=cols,
+                       filename=path)
+
+
+def _read_cool_h5py(path, group, extra_bins):
+    import h5py
+    with h5py.File(path, "r") as h5:
+        g = h5[group]
+        names = [x.decode() if isinstance(x, bytes) else str(x) for x in g["chroms/name"][:]]
+        lengths = g["chroms/length"][:].astype(np.int64)
+        binsize = int(g.attrs["bin-size"])
+        want = extra_bins if extra_bins is not None else ["weight", "cov_cis_raw", "cov_tot_raw"]
+        cols = {c: g["bins"][c][:] for c in want if c in g["bins"]}
+        return ArrayCooler(pd.Series(lengths, index=names), binsize, g["indexes/bin1_offset"][:].astype(np.int64),
+                           g["pixels/bin2_id"][:], g["pixels/count"][:].astype(np.int32), bins=cols, filename=path)

@@ -13,6 +13,8 @@ sites in coolpuppy/coolpup.py (line numbers of the reference):
 
 A real ``cooler.Cooler`` can be adapted with :func:`from_cooler` when the package is installed.
 """
+import os
+
 import numpy as np
 import pandas as pd
 
@@ -144,7 +146,12 @@ def from_cooler(clr):
 
 
 def as_array_cooler(clr):
-    """Return clr if it already exposes ``pixel_table()``, else adapt it."""
+    """Return clr if it already exposes ``pixel_table()``; open it when it is a path / cooler URI
+    ("file.cool" or "file.mcool::resolutions/10000"); otherwise adapt a ``cooler.Cooler``."""
     if hasattr(clr, "pixel_table"):
         return clr
+    if isinstance(clr, (str, os.PathLike)):
+        from .cool_io import read_cool
+        path, _, group = str(clr).partition("::")
+        return read_cool(path, group=group or "/")
     return from_cooler(clr)
