@@ -78,6 +78,31 @@ _SIGNATURES = {
 _lib = None
 
 
+def _prefer_torch_hip_runtime():
+    """If PyTorch-ROCm is installed but not imported yet, load ITS bundled libamdhip64 first.
+
+    libpup_hip.so needs libamdhip64.so.7; a process can hold only one copy of that soname.  When this library loads
+    the system ROCm copy first and torch is imported afterwards, torch ends up on a runtime it was not built with
+    and reports "No HIP GPUs are available".  Loading torch's copy first (what happens anyway when torch is
+    imported first) keeps both on the runtime torch ships.  Without torch the system ROCm runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load (once) and return the ctypes handle; raises if the HIP extension was not built."""
     global _lib
@@ -88,6 +113,7 @@ def lib():
                 "`python -c 'import __graft_entry__ as g; g.build()'` (or coolpuppy_amd.build.build_hip()). "
                 "There is no CPU fallback."
             )
+        _prefer_torch_hip_runtime()
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)   # AttributeError if the .so lacks a declared symbol
