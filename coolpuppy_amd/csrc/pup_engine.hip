@@ -68,7 +68,7 @@ struct pup_ctx {
     // workspaces
     DevBuf<int> d_r0, d_c0;
     DevBuf<unsigned char> d_chunk_flip;
-    DevBuf<int> d_chunk_stride, d_block_chunk;
+    DevBuf<int> d_chunk_stride, d_block_chunk, d_block_band;
     DevBuf<long long> d_chunk_begin, d_chunk_end, d_seg1, d_seg2, d_dn;
     DevBuf<double> part_f64, slice_f64;
     DevBuf<unsigned> part_num;
@@ -143,6 +143,17 @@ void launch_k1r(const pup::K1Args& a, int nchunks, hipStream_t s) {
         hipLaunchKernelGGL((pup::pileup_regtile_kernel<W, true>), dim3(nchunks), dim3(pup::kWave), 0, s, a);
     else
         hipLaunchKernelGGL((pup::pileup_regtile_kernel<W, false>), dim3(nchunks), dim3(pup::kWave), 0, s, a);
+}
+
+// banded register-tile kernel: NCH column chunks of 16 cells -> windows up to 16*NCH wide
+int band_nch(int W) { return W <= 64 ? 4 : (W <= 128 ? 8 : 16); }
+
+template <int NCH>
+void launch_k1b(const pup::K1Args& a, int nblocks, hipStream_t s) {
+    if (a.mode & PUP_MODE_OOE)
+        hipLaunchKernelGGL((pup::pileup_band_kernel<NCH, true>), dim3(nblocks), dim3(pup::kWave), 0, s, a);
+    else
+        hipLaunchKernelGGL((pup::pileup_band_kernel<NCH, false>), dim3(nblocks), dim3(pup::kWave), 0, s, a);
 }
 
 // window widths the register-tile kernel is instantiated for (pad 1..15 -> W = 3..31)
@@ -225,7 +236,7 @@ void pup_destroy(pup_ctx* c) {
     collect_events(c);
     c->indptr.release(); c->px.release(); c->cnt32.release(); c->bal.release(); c->badbits.release(); c->idx.release(); c->idx_chrom.release(); c->weight.release(); c->cov.release(); c->expv.release(); c->exp_pair.release(); c->exp_regions.release();
     c->acc_f64.release(); c->acc_i64.release();
-    c->d_r0.release(); c->d_c0.release(); c->d_chunk_flip.release(); c->d_chunk_stride.release(); c->d_block_chunk.release();
+    c->d_r0.release(); c->d_c0.release(); c->d_chunk_flip.release(); c->d_chunk_stride.release(); c->d_block_chunk.release(); c->d_block_band.release();
     c->d_chunk_begin.release(); c->d_chunk_end.release(); c->d_seg1.release(); c->d_seg2.release();
     c->d_dn.release();
     c->part_f64.release(); c->slice_f64.release(); c->part_num.release(); c->slice_num.release();
@@ -466,9 +477,9 @@ int pup_reset(pup_ctx* c, int32_t n_tiles, int32_t pad) {
     if (!c) return PUP_EINVAL;
     if (n_tiles <= 0 || pad < 0) return fail(c, PUP_EINVAL, "pup_reset: n_tiles=%d pad=%d", n_tiles, pad);
     const int W = 2 * pad + 1;
-    if (pup::k1_lds_bytes(W) > (size_t)c->max_lds)
-        return fail(c, PUP_ENOTSUP, "pup_reset: window %dx%d needs %zu B of LDS per wave, device offers %d",
-                    W, W, pup::k1_lds_bytes(W), c->max_lds);
+    if (W > 255 && pup::k1_lds_bytes(W) > (size_t)c->max_lds)
+        return fail(c, PUP_ENOTSUP, "pup_reset: window %dx%d is wider than the banded kernel serves (255) and needs "
+                    "%zu B of LDS per wave, device offers %d", W, W, pup::k1_lds_bytes(W), c->max_lds);
     int rc = bind(c); if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const size_t W2 = (size_t)W * W;
@@ -548,10 +559,14 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, 
     }
     const int S = c->group_waves > 0 ? c->group_waves : 128;
     const int n_xcd = 8;
+    // kernel family: register tile (W <= 31), banded register tile (W <= 255), LDS tile (EXPECTED pass, variant&2)
+    const bool lds_kernel = (mode & PUP_MODE_EXPECTED) || (c->variant & 2);
+    const bool band_kernel = !lds_kernel && c->W > 31;
+    const int nbands = band_kernel ? (c->W + (pup::kWave / band_nch(c->W)) - 1) / (pup::kWave / band_nch(c->W)) : 1;
     std::vector<long long> cb, ce, tile_chunk_ptr((size_t)c->T + 1, 0), dn((size_t)c->T);
     std::vector<unsigned char> cf;
     std::vector<int> cs;
-    std::vector<std::vector<int>> xcd_list((size_t)n_xcd);
+    std::vector<std::vector<int>> xcd_list((size_t)n_xcd);       // entries: chunk * nbands + band
     long long group_no = 0;
     auto add_run = [&](long long b, long long e, unsigned char flip) {
         for (long long g0 = b; g0 < e; g0 += (long long)S * C) {
@@ -559,7 +574,7 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, 
             const int waves = (int)std::min<long long>(S, std::max<long long>(1, (g1 - g0 + 15) / 16));
             auto& lst = xcd_list[(size_t)(group_no++ % n_xcd)];
             for (int j = 0; j < waves; ++j) {
-                lst.push_back((int)cb.size());
+                for (int b = 0; b < nbands; ++b) lst.push_back((int)cb.size() * nbands + b);
                 cb.push_back(g0 + j); ce.push_back(g1); cs.push_back(waves); cf.push_back(flip);
             }
         }
@@ -574,9 +589,13 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, 
     }
     size_t per_xcd = 0;
     for (auto& l : xcd_list) per_xcd = std::max(per_xcd, l.size());
-    std::vector<int> block_chunk(per_xcd * (size_t)n_xcd, -1);
+    std::vector<int> block_chunk(per_xcd * (size_t)n_xcd, -1), block_band(per_xcd * (size_t)n_xcd, 0);
     for (int x = 0; x < n_xcd; ++x)
-        for (size_t i = 0; i < xcd_list[(size_t)x].size(); ++i) block_chunk[i * (size_t)n_xcd + (size_t)x] = xcd_list[(size_t)x][i];
+        for (size_t i = 0; i < xcd_list[(size_t)x].size(); ++i) {
+            const int e = xcd_list[(size_t)x][i];
+            block_chunk[i * (size_t)n_xcd + (size_t)x] = e / nbands;
+            block_band[i * (size_t)n_xcd + (size_t)x] = e % nbands;
+        }
     const long long nblocks = (long long)block_chunk.size();
     const long long nchunks = (long long)cb.size();
     if (nchunks > 0x7fffffffLL || nblocks > 0x7fffffffLL) return fail(c, PUP_ENOTSUP, "pup_accumulate: too many chunks");
@@ -612,6 +631,8 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, 
     HIPCHK(c, hipMemcpy(c->d_chunk_stride.p, cs.data(), (size_t)nchunks * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(c, c->d_block_chunk.reserve((size_t)nblocks));
     HIPCHK(c, hipMemcpy(c->d_block_chunk.p, block_chunk.data(), (size_t)nblocks * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, c->d_block_band.reserve((size_t)nblocks));
+    HIPCHK(c, hipMemcpy(c->d_block_band.p, block_band.data(), (size_t)nblocks * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_seg2.p, seg2.data(), seg2.size() * 8, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_dn.p, dn.data(), (size_t)c->T * 8, hipMemcpyHostToDevice));
     if (two_level) {
@@ -641,7 +662,7 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, 
     a.exp_pair = c->have_exp_pair ? c->exp_pair.p : nullptr;
     a.r0 = dr0; a.c0 = dc0;
     a.chunk_begin = c->d_chunk_begin.p; a.chunk_end = c->d_chunk_end.p; a.chunk_flip = c->d_chunk_flip.p;
-    a.chunk_stride = c->d_chunk_stride.p; a.block_chunk = c->d_block_chunk.p;
+    a.chunk_stride = c->d_chunk_stride.p; a.block_chunk = c->d_block_chunk.p; a.block_band = c->d_block_band.p;
     a.part_f64 = c->part_f64.p; a.part_num = c->part_num.p;
     a.counters = c->counters.p; a.err = c->d_err.p;
     a.W = W; a.ignore_diags = ignore_diags; a.mode = mode;
@@ -652,9 +673,23 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, 
         HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1)); HIPCHK(c, hipEventCreate(&e2));
         HIPCHK(c, hipEventRecord(e0, c->stream));
     }
-    // small windows: register-tile kernel; EXPECTED-only passes, wide windows and variant&2: LDS-tile kernel
-    const bool regtile = !m_exp && !(c->variant & 2) && launch_regtile(W, a, (int)nblocks, c->stream);
-    if (!regtile) {
+    // small windows: register-tile kernel; wide windows: banded register-tile kernel; EXPECTED-only passes and
+    // variant&2: LDS-tile kernel (needs the whole tile in LDS)
+    const bool lds_kernel2 = m_exp || (c->variant & 2);
+    bool launched = false;
+    if (!lds_kernel2 && W <= 31) launched = launch_regtile(W, a, (int)nblocks, c->stream);
+    if (!lds_kernel2 && !launched && W > 31 && W <= 255) {
+        switch (band_nch(W)) {
+            case 4:  launch_k1b<4>(a, (int)nblocks, c->stream); break;
+            case 8:  launch_k1b<8>(a, (int)nblocks, c->stream); break;
+            default: launch_k1b<16>(a, (int)nblocks, c->stream); break;
+        }
+        launched = true;
+    }
+    if (!launched) {
+        if (pup::k1_lds_bytes(W) > (size_t)c->max_lds)
+            return fail(c, PUP_ENOTSUP, "pup_accumulate: window %dx%d needs %zu B of LDS for this pass, device offers %d",
+                        W, W, pup::k1_lds_bytes(W), c->max_lds);
         switch (W) {
             case 21: launch_k1<21>(a, (int)nblocks, lds, c->stream); break;
             case 51: launch_k1<51>(a, (int)nblocks, lds, c->stream); break;

@@ -96,6 +96,7 @@ struct K1Args {
                                    //           XCD works on at any moment is a few consecutive rows (L2-resident)
     const int*       block_chunk;  // [gridDim.x] chunk executed by each workgroup (-1: none); groups are laid out
                                    //           so that workgroups b, b+8, b+16, ... (one XCD) share a group
+    const int*       block_band;   // [gridDim.x] row band of the window the workgroup owns (banded kernel; else 0)
     // per-chunk partial outputs
     double*   part_f64;   // [nchunks][W2 + 2W]   (sum | cov_start | cov_end)
     unsigned* part_num;   // [nchunks][W2]
@@ -601,6 +602,197 @@ __global__ __launch_bounds__(kWave, rt_min_waves(W)) void pileup_regtile_kernel(
         }
     }
     for (int t = lane; t < 2 * W; t += kWave) of[W2 + t] = m_cov ? cov_lds[t] : 0.0;
+    for (int off = 32; off > 0; off >>= 1) {
+        npix   += __shfl_down(npix, off);
+        nprobe += __shfl_down(nprobe, off);
+    }
+    if (lane == 0 && a.counters) {
+        atomicAdd(&a.counters[0], npix);
+        atomicAdd(&a.counters[1], nprobe);
+    }
+}
+
+// ---- K1b: banded register-tile kernel for wide windows (31 < W <= 16*NCH, up to 255) ----------------------------
+// Same idea as K1r, but a wave owns only a BAND of H = 64/NCH consecutive window rows of every snippet of its chunk
+// (lane (p,k): row band*H + p, the 16 columns [16k, 16k+16)), so the per-lane register tile stays 16 cells whatever
+// the window width; the ceil(W/H) band-waves of a chunk write disjoint rows of the chunk's one partial tile.
+// NCH = 4 / 8 / 16 serves W <= 64 / 128 / 255.  Row/column validity bits are fetched per lane (rows: one bit,
+// columns: 16 bits) because a band's rows and a lane's columns are no longer wave-uniform 32-bit masks.
+constexpr int kBandCH = 16;
+
+struct BandStage {
+    unsigned long long p0, cums, cur, nxt;
+    unsigned long long rw, cw0, cw1;   // masked-bin words: the lane's row, the lane's 16 columns
+    int                ws, sh;
+    long long          spos;
+    unsigned           sbits;
+    int                r0, c0;
+    bool               valid, indexed;
+};
+
+template <int NCH, bool OOE>
+__global__ __launch_bounds__(kWave, 3) void pileup_band_kernel(K1Args a) {
+    constexpr int CH = kBandCH;
+    constexpr int H  = kWave / NCH;                  // rows per band
+    const int W  = a.W;
+    const int W2 = W * W;
+    const int lane = threadIdx.x;
+    const int ck = a.block_chunk[blockIdx.x];
+    if (ck < 0) return;
+    const int band = a.block_band[blockIdx.x];
+    const int p_in = lane / NCH;
+    const int k    = lane - p_in * NCH;
+    const int pg_raw = band * H + p_in;              // window row of this lane
+    const int q0 = k * CH;
+    const bool lane_ok = (pg_raw < W) && (q0 < W);
+    const int pg = pg_raw < W ? pg_raw : W - 1;
+    const int chw = lane_ok ? ((W - q0) < CH ? (W - q0) : CH) : 0;
+    const unsigned chmask = chw >= 32 ? 0xffffffffu : ((1u << chw) - 1u);
+    const int qs = q0 < W ? q0 : 0;
+
+    const bool m_cov   = (a.mode & 0x04u) && a.cov != nullptr;
+    const bool m_tr    = a.mode & 0x08u;
+    const bool use_exp = OOE && ((a.expv != nullptr && a.nexp > 0) || a.n_exp_regions > 0);
+    const int  igd     = a.ignore_diags;
+    const bool have_idx = a.idx != nullptr;
+    const double qnan = __builtin_nan("");
+    ExpCache ecache;
+
+    double   sum[CH];
+    unsigned num[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { sum[i] = 0.0; num[i] = 0u; }
+    double cov_s = 0.0, cov_e = 0.0;                 // lanes with k == 0: coverage of window row pg / column pg
+
+    const long long cb = a.chunk_begin[ck];
+    const long long ce = a.chunk_end[ck];
+    const long long cstep = a.chunk_stride[ck];
+    const int fl = a.chunk_flip[ck];
+    unsigned long long npix = 0, nprobe = 0;
+    int ch_start = 0, ch_end = -1, ch_nblk = 0; long long ch_base = 0;
+
+    auto issue = [&](BandStage& g, long long s) __attribute__((always_inline)) {
+        g.valid = false; g.indexed = false;
+        if (s >= ce) return;
+        g.r0 = __builtin_amdgcn_readfirstlane(a.r0[s]);
+        g.c0 = __builtin_amdgcn_readfirstlane(a.c0[s]);
+        if (g.r0 < 0 || g.c0 < 0 || (long long)g.r0 + W > a.nbins || (long long)g.c0 + W > a.nbins) {
+            if (lane == 0 && band == 0) atomicExch(a.err, 1);
+            return;
+        }
+        g.valid = true;
+        if (have_idx) {
+            if (!(g.r0 >= ch_start && g.r0 < ch_end)) {
+                int lo = 0, hi_k = a.n_chrom;
+                while (lo < hi_k) { const int m = (lo + hi_k) >> 1; if (a.idx_chrom[m].end <= g.r0) lo = m + 1; else hi_k = m; }
+                if (lo < a.n_chrom) {
+                    const IdxChrom c = a.idx_chrom[lo];
+                    ch_start = c.start; ch_end = c.end; ch_nblk = c.nblk; ch_base = c.blk_base;
+                } else { ch_start = 0; ch_end = -1; }
+            }
+            g.indexed = g.r0 >= ch_start && g.r0 + W <= ch_end && g.c0 >= ch_start && g.c0 + W <= ch_end;
+        }
+        const int r = g.r0 + pg;
+        if (g.indexed) {
+            const int rel = (g.c0 - ch_start) + qs;
+            const int b = rel / kIdxCols, o = rel - b * kIdxCols;
+            g.ws = o >> 6;
+            g.sh = o & 63;
+            const U64x2* base = reinterpret_cast<const U64x2*>(a.idx + ch_base + (long long)(r - ch_start) * ch_nblk + b);
+            const U64x2 h = base[0];
+            g.p0 = h.a; g.cums = h.b;
+            const U64x2 w = *reinterpret_cast<const U64x2*>(reinterpret_cast<const char*>(base) + 16 + 8 * g.ws);
+            g.cur = w.a; g.nxt = w.b;
+        } else {
+            const RowLoc loc = search_row_chunk<CH>(a, r, g.c0 + qs, nprobe);
+            g.spos = loc.pos; g.sbits = loc.bits;
+        }
+        g.rw = a.badbits[r >> 6];
+        const U64x2 cw = *reinterpret_cast<const U64x2*>(a.badbits + ((g.c0 + qs) >> 6));
+        g.cw0 = cw.a; g.cw1 = cw.b;
+    };
+
+    auto process = [&](const BandStage& g) __attribute__((always_inline)) {
+        if (!g.valid) return;
+        long long pos; unsigned bits;
+        if (g.indexed) {
+            unsigned long long b64 = g.cur >> g.sh;
+            if (g.sh) b64 |= g.nxt << (64 - g.sh);
+            bits = (unsigned)b64 & chmask;
+            const unsigned cum = g.ws ? (unsigned)(g.cums >> ((g.ws - 1) * 16)) & 0xffffu : 0u;
+            pos = (long long)(g.p0 + cum + (unsigned long long)__popcll(g.cur & ((1ull << g.sh) - 1ull)));
+        } else { pos = g.spos; bits = g.sbits & chmask; }
+        double v[CH];
+#pragma unroll
+        for (int i = 0; i < CH; i += 2) {
+            const F64x2 pr = *reinterpret_cast<const F64x2*>(a.bal + pos + __popc(bits & ((1u << i) - 1u)));
+            v[i] = pr.a;
+            if (i + 1 < CH) v[i + 1] = ((bits >> i) & 1u) ? pr.b : pr.a;
+        }
+        const int r = g.r0 + pg, cc = g.c0 + qs;
+        const int csh = cc & 63;
+        unsigned long long cb64 = g.cw0 >> csh;
+        if (csh) cb64 |= g.cw1 << (64 - csh);
+        unsigned ok = chmask & ~(unsigned)cb64;
+        if ((g.rw >> (r & 63)) & 1ull) ok = 0u;
+        if (igd >= 0) {
+            const int t0 = igd - (cc - r);
+            ok &= t0 <= 0 ? 0xffffffffu : (t0 >= 32 ? 0u : ~((1u << t0) - 1u));
+        }
+        double ev[CH];
+        if (OOE) {
+            ExpSel es; es.base = a.expv; es.len = 0; es.scalar = qnan; es.is_scalar = true;
+            if (use_exp) es = select_expected(a, ecache, g.r0, g.c0);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                long long ad = (long long)(cc + i) - r; if (ad < 0) ad = -ad;
+                const double e = es.is_scalar ? es.scalar : es.base[ad < es.len ? ad : 0];
+                ev[i] = (es.is_scalar || ad < es.len) ? e : qnan;
+            }
+        }
+        if (m_cov && lane_ok && k == 0) {
+            const double cr = a.cov[g.r0 + pg], cv = a.cov[g.c0 + pg];
+            const double vs = m_tr ? cv : cr, ve = m_tr ? cr : cv;
+            if (vs == vs) cov_s += vs;
+            if (ve == ve) cov_e += ve;
+        }
+        npix += (unsigned long long)__popc(bits);
+        const unsigned addm = ok & bits;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            if (OOE) {
+                const double q = v[i] / ev[i];
+                const bool okn = ((ok >> i) & 1u) && (ev[i] == ev[i]) && (ev[i] != 0.0);
+                num[i] += okn ? 1u : 0u;
+                sum[i] += (((addm >> i) & 1u) && (q == q)) ? q : 0.0;
+            } else {
+                num[i] += (ok >> i) & 1u;
+                sum[i] += ((addm >> i) & 1u) ? v[i] : 0.0;
+            }
+        }
+    };
+
+    BandStage A, B;
+    issue(A, cb);
+    for (long long s = cb; s < ce; s += 2 * cstep) {
+        issue(B, s + cstep);
+        process(A);
+        issue(A, s + 2 * cstep);
+        process(B);
+    }
+
+    const size_t L = (size_t)W2 + 2 * (size_t)W;
+    double*   of = a.part_f64 + (size_t)ck * L;
+    unsigned* on = a.part_num + (size_t)ck * W2;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        if ((chmask >> i) & 1u) {
+            const int cell = map_cell(pg, q0 + i, W, m_tr, fl);
+            of[cell] = sum[i];
+            on[cell] = num[i];
+        }
+    }
+    if (lane_ok && k == 0) { of[W2 + pg] = cov_s; of[W2 + W + pg] = cov_e; }
     for (int off = 32; off > 0; off >>= 1) {
         npix   += __shfl_down(npix, off);
         nprobe += __shfl_down(nprobe, off);
