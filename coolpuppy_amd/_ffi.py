@@ -16,6 +16,7 @@ MODE_EXPECTED = 0x02
 MODE_COV = 0x04
 MODE_TRANSPOSE = 0x08
 MODE_DEVPTR = 0x10
+MODE_LOCAL = 0x20
 
 PUP_OK = 0
 ERROR_NAMES = {
@@ -60,6 +61,8 @@ _SIGNATURES = {
     "pup_reset": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "pup_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                  C.c_int32, C.c_uint32]),
+    "pup_accumulate_rescaled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                          C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32]),
     "pup_stripes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_uint32,
                               C.c_void_p, C.c_void_p]),
     "pup_sync": (C.c_int, [C.c_void_p]),

@@ -70,11 +70,23 @@ def assign_groups(intervals, groupby=[]):
     return intervals
 
 
+def _scaled_interval(start, end, scale):
+    """bioframe.expand(df, scale=...): grow an interval by 0.5*(scale-1)*length on both sides, rounded (np.round,
+    half to even) back to the integer dtype of the input — what the reference calls for rescaled pile-ups."""
+    start = np.asarray(start)
+    end = np.asarray(end)
+    pads = 0.5 * (scale - 1) * (end - start)
+    return np.round(start - pads).astype(start.dtype), np.round(end + pads).astype(end.dtype)
+
+
 def expand(intervals, flank, resolution, rescale_flank=None):
-    """Window of one feature: the bin holding its centre, +- flank (reference :78-91)."""
-    if rescale_flank is not None:
-        raise NotImplementedError("rescale_flank (rescaled pile-ups) is not implemented in coolpuppy_amd")
+    """Window of one feature: the bin holding its centre +- flank, or (rescaled pile-ups) the feature itself
+    extended by rescale_flank times its length on each side (reference :78-91)."""
     out = intervals.copy()
+    if rescale_flank is not None:
+        out["exp_start"], out["exp_end"] = _scaled_interval(out["start"].values, out["end"].values,
+                                                            2 * rescale_flank + 1)
+        return out
     cbin_start = np.floor(out["center"] / resolution) * resolution
     out["exp_start"] = cbin_start - flank
     out["exp_end"] = np.floor(out["center"] / resolution + 1) * resolution + flank
@@ -84,7 +96,10 @@ def expand(intervals, flank, resolution, rescale_flank=None):
 def expand2D(intervals, flank, resolution, rescale_flank=None):
     """Two-sided version of :func:`expand` (reference :94-115)."""
     if rescale_flank is not None:
-        raise NotImplementedError("rescale_flank (rescaled pile-ups) is not implemented in coolpuppy_amd")
+        for side in ("1", "2"):
+            intervals["exp_start" + side], intervals["exp_end" + side] = _scaled_interval(
+                intervals["start" + side].values, intervals["end" + side].values, 2 * rescale_flank + 1)
+        return intervals
     for side in ("1", "2"):
         c = intervals["center" + side]
         intervals["exp_start" + side] = np.floor(c // resolution) * resolution - flank
@@ -192,9 +207,7 @@ class CoordCreator:
             self.kind = self.features_format
         if self.kind not in ("bed", "bedpe"):
             raise ValueError('kind can only be "bed" or "bedpe"')
-        if self.rescale_flank is not None:
-            raise NotImplementedError("rescale_flank (rescaled pile-ups) is not implemented in coolpuppy_amd")
-        if self.flank % self.resolution != 0:
+        if self.rescale_flank is None and self.flank % self.resolution != 0:
             raise ValueError(
                 f"flank ({self.flank}) must be a multiple of the resolution ({self.resolution}): the window "
                 "would not be 2*(flank//resolution)+1 bins wide")
@@ -714,7 +727,13 @@ class PileUpper:
                 raise ValueError("Cannot use rescale without setting rescale_flank")
             elif self.rescale_size % 2 == 0:
                 raise ValueError("Please provide an odd rescale_size")
-            raise NotImplementedError("rescaled pile-ups are not implemented in coolpuppy_amd")
+            if self.store_stripes:
+                raise NotImplementedError("store_stripes together with rescaled pile-ups is not implemented")
+            logger.info(f"Rescaling with rescale_flank = {self.rescale_flank} to "
+                        f"{self.rescale_size}x{self.rescale_size} pixels")
+        elif self.rescale_flank is not None:
+            raise ValueError("rescale_flank is set on the CoordCreator but rescale=False: windows would not be "
+                             "2*pad_bins+1 bins wide")
         if self.ignore_diags is None or self.ignore_diags < 0:
             raise ValueError("ignore_diags must be >= 0 (the engine reads the upper-triangular pixel table)")
 
@@ -799,13 +818,15 @@ class PileUpper:
         lo1, hi1, off1 = self._global_extents[region1]
         lo2, hi2, off2 = self._global_extents[region2]
         W = 2 * self.pad_bins + 1
-        if not (np.all(tbl["endBin1"] - tbl["stBin1"] == W) and np.all(tbl["endBin2"] - tbl["stBin2"] == W)):
-            raise ValueError("window size differs from 2*pad_bins+1; rescaled windows are not supported")
+        hh = (tbl["endBin1"] - tbl["stBin1"]).astype(np.int64)
+        ww = (tbl["endBin2"] - tbl["stBin2"]).astype(np.int64)
+        if not getattr(self, "rescale", False) and not (np.all(hh == W) and np.all(ww == W)):
+            raise ValueError("window size differs from 2*pad_bins+1")
         r0 = tbl["stBin1"].astype(np.int64) + off1
         c0 = tbl["stBin2"].astype(np.int64) + off2
-        ok = (r0 >= lo1) & (r0 + W <= hi1) & (c0 >= lo2) & (c0 + W <= hi2)     # reference :1111-1114
+        ok = (r0 >= lo1) & (r0 + hh <= hi1) & (c0 >= lo2) & (c0 + ww <= hi2)   # reference :1111-1114
         tbl = tbl.take(ok)
-        r0, c0 = r0[ok], c0[ok]
+        r0, c0, hh, ww = r0[ok], c0[ok], hh[ok], ww[ok]
         n = len(r0)
         flip = tbl["flip"].astype(bool) if "flip" in tbl else np.zeros(n, bool)
         coords = None
@@ -840,11 +861,11 @@ class PileUpper:
             codes, keys = _factorize_rows(kc, [lambda i, u=chrom_u: u[i], None, None])
             dup = np.repeat(np.arange(n), 2)
             return {"r0": r0[dup], "c0": c0[dup], "kind": tbl["kind"].astype(np.int8)[dup], "flip": flip[dup],
-                    "group_codes": codes, "group_keys": keys, "n": 2 * n}
+                    "group_codes": codes, "group_keys": keys, "n": 2 * n, "h": hh[dup], "w": ww[dup], "coords": None}
         else:
             codes, keys = np.full(n, -1, np.int64), []
         return {"r0": r0, "c0": c0, "kind": tbl["kind"].astype(np.int8), "flip": flip, "group_codes": codes,
-                "group_keys": keys, "n": n, "coords": coords}
+                "group_keys": keys, "n": n, "coords": coords, "h": hh, "w": ww}
 
     # -- the pile-up -------------------------------------------------------------------------------------------
     def pileupsWithControl(self, nproc=None, groupby=[], ignore_group_order=False, modify_2Dintervals_func=None,
@@ -915,6 +936,8 @@ class PileUpper:
         """Turn per-region window tables into a declarative list of engine calls plus the group bookkeeping
         the finaliser needs.  Pure host code (no GPU): tests replay a plan on the CPU oracle."""
         from .engine import MODE_COV, MODE_EXPECTED, MODE_OOE, MODE_TRANSPOSE
+        MODE_LOCAL = 0x20
+        rescale = bool(getattr(self, "rescale", False))
         if grouped is None:
             grouped = bool(groupby)
         # global group table in the reference's first-appearance order: regions in order, each region's
@@ -984,13 +1007,16 @@ class PileUpper:
             # engine rows must come from the earlier region of the upper-triangular table
             transpose = self._global_extents[region1][0] > self._global_extents[region2][0]
             r0, c0 = (b["c0"], b["r0"]) if transpose else (b["r0"], b["c0"])
+            hh, ww = (b["w"], b["h"]) if transpose else (b["h"], b["w"])
             tr = MODE_TRANSPOSE if transpose else 0
-            mode = (MODE_OOE if (self.expected and self.ooe) else 0) | (MODE_COV if self.coverage_norm else 0) | tr
-            raw.append((region1, region2, expected, r0, c0, b["flip"], b["kind"].astype(np.int64) * G + g, igd, mode))
+            loc = MODE_LOCAL if (rescale and self.local) else 0
+            mode = (MODE_OOE if (self.expected and self.ooe) else 0) | (MODE_COV if self.coverage_norm else 0) | tr | loc
+            raw.append((region1, region2, expected, r0, c0, b["flip"], b["kind"].astype(np.int64) * G + g, igd, mode,
+                        hh, ww))
             if exp_as_control:
                 roi = b["kind"] == KIND_ROI
                 raw.append((region1, region2, expected, r0[roi], c0[roi], b["flip"][roi], G + g[roi], igd,
-                            MODE_EXPECTED | tr))
+                            MODE_EXPECTED | tr | loc, hh[roi], ww[roi]))
         # regions that need no per-region state (no expected vector) and share mode / diagonal mask go to the
         # engine as ONE call: fewer launches, and the engine's interleaved groups span region boundaries
         stripe_jobs = []
@@ -1019,16 +1045,19 @@ class PileUpper:
             prev = merged[-1][0] if merged else None
             same_exp = (item[2] is None and prev is not None and prev[2] is None) or \
                 (isinstance(item[2], str) and prev is not None and isinstance(prev[2], str))
+            fields = (item[3], item[4], item[5], item[6], item[9], item[10])
             if prev is not None and same_exp and item[7] == prev[7] and item[8] == prev[8]:
-                merged[-1][1].append(item[3:7])
+                merged[-1][1].append(fields)
             else:
-                merged.append([item, [item[3:7]]])
+                merged.append([item, [fields]])
         calls = []
         for head, parts in merged:
-            f = [np.concatenate([p[k] for p in parts]) if len(parts) > 1 else parts[0][k] for k in range(4)]
-            calls.append(_engine_call(head[0], head[1], head[2], f[0], f[1], f[2], f[3], T, head[7], head[8]))
+            f = [np.concatenate([p[k] for p in parts]) if len(parts) > 1 else parts[0][k] for k in range(6)]
+            calls.append(_engine_call(head[0], head[1], head[2], f[0], f[1], f[2], f[3], T, head[7], head[8],
+                                      extra={"h": f[4], "w": f[5]} if rescale else None))
         return {"T": T, "G": G, "gid": gid, "order": order, "contrib": contrib, "want_control": want_control,
-                "groupby": list(groupby), "grouped": bool(grouped), "calls": calls, "pad": self.pad_bins,
+                "groupby": list(groupby), "grouped": bool(grouped), "calls": calls,
+                "pad": (self.rescale_size - 1) // 2 if rescale else self.pad_bins, "rescale": rescale,
                 "n_regions": len(batches),
                 "expected_table": exp_table, "stripe_jobs": stripe_jobs,
                 "weight_name": self.clr_weight_name if self.clr_weight_name else None,
@@ -1057,8 +1086,12 @@ class PileUpper:
             else:
                 eng.set_expected(c["expected"])
                 table_set = False
-            eng.accumulate(c["r0"], c["c0"], c["tile_ptr"], flip_from=c["flip_from"],
-                           ignore_diags=c["ignore_diags"], mode=c["mode"])
+            if plan.get("rescale"):
+                eng.accumulate_rescaled(c["r0"], c["c0"], c["h"], c["w"], c["tile_ptr"], flip_from=c["flip_from"],
+                                        ignore_diags=c["ignore_diags"], mode=c["mode"])
+            else:
+                eng.accumulate(c["r0"], c["c0"], c["tile_ptr"], flip_from=c["flip_from"],
+                               ignore_diags=c["ignore_diags"], mode=c["mode"])
         _dist.allreduce_engine(eng)
         acc = eng.fetch()
         if plan.get("stripe_jobs"):
@@ -1202,7 +1235,7 @@ class PileUpper:
         return pups
 
 
-def _engine_call(region1, region2, expected, r0, c0, flip, tile, T, igd, mode):
+def _engine_call(region1, region2, expected, r0, c0, flip, tile, T, igd, mode, extra=None):
     """One pup_accumulate call: snippets grouped by (tile, flip) — stable, so genome order is kept inside a
     group; within a tile the anti-transposed snippets come last (flip_from marks where they start)."""
     n = len(tile)
@@ -1219,15 +1252,20 @@ def _engine_call(region1, region2, expected, r0, c0, flip, tile, T, igd, mode):
         else:
             o = np.argsort(key, kind="stable")
         r0, c0 = r0[o], c0[o]
+        if extra:
+            extra = {k: np.asarray(v)[o] for k, v in extra.items()}
     per_tile = counts.reshape(T, 2)
     tile_ptr = np.concatenate([[0], np.cumsum(per_tile.sum(axis=1))]).astype(np.int64)
     flip_from = (tile_ptr[:-1] + per_tile[:, 0]).astype(np.int64) if any_flip else None
     # after the grouping the tile / flip of every snippet follow from the segment sizes
     tile_sorted = np.repeat(np.arange(T, dtype=np.int32), per_tile.sum(axis=1))
     flip_sorted = np.repeat(np.tile(np.array([0, 1], np.uint8), T), counts) if any_flip else None
-    return {"region1": region1, "region2": region2, "expected": expected,
+    call = {"region1": region1, "region2": region2, "expected": expected,
             "r0": np.ascontiguousarray(r0), "c0": np.ascontiguousarray(c0), "flip": flip_sorted,
             "flip_from": flip_from, "tile": tile_sorted, "tile_ptr": tile_ptr, "ignore_diags": igd, "mode": mode}
+    for k, v in (extra or {}).items():
+        call[k] = np.ascontiguousarray(v, np.int32)
+    return call
 
 
 def _collect_stripes(plan, acc):
@@ -1272,7 +1310,7 @@ def iter_expected_subcalls(plan, call):
         else:
             expected = et["vectors"][i] if i < len(et["end"]) else np.array([np.nan, np.nan])
         sub = dict(call)
-        for name in ("r0", "c0", "tile", "flip"):
+        for name in ("r0", "c0", "tile", "flip", "h", "w"):
             if call.get(name) is not None:
                 sub[name] = call[name][sel]
         T = len(call["tile_ptr"]) - 1

@@ -66,7 +66,7 @@ struct pup_ctx {
     DevBuf<long long> acc_i64;
     int T = 0, pad = 0, W = 0;
     // workspaces
-    DevBuf<int> d_r0, d_c0;
+    DevBuf<int> d_r0, d_c0, d_h, d_w;
     DevBuf<unsigned char> d_chunk_flip;
     DevBuf<int> d_chunk_stride, d_block_chunk, d_block_band;
     DevBuf<long long> d_chunk_begin, d_chunk_end, d_seg1, d_seg2, d_dn;
@@ -236,7 +236,7 @@ void pup_destroy(pup_ctx* c) {
     collect_events(c);
     c->indptr.release(); c->px.release(); c->cnt32.release(); c->bal.release(); c->badbits.release(); c->idx.release(); c->idx_chrom.release(); c->weight.release(); c->cov.release(); c->expv.release(); c->exp_pair.release(); c->exp_regions.release();
     c->acc_f64.release(); c->acc_i64.release();
-    c->d_r0.release(); c->d_c0.release(); c->d_chunk_flip.release(); c->d_chunk_stride.release(); c->d_block_chunk.release(); c->d_block_band.release();
+    c->d_r0.release(); c->d_c0.release(); c->d_h.release(); c->d_w.release(); c->d_chunk_flip.release(); c->d_chunk_stride.release(); c->d_block_chunk.release(); c->d_block_band.release();
     c->d_chunk_begin.release(); c->d_chunk_end.release(); c->d_seg1.release(); c->d_seg2.release();
     c->d_dn.release();
     c->part_f64.release(); c->slice_f64.release(); c->part_num.release(); c->slice_num.release();
@@ -492,9 +492,30 @@ int pup_reset(pup_ctx* c, int32_t n_tiles, int32_t pad) {
     return PUP_OK;
 }
 
+static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, const int32_t* hgt, const int32_t* wid,
+                           int64_t n, const int64_t* tile_ptr, const int64_t* flip_from, int32_t ignore_diags,
+                           uint32_t mode);
+
 int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, const int64_t* tile_ptr,
                    const int64_t* flip_from, int32_t ignore_diags, uint32_t mode) {
+    if (mode & PUP_MODE_LOCAL) return c ? fail(c, PUP_EINVAL, "pup_accumulate: PUP_MODE_LOCAL only applies to rescaled pile-ups") : PUP_EINVAL;
+    return accumulate_impl(c, r0, c0, nullptr, nullptr, n, tile_ptr, flip_from, ignore_diags, mode);
+}
+
+int pup_accumulate_rescaled(pup_ctx* c, const int32_t* r0, const int32_t* c0, const int32_t* height, const int32_t* width,
+                            int64_t n, const int64_t* tile_ptr, const int64_t* flip_from, int32_t ignore_diags,
+                            uint32_t mode) {
     if (!c) return PUP_EINVAL;
+    if (n > 0 && (!height || !width)) return fail(c, PUP_EINVAL, "pup_accumulate_rescaled: NULL window sizes");
+    if (mode & PUP_MODE_DEVPTR) return fail(c, PUP_EINVAL, "pup_accumulate_rescaled: host arrays only");
+    return accumulate_impl(c, r0, c0, height, width, n, tile_ptr, flip_from, ignore_diags, mode);
+}
+
+static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, const int32_t* hgt, const int32_t* wid,
+                           int64_t n, const int64_t* tile_ptr, const int64_t* flip_from, int32_t ignore_diags,
+                           uint32_t mode) {
+    if (!c) return PUP_EINVAL;
+    const bool rescale = hgt != nullptr;
     if (!c->have_px) return fail(c, PUP_ESTATE, "pup_accumulate: no pixel table loaded");
     if (!c->have_bal) return fail(c, PUP_ESTATE, "pup_accumulate: call pup_load_bins first (weights or NULL for raw)");
     if (c->T <= 0) return fail(c, PUP_ESTATE, "pup_accumulate: call pup_reset first");
@@ -533,6 +554,15 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, 
         HIPCHK(c, hipMemcpy(c->d_c0.p, c0, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
         dr0 = c->d_r0.p; dc0 = c->d_c0.p;
     }
+    if (rescale) {
+        HIPCHK(c, c->d_h.reserve((size_t)n)); HIPCHK(c, c->d_w.reserve((size_t)n));
+        HIPCHK(c, hipMemcpy(c->d_h.p, hgt, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_w.p, wid, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+        const size_t need = (size_t)c->W * c->W * 12 + 16 * (size_t)c->W;
+        if (need > (size_t)c->max_lds)
+            return fail(c, PUP_ENOTSUP, "pup_accumulate_rescaled: a %dx%d output tile needs %zu B of LDS, device offers %d",
+                        c->W, c->W, need, c->max_lds);
+    }
 
     // launch geometry (chunk / group / reduction tables) depends only on the snippet COUNTS per tile and on
     // the tuning: when it repeats (steady-state loops, benchmarks) the device tables of the last call are reused
@@ -540,7 +570,7 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, 
     gkey.reserve(8 + 2 * (size_t)c->T);
     gkey.push_back(n); gkey.push_back(c->T); gkey.push_back(c->W); gkey.push_back(c->chunk_snippets);
     gkey.push_back(c->group_waves); gkey.push_back(c->variant & 2); gkey.push_back((mode & PUP_MODE_EXPECTED) ? 1 : 0);
-    gkey.push_back(flip_from ? 1 : 0);
+    gkey.push_back(flip_from ? 1 : 0); gkey.push_back(rescale ? 1 : 0);
     for (int t = 0; t <= c->T; ++t) gkey.push_back(tile_ptr[t]);
     if (flip_from) for (int t = 0; t < c->T; ++t) gkey.push_back(flip_from[t]);
     const bool geom_hit = (gkey == c->geom_key);
@@ -557,10 +587,11 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, 
         const long long target = (long long)std::max(c->n_cu, 64) * 32 * 4;   // ~4 chunks per wave slot
         C = std::max<long long>(16, (n + target - 1) / target);
     }
+    if (rescale) C = std::max<long long>(1, (n + (long long)c->n_cu * 2 - 1) / ((long long)c->n_cu * 2));   // heavy snippets: ~2 workgroups per CU
     const int S = c->group_waves > 0 ? c->group_waves : 128;
     const int n_xcd = 8;
     // kernel family: register tile (W <= 31), banded register tile (W <= 255), LDS tile (EXPECTED pass, variant&2)
-    const bool lds_kernel = (mode & PUP_MODE_EXPECTED) || (c->variant & 2);
+    const bool lds_kernel = (mode & PUP_MODE_EXPECTED) || (c->variant & 2) || rescale;
     const bool band_kernel = !lds_kernel && c->W > 31;
     const int nbands = band_kernel ? (c->W + (pup::kWave / band_nch(c->W)) - 1) / (pup::kWave / band_nch(c->W)) : 1;
     std::vector<long long> cb, ce, tile_chunk_ptr((size_t)c->T + 1, 0), dn((size_t)c->T);
@@ -677,8 +708,15 @@ int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, 
     // variant&2: LDS-tile kernel (needs the whole tile in LDS)
     const bool lds_kernel2 = m_exp || (c->variant & 2);
     bool launched = false;
-    if (!lds_kernel2 && W <= 31) launched = launch_regtile(W, a, (int)nblocks, c->stream);
-    if (!lds_kernel2 && !launched && W > 31 && W <= 255) {
+    if (rescale) {
+        const size_t rs_lds = (size_t)W * W * 12 + 16 * (size_t)W;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(pup::pileup_rescale_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_lds);
+        hipLaunchKernelGGL(pup::pileup_rescale_kernel, dim3((unsigned)nblocks), dim3(256), rs_lds, c->stream, a,
+                           (const int*)c->d_h.p, (const int*)c->d_w.p);
+        launched = true;
+    }
+    if (!launched && !lds_kernel2 && W <= 31) launched = launch_regtile(W, a, (int)nblocks, c->stream);
+    if (!launched && !lds_kernel2 && W > 31 && W <= 255) {
         switch (band_nch(W)) {
             case 4:  launch_k1b<4>(a, (int)nblocks, c->stream); break;
             case 8:  launch_k1b<8>(a, (int)nblocks, c->stream); break;

@@ -803,6 +803,192 @@ __global__ __launch_bounds__(kWave, 3) void pileup_band_kernel(K1Args a) {
     }
 }
 
+// ---- K5: rescaled pile-up (variable h x w windows zoomed to S x S) -------------------------------------------
+// PileUpper._rescale_snip (coolpup.py:1193-1234) with cooltools' zoom_array on the GPU: per snippet the masked /
+// normalised window is (local pile-ups) symmetrised by nanmean, NaN -> 0 (+inf -> DBL_MAX, np.nan_to_num), blown up
+// by bilinear interpolation (scipy.ndimage.zoom order=1: sample o of an axis reads coordinate o*(n_in-1)/(n_out-1);
+// a coordinate that rounding pushes past n_in-1 yields 0) to the integer multiple (mh*S) x (mw*S) of the target and
+// block-averaged; an output cell is NaN when any contributing sample touched a NaN.  An all-NaN window contributes
+// zeros (counted in num), as the reference does.  One 256-thread workgroup per chunk; thread t owns output cells
+// t, t+256, ... of the chunk's LDS tile for every snippet (no atomics, no barrier in the snippet loop); every input
+// cell is fetched on demand (rank-bitmap index or binary search) — rescaled pile-ups are thousands of windows, not
+// millions, so the gather is not staged.
+struct RsGeom { int ch_start, ch_end, ch_nblk; long long ch_base; bool have; };
+
+__device__ __forceinline__ double lookup_bal(const K1Args& a, const RsGeom& g, int row, int col) {
+    if (g.have && row >= g.ch_start && row < g.ch_end && col >= g.ch_start && col < g.ch_end) {
+        const int rel = col - g.ch_start;
+        const int b = rel / kIdxCols, o = rel - b * kIdxCols;
+        const int ws = o >> 6, sh = o & 63;
+        const IdxBlock* blk = a.idx + g.ch_base + (long long)(row - g.ch_start) * g.ch_nblk + b;
+        const unsigned long long wbits = blk->bits[ws];
+        if (!((wbits >> sh) & 1ull)) return 0.0;
+        const unsigned cum = ws ? blk->cum[ws - 1] : 0u;
+        const long long pos = (long long)(blk->pos + cum + (unsigned long long)__popcll(wbits & ((1ull << sh) - 1ull)));
+        return a.bal[pos];
+    }
+    long long lo = a.indptr[row], hi = a.indptr[row + 1];
+    const long long end = hi;
+    while (lo < hi) { const long long m = (lo + hi) >> 1; if (a.px[m].x < col) lo = m + 1; else hi = m; }
+    return (lo < end && a.px[lo].x == col) ? a.bal[lo] : 0.0;
+}
+
+__device__ __forceinline__ bool bin_bad(const K1Args& a, int bin) { return (a.badbits[bin >> 6] >> (bin & 63)) & 1ull; }
+
+__global__ __launch_bounds__(256) void pileup_rescale_kernel(K1Args a, const int* __restrict__ hs, const int* __restrict__ wsz) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int S = a.W, S2 = S * S;
+    double*   tsum = reinterpret_cast<double*>(smem_raw);
+    double*   tcov = tsum + S2;                               // [2S]
+    unsigned* tnum = reinterpret_cast<unsigned*>(tcov + 2 * S);
+    const int ck = a.block_chunk[blockIdx.x];
+    if (ck < 0) return;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    for (int t = tid; t < S2; t += nthr) { tsum[t] = 0.0; tnum[t] = 0u; }
+    for (int t = tid; t < 2 * S; t += nthr) tcov[t] = 0.0;
+    // every thread only ever touches its own cells: no barrier needed before the loop
+
+    const bool m_ooe = a.mode & 0x01u, m_exp = a.mode & 0x02u, m_cov = (a.mode & 0x04u) && a.cov != nullptr;
+    const bool m_tr = a.mode & 0x08u, m_local = a.mode & 0x20u;
+    const bool use_exp = (m_ooe || m_exp) && ((a.expv != nullptr && a.nexp > 0) || a.n_exp_regions > 0);
+    const int igd = a.ignore_diags;
+    const double qn = __builtin_nan("");
+    const double DBLMAX = 1.7976931348623157e308;
+    const long long cb = a.chunk_begin[ck], ce = a.chunk_end[ck], cstep = a.chunk_stride[ck];
+    const int fl = a.chunk_flip[ck];
+    ExpCache ecache;
+    RsGeom geo{0, -1, 0, 0, false};
+
+    for (long long s = cb; s < ce; s += cstep) {
+        const int rs = a.r0[s], cs = a.c0[s], h = hs[s], w = wsz[s];
+        if (rs < 0 || cs < 0 || h < 1 || w < 1 || (long long)rs + h > a.nbins || (long long)cs + w > a.nbins) {
+            if (tid == 0) atomicExch(a.err, 1);
+            continue;
+        }
+        if (a.idx != nullptr && !(rs >= geo.ch_start && rs < geo.ch_end)) {
+            int lo = 0, hi_k = a.n_chrom;
+            while (lo < hi_k) { const int m = (lo + hi_k) >> 1; if (a.idx_chrom[m].end <= rs) lo = m + 1; else hi_k = m; }
+            if (lo < a.n_chrom) { const IdxChrom c = a.idx_chrom[lo]; geo = RsGeom{c.start, c.end, c.nblk, c.blk_base, true}; }
+            else geo = RsGeom{0, -1, 0, 0, false};
+        }
+        ExpSel es; es.base = a.expv; es.len = 0; es.scalar = qn; es.is_scalar = true;
+        if (use_exp) es = select_expected(a, ecache, rs, cs);
+
+        // masked, normalised window cell (i, j) before symmetrisation; NaN = masked
+        auto cell = [&](int i, int j) -> double {
+            const int row = rs + i, col = cs + j;
+            long long ad = (long long)col - row; if (ad < 0) ad = -ad;
+            if (m_exp) return es.at(ad);
+            if (bin_bad(a, row) || bin_bad(a, col)) return qn;
+            if (igd >= 0 && (col - row) < igd) return qn;
+            double v = lookup_bal(a, geo, row, col);
+            if (m_ooe) v = v / es.at(ad);
+            return v;
+        };
+        auto cell_sym = [&](int i, int j) -> double {
+            double v = cell(i, j);
+            if (m_local && h == w) {
+                const double u = cell(j, i);                  // square window (same feature on both sides)
+                if (v != v) v = u; else if (u == u) v = 0.5 * (v + u);
+            }
+            return v;
+        };
+        // ---- does the window hold any non-NaN cell?  (masks only; with expected also the expected's validity) ----
+        bool all_nan;
+        if (m_exp) {
+            all_nan = true;
+            for (int d = 0; d < h + w - 1 && all_nan; ++d) { long long ad = (long long)(cs - rs) - (h - 1) + d; if (ad < 0) ad = -ad;
+                                                             const double e = es.at(ad); if (e == e) all_nan = false; }
+        } else {
+            int imin = -1, jmax = -1;
+            for (int i = 0; i < h && imin < 0; ++i) if (!bin_bad(a, rs + i)) imin = i;
+            for (int j = w - 1; j >= 0 && jmax < 0; --j) if (!bin_bad(a, cs + j)) jmax = j;
+            all_nan = imin < 0 || jmax < 0 || (igd >= 0 && (cs + jmax) - (rs + imin) < igd);
+            if (!all_nan && m_ooe) {
+                // some unmasked diagonal must carry a usable expected value
+                bool any = false;
+                const long long dlo = igd >= 0 ? (igd > (long long)(cs - rs) - (h - 1) ? igd : (long long)(cs - rs) - (h - 1))
+                                               : (long long)(cs - rs) - (h - 1);
+                const long long dhi = (long long)(cs - rs) + (w - 1);
+                for (long long d = dlo; d <= dhi && !any; ++d) { const double e = es.at(d < 0 ? -d : d); if (e == e) any = true; }
+                all_nan = !any;
+            }
+        }
+        const int mh = S < h ? (h + S - 1) / S : 1, mw = S < w ? (w + S - 1) / S : 1;
+        const int th = S * mh, tw = S * mw;
+        const double sy = th > 1 ? (double)(h - 1) / (double)(th - 1) : 0.0;
+        const double sx = tw > 1 ? (double)(w - 1) / (double)(tw - 1) : 0.0;
+        const double inv = 1.0 / ((double)mh * (double)mw);
+        for (int t = tid; t < S2; t += nthr) {
+            const int A = t / S, B = t - A * S;
+            double acc = 0.0; bool anynan = false;
+            if (!all_nan) {
+                for (int da = 0; da < mh; ++da) {
+                    const double ya = (double)(A * mh + da) * sy;
+                    const bool oob_y = ya > (double)(h - 1);
+                    const int i0 = oob_y ? h - 1 : (int)ya;
+                    const double ty = ya - (double)i0;
+                    const int i1 = i0 + 1 < h ? i0 + 1 : h - 1;
+                    double rowacc = 0.0;
+                    for (int db = 0; db < mw; ++db) {
+                        const double xb = (double)(B * mw + db) * sx;
+                        const bool oob = oob_y || xb > (double)(w - 1);
+                        if (oob) continue;                       // constant-mode sample outside the input: 0, not NaN
+                        const int j0 = (int)xb;
+                        const double tx = xb - (double)j0;
+                        const int j1 = j0 + 1 < w ? j0 + 1 : w - 1;
+                        double v00 = cell_sym(i0, j0), v01 = tx > 0.0 ? cell_sym(i0, j1) : 0.0;
+                        double v10 = ty > 0.0 ? cell_sym(i1, j0) : 0.0, v11 = (ty > 0.0 && tx > 0.0) ? cell_sym(i1, j1) : 0.0;
+                        // a NaN input taints the sample only when its interpolation weight is non-zero
+                        const bool n00 = v00 != v00, n01 = v01 != v01, n10 = v10 != v10, n11 = v11 != v11;
+                        if (n00 || n01 || n10 || n11) anynan = true;
+                        auto clean = [&](double v) { return v != v ? 0.0 : (v > DBLMAX ? DBLMAX : (v < -DBLMAX ? -DBLMAX : v)); };
+                        v00 = clean(v00); v01 = clean(v01); v10 = clean(v10); v11 = clean(v11);
+                        rowacc += (v00 * (1.0 - tx) + v01 * tx) * (1.0 - ty) + (v10 * (1.0 - tx) + v11 * tx) * ty;
+                    }
+                    acc += rowacc;
+                }
+                acc *= inv;
+            }
+            if (!anynan) {
+                const int cellidx = t;                          // window frame; flip / transpose applied at the flush
+                if (acc == acc) tsum[cellidx] += acc;
+                if (!(acc != acc) && !__builtin_isinf(acc)) tnum[cellidx] += 1u;
+            }
+        }
+        if (m_cov && !m_exp) {
+            // zoom_array of the coverage vectors (1-D): same sampling, same block mean; NaN coverage adds nothing
+            for (int t = tid; t < 2 * S; t += nthr) {
+                const bool start_side = t < S;
+                const int A = start_side ? t : t - S;
+                const bool rows = start_side != m_tr;             // cov_start follows the reference's rows
+                const int n_in = rows ? h : w, m = rows ? mh : mw, base = rows ? rs : cs;
+                const int n_t = S * m;
+                const double sc = n_t > 1 ? (double)(n_in - 1) / (double)(n_t - 1) : 0.0;
+                double accv = 0.0;
+                for (int d = 0; d < m; ++d) {
+                    const double y = (double)(A * m + d) * sc;
+                    if (y > (double)(n_in - 1)) continue;
+                    const int i0 = (int)y; const double tt = y - (double)i0; const int i1 = i0 + 1 < n_in ? i0 + 1 : n_in - 1;
+                    accv += a.cov[base + i0] * (1.0 - tt) + (tt > 0.0 ? a.cov[base + i1] * tt : 0.0);
+                }
+                accv /= (double)m;
+                if (accv == accv) tcov[t] += accv;
+            }
+        }
+    }
+    // ---- flush (owner threads write their own cells) ----
+    const size_t L = (size_t)S2 + 2 * (size_t)S;
+    double*   of = a.part_f64 + (size_t)ck * L;
+    unsigned* on = a.part_num + (size_t)ck * S2;
+    for (int t = tid; t < S2; t += nthr) {
+        const int A = t / S, B = t - A * S;
+        const int cellidx = map_cell(A, B, S, m_tr, fl);
+        of[cellidx] = tsum[t]; on[cellidx] = tnum[t];
+    }
+    for (int t = tid; t < 2 * S; t += nthr) of[S2 + t] = tcov[t];
+}
+
 // ---- per (table, weight column) precomputation ---------------------------------------------------------------
 // balanced value of every pixel (one wave per row) — the product PileUpper.get_data() obtains from
 // cooler's matrix(balance=w) once per region (coolpup.py:1053-1055), evaluated in the same order

@@ -82,7 +82,7 @@ def slice_call(call, rank, world_size):
     per_tile = cnt.reshape(T, 2)
     new_tp = np.concatenate([[0], np.cumsum(per_tile.sum(axis=1))]).astype(np.int64)
     out = dict(call)
-    for k in ("r0", "c0", "tile", "flip"):
+    for k in ("r0", "c0", "tile", "flip", "h", "w"):
         if call.get(k) is not None:
             out[k] = np.ascontiguousarray(call[k][idx])
     out["tile_ptr"] = new_tp

@@ -152,6 +152,18 @@ class PileupEngine:
         self._check(self._lib.pup_accumulate(self._h, _ptr(r0), _ptr(c0), r0.shape[0], _ptr(tile_ptr), _ptr(ff),
                                              int(ignore_diags), int(mode) & ~MODE_DEVPTR))
 
+    def accumulate_rescaled(self, r0, c0, height, width, tile_ptr, *, flip_from=None, ignore_diags=2, mode=0):
+        """Rescaled pile-up: variable height x width windows zoomed to the W x W tile (W = 2*pad+1 = rescale_size)."""
+        r0, c0 = _as(r0, np.int32), _as(c0, np.int32)
+        hh, ww = _as(height, np.int32), _as(width, np.int32)
+        tile_ptr = _as(tile_ptr, np.int64)
+        if tile_ptr.shape[0] != self.n_tiles + 1:
+            raise ValueError(f"tile_ptr needs {self.n_tiles + 1} entries")
+        ff = None if flip_from is None else _as(flip_from, np.int64)
+        self._check(self._lib.pup_accumulate_rescaled(self._h, _ptr(r0), _ptr(c0), _ptr(hh), _ptr(ww), r0.shape[0],
+                                                      _ptr(tile_ptr), _ptr(ff), int(ignore_diags),
+                                                      int(mode) & ~MODE_DEVPTR))
+
     def accumulate_device(self, r0_ptr, c0_ptr, n, tile_ptr, *, flip_from=None, ignore_diags=2, mode=0):
         """Same, with r0/c0 already resident in HBM (raw device addresses, e.g. tensor.data_ptr())."""
         tile_ptr = _as(tile_ptr, np.int64)

@@ -21,6 +21,7 @@
  *                                        (flip bit: flip_snip_func     coolpuppy/coolpup.py:128-147)
  *   pup_coverage                      <- cooltools.api.coverage.coverage(clr, ignore_diags=..., store=True), called by
  *                                        PileUpper.__init__ when cov_*_raw is missing     coolpuppy/coolpup.py:955-963
+ *   pup_accumulate_rescaled           <- the same loop with _rescale_snip               coolpuppy/coolpup.py:1159-1162, 1193-1234
  *   pup_stripes                       <- the store_stripes branch of _stream_snips   coolpuppy/coolpup.py:1164-1182
  *   pup_fetch / pup_export / pup_import
  *                                     <- sum_pups cross-region merge   coolpuppy/lib/puputils.py:88-113
@@ -66,6 +67,8 @@ typedef struct pup_ctx pup_ctx;
 #define PUP_MODE_TRANSPOSE  0x08u  /* (r0,c0) were swapped by the caller so that r0's region precedes
                                       c0's in the upper-triangular table; cells are stored transposed */
 #define PUP_MODE_DEVPTR     0x10u  /* r0 / c0 are DEVICE pointers (already resident in HBM) */
+#define PUP_MODE_LOCAL      0x20u  /* rescaled pile-ups only: symmetrise each (square, on-diagonal) window by nanmean
+                                      with its transpose before zooming (local=True, coolpup.py:1215-1220) */
 
 /* lifetime ---------------------------------------------------------------------------------------- */
 int  pup_create(int device_id, pup_ctx** out);
@@ -157,6 +160,17 @@ int pup_accumulate(pup_ctx* ctx, const int32_t* r0, const int32_t* c0, int64_t n
  */
 int pup_stripes(pup_ctx* ctx, const int32_t* r0, const int32_t* c0, int64_t n, int32_t pad, int32_t ignore_diags,
                 uint32_t mode, double* horizontal, double* vertical);
+
+/*
+ * Rescaled pile-up (rescale=True, PileUpper._rescale_snip, coolpup.py:1193-1234): snippet s is the height[s] x width[s]
+ * window at (r0[s], c0[s]); it is masked / normalised like any snippet, zoomed to W x W (W = 2*pad+1 of pup_reset =
+ * rescale_size) exactly like cooltools' zoom_array (bilinear blow-up to an integer multiple, block mean, NaN where
+ * a NaN input contributed; an all-NaN window adds zeros) and added to its tile.  Coverage vectors are zoomed too
+ * (PUP_MODE_COV).  Host arrays only.  Same grouping arguments as pup_accumulate.
+ */
+int pup_accumulate_rescaled(pup_ctx* ctx, const int32_t* r0, const int32_t* c0, const int32_t* height,
+                            const int32_t* width, int64_t n, const int64_t* tile_ptr, const int64_t* flip_from,
+                            int32_t ignore_diags, uint32_t mode);
 
 /* wait for all queued work; surfaces asynchronous errors (PUP_ERANGE, PUP_EHIP) */
 int pup_sync(pup_ctx* ctx);

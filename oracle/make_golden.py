@@ -184,6 +184,24 @@ def scenarios():
     add("G11d_stripes_local", "small", bed, features_format="bed", local=True, store_stripes=True, flank=100_000)
     add("G11e_stripes_trans", "small", trans_bedpe(clr, 80, 14), features_format="bedpe", trans=True,
         store_stripes=True, flank=100_000)
+    tads = pd.DataFrame({
+        "chrom": ["chrA"] * 7 + ["chrB"] * 4 + ["chrC"] * 2,
+        "start": [300_000, 1_000_000, 3_000_000, 6_050_000, 9_000_000, 15_000_000, 21_500_000,
+                  2_000_000, 5_000_000, 9_000_000, 13_000_000, 1_500_000, 4_000_000],
+        "end": [420_000, 1_400_000, 3_900_000, 6_300_000, 11_500_000, 15_250_000, 21_900_000,
+                2_600_000, 5_130_000, 9_990_000, 13_770_000, 2_700_000, 4_490_000]})
+    add("G12_rescale_local", "small", tads, features_format="bed", local=True, rescale=True, rescale_flank=1,
+        rescale_size=33)
+    add("G12b_rescale_local_expected", "small", tads, features_format="bed", local=True, rescale=True,
+        rescale_flank=0.5, rescale_size=21, expected=exp_chrom)
+    add("G12c_rescale_local_raw_covnorm_diag0", "small", tads, features_format="bed", local=True, rescale=True,
+        rescale_flank=1, rescale_size=33, clr_weight_name=None, coverage_norm=True, min_diag=0)
+    add("G12d_rescale_bedpe_controls", "small", bedpe.iloc[:150], features_format="bedpe", rescale=True,
+        rescale_flank=3, rescale_size=15, nshifts=2, seed=21, flank=100_000)
+    add("G12e_rescale_local_expected_not_ooe", "small", tads, features_format="bed", local=True, rescale=True,
+        rescale_flank=1, rescale_size=33, expected=exp_chrom, ooe=False)
+    add("G12f_rescale_bed_combinations", "small", tads, features_format="bed", rescale=True, rescale_flank=1,
+        rescale_size=25, mindist=0)
     # the reference's own stripe test (tests/test_coolpup.py:143-172): raw counts, ignore_diags=0, first coordinates row
     # known-answer tests of the reference's own test-suite (tests/test_coolpup.py), n depends on coordinates only
     toy_kw = dict(features_format="bed", flank=2_000_000, mindist=0)
@@ -292,7 +310,7 @@ def main():
             warnings.simplefilter("ignore")
             df = ref.pileup(clr, sc["features"].copy(), view_df=None if sc["view"] is None else sc["view"].copy(),
                             expected_df=None if sc["expected"] is None else sc["expected"].copy(), **kw)
-        W = 2 * (kw["flank"] // clr.binsize) + 1
+        W = kw["rescale_size"] if kw.get("rescale") else 2 * (kw["flank"] // clr.binsize) + 1
         rec = record(df, W)
         meta = {"name": sc["name"], "cooler": sc["cooler"], "kw": sc["kw"], "features": csv_text(sc["features"]),
                 "view": csv_text(sc["view"]), "expected": csv_text(sc["expected"])}

@@ -178,3 +178,92 @@ def stripes_c(indptr, col, cnt, weight, expv, r0, c0, pad, ignore_diags, mode):
         h[s] = data[pad, :]
         v[s] = data[:, pad][::-1]
     return h, v
+
+
+MODE_LOCAL = 0x20
+
+
+def zoom_array(in_array, final_shape):
+    """cooltools.lib.numutils.zoom_array restated (source not in the reference tree: parity with a real cooltools
+    install is unpinned): blow the array up with scipy.ndimage.zoom(order=1) to the nearest integer multiple of
+    final_shape (zoom factors + 1e-7), then block-average down to final_shape."""
+    from scipy.ndimage import zoom
+    in_array = np.asarray(in_array, dtype=np.double)
+    in_shape = in_array.shape
+    assert len(in_shape) == len(final_shape)
+    mults = [int(np.ceil(in_shape[i] / final_shape[i])) if final_shape[i] < in_shape[i] else 1
+             for i in range(len(in_shape))]
+    temp_shape = tuple(i * j for i, j in zip(final_shape, mults))
+    zoom_multipliers = np.array(temp_shape) / np.array(in_shape) + 0.0000001
+    assert zoom_multipliers.min() >= 1
+    rescaled = zoom(in_array, zoom_multipliers, order=1)
+    for ind, mult in enumerate(mults):
+        if mult != 1:
+            sh = list(rescaled.shape)
+            assert sh[ind] % mult == 0
+            rescaled.shape = sh[:ind] + [sh[ind] // mult, mult] + sh[ind + 1:]
+            rescaled = np.mean(rescaled, axis=ind + 1)
+    assert rescaled.shape == tuple(final_shape)
+    return rescaled
+
+
+def rescale_snip(data, S, local):
+    """PileUpper._rescale_snip on one window (reference coolpup.py:1212-1228)."""
+    import warnings
+    if data.size == 0 or np.all(np.isnan(data)):
+        return np.zeros((S, S))
+    if local:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", category=RuntimeWarning)
+            data = np.nanmean(np.dstack((data, data.T)), 2)
+    nans = np.isnan(data) * 1
+    data = np.nan_to_num(data)
+    data = zoom_array(data, (S, S))
+    nanzoom = zoom_array(nans, (S, S))
+    data[np.ceil(nanzoom).astype(bool)] = np.nan
+    with np.errstate(divide="ignore"):
+        data = data * (1 / np.isfinite(nanzoom))
+    return data
+
+
+def pileup_rescaled(bigdata, lo1, lo2, weight, cov, expv, r0, c0, h, w, flip, tile, n_tiles, S, ignore_diags, mode,
+                    acc=None):
+    """Rescaled pile-up (variable h x w windows zoomed to S x S): the reference's operation sequence,
+    _stream_snips + _rescale_snip + _add_snip, on a region CSR (rows from global bin lo1, columns from lo2)."""
+    if acc is None:
+        acc = empty_acc(n_tiles, (S - 1) // 2)
+    local = bool(mode & MODE_LOCAL)
+    for s in range(len(r0)):
+        rs, cs, hh, ww = int(r0[s]), int(c0[s]), int(h[s]), int(w[s])
+        t = tile[s]
+        have_exp = (mode & (MODE_OOE | MODE_EXPECTED)) and expv is not None
+        if have_exp:
+            ev = np.atleast_1d(expv)
+            if ev.shape[0] == 1:
+                exp_data = np.full((hh, ww), ev[0])
+            else:
+                d = np.abs((cs + np.arange(ww))[None, :] - (rs + np.arange(hh))[:, None])
+                exp_data = np.where(d < ev.shape[0], ev[np.minimum(d, ev.shape[0] - 1)], np.nan)
+        if mode & MODE_EXPECTED:
+            data = exp_data.astype(float)
+        else:
+            data = bigdata[rs - lo1:rs - lo1 + hh, cs - lo2:cs - lo2 + ww].toarray().astype(float)
+            if weight is not None:
+                data[np.isnan(weight[rs:rs + hh]), :] = np.nan
+                data[:, np.isnan(weight[cs:cs + ww])] = np.nan
+            if ignore_diags >= 0:
+                D = ((cs + np.arange(ww))[None, :] - (rs + np.arange(hh))[:, None]) < ignore_diags
+                data[D] = np.nan
+            if mode & MODE_OOE:
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    data = data / (exp_data if have_exp else np.nan)
+        data = rescale_snip(data, S, local)
+        if (mode & MODE_COV) and cov is not None and not (mode & MODE_EXPECTED):
+            acc["cov_start"][t] = np.nansum([acc["cov_start"][t], zoom_array(cov[rs:rs + hh], (S,))], axis=0)
+            acc["cov_end"][t] = np.nansum([acc["cov_end"][t], zoom_array(cov[cs:cs + ww], (S,))], axis=0)
+        if flip is not None and flip[s]:
+            data = np.rot90(np.flipud(data))
+        acc["sum"][t] = np.nansum([acc["sum"][t], data], axis=0)
+        acc["num"][t] += np.isfinite(data).astype(int)
+        acc["n"][t] += 1
+    return acc

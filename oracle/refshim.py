@@ -18,6 +18,9 @@ multiprocessing_logging) and the upstream behaviour each stand-in restates:
 * ``cooltools.lib.checks.is_valid_expected / is_compatible_viewframe``: accept (return True).
 * ``bioframe.make_viewframe``: chrom/start/end/name frame; name defaults to the chromosome.
   ``bioframe.sort_bedframe(df, view_df)``: view chromosome order, then start, end.
+  ``bioframe.expand(df, scale=s)``: grow every interval by 0.5*(s-1)*length per side, np.round to the int dtype.
+* ``cooltools.numutils.zoom_array``: scipy.ndimage.zoom(order=1) to an integer multiple of the target, then block mean
+  (oracle/pileup_oracle.py::zoom_array; scipy itself is the real package).
 * ``natsort.natsorted``, ``more_itertools.collapse(it, base_type=dict)``.
 
 Because these restate third-party behaviour from documentation/knowledge (their source is not on disk),
@@ -127,6 +130,19 @@ def sort_bedframe(df, view_df=None, reset_index=True, df_view_col=None, view_nam
     return out.reset_index(drop=True) if reset_index else out
 
 
+def bf_expand(df, pad=None, scale=None, side="both", cols=None):
+    """bioframe.expand restated for the scale= form coolpuppy uses: each interval grows by 0.5*(scale-1)*length on
+    both sides; the result is rounded (np.round, half to even) back to the original integer dtype."""
+    ck, sk, ek = ("chrom", "start", "end") if cols is None else cols
+    out = df.copy()
+    types = df.dtypes[[sk, ek]]
+    pads = 0.5 * (scale - 1) * (df[ek].values - df[sk].values)
+    out[sk] = df[sk].values - pads
+    out[ek] = df[ek].values + pads
+    out[[sk, ek]] = np.round(out[[sk, ek]]).astype(types)
+    return out
+
+
 def natsorted(seq):
     def key(s):
         return [int(t) if t.isdigit() else t.lower() for t in re.split(r"(\d+)", str(s))]
@@ -158,10 +174,10 @@ def install():
 
     mod("natsort", natsorted=natsorted)
     mod("more_itertools", collapse=collapse)
-    mod("bioframe", make_viewframe=make_viewframe, sort_bedframe=sort_bedframe)
+    mod("bioframe", make_viewframe=make_viewframe, sort_bedframe=sort_bedframe, expand=bf_expand)
     api = mod("cooler.api", Cooler=ShimCooler)
     mod("cooler", api=api, Cooler=ShimCooler)
-    numutils = mod("cooltools.numutils", LazyToeplitz=LazyToeplitz)
+    numutils = mod("cooltools.numutils", LazyToeplitz=LazyToeplitz, zoom_array=po.zoom_array)
     common = mod("cooltools.lib.common", make_cooler_view=make_cooler_view)
     checks = mod("cooltools.lib.checks", is_valid_expected=lambda *a, **k: True,
                  is_compatible_viewframe=lambda *a, **k: True)

@@ -114,8 +114,16 @@ def oracle_run_plan(pu, plan):
     cov = bins[plan["cov_name"]][:].values if plan["cov_name"] else None
     acc = po.empty_acc(plan["T"], plan["pad"])
     from coolpuppy_amd.coolpup import iter_expected_subcalls
+    big = None
     for call in plan["calls"]:
         for expected, c in iter_expected_subcalls(plan, call):
+            if plan.get("rescale"):
+                if big is None:
+                    nb = indptr.shape[0] - 1
+                    big = po.symmetric_csr(indptr, col, cnt, weight, 0, nb, 0, nb)
+                po.pileup_rescaled(big, 0, 0, weight, cov, expected, c["r0"], c["c0"], c["h"], c["w"], c["flip"],
+                                   c["tile"], plan["T"], 2 * plan["pad"] + 1, c["ignore_diags"], c["mode"], acc=acc)
+                continue
             po.pileup_c(indptr, col, cnt, weight, cov, expected, c["r0"], c["c0"], c["flip"], c["tile"],
                         plan["T"], plan["pad"], c["ignore_diags"], c["mode"], acc=acc)
     if plan.get("stripe_jobs"):
