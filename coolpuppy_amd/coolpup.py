@@ -14,8 +14,9 @@ for a GPU instead of a per-snippet Python loop:
 * the tail of ``pileupsWithControl`` (:1511-1654) — merge, coverage normalisation, ROI/control ratio,
   inf→NaN, symmetrisation, annotation — is restated with pandas on the fetched tiles.
 
-Not implemented (raise ``NotImplementedError``): rescaled pile-ups, stored stripes, by-window
-pile-ups and per-snippet Python callbacks (``postprocess_func`` / ``extra_sum_funcs``) — SURVEY.md §8(f).
+By-window pile-ups, stored stripes, coverage computation and rescaled pile-ups are served by the
+same engine (K3 / K4 / K5).  Not implemented (raise ``NotImplementedError``): per-snippet Python callbacks
+(``postprocess_func`` / ``extra_sum_funcs``) and ``store_stripes`` combined with by-window or rescaled pile-ups.
 """
 import itertools
 import logging

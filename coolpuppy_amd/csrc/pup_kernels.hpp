@@ -836,6 +836,7 @@ __device__ __forceinline__ double lookup_bal(const K1Args& a, const RsGeom& g, i
 __device__ __forceinline__ bool bin_bad(const K1Args& a, int bin) { return (a.badbits[bin >> 6] >> (bin & 63)) & 1ull; }
 
 __global__ __launch_bounds__(256) void pileup_rescale_kernel(K1Args a, const int* __restrict__ hs, const int* __restrict__ wsz) {
+#pragma clang fp contract(off)      // zoom coordinates must be plain IEEE products (see below)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int S = a.W, S2 = S * S;
     double*   tsum = reinterpret_cast<double*>(smem_raw);
@@ -916,22 +917,24 @@ __global__ __launch_bounds__(256) void pileup_rescale_kernel(K1Args a, const int
         }
         const int mh = S < h ? (h + S - 1) / S : 1, mw = S < w ? (w + S - 1) / S : 1;
         const int th = S * mh, tw = S * mw;
-        const double sy = th > 1 ? (double)(h - 1) / (double)(th - 1) : 0.0;
-        const double sx = tw > 1 ? (double)(w - 1) / (double)(tw - 1) : 0.0;
+        // scipy's coordinates are plain IEEE products o * ((n_in-1)/(n_out-1)): keep the compiler from fusing the
+        // product into the later subtraction (an FMA would make an exactly-integer coordinate look fractional)
+        const double sy = th > 1 ? __ddiv_rn((double)(h - 1), (double)(th - 1)) : 0.0;
+        const double sx = tw > 1 ? __ddiv_rn((double)(w - 1), (double)(tw - 1)) : 0.0;
         const double inv = 1.0 / ((double)mh * (double)mw);
         for (int t = tid; t < S2; t += nthr) {
             const int A = t / S, B = t - A * S;
             double acc = 0.0; bool anynan = false;
             if (!all_nan) {
                 for (int da = 0; da < mh; ++da) {
-                    const double ya = (double)(A * mh + da) * sy;
+                    const double ya = __dmul_rn((double)(A * mh + da), sy);
                     const bool oob_y = ya > (double)(h - 1);
                     const int i0 = oob_y ? h - 1 : (int)ya;
                     const double ty = ya - (double)i0;
                     const int i1 = i0 + 1 < h ? i0 + 1 : h - 1;
                     double rowacc = 0.0;
                     for (int db = 0; db < mw; ++db) {
-                        const double xb = (double)(B * mw + db) * sx;
+                        const double xb = __dmul_rn((double)(B * mw + db), sx);
                         const bool oob = oob_y || xb > (double)(w - 1);
                         if (oob) continue;                       // constant-mode sample outside the input: 0, not NaN
                         const int j0 = (int)xb;
@@ -964,10 +967,10 @@ __global__ __launch_bounds__(256) void pileup_rescale_kernel(K1Args a, const int
                 const bool rows = start_side != m_tr;             // cov_start follows the reference's rows
                 const int n_in = rows ? h : w, m = rows ? mh : mw, base = rows ? rs : cs;
                 const int n_t = S * m;
-                const double sc = n_t > 1 ? (double)(n_in - 1) / (double)(n_t - 1) : 0.0;
+                const double sc = n_t > 1 ? __ddiv_rn((double)(n_in - 1), (double)(n_t - 1)) : 0.0;
                 double accv = 0.0;
                 for (int d = 0; d < m; ++d) {
-                    const double y = (double)(A * m + d) * sc;
+                    const double y = __dmul_rn((double)(A * m + d), sc);
                     if (y > (double)(n_in - 1)) continue;
                     const int i0 = (int)y; const double tt = y - (double)i0; const int i1 = i0 + 1 < n_in ? i0 + 1 : n_in - 1;
                     accv += a.cov[base + i0] * (1.0 - tt) + (tt > 0.0 ? a.cov[base + i1] * tt : 0.0);
