@@ -225,12 +225,20 @@ class CoordCreator:
         else:
             assert have.issuperset(bedpe_cols), \
                 "Column names must include chrom1, start1, end1, chrom2, start2, and end2"
-            iv[["chrom1", "chrom2"]] = iv[["chrom1", "chrom2"]].astype(str)
-            iv["center1"] = (iv["start1"] + iv["end1"]) / 2
-            iv["center2"] = (iv["start2"] + iv["end2"]) / 2
-            iv["distance"] = iv["center2"] - iv["center1"]
-            absd = iv["distance"].abs()
-            iv = iv[(self.mindist <= absd) & (absd <= self.maxdist)].reset_index(drop=True)
+            # same columns / filter as the reference (:296-321), but the distance filter runs BEFORE the new
+            # columns are attached: filtering a freshly widened frame makes pandas re-consolidate every block
+            c1 = (iv["start1"].values + iv["end1"].values) / 2
+            c2 = (iv["start2"].values + iv["end2"].values) / 2
+            absd = np.abs(c2 - c1)
+            keep = (self.mindist <= absd) & (absd <= self.maxdist)
+            if not keep.all():
+                iv = iv[keep].reset_index(drop=True)
+                c1, c2 = c1[keep], c2[keep]
+            iv["chrom1"] = iv["chrom1"].astype(str)
+            iv["chrom2"] = iv["chrom2"].astype(str)
+            iv["center1"] = c1
+            iv["center2"] = c2
+            iv["distance"] = c2 - c1
             iv = expand2D(iv, self.flank, self.resolution, self.rescale_flank)
         self.intervals = iv
 
@@ -268,7 +276,7 @@ class CoordCreator:
         self.intervals = self._binnify(self.intervals)
 
         keys = ["stBin", "endBin"] if self.kind == "bed" else ["stBin1", "endBin1", "stBin2", "endBin2"]
-        dups = self.intervals.duplicated(subset=keys)
+        dups = self.intervals.duplicated(subset=keys) if logger.isEnabledFor(logging.DEBUG) else np.zeros(0, bool)
         if dups.any():
             logger.debug(f"{dups.mean() * 100:.2f}% of intervals fall within the same bin as another interval. "
                          "These are all included in the pileup.")
@@ -819,15 +827,17 @@ class PileUpper:
         lo1, hi1, off1 = self._global_extents[region1]
         lo2, hi2, off2 = self._global_extents[region2]
         W = 2 * self.pad_bins + 1
-        hh = (tbl["endBin1"] - tbl["stBin1"]).astype(np.int64)
-        ww = (tbl["endBin2"] - tbl["stBin2"]).astype(np.int64)
+        # global bin ids fit 32 bits (the engine's own limit); narrow here so every later pass moves half the bytes
+        hh = (tbl["endBin1"] - tbl["stBin1"]).astype(np.int32)
+        ww = (tbl["endBin2"] - tbl["stBin2"]).astype(np.int32)
         if not getattr(self, "rescale", False) and not (np.all(hh == W) and np.all(ww == W)):
             raise ValueError("window size differs from 2*pad_bins+1")
-        r0 = tbl["stBin1"].astype(np.int64) + off1
-        c0 = tbl["stBin2"].astype(np.int64) + off2
+        r0 = (tbl["stBin1"] + off1).astype(np.int32)
+        c0 = (tbl["stBin2"] + off2).astype(np.int32)
         ok = (r0 >= lo1) & (r0 + hh <= hi1) & (c0 >= lo2) & (c0 + ww <= hi2)   # reference :1111-1114
-        tbl = tbl.take(ok)
-        r0, c0, hh, ww = r0[ok], c0[ok], hh[ok], ww[ok]
+        if not ok.all():
+            tbl = tbl.take(ok)
+            r0, c0, hh, ww = r0[ok], c0[ok], hh[ok], ww[ok]
         n = len(r0)
         flip = tbl["flip"].astype(bool) if "flip" in tbl else np.zeros(n, bool)
         coords = None
@@ -994,9 +1004,9 @@ class PileUpper:
             if b is None or b["n"] == 0:
                 continue
             if grouped:
-                g = np.array([gid[k] for k in b["group_keys"]], np.int64)[b["group_codes"]]
+                g = np.array([gid[k] for k in b["group_keys"]], np.int32)[b["group_codes"]]
             else:
-                g = np.zeros(b["n"], np.int64)
+                g = np.zeros(b["n"], np.int32)
             expected = None
             if self.expected:
                 if exp_table is not None:
@@ -1012,8 +1022,8 @@ class PileUpper:
             tr = MODE_TRANSPOSE if transpose else 0
             loc = MODE_LOCAL if (rescale and self.local) else 0
             mode = (MODE_OOE if (self.expected and self.ooe) else 0) | (MODE_COV if self.coverage_norm else 0) | tr | loc
-            raw.append((region1, region2, expected, r0, c0, b["flip"], b["kind"].astype(np.int64) * G + g, igd, mode,
-                        hh, ww))
+            raw.append((region1, region2, expected, r0, c0, b["flip"], b["kind"].astype(np.int32) * np.int32(G) + g,
+                        igd, mode, hh, ww))
             if exp_as_control:
                 roi = b["kind"] == KIND_ROI
                 raw.append((region1, region2, expected, r0[roi], c0[roi], b["flip"][roi], G + g[roi], igd,
@@ -1051,11 +1061,8 @@ class PileUpper:
                 merged[-1][1].append(fields)
             else:
                 merged.append([item, [fields]])
-        calls = []
-        for head, parts in merged:
-            f = [np.concatenate([p[k] for p in parts]) if len(parts) > 1 else parts[0][k] for k in range(6)]
-            calls.append(_engine_call(head[0], head[1], head[2], f[0], f[1], f[2], f[3], T, head[7], head[8],
-                                      extra={"h": f[4], "w": f[5]} if rescale else None))
+        calls = [_engine_call_parts(head[0], head[1], head[2], parts, T, head[7], head[8], rescale)
+                 for head, parts in merged]
         return {"T": T, "G": G, "gid": gid, "order": order, "contrib": contrib, "want_control": want_control,
                 "groupby": list(groupby), "grouped": bool(grouped), "calls": calls,
                 "pad": (self.rescale_size - 1) // 2 if rescale else self.pad_bins, "rescale": rescale,
@@ -1269,6 +1276,56 @@ def _engine_call(region1, region2, expected, r0, c0, flip, tile, T, igd, mode, e
     return call
 
 
+def _engine_call_parts(region1, region2, expected, parts, T, igd, mode, rescale):
+    """_engine_call over the concatenation of per-region parts (r0, c0, flip, tile, h, w) WITHOUT concatenating
+    first: each part is grouped by (tile, flip) on its own (cache-sized stable radix sorts), then the segments
+    are copied straight to their final place — region order inside a segment is the stable order of the whole."""
+    nk = 2 * T
+    if len(parts) == 1 or nk >= 65536 or nk * len(parts) > 200_000:
+        f = [np.concatenate([p[k] for p in parts]) if len(parts) > 1 else parts[0][k] for k in range(6)]
+        return _engine_call(region1, region2, expected, f[0], f[1], f[2], f[3], T, igd, mode,
+                            extra={"h": f[4], "w": f[5]} if rescale else None)
+    nf = 6 if rescale else 2
+    counts = np.zeros((len(parts), nk), np.int64)
+    grouped = []
+    any_flip = False
+    for i, p in enumerate(parts):
+        key = np.asarray(p[3]).astype(np.uint16) * np.uint16(2)
+        if p[2] is not None and np.any(p[2]):
+            any_flip = True
+            key = key + np.asarray(p[2], bool)
+        counts[i] = np.bincount(key, minlength=nk)
+        cols = [np.asarray(p[0]).astype(np.int32, copy=False), np.asarray(p[1]).astype(np.int32, copy=False)]
+        if rescale:
+            cols += [np.asarray(p[4]).astype(np.int32, copy=False), np.asarray(p[5]).astype(np.int32, copy=False)]
+        if len(key) > 1 and not np.all(key[1:] >= key[:-1]):
+            o = np.argsort(key, kind="stable")                     # 16-bit keys: radix sort
+            cols = [c[o] for c in cols]
+        grouped.append(cols)
+    total = counts.sum(axis=0)
+    n = int(total.sum())
+    key_start = np.concatenate([[0], np.cumsum(total)])[:-1]
+    dst = key_start[None, :] + np.cumsum(counts, axis=0) - counts      # where part i's segment of key k goes
+    out = [np.empty(n, np.int32) for _ in range(len(grouped[0]))]
+    for i, cols in enumerate(grouped):
+        src = np.concatenate([[0], np.cumsum(counts[i])])
+        for k in np.flatnonzero(counts[i]):
+            a, b, d = int(src[k]), int(src[k + 1]), int(dst[i, k])
+            for o_, c_ in zip(out, cols):
+                o_[d:d + (b - a)] = c_[a:b]
+    per_tile = total.reshape(T, 2)
+    tile_ptr = np.concatenate([[0], np.cumsum(per_tile.sum(axis=1))]).astype(np.int64)
+    flip_from = (tile_ptr[:-1] + per_tile[:, 0]).astype(np.int64) if any_flip else None
+    call = {"region1": region1, "region2": region2, "expected": expected, "r0": out[0], "c0": out[1],
+            "flip": np.repeat(np.tile(np.array([0, 1], np.uint8), T), total) if any_flip else None,
+            "flip_from": flip_from, "tile": np.repeat(np.arange(T, dtype=np.int32), per_tile.sum(axis=1)),
+            "tile_ptr": tile_ptr, "ignore_diags": igd, "mode": mode}
+    if rescale:
+        call["h"], call["w"] = out[2], out[3]
+    del nf
+    return call
+
+
 def _collect_stripes(plan, acc):
     """Per group key: (coordinates [n,6] str, horizontal [n,W], vertical [n,W]) in the reference's accumulation
     order — regions in order, snippets in stream order; the "all" row of a grouped pile-up concatenates, region by
@@ -1346,7 +1403,36 @@ def _factorize_rows(cols, decoders=None):
     """Row-wise factorisation of several columns: (codes int64, keys = list of tuples in first-appearance
     order).  decoders[j], when given, maps the stored value of column j to the value shown in the key."""
     decoders = decoders or [None] * len(cols)
-    per = [pd.factorize(c, sort=False) for c in cols]
+    per = []
+    for c in cols:
+        c = np.asarray(c)
+        if c.dtype.kind in "iu" and len(c) and 0 <= int(c.min()) and int(c.max()) < 4096:
+            per.append((c, np.arange(int(c.max()) + 1)))      # already small codes: no hashing needed
+        else:
+            per.append(pd.factorize(c, sort=False))
+    small = 1
+    for _, uniq in per:
+        small *= len(uniq) + 1
+    if small <= (1 << 22) and len(cols[0]):
+        # dense mixed-radix code -> first-appearance numbering with two O(n) passes and one small table
+        combined = np.zeros(len(cols[0]), np.int32)
+        for codes, uniq in per:
+            combined = combined * np.int32(len(uniq) + 1) + codes.astype(np.int32, copy=False)
+        n = len(combined)
+        first = np.full(small, -1, np.int64)
+        first[combined[::-1]] = np.arange(n - 1, -1, -1)         # reversed writes: the first occurrence wins
+        seen = np.flatnonzero(first >= 0)
+        seen = seen[np.argsort(first[seen], kind="stable")]
+        lut = np.zeros(small, np.int64)
+        lut[seen] = np.arange(len(seen))
+        keys = []
+        for r in first[seen]:
+            vals = []
+            for j, (cj, uj) in enumerate(per):
+                v = uj[cj[r]]
+                vals.append(decoders[j](v) if decoders[j] is not None else v)
+            keys.append(tuple(vals))
+        return lut[combined], keys
     radix = 1
     for _, uniq in per:
         radix *= len(uniq) + 1
