@@ -65,6 +65,8 @@ _SIGNATURES = {
                                           C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32]),
     "pup_stripes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_uint32,
                               C.c_void_p, C.c_void_p]),
+    "pup_extract": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                              C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pup_sync": (C.c_int, [C.c_void_p]),
     "pup_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pup_packed_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -29,7 +29,7 @@ import numpy as np
 import pandas as pd
 
 from .cooler_lite import as_array_cooler
-from .lib.puputils import finalize_pileups
+from .lib.puputils import _add_snip, _collapse, finalize_callback_pileups, finalize_pileups, sum_pups
 
 logger = logging.getLogger("coolpuppy")
 
@@ -117,6 +117,24 @@ def flip_mark_intervals_func(intervals, flipby, flip_negative_strand, extra_func
     if extra_func is not None:
         intervals = extra_func(intervals)
     return intervals
+
+
+def flip_snip_func(snip, groupby, ignore_group_order, extra_func=None):
+    """Per-snippet half of the flip (reference :128-147): anti-transpose the window of a marked snippet; with
+    ignore_group_order also swap every paired annotation X1 <-> X2 and rebuild its group.  Only the callback path
+    calls it — the engine applies the flip while accumulating."""
+    if snip["flip"]:
+        snip["data"] = np.rot90(np.flipud(snip["data"]))
+        if ignore_group_order:
+            names = list(snip)
+            stems = sorted({k[:-1] for k in names if f"{k[:-1]}1" in snip and f"{k[:-1]}2" in snip})
+            for stem in stems:
+                snip[f"{stem}1"], snip[f"{stem}2"] = snip[f"{stem}2"], snip[f"{stem}1"]
+            if groupby:
+                snip["group"] = np.array([snip[col] for col in groupby], dtype=object)
+    if extra_func is not None:
+        snip = extra_func(snip)
+    return snip
 
 
 class _Cols(dict):
@@ -784,7 +802,7 @@ class PileUpper:
         return g, None
 
     def region_snippets(self, region1, region2=None, groupby=[], modify_2Dintervals_func=None, columns=(),
-                        by_window=False):
+                        by_window=False, keep_table=False):
         """Host half of ``pileup_region`` (reference :1285-1358 down to the skip test :1105-1114).
 
         Returns None when the region has no feature, else a dict with the accepted windows:
@@ -796,7 +814,9 @@ class PileUpper:
         reg1 = tuple(self.view_df.loc[region1, ["chrom", "start", "end"]])
         reg2 = tuple(self.view_df.loc[region2, ["chrom", "start", "end"]])
         carry = columns
-        builtin = modify_2Dintervals_func is None or _is_builtin_modify(modify_2Dintervals_func)
+        # keep_table (callback path): rows must carry the reference's own column values (e.g. band tuples), so
+        # even the built-in modify functions run in their DataFrame form
+        builtin = (modify_2Dintervals_func is None or _is_builtin_modify(modify_2Dintervals_func)) and not keep_table
         src = {}                       # groupby column -> (carried column, decoder)
         if carry is not None and builtin:
             carry = list(carry)
@@ -820,7 +840,7 @@ class PileUpper:
             return None
         decoders = {}
         if modify_2Dintervals_func is not None:
-            if _is_builtin_modify(modify_2Dintervals_func):
+            if builtin:
                 tbl, decoders = _apply_builtin_modify(tbl, modify_2Dintervals_func)
             else:
                 tbl = _Cols.from_frame(modify_2Dintervals_func(tbl.frame()))
@@ -875,17 +895,20 @@ class PileUpper:
                     "group_codes": codes, "group_keys": keys, "n": 2 * n, "h": hh[dup], "w": ww[dup], "coords": None}
         else:
             codes, keys = np.full(n, -1, np.int64), []
-        return {"r0": r0, "c0": c0, "kind": tbl["kind"].astype(np.int8), "flip": flip, "group_codes": codes,
-                "group_keys": keys, "n": n, "coords": coords, "h": hh, "w": ww}
+        out = {"r0": r0, "c0": c0, "kind": tbl["kind"].astype(np.int8), "flip": flip, "group_codes": codes,
+               "group_keys": keys, "n": n, "coords": coords, "h": hh, "w": ww}
+        if keep_table:
+            out["table"] = tbl                 # the accepted rows with every carried column (callback path)
+        return out
 
     # -- the pile-up -------------------------------------------------------------------------------------------
     def pileupsWithControl(self, nproc=None, groupby=[], ignore_group_order=False, modify_2Dintervals_func=None,
                            postprocess_func=None, extra_sum_funcs=None, _columns=(), _by_window=False):
         """All regions -> normalised pile-ups DataFrame (reference :1360-1654)."""
         self.ignore_group_order = ignore_group_order
-        if postprocess_func is not None or extra_sum_funcs:
-            raise NotImplementedError(
-                "per-snippet Python callbacks (postprocess_func / extra_sum_funcs) cannot run on the GPU engine")
+        callbacks = postprocess_func is not None or bool(extra_sum_funcs)
+        if callbacks and _by_window:
+            raise NotImplementedError("by-window pile-ups already group per feature on the GPU; no callbacks there")
         if nproc is None:
             nproc = self.nproc
         if len(self.chroms) == 0:
@@ -933,6 +956,16 @@ class PileUpper:
                              flip_negative_strand=self.flip_negative_strand, extra_func=modify_2Dintervals_func)
             if columns is not None:
                 columns += ["strand1"] if self.flip_negative_strand else [f"{flipby}1", f"{flipby}2"]
+            if callbacks:
+                postprocess_func = partial(flip_snip_func, groupby=groupby, ignore_group_order=self.ignore_group_order,
+                                           extra_func=postprocess_func)
+        if callbacks:
+            # per-snippet Python callbacks: the GPU produces the windows, the host runs the callbacks and the
+            # reference's per-snippet accumulation on them (coolpup.py:1236-1283)
+            pileups = [self._callback_region(r1, r2, groupby, modify, postprocess_func, extra_sum_funcs)
+                       for r1, r2 in self._region_pairs()]
+            want_control = bool(self.control) or (bool(self.expected) and not self.ooe)
+            return finalize_callback_pileups(self, pileups, groupby, want_control, extra_sum_funcs)
         batches = []
         for region1, region2 in self._region_pairs():
             b = self.region_snippets(region1, region2, groupby=groupby, modify_2Dintervals_func=modify,
@@ -1137,17 +1170,127 @@ class PileUpper:
                       extra_sum_funcs=None):
         """One region (pair) -> {"ROI": {group: pup}, "control": {group: pup}} with summed, un-normalised
         tiles (reference :1285-1358): pup = data (sum), num, n, cov_start, cov_end."""
-        if postprocess_func is not None or extra_sum_funcs:
-            raise NotImplementedError("per-snippet Python callbacks cannot run on the GPU engine")
         if region2 is None:
             region2 = region1
         if not hasattr(self, "ignore_group_order"):
             self.ignore_group_order = False
+        if postprocess_func is not None or extra_sum_funcs:
+            return self._callback_region(region1, region2, groupby, modify_2Dintervals_func, postprocess_func,
+                                         extra_sum_funcs)
         b = self.region_snippets(region1, region2, groupby=groupby, modify_2Dintervals_func=modify_2Dintervals_func,
                                  columns=None)
         plan = self.make_plan([(region1, region2, b)], groupby)
         acc = self.run_plan(plan)
         return _tiles_to_pups(plan, acc)
+
+    # -- per-snippet Python callbacks -------------------------------------------------------------------------------
+    _CALLBACK_BATCH = 16384            # windows fetched from the GPU per pup_extract call
+
+    def _windows(self, b, region1, region2, sel, mode_extra=0):
+        """Windows of the snippets b[sel] of one region pair, from the GPU (pup_extract): (data, cov_start, cov_end).
+        ``self._window_source`` (tests: an oracle stand-in with the same signature) replaces the engine."""
+        from .engine import MODE_COV, MODE_OOE, MODE_TRANSPOSE
+        transpose = self._global_extents[region1][0] > self._global_extents[region2][0]
+        r0, c0 = (b["c0"][sel], b["r0"][sel]) if transpose else (b["r0"][sel], b["c0"][sel])
+        hh, ww = (b["w"][sel], b["h"][sel]) if transpose else (b["h"][sel], b["w"][sel])
+        rescale = bool(self.rescale)
+        mode = mode_extra | (MODE_TRANSPOSE if transpose else 0) | (0x20 if (rescale and self.local) else 0)
+        if not (mode_extra & 0x02):
+            mode |= (MODE_OOE if (self.expected and self.ooe) else 0) | (MODE_COV if self.coverage_norm else 0)
+        expected = None
+        if self.expected:
+            expected = np.array([self.get_expected_trans(region1, region2)], np.float64) if self.trans \
+                else self._expected_vectors[region1]
+        igd = -1 if self.trans else int(self.ignore_diags)
+        pad = (self.rescale_size - 1) // 2 if rescale else self.pad_bins
+        kw = dict(height=hh if rescale else None, width=ww if rescale else None, ignore_diags=igd, mode=mode,
+                  coverage=bool(mode & MODE_COV))
+        src = getattr(self, "_window_source", None)
+        if src is not None:
+            return src(self, expected, r0, c0, pad, **kw)
+        from . import dist as _dist
+        eng = _engine_for(self._aclr, _dist.local_device())
+        bins = self.clr.bins()
+        eng.load_bins(bins[self.clr_weight_name][:].values if self.clr_weight_name else None,
+                      bins[self.coverage_norm][:].values if self.coverage_norm else None)
+        if expected is not None:
+            eng.set_expected(expected)
+        got = eng.extract(r0, c0, pad, **kw)
+        return got if kw["coverage"] else (got, None, None)
+
+    def _callback_region(self, region1, region2, groupby, modify_2Dintervals_func, postprocess_func, extra_sum_funcs):
+        """pileup_region with per-snippet Python callbacks (reference :1285-1358 with :1236-1283): the snippet
+        stream is rebuilt row by row — annotations as the reference's dict rows, windows from the GPU in batches —
+        and fed through postprocess_func and _add_snip in the reference's order."""
+        from functools import reduce
+        from .engine import MODE_EXPECTED
+        if region2 is None:
+            region2 = region1
+        exp_as_control = bool(self.expected) and not self.ooe
+        if exp_as_control and self.rescale and self.coverage_norm:
+            raise NotImplementedError("callbacks with rescale + coverage_norm + non-ooe expected")
+        outdict = {"ROI": {}, "control": {}}
+        b = self.region_snippets(region1, region2, groupby=groupby, modify_2Dintervals_func=modify_2Dintervals_func,
+                                 columns=None, keep_table=True)
+        if b is not None and b["n"] > 0:
+            tbl = b["table"]
+            frame = pd.DataFrame({k: v for k, v in tbl.items() if not k.startswith("_gc_")})
+            frame["kind"] = np.where(b["kind"] == KIND_ROI, "ROI", "control")
+            # bins become region-relative before the snippet is handed on (reference :1104-1110)
+            ml1, ml2 = self.view_df_extents[region1][0], self.view_df_extents[region2][0]
+            for c, ml in (("stBin1", ml1), ("endBin1", ml1), ("stBin2", ml2), ("endBin2", ml2)):
+                frame[c] = frame[c] - ml
+            frame = assign_groups(frame, groupby)
+            frame = frame.reindex(columns=list(frame.columns) + ["data", "cov_start", "cov_end", "horizontal_stripe",
+                                                                 "vertical_stripe"])
+            rows = frame.to_dict(orient="records")
+            n = b["n"]
+            for lo in range(0, n, self._CALLBACK_BATCH):
+                sel = np.arange(lo, min(n, lo + self._CALLBACK_BATCH))
+                data, cov_s, cov_e = self._windows(b, region1, region2, sel)
+                exp_data = None
+                if exp_as_control:
+                    exp_data = self._windows(b, region1, region2, sel, mode_extra=MODE_EXPECTED)[0]
+                stream = self._snip_stream(rows, sel, data, cov_s, cov_e, exp_data)
+                if postprocess_func is not None:
+                    stream = map(postprocess_func, stream)
+                for snip in _collapse(stream):
+                    key = snip["group"]
+                    _add_snip(outdict[snip["kind"]], key if isinstance(key, str) else tuple(key), snip,
+                              extra_funcs=extra_sum_funcs)
+        sum_func = partial(sum_pups, extra_funcs=extra_sum_funcs)
+        if "all" not in outdict["ROI"]:
+            outdict["ROI"]["all"] = reduce(sum_func, outdict["ROI"].values(), self.empty_pup)
+        if self.control or exp_as_control:
+            if "all" not in outdict["control"]:
+                outdict["control"]["all"] = reduce(sum_func, outdict["control"].values(), self.empty_pup)
+        return outdict
+
+    def _snip_stream(self, rows, sel, data, cov_s, cov_e, exp_data):
+        """The reference's _stream_snips from the window onwards (:1116-1191): fill the row dict and yield it
+        (followed by its expected twin when the expected serves as control)."""
+        exp_as_control = exp_data is not None
+        for j, i in enumerate(sel):
+            snip = rows[i]
+            if exp_as_control and snip["kind"] == "ROI":
+                exp_snip = snip.copy()
+                exp_snip["kind"] = "control"
+                exp_snip["data"] = exp_data[j]
+                exp_snip["coordinates"] = []
+            if cov_s is not None:
+                snip["cov_start"], snip["cov_end"] = cov_s[j], cov_e[j]
+            snip["data"] = data[j]
+            if self.store_stripes:
+                cntr = int(np.floor(snip["data"].shape[0] / 2))
+                snip["horizontal_stripe"] = np.array(snip["data"][cntr, :], dtype=float)
+                snip["vertical_stripe"] = np.array(snip["data"][:, cntr][::-1], dtype=float)
+                snip["coordinates"] = ".".join(str(snip[c]) for c in ("chrom1", "start1", "end1", "chrom2", "start2",
+                                                                      "end2"))
+            else:
+                snip["horizontal_stripe"], snip["vertical_stripe"], snip["coordinates"] = [], [], []
+            yield snip
+            if exp_as_control and snip["kind"] == "ROI":
+                yield exp_snip
 
     # -- by-X wrappers (reference :1656-1919) ---------------------------------------------------------------------
     def pileupsByStrandWithControl(self, nproc=None, groupby=[], ignore_group_order=False):

@@ -712,7 +712,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         const size_t rs_lds = (size_t)W * W * 12 + 16 * (size_t)W;
         hipFuncSetAttribute(reinterpret_cast<const void*>(pup::pileup_rescale_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_lds);
         hipLaunchKernelGGL(pup::pileup_rescale_kernel, dim3((unsigned)nblocks), dim3(256), rs_lds, c->stream, a,
-                           (const int*)c->d_h.p, (const int*)c->d_w.p);
+                           (const int*)c->d_h.p, (const int*)c->d_w.p, (double*)nullptr, (double*)nullptr, 0LL);
         launched = true;
     }
     if (!launched && !lds_kernel2 && W <= 31) launched = launch_regtile(W, a, (int)nblocks, c->stream);
@@ -800,6 +800,83 @@ int pup_stripes(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, int
     if (e == hipSuccess) e = hipMemcpy(vertical, d_out.p + (size_t)n * W, (size_t)n * W * sizeof(double), hipMemcpyDeviceToHost);
     d_out.release();
     if (e != hipSuccess) return fail(c, PUP_EHIP, "pup_stripes: %s", hipGetErrorString(e));
+    return check_async_error(c);
+}
+
+int pup_extract(pup_ctx* c, const int32_t* r0, const int32_t* c0, const int32_t* height, const int32_t* width,
+                int64_t n, int32_t pad, int32_t ignore_diags, uint32_t mode, double* data, double* cov_start,
+                double* cov_end) {
+    if (!c) return PUP_EINVAL;
+    const bool rescale = height != nullptr || width != nullptr;
+    if (!c->have_px) return fail(c, PUP_ESTATE, "pup_extract: no pixel table loaded");
+    if (!c->have_bal) return fail(c, PUP_ESTATE, "pup_extract: call pup_load_bins first (weights or NULL for raw)");
+    if (n < 0 || pad < 0 || (n > 0 && (!r0 || !c0 || !data)) || (rescale && (!height || !width)))
+        return fail(c, PUP_EINVAL, "pup_extract: NULL arrays or negative sizes");
+    if ((cov_start == nullptr) != (cov_end == nullptr))
+        return fail(c, PUP_EINVAL, "pup_extract: cov_start and cov_end must be given together");
+    const bool m_ooe = mode & PUP_MODE_OOE, m_exp = mode & PUP_MODE_EXPECTED;
+    if ((m_ooe || m_exp) && c->nexp == 0 && c->n_exp_regions == 0)
+        return fail(c, PUP_ESTATE, "pup_extract: OOE/EXPECTED mode without expected");
+    if (m_ooe && m_exp) return fail(c, PUP_EINVAL, "pup_extract: OOE and EXPECTED are exclusive");
+    if (mode & PUP_MODE_DEVPTR) return fail(c, PUP_EINVAL, "pup_extract: DEVPTR is not supported");
+    if ((mode & PUP_MODE_COV) && (!c->have_cov || !cov_start))
+        return fail(c, PUP_ESTATE, "pup_extract: COV mode needs a coverage vector and cov_start / cov_end outputs");
+    if (n == 0) return PUP_OK;
+    int rc = bind(c); if (rc) return rc;
+    const int W = 2 * pad + 1;
+    const size_t W2 = (size_t)W * W;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, c->d_r0.reserve((size_t)n)); HIPCHK(c, c->d_c0.reserve((size_t)n));
+    HIPCHK(c, hipMemcpy(c->d_r0.p, r0, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_c0.p, c0, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    if (rescale) {
+        HIPCHK(c, c->d_h.reserve((size_t)n)); HIPCHK(c, c->d_w.reserve((size_t)n));
+        HIPCHK(c, hipMemcpy(c->d_h.p, height, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_w.p, width, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    }
+    DevBuf<double> d_out, d_cov;
+    hipError_t e = d_out.reserve((size_t)n * W2);
+    if (e == hipSuccess && cov_start) e = d_cov.reserve((size_t)n * 2 * W);
+    if (e == hipSuccess) {
+        pup::K1Args a{};
+        a.indptr = c->indptr.p; a.px = c->px.p; a.cnt32 = c->cnt32.p;
+        a.bal = c->bal.p; a.badbits = c->badbits.p;
+        const bool use_idx = c->have_idx && !(c->variant & 1);
+        a.idx = use_idx ? c->idx.p : nullptr; a.idx_chrom = use_idx ? c->idx_chrom.p : nullptr;
+        a.n_chrom = use_idx ? c->n_chrom : 0;
+        a.weight = c->have_weight ? c->weight.p : nullptr;
+        a.cov = c->have_cov ? c->cov.p : nullptr;
+        a.expv = (c->nexp > 0 || (c->n_exp_regions > 0 && !c->have_exp_pair)) ? c->expv.p : nullptr;
+        a.nexp = c->nexp; a.nbins = c->nbins;
+        a.exp_regions = c->n_exp_regions > 0 ? c->exp_regions.p : nullptr; a.n_exp_regions = c->n_exp_regions;
+        a.exp_pair = c->have_exp_pair ? c->exp_pair.p : nullptr;
+        a.r0 = c->d_r0.p; a.c0 = c->d_c0.p; a.err = c->d_err.p; a.counters = c->counters.p;
+        a.W = W; a.ignore_diags = ignore_diags; a.mode = mode;
+        const unsigned grid = (unsigned)std::min<int64_t>(n, 16384);
+        if (rescale) {
+            const size_t rs_lds = W2 * 12 + 16 * (size_t)W;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(pup::pileup_rescale_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_lds);
+            if (cov_start && !(mode & PUP_MODE_COV)) e = hipMemsetAsync(d_cov.p, 0xff, (size_t)n * 2 * W * 8, c->stream);  // NaN
+            hipLaunchKernelGGL(pup::pileup_rescale_kernel, dim3(grid), dim3(256), rs_lds, c->stream, a,
+                               (const int*)c->d_h.p, (const int*)c->d_w.p, d_out.p, cov_start ? d_cov.p : (double*)nullptr,
+                               (long long)n);
+        } else {
+            hipLaunchKernelGGL(pup::extract_windows_kernel, dim3(grid), dim3(256), 0, c->stream, a, (long long)n, d_out.p,
+                               cov_start ? d_cov.p : (double*)nullptr);
+        }
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(data, d_out.p, (size_t)n * W2 * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && cov_start) {
+        // device layout per snippet: {cov_start[W], cov_end[W]}
+        e = hipMemcpy2D(cov_start, (size_t)W * 8, d_cov.p, (size_t)2 * W * 8, (size_t)W * 8, (size_t)n, hipMemcpyDeviceToHost);
+        if (e == hipSuccess)
+            e = hipMemcpy2D(cov_end, (size_t)W * 8, d_cov.p + W, (size_t)2 * W * 8, (size_t)W * 8, (size_t)n, hipMemcpyDeviceToHost);
+    }
+    d_out.release(); d_cov.release();
+    if (e != hipSuccess) return fail(c, PUP_EHIP, "pup_extract: %s", hipGetErrorString(e));
     return check_async_error(c);
 }
 

@@ -835,14 +835,21 @@ __device__ __forceinline__ double lookup_bal(const K1Args& a, const RsGeom& g, i
 
 __device__ __forceinline__ bool bin_bad(const K1Args& a, int bin) { return (a.badbits[bin >> 6] >> (bin & 63)) & 1ull; }
 
-__global__ __launch_bounds__(256) void pileup_rescale_kernel(K1Args a, const int* __restrict__ hs, const int* __restrict__ wsz) {
+//
+// Emission mode (emit != nullptr, pup_extract): nothing is accumulated; the zoomed S x S tile of snippet s is written
+// to emit[s] (reference frame, i.e. TRANSPOSE undone; NaN where the reference's zoomed NaN mask is set) and its zoomed
+// coverage vectors to emit_cov[s] = {cov_start[S], cov_end[S]}.  Blocks then stride over snippets 0..emit_n.
+__global__ __launch_bounds__(256) void pileup_rescale_kernel(K1Args a, const int* __restrict__ hs, const int* __restrict__ wsz,
+                                                             double* __restrict__ emit, double* __restrict__ emit_cov,
+                                                             long long emit_n) {
 #pragma clang fp contract(off)      // zoom coordinates must be plain IEEE products (see below)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int S = a.W, S2 = S * S;
     double*   tsum = reinterpret_cast<double*>(smem_raw);
     double*   tcov = tsum + S2;                               // [2S]
     unsigned* tnum = reinterpret_cast<unsigned*>(tcov + 2 * S);
-    const int ck = a.block_chunk[blockIdx.x];
+    const bool emitting = emit != nullptr;
+    const int ck = emitting ? (int)blockIdx.x : a.block_chunk[blockIdx.x];
     if (ck < 0) return;
     const int tid = threadIdx.x, nthr = blockDim.x;
     for (int t = tid; t < S2; t += nthr) { tsum[t] = 0.0; tnum[t] = 0u; }
@@ -855,8 +862,10 @@ __global__ __launch_bounds__(256) void pileup_rescale_kernel(K1Args a, const int
     const int igd = a.ignore_diags;
     const double qn = __builtin_nan("");
     const double DBLMAX = 1.7976931348623157e308;
-    const long long cb = a.chunk_begin[ck], ce = a.chunk_end[ck], cstep = a.chunk_stride[ck];
-    const int fl = a.chunk_flip[ck];
+    const long long cb = emitting ? (long long)blockIdx.x : a.chunk_begin[ck];
+    const long long ce = emitting ? emit_n : a.chunk_end[ck];
+    const long long cstep = emitting ? (long long)gridDim.x : a.chunk_stride[ck];
+    const int fl = emitting ? 0 : a.chunk_flip[ck];
     ExpCache ecache;
     RsGeom geo{0, -1, 0, 0, false};
 
@@ -953,7 +962,9 @@ __global__ __launch_bounds__(256) void pileup_rescale_kernel(K1Args a, const int
                 }
                 acc *= inv;
             }
-            if (!anynan) {
+            if (emitting) {
+                emit[(size_t)s * S2 + (m_tr ? B * S + A : t)] = anynan ? qn : acc;
+            } else if (!anynan) {
                 const int cellidx = t;                          // window frame; flip / transpose applied at the flush
                 if (acc == acc) tsum[cellidx] += acc;
                 if (!(acc != acc) && !__builtin_isinf(acc)) tnum[cellidx] += 1u;
@@ -976,10 +987,12 @@ __global__ __launch_bounds__(256) void pileup_rescale_kernel(K1Args a, const int
                     accv += a.cov[base + i0] * (1.0 - tt) + (tt > 0.0 ? a.cov[base + i1] * tt : 0.0);
                 }
                 accv /= (double)m;
-                if (accv == accv) tcov[t] += accv;
+                if (emitting) { if (emit_cov) emit_cov[(size_t)s * 2 * S + t] = accv; }
+                else if (accv == accv) tcov[t] += accv;
             }
         }
     }
+    if (emitting) return;
     // ---- flush (owner threads write their own cells) ----
     const size_t L = (size_t)S2 + 2 * (size_t)S;
     double*   of = a.part_f64 + (size_t)ck * L;
@@ -1216,6 +1229,63 @@ __global__ __launch_bounds__(kWave) void stripes_kernel(K1Args a, long long n, d
             if (a.ignore_diags >= 0 && (col - row) < a.ignore_diags) v = qn;
             if (m_ooe) { long long ad = (long long)col - row; if (ad < 0) ad = -ad; v = v / es.at(ad); }
             (horiz ? h_out : v_out)[s * W + i] = v;
+        }
+    }
+}
+
+// ---- K6: per-snippet windows (pup_extract) ------------------------------------------------------------------------
+// The W x W window of every snippet exactly as PileUpper._stream_snips yields it (coolpup.py:1104-1158): balanced
+// values, NaN on masked bins and ignored diagonals, divided by expected (OOE), or the expected window itself
+// (EXPECTED, the reference's exp_snip); written in the reference's frame (TRANSPOSE undone, no flip — the flip is a
+// per-snippet post-processing step in the reference, coolpup.py:128-131).  Exists for the per-snippet Python
+// callbacks (postprocess_func / extra_sum_funcs), whose cost per snippet dwarfs this gather: one 256-thread
+// workgroup per snippet, every cell looked up on its own through the rank-bitmap index (or a binary search).
+__global__ __launch_bounds__(256) void extract_windows_kernel(K1Args a, long long n, double* __restrict__ out,
+                                                              double* __restrict__ cov_out) {
+    const int W = a.W, W2 = W * W;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const bool m_ooe = a.mode & 0x01u, m_exp = a.mode & 0x02u, m_cov = (a.mode & 0x04u) && a.cov != nullptr;
+    const bool m_tr = a.mode & 0x08u;
+    const bool use_exp = (m_ooe || m_exp) && ((a.expv != nullptr && a.nexp > 0) || a.n_exp_regions > 0);
+    const int igd = a.ignore_diags;
+    const double qn = __builtin_nan("");
+    ExpCache ecache;
+    RsGeom geo{0, -1, 0, 0, false};
+    for (long long s = blockIdx.x; s < n; s += gridDim.x) {
+        const int rs = a.r0[s], cs = a.c0[s];
+        if (rs < 0 || cs < 0 || (long long)rs + W > a.nbins || (long long)cs + W > a.nbins) {
+            if (tid == 0) atomicExch(a.err, 1);
+            continue;
+        }
+        if (a.idx != nullptr && !(rs >= geo.ch_start && rs < geo.ch_end)) {
+            int lo = 0, hi_k = a.n_chrom;
+            while (lo < hi_k) { const int m = (lo + hi_k) >> 1; if (a.idx_chrom[m].end <= rs) lo = m + 1; else hi_k = m; }
+            if (lo < a.n_chrom) { const IdxChrom c = a.idx_chrom[lo]; geo = RsGeom{c.start, c.end, c.nblk, c.blk_base, true}; }
+            else geo = RsGeom{0, -1, 0, 0, false};
+        }
+        ExpSel es; es.base = a.expv; es.len = 0; es.scalar = qn; es.is_scalar = true;
+        if (use_exp) es = select_expected(a, ecache, rs, cs);
+        for (int t = tid; t < W2; t += nthr) {
+            const int i = t / W, j = t - i * W;
+            const int row = rs + i, col = cs + j;
+            long long ad = (long long)col - row; if (ad < 0) ad = -ad;
+            double v;
+            if (m_exp) v = es.at(ad);
+            else if (bin_bad(a, row) || bin_bad(a, col)) v = qn;
+            else if (igd >= 0 && (col - row) < igd) v = qn;
+            else {
+                v = lookup_bal(a, geo, row, col);
+                if (m_ooe) v = v / es.at(ad);
+            }
+            out[(size_t)s * W2 + (m_tr ? j * W + i : t)] = v;
+        }
+        if (cov_out != nullptr) {
+            for (int t = tid; t < 2 * W; t += nthr) {
+                const bool start_side = t < W;
+                const int k = start_side ? t : t - W;
+                const bool rows = start_side != m_tr;            // cov_start follows the reference's rows
+                cov_out[(size_t)s * 2 * W + t] = m_cov ? a.cov[(rows ? rs : cs) + k] : qn;
+            }
         }
     }
 }

@@ -182,6 +182,21 @@ class PileupEngine:
                                           int(mode), _ptr(h), _ptr(v)))
         return h, v
 
+    def extract(self, r0, c0, pad, *, height=None, width=None, ignore_diags=2, mode=0, coverage=False):
+        """Per-snippet windows for host callbacks: data [n,W,W] as _stream_snips yields them (NaN-masked, /expected with
+        MODE_OOE, the expected window with MODE_EXPECTED; rescaled to W x W when height/width are given).  With
+        coverage=True also returns (cov_start [n,W], cov_end [n,W]).  Nothing is accumulated."""
+        r0, c0 = _as(r0, np.int32), _as(c0, np.int32)
+        hh = None if height is None else _as(height, np.int32)
+        ww = None if width is None else _as(width, np.int32)
+        n, W = r0.shape[0], 2 * int(pad) + 1
+        data = np.empty((n, W, W), np.float64)
+        cs = np.empty((n, W), np.float64) if coverage else None
+        ce = np.empty((n, W), np.float64) if coverage else None
+        self._check(self._lib.pup_extract(self._h, _ptr(r0), _ptr(c0), _ptr(hh), _ptr(ww), n, int(pad), int(ignore_diags),
+                                          int(mode) & ~MODE_DEVPTR, _ptr(data), _ptr(cs), _ptr(ce)))
+        return (data, cs, ce) if coverage else data
+
     def sync(self):
         self._check(self._lib.pup_sync(self._h))
 

@@ -21,21 +21,95 @@ _ANNOTATION_ATTRS = [
 ]
 
 
+def _collapse(items):
+    """Flatten nested iterables down to dicts (more_itertools.collapse(..., base_type=dict))."""
+    if isinstance(items, (dict, str, bytes)):
+        yield items
+        return
+    try:
+        it = iter(items)
+    except TypeError:
+        yield items
+        return
+    for x in it:
+        yield from _collapse(x)
+
+
+def _add_snip(outdict, key, snip, extra_funcs=None):
+    """Add one snippet to the pile-up of its group (reference lib/puputils.py:12-41): the first snippet of a group
+    seeds the entry, later ones are nansum-ed into data / coverage, counted in num (finite cells) and n, and have
+    their stripes / coordinates appended; every extra function then maps (entry, snip) -> entry."""
+    if key not in outdict:
+        entry = {k: snip[k] for k in ("data", "cov_start", "cov_end")}
+        entry["coordinates"] = [snip["coordinates"]]
+        entry["horizontal_stripe"] = [snip["horizontal_stripe"]]
+        entry["vertical_stripe"] = [snip["vertical_stripe"]]
+        entry["num"] = np.isfinite(snip["data"]).astype(int)
+        entry["n"] = 1
+        outdict[key] = entry
+    else:
+        entry = outdict[key]
+        entry["data"] = np.nansum([entry["data"], snip["data"]], axis=0)
+        entry["num"] += np.isfinite(snip["data"]).astype(int)
+        entry["cov_start"] = np.nansum([entry["cov_start"], snip["cov_start"]], axis=0)
+        entry["cov_end"] = np.nansum([entry["cov_end"], snip["cov_end"]], axis=0)
+        entry["n"] += 1
+        for k in ("horizontal_stripe", "vertical_stripe", "coordinates"):
+            entry[k] = entry[k] + [snip[k]]
+    if extra_funcs is not None:
+        for _, func in extra_funcs.items():
+            outdict[key] = func(outdict[key], snip)
+
+
 def sum_pups(pup1, pup2, extra_funcs={}):
-    """Sum two pile-up dicts (data, num, n, cov_start, cov_end); NaN/inf in data are replaced first,
-    exactly like the reference's ``np.nan_to_num`` (lib/puputils.py:97-98)."""
-    d1, d2 = np.nan_to_num(pup1["data"]), np.nan_to_num(pup2["data"])
+    """Sum two pile-up dicts (data, num, n, cov_start, cov_end, stripes, coordinates); NaN/inf in data are replaced
+    first — in place, on both inputs — exactly like the reference's ``np.nan_to_num`` (lib/puputils.py:97-98).
+    With extra_funcs the reference REPLACES the summed pile-up by the return value of func(pup1, pup2)
+    (lib/puputils.py:110-112); that is kept, because callers of the callback API see it."""
+    pup1["data"] = np.nan_to_num(pup1["data"])
+    pup2["data"] = np.nan_to_num(pup2["data"])
     out = {
-        "data": d1 + d2,
+        "data": pup1["data"] + pup2["data"],
         "cov_start": pup1["cov_start"] + pup2["cov_start"],
         "cov_end": pup1["cov_end"] + pup2["cov_end"],
         "n": pup1.get("n", 1) + pup2.get("n", 1),
-        "num": pup1.get("num", np.isfinite(d1).astype(int)) + pup2.get("num", np.isfinite(d2).astype(int)),
-        "horizontal_stripe": list(pup1.get("horizontal_stripe", [])) + list(pup2.get("horizontal_stripe", [])),
-        "vertical_stripe": list(pup1.get("vertical_stripe", [])) + list(pup2.get("vertical_stripe", [])),
-        "coordinates": list(pup1.get("coordinates", [])) + list(pup2.get("coordinates", [])),
+        "num": pup1.get("num", np.isfinite(pup1["data"]).astype(int))
+        + pup2.get("num", np.isfinite(pup2["data"]).astype(int)),
+        "horizontal_stripe": pup1["horizontal_stripe"] + pup2["horizontal_stripe"],
+        "vertical_stripe": pup1["vertical_stripe"] + pup2["vertical_stripe"],
+        "coordinates": pup1["coordinates"] + pup2["coordinates"],
     }
+    if extra_funcs:
+        for _, func in extra_funcs.items():
+            out = func(pup1, pup2)
     return pd.Series(out)
+
+
+def accumulate_values(dict1, dict2, key):
+    """An extra_sum_func: collect dict2[key] into the flat list dict1[key] (reference lib/puputils.py:244-253)."""
+    assert key in dict2, f"{key} not in dict2"
+    if key in dict1:
+        dict1[key] = list(_collapse([dict1[key], dict2[key]]))
+    else:
+        dict1[key] = [dict2[key]]
+    return dict1
+
+
+def bin_distance(snip, band_edges="default"):
+    """Per-snippet form of bin_distance_intervals (reference lib/puputils.py:193-215): adds 'distance_band'."""
+    if isinstance(band_edges, str) and band_edges == "default":
+        band_edges = np.append([0], 50000 * 2 ** np.arange(30))
+    i = np.searchsorted(band_edges, snip["distance"])
+    snip["distance_band"] = tuple(band_edges[i - 1: i + 1])
+    return snip
+
+
+def group_by_region(snip):
+    """A postprocess_func: count the snippet once for the feature on each side (reference lib/puputils.py:218-223)."""
+    for side in ("1", "2"):
+        s = snip.copy()
+        s["group"] = (s["chrom" + side], s["start" + side], s["end" + side])
+        yield s
 
 
 def norm_coverage(snip):
@@ -77,12 +151,46 @@ def _copy_array_halves(x):
 
 def finalize_pileups(pu, acc, order, contrib, gid, G, groupby, want_control, n_regions, grouped=None, stripes=None):
     """Tail of pileupsWithControl (coolpup.py:1533-1654) on summed tiles -> annotated DataFrame."""
-    import warnings
     if grouped is None:
         grouped = bool(groupby)
     roi = _tile_frame(acc, KIND_ROI, order, contrib, gid, G, grouped)
     ctrl = _tile_frame(acc, KIND_CONTROL, order, contrib, gid, G, grouped) if want_control else None
+    return _finalize_frames(pu, roi, ctrl, groupby, want_control, stripes)
 
+
+def merge_region_pups(per_region, extra_funcs=None):
+    """[{group: pup}, ...] (one dict per region, in region order) -> DataFrame indexed by group, one column per pup
+    field: groups in order of first appearance, each reduced over the regions holding it with sum_pups — a group
+    held by a single region is passed through untouched (reference coolpup.py:1511-1531)."""
+    from functools import partial, reduce
+    sum_func = partial(sum_pups, extra_funcs=extra_funcs)
+    keys = list(dict.fromkeys(k for d in per_region for k in d))
+    merged = {}
+    for k in keys:
+        held = [pd.Series(d[k]) for d in per_region if k in d]
+        merged[k] = reduce(sum_func, held)
+    # fields as rows, then transposed: every column ends up with object dtype, as in the reference's frames
+    out = pd.DataFrame(dict(enumerate(merged.values()))).T
+    out.index = pd.Index(keys, tupleize_cols=False)
+    return out
+
+
+def finalize_callback_pileups(pu, pileups, groupby, want_control, extra_sum_funcs=None):
+    """Callback mode: per-region host pile-ups ({"ROI": {...}, "control": {...}} each) -> annotated DataFrame."""
+    roi = merge_region_pups([p["ROI"] for p in pileups], extra_sum_funcs)
+    ctrl = merge_region_pups([p["control"] for p in pileups], extra_sum_funcs) if want_control else None
+    stripes = None
+    if pu.store_stripes:
+        # coordinates were joined with "." per snippet and are split again here (coolpup.py:1170-1182, 1557-1560)
+        stripes = {}
+        for key in roi.index:
+            co = np.vstack([c.split(".") for c in roi.loc[key, "coordinates"]])
+            stripes[key] = (co, np.vstack(roi.loc[key, "horizontal_stripe"]), np.vstack(roi.loc[key, "vertical_stripe"]))
+    return _finalize_frames(pu, roi, ctrl, groupby, want_control, stripes, extra_sum_funcs=extra_sum_funcs)
+
+
+def _finalize_frames(pu, roi, ctrl, groupby, want_control, stripes=None, extra_sum_funcs=None):
+    import warnings
     if pu.coverage_norm:
         roi = roi.apply(norm_coverage, axis=1)
         if pu.control:
@@ -134,6 +242,12 @@ def finalize_pileups(pu, acc, order, contrib, gid, G, groupby, want_control, n_r
         )
         for val in groupby:
             normalized_roi.insert(0, val, normalized_roi.pop(val))
+    if extra_sum_funcs:
+        for key in extra_sum_funcs:
+            normalized_roi[key] = roi[key].values
+            if pu.control:
+                # index-aligned against the already re-numbered frame, as in the reference (coolpup.py:1621-1622)
+                normalized_roi[f"control_{key}"] = ctrl[key]
     import logging
     logging.getLogger("coolpuppy").info(f"Total number of piled up windows: {int(n)}")
 

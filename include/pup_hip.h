@@ -23,6 +23,8 @@
  *                                        PileUpper.__init__ when cov_*_raw is missing     coolpuppy/coolpup.py:955-963
  *   pup_accumulate_rescaled           <- the same loop with _rescale_snip               coolpuppy/coolpup.py:1159-1162, 1193-1234
  *   pup_stripes                       <- the store_stripes branch of _stream_snips   coolpuppy/coolpup.py:1164-1182
+ *   pup_extract                       <- _stream_snips as a producer of per-snippet windows for the Python callbacks
+ *                                        (postprocess_func / extra_sum_funcs)          coolpuppy/coolpup.py:1104-1162, 1261-1262
  *   pup_fetch / pup_export / pup_import
  *                                     <- sum_pups cross-region merge   coolpuppy/lib/puputils.py:88-113
  *                                        and the reduce at             coolpuppy/coolpup.py:1511-1531
@@ -160,6 +162,20 @@ int pup_accumulate(pup_ctx* ctx, const int32_t* r0, const int32_t* c0, int64_t n
  */
 int pup_stripes(pup_ctx* ctx, const int32_t* r0, const int32_t* c0, int64_t n, int32_t pad, int32_t ignore_diags,
                 uint32_t mode, double* horizontal, double* vertical);
+
+/*
+ * Per-snippet windows for host-side callbacks: data[s] ([n][W][W] float64, W = 2*pad+1, caller-allocated host array)
+ * receives the window of snippet s exactly as the reference's _stream_snips yields snip["data"]
+ * (coolpup.py:1104-1158): balanced values, NaN on masked bins / ignored diagonals, divided by expected with
+ * PUP_MODE_OOE, or the expected window itself with PUP_MODE_EXPECTED (the reference's exp_snip); reference frame
+ * (PUP_MODE_TRANSPOSE undone), not flipped.  height / width (nullable, both or neither): variable-size windows
+ * rescaled to W x W as in pup_accumulate_rescaled (_rescale_snip, coolpup.py:1193-1234; PUP_MODE_LOCAL applies).
+ * cov_start / cov_end (nullable, [n][W] each): the coverage slices of the window's rows / columns (zoomed when
+ * rescaling) with PUP_MODE_COV, NaN otherwise.  Nothing is accumulated; synchronous.
+ */
+int pup_extract(pup_ctx* ctx, const int32_t* r0, const int32_t* c0, const int32_t* height, const int32_t* width,
+                int64_t n, int32_t pad, int32_t ignore_diags, uint32_t mode, double* data, double* cov_start,
+                double* cov_end);
 
 /*
  * Rescaled pile-up (rescale=True, PileUpper._rescale_snip, coolpup.py:1193-1234): snippet s is the height[s] x width[s]

@@ -1,0 +1,102 @@
+"""TEST INFRASTRUCTURE — per-snippet callback scenarios (postprocess_func / extra_sum_funcs).
+
+The same scenario table drives the reference (oracle/make_golden.py, in the build container) and coolpuppy_amd (tests):
+``run(mod, putils, clr, sc)`` only uses the API both expose — CoordCreator, PileUpper.pileupsWithControl — so the
+goldens pin what a user of that API sees, including the reference's quirks (with extra_sum_funcs the merged
+pile-up is whatever the callback returns, lib/puputils.py:110-112).  Callbacks use numpy only.
+"""
+import warnings
+
+import numpy as np
+
+
+def centre_mean(snip):
+    d = np.asarray(snip["data"], float)
+    c = d.shape[0] // 2
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", category=RuntimeWarning)
+        snip["centre"] = float(np.nanmean(d[c - 1:c + 2, c - 1:c + 2]))
+    return snip
+
+
+def domain_score_like(snip):
+    """Mean of the central third over the mean of the two flanking off-diagonal blocks (TAD_score.ipynb's idea)."""
+    d = np.asarray(snip["data"], float)
+    t = d.shape[0] // 3
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", category=RuntimeWarning)
+        inside = np.nanmean(d[t:2 * t, t:2 * t])
+        outside = np.nanmean(np.concatenate([d[:t, t:2 * t].ravel(), d[t:2 * t, 2 * t:].ravel()]))
+    snip["centre"] = float(inside / outside) if outside else float("nan")
+    return snip
+
+
+def double_data(snip):
+    snip["data"] = np.asarray(snip["data"], float) * 2.0
+    return snip
+
+
+def band_group(putils):
+    def f(snip):
+        snip = putils.bin_distance(snip)
+        snip["group"] = (tuple(int(x) for x in snip["distance_band"]),)
+        return snip
+    return f
+
+
+def scenarios(bedpe, bed, tads, exp_chrom):
+    """name -> dict(features, cc=CoordCreator kwargs, pu=PileUpper kwargs, expected, call=pileupsWithControl kwargs as
+    NAMES resolved by run())."""
+    S = []
+
+    def add(name, features, cc, pu=None, expected=None, **call):
+        S.append({"name": name, "features": features, "cc": cc, "pu": pu or {}, "expected": expected, "call": call})
+
+    add("G13a_bedpe_controls_collect_centre", bedpe.iloc[:160], dict(features_format="bedpe", flank=100_000, nshifts=2,
+                                                                     seed=3), dict(control=True),
+        postprocess="centre_mean", extra={"centre": "collect_centre"})
+    add("G13b_rescale_local_expected_domain_score", tads, dict(features_format="bed", local=True, rescale_flank=1),
+        dict(rescale=True, rescale_size=33, ignore_diags=0), expected=exp_chrom,
+        postprocess="domain_score_like", extra={"centre": "collect_centre"})
+    add("G13c_bedpe_double_data", bedpe.iloc[:200], dict(features_format="bedpe", flank=100_000, nshifts=0),
+        postprocess="double_data")
+    add("G13d_bed_strand_flip_double", bed, dict(features_format="bed", flank=100_000, nshifts=0, mindist=300_000,
+                                                 maxdist=3_000_000),
+        dict(flip_negative_strand=True), postprocess="double_data", groupby=["strand1", "strand2"])
+    add("G13e_bedpe_group_by_region", bedpe.iloc[:60], dict(features_format="bedpe", flank=100_000, nshifts=0),
+        postprocess="group_by_region")
+    add("G13f_expected_not_ooe_stripes_centre", bedpe.iloc[:120], dict(features_format="bedpe", flank=100_000, nshifts=0),
+        dict(ooe=False, store_stripes=True), expected=exp_chrom, postprocess="centre_mean")
+    add("G13g_band_group_postprocess", bedpe.iloc[:200], dict(features_format="bedpe", flank=100_000, nshifts=1, seed=5),
+        dict(control=True), postprocess="band_group")
+    add("G13h_ignore_group_order_strands", bed, dict(features_format="bed", flank=100_000, nshifts=0, mindist=300_000,
+                                                     maxdist=2_000_000),
+        postprocess="centre_mean", groupby=["strand1", "strand2"], ignore_group_order=True)
+    add("G13i_raw_covnorm_double", bedpe.iloc[:150], dict(features_format="bedpe", flank=100_000, nshifts=2, seed=8),
+        dict(control=True, clr_weight_name=None, coverage_norm="cov_tot_raw"), postprocess="double_data")
+    return S
+
+
+def run(mod, putils, clr, sc, view=None):
+    """Run one scenario against module ``mod`` (the reference's coolpup or coolpuppy_amd.coolpup)."""
+    named = {
+        "centre_mean": centre_mean, "domain_score_like": domain_score_like, "double_data": double_data,
+        "group_by_region": putils.group_by_region, "band_group": band_group(putils),
+        "collect_centre": lambda d1, d2: putils.accumulate_values(d1, d2, "centre"),
+    }
+    call = dict(sc["call"])
+    kw = {}
+    if call.get("postprocess"):
+        kw["postprocess_func"] = named[call.pop("postprocess")]
+    if call.get("extra"):
+        kw["extra_sum_funcs"] = {k: named[v] for k, v in call.pop("extra").items()}
+    kw.update(call)
+    cckw = dict(sc["cc"])
+    if cckw.get("seed") is not None:
+        np.random.seed(cckw["seed"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cc = mod.CoordCreator(sc["features"].copy(), clr.binsize, chroms=list(clr.chromnames), **cckw)
+        pu = mod.PileUpper(clr, cc, view_df=view, expected=False if sc["expected"] is None else sc["expected"].copy(),
+                           **sc["pu"])
+        return pu.pileupsWithControl(**kw)

@@ -94,6 +94,15 @@ def trans_expected(clr, view):
     return pd.DataFrame(rows, columns=["region1", "region2", "n_valid", "balanced.avg"])
 
 
+def tad_features():
+    return pd.DataFrame({
+        "chrom": ["chrA"] * 7 + ["chrB"] * 4 + ["chrC"] * 2,
+        "start": [300_000, 1_000_000, 3_000_000, 6_050_000, 9_000_000, 15_000_000, 21_500_000,
+                  2_000_000, 5_000_000, 9_000_000, 13_000_000, 1_500_000, 4_000_000],
+        "end": [420_000, 1_400_000, 3_900_000, 6_300_000, 11_500_000, 15_250_000, 21_900_000,
+                2_600_000, 5_130_000, 9_990_000, 13_770_000, 2_700_000, 4_490_000]})
+
+
 def csv_text(df):
     return None if df is None else df.to_csv(index=False)
 
@@ -184,12 +193,7 @@ def scenarios():
     add("G11d_stripes_local", "small", bed, features_format="bed", local=True, store_stripes=True, flank=100_000)
     add("G11e_stripes_trans", "small", trans_bedpe(clr, 80, 14), features_format="bedpe", trans=True,
         store_stripes=True, flank=100_000)
-    tads = pd.DataFrame({
-        "chrom": ["chrA"] * 7 + ["chrB"] * 4 + ["chrC"] * 2,
-        "start": [300_000, 1_000_000, 3_000_000, 6_050_000, 9_000_000, 15_000_000, 21_500_000,
-                  2_000_000, 5_000_000, 9_000_000, 13_000_000, 1_500_000, 4_000_000],
-        "end": [420_000, 1_400_000, 3_900_000, 6_300_000, 11_500_000, 15_250_000, 21_900_000,
-                2_600_000, 5_130_000, 9_990_000, 13_770_000, 2_700_000, 4_490_000]})
+    tads = tad_features()
     add("G12_rescale_local", "small", tads, features_format="bed", local=True, rescale=True, rescale_flank=1,
         rescale_size=33)
     add("G12b_rescale_local_expected", "small", tads, features_format="bed", local=True, rescale=True,
@@ -280,6 +284,43 @@ def record(df, W):
     rec["scalars"] = json.dumps(scalars, default=str)
     assert rec["data"].shape[0] == rows
     return rec
+
+
+def record_extra(df, rec, key):
+    """A column of per-group value lists (extra_sum_funcs output): ptr + flat values; a non-list cell (NaN) has
+    ptr step -1."""
+    if key not in df.columns:
+        return
+    ptr, vals, is_list = [0], [], []
+    for cell in df[key]:
+        if isinstance(cell, (list, tuple, np.ndarray)):
+            vals.extend(float(v) for v in cell)
+            is_list.append(1)
+        else:
+            is_list.append(0)
+        ptr.append(len(vals))
+    rec[f"extra__{key}__ptr"] = np.array(ptr, np.int64)
+    rec[f"extra__{key}__vals"] = np.array(vals, np.float64)
+    rec[f"extra__{key}__is_list"] = np.array(is_list, np.int8)
+
+
+def callback_goldens(ref, coolers, index):
+    """Scenarios that drive PileUpper.pileupsWithControl with per-snippet callbacks (oracle/callbacks.py)."""
+    import importlib
+    from oracle import callbacks as cbs
+    ref_putils = importlib.import_module("coolpuppy.lib.puputils")
+    small = coolers["small"]
+    clr = refshim.ShimCooler(small)
+    for sc in cbs.scenarios(bedpe_features(small), bed_features(small), tad_features(), synth.cis_expected(small)):
+        df = cbs.run(ref, ref_putils, clr, sc)
+        W = sc["pu"]["rescale_size"] if sc["pu"].get("rescale") else 2 * (sc["cc"]["flank"] // clr.binsize) + 1
+        rec = record(df, W)
+        for key in ("centre", "control_centre"):
+            record_extra(df, rec, key)
+        rec["meta"] = json.dumps({"name": sc["name"], "cooler": "small", "callback": True})
+        np.savez_compressed(os.path.join(GOLD, sc["name"] + ".npz"), **rec)
+        gl = group_list(df)
+        print(f"{sc['name']:45s} rows={len(df):3d} n_all={int(df['n'].iloc[gl.index('all')])}")
 
 
 def main():
@@ -378,6 +419,7 @@ def main():
                 regions[f"{r}|{kind}|num"] = np.asarray(p["num"]).astype(np.int64)
                 regions[f"{r}|{kind}|n"] = np.int64(p["n"])
     np.savez_compressed(os.path.join(GOLD, "regions.npz"), **regions)
+    callback_goldens(ref, coolers, index)
     with open(os.path.join(GOLD, "index.json"), "w") as f:
         json.dump(index, f, indent=0)
     # the reference's own small test data files (data, not source) used by the KAT scenarios

@@ -267,3 +267,49 @@ def pileup_rescaled(bigdata, lo1, lo2, weight, cov, expv, r0, c0, h, w, flip, ti
         acc["num"][t] += np.isfinite(data).astype(int)
         acc["n"][t] += 1
     return acc
+
+
+def windows_scipy(bigdata, lo1, lo2, weight, cov, expv, r0, c0, pad, ignore_diags, mode, h=None, w=None):
+    """The per-snippet windows _stream_snips yields (reference coolpup.py:1104-1162), before any flip:
+    (data [n,W,W], cov_start [n,W], cov_end [n,W]), W = 2*pad+1; with h / w the variable-size windows are passed
+    through _rescale_snip (W = rescale_size).  Coverage rows are NaN unless MODE_COV.  Checker for pup_extract."""
+    W = 2 * pad + 1
+    n = len(r0)
+    out = np.empty((n, W, W))
+    cs_out = np.full((n, W), np.nan)
+    ce_out = np.full((n, W), np.nan)
+    rescale = h is not None
+    local = bool(mode & MODE_LOCAL)
+    for s in range(n):
+        rs, cs = (int(c0[s]), int(r0[s])) if mode & MODE_TRANSPOSE else (int(r0[s]), int(c0[s]))
+        hh, ww = (int(h[s]), int(w[s])) if rescale else (W, W)
+        if rescale and (mode & MODE_TRANSPOSE):
+            hh, ww = ww, hh
+        have_exp = (mode & (MODE_OOE | MODE_EXPECTED)) and expv is not None
+        if have_exp:
+            ev = np.atleast_1d(expv)
+            if ev.shape[0] == 1:
+                exp_data = np.full((hh, ww), ev[0])
+            else:
+                d = np.abs((cs + np.arange(ww))[None, :] - (rs + np.arange(hh))[:, None])
+                exp_data = np.where(d < ev.shape[0], ev[np.minimum(d, ev.shape[0] - 1)], np.nan)
+        if mode & MODE_EXPECTED:
+            data = exp_data.astype(float)
+        else:
+            data = bigdata[rs - lo1:rs - lo1 + hh, cs - lo2:cs - lo2 + ww].toarray().astype(float)
+            if weight is not None:
+                data[np.isnan(weight[rs:rs + hh]), :] = np.nan
+                data[:, np.isnan(weight[cs:cs + ww])] = np.nan
+            if ignore_diags >= 0:
+                D = ((cs + np.arange(ww))[None, :] - (rs + np.arange(hh))[:, None]) < ignore_diags
+                data[D] = np.nan
+            if mode & MODE_OOE:
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    data = data / (exp_data if have_exp else np.nan)
+        if rescale:
+            data = rescale_snip(data, W, local)
+        out[s] = data
+        if (mode & MODE_COV) and cov is not None and not (mode & MODE_EXPECTED):
+            cs_out[s] = zoom_array(cov[rs:rs + hh], (W,)) if rescale else cov[rs:rs + hh]
+            ce_out[s] = zoom_array(cov[cs:cs + ww], (W,)) if rescale else cov[cs:cs + ww]
+    return out, cs_out, ce_out
