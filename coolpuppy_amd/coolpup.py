@@ -15,8 +15,8 @@ for a GPU instead of a per-snippet Python loop:
   inf→NaN, symmetrisation, annotation — is restated with pandas on the fetched tiles.
 
 By-window pile-ups, stored stripes, coverage computation and rescaled pile-ups are served by the
-same engine (K3 / K4 / K5).  Not implemented (raise ``NotImplementedError``): per-snippet Python callbacks
-(``postprocess_func`` / ``extra_sum_funcs``) and ``store_stripes`` combined with by-window or rescaled pile-ups.
+same engine (K3 / K4 / K5).  Per-snippet Python callbacks (``postprocess_func`` / ``extra_sum_funcs``) get their
+windows from the engine (``pup_extract``, K6) and run, with the reference's per-snippet bookkeeping, on the host.
 """
 import itertools
 import logging
@@ -754,8 +754,6 @@ class PileUpper:
                 raise ValueError("Cannot use rescale without setting rescale_flank")
             elif self.rescale_size % 2 == 0:
                 raise ValueError("Please provide an odd rescale_size")
-            if self.store_stripes:
-                raise NotImplementedError("store_stripes together with rescaled pile-ups is not implemented")
             logger.info(f"Rescaling with rescale_flank = {self.rescale_flank} to "
                         f"{self.rescale_size}x{self.rescale_size} pixels")
         elif self.rescale_flank is not None:
@@ -1080,10 +1078,14 @@ class PileUpper:
                     expected = "table" if exp_table is not None else (
                         np.array([self.get_expected_trans(region1, region2)], np.float64) if self.trans
                         else self._expected_vectors[region1])
-                stripe_jobs.append({"expected": expected, "ignore_diags": -1 if self.trans else int(self.ignore_diags),
-                                    "mode": (MODE_OOE if (self.expected and self.ooe) else 0) | (MODE_TRANSPOSE if transpose else 0),
-                                    "r0": r0.astype(np.int32), "c0": c0.astype(np.int32), "gid": gk,
-                                    "coords": b["coords"][roi]})
+                job = {"expected": expected, "ignore_diags": -1 if self.trans else int(self.ignore_diags),
+                       "mode": (MODE_OOE if (self.expected and self.ooe) else 0) | (MODE_TRANSPOSE if transpose else 0)
+                       | (MODE_LOCAL if (rescale and self.local) else 0),
+                       "r0": r0.astype(np.int32), "c0": c0.astype(np.int32), "gid": gk, "coords": b["coords"][roi]}
+                if rescale:   # stripes of the ZOOMED window (reference :1159-1169): whole windows via pup_extract
+                    hh, ww = (b["w"][roi], b["h"][roi]) if transpose else (b["h"][roi], b["w"][roi])
+                    job["h"], job["w"] = hh.astype(np.int32), ww.astype(np.int32)
+                stripe_jobs.append(job)
         merged = []                     # [head item, [parts of fields 3..6]]
         for item in raw:
             prev = merged[-1][0] if merged else None
@@ -1144,6 +1146,13 @@ class PileUpper:
                     eng.set_expected_table(et["start"], et["end"], vectors=et["vectors"], pair=et["pair"])
                 else:
                     eng.set_expected(job["expected"])
+                if "h" in job:
+                    win = eng.extract(job["r0"], job["c0"], plan["pad"], height=job["h"], width=job["w"],
+                                      ignore_diags=job["ignore_diags"], mode=job["mode"])
+                    cntr = plan["pad"]
+                    acc["stripes"].append((np.ascontiguousarray(win[:, cntr, :]),
+                                           np.ascontiguousarray(win[:, ::-1, cntr])))
+                    continue
                 acc["stripes"].append(eng.stripes(job["r0"], job["c0"], plan["pad"], ignore_diags=job["ignore_diags"],
                                                   mode=job["mode"]))
         return acc
@@ -1309,7 +1318,13 @@ class PileUpper:
             raise ValueError("Cannot do by-window pileups for local")
         if self.kind != "bed":
             raise ValueError("Can't make by-window pileups without making combinations")
-        pups = self.pileupsWithControl(nproc=nproc, _by_window=True)
+        if self.store_stripes:
+            # per-feature stripe lists: the reference's own route (postprocess_func=group_by_region, :1724-1726) —
+            # windows from pup_extract, grouping on the host
+            from .lib.puputils import group_by_region
+            pups = self.pileupsWithControl(nproc=nproc, postprocess_func=group_by_region)
+        else:
+            pups = self.pileupsWithControl(nproc=nproc, _by_window=True)
         is_all = pups["group"].apply(lambda g: isinstance(g, str) and g == "all")
         coords = pd.DataFrame([("all", -1, -1) if a else tuple(g) for a, g in zip(is_all, pups["group"])],
                               index=pups.index, columns=["chrom", "start", "end"])

@@ -183,9 +183,9 @@ def finalize_callback_pileups(pu, pileups, groupby, want_control, extra_sum_func
     if pu.store_stripes:
         # coordinates were joined with "." per snippet and are split again here (coolpup.py:1170-1182, 1557-1560)
         stripes = {}
-        for key in roi.index:
-            co = np.vstack([c.split(".") for c in roi.loc[key, "coordinates"]])
-            stripes[key] = (co, np.vstack(roi.loc[key, "horizontal_stripe"]), np.vstack(roi.loc[key, "vertical_stripe"]))
+        for i, key in enumerate(roi.index):          # positional: tuple keys would be read as multi-axis labels
+            co = np.vstack([c.split(".") for c in roi["coordinates"].iloc[i]])
+            stripes[key] = (co, np.vstack(roi["horizontal_stripe"].iloc[i]), np.vstack(roi["vertical_stripe"].iloc[i]))
     return _finalize_frames(pu, roi, ctrl, groupby, want_control, stripes, extra_sum_funcs=extra_sum_funcs)
 
 

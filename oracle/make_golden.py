@@ -187,6 +187,8 @@ def scenarios():
         maxdist=2_000_000)
     add("G10b_by_window_controls", "small", bed.groupby("chrom").head(12), features_format="bed", flank=50_000,
         by_window=True, nshifts=2, seed=10, maxdist=4_000_000)
+    add("G10c_by_window_stripes", "small", bed.groupby("chrom").head(10), features_format="bed", flank=50_000,
+        by_window=True, store_stripes=True, maxdist=4_000_000)
     add("G11_stripes_raw", "small", bedpe, store_stripes=True, clr_weight_name=None, min_diag=0, **base)
     add("G11b_stripes_controls_strand", "small", bedpe, store_stripes=True, nshifts=2, seed=12, by_strand=True, **base)
     add("G11c_stripes_expected_ooe_view", "small", bedpe, view=view_sub, expected=exp_view, store_stripes=True, **base)
@@ -206,6 +208,10 @@ def scenarios():
         rescale_flank=1, rescale_size=33, expected=exp_chrom, ooe=False)
     add("G12f_rescale_bed_combinations", "small", tads, features_format="bed", rescale=True, rescale_flank=1,
         rescale_size=25, mindist=0)
+    add("G12g_rescale_local_stripes_expected", "small", tads, features_format="bed", local=True, rescale=True,
+        rescale_flank=1, rescale_size=33, expected=exp_chrom, store_stripes=True)
+    add("G12h_rescale_bedpe_stripes_controls", "small", bedpe.iloc[:100], features_format="bedpe", rescale=True,
+        rescale_flank=2, rescale_size=15, nshifts=1, seed=23, flank=100_000, store_stripes=True)
     # the reference's own stripe test (tests/test_coolpup.py:143-172): raw counts, ignore_diags=0, first coordinates row
     # known-answer tests of the reference's own test-suite (tests/test_coolpup.py), n depends on coordinates only
     toy_kw = dict(features_format="bed", flank=2_000_000, mindist=0)
@@ -324,9 +330,16 @@ def callback_goldens(ref, coolers, index):
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="", help="comma list of scenario names: (re)generate just these and merge them "
+                                               "into index.json; coolers / streams / regions files are left alone")
+    only = [x for x in ap.parse_args().only.split(",") if x]
     os.makedirs(GOLD, exist_ok=True)
     ref = refshim.import_reference()
     coolers, S = scenarios()
+    if only:
+        S = [sc for sc in S if sc["name"] in only]
     # ---- coolers ------------------------------------------------------------------------------------------
     blob = {}
     for name, c in coolers.items():
@@ -339,7 +352,8 @@ def main():
         for col in ("weight", "cov_tot_raw", "cov_cis_raw"):
             blob[f"{name}__{col}"] = c.bins()[col][:].values
         blob[f"{name}__filename"] = np.array(c.filename)
-    np.savez_compressed(os.path.join(GOLD, "coolers.npz"), **blob)
+    if not only:
+        np.savez_compressed(os.path.join(GOLD, "coolers.npz"), **blob)
 
     streams, index = {}, []
     for sc in S:
@@ -399,6 +413,12 @@ def main():
                 arr = np.array([[r["stBin1"], r["stBin2"], 0 if r["kind"] == "ROI" else 1] for r in rows],
                                dtype=np.int64).reshape(-1, 3)
                 streams[f"{sc['name']}|{r1}|{r2}"] = arr
+    if only:
+        names = [sc["name"] for sc in scenarios()[1]]
+        have = set(json.load(open(os.path.join(GOLD, "index.json")))) | set(index)
+        with open(os.path.join(GOLD, "index.json"), "w") as f:
+            json.dump([n for n in names if n in have], f, indent=0)
+        return
     np.savez_compressed(os.path.join(GOLD, "streams.npz"), **streams)
 
     # ---- raw per-region tiles from the reference's pileup_region (un-normalised sums) --------------------------

@@ -133,6 +133,20 @@ def oracle_run_plan(pu, plan):
                     "tile": np.zeros(len(job["r0"]), np.int32), "flip": None, "tile_ptr": np.array([0, len(job["r0"])])}
             W = 2 * plan["pad"] + 1
             h = np.empty((len(job["r0"]), W)); v = np.empty((len(job["r0"]), W))
+            if "h" in job:      # rescaled: stripes of the zoomed windows
+                if big is None:
+                    nb = indptr.shape[0] - 1
+                    big = po.symmetric_csr(indptr, col, cnt, weight, 0, nb, 0, nb)
+                fake["h"], fake["w"] = job["h"], job["w"]
+                for expected, sc in iter_expected_subcalls(plan, fake):
+                    win = po.windows_scipy(big, 0, 0, weight, None, expected, sc["r0"], sc["c0"], plan["pad"],
+                                           job["ignore_diags"], sc["mode"], h=sc["h"], w=sc["w"])[0]
+                    for k in range(len(sc["r0"])):
+                        sel = np.flatnonzero((job["r0"] == sc["r0"][k]) & (job["c0"] == sc["c0"][k])
+                                             & (job["h"] == sc["h"][k]) & (job["w"] == sc["w"][k]))
+                        h[sel] = win[k][plan["pad"], :]; v[sel] = win[k][::-1, plan["pad"]]
+                acc["stripes"].append((h, v))
+                continue
             pos = {int(a) * (1 << 32) + int(b): i for i, (a, b) in enumerate(zip(job["r0"], job["c0"]))}
             for expected, sc in iter_expected_subcalls(plan, fake):
                 hh, vv = po.stripes_c(indptr, col, cnt, weight, expected, sc["r0"], sc["c0"], plan["pad"],
@@ -143,3 +157,18 @@ def oracle_run_plan(pu, plan):
             del pos
             acc["stripes"].append((h, v))
     return acc
+
+
+def oracle_windows(pu, expected, r0, c0, pad, height=None, width=None, ignore_diags=2, mode=0, coverage=False):
+    """CPU stand-in for PileupEngine.extract (PileUpper._window_source hook) built on the numpy/scipy oracle."""
+    from oracle import pileup_oracle as po
+    indptr, col, cnt = pu._aclr.pixel_table()
+    bins = pu.clr.bins()
+    weight = bins[pu.clr_weight_name][:].values if pu.clr_weight_name else None
+    cov = bins[pu.coverage_norm][:].values if pu.coverage_norm else None
+    if not hasattr(pu, "_oracle_big"):
+        nb = indptr.shape[0] - 1
+        pu._oracle_big = po.symmetric_csr(indptr, col, cnt, weight, 0, nb, 0, nb)
+    data, cs, ce = po.windows_scipy(pu._oracle_big, 0, 0, weight, cov, expected, r0, c0, pad, ignore_diags, mode,
+                                    h=height, w=width)
+    return (data, cs, ce) if coverage else (data, None, None)

@@ -34,19 +34,6 @@ NAMES = ["G13a_bedpe_controls_collect_centre", "G13b_rescale_local_expected_doma
          "G13g_band_group_postprocess", "G13h_ignore_group_order_strands", "G13i_raw_covnorm_double"]
 
 
-def _oracle_windows(pu, expected, r0, c0, pad, height=None, width=None, ignore_diags=2, mode=0, coverage=False):
-    indptr, col, cnt = pu._aclr.pixel_table()
-    bins = pu.clr.bins()
-    weight = bins[pu.clr_weight_name][:].values if pu.clr_weight_name else None
-    cov = bins[pu.coverage_norm][:].values if pu.coverage_norm else None
-    if not hasattr(pu, "_oracle_big"):
-        nb = indptr.shape[0] - 1
-        pu._oracle_big = po.symmetric_csr(indptr, col, cnt, weight, 0, nb, 0, nb)
-    data, cs, ce = po.windows_scipy(pu._oracle_big, 0, 0, weight, cov, expected, r0, c0, pad, ignore_diags, mode,
-                                    h=height, w=width)
-    return (data, cs, ce) if coverage else (data, None, None)
-
-
 def _check(name, df, rtol):
     z = np.load(os.path.join(gu.GOLD, name + ".npz"))
     gu.compare(z, df, rtol)
@@ -64,7 +51,7 @@ def _check(name, df, rtol):
 
 
 class _OraclePileUpper(coolpup.PileUpper):
-    _window_source = staticmethod(lambda pu, *a, **k: _oracle_windows(pu, *a, **k))
+    _window_source = staticmethod(gu.oracle_windows)
 
 
 class _HostMod:
