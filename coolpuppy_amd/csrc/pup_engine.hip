@@ -263,7 +263,7 @@ int pup_load_pixels(pup_ctx* c, const int64_t* bin1_offset, const void* bin2_id,
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_px = false; c->have_idx = false;
     HIPCHK(c, c->indptr.reserve((size_t)nbins + 1));
-    HIPCHK(c, c->px.reserve((size_t)std::max<int64_t>(nnz, 1)));
+    HIPCHK(c, c->px.reserve((size_t)nnz + 64));         // +64: K3 reads pixel pairs (16-byte loads) across a row's end
     HIPCHK(c, c->cnt32.reserve((size_t)nnz + 64));     // +64: the register-tile kernel loads counts unconditionally
     HIPCHK(c, hipMemset(c->cnt32.p + nnz, 0, 64 * sizeof(int)));
     HIPCHK(c, hipMemcpy(c->indptr.p, bin1_offset, ((size_t)nbins + 1) * sizeof(long long), hipMemcpyHostToDevice));
@@ -387,8 +387,8 @@ int pup_coverage(pup_ctx* c, const int64_t* chrom_offset, int32_t n_chroms, int3
     d_tab.release(); d_cov.release();
     if (status != PUP_OK) return status;
     for (size_t i = 0; i < nb; ++i) {
-        if (cov_cis) cov_cis[i] = (double)(h[nb + i] - h[i]);      // total minus inter-chromosomal
-        if (cov_tot) cov_tot[i] = (double)h[nb + i];
+        if (cov_cis) cov_cis[i] = (double)h[nb + i];
+        if (cov_tot) cov_tot[i] = (double)(h[nb + i] + h[i]);      // intra- plus inter-chromosomal
     }
     return PUP_OK;
 }

@@ -1143,44 +1143,55 @@ __global__ __launch_bounds__(64 * kRedParts) void reduce_partials_kernel(
 // a workgroup owns kCovRows consecutive rows; row sums are wave-reduced, column sums go to an LDS histogram over
 // the kCovCols columns following the block's first row (where almost all cis mass lies) and to global integer
 // atomics beyond it.  Integer (u64) accumulation: exact and order-independent.
-constexpr int kCovRows = 32;
+constexpr int kCovRows = 64;
 constexpr int kCovCols = 4096;
-// cov_tot accumulates every pixel; cov_trans only inter-chromosomal pixels (rare): cov_cis = cov_tot - cov_trans
+// cov_cis accumulates intra-chromosomal pixels, cov_trans inter-chromosomal ones (one atomic per pixel either way);
+// the host forms cov_tot = cov_cis + cov_trans.  A wave streams its row with 16-byte loads (two pixels per lane), two
+// loads in flight per lane: the pass is bound by load latency, not by the LDS atomics (the distinct columns of one
+// row never collide).  Columns beyond the block's LDS window and all trans columns take global atomics.
 __global__ __launch_bounds__(256) void coverage_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
                                                        const IdxChrom* __restrict__ chroms, int n_chrom, int ignore_diags,
-                                                       unsigned long long* cov_trans, unsigned long long* cov_tot,
+                                                       unsigned long long* cov_trans, unsigned long long* cov_cis,
                                                        long long nbins) {
-    __shared__ unsigned long long h_tot[kCovCols];
+    __shared__ unsigned long long h_cis[kCovCols];
     const long long row0 = (long long)blockIdx.x * kCovRows;
-    for (int t = threadIdx.x; t < kCovCols; t += blockDim.x) h_tot[t] = 0ull;
+    for (int t = threadIdx.x; t < kCovCols; t += blockDim.x) h_cis[t] = 0ull;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     for (long long r = row0 + wave; r < row0 + kCovRows && r < nbins; r += nwave) {
         int lo = 0, hi = n_chrom;
         while (lo < hi) { const int m = (lo + hi) >> 1; if (chroms[m].end <= r) lo = m + 1; else hi = m; }
         const long long chrom_end = lo < n_chrom ? chroms[lo].end : nbins;
-        unsigned long long s_trans = 0, s_tot = 0;
+        unsigned long long s_trans = 0, s_cis = 0;
         const long long b = indptr[r], e = indptr[r + 1];
-        for (long long k = b + lane; k < e; k += 64) {
-            const int2 pc = px[k];
-            const long long d = (long long)pc.x - r;
-            const unsigned long long w = ((d < 0 ? -d : d) < ignore_diags) ? 0ull : (unsigned long long)(unsigned)pc.y;
-            s_tot += w;
-            if (pc.x >= chrom_end) { s_trans += w; atomicAdd(&cov_trans[pc.x], w); }
-            const long long rel = (long long)pc.x - row0;
-            if (rel < kCovCols) atomicAdd(&h_tot[rel], w);
-            else atomicAdd(&cov_tot[pc.x], w);
+        auto add = [&](long long k, int col, int cnt) __attribute__((always_inline)) {
+            if (k < b || k >= e) return;
+            const long long d = (long long)col - r;
+            const unsigned long long w = ((d < 0 ? -d : d) < ignore_diags) ? 0ull : (unsigned long long)(unsigned)cnt;
+            if (col >= chrom_end) { s_trans += w; atomicAdd(&cov_trans[col], w); return; }
+            s_cis += w;
+            const long long rel = (long long)col - row0;
+            if (rel < kCovCols) atomicAdd(&h_cis[rel], w);
+            else atomicAdd(&cov_cis[col], w);
+        };
+        // pixel pairs at even offsets (16-byte aligned); the table is padded, so the pair straddling e is readable
+        for (long long k = (b & ~1LL) + 2 * lane; k < e; k += 256) {
+            const int4 v0 = *reinterpret_cast<const int4*>(px + k);
+            const bool two = k + 128 < e;
+            const int4 v1 = two ? *reinterpret_cast<const int4*>(px + k + 128) : int4{0, 0, 0, 0};
+            add(k, v0.x, v0.y); add(k + 1, v0.z, v0.w);
+            if (two) { add(k + 128, v1.x, v1.y); add(k + 129, v1.z, v1.w); }
         }
-        for (int off = 32; off > 0; off >>= 1) { s_trans += __shfl_down(s_trans, off); s_tot += __shfl_down(s_tot, off); }
+        for (int off = 32; off > 0; off >>= 1) { s_trans += __shfl_down(s_trans, off); s_cis += __shfl_down(s_cis, off); }
         if (lane == 0) {
-            atomicAdd(&h_tot[r - row0], s_tot);
+            atomicAdd(&h_cis[r - row0], s_cis);
             if (s_trans) atomicAdd(&cov_trans[r], s_trans);
         }
     }
     __syncthreads();
     for (int t = threadIdx.x; t < kCovCols; t += blockDim.x) {
         const long long c = row0 + t;
-        if (c < nbins && h_tot[t]) atomicAdd(&cov_tot[c], h_tot[t]);
+        if (c < nbins && h_cis[t]) atomicAdd(&cov_cis[c], h_cis[t]);
     }
 }
 
