@@ -464,24 +464,40 @@ class CoordCreator:
             c["gc"][name] = (codes.astype(np.int64), uniq)
         return c["gc"][name]
 
+    def _pair_bucket(self, k1, k2):
+        """Rows of self.intervals with (chrom1, chrom2) codes (k1, k2), ascending — from one stable sort of the
+        pair codes, so selecting the rows of every region (pair) costs O(rows of that pair), not O(all rows)."""
+        c = self._cache()
+        if "pair_order" not in c:
+            nc = len(c["chrom_code"]) + 1
+            code = c["c1"].astype(np.int64) * nc + c["c2"]
+            c["pair_order"] = np.argsort(code, kind="stable")
+            c["pair_ptr"] = np.concatenate([[0], np.cumsum(np.bincount(code, minlength=nc * nc))])
+            c["pair_nc"] = nc
+        if k1 < 0 or k2 < 0:
+            return np.zeros(0, np.int64)
+        code = k1 * c["pair_nc"] + k2
+        return c["pair_order"][c["pair_ptr"][code]:c["pair_ptr"][code + 1]]
+
     def _rows_pairs_region(self, region):
         chrom, start, end = region
         c = self._cache()
         k = c["chrom_code"].get(str(chrom), -1)
-        m = ((c["c1"] == k) & (c["c2"] == k) & (c["start1"] >= start) & (c["end1"] < end)
-             & (c["start2"] >= start) & (c["end2"] < end))
-        return np.flatnonzero(m)
+        rows = self._pair_bucket(k, k)
+        m = ((c["start1"][rows] >= start) & (c["end1"][rows] < end) & (c["start2"][rows] >= start)
+             & (c["end2"][rows] < end))
+        return rows if m.all() else rows[m]
 
     def _rows_trans_pairs(self, region1, region2):
         c1n, s1, e1 = region1
         c2n, s2, e2 = region2
         c = self._cache()
         k1, k2 = c["chrom_code"].get(str(c1n), -1), c["chrom_code"].get(str(c2n), -1)
-        fwd = ((c["c1"] == k1) & (c["c2"] == k2) & (c["start1"] >= s1) & (c["end1"] < e1)
-               & (c["start2"] >= s2) & (c["end2"] < e2))
-        rev = ((c["c2"] == k1) & (c["c1"] == k2) & (c["start2"] >= s1) & (c["end2"] < e1)
-               & (c["start1"] >= s2) & (c["end1"] < e2))
-        return np.concatenate([np.flatnonzero(fwd), np.flatnonzero(rev)])      # same order as the reference's concat
+        f = self._pair_bucket(k1, k2)
+        fwd = f[(c["start1"][f] >= s1) & (c["end1"][f] < e1) & (c["start2"][f] >= s2) & (c["end2"][f] < e2)]
+        r = self._pair_bucket(k2, k1)
+        rev = r[(c["start2"][r] >= s1) & (c["end2"][r] < e1) & (c["start1"][r] >= s2) & (c["end1"][r] < e2)]
+        return np.concatenate([fwd, rev])      # same order as the reference's concat
 
     def _rows_region(self, region):
         chrom, start, end = region
@@ -778,6 +794,13 @@ class PileUpper:
         n = self.rescale_size if self.rescale else 2 * self.pad_bins + 1
         return np.zeros((n, n))
 
+    def _region_tuple(self, name):
+        """(chrom, start, end) of a view region; cached — a trans pile-up asks 2 x 253 times."""
+        cache = self.__dict__.setdefault("_region_tuples", {})
+        if name not in cache:
+            cache[name] = tuple(self.view_df.loc[name, ["chrom", "start", "end"]])
+        return cache[name]
+
     # -- host side of pileup_region: windows of one region (pair) as engine inputs ----------------------------
     def _region_pairs(self):
         if self.trans:
@@ -809,8 +832,7 @@ class PileUpper:
         """
         if region2 is None:
             region2 = region1
-        reg1 = tuple(self.view_df.loc[region1, ["chrom", "start", "end"]])
-        reg2 = tuple(self.view_df.loc[region2, ["chrom", "start", "end"]])
+        reg1, reg2 = self._region_tuple(region1), self._region_tuple(region2)
         carry = columns
         # keep_table (callback path): rows must carry the reference's own column values (e.g. band tuples), so
         # even the built-in modify functions run in their DataFrame form

@@ -53,8 +53,9 @@ struct pup_ctx {
     bool have_bal = false;
     DevBuf<pup::IdxBlock> idx;
     DevBuf<pup::IdxChrom> idx_chrom;
+    DevBuf<unsigned> rowseg;               // [nbins][n_chrom+1] search bounds per (row, chromosome), see K1Args
     int n_chrom = 0;
-    bool have_idx = false;
+    bool have_idx = false, have_rowseg = false;
     long long idx_bytes = 0;
     DevBuf<double> weight, cov, expv, exp_pair;
     DevBuf<pup::ExpRegion> exp_regions;
@@ -340,6 +341,16 @@ int pup_build_index(pup_ctx* c, const int64_t* chrom_offset, int32_t n_chroms, i
                        c->indptr.p, c->px.p, c->idx_chrom.p, n_chroms, c->idx.p, c->nbins);
     hipLaunchKernelGGL(pup::index_rank_kernel, dim3((unsigned)((c->nbins + 255) / 256)), dim3(256), 0, c->stream,
                        c->indptr.p, c->idx_chrom.p, n_chroms, c->idx.p, c->nbins);
+    // search bounds for windows the rank-bitmap index does not cover (inter-chromosomal): skipped when a row can
+    // hold 2^32 pixels or the table would be out of proportion (many small contigs)
+    c->have_rowseg = false;
+    const long long seg_entries = c->nbins * (long long)(n_chroms + 1);
+    if (n_chroms > 1 && c->nnz < 0xffffffffLL && seg_entries * 4 <= std::max<long long>(c->nnz, 1 << 20)) {
+        HIPCHK(c, c->rowseg.reserve((size_t)seg_entries));
+        hipLaunchKernelGGL(pup::rowseg_kernel, dim3((unsigned)((seg_entries + 255) / 256)), dim3(256), 0, c->stream,
+                           c->indptr.p, c->px.p, c->idx_chrom.p, n_chroms, c->rowseg.p, c->nbins);
+        c->have_rowseg = true;
+    }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->n_chrom = n_chroms; c->have_idx = true; c->idx_bytes = bytes;
@@ -685,6 +696,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     const bool use_idx = c->have_idx && !(c->variant & 1);
     a.idx = use_idx ? c->idx.p : nullptr; a.idx_chrom = use_idx ? c->idx_chrom.p : nullptr;
     a.n_chrom = use_idx ? c->n_chrom : 0;
+    a.rowseg = (use_idx && c->have_rowseg) ? c->rowseg.p : nullptr;
     a.weight = c->have_weight ? c->weight.p : nullptr;
     a.cov = c->have_cov ? c->cov.p : nullptr;
     a.expv = (c->nexp > 0 || (c->n_exp_regions > 0 && !c->have_exp_pair)) ? c->expv.p : nullptr;
@@ -844,6 +856,7 @@ int pup_extract(pup_ctx* c, const int32_t* r0, const int32_t* c0, const int32_t*
         const bool use_idx = c->have_idx && !(c->variant & 1);
         a.idx = use_idx ? c->idx.p : nullptr; a.idx_chrom = use_idx ? c->idx_chrom.p : nullptr;
         a.n_chrom = use_idx ? c->n_chrom : 0;
+    a.rowseg = (use_idx && c->have_rowseg) ? c->rowseg.p : nullptr;
         a.weight = c->have_weight ? c->weight.p : nullptr;
         a.cov = c->have_cov ? c->cov.p : nullptr;
         a.expv = (c->nexp > 0 || (c->n_exp_regions > 0 && !c->have_exp_pair)) ? c->expv.p : nullptr;

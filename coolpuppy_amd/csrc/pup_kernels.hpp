@@ -76,6 +76,9 @@ struct K1Args {
     const IdxBlock*  idx;      // rank-bitmap index or nullptr
     const IdxChrom*  idx_chrom;
     int              n_chrom;
+    const unsigned*  rowseg;   // [nbins][n_chrom+1] or nullptr: offset, from the row's first pixel, of its first pixel
+                               //          in chromosome k (entry n_chrom = row length): bounds the binary search
+                               //          of a window that the rank-bitmap index does not cover (trans)
     const double*    weight;   // [nbins] or nullptr (raw)
     const double*    cov;      // [nbins] or nullptr
     const double*    expv;     // [nexp] or nullptr: ONE by-diagonal vector (nexp >= 2) or ONE scalar (nexp == 1) ...
@@ -371,12 +374,15 @@ struct RowLoc { long long pos; unsigned bits; };
 struct __attribute__((packed, aligned(8))) U64x2 { unsigned long long a, b; };
 struct __attribute__((packed, aligned(8))) F64x2 { double a, b; };
 
-// binary search for a row's first pixel with column >= c_first, then the presence bits of CHW columns
+// binary search for a row's first pixel with column >= c_first, then the presence bits of CHW columns.
+// seg (nullable): the row's {first, one-past-last} pixel offsets of the chromosome holding c_first.
 template <int CHW>
-__device__ __forceinline__ RowLoc search_row_chunk(const K1Args& a, int r, int c_first, unsigned long long& nprobe) {
-    long long lo = a.indptr[r];
+__device__ __forceinline__ RowLoc search_row_chunk(const K1Args& a, int r, int c_first, unsigned long long& nprobe,
+                                                   const unsigned* __restrict__ seg = nullptr) {
+    const long long base = a.indptr[r];
     const long long h = a.indptr[r + 1];
-    long long b = h;
+    long long lo = base, b = h, hend = h;
+    if (seg) { lo = base + seg[0]; b = hend = base + seg[1]; }     // nothing past the chromosome's segment can match
     while (lo < b) {
         const long long m = (lo + b) >> 1;
         if (a.px[m].x < c_first) lo = m + 1; else b = m;
@@ -385,12 +391,41 @@ __device__ __forceinline__ RowLoc search_row_chunk(const K1Args& a, int r, int c
     unsigned bits = 0;
 #pragma unroll
     for (int i = 0; i < CHW; ++i) {
-        if (lo + i < h) {
+        if (lo + i < hend) {
             const int d = a.px[lo + i].x - c_first;
             if (d < CHW) bits |= 1u << d;
         }
     }
     return {lo, bits};
+}
+
+// chromosome (index into idx_chrom) holding bin c, cached across snippets; wave-uniform
+struct ChromOf { int start = 0, end = -1, k = 0; };
+__device__ __forceinline__ int chrom_of(const K1Args& a, ChromOf& cc, int c) {
+    if (!(c >= cc.start && c < cc.end)) {
+        int lo = 0, hi = a.n_chrom;
+        while (lo < hi) { const int m = (lo + hi) >> 1; if (a.idx_chrom[m].end <= c) lo = m + 1; else hi = m; }
+        if (lo >= a.n_chrom) lo = a.n_chrom - 1;
+        cc.k = lo; cc.start = a.idx_chrom[lo].start; cc.end = a.idx_chrom[lo].end;
+    }
+    return cc.k;
+}
+
+// one thread per (row, chromosome boundary): rowseg[row][k] = pixels of the row with column < start of chromosome k
+__global__ __launch_bounds__(256) void rowseg_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
+                                                     const IdxChrom* __restrict__ chroms, int n_chrom,
+                                                     unsigned* __restrict__ rowseg, long long nbins) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int stride = n_chrom + 1;
+    if (t >= nbins * stride) return;
+    const long long r = t / stride;
+    const int k = (int)(t - r * stride);
+    const long long base = indptr[r], end = indptr[r + 1];
+    if (k == n_chrom) { rowseg[t] = (unsigned)(end - base); return; }
+    const int c_first = chroms[k].start;
+    long long lo = base, hi = end;
+    while (lo < hi) { const long long m = (lo + hi) >> 1; if (px[m].x < c_first) lo = m + 1; else hi = m; }
+    rowseg[t] = (unsigned)(lo - base);
 }
 
 // ---- K1r: register-tile variant for small windows (W <= 32) ----------------------------------------------
@@ -444,6 +479,7 @@ __global__ __launch_bounds__(kWave, rt_min_waves(W)) void pileup_regtile_kernel(
     const bool have_idx = a.idx != nullptr;
     const double qnan = __builtin_nan("");
     ExpCache ecache;
+    ChromOf colchrom;
 
     const int ck = a.block_chunk[blockIdx.x];
     if (ck < 0) return;                                               // padding workgroup (wave-uniform)
@@ -498,7 +534,9 @@ __global__ __launch_bounds__(kWave, rt_min_waves(W)) void pileup_regtile_kernel(
             const U64x2 w = *reinterpret_cast<const U64x2*>(reinterpret_cast<const char*>(base) + 16 + 8 * g.ws);
             g.cur = w.a; g.nxt = w.b;
         } else {
-            const RowLoc loc = search_row_chunk<CH>(a, r, g.c0 + qs, nprobe);
+            const unsigned* seg = nullptr;
+            if (a.rowseg != nullptr) seg = a.rowseg + (long long)r * (a.n_chrom + 1) + chrom_of(a, colchrom, g.c0);
+            const RowLoc loc = search_row_chunk<CH>(a, r, g.c0 + qs, nprobe, seg);
             g.spos = loc.pos; g.sbits = loc.bits;
         }
         // masked-bin bits of the window's rows and columns: wave-uniform -> scalar loads and scalar shifts
@@ -657,6 +695,7 @@ __global__ __launch_bounds__(kWave, 3) void pileup_band_kernel(K1Args a) {
     const bool have_idx = a.idx != nullptr;
     const double qnan = __builtin_nan("");
     ExpCache ecache;
+    ChromOf colchrom;
 
     double   sum[CH];
     unsigned num[CH];
@@ -704,7 +743,9 @@ __global__ __launch_bounds__(kWave, 3) void pileup_band_kernel(K1Args a) {
             const U64x2 w = *reinterpret_cast<const U64x2*>(reinterpret_cast<const char*>(base) + 16 + 8 * g.ws);
             g.cur = w.a; g.nxt = w.b;
         } else {
-            const RowLoc loc = search_row_chunk<CH>(a, r, g.c0 + qs, nprobe);
+            const unsigned* seg = nullptr;
+            if (a.rowseg != nullptr) seg = a.rowseg + (long long)r * (a.n_chrom + 1) + chrom_of(a, colchrom, g.c0);
+            const RowLoc loc = search_row_chunk<CH>(a, r, g.c0 + qs, nprobe, seg);
             g.spos = loc.pos; g.sbits = loc.bits;
         }
         g.rw = a.badbits[r >> 6];
@@ -723,11 +764,17 @@ __global__ __launch_bounds__(kWave, 3) void pileup_band_kernel(K1Args a) {
             pos = (long long)(g.p0 + cum + (unsigned long long)__popcll(g.cur & ((1ull << g.sh) - 1ull)));
         } else { pos = g.spos; bits = g.sbits & chmask; }
         double v[CH];
+        // sparse (inter-chromosomal) windows: most bands hold no pixel at all -> skip the value loads wave-wide
+        if (g.indexed || __ballot(bits != 0u) != 0ull) {
 #pragma unroll
-        for (int i = 0; i < CH; i += 2) {
-            const F64x2 pr = *reinterpret_cast<const F64x2*>(a.bal + pos + __popc(bits & ((1u << i) - 1u)));
-            v[i] = pr.a;
-            if (i + 1 < CH) v[i + 1] = ((bits >> i) & 1u) ? pr.b : pr.a;
+            for (int i = 0; i < CH; i += 2) {
+                const F64x2 pr = *reinterpret_cast<const F64x2*>(a.bal + pos + __popc(bits & ((1u << i) - 1u)));
+                v[i] = pr.a;
+                if (i + 1 < CH) v[i + 1] = ((bits >> i) & 1u) ? pr.b : pr.a;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) v[i] = 0.0;
         }
         const int r = g.r0 + pg, cc = g.c0 + qs;
         const int csh = cc & 63;

@@ -19,16 +19,21 @@ from coolpuppy_amd import coolpup, synth  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--plain", action="store_true", help="no by-distance / by-strand grouping")
+    ap.add_argument("--trans", action="store_true", help="config-4 shape: inter-chromosomal pairs, pad=25, no controls")
     ap.add_argument("--pairs", type=int, default=1_000_000)
     ap.add_argument("--top", type=int, default=40)
     a = ap.parse_args()
     warnings.simplefilter("ignore")
     hg = synth.make_cooler({c: synth.HG38[c] for c in synth.HG38}, binsize=10_000, lam=20, seed=1000, name="sparse_hg38",
                            parallel=True)
-    feats = synth.random_cis_pairs(hg, a.pairs, seed=42, strands=True)
-    kw = dict(features_format="bedpe", flank=100_000, nshifts=10, seed=0)
-    if not a.plain:
-        kw.update(by_distance=True, by_strand=True)
+    if a.trans:
+        feats = synth.random_trans_pairs(hg, a.pairs // 2, seed=43)
+        kw = dict(features_format="bedpe", flank=250_000, trans=True)
+    else:
+        feats = synth.random_cis_pairs(hg, a.pairs, seed=42, strands=True)
+        kw = dict(features_format="bedpe", flank=100_000, nshifts=10, seed=0)
+        if not a.plain:
+            kw.update(by_distance=True, by_strand=True)
     coolpup.pileup(hg, feats, **kw)
     for _ in range(2):
         t = time.time()
