@@ -609,14 +609,15 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     std::vector<unsigned char> cf;
     std::vector<int> cs;
     std::vector<std::vector<int>> xcd_list((size_t)n_xcd);       // entries: chunk * nbands + band
-    long long group_no = 0;
+    struct Group { long long key; int first_chunk, waves; };
+    std::vector<Group> groups;
+    const bool host_pos = !(mode & PUP_MODE_DEVPTR);
     auto add_run = [&](long long b, long long e, unsigned char flip) {
         for (long long g0 = b; g0 < e; g0 += (long long)S * C) {
             const long long g1 = std::min(e, g0 + (long long)S * C);
             const int waves = (int)std::min<long long>(S, std::max<long long>(1, (g1 - g0 + 15) / 16));
-            auto& lst = xcd_list[(size_t)(group_no++ % n_xcd)];
+            groups.push_back(Group{host_pos ? (long long)r0[g0] : (long long)groups.size(), (int)cb.size(), waves});
             for (int j = 0; j < waves; ++j) {
-                for (int b = 0; b < nbands; ++b) lst.push_back((int)cb.size() * nbands + b);
                 cb.push_back(g0 + j); ce.push_back(g1); cs.push_back(waves); cf.push_back(flip);
             }
         }
@@ -628,6 +629,17 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         add_run(b, f, 0);
         add_run(f, e, 1);
         tile_chunk_ptr[(size_t)t + 1] = (long long)cb.size();
+    }
+    // Launch order = matrix position, across tiles: with many tiles (by-distance x by-strand ...) every tile walks
+    // the whole genome, so running the tiles one after the other re-reads every matrix row once per tile from HBM;
+    // dealing the groups out by the row of their first snippet lets the groups that are in flight together — of
+    // whatever tile — share rows in L2 / MALL.  (Chunk numbering, hence the reduction, stays tile-contiguous.)
+    if (host_pos && c->T > 1)
+        std::stable_sort(groups.begin(), groups.end(), [](const Group& x, const Group& y) { return x.key < y.key; });
+    for (size_t g = 0; g < groups.size(); ++g) {
+        auto& lst = xcd_list[g % (size_t)n_xcd];
+        for (int j = 0; j < groups[g].waves; ++j)
+            for (int b = 0; b < nbands; ++b) lst.push_back((groups[g].first_chunk + j) * nbands + b);
     }
     size_t per_xcd = 0;
     for (auto& l : xcd_list) per_xcd = std::max(per_xcd, l.size());
