@@ -612,10 +612,12 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     struct Group { long long key; int first_chunk, waves; };
     std::vector<Group> groups;
     const bool host_pos = !(mode & PUP_MODE_DEVPTR);
+    std::vector<long long> group_start;                             // DEVPTR: first snippet of every group
     auto add_run = [&](long long b, long long e, unsigned char flip) {
         for (long long g0 = b; g0 < e; g0 += (long long)S * C) {
             const long long g1 = std::min(e, g0 + (long long)S * C);
             const int waves = (int)std::min<long long>(S, std::max<long long>(1, (g1 - g0 + 15) / 16));
+            if (!host_pos) group_start.push_back(g0);
             groups.push_back(Group{host_pos ? (long long)r0[g0] : (long long)groups.size(), (int)cb.size(), waves});
             for (int j = 0; j < waves; ++j) {
                 cb.push_back(g0 + j); ce.push_back(g1); cs.push_back(waves); cf.push_back(flip);
@@ -634,7 +636,25 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     // the whole genome, so running the tiles one after the other re-reads every matrix row once per tile from HBM;
     // dealing the groups out by the row of their first snippet lets the groups that are in flight together — of
     // whatever tile — share rows in L2 / MALL.  (Chunk numbering, hence the reduction, stays tile-contiguous.)
-    if (host_pos && c->T > 1)
+    if (!host_pos && c->T > 1 && !groups.empty()) {
+        // snippets are device-resident: fetch just the first row of every group
+        const int ng = (int)groups.size();
+        DevBuf<long long> d_pos; DevBuf<int> d_key;
+        std::vector<int> keys((size_t)ng);
+        hipError_t ge = d_pos.reserve((size_t)ng);
+        if (ge == hipSuccess) ge = d_key.reserve((size_t)ng);
+        if (ge == hipSuccess) ge = hipMemcpy(d_pos.p, group_start.data(), (size_t)ng * 8, hipMemcpyHostToDevice);
+        if (ge == hipSuccess) {
+            hipLaunchKernelGGL(pup::gather_int_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, c->stream, dr0,
+                               (const long long*)d_pos.p, d_key.p, ng);
+            ge = hipStreamSynchronize(c->stream);
+        }
+        if (ge == hipSuccess) ge = hipMemcpy(keys.data(), d_key.p, (size_t)ng * 4, hipMemcpyDeviceToHost);
+        d_pos.release(); d_key.release();
+        if (ge != hipSuccess) return fail(c, PUP_EHIP, "pup_accumulate: %s", hipGetErrorString(ge));
+        for (int g = 0; g < ng; ++g) groups[(size_t)g].key = keys[(size_t)g];
+    }
+    if (c->T > 1)
         std::stable_sort(groups.begin(), groups.end(), [](const Group& x, const Group& y) { return x.key < y.key; });
     for (size_t g = 0; g < groups.size(); ++g) {
         auto& lst = xcd_list[g % (size_t)n_xcd];

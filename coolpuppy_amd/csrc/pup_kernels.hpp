@@ -1348,6 +1348,12 @@ __global__ __launch_bounds__(256) void extract_windows_kernel(K1Args a, long lon
     }
 }
 
+// out[i] = src[pos[i]] (first-snippet rows of the launch groups when the snippets already live on the device)
+__global__ void gather_int_kernel(const int* __restrict__ src, const long long* __restrict__ pos, int* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[pos[i]];
+}
+
 // n[t] += dn[t]
 __global__ void add_counts_kernel(long long* n, const long long* dn, int T) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--sort", type=int, default=1)
+    ap.add_argument("--tiles", type=int, default=1, help="split ROI and control snippets over this many groups each")
     ap.add_argument("--variant", type=int, default=0, help="1 = ignore the rank-bitmap index")
     ap.add_argument("--group", type=str, default="0", help="comma list of waves-per-group values to sweep")
     a = ap.parse_args()
@@ -50,6 +51,14 @@ def main():
     order = np.lexsort((c, r, k)) if a.sort else np.argsort(k, kind="stable")
     r, c, k = r[order].astype(np.int32), c[order].astype(np.int32), k[order]
     tile_ptr = np.array([0, int((k == 0).sum()), len(k)], np.int64)
+    n_tiles = 2
+    if a.tiles > 1:
+        # by-distance x by-strand shape: every snippet gets one of a.tiles groups per kind (position order kept)
+        g = np.random.RandomState(1).randint(0, a.tiles, len(k)) + a.tiles * k.astype(np.int64)
+        o = np.argsort(g, kind="stable")
+        r, c, k = r[o], c[o], k[o]
+        n_tiles = 2 * a.tiles
+        tile_ptr = np.concatenate([[0], np.cumsum(np.bincount(g, minlength=n_tiles))]).astype(np.int64)
     print(f"snippets: {len(r)}", flush=True)
     eng = PileupEngine(0)
     t = time.time(); eng.load_pixels(*clr.pixel_table()); print(f"H2D pixels {time.time()-t:.2f}s")
@@ -58,7 +67,7 @@ def main():
     eng.set_profiling(True)
     for grp in [int(x) for x in a.group.split(",")]:
       eng.set_tuning(a.chunk, a.variant | (grp << 8))
-      eng.reset(2, a.pad)
+      eng.reset(n_tiles, a.pad)
       print("group_waves", grp, flush=True)
       for rep in range(a.reps):
           eng.clear_stats()
@@ -76,7 +85,7 @@ def main():
                             "probes_per_snip": round(st["probe_loads"] / n, 1),
                             "alg_GBps": round(alg_bytes / (st["k1_ms"] * 1e-3) / 1e9, 1)}), flush=True)
     out = eng.fetch()
-    print("n", out["n"], "center", out["sum"][:, a.pad, a.pad] / np.maximum(out["num"][:, a.pad, a.pad], 1))
+    print("n", out["n"][:4], "center", (out["sum"][:, a.pad, a.pad] / np.maximum(out["num"][:, a.pad, a.pad], 1))[:4])
 
 
 if __name__ == "__main__":

@@ -169,11 +169,16 @@ def main():
             r["nan_cells_in_pileup"] = int(np.isnan(df["data"].iloc[0]).sum())      # SURVEY: 61 for ignore_diags=2
             res.append(r)
     # ---- configs 3 and 4 on the human-scale table ---------------------------------------------------------------
-    if want is None or want & {"3", "4"}:
+    if want is None or want & {"2", "3", "4"}:
         t = time.time()
         hg = synth.make_cooler({c: synth.HG38[c] for c in synth.HG38}, binsize=10_000, lam=4200, seed=1000,
                                name="synthetic_hg38_10kb", parallel=True, trans_nnz=50_000_000)
         print(f"hg38-like cooler: {hg.nbins} bins, {hg.nnz} nnz, {time.time()-t:.1f}s", flush=True)
+    if want is None or "2" in want:
+        feats = synth.random_cis_pairs(hg, 1_000_000, seed=42, strands=True)
+        r, _ = run("configs[2] 1e6 pairs, nshifts=10 (the bench workload, through pileup())", hg, feats,
+                   dict(features_format="bedpe", flank=100_000, nshifts=10, seed=0))
+        res.append(r)
     if want is None or "3" in want:
         feats = synth.random_cis_pairs(hg, 1_000_000, seed=42, strands=True)
         r, _ = run("configs[3] 1e6 pairs, by-distance + by-strand, nshifts=10", hg, feats,
