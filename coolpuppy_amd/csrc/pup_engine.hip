@@ -68,9 +68,13 @@ struct pup_ctx {
     int T = 0, pad = 0, W = 0;
     // workspaces
     DevBuf<int> d_r0, d_c0, d_h, d_w;
-    DevBuf<unsigned char> d_chunk_flip;
-    DevBuf<int> d_chunk_stride, d_block_chunk, d_block_band;
-    DevBuf<long long> d_chunk_begin, d_chunk_end, d_seg1, d_seg2, d_dn;
+    // launch geometry: ONE device blob (one H2D copy per new geometry), the typed views below point into it
+    DevBuf<unsigned char> d_geom;
+    struct GeomView {
+        const long long *chunk_begin = nullptr, *chunk_end = nullptr, *seg1 = nullptr, *seg2 = nullptr, *dn = nullptr;
+        const int *chunk_stride = nullptr, *block_chunk = nullptr, *block_band = nullptr;
+        const unsigned char* chunk_flip = nullptr;
+    } gv;
     DevBuf<double> part_f64, slice_f64;
     DevBuf<unsigned> part_num;
     DevBuf<long long> slice_num;
@@ -237,9 +241,7 @@ void pup_destroy(pup_ctx* c) {
     collect_events(c);
     c->indptr.release(); c->px.release(); c->cnt32.release(); c->bal.release(); c->badbits.release(); c->idx.release(); c->idx_chrom.release(); c->weight.release(); c->cov.release(); c->expv.release(); c->exp_pair.release(); c->exp_regions.release();
     c->acc_f64.release(); c->acc_i64.release();
-    c->d_r0.release(); c->d_c0.release(); c->d_h.release(); c->d_w.release(); c->d_chunk_flip.release(); c->d_chunk_stride.release(); c->d_block_chunk.release(); c->d_block_band.release();
-    c->d_chunk_begin.release(); c->d_chunk_end.release(); c->d_seg1.release(); c->d_seg2.release();
-    c->d_dn.release();
+    c->d_r0.release(); c->d_c0.release(); c->d_h.release(); c->d_w.release(); c->d_geom.release();
     c->part_f64.release(); c->slice_f64.release(); c->part_num.release(); c->slice_num.release();
     c->counters.release(); c->d_err.release();
     for (auto& s : c->slots) if (s) (void)hipEventDestroy(s);
@@ -694,25 +696,35 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     const long long nslices = two_level ? (long long)seg1.size() - 1 : 0;
 
     HIPCHK(c, hipStreamSynchronize(c->stream));   // chunk/segment tables of the previous call are free now
-    HIPCHK(c, c->d_chunk_begin.reserve((size_t)nchunks)); HIPCHK(c, c->d_chunk_end.reserve((size_t)nchunks));
-    HIPCHK(c, c->d_seg2.reserve(seg2.size())); HIPCHK(c, c->d_dn.reserve((size_t)c->T));
     HIPCHK(c, c->part_f64.reserve((size_t)nchunks * Lf)); HIPCHK(c, c->part_num.reserve((size_t)nchunks * W2));
-    HIPCHK(c, hipMemcpy(c->d_chunk_begin.p, cb.data(), (size_t)nchunks * 8, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->d_chunk_end.p, ce.data(), (size_t)nchunks * 8, hipMemcpyHostToDevice));
-    HIPCHK(c, c->d_chunk_flip.reserve((size_t)nchunks));
-    HIPCHK(c, hipMemcpy(c->d_chunk_flip.p, cf.data(), (size_t)nchunks, hipMemcpyHostToDevice));
-    HIPCHK(c, c->d_chunk_stride.reserve((size_t)nchunks));
-    HIPCHK(c, hipMemcpy(c->d_chunk_stride.p, cs.data(), (size_t)nchunks * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(c, c->d_block_chunk.reserve((size_t)nblocks));
-    HIPCHK(c, hipMemcpy(c->d_block_chunk.p, block_chunk.data(), (size_t)nblocks * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(c, c->d_block_band.reserve((size_t)nblocks));
-    HIPCHK(c, hipMemcpy(c->d_block_band.p, block_band.data(), (size_t)nblocks * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->d_seg2.p, seg2.data(), seg2.size() * 8, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->d_dn.p, dn.data(), (size_t)c->T * 8, hipMemcpyHostToDevice));
-    if (two_level) {
-        HIPCHK(c, c->d_seg1.reserve(seg1.size()));
-        HIPCHK(c, hipMemcpy(c->d_seg1.p, seg1.data(), seg1.size() * 8, hipMemcpyHostToDevice));
-        HIPCHK(c, c->slice_f64.reserve((size_t)nslices * Lf)); HIPCHK(c, c->slice_num.reserve((size_t)nslices * W2));
+    if (two_level) { HIPCHK(c, c->slice_f64.reserve((size_t)nslices * Lf)); HIPCHK(c, c->slice_num.reserve((size_t)nslices * W2)); }
+    {
+        // pack every table into one host blob (8-byte aligned sections) -> one H2D copy
+        std::vector<unsigned char> blob;
+        auto put = [&](const void* src, size_t bytes) {
+            const size_t off = (blob.size() + 7) & ~(size_t)7;
+            blob.resize(off + bytes);
+            if (bytes) std::memcpy(blob.data() + off, src, bytes);
+            return off;
+        };
+        const size_t o_cb = put(cb.data(), (size_t)nchunks * 8), o_ce = put(ce.data(), (size_t)nchunks * 8);
+        const size_t o_s2 = put(seg2.data(), seg2.size() * 8), o_dn = put(dn.data(), (size_t)c->T * 8);
+        const size_t o_s1 = put(seg1.data(), seg1.size() * 8);
+        const size_t o_cs = put(cs.data(), (size_t)nchunks * 4);
+        const size_t o_bc = put(block_chunk.data(), (size_t)nblocks * 4), o_bb = put(block_band.data(), (size_t)nblocks * 4);
+        const size_t o_cf = put(cf.data(), (size_t)nchunks);
+        HIPCHK(c, c->d_geom.reserve(blob.size() + 8));
+        HIPCHK(c, hipMemcpy(c->d_geom.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
+        const unsigned char* g = c->d_geom.p;
+        c->gv.chunk_begin = reinterpret_cast<const long long*>(g + o_cb);
+        c->gv.chunk_end = reinterpret_cast<const long long*>(g + o_ce);
+        c->gv.seg2 = reinterpret_cast<const long long*>(g + o_s2);
+        c->gv.dn = reinterpret_cast<const long long*>(g + o_dn);
+        c->gv.seg1 = reinterpret_cast<const long long*>(g + o_s1);
+        c->gv.chunk_stride = reinterpret_cast<const int*>(g + o_cs);
+        c->gv.block_chunk = reinterpret_cast<const int*>(g + o_bc);
+        c->gv.block_band = reinterpret_cast<const int*>(g + o_bb);
+        c->gv.chunk_flip = g + o_cf;
     }
     c->g_nchunks = nchunks; c->g_nblocks = nblocks; c->g_two_level = two_level; c->g_nslices = nslices;
     c->geom_key = gkey;
@@ -736,8 +748,8 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     a.exp_regions = c->n_exp_regions > 0 ? c->exp_regions.p : nullptr; a.n_exp_regions = c->n_exp_regions;
     a.exp_pair = c->have_exp_pair ? c->exp_pair.p : nullptr;
     a.r0 = dr0; a.c0 = dc0;
-    a.chunk_begin = c->d_chunk_begin.p; a.chunk_end = c->d_chunk_end.p; a.chunk_flip = c->d_chunk_flip.p;
-    a.chunk_stride = c->d_chunk_stride.p; a.block_chunk = c->d_block_chunk.p; a.block_band = c->d_block_band.p;
+    a.chunk_begin = c->gv.chunk_begin; a.chunk_end = c->gv.chunk_end; a.chunk_flip = c->gv.chunk_flip;
+    a.chunk_stride = c->gv.chunk_stride; a.block_chunk = c->gv.block_chunk; a.block_band = c->gv.block_band;
     a.part_f64 = c->part_f64.p; a.part_num = c->part_num.p;
     a.counters = c->counters.p; a.err = c->d_err.p;
     a.W = W; a.ignore_diags = ignore_diags; a.mode = mode;
@@ -787,15 +799,15 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     const dim3 rg2((unsigned)((Lf + Li + 63) / 64), (unsigned)c->T);
     if (two_level) {
         hipLaunchKernelGGL((pup::reduce_partials_kernel<unsigned, false>), rg1, rb, 0, c->stream,
-                           c->part_f64.p, c->part_num.p, c->d_seg1.p, (int)Lf, Li, c->slice_f64.p, c->slice_num.p);
+                           c->part_f64.p, c->part_num.p, c->gv.seg1, (int)Lf, Li, c->slice_f64.p, c->slice_num.p);
         hipLaunchKernelGGL((pup::reduce_partials_kernel<long long, true>), rg2, rb, 0, c->stream,
-                           c->slice_f64.p, c->slice_num.p, c->d_seg2.p, (int)Lf, Li, c->acc_f64.p, c->acc_i64.p);
+                           c->slice_f64.p, c->slice_num.p, c->gv.seg2, (int)Lf, Li, c->acc_f64.p, c->acc_i64.p);
     } else {
         hipLaunchKernelGGL((pup::reduce_partials_kernel<unsigned, true>), rg2, rb, 0, c->stream,
-                           c->part_f64.p, c->part_num.p, c->d_seg2.p, (int)Lf, Li, c->acc_f64.p, c->acc_i64.p);
+                           c->part_f64.p, c->part_num.p, c->gv.seg2, (int)Lf, Li, c->acc_f64.p, c->acc_i64.p);
     }
     hipLaunchKernelGGL(pup::add_counts_kernel, dim3((unsigned)((c->T + 255) / 256)), dim3(256), 0, c->stream,
-                       c->acc_i64.p + (size_t)c->T * W2, c->d_dn.p, c->T);
+                       c->acc_i64.p + (size_t)c->T * W2, c->gv.dn, c->T);
     HIPCHK(c, hipGetLastError());
     if (c->profiling) {
         HIPCHK(c, hipEventRecord(e2, c->stream));
