@@ -715,12 +715,18 @@ class PileUpper:
                 exp = exp[exp["region1"] == exp["region2"]].reset_index(drop=True)
                 if "dist" not in exp.columns:
                     raise ValueError("provided expected is not valid")
+                # by-diagonal vector of every view region in table order (ExpectedSnipper.select -> LazyToeplitz);
+                # one factorisation instead of a string comparison of the whole table per region
+                codes, uniq = pd.factorize(exp["region1"].values)
+                order = np.argsort(codes, kind="stable")
+                ptr = np.concatenate([[0], np.cumsum(np.bincount(codes, minlength=len(uniq)))])
+                where = {u: i for i, u in enumerate(uniq)}
+                values = exp[self.expected_value_col].values.astype(np.float64)
                 for name in self.view_df["name"]:
-                    rows = exp[exp["region1"] == name]
-                    if len(rows) == 0:
+                    i = where.get(name)
+                    if i is None or ptr[i + 1] == ptr[i]:
                         raise ValueError("provided expected is not valid")
-                    # by-diagonal vector in table order (ExpectedSnipper.select -> LazyToeplitz)
-                    self._expected_vectors[name] = rows[self.expected_value_col].values.astype(np.float64)
+                    self._expected_vectors[name] = values[order[ptr[i]:ptr[i + 1]]]
                 self.expected_df = exp
             self.expected = True
         self.view_df = self.view_df.set_index("name")

@@ -20,13 +20,21 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--plain", action="store_true", help="no by-distance / by-strand grouping")
     ap.add_argument("--trans", action="store_true", help="config-4 shape: inter-chromosomal pairs, pad=25, no controls")
+    ap.add_argument("--local", action="store_true", help="config-1 shape: Bonev CTCF+ local pile-up with expected")
     ap.add_argument("--pairs", type=int, default=1_000_000)
     ap.add_argument("--top", type=int, default=40)
     a = ap.parse_args()
     warnings.simplefilter("ignore")
     hg = synth.make_cooler({c: synth.HG38[c] for c in synth.HG38}, binsize=10_000, lam=20, seed=1000, name="sparse_hg38",
                            parallel=True)
-    if a.trans:
+    if a.local:
+        import gzip
+        import pandas as pd
+        hg = synth.make_cooler(synth.MM9, binsize=10_000, lam=20, seed=1000, name="sparse_mm9", parallel=True)
+        with gzip.open(os.path.join(ROOT, "tests", "golden", "ref_data", "Bonev_CTCF+.bed.gz"), "rt") as f:
+            feats = pd.read_csv(f, sep="\t", header=None, names=["chrom", "start", "end"])
+        kw = dict(features_format="bed", flank=100_000, local=True, expected_df=synth.cis_expected(hg))
+    elif a.trans:
         feats = synth.random_trans_pairs(hg, a.pairs // 2, seed=43)
         kw = dict(features_format="bedpe", flank=250_000, trans=True)
     else:
