@@ -1765,7 +1765,9 @@ def pileup(clr, features, features_format="bed", view_df=None, expected_df=None,
         flags = (False, False, False)
     pups["by_window"], pups["by_strand"], pups["by_distance"] = flags
     pups["groupby"] = [groupby] * pups.shape[0]
-    pups["expected"] = pups["expected"].fillna(False)
+    with warnings.catch_warnings():          # pandas announces a dtype change of object fillna; the value is what matters
+        warnings.simplefilter("ignore", FutureWarning)
+        pups["expected"] = pups["expected"].fillna(False)
     pups["cooler"] = os.path.splitext(os.path.basename(clr.filename))[0]
     return pups
 
