@@ -64,7 +64,7 @@ def _tmp(name):
 
 
 def workload_key(a):
-    return hashlib.sha1(f"w4|{a.chroms}|{a.lam}|{a.pairs}|{a.nshifts}|{a.pad}".encode()).hexdigest()[:12]
+    return hashlib.sha1(f"w5|{a.chroms}|{a.lam}|{a.pairs}|{a.nshifts}|{a.pad}".encode()).hexdigest()[:12]
 
 
 def cooler_path(a):
@@ -95,7 +95,7 @@ def build_cooler(a):
 
 def build_snippets(a, cool, k):
     """Snippet set k: a.pairs random cis BEDPE pairs (pair seed 42+k) through the host-side coordinate layer
-    (CoordCreator semantics, control-shift RNG seed k) -> position-sorted (r0, c0) with ROI first."""
+    (CoordCreator semantics, control-shift RNG seed k) -> block-ordered (r0, c0) with ROI first."""
     from coolpuppy_amd.cooler_lite import ArrayCooler
     from coolpuppy_amd.coolpup import CoordCreator, snippet_batches
     clr = ArrayCooler(_chromsizes(a), 10_000, cool["bin1_offset"], cool["bin2_id"], cool["count"],
@@ -105,7 +105,10 @@ def build_snippets(a, cool, k):
     cc = CoordCreator(pairs, clr.binsize, features_format="bedpe", flank=a.pad * clr.binsize,
                       nshifts=a.nshifts, mindist="auto")
     r0, c0, kind = snippet_batches(cc, clr, control=a.nshifts > 0)
-    order = np.lexsort((c0, r0, kind))
+    # resident order = the engine's preferred input layout: ROI tile first, then inside each tile by 16 x 16 block of
+    # top-left corners (block row, block column), then position — see pup_set_tuning in include/pup_hip.h
+    from coolpuppy_amd.engine import PileupEngine
+    order = PileupEngine.block_order(r0, c0, clr.chrom_offset, tile=kind)
     return {"r0": r0[order].astype(np.int32), "c0": c0[order].astype(np.int32), "n_roi": np.int64((kind == 0).sum())}
 
 
@@ -286,12 +289,16 @@ def main():
                 traffic = None
         roofline = {
             "bound": "hbm",
-            "kernel": (f"pup::pileup_regtile_kernel<{W}, false>" if W <= 31 else f"pup::pileup_chunk_kernel<{W}>"),
+            "kernel": ((f"pup::pileup_tiled_kernel<{W}, false, 16> (dense tile) + pup::pileup_regtile_kernel<{W}, false> "
+                        "(sparse tile), one launch each per step" if st.get("staged_regions", 0) > 0
+                        else f"pup::pileup_regtile_kernel<{W}, false>") if W <= 31 else f"pup::pileup_band_kernel"),
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBPS * a.gpus, "unit": "GB/s", "frac": round(achieved / (HBM_PEAK_GBPS * a.gpus), 4),
             "traffic": traffic, "kernel_ms_per_launch": round(k1_ms_per_launch, 4),
             "algorithmic_bytes_per_launch": round(alg_bytes_total / a.steps / a.gpus),
             "nnz_win_mean": round(pix_total / max(snip_total, 1), 1),
+            "staged_regions_per_launch": int(st.get("staged_regions", 0)),
+            "prepass_ms_per_launch": round(st.get("prepare_ms", 0.0) / launches, 4),
         }
         # ---- CPU baseline + same-run parity on a bounded sample (N=1 only) ------------------------------
         cpu = None

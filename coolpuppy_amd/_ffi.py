@@ -33,6 +33,8 @@ class PupStats(C.Structure):
         ("pixels_in_windows", C.c_int64),
         ("probe_loads", C.c_int64),
         ("coverage_ms", C.c_double),
+        ("staged_regions", C.c_int64),
+        ("prepare_ms", C.c_double),
     ]
 
 

@@ -9,6 +9,8 @@
 #include "pup_kernels.hpp"
 
 #include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -68,11 +70,19 @@ struct pup_ctx {
     int T = 0, pad = 0, W = 0;
     // workspaces
     DevBuf<int> d_r0, d_c0, d_h, d_w;
+    // block-ordered copy of the snippets for the staged kernel (K1t)
+    DevBuf<unsigned long long> d_keys, d_keys2, d_kcount;
+    DevBuf<unsigned> d_vals, d_vals2, d_k32, d_k32b, d_bitmap;
+    DevBuf<int> d_sr0, d_sc0;
+    DevBuf<long long> d_segend;
+    DevBuf<unsigned char> d_sorttmp;
+    long long tiled_min = 1000000;          // fewer snippets: the whole pile-up is a fraction of a millisecond anyway
+    unsigned long long last_stagings = 0;   // diagnostics: region stagings of the last K1t launch (0: K1r ran)
     // launch geometry: ONE device blob (one H2D copy per new geometry), the typed views below point into it
     DevBuf<unsigned char> d_geom;
     struct GeomView {
         const long long *chunk_begin = nullptr, *chunk_end = nullptr, *seg1 = nullptr, *seg2 = nullptr, *dn = nullptr;
-        const int *chunk_stride = nullptr, *block_chunk = nullptr, *block_band = nullptr;
+        const int *chunk_stride = nullptr, *block_chunk = nullptr, *block_band = nullptr, *block_chunk_t = nullptr;
         const unsigned char* chunk_flip = nullptr;
     } gv;
     DevBuf<double> part_f64, slice_f64;
@@ -88,7 +98,7 @@ struct pup_ctx {
     hipEvent_t slots[8] = {};
     int chunk_snippets = 0, variant = 0, group_waves = 0;
     std::vector<long long> geom_key;            // launch-geometry cache (see pup_accumulate)
-    long long g_nchunks = 0, g_nblocks = 0, g_nslices = 0;
+    long long g_nchunks = 0, g_nblocks = 0, g_nblocks_t = 0, g_nslices = 0;
     bool g_two_level = false;
     int max_lds = 0, n_cu = 0;
     float last_coverage_ms = 0.f;
@@ -148,6 +158,38 @@ void launch_k1r(const pup::K1Args& a, int nchunks, hipStream_t s) {
         hipLaunchKernelGGL((pup::pileup_regtile_kernel<W, true>), dim3(nchunks), dim3(pup::kWave), 0, s, a);
     else
         hipLaunchKernelGGL((pup::pileup_regtile_kernel<W, false>), dim3(nchunks), dim3(pup::kWave), 0, s, a);
+}
+
+// block-staged kernel (K1t), B = 16
+template <int W>
+void launch_k1t(const pup::K1Args& a, int nchunks, hipStream_t s) {
+    if (a.mode & PUP_MODE_OOE)
+        hipLaunchKernelGGL((pup::pileup_tiled_kernel<W, true, 16>), dim3(nchunks), dim3(pup::kWave), 0, s, a);
+    else
+        hipLaunchKernelGGL((pup::pileup_tiled_kernel<W, false, 16>), dim3(nchunks), dim3(pup::kWave), 0, s, a);
+}
+
+bool tiled_supported(int W) { return W >= 3 && W <= 31 && (W & 1); }
+
+bool launch_tiled(int W, const pup::K1Args& a, int nchunks, hipStream_t s) {
+    switch (W) {
+        case 3:  launch_k1t<3>(a, nchunks, s);  return true;
+        case 5:  launch_k1t<5>(a, nchunks, s);  return true;
+        case 7:  launch_k1t<7>(a, nchunks, s);  return true;
+        case 9:  launch_k1t<9>(a, nchunks, s);  return true;
+        case 11: launch_k1t<11>(a, nchunks, s); return true;
+        case 13: launch_k1t<13>(a, nchunks, s); return true;
+        case 15: launch_k1t<15>(a, nchunks, s); return true;
+        case 17: launch_k1t<17>(a, nchunks, s); return true;
+        case 19: launch_k1t<19>(a, nchunks, s); return true;
+        case 21: launch_k1t<21>(a, nchunks, s); return true;
+        case 23: launch_k1t<23>(a, nchunks, s); return true;
+        case 25: launch_k1t<25>(a, nchunks, s); return true;
+        case 27: launch_k1t<27>(a, nchunks, s); return true;
+        case 29: launch_k1t<29>(a, nchunks, s); return true;
+        case 31: launch_k1t<31>(a, nchunks, s); return true;
+        default: return false;
+    }
 }
 
 // banded register-tile kernel: NCH column chunks of 16 cells -> windows up to 16*NCH wide
@@ -242,6 +284,9 @@ void pup_destroy(pup_ctx* c) {
     c->indptr.release(); c->px.release(); c->cnt32.release(); c->bal.release(); c->badbits.release(); c->idx.release(); c->idx_chrom.release(); c->weight.release(); c->cov.release(); c->expv.release(); c->exp_pair.release(); c->exp_regions.release();
     c->acc_f64.release(); c->acc_i64.release();
     c->d_r0.release(); c->d_c0.release(); c->d_h.release(); c->d_w.release(); c->d_geom.release();
+    c->d_keys.release(); c->d_keys2.release(); c->d_kcount.release(); c->d_vals.release(); c->d_vals2.release();
+    c->d_sr0.release(); c->d_sc0.release(); c->d_segend.release(); c->d_sorttmp.release();
+    c->d_k32.release(); c->d_k32b.release(); c->d_bitmap.release();
     c->part_f64.release(); c->slice_f64.release(); c->part_num.release(); c->slice_num.release();
     c->counters.release(); c->d_err.release();
     for (auto& s : c->slots) if (s) (void)hipEventDestroy(s);
@@ -577,6 +622,136 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
                         c->W, c->W, need, c->max_lds);
     }
 
+    // ---- many overlapping cis windows: block order + staged kernel (K1t) -----------------------------------
+    // Eligible: register-tile widths, plain / OOE modes, every window covered by the rank-bitmap index.  The
+    // snippets' block keys are computed on the device; if the given order already keeps blocks together the
+    // kernel runs on it, otherwise the snippets are radix-sorted by (segment, block) into a scratch copy.
+    bool tiled = false;                                  // any segment goes to K1t
+    std::vector<char> seg_tiled((size_t)2 * c->T, 0);    // per (tile, flip) run
+    const int *kr0 = dr0, *kc0 = dc0;
+    c->last_stagings = 0;
+    {
+        const bool force = (c->variant & 8) != 0, forbid = (c->variant & 16) != 0;
+        const bool use_idx_t = c->have_idx && !(c->variant & 1);
+        if (!forbid && !rescale && !(mode & (PUP_MODE_EXPECTED | PUP_MODE_TRANSPOSE)) && !(c->variant & 2) && use_idx_t &&
+            ignore_diags >= 0 && tiled_supported(W) && n < 0xffffffffLL && (force || n >= c->tiled_min) &&
+            2 * c->T <= pup::kMaxSegCount) {
+            const int B = 16;
+            const size_t nseg = (size_t)2 * c->T;
+            std::vector<long long> seg_end;
+            for (int t = 0; t < c->T; ++t) { seg_end.push_back(flip_from ? flip_from[t] : tile_ptr[t + 1]); seg_end.push_back(tile_ptr[t + 1]); }
+            auto nbits = [](unsigned long long v) { int b = 1; while ((v >> b) != 0) ++b; return b; };
+            long long max_len = 1;
+            {
+                std::vector<pup::IdxChrom> tab((size_t)c->n_chrom);
+                HIPCHK(c, hipMemcpy(tab.data(), c->idx_chrom.p, tab.size() * sizeof(pup::IdxChrom), hipMemcpyDeviceToHost));
+                for (auto& ch : tab) max_len = std::max<long long>(max_len, ch.end - ch.start);
+            }
+            const int sh_br = nbits((unsigned long long)(max_len / B + 1));
+            const int sh_seg = sh_br + nbits((unsigned long long)c->nbins + 1);
+            const int end_bit = sh_seg + nbits((unsigned long long)(nseg > 1 ? nseg - 1 : 1));
+            if (end_bit <= 64) {
+                hipEvent_t ep0 = nullptr, ep1 = nullptr;
+                if (c->profiling) { HIPCHK(c, hipEventCreate(&ep0)); HIPCHK(c, hipEventCreate(&ep1)); HIPCHK(c, hipEventRecord(ep0, c->stream)); }
+                // counters: [0] ineligible windows, [1 .. 1+nseg) changes per segment in the given order,
+                // [1+nseg .. 1+2nseg) changes per segment in block order
+                const size_t ncnt = 1 + 3 * (nseg + 1);           // ... then sampled windows / sampled distinct blocks per segment
+                std::vector<unsigned long long> cnt(ncnt, 0);
+                HIPCHK(c, c->d_keys.reserve((size_t)n)); HIPCHK(c, c->d_vals.reserve((size_t)n));
+                HIPCHK(c, c->d_segend.reserve(seg_end.size())); HIPCHK(c, c->d_kcount.reserve(ncnt));
+                HIPCHK(c, hipMemcpyAsync(c->d_segend.p, seg_end.data(), seg_end.size() * 8, hipMemcpyHostToDevice, c->stream));
+                HIPCHK(c, hipMemsetAsync(c->d_kcount.p, 0, ncnt * sizeof(unsigned long long), c->stream));
+                const unsigned gk = (unsigned)((n + 255) / 256);
+                hipLaunchKernelGGL(pup::block_key_kernel, dim3(gk), dim3(256), 0, c->stream, dr0, dc0, (long long)n,
+                                   (const long long*)c->d_segend.p, (int)seg_end.size(), (const pup::IdxChrom*)c->idx_chrom.p,
+                                   c->n_chrom, W, B, sh_br, sh_seg, c->d_keys.p, c->d_vals.p, c->d_kcount.p);
+                const unsigned gs = (unsigned)std::min<long long>((n + 255) / 256, (long long)c->n_cu * 8);
+                hipLaunchKernelGGL(pup::count_changes_kernel, dim3(gs), dim3(256), 0, c->stream,
+                                   (const unsigned long long*)c->d_keys.p, (long long)n, sh_seg, (int)nseg, c->d_kcount.p + 1);
+                HIPCHK(c, hipStreamSynchronize(c->stream));      // also fences seg_end's host buffer
+                HIPCHK(c, hipMemcpy(cnt.data(), c->d_kcount.p, ncnt * 8, hipMemcpyDeviceToHost));
+                // a segment is worth staging when a staged region serves >= 4 windows on average
+                auto decide = [&](const unsigned long long* changes) {
+                    unsigned long long total = 0; bool any = false;
+                    for (size_t sg = 0; sg < nseg; ++sg) {
+                        const long long len = seg_end[sg] - (sg ? seg_end[sg - 1] : 0);
+                        seg_tiled[sg] = len > 0 && (force || (len >= 20000 && changes[sg] * 4 <= (unsigned long long)len));
+                        if (seg_tiled[sg]) { any = true; total += changes[sg]; }
+                    }
+                    c->last_stagings = total;
+                    return any;
+                };
+                if (cnt[0] == 0) {
+                    unsigned long long ch_all = 0;
+                    for (size_t sg = 0; sg < nseg; ++sg) ch_all += cnt[1 + sg];
+                    if (ch_all * 4 <= (unsigned long long)n) tiled = decide(cnt.data() + 1);       // given order is block order
+                    else {
+                        // would block order pay?  estimate the distinct blocks per segment before sorting anything
+                        unsigned mbits = 1u << 24;
+                        while ((unsigned long long)mbits < 4ull * (unsigned long long)n && mbits < (1u << 30)) mbits <<= 1;
+                        HIPCHK(c, c->d_bitmap.reserve((size_t)(mbits >> 5)));
+                        HIPCHK(c, hipMemsetAsync(c->d_bitmap.p, 0, (size_t)(mbits >> 5) * 4, c->stream));
+                        hipLaunchKernelGGL(pup::distinct_blocks_kernel, dim3(gs), dim3(256), 0, c->stream,
+                                           (const unsigned long long*)c->d_keys.p, (long long)n, sh_seg, (int)nseg, c->d_bitmap.p,
+                                           mbits - 1u, c->d_kcount.p + 1 + (nseg + 1), c->d_kcount.p + 1 + 2 * (nseg + 1));
+                        HIPCHK(c, hipStreamSynchronize(c->stream));
+                        HIPCHK(c, hipMemcpy(cnt.data(), c->d_kcount.p, ncnt * 8, hipMemcpyDeviceToHost));
+                        // estimated stagings per segment = its windows / (sampled windows per sampled distinct block)
+                        std::vector<unsigned long long> est(nseg, 0);
+                        for (size_t sg = 0; sg < nseg; ++sg) {
+                            const unsigned long long seen = cnt[1 + (nseg + 1) + sg], fresh = cnt[1 + 2 * (nseg + 1) + sg];
+                            const long long len = seg_end[sg] - (sg ? seg_end[sg - 1] : 0);
+                            est[sg] = seen ? (unsigned long long)((double)len * (double)std::max<unsigned long long>(fresh, 1) / (double)seen) : (unsigned long long)len;
+                        }
+                        long long covered = 0;
+                        if (decide(est.data()))
+                            for (size_t sg = 0; sg < nseg; ++sg) if (seg_tiled[sg]) covered += seg_end[sg] - (sg ? seg_end[sg - 1] : 0);
+                        if (force || covered * 2 >= n) {
+                            HIPCHK(c, c->d_vals2.reserve((size_t)n));
+                            hipError_t se = hipSuccess;
+                            size_t tmp_bytes = 0;
+                            const unsigned long long* sorted64 = nullptr;
+                            if (end_bit <= 32) {
+                                HIPCHK(c, c->d_k32.reserve((size_t)n)); HIPCHK(c, c->d_k32b.reserve((size_t)n));
+                                hipLaunchKernelGGL(pup::narrow_keys_kernel, dim3(gk), dim3(256), 0, c->stream,
+                                                   (const unsigned long long*)c->d_keys.p, (long long)n, c->d_k32.p);
+                                se = rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_vals.p, c->d_vals2.p,
+                                                               (size_t)n, 0, end_bit, c->stream);
+                                if (se == hipSuccess) se = c->d_sorttmp.reserve(tmp_bytes + 16);
+                                if (se == hipSuccess)
+                                    se = rocprim::radix_sort_pairs(c->d_sorttmp.p, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_vals.p,
+                                                                   c->d_vals2.p, (size_t)n, 0, end_bit, c->stream);
+                            } else {
+                                HIPCHK(c, c->d_keys2.reserve((size_t)n));
+                                se = rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_vals.p, c->d_vals2.p,
+                                                               (size_t)n, 0, end_bit, c->stream);
+                                if (se == hipSuccess) se = c->d_sorttmp.reserve(tmp_bytes + 16);
+                                if (se == hipSuccess)
+                                    se = rocprim::radix_sort_pairs(c->d_sorttmp.p, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_vals.p,
+                                                                   c->d_vals2.p, (size_t)n, 0, end_bit, c->stream);
+                                sorted64 = c->d_keys2.p;
+                            }
+                            if (se != hipSuccess) return fail(c, PUP_EHIP, "pup_accumulate: block sort: %s", hipGetErrorString(se));
+                            (void)sorted64;
+                            // the estimate stands in for the exact staging count (it only feeds the statistics)
+                            HIPCHK(c, c->d_sr0.reserve((size_t)n)); HIPCHK(c, c->d_sc0.reserve((size_t)n));
+                            hipLaunchKernelGGL(pup::permute_snippets_kernel, dim3(gk), dim3(256), 0, c->stream, dr0, dc0,
+                                               (const unsigned*)c->d_vals2.p, (long long)n, c->d_sr0.p, c->d_sc0.p);
+                            tiled = true; kr0 = c->d_sr0.p; kc0 = c->d_sc0.p;
+                        }
+                    }
+                }
+                if (!tiled) { std::fill(seg_tiled.begin(), seg_tiled.end(), 0); c->last_stagings = 0; }
+                if (ep0) {
+                    float ms = 0.f;
+                    if (hipEventRecord(ep1, c->stream) == hipSuccess && hipEventSynchronize(ep1) == hipSuccess &&
+                        hipEventElapsedTime(&ms, ep0, ep1) == hipSuccess) c->stats.prepare_ms += ms;
+                    (void)hipEventDestroy(ep0); (void)hipEventDestroy(ep1);
+                }
+            }
+        }
+    }
+
     // launch geometry (chunk / group / reduction tables) depends only on the snippet COUNTS per tile and on
     // the tuning: when it repeats (steady-state loops, benchmarks) the device tables of the last call are reused
     std::vector<long long> gkey;
@@ -584,6 +759,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     gkey.push_back(n); gkey.push_back(c->T); gkey.push_back(c->W); gkey.push_back(c->chunk_snippets);
     gkey.push_back(c->group_waves); gkey.push_back(c->variant & 2); gkey.push_back((mode & PUP_MODE_EXPECTED) ? 1 : 0);
     gkey.push_back(flip_from ? 1 : 0); gkey.push_back(rescale ? 1 : 0);
+    for (char f : seg_tiled) gkey.push_back(f);
     for (int t = 0; t <= c->T; ++t) gkey.push_back(tile_ptr[t]);
     if (flip_from) for (int t = 0; t < c->T; ++t) gkey.push_back(flip_from[t]);
     const bool geom_hit = (gkey == c->geom_key);
@@ -601,7 +777,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         C = std::max<long long>(16, (n + target - 1) / target);
     }
     if (rescale) C = std::max<long long>(1, (n + (long long)c->n_cu * 2 - 1) / ((long long)c->n_cu * 2));   // heavy snippets: ~2 workgroups per CU
-    const int S = c->group_waves > 0 ? c->group_waves : 128;
+    const int S_plain = c->group_waves > 0 ? c->group_waves : 128;
     const int n_xcd = 8;
     // kernel family: register tile (W <= 31), banded register tile (W <= 255), LDS tile (EXPECTED pass, variant&2)
     const bool lds_kernel = (mode & PUP_MODE_EXPECTED) || (c->variant & 2) || rescale;
@@ -611,16 +787,18 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     std::vector<unsigned char> cf;
     std::vector<int> cs;
     std::vector<std::vector<int>> xcd_list((size_t)n_xcd);       // entries: chunk * nbands + band
-    struct Group { long long key; int first_chunk, waves; };
+    std::vector<std::vector<int>> xcd_list_t((size_t)n_xcd);     // the same for the chunks the staged kernel runs
+    struct Group { long long key; int first_chunk, waves; bool staged; };
     std::vector<Group> groups;
-    const bool host_pos = !(mode & PUP_MODE_DEVPTR);
+    const bool host_pos = !(mode & PUP_MODE_DEVPTR) && kr0 == dr0;   // host order == launch order
     std::vector<long long> group_start;                             // DEVPTR: first snippet of every group
-    auto add_run = [&](long long b, long long e, unsigned char flip) {
+    auto add_run = [&](long long b, long long e, unsigned char flip, bool staged) {
+        const int S = staged ? 1 : S_plain;                         // K1t: a chunk is a contiguous snippet range
         for (long long g0 = b; g0 < e; g0 += (long long)S * C) {
             const long long g1 = std::min(e, g0 + (long long)S * C);
             const int waves = (int)std::min<long long>(S, std::max<long long>(1, (g1 - g0 + 15) / 16));
             if (!host_pos) group_start.push_back(g0);
-            groups.push_back(Group{host_pos ? (long long)r0[g0] : (long long)groups.size(), (int)cb.size(), waves});
+            groups.push_back(Group{host_pos ? (long long)r0[g0] : (long long)groups.size(), (int)cb.size(), waves, staged});
             for (int j = 0; j < waves; ++j) {
                 cb.push_back(g0 + j); ce.push_back(g1); cs.push_back(waves); cf.push_back(flip);
             }
@@ -630,8 +808,8 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         const long long b = tile_ptr[t], e = tile_ptr[t + 1];
         const long long f = flip_from ? flip_from[t] : e;          // [b, f) as is, [f, e) flipped
         dn[(size_t)t] = e - b;
-        add_run(b, f, 0);
-        add_run(f, e, 1);
+        add_run(b, f, 0, seg_tiled[(size_t)2 * t] != 0);
+        add_run(f, e, 1, seg_tiled[(size_t)2 * t + 1] != 0);
         tile_chunk_ptr[(size_t)t + 1] = (long long)cb.size();
     }
     // Launch order = matrix position, across tiles: with many tiles (by-distance x by-strand ...) every tile walks
@@ -647,7 +825,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         if (ge == hipSuccess) ge = d_key.reserve((size_t)ng);
         if (ge == hipSuccess) ge = hipMemcpy(d_pos.p, group_start.data(), (size_t)ng * 8, hipMemcpyHostToDevice);
         if (ge == hipSuccess) {
-            hipLaunchKernelGGL(pup::gather_int_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, c->stream, dr0,
+            hipLaunchKernelGGL(pup::gather_int_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, c->stream, kr0,
                                (const long long*)d_pos.p, d_key.p, ng);
             ge = hipStreamSynchronize(c->stream);
         }
@@ -658,20 +836,29 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     }
     if (c->T > 1)
         std::stable_sort(groups.begin(), groups.end(), [](const Group& x, const Group& y) { return x.key < y.key; });
-    for (size_t g = 0; g < groups.size(); ++g) {
-        auto& lst = xcd_list[g % (size_t)n_xcd];
-        for (int j = 0; j < groups[g].waves; ++j)
-            for (int b = 0; b < nbands; ++b) lst.push_back((groups[g].first_chunk + j) * nbands + b);
-    }
-    size_t per_xcd = 0;
-    for (auto& l : xcd_list) per_xcd = std::max(per_xcd, l.size());
-    std::vector<int> block_chunk(per_xcd * (size_t)n_xcd, -1), block_band(per_xcd * (size_t)n_xcd, 0);
-    for (int x = 0; x < n_xcd; ++x)
-        for (size_t i = 0; i < xcd_list[(size_t)x].size(); ++i) {
-            const int e = xcd_list[(size_t)x][i];
-            block_chunk[i * (size_t)n_xcd + (size_t)x] = e / nbands;
-            block_band[i * (size_t)n_xcd + (size_t)x] = e % nbands;
+    {
+        size_t gp = 0, gt = 0;
+        for (size_t g = 0; g < groups.size(); ++g) {
+            auto& lst = groups[g].staged ? xcd_list_t[gt++ % (size_t)n_xcd] : xcd_list[gp++ % (size_t)n_xcd];
+            for (int j = 0; j < groups[g].waves; ++j)
+                for (int b = 0; b < nbands; ++b) lst.push_back((groups[g].first_chunk + j) * nbands + b);
         }
+    }
+    auto deal = [&](const std::vector<std::vector<int>>& lists, std::vector<int>& bc, std::vector<int>& bb) {
+        size_t per_xcd = 0;
+        for (auto& l : lists) per_xcd = std::max(per_xcd, l.size());
+        bc.assign(per_xcd * (size_t)n_xcd, -1); bb.assign(per_xcd * (size_t)n_xcd, 0);
+        for (int x = 0; x < n_xcd; ++x)
+            for (size_t i = 0; i < lists[(size_t)x].size(); ++i) {
+                const int e = lists[(size_t)x][i];
+                bc[i * (size_t)n_xcd + (size_t)x] = e / nbands;
+                bb[i * (size_t)n_xcd + (size_t)x] = e % nbands;
+            }
+    };
+    std::vector<int> block_chunk, block_band, block_chunk_t, block_band_t;
+    deal(xcd_list, block_chunk, block_band);
+    deal(xcd_list_t, block_chunk_t, block_band_t);
+    const long long nblocks_t = (long long)block_chunk_t.size();
     const long long nblocks = (long long)block_chunk.size();
     const long long nchunks = (long long)cb.size();
     if (nchunks > 0x7fffffffLL || nblocks > 0x7fffffffLL) return fail(c, PUP_ENOTSUP, "pup_accumulate: too many chunks");
@@ -712,6 +899,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         const size_t o_s1 = put(seg1.data(), seg1.size() * 8);
         const size_t o_cs = put(cs.data(), (size_t)nchunks * 4);
         const size_t o_bc = put(block_chunk.data(), (size_t)nblocks * 4), o_bb = put(block_band.data(), (size_t)nblocks * 4);
+        const size_t o_bt = put(block_chunk_t.data(), (size_t)nblocks_t * 4);
         const size_t o_cf = put(cf.data(), (size_t)nchunks);
         HIPCHK(c, c->d_geom.reserve(blob.size() + 8));
         HIPCHK(c, hipMemcpy(c->d_geom.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
@@ -724,8 +912,10 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         c->gv.chunk_stride = reinterpret_cast<const int*>(g + o_cs);
         c->gv.block_chunk = reinterpret_cast<const int*>(g + o_bc);
         c->gv.block_band = reinterpret_cast<const int*>(g + o_bb);
+        c->gv.block_chunk_t = reinterpret_cast<const int*>(g + o_bt);
         c->gv.chunk_flip = g + o_cf;
     }
+    c->g_nblocks_t = nblocks_t;
     c->g_nchunks = nchunks; c->g_nblocks = nblocks; c->g_two_level = two_level; c->g_nslices = nslices;
     c->geom_key = gkey;
     }   // !geom_hit
@@ -747,7 +937,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     a.nexp = c->nexp; a.nbins = c->nbins;
     a.exp_regions = c->n_exp_regions > 0 ? c->exp_regions.p : nullptr; a.n_exp_regions = c->n_exp_regions;
     a.exp_pair = c->have_exp_pair ? c->exp_pair.p : nullptr;
-    a.r0 = dr0; a.c0 = dc0;
+    a.r0 = kr0; a.c0 = kc0;
     a.chunk_begin = c->gv.chunk_begin; a.chunk_end = c->gv.chunk_end; a.chunk_flip = c->gv.chunk_flip;
     a.chunk_stride = c->gv.chunk_stride; a.block_chunk = c->gv.block_chunk; a.block_band = c->gv.block_band;
     a.part_f64 = c->part_f64.p; a.part_num = c->part_num.p;
@@ -770,6 +960,13 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         hipLaunchKernelGGL(pup::pileup_rescale_kernel, dim3((unsigned)nblocks), dim3(256), rs_lds, c->stream, a,
                            (const int*)c->d_h.p, (const int*)c->d_w.p, (double*)nullptr, (double*)nullptr, 0LL);
         launched = true;
+    }
+    if (!launched && tiled && c->g_nblocks_t > 0) {
+        // the segments whose windows overlap enough go to the staged kernel, the rest (below) to the plain one
+        pup::K1Args at = a;
+        at.block_chunk = c->gv.block_chunk_t;
+        if (!launch_tiled(W, at, (int)c->g_nblocks_t, c->stream)) return fail(c, PUP_ENOTSUP, "pup_accumulate: staged kernel not built for W=%d", W);
+        if (nblocks == 0) launched = true;
     }
     if (!launched && !lds_kernel2 && W <= 31) launched = launch_regtile(W, a, (int)nblocks, c->stream);
     if (!launched && !lds_kernel2 && W > 31 && W <= 255) {
@@ -1012,6 +1209,7 @@ int pup_get_stats(pup_ctx* c, pup_stats* out) {
     c->stats.pixels_in_windows = (int64_t)h[0];
     c->stats.probe_loads = (int64_t)h[1];
     c->stats.coverage_ms = c->last_coverage_ms;
+    c->stats.staged_regions = (int64_t)c->last_stagings;
     *out = c->stats;
     return PUP_OK;
 }

@@ -650,6 +650,341 @@ __global__ __launch_bounds__(kWave, rt_min_waves(W)) void pileup_regtile_kernel(
     }
 }
 
+// ---- K1t: block-staged register tile (many OVERLAPPING cis windows) ------------------------------------------
+// When a pile-up is large, windows overlap: 1e7 control windows on a human 10 kb map put ~20 of them into every
+// B x B block of top-left corners.  K1r fetches every window on its own (index line + pixel values per row, ~75 L2
+// lines per window).  K1t needs the snippets ordered by block (r0 / B, c0 / B) — the engine sorts them on the
+// device — and lets a wave STAGE the (B+W-1)^2 region a block's windows live in ONCE into LDS, as final cell values:
+// everything the reference does to a cell depends on its absolute (row, col) only — balanced value, masked bins,
+// ignored diagonals, expected of |col-row| — so the staged cell already is what gets summed (0 where nothing is
+// to be added) and one validity bit per cell says whether it counts in num.  Per window the wave then does 7 LDS
+// reads + 7 f64 adds per lane (W=21) instead of ~180 VALU instructions and 6 global loads.
+// Same register accumulators, chunk flush and reduction as K1r; chunks are contiguous snippet ranges here.
+// Only windows the rank-bitmap index covers (cis, inside one chromosome) are eligible — the engine checks all of
+// them before choosing this kernel.
+template <int W, bool OOE, int B>
+__global__ __launch_bounds__(kWave) void pileup_tiled_kernel(K1Args a) {
+    static_assert(W >= 1 && W <= 32 && B + W - 1 <= 64, "staged region rows must fit one 64-bit validity word");
+    constexpr int NCH = kWave / W;
+    constexpr int CH  = (W + NCH - 1) / NCH;
+    constexpr int W2  = W * W;
+    constexpr int RS  = B + W - 1;                   // staged region: RS x RS bins
+    constexpr int LS  = RS | 1;                      // odd row stride (LDS banks)
+    constexpr int NT  = (RS + 15) / 16;              // column chunks per region row (staging lane-tasks)
+    constexpr int TC  = ((RS + NT - 1) / NT + 1) & ~1;   // even chunk width <= 16, NT * TC >= RS
+    constexpr int NTASK = RS * NT;
+    __shared__ double tile[RS * LS + 2 * 16];
+    __shared__ unsigned long long vbits[RS];          // bit c: cell (row, c) counts in num
+    __shared__ unsigned long long pbits[RS];          // bit c: cell holds a pixel (statistics only)
+    __shared__ double cov_lds[2 * W];
+    const int lane = threadIdx.x;
+    const int p_raw = lane / NCH;
+    const int k  = lane - p_raw * NCH;
+    const int q0 = k * CH;
+    const bool lane_ok = (p_raw < W) && (q0 < W);
+    const int p  = p_raw < W ? p_raw : W - 1;
+    const int chw = lane_ok ? ((W - q0) < CH ? (W - q0) : CH) : 0;
+    const unsigned chmask = chw >= 32 ? 0xffffffffu : ((1u << chw) - 1u);
+    const int qs = q0 < W ? q0 : 0;
+
+    const bool m_cov   = (a.mode & 0x04u) && a.cov != nullptr;
+    const bool use_exp = OOE && ((a.expv != nullptr && a.nexp > 0) || a.n_exp_regions > 0);
+    const int  igd     = a.ignore_diags;
+    const bool stats   = a.counters != nullptr;
+    const double qnan = __builtin_nan("");
+    ExpCache ecache;
+
+    const int ck = a.block_chunk[blockIdx.x];
+    if (ck < 0) return;
+    double   sum[CH];
+    unsigned num[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { sum[i] = 0.0; num[i] = 0u; }
+    if (m_cov) for (int t = lane; t < 2 * W; t += kWave) cov_lds[t] = 0.0;
+    __syncthreads();
+
+    const long long cb = a.chunk_begin[ck], ce = a.chunk_end[ck];
+    const int fl = a.chunk_flip[ck];
+    unsigned long long npix = 0;
+    int ch_start = 0, ch_end = -1, ch_nblk = 0; long long ch_base = 0;
+    int R = -1, C = -1;                               // origin of the staged region (multiples of B); -1: none
+    const double* staged_exp = nullptr;
+
+    // ---- stage the region of block (R, C): lane-task t = (region row, chunk of TC columns) ------------------
+    struct Task { int rr, kc, row, col0, width; bool inside; unsigned bits, ok; long long pos; };
+    auto task_locate = [&](Task& T, int t) __attribute__((always_inline)) {
+        T.rr = t / NT; T.kc = t - T.rr * NT;
+        T.row = R + T.rr; T.col0 = C + TC * T.kc;
+        const int wd = RS - TC * T.kc;
+        T.width = wd < TC ? wd : TC;
+        T.inside = t < NTASK && T.row < ch_end && T.col0 < ch_end;      // R, C >= ch_start by construction
+        T.bits = 0; T.ok = 0; T.pos = 0;
+        if (!T.inside) return;
+        const int rel = T.col0 - ch_start;
+        const int b = rel / kIdxCols, o = rel - b * kIdxCols;
+        const int ws = o >> 6, sh = o & 63;
+        const U64x2* base = reinterpret_cast<const U64x2*>(a.idx + ch_base + (long long)(T.row - ch_start) * ch_nblk + b);
+        const U64x2 h = base[0];
+        const U64x2 w = *reinterpret_cast<const U64x2*>(reinterpret_cast<const char*>(base) + 16 + 8 * ws);
+        const unsigned long long rw = a.badbits[T.row >> 6];
+        const U64x2 cw = *reinterpret_cast<const U64x2*>(a.badbits + (T.col0 >> 6));
+        unsigned long long b64 = w.a >> sh;
+        if (sh) b64 |= w.b << (64 - sh);
+        const unsigned wmask = (1u << T.width) - 1u;
+        T.bits = (unsigned)b64 & wmask;
+        const unsigned cum = ws ? (unsigned)(h.b >> ((ws - 1) * 16)) & 0xffffu : 0u;
+        T.pos = (long long)(h.a + cum + (unsigned long long)__popcll(w.a & ((1ull << sh) - 1ull)));
+        // validity of the task's cells: masked bins, chromosome end, ignored diagonals
+        const int csh = T.col0 & 63;
+        unsigned long long cb64 = cw.a >> csh;
+        if (csh) cb64 |= cw.b << (64 - csh);
+        unsigned ok = wmask & ~(unsigned)cb64;
+        if ((rw >> (T.row & 63)) & 1ull) ok = 0u;
+        const int over = T.col0 + T.width - ch_end;     // columns at / past the chromosome's end are in no eligible window
+        if (over > 0) ok &= over >= T.width ? 0u : ((1u << (T.width - over)) - 1u);
+        if (igd >= 0) {
+            const int t0 = igd - (T.col0 - T.row);
+            ok &= t0 <= 0 ? 0xffffffffu : (t0 >= 32 ? 0u : ~((1u << t0) - 1u));
+        }
+        T.ok = ok;
+    };
+    auto task_load = [&](const Task& T, F64x2 (&prs)[TC / 2]) __attribute__((always_inline)) {
+        // all pair loads, unconditionally (bal is padded; a cell without a pixel reads a neighbour that is then
+        // discarded): predicated loads would serialise the memory latencies
+#pragma unroll
+        for (int i = 0; i < TC; i += 2)
+            prs[i / 2] = *reinterpret_cast<const F64x2*>(a.bal + T.pos + __popc(T.bits & ((1u << i) - 1u)));
+    };
+    auto task_store = [&](const Task& T, const F64x2 (&prs)[TC / 2], const ExpSel& es, int t) __attribute__((always_inline)) {
+        if (t >= NTASK) return;
+        double* dst = tile + T.rr * LS + TC * T.kc;
+        unsigned okn = T.ok;
+        const unsigned bits = T.bits, ok = T.ok;
+#pragma unroll
+        for (int i = 0; i < TC; i += 2) {
+            const F64x2 pr = prs[i / 2];
+            double v0 = ((bits >> i) & 1u) ? pr.a : 0.0;
+            double v1 = ((bits >> (i + 1)) & 1u) ? (((bits >> i) & 1u) ? pr.b : pr.a) : 0.0;
+            if (OOE) {
+                long long ad0 = (long long)(T.col0 + i) - T.row; if (ad0 < 0) ad0 = -ad0;
+                long long ad1 = (long long)(T.col0 + i + 1) - T.row; if (ad1 < 0) ad1 = -ad1;
+                const double e0 = use_exp ? es.at(ad0) : qnan, e1 = use_exp ? es.at(ad1) : qnan;
+                const double q0v = v0 / e0, q1v = v1 / e1;
+                v0 = (((bits >> i) & 1u) && q0v == q0v) ? q0v : 0.0;               // NaN quotients are skipped, inf is kept
+                v1 = (((bits >> (i + 1)) & 1u) && q1v == q1v) ? q1v : 0.0;
+                if (!(e0 == e0) || e0 == 0.0) okn &= ~(1u << i);
+                if (!(e1 == e1) || e1 == 0.0) okn &= ~(1u << (i + 1));
+            }
+            if (i < T.width)     dst[i]     = ((ok >> i) & 1u) ? v0 : 0.0;
+            if (i + 1 < T.width) dst[i + 1] = ((ok >> (i + 1)) & 1u) ? v1 : 0.0;
+        }
+        atomicOr(&vbits[T.rr], (unsigned long long)okn << (TC * T.kc));
+        if (stats) atomicOr(&pbits[T.rr], (unsigned long long)bits << (TC * T.kc));
+    };
+    auto stage = [&](const ExpSel& es) {
+        __syncthreads();                              // earlier windows are done reading the tile
+        for (int t = lane; t < RS; t += kWave) { vbits[t] = 0ull; pbits[t] = 0ull; }
+        __syncthreads();
+        // two lane-tasks per lane and round: both index lines, then both sets of value loads, are in flight together
+        for (int t0 = lane; t0 < NTASK; t0 += 2 * kWave) {
+            Task TA, TB;
+            F64x2 pa[TC / 2], pb[TC / 2];
+            task_locate(TA, t0);
+            task_locate(TB, t0 + kWave);
+            task_load(TA, pa);
+            task_load(TB, pb);
+            task_store(TA, pa, es, t0);
+            task_store(TB, pb, es, t0 + kWave);
+        }
+        __syncthreads();
+    };
+
+    // one window out of the staged region into the register accumulators
+    auto gather = [&](int r0, int c0, double (&v)[CH], unsigned& vw, unsigned& pw) __attribute__((always_inline)) {
+        const int rr = (r0 - R) + p, cc = (c0 - C) + qs;
+        const double* src = tile + rr * LS + cc;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) v[i] = src[i];                    // idle lanes / cells gather garbage that is never flushed
+        vw = (unsigned)(vbits[rr] >> cc);
+        pw = stats ? (unsigned)(pbits[rr] >> cc) & chmask : 0u;
+    };
+    auto add = [&](int r0, int c0, const double (&v)[CH], unsigned vw, unsigned pw) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) { sum[i] += v[i]; num[i] += (vw >> i) & 1u; }
+        if (m_cov && lane_ok && k == 0) {
+            const double vs = a.cov[r0 + p], ve = a.cov[c0 + p];
+            if (vs == vs) cov_lds[p] += vs;
+            if (ve == ve) cov_lds[W + p] += ve;
+        }
+        npix += (unsigned long long)__popc(pw);
+    };
+    // does the window belong to the staged region?  Else make its block the staged one (false: bad window)
+    auto ensure = [&](int r0, int c0) -> bool {
+        if (r0 < 0 || c0 < 0 || (long long)r0 + W > a.nbins || (long long)c0 + W > a.nbins) {
+            if (lane == 0) atomicExch(a.err, 1);
+            return false;
+        }
+        ExpSel es; es.base = a.expv; es.len = 0; es.scalar = qnan; es.is_scalar = true;
+        if (use_exp) es = select_expected(a, ecache, r0, c0);
+        const int dr = r0 - R, dc = c0 - C;
+        if (R >= 0 && dr >= 0 && dr < B && dc >= 0 && dc < B && r0 < ch_end && !(OOE && es.base != staged_exp)) return true;
+        if (!(r0 >= ch_start && r0 < ch_end)) {
+            int lo = 0, hi_k = a.n_chrom;
+            while (lo < hi_k) { const int m = (lo + hi_k) >> 1; if (a.idx_chrom[m].end <= r0) lo = m + 1; else hi_k = m; }
+            if (lo >= a.n_chrom) { if (lane == 0) atomicExch(a.err, 1); return false; }
+            const IdxChrom cinfo = a.idx_chrom[lo];
+            ch_start = cinfo.start; ch_end = cinfo.end; ch_nblk = cinfo.nblk; ch_base = cinfo.blk_base;
+        }
+        if (c0 < ch_start || c0 + W > ch_end || r0 + W > ch_end) { if (lane == 0) atomicExch(a.err, 1); return false; }
+        // block grid anchored at the chromosome start, so a region never begins before it
+        R = ch_start + ((r0 - ch_start) / B) * B;
+        C = ch_start + ((c0 - ch_start) / B) * B;
+        staged_exp = es.base;
+        stage(es);
+        return true;
+    };
+    auto same_block = [&](int r0, int c0) -> bool {       // cheap test used to pair two windows
+        const int dr = r0 - R, dc = c0 - C;
+        return !OOE && dr >= 0 && dr < B && dc >= 0 && dc < B && r0 + W <= ch_end && c0 + W <= ch_end && c0 >= ch_start;
+    };
+
+    // coordinates are fetched 64 snippets at a time (one per lane, next batch in flight) and handed out by readlane:
+    // a per-snippet global load would put its full latency on the critical path of this short loop body
+    int r0n = (cb + lane < ce) ? a.r0[cb + lane] : 0, c0n = (cb + lane < ce) ? a.c0[cb + lane] : 0;
+    for (long long s0 = cb; s0 < ce; s0 += kWave) {
+        const int r0v = r0n, c0v = c0n;
+        { const long long sn = s0 + kWave + lane; r0n = sn < ce ? a.r0[sn] : 0; c0n = sn < ce ? a.c0[sn] : 0; }
+        const int nb = (int)((ce - s0) < kWave ? (ce - s0) : kWave);
+        int j = 0;
+        while (j < nb) {
+            const int ra = __builtin_amdgcn_readlane(r0v, j), ca = __builtin_amdgcn_readlane(c0v, j);
+            if (!ensure(ra, ca)) { ++j; continue; }
+            double va[CH]; unsigned vwa, pwa;
+            gather(ra, ca, va, vwa, pwa);
+            // the next window usually lives in the same region: fetch it before adding this one (LDS latency)
+            if (j + 1 < nb) {
+                const int rb = __builtin_amdgcn_readlane(r0v, j + 1), cbx = __builtin_amdgcn_readlane(c0v, j + 1);
+                if (same_block(rb, cbx)) {
+                    double vb[CH]; unsigned vwb, pwb;
+                    gather(rb, cbx, vb, vwb, pwb);
+                    add(ra, ca, va, vwa, pwa);
+                    add(rb, cbx, vb, vwb, pwb);
+                    j += 2;
+                    continue;
+                }
+            }
+            add(ra, ca, va, vwa, pwa);
+            ++j;
+        }
+    }
+
+    __syncthreads();
+    const size_t L = (size_t)W2 + 2 * (size_t)W;
+    double*   of = a.part_f64 + (size_t)ck * L;
+    unsigned* on = a.part_num + (size_t)ck * W2;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        if ((chmask >> i) & 1u) {
+            const int cell = map_cell(p, q0 + i, W, false, fl);
+            of[cell] = sum[i];
+            on[cell] = num[i];
+        }
+    }
+    for (int t = lane; t < 2 * W; t += kWave) of[W2 + t] = m_cov ? cov_lds[t] : 0.0;
+    for (int off = 32; off > 0; off >>= 1) npix += __shfl_down(npix, off);
+    if (lane == 0 && stats) atomicAdd(&a.counters[0], npix);
+}
+
+// key of a snippet for the block order K1t wants: (segment = tile/flip run, block row, block col), plus a check
+// that the window is one the rank-bitmap index covers (cis, inside one chromosome); counts the ineligible ones
+__global__ __launch_bounds__(256) void block_key_kernel(const int* __restrict__ r0, const int* __restrict__ c0, long long n,
+                                                        const long long* __restrict__ seg_end, int nseg,
+                                                        const IdxChrom* __restrict__ chroms, int n_chrom, int W, int B,
+                                                        int sh_br, int sh_seg,
+                                                        unsigned long long* __restrict__ keys, unsigned* __restrict__ vals,
+                                                        unsigned long long* __restrict__ counters /* [0] ineligible */) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int r = r0[i], c = c0[i];
+    int lo = 0, hi = nseg;
+    while (lo < hi) { const int m = (lo + hi) >> 1; if (seg_end[m] <= i) lo = m + 1; else hi = m; }
+    int a = 0, b = n_chrom;
+    while (a < b) { const int m = (a + b) >> 1; if (chroms[m].end <= r) a = m + 1; else b = m; }
+    bool ok = r >= 0 && c >= 0 && a < n_chrom;
+    unsigned long long br = 0, bc = 0;
+    if (ok) {
+        const int cs = chroms[a].start, ce = chroms[a].end;
+        ok = r >= cs && r + W <= ce && c >= cs && c + W <= ce;
+        if (ok) {
+            br = (unsigned long long)cs + (unsigned long long)((r - cs) / B);   // unique and increasing over the genome
+            bc = (unsigned long long)((c - cs) / B);
+        }
+    }
+    if (!ok) atomicAdd(&counters[0], 1ull);
+    keys[i] = ((unsigned long long)lo << sh_seg) | (br << sh_br) | bc;
+    vals[i] = (unsigned)i;
+}
+
+// per segment (tile / flip run): number of positions where the block key differs from its predecessor
+// (= region stagings K1t would do in this order).  Grid-stride; counts are kept per workgroup in LDS and flushed once
+// (global atomics from every wave to the same few counters cost milliseconds).  nseg <= kMaxSegCount.
+constexpr int kMaxSegCount = 1024;
+__global__ __launch_bounds__(256) void count_changes_kernel(const unsigned long long* __restrict__ keys, long long n,
+                                                            int sh_seg, int nseg, unsigned long long* __restrict__ per_seg) {
+    __shared__ unsigned cnt[kMaxSegCount];
+    for (int t = threadIdx.x; t < nseg; t += blockDim.x) cnt[t] = 0u;
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned long long k = keys[i];
+        if (i == 0 || k != keys[i - 1]) atomicAdd(&cnt[(int)(k >> sh_seg)], 1u);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < nseg; t += blockDim.x) if (cnt[t]) atomicAdd(&per_seg[t], (unsigned long long)cnt[t]);
+}
+
+__global__ __launch_bounds__(256) void permute_snippets_kernel(const int* __restrict__ r0, const int* __restrict__ c0,
+                                                               const unsigned* __restrict__ order, long long n,
+                                                               int* __restrict__ r0s, int* __restrict__ c0s) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const unsigned j = order[i]; r0s[i] = r0[j]; c0s[i] = c0[j]; }
+}
+
+// 32-bit copy of the keys (when they fit): halves the radix passes of the block sort
+__global__ __launch_bounds__(256) void narrow_keys_kernel(const unsigned long long* __restrict__ k64, long long n,
+                                                          unsigned* __restrict__ k32) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) k32[i] = (unsigned)k64[i];
+}
+
+// Estimate of the windows per DISTINCT block, per segment, without sorting: only the blocks whose hashed key falls in
+// one of 8 classes are looked at (sampling by BLOCK keeps windows-per-block unbiased); each of their windows counts in
+// seen[seg] and sets one bit of a hashed bitmap — a window that finds its bit clear counts in fresh[seg].
+// windows per block ~ seen / fresh (bitmap collisions undercount fresh by a few per cent at the load factor used).
+__global__ __launch_bounds__(256) void distinct_blocks_kernel(const unsigned long long* __restrict__ keys, long long n,
+                                                              int sh_seg, int nseg, unsigned* __restrict__ bitmap,
+                                                              unsigned mask_bits, unsigned long long* __restrict__ seen,
+                                                              unsigned long long* __restrict__ fresh) {
+    __shared__ unsigned s_seen[kMaxSegCount], s_fresh[kMaxSegCount];
+    for (int t = threadIdx.x; t < nseg; t += blockDim.x) { s_seen[t] = 0u; s_fresh[t] = 0u; }
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned long long k = keys[i];
+        unsigned long long h = k * 0x9E3779B97F4A7C15ull;
+        h ^= h >> 29;
+        if ((h >> 61) != 0ull) continue;                       // 1 block class in 8
+        const int seg = (int)(k >> sh_seg);
+        const unsigned bit = (unsigned)h & mask_bits;
+        const unsigned old = atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
+        atomicAdd(&s_seen[seg], 1u);
+        if (!((old >> (bit & 31)) & 1u)) atomicAdd(&s_fresh[seg], 1u);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < nseg; t += blockDim.x) {
+        if (s_seen[t]) atomicAdd(&seen[t], (unsigned long long)s_seen[t]);
+        if (s_fresh[t]) atomicAdd(&fresh[t], (unsigned long long)s_fresh[t]);
+    }
+}
+
 // ---- K1b: banded register-tile kernel for wide windows (31 < W <= 16*NCH, up to 255) ----------------------------
 // Same idea as K1r, but a wave owns only a BAND of H = 64/NCH consecutive window rows of every snippet of its chunk
 // (lane (p,k): row band*H + p, the 16 columns [16k, 16k+16)), so the per-lane register tile stays 16 cells whatever

@@ -231,7 +231,22 @@ class PileupEngine:
         self._check(self._lib.pup_set_profiling(self._h, int(bool(enabled))))
 
     def set_tuning(self, chunk_snippets=0, variant=0):
+        """variant bits: 1 ignore the index, 2 LDS-tile kernel, 8 force / 16 forbid the block-staged kernel, see pup_hip.h."""
         self._check(self._lib.pup_set_tuning(self._h, int(chunk_snippets), int(variant)))
+
+    @staticmethod
+    def block_order(r0, c0, chrom_offset, tile=None, block=16):
+        """Permutation that puts snippets in the order the block-staged kernel wants inside every tile segment:
+        (tile, block row, block column, r0, c0), blocks anchored at the chromosome start.  A resident snippet set kept
+        in this order is piled up without the device-side sort (pup_set_tuning in pup_hip.h)."""
+        r0 = np.asarray(r0, np.int64)
+        c0 = np.asarray(c0, np.int64)
+        co = np.asarray(chrom_offset, np.int64)
+        start = co[np.clip(np.searchsorted(co, r0, side="right") - 1, 0, len(co) - 2)]
+        br = start + (r0 - start) // block
+        bc = (c0 - start) // block
+        keys = (c0, r0, bc, br) if tile is None else (c0, r0, bc, br, np.asarray(tile))
+        return np.lexsort(keys)
 
     def stats(self):
         s = _ffi.PupStats()

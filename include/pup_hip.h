@@ -218,6 +218,8 @@ typedef struct pup_stats {
     int64_t pixels_in_windows; /* sum over snippets of nnz inside the window (counted on device) */
     int64_t probe_loads;    /* binary-search probes issued (counted on device) */
     double  coverage_ms;    /* device time of the last pup_coverage kernel, ms */
+    int64_t staged_regions; /* last pup_accumulate: regions staged by the block-staged kernel (0: it did not run) */
+    double  prepare_ms;     /* total device time of the block-key / sort / permute prepass of that kernel, ms */
 } pup_stats;
 /* profiling on: every kernel launch is bracketed by HIP events on the context's stream */
 int pup_set_profiling(pup_ctx* ctx, int enabled);
@@ -227,7 +229,13 @@ int pup_clear_stats(pup_ctx* ctx);
 int pup_event_record(pup_ctx* ctx, int slot);
 int pup_event_elapsed_ms(pup_ctx* ctx, int slot_begin, int slot_end, float* ms);
 /* tuning knobs (0 = library default): snippets per chunk (per wave); variant bit 0 = ignore the index (binary
- * search only), bit 1 = LDS-tile kernel for every width, bits 8..23 = waves per interleaved group */
+ * search only), bit 1 = LDS-tile kernel for every width, bit 3 = always use the block-staged kernel where it is
+ * eligible (tests), bit 4 = never use it, bits 8..23 = waves per interleaved group.
+ * Block-staged kernel: a call of >= 1e6 cis windows (W <= 31, every window inside one chromosome, index built) is
+ * examined on the device; tile segments whose windows overlap enough (>= 4 windows per 16 x 16 block of top-left
+ * corners) are radix-sorted by block into a scratch copy — unless the caller already passes them in that order:
+ * (tile, flip, chromosome, (r0 - chrom_start) / 16, (c0 - chrom_start) / 16) — and piled up from LDS-staged regions.
+ * Results do not depend on which kernel ran (integers exactly, sums up to the order of the f64 additions). */
 int pup_set_tuning(pup_ctx* ctx, int32_t chunk_snippets, int32_t variant);
 
 #ifdef __cplusplus

@@ -16,15 +16,16 @@ def small_clr():
                              trans_nnz=40_000)
 
 
-@pytest.fixture(scope="module", params=["indexed", "search"])
+@pytest.fixture(scope="module", params=["indexed", "search", "staged"])
 def engine(hip_lib, small_clr, request):
-    """Both ways of locating a row's pixels must give identical results: the rank-bitmap index
-    (cis windows) and the binary search (index ignored: variant 1)."""
+    """All ways of locating a row's pixels must give identical results: the rank-bitmap index (cis windows), the
+    binary search (index ignored: variant 1), and the block-staged kernel (variant 8 forces it — device block sort +
+    LDS-staged regions — for every eligible call, however small)."""
     from coolpuppy_amd.engine import PileupEngine
     eng = PileupEngine(0)
     eng.load_pixels(*small_clr.pixel_table())
     assert eng.build_index(small_clr.chrom_offset)
-    eng._variant = 1 if request.param == "search" else 0
+    eng._variant = {"indexed": 0, "search": 1, "staged": 8}[request.param]
     eng.set_tuning(0, eng._variant)
     yield eng
     eng.close()

@@ -101,3 +101,47 @@ def test_oracle_on_strided_sample(eng, big, oracle_mod):
     np.testing.assert_allclose(got["sum"], want["sum"], rtol=1e-6, atol=0)
     np.testing.assert_allclose(got["cov_start"], want["cov_start"], rtol=1e-12)
     np.testing.assert_allclose(got["cov_end"], want["cov_end"], rtol=1e-12)
+
+
+def test_block_staged_kernel_takes_over_large_overlapping_calls(hip_lib):
+    """>= 1e6 overlapping cis windows: the engine sorts them by block on the device and piles the dense tile up from
+    LDS-staged regions (K1t), the sparse tile with the plain kernel; same integers, same sums up to addition order.
+    Pre-blocked input (PileupEngine.block_order) takes the same path without the sort."""
+    from coolpuppy_amd import synth
+    from coolpuppy_amd.engine import PileupEngine
+    clr = synth.make_cooler({"chrA": 40_000_000, "chrB": 25_000_000}, lam=120, seed=5)
+    rng = np.random.default_rng(9)
+    n_dense, n_sparse, pad = 1_300_000, 30_000, 10
+    W = 2 * pad + 1
+    lo, hi = clr.extent("chrA")
+    lo2, hi2 = clr.extent("chrB")
+    r0 = np.concatenate([rng.integers(lo, hi - W - 300, n_dense // 2), rng.integers(lo2, hi2 - W - 300, n_dense - n_dense // 2),
+                         rng.integers(lo, hi - W - 300, n_sparse)])
+    c0 = r0 + rng.integers(0, 280, len(r0))
+    tile_ptr = np.array([0, n_dense, n_dense + n_sparse], np.int64)
+    r0, c0 = r0.astype(np.int32), c0.astype(np.int32)
+    eng = PileupEngine(0)
+    eng.load_pixels(*clr.pixel_table())
+    eng.build_index(clr.chrom_offset)
+    eng.load_bins(clr.bins()["weight"][:].values, clr.bins()["cov_tot_raw"][:].values)
+    res = {}
+    for name, variant in (("plain", 16), ("auto", 0)):
+        eng.set_tuning(0, variant)
+        eng.reset(2, pad)
+        eng.accumulate(r0, c0, tile_ptr, ignore_diags=2, mode=0x04)
+        res[name] = (eng.fetch(), eng.stats()["staged_regions"])
+    assert res["plain"][1] == 0 and res["auto"][1] > 0
+    # pre-blocked input: no sort, same kernel
+    tile = np.repeat([0, 1], [n_dense, n_sparse])
+    o = PileupEngine.block_order(r0, c0, clr.chrom_offset, tile=tile)
+    eng.reset(2, pad)
+    eng.accumulate(r0[o], c0[o], tile_ptr, ignore_diags=2, mode=0x04)
+    res["blocked"] = (eng.fetch(), eng.stats()["staged_regions"])
+    assert res["blocked"][1] > 0
+    for name in ("auto", "blocked"):
+        got, want = res[name][0], res["plain"][0]
+        np.testing.assert_array_equal(got["n"], want["n"])
+        np.testing.assert_array_equal(got["num"], want["num"])
+        for k in ("sum", "cov_start", "cov_end"):
+            np.testing.assert_allclose(got[k], want[k], rtol=1e-11, atol=0)
+    eng.close()

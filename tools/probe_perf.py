@@ -83,6 +83,7 @@ def main():
                             "snips_per_s_k1": round(n / (st["k1_ms"] * 1e-3)),
                             "nnz_win_mean": round(st["pixels_in_windows"] / n, 1),
                             "probes_per_snip": round(st["probe_loads"] / n, 1),
+                            "staged_regions": st["staged_regions"], "prepare_ms": round(st["prepare_ms"], 3),
                             "alg_GBps": round(alg_bytes / (st["k1_ms"] * 1e-3) / 1e9, 1)}), flush=True)
     out = eng.fetch()
     print("n", out["n"][:4], "center", (out["sum"][:, a.pad, a.pad] / np.maximum(out["num"][:, a.pad, a.pad], 1))[:4])
