@@ -289,8 +289,8 @@ def main():
                 traffic = None
         roofline = {
             "bound": "hbm",
-            "kernel": ((f"pup::pileup_tiled_kernel<{W}, false, 16> (dense tile) + pup::pileup_regtile_kernel<{W}, false> "
-                        "(sparse tile), one launch each per step" if st.get("staged_regions", 0) > 0
+            "kernel": ((f"pup::pileup_tiled_kernel<{W}, false, 16, 16> (dense tile) + pup::pileup_regtile_kernel<{W}, false> "
+                        "(sparse tile), side by side on two streams, one launch each per step" if st.get("staged_regions", 0) > 0
                         else f"pup::pileup_regtile_kernel<{W}, false>") if W <= 31 else f"pup::pileup_band_kernel"),
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBPS * a.gpus, "unit": "GB/s", "frac": round(achieved / (HBM_PEAK_GBPS * a.gpus), 4),

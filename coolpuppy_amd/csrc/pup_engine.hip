@@ -45,6 +45,8 @@ struct DevBuf {           // grow-only device buffer
 struct pup_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;          // the plain kernel of a mixed (staged + plain) pile-up runs beside the staged one
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     // resident tables
     DevBuf<long long> indptr;
@@ -160,13 +162,14 @@ void launch_k1r(const pup::K1Args& a, int nchunks, hipStream_t s) {
         hipLaunchKernelGGL((pup::pileup_regtile_kernel<W, false>), dim3(nchunks), dim3(pup::kWave), 0, s, a);
 }
 
-// block-staged kernel (K1t), B = 16
+// block-staged kernel (K1t): blocks of kTileBR x kTileBC top-left corners
+constexpr int kTileBR = 16, kTileBC = 16;   // measured: 32x16 and 8x8 are slower (LDS occupancy / staging count)
 template <int W>
 void launch_k1t(const pup::K1Args& a, int nchunks, hipStream_t s) {
     if (a.mode & PUP_MODE_OOE)
-        hipLaunchKernelGGL((pup::pileup_tiled_kernel<W, true, 16>), dim3(nchunks), dim3(pup::kWave), 0, s, a);
+        hipLaunchKernelGGL((pup::pileup_tiled_kernel<W, true, kTileBR, kTileBC>), dim3(nchunks), dim3(pup::kWave), 0, s, a);
     else
-        hipLaunchKernelGGL((pup::pileup_tiled_kernel<W, false, 16>), dim3(nchunks), dim3(pup::kWave), 0, s, a);
+        hipLaunchKernelGGL((pup::pileup_tiled_kernel<W, false, kTileBR, kTileBC>), dim3(nchunks), dim3(pup::kWave), 0, s, a);
 }
 
 bool tiled_supported(int W) { return W >= 3 && W <= 31 && (W & 1); }
@@ -266,6 +269,8 @@ int pup_create(int device_id, pup_ctx** out) {
         c->n_cu = prop.multiProcessorCount;
     } else { c->max_lds = 64 * 1024; c->n_cu = 256; }
     for (auto& s : c->slots) (void)hipEventCreate(&s);
+    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) c->stream2 = nullptr;
+    (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming); (void)hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (c->counters.reserve(2) != hipSuccess || c->d_err.reserve(1) != hipSuccess) {
         pup_destroy(c);
         return fail(nullptr, PUP_ENOMEM, "pup_create: device allocation failed");
@@ -290,6 +295,9 @@ void pup_destroy(pup_ctx* c) {
     c->part_f64.release(); c->slice_f64.release(); c->part_num.release(); c->slice_num.release();
     c->counters.release(); c->d_err.release();
     for (auto& s : c->slots) if (s) (void)hipEventDestroy(s);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -636,7 +644,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         if (!forbid && !rescale && !(mode & (PUP_MODE_EXPECTED | PUP_MODE_TRANSPOSE)) && !(c->variant & 2) && use_idx_t &&
             ignore_diags >= 0 && tiled_supported(W) && n < 0xffffffffLL && (force || n >= c->tiled_min) &&
             2 * c->T <= pup::kMaxSegCount) {
-            const int B = 16;
+            const int BR = kTileBR, BC = kTileBC;
             const size_t nseg = (size_t)2 * c->T;
             std::vector<long long> seg_end;
             for (int t = 0; t < c->T; ++t) { seg_end.push_back(flip_from ? flip_from[t] : tile_ptr[t + 1]); seg_end.push_back(tile_ptr[t + 1]); }
@@ -647,7 +655,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
                 HIPCHK(c, hipMemcpy(tab.data(), c->idx_chrom.p, tab.size() * sizeof(pup::IdxChrom), hipMemcpyDeviceToHost));
                 for (auto& ch : tab) max_len = std::max<long long>(max_len, ch.end - ch.start);
             }
-            const int sh_br = nbits((unsigned long long)(max_len / B + 1));
+            const int sh_br = nbits((unsigned long long)(max_len / BC + 1));
             const int sh_seg = sh_br + nbits((unsigned long long)c->nbins + 1);
             const int end_bit = sh_seg + nbits((unsigned long long)(nseg > 1 ? nseg - 1 : 1));
             if (end_bit <= 64) {
@@ -664,7 +672,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
                 const unsigned gk = (unsigned)((n + 255) / 256);
                 hipLaunchKernelGGL(pup::block_key_kernel, dim3(gk), dim3(256), 0, c->stream, dr0, dc0, (long long)n,
                                    (const long long*)c->d_segend.p, (int)seg_end.size(), (const pup::IdxChrom*)c->idx_chrom.p,
-                                   c->n_chrom, W, B, sh_br, sh_seg, c->d_keys.p, c->d_vals.p, c->d_kcount.p);
+                                   c->n_chrom, W, BR, BC, sh_br, sh_seg, c->d_keys.p, c->d_vals.p, c->d_kcount.p);
                 const unsigned gs = (unsigned)std::min<long long>((n + 255) / 256, (long long)c->n_cu * 8);
                 hipLaunchKernelGGL(pup::count_changes_kernel, dim3(gs), dim3(256), 0, c->stream,
                                    (const unsigned long long*)c->d_keys.p, (long long)n, sh_seg, (int)nseg, c->d_kcount.p + 1);
@@ -839,7 +847,9 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     {
         size_t gp = 0, gt = 0;
         for (size_t g = 0; g < groups.size(); ++g) {
-            auto& lst = groups[g].staged ? xcd_list_t[gt++ % (size_t)n_xcd] : xcd_list[gp++ % (size_t)n_xcd];
+            // staged chunks are small (one wave, ~20 blocks): deal them out in runs of 32, so that neighbouring block
+            // rows — whose staged regions overlap in 20 of 36 matrix rows — meet in the same XCD's L2
+            auto& lst = groups[g].staged ? xcd_list_t[(gt++ / 32) % (size_t)n_xcd] : xcd_list[gp++ % (size_t)n_xcd];
             for (int j = 0; j < groups[g].waves; ++j)
                 for (int b = 0; b < nbands; ++b) lst.push_back((groups[g].first_chunk + j) * nbands + b);
         }
@@ -962,11 +972,20 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         launched = true;
     }
     if (!launched && tiled && c->g_nblocks_t > 0) {
-        // the segments whose windows overlap enough go to the staged kernel, the rest (below) to the plain one
+        // the segments whose windows overlap enough go to the staged kernel, the rest to the plain one — side by
+        // side on a second stream: the staged kernel is LDS-limited to ~3 waves per SIMD and leaves wave slots free
         pup::K1Args at = a;
         at.block_chunk = c->gv.block_chunk_t;
+        const bool side = nblocks > 0 && c->stream2 && c->ev_fork && c->ev_join;
+        if (side) {
+            HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+            launch_regtile(W, a, (int)nblocks, c->stream2);
+            HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
+        }
         if (!launch_tiled(W, at, (int)c->g_nblocks_t, c->stream)) return fail(c, PUP_ENOTSUP, "pup_accumulate: staged kernel not built for W=%d", W);
-        if (nblocks == 0) launched = true;
+        if (side) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        if (side || nblocks == 0) launched = true;
     }
     if (!launched && !lds_kernel2 && W <= 31) launched = launch_regtile(W, a, (int)nblocks, c->stream);
     if (!launched && !lds_kernel2 && W > 31 && W <= 255) {

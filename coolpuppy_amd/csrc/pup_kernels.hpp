@@ -652,9 +652,9 @@ __global__ __launch_bounds__(kWave, rt_min_waves(W)) void pileup_regtile_kernel(
 
 // ---- K1t: block-staged register tile (many OVERLAPPING cis windows) ------------------------------------------
 // When a pile-up is large, windows overlap: 1e7 control windows on a human 10 kb map put ~20 of them into every
-// B x B block of top-left corners.  K1r fetches every window on its own (index line + pixel values per row, ~75 L2
-// lines per window).  K1t needs the snippets ordered by block (r0 / B, c0 / B) — the engine sorts them on the
-// device — and lets a wave STAGE the (B+W-1)^2 region a block's windows live in ONCE into LDS, as final cell values:
+// 16 x 16 block of top-left corners.  K1r fetches every window on its own (index line + pixel values per row, ~75 L2
+// lines per window).  K1t needs the snippets ordered by block (r0 / BR, c0 / BC) — the engine sorts them on the
+// device — and lets a wave STAGE the (BR+W-1) x (BC+W-1) region a block's windows live in ONCE into LDS, as final cell values:
 // everything the reference does to a cell depends on its absolute (row, col) only — balanced value, masked bins,
 // ignored diagonals, expected of |col-row| — so the staged cell already is what gets summed (0 where nothing is
 // to be added) and one validity bit per cell says whether it counts in num.  Per window the wave then does 7 LDS
@@ -662,20 +662,21 @@ __global__ __launch_bounds__(kWave, rt_min_waves(W)) void pileup_regtile_kernel(
 // Same register accumulators, chunk flush and reduction as K1r; chunks are contiguous snippet ranges here.
 // Only windows the rank-bitmap index covers (cis, inside one chromosome) are eligible — the engine checks all of
 // them before choosing this kernel.
-template <int W, bool OOE, int B>
+template <int W, bool OOE, int BR, int BC>
 __global__ __launch_bounds__(kWave) void pileup_tiled_kernel(K1Args a) {
-    static_assert(W >= 1 && W <= 32 && B + W - 1 <= 64, "staged region rows must fit one 64-bit validity word");
+    static_assert(W >= 1 && W <= 32 && BC + W - 1 <= 64, "staged region rows must fit one 64-bit validity word");
     constexpr int NCH = kWave / W;
     constexpr int CH  = (W + NCH - 1) / NCH;
     constexpr int W2  = W * W;
-    constexpr int RS  = B + W - 1;                   // staged region: RS x RS bins
+    constexpr int RSR = BR + W - 1;                  // staged region: RSR rows x RS columns of bins
+    constexpr int RS  = BC + W - 1;
     constexpr int LS  = RS | 1;                      // odd row stride (LDS banks)
     constexpr int NT  = (RS + 15) / 16;              // column chunks per region row (staging lane-tasks)
     constexpr int TC  = ((RS + NT - 1) / NT + 1) & ~1;   // even chunk width <= 16, NT * TC >= RS
-    constexpr int NTASK = RS * NT;
-    __shared__ double tile[RS * LS + 2 * 16];
-    __shared__ unsigned long long vbits[RS];          // bit c: cell (row, c) counts in num
-    __shared__ unsigned long long pbits[RS];          // bit c: cell holds a pixel (statistics only)
+    constexpr int NTASK = RSR * NT;
+    __shared__ double tile[RSR * LS + 2 * 16];
+    __shared__ unsigned long long vbits[RSR];         // bit c: cell (row, c) counts in num
+    __shared__ unsigned long long pbits[RSR];         // bit c: cell holds a pixel (statistics only)
     __shared__ double cov_lds[2 * W];
     const int lane = threadIdx.x;
     const int p_raw = lane / NCH;
@@ -707,7 +708,7 @@ __global__ __launch_bounds__(kWave) void pileup_tiled_kernel(K1Args a) {
     const int fl = a.chunk_flip[ck];
     unsigned long long npix = 0;
     int ch_start = 0, ch_end = -1, ch_nblk = 0; long long ch_base = 0;
-    int R = -1, C = -1;                               // origin of the staged region (multiples of B); -1: none
+    int R = -1, C = -1;                               // origin of the staged region (block grid); -1: none
     const double* staged_exp = nullptr;
 
     // ---- stage the region of block (R, C): lane-task t = (region row, chunk of TC columns) ------------------
@@ -783,7 +784,7 @@ __global__ __launch_bounds__(kWave) void pileup_tiled_kernel(K1Args a) {
     };
     auto stage = [&](const ExpSel& es) {
         __syncthreads();                              // earlier windows are done reading the tile
-        for (int t = lane; t < RS; t += kWave) { vbits[t] = 0ull; pbits[t] = 0ull; }
+        for (int t = lane; t < RSR; t += kWave) { vbits[t] = 0ull; pbits[t] = 0ull; }
         __syncthreads();
         // two lane-tasks per lane and round: both index lines, then both sets of value loads, are in flight together
         for (int t0 = lane; t0 < NTASK; t0 += 2 * kWave) {
@@ -827,7 +828,7 @@ __global__ __launch_bounds__(kWave) void pileup_tiled_kernel(K1Args a) {
         ExpSel es; es.base = a.expv; es.len = 0; es.scalar = qnan; es.is_scalar = true;
         if (use_exp) es = select_expected(a, ecache, r0, c0);
         const int dr = r0 - R, dc = c0 - C;
-        if (R >= 0 && dr >= 0 && dr < B && dc >= 0 && dc < B && r0 < ch_end && !(OOE && es.base != staged_exp)) return true;
+        if (R >= 0 && dr >= 0 && dr < BR && dc >= 0 && dc < BC && r0 < ch_end && !(OOE && es.base != staged_exp)) return true;
         if (!(r0 >= ch_start && r0 < ch_end)) {
             int lo = 0, hi_k = a.n_chrom;
             while (lo < hi_k) { const int m = (lo + hi_k) >> 1; if (a.idx_chrom[m].end <= r0) lo = m + 1; else hi_k = m; }
@@ -837,15 +838,15 @@ __global__ __launch_bounds__(kWave) void pileup_tiled_kernel(K1Args a) {
         }
         if (c0 < ch_start || c0 + W > ch_end || r0 + W > ch_end) { if (lane == 0) atomicExch(a.err, 1); return false; }
         // block grid anchored at the chromosome start, so a region never begins before it
-        R = ch_start + ((r0 - ch_start) / B) * B;
-        C = ch_start + ((c0 - ch_start) / B) * B;
+        R = ch_start + ((r0 - ch_start) / BR) * BR;
+        C = ch_start + ((c0 - ch_start) / BC) * BC;
         staged_exp = es.base;
         stage(es);
         return true;
     };
     auto same_block = [&](int r0, int c0) -> bool {       // cheap test used to pair two windows
         const int dr = r0 - R, dc = c0 - C;
-        return !OOE && dr >= 0 && dr < B && dc >= 0 && dc < B && r0 + W <= ch_end && c0 + W <= ch_end && c0 >= ch_start;
+        return !OOE && dr >= 0 && dr < BR && dc >= 0 && dc < BC && r0 + W <= ch_end && c0 + W <= ch_end && c0 >= ch_start;
     };
 
     // coordinates are fetched 64 snippets at a time (one per lane, next batch in flight) and handed out by readlane:
@@ -899,7 +900,7 @@ __global__ __launch_bounds__(kWave) void pileup_tiled_kernel(K1Args a) {
 // that the window is one the rank-bitmap index covers (cis, inside one chromosome); counts the ineligible ones
 __global__ __launch_bounds__(256) void block_key_kernel(const int* __restrict__ r0, const int* __restrict__ c0, long long n,
                                                         const long long* __restrict__ seg_end, int nseg,
-                                                        const IdxChrom* __restrict__ chroms, int n_chrom, int W, int B,
+                                                        const IdxChrom* __restrict__ chroms, int n_chrom, int W, int BR, int BC,
                                                         int sh_br, int sh_seg,
                                                         unsigned long long* __restrict__ keys, unsigned* __restrict__ vals,
                                                         unsigned long long* __restrict__ counters /* [0] ineligible */) {
@@ -916,8 +917,8 @@ __global__ __launch_bounds__(256) void block_key_kernel(const int* __restrict__ 
         const int cs = chroms[a].start, ce = chroms[a].end;
         ok = r >= cs && r + W <= ce && c >= cs && c + W <= ce;
         if (ok) {
-            br = (unsigned long long)cs + (unsigned long long)((r - cs) / B);   // unique and increasing over the genome
-            bc = (unsigned long long)((c - cs) / B);
+            br = (unsigned long long)cs + (unsigned long long)((r - cs) / BR);  // unique and increasing over the genome
+            bc = (unsigned long long)((c - cs) / BC);
         }
     }
     if (!ok) atomicAdd(&counters[0], 1ull);

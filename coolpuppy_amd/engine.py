@@ -234,17 +234,21 @@ class PileupEngine:
         """variant bits: 1 ignore the index, 2 LDS-tile kernel, 8 force / 16 forbid the block-staged kernel, see pup_hip.h."""
         self._check(self._lib.pup_set_tuning(self._h, int(chunk_snippets), int(variant)))
 
+    BLOCK_ROWS, BLOCK_COLS = 16, 16      # kTileBR x kTileBC of pup_engine.hip
+
     @staticmethod
-    def block_order(r0, c0, chrom_offset, tile=None, block=16):
+    def block_order(r0, c0, chrom_offset, tile=None, block=None):
         """Permutation that puts snippets in the order the block-staged kernel wants inside every tile segment:
-        (tile, block row, block column, r0, c0), blocks anchored at the chromosome start.  A resident snippet set kept
-        in this order is piled up without the device-side sort (pup_set_tuning in pup_hip.h)."""
+        (tile, block row, block column, r0, c0), blocks of BLOCK_ROWS x BLOCK_COLS top-left corners anchored at the
+        chromosome start.  A resident snippet set kept in this order is piled up without the device-side sort
+        (pup_set_tuning in pup_hip.h)."""
+        br_size, bc_size = block or (PileupEngine.BLOCK_ROWS, PileupEngine.BLOCK_COLS)
         r0 = np.asarray(r0, np.int64)
         c0 = np.asarray(c0, np.int64)
         co = np.asarray(chrom_offset, np.int64)
         start = co[np.clip(np.searchsorted(co, r0, side="right") - 1, 0, len(co) - 2)]
-        br = start + (r0 - start) // block
-        bc = (c0 - start) // block
+        br = start + (r0 - start) // br_size
+        bc = (c0 - start) // bc_size
         keys = (c0, r0, bc, br) if tile is None else (c0, r0, bc, br, np.asarray(tile))
         return np.lexsort(keys)
 

@@ -45,12 +45,15 @@ for d in sorted(glob.glob(os.path.join(prof, "pmc_*"))):
         e["vgpr"] = int(g.VGPR_Count.iloc[0]); e["agpr"] = int(g.Accum_VGPR_Count.iloc[0])
         e["lds_bytes"] = int(g.LDS_Block_Size.iloc[0])
 
-k1 = next(k for k in summary if "pileup_" in k)
+# the pile-up step may be served by two kernels (block-staged for dense tiles + plain register tile for sparse ones):
+# traffic and time of "K1" are the sums over the pile-up kernels launched once per step
+k1s = [k for k in summary if "pileup_" in k]
+k1 = " + ".join(k1s)
 cal = next((k for k in summary if "balance_pixels" in k), None)
 doc = {"bench_line_under_rocprof": bench, "kernels": summary,
        "units": "FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB"}
-fetch_kib = summary[k1]["counters"]["FETCH_SIZE"]["mean_per_launch"]
-write_kib = summary[k1]["counters"]["WRITE_SIZE"]["mean_per_launch"]
+fetch_kib = sum(summary[k]["counters"]["FETCH_SIZE"]["mean_per_launch"] for k in k1s)
+write_kib = sum(summary[k]["counters"]["WRITE_SIZE"]["mean_per_launch"] for k in k1s)
 factor = 2.0      # MI355X_MICROARCH.md: gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced reads
 if cal:
     known_read = nnz * 8.0
@@ -68,8 +71,8 @@ doc["k1"] = {"kernel": k1, "FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_
 json.dump(doc, open(os.path.join(out, f"{tag}_pmc_summary.json"), "w"), indent=1)
 import hashlib
 c = bench["config"]
-# must match bench.workload_key(): w4|chroms|lam|pairs|nshifts|pad  (defaults: 23 chroms, lam 4200)
-key = hashlib.sha1(f"w4|23|4200.0|{c['pairs']}|{c['nshifts']}|{c['pad']}".encode()).hexdigest()[:12]
+# must match bench.workload_key(): w5|chroms|lam|pairs|nshifts|pad  (defaults: 23 chroms, lam 4200)
+key = hashlib.sha1(f"w5|23|4200.0|{c['pairs']}|{c['nshifts']}|{c['pad']}".encode()).hexdigest()[:12]
 json.dump({"workload_key": key, "hbm_bytes_per_launch": hbm, "kernel": k1, "source": f"profiles/{tag}_pmc_summary.json",
            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB->bytes, FETCH_SIZE x calibration "
                      "factor measured on balance_pixels_kernel (known 8 B/pixel stream) in the same run"},
