@@ -651,18 +651,22 @@ _ENGINES = {}
 
 
 def _engine_for(clr, device_id):
-    """One resident pixel table per (cooler object, device): repeated pile-ups skip the upload."""
+    """One resident pixel table per (cooler object, device): repeated pile-ups skip the upload.
+    COOLPUPPY_AMD_VARIANT (int, see pup_set_tuning) selects a kernel variant — used by the tests to run whole
+    pileup() calls through a kernel the engine would not pick for inputs that small."""
     from .engine import PileupEngine
     key = (id(clr), device_id)
     hit = _ENGINES.get(key)
     if hit is not None and hit[0] is clr:
-        return hit[1]
-    for k in [k for k, v in _ENGINES.items() if k[1] == device_id]:   # one table per device at a time
-        _ENGINES.pop(k)[1].close()
-    eng = PileupEngine(device_id)
-    eng.load_pixels(*clr.pixel_table())
-    eng.build_index(clr.chrom_offset)      # optional accelerator; False (too large) just means binary search
-    _ENGINES[key] = (clr, eng)
+        eng = hit[1]
+    else:
+        for k in [k for k, v in _ENGINES.items() if k[1] == device_id]:   # one table per device at a time
+            _ENGINES.pop(k)[1].close()
+        eng = PileupEngine(device_id)
+        eng.load_pixels(*clr.pixel_table())
+        eng.build_index(clr.chrom_offset)      # optional accelerator; False (too large) just means binary search
+        _ENGINES[key] = (clr, eng)
+    eng.set_tuning(0, int(os.environ.get("COOLPUPPY_AMD_VARIANT", "0") or 0))
     return eng
 
 
