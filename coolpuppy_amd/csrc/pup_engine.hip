@@ -718,7 +718,6 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
                             HIPCHK(c, c->d_vals2.reserve((size_t)n));
                             hipError_t se = hipSuccess;
                             size_t tmp_bytes = 0;
-                            const unsigned long long* sorted64 = nullptr;
                             if (end_bit <= 32) {
                                 HIPCHK(c, c->d_k32.reserve((size_t)n)); HIPCHK(c, c->d_k32b.reserve((size_t)n));
                                 hipLaunchKernelGGL(pup::narrow_keys_kernel, dim3(gk), dim3(256), 0, c->stream,
@@ -737,10 +736,8 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
                                 if (se == hipSuccess)
                                     se = rocprim::radix_sort_pairs(c->d_sorttmp.p, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_vals.p,
                                                                    c->d_vals2.p, (size_t)n, 0, end_bit, c->stream);
-                                sorted64 = c->d_keys2.p;
                             }
                             if (se != hipSuccess) return fail(c, PUP_EHIP, "pup_accumulate: block sort: %s", hipGetErrorString(se));
-                            (void)sorted64;
                             // the estimate stands in for the exact staging count (it only feeds the statistics)
                             HIPCHK(c, c->d_sr0.reserve((size_t)n)); HIPCHK(c, c->d_sc0.reserve((size_t)n));
                             hipLaunchKernelGGL(pup::permute_snippets_kernel, dim3(gk), dim3(256), 0, c->stream, dr0, dc0,
@@ -966,7 +963,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     bool launched = false;
     if (rescale) {
         const size_t rs_lds = (size_t)W * W * 12 + 16 * (size_t)W;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(pup::pileup_rescale_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pup::pileup_rescale_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_lds);
         hipLaunchKernelGGL(pup::pileup_rescale_kernel, dim3((unsigned)nblocks), dim3(256), rs_lds, c->stream, a,
                            (const int*)c->d_h.p, (const int*)c->d_w.p, (double*)nullptr, (double*)nullptr, 0LL);
         launched = true;
@@ -1128,8 +1125,8 @@ int pup_extract(pup_ctx* c, const int32_t* r0, const int32_t* c0, const int32_t*
         const unsigned grid = (unsigned)std::min<int64_t>(n, 16384);
         if (rescale) {
             const size_t rs_lds = W2 * 12 + 16 * (size_t)W;
-            hipFuncSetAttribute(reinterpret_cast<const void*>(pup::pileup_rescale_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pup::pileup_rescale_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_lds);
             if (cov_start && !(mode & PUP_MODE_COV)) e = hipMemsetAsync(d_cov.p, 0xff, (size_t)n * 2 * W * 8, c->stream);  // NaN
             hipLaunchKernelGGL(pup::pileup_rescale_kernel, dim3(grid), dim3(256), rs_lds, c->stream, a,
                                (const int*)c->d_h.p, (const int*)c->d_w.p, d_out.p, cov_start ? d_cov.p : (double*)nullptr,
