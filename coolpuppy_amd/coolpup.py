@@ -103,8 +103,16 @@ def expand2D(intervals, flank, resolution, rescale_flank=None):
         return intervals
     for side in ("1", "2"):
         c = intervals["center" + side]
-        intervals["exp_start" + side] = np.floor(c // resolution) * resolution - flank
-        intervals["exp_end" + side] = np.floor(c / resolution + 1) * resolution + flank
+        if (float(resolution).is_integer() and intervals["start" + side].dtype.kind in "iu"
+                and intervals["end" + side].dtype.kind in "iu"):
+            # centres are multiples of 0.5 and the resolution is an integer: c // res == floor(c / res) exactly (the
+            # quotient is never within rounding distance of an integer unless it is one), one division serves both
+            q = c.values / resolution
+            intervals["exp_start" + side] = np.floor(q) * resolution - flank
+            intervals["exp_end" + side] = np.floor(q + 1) * resolution + flank
+        else:
+            intervals["exp_start" + side] = np.floor(c // resolution) * resolution - flank
+            intervals["exp_end" + side] = np.floor(c / resolution + 1) * resolution + flank
     return intervals
 
 
@@ -234,6 +242,7 @@ class CoordCreator:
         if self.subset > 0:
             self.intervals = self._subset(self.intervals)
 
+        presorted = False
         iv = self.intervals
         if self.kind == "bed":
             assert have.issuperset(bed_cols), "Column names must include chrom, start, and end"
@@ -254,9 +263,14 @@ class CoordCreator:
                 c1, c2 = c1[keep], c2[keep]
             iv["chrom1"] = iv["chrom1"].astype(str)
             iv["chrom2"] = iv["chrom2"].astype(str)
+            # the reference sorts in _binnify (:489-527), after it has attached ~10 derived columns; every one of them is
+            # a row-wise function of the input columns, so sorting NOW (same keys, same stable pandas sort, index labels
+            # kept) gives the same frame while permuting half as many columns
             iv["center1"] = c1
             iv["center2"] = c2
             iv["distance"] = c2 - c1
+            iv = iv.sort_values(["chrom1", "chrom2", "start1", "start2"])
+            presorted = True
             iv = expand2D(iv, self.flank, self.resolution, self.rescale_flank)
         self.intervals = iv
 
@@ -291,7 +305,7 @@ class CoordCreator:
                    """
             )
 
-        self.intervals = self._binnify(self.intervals)
+        self.intervals = self._binnify(self.intervals, presorted=presorted)
 
         keys = ["stBin", "endBin"] if self.kind == "bed" else ["stBin1", "endBin1", "stBin2", "endBin2"]
         dups = self.intervals.duplicated(subset=keys) if logger.isEnabledFor(logging.DEBUG) else np.zeros(0, bool)
@@ -311,7 +325,7 @@ class CoordCreator:
             return df.sample(self.subset)
         return df
 
-    def _binnify(self, intervals):
+    def _binnify(self, intervals, presorted=False):
         """Sort and convert expanded coordinates to bins (reference :489-527). pandas does the sort so the
         row order (hence the control-shift assignment) is the reference's."""
         res = self.resolution
@@ -319,7 +333,8 @@ class CoordCreator:
             intervals = intervals.sort_values(["chrom", "start"])
             sides = [""]
         else:
-            intervals = intervals.sort_values(["chrom1", "chrom2", "start1", "start2"])
+            if not presorted:
+                intervals = intervals.sort_values(["chrom1", "chrom2", "start1", "start2"])
             sides = ["1", "2"]
         for s in sides:
             intervals["stBin" + s] = np.floor(intervals["exp_start" + s] / res).astype(int)
@@ -366,8 +381,9 @@ class CoordCreator:
                 ctrl[name] = ctrl[name] + shift2
         # ... but the BINS of both sides move by `shift` (reference :442-445)
         dbin = np.round(shift / self.resolution).astype(int)
+        dbin32 = dbin.astype(np.int32)
         for name in ("stBin1", "endBin1", "stBin2", "endBin2"):
-            ctrl[name] = ctrl[name] + dbin
+            ctrl[name] = ctrl[name] + (dbin32 if ctrl[name].dtype == np.int32 else dbin)
         roi = _Cols(cols)
         roi["kind"] = np.full(n, KIND_ROI, np.int8)
         ctrl["kind"] = np.full(m, KIND_CONTROL, np.int8)
@@ -444,7 +460,11 @@ class CoordCreator:
     def _col(self, name):
         c = self._cache()
         if name not in c["cols"]:
-            c["cols"][name] = self.intervals[name].values
+            v = self.intervals[name].values
+            if name.startswith(("stBin", "endBin")) and v.dtype.kind in "iu" and len(v) and \
+                    -2**31 < int(v.min()) and int(v.max()) < 2**31 - 2**24:
+                v = v.astype(np.int32)      # bins: every later pass (tile x nshifts, shift, filter) moves half the bytes
+            c["cols"][name] = v
         return c["cols"][name]
 
     def group_codes(self, name):
