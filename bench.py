@@ -297,6 +297,10 @@ def main():
             "traffic": traffic, "kernel_ms_per_launch": round(k1_ms_per_launch, 4),
             "algorithmic_bytes_per_launch": round(alg_bytes_total / a.steps / a.gpus),
             "nnz_win_mean": round(pix_total / max(snip_total, 1), 1),
+            "note": ("frac > 1 is possible by construction: 'achieved' charges every window its own algorithmic bytes "
+                     "(SURVEY 8d), while the block-staged kernel serves all windows of a 16x16 block from one region "
+                     "staged in LDS; 'traffic' is the real HBM byte count per launch (rocprofv3 PMC)"
+                     if st.get("staged_regions", 0) > 0 else "achieved = algorithmic bytes per launch / kernel time"),
             "staged_regions_per_launch": int(st.get("staged_regions", 0)),
             "prepass_ms_per_launch": round(st.get("prepare_ms", 0.0) / launches, 4),
         }
