@@ -799,8 +799,9 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     std::vector<long long> group_start;                             // DEVPTR: first snippet of every group
     auto add_run = [&](long long b, long long e, unsigned char flip, bool staged) {
         const int S = staged ? 1 : S_plain;                         // K1t: a chunk is a contiguous snippet range
-        for (long long g0 = b; g0 < e; g0 += (long long)S * C) {
-            const long long g1 = std::min(e, g0 + (long long)S * C);
+        const long long Cr = (staged && c->chunk_snippets <= 0) ? (C * 3) / 2 : C;   // every chunk start costs a staging
+        for (long long g0 = b; g0 < e; g0 += (long long)S * Cr) {
+            const long long g1 = std::min(e, g0 + (long long)S * Cr);
             const int waves = (int)std::min<long long>(S, std::max<long long>(1, (g1 - g0 + 15) / 16));
             if (!host_pos) group_start.push_back(g0);
             groups.push_back(Group{host_pos ? (long long)r0[g0] : (long long)groups.size(), (int)cb.size(), waves, staged});
