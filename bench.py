@@ -287,6 +287,11 @@ def main():
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        peak_measured = None
+        try:
+            peak_measured = json.load(open(os.path.join(ROOT, "profiles", "hbm_peak.json")))
+        except Exception:
+            pass
         roofline = {
             "bound": "hbm",
             "kernel": ((f"pup::pileup_tiled_kernel<{W}, false, 16, 16> (dense tile) + pup::pileup_regtile_kernel<{W}, false> "
@@ -301,6 +306,8 @@ def main():
                      "(SURVEY 8d), while the block-staged kernel serves all windows of a 16x16 block from one region "
                      "staged in LDS; 'traffic' is the real HBM byte count per launch (rocprofv3 PMC)"
                      if st.get("staged_regions", 0) > 0 else "achieved = algorithmic bytes per launch / kernel time"),
+            "peak_measured_GBps": (None if peak_measured is None else
+                                   {k: peak_measured[k] for k in ("read_GBps", "copy_GBps", "triad_GBps")}),
             "staged_regions_per_launch": int(st.get("staged_regions", 0)),
             "prepass_ms_per_launch": round(st.get("prepare_ms", 0.0) / launches, 4),
         }
