@@ -106,20 +106,26 @@ def allreduce_arrays(f64, i64):
 
 
 def allreduce_engine(eng):
-    """All-reduce the engine's packed accumulators across ranks, device to device (no host round trip)."""
+    """All-reduce the engine's packed accumulators across ranks: device to device with the nccl (= RCCL) backend,
+    through host memory with any other backend."""
     d = _dist()
     if d is None or d.get_world_size() == 1:
         return
     import torch
-    if d.get_backend() != "nccl":
-        raise RuntimeError("allreduce_engine needs the nccl (RCCL) backend: accumulators live in HBM")
     nf, ni = eng.packed_sizes()
     dev = torch.device("cuda", eng.device_id)
     bf = torch.empty(nf, dtype=torch.float64, device=dev)
     bi = torch.empty(ni, dtype=torch.int64, device=dev)
     torch.cuda.synchronize(dev)
     eng.export_to(bf.data_ptr(), bi.data_ptr())
-    d.all_reduce(bf)
-    d.all_reduce(bi)
+    if d.get_backend() == "nccl":          # RCCL over xGMI, device to device
+        d.all_reduce(bf)
+        d.all_reduce(bi)
+    else:                                  # e.g. gloo (tests: two ranks sharing one GPU): through host memory
+        hf, hi = bf.cpu(), bi.cpu()
+        d.all_reduce(hf)
+        d.all_reduce(hi)
+        bf.copy_(hf)
+        bi.copy_(hi)
     torch.cuda.synchronize(dev)
     eng.import_from(bf.data_ptr(), bi.data_ptr())

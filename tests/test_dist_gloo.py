@@ -99,3 +99,43 @@ def test_shard_is_deterministic_and_balanced():
     loads = [sum(w[i] for i in p) for p in parts]
     assert max(loads) - min(loads) <= 4
     assert parts == [pdist.shard(len(w), weights=w, rank=r, world_size=3) for r in range(3)]
+
+
+GPU_WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+os.environ["COOLPUPPY_AMD_DEVICE"] = "0"
+import torch.distributed as dist
+import golden_util as gu
+from coolpuppy_amd import coolpup
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2)
+out = {{}}
+for name in {names!r}:
+    z, df = gu.run(name, coolpup.pileup)
+    gu.compare(z, df, rtol=1e-6)
+    out[name] = int(len(df))
+dist.barrier()
+if dist.get_rank() == 0:
+    print("RESULT " + json.dumps(out))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_one_gpu_and_match_goldens(hip_lib, tmp_path):
+    """The library's multi-GPU path on real hardware: two processes (both on GPU 0, gloo rendezvous) each pile up
+    their slice of every engine call, exchange the packed accumulators (pup_export -> all-reduce -> pup_import) and
+    must both end with the reference's golden result."""
+    names = ["G1_bedpe_balanced", "G3_nshifts3", "G6c_by_strand_distance_controls", "G4_expected_ooe", "G2_raw_covnorm"]
+    names = [n for n in names if os.path.exists(os.path.join(ROOT, "tests", "golden", n + ".npz"))]
+    assert len(names) >= 3
+    script = tmp_path / "gpu_worker.py"
+    script.write_text(GPU_WORKER.format(root=ROOT, port=29517, names=names))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True, env=env) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    assert any("RESULT" in so for so, _ in outs)
