@@ -112,6 +112,17 @@ def group_by_region(snip):
         yield s
 
 
+def get_score(pup, center=3, ignore_central=3):
+    """One number for any pile-up (reference lib/puputils.py:44-85): off-diagonal -> mean of the central `center`
+    pixels; local -> insulation strength; local and rescaled -> domain score."""
+    from .numutils import get_domain_score, get_enrichment, get_insulation_strength
+    if not pup["local"]:
+        return get_enrichment(pup["data"], center)
+    if pup["rescale"]:
+        return get_domain_score(pup["data"], pup["rescale_flank"])
+    return get_insulation_strength(pup["data"], ignore_central)
+
+
 def norm_coverage(snip):
     """data /= outer(cov_start, cov_end) / nanmean(...) ; NaN -> 0 (reference lib/puputils.py:168-190)."""
     coverage = np.outer(snip["cov_start"], snip["cov_end"])

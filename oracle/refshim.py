@@ -177,7 +177,14 @@ def install():
     mod("bioframe", make_viewframe=make_viewframe, sort_bedframe=sort_bedframe, expand=bf_expand)
     api = mod("cooler.api", Cooler=ShimCooler)
     mod("cooler", api=api, Cooler=ShimCooler)
-    numutils = mod("cooltools.numutils", LazyToeplitz=LazyToeplitz, zoom_array=po.zoom_array)
+    def fill_diag(arr, x, i=0, copy=True):
+        out = np.array(arr, dtype=float, copy=True) if copy else arr
+        n, m = out.shape
+        k = np.arange(max(0, -i), min(n, m - i))
+        out[k, k + i] = x
+        return out
+
+    numutils = mod("cooltools.numutils", LazyToeplitz=LazyToeplitz, zoom_array=po.zoom_array, fill_diag=fill_diag)
     common = mod("cooltools.lib.common", make_cooler_view=make_cooler_view)
     checks = mod("cooltools.lib.checks", is_valid_expected=lambda *a, **k: True,
                  is_compatible_viewframe=lambda *a, **k: True)
