@@ -123,6 +123,37 @@ def get_score(pup, center=3, ignore_central=3):
     return get_insulation_strength(pup["data"], ignore_central)
 
 
+_NOT_COMPARED = ["control_n", "control_num", "n", "num", "clr", "chroms", "minshift", "expected_file", "group", "maxshift",
+                 "mindist", "maxdist", "subset", "seed", "data", "horizontal_stripe", "vertical_stripe", "cooler",
+                 "features", "outname", "coordinates"]
+
+
+def divide_pups(pup1, pup2):
+    """Ratio of two single-row pile-up frames of identical geometry (reference lib/puputils.py:116-165): data1 / data2,
+    n summed, annotation columns that differ are reported with a warning, stripes divided only when both hold the same
+    coordinates (inf / NaN quotients -> 0)."""
+    import logging
+    import warnings
+    if pup1.shape[0] > 1 or pup2.shape[0] > 1:
+        raise ValueError("Pileups cannot contain multiple conditions")
+    pup1, pup2 = pup1.reset_index(drop=True), pup2.reset_index(drop=True)
+    out = pup1.drop(columns=list(set(_NOT_COMPARED) & set(pup1.columns)))
+    for col in out.columns:
+        if np.all(np.sort(pup1[col]) != np.sort(pup2[col])):
+            warnings.warn(f"Note that {col} is different between the two pileups")
+    out["data"] = pup1["data"] / pup2["data"]
+    out["clrs"] = str(pup1["clr"]) + "/" + str(pup2["clr"])
+    out["n"] = pup1["n"] + pup2["n"]
+    if {"vertical_stripe", "horizontal_stripe"}.issubset(pup1.columns):
+        if np.all(np.sort(pup1["coordinates"]) == np.sort(pup2["coordinates"])):
+            out["coordinates"] = pup1["coordinates"]
+            for stripe in ("vertical_stripe", "horizontal_stripe"):
+                out[stripe] = (pup1[stripe] / pup2[stripe]).apply(lambda x: np.where(np.isin(x, [np.inf, np.nan]), 0, x))
+        else:
+            logging.info("Stripes cannot be divided, coordinates differ between pups")
+    return out
+
+
 def norm_coverage(snip):
     """data /= outer(cov_start, cov_end) / nanmean(...) ; NaN -> 0 (reference lib/puputils.py:168-190)."""
     coverage = np.outer(snip["cov_start"], snip["cov_end"])
