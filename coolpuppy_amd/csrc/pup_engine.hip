@@ -763,7 +763,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     gkey.reserve(8 + 2 * (size_t)c->T);
     gkey.push_back(n); gkey.push_back(c->T); gkey.push_back(c->W); gkey.push_back(c->chunk_snippets);
     gkey.push_back(c->group_waves); gkey.push_back(c->variant & 2); gkey.push_back((mode & PUP_MODE_EXPECTED) ? 1 : 0);
-    gkey.push_back(flip_from ? 1 : 0); gkey.push_back(rescale ? 1 : 0);
+    gkey.push_back(flip_from ? 1 : 0); gkey.push_back(rescale ? 1 : 0); gkey.push_back((ignore_diags < 0 ? 1 : 0) | (c->variant & 32) | ((c->nexp == 1 || c->have_exp_pair) ? 2 : 0) | ((mode & PUP_MODE_OOE) ? 4 : 0));
     for (char f : seg_tiled) gkey.push_back(f);
     for (int t = 0; t <= c->T; ++t) gkey.push_back(tile_ptr[t]);
     if (flip_from) for (int t = 0; t < c->T; ++t) gkey.push_back(flip_from[t]);
@@ -782,11 +782,22 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         C = std::max<long long>(16, (n + target - 1) / target);
     }
     if (rescale) C = std::max<long long>(1, (n + (long long)c->n_cu * 2 - 1) / ((long long)c->n_cu * 2));   // heavy snippets: ~2 workgroups per CU
+    const bool sparse_geom = !((mode & PUP_MODE_EXPECTED) || (c->variant & 2) || rescale) && ignore_diags < 0 && c->W <= 63 &&
+                             !(c->variant & 32) && pup::k1s_lds_bytes(c->W) <= (size_t)c->max_lds &&
+                             (!(mode & PUP_MODE_OOE) || c->nexp == 1 || c->have_exp_pair);
+    if (sparse_geom && c->chunk_snippets <= 0) {
+        // a sparse-kernel window is cheap, a chunk is not (zeroing and flushing a W^2 tile): two chunks per wave slot
+        const long long slots = (long long)c->n_cu * std::max<long long>(1, (160 * 1024) / (long long)pup::k1s_lds_bytes(c->W));
+        C = std::max<long long>(64, (n + 2 * slots - 1) / (2 * slots));
+    }
     const int S_plain = c->group_waves > 0 ? c->group_waves : 128;
     const int n_xcd = 8;
     // kernel family: register tile (W <= 31), banded register tile (W <= 255), LDS tile (EXPECTED pass, variant&2)
     const bool lds_kernel = (mode & PUP_MODE_EXPECTED) || (c->variant & 2) || rescale;
-    const bool band_kernel = !lds_kernel && c->W > 31;
+    // inter-chromosomal windows (no diagonal mask): sparse kernel, O(W) per window
+    // (OOE needs ONE expected value per window there: the trans scalar or the region-pair table)
+    const bool sparse_kernel = sparse_geom;
+    const bool band_kernel = !lds_kernel && !sparse_kernel && c->W > 31;
     const int nbands = band_kernel ? (c->W + (pup::kWave / band_nch(c->W)) - 1) / (pup::kWave / band_nch(c->W)) : 1;
     std::vector<long long> cb, ce, tile_chunk_ptr((size_t)c->T + 1, 0), dn((size_t)c->T);
     std::vector<unsigned char> cf;
@@ -984,6 +995,20 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         if (!launch_tiled(W, at, (int)c->g_nblocks_t, c->stream)) return fail(c, PUP_ENOTSUP, "pup_accumulate: staged kernel not built for W=%d", W);
         if (side) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         if (side || nblocks == 0) launched = true;
+    }
+    const bool sparse_launch = !lds_kernel2 && !rescale && ignore_diags < 0 && W <= 63 && !(c->variant & 32) &&
+                               pup::k1s_lds_bytes(W) <= (size_t)c->max_lds &&
+                               (!(mode & PUP_MODE_OOE) || c->nexp == 1 || c->have_exp_pair);
+    if (!launched && sparse_launch) {
+        const size_t sl = pup::k1s_lds_bytes(W);
+        if (mode & PUP_MODE_OOE) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pup::pileup_sparse_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl);
+            hipLaunchKernelGGL((pup::pileup_sparse_kernel<true>), dim3((unsigned)nblocks), dim3(pup::kWave), sl, c->stream, a);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pup::pileup_sparse_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl);
+            hipLaunchKernelGGL((pup::pileup_sparse_kernel<false>), dim3((unsigned)nblocks), dim3(pup::kWave), sl, c->stream, a);
+        }
+        launched = true;
     }
     if (!launched && !lds_kernel2 && W <= 31) launched = launch_regtile(W, a, (int)nblocks, c->stream);
     if (!launched && !lds_kernel2 && W > 31 && W <= 255) {

@@ -986,6 +986,132 @@ __global__ __launch_bounds__(256) void distinct_blocks_kernel(const unsigned lon
     }
 }
 
+// ---- K1s: sparse kernel for inter-chromosomal (trans) windows, W <= 63 ---------------------------------------
+// A trans window holds a handful of pixels (5e7 trans pixels under 4.6e10 cells: ~3 per 51 x 51 window), yet a dense
+// kernel touches all W^2 cells of every window — to count num.  Without a diagonal mask the validity of cell (p, q) of
+// a window factorises: valid = e_ok * !rowbad[p] * !colbad[q], so over a chunk
+//     num[p][q] = N_e  -  R[p]  -  C[q]  +  RC[p][q]
+// with N_e the windows whose expected is usable, R / C how often window row p / column q was a masked bin, and RC how
+// often both were (sparse: ~1 bad row x ~1 bad column per window).  Per window the wave therefore does O(W) work: one
+// lane per window row searches its matrix row (bounded by the per-chromosome segment table) and adds the few pixels
+// it finds to a per-wave LDS tile.  Same chunk flush and reduction as the other K1 kernels.
+// LDS per wave: W^2 * 12 + W * 24 bytes (W = 51: 32 KB).
+__host__ __device__ inline size_t k1s_lds_bytes(int W) { return (size_t)W * W * 12 + (size_t)W * 24; }
+
+template <bool OOE>
+__global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int W = a.W, W2 = W * W;
+    double*   tsum = reinterpret_cast<double*>(smem_raw);            // [W2]
+    double*   tcov = tsum + W2;                                      // [2W]
+    unsigned* trc  = reinterpret_cast<unsigned*>(tcov + 2 * W);      // [W2]  RC
+    unsigned* trb  = trc + W2;                                       // [W]   R
+    unsigned* tcb  = trb + W;                                        // [W]   C
+    const int lane = threadIdx.x;
+    const int ck = a.block_chunk[blockIdx.x];
+    if (ck < 0) return;
+    for (int t = lane; t < W2; t += kWave) { tsum[t] = 0.0; trc[t] = 0u; }
+    for (int t = lane; t < 2 * W; t += kWave) tcov[t] = 0.0;
+    for (int t = lane; t < W; t += kWave) { trb[t] = 0u; tcb[t] = 0u; }
+    __syncthreads();
+
+    const bool m_cov = (a.mode & 0x04u) && a.cov != nullptr;
+    const bool m_tr  = a.mode & 0x08u;
+    const bool use_exp = OOE && ((a.expv != nullptr && a.nexp > 0) || a.n_exp_regions > 0);
+    const double qnan = __builtin_nan("");
+    const long long cb = a.chunk_begin[ck], ce = a.chunk_end[ck], cstep = a.chunk_stride[ck];
+    const int fl = a.chunk_flip[ck];
+    ExpCache ecache;
+    ChromOf colchrom;
+    unsigned n_e = 0;                                                // wave-uniform
+    unsigned long long npix = 0, nprobe = 0;
+    const bool rowlane = lane < W;
+
+    // coordinates of 64 snippets per batch (one per lane, next batch in flight), handed out by readlane
+    auto coord = [&](long long s0, const int* __restrict__ src) { const long long sl = s0 + (long long)lane * cstep; return sl < ce ? src[sl] : 0; };
+    int r0n = coord(cb, a.r0), c0n = coord(cb, a.c0);
+    for (long long s0 = cb; s0 < ce; s0 += (long long)kWave * cstep) {
+      const int r0v = r0n, c0v = c0n;
+      r0n = coord(s0 + (long long)kWave * cstep, a.r0); c0n = coord(s0 + (long long)kWave * cstep, a.c0);
+      const long long left = (ce - s0 + cstep - 1) / cstep;
+      const int nb = (int)(left < kWave ? left : kWave);
+      for (int j = 0; j < nb; ++j) {
+        const int r0 = __builtin_amdgcn_readlane(r0v, j);
+        const int c0 = __builtin_amdgcn_readlane(c0v, j);
+        if (r0 < 0 || c0 < 0 || (long long)r0 + W > a.nbins || (long long)c0 + W > a.nbins) {
+            if (lane == 0) atomicExch(a.err, 1);
+            continue;
+        }
+        double e = 1.0;
+        bool e_ok = true;
+        if (OOE) {
+            ExpSel es; es.base = a.expv; es.len = 0; es.scalar = qnan; es.is_scalar = true;
+            if (use_exp) es = select_expected(a, ecache, r0, c0);
+            // trans expected is one scalar per region pair; a by-diagonal vector here would need the dense kernels
+            e = es.is_scalar ? es.scalar : qnan;
+            e_ok = (e == e) && (e != 0.0);
+        }
+        // masked bins of the window's rows (lane = row) and columns (lane = column)
+        const int myrow = r0 + (rowlane ? lane : 0), mycol = c0 + (rowlane ? lane : 0);
+        const bool rbad = rowlane && ((a.badbits[myrow >> 6] >> (myrow & 63)) & 1ull);
+        const bool cbad = rowlane && ((a.badbits[mycol >> 6] >> (mycol & 63)) & 1ull);
+        const unsigned long long rowmask = __ballot(rbad), colmask = __ballot(cbad);
+        if (e_ok) {
+            ++n_e;
+            if (rbad) trb[lane] += 1u;
+            if (cbad) tcb[lane] += 1u;
+            if (rowmask && colmask) {
+                unsigned long long rm = rowmask;
+                while (rm) {                                          // wave-uniform loop over the (rare) masked rows
+                    const int p = __ffsll((long long)rm) - 1; rm &= rm - 1;
+                    if (cbad) trc[p * W + lane] += 1u;
+                }
+            }
+        }
+        if (m_cov && rowlane) {
+            const double cr = a.cov[r0 + lane], cv = a.cov[c0 + lane];
+            const double vs = m_tr ? cv : cr, ve = m_tr ? cr : cv;
+            if (vs == vs) tcov[lane] += vs;
+            if (ve == ve) tcov[W + lane] += ve;
+        }
+        // pixels of this lane's matrix row inside [c0, c0 + W)
+        if (rowlane) {
+            const long long base = a.indptr[myrow], rowend = a.indptr[myrow + 1];
+            long long lo = base, hi = rowend;
+            if (a.rowseg != nullptr) {
+                const unsigned* seg = a.rowseg + (long long)myrow * (a.n_chrom + 1) + chrom_of(a, colchrom, c0);
+                lo = base + seg[0]; hi = base + seg[1];
+            }
+            long long b = hi;
+            while (lo < b) { const long long m = (lo + b) >> 1; if (a.px[m].x < c0) lo = m + 1; else b = m; ++nprobe; }
+            for (long long k = lo; k < hi; ++k) {
+                const int q = a.px[k].x - c0;
+                if (q >= W) break;
+                ++npix;
+                if (rbad || ((colmask >> q) & 1ull)) continue;          // masked bin: contributes nothing
+                const double v = a.bal[k];
+                const double x = OOE ? v / e : v;
+                if (x == x) tsum[lane * W + q] += x;                   // lane owns row `lane` of the tile: no race
+            }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- flush: num from the factorised counts; window frame -> accumulator frame ---------------------------
+    const size_t L = (size_t)W2 + 2 * (size_t)W;
+    double*   of = a.part_f64 + (size_t)ck * L;
+    unsigned* on = a.part_num + (size_t)ck * W2;
+    for (int t = lane; t < W2; t += kWave) {
+        const int p = t / W, q = t - p * W;
+        const int cell = map_cell(p, q, W, m_tr, fl);
+        of[cell] = tsum[t];
+        on[cell] = n_e - trb[p] - tcb[q] + trc[t];
+    }
+    for (int t = lane; t < 2 * W; t += kWave) of[W2 + t] = m_cov ? tcov[t] : 0.0;
+    for (int off = 32; off > 0; off >>= 1) { npix += __shfl_down(npix, off); nprobe += __shfl_down(nprobe, off); }
+    if (lane == 0 && a.counters) { atomicAdd(&a.counters[0], npix); atomicAdd(&a.counters[1], nprobe); }
+}
+
 // ---- K1b: banded register-tile kernel for wide windows (31 < W <= 16*NCH, up to 255) ----------------------------
 // Same idea as K1r, but a wave owns only a BAND of H = 64/NCH consecutive window rows of every snippet of its chunk
 // (lane (p,k): row band*H + p, the 16 columns [16k, 16k+16)), so the per-lane register tile stays 16 cells whatever

@@ -230,7 +230,8 @@ int pup_event_record(pup_ctx* ctx, int slot);
 int pup_event_elapsed_ms(pup_ctx* ctx, int slot_begin, int slot_end, float* ms);
 /* tuning knobs (0 = library default): snippets per chunk (per wave); variant bit 0 = ignore the index (binary
  * search only), bit 1 = LDS-tile kernel for every width, bit 3 = always use the block-staged kernel where it is
- * eligible (tests), bit 4 = never use it, bits 8..23 = waves per interleaved group.
+ * eligible (tests), bit 4 = never use it, bit 5 = never use the sparse trans kernel, bits 8..23 = waves per
+ * interleaved group.
  * Block-staged kernel: a call of >= 1e6 cis windows (W <= 31, every window inside one chromosome, index built) is
  * examined on the device; tile segments whose windows overlap enough (>= 4 windows per 16 x 16 block of top-left
  * corners) are radix-sorted by block into a scratch copy — unless the caller already passes them in that order:

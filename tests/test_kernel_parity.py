@@ -255,3 +255,48 @@ def test_cis_windows_near_chromosome_ends_and_trans_fallback(engine, small_clr, 
     engine.reset(1, pad)
     engine.accumulate(r0, c0, np.array([0, len(r0)], np.int64), ignore_diags=-1, mode=0)
     _compare(engine.fetch(), want)
+
+
+@pytest.mark.parametrize("pad", [10, 25, 31])
+@pytest.mark.parametrize("scenario", ["balanced", "raw_cov_flip", "ooe_exp_zero", "ooe_exp_nan"])
+def test_trans_sparse_kernel_vs_oracle_and_dense(hip_lib, small_clr, oracle_mod, pad, scenario):
+    """Inter-chromosomal windows take the sparse kernel (num from factorised bad-row / bad-column counts): oracle
+    parity, and the same integers as the dense kernels (variant 32 switches the sparse one off)."""
+    from coolpuppy_amd.engine import PileupEngine
+    po = oracle_mod
+    clr = small_clr
+    indptr, col, cnt = clr.pixel_table()
+    w = clr.bins()["weight"][:].values
+    cov = clr.bins()["cov_tot_raw"][:].values
+    W, T, n = 2 * pad + 1, 3, 1200
+    rng = np.random.default_rng(50 + pad)
+    loA, hiA = clr.extent("chrA")
+    loC, hiC = clr.extent("chrC")
+    r0 = rng.integers(loA, hiA - W, n).astype(np.int32)
+    c0 = rng.integers(loC, hiC - W, n).astype(np.int32)
+    tile = rng.integers(0, T, n).astype(np.int32)
+    flip, mode, weight, covv, expv = None, 0, w, None, None
+    if scenario == "raw_cov_flip":
+        mode, weight, covv = po.MODE_COV, None, cov
+        flip = (rng.random(n) < 0.4).astype(np.uint8)
+    elif scenario == "ooe_exp_zero":
+        mode, expv = po.MODE_OOE, np.array([0.0])
+    elif scenario == "ooe_exp_nan":
+        mode, expv = po.MODE_OOE, np.array([np.nan])
+    r0, c0, flip, tile, tile_ptr = _group(r0, c0, flip, tile, T)
+    ff = _flip_from(flip, tile, tile_ptr)
+    want = po.pileup_c(indptr, col, cnt, weight, covv, expv, r0, c0, flip, tile, T, pad, -1, mode)
+    got = {}
+    for name, variant in (("sparse", 0), ("dense", 32)):
+        eng = PileupEngine(0)
+        eng.load_pixels(indptr, col, cnt)
+        eng.build_index(clr.chrom_offset)
+        eng.set_tuning(0, variant)
+        eng.load_bins(weight, covv)
+        eng.set_expected(expv)
+        eng.reset(T, pad)
+        eng.accumulate(r0, c0, tile_ptr, flip_from=ff, ignore_diags=-1, mode=mode)
+        got[name] = eng.fetch()
+        eng.close()
+        _compare(got[name], want)
+    np.testing.assert_array_equal(got["sparse"]["num"], got["dense"]["num"])
