@@ -1027,74 +1027,97 @@ __global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
     unsigned long long npix = 0, nprobe = 0;
     const bool rowlane = lane < W;
 
-    // coordinates of 64 snippets per batch (one per lane, next batch in flight), handed out by readlane
-    auto coord = [&](long long s0, const int* __restrict__ src) { const long long sl = s0 + (long long)lane * cstep; return sl < ce ? src[sl] : 0; };
-    int r0n = coord(cb, a.r0), c0n = coord(cb, a.c0);
-    for (long long s0 = cb; s0 < ce; s0 += (long long)kWave * cstep) {
-      const int r0v = r0n, c0v = c0n;
-      r0n = coord(s0 + (long long)kWave * cstep, a.r0); c0n = coord(s0 + (long long)kWave * cstep, a.c0);
-      const long long left = (ce - s0 + cstep - 1) / cstep;
-      const int nb = (int)(left < kWave ? left : kWave);
-      for (int j = 0; j < nb; ++j) {
-        const int r0 = __builtin_amdgcn_readlane(r0v, j);
-        const int c0 = __builtin_amdgcn_readlane(c0v, j);
+    // one window's state between its phases; two windows are in flight per wave (their dependent load chains —
+    // bin masks / row bounds, bisection probes, pixels — interleave, the kernel being latency-bound)
+    struct Win { int r0, c0, myrow; bool valid, rbad, cbad, e_ok; unsigned long long rowmask, colmask; double e;
+                 long long lo, b, hi; };
+    auto begin = [&](Win& w, int r0, int c0, bool have) __attribute__((always_inline)) {
+        w.valid = false; w.lo = 0; w.b = 0; w.hi = 0;
+        if (!have) return;
         if (r0 < 0 || c0 < 0 || (long long)r0 + W > a.nbins || (long long)c0 + W > a.nbins) {
             if (lane == 0) atomicExch(a.err, 1);
-            continue;
+            return;
         }
-        double e = 1.0;
-        bool e_ok = true;
+        w.valid = true; w.r0 = r0; w.c0 = c0; w.e = 1.0; w.e_ok = true;
         if (OOE) {
             ExpSel es; es.base = a.expv; es.len = 0; es.scalar = qnan; es.is_scalar = true;
             if (use_exp) es = select_expected(a, ecache, r0, c0);
-            // trans expected is one scalar per region pair; a by-diagonal vector here would need the dense kernels
-            e = es.is_scalar ? es.scalar : qnan;
-            e_ok = (e == e) && (e != 0.0);
+            // trans expected is one scalar per region pair (the engine sends by-diagonal vectors to the dense kernels)
+            w.e = es.is_scalar ? es.scalar : qnan;
+            w.e_ok = (w.e == w.e) && (w.e != 0.0);
         }
         // masked bins of the window's rows (lane = row) and columns (lane = column)
-        const int myrow = r0 + (rowlane ? lane : 0), mycol = c0 + (rowlane ? lane : 0);
-        const bool rbad = rowlane && ((a.badbits[myrow >> 6] >> (myrow & 63)) & 1ull);
-        const bool cbad = rowlane && ((a.badbits[mycol >> 6] >> (mycol & 63)) & 1ull);
-        const unsigned long long rowmask = __ballot(rbad), colmask = __ballot(cbad);
-        if (e_ok) {
+        w.myrow = r0 + (rowlane ? lane : 0);
+        const int mycol = c0 + (rowlane ? lane : 0);
+        w.rbad = rowlane && ((a.badbits[w.myrow >> 6] >> (w.myrow & 63)) & 1ull);
+        w.cbad = rowlane && ((a.badbits[mycol >> 6] >> (mycol & 63)) & 1ull);
+        if (rowlane) {
+            const long long base = a.indptr[w.myrow];
+            w.lo = base; w.hi = a.indptr[w.myrow + 1];
+            if (a.rowseg != nullptr) {
+                const unsigned* seg = a.rowseg + (long long)w.myrow * (a.n_chrom + 1) + chrom_of(a, colchrom, c0);
+                w.lo = base + seg[0]; w.hi = base + seg[1];
+            }
+            w.b = w.hi;
+        }
+    };
+    auto finish = [&](Win& w) __attribute__((always_inline)) {
+        if (!w.valid) return;                                         // wave-uniform
+        w.rowmask = __ballot(w.rbad); w.colmask = __ballot(w.cbad);
+        if (w.e_ok) {
             ++n_e;
-            if (rbad) trb[lane] += 1u;
-            if (cbad) tcb[lane] += 1u;
-            if (rowmask && colmask) {
-                unsigned long long rm = rowmask;
+            if (w.rbad) trb[lane] += 1u;
+            if (w.cbad) tcb[lane] += 1u;
+            if (w.rowmask && w.colmask) {
+                unsigned long long rm = w.rowmask;
                 while (rm) {                                          // wave-uniform loop over the (rare) masked rows
                     const int p = __ffsll((long long)rm) - 1; rm &= rm - 1;
-                    if (cbad) trc[p * W + lane] += 1u;
+                    if (w.cbad) trc[p * W + lane] += 1u;
                 }
             }
         }
         if (m_cov && rowlane) {
-            const double cr = a.cov[r0 + lane], cv = a.cov[c0 + lane];
+            const double cr = a.cov[w.r0 + lane], cv = a.cov[w.c0 + lane];
             const double vs = m_tr ? cv : cr, ve = m_tr ? cr : cv;
             if (vs == vs) tcov[lane] += vs;
             if (ve == ve) tcov[W + lane] += ve;
         }
-        // pixels of this lane's matrix row inside [c0, c0 + W)
         if (rowlane) {
-            const long long base = a.indptr[myrow], rowend = a.indptr[myrow + 1];
-            long long lo = base, hi = rowend;
-            if (a.rowseg != nullptr) {
-                const unsigned* seg = a.rowseg + (long long)myrow * (a.n_chrom + 1) + chrom_of(a, colchrom, c0);
-                lo = base + seg[0]; hi = base + seg[1];
-            }
-            long long b = hi;
-            while (lo < b) { const long long m = (lo + b) >> 1; if (a.px[m].x < c0) lo = m + 1; else b = m; ++nprobe; }
-            for (long long k = lo; k < hi; ++k) {
-                const int q = a.px[k].x - c0;
+            for (long long k = w.lo; k < w.hi; ++k) {                 // pixels of this lane's matrix row inside [c0, c0 + W)
+                const int q = a.px[k].x - w.c0;
                 if (q >= W) break;
                 ++npix;
-                if (rbad || ((colmask >> q) & 1ull)) continue;          // masked bin: contributes nothing
+                if (w.rbad || ((w.colmask >> q) & 1ull)) continue;    // masked bin: contributes nothing
                 const double v = a.bal[k];
-                const double x = OOE ? v / e : v;
-                if (x == x) tsum[lane * W + q] += x;                   // lane owns row `lane` of the tile: no race
+                const double x = OOE ? v / w.e : v;
+                if (x == x) tsum[lane * W + q] += x;                 // lane owns row `lane` of the tile: no race
             }
         }
-      }
+    };
+
+    // coordinates of 64 snippets per batch (one per lane, next batch in flight), handed out by readlane
+    auto coord = [&](long long s0, const int* __restrict__ src) { const long long sl = s0 + (long long)lane * cstep; return sl < ce ? src[sl] : 0; };
+    int r0n = coord(cb, a.r0), c0n = coord(cb, a.c0);
+    for (long long s0 = cb; s0 < ce; s0 += (long long)kWave * cstep) {
+        const int r0v = r0n, c0v = c0n;
+        r0n = coord(s0 + (long long)kWave * cstep, a.r0); c0n = coord(s0 + (long long)kWave * cstep, a.c0);
+        const long long left = (ce - s0 + cstep - 1) / cstep;
+        const int nb = (int)(left < kWave ? left : kWave);
+        for (int j = 0; j < nb; j += 2) {
+            Win A, B;
+            begin(A, __builtin_amdgcn_readlane(r0v, j), __builtin_amdgcn_readlane(c0v, j), true);
+            const int j1 = j + 1 < nb ? j + 1 : j;
+            begin(B, __builtin_amdgcn_readlane(r0v, j1), __builtin_amdgcn_readlane(c0v, j1), j + 1 < nb);
+            // both bisections in lockstep: the two probes of a step are independent loads
+            while (__ballot(A.lo < A.b || B.lo < B.b)) {
+                const long long mA = (A.lo + A.b) >> 1, mB = (B.lo + B.b) >> 1;
+                const int xA = a.px[mA].x, xB = a.px[mB].x;           // padded table: reading at a row's end is harmless
+                if (A.lo < A.b) { if (xA < A.c0) A.lo = mA + 1; else A.b = mA; ++nprobe; }
+                if (B.lo < B.b) { if (xB < B.c0) B.lo = mB + 1; else B.b = mB; ++nprobe; }
+            }
+            finish(A);
+            finish(B);
+        }
     }
     __syncthreads();
     // ---- flush: num from the factorised counts; window frame -> accumulator frame ---------------------------
