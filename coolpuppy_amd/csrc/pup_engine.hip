@@ -608,6 +608,11 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
 
     const int W = c->W;
     const size_t W2 = (size_t)W * W, Lf = W2 + 2 * (size_t)W;
+    // rescaled windows are heavy (10^5 input cells each) and their S^2 output tile lives in LDS: as many workgroups per CU
+    // as that allows, ~4 rounds of them, 1024 threads each when only one or two fit (latency hiding comes from waves)
+    const size_t rs_tile = (size_t)c->W * c->W * 12 + 16 * (size_t)c->W;
+    const int rs_wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(rs_tile, 1)));
+    const int rs_threads = rs_wg_per_cu <= 2 ? 1024 : 512;
 
     // ---- snippets to device ----------------------------------------------------------------------
     const int *dr0, *dc0;
@@ -781,7 +786,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         const long long target = (long long)std::max(c->n_cu, 64) * 32 * 4;   // ~4 chunks per wave slot
         C = std::max<long long>(16, (n + target - 1) / target);
     }
-    if (rescale) C = std::max<long long>(1, (n + (long long)c->n_cu * 2 - 1) / ((long long)c->n_cu * 2));   // heavy snippets: ~2 workgroups per CU
+    if (rescale) C = std::max<long long>(1, (n + (long long)c->n_cu * rs_wg_per_cu * 4 - 1) / ((long long)c->n_cu * rs_wg_per_cu * 4));
     const bool sparse_geom = !((mode & PUP_MODE_EXPECTED) || (c->variant & 2) || rescale) && ignore_diags < 0 && c->W <= 63 &&
                              !(c->variant & 32) && pup::k1s_lds_bytes(c->W) <= (size_t)c->max_lds &&
                              (!(mode & PUP_MODE_OOE) || c->nexp == 1 || c->have_exp_pair);
@@ -976,7 +981,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     if (rescale) {
         const size_t rs_lds = (size_t)W * W * 12 + 16 * (size_t)W;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pup::pileup_rescale_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_lds);
-        hipLaunchKernelGGL(pup::pileup_rescale_kernel, dim3((unsigned)nblocks), dim3(256), rs_lds, c->stream, a,
+        hipLaunchKernelGGL(pup::pileup_rescale_kernel, dim3((unsigned)nblocks), dim3(rs_threads), rs_lds, c->stream, a,
                            (const int*)c->d_h.p, (const int*)c->d_w.p, (double*)nullptr, (double*)nullptr, 0LL);
         launched = true;
     }

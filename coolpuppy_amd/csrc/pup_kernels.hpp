@@ -1371,7 +1371,7 @@ __device__ __forceinline__ bool bin_bad(const K1Args& a, int bin) { return (a.ba
 // Emission mode (emit != nullptr, pup_extract): nothing is accumulated; the zoomed S x S tile of snippet s is written
 // to emit[s] (reference frame, i.e. TRANSPOSE undone; NaN where the reference's zoomed NaN mask is set) and its zoomed
 // coverage vectors to emit_cov[s] = {cov_start[S], cov_end[S]}.  Blocks then stride over snippets 0..emit_n.
-__global__ __launch_bounds__(256) void pileup_rescale_kernel(K1Args a, const int* __restrict__ hs, const int* __restrict__ wsz,
+__global__ __launch_bounds__(1024) void pileup_rescale_kernel(K1Args a, const int* __restrict__ hs, const int* __restrict__ wsz,
                                                              double* __restrict__ emit, double* __restrict__ emit_cov,
                                                              long long emit_n) {
 #pragma clang fp contract(off)      // zoom coordinates must be plain IEEE products (see below)
