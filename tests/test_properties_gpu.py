@@ -145,3 +145,55 @@ def test_block_staged_kernel_takes_over_large_overlapping_calls(hip_lib):
         for k in ("sum", "cov_start", "cov_end"):
             np.testing.assert_allclose(got[k], want[k], rtol=1e-11, atol=0)
     eng.close()
+
+
+@pytest.mark.parametrize("pad", list(range(1, 16)))
+def test_block_staged_kernel_equals_plain_kernel_for_every_width(hip_lib, pad):
+    """All 15 x 2 instantiations of the block-staged kernel (W = 3 .. 31, plain / OOE): forced on, against the plain
+    register-tile kernel on the same random inputs — several chromosomes, windows touching chromosome starts and ends,
+    windows below the diagonal, flips, three tiles, expected with zeros / NaN, raw counts with coverage."""
+    from coolpuppy_amd import synth
+    from coolpuppy_amd.engine import MODE_COV, MODE_OOE, PileupEngine
+    clr = synth.make_cooler({"chrA": 12_000_000, "chrB": 7_000_000, "chrC": 3_000_000}, lam=60, seed=21)
+    W, T, n = 2 * pad + 1, 3, 6000
+    rng = np.random.default_rng(1000 + pad)
+    r0l, c0l = [], []
+    for ch in clr.chromnames:
+        lo, hi = clr.extent(ch)
+        m = n // 3
+        r = rng.integers(lo, hi - W + 1, m)
+        c = np.clip(r + rng.integers(-6, 120, m), lo, hi - W)
+        r[:8] = lo; c[:8] = lo + np.arange(8)                       # chromosome start
+        r[8:16] = hi - W - np.arange(8); c[8:16] = hi - W           # chromosome end
+        r0l.append(r); c0l.append(c)
+    r0 = np.concatenate(r0l).astype(np.int32); c0 = np.concatenate(c0l).astype(np.int32)
+    tile = rng.integers(0, T, len(r0)).astype(np.int32)
+    flip = (rng.random(len(r0)) < 0.3)
+    key = tile.astype(np.int64) * 2 + flip
+    o = np.argsort(key, kind="stable")
+    r0, c0, tile, flip = r0[o], c0[o], tile[o], flip[o]
+    tile_ptr = np.concatenate([[0], np.cumsum(np.bincount(tile, minlength=T))]).astype(np.int64)
+    flip_from = tile_ptr[1:] - np.bincount(tile[flip], minlength=T)
+    w = clr.bins()["weight"][:].values
+    cov = clr.bins()["cov_tot_raw"][:].values
+    e = synth.cis_expected(clr)
+    expv = e[e.region1 == "chrA"]["balanced.avg"].values.copy()
+    expv[3] = 0.0; expv[7] = np.nan
+    eng = PileupEngine(0)
+    eng.load_pixels(*clr.pixel_table())
+    eng.build_index(clr.chrom_offset)
+    for weight, covv, mode, igd in ((w, None, 0, 2), (w, None, MODE_OOE, 2), (None, cov, MODE_COV, 0)):
+        eng.load_bins(weight, covv)
+        eng.set_expected(expv if mode & MODE_OOE else None)
+        res = {}
+        for name, variant in (("plain", 16), ("staged", 8)):
+            eng.set_tuning(0, variant)
+            eng.reset(T, pad)
+            eng.accumulate(r0, c0, tile_ptr, flip_from=flip_from, ignore_diags=igd, mode=mode)
+            res[name] = (eng.fetch(), eng.stats()["staged_regions"])
+        assert res["plain"][1] == 0 and res["staged"][1] > 0
+        for k in ("n", "num"):
+            np.testing.assert_array_equal(res["staged"][0][k], res["plain"][0][k])
+        for k in ("sum", "cov_start", "cov_end"):
+            np.testing.assert_allclose(res["staged"][0][k], res["plain"][0][k], rtol=1e-11, atol=0, equal_nan=True)
+    eng.close()
