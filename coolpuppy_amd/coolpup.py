@@ -325,6 +325,28 @@ class CoordCreator:
             return df.sample(self.subset)
         return df
 
+    def bedpe2bed(self, df, ends=True, how="center"):
+        """Both anchors of every pair as one sorted BED frame (ends=True), or one long interval per pair
+        (how = "outer" | "inner"); reference :463-487 (its how="center" branch calls np.mean with two arrays and
+        cannot run — the same call is made here)."""
+        if ends:
+            parts = []
+            for side in ("1", "2"):
+                part = df[["chrom" + side, "start" + side, "end" + side]]
+                part.columns = ["chrom", "start", "end"]
+                parts.append(part)
+            return pd.concat(parts).sort_values(["chrom", "start", "end"]).reset_index(drop=True)
+        if how == "center":
+            df["start"] = np.mean(df["start1"], df["end1"], axis=0)
+            df["end"] = np.mean(df["start2"], df["end2"], axis=0)
+        elif how == "outer":
+            df = df[["chrom1", "start1", "end2"]]
+            df.columns = ["chrom", "start", "end"]
+        elif how == "inner":
+            df = df[["chrom1", "end1", "start2"]]
+            df.columns = ["chrom", "start", "end"]
+        return df
+
     def _binnify(self, intervals, presorted=False):
         """Sort and convert expanded coordinates to bins (reference :489-527). pandas does the sort so the
         row order (hence the control-shift assignment) is the reference's."""
@@ -625,6 +647,8 @@ class CoordCreator:
         if modify_2Dintervals_func is not None:
             intervals = modify_2Dintervals_func(intervals)
         intervals = assign_groups(intervals, groupby)
+        intervals = intervals.reindex(columns=list(intervals.columns) + ["data", "cov_start", "cov_end",
+                                                                        "horizontal_stripe", "vertical_stripe"])
         if not len(intervals) >= 1:
             logger.debug("Empty selection")
             yield None
@@ -1280,49 +1304,75 @@ class PileUpper:
         return got if kw["coverage"] else (got, None, None)
 
     def _callback_region(self, region1, region2, groupby, modify_2Dintervals_func, postprocess_func, extra_sum_funcs):
-        """pileup_region with per-snippet Python callbacks (reference :1285-1358 with :1236-1283): the snippet
-        stream is rebuilt row by row — annotations as the reference's dict rows, windows from the GPU in batches —
-        and fed through postprocess_func and _add_snip in the reference's order."""
-        from functools import reduce
+        """pileup_region with per-snippet Python callbacks (reference :1285-1358): the region's window table as the
+        reference's dict rows -> _stream_snips (windows from the GPU) -> accumulate_stream (callbacks, _add_snip)."""
+        if region2 is None:
+            region2 = region1
+        b = self.region_snippets(region1, region2, groupby=groupby, modify_2Dintervals_func=modify_2Dintervals_func,
+                                 columns=None, keep_table=True)
+        rows = []
+        if b is not None and b["n"] > 0:
+            frame = pd.DataFrame({k: v for k, v in b["table"].items() if not k.startswith("_gc_")})
+            frame["kind"] = np.where(b["kind"] == KIND_ROI, "ROI", "control")
+            frame = assign_groups(frame, groupby)
+            frame = frame.reindex(columns=list(frame.columns) + ["data", "cov_start", "cov_end", "horizontal_stripe",
+                                                                 "vertical_stripe"])
+            rows = frame.to_dict(orient="records")
+        return self.accumulate_stream(self._stream_snips(iter(rows), region1, region2),
+                                      postprocess_func=postprocess_func, extra_funcs=extra_sum_funcs)
+
+    def _stream_snips(self, intervals, region1, region2=None):
+        """The reference's snippet generator (:1059-1191) with the per-snippet matrix work done by the GPU: rows of
+        ``intervals`` (dicts as CoordCreator.pos_stream yields them: chromosome-relative stBin1/endBin1/stBin2/endBin2,
+        kind, group, ...) come back, in order, with ``data`` (window as the reference builds it: balanced, NaN-masked,
+        / expected, rescaled), ``cov_start`` / ``cov_end``, stripes and coordinates filled in; a row whose window
+        leaves its region is dropped (:1111-1114); with expected and ooe=False each row is followed by its expected
+        twin of kind "control".  Windows are fetched from the engine in batches (pup_extract)."""
         from .engine import MODE_EXPECTED
+        rows = [r for r in intervals if r is not None]
+        if not rows:
+            return
         if region2 is None:
             region2 = region1
         exp_as_control = bool(self.expected) and not self.ooe
         if exp_as_control and self.rescale and self.coverage_norm:
             raise NotImplementedError("callbacks with rescale + coverage_norm + non-ooe expected")
+        lo1, hi1, off1 = self._global_extents[region1]
+        lo2, hi2, off2 = self._global_extents[region2]
+        ml1, ml2 = self.view_df_extents[region1][0], self.view_df_extents[region2][0]
+        st1 = np.array([r["stBin1"] for r in rows], np.int64); en1 = np.array([r["endBin1"] for r in rows], np.int64)
+        st2 = np.array([r["stBin2"] for r in rows], np.int64); en2 = np.array([r["endBin2"] for r in rows], np.int64)
+        keep = np.flatnonzero((st1 + off1 >= lo1) & (en1 + off1 <= hi1) & (st2 + off2 >= lo2) & (en2 + off2 <= hi2))
+        for i in keep:      # bins become region-relative before the snippet is handed on (reference :1104-1110)
+            r = rows[i]
+            r["stBin1"], r["endBin1"] = int(st1[i] - ml1), int(en1[i] - ml1)
+            r["stBin2"], r["endBin2"] = int(st2[i] - ml2), int(en2[i] - ml2)
+        b = {"r0": (st1 + off1).astype(np.int32), "c0": (st2 + off2).astype(np.int32),
+             "h": (en1 - st1).astype(np.int32), "w": (en2 - st2).astype(np.int32)}
+        if not self.rescale and len(keep) and not (np.all(b["h"][keep] == 2 * self.pad_bins + 1)
+                                                   and np.all(b["w"][keep] == 2 * self.pad_bins + 1)):
+            raise ValueError("window size differs from 2*pad_bins+1")
+        for lo in range(0, len(keep), self._CALLBACK_BATCH):
+            sel = keep[lo:lo + self._CALLBACK_BATCH]
+            data, cov_s, cov_e = self._windows(b, region1, region2, sel)
+            exp_data = self._windows(b, region1, region2, sel, mode_extra=MODE_EXPECTED)[0] if exp_as_control else None
+            yield from self._snip_stream(rows, sel, data, cov_s, cov_e, exp_data)
+
+    def accumulate_stream(self, snip_stream, postprocess_func=None, extra_funcs=None):
+        """Pile a stream of snippets (dicts with data, cov_start, cov_end, kind, group, ...) up per kind and group
+        (reference :1236-1283): postprocess_func maps every snippet (it may return several), _add_snip adds it,
+        "all" is the sum of the groups when no snippet was grouped under that name."""
+        from functools import reduce
+        if postprocess_func is not None:
+            snip_stream = map(postprocess_func, snip_stream)
         outdict = {"ROI": {}, "control": {}}
-        b = self.region_snippets(region1, region2, groupby=groupby, modify_2Dintervals_func=modify_2Dintervals_func,
-                                 columns=None, keep_table=True)
-        if b is not None and b["n"] > 0:
-            tbl = b["table"]
-            frame = pd.DataFrame({k: v for k, v in tbl.items() if not k.startswith("_gc_")})
-            frame["kind"] = np.where(b["kind"] == KIND_ROI, "ROI", "control")
-            # bins become region-relative before the snippet is handed on (reference :1104-1110)
-            ml1, ml2 = self.view_df_extents[region1][0], self.view_df_extents[region2][0]
-            for c, ml in (("stBin1", ml1), ("endBin1", ml1), ("stBin2", ml2), ("endBin2", ml2)):
-                frame[c] = frame[c] - ml
-            frame = assign_groups(frame, groupby)
-            frame = frame.reindex(columns=list(frame.columns) + ["data", "cov_start", "cov_end", "horizontal_stripe",
-                                                                 "vertical_stripe"])
-            rows = frame.to_dict(orient="records")
-            n = b["n"]
-            for lo in range(0, n, self._CALLBACK_BATCH):
-                sel = np.arange(lo, min(n, lo + self._CALLBACK_BATCH))
-                data, cov_s, cov_e = self._windows(b, region1, region2, sel)
-                exp_data = None
-                if exp_as_control:
-                    exp_data = self._windows(b, region1, region2, sel, mode_extra=MODE_EXPECTED)[0]
-                stream = self._snip_stream(rows, sel, data, cov_s, cov_e, exp_data)
-                if postprocess_func is not None:
-                    stream = map(postprocess_func, stream)
-                for snip in _collapse(stream):
-                    key = snip["group"]
-                    _add_snip(outdict[snip["kind"]], key if isinstance(key, str) else tuple(key), snip,
-                              extra_funcs=extra_sum_funcs)
-        sum_func = partial(sum_pups, extra_funcs=extra_sum_funcs)
+        for snip in _collapse(snip_stream):
+            key = snip["group"]
+            _add_snip(outdict[snip["kind"]], key if isinstance(key, str) else tuple(key), snip, extra_funcs=extra_funcs)
+        sum_func = partial(sum_pups, extra_funcs=extra_funcs)
         if "all" not in outdict["ROI"]:
             outdict["ROI"]["all"] = reduce(sum_func, outdict["ROI"].values(), self.empty_pup)
-        if self.control or exp_as_control:
+        if self.control or (self.expected and not self.ooe):
             if "all" not in outdict["control"]:
                 outdict["control"]["all"] = reduce(sum_func, outdict["control"].values(), self.empty_pup)
         return outdict
