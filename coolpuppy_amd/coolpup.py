@@ -589,6 +589,11 @@ class CoordCreator:
         # ---- bed: combinations ----
         rows_l = self._rows_region(tuple(region1))
         rows_r = rows_l if region2 is None or tuple(region2) == tuple(region1) else self._rows_region(tuple(region2))
+        return self._combination_table(rows_l, rows_r, nshifts, columns)
+
+    def _combination_table(self, rows_l, rows_r, nshifts, columns):
+        """Windows of all feature pairs (left feature from rows_l, right one from rows_r; row ids into self.intervals)."""
+        have = set(self.intervals.columns)
         want = None if columns is None else set(columns) | {"center1", "center2"}
 
         def side(rows, s):
@@ -657,8 +662,31 @@ class CoordCreator:
 
     def get_combinations(self, filter_func1, filter_func2=None, intervals=None, control=False, groupby=[],
                          modify_2Dintervals_func=None):
-        raise NotImplementedError(
-            "coolpuppy_amd generates bed combinations as column tables: use CoordCreator.region_table()")
+        """Per-snippet dict rows of the pairwise combinations of BED features, as the reference yields them
+        (:598-714).  Slow path kept for the low-level API; built on the same column tables the engine path uses."""
+        if intervals is None:
+            intervals = self.intervals
+        if not len(intervals) >= 1:
+            logger.debug("Empty selection")
+            yield None
+            return
+        if intervals is not self.intervals:
+            raise NotImplementedError("get_combinations works on the CoordCreator's own intervals")
+        tagged = intervals.assign(_row=np.arange(len(intervals)))
+        rows_l = filter_func1(tagged)["_row"].values
+        rows_r = rows_l if filter_func2 is None else filter_func2(tagged)["_row"].values
+        tbl = self._combination_table(rows_l, rows_r, self.nshifts * bool(control), None)
+        if tbl is None or len(tbl) == 0:
+            return
+        frame = pd.DataFrame({k: v for k, v in tbl.items() if not k.startswith("_gc_")})
+        frame["kind"] = np.where(tbl["kind"] == KIND_ROI, "ROI", "control")
+        if modify_2Dintervals_func is not None:
+            frame = modify_2Dintervals_func(frame)
+        frame = assign_groups(frame, groupby)
+        frame = frame.reindex(columns=list(frame.columns) + ["data", "cov_start", "cov_end", "horizontal_stripe",
+                                                             "vertical_stripe"])
+        for row in frame.to_dict(orient="records"):
+            yield row
 
     def empty_stream(self, *args, **kwargs):
         yield from ()
