@@ -212,6 +212,52 @@ def scenarios():
         rescale_flank=1, rescale_size=33, expected=exp_chrom, store_stripes=True)
     add("G12h_rescale_bedpe_stripes_controls", "small", bedpe.iloc[:100], features_format="bedpe", rescale=True,
         rescale_flank=2, rescale_size=15, nshifts=1, seed=23, flank=100_000, store_stripes=True)
+    # ---- randomised option combinations (seeded): interactions no hand-written scenario happens to cover ----------
+    frng = np.random.default_rng(20240928)
+    for k in range(32):
+        kind = ["bedpe", "bed", "bed_local"][k % 3]
+        kw = dict(flank=int(frng.choice([50_000, 100_000, 150_000])))
+        if kind == "bedpe":
+            feats = bedpe.iloc[frng.choice(len(bedpe), int(frng.integers(60, 220)), replace=False)].sort_index()
+            kw["features_format"] = "bedpe"
+            if frng.random() < 0.5:
+                kw["mindist"] = int(frng.choice([0, 300_000]))
+        else:
+            feats = bed.iloc[frng.choice(len(bed), int(frng.integers(30, 70)), replace=False)].sort_index()
+            kw["features_format"] = "bed"
+            if kind == "bed_local":
+                kw["local"] = True
+            else:
+                kw["mindist"] = int(frng.choice([200_000, 400_000])); kw["maxdist"] = int(frng.choice([2_000_000, 4_000_000]))
+        use_view = frng.random() < 0.4
+        mode = frng.choice(["plain", "controls", "expected_ooe", "expected_not_ooe", "raw_cov"])
+        if mode == "controls":
+            kw["nshifts"] = int(frng.integers(1, 5)); kw["seed"] = int(frng.integers(0, 100))
+        elif mode == "raw_cov":
+            kw["clr_weight_name"] = None; kw["coverage_norm"] = str(frng.choice(["total", "cis"]))
+            kw["min_diag"] = int(frng.choice([0, 2]))
+        elif mode == "expected_not_ooe":
+            kw["ooe"] = False
+        expected = None
+        if mode.startswith("expected"):
+            expected = exp_view if use_view else exp_chrom
+        if kind != "bed_local":
+            g = frng.random()
+            if g < 0.25:
+                kw["by_strand"] = True
+            elif g < 0.45 and kind == "bedpe":
+                kw["by_distance"] = True
+            elif g < 0.6:
+                kw["by_strand"] = True; kw["by_distance"] = True
+            elif g < 0.7 and kind == "bed":
+                kw["by_window"] = True
+            if kw.get("by_strand") and frng.random() < 0.5:
+                kw["flip_negative_strand"] = True
+            if kw.get("by_strand") and kind == "bed" and frng.random() < 0.4:
+                kw["ignore_group_order"] = True
+        if frng.random() < 0.25 and not kw.get("by_window"):
+            kw["store_stripes"] = True
+        add(f"F{k:02d}_{kind}_{mode}", "small", feats, view=view_sub if use_view else None, expected=expected, **kw)
     # the reference's own stripe test (tests/test_coolpup.py:143-172): raw counts, ignore_diags=0, first coordinates row
     # known-answer tests of the reference's own test-suite (tests/test_coolpup.py), n depends on coordinates only
     toy_kw = dict(features_format="bed", flank=2_000_000, mindist=0)
@@ -387,10 +433,16 @@ def main():
         kw = dict(sc["kw"])
         if isinstance(kw.get("by_distance"), list):
             kw["by_distance"] = np.array(kw["by_distance"])
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            df = ref.pileup(clr, sc["features"].copy(), view_df=None if sc["view"] is None else sc["view"].copy(),
-                            expected_df=None if sc["expected"] is None else sc["expected"].copy(), **kw)
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                df = ref.pileup(clr, sc["features"].copy(), view_df=None if sc["view"] is None else sc["view"].copy(),
+                                expected_df=None if sc["expected"] is None else sc["expected"].copy(), **kw)
+        except Exception as exc:      # an option combination the reference itself rejects / cannot run: not a scenario
+            if not sc["name"].startswith("F"):
+                raise
+            print(f"{sc['name']:45s} reference raised {type(exc).__name__}: {str(exc)[:80]}")
+            continue
         W = kw["rescale_size"] if kw.get("rescale") else 2 * (kw["flank"] // clr.binsize) + 1
         rec = record(df, W)
         meta = {"name": sc["name"], "cooler": sc["cooler"], "kw": sc["kw"], "features": csv_text(sc["features"]),
