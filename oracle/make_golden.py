@@ -258,6 +258,32 @@ def scenarios():
         if frng.random() < 0.25 and not kw.get("by_window"):
             kw["store_stripes"] = True
         add(f"F{k:02d}_{kind}_{mode}", "small", feats, view=view_sub if use_view else None, expected=expected, **kw)
+    for k in range(8):       # trans and rescaled option combinations
+        if k % 2 == 0:
+            tb = trans_bedpe(clr, int(frng.integers(80, 200)), int(frng.integers(100, 200)))
+            kw = dict(features_format="bedpe", trans=True, flank=int(frng.choice([50_000, 100_000, 250_000])))
+            m = frng.choice(["plain", "controls", "expected", "stripes"])
+            expected = None
+            if m == "controls":
+                kw["nshifts"] = int(frng.integers(1, 4)); kw["seed"] = int(frng.integers(0, 50))
+            elif m == "expected":
+                expected = tr_exp; kw["ooe"] = bool(frng.random() < 0.6)
+            elif m == "stripes":
+                kw["store_stripes"] = True
+            add(f"F{32 + k:02d}_trans_{m}", "small", tb, view=view_chrom if expected is not None else None, expected=expected, **kw)
+        else:
+            kw = dict(features_format="bed", local=True, rescale=True, rescale_flank=float(frng.choice([0.5, 1, 2])),
+                      rescale_size=int(frng.choice([15, 21, 33])))
+            m = frng.choice(["plain", "expected", "raw_cov", "stripes"])
+            expected = None
+            if m == "expected":
+                expected = exp_chrom; kw["ooe"] = bool(frng.random() < 0.6)
+            elif m == "raw_cov":
+                kw["clr_weight_name"] = None; kw["coverage_norm"] = True; kw["min_diag"] = int(frng.choice([0, 2]))
+            elif m == "stripes":
+                kw["store_stripes"] = True
+            add(f"F{32 + k:02d}_rescale_{m}", "small", tads.iloc[frng.choice(len(tads), 9, replace=False)].sort_index(),
+                expected=expected, **kw)
     # the reference's own stripe test (tests/test_coolpup.py:143-172): raw counts, ignore_diags=0, first coordinates row
     # known-answer tests of the reference's own test-suite (tests/test_coolpup.py), n depends on coordinates only
     toy_kw = dict(features_format="bed", flank=2_000_000, mindist=0)
