@@ -357,7 +357,7 @@ def main():
             if not ok:
                 print("[bench] PARITY FAILURE against the oracle on the sample", file=sys.stderr)
         line = {
-            "metric": "snippets/sec (21x21 windows @10kb, ROI + control snippets accumulated)",
+            "metric": f"snippets/sec ({W}x{W} windows @10kb, ROI + control snippets accumulated)",
             "value": round(value, 1), "unit": "snippets/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
