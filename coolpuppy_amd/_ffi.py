@@ -74,6 +74,7 @@ _SIGNATURES = {
     "pup_packed_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pup_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pup_import": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pup_allreduce": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pup_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "pup_get_stats": (C.c_int, [C.c_void_p, C.POINTER(PupStats)]),
     "pup_clear_stats": (C.c_int, [C.c_void_p]),

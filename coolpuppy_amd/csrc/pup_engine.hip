@@ -16,6 +16,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
 #include <new>
 #include <string>
 #include <vector>
@@ -1240,6 +1241,53 @@ int pup_import(pup_ctx* c, const void* dev_f64, const void* dev_i64) {
     HIPCHK(c, hipMemcpy(c->acc_i64.p, dev_i64, (size_t)ni * 8, hipMemcpyDeviceToDevice));
     HIPCHK(c, hipDeviceSynchronize());
     return PUP_OK;
+}
+
+// ---- native collective: RCCL all-reduce of the packed accumulators, in place, on the context's stream -----------
+// librccl is opened on first use (no link-time dependency: single-GPU users never load it).  Only the handful of
+// declarations needed are restated here (rccl.h: ncclResult_t 0 = success, ncclInt64 = 4, ncclFloat64 = 8, ncclSum = 0).
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool tried = false;
+};
+RcclApi g_rccl;
+bool load_rccl() {
+    if (g_rccl.tried) return g_rccl.AllReduce != nullptr;
+    g_rccl.tried = true;
+    // the soname first: if the process already holds an RCCL (e.g. the copy bundled with torch) that one is reused
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"}) {
+        g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.lib) break;
+    }
+    if (!g_rccl.lib) return false;
+    g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(g_rccl.lib, "ncclAllReduce"));
+    g_rccl.GroupStart = reinterpret_cast<decltype(g_rccl.GroupStart)>(dlsym(g_rccl.lib, "ncclGroupStart"));
+    g_rccl.GroupEnd = reinterpret_cast<decltype(g_rccl.GroupEnd)>(dlsym(g_rccl.lib, "ncclGroupEnd"));
+    g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(g_rccl.lib, "ncclGetErrorString"));
+    if (!g_rccl.AllReduce || !g_rccl.GroupStart || !g_rccl.GroupEnd) { g_rccl.AllReduce = nullptr; return false; }
+    return true;
+}
+}  // namespace
+
+int pup_allreduce(pup_ctx* c, void* rccl_comm) {
+    if (!c) return PUP_EINVAL;
+    if (!rccl_comm) return fail(c, PUP_EINVAL, "pup_allreduce: NULL communicator");
+    if (c->T <= 0) return fail(c, PUP_ESTATE, "pup_allreduce: call pup_reset first");
+    if (!load_rccl()) return fail(c, PUP_ENOTSUP, "pup_allreduce: librccl.so could not be loaded");
+    int rc = bind(c); if (rc) return rc;
+    int64_t nf, ni; pup_packed_sizes(c, &nf, &ni);
+    auto err = [&](int r) { return g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "rccl error"; };
+    int r = g_rccl.GroupStart();
+    if (r == 0) r = g_rccl.AllReduce(c->acc_f64.p, c->acc_f64.p, (size_t)nf, /*ncclFloat64*/ 8, /*ncclSum*/ 0, rccl_comm, c->stream);
+    if (r == 0) r = g_rccl.AllReduce(c->acc_i64.p, c->acc_i64.p, (size_t)ni, /*ncclInt64*/ 4, /*ncclSum*/ 0, rccl_comm, c->stream);
+    const int r2 = g_rccl.GroupEnd();
+    if (r != 0 || r2 != 0) return fail(c, PUP_EHIP, "pup_allreduce: %s", err(r != 0 ? r : r2));
+    return PUP_OK;                       // asynchronous: ordered on the context's stream like every other call
 }
 
 int pup_set_profiling(pup_ctx* c, int enabled) {

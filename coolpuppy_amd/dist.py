@@ -105,6 +105,44 @@ def allreduce_arrays(f64, i64):
     return tf.cpu().numpy(), ti.cpu().numpy()
 
 
+_NATIVE_COMMS = {}
+
+
+def native_comm(eng):
+    """An RCCL communicator (ncclComm_t address) for this engine's device over all ranks, created once: rank 0 draws
+    the ncclUniqueId, torch.distributed (any backend) only carries its 128 bytes to the other ranks.  Opt-in path
+    (COOLPUPPY_AMD_NATIVE_RCCL=1): exercised on hardware with a one-rank communicator only in round 1."""
+    import ctypes as C
+    d = _dist()
+    rank, world = d.get_rank(), d.get_world_size()
+    key = (eng.device_id, world)
+    if key in _NATIVE_COMMS:
+        return _NATIVE_COMMS[key][0]
+    try:
+        rccl = C.CDLL("librccl.so.1")
+    except OSError:
+        rccl = C.CDLL("librccl.so")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    if rank == 0 and rccl.ncclGetUniqueId(C.byref(uid)) != 0:
+        raise RuntimeError("ncclGetUniqueId failed")
+    import torch
+    t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).clone()
+    if d.get_backend() == "nccl":
+        t = t.cuda(eng.device_id)
+    d.broadcast(t, src=0)
+    C.memmove(C.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    torch.cuda.set_device(eng.device_id)
+    if rccl.ncclCommInitRank(C.byref(comm), world, uid, rank) != 0:
+        raise RuntimeError("ncclCommInitRank failed")
+    _NATIVE_COMMS[key] = (comm.value, rccl)
+    return comm.value
+
+
 def allreduce_engine(eng):
     """All-reduce the engine's packed accumulators across ranks: device to device with the nccl (= RCCL) backend,
     through host memory with any other backend."""
@@ -112,6 +150,9 @@ def allreduce_engine(eng):
     if d is None or d.get_world_size() == 1:
         return
     import torch
+    if os.environ.get("COOLPUPPY_AMD_NATIVE_RCCL", "") == "1":
+        eng.allreduce(native_comm(eng))       # in place on the engine's stream: no staging copies, no host sync
+        return
     nf, ni = eng.packed_sizes()
     dev = torch.device("cuda", eng.device_id)
     bf = torch.empty(nf, dtype=torch.float64, device=dev)

@@ -227,6 +227,12 @@ class PileupEngine:
         self._check(self._lib.pup_import(self._h, C.c_void_p(dev_f64_ptr), C.c_void_p(dev_i64_ptr)))
 
     # -- measurement --------------------------------------------------------------------------------------
+    def allreduce(self, rccl_comm):
+        """In-place RCCL all-reduce of the packed accumulators over an ncclComm_t (int address or c_void_p), asynchronous
+        on the engine's stream — the torch-free form of export_to / all_reduce / import_from."""
+        addr = rccl_comm.value if isinstance(rccl_comm, C.c_void_p) else int(rccl_comm)
+        self._check(self._lib.pup_allreduce(self._h, C.c_void_p(addr)))
+
     def set_profiling(self, enabled=True):
         self._check(self._lib.pup_set_profiling(self._h, int(bool(enabled))))
 

@@ -22,6 +22,7 @@
  *   pup_coverage                      <- cooltools.api.coverage.coverage(clr, ignore_diags=..., store=True), called by
  *                                        PileUpper.__init__ when cov_*_raw is missing     coolpuppy/coolpup.py:955-963
  *   pup_accumulate_rescaled           <- the same loop with _rescale_snip               coolpuppy/coolpup.py:1159-1162, 1193-1234
+ *   pup_export / pup_import / pup_allreduce <- reduce(sum_pups) over worker processes  coolpuppy/coolpup.py:1495-1531
  *   pup_stripes                       <- the store_stripes branch of _stream_snips   coolpuppy/coolpup.py:1164-1182
  *   pup_extract                       <- _stream_snips as a producer of per-snippet windows for the Python callbacks
  *                                        (postprocess_func / extra_sum_funcs)          coolpuppy/coolpup.py:1104-1162, 1261-1262
@@ -208,6 +209,15 @@ int pup_fetch(pup_ctx* ctx, double* sum, int64_t* num, int64_t* n, double* cov_s
 int pup_packed_sizes(pup_ctx* ctx, int64_t* n_f64, int64_t* n_i64);
 int pup_export(pup_ctx* ctx, void* dev_f64, void* dev_i64);
 int pup_import(pup_ctx* ctx, const void* dev_f64, const void* dev_i64);
+
+/*
+ * The same exchange without leaving the library: in-place RCCL all-reduce (sum) of the packed accumulators over the
+ * communicator `rccl_comm` (an ncclComm_t created by the caller for this context's device; every rank calls with
+ * identical n_tiles / pad), enqueued on the context's stream — no staging copy, no host synchronisation.  librccl is
+ * opened with dlopen on first use.  Replaces reduce(sum_pups) across the reference's worker processes
+ * (coolpuppy/coolpup.py:1495-1531).  PUP_ENOTSUP when librccl cannot be loaded.
+ */
+int pup_allreduce(pup_ctx* ctx, void* rccl_comm);
 
 /* measurement ------------------------------------------------------------------------------------- */
 typedef struct pup_stats {

@@ -41,3 +41,41 @@ def test_pileup_computes_missing_coverage_column(hip_lib, oracle_mod):
     assert "cov_tot_raw" in bare.bins().columns
     np.testing.assert_allclose(a["data"].iloc[0], b["data"].iloc[0], rtol=1e-12, equal_nan=True)
     np.testing.assert_array_equal(a["num"].iloc[0], b["num"].iloc[0])
+
+
+def test_native_rccl_allreduce_single_rank(hip_lib):
+    """pup_allreduce with a one-rank RCCL communicator (all the box offers): the call path through dlopen'd librccl
+    runs on the engine's stream and leaves the accumulators as they were (sum over one rank)."""
+    import ctypes as C
+    import numpy as np
+    from coolpuppy_amd import synth
+    from coolpuppy_amd.engine import PileupEngine
+    try:
+        rccl = C.CDLL("librccl.so")
+    except OSError:
+        rccl = C.CDLL("/opt/rocm/lib/librccl.so")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    eng = PileupEngine(0)                                       # binds device 0 before the communicator is created
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    clr = synth.make_cooler({"chrA": 8_000_000, "chrB": 5_000_000}, lam=60, seed=3)
+    eng.load_pixels(*clr.pixel_table())
+    eng.load_bins(clr.bins()["weight"][:].values, None)
+    rng = np.random.default_rng(0)
+    r0 = rng.integers(0, 700, 500).astype(np.int32)
+    c0 = (r0 + rng.integers(0, 60, 500)).astype(np.int32)
+    eng.reset(2, 10)
+    eng.accumulate(r0, c0, np.array([0, 200, 500]), ignore_diags=2, mode=0)
+    before = eng.fetch()
+    eng.allreduce(comm)
+    after = eng.fetch()
+    for k in before:
+        np.testing.assert_array_equal(before[k], after[k])
+    eng.close()
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    rccl.ncclCommDestroy(comm)
