@@ -1223,23 +1223,25 @@ int pup_export(pup_ctx* c, void* dev_f64, void* dev_i64) {
     if (!c) return PUP_EINVAL;
     if (c->T <= 0) return fail(c, PUP_ESTATE, "pup_export: call pup_reset first");
     if (!dev_f64 || !dev_i64) return fail(c, PUP_EINVAL, "pup_export: NULL destination");
-    int rc = pup_sync(c); if (rc) return rc;
+    int rc = bind(c); if (rc) return rc;
     int64_t nf, ni; pup_packed_sizes(c, &nf, &ni);
-    HIPCHK(c, hipMemcpy(dev_f64, c->acc_f64.p, (size_t)nf * 8, hipMemcpyDeviceToDevice));
-    HIPCHK(c, hipMemcpy(dev_i64, c->acc_i64.p, (size_t)ni * 8, hipMemcpyDeviceToDevice));
-    HIPCHK(c, hipDeviceSynchronize());
-    return PUP_OK;
+    // ordered behind the pile-up kernels on the context's stream; ONE synchronisation makes the copies visible to
+    // whatever stream the caller's collective runs on
+    HIPCHK(c, hipMemcpyAsync(dev_f64, c->acc_f64.p, (size_t)nf * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dev_i64, c->acc_i64.p, (size_t)ni * 8, hipMemcpyDeviceToDevice, c->stream));
+    return pup_sync(c);
 }
 
 int pup_import(pup_ctx* c, const void* dev_f64, const void* dev_i64) {
     if (!c) return PUP_EINVAL;
     if (c->T <= 0) return fail(c, PUP_ESTATE, "pup_import: call pup_reset first");
     if (!dev_f64 || !dev_i64) return fail(c, PUP_EINVAL, "pup_import: NULL source");
-    int rc = pup_sync(c); if (rc) return rc;
+    int rc = bind(c); if (rc) return rc;
     int64_t nf, ni; pup_packed_sizes(c, &nf, &ni);
-    HIPCHK(c, hipMemcpy(c->acc_f64.p, dev_f64, (size_t)nf * 8, hipMemcpyDeviceToDevice));
-    HIPCHK(c, hipMemcpy(c->acc_i64.p, dev_i64, (size_t)ni * 8, hipMemcpyDeviceToDevice));
-    HIPCHK(c, hipDeviceSynchronize());
+    // the caller has synchronised its collective; the sources may be released as soon as this returns
+    HIPCHK(c, hipMemcpyAsync(c->acc_f64.p, dev_f64, (size_t)nf * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->acc_i64.p, dev_i64, (size_t)ni * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return PUP_OK;
 }
 
