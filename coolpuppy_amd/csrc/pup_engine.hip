@@ -684,13 +684,14 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
                                    (const unsigned long long*)c->d_keys.p, (long long)n, sh_seg, (int)nseg, c->d_kcount.p + 1);
                 HIPCHK(c, hipStreamSynchronize(c->stream));      // also fences seg_end's host buffer
                 HIPCHK(c, hipMemcpy(cnt.data(), c->d_kcount.p, ncnt * 8, hipMemcpyDeviceToHost));
-                // a segment is worth staging when a staged region serves >= 6 windows on average (measured: one staging costs
-                // about as much as 5 windows of the plain kernel)
+                // a segment is worth staging when a staged region serves >= 3 windows on average.  Measured on the
+                // bench table: threshold 2 / 3 / 4 / 6 -> 2 tiles 3.02 / 2.66 / 2.66 / 2.64 ms, 42 tiles 5.96 / 5.25 /
+                // 5.6 / 9.3 ms (sparse tiles are where the plain kernel is at its slowest, ~1 ns per window)
                 auto decide = [&](const unsigned long long* changes) {
                     unsigned long long total = 0; bool any = false;
                     for (size_t sg = 0; sg < nseg; ++sg) {
                         const long long len = seg_end[sg] - (sg ? seg_end[sg - 1] : 0);
-                        seg_tiled[sg] = len > 0 && (force || (len >= 20000 && changes[sg] * 6 <= (unsigned long long)len));
+                        seg_tiled[sg] = len > 0 && (force || (len >= 20000 && changes[sg] * 3 <= (unsigned long long)len));
                         if (seg_tiled[sg]) { any = true; total += changes[sg]; }
                     }
                     c->last_stagings = total;

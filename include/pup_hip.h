@@ -243,7 +243,7 @@ int pup_event_elapsed_ms(pup_ctx* ctx, int slot_begin, int slot_end, float* ms);
  * eligible (tests), bit 4 = never use it, bit 5 = never use the sparse trans kernel, bits 8..23 = waves per
  * interleaved group.
  * Block-staged kernel: a call of >= 1e6 cis windows (W <= 31, every window inside one chromosome, index built) is
- * examined on the device; tile segments whose windows overlap enough (>= 6 windows per 16 x 16 block of top-left
+ * examined on the device; tile segments whose windows overlap enough (>= 3 windows per 16 x 16 block of top-left
  * corners) are radix-sorted by block into a scratch copy — unless the caller already passes them in that order:
  * (tile, flip, chromosome, (r0 - chrom_start) / 16, (c0 - chrom_start) / 16) — and piled up from LDS-staged regions.
  * Results do not depend on which kernel ran (integers exactly, sums up to the order of the f64 additions). */
