@@ -1773,7 +1773,16 @@ def _apply_builtin_modify(tbl, func):
     edges = kw.get("band_edges", "default")
     if isinstance(edges, str) and edges == "default":
         edges = _default_band_edges()
-    tbl["distance_band"] = np.searchsorted(edges, tbl["distance"], side="right")
+    d = np.asarray(tbl["distance"])
+    # control rows repeat the distances of the ROI rows (ROI block followed by whole copies of it, _control_cols): when
+    # the table has that shape the band ids of the first block serve every copy
+    n = len(d)
+    n_roi = int(np.count_nonzero(np.asarray(tbl["kind"]) == KIND_ROI)) if "kind" in tbl else n
+    if 0 < n_roi < n and n % n_roi == 0 and bool(np.all(d.reshape(n // n_roi, n_roi) == d[:n_roi])):
+        ids = np.tile(np.searchsorted(edges, d[:n_roi], side="right"), n // n_roi)     # one comparison pass instead
+    else:
+        ids = np.searchsorted(edges, d, side="right")
+    tbl["distance_band"] = ids
     decoders["distance_band"] = lambda i, e=edges: tuple(e[i - 1:i + 1])
     return tbl, decoders
 
