@@ -68,3 +68,19 @@ def test_score_utilities_match_the_reference():
         got = [pu.get_score({"data": a.copy(), "local": loc, "rescale": rs, "rescale_flank": 1})
                for loc, rs in ((False, False), (True, False), (True, True))]
         np.testing.assert_allclose(got, z[f"score{k}"], rtol=1e-13)
+
+
+def test_block_order_groups_snippets_by_tile_and_block():
+    """PileupEngine.block_order (host helper, no GPU): tile-major, then 16 x 16 blocks anchored at chromosome starts,
+    position inside a block; it is a permutation."""
+    from coolpuppy_amd.engine import PileupEngine
+    rng = np.random.default_rng(4)
+    chrom_offset = np.array([0, 1000, 1700, 2500])
+    r0 = rng.integers(0, 2400, 5000)
+    c0 = r0 + rng.integers(0, 90, 5000)
+    tile = rng.integers(0, 3, 5000)
+    o = PileupEngine.block_order(r0, c0, chrom_offset, tile=tile)
+    assert sorted(o.tolist()) == list(range(5000))
+    start = chrom_offset[np.searchsorted(chrom_offset, r0, side="right") - 1]
+    key = np.stack([tile, start + (r0 - start) // 16, (c0 - start) // 16, r0, c0], axis=1)[o]
+    assert all(tuple(key[i]) <= tuple(key[i + 1]) for i in range(len(key) - 1))
