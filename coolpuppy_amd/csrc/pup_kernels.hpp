@@ -846,7 +846,9 @@ __global__ __launch_bounds__(kWave) void pileup_tiled_kernel(K1Args a) {
     };
     auto same_block = [&](int r0, int c0) -> bool {       // cheap test used to pair two windows
         const int dr = r0 - R, dc = c0 - C;
-        return !OOE && dr >= 0 && dr < BR && dc >= 0 && dc < BC && r0 + W <= ch_end && c0 + W <= ch_end && c0 >= ch_start;
+        if (!(dr >= 0 && dr < BR && dc >= 0 && dc < BC && r0 + W <= ch_end && c0 + W <= ch_end && c0 >= ch_start)) return false;
+        if (OOE && use_exp) return select_expected(a, ecache, r0, c0).base == staged_exp;   // same region's expected
+        return true;
     };
 
     // coordinates are fetched 64 snippets at a time (one per lane, next batch in flight) and handed out by readlane:
