@@ -559,90 +559,25 @@ int pup_reset(pup_ctx* c, int32_t n_tiles, int32_t pad) {
     return PUP_OK;
 }
 
-static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, const int32_t* hgt, const int32_t* wid,
-                           int64_t n, const int64_t* tile_ptr, const int64_t* flip_from, int32_t ignore_diags,
-                           uint32_t mode);
+// ---- block-order prepass of the staged kernel (K1t) ----------------------------------------------------------
+// Decides, per (tile, flip) segment of one pup_accumulate call, whether its windows overlap enough to be piled up
+// from LDS-staged regions, and provides the snippets in block order (the caller's arrays when they already are,
+// else a radix-sorted scratch copy).  Eligible calls: register-tile widths, plain / OOE modes, cis (ignore_diags >= 0),
+// rank-bitmap index present and covering every window.  Everything else leaves `tiled` false at no cost.
+struct BlockOrder {
+    bool tiled = false;                 // any segment goes to K1t
+    std::vector<char> seg_tiled;        // per (tile, flip) run
+    const int* r0 = nullptr;            // snippets in launch order (device)
+    const int* c0 = nullptr;
+};
 
-int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, const int64_t* tile_ptr,
-                   const int64_t* flip_from, int32_t ignore_diags, uint32_t mode) {
-    if (mode & PUP_MODE_LOCAL) return c ? fail(c, PUP_EINVAL, "pup_accumulate: PUP_MODE_LOCAL only applies to rescaled pile-ups") : PUP_EINVAL;
-    return accumulate_impl(c, r0, c0, nullptr, nullptr, n, tile_ptr, flip_from, ignore_diags, mode);
-}
-
-int pup_accumulate_rescaled(pup_ctx* c, const int32_t* r0, const int32_t* c0, const int32_t* height, const int32_t* width,
-                            int64_t n, const int64_t* tile_ptr, const int64_t* flip_from, int32_t ignore_diags,
-                            uint32_t mode) {
-    if (!c) return PUP_EINVAL;
-    if (n > 0 && (!height || !width)) return fail(c, PUP_EINVAL, "pup_accumulate_rescaled: NULL window sizes");
-    if (mode & PUP_MODE_DEVPTR) return fail(c, PUP_EINVAL, "pup_accumulate_rescaled: host arrays only");
-    return accumulate_impl(c, r0, c0, height, width, n, tile_ptr, flip_from, ignore_diags, mode);
-}
-
-static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, const int32_t* hgt, const int32_t* wid,
-                           int64_t n, const int64_t* tile_ptr, const int64_t* flip_from, int32_t ignore_diags,
-                           uint32_t mode) {
-    if (!c) return PUP_EINVAL;
-    const bool rescale = hgt != nullptr;
-    if (!c->have_px) return fail(c, PUP_ESTATE, "pup_accumulate: no pixel table loaded");
-    if (!c->have_bal) return fail(c, PUP_ESTATE, "pup_accumulate: call pup_load_bins first (weights or NULL for raw)");
-    if (c->T <= 0) return fail(c, PUP_ESTATE, "pup_accumulate: call pup_reset first");
-    if (n < 0 || !tile_ptr || (n > 0 && (!r0 || !c0)))
-        return fail(c, PUP_EINVAL, "pup_accumulate: NULL snippet arrays or negative n");
-    if (tile_ptr[0] != 0 || tile_ptr[c->T] != n)
-        return fail(c, PUP_EINVAL, "pup_accumulate: tile_ptr must run from 0 to n=%lld (got %lld..%lld)",
-                    (long long)n, (long long)tile_ptr[0], (long long)tile_ptr[c->T]);
-    for (int t = 0; t < c->T; ++t) {
-        if (tile_ptr[t + 1] < tile_ptr[t])
-            return fail(c, PUP_EINVAL, "pup_accumulate: tile_ptr decreases at tile %d", t);
-        if (flip_from && (flip_from[t] < tile_ptr[t] || flip_from[t] > tile_ptr[t + 1]))
-            return fail(c, PUP_EINVAL, "pup_accumulate: flip_from[%d]=%lld outside its tile [%lld, %lld]", t,
-                        (long long)flip_from[t], (long long)tile_ptr[t], (long long)tile_ptr[t + 1]);
-    }
-    const bool m_ooe = mode & PUP_MODE_OOE, m_exp = mode & PUP_MODE_EXPECTED;
-    if ((m_ooe || m_exp) && c->nexp == 0 && c->n_exp_regions == 0)
-        return fail(c, PUP_ESTATE, "pup_accumulate: OOE/EXPECTED mode without pup_set_expected");
-    if (m_ooe && m_exp) return fail(c, PUP_EINVAL, "pup_accumulate: OOE and EXPECTED are exclusive");
-    if ((mode & PUP_MODE_COV) && !c->have_cov)
-        return fail(c, PUP_ESTATE, "pup_accumulate: COV mode without a coverage vector");
-    if (n == 0) return PUP_OK;
-    int rc = bind(c); if (rc) return rc;
-
+static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const int64_t* tile_ptr, const int64_t* flip_from,
+                     int32_t ignore_diags, uint32_t mode, bool rescale, BlockOrder& out) {
     const int W = c->W;
-    const size_t W2 = (size_t)W * W, Lf = W2 + 2 * (size_t)W;
-    // rescaled windows are heavy (10^5 input cells each) and their S^2 output tile lives in LDS: as many workgroups per CU
-    // as that allows, ~4 rounds of them, 1024 threads each when only one or two fit (latency hiding comes from waves)
-    const size_t rs_tile = (size_t)c->W * c->W * 12 + 16 * (size_t)c->W;
-    const int rs_wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(rs_tile, 1)));
-    const int rs_threads = rs_wg_per_cu <= 2 ? 1024 : 512;
-
-    // ---- snippets to device ----------------------------------------------------------------------
-    const int *dr0, *dc0;
-    if (mode & PUP_MODE_DEVPTR) { dr0 = r0; dc0 = c0; }
-    else {
-        // earlier launches may still read the staging buffers
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        HIPCHK(c, c->d_r0.reserve((size_t)n)); HIPCHK(c, c->d_c0.reserve((size_t)n));
-        HIPCHK(c, hipMemcpy(c->d_r0.p, r0, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(c->d_c0.p, c0, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
-        dr0 = c->d_r0.p; dc0 = c->d_c0.p;
-    }
-    if (rescale) {
-        HIPCHK(c, c->d_h.reserve((size_t)n)); HIPCHK(c, c->d_w.reserve((size_t)n));
-        HIPCHK(c, hipMemcpy(c->d_h.p, hgt, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(c->d_w.p, wid, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
-        const size_t need = (size_t)c->W * c->W * 12 + 16 * (size_t)c->W;
-        if (need > (size_t)c->max_lds)
-            return fail(c, PUP_ENOTSUP, "pup_accumulate_rescaled: a %dx%d output tile needs %zu B of LDS, device offers %d",
-                        c->W, c->W, need, c->max_lds);
-    }
-
-    // ---- many overlapping cis windows: block order + staged kernel (K1t) -----------------------------------
-    // Eligible: register-tile widths, plain / OOE modes, every window covered by the rank-bitmap index.  The
-    // snippets' block keys are computed on the device; if the given order already keeps blocks together the
-    // kernel runs on it, otherwise the snippets are radix-sorted by (segment, block) into a scratch copy.
-    bool tiled = false;                                  // any segment goes to K1t
-    std::vector<char> seg_tiled((size_t)2 * c->T, 0);    // per (tile, flip) run
-    const int *kr0 = dr0, *kc0 = dc0;
+    bool tiled = false;
+    std::vector<char>& seg_tiled = out.seg_tiled;
+    seg_tiled.assign((size_t)2 * c->T, 0);
+    out.r0 = dr0; out.c0 = dc0;
     c->last_stagings = 0;
     {
         const bool force = (c->variant & 8) != 0, forbid = (c->variant & 16) != 0;
@@ -750,7 +685,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
                             HIPCHK(c, c->d_sr0.reserve((size_t)n)); HIPCHK(c, c->d_sc0.reserve((size_t)n));
                             hipLaunchKernelGGL(pup::permute_snippets_kernel, dim3(gk), dim3(256), 0, c->stream, dr0, dc0,
                                                (const unsigned*)c->d_vals2.p, (long long)n, c->d_sr0.p, c->d_sc0.p);
-                            tiled = true; kr0 = c->d_sr0.p; kc0 = c->d_sc0.p;
+                            tiled = true; out.r0 = c->d_sr0.p; out.c0 = c->d_sc0.p;
                         }
                     }
                 }
@@ -764,6 +699,94 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
             }
         }
     }
+
+    out.tiled = tiled;
+    return PUP_OK;
+}
+
+static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, const int32_t* hgt, const int32_t* wid,
+                           int64_t n, const int64_t* tile_ptr, const int64_t* flip_from, int32_t ignore_diags,
+                           uint32_t mode);
+
+int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, const int64_t* tile_ptr,
+                   const int64_t* flip_from, int32_t ignore_diags, uint32_t mode) {
+    if (mode & PUP_MODE_LOCAL) return c ? fail(c, PUP_EINVAL, "pup_accumulate: PUP_MODE_LOCAL only applies to rescaled pile-ups") : PUP_EINVAL;
+    return accumulate_impl(c, r0, c0, nullptr, nullptr, n, tile_ptr, flip_from, ignore_diags, mode);
+}
+
+int pup_accumulate_rescaled(pup_ctx* c, const int32_t* r0, const int32_t* c0, const int32_t* height, const int32_t* width,
+                            int64_t n, const int64_t* tile_ptr, const int64_t* flip_from, int32_t ignore_diags,
+                            uint32_t mode) {
+    if (!c) return PUP_EINVAL;
+    if (n > 0 && (!height || !width)) return fail(c, PUP_EINVAL, "pup_accumulate_rescaled: NULL window sizes");
+    if (mode & PUP_MODE_DEVPTR) return fail(c, PUP_EINVAL, "pup_accumulate_rescaled: host arrays only");
+    return accumulate_impl(c, r0, c0, height, width, n, tile_ptr, flip_from, ignore_diags, mode);
+}
+
+static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, const int32_t* hgt, const int32_t* wid,
+                           int64_t n, const int64_t* tile_ptr, const int64_t* flip_from, int32_t ignore_diags,
+                           uint32_t mode) {
+    if (!c) return PUP_EINVAL;
+    const bool rescale = hgt != nullptr;
+    if (!c->have_px) return fail(c, PUP_ESTATE, "pup_accumulate: no pixel table loaded");
+    if (!c->have_bal) return fail(c, PUP_ESTATE, "pup_accumulate: call pup_load_bins first (weights or NULL for raw)");
+    if (c->T <= 0) return fail(c, PUP_ESTATE, "pup_accumulate: call pup_reset first");
+    if (n < 0 || !tile_ptr || (n > 0 && (!r0 || !c0)))
+        return fail(c, PUP_EINVAL, "pup_accumulate: NULL snippet arrays or negative n");
+    if (tile_ptr[0] != 0 || tile_ptr[c->T] != n)
+        return fail(c, PUP_EINVAL, "pup_accumulate: tile_ptr must run from 0 to n=%lld (got %lld..%lld)",
+                    (long long)n, (long long)tile_ptr[0], (long long)tile_ptr[c->T]);
+    for (int t = 0; t < c->T; ++t) {
+        if (tile_ptr[t + 1] < tile_ptr[t])
+            return fail(c, PUP_EINVAL, "pup_accumulate: tile_ptr decreases at tile %d", t);
+        if (flip_from && (flip_from[t] < tile_ptr[t] || flip_from[t] > tile_ptr[t + 1]))
+            return fail(c, PUP_EINVAL, "pup_accumulate: flip_from[%d]=%lld outside its tile [%lld, %lld]", t,
+                        (long long)flip_from[t], (long long)tile_ptr[t], (long long)tile_ptr[t + 1]);
+    }
+    const bool m_ooe = mode & PUP_MODE_OOE, m_exp = mode & PUP_MODE_EXPECTED;
+    if ((m_ooe || m_exp) && c->nexp == 0 && c->n_exp_regions == 0)
+        return fail(c, PUP_ESTATE, "pup_accumulate: OOE/EXPECTED mode without pup_set_expected");
+    if (m_ooe && m_exp) return fail(c, PUP_EINVAL, "pup_accumulate: OOE and EXPECTED are exclusive");
+    if ((mode & PUP_MODE_COV) && !c->have_cov)
+        return fail(c, PUP_ESTATE, "pup_accumulate: COV mode without a coverage vector");
+    if (n == 0) return PUP_OK;
+    int rc = bind(c); if (rc) return rc;
+
+    const int W = c->W;
+    const size_t W2 = (size_t)W * W, Lf = W2 + 2 * (size_t)W;
+    // rescaled windows are heavy (10^5 input cells each) and their S^2 output tile lives in LDS: as many workgroups per CU
+    // as that allows, ~4 rounds of them, 1024 threads each when only one or two fit (latency hiding comes from waves)
+    const size_t rs_tile = (size_t)c->W * c->W * 12 + 16 * (size_t)c->W;
+    const int rs_wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(rs_tile, 1)));
+    const int rs_threads = rs_wg_per_cu <= 2 ? 1024 : 512;
+
+    // ---- snippets to device ----------------------------------------------------------------------
+    const int *dr0, *dc0;
+    if (mode & PUP_MODE_DEVPTR) { dr0 = r0; dc0 = c0; }
+    else {
+        // earlier launches may still read the staging buffers
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, c->d_r0.reserve((size_t)n)); HIPCHK(c, c->d_c0.reserve((size_t)n));
+        HIPCHK(c, hipMemcpy(c->d_r0.p, r0, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_c0.p, c0, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+        dr0 = c->d_r0.p; dc0 = c->d_c0.p;
+    }
+    if (rescale) {
+        HIPCHK(c, c->d_h.reserve((size_t)n)); HIPCHK(c, c->d_w.reserve((size_t)n));
+        HIPCHK(c, hipMemcpy(c->d_h.p, hgt, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_w.p, wid, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+        const size_t need = (size_t)c->W * c->W * 12 + 16 * (size_t)c->W;
+        if (need > (size_t)c->max_lds)
+            return fail(c, PUP_ENOTSUP, "pup_accumulate_rescaled: a %dx%d output tile needs %zu B of LDS, device offers %d",
+                        c->W, c->W, need, c->max_lds);
+    }
+
+    // ---- many overlapping cis windows: block order + staged kernel (K1t), see plan_block_order ---------------
+    BlockOrder order;
+    { const int prc = plan_block_order(c, dr0, dc0, n, tile_ptr, flip_from, ignore_diags, mode, rescale, order); if (prc) return prc; }
+    const bool tiled = order.tiled;
+    const std::vector<char>& seg_tiled = order.seg_tiled;
+    const int *kr0 = order.r0, *kc0 = order.c0;
 
     // launch geometry (chunk / group / reduction tables) depends only on the snippet COUNTS per tile and on
     // the tuning: when it repeats (steady-state loops, benchmarks) the device tables of the last call are reused
