@@ -28,7 +28,7 @@ def build_hip(force=False, verbose=False):
     """Compile coolpuppy_amd/libpup_hip.so for gfx950. Returns the path."""
     if not force and not is_stale():
         return OUT
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
            "-Wall", "-Wno-unused-result", SRC, "-o", OUT]
     if verbose:
         print(" ".join(cmd))

@@ -231,6 +231,8 @@ bool launch_regtile(int W, const pup::K1Args& a, int nchunks, hipStream_t s) {
 
 }  // namespace
 
+// the library is built with -fvisibility=hidden: only the C ABI of include/pup_hip.h is exported
+#pragma GCC visibility push(default)
 extern "C" {
 
 int pup_version(void) { return 100; }
@@ -1283,7 +1285,7 @@ struct RcclApi {
     bool tried = false;
 };
 RcclApi g_rccl;
-bool load_rccl() {
+static bool load_rccl() {
     if (g_rccl.tried) return g_rccl.AllReduce != nullptr;
     g_rccl.tried = true;
     // the soname first: if the process already holds an RCCL (e.g. the copy bundled with torch) that one is reused
@@ -1369,3 +1371,4 @@ int pup_set_tuning(pup_ctx* c, int32_t chunk_snippets, int32_t variant) {
 }
 
 }  // extern "C"
+#pragma GCC visibility pop
