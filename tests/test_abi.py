@@ -23,6 +23,14 @@ def test_header_symbols_exported_and_bound(hip_lib):
     raw = C.CDLL(_ffi.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), f"{name} is declared in include/pup_hip.h but not exported by libpup_hip.so"
+    # ... and nothing else: the object is built with hidden visibility, its dynamic symbol table holds the C ABI only
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", _ffi.LIB_PATH], capture_output=True, text=True)
+    if out.returncode == 0:
+        exported = sorted(line.split()[-1] for line in out.stdout.splitlines() if " T " in line)
+        assert exported == declared, f"unexpected exports: {sorted(set(exported) - set(declared))}"
 
 
 def test_version_and_null_handling(hip_lib):
