@@ -8,13 +8,20 @@ controls (seed 0) => ~1.1e7 snippets per step.  A "step" = one full pass: zero t
 pile up every snippet (ROI + controls) of this rank's shard from HBM-resident inputs, and (N>1)
 all-reduce the packed sum/num/n/cov accumulators over RCCL.
 
-Scaling (default WEAK, per-GPU work fixed): the pixel table is replicated on every GPU (2.7 GB of 288 GB) and
-every rank piles up its OWN set of 1e6 pairs (pair seed 42+rank, control seed rank); the step ends with the real
-exchange of the path — one all-reduce of the packed tiles — so the job's result is the pile-up over all N sets.
-`--scaling strong` splits ONE 1e6-pair set over the ranks instead (contiguous slices of the sorted snippets).
+Input order: the resident snippets are in the order `pileup()` hands them to the engine — grouped by tile
+(ROI, control), inside a tile the reference's stream order (view regions in order; per region the ROI rows, then one
+block per control shift: coolpuppy/coolpup.py:716-746).  Whatever re-ordering the engine wants (the device-side
+block sort of the staged kernel) is therefore INSIDE the timed step.  The same workload pre-sorted into the engine's
+block order is timed afterwards and reported as a secondary field (`preblocked`), never as `value`.
 
-Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (K1 kernel,
-HIP-event timed inside this process) and `cpu_baseline` (the C oracle on a bounded sample, N=1 only).
+Scaling: N=1 is the whole workload on one GPU.  For N>1 the default is STRONG scaling of the same fixed workload with
+the chromosomes sharded over the ranks (north_star: "chromosomes shard across the GPUs with a final RCCL all-reduce"):
+rank r owns the chromosomes an LPT assignment by snippet count gives it, piles up only the snippets of those
+chromosomes and the step ends with one all-reduce of the packed tiles.  `--scaling weak` gives every rank its own
+full 1e6-pair set instead (per-GPU work fixed).
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (pile-up kernels, HIP-event timed
+inside this process) and `cpu_baseline` (N=1 only).
 """
 import argparse
 import hashlib
@@ -33,27 +40,30 @@ from coolpuppy_amd import synth  # noqa: E402  (numpy only; torch is imported af
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 TB/s achievable)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs", type=int, default=1_000_000)
     ap.add_argument("--nshifts", type=int, default=10)
     ap.add_argument("--pad", type=int, default=10)
     ap.add_argument("--lam", type=float, default=4200.0, help="Poisson contacts drawn per row before de-duplication")
     ap.add_argument("--chroms", type=int, default=23, help="use the first K hg38 chromosomes (23 = all)")
-    ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="snippets timed on the CPU oracle (0 = skip)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all cores, capped at 64)")
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="snippets timed on the C oracle (0 = no CPU baseline)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baselines (0 = all cores, capped at 64)")
+    ap.add_argument("--ref-algo-sample", type=int, default=20_000,
+                    help="snippets timed on the algorithm-faithful scipy restatement, one core (0 = skip)")
     ap.add_argument("--no-cache", action="store_true")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: every rank piles up its own set of --pairs pairs on the shared table; "
-                         "strong: the ranks split ONE set")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
+                    help="auto: strong (chromosomes sharded over the ranks) for N>1; weak: every rank piles up its own "
+                         "set of --pairs pairs on a replicated table")
     ap.add_argument("--no-index", action="store_true", help="binary search only (skip the rank-bitmap index)")
+    ap.add_argument("--variant", type=int, default=0, help="pup_set_tuning variant bits (kernel selection; 0 = default)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo (+ COOLPUPPY_AMD_BENCH_DEVICE=0) lets several ranks share ONE GPU "
                          "to smoke-test the N>1 code path on a single-GPU box")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -64,7 +74,17 @@ def _tmp(name):
 
 
 def workload_key(a):
-    return hashlib.sha1(f"w5|{a.chroms}|{a.lam}|{a.pairs}|{a.nshifts}|{a.pad}".encode()).hexdigest()[:12]
+    return hashlib.sha1(f"w6|{a.chroms}|{a.lam}|{a.pairs}|{a.nshifts}|{a.pad}".encode()).hexdigest()[:12]
+
+
+def source_key():
+    """Hash of the kernel sources: measured HBM traffic (profiles/traffic.json) is only quoted for the kernels it was
+    measured on."""
+    h = hashlib.sha1()
+    for f in ("pup_kernels.hpp", "pup_engine.hip"):
+        with open(os.path.join(ROOT, "coolpuppy_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def cooler_path(a):
@@ -93,9 +113,52 @@ def build_cooler(a):
             "weight": clr.bins()["weight"][:].values, "chrom_offset": clr.chrom_offset}
 
 
+def _lower_bound_rows(indptr, col, target):
+    """Per matrix row r: first pixel of the row with column >= target[r] (vectorised bisection over all rows)."""
+    lo, hi = indptr[:-1].copy(), indptr[1:].copy()
+    while True:
+        act = lo < hi
+        if not act.any():
+            return lo
+        mid = (lo + hi) >> 1
+        less = np.zeros(len(lo), bool)
+        less[act] = col[mid[act]] < target[act]
+        lo = np.where(act & less, mid + 1, lo)
+        hi = np.where(act & ~less, mid, hi)
+
+
+def touched_tables(cool, r0, c0, W):
+    """What the windows necessarily touch of the resident tables (the COMPULSORY traffic of one pass, whatever the
+    kernel): per matrix row the column hull [min c0, max c0 + W) over the windows covering that row; pixels inside the
+    hulls, 64-byte rank-bitmap index lines (320 columns each, anchored at the chromosome start) under the hulls, rows
+    touched."""
+    indptr, col, co = cool["bin1_offset"], cool["bin2_id"], cool["chrom_offset"]
+    nb = len(indptr) - 1
+    BIG = np.int64(1) << 40
+    lo_w = np.full(nb + W, BIG, np.int64)
+    hi_w = np.full(nb + W, -1, np.int64)
+    order = np.argsort(r0, kind="stable")
+    rs, cs = r0[order].astype(np.int64), c0[order].astype(np.int64)
+    first = np.flatnonzero(np.concatenate([[True], rs[1:] != rs[:-1]]))
+    lo_w[rs[first]] = np.minimum.reduceat(cs, first)
+    hi_w[rs[first]] = np.maximum.reduceat(cs, first) + W
+    lo_r, hi_r = np.full(nb, BIG, np.int64), np.full(nb, -1, np.int64)
+    for p in range(W):                      # row r is covered by the windows whose first row is r-p
+        lo_r[p:] = np.minimum(lo_r[p:], lo_w[: nb - p])
+        hi_r[p:] = np.maximum(hi_r[p:], hi_w[: nb - p])
+    rows = hi_r > lo_r
+    lo_c = np.where(rows, lo_r, 0)
+    hi_c = np.where(rows, hi_r, 0)
+    pix = _lower_bound_rows(indptr, col, hi_c) - _lower_bound_rows(indptr, col, lo_c)
+    start = co[np.clip(np.searchsorted(co, np.arange(nb), side="right") - 1, 0, len(co) - 2)]
+    lines = np.where(rows, (hi_c - 1 - start) // 320 - (lo_c - start) // 320 + 1, 0)
+    return {"pixels": int(pix[rows].sum()), "index_lines": int(lines.sum()), "rows": int(rows.sum())}
+
+
 def build_snippets(a, cool, k):
     """Snippet set k: a.pairs random cis BEDPE pairs (pair seed 42+k) through the host-side coordinate layer
-    (CoordCreator semantics, control-shift RNG seed k) -> block-ordered (r0, c0) with ROI first."""
+    (CoordCreator semantics, control-shift RNG seed k) -> (r0, c0) grouped by tile (ROI, control) in the reference's
+    stream order, exactly what pileup() passes to pup_accumulate."""
     from coolpuppy_amd.cooler_lite import ArrayCooler
     from coolpuppy_amd.coolpup import CoordCreator, snippet_batches
     clr = ArrayCooler(_chromsizes(a), 10_000, cool["bin1_offset"], cool["bin2_id"], cool["count"],
@@ -105,11 +168,11 @@ def build_snippets(a, cool, k):
     cc = CoordCreator(pairs, clr.binsize, features_format="bedpe", flank=a.pad * clr.binsize,
                       nshifts=a.nshifts, mindist="auto")
     r0, c0, kind = snippet_batches(cc, clr, control=a.nshifts > 0)
-    # resident order = the engine's preferred input layout: ROI tile first, then inside each tile by 16 x 16 block of
-    # top-left corners (block row, block column), then position — see pup_set_tuning in include/pup_hip.h
-    from coolpuppy_amd.engine import PileupEngine
-    order = PileupEngine.block_order(r0, c0, clr.chrom_offset, tile=kind)
-    return {"r0": r0[order].astype(np.int32), "c0": c0[order].astype(np.int32), "n_roi": np.int64((kind == 0).sum())}
+    order = np.argsort(kind, kind="stable")           # tile-grouped; stream order inside a tile
+    r0, c0 = r0[order].astype(np.int32), c0[order].astype(np.int32)
+    t = touched_tables(cool, r0, c0, 2 * a.pad + 1)
+    return {"r0_stream": r0, "c0_stream": c0, "n_roi": np.int64((kind == 0).sum()),
+            "touched": np.array([t["pixels"], t["index_lines"], t["rows"]], np.int64)}
 
 
 def _wait_for(path):
@@ -141,6 +204,73 @@ def load_workload(a, rank, world):
 
 
 # ----------------------------------------------------------------------------------------------------
+# CPU baselines that fork (before any GPU runtime exists in this process)
+# ----------------------------------------------------------------------------------------------------
+_REF = {}
+
+
+def _ref_algo_worker(bounds):
+    lo, hi = bounds
+    from oracle import pileup_oracle as po
+    g = _REF
+    t = time.perf_counter()
+    acc = po.pileup_scipy(g["big"], g["lo"], g["lo"], g["w"], None, None, g["r0"][lo:hi], g["c0"][lo:hi], None,
+                          g["tile"][lo:hi], 2, g["pad"], 2, 0)
+    return time.perf_counter() - t, acc
+
+
+def ref_algo_baseline(a, wl):
+    """The reference's ALGORITHM on the host cores, timed the way the reference runs it: per region one symmetric
+    scipy CSR (get_data), then per snippet CSR slice -> dense -> NaN rows/cols -> diagonal mask -> nansum / isfinite
+    (oracle.pileup_scipy; the reference's quadratic list rebuild is not reproduced).  One region (the chromosome with
+    the most snippets), a bounded snippet sample; 1 core, then the same sample split over C forked workers."""
+    from oracle import pileup_oracle as po
+    import multiprocessing as mp
+    co = wl["chrom_offset"]
+    r0, c0, n_roi = wl["r0_stream"], wl["c0_stream"], int(wl["n_roi"])
+    chrom = np.searchsorted(co, r0, side="right") - 1
+    k = int(np.bincount(chrom).argmax())
+    lo, hi = int(co[k]), int(co[k + 1])
+    sel = np.flatnonzero(chrom == k)
+    m = min(a.ref_algo_sample, len(sel))
+    sel = sel[np.linspace(0, len(sel) - 1, m).astype(np.int64)]
+    t = time.perf_counter()
+    big = po.symmetric_csr(wl["bin1_offset"], wl["bin2_id"], wl["count"], wl["weight"], lo, hi, lo, hi)
+    t_csr = time.perf_counter() - t
+    _REF.update(big=big, lo=lo, w=wl["weight"], r0=r0[sel], c0=c0[sel], tile=(sel >= n_roi).astype(np.int32), pad=a.pad)
+    m1 = max(1, m // 8)
+    t1, _ = _ref_algo_worker((0, m1))
+    C_thr = max(1, min(a.cpu_threads if a.cpu_threads > 0 else (os.cpu_count() or 1), 64))
+    cuts = np.linspace(0, m, C_thr + 1).astype(np.int64)
+    ctx = mp.get_context("fork")
+    t = time.perf_counter()
+    with ctx.Pool(C_thr) as pool:
+        parts = pool.map(_ref_algo_worker, [(int(cuts[i]), int(cuts[i + 1])) for i in range(C_thr)])
+    t_all = time.perf_counter() - t
+    acc = {kk: sum(p[1][kk] for p in parts) for kk in ("sum", "num", "n")}
+    out = {"one_core_snippets_per_s": round(m1 / t1, 1), "all_cores_snippets_per_s": round(m / t_all, 1), "cores": C_thr,
+           "sample": f"{m} snippets of the busiest chromosome (global bins {lo}..{hi}); 1 core on {m1} of them "
+                     f"({t1:.1f}s), {C_thr} forked workers on all of them ({t_all:.1f}s incl. pool start); "
+                     f"symmetric region CSR built once in {t_csr:.1f}s (not counted)",
+           "what": "oracle.pileup_scipy: the reference's per-snippet operation sequence on a scipy CSR "
+                   "(coolpuppy/coolpup.py:1104-1157 + lib/puputils.py:12-41)"}
+    keep = {"sel": sel, "acc": acc}
+    _REF.clear()
+    return out, keep
+
+
+def lpt_assign(costs, world):
+    """Longest-processing-time assignment of items to ranks (deterministic)."""
+    load = np.zeros(world)
+    owner = np.zeros(len(costs), np.int64)
+    for i in np.argsort(-np.asarray(costs), kind="stable"):
+        r = int(np.argmin(load))
+        owner[i] = r
+        load[r] += costs[i]
+    return owner
+
+
+# ----------------------------------------------------------------------------------------------------
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -150,8 +280,13 @@ def main():
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         a.gpus = world
+    if a.scaling == "auto":
+        a.scaling = "strong"                  # N=1: the whole workload either way
 
     wl = load_workload(a, rank, world)
+    ref_algo = ref_keep = None
+    if rank == 0 and a.gpus == 1 and a.cpu_sample > 0 and a.ref_algo_sample > 0:
+        ref_algo, ref_keep = ref_algo_baseline(a, wl)
 
     import torch
     import torch.distributed as dist
@@ -188,22 +323,23 @@ def main():
         torch.cuda.synchronize()
 
     W = 2 * a.pad + 1
-    n_set = int(wl["r0"].shape[0])
+    r0_all, c0_all = wl["r0_stream"], wl["c0_stream"]
+    n_set = int(r0_all.shape[0])
     n_roi = int(wl["n_roi"])
-    if a.scaling == "weak":
-        # every rank owns a full workload (its own pairs / control shifts) on the replicated table
-        r0, c0 = wl["r0"], wl["c0"]
+    co = wl["chrom_offset"]
+    if a.scaling == "weak" or world == 1:
+        r0, c0 = r0_all, c0_all
         tile_ptr = np.array([0, n_roi, n_set], np.int64)
+        sharding = "table replicated; every rank piles up its own pair set" if world > 1 else "single GPU"
     else:
-        # strong: contiguous slice of each tile's (sorted) snippet range of the one shared set
-        def part(lo, hi):
-            m = hi - lo
-            return lo + (m * rank) // world, lo + (m * (rank + 1)) // world
-        a0, a1 = part(0, n_roi)
-        b0, b1 = part(n_roi, n_set)
-        r0 = np.concatenate([wl["r0"][a0:a1], wl["r0"][b0:b1]])
-        c0 = np.concatenate([wl["c0"][a0:a1], wl["c0"][b0:b1]])
-        tile_ptr = np.array([0, a1 - a0, (a1 - a0) + (b1 - b0)], np.int64)
+        # strong: chromosomes -> ranks by LPT on their snippet counts; a rank piles up only its chromosomes' snippets
+        chrom = np.searchsorted(co, r0_all, side="right") - 1
+        owner = lpt_assign(np.bincount(chrom, minlength=len(co) - 1), world)
+        mine = owner[chrom] == rank
+        kind = np.arange(n_set) >= n_roi
+        r0, c0 = r0_all[mine], c0_all[mine]
+        tile_ptr = np.array([0, int((~kind[mine]).sum()), int(mine.sum())], np.int64)
+        sharding = "chromosomes sharded over the ranks (LPT on snippet counts), pixel table resident on every rank"
     n_local = int(tile_ptr[-1])
 
     eng = PileupEngine(local_rank)
@@ -213,31 +349,42 @@ def main():
     eng.sync()
     t_h2d = time.time() - t_h2d
     t_idx = time.time()
-    have_index = eng.build_index(wl["chrom_offset"]) if not a.no_index else False
+    have_index = eng.build_index(co) if not a.no_index else False
     t_idx = time.time() - t_idx
+    eng.set_tuning(0, a.variant)
     eng.reset(2, a.pad)
-    d_r0 = torch.from_numpy(r0).cuda()
-    d_c0 = torch.from_numpy(c0).cuda()
+    d_r0 = torch.from_numpy(np.ascontiguousarray(r0)).cuda()
+    d_c0 = torch.from_numpy(np.ascontiguousarray(c0)).cuda()
     nf, ni = eng.packed_sizes()
     buf_f = torch.zeros(nf, dtype=torch.float64, device="cuda")
     buf_i = torch.zeros(ni, dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
 
-    def step():
-        eng.reset(2, a.pad)
-        eng.accumulate_device(d_r0.data_ptr(), d_c0.data_ptr(), n_local, tile_ptr, ignore_diags=2, mode=0)
-        if world > 1:
-            eng.export_to(buf_f.data_ptr(), buf_i.data_ptr())
-            allreduce(buf_f)
-            allreduce(buf_i)
-            torch.cuda.synchronize()
-            eng.import_from(buf_f.data_ptr(), buf_i.data_ptr())
-        else:
-            eng.sync()
+    def make_step(p_r0, p_c0, n, tptr):
+        def step():
+            eng.reset(2, a.pad)
+            eng.accumulate_device(p_r0, p_c0, n, tptr, ignore_diags=2, mode=0)
+            if world > 1:
+                eng.export_to(buf_f.data_ptr(), buf_i.data_ptr())
+                allreduce(buf_f)
+                allreduce(buf_i)
+                torch.cuda.synchronize()
+                eng.import_from(buf_f.data_ptr(), buf_i.data_ptr())
+            else:
+                eng.sync()
+        return step
 
+    step = make_step(d_r0.data_ptr(), d_c0.data_ptr(), n_local, tile_ptr)
+    # pixel statistics (nnz per window, for the algorithmic byte count) are gathered once, outside the timed region
+    eng.set_profiling(1)
+    eng.clear_stats()
+    step()
+    st0 = eng.stats()
+    pix_per_step_local, staged_regions = float(st0["pixels_in_windows"]), int(st0.get("staged_regions", 0))
+    eng.set_profiling(0)
     for _ in range(a.warmup):
         step()
-    eng.set_profiling(True)
+    eng.set_profiling(3)          # HIP events around the kernels, no pixel counting inside the timed kernels
     eng.clear_stats()
     barrier()
     t0 = time.perf_counter()
@@ -246,132 +393,172 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     st = eng.stats()
-    eng.set_profiling(False)
+    eng.set_profiling(0)
 
     n_all = n_local
     if world > 1:
-        nn = torch.tensor([float(n_local)], dtype=torch.float64, device="cuda")
+        nn = torch.tensor([float(n_local), pix_per_step_local], dtype=torch.float64, device="cuda")
         allreduce(nn)
-        n_all = int(nn.item())
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        n_all, pix_per_step = int(nn[0].item()), float(nn[1].item())
+        tt = torch.tensor([dt, st["k1_ms"]], dtype=torch.float64, device="cuda")
         allreduce(tt, dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        agg = torch.tensor([st["k1_ms"], float(st["pixels_in_windows"]), float(st["snippets"])],
-                           dtype=torch.float64, device="cuda")
-        mx = agg.clone()
-        allreduce(agg)                            # sums over ranks
-        allreduce(mx, dist.ReduceOp.MAX)
-        k1_ms_max = float(mx[0].item())
-        pix_total, snip_total = float(agg[1].item()), float(agg[2].item())
+        dt, k1_ms_max = float(tt[0].item()), float(tt[1].item())
     else:
-        k1_ms_max = st["k1_ms"]
-        pix_total, snip_total = float(st["pixels_in_windows"]), float(st["snippets"])
+        k1_ms_max, pix_per_step = st["k1_ms"], pix_per_step_local
 
     out = eng.fetch()
+
+    # ---- secondary: the same snippets pre-sorted into the engine's block order (no device sort in the step) -------
+    preblocked = None
+    if world == 1:
+        order = PileupEngine.block_order(r0, c0, co, tile=(np.arange(n_local) >= n_roi), pad=a.pad)
+        p_r0 = torch.from_numpy(np.ascontiguousarray(r0[order])).cuda()
+        p_c0 = torch.from_numpy(np.ascontiguousarray(c0[order])).cuda()
+        pstep = make_step(p_r0.data_ptr(), p_c0.data_ptr(), n_local, tile_ptr)
+        for _ in range(3):
+            pstep()
+        torch.cuda.synchronize()
+        psteps = max(10, min(a.steps, 50))
+        t1 = time.perf_counter()
+        for _ in range(psteps):
+            pstep()
+        torch.cuda.synchronize()
+        pdt = time.perf_counter() - t1
+        preblocked = {"ms_per_step": round(pdt / psteps * 1e3, 4), "snippets_per_s": round(n_local * psteps / pdt, 1),
+                      "note": "resident set already in the staged kernel's block order: the step skips the device sort"}
+        del p_r0, p_c0
 
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         value = n_all * a.steps / dt
-        # ---- roofline of the dominant kernel (K1), per launch -----------------------------------------
-        # algorithmic bytes per snippet: 8(W+1) indptr + 8*nnz_win pixels + 16W weights + 12
+        # ---- roofline of the pile-up kernels, per launch ------------------------------------------------
         launches = max(int(st["k1_launches"]), 1)
-        alg_bytes_total = snip_total * (8 * (W + 1) + 16 * W + 12) + 8.0 * pix_total     # all ranks, all steps
-        k1_ms_per_launch = k1_ms_max / launches                                           # slowest rank
-        achieved = alg_bytes_total / a.steps / (k1_ms_per_launch * 1e-3) / 1e9             # GB/s, whole job
-        traffic = None
+        k1_ms = k1_ms_max / launches                                            # slowest rank
+        # (1) SURVEY 8(d) algorithmic bytes: every window charged its own bytes
+        alg_bytes = n_all * (8 * (W + 1) + 16 * W + 12) + 8.0 * pix_per_step
+        achieved = alg_bytes / (k1_ms * 1e-3) / 1e9
+        # (2) compulsory bytes: what one pass must read whatever the kernel — the pixels' values (8 B, `bal`) and the
+        #     rank-bitmap index lines (64 B) under the windows' row hulls, the snippet coordinates (8 B each)
+        tp = wl["touched"]
+        compulsory = float(tp[0]) * 8 + float(tp[1]) * 64 + 8.0 * n_set
+        # (3) measured HBM bytes (rocprofv3 PMC passes over this command; quoted only for these kernel sources)
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and a.gpus == 1 and a.variant == 0:
             try:
                 tj = json.load(open(tpath))
-                if tj.get("workload_key") == workload_key(a) and a.gpus == 1:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                if tj.get("workload_key") == workload_key(a) and tj.get("source_key") == source_key():
+                    traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
             except Exception:
                 traffic = None
+        peak = HBM_PEAK_GBPS * a.gpus
+        frac_comp = compulsory / (k1_ms * 1e-3) / 1e9 / peak if a.scaling != "weak" or a.gpus == 1 else None
+        frac_traffic = None if traffic is None else traffic / (k1_ms * 1e-3) / 1e9 / peak
         peak_measured = None
         try:
             peak_measured = json.load(open(os.path.join(ROOT, "profiles", "hbm_peak.json")))
         except Exception:
             pass
+        staged = staged_regions > 0
+        wgk = not (a.variant & 64)
         roofline = {
             "bound": "hbm",
-            "kernel": ((f"pup::pileup_tiled_kernel<{W}, false, 16, 16> (dense tile) + pup::pileup_regtile_kernel<{W}, false> "
-                        "(sparse tile), side by side on two streams, one launch each per step" if st.get("staged_regions", 0) > 0
-                        else f"pup::pileup_regtile_kernel<{W}, false>") if W <= 31 else f"pup::pileup_band_kernel"),
-            "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBPS * a.gpus, "unit": "GB/s", "frac": round(achieved / (HBM_PEAK_GBPS * a.gpus), 4),
-            "traffic": traffic, "kernel_ms_per_launch": round(k1_ms_per_launch, 4),
-            "algorithmic_bytes_per_launch": round(alg_bytes_total / a.steps / a.gpus),
-            "nnz_win_mean": round(pix_total / max(snip_total, 1), 1),
-            "note": ("frac > 1 is possible by construction: 'achieved' charges every window its own algorithmic bytes "
-                     "(SURVEY 8d), while the block-staged kernel serves all windows of a 16x16 block from one region "
-                     "staged in LDS; 'traffic' is the real HBM byte count per launch (rocprofv3 PMC)"
-                     if st.get("staged_regions", 0) > 0 else "achieved = algorithmic bytes per launch / kernel time"),
+            "kernel": ((f"pup::pileup_wgtile_kernel<{W}, false, {4 if a.variant & 128 else 8}>" if wgk else
+                        f"pup::pileup_tiled_kernel<{W}, false, 16, 16>") + " (block-staged; + pup::pileup_regtile_kernel "
+                       "beside it for segments too sparse to stage)" if staged else f"pup::pileup_regtile_kernel<{W}, false>"),
+            "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
+            # the physically bounded fraction: measured HBM bytes when known for this build, else the compulsory bytes
+            "frac": round(frac_traffic if frac_traffic is not None else frac_comp, 4) if (frac_traffic or frac_comp) else None,
+            "frac_is": "frac_traffic" if frac_traffic is not None else "frac_compulsory",
+            "frac_compulsory": None if frac_comp is None else round(frac_comp, 4),
+            "frac_traffic": None if frac_traffic is None else round(frac_traffic, 4),
+            "algorithmic_over_peak": round(achieved / peak, 4),
+            "traffic": traffic, "traffic_source": traffic_src,
+            "kernel_ms_per_launch": round(k1_ms, 4),
+            "algorithmic_bytes_per_launch": round(alg_bytes / a.gpus),
+            "compulsory_bytes_per_launch": round(compulsory),
+            "compulsory": {"pixels_under_row_hulls": int(tp[0]), "index_lines": int(tp[1]), "rows": int(tp[2]),
+                           "coordinate_bytes": 8 * n_set},
+            "nnz_win_mean": round(pix_per_step / max(n_all, 1), 1),
+            "note": ("achieved = SURVEY 8(d) algorithmic bytes / kernel time: every window is charged its own bytes, so a "
+                     "kernel that serves many windows from one LDS-staged region can exceed the HBM peak on it "
+                     "(algorithmic_over_peak is NOT a roofline fraction).  frac = measured HBM bytes (rocprofv3 PMC, "
+                     "profiles/) / kernel time / peak when a measurement of these kernel sources is on file, else "
+                     "compulsory bytes / kernel time / peak"),
             "peak_measured_GBps": (None if peak_measured is None else
                                    {k: peak_measured[k] for k in ("read_GBps", "copy_GBps", "triad_GBps")}),
-            "staged_regions_per_launch": int(st.get("staged_regions", 0)),
+            "staged_regions_per_launch": staged_regions,
             "prepass_ms_per_launch": round(st.get("prepare_ms", 0.0) / launches, 4),
         }
-        # ---- CPU baseline + same-run parity on a bounded sample (N=1 only) ------------------------------
+        # ---- CPU baselines + same-run parity on bounded samples (N=1 only) ------------------------------
         cpu = None
         if a.gpus == 1 and a.cpu_sample > 0:
             from oracle import pileup_oracle as po
             po.build()
             m = min(a.cpu_sample, n_set)
             idx = np.linspace(0, n_set - 1, m).astype(np.int64)
-            sr0, sc0 = wl["r0"][idx], wl["c0"][idx]
+            sr0, sc0 = r0_all[idx], c0_all[idx]
             stile = (idx >= n_roi).astype(np.int32)
-            # (1) one core: the scalar port as is, on a quarter of the sample
-            m1 = max(1, m // 4)
-            t = time.perf_counter()
-            po.pileup_c(wl["bin1_offset"], wl["bin2_id"], wl["count"], wl["weight"], None, None,
-                        sr0[:m1], sc0[:m1], None, stile[:m1], 2, a.pad, 2, 0)
-            one_core = m1 / (time.perf_counter() - t)
-            # (2) all host cores (capped): the same C function on C threads (ctypes releases the GIL), each with its
-            #     own accumulators, summed afterwards — the reference's own grain is one region per process
-            from concurrent.futures import ThreadPoolExecutor
-            C_thr = max(1, min(a.cpu_threads if a.cpu_threads > 0 else (os.cpu_count() or 1), 64))
-            cuts = np.linspace(0, m, C_thr + 1).astype(np.int64)
             arrs = [np.ascontiguousarray(x) for x in (wl["bin1_offset"], wl["bin2_id"], wl["count"], wl["weight"])]
-
-            def work(k):
-                lo_, hi_ = int(cuts[k]), int(cuts[k + 1])
-                return po.pileup_c(arrs[0], arrs[1], arrs[2], arrs[3], None, None, sr0[lo_:hi_], sc0[lo_:hi_], None,
-                                   stile[lo_:hi_], 2, a.pad, 2, 0)
-            po._load()
+            C_thr = max(1, min(a.cpu_threads if a.cpu_threads > 0 else (os.cpu_count() or 1), 64))
+            # (1) the scalar per-cell port (the test oracle as is), one core, on 1/16 of the sample
+            m1 = max(1, m // 16)
             t = time.perf_counter()
-            with ThreadPoolExecutor(C_thr) as ex:
-                parts = list(ex.map(work, range(C_thr)))
+            po.pileup_c(arrs[0], arrs[1], arrs[2], arrs[3], None, None, sr0[:m1], sc0[:m1], None, stile[:m1], 2, a.pad, 2, 0)
+            percell_one = m1 / (time.perf_counter() - t)
+            # (2) "best CPU": row-sliced windows, one core and C OpenMP threads
+            m2 = max(1, m // 8)
+            t = time.perf_counter()
+            po.pileup_c_mt(arrs[0], arrs[1], arrs[2], arrs[3], None, None, sr0[:m2], sc0[:m2], None, stile[:m2], 2,
+                           a.pad, 2, 0, 1)
+            rows_one = m2 / (time.perf_counter() - t)
+            t = time.perf_counter()
+            want = po.pileup_c_mt(arrs[0], arrs[1], arrs[2], arrs[3], None, None, sr0, sc0, None, stile, 2, a.pad, 2, 0,
+                                  C_thr)
             cpu_s = time.perf_counter() - t
-            want = {k: sum(p[k] for p in parts) for k in ("sum", "num", "n")}
             sptr = np.array([0, int((stile == 0).sum()), m], np.int64)
             eng.reset(2, a.pad)
             eng.accumulate(sr0, sc0, sptr, ignore_diags=2, mode=0)
             got = eng.fetch()
             ok = (np.array_equal(got["n"], want["n"]) and np.array_equal(got["num"], want["num"])
                   and np.allclose(got["sum"], want["sum"], rtol=1e-6, atol=0, equal_nan=True))
+            ok_ref = None
+            if ref_keep is not None:
+                sel = ref_keep["sel"]
+                rt = (sel >= n_roi).astype(np.int64)
+                o2 = np.argsort(rt, kind="stable")
+                eng.reset(2, a.pad)
+                eng.accumulate(r0_all[sel][o2], c0_all[sel][o2], np.array([0, int((rt == 0).sum()), len(sel)], np.int64),
+                               ignore_diags=2, mode=0)
+                g2, w2 = eng.fetch(), ref_keep["acc"]
+                ok_ref = bool(np.array_equal(g2["n"], w2["n"]) and np.array_equal(g2["num"], w2["num"])
+                              and np.allclose(g2["sum"], w2["sum"], rtol=1e-6, atol=0, equal_nan=True))
             cpu = {"value": round(m / cpu_s, 1), "unit": "snippets/s", "cores": C_thr, "kind": "port",
-                   "sample": f"{m} snippets strided over the {n_set} of this workload, C oracle (oracle/pileup_oracle.c) "
-                             f"on {C_thr} threads, {cpu_s:.1f}s; one thread: {one_core:.0f} snippets/s",
-                   "single_core_value": round(one_core, 1), "host_cpu_count": os.cpu_count(),
-                   "gpu_matches_oracle_on_sample": bool(ok)}
-            if not ok:
+                   "sample": f"{m} snippets strided over the {n_set} of this workload; best-CPU form of the C oracle "
+                             f"(oracle/pileup_oracle.c: row-sliced windows, {C_thr} OpenMP threads, private accumulators), "
+                             f"{cpu_s:.1f}s; one thread: {rows_one:.0f} snippets/s; per-cell-bisection form (the test "
+                             f"checker), one thread: {percell_one:.0f} snippets/s",
+                   "single_core_value": round(rows_one, 1), "percell_single_core_value": round(percell_one, 1),
+                   "host_cpu_count": os.cpu_count(),
+                   "cpu_ref_algo": ref_algo,
+                   "gpu_matches_oracle_on_sample": bool(ok), "gpu_matches_ref_algo_on_sample": ok_ref}
+            if not ok or ok_ref is False:
                 print("[bench] PARITY FAILURE against the oracle on the sample", file=sys.stderr)
         line = {
             "metric": f"snippets/sec ({W}x{W} windows @10kb, ROI + control snippets accumulated)",
             "value": round(value, 1), "unit": "snippets/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": a.scaling,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": a.scaling if a.gpus > 1 else "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": "BASELINE configs[2]: synthetic hg38 10kb CSR + 1e6 random cis BEDPE pairs, pad=10, "
                             "nshifts=10, balanced, ignore_diags=2",
+                "order": "reference stream",
                 "nnz": int(wl["bin2_id"].shape[0]), "nbins": int(wl["bin1_offset"].shape[0] - 1),
                 "pairs": a.pairs, "nshifts": a.nshifts, "pad": a.pad, "snippets_per_step": n_all,
-                "parallelism": (f"{a.gpus} rank(s), pixel table replicated; " +
-                                ("each rank piles up its own 1e6-pair set" if a.scaling == "weak"
-                                 else "one snippet set split evenly over the ranks") +
-                                "; RCCL all-reduce of the packed tiles every step"),
+                "parallelism": f"{a.gpus} rank(s); {sharding}; RCCL all-reduce of the packed tiles every step (N>1)",
+                "variant": a.variant,
             },
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "preblocked": preblocked,
             "h2d_pixel_table_s": round(t_h2d, 3), "rank_bitmap_index": bool(have_index),
             "index_build_s": round(t_idx, 3),
             "check": {"n": [int(x) for x in out["n"]],

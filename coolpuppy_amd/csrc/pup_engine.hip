@@ -94,7 +94,8 @@ struct pup_ctx {
     DevBuf<unsigned long long> counters;   // [2]
     DevBuf<int> d_err;
     // stats / timing
-    bool profiling = false;
+    bool profiling = false;      // HIP events around the kernels
+    bool count_pixels = false;   // kernels also count the pixels inside the windows (statistics; costs a little)
     pup_stats stats{};
     struct EvTriple { hipEvent_t a, b, c; };   // K1 = a..b, reduction = b..c
     std::vector<EvTriple> pending;             // awaiting a stream sync
@@ -174,6 +175,41 @@ void launch_k1t(const pup::K1Args& a, int nchunks, hipStream_t s) {
 }
 
 bool tiled_supported(int W) { return W >= 3 && W <= 31 && (W & 1); }
+
+// workgroup-staged kernel (K1q): a workgroup of NW waves shares one 64 x 64 region = a (65-W)^2 block of corners
+constexpr int kWgRegion = 64;
+template <int W>
+void launch_k1q(const pup::K1Args& a, int nchunks, int nw, hipStream_t s) {
+    const bool ooe = a.mode & PUP_MODE_OOE;
+    if (nw == 4) {
+        if (ooe) hipLaunchKernelGGL((pup::pileup_wgtile_kernel<W, true, 4>), dim3(nchunks), dim3(pup::kWave * 4), 0, s, a);
+        else     hipLaunchKernelGGL((pup::pileup_wgtile_kernel<W, false, 4>), dim3(nchunks), dim3(pup::kWave * 4), 0, s, a);
+    } else {
+        if (ooe) hipLaunchKernelGGL((pup::pileup_wgtile_kernel<W, true, 8>), dim3(nchunks), dim3(pup::kWave * 8), 0, s, a);
+        else     hipLaunchKernelGGL((pup::pileup_wgtile_kernel<W, false, 8>), dim3(nchunks), dim3(pup::kWave * 8), 0, s, a);
+    }
+}
+
+bool launch_wgtiled(int W, const pup::K1Args& a, int nchunks, int nw, hipStream_t s) {
+    switch (W) {
+        case 3:  launch_k1q<3>(a, nchunks, nw, s);  return true;
+        case 5:  launch_k1q<5>(a, nchunks, nw, s);  return true;
+        case 7:  launch_k1q<7>(a, nchunks, nw, s);  return true;
+        case 9:  launch_k1q<9>(a, nchunks, nw, s);  return true;
+        case 11: launch_k1q<11>(a, nchunks, nw, s); return true;
+        case 13: launch_k1q<13>(a, nchunks, nw, s); return true;
+        case 15: launch_k1q<15>(a, nchunks, nw, s); return true;
+        case 17: launch_k1q<17>(a, nchunks, nw, s); return true;
+        case 19: launch_k1q<19>(a, nchunks, nw, s); return true;
+        case 21: launch_k1q<21>(a, nchunks, nw, s); return true;
+        case 23: launch_k1q<23>(a, nchunks, nw, s); return true;
+        case 25: launch_k1q<25>(a, nchunks, nw, s); return true;
+        case 27: launch_k1q<27>(a, nchunks, nw, s); return true;
+        case 29: launch_k1q<29>(a, nchunks, nw, s); return true;
+        case 31: launch_k1q<31>(a, nchunks, nw, s); return true;
+        default: return false;
+    }
+}
 
 bool launch_tiled(int W, const pup::K1Args& a, int nchunks, hipStream_t s) {
     switch (W) {
@@ -587,7 +623,10 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
         if (!forbid && !rescale && !(mode & (PUP_MODE_EXPECTED | PUP_MODE_TRANSPOSE)) && !(c->variant & 2) && use_idx_t &&
             ignore_diags >= 0 && tiled_supported(W) && n < 0xffffffffLL && (force || n >= c->tiled_min) &&
             2 * c->T <= pup::kMaxSegCount) {
-            const int BR = kTileBR, BC = kTileBC;
+            // blocks of top-left corners: K1q stages a 64 x 64 region per workgroup, K1t (variant bit 6) 36 x 36 per wave
+            const bool wg = !(c->variant & 64);
+            const int BR = wg ? kWgRegion - W + 1 : kTileBR, BC = wg ? kWgRegion - W + 1 : kTileBC;
+            const unsigned long long min_per_block = wg ? 8 : 3;    // windows per staged region that pay for the staging
             const size_t nseg = (size_t)2 * c->T;
             std::vector<long long> seg_end;
             for (int t = 0; t < c->T; ++t) { seg_end.push_back(flip_from ? flip_from[t] : tile_ptr[t + 1]); seg_end.push_back(tile_ptr[t + 1]); }
@@ -628,7 +667,7 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
                     unsigned long long total = 0; bool any = false;
                     for (size_t sg = 0; sg < nseg; ++sg) {
                         const long long len = seg_end[sg] - (sg ? seg_end[sg - 1] : 0);
-                        seg_tiled[sg] = len > 0 && (force || (len >= 20000 && changes[sg] * 3 <= (unsigned long long)len));
+                        seg_tiled[sg] = len > 0 && (force || (len >= 20000 && changes[sg] * min_per_block <= (unsigned long long)len));
                         if (seg_tiled[sg]) { any = true; total += changes[sg]; }
                     }
                     c->last_stagings = total;
@@ -795,7 +834,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     std::vector<long long> gkey;
     gkey.reserve(8 + 2 * (size_t)c->T);
     gkey.push_back(n); gkey.push_back(c->T); gkey.push_back(c->W); gkey.push_back(c->chunk_snippets);
-    gkey.push_back(c->group_waves); gkey.push_back(c->variant & 2); gkey.push_back((mode & PUP_MODE_EXPECTED) ? 1 : 0);
+    gkey.push_back(c->group_waves); gkey.push_back(c->variant & (2 | 64)); gkey.push_back((mode & PUP_MODE_EXPECTED) ? 1 : 0);
     gkey.push_back(flip_from ? 1 : 0); gkey.push_back(rescale ? 1 : 0); gkey.push_back((ignore_diags < 0 ? 1 : 0) | (c->variant & 32) | ((c->nexp == 1 || c->have_exp_pair) ? 2 : 0) | ((mode & PUP_MODE_OOE) ? 4 : 0));
     for (char f : seg_tiled) gkey.push_back(f);
     for (int t = 0; t <= c->T; ++t) gkey.push_back(tile_ptr[t]);
@@ -824,6 +863,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         C = std::max<long long>(64, (n + 2 * slots - 1) / (2 * slots));
     }
     const int S_plain = c->group_waves > 0 ? c->group_waves : 128;
+    const bool wg_kernel = !(c->variant & 64);
     const int n_xcd = 8;
     // kernel family: register tile (W <= 31), banded register tile (W <= 255), LDS tile (EXPECTED pass, variant&2)
     const bool lds_kernel = (mode & PUP_MODE_EXPECTED) || (c->variant & 2) || rescale;
@@ -842,8 +882,10 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     const bool host_pos = !(mode & PUP_MODE_DEVPTR) && kr0 == dr0;   // host order == launch order
     std::vector<long long> group_start;                             // DEVPTR: first snippet of every group
     auto add_run = [&](long long b, long long e, unsigned char flip, bool staged) {
-        const int S = staged ? 1 : S_plain;                         // K1t: a chunk is a contiguous snippet range
-        const long long Cr = (staged && c->chunk_snippets <= 0) ? (C * 3) / 2 : C;   // every chunk start costs a staging
+        const int S = staged ? 1 : S_plain;                         // K1t / K1q: a chunk is a contiguous snippet range
+        long long Cr = (staged && c->chunk_snippets <= 0) ? (C * 3) / 2 : C;   // every chunk start costs a staging
+        // K1q: a chunk is a WORKGROUP's range (one partial tile, several 64 x 64 regions): ~4 rounds of 4 workgroups per CU
+        if (staged && wg_kernel && c->chunk_snippets <= 0) Cr = std::max<long long>(512, (n + (long long)c->n_cu * 16 - 1) / ((long long)c->n_cu * 16));
         for (long long g0 = b; g0 < e; g0 += (long long)S * Cr) {
             const long long g1 = std::min(e, g0 + (long long)S * Cr);
             const int waves = (int)std::min<long long>(S, std::max<long long>(1, (g1 - g0 + 15) / 16));
@@ -993,7 +1035,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     a.chunk_begin = c->gv.chunk_begin; a.chunk_end = c->gv.chunk_end; a.chunk_flip = c->gv.chunk_flip;
     a.chunk_stride = c->gv.chunk_stride; a.block_chunk = c->gv.block_chunk; a.block_band = c->gv.block_band;
     a.part_f64 = c->part_f64.p; a.part_num = c->part_num.p;
-    a.counters = c->counters.p; a.err = c->d_err.p;
+    a.counters = c->count_pixels ? c->counters.p : nullptr; a.err = c->d_err.p;
     a.W = W; a.ignore_diags = ignore_diags; a.mode = mode;
     const size_t lds = pup::k1_lds_bytes(W);
 
@@ -1025,7 +1067,9 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
             launch_regtile(W, a, (int)nblocks, c->stream2);
             HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
         }
-        if (!launch_tiled(W, at, (int)c->g_nblocks_t, c->stream)) return fail(c, PUP_ENOTSUP, "pup_accumulate: staged kernel not built for W=%d", W);
+        const bool ok_t = (c->variant & 64) ? launch_tiled(W, at, (int)c->g_nblocks_t, c->stream)
+                                            : launch_wgtiled(W, at, (int)c->g_nblocks_t, (c->variant & 128) ? 4 : 8, c->stream);
+        if (!ok_t) return fail(c, PUP_ENOTSUP, "pup_accumulate: staged kernel not built for W=%d", W);
         if (side) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         if (side || nblocks == 0) launched = true;
     }
@@ -1321,7 +1365,8 @@ int pup_allreduce(pup_ctx* c, void* rccl_comm) {
 
 int pup_set_profiling(pup_ctx* c, int enabled) {
     if (!c) return PUP_EINVAL;
-    c->profiling = enabled != 0;
+    c->profiling = (enabled & 1) != 0;
+    c->count_pixels = (enabled & 1) != 0 && (enabled & 2) == 0;
     return PUP_OK;
 }
 

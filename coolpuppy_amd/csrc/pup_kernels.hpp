@@ -898,6 +898,315 @@ __global__ __launch_bounds__(kWave) void pileup_tiled_kernel(K1Args a) {
     if (lane == 0 && stats) atomicAdd(&a.counters[0], npix);
 }
 
+// LDS reads the compiler must not merge: two ds_read_b64 at one base become ds_read2_b64, which the LDS serves at half
+// the bytes per clock (128 vs 256 B/clk/CU on gfx950).  Issued through inline asm (the compiler does not track them):
+// lds_wait_all() + lds_pin() must stand between a read and the first use of its value.
+template <int OFF>
+__device__ __forceinline__ void lds_read_b64(double& dst, unsigned addr) {
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int I, int N, int STRIDE_BYTES>
+struct LdsReadRow {
+    static __device__ __forceinline__ void go(double* v, unsigned addr) {
+        lds_read_b64<I * STRIDE_BYTES>(v[I], addr);
+        LdsReadRow<I + 1, N, STRIDE_BYTES>::go(v, addr);
+    }
+};
+template <int N, int STRIDE_BYTES>
+struct LdsReadRow<N, N, STRIDE_BYTES> { static __device__ __forceinline__ void go(double*, unsigned) {} };
+__device__ __forceinline__ void lds_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+template <int N>
+__device__ __forceinline__ void lds_pin(double (&v)[N]) {     // later uses of v[] are ordered after the preceding asm
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));
+}
+
+// ---- K1q: workgroup-staged register tile ------------------------------------------------------------------------
+// K1t's scheme with the staging SHARED and wave64-shaped: a workgroup of NW waves stages one 64 x 64 region of bins —
+// the windows of a (65-W) x (65-W) block of top-left corners (W = 21: 44 x 44, ~8x the windows of K1t's 16 x 16 block
+// for 3.2x the cells, so every matrix cell is staged 2.1 times instead of 5.1).
+//   * staging: a WAVE per region row, a LANE per region column.  The row's 64 presence bits come from one index line
+//     through scalar loads; the pixels under them are contiguous in `bal`, lane l's being the mbcnt(bits, l)-th of the
+//     run: one coalesced value load per row, masks applied as 64-bit lane predicates (see `stage`);
+//   * the block's windows are dealt out to the waves (window j of the run to wave j % NW), each wave keeping K1r's
+//     register accumulators; the waves' tiles are merged in a fixed order at the end of the chunk (one partial per
+//     workgroup);
+//   * cells of a lane are INTERLEAVED: lane (p, k) owns columns k, k + NCH, k + 2 NCH, ... of window row p, and the
+//     region's row stride is LS = 64 + NCH doubles, so the 8-byte address of lane l in any of its reads is
+//     const + 64 p + l: the 32 lanes of an LDS lane group hit 32 different bank pairs — ds_read_b64 at its
+//     conflict-free rate of 256 B/clk for every window offset and width;
+//   * every wave reads the same 64 coordinates per batch; which windows belong to the staged block is one ballot, so
+//     the waves agree on the control flow without talking to each other; barriers only frame a staging.
+// Eligibility, validity bits, expected handling and results are K1t's (same integers; sums differ by the order of
+// the f64 additions only).
+template <int W, bool OOE, int NW>
+__global__ __launch_bounds__(kWave * NW) void pileup_wgtile_kernel(K1Args a) {
+    static_assert(W >= 3 && W <= 32, "workgroup-staged kernel serves windows of 3..32 bins");
+    static_assert(NW == 4 || NW == 8 || NW == 16, "the region's 64 rows are dealt out evenly to the waves");
+    constexpr int NCH = kWave / W;
+    constexpr int CH  = (W + NCH - 1) / NCH;
+    constexpr int W2  = W * W;
+    constexpr int RS  = 64;                              // staged region: RS x RS bins
+    constexpr int BR  = RS - W + 1, BC = RS - W + 1;     // block of top-left corners it serves
+    constexpr int LS  = RS + ((NCH % 32) ? (NCH % 32) : 32);   // row stride, LS % 32 == NCH % 32 (see above)
+    constexpr int RPW = RS / NW;                         // region rows staged by each wave
+    constexpr int NTHR = kWave * NW;
+    static_assert(RS == kWave, "one lane per region column");
+    static_assert((size_t)W2 * 12 <= (size_t)RS * LS * 8, "merge scratch must fit the region buffer");
+    __shared__ double tile[RS * LS];
+    __shared__ unsigned long long vbits[RS];             // bit c: cell (row, c) counts in num
+    __shared__ unsigned long long pbits[RS];             // bit c: cell holds a pixel (statistics only)
+    __shared__ double cov_lds[NW][2 * W];
+    const int tid  = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p_raw = lane / NCH;
+    const int k  = lane - p_raw * NCH;
+    const bool row_ok = p_raw < W;
+    const int p  = row_ok ? p_raw : W - 1;               // idle lanes shadow the last row, flush nothing
+    unsigned chmask = 0u;                                // bit i: the lane owns window cell (p, k + NCH * i)
+#pragma unroll
+    for (int i = 0; i < CH; ++i) if (row_ok && k + NCH * i < W) chmask |= 1u << i;
+
+    const bool m_cov   = (a.mode & 0x04u) && a.cov != nullptr;
+    const bool use_exp = OOE && ((a.expv != nullptr && a.nexp > 0) || a.n_exp_regions > 0);
+    const int  igd     = a.ignore_diags;
+    const bool stats   = a.counters != nullptr;
+    const double qnan = __builtin_nan("");
+    ExpCache ecache;
+
+    const int ck = a.block_chunk[blockIdx.x];
+    if (ck < 0) return;                                  // padding workgroup (uniform)
+    double   sum[CH];
+    unsigned num[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { sum[i] = 0.0; num[i] = 0u; }
+    if (m_cov) for (int t = lane; t < 2 * W; t += kWave) cov_lds[wave][t] = 0.0;
+
+    const long long cb = a.chunk_begin[ck], ce = a.chunk_end[ck];
+    const int fl = a.chunk_flip[ck];
+    unsigned long long npix = 0;
+    int ch_start = 0, ch_end = -1, ch_nblk = 0; long long ch_base = 0;
+    int R = 0, C = 0; bool staged = false;               // origin of the staged region (block grid)
+    const double* staged_exp = nullptr;
+    int er_start = 0, er_end = 0x7fffffff;               // rows whose expected is the staged one (OOE with a region table)
+
+    // ---- stage the region of block (R, C): a WAVE per region row, a LANE per region column ---------------------------
+    // The 64 columns of a region row are one 64-bit slice of the row's presence bits, and the pixels under it are
+    // contiguous in `bal`: lane l holds column C + l, its pixel is the (number of set bits below l)-th of the run
+    // (v_mbcnt), so a row's value load is ONE coalesced read of <= 512 contiguous bytes, the masks (masked bins,
+    // diagonal, chromosome end) are 64-bit words applied as lane predicates, and the LDS store is conflict-free.
+    // Three phases per wave, each with all of its loads in flight together:
+    //   A  lane i < RPW fetches the index line words of the wave's i-th row and works out bits / position / masks;
+    //   B  per row: broadcast position and bits (readlane), rank = mbcnt, issue the value load;
+    //   C  per row: apply the keep mask, (OOE) divide by expected, store.
+    auto stage = [&](const ExpSel& es) {
+        __syncthreads();                                 // every wave is done with the previous region
+        const int rel = C - ch_start;                    // R, C >= ch_start by construction
+        const int b = rel / kIdxCols, o = rel - b * kIdxCols;
+        const int ws = o >> 6, sh = o & 63;
+        unsigned long long colok;
+        {
+            const unsigned long long* cw = a.badbits + (C >> 6);
+            const int csh = C & 63;
+            unsigned long long colbad = cw[0] >> csh;
+            if (csh) colbad |= cw[1] << (64 - csh);
+            colok = ~colbad;
+            const int over = C + RS - ch_end;            // columns at / past the chromosome's end are in no eligible window
+            if (over > 0) colok &= over >= 64 ? 0ull : (~0ull >> over);
+        }
+        // ---- A: lane i = the wave's i-th row ----
+        unsigned long long l_bits = 0ull, l_keep = 0ull, l_ok = 0ull; long long l_pos = 0;
+        {
+            const int row = R + wave * RPW + (lane < RPW ? lane : 0);
+            if (lane < RPW && row < ch_end) {
+                const char* line = reinterpret_cast<const char*>(a.idx + ch_base + (long long)(row - ch_start) * ch_nblk + b);
+                const U64x2 h = *reinterpret_cast<const U64x2*>(line);                    // {pos, cum[4]}
+                const U64x2 w = *reinterpret_cast<const U64x2*>(line + 16 + 8 * ws);      // {bits[ws], bits[ws+1] | next0}
+                const unsigned long long rw = a.badbits[row >> 6];
+                l_bits = w.a >> sh;
+                if (sh) l_bits |= w.b << (64 - sh);
+                const unsigned cum = ws ? (unsigned)(h.b >> ((ws - 1) * 16)) & 0xffffu : 0u;
+                l_pos = (long long)(h.a + cum + (unsigned long long)__popcll(w.a & ((1ull << sh) - 1ull)));
+                l_ok = ((rw >> (row & 63)) & 1ull) ? 0ull : colok;
+                if (igd >= 0) {
+                    const int t0 = igd - (C - row);     // column C + l is on or above the first kept diagonal iff l >= t0
+                    l_ok &= t0 <= 0 ? ~0ull : (t0 >= 64 ? 0ull : ~((1ull << t0) - 1ull));
+                }
+                l_keep = l_bits & l_ok;
+            }
+        }
+        auto bcast64 = [&](unsigned long long v, int i) -> unsigned long long {
+            const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, i), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), i);
+            return ((unsigned long long)hi << 32) | lo;
+        };
+        // ---- B: value loads of all the wave's rows ----
+        double v[RPW];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const unsigned long long bits = bcast64(l_bits, i);
+            const long long pos = (long long)bcast64((unsigned long long)l_pos, i);
+            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bits >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bits, 0u));
+            v[i] = a.bal[pos + rank];                    // bal is padded: a lane without a pixel reads a neighbour, discarded
+        }
+        // ---- C: masks, expected, store ----
+        unsigned long long l_okn = l_ok;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int rr = wave * RPW + i;
+            const bool keep = __builtin_amdgcn_inverse_ballot_w64(bcast64(l_keep, i));
+            double val = v[i];
+            bool good = keep;
+            if (OOE) {
+                const int row = R + rr;
+                long long ad = (long long)(C + lane) - row; if (ad < 0) ad = -ad;
+                const double e = use_exp ? es.at(ad) : qnan;
+                val = val / e;
+                good = keep && (val == val);            // NaN quotients are skipped, inf is kept
+                // usable expected = neither NaN nor zero.  The predicate goes through a register the compiler cannot see
+                // through: hipcc (ROCm 7.2) folds __ballot(e == e && e != 0.0) — and the equivalent v_cmp_class test —
+                // into v_cmp_neq_f64, the UNORDERED not-equal, which lets NaN pass
+                int e_ok = (e == e && e != 0.0) ? 1 : 0;
+                asm volatile("" : "+v"(e_ok));
+                const unsigned long long eok = __ballot(e_ok);
+                if (lane == i) l_okn &= eok;
+            }
+            tile[rr * LS + lane] = good ? val : 0.0;
+        }
+        if (lane < RPW) { vbits[wave * RPW + lane] = l_okn; if (stats) pbits[wave * RPW + lane] = l_bits; }
+        __syncthreads();
+    };
+
+    // make the block of the (wave-uniform) window (r0, c0) the staged one; false: bad window
+    auto restage = [&](int r0, int c0) -> bool {
+        if (r0 < 0 || c0 < 0 || (long long)r0 + W > a.nbins || (long long)c0 + W > a.nbins) {
+            if (tid == 0) atomicExch(a.err, 1);
+            return false;
+        }
+        ExpSel es; es.base = a.expv; es.len = 0; es.scalar = qnan; es.is_scalar = true;
+        if (use_exp) es = select_expected(a, ecache, r0, c0);
+        if (!(r0 >= ch_start && r0 < ch_end)) {
+            int lo = 0, hi_k = a.n_chrom;
+            while (lo < hi_k) { const int m = (lo + hi_k) >> 1; if (a.idx_chrom[m].end <= r0) lo = m + 1; else hi_k = m; }
+            if (lo >= a.n_chrom) { if (tid == 0) atomicExch(a.err, 1); return false; }
+            const IdxChrom cinfo = a.idx_chrom[lo];
+            ch_start = cinfo.start; ch_end = cinfo.end; ch_nblk = cinfo.nblk; ch_base = cinfo.blk_base;
+        }
+        if (c0 < ch_start || c0 + W > ch_end || r0 + W > ch_end) { if (tid == 0) atomicExch(a.err, 1); return false; }
+        // block grid anchored at the chromosome start (the division runs on the vector unit: tell the compiler the
+        // results are wave-uniform, or every address derived from them becomes per-lane arithmetic)
+        R = __builtin_amdgcn_readfirstlane(ch_start + ((r0 - ch_start) / BR) * BR);
+        C = __builtin_amdgcn_readfirstlane(ch_start + ((c0 - ch_start) / BC) * BC);
+        staged_exp = es.base; staged = true;
+        if (OOE && use_exp && a.n_exp_regions > 0) { er_start = ecache.r_start; er_end = ecache.r_end; }
+        stage(es);
+        return true;
+    };
+
+    // one window out of the staged region
+    const int lane_off = p * LS + k;
+    const unsigned tile_lds = (unsigned)(uintptr_t)tile;       // LDS byte address of the region buffer
+    auto gather = [&](int r0, int c0, double (&v)[CH], unsigned& vw, unsigned& pw) __attribute__((always_inline)) {
+        const int dr = r0 - R, dc = c0 - C;              // wave-uniform
+        // single ds_read_b64 each (see lds_read_b64); cells the lane does not own read padding, never flushed
+        LdsReadRow<0, CH, 8 * NCH>::go(v, tile_lds + 8u * (unsigned)(dr * LS + dc + lane_off));
+        vw = (unsigned)(vbits[dr + p] >> (dc + k));
+        pw = stats ? (unsigned)(pbits[dr + p] >> (dc + k)) : 0u;
+    };
+    auto add = [&](int r0, int c0, const double (&v)[CH], unsigned vw, unsigned pw) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) { sum[i] += v[i]; num[i] += (vw >> (NCH * i)) & 1u; }
+        if (m_cov && row_ok && k == 0) {
+            const double vs = a.cov[r0 + p], ve = a.cov[c0 + p];
+            if (vs == vs) cov_lds[wave][p] += vs;
+            if (ve == ve) cov_lds[wave][W + p] += ve;
+        }
+        if (stats) {
+            unsigned m = 0u;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) if ((chmask >> i) & 1u) m += (pw >> (NCH * i)) & 1u;
+            npix += m;
+        }
+    };
+
+    // coordinates: 64 windows per batch, one per lane (every wave holds the same batch), next batch in flight
+    int r0n = (cb + lane < ce) ? a.r0[cb + lane] : -1, c0n = (cb + lane < ce) ? a.c0[cb + lane] : -1;
+    for (long long s0 = cb; s0 < ce; s0 += kWave) {
+        const int r0v = r0n, c0v = c0n;
+        { const long long sn = s0 + kWave + lane; r0n = sn < ce ? a.r0[sn] : -1; c0n = sn < ce ? a.c0[sn] : -1; }
+        const int nb = (int)((ce - s0) < kWave ? (ce - s0) : kWave);
+        int j = 0;
+        while (j < nb) {
+            // windows j .. j+m-1 of the batch live in the staged block (m >= 1 after a successful restage)
+            auto in_block = [&]() -> unsigned long long {
+                const bool in = staged && lane >= j && lane < nb &&
+                                (unsigned)(r0v - R) < (unsigned)BR && (unsigned)(c0v - C) < (unsigned)BC &&
+                                r0v + W <= ch_end && c0v + W <= ch_end &&
+                                (!(OOE) || (r0v >= er_start && r0v < er_end));
+                return __ballot(in) >> j;
+            };
+            unsigned long long mask = in_block();
+            if (!(mask & 1ull)) {
+                const int ra = __builtin_amdgcn_readlane(r0v, j), ca = __builtin_amdgcn_readlane(c0v, j);
+                if (!restage(ra, ca)) { ++j; continue; }
+                mask = in_block() | 1ull;
+            }
+            const int m = ~mask ? __builtin_ctzll(~mask) : kWave;
+            const int jend = j + m;
+            int jj = j + wave;
+            for (; jj + NW < jend; jj += 2 * NW) {        // two windows in flight: both gathered before either is added
+                const int ra = __builtin_amdgcn_readlane(r0v, jj), ca = __builtin_amdgcn_readlane(c0v, jj);
+                const int rb = __builtin_amdgcn_readlane(r0v, jj + NW), cbx = __builtin_amdgcn_readlane(c0v, jj + NW);
+                double va[CH], vb[CH]; unsigned vwa, pwa, vwb, pwb;
+                gather(ra, ca, va, vwa, pwa);
+                gather(rb, cbx, vb, vwb, pwb);
+                lds_wait_all(); lds_pin(va); lds_pin(vb);
+                add(ra, ca, va, vwa, pwa);
+                add(rb, cbx, vb, vwb, pwb);
+            }
+            if (jj < jend) {
+                const int ra = __builtin_amdgcn_readlane(r0v, jj), ca = __builtin_amdgcn_readlane(c0v, jj);
+                double va[CH]; unsigned vwa, pwa;
+                gather(ra, ca, va, vwa, pwa);
+                lds_wait_all(); lds_pin(va);
+                add(ra, ca, va, vwa, pwa);
+            }
+            j = jend;
+        }
+    }
+
+    // ---- merge the waves' register tiles in wave order (fixed summation order), then one partial per workgroup -----
+    __syncthreads();
+    double*   mf = tile;
+    unsigned* mn = reinterpret_cast<unsigned*>(tile + W2);
+    for (int w = 0; w < NW; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                if ((chmask >> i) & 1u) {
+                    const int cell = map_cell(p, k + NCH * i, W, false, fl);
+                    if (w == 0) { mf[cell] = sum[i]; mn[cell] = num[i]; }
+                    else        { mf[cell] += sum[i]; mn[cell] += num[i]; }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const size_t L = (size_t)W2 + 2 * (size_t)W;
+    double*   of = a.part_f64 + (size_t)ck * L;
+    unsigned* on = a.part_num + (size_t)ck * W2;
+    for (int t = tid; t < W2; t += NTHR) { of[t] = mf[t]; on[t] = mn[t]; }
+    for (int t = tid; t < 2 * W; t += NTHR) {
+        double s = 0.0;
+        if (m_cov) for (int w = 0; w < NW; ++w) s += cov_lds[w][t];
+        of[W2 + t] = s;
+    }
+    if (stats) {
+        for (int off = 32; off > 0; off >>= 1) npix += __shfl_down(npix, off);
+        if (lane == 0) atomicAdd(&a.counters[0], npix);
+    }
+}
+
 // key of a snippet for the block order K1t wants: (segment = tile/flip run, block row, block col), plus a check
 // that the window is one the rank-bitmap index covers (cis, inside one chromosome); counts the ineligible ones
 __global__ __launch_bounds__(256) void block_key_kernel(const int* __restrict__ r0, const int* __restrict__ c0, long long n,

@@ -234,21 +234,23 @@ class PileupEngine:
         self._check(self._lib.pup_allreduce(self._h, C.c_void_p(addr)))
 
     def set_profiling(self, enabled=True):
-        self._check(self._lib.pup_set_profiling(self._h, int(bool(enabled))))
+        """True / 1: HIP-event timing of the kernels + pixel statistics; 3: timing only; False / 0: off."""
+        self._check(self._lib.pup_set_profiling(self._h, int(enabled)))
 
     def set_tuning(self, chunk_snippets=0, variant=0):
         """variant bits: 1 ignore the index, 2 LDS-tile kernel, 8 force / 16 forbid the block-staged kernel, see pup_hip.h."""
         self._check(self._lib.pup_set_tuning(self._h, int(chunk_snippets), int(variant)))
 
-    BLOCK_ROWS, BLOCK_COLS = 16, 16      # kTileBR x kTileBC of pup_engine.hip
+    REGION = 64                          # kWgRegion of pup_engine.hip: the staged kernel's region is 64 x 64 bins
 
     @staticmethod
-    def block_order(r0, c0, chrom_offset, tile=None, block=None):
+    def block_order(r0, c0, chrom_offset, tile=None, block=None, pad=10):
         """Permutation that puts snippets in the order the block-staged kernel wants inside every tile segment:
-        (tile, block row, block column, r0, c0), blocks of BLOCK_ROWS x BLOCK_COLS top-left corners anchored at the
+        (tile, block row, block column, r0, c0), blocks of (65 - W)^2 top-left corners (W = 2*pad+1) anchored at the
         chromosome start.  A resident snippet set kept in this order is piled up without the device-side sort
         (pup_set_tuning in pup_hip.h)."""
-        br_size, bc_size = block or (PileupEngine.BLOCK_ROWS, PileupEngine.BLOCK_COLS)
+        side = PileupEngine.REGION - (2 * int(pad) + 1) + 1
+        br_size, bc_size = block or (side, side)
         r0 = np.asarray(r0, np.int64)
         c0 = np.asarray(c0, np.int64)
         co = np.asarray(chrom_offset, np.int64)

@@ -231,7 +231,9 @@ typedef struct pup_stats {
     int64_t staged_regions; /* last pup_accumulate: regions staged by the block-staged kernel (0: it did not run) */
     double  prepare_ms;     /* total device time of the block-key / sort / permute prepass of that kernel, ms */
 } pup_stats;
-/* profiling on: every kernel launch is bracketed by HIP events on the context's stream */
+/* profiling: bit 0 = every kernel launch is bracketed by HIP events on the context's stream and the pile-up kernels
+ * count the pixels inside the windows (pixels_in_windows, probe_loads); bit 1 (with bit 0) = events only, no counting
+ * inside the kernels (what a timed benchmark loop wants).  0 = off. */
 int pup_set_profiling(pup_ctx* ctx, int enabled);
 int pup_get_stats(pup_ctx* ctx, pup_stats* out);   /* implies pup_sync */
 int pup_clear_stats(pup_ctx* ctx);

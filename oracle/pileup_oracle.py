@@ -32,7 +32,7 @@ _lib = None
 def build(force=False):
     """gcc -O2 the C restatement into oracle/liboracle.so."""
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
-        subprocess.run(["gcc", "-O2", "-Wall", "-shared", "-fPIC", _SRC, "-o", _SO, "-lm"], check=True)
+        subprocess.run(["gcc", "-O2", "-Wall", "-fopenmp", "-shared", "-fPIC", _SRC, "-o", _SO, "-lm"], check=True)
     return _SO
 
 
@@ -44,6 +44,9 @@ def _load():
         _lib.oracle_pileup.restype = C.c_int
         _lib.oracle_pileup.argtypes = [C.c_void_p] * 3 + [C.c_int64] + [C.c_void_p] * 3 + [C.c_int64] + \
             [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_int32, C.c_uint32] + [C.c_void_p] * 5
+        _lib.oracle_pileup_mt.restype = C.c_int
+        _lib.oracle_pileup_mt.argtypes = [C.c_void_p] * 3 + [C.c_int64] + [C.c_void_p] * 3 + [C.c_int64] + \
+            [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_int32] + [C.c_void_p] * 5
     return _lib
 
 
@@ -80,6 +83,32 @@ def pileup_c(indptr, col, cnt, weight, cov, expv, r0, c0, flip, tile, n_tiles, p
                            _p(acc["cov_start"]), _p(acc["cov_end"]))
     if rc != 0:
         raise RuntimeError(f"oracle_pileup failed with {rc}")
+    return acc
+
+
+def pileup_c_mt(indptr, col, cnt, weight, cov, expv, r0, c0, flip, tile, n_tiles, pad, ignore_diags, mode, nthreads,
+                acc=None):
+    """The "best CPU" form of :func:`pileup_c` (row-sliced windows, ``nthreads`` OpenMP threads) — bench.py's
+    cpu_baseline only.  Same integers as pileup_c; sums equal up to the f64 addition order across threads."""
+    lib = _load()
+    indptr = np.ascontiguousarray(indptr, np.int64)
+    col = np.ascontiguousarray(col, np.int32)
+    cnt = np.ascontiguousarray(cnt, np.int32)
+    weight = None if weight is None else np.ascontiguousarray(weight, np.float64)
+    cov = None if cov is None else np.ascontiguousarray(cov, np.float64)
+    expv = None if expv is None else np.atleast_1d(np.ascontiguousarray(expv, np.float64))
+    r0 = np.ascontiguousarray(r0, np.int32)
+    c0 = np.ascontiguousarray(c0, np.int32)
+    flip = None if flip is None else np.ascontiguousarray(flip, np.uint8)
+    tile = np.ascontiguousarray(tile, np.int32)
+    if acc is None:
+        acc = empty_acc(n_tiles, pad)
+    rc = lib.oracle_pileup_mt(_p(indptr), _p(col), _p(cnt), indptr.shape[0] - 1, _p(weight), _p(cov), _p(expv),
+                              0 if expv is None else expv.shape[0], _p(r0), _p(c0), _p(flip), _p(tile), r0.shape[0],
+                              n_tiles, pad, ignore_diags, mode, int(nthreads), _p(acc["sum"]), _p(acc["num"]),
+                              _p(acc["n"]), _p(acc["cov_start"]), _p(acc["cov_end"]))
+    if rc != 0:
+        raise RuntimeError(f"oracle_pileup_mt failed with {rc}")
     return acc
 
 

@@ -71,16 +71,17 @@ def test_score_utilities_match_the_reference():
 
 
 def test_block_order_groups_snippets_by_tile_and_block():
-    """PileupEngine.block_order (host helper, no GPU): tile-major, then 16 x 16 blocks anchored at chromosome starts,
-    position inside a block; it is a permutation."""
+    """PileupEngine.block_order (host helper, no GPU): tile-major, then (65 - W)^2 blocks of corners anchored at
+    chromosome starts, position inside a block; it is a permutation."""
     from coolpuppy_amd.engine import PileupEngine
     rng = np.random.default_rng(4)
     chrom_offset = np.array([0, 1000, 1700, 2500])
     r0 = rng.integers(0, 2400, 5000)
     c0 = r0 + rng.integers(0, 90, 5000)
     tile = rng.integers(0, 3, 5000)
-    o = PileupEngine.block_order(r0, c0, chrom_offset, tile=tile)
-    assert sorted(o.tolist()) == list(range(5000))
-    start = chrom_offset[np.searchsorted(chrom_offset, r0, side="right") - 1]
-    key = np.stack([tile, start + (r0 - start) // 16, (c0 - start) // 16, r0, c0], axis=1)[o]
-    assert all(tuple(key[i]) <= tuple(key[i + 1]) for i in range(len(key) - 1))
+    for pad, side in ((10, 44), (3, 58), (15, 34)):
+        o = PileupEngine.block_order(r0, c0, chrom_offset, tile=tile, pad=pad)
+        assert sorted(o.tolist()) == list(range(5000))
+        start = chrom_offset[np.searchsorted(chrom_offset, r0, side="right") - 1]
+        key = np.stack([tile, start + (r0 - start) // side, (c0 - start) // side, r0, c0], axis=1)[o]
+        assert all(tuple(key[i]) <= tuple(key[i + 1]) for i in range(len(key) - 1))

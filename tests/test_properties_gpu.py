@@ -133,7 +133,7 @@ def test_block_staged_kernel_takes_over_large_overlapping_calls(hip_lib):
     assert res["plain"][1] == 0 and res["auto"][1] > 0
     # pre-blocked input: no sort, same kernel
     tile = np.repeat([0, 1], [n_dense, n_sparse])
-    o = PileupEngine.block_order(r0, c0, clr.chrom_offset, tile=tile)
+    o = PileupEngine.block_order(r0, c0, clr.chrom_offset, tile=tile, pad=pad)
     eng.reset(2, pad)
     eng.accumulate(r0[o], c0[o], tile_ptr, ignore_diags=2, mode=0x04)
     res["blocked"] = (eng.fetch(), eng.stats()["staged_regions"])
@@ -186,14 +186,17 @@ def test_block_staged_kernel_equals_plain_kernel_for_every_width(hip_lib, pad):
         eng.load_bins(weight, covv)
         eng.set_expected(expv if mode & MODE_OOE else None)
         res = {}
-        for name, variant in (("plain", 16), ("staged", 8)):
+        # staged: the workgroup-staged kernel with 8 waves (default) and 4 waves (+128), and the one-wave kernel (+64)
+        for name, variant in (("plain", 16), ("staged", 8), ("staged4", 8 | 128), ("staged1", 8 | 64)):
             eng.set_tuning(0, variant)
             eng.reset(T, pad)
             eng.accumulate(r0, c0, tile_ptr, flip_from=flip_from, ignore_diags=igd, mode=mode)
             res[name] = (eng.fetch(), eng.stats()["staged_regions"])
-        assert res["plain"][1] == 0 and res["staged"][1] > 0
-        for k in ("n", "num"):
-            np.testing.assert_array_equal(res["staged"][0][k], res["plain"][0][k])
-        for k in ("sum", "cov_start", "cov_end"):
-            np.testing.assert_allclose(res["staged"][0][k], res["plain"][0][k], rtol=1e-11, atol=0, equal_nan=True)
+        assert res["plain"][1] == 0
+        for name in ("staged", "staged4", "staged1"):
+            assert res[name][1] > 0
+            for k in ("n", "num"):
+                np.testing.assert_array_equal(res[name][0][k], res["plain"][0][k])
+            for k in ("sum", "cov_start", "cov_end"):
+                np.testing.assert_allclose(res[name][0][k], res["plain"][0][k], rtol=1e-11, atol=0, equal_nan=True)
     eng.close()
