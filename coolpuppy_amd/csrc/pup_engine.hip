@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -74,8 +76,10 @@ struct pup_ctx {
     // workspaces
     DevBuf<int> d_r0, d_c0, d_h, d_w;
     // block-ordered copy of the snippets for the staged kernel (K1t)
-    DevBuf<unsigned long long> d_keys, d_keys2, d_kcount;
-    DevBuf<unsigned> d_vals, d_vals2, d_k32, d_k32b, d_bitmap;
+    DevBuf<unsigned long long> d_keys, d_keys2;
+    DevBuf<unsigned> d_vals, d_vals2, d_k32, d_k32b, d_cnt32, d_starts;
+    DevBuf<unsigned char> d_head;
+    DevBuf<pup::BlockEntry> d_blocks;
     DevBuf<int> d_sr0, d_sc0;
     DevBuf<long long> d_segend;
     DevBuf<unsigned char> d_sorttmp;
@@ -164,70 +168,44 @@ void launch_k1r(const pup::K1Args& a, int nchunks, hipStream_t s) {
         hipLaunchKernelGGL((pup::pileup_regtile_kernel<W, false>), dim3(nchunks), dim3(pup::kWave), 0, s, a);
 }
 
-// block-staged kernel (K1t): blocks of kTileBR x kTileBC top-left corners
-constexpr int kTileBR = 16, kTileBC = 16;   // measured: 32x16 and 8x8 are slower (LDS occupancy / staging count)
-template <int W>
-void launch_k1t(const pup::K1Args& a, int nchunks, hipStream_t s) {
-    if (a.mode & PUP_MODE_OOE)
-        hipLaunchKernelGGL((pup::pileup_tiled_kernel<W, true, kTileBR, kTileBC>), dim3(nchunks), dim3(pup::kWave), 0, s, a);
-    else
-        hipLaunchKernelGGL((pup::pileup_tiled_kernel<W, false, kTileBR, kTileBC>), dim3(nchunks), dim3(pup::kWave), 0, s, a);
-}
-
 bool tiled_supported(int W) { return W >= 3 && W <= 31 && (W & 1); }
 
-// workgroup-staged kernel (K1q): a workgroup of NW waves shares one 64 x 64 region = a (65-W)^2 block of corners
+// workgroup-staged kernel (K1q): a workgroup of NW waves shares one 64 x 64 region = a (65-W)^2 block of corners;
+// ACC = 2 when two tiles share the pass
 constexpr int kWgRegion = 64;
+template <int W, int NW, int ACC>
+void launch_k1q_(const pup::K1Args& a, int nchunks, hipStream_t s) {
+    if (a.mode & PUP_MODE_OOE)
+        hipLaunchKernelGGL((pup::pileup_wgtile_kernel<W, true, NW, ACC>), dim3(nchunks), dim3(pup::kWave * NW), 0, s, a);
+    else
+        hipLaunchKernelGGL((pup::pileup_wgtile_kernel<W, false, NW, ACC>), dim3(nchunks), dim3(pup::kWave * NW), 0, s, a);
+}
 template <int W>
-void launch_k1q(const pup::K1Args& a, int nchunks, int nw, hipStream_t s) {
-    const bool ooe = a.mode & PUP_MODE_OOE;
-    if (nw == 4) {
-        if (ooe) hipLaunchKernelGGL((pup::pileup_wgtile_kernel<W, true, 4>), dim3(nchunks), dim3(pup::kWave * 4), 0, s, a);
-        else     hipLaunchKernelGGL((pup::pileup_wgtile_kernel<W, false, 4>), dim3(nchunks), dim3(pup::kWave * 4), 0, s, a);
-    } else {
-        if (ooe) hipLaunchKernelGGL((pup::pileup_wgtile_kernel<W, true, 8>), dim3(nchunks), dim3(pup::kWave * 8), 0, s, a);
-        else     hipLaunchKernelGGL((pup::pileup_wgtile_kernel<W, false, 8>), dim3(nchunks), dim3(pup::kWave * 8), 0, s, a);
+void launch_k1q(const pup::K1Args& a, int nchunks, int nw, int acc, hipStream_t s) {
+    if (W == 21 && nw == 8) {             // tuning probe (variant bit 7): 8-wave workgroups, built for the headline width only
+        if (acc == 2) launch_k1q_<21, 8, 2>(a, nchunks, s); else launch_k1q_<21, 8, 1>(a, nchunks, s);
+        return;
     }
+    if (acc == 2) launch_k1q_<W, 4, 2>(a, nchunks, s); else launch_k1q_<W, 4, 1>(a, nchunks, s);
 }
 
-bool launch_wgtiled(int W, const pup::K1Args& a, int nchunks, int nw, hipStream_t s) {
+bool launch_wgtiled(int W, const pup::K1Args& a, int nchunks, int nw, int acc, hipStream_t s) {
     switch (W) {
-        case 3:  launch_k1q<3>(a, nchunks, nw, s);  return true;
-        case 5:  launch_k1q<5>(a, nchunks, nw, s);  return true;
-        case 7:  launch_k1q<7>(a, nchunks, nw, s);  return true;
-        case 9:  launch_k1q<9>(a, nchunks, nw, s);  return true;
-        case 11: launch_k1q<11>(a, nchunks, nw, s); return true;
-        case 13: launch_k1q<13>(a, nchunks, nw, s); return true;
-        case 15: launch_k1q<15>(a, nchunks, nw, s); return true;
-        case 17: launch_k1q<17>(a, nchunks, nw, s); return true;
-        case 19: launch_k1q<19>(a, nchunks, nw, s); return true;
-        case 21: launch_k1q<21>(a, nchunks, nw, s); return true;
-        case 23: launch_k1q<23>(a, nchunks, nw, s); return true;
-        case 25: launch_k1q<25>(a, nchunks, nw, s); return true;
-        case 27: launch_k1q<27>(a, nchunks, nw, s); return true;
-        case 29: launch_k1q<29>(a, nchunks, nw, s); return true;
-        case 31: launch_k1q<31>(a, nchunks, nw, s); return true;
-        default: return false;
-    }
-}
-
-bool launch_tiled(int W, const pup::K1Args& a, int nchunks, hipStream_t s) {
-    switch (W) {
-        case 3:  launch_k1t<3>(a, nchunks, s);  return true;
-        case 5:  launch_k1t<5>(a, nchunks, s);  return true;
-        case 7:  launch_k1t<7>(a, nchunks, s);  return true;
-        case 9:  launch_k1t<9>(a, nchunks, s);  return true;
-        case 11: launch_k1t<11>(a, nchunks, s); return true;
-        case 13: launch_k1t<13>(a, nchunks, s); return true;
-        case 15: launch_k1t<15>(a, nchunks, s); return true;
-        case 17: launch_k1t<17>(a, nchunks, s); return true;
-        case 19: launch_k1t<19>(a, nchunks, s); return true;
-        case 21: launch_k1t<21>(a, nchunks, s); return true;
-        case 23: launch_k1t<23>(a, nchunks, s); return true;
-        case 25: launch_k1t<25>(a, nchunks, s); return true;
-        case 27: launch_k1t<27>(a, nchunks, s); return true;
-        case 29: launch_k1t<29>(a, nchunks, s); return true;
-        case 31: launch_k1t<31>(a, nchunks, s); return true;
+        case 3:  launch_k1q<3>(a, nchunks, nw, acc, s);  return true;
+        case 5:  launch_k1q<5>(a, nchunks, nw, acc, s);  return true;
+        case 7:  launch_k1q<7>(a, nchunks, nw, acc, s);  return true;
+        case 9:  launch_k1q<9>(a, nchunks, nw, acc, s);  return true;
+        case 11: launch_k1q<11>(a, nchunks, nw, acc, s); return true;
+        case 13: launch_k1q<13>(a, nchunks, nw, acc, s); return true;
+        case 15: launch_k1q<15>(a, nchunks, nw, acc, s); return true;
+        case 17: launch_k1q<17>(a, nchunks, nw, acc, s); return true;
+        case 19: launch_k1q<19>(a, nchunks, nw, acc, s); return true;
+        case 21: launch_k1q<21>(a, nchunks, nw, acc, s); return true;
+        case 23: launch_k1q<23>(a, nchunks, nw, acc, s); return true;
+        case 25: launch_k1q<25>(a, nchunks, nw, acc, s); return true;
+        case 27: launch_k1q<27>(a, nchunks, nw, acc, s); return true;
+        case 29: launch_k1q<29>(a, nchunks, nw, acc, s); return true;
+        case 31: launch_k1q<31>(a, nchunks, nw, acc, s); return true;
         default: return false;
     }
 }
@@ -328,9 +306,10 @@ void pup_destroy(pup_ctx* c) {
     c->indptr.release(); c->px.release(); c->cnt32.release(); c->bal.release(); c->badbits.release(); c->idx.release(); c->idx_chrom.release(); c->weight.release(); c->cov.release(); c->expv.release(); c->exp_pair.release(); c->exp_regions.release();
     c->acc_f64.release(); c->acc_i64.release();
     c->d_r0.release(); c->d_c0.release(); c->d_h.release(); c->d_w.release(); c->d_geom.release();
-    c->d_keys.release(); c->d_keys2.release(); c->d_kcount.release(); c->d_vals.release(); c->d_vals2.release();
+    c->d_keys.release(); c->d_keys2.release(); c->d_cnt32.release(); c->d_vals.release(); c->d_vals2.release();
+    c->d_starts.release(); c->d_head.release(); c->d_blocks.release();
     c->d_sr0.release(); c->d_sc0.release(); c->d_segend.release(); c->d_sorttmp.release();
-    c->d_k32.release(); c->d_k32b.release(); c->d_bitmap.release();
+    c->d_k32.release(); c->d_k32b.release();
     c->part_f64.release(); c->slice_f64.release(); c->part_num.release(); c->slice_num.release();
     c->counters.release(); c->d_err.release();
     for (auto& s : c->slots) if (s) (void)hipEventDestroy(s);
@@ -597,151 +576,183 @@ int pup_reset(pup_ctx* c, int32_t n_tiles, int32_t pad) {
     return PUP_OK;
 }
 
-// ---- block-order prepass of the staged kernel (K1t) ----------------------------------------------------------
-// Decides, per (tile, flip) segment of one pup_accumulate call, whether its windows overlap enough to be piled up
-// from LDS-staged regions, and provides the snippets in block order (the caller's arrays when they already are,
-// else a radix-sorted scratch copy).  Eligible calls: register-tile widths, plain / OOE modes, cis (ignore_diags >= 0),
-// rank-bitmap index present and covering every window.  Everything else leaves `tiled` false at no cost.
+// ---- block-order prepass of the workgroup-staged kernel (K1q) ---------------------------------------------------
+// Decides, per segment of one pup_accumulate call, whether its windows overlap enough to be piled up from LDS-staged
+// regions, and provides the snippets in block order plus the block table the kernel walks.  Eligible calls:
+// register-tile widths, plain / OOE modes, cis (ignore_diags >= 0), rank-bitmap index present and covering every
+// window.  Everything else leaves `tiled` false at no cost.
+//   segment = the snippets that share a pass: (tile, flip) — or, when tiles are PAIRED (T even: tile t with tile
+//   t + T/2, the ROI and the control tile of one group in the host layer's numbering), (pair, flip) with the tile's
+//   half as a per-window slot bit, so that a sparse tile rides on the regions its dense partner stages anyway.
+// Device pipeline, one host synchronisation: keys (segment | expected region | block row | block col) -> radix sort
+// (rocPRIM) -> permuted copy + block-start flags -> compaction of the block starts (rocPRIM select) -> first block of
+// every segment -> [sync: ineligible windows, blocks, blocks per segment] -> block table.
 struct BlockOrder {
-    bool tiled = false;                 // any segment goes to K1t
-    std::vector<char> seg_tiled;        // per (tile, flip) run
+    bool tiled = false;                 // any segment goes to K1q
+    bool paired = false;                // two accumulator sets per chunk
+    int  nseg = 0;
+    std::vector<char> seg_tiled;        // [nseg]
+    std::vector<long long> seg_win0;    // [nseg+1] windows of segment s in launch order: [seg_win0[s], seg_win0[s+1])
+    std::vector<int> seg_blk0;          // [nseg+1] blocks of segment s in the block table
     const int* r0 = nullptr;            // snippets in launch order (device)
     const int* c0 = nullptr;
 };
 
 static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const int64_t* tile_ptr, const int64_t* flip_from,
                      int32_t ignore_diags, uint32_t mode, bool rescale, BlockOrder& out) {
-    const int W = c->W;
-    bool tiled = false;
-    std::vector<char>& seg_tiled = out.seg_tiled;
-    seg_tiled.assign((size_t)2 * c->T, 0);
-    out.r0 = dr0; out.c0 = dc0;
+    const int W = c->W, T = c->T;
+    out.tiled = false; out.paired = false; out.r0 = dr0; out.c0 = dc0;
     c->last_stagings = 0;
+    const bool force = (c->variant & 8) != 0, forbid = (c->variant & 16) != 0;
+    const bool use_idx_t = c->have_idx && !(c->variant & 1);
+    if (forbid || rescale || (mode & (PUP_MODE_EXPECTED | PUP_MODE_TRANSPOSE)) || (c->variant & 2) || !use_idx_t ||
+        ignore_diags < 0 || !tiled_supported(W) || n >= 0x7fffffffLL || !(force || n >= c->tiled_min) ||
+        2 * T > pup::kMaxSegCount || c->nbins >= (1LL << pup::kSlotBit))
+        return PUP_OK;
+    const int BR = kWgRegion - W + 1, BC = kWgRegion - W + 1;
+    const unsigned long long min_per_block = 8;          // windows per staged region that pay for the staging
+    const int n_eregs = ((mode & PUP_MODE_OOE) && c->n_exp_regions > 0 && !c->have_exp_pair) ? c->n_exp_regions : 0;
+    auto nbits = [](unsigned long long v) { int b = 1; while ((v >> b) != 0) ++b; return b; };
+    long long max_len = 1;
     {
-        const bool force = (c->variant & 8) != 0, forbid = (c->variant & 16) != 0;
-        const bool use_idx_t = c->have_idx && !(c->variant & 1);
-        if (!forbid && !rescale && !(mode & (PUP_MODE_EXPECTED | PUP_MODE_TRANSPOSE)) && !(c->variant & 2) && use_idx_t &&
-            ignore_diags >= 0 && tiled_supported(W) && n < 0xffffffffLL && (force || n >= c->tiled_min) &&
-            2 * c->T <= pup::kMaxSegCount) {
-            // blocks of top-left corners: K1q stages a 64 x 64 region per workgroup, K1t (variant bit 6) 36 x 36 per wave
-            const bool wg = !(c->variant & 64);
-            const int BR = wg ? kWgRegion - W + 1 : kTileBR, BC = wg ? kWgRegion - W + 1 : kTileBC;
-            const unsigned long long min_per_block = wg ? 8 : 3;    // windows per staged region that pay for the staging
-            const size_t nseg = (size_t)2 * c->T;
-            std::vector<long long> seg_end;
-            for (int t = 0; t < c->T; ++t) { seg_end.push_back(flip_from ? flip_from[t] : tile_ptr[t + 1]); seg_end.push_back(tile_ptr[t + 1]); }
-            auto nbits = [](unsigned long long v) { int b = 1; while ((v >> b) != 0) ++b; return b; };
-            long long max_len = 1;
-            {
-                std::vector<pup::IdxChrom> tab((size_t)c->n_chrom);
-                HIPCHK(c, hipMemcpy(tab.data(), c->idx_chrom.p, tab.size() * sizeof(pup::IdxChrom), hipMemcpyDeviceToHost));
-                for (auto& ch : tab) max_len = std::max<long long>(max_len, ch.end - ch.start);
-            }
-            const int sh_br = nbits((unsigned long long)(max_len / BC + 1));
-            const int sh_seg = sh_br + nbits((unsigned long long)c->nbins + 1);
-            const int end_bit = sh_seg + nbits((unsigned long long)(nseg > 1 ? nseg - 1 : 1));
-            if (end_bit <= 64) {
-                hipEvent_t ep0 = nullptr, ep1 = nullptr;
-                if (c->profiling) { HIPCHK(c, hipEventCreate(&ep0)); HIPCHK(c, hipEventCreate(&ep1)); HIPCHK(c, hipEventRecord(ep0, c->stream)); }
-                // counters: [0] ineligible windows, [1 .. 1+nseg) changes per segment in the given order,
-                // [1+nseg .. 1+2nseg) changes per segment in block order
-                const size_t ncnt = 1 + 3 * (nseg + 1);           // ... then sampled windows / sampled distinct blocks per segment
-                std::vector<unsigned long long> cnt(ncnt, 0);
-                HIPCHK(c, c->d_keys.reserve((size_t)n)); HIPCHK(c, c->d_vals.reserve((size_t)n));
-                HIPCHK(c, c->d_segend.reserve(seg_end.size())); HIPCHK(c, c->d_kcount.reserve(ncnt));
-                HIPCHK(c, hipMemcpyAsync(c->d_segend.p, seg_end.data(), seg_end.size() * 8, hipMemcpyHostToDevice, c->stream));
-                HIPCHK(c, hipMemsetAsync(c->d_kcount.p, 0, ncnt * sizeof(unsigned long long), c->stream));
-                const unsigned gk = (unsigned)((n + 255) / 256);
-                hipLaunchKernelGGL(pup::block_key_kernel, dim3(gk), dim3(256), 0, c->stream, dr0, dc0, (long long)n,
-                                   (const long long*)c->d_segend.p, (int)seg_end.size(), (const pup::IdxChrom*)c->idx_chrom.p,
-                                   c->n_chrom, W, BR, BC, sh_br, sh_seg, c->d_keys.p, c->d_vals.p, c->d_kcount.p);
-                const unsigned gs = (unsigned)std::min<long long>((n + 255) / 256, (long long)c->n_cu * 8);
-                hipLaunchKernelGGL(pup::count_changes_kernel, dim3(gs), dim3(256), 0, c->stream,
-                                   (const unsigned long long*)c->d_keys.p, (long long)n, sh_seg, (int)nseg, c->d_kcount.p + 1);
-                HIPCHK(c, hipStreamSynchronize(c->stream));      // also fences seg_end's host buffer
-                HIPCHK(c, hipMemcpy(cnt.data(), c->d_kcount.p, ncnt * 8, hipMemcpyDeviceToHost));
-                // a segment is worth staging when a staged region serves >= 3 windows on average.  Measured on the
-                // bench table: threshold 2 / 3 / 4 / 6 -> 2 tiles 3.02 / 2.66 / 2.66 / 2.64 ms, 42 tiles 5.96 / 5.25 /
-                // 5.6 / 9.3 ms (sparse tiles are where the plain kernel is at its slowest, ~1 ns per window)
-                auto decide = [&](const unsigned long long* changes) {
-                    unsigned long long total = 0; bool any = false;
-                    for (size_t sg = 0; sg < nseg; ++sg) {
-                        const long long len = seg_end[sg] - (sg ? seg_end[sg - 1] : 0);
-                        seg_tiled[sg] = len > 0 && (force || (len >= 20000 && changes[sg] * min_per_block <= (unsigned long long)len));
-                        if (seg_tiled[sg]) { any = true; total += changes[sg]; }
-                    }
-                    c->last_stagings = total;
-                    return any;
-                };
-                if (cnt[0] == 0) {
-                    unsigned long long ch_all = 0;
-                    for (size_t sg = 0; sg < nseg; ++sg) ch_all += cnt[1 + sg];
-                    if (ch_all * 4 <= (unsigned long long)n) tiled = decide(cnt.data() + 1);       // given order is block order
-                    else {
-                        // would block order pay?  estimate the distinct blocks per segment before sorting anything
-                        unsigned mbits = 1u << 24;
-                        while ((unsigned long long)mbits < 4ull * (unsigned long long)n && mbits < (1u << 30)) mbits <<= 1;
-                        HIPCHK(c, c->d_bitmap.reserve((size_t)(mbits >> 5)));
-                        HIPCHK(c, hipMemsetAsync(c->d_bitmap.p, 0, (size_t)(mbits >> 5) * 4, c->stream));
-                        hipLaunchKernelGGL(pup::distinct_blocks_kernel, dim3(gs), dim3(256), 0, c->stream,
-                                           (const unsigned long long*)c->d_keys.p, (long long)n, sh_seg, (int)nseg, c->d_bitmap.p,
-                                           mbits - 1u, c->d_kcount.p + 1 + (nseg + 1), c->d_kcount.p + 1 + 2 * (nseg + 1));
-                        HIPCHK(c, hipStreamSynchronize(c->stream));
-                        HIPCHK(c, hipMemcpy(cnt.data(), c->d_kcount.p, ncnt * 8, hipMemcpyDeviceToHost));
-                        // estimated stagings per segment = its windows / (sampled windows per sampled distinct block)
-                        std::vector<unsigned long long> est(nseg, 0);
-                        for (size_t sg = 0; sg < nseg; ++sg) {
-                            const unsigned long long seen = cnt[1 + (nseg + 1) + sg], fresh = cnt[1 + 2 * (nseg + 1) + sg];
-                            const long long len = seg_end[sg] - (sg ? seg_end[sg - 1] : 0);
-                            est[sg] = seen ? (unsigned long long)((double)len * (double)std::max<unsigned long long>(fresh, 1) / (double)seen) : (unsigned long long)len;
-                        }
-                        long long covered = 0;
-                        if (decide(est.data()))
-                            for (size_t sg = 0; sg < nseg; ++sg) if (seg_tiled[sg]) covered += seg_end[sg] - (sg ? seg_end[sg - 1] : 0);
-                        if (force || covered * 2 >= n) {
-                            HIPCHK(c, c->d_vals2.reserve((size_t)n));
-                            hipError_t se = hipSuccess;
-                            size_t tmp_bytes = 0;
-                            if (end_bit <= 32) {
-                                HIPCHK(c, c->d_k32.reserve((size_t)n)); HIPCHK(c, c->d_k32b.reserve((size_t)n));
-                                hipLaunchKernelGGL(pup::narrow_keys_kernel, dim3(gk), dim3(256), 0, c->stream,
-                                                   (const unsigned long long*)c->d_keys.p, (long long)n, c->d_k32.p);
-                                se = rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_vals.p, c->d_vals2.p,
-                                                               (size_t)n, 0, end_bit, c->stream);
-                                if (se == hipSuccess) se = c->d_sorttmp.reserve(tmp_bytes + 16);
-                                if (se == hipSuccess)
-                                    se = rocprim::radix_sort_pairs(c->d_sorttmp.p, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_vals.p,
-                                                                   c->d_vals2.p, (size_t)n, 0, end_bit, c->stream);
-                            } else {
-                                HIPCHK(c, c->d_keys2.reserve((size_t)n));
-                                se = rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_vals.p, c->d_vals2.p,
-                                                               (size_t)n, 0, end_bit, c->stream);
-                                if (se == hipSuccess) se = c->d_sorttmp.reserve(tmp_bytes + 16);
-                                if (se == hipSuccess)
-                                    se = rocprim::radix_sort_pairs(c->d_sorttmp.p, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_vals.p,
-                                                                   c->d_vals2.p, (size_t)n, 0, end_bit, c->stream);
-                            }
-                            if (se != hipSuccess) return fail(c, PUP_EHIP, "pup_accumulate: block sort: %s", hipGetErrorString(se));
-                            // the estimate stands in for the exact staging count (it only feeds the statistics)
-                            HIPCHK(c, c->d_sr0.reserve((size_t)n)); HIPCHK(c, c->d_sc0.reserve((size_t)n));
-                            hipLaunchKernelGGL(pup::permute_snippets_kernel, dim3(gk), dim3(256), 0, c->stream, dr0, dc0,
-                                               (const unsigned*)c->d_vals2.p, (long long)n, c->d_sr0.p, c->d_sc0.p);
-                            tiled = true; out.r0 = c->d_sr0.p; out.c0 = c->d_sc0.p;
-                        }
-                    }
-                }
-                if (!tiled) { std::fill(seg_tiled.begin(), seg_tiled.end(), 0); c->last_stagings = 0; }
-                if (ep0) {
-                    float ms = 0.f;
-                    if (hipEventRecord(ep1, c->stream) == hipSuccess && hipEventSynchronize(ep1) == hipSuccess &&
-                        hipEventElapsedTime(&ms, ep0, ep1) == hipSuccess) c->stats.prepare_ms += ms;
-                    (void)hipEventDestroy(ep0); (void)hipEventDestroy(ep1);
-                }
-            }
-        }
+        std::vector<pup::IdxChrom> tab((size_t)c->n_chrom);
+        HIPCHK(c, hipMemcpy(tab.data(), c->idx_chrom.p, tab.size() * sizeof(pup::IdxChrom), hipMemcpyDeviceToHost));
+        for (auto& ch : tab) max_len = std::max<long long>(max_len, ch.end - ch.start);
     }
+    // (tile, flip) runs of the caller's order
+    std::vector<long long> seg_end2t;
+    for (int t = 0; t < T; ++t) { seg_end2t.push_back(flip_from ? flip_from[t] : tile_ptr[t + 1]); seg_end2t.push_back(tile_ptr[t + 1]); }
+    auto run_len = [&](int t, int f) { const long long b = tile_ptr[t], e = tile_ptr[t + 1], m = flip_from ? flip_from[t] : e; return f ? e - m : m - b; };
 
-    out.tiled = tiled;
+    hipEvent_t ep0 = nullptr, ep1 = nullptr;
+    if (c->profiling) { HIPCHK(c, hipEventCreate(&ep0)); HIPCHK(c, hipEventCreate(&ep1)); HIPCHK(c, hipEventRecord(ep0, c->stream)); }
+    auto stop_timer = [&]() {
+        if (!ep0) return;
+        float ms = 0.f;
+        if (hipEventRecord(ep1, c->stream) == hipSuccess && hipEventSynchronize(ep1) == hipSuccess &&
+            hipEventElapsedTime(&ms, ep0, ep1) == hipSuccess) c->stats.prepare_ms += ms;
+        (void)hipEventDestroy(ep0); (void)hipEventDestroy(ep1); ep0 = ep1 = nullptr;
+    };
+
+    const bool can_pair = T >= 2 && (T % 2) == 0 && !(c->variant & 64);
+    for (int attempt = can_pair ? 0 : 1; attempt < 2; ++attempt) {
+        const bool paired = attempt == 0;
+        const int H = paired ? T / 2 : 0;
+        const int nseg = paired ? 2 * H : 2 * T;
+        std::vector<long long> seg_win0((size_t)nseg + 1, 0);
+        for (int sg = 0; sg < nseg; ++sg) {
+            const int f = sg & 1, u = sg >> 1;
+            seg_win0[(size_t)sg + 1] = seg_win0[(size_t)sg] + (paired ? run_len(u, f) + run_len(u + H, f) : run_len(u, f));
+        }
+        const int bits_bc = nbits((unsigned long long)(max_len / BC + 1)), bits_br = nbits((unsigned long long)c->nbins + 1);
+        const int bits_er = n_eregs > 0 ? nbits((unsigned long long)n_eregs) : 0;
+        const int sh_br = bits_bc, sh_er = sh_br + bits_br, sh_seg = sh_er + bits_er;
+        const int end_bit = sh_seg + nbits((unsigned long long)(nseg > 1 ? nseg - 1 : 1));
+        if (end_bit > 64) { stop_timer(); return PUP_OK; }
+        const size_t ncnt = 2 + (size_t)nseg + 1;         // [0] ineligible windows, [1] blocks, [2 ..] first block of every segment + total
+        HIPCHK(c, c->d_keys.reserve((size_t)n)); HIPCHK(c, c->d_vals.reserve((size_t)n)); HIPCHK(c, c->d_vals2.reserve((size_t)n));
+        HIPCHK(c, c->d_segend.reserve(seg_end2t.size() + (size_t)nseg + 1)); HIPCHK(c, c->d_cnt32.reserve(ncnt));
+        HIPCHK(c, c->d_sr0.reserve((size_t)n)); HIPCHK(c, c->d_sc0.reserve((size_t)n));
+        HIPCHK(c, c->d_head.reserve((size_t)n)); HIPCHK(c, c->d_starts.reserve((size_t)n + 1));
+        // host tables of this attempt: the (tile, flip) boundaries for the key kernel, the segment boundaries in sorted order
+        std::vector<long long> htab(seg_end2t);
+        htab.insert(htab.end(), seg_win0.begin(), seg_win0.end());
+        HIPCHK(c, hipMemcpyAsync(c->d_segend.p, htab.data(), htab.size() * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_cnt32.p, 0, 2 * sizeof(unsigned), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_cnt32.p + 2, 0xff, ((size_t)nseg + 1) * sizeof(unsigned), c->stream));
+        const unsigned gk = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(pup::block_key_kernel, dim3(gk), dim3(256), 0, c->stream, dr0, dc0, (long long)n,
+                           (const long long*)c->d_segend.p, (int)seg_end2t.size(), H, (const pup::IdxChrom*)c->idx_chrom.p,
+                           c->n_chrom, (const pup::ExpRegion*)(n_eregs > 0 ? c->exp_regions.p : nullptr), n_eregs,
+                           W, BR, BC, sh_br, sh_er, sh_seg, c->d_keys.p, c->d_vals.p, c->d_cnt32.p);
+        hipError_t se = hipSuccess;
+        size_t tmp_bytes = 0;
+        const bool k32 = end_bit <= 32;
+        if (k32) {
+            HIPCHK(c, c->d_k32.reserve((size_t)n)); HIPCHK(c, c->d_k32b.reserve((size_t)n));
+            hipLaunchKernelGGL(pup::narrow_keys_kernel, dim3(gk), dim3(256), 0, c->stream,
+                               (const unsigned long long*)c->d_keys.p, (long long)n, c->d_k32.p);
+            se = rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_vals.p, c->d_vals2.p,
+                                           (size_t)n, 0, end_bit, c->stream);
+            if (se == hipSuccess) se = c->d_sorttmp.reserve(tmp_bytes + 16);
+            if (se == hipSuccess)
+                se = rocprim::radix_sort_pairs(c->d_sorttmp.p, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_vals.p,
+                                               c->d_vals2.p, (size_t)n, 0, end_bit, c->stream);
+            if (se == hipSuccess)
+                hipLaunchKernelGGL((pup::permute_snippets_kernel<unsigned>), dim3(gk), dim3(256), 0, c->stream, dr0, dc0,
+                                   (const unsigned*)c->d_vals2.p, (const unsigned*)c->d_k32b.p, (long long)n,
+                                   c->d_sr0.p, c->d_sc0.p, c->d_head.p);
+        } else {
+            HIPCHK(c, c->d_keys2.reserve((size_t)n));
+            se = rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_vals.p, c->d_vals2.p,
+                                           (size_t)n, 0, end_bit, c->stream);
+            if (se == hipSuccess) se = c->d_sorttmp.reserve(tmp_bytes + 16);
+            if (se == hipSuccess)
+                se = rocprim::radix_sort_pairs(c->d_sorttmp.p, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_vals.p,
+                                               c->d_vals2.p, (size_t)n, 0, end_bit, c->stream);
+            if (se == hipSuccess)
+                hipLaunchKernelGGL((pup::permute_snippets_kernel<unsigned long long>), dim3(gk), dim3(256), 0, c->stream, dr0, dc0,
+                                   (const unsigned*)c->d_vals2.p, (const unsigned long long*)c->d_keys2.p, (long long)n,
+                                   c->d_sr0.p, c->d_sc0.p, c->d_head.p);
+        }
+        if (se != hipSuccess) return fail(c, PUP_EHIP, "pup_accumulate: block sort: %s", hipGetErrorString(se));
+        // block starts = positions of the flags, compacted in order
+        {
+            size_t sel_bytes = 0;
+            rocprim::counting_iterator<unsigned> pos0(0u);
+            se = rocprim::select(nullptr, sel_bytes, pos0, (const unsigned char*)c->d_head.p, c->d_starts.p, c->d_cnt32.p + 1,
+                                 (size_t)n, c->stream);
+            if (se == hipSuccess) se = c->d_sorttmp.reserve(sel_bytes + 16);
+            if (se == hipSuccess)
+                se = rocprim::select(c->d_sorttmp.p, sel_bytes, pos0, (const unsigned char*)c->d_head.p, c->d_starts.p,
+                                     c->d_cnt32.p + 1, (size_t)n, c->stream);
+            if (se != hipSuccess) return fail(c, PUP_EHIP, "pup_accumulate: block compaction: %s", hipGetErrorString(se));
+        }
+        hipLaunchKernelGGL(pup::segment_blocks_kernel, dim3(1), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
+                           (const unsigned*)(c->d_cnt32.p + 1), (const long long*)(c->d_segend.p + seg_end2t.size()), nseg,
+                           c->d_cnt32.p + 2);
+        std::vector<unsigned> cnt(ncnt, 0);
+        HIPCHK(c, hipMemcpyAsync(cnt.data(), c->d_cnt32.p, ncnt * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));      // the one synchronisation (also fences htab)
+        if (cnt[0] != 0) { stop_timer(); return PUP_OK; }   // a window the index does not cover: the plain kernels take the call
+        const long long nblk = (long long)cnt[1];
+        std::vector<int> seg_blk0((size_t)nseg + 1);
+        for (int sg = 0; sg <= nseg; ++sg) seg_blk0[(size_t)sg] = (int)cnt[2 + (size_t)sg];
+        // a segment is worth staging when a staged region serves >= min_per_block windows on average
+        std::vector<char> seg_tiled((size_t)nseg, 0);
+        bool any = false, all = true; long long covered = 0; unsigned long long stagings = 0;
+        for (int sg = 0; sg < nseg; ++sg) {
+            const long long len = seg_win0[(size_t)sg + 1] - seg_win0[(size_t)sg];
+            const long long nb = seg_blk0[(size_t)sg + 1] - seg_blk0[(size_t)sg];
+            if (len <= 0) continue;
+            const bool st = force || (len >= 20000 && (unsigned long long)nb * min_per_block <= (unsigned long long)len);
+            seg_tiled[(size_t)sg] = st;
+            if (st) { any = true; covered += len; stagings += (unsigned long long)nb; } else all = false;
+        }
+        if (paired && !all) continue;                     // a pair too sparse to stage: plan again with every tile on its own
+        if (!any || (!force && covered * 2 < n)) { stop_timer(); return PUP_OK; }
+        // block table (device, asynchronous from here on)
+        HIPCHK(c, c->d_blocks.reserve((size_t)std::max<long long>(nblk, 1)));
+        const unsigned gb = (unsigned)((nblk + 255) / 256);
+        if (k32)
+            hipLaunchKernelGGL((pup::block_table_kernel<unsigned>), dim3(gb), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
+                               (const unsigned*)(c->d_cnt32.p + 1), (long long)n, (const unsigned*)c->d_k32b.p,
+                               (const int*)c->d_sr0.p, (const int*)c->d_sc0.p, (const pup::IdxChrom*)c->idx_chrom.p, c->n_chrom,
+                               BR, BC, sh_er, sh_seg, n_eregs, c->d_blocks.p);
+        else
+            hipLaunchKernelGGL((pup::block_table_kernel<unsigned long long>), dim3(gb), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
+                               (const unsigned*)(c->d_cnt32.p + 1), (long long)n, (const unsigned long long*)c->d_keys2.p,
+                               (const int*)c->d_sr0.p, (const int*)c->d_sc0.p, (const pup::IdxChrom*)c->idx_chrom.p, c->n_chrom,
+                               BR, BC, sh_er, sh_seg, n_eregs, c->d_blocks.p);
+        HIPCHK(c, hipGetLastError());
+        out.tiled = true; out.paired = paired; out.nseg = nseg;
+        out.seg_tiled = seg_tiled; out.seg_win0 = seg_win0; out.seg_blk0 = seg_blk0;
+        out.r0 = c->d_sr0.p; out.c0 = c->d_sc0.p;
+        c->last_stagings = stagings;
+        stop_timer();
+        return PUP_OK;
+    }
+    stop_timer();
     return PUP_OK;
 }
 
@@ -822,32 +833,36 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
                         c->W, c->W, need, c->max_lds);
     }
 
-    // ---- many overlapping cis windows: block order + staged kernel (K1t), see plan_block_order ---------------
+    // ---- many overlapping cis windows: block order + workgroup-staged kernel (K1q), see plan_block_order -----------
     BlockOrder order;
     { const int prc = plan_block_order(c, dr0, dc0, n, tile_ptr, flip_from, ignore_diags, mode, rescale, order); if (prc) return prc; }
-    const bool tiled = order.tiled;
-    const std::vector<char>& seg_tiled = order.seg_tiled;
+    const bool tiled = order.tiled, paired = order.tiled && order.paired;
     const int *kr0 = order.r0, *kc0 = order.c0;
+    const int T = c->T, H = paired ? T / 2 : 0;
+    const int nw_q = (c->variant & 128) ? 8 : 4;          // waves per K1q workgroup
 
-    // launch geometry (chunk / group / reduction tables) depends only on the snippet COUNTS per tile and on
-    // the tuning: when it repeats (steady-state loops, benchmarks) the device tables of the last call are reused
+    // launch geometry (chunk / group / reduction tables) depends only on the snippet COUNTS per tile, the blocks per
+    // segment and the tuning: when it repeats (steady-state loops, benchmarks) the device tables of the last call are reused
     std::vector<long long> gkey;
-    gkey.reserve(8 + 2 * (size_t)c->T);
-    gkey.push_back(n); gkey.push_back(c->T); gkey.push_back(c->W); gkey.push_back(c->chunk_snippets);
-    gkey.push_back(c->group_waves); gkey.push_back(c->variant & (2 | 64)); gkey.push_back((mode & PUP_MODE_EXPECTED) ? 1 : 0);
+    gkey.reserve(16 + 4 * (size_t)T);
+    gkey.push_back(n); gkey.push_back(T); gkey.push_back(c->W); gkey.push_back(c->chunk_snippets);
+    gkey.push_back(c->group_waves); gkey.push_back(c->variant & (2 | 64 | 128)); gkey.push_back((mode & PUP_MODE_EXPECTED) ? 1 : 0);
     gkey.push_back(flip_from ? 1 : 0); gkey.push_back(rescale ? 1 : 0); gkey.push_back((ignore_diags < 0 ? 1 : 0) | (c->variant & 32) | ((c->nexp == 1 || c->have_exp_pair) ? 2 : 0) | ((mode & PUP_MODE_OOE) ? 4 : 0));
-    for (char f : seg_tiled) gkey.push_back(f);
-    for (int t = 0; t <= c->T; ++t) gkey.push_back(tile_ptr[t]);
-    if (flip_from) for (int t = 0; t < c->T; ++t) gkey.push_back(flip_from[t]);
+    gkey.push_back(tiled ? (paired ? 2 : 1) : 0);
+    if (tiled) { for (char f : order.seg_tiled) gkey.push_back(f); for (int b : order.seg_blk0) gkey.push_back(b); }
+    for (int t = 0; t <= T; ++t) gkey.push_back(tile_ptr[t]);
+    if (flip_from) for (int t = 0; t < T; ++t) gkey.push_back(flip_from[t]);
     const bool geom_hit = (gkey == c->geom_key);
     if (!geom_hit) {
     c->geom_key.clear();
     // ---- chunk table -------------------------------------------------------------------------------------
-    // A chunk = the snippets one wave accumulates (one tile, one flip state).  Chunks come in GROUPS: a group
-    // owns a contiguous range of the (position-sorted) snippets and its S chunks interleave over it (chunk j
-    // takes range[j], range[j+S], ...), so the waves of a group walk the same few matrix rows together and
-    // the rows stay in the XCD's L2.  Groups are dealt round-robin to the 8 XCDs; workgroup b runs on XCD
-    // b % 8 (observed dispatch rule, used for speed only), so a group's chunks get ids b = xcd + 8*i.
+    // A chunk = what one wave (K1r and friends) or one workgroup (K1q) accumulates: one tile (K1q with paired tiles: one
+    // pair) and one flip state; it writes one partial record per accumulator set.
+    // Plain chunks come in GROUPS: a group owns a contiguous range of the (position-sorted) snippets and its S chunks
+    // interleave over it (chunk j takes range[j], range[j+S], ...), so the waves of a group walk the same few matrix
+    // rows together and the rows stay in the XCD's L2.  Groups are dealt round-robin to the 8 XCDs; workgroup b runs on
+    // XCD b % 8 (observed dispatch rule, used for speed only), so a group's chunks get ids b = xcd + 8*i.
+    // K1q chunks are ranges of BLOCKS of the block table (chunk_begin / chunk_end index it).
     long long C = c->chunk_snippets;
     if (C <= 0) {
         const long long target = (long long)std::max(c->n_cu, 64) * 32 * 4;   // ~4 chunks per wave slot
@@ -863,7 +878,6 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         C = std::max<long long>(64, (n + 2 * slots - 1) / (2 * slots));
     }
     const int S_plain = c->group_waves > 0 ? c->group_waves : 128;
-    const bool wg_kernel = !(c->variant & 64);
     const int n_xcd = 8;
     // kernel family: register tile (W <= 31), banded register tile (W <= 255), LDS tile (EXPECTED pass, variant&2)
     const bool lds_kernel = (mode & PUP_MODE_EXPECTED) || (c->variant & 2) || rescale;
@@ -872,7 +886,17 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     const bool sparse_kernel = sparse_geom;
     const bool band_kernel = !lds_kernel && !sparse_kernel && c->W > 31;
     const int nbands = band_kernel ? (c->W + (pup::kWave / band_nch(c->W)) - 1) / (pup::kWave / band_nch(c->W)) : 1;
-    std::vector<long long> cb, ce, tile_chunk_ptr((size_t)c->T + 1, 0), dn((size_t)c->T);
+    // blocks per K1q chunk: ~4 rounds of 4 workgroups per CU, at least 4 regions per workgroup (the first one is not overlapped)
+    long long BPC = 4;
+    if (tiled) {
+        long long staged_blocks = 0;
+        for (int sg = 0; sg < order.nseg; ++sg)
+            if (order.seg_tiled[(size_t)sg]) staged_blocks += order.seg_blk0[(size_t)sg + 1] - order.seg_blk0[(size_t)sg];
+        BPC = c->chunk_snippets > 0 ? c->chunk_snippets
+                                    : std::max<long long>(4, (staged_blocks + (long long)c->n_cu * 16 - 1) / ((long long)c->n_cu * 16));
+    }
+    const int U = paired ? H : T;                                   // pass units: pairs or tiles
+    std::vector<long long> cb, ce, unit_chunk_ptr((size_t)U + 1, 0), dn((size_t)T);
     std::vector<unsigned char> cf;
     std::vector<int> cs;
     std::vector<std::vector<int>> xcd_list((size_t)n_xcd);       // entries: chunk * nbands + band
@@ -881,34 +905,52 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     std::vector<Group> groups;
     const bool host_pos = !(mode & PUP_MODE_DEVPTR) && kr0 == dr0;   // host order == launch order
     std::vector<long long> group_start;                             // DEVPTR: first snippet of every group
-    auto add_run = [&](long long b, long long e, unsigned char flip, bool staged) {
-        const int S = staged ? 1 : S_plain;                         // K1t / K1q: a chunk is a contiguous snippet range
-        long long Cr = (staged && c->chunk_snippets <= 0) ? (C * 3) / 2 : C;   // every chunk start costs a staging
-        // K1q: a chunk is a WORKGROUP's range (one partial tile, several 64 x 64 regions): ~4 rounds of 4 workgroups per CU
-        if (staged && wg_kernel && c->chunk_snippets <= 0) Cr = std::max<long long>(512, (n + (long long)c->n_cu * 16 - 1) / ((long long)c->n_cu * 16));
-        for (long long g0 = b; g0 < e; g0 += (long long)S * Cr) {
-            const long long g1 = std::min(e, g0 + (long long)S * Cr);
-            const int waves = (int)std::min<long long>(S, std::max<long long>(1, (g1 - g0 + 15) / 16));
+    auto add_run = [&](long long b, long long e, unsigned char flip) {          // plain chunks over snippets [b, e)
+        for (long long g0 = b; g0 < e; g0 += (long long)S_plain * C) {
+            const long long g1 = std::min(e, g0 + (long long)S_plain * C);
+            const int waves = (int)std::min<long long>(S_plain, std::max<long long>(1, (g1 - g0 + 15) / 16));
             if (!host_pos) group_start.push_back(g0);
-            groups.push_back(Group{host_pos ? (long long)r0[g0] : (long long)groups.size(), (int)cb.size(), waves, staged});
+            groups.push_back(Group{host_pos ? (long long)r0[g0] : (long long)groups.size(), (int)cb.size(), waves, false});
             for (int j = 0; j < waves; ++j) {
                 cb.push_back(g0 + j); ce.push_back(g1); cs.push_back(waves); cf.push_back(flip);
             }
         }
     };
-    for (int t = 0; t < c->T; ++t) {
-        const long long b = tile_ptr[t], e = tile_ptr[t + 1];
-        const long long f = flip_from ? flip_from[t] : e;          // [b, f) as is, [f, e) flipped
-        dn[(size_t)t] = e - b;
-        add_run(b, f, 0, seg_tiled[(size_t)2 * t] != 0);
-        add_run(f, e, 1, seg_tiled[(size_t)2 * t + 1] != 0);
-        tile_chunk_ptr[(size_t)t + 1] = (long long)cb.size();
+    auto add_blocks = [&](long long b, long long e, unsigned char flip) {       // K1q chunks over blocks [b, e)
+        for (long long g0 = b; g0 < e; g0 += BPC) {
+            if (!host_pos) group_start.push_back(0);
+            groups.push_back(Group{(long long)groups.size(), (int)cb.size(), 1, true});
+            cb.push_back(g0); ce.push_back(std::min(e, g0 + BPC)); cs.push_back(1); cf.push_back(flip);
+        }
+    };
+    for (int t = 0; t < T; ++t) dn[(size_t)t] = tile_ptr[t + 1] - tile_ptr[t];
+    for (int u = 0; u < U; ++u) {
+        for (int f = 0; f < 2; ++f) {
+            if (tiled) {
+                const int sg = 2 * u + f;                           // segments are (unit, flip) in this order
+                if (order.seg_tiled[(size_t)sg]) add_blocks(order.seg_blk0[(size_t)sg], order.seg_blk0[(size_t)sg + 1], (unsigned char)f);
+                else add_run(order.seg_win0[(size_t)sg], order.seg_win0[(size_t)sg + 1], (unsigned char)f);   // never with pairs
+            } else {
+                const long long b = tile_ptr[u], e = tile_ptr[u + 1], m = flip_from ? flip_from[u] : e;
+                if (f == 0) add_run(b, m, 0); else add_run(m, e, 1);
+            }
+        }
+        unit_chunk_ptr[(size_t)u + 1] = (long long)cb.size();
     }
+    const long long nchunks = (long long)cb.size();
+    // records: chunk ck writes record ck (+ nchunks for the second accumulator set of a pair): tile t's records are contiguous
+    const long long nrec = paired ? 2 * nchunks : nchunks;
+    std::vector<long long> tile_rec_ptr((size_t)T + 1, 0);
+    for (int t = 0; t <= T; ++t)
+        tile_rec_ptr[(size_t)t] = !paired ? unit_chunk_ptr[(size_t)t]
+                                          : (t < H ? unit_chunk_ptr[(size_t)t] : nchunks + unit_chunk_ptr[(size_t)(t - H)]);
     // Launch order = matrix position, across tiles: with many tiles (by-distance x by-strand ...) every tile walks
     // the whole genome, so running the tiles one after the other re-reads every matrix row once per tile from HBM;
     // dealing the groups out by the row of their first snippet lets the groups that are in flight together — of
     // whatever tile — share rows in L2 / MALL.  (Chunk numbering, hence the reduction, stays tile-contiguous.)
-    if (!host_pos && c->T > 1 && !groups.empty()) {
+    bool any_plain = false;
+    for (auto& g : groups) any_plain = any_plain || !g.staged;
+    if (!host_pos && any_plain && T > 1 && !groups.empty()) {
         // snippets are device-resident: fetch just the first row of every group
         const int ng = (int)groups.size();
         DevBuf<long long> d_pos; DevBuf<int> d_key;
@@ -924,16 +966,16 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         if (ge == hipSuccess) ge = hipMemcpy(keys.data(), d_key.p, (size_t)ng * 4, hipMemcpyDeviceToHost);
         d_pos.release(); d_key.release();
         if (ge != hipSuccess) return fail(c, PUP_EHIP, "pup_accumulate: %s", hipGetErrorString(ge));
-        for (int g = 0; g < ng; ++g) groups[(size_t)g].key = keys[(size_t)g];
+        for (int g = 0; g < ng; ++g) if (!groups[(size_t)g].staged) groups[(size_t)g].key = keys[(size_t)g];
     }
-    if (c->T > 1)
-        std::stable_sort(groups.begin(), groups.end(), [](const Group& x, const Group& y) { return x.key < y.key; });
+    if (T > 1 && any_plain)
+        std::stable_sort(groups.begin(), groups.end(), [](const Group& x, const Group& y) { return (x.staged ? 0 : x.key) < (y.staged ? 0 : y.key); });
     {
         size_t gp = 0, gt = 0;
         for (size_t g = 0; g < groups.size(); ++g) {
-            // staged chunks are small (one wave, ~20 blocks): deal them out in runs of 32, so that neighbouring block
-            // rows — whose staged regions overlap in 20 of 36 matrix rows — meet in the same XCD's L2
-            auto& lst = groups[g].staged ? xcd_list_t[(gt++ / 32) % (size_t)n_xcd] : xcd_list[gp++ % (size_t)n_xcd];
+            // K1q chunks are block ranges in genome order: deal them out in runs of 8, so that neighbouring block rows —
+            // whose staged regions overlap in W-1 of 64 matrix rows — meet in the same XCD's L2
+            auto& lst = groups[g].staged ? xcd_list_t[(gt++ / 8) % (size_t)n_xcd] : xcd_list[gp++ % (size_t)n_xcd];
             for (int j = 0; j < groups[g].waves; ++j)
                 for (int b = 0; b < nbands; ++b) lst.push_back((groups[g].first_chunk + j) * nbands + b);
         }
@@ -954,30 +996,29 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     deal(xcd_list_t, block_chunk_t, block_band_t);
     const long long nblocks_t = (long long)block_chunk_t.size();
     const long long nblocks = (long long)block_chunk.size();
-    const long long nchunks = (long long)cb.size();
-    if (nchunks > 0x7fffffffLL || nblocks > 0x7fffffffLL) return fail(c, PUP_ENOTSUP, "pup_accumulate: too many chunks");
+    if (nrec > 0x7fffffffLL || nblocks > 0x7fffffffLL) return fail(c, PUP_ENOTSUP, "pup_accumulate: too many chunks");
     if (C > 0xffffffffLL) return fail(c, PUP_ENOTSUP, "pup_accumulate: chunk too long for 32-bit num partials");
 
-    // two-level reduction plan: chunks -> slices of <= S chunks (within a tile) -> tiles
+    // two-level reduction plan: records -> slices of <= SL records (within a tile) -> tiles
     const long long SL = 256;
     long long max_per_tile = 0;
-    for (int t = 0; t < c->T; ++t)
-        max_per_tile = std::max(max_per_tile, tile_chunk_ptr[(size_t)t + 1] - tile_chunk_ptr[(size_t)t]);
+    for (int t = 0; t < T; ++t)
+        max_per_tile = std::max(max_per_tile, tile_rec_ptr[(size_t)t + 1] - tile_rec_ptr[(size_t)t]);
     const bool two_level = max_per_tile > 2 * SL;
-    std::vector<long long> seg1, seg2;   // seg1: slice -> chunk range; seg2: tile -> slice (or chunk) range
+    std::vector<long long> seg1, seg2;   // seg1: slice -> record range; seg2: tile -> slice (or record) range
     if (two_level) {
-        seg2.assign((size_t)c->T + 1, 0);
+        seg2.assign((size_t)T + 1, 0);
         seg1.push_back(0);
-        for (int t = 0; t < c->T; ++t) {
-            const long long b = tile_chunk_ptr[(size_t)t], e = tile_chunk_ptr[(size_t)t + 1];
+        for (int t = 0; t < T; ++t) {
+            const long long b = tile_rec_ptr[(size_t)t], e = tile_rec_ptr[(size_t)t + 1];
             for (long long k = b; k < e; k += SL) seg1.push_back(std::min(e, k + SL));
             seg2[(size_t)t + 1] = (long long)seg1.size() - 1;
         }
-    } else seg2 = tile_chunk_ptr;
+    } else seg2 = tile_rec_ptr;
     const long long nslices = two_level ? (long long)seg1.size() - 1 : 0;
 
     HIPCHK(c, hipStreamSynchronize(c->stream));   // chunk/segment tables of the previous call are free now
-    HIPCHK(c, c->part_f64.reserve((size_t)nchunks * Lf)); HIPCHK(c, c->part_num.reserve((size_t)nchunks * W2));
+    HIPCHK(c, c->part_f64.reserve((size_t)nrec * Lf)); HIPCHK(c, c->part_num.reserve((size_t)nrec * W2));
     if (two_level) { HIPCHK(c, c->slice_f64.reserve((size_t)nslices * Lf)); HIPCHK(c, c->slice_num.reserve((size_t)nslices * W2)); }
     {
         // pack every table into one host blob (8-byte aligned sections) -> one H2D copy
@@ -989,7 +1030,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
             return off;
         };
         const size_t o_cb = put(cb.data(), (size_t)nchunks * 8), o_ce = put(ce.data(), (size_t)nchunks * 8);
-        const size_t o_s2 = put(seg2.data(), seg2.size() * 8), o_dn = put(dn.data(), (size_t)c->T * 8);
+        const size_t o_s2 = put(seg2.data(), seg2.size() * 8), o_dn = put(dn.data(), (size_t)T * 8);
         const size_t o_s1 = put(seg1.data(), seg1.size() * 8);
         const size_t o_cs = put(cs.data(), (size_t)nchunks * 4);
         const size_t o_bc = put(block_chunk.data(), (size_t)nblocks * 4), o_bb = put(block_band.data(), (size_t)nblocks * 4);
@@ -1015,7 +1056,6 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     }   // !geom_hit
     const long long nchunks = c->g_nchunks, nblocks = c->g_nblocks, nslices = c->g_nslices;
     const bool two_level = c->g_two_level;
-    (void)nchunks;
 
     // ---- K1 ---------------------------------------------------------------------------------------
     pup::K1Args a{};
@@ -1034,6 +1074,8 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     a.r0 = kr0; a.c0 = kc0;
     a.chunk_begin = c->gv.chunk_begin; a.chunk_end = c->gv.chunk_end; a.chunk_flip = c->gv.chunk_flip;
     a.chunk_stride = c->gv.chunk_stride; a.block_chunk = c->gv.block_chunk; a.block_band = c->gv.block_band;
+    a.blocks = tiled ? c->d_blocks.p : nullptr;
+    a.rec_stride = (int)nchunks;
     a.part_f64 = c->part_f64.p; a.part_num = c->part_num.p;
     a.counters = c->count_pixels ? c->counters.p : nullptr; a.err = c->d_err.p;
     a.W = W; a.ignore_diags = ignore_diags; a.mode = mode;
@@ -1057,7 +1099,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     }
     if (!launched && tiled && c->g_nblocks_t > 0) {
         // the segments whose windows overlap enough go to the staged kernel, the rest to the plain one — side by
-        // side on a second stream: the staged kernel is LDS-limited to ~3 waves per SIMD and leaves wave slots free
+        // side on a second stream
         pup::K1Args at = a;
         at.block_chunk = c->gv.block_chunk_t;
         const bool side = nblocks > 0 && c->stream2 && c->ev_fork && c->ev_join;
@@ -1067,9 +1109,8 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
             launch_regtile(W, a, (int)nblocks, c->stream2);
             HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
         }
-        const bool ok_t = (c->variant & 64) ? launch_tiled(W, at, (int)c->g_nblocks_t, c->stream)
-                                            : launch_wgtiled(W, at, (int)c->g_nblocks_t, (c->variant & 128) ? 4 : 8, c->stream);
-        if (!ok_t) return fail(c, PUP_ENOTSUP, "pup_accumulate: staged kernel not built for W=%d", W);
+        if (!launch_wgtiled(W, at, (int)c->g_nblocks_t, nw_q, paired ? 2 : 1, c->stream))
+            return fail(c, PUP_ENOTSUP, "pup_accumulate: staged kernel not built for W=%d", W);
         if (side) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         if (side || nblocks == 0) launched = true;
     }

@@ -21,6 +21,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace pup {
 
@@ -100,9 +101,12 @@ struct K1Args {
     const int*       block_chunk;  // [gridDim.x] chunk executed by each workgroup (-1: none); groups are laid out
                                    //           so that workgroups b, b+8, b+16, ... (one XCD) share a group
     const int*       block_band;   // [gridDim.x] row band of the window the workgroup owns (banded kernel; else 0)
+    // block table of the workgroup-staged kernel (K1q): its chunks are ranges of BLOCKS, chunk_begin / chunk_end index here
+    const void*      blocks;       // [nblocks] BlockEntry {R, C, first window, windows, windows of slot 0, expected region}
+    int              rec_stride;   // K1q with two accumulator sets: partial record of (chunk, slot) = slot * rec_stride + chunk
     // per-chunk partial outputs
-    double*   part_f64;   // [nchunks][W2 + 2W]   (sum | cov_start | cov_end)
-    unsigned* part_num;   // [nchunks][W2]
+    double*   part_f64;   // [nrecords][W2 + 2W]   (sum | cov_start | cov_end)
+    unsigned* part_num;   // [nrecords][W2]
     // diagnostics
     unsigned long long* counters;  // [0] pixels inside windows, [1] search probes
     int*                err;       // set to 1 when a window leaves the bin table
@@ -650,254 +654,6 @@ __global__ __launch_bounds__(kWave, rt_min_waves(W)) void pileup_regtile_kernel(
     }
 }
 
-// ---- K1t: block-staged register tile (many OVERLAPPING cis windows) ------------------------------------------
-// When a pile-up is large, windows overlap: 1e7 control windows on a human 10 kb map put ~20 of them into every
-// 16 x 16 block of top-left corners.  K1r fetches every window on its own (index line + pixel values per row, ~75 L2
-// lines per window).  K1t needs the snippets ordered by block (r0 / BR, c0 / BC) — the engine sorts them on the
-// device — and lets a wave STAGE the (BR+W-1) x (BC+W-1) region a block's windows live in ONCE into LDS, as final cell values:
-// everything the reference does to a cell depends on its absolute (row, col) only — balanced value, masked bins,
-// ignored diagonals, expected of |col-row| — so the staged cell already is what gets summed (0 where nothing is
-// to be added) and one validity bit per cell says whether it counts in num.  Per window the wave then does 7 LDS
-// reads + 7 f64 adds per lane (W=21) instead of ~180 VALU instructions and 6 global loads.
-// Same register accumulators, chunk flush and reduction as K1r; chunks are contiguous snippet ranges here.
-// Only windows the rank-bitmap index covers (cis, inside one chromosome) are eligible — the engine checks all of
-// them before choosing this kernel.
-template <int W, bool OOE, int BR, int BC>
-__global__ __launch_bounds__(kWave) void pileup_tiled_kernel(K1Args a) {
-    static_assert(W >= 1 && W <= 32 && BC + W - 1 <= 64, "staged region rows must fit one 64-bit validity word");
-    constexpr int NCH = kWave / W;
-    constexpr int CH  = (W + NCH - 1) / NCH;
-    constexpr int W2  = W * W;
-    constexpr int RSR = BR + W - 1;                  // staged region: RSR rows x RS columns of bins
-    constexpr int RS  = BC + W - 1;
-    constexpr int LS  = RS | 1;                      // odd row stride (LDS banks)
-    constexpr int NT  = (RS + 15) / 16;              // column chunks per region row (staging lane-tasks)
-    constexpr int TC  = ((RS + NT - 1) / NT + 1) & ~1;   // even chunk width <= 16, NT * TC >= RS
-    constexpr int NTASK = RSR * NT;
-    __shared__ double tile[RSR * LS + 2 * 16];
-    __shared__ unsigned long long vbits[RSR];         // bit c: cell (row, c) counts in num
-    __shared__ unsigned long long pbits[RSR];         // bit c: cell holds a pixel (statistics only)
-    __shared__ double cov_lds[2 * W];
-    const int lane = threadIdx.x;
-    const int p_raw = lane / NCH;
-    const int k  = lane - p_raw * NCH;
-    const int q0 = k * CH;
-    const bool lane_ok = (p_raw < W) && (q0 < W);
-    const int p  = p_raw < W ? p_raw : W - 1;
-    const int chw = lane_ok ? ((W - q0) < CH ? (W - q0) : CH) : 0;
-    const unsigned chmask = chw >= 32 ? 0xffffffffu : ((1u << chw) - 1u);
-    const int qs = q0 < W ? q0 : 0;
-
-    const bool m_cov   = (a.mode & 0x04u) && a.cov != nullptr;
-    const bool use_exp = OOE && ((a.expv != nullptr && a.nexp > 0) || a.n_exp_regions > 0);
-    const int  igd     = a.ignore_diags;
-    const bool stats   = a.counters != nullptr;
-    const double qnan = __builtin_nan("");
-    ExpCache ecache;
-
-    const int ck = a.block_chunk[blockIdx.x];
-    if (ck < 0) return;
-    double   sum[CH];
-    unsigned num[CH];
-#pragma unroll
-    for (int i = 0; i < CH; ++i) { sum[i] = 0.0; num[i] = 0u; }
-    if (m_cov) for (int t = lane; t < 2 * W; t += kWave) cov_lds[t] = 0.0;
-    __syncthreads();
-
-    const long long cb = a.chunk_begin[ck], ce = a.chunk_end[ck];
-    const int fl = a.chunk_flip[ck];
-    unsigned long long npix = 0;
-    int ch_start = 0, ch_end = -1, ch_nblk = 0; long long ch_base = 0;
-    int R = -1, C = -1;                               // origin of the staged region (block grid); -1: none
-    const double* staged_exp = nullptr;
-
-    // ---- stage the region of block (R, C): lane-task t = (region row, chunk of TC columns) ------------------
-    struct Task { int rr, kc, row, col0, width; bool inside; unsigned bits, ok; long long pos; };
-    auto task_locate = [&](Task& T, int t) __attribute__((always_inline)) {
-        T.rr = t / NT; T.kc = t - T.rr * NT;
-        T.row = R + T.rr; T.col0 = C + TC * T.kc;
-        const int wd = RS - TC * T.kc;
-        T.width = wd < TC ? wd : TC;
-        T.inside = t < NTASK && T.row < ch_end && T.col0 < ch_end;      // R, C >= ch_start by construction
-        T.bits = 0; T.ok = 0; T.pos = 0;
-        if (!T.inside) return;
-        const int rel = T.col0 - ch_start;
-        const int b = rel / kIdxCols, o = rel - b * kIdxCols;
-        const int ws = o >> 6, sh = o & 63;
-        const U64x2* base = reinterpret_cast<const U64x2*>(a.idx + ch_base + (long long)(T.row - ch_start) * ch_nblk + b);
-        const U64x2 h = base[0];
-        const U64x2 w = *reinterpret_cast<const U64x2*>(reinterpret_cast<const char*>(base) + 16 + 8 * ws);
-        const unsigned long long rw = a.badbits[T.row >> 6];
-        const U64x2 cw = *reinterpret_cast<const U64x2*>(a.badbits + (T.col0 >> 6));
-        unsigned long long b64 = w.a >> sh;
-        if (sh) b64 |= w.b << (64 - sh);
-        const unsigned wmask = (1u << T.width) - 1u;
-        T.bits = (unsigned)b64 & wmask;
-        const unsigned cum = ws ? (unsigned)(h.b >> ((ws - 1) * 16)) & 0xffffu : 0u;
-        T.pos = (long long)(h.a + cum + (unsigned long long)__popcll(w.a & ((1ull << sh) - 1ull)));
-        // validity of the task's cells: masked bins, chromosome end, ignored diagonals
-        const int csh = T.col0 & 63;
-        unsigned long long cb64 = cw.a >> csh;
-        if (csh) cb64 |= cw.b << (64 - csh);
-        unsigned ok = wmask & ~(unsigned)cb64;
-        if ((rw >> (T.row & 63)) & 1ull) ok = 0u;
-        const int over = T.col0 + T.width - ch_end;     // columns at / past the chromosome's end are in no eligible window
-        if (over > 0) ok &= over >= T.width ? 0u : ((1u << (T.width - over)) - 1u);
-        if (igd >= 0) {
-            const int t0 = igd - (T.col0 - T.row);
-            ok &= t0 <= 0 ? 0xffffffffu : (t0 >= 32 ? 0u : ~((1u << t0) - 1u));
-        }
-        T.ok = ok;
-    };
-    auto task_load = [&](const Task& T, F64x2 (&prs)[TC / 2]) __attribute__((always_inline)) {
-        // all pair loads, unconditionally (bal is padded; a cell without a pixel reads a neighbour that is then
-        // discarded): predicated loads would serialise the memory latencies
-#pragma unroll
-        for (int i = 0; i < TC; i += 2)
-            prs[i / 2] = *reinterpret_cast<const F64x2*>(a.bal + T.pos + __popc(T.bits & ((1u << i) - 1u)));
-    };
-    auto task_store = [&](const Task& T, const F64x2 (&prs)[TC / 2], const ExpSel& es, int t) __attribute__((always_inline)) {
-        if (t >= NTASK) return;
-        double* dst = tile + T.rr * LS + TC * T.kc;
-        unsigned okn = T.ok;
-        const unsigned bits = T.bits, ok = T.ok;
-#pragma unroll
-        for (int i = 0; i < TC; i += 2) {
-            const F64x2 pr = prs[i / 2];
-            double v0 = ((bits >> i) & 1u) ? pr.a : 0.0;
-            double v1 = ((bits >> (i + 1)) & 1u) ? (((bits >> i) & 1u) ? pr.b : pr.a) : 0.0;
-            if (OOE) {
-                long long ad0 = (long long)(T.col0 + i) - T.row; if (ad0 < 0) ad0 = -ad0;
-                long long ad1 = (long long)(T.col0 + i + 1) - T.row; if (ad1 < 0) ad1 = -ad1;
-                const double e0 = use_exp ? es.at(ad0) : qnan, e1 = use_exp ? es.at(ad1) : qnan;
-                const double q0v = v0 / e0, q1v = v1 / e1;
-                v0 = (((bits >> i) & 1u) && q0v == q0v) ? q0v : 0.0;               // NaN quotients are skipped, inf is kept
-                v1 = (((bits >> (i + 1)) & 1u) && q1v == q1v) ? q1v : 0.0;
-                if (!(e0 == e0) || e0 == 0.0) okn &= ~(1u << i);
-                if (!(e1 == e1) || e1 == 0.0) okn &= ~(1u << (i + 1));
-            }
-            if (i < T.width)     dst[i]     = ((ok >> i) & 1u) ? v0 : 0.0;
-            if (i + 1 < T.width) dst[i + 1] = ((ok >> (i + 1)) & 1u) ? v1 : 0.0;
-        }
-        atomicOr(&vbits[T.rr], (unsigned long long)okn << (TC * T.kc));
-        if (stats) atomicOr(&pbits[T.rr], (unsigned long long)bits << (TC * T.kc));
-    };
-    auto stage = [&](const ExpSel& es) {
-        __syncthreads();                              // earlier windows are done reading the tile
-        for (int t = lane; t < RSR; t += kWave) { vbits[t] = 0ull; pbits[t] = 0ull; }
-        __syncthreads();
-        // two lane-tasks per lane and round: both index lines, then both sets of value loads, are in flight together
-        for (int t0 = lane; t0 < NTASK; t0 += 2 * kWave) {
-            Task TA, TB;
-            F64x2 pa[TC / 2], pb[TC / 2];
-            task_locate(TA, t0);
-            task_locate(TB, t0 + kWave);
-            task_load(TA, pa);
-            task_load(TB, pb);
-            task_store(TA, pa, es, t0);
-            task_store(TB, pb, es, t0 + kWave);
-        }
-        __syncthreads();
-    };
-
-    // one window out of the staged region into the register accumulators
-    auto gather = [&](int r0, int c0, double (&v)[CH], unsigned& vw, unsigned& pw) __attribute__((always_inline)) {
-        const int rr = (r0 - R) + p, cc = (c0 - C) + qs;
-        const double* src = tile + rr * LS + cc;
-#pragma unroll
-        for (int i = 0; i < CH; ++i) v[i] = src[i];                    // idle lanes / cells gather garbage that is never flushed
-        vw = (unsigned)(vbits[rr] >> cc);
-        pw = stats ? (unsigned)(pbits[rr] >> cc) & chmask : 0u;
-    };
-    auto add = [&](int r0, int c0, const double (&v)[CH], unsigned vw, unsigned pw) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < CH; ++i) { sum[i] += v[i]; num[i] += (vw >> i) & 1u; }
-        if (m_cov && lane_ok && k == 0) {
-            const double vs = a.cov[r0 + p], ve = a.cov[c0 + p];
-            if (vs == vs) cov_lds[p] += vs;
-            if (ve == ve) cov_lds[W + p] += ve;
-        }
-        npix += (unsigned long long)__popc(pw);
-    };
-    // does the window belong to the staged region?  Else make its block the staged one (false: bad window)
-    auto ensure = [&](int r0, int c0) -> bool {
-        if (r0 < 0 || c0 < 0 || (long long)r0 + W > a.nbins || (long long)c0 + W > a.nbins) {
-            if (lane == 0) atomicExch(a.err, 1);
-            return false;
-        }
-        ExpSel es; es.base = a.expv; es.len = 0; es.scalar = qnan; es.is_scalar = true;
-        if (use_exp) es = select_expected(a, ecache, r0, c0);
-        const int dr = r0 - R, dc = c0 - C;
-        if (R >= 0 && dr >= 0 && dr < BR && dc >= 0 && dc < BC && r0 < ch_end && !(OOE && es.base != staged_exp)) return true;
-        if (!(r0 >= ch_start && r0 < ch_end)) {
-            int lo = 0, hi_k = a.n_chrom;
-            while (lo < hi_k) { const int m = (lo + hi_k) >> 1; if (a.idx_chrom[m].end <= r0) lo = m + 1; else hi_k = m; }
-            if (lo >= a.n_chrom) { if (lane == 0) atomicExch(a.err, 1); return false; }
-            const IdxChrom cinfo = a.idx_chrom[lo];
-            ch_start = cinfo.start; ch_end = cinfo.end; ch_nblk = cinfo.nblk; ch_base = cinfo.blk_base;
-        }
-        if (c0 < ch_start || c0 + W > ch_end || r0 + W > ch_end) { if (lane == 0) atomicExch(a.err, 1); return false; }
-        // block grid anchored at the chromosome start, so a region never begins before it
-        R = ch_start + ((r0 - ch_start) / BR) * BR;
-        C = ch_start + ((c0 - ch_start) / BC) * BC;
-        staged_exp = es.base;
-        stage(es);
-        return true;
-    };
-    auto same_block = [&](int r0, int c0) -> bool {       // cheap test used to pair two windows
-        const int dr = r0 - R, dc = c0 - C;
-        if (!(dr >= 0 && dr < BR && dc >= 0 && dc < BC && r0 + W <= ch_end && c0 + W <= ch_end && c0 >= ch_start)) return false;
-        if (OOE && use_exp) return select_expected(a, ecache, r0, c0).base == staged_exp;   // same region's expected
-        return true;
-    };
-
-    // coordinates are fetched 64 snippets at a time (one per lane, next batch in flight) and handed out by readlane:
-    // a per-snippet global load would put its full latency on the critical path of this short loop body
-    int r0n = (cb + lane < ce) ? a.r0[cb + lane] : 0, c0n = (cb + lane < ce) ? a.c0[cb + lane] : 0;
-    for (long long s0 = cb; s0 < ce; s0 += kWave) {
-        const int r0v = r0n, c0v = c0n;
-        { const long long sn = s0 + kWave + lane; r0n = sn < ce ? a.r0[sn] : 0; c0n = sn < ce ? a.c0[sn] : 0; }
-        const int nb = (int)((ce - s0) < kWave ? (ce - s0) : kWave);
-        int j = 0;
-        while (j < nb) {
-            const int ra = __builtin_amdgcn_readlane(r0v, j), ca = __builtin_amdgcn_readlane(c0v, j);
-            if (!ensure(ra, ca)) { ++j; continue; }
-            double va[CH]; unsigned vwa, pwa;
-            gather(ra, ca, va, vwa, pwa);
-            // the next window usually lives in the same region: fetch it before adding this one (LDS latency)
-            if (j + 1 < nb) {
-                const int rb = __builtin_amdgcn_readlane(r0v, j + 1), cbx = __builtin_amdgcn_readlane(c0v, j + 1);
-                if (same_block(rb, cbx)) {
-                    double vb[CH]; unsigned vwb, pwb;
-                    gather(rb, cbx, vb, vwb, pwb);
-                    add(ra, ca, va, vwa, pwa);
-                    add(rb, cbx, vb, vwb, pwb);
-                    j += 2;
-                    continue;
-                }
-            }
-            add(ra, ca, va, vwa, pwa);
-            ++j;
-        }
-    }
-
-    __syncthreads();
-    const size_t L = (size_t)W2 + 2 * (size_t)W;
-    double*   of = a.part_f64 + (size_t)ck * L;
-    unsigned* on = a.part_num + (size_t)ck * W2;
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-        if ((chmask >> i) & 1u) {
-            const int cell = map_cell(p, q0 + i, W, false, fl);
-            of[cell] = sum[i];
-            on[cell] = num[i];
-        }
-    }
-    for (int t = lane; t < 2 * W; t += kWave) of[W2 + t] = m_cov ? cov_lds[t] : 0.0;
-    for (int off = 32; off > 0; off >>= 1) npix += __shfl_down(npix, off);
-    if (lane == 0 && stats) atomicAdd(&a.counters[0], npix);
-}
-
 // LDS reads the compiler must not merge: two ds_read_b64 at one base become ds_read2_b64, which the LDS serves at half
 // the bytes per clock (128 vs 256 B/clk/CU on gfx950).  Issued through inline asm (the compiler does not track them):
 // lds_wait_all() + lds_pin() must stand between a read and the first use of its value.
@@ -921,33 +677,49 @@ __device__ __forceinline__ void lds_pin(double (&v)[N]) {     // later uses of v
     for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));
 }
 
-// ---- K1q: workgroup-staged register tile ------------------------------------------------------------------------
-// K1t's scheme with the staging SHARED and wave64-shaped: a workgroup of NW waves stages one 64 x 64 region of bins —
-// the windows of a (65-W) x (65-W) block of top-left corners (W = 21: 44 x 44, ~8x the windows of K1t's 16 x 16 block
-// for 3.2x the cells, so every matrix cell is staged 2.1 times instead of 5.1).
-//   * staging: a WAVE per region row, a LANE per region column.  The row's 64 presence bits come from one index line
-//     through scalar loads; the pixels under them are contiguous in `bal`, lane l's being the mbcnt(bits, l)-th of the
-//     run: one coalesced value load per row, masks applied as 64-bit lane predicates (see `stage`);
-//   * the block's windows are dealt out to the waves (window j of the run to wave j % NW), each wave keeping K1r's
-//     register accumulators; the waves' tiles are merged in a fixed order at the end of the chunk (one partial per
-//     workgroup);
+// ---- K1q: workgroup-staged register tile (many OVERLAPPING cis windows) -------------------------------------------
+// When a pile-up is large its windows OVERLAP: 1e7 control windows on a human 10 kb map put ~135 top-left corners
+// into every 44 x 44 block of the matrix.  K1r fetches every window on its own (index line + pixel values per row,
+// ~75 L2 lines per window).  K1q has the engine sort the snippets by BLOCK of corners on the device and build a
+// block table {R, C, first window, windows}; a workgroup of NW waves then walks a range of blocks and for each one
+// STAGES the 64 x 64 region of bins its windows live in ONCE into LDS, as final cell values: everything the
+// reference does to a cell depends on its absolute (row, col) only — balanced value, masked bins, ignored
+// diagonals, expected of |col-row| — so the staged cell already is what gets summed (0 where nothing is to be added)
+// and one validity bit per cell says whether it counts in num.  Per window a wave then does CH LDS reads + CH f64 adds
+// per lane instead of ~180 VALU instructions and 6 global loads.
+//   * block = (65-W) x (65-W) corners (W = 21: 44 x 44): every matrix cell is staged 2.1 times;
+//   * staging is wave64-shaped: a WAVE per region row, a LANE per region column.  The row's 64 presence bits are one
+//     slice of an index line; the pixels under them are contiguous in `bal`, lane l's being the mbcnt(bits, l)-th of
+//     the run: ONE coalesced value load per row, masks applied as 64-bit lane predicates, conflict-free LDS store;
+//   * staging is software-pipelined over the block table: while the windows of block b are piled up, the value loads
+//     of block b+1 and the index-line loads of block b+2 are in flight (registers), so a region costs its issue
+//     slots, not two memory round trips;
+//   * the block's windows are dealt out to the waves (window j to wave j % NW), each wave keeping K1r's register
+//     accumulators; the waves' tiles are merged in a fixed order at the end of the chunk (one partial per workgroup);
+//   * ACC = 2: the snippets of TWO tiles (the engine pairs tile t with tile t + T/2: ROI and control of one group) share
+//     the pass — a slot bit per window (bit 30 of c0 in the sorted copy) picks the accumulator set — so a sparse ROI
+//     tile rides on the regions its dense control tile stages anyway;
 //   * cells of a lane are INTERLEAVED: lane (p, k) owns columns k, k + NCH, k + 2 NCH, ... of window row p, and the
 //     region's row stride is LS = 64 + NCH doubles, so the 8-byte address of lane l in any of its reads is
 //     const + 64 p + l: the 32 lanes of an LDS lane group hit 32 different bank pairs — ds_read_b64 at its
-//     conflict-free rate of 256 B/clk for every window offset and width;
-//   * every wave reads the same 64 coordinates per batch; which windows belong to the staged block is one ballot, so
-//     the waves agree on the control flow without talking to each other; barriers only frame a staging.
-// Eligibility, validity bits, expected handling and results are K1t's (same integers; sums differ by the order of
-// the f64 additions only).
-template <int W, bool OOE, int NW>
+//     conflict-free rate of 256 B/clk for every window offset and width.
+// Only windows the rank-bitmap index covers (cis, inside one chromosome) are eligible — the engine checks all of them
+// before choosing this kernel.  Same integers as K1r; sums differ by the order of the f64 additions only.
+constexpr int kSlotBit = 30;                          // bit of c0 (sorted copy) holding the window's accumulator slot
+constexpr int kMaxSegCount = 1024;                    // segments (tile x flip runs) one block-ordered call may have
+// block table entry: origin of the staged region; its windows [start, start + count) in the sorted copy, the first
+// count0 of which go to accumulator slot 0 (the sort is stable: a pair's first tile comes first); expected region
+struct __attribute__((aligned(32))) BlockEntry { int R, C, start, count, count0, ereg, pad0, pad1; };
+
+template <int W, bool OOE, int NW, int ACC>
 __global__ __launch_bounds__(kWave * NW) void pileup_wgtile_kernel(K1Args a) {
     static_assert(W >= 3 && W <= 32, "workgroup-staged kernel serves windows of 3..32 bins");
     static_assert(NW == 4 || NW == 8 || NW == 16, "the region's 64 rows are dealt out evenly to the waves");
+    static_assert(ACC == 1 || ACC == 2, "one or two accumulator sets");
     constexpr int NCH = kWave / W;
     constexpr int CH  = (W + NCH - 1) / NCH;
     constexpr int W2  = W * W;
     constexpr int RS  = 64;                              // staged region: RS x RS bins
-    constexpr int BR  = RS - W + 1, BC = RS - W + 1;     // block of top-left corners it serves
     constexpr int LS  = RS + ((NCH % 32) ? (NCH % 32) : 32);   // row stride, LS % 32 == NCH % 32 (see above)
     constexpr int RPW = RS / NW;                         // region rows staged by each wave
     constexpr int NTHR = kWave * NW;
@@ -956,7 +728,7 @@ __global__ __launch_bounds__(kWave * NW) void pileup_wgtile_kernel(K1Args a) {
     __shared__ double tile[RS * LS];
     __shared__ unsigned long long vbits[RS];             // bit c: cell (row, c) counts in num
     __shared__ unsigned long long pbits[RS];             // bit c: cell holds a pixel (statistics only)
-    __shared__ double cov_lds[NW][2 * W];
+    __shared__ double cov_lds[NW][ACC][2 * W];
     const int tid  = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -973,93 +745,116 @@ __global__ __launch_bounds__(kWave * NW) void pileup_wgtile_kernel(K1Args a) {
     const int  igd     = a.ignore_diags;
     const bool stats   = a.counters != nullptr;
     const double qnan = __builtin_nan("");
-    ExpCache ecache;
 
     const int ck = a.block_chunk[blockIdx.x];
     if (ck < 0) return;                                  // padding workgroup (uniform)
-    double   sum[CH];
-    unsigned num[CH];
+    double   sum[ACC][CH];
+    unsigned num[ACC][CH];
 #pragma unroll
-    for (int i = 0; i < CH; ++i) { sum[i] = 0.0; num[i] = 0u; }
-    if (m_cov) for (int t = lane; t < 2 * W; t += kWave) cov_lds[wave][t] = 0.0;
+    for (int s = 0; s < ACC; ++s)
+#pragma unroll
+        for (int i = 0; i < CH; ++i) { sum[s][i] = 0.0; num[s][i] = 0u; }
+    if (m_cov) for (int t = lane; t < ACC * 2 * W; t += kWave) (&cov_lds[wave][0][0])[t] = 0.0;
 
-    const long long cb = a.chunk_begin[ck], ce = a.chunk_end[ck];
+    const int bb = (int)a.chunk_begin[ck], be = (int)a.chunk_end[ck];     // blocks [bb, be) of the block table
     const int fl = a.chunk_flip[ck];
+    const BlockEntry* __restrict__ blocks = reinterpret_cast<const BlockEntry*>(a.blocks);
     unsigned long long npix = 0;
     int ch_start = 0, ch_end = -1, ch_nblk = 0; long long ch_base = 0;
-    int R = 0, C = 0; bool staged = false;               // origin of the staged region (block grid)
-    const double* staged_exp = nullptr;
-    int er_start = 0, er_end = 0x7fffffff;               // rows whose expected is the staged one (OOE with a region table)
 
-    // ---- stage the region of block (R, C): a WAVE per region row, a LANE per region column ---------------------------
-    // The 64 columns of a region row are one 64-bit slice of the row's presence bits, and the pixels under it are
-    // contiguous in `bal`: lane l holds column C + l, its pixel is the (number of set bits below l)-th of the run
-    // (v_mbcnt), so a row's value load is ONE coalesced read of <= 512 contiguous bytes, the masks (masked bins,
-    // diagonal, chromosome end) are 64-bit words applied as lane predicates, and the LDS store is conflict-free.
-    // Three phases per wave, each with all of its loads in flight together:
-    //   A  lane i < RPW fetches the index line words of the wave's i-th row and works out bits / position / masks;
-    //   B  per row: broadcast position and bits (readlane), rank = mbcnt, issue the value load;
-    //   C  per row: apply the keep mask, (OOE) divide by expected, store.
-    auto stage = [&](const ExpSel& es) {
-        __syncthreads();                                 // every wave is done with the previous region
-        const int rel = C - ch_start;                    // R, C >= ch_start by construction
-        const int b = rel / kIdxCols, o = rel - b * kIdxCols;
-        const int ws = o >> 6, sh = o & 63;
-        unsigned long long colok;
-        {
-            const unsigned long long* cw = a.badbits + (C >> 6);
-            const int csh = C & 63;
-            unsigned long long colbad = cw[0] >> csh;
-            if (csh) colbad |= cw[1] << (64 - csh);
-            colok = ~colbad;
-            const int over = C + RS - ch_end;            // columns at / past the chromosome's end are in no eligible window
-            if (over > 0) colok &= over >= 64 ? 0ull : (~0ull >> over);
+    // ---- staging, in pieces (see the pipeline in the block loop) ----------------------------------------------------
+    struct Geo { int R, C, start, count, count0, ereg, ch_end, ws, sh, nblk; unsigned long long colok; const IdxBlock* line0; };
+    struct Raw { U64x2 h, w; unsigned long long rw; };                     // lane i < RPW: index words of the wave's i-th row
+    struct Row { unsigned long long bits, keep, okn; long long pos; };     // lane i < RPW: what they amount to
+    auto geo_of = [&](int b) -> Geo {
+        const BlockEntry e = blocks[b];
+        Geo g; g.R = e.R; g.C = e.C; g.start = e.start; g.count = e.count; g.count0 = e.count0; g.ereg = e.ereg;
+        if (!(g.R >= ch_start && g.R < ch_end)) {        // blocks arrive sorted: rare
+            int lo = 0, hi_k = a.n_chrom;
+            while (lo < hi_k) { const int m = (lo + hi_k) >> 1; if (a.idx_chrom[m].end <= g.R) lo = m + 1; else hi_k = m; }
+            if (lo >= a.n_chrom) lo = a.n_chrom - 1;     // cannot happen: the engine verified every window
+            const IdxChrom cinfo = a.idx_chrom[lo];
+            ch_start = cinfo.start; ch_end = cinfo.end; ch_nblk = cinfo.nblk; ch_base = cinfo.blk_base;
         }
-        // ---- A: lane i = the wave's i-th row ----
-        unsigned long long l_bits = 0ull, l_keep = 0ull, l_ok = 0ull; long long l_pos = 0;
-        {
-            const int row = R + wave * RPW + (lane < RPW ? lane : 0);
-            if (lane < RPW && row < ch_end) {
-                const char* line = reinterpret_cast<const char*>(a.idx + ch_base + (long long)(row - ch_start) * ch_nblk + b);
-                const U64x2 h = *reinterpret_cast<const U64x2*>(line);                    // {pos, cum[4]}
-                const U64x2 w = *reinterpret_cast<const U64x2*>(line + 16 + 8 * ws);      // {bits[ws], bits[ws+1] | next0}
-                const unsigned long long rw = a.badbits[row >> 6];
-                l_bits = w.a >> sh;
-                if (sh) l_bits |= w.b << (64 - sh);
-                const unsigned cum = ws ? (unsigned)(h.b >> ((ws - 1) * 16)) & 0xffffu : 0u;
-                l_pos = (long long)(h.a + cum + (unsigned long long)__popcll(w.a & ((1ull << sh) - 1ull)));
-                l_ok = ((rw >> (row & 63)) & 1ull) ? 0ull : colok;
-                if (igd >= 0) {
-                    const int t0 = igd - (C - row);     // column C + l is on or above the first kept diagonal iff l >= t0
-                    l_ok &= t0 <= 0 ? ~0ull : (t0 >= 64 ? 0ull : ~((1ull << t0) - 1ull));
-                }
-                l_keep = l_bits & l_ok;
-            }
+        g.ch_end = ch_end; g.nblk = ch_nblk;
+        const int rel = g.C - ch_start;                  // R, C >= ch_start: the block grid is anchored there
+        const int bi = rel / kIdxCols, o = rel - bi * kIdxCols;
+        g.ws = o >> 6; g.sh = o & 63;
+        g.line0 = a.idx + ch_base + (long long)(g.R - ch_start) * ch_nblk + bi;
+        const unsigned long long* cw = a.badbits + (g.C >> 6);
+        const int csh = g.C & 63;
+        unsigned long long colbad = cw[0] >> csh;
+        if (csh) colbad |= cw[1] << (64 - csh);
+        g.colok = ~colbad;
+        const int over = g.C + RS - ch_end;              // columns at / past the chromosome's end are in no eligible window
+        if (over > 0) g.colok &= over >= 64 ? 0ull : (~0ull >> over);
+        return g;
+    };
+    const int my_rr = wave * RPW + (lane < RPW ? lane : 0);               // region row this lane looks up in phase A
+    auto load_raw = [&](const Geo& g, Raw& x) __attribute__((always_inline)) {
+        x.h.a = 0ull; x.h.b = 0ull; x.w.a = 0ull; x.w.b = 0ull; x.rw = ~0ull;
+        const int row = g.R + my_rr;
+        if (lane < RPW && row < g.ch_end) {
+            const char* line = reinterpret_cast<const char*>(g.line0 + (long long)my_rr * g.nblk);
+            x.h = *reinterpret_cast<const U64x2*>(line);                       // {pos, cum[4]}
+            x.w = *reinterpret_cast<const U64x2*>(line + 16 + 8 * g.ws);       // {bits[ws], bits[ws+1] | next0}
+            x.rw = a.badbits[row >> 6];
         }
-        auto bcast64 = [&](unsigned long long v, int i) -> unsigned long long {
-            const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, i), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), i);
-            return ((unsigned long long)hi << 32) | lo;
-        };
-        // ---- B: value loads of all the wave's rows ----
-        double v[RPW];
+    };
+    auto finish_rows = [&](const Geo& g, const Raw& x) __attribute__((always_inline)) -> Row {
+        Row r;
+        const int row = g.R + my_rr;
+        const bool live = lane < RPW && row < g.ch_end;
+        r.bits = x.w.a >> g.sh;
+        if (g.sh) r.bits |= x.w.b << (64 - g.sh);
+        const unsigned cum = g.ws ? (unsigned)(x.h.b >> ((g.ws - 1) * 16)) & 0xffffu : 0u;
+        r.pos = (long long)(x.h.a + cum + (unsigned long long)__popcll(x.w.a & ((1ull << g.sh) - 1ull)));
+        unsigned long long ok = ((x.rw >> (row & 63)) & 1ull) ? 0ull : g.colok;
+        if (igd >= 0) {
+            const int t0 = igd - (g.C - row);           // column C + l is on or above the first kept diagonal iff l >= t0
+            ok &= t0 <= 0 ? ~0ull : (t0 >= 64 ? 0ull : ~((1ull << t0) - 1ull));
+        }
+        if (!live) { r.bits = 0ull; ok = 0ull; r.pos = 0; }
+        r.okn = ok; r.keep = r.bits & ok;
+        return r;
+    };
+    auto bcast64 = [&](unsigned long long v, int i) __attribute__((always_inline)) -> unsigned long long {
+        const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, i), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), i);
+        return ((unsigned long long)hi << 32) | lo;
+    };
+    auto issue_values = [&](const Row& r, double (&v)[RPW]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
-            const unsigned long long bits = bcast64(l_bits, i);
-            const long long pos = (long long)bcast64((unsigned long long)l_pos, i);
+            const unsigned long long bits = bcast64(r.bits, i);
+            const long long pos = (long long)bcast64((unsigned long long)r.pos, i);
             const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bits >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bits, 0u));
             v[i] = a.bal[pos + rank];                    // bal is padded: a lane without a pixel reads a neighbour, discarded
         }
-        // ---- C: masks, expected, store ----
-        unsigned long long l_okn = l_ok;
+    };
+    auto exp_of = [&](const Geo& g) -> ExpSel {
+        ExpSel es; es.base = a.expv; es.len = 0; es.scalar = qnan; es.is_scalar = true;
+        if (!use_exp) return es;
+        if (a.n_exp_regions <= 0) {
+            es.len = a.nexp; es.is_scalar = (a.nexp == 1);
+            es.scalar = (a.nexp == 1 && a.expv) ? a.expv[0] : qnan;
+            if (!a.expv || a.nexp <= 0) { es.is_scalar = true; es.scalar = qnan; }
+            return es;
+        }
+        const int er = g.ereg;                           // expected region of the block's windows (part of the sort key)
+        es.is_scalar = false;
+        if (er >= 0 && er < a.n_exp_regions) { const ExpRegion g = a.exp_regions[er]; es.base = a.expv + g.off; es.len = g.len; }
+        return es;
+    };
+    auto store_region = [&](const Geo& g, Row& r, const double (&v)[RPW], const ExpSel& es) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
             const int rr = wave * RPW + i;
-            const bool keep = __builtin_amdgcn_inverse_ballot_w64(bcast64(l_keep, i));
+            const bool keep = __builtin_amdgcn_inverse_ballot_w64(bcast64(r.keep, i));
             double val = v[i];
             bool good = keep;
             if (OOE) {
-                const int row = R + rr;
-                long long ad = (long long)(C + lane) - row; if (ad < 0) ad = -ad;
+                const int row = g.R + rr;
+                long long ad = (long long)(g.C + lane) - row; if (ad < 0) ad = -ad;
                 const double e = use_exp ? es.at(ad) : qnan;
                 val = val / e;
                 good = keep && (val == val);            // NaN quotients are skipped, inf is kept
@@ -1069,57 +864,30 @@ __global__ __launch_bounds__(kWave * NW) void pileup_wgtile_kernel(K1Args a) {
                 int e_ok = (e == e && e != 0.0) ? 1 : 0;
                 asm volatile("" : "+v"(e_ok));
                 const unsigned long long eok = __ballot(e_ok);
-                if (lane == i) l_okn &= eok;
+                if (lane == i) r.okn &= eok;
             }
             tile[rr * LS + lane] = good ? val : 0.0;
         }
-        if (lane < RPW) { vbits[wave * RPW + lane] = l_okn; if (stats) pbits[wave * RPW + lane] = l_bits; }
-        __syncthreads();
+        if (lane < RPW) { vbits[wave * RPW + lane] = r.okn; if (stats) pbits[wave * RPW + lane] = r.bits; }
     };
 
-    // make the block of the (wave-uniform) window (r0, c0) the staged one; false: bad window
-    auto restage = [&](int r0, int c0) -> bool {
-        if (r0 < 0 || c0 < 0 || (long long)r0 + W > a.nbins || (long long)c0 + W > a.nbins) {
-            if (tid == 0) atomicExch(a.err, 1);
-            return false;
-        }
-        ExpSel es; es.base = a.expv; es.len = 0; es.scalar = qnan; es.is_scalar = true;
-        if (use_exp) es = select_expected(a, ecache, r0, c0);
-        if (!(r0 >= ch_start && r0 < ch_end)) {
-            int lo = 0, hi_k = a.n_chrom;
-            while (lo < hi_k) { const int m = (lo + hi_k) >> 1; if (a.idx_chrom[m].end <= r0) lo = m + 1; else hi_k = m; }
-            if (lo >= a.n_chrom) { if (tid == 0) atomicExch(a.err, 1); return false; }
-            const IdxChrom cinfo = a.idx_chrom[lo];
-            ch_start = cinfo.start; ch_end = cinfo.end; ch_nblk = cinfo.nblk; ch_base = cinfo.blk_base;
-        }
-        if (c0 < ch_start || c0 + W > ch_end || r0 + W > ch_end) { if (tid == 0) atomicExch(a.err, 1); return false; }
-        // block grid anchored at the chromosome start (the division runs on the vector unit: tell the compiler the
-        // results are wave-uniform, or every address derived from them becomes per-lane arithmetic)
-        R = __builtin_amdgcn_readfirstlane(ch_start + ((r0 - ch_start) / BR) * BR);
-        C = __builtin_amdgcn_readfirstlane(ch_start + ((c0 - ch_start) / BC) * BC);
-        staged_exp = es.base; staged = true;
-        if (OOE && use_exp && a.n_exp_regions > 0) { er_start = ecache.r_start; er_end = ecache.r_end; }
-        stage(es);
-        return true;
-    };
-
-    // one window out of the staged region
+    // ---- one window out of the staged region ---------------------------------------------------------------------
     const int lane_off = p * LS + k;
     const unsigned tile_lds = (unsigned)(uintptr_t)tile;       // LDS byte address of the region buffer
-    auto gather = [&](int r0, int c0, double (&v)[CH], unsigned& vw, unsigned& pw) __attribute__((always_inline)) {
-        const int dr = r0 - R, dc = c0 - C;              // wave-uniform
+    auto gather = [&](int dr, int dc, double (&v)[CH], unsigned& vw, unsigned& pw) __attribute__((always_inline)) {
         // single ds_read_b64 each (see lds_read_b64); cells the lane does not own read padding, never flushed
         LdsReadRow<0, CH, 8 * NCH>::go(v, tile_lds + 8u * (unsigned)(dr * LS + dc + lane_off));
         vw = (unsigned)(vbits[dr + p] >> (dc + k));
         pw = stats ? (unsigned)(pbits[dr + p] >> (dc + k)) : 0u;
     };
-    auto add = [&](int r0, int c0, const double (&v)[CH], unsigned vw, unsigned pw) __attribute__((always_inline)) {
+    auto add_to = [&](double (&sm)[CH], unsigned (&nm)[CH], int slot, int r0, int c0, const double (&v)[CH], unsigned vw, unsigned pw)
+            __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < CH; ++i) { sum[i] += v[i]; num[i] += (vw >> (NCH * i)) & 1u; }
+        for (int i = 0; i < CH; ++i) { sm[i] += v[i]; nm[i] += (vw >> (NCH * i)) & 1u; }
         if (m_cov && row_ok && k == 0) {
             const double vs = a.cov[r0 + p], ve = a.cov[c0 + p];
-            if (vs == vs) cov_lds[wave][p] += vs;
-            if (ve == ve) cov_lds[wave][W + p] += ve;
+            if (vs == vs) cov_lds[wave][slot][p] += vs;
+            if (ve == ve) cov_lds[wave][slot][W + p] += ve;
         }
         if (stats) {
             unsigned m = 0u;
@@ -1128,78 +896,114 @@ __global__ __launch_bounds__(kWave * NW) void pileup_wgtile_kernel(K1Args a) {
             npix += m;
         }
     };
+    constexpr int kCoordMask = (1 << kSlotBit) - 1;
+    // windows [j0, j1) of the batch held in (r0v, c0v), all of accumulator slot S; window j goes to wave (j - j0) % NW
+    auto run = [&](auto slot_tag, const Geo& g, int r0v, int c0v, int j0, int j1) __attribute__((always_inline)) {
+        constexpr int S = decltype(slot_tag)::value;
+        int jj = j0 + wave;
+        for (; jj + NW < j1; jj += 2 * NW) {              // two windows in flight: both gathered before either is added
+            const int ra = __builtin_amdgcn_readlane(r0v, jj), ca = __builtin_amdgcn_readlane(c0v, jj) & kCoordMask;
+            const int rb = __builtin_amdgcn_readlane(r0v, jj + NW), cb = __builtin_amdgcn_readlane(c0v, jj + NW) & kCoordMask;
+            double va[CH], vb[CH]; unsigned vwa, pwa, vwb, pwb;
+            gather(ra - g.R, ca - g.C, va, vwa, pwa);
+            gather(rb - g.R, cb - g.C, vb, vwb, pwb);
+            lds_wait_all(); lds_pin(va); lds_pin(vb);
+            add_to(sum[S], num[S], S, ra, ca, va, vwa, pwa);
+            add_to(sum[S], num[S], S, rb, cb, vb, vwb, pwb);
+        }
+        if (jj < j1) {
+            const int ra = __builtin_amdgcn_readlane(r0v, jj), ca = __builtin_amdgcn_readlane(c0v, jj) & kCoordMask;
+            double va[CH]; unsigned vwa, pwa;
+            gather(ra - g.R, ca - g.C, va, vwa, pwa);
+            lds_wait_all(); lds_pin(va);
+            add_to(sum[S], num[S], S, ra, ca, va, vwa, pwa);
+        }
+    };
+    // the windows [g.start, g.start + g.count) of the staged block; (r0f, c0f) = the first 64 of them, one per lane
+    auto windows = [&](const Geo& g, int r0f, int c0f) __attribute__((always_inline)) {
+        for (int s0 = 0; s0 < g.count; s0 += kWave) {
+            const int r0v = r0f, c0v = c0f;
+            if (s0 + kWave < g.count) {                   // next batch of this block
+                const int sn = s0 + kWave + lane;
+                r0f = sn < g.count ? a.r0[g.start + sn] : 0; c0f = sn < g.count ? a.c0[g.start + sn] : 0;
+            }
+            const int nb = (g.count - s0) < kWave ? (g.count - s0) : kWave;
+            if (ACC == 2) {
+                int split = g.count0 - s0;                // windows of the batch before `split` belong to slot 0
+                split = split < 0 ? 0 : (split > nb ? nb : split);
+                run(std::integral_constant<int, 0>{}, g, r0v, c0v, 0, split);
+                run(std::integral_constant<int, ACC - 1>{}, g, r0v, c0v, split, nb);
+            } else run(std::integral_constant<int, 0>{}, g, r0v, c0v, 0, nb);
+        }
+    };
+    auto first_coords = [&](const Geo& g, int& r0f, int& c0f) __attribute__((always_inline)) {
+        r0f = lane < g.count ? a.r0[g.start + lane] : 0; c0f = lane < g.count ? a.c0[g.start + lane] : 0;
+    };
 
-    // coordinates: 64 windows per batch, one per lane (every wave holds the same batch), next batch in flight
-    int r0n = (cb + lane < ce) ? a.r0[cb + lane] : -1, c0n = (cb + lane < ce) ? a.c0[cb + lane] : -1;
-    for (long long s0 = cb; s0 < ce; s0 += kWave) {
-        const int r0v = r0n, c0v = c0n;
-        { const long long sn = s0 + kWave + lane; r0n = sn < ce ? a.r0[sn] : -1; c0n = sn < ce ? a.c0[sn] : -1; }
-        const int nb = (int)((ce - s0) < kWave ? (ce - s0) : kWave);
-        int j = 0;
-        while (j < nb) {
-            // windows j .. j+m-1 of the batch live in the staged block (m >= 1 after a successful restage)
-            auto in_block = [&]() -> unsigned long long {
-                const bool in = staged && lane >= j && lane < nb &&
-                                (unsigned)(r0v - R) < (unsigned)BR && (unsigned)(c0v - C) < (unsigned)BC &&
-                                r0v + W <= ch_end && c0v + W <= ch_end &&
-                                (!(OOE) || (r0v >= er_start && r0v < er_end));
-                return __ballot(in) >> j;
-            };
-            unsigned long long mask = in_block();
-            if (!(mask & 1ull)) {
-                const int ra = __builtin_amdgcn_readlane(r0v, j), ca = __builtin_amdgcn_readlane(c0v, j);
-                if (!restage(ra, ca)) { ++j; continue; }
-                mask = in_block() | 1ull;
-            }
-            const int m = ~mask ? __builtin_ctzll(~mask) : kWave;
-            const int jend = j + m;
-            int jj = j + wave;
-            for (; jj + NW < jend; jj += 2 * NW) {        // two windows in flight: both gathered before either is added
-                const int ra = __builtin_amdgcn_readlane(r0v, jj), ca = __builtin_amdgcn_readlane(c0v, jj);
-                const int rb = __builtin_amdgcn_readlane(r0v, jj + NW), cbx = __builtin_amdgcn_readlane(c0v, jj + NW);
-                double va[CH], vb[CH]; unsigned vwa, pwa, vwb, pwb;
-                gather(ra, ca, va, vwa, pwa);
-                gather(rb, cbx, vb, vwb, pwb);
-                lds_wait_all(); lds_pin(va); lds_pin(vb);
-                add(ra, ca, va, vwa, pwa);
-                add(rb, cbx, vb, vwb, pwb);
-            }
-            if (jj < jend) {
-                const int ra = __builtin_amdgcn_readlane(r0v, jj), ca = __builtin_amdgcn_readlane(c0v, jj);
-                double va[CH]; unsigned vwa, pwa;
-                gather(ra, ca, va, vwa, pwa);
-                lds_wait_all(); lds_pin(va);
-                add(ra, ca, va, vwa, pwa);
-            }
-            j = jend;
+    // ---- the block loop: region b is piled up while b+1's values and b+2's index lines are on their way -----------
+    if (bb < be) {
+        Geo g0 = geo_of(bb), g1 = g0, g2 = g0;
+        Raw x1, x2;
+        Row rw0, rw1;
+        double v[RPW];
+        int r0f, c0f, r1f = 0, c1f = 0;
+        {   // prologue: stage block bb without overlap, start the lookups of bb+1
+            Raw x0;
+            load_raw(g0, x0);
+            first_coords(g0, r0f, c0f);
+            if (bb + 1 < be) { g1 = geo_of(bb + 1); load_raw(g1, x1); }
+            rw0 = finish_rows(g0, x0);
+            issue_values(rw0, v);
+            const ExpSel es0 = exp_of(g0);
+            __syncthreads();
+            store_region(g0, rw0, v, es0);
+            __syncthreads();
+            if (bb + 1 < be) rw1 = finish_rows(g1, x1);
+        }
+        for (int b = bb; b < be; ++b) {
+            const bool has1 = b + 1 < be, has2 = b + 2 < be;
+            if (has1) { issue_values(rw1, v); first_coords(g1, r1f, c1f); }
+            if (has2) { g2 = geo_of(b + 2); load_raw(g2, x2); }
+            windows(g0, r0f, c0f);
+            if (!has1) break;
+            const ExpSel es1 = exp_of(g1);
+            __syncthreads();                             // every wave is done reading region b
+            store_region(g1, rw1, v, es1);
+            __syncthreads();
+            g0 = g1; r0f = r1f; c0f = c1f;
+            if (has2) { g1 = g2; rw1 = finish_rows(g2, x2); }
         }
     }
 
-    // ---- merge the waves' register tiles in wave order (fixed summation order), then one partial per workgroup -----
-    __syncthreads();
+    // ---- merge the waves' register tiles in wave order (fixed summation order): one partial per slot and workgroup ----
+    const size_t L = (size_t)W2 + 2 * (size_t)W;
     double*   mf = tile;
     unsigned* mn = reinterpret_cast<unsigned*>(tile + W2);
-    for (int w = 0; w < NW; ++w) {
-        if (wave == w) {
 #pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                if ((chmask >> i) & 1u) {
-                    const int cell = map_cell(p, k + NCH * i, W, false, fl);
-                    if (w == 0) { mf[cell] = sum[i]; mn[cell] = num[i]; }
-                    else        { mf[cell] += sum[i]; mn[cell] += num[i]; }
+    for (int s = 0; s < ACC; ++s) {
+        __syncthreads();
+        for (int w = 0; w < NW; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    if ((chmask >> i) & 1u) {
+                        const int cell = map_cell(p, k + NCH * i, W, false, fl);
+                        if (w == 0) { mf[cell] = sum[s][i]; mn[cell] = num[s][i]; }
+                        else        { mf[cell] += sum[s][i]; mn[cell] += num[s][i]; }
+                    }
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
-    }
-    const size_t L = (size_t)W2 + 2 * (size_t)W;
-    double*   of = a.part_f64 + (size_t)ck * L;
-    unsigned* on = a.part_num + (size_t)ck * W2;
-    for (int t = tid; t < W2; t += NTHR) { of[t] = mf[t]; on[t] = mn[t]; }
-    for (int t = tid; t < 2 * W; t += NTHR) {
-        double s = 0.0;
-        if (m_cov) for (int w = 0; w < NW; ++w) s += cov_lds[w][t];
-        of[W2 + t] = s;
+        const size_t rec = (size_t)s * (size_t)a.rec_stride + (size_t)ck;
+        double*   of = a.part_f64 + rec * L;
+        unsigned* on = a.part_num + rec * W2;
+        for (int t = tid; t < W2; t += NTHR) { of[t] = mf[t]; on[t] = mn[t]; }
+        for (int t = tid; t < 2 * W; t += NTHR) {
+            double acc = 0.0;
+            if (m_cov) for (int w = 0; w < NW; ++w) acc += cov_lds[w][s][t];
+            of[W2 + t] = acc;
+        }
     }
     if (stats) {
         for (int off = 32; off > 0; off >>= 1) npix += __shfl_down(npix, off);
@@ -1207,58 +1011,45 @@ __global__ __launch_bounds__(kWave * NW) void pileup_wgtile_kernel(K1Args a) {
     }
 }
 
-// key of a snippet for the block order K1t wants: (segment = tile/flip run, block row, block col), plus a check
-// that the window is one the rank-bitmap index covers (cis, inside one chromosome); counts the ineligible ones
+// ---- block-order prepass of K1q ------------------------------------------------------------------------------------
+// key of a snippet: (segment, expected region, block row, block col).  Segment = the (tile pair | tile, flip) run the
+// snippet is piled up with; `pair_half` = T/2 when tile t shares its pass with tile t + T/2 (then slot = t / (T/2) goes
+// into bit 31 of the value), 0 when every tile has its own pass.  Also checks that the window is one the rank-bitmap
+// index covers (cis, inside one chromosome) and counts the ineligible ones.
 __global__ __launch_bounds__(256) void block_key_kernel(const int* __restrict__ r0, const int* __restrict__ c0, long long n,
-                                                        const long long* __restrict__ seg_end, int nseg,
-                                                        const IdxChrom* __restrict__ chroms, int n_chrom, int W, int BR, int BC,
-                                                        int sh_br, int sh_seg,
+                                                        const long long* __restrict__ seg_end, int nseg2t, int pair_half,
+                                                        const IdxChrom* __restrict__ chroms, int n_chrom,
+                                                        const ExpRegion* __restrict__ eregs, int n_eregs,
+                                                        int W, int BR, int BC, int sh_br, int sh_er, int sh_seg,
                                                         unsigned long long* __restrict__ keys, unsigned* __restrict__ vals,
-                                                        unsigned long long* __restrict__ counters /* [0] ineligible */) {
+                                                        unsigned* __restrict__ counters /* [0] ineligible */) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int r = r0[i], c = c0[i];
-    int lo = 0, hi = nseg;
+    int lo = 0, hi = nseg2t;
     while (lo < hi) { const int m = (lo + hi) >> 1; if (seg_end[m] <= i) lo = m + 1; else hi = m; }
-    int a = 0, b = n_chrom;
-    while (a < b) { const int m = (a + b) >> 1; if (chroms[m].end <= r) a = m + 1; else b = m; }
-    bool ok = r >= 0 && c >= 0 && a < n_chrom;
-    unsigned long long br = 0, bc = 0;
+    const int t = lo >> 1, f = lo & 1;                   // tile, flip state of the snippet
+    unsigned seg = (unsigned)lo, slot = 0u;
+    if (pair_half > 0) { slot = (unsigned)(t / pair_half); seg = (unsigned)((t % pair_half) * 2 + f); }
+    int ca = 0, cb = n_chrom;
+    while (ca < cb) { const int m = (ca + cb) >> 1; if (chroms[m].end <= r) ca = m + 1; else cb = m; }
+    bool ok = r >= 0 && c >= 0 && ca < n_chrom;
+    unsigned long long br = 0, bc = 0, er = 0;
     if (ok) {
-        const int cs = chroms[a].start, ce = chroms[a].end;
+        const int cs = chroms[ca].start, ce = chroms[ca].end;
         ok = r >= cs && r + W <= ce && c >= cs && c + W <= ce;
         if (ok) {
             br = (unsigned long long)cs + (unsigned long long)((r - cs) / BR);  // unique and increasing over the genome
             bc = (unsigned long long)((c - cs) / BC);
         }
     }
-    if (!ok) atomicAdd(&counters[0], 1ull);
-    keys[i] = ((unsigned long long)lo << sh_seg) | (br << sh_br) | bc;
-    vals[i] = (unsigned)i;
-}
-
-// per segment (tile / flip run): number of positions where the block key differs from its predecessor
-// (= region stagings K1t would do in this order).  Grid-stride; counts are kept per workgroup in LDS and flushed once
-// (global atomics from every wave to the same few counters cost milliseconds).  nseg <= kMaxSegCount.
-constexpr int kMaxSegCount = 1024;
-__global__ __launch_bounds__(256) void count_changes_kernel(const unsigned long long* __restrict__ keys, long long n,
-                                                            int sh_seg, int nseg, unsigned long long* __restrict__ per_seg) {
-    __shared__ unsigned cnt[kMaxSegCount];
-    for (int t = threadIdx.x; t < nseg; t += blockDim.x) cnt[t] = 0u;
-    __syncthreads();
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const unsigned long long k = keys[i];
-        if (i == 0 || k != keys[i - 1]) atomicAdd(&cnt[(int)(k >> sh_seg)], 1u);
+    if (n_eregs > 0) {                                   // the region whose expected the snippet divides by (that of its first row)
+        const int e = find_exp_region(eregs, n_eregs, r);
+        er = (unsigned long long)(e < 0 ? n_eregs : e);
     }
-    __syncthreads();
-    for (int t = threadIdx.x; t < nseg; t += blockDim.x) if (cnt[t]) atomicAdd(&per_seg[t], (unsigned long long)cnt[t]);
-}
-
-__global__ __launch_bounds__(256) void permute_snippets_kernel(const int* __restrict__ r0, const int* __restrict__ c0,
-                                                               const unsigned* __restrict__ order, long long n,
-                                                               int* __restrict__ r0s, int* __restrict__ c0s) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { const unsigned j = order[i]; r0s[i] = r0[j]; c0s[i] = c0[j]; }
+    if (!ok) atomicAdd(&counters[0], 1u);
+    keys[i] = ((unsigned long long)seg << sh_seg) | (er << sh_er) | (br << sh_br) | bc;
+    vals[i] = (unsigned)i | (slot << 31);
 }
 
 // 32-bit copy of the keys (when they fit): halves the radix passes of the block sort
@@ -1268,33 +1059,70 @@ __global__ __launch_bounds__(256) void narrow_keys_kernel(const unsigned long lo
     if (i < n) k32[i] = (unsigned)k64[i];
 }
 
-// Estimate of the windows per DISTINCT block, per segment, without sorting: only the blocks whose hashed key falls in
-// one of 8 classes are looked at (sampling by BLOCK keeps windows-per-block unbiased); each of their windows counts in
-// seen[seg] and sets one bit of a hashed bitmap — a window that finds its bit clear counts in fresh[seg].
-// windows per block ~ seen / fresh (bitmap collisions undercount fresh by a few per cent at the load factor used).
-__global__ __launch_bounds__(256) void distinct_blocks_kernel(const unsigned long long* __restrict__ keys, long long n,
-                                                              int sh_seg, int nseg, unsigned* __restrict__ bitmap,
-                                                              unsigned mask_bits, unsigned long long* __restrict__ seen,
-                                                              unsigned long long* __restrict__ fresh) {
-    __shared__ unsigned s_seen[kMaxSegCount], s_fresh[kMaxSegCount];
-    for (int t = threadIdx.x; t < nseg; t += blockDim.x) { s_seen[t] = 0u; s_fresh[t] = 0u; }
-    __syncthreads();
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const unsigned long long k = keys[i];
-        unsigned long long h = k * 0x9E3779B97F4A7C15ull;
-        h ^= h >> 29;
-        if ((h >> 61) != 0ull) continue;                       // 1 block class in 8
-        const int seg = (int)(k >> sh_seg);
-        const unsigned bit = (unsigned)h & mask_bits;
-        const unsigned old = atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
-        atomicAdd(&s_seen[seg], 1u);
-        if (!((old >> (bit & 31)) & 1u)) atomicAdd(&s_fresh[seg], 1u);
+// snippets into block order (slot bit moved into bit kSlotBit of c0) + "a new block starts here" flags
+template <typename KeyT>
+__global__ __launch_bounds__(256) void permute_snippets_kernel(const int* __restrict__ r0, const int* __restrict__ c0,
+                                                               const unsigned* __restrict__ order,
+                                                               const KeyT* __restrict__ sorted_keys, long long n,
+                                                               int* __restrict__ r0s, int* __restrict__ c0s,
+                                                               unsigned char* __restrict__ head) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned v = order[i], j = v & 0x7fffffffu;
+    r0s[i] = r0[j];
+    c0s[i] = c0[j] | (int)((v >> 31) << kSlotBit);
+    head[i] = (i == 0 || sorted_keys[i] != sorted_keys[i - 1]) ? 1 : 0;
+}
+
+// first block of every segment: seg_blk0[s] = number of block starts before the segment's first window (the segments'
+// window ranges in sorted order are known on the host: seg_win0[0..nseg]); one thread per segment boundary
+__global__ __launch_bounds__(256) void segment_blocks_kernel(const unsigned* __restrict__ starts, const unsigned* __restrict__ n_runs,
+                                                             const long long* __restrict__ seg_win0, int nseg,
+                                                             unsigned* __restrict__ seg_blk0) {
+    const unsigned nr = n_runs[0];
+    for (int s = threadIdx.x; s <= nseg; s += blockDim.x) {
+        const long long w0 = seg_win0[s];
+        unsigned lo = 0, hi = nr;
+        while (lo < hi) { const unsigned m = (lo + hi) >> 1; if ((long long)starts[m] < w0) lo = m + 1; else hi = m; }
+        seg_blk0[s] = lo;
     }
-    __syncthreads();
-    for (int t = threadIdx.x; t < nseg; t += blockDim.x) {
-        if (s_seen[t]) atomicAdd(&seen[t], (unsigned long long)s_seen[t]);
-        if (s_fresh[t]) atomicAdd(&fresh[t], (unsigned long long)s_fresh[t]);
+}
+
+// block table from the compacted block starts: entry b = {region origin R, C, first window, windows}, and the expected
+// region of the block's windows (decoded from the key)
+template <typename KeyT>
+__global__ __launch_bounds__(256) void block_table_kernel(const unsigned* __restrict__ starts, const unsigned* __restrict__ n_runs,
+                                                          long long n, const KeyT* __restrict__ sorted_keys,
+                                                          const int* __restrict__ r0s, const int* __restrict__ c0s,
+                                                          const IdxChrom* __restrict__ chroms, int n_chrom, int BR, int BC,
+                                                          int sh_er, int sh_seg, int n_eregs,
+                                                          BlockEntry* __restrict__ blocks) {
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nr = (long long)n_runs[0];
+    if (b >= nr) return;
+    const unsigned s = starts[b];
+    const long long e = (b + 1 < nr) ? (long long)starts[b + 1] : n;
+    const int r = r0s[s], c = c0s[s] & ((1 << kSlotBit) - 1);
+    int ca = 0, cb = n_chrom;
+    while (ca < cb) { const int m = (ca + cb) >> 1; if (chroms[m].end <= r) ca = m + 1; else cb = m; }
+    if (ca >= n_chrom) ca = n_chrom - 1;
+    const int cs = chroms[ca].start;
+    BlockEntry be;
+    be.R = cs + ((r - cs) / BR) * BR;                  // block grid anchored at the chromosome start
+    be.C = cs + ((c - cs) / BC) * BC;
+    be.start = (int)s; be.count = (int)(e - (long long)s);
+    {   // slot-0 windows come first inside a block (stable sort): find the first window with the slot bit set
+        long long lo = (long long)s, hi = e;
+        while (lo < hi) { const long long m = (lo + hi) >> 1; if (((c0s[m] >> kSlotBit) & 1) == 0) lo = m + 1; else hi = m; }
+        be.count0 = (int)(lo - (long long)s);
     }
+    be.ereg = -1; be.pad0 = 0; be.pad1 = 0;
+    if (n_eregs > 0) {
+        const unsigned long long key = (unsigned long long)sorted_keys[s];
+        const int er = (int)((key >> sh_er) & ((1ull << (sh_seg - sh_er)) - 1ull));
+        be.ereg = er < n_eregs ? er : -1;
+    }
+    blocks[b] = be;
 }
 
 // ---- K1s: sparse kernel for inter-chromosomal (trans) windows, W <= 63 ---------------------------------------
