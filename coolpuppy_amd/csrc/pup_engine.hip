@@ -173,39 +173,49 @@ bool tiled_supported(int W) { return W >= 3 && W <= 31 && (W & 1); }
 // workgroup-staged kernel (K1q): a workgroup of NW waves shares one 64 x 64 region = a (65-W)^2 block of corners;
 // ACC = 2 when two tiles share the pass
 constexpr int kWgRegion = 64;
-template <int W, int NW, int ACC>
-void launch_k1q_(const pup::K1Args& a, int nchunks, hipStream_t s) {
+// fact: every window is clear of the diagonal mask and nothing is divided by expected -> validity factorises (FACT)
+// extra: coverage vectors and / or pixel statistics ride along (kept out of the plain instantiation's window loop)
+template <int W, int NW, int ACC, bool EXTRA>
+void launch_k1q__(const pup::K1Args& a, int nchunks, bool fact, hipStream_t s) {
+    const size_t dyn = 0;
     if (a.mode & PUP_MODE_OOE)
-        hipLaunchKernelGGL((pup::pileup_wgtile_kernel<W, true, NW, ACC>), dim3(nchunks), dim3(pup::kWave * NW), 0, s, a);
+        hipLaunchKernelGGL((pup::pileup_wgtile_kernel<W, true, NW, ACC, false, EXTRA>), dim3(nchunks), dim3(pup::kWave * NW), dyn, s, a);
+    else if (fact)
+        hipLaunchKernelGGL((pup::pileup_wgtile_kernel<W, false, NW, ACC, true, EXTRA>), dim3(nchunks), dim3(pup::kWave * NW), dyn, s, a);
     else
-        hipLaunchKernelGGL((pup::pileup_wgtile_kernel<W, false, NW, ACC>), dim3(nchunks), dim3(pup::kWave * NW), 0, s, a);
+        hipLaunchKernelGGL((pup::pileup_wgtile_kernel<W, false, NW, ACC, false, EXTRA>), dim3(nchunks), dim3(pup::kWave * NW), dyn, s, a);
+}
+template <int W, int NW, int ACC>
+void launch_k1q_(const pup::K1Args& a, int nchunks, bool fact, hipStream_t s) {
+    const bool extra = ((a.mode & PUP_MODE_COV) && a.cov != nullptr) || a.counters != nullptr;
+    if (extra) launch_k1q__<W, NW, ACC, true>(a, nchunks, fact, s); else launch_k1q__<W, NW, ACC, false>(a, nchunks, fact, s);
 }
 template <int W>
-void launch_k1q(const pup::K1Args& a, int nchunks, int nw, int acc, hipStream_t s) {
+void launch_k1q(const pup::K1Args& a, int nchunks, int nw, int acc, bool fact, hipStream_t s) {
     if (W == 21 && nw == 8) {             // tuning probe (variant bit 7): 8-wave workgroups, built for the headline width only
-        if (acc == 2) launch_k1q_<21, 8, 2>(a, nchunks, s); else launch_k1q_<21, 8, 1>(a, nchunks, s);
+        if (acc == 2) launch_k1q_<21, 8, 2>(a, nchunks, fact, s); else launch_k1q_<21, 8, 1>(a, nchunks, fact, s);
         return;
     }
-    if (acc == 2) launch_k1q_<W, 4, 2>(a, nchunks, s); else launch_k1q_<W, 4, 1>(a, nchunks, s);
+    if (acc == 2) launch_k1q_<W, 4, 2>(a, nchunks, fact, s); else launch_k1q_<W, 4, 1>(a, nchunks, fact, s);
 }
 
-bool launch_wgtiled(int W, const pup::K1Args& a, int nchunks, int nw, int acc, hipStream_t s) {
+bool launch_wgtiled(int W, const pup::K1Args& a, int nchunks, int nw, int acc, bool fact, hipStream_t s) {
     switch (W) {
-        case 3:  launch_k1q<3>(a, nchunks, nw, acc, s);  return true;
-        case 5:  launch_k1q<5>(a, nchunks, nw, acc, s);  return true;
-        case 7:  launch_k1q<7>(a, nchunks, nw, acc, s);  return true;
-        case 9:  launch_k1q<9>(a, nchunks, nw, acc, s);  return true;
-        case 11: launch_k1q<11>(a, nchunks, nw, acc, s); return true;
-        case 13: launch_k1q<13>(a, nchunks, nw, acc, s); return true;
-        case 15: launch_k1q<15>(a, nchunks, nw, acc, s); return true;
-        case 17: launch_k1q<17>(a, nchunks, nw, acc, s); return true;
-        case 19: launch_k1q<19>(a, nchunks, nw, acc, s); return true;
-        case 21: launch_k1q<21>(a, nchunks, nw, acc, s); return true;
-        case 23: launch_k1q<23>(a, nchunks, nw, acc, s); return true;
-        case 25: launch_k1q<25>(a, nchunks, nw, acc, s); return true;
-        case 27: launch_k1q<27>(a, nchunks, nw, acc, s); return true;
-        case 29: launch_k1q<29>(a, nchunks, nw, acc, s); return true;
-        case 31: launch_k1q<31>(a, nchunks, nw, acc, s); return true;
+        case 3:  launch_k1q<3>(a, nchunks, nw, acc, fact, s);  return true;
+        case 5:  launch_k1q<5>(a, nchunks, nw, acc, fact, s);  return true;
+        case 7:  launch_k1q<7>(a, nchunks, nw, acc, fact, s);  return true;
+        case 9:  launch_k1q<9>(a, nchunks, nw, acc, fact, s);  return true;
+        case 11: launch_k1q<11>(a, nchunks, nw, acc, fact, s); return true;
+        case 13: launch_k1q<13>(a, nchunks, nw, acc, fact, s); return true;
+        case 15: launch_k1q<15>(a, nchunks, nw, acc, fact, s); return true;
+        case 17: launch_k1q<17>(a, nchunks, nw, acc, fact, s); return true;
+        case 19: launch_k1q<19>(a, nchunks, nw, acc, fact, s); return true;
+        case 21: launch_k1q<21>(a, nchunks, nw, acc, fact, s); return true;
+        case 23: launch_k1q<23>(a, nchunks, nw, acc, fact, s); return true;
+        case 25: launch_k1q<25>(a, nchunks, nw, acc, fact, s); return true;
+        case 27: launch_k1q<27>(a, nchunks, nw, acc, fact, s); return true;
+        case 29: launch_k1q<29>(a, nchunks, nw, acc, fact, s); return true;
+        case 31: launch_k1q<31>(a, nchunks, nw, acc, fact, s); return true;
         default: return false;
     }
 }
@@ -590,6 +600,7 @@ int pup_reset(pup_ctx* c, int32_t n_tiles, int32_t pad) {
 struct BlockOrder {
     bool tiled = false;                 // any segment goes to K1q
     bool paired = false;                // two accumulator sets per chunk
+    bool fact = false;                  // no window is reached by the diagonal mask, nothing divided by expected: FACT kernel
     int  nseg = 0;
     std::vector<char> seg_tiled;        // [nseg]
     std::vector<long long> seg_win0;    // [nseg+1] windows of segment s in launch order: [seg_win0[s], seg_win0[s+1])
@@ -649,7 +660,8 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
         const int sh_br = bits_bc, sh_er = sh_br + bits_br, sh_seg = sh_er + bits_er;
         const int end_bit = sh_seg + nbits((unsigned long long)(nseg > 1 ? nseg - 1 : 1));
         if (end_bit > 64) { stop_timer(); return PUP_OK; }
-        const size_t ncnt = 2 + (size_t)nseg + 1;         // [0] ineligible windows, [1] blocks, [2 ..] first block of every segment + total
+        // [0] ineligible windows, [1] blocks, [2 .. 2+nseg] first block of every segment + total, [last] windows a diagonal mask reaches
+        const size_t ncnt = 2 + (size_t)nseg + 1 + 1;
         HIPCHK(c, c->d_keys.reserve((size_t)n)); HIPCHK(c, c->d_vals.reserve((size_t)n)); HIPCHK(c, c->d_vals2.reserve((size_t)n));
         HIPCHK(c, c->d_segend.reserve(seg_end2t.size() + (size_t)nseg + 1)); HIPCHK(c, c->d_cnt32.reserve(ncnt));
         HIPCHK(c, c->d_sr0.reserve((size_t)n)); HIPCHK(c, c->d_sc0.reserve((size_t)n));
@@ -659,12 +671,13 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
         htab.insert(htab.end(), seg_win0.begin(), seg_win0.end());
         HIPCHK(c, hipMemcpyAsync(c->d_segend.p, htab.data(), htab.size() * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_cnt32.p, 0, 2 * sizeof(unsigned), c->stream));
-        HIPCHK(c, hipMemsetAsync(c->d_cnt32.p + 2, 0xff, ((size_t)nseg + 1) * sizeof(unsigned), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_cnt32.p + ncnt - 1, 0, sizeof(unsigned), c->stream));
         const unsigned gk = (unsigned)((n + 255) / 256);
         hipLaunchKernelGGL(pup::block_key_kernel, dim3(gk), dim3(256), 0, c->stream, dr0, dc0, (long long)n,
                            (const long long*)c->d_segend.p, (int)seg_end2t.size(), H, (const pup::IdxChrom*)c->idx_chrom.p,
                            c->n_chrom, (const pup::ExpRegion*)(n_eregs > 0 ? c->exp_regions.p : nullptr), n_eregs,
-                           W, BR, BC, sh_br, sh_er, sh_seg, c->d_keys.p, c->d_vals.p, c->d_cnt32.p);
+                           W, BR, BC, sh_br, sh_er, sh_seg, ignore_diags + W - 1, c->d_keys.p, c->d_vals.p, c->d_cnt32.p,
+                           c->d_cnt32.p + ncnt - 1);
         hipError_t se = hipSuccess;
         size_t tmp_bytes = 0;
         const bool k32 = end_bit <= 32;
@@ -746,6 +759,7 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
                                BR, BC, sh_er, sh_seg, n_eregs, c->d_blocks.p);
         HIPCHK(c, hipGetLastError());
         out.tiled = true; out.paired = paired; out.nseg = nseg;
+        out.fact = !(mode & PUP_MODE_OOE) && cnt[ncnt - 1] == 0 && !(c->variant & 4);
         out.seg_tiled = seg_tiled; out.seg_win0 = seg_win0; out.seg_blk0 = seg_blk0;
         out.r0 = c->d_sr0.p; out.c0 = c->d_sc0.p;
         c->last_stagings = stagings;
@@ -848,7 +862,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     gkey.push_back(n); gkey.push_back(T); gkey.push_back(c->W); gkey.push_back(c->chunk_snippets);
     gkey.push_back(c->group_waves); gkey.push_back(c->variant & (2 | 64 | 128)); gkey.push_back((mode & PUP_MODE_EXPECTED) ? 1 : 0);
     gkey.push_back(flip_from ? 1 : 0); gkey.push_back(rescale ? 1 : 0); gkey.push_back((ignore_diags < 0 ? 1 : 0) | (c->variant & 32) | ((c->nexp == 1 || c->have_exp_pair) ? 2 : 0) | ((mode & PUP_MODE_OOE) ? 4 : 0));
-    gkey.push_back(tiled ? (paired ? 2 : 1) : 0);
+    gkey.push_back(tiled ? (paired ? 2 : 1) + (order.fact ? 4 : 0) : 0);
     if (tiled) { for (char f : order.seg_tiled) gkey.push_back(f); for (int b : order.seg_blk0) gkey.push_back(b); }
     for (int t = 0; t <= T; ++t) gkey.push_back(tile_ptr[t]);
     if (flip_from) for (int t = 0; t < T; ++t) gkey.push_back(flip_from[t]);
@@ -1109,7 +1123,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
             launch_regtile(W, a, (int)nblocks, c->stream2);
             HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
         }
-        if (!launch_wgtiled(W, at, (int)c->g_nblocks_t, nw_q, paired ? 2 : 1, c->stream))
+        if (!launch_wgtiled(W, at, (int)c->g_nblocks_t, nw_q, paired ? 2 : 1, order.fact, c->stream))
             return fail(c, PUP_ENOTSUP, "pup_accumulate: staged kernel not built for W=%d", W);
         if (side) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         if (side || nblocks == 0) launched = true;

@@ -657,9 +657,13 @@ __global__ __launch_bounds__(kWave, rt_min_waves(W)) void pileup_regtile_kernel(
 // LDS reads the compiler must not merge: two ds_read_b64 at one base become ds_read2_b64, which the LDS serves at half
 // the bytes per clock (128 vs 256 B/clk/CU on gfx950).  Issued through inline asm (the compiler does not track them):
 // lds_wait_all() + lds_pin() must stand between a read and the first use of its value.
+// The destination is EARLY-CLOBBER: it must not share a register with the address.  A burst of reads off one address
+// register whose last read returned into that register (`ds_read_b64 v[128:129], v128 offset:0x90`) gave wrong data
+// as soon as several workgroups shared a CU (found by tests/test_properties_gpu.py::test_staged_kernel_many_workgroups);
+// lds_wait_all(addresses) additionally keeps the address registers untouched until the data has arrived.
 template <int OFF>
 __device__ __forceinline__ void lds_read_b64(double& dst, unsigned addr) {
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(OFF));
 }
 template <int I, int N, int STRIDE_BYTES>
 struct LdsReadRow {
@@ -671,6 +675,12 @@ struct LdsReadRow {
 template <int N, int STRIDE_BYTES>
 struct LdsReadRow<N, N, STRIDE_BYTES> { static __device__ __forceinline__ void go(double*, unsigned) {} };
 __device__ __forceinline__ void lds_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// the same, and the address registers of the reads stay untouched until here (the compiler does not know the asm reads
+// are still in flight and would otherwise recycle their address VGPRs right behind them)
+__device__ __forceinline__ void lds_wait_all(unsigned a0, unsigned a1, unsigned a2, unsigned a3) {
+    asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "memory");
+}
+__device__ __forceinline__ void lds_pin1(double& v) { asm volatile("" : "+v"(v)); }
 template <int N>
 __device__ __forceinline__ void lds_pin(double (&v)[N]) {     // later uses of v[] are ordered after the preceding asm
 #pragma unroll
@@ -711,9 +721,10 @@ constexpr int kMaxSegCount = 1024;                    // segments (tile x flip r
 // count0 of which go to accumulator slot 0 (the sort is stable: a pair's first tile comes first); expected region
 struct __attribute__((aligned(32))) BlockEntry { int R, C, start, count, count0, ereg, pad0, pad1; };
 
-template <int W, bool OOE, int NW, int ACC>
+template <int W, bool OOE, int NW, int ACC, bool FACT, bool EXTRA>
 __global__ __launch_bounds__(kWave * NW) void pileup_wgtile_kernel(K1Args a) {
-    static_assert(W >= 3 && W <= 32, "workgroup-staged kernel serves windows of 3..32 bins");
+    static_assert(W >= 3 && W <= 31, "workgroup-staged kernel serves windows of 3..31 bins");
+    static_assert(!(FACT && OOE), "factorised counting needs validity to factorise into row and column masks");
     static_assert(NW == 4 || NW == 8 || NW == 16, "the region's 64 rows are dealt out evenly to the waves");
     static_assert(ACC == 1 || ACC == 2, "one or two accumulator sets");
     constexpr int NCH = kWave / W;
@@ -729,6 +740,9 @@ __global__ __launch_bounds__(kWave * NW) void pileup_wgtile_kernel(K1Args a) {
     __shared__ unsigned long long vbits[RS];             // bit c: cell (row, c) counts in num
     __shared__ unsigned long long pbits[RS];             // bit c: cell holds a pixel (statistics only)
     __shared__ double cov_lds[NW][ACC][2 * W];
+    // FACT: num[p][q] = N - R[p] - C[q] + RC[p][q] (see fact_batch): the sparse both-masked pairs, and the totals
+    __shared__ unsigned rc_lds[ACC][FACT ? W2 : 1];
+    __shared__ unsigned fact_tot[FACT ? ACC * (2 * W + 1) : 1];     // per slot: R[W] | C[W] | N
     const int tid  = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -740,10 +754,10 @@ __global__ __launch_bounds__(kWave * NW) void pileup_wgtile_kernel(K1Args a) {
 #pragma unroll
     for (int i = 0; i < CH; ++i) if (row_ok && k + NCH * i < W) chmask |= 1u << i;
 
-    const bool m_cov   = (a.mode & 0x04u) && a.cov != nullptr;
+    const bool m_cov   = EXTRA && (a.mode & 0x04u) && a.cov != nullptr;
     const bool use_exp = OOE && ((a.expv != nullptr && a.nexp > 0) || a.n_exp_regions > 0);
     const int  igd     = a.ignore_diags;
-    const bool stats   = a.counters != nullptr;
+    const bool stats   = EXTRA && a.counters != nullptr;
     const double qnan = __builtin_nan("");
 
     const int ck = a.block_chunk[blockIdx.x];
@@ -755,6 +769,10 @@ __global__ __launch_bounds__(kWave * NW) void pileup_wgtile_kernel(K1Args a) {
 #pragma unroll
         for (int i = 0; i < CH; ++i) { sum[s][i] = 0.0; num[s][i] = 0u; }
     if (m_cov) for (int t = lane; t < ACC * 2 * W; t += kWave) (&cov_lds[wave][0][0])[t] = 0.0;
+    if constexpr (FACT) {                                // visible after the prologue's barrier
+        for (int t = tid; t < ACC * W2; t += NTHR) (&rc_lds[0][0])[t] = 0u;
+        for (int t = tid; t < ACC * (2 * W + 1); t += NTHR) fact_tot[t] = 0u;
+    }
 
     const int bb = (int)a.chunk_begin[ck], be = (int)a.chunk_end[ck];     // blocks [bb, be) of the block table
     const int fl = a.chunk_flip[ck];
@@ -763,7 +781,8 @@ __global__ __launch_bounds__(kWave * NW) void pileup_wgtile_kernel(K1Args a) {
     int ch_start = 0, ch_end = -1, ch_nblk = 0; long long ch_base = 0;
 
     // ---- staging, in pieces (see the pipeline in the block loop) ----------------------------------------------------
-    struct Geo { int R, C, start, count, count0, ereg, ch_end, ws, sh, nblk; unsigned long long colok; const IdxBlock* line0; };
+    struct Geo { int R, C, start, count, count0, ereg, ch_end, ws, sh, nblk; unsigned long long colok, rowbad, colbad;
+                 const IdxBlock* line0; };
     struct Raw { U64x2 h, w; unsigned long long rw; };                     // lane i < RPW: index words of the wave's i-th row
     struct Row { unsigned long long bits, keep, okn; long long pos; };     // lane i < RPW: what they amount to
     auto geo_of = [&](int b) -> Geo {
@@ -788,6 +807,13 @@ __global__ __launch_bounds__(kWave * NW) void pileup_wgtile_kernel(K1Args a) {
         g.colok = ~colbad;
         const int over = g.C + RS - ch_end;              // columns at / past the chromosome's end are in no eligible window
         if (over > 0) g.colok &= over >= 64 ? 0ull : (~0ull >> over);
+        g.colbad = colbad; g.rowbad = 0ull;
+        if (FACT) {                                      // masked bins among the region's rows
+            const unsigned long long* rwp = a.badbits + (g.R >> 6);
+            const int rsh = g.R & 63;
+            g.rowbad = rwp[0] >> rsh;
+            if (rsh) g.rowbad |= rwp[1] << (64 - rsh);
+        }
         return g;
     };
     const int my_rr = wave * RPW + (lane < RPW ? lane : 0);               // region row this lane looks up in phase A
@@ -798,7 +824,7 @@ __global__ __launch_bounds__(kWave * NW) void pileup_wgtile_kernel(K1Args a) {
             const char* line = reinterpret_cast<const char*>(g.line0 + (long long)my_rr * g.nblk);
             x.h = *reinterpret_cast<const U64x2*>(line);                       // {pos, cum[4]}
             x.w = *reinterpret_cast<const U64x2*>(line + 16 + 8 * g.ws);       // {bits[ws], bits[ws+1] | next0}
-            x.rw = a.badbits[row >> 6];
+            if (!FACT) x.rw = a.badbits[row >> 6];
         }
     };
     auto finish_rows = [&](const Geo& g, const Raw& x) __attribute__((always_inline)) -> Row {
@@ -815,7 +841,9 @@ __global__ __launch_bounds__(kWave * NW) void pileup_wgtile_kernel(K1Args a) {
             ok &= t0 <= 0 ? ~0ull : (t0 >= 64 ? 0ull : ~((1ull << t0) - 1ull));
         }
         if (!live) { r.bits = 0ull; ok = 0ull; r.pos = 0; }
-        r.okn = ok; r.keep = r.bits & ok;
+        // FACT: every window of the call is clear of the diagonal mask and `bal` is 0 on masked bins: a cell holds its
+        // pixel's value or 0, no mask needed; validity is counted from the row / column masks instead
+        r.okn = ok; r.keep = FACT ? r.bits : (r.bits & ok);
         return r;
     };
     auto bcast64 = [&](unsigned long long v, int i) __attribute__((always_inline)) -> unsigned long long {
@@ -868,72 +896,114 @@ __global__ __launch_bounds__(kWave * NW) void pileup_wgtile_kernel(K1Args a) {
             }
             tile[rr * LS + lane] = good ? val : 0.0;
         }
-        if (lane < RPW) { vbits[wave * RPW + lane] = r.okn; if (stats) pbits[wave * RPW + lane] = r.bits; }
+        if (lane < RPW) { if (!FACT) vbits[wave * RPW + lane] = r.okn; if (stats) pbits[wave * RPW + lane] = r.bits; }
     };
 
-    // ---- one window out of the staged region ---------------------------------------------------------------------
-    const int lane_off = p * LS + k;
-    const unsigned tile_lds = (unsigned)(uintptr_t)tile;       // LDS byte address of the region buffer
-    auto gather = [&](int dr, int dc, double (&v)[CH], unsigned& vw, unsigned& pw) __attribute__((always_inline)) {
-        // single ds_read_b64 each (see lds_read_b64); cells the lane does not own read padding, never flushed
-        LdsReadRow<0, CH, 8 * NCH>::go(v, tile_lds + 8u * (unsigned)(dr * LS + dc + lane_off));
-        vw = (unsigned)(vbits[dr + p] >> (dc + k));
-        pw = stats ? (unsigned)(pbits[dr + p] >> (dc + k)) : 0u;
-    };
-    auto add_to = [&](double (&sm)[CH], unsigned (&nm)[CH], int slot, int r0, int c0, const double (&v)[CH], unsigned vw, unsigned pw)
-            __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < CH; ++i) { sm[i] += v[i]; nm[i] += (vw >> (NCH * i)) & 1u; }
-        if (m_cov && row_ok && k == 0) {
-            const double vs = a.cov[r0 + p], ve = a.cov[c0 + p];
-            if (vs == vs) cov_lds[wave][slot][p] += vs;
-            if (ve == ve) cov_lds[wave][slot][W + p] += ve;
-        }
-        if (stats) {
-            unsigned m = 0u;
-#pragma unroll
-            for (int i = 0; i < CH; ++i) if ((chmask >> i) & 1u) m += (pw >> (NCH * i)) & 1u;
-            npix += m;
-        }
-    };
+    // ---- the windows of the staged block ---------------------------------------------------------------------------
+    // Per batch of 64 windows (one per lane, every wave holds the same batch) the LDS byte offset of each window's
+    // corner is worked out once, in vector form; per window a wave then needs one readlane, one address add, CH LDS
+    // reads and CH f64 adds (+ the validity bits, or nothing at all when validity factorises).
+    const unsigned lane_off8 = (unsigned)(uintptr_t)tile + 8u * (unsigned)(p * LS + k);   // LDS byte address of the lane's first cell
+    const unsigned vb_lane8 = (unsigned)(uintptr_t)vbits + 8u * (unsigned)p;               // ... of the validity word of its row
     constexpr int kCoordMask = (1 << kSlotBit) - 1;
-    // windows [j0, j1) of the batch held in (r0v, c0v), all of accumulator slot S; window j goes to wave (j - j0) % NW
-    auto run = [&](auto slot_tag, const Geo& g, int r0v, int c0v, int j0, int j1) __attribute__((always_inline)) {
+    // windows [j0, j1) of the batch, all of accumulator slot S; window j goes to wave (j - j0) % NW
+    auto run = [&](auto slot_tag, const Geo& g, int offv, int drv, int dcv, int j0, int j1) __attribute__((always_inline)) {
         constexpr int S = decltype(slot_tag)::value;
+        // validity word of the window's row p: read like the cells (lds_read_b64), shifted to the lane's first column
+        // once the data is there (`bits_of`)
+        auto gather = [&](int jj, double (&v)[CH], double& vraw, unsigned& ad0, unsigned& ad1) __attribute__((always_inline)) {
+            // single ds_read_b64 each (see lds_read_b64); cells the lane does not own read padding, never flushed
+            ad0 = lane_off8 + (unsigned)__builtin_amdgcn_readlane(offv, jj);
+            LdsReadRow<0, CH, 8 * NCH>::go(v, ad0);
+            vraw = 0.0; ad1 = ad0;
+            if (!FACT) { ad1 = vb_lane8 + 8u * (unsigned)__builtin_amdgcn_readlane(drv, jj); lds_read_b64<0>(vraw, ad1); }
+        };
+        auto bits_of = [&](int jj, double vraw) __attribute__((always_inline)) -> unsigned {
+            if (FACT) return 0u;
+            return (unsigned)((unsigned long long)__double_as_longlong(vraw) >> (__builtin_amdgcn_readlane(dcv, jj) + k));
+        };
+        auto extra = [&](int jj) __attribute__((always_inline)) {          // coverage vectors, pixel statistics
+            const int dr = __builtin_amdgcn_readlane(drv, jj), dc = __builtin_amdgcn_readlane(dcv, jj);
+            if (m_cov && row_ok && k == 0) {
+                const double vs = a.cov[g.R + dr + p], ve = a.cov[g.C + dc + p];
+                if (vs == vs) cov_lds[wave][S][p] += vs;
+                if (ve == ve) cov_lds[wave][S][W + p] += ve;
+            }
+            if (stats) {
+                const unsigned pw = (unsigned)(pbits[dr + p] >> (dc + k));
+                unsigned m = 0u;
+#pragma unroll
+                for (int i = 0; i < CH; ++i) if ((chmask >> i) & 1u) m += (pw >> (NCH * i)) & 1u;
+                npix += m;
+            }
+        };
+        auto add = [&](const double (&v)[CH], unsigned vw) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) { sum[S][i] += v[i]; if (!FACT) num[S][i] += (vw >> (NCH * i)) & 1u; }
+        };
         int jj = j0 + wave;
         for (; jj + NW < j1; jj += 2 * NW) {              // two windows in flight: both gathered before either is added
-            const int ra = __builtin_amdgcn_readlane(r0v, jj), ca = __builtin_amdgcn_readlane(c0v, jj) & kCoordMask;
-            const int rb = __builtin_amdgcn_readlane(r0v, jj + NW), cb = __builtin_amdgcn_readlane(c0v, jj + NW) & kCoordMask;
-            double va[CH], vb[CH]; unsigned vwa, pwa, vwb, pwb;
-            gather(ra - g.R, ca - g.C, va, vwa, pwa);
-            gather(rb - g.R, cb - g.C, vb, vwb, pwb);
-            lds_wait_all(); lds_pin(va); lds_pin(vb);
-            add_to(sum[S], num[S], S, ra, ca, va, vwa, pwa);
-            add_to(sum[S], num[S], S, rb, cb, vb, vwb, pwb);
+            double va[CH], vb[CH], wa, wb; unsigned a0, a1, a2, a3;
+            gather(jj, va, wa, a0, a1);
+            gather(jj + NW, vb, wb, a2, a3);
+            lds_wait_all(a0, a1, a2, a3); lds_pin(va); lds_pin(vb); lds_pin1(wa); lds_pin1(wb);
+            add(va, bits_of(jj, wa));
+            add(vb, bits_of(jj + NW, wb));
+            if (EXTRA) { extra(jj); extra(jj + NW); }
         }
         if (jj < j1) {
-            const int ra = __builtin_amdgcn_readlane(r0v, jj), ca = __builtin_amdgcn_readlane(c0v, jj) & kCoordMask;
-            double va[CH]; unsigned vwa, pwa;
-            gather(ra - g.R, ca - g.C, va, vwa, pwa);
-            lds_wait_all(); lds_pin(va);
-            add_to(sum[S], num[S], S, ra, ca, va, vwa, pwa);
+            double va[CH], wa; unsigned a0, a1;
+            gather(jj, va, wa, a0, a1);
+            lds_wait_all(a0, a1, a0, a1); lds_pin(va); lds_pin1(wa);
+            add(va, bits_of(jj, wa));
+            if (EXTRA) extra(jj);
         }
+    };
+    // FACT bookkeeping of one batch, by ONE wave, a lane per window: validity of cell (p, q) of a window factorises (no
+    // diagonal mask reaches it): valid = !rowbad[p] & !colbad[q], so over the chunk num[p][q] = N - R[p] - C[q] + RC[p][q].
+    // fact_tot[slot] = {R[W], C[W], N}; rc_lds[slot] = RC (masked row meets masked column: rare).  Integer LDS atomics:
+    // exact and order-independent.
+    auto fact_batch = [&](const Geo& g, int drv, int dcv, int nb, int split) __attribute__((always_inline)) {
+      if constexpr (FACT) {
+        constexpr unsigned WMASK = (1u << W) - 1u;
+        const bool live = lane < nb;
+        const int slot = (ACC == 2 && lane >= split) ? 1 : 0;
+        unsigned rb = live ? (unsigned)(g.rowbad >> (drv & 63)) & WMASK : 0u;
+        const unsigned cbm = live ? (unsigned)(g.colbad >> (dcv & 63)) & WMASK : 0u;
+        const int tb = slot * (2 * W + 1);
+        const unsigned long long lv = __ballot(live && slot == 0);
+        if (lane == 0) {
+            atomicAdd(&fact_tot[2 * W], (unsigned)__popcll(lv));
+            if (ACC == 2) atomicAdd(&fact_tot[(2 * W + 1) + 2 * W], (unsigned)(nb - __popcll(lv)));
+        }
+        unsigned cc = cbm;
+        while (cc) { const int q = __ffs((int)cc) - 1; cc &= cc - 1u; atomicAdd(&fact_tot[tb + W + q], 1u); }
+        while (rb) {
+            const int pp = __ffs((int)rb) - 1; rb &= rb - 1u;
+            atomicAdd(&fact_tot[tb + pp], 1u);
+            unsigned c2 = cbm;
+            while (c2) { const int q = __ffs((int)c2) - 1; c2 &= c2 - 1u; atomicAdd(&rc_lds[slot][pp * W + q], 1u); }
+        }
+      }
     };
     // the windows [g.start, g.start + g.count) of the staged block; (r0f, c0f) = the first 64 of them, one per lane
     auto windows = [&](const Geo& g, int r0f, int c0f) __attribute__((always_inline)) {
-        for (int s0 = 0; s0 < g.count; s0 += kWave) {
-            const int r0v = r0f, c0v = c0f;
+        int batch = 0;
+        for (int s0 = 0; s0 < g.count; s0 += kWave, ++batch) {
+            const int drv = r0f - g.R, dcv = (c0f & kCoordMask) - g.C;        // per lane: its window's corner inside the region
+            const int offv = 8 * (drv * LS + dcv);
             if (s0 + kWave < g.count) {                   // next batch of this block
                 const int sn = s0 + kWave + lane;
                 r0f = sn < g.count ? a.r0[g.start + sn] : 0; c0f = sn < g.count ? a.c0[g.start + sn] : 0;
             }
             const int nb = (g.count - s0) < kWave ? (g.count - s0) : kWave;
+            int split = g.count0 - s0;                    // windows of the batch before `split` belong to slot 0
+            split = split < 0 ? 0 : (split > nb ? nb : split);
+            if (FACT && (batch % NW) == wave) fact_batch(g, drv, dcv, nb, split);
             if (ACC == 2) {
-                int split = g.count0 - s0;                // windows of the batch before `split` belong to slot 0
-                split = split < 0 ? 0 : (split > nb ? nb : split);
-                run(std::integral_constant<int, 0>{}, g, r0v, c0v, 0, split);
-                run(std::integral_constant<int, ACC - 1>{}, g, r0v, c0v, split, nb);
-            } else run(std::integral_constant<int, 0>{}, g, r0v, c0v, 0, nb);
+                run(std::integral_constant<int, 0>{}, g, offv, drv, dcv, 0, split);
+                run(std::integral_constant<int, ACC - 1>{}, g, offv, drv, dcv, split, nb);
+            } else run(std::integral_constant<int, 0>{}, g, offv, drv, dcv, 0, nb);
         }
     };
     auto first_coords = [&](const Geo& g, int& r0f, int& c0f) __attribute__((always_inline)) {
@@ -998,6 +1068,15 @@ __global__ __launch_bounds__(kWave * NW) void pileup_wgtile_kernel(K1Args a) {
         const size_t rec = (size_t)s * (size_t)a.rec_stride + (size_t)ck;
         double*   of = a.part_f64 + rec * L;
         unsigned* on = a.part_num + rec * W2;
+        if constexpr (FACT) {
+            // num of every cell from the factorised counts, in the accumulator frame
+            const unsigned* tot = fact_tot + s * (2 * W + 1);
+            for (int t = tid; t < W2; t += NTHR) {
+                const int pp = t / W, qq = t - pp * W;
+                mn[map_cell(pp, qq, W, false, fl)] = tot[2 * W] - tot[pp] - tot[W + qq] + rc_lds[s][t];
+            }
+            __syncthreads();
+        }
         for (int t = tid; t < W2; t += NTHR) { of[t] = mf[t]; on[t] = mn[t]; }
         for (int t = tid; t < 2 * W; t += NTHR) {
             double acc = 0.0;
@@ -1021,8 +1100,10 @@ __global__ __launch_bounds__(256) void block_key_kernel(const int* __restrict__ 
                                                         const IdxChrom* __restrict__ chroms, int n_chrom,
                                                         const ExpRegion* __restrict__ eregs, int n_eregs,
                                                         int W, int BR, int BC, int sh_br, int sh_er, int sh_seg,
+                                                        int clear_gap /* igd + W - 1 */,
                                                         unsigned long long* __restrict__ keys, unsigned* __restrict__ vals,
-                                                        unsigned* __restrict__ counters /* [0] ineligible */) {
+                                                        unsigned* __restrict__ counters /* [0] ineligible */,
+                                                        unsigned* __restrict__ n_unclear /* windows a diagonal mask reaches */) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int r = r0[i], c = c0[i];
@@ -1048,6 +1129,10 @@ __global__ __launch_bounds__(256) void block_key_kernel(const int* __restrict__ 
         er = (unsigned long long)(e < 0 ? n_eregs : e);
     }
     if (!ok) atomicAdd(&counters[0], 1u);
+    {   // one atomic per wave, not per window (a call of near-diagonal windows would serialise on the counter)
+        const unsigned long long near = __ballot(c - r < clear_gap);
+        if (near != 0ull && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)near) - 1)) atomicAdd(n_unclear, (unsigned)__popcll(near));
+    }
     keys[i] = ((unsigned long long)seg << sh_seg) | (er << sh_er) | (br << sh_br) | bc;
     vals[i] = (unsigned)i | (slot << 31);
 }

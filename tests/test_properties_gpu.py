@@ -200,3 +200,51 @@ def test_block_staged_kernel_equals_plain_kernel_for_every_width(hip_lib, pad):
             for k in ("sum", "cov_start", "cov_end"):
                 np.testing.assert_allclose(res[name][0][k], res["plain"][0][k], rtol=1e-11, atol=0, equal_nan=True)
     eng.close()
+
+
+@pytest.mark.parametrize("pad", [2, 10, 15])
+def test_staged_kernel_many_workgroups(hip_lib, pad):
+    """The workgroup-staged kernel with several workgroups sharing every CU (one block per workgroup, ~1500 of them):
+    the configuration in which a register-allocation dependent fault of its hand-issued LDS reads showed (see
+    lds_read_b64 in pup_kernels.hpp) while every single-workgroup-per-CU case passed.  Plain / OOE / coverage, paired
+    and single tiles, windows near and far from the diagonal (per-cell and factorised validity), against the plain
+    register-tile kernel; repeated, because the fault was timing dependent."""
+    from coolpuppy_amd import synth
+    from coolpuppy_amd.engine import MODE_COV, MODE_OOE, PileupEngine
+    clr = synth.make_cooler({"chrA": 60_000_000, "chrB": 15_000_000}, lam=40, seed=31)
+    W = 2 * pad + 1
+    rng = np.random.default_rng(500 + pad)
+    lo, hi = clr.extent("chrA")
+    n = 12_000
+    r0 = rng.integers(lo, hi - W - 400, n).astype(np.int32)
+    w = clr.bins()["weight"][:].values
+    cov = clr.bins()["cov_tot_raw"][:].values
+    e = synth.cis_expected(clr)
+    expv = e[e.region1 == "chrA"]["balanced.avg"].values.copy()
+    expv[5] = np.nan
+    eng = PileupEngine(0)
+    eng.load_pixels(*clr.pixel_table())
+    eng.build_index(clr.chrom_offset)
+    for label, off in (("near", rng.integers(-8, 380, n)), ("far", rng.integers(W + 2, 380, n))):
+        c0 = np.clip(r0 + off, lo, hi - W).astype(np.int32)
+        for T in (1, 2):
+            tile_ptr = np.array([0, n], np.int64) if T == 1 else np.array([0, n // 5, n], np.int64)
+            for weight, covv, mode, igd in ((w, None, 0, 2), (w, None, MODE_OOE, 2), (None, cov, MODE_COV, 1)):
+                eng.load_bins(weight, covv)
+                eng.set_expected(expv if mode & MODE_OOE else None)
+                eng.set_tuning(0, 16)
+                eng.reset(T, pad)
+                eng.accumulate(r0, c0, tile_ptr, ignore_diags=igd, mode=mode)
+                want = eng.fetch()
+                for variant in (8, 8 | 4, 8 | 64):          # default, per-cell validity forced, tiles not paired
+                    for rep in range(3):
+                        eng.set_tuning(1, variant)           # one block per workgroup
+                        eng.reset(T, pad)
+                        eng.accumulate(r0, c0, tile_ptr, ignore_diags=igd, mode=mode)
+                        got = eng.fetch()
+                        assert eng.stats()["staged_regions"] > 700
+                        for k in ("n", "num"):
+                            np.testing.assert_array_equal(got[k], want[k], err_msg=f"{label} T={T} mode={mode} variant={variant}")
+                        for k in ("sum", "cov_start", "cov_end"):
+                            np.testing.assert_allclose(got[k], want[k], rtol=1e-11, atol=0, equal_nan=True)
+    eng.close()
