@@ -50,9 +50,9 @@ def parse(argv=None):
     ap.add_argument("--pad", type=int, default=10)
     ap.add_argument("--lam", type=float, default=4200.0, help="Poisson contacts drawn per row before de-duplication")
     ap.add_argument("--chroms", type=int, default=23, help="use the first K hg38 chromosomes (23 = all)")
-    ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="snippets timed on the C oracle (0 = no CPU baseline)")
+    ap.add_argument("--cpu-sample", type=int, default=12_000_000, help="snippets timed on the C oracle (0 = no CPU baseline)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baselines (0 = all cores, capped at 64)")
-    ap.add_argument("--ref-algo-sample", type=int, default=20_000,
+    ap.add_argument("--ref-algo-sample", type=int, default=300_000,
                     help="snippets timed on the algorithm-faithful scipy restatement, one core (0 = skip)")
     ap.add_argument("--no-cache", action="store_true")
     ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
@@ -441,6 +441,10 @@ def main():
         #     rank-bitmap index lines (64 B) under the windows' row hulls, the snippet coordinates (8 B each)
         tp = wl["touched"]
         compulsory = float(tp[0]) * 8 + float(tp[1]) * 64 + 8.0 * n_set
+        #     ... and the looser "one pass over the resident tables" (every pixel value + the whole index + coordinates)
+        nnz_all, nb_all = float(wl["bin2_id"].shape[0]), float(wl["bin1_offset"].shape[0] - 1)
+        idx_lines_all = float(sum((int(co[k + 1] - co[k]) * -(-int(co[k + 1] - co[k]) // 320)) for k in range(len(co) - 1)))
+        table_pass = nnz_all * 8 + idx_lines_all * 64 + 8.0 * n_set
         # (3) measured HBM bytes (rocprofv3 PMC passes over this command; quoted only for these kernel sources)
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -454,29 +458,31 @@ def main():
         peak = HBM_PEAK_GBPS * a.gpus
         frac_comp = compulsory / (k1_ms * 1e-3) / 1e9 / peak if a.scaling != "weak" or a.gpus == 1 else None
         frac_traffic = None if traffic is None else traffic / (k1_ms * 1e-3) / 1e9 / peak
+        frac_table = table_pass / (k1_ms * 1e-3) / 1e9 / peak if (a.scaling != "weak" or a.gpus == 1) else None
         peak_measured = None
         try:
             peak_measured = json.load(open(os.path.join(ROOT, "profiles", "hbm_peak.json")))
         except Exception:
             pass
         staged = staged_regions > 0
-        wgk = not (a.variant & 64)
         roofline = {
             "bound": "hbm",
-            "kernel": ((f"pup::pileup_wgtile_kernel<{W}, false, {4 if a.variant & 128 else 8}>" if wgk else
-                        f"pup::pileup_tiled_kernel<{W}, false, 16, 16>") + " (block-staged; + pup::pileup_regtile_kernel "
-                       "beside it for segments too sparse to stage)" if staged else f"pup::pileup_regtile_kernel<{W}, false>"),
+            "kernel": (f"pup::pileup_wgtile_kernel<{W}, false, {8 if a.variant & 128 else 4}, {1 if a.variant & 64 else 2}, "
+                       f"{'false' if a.variant & 4 else 'true'}, false> (workgroup-staged, ROI and control tile in one pass)"
+                       if staged else f"pup::pileup_regtile_kernel<{W}, false>"),
             "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
             # the physically bounded fraction: measured HBM bytes when known for this build, else the compulsory bytes
             "frac": round(frac_traffic if frac_traffic is not None else frac_comp, 4) if (frac_traffic or frac_comp) else None,
             "frac_is": "frac_traffic" if frac_traffic is not None else "frac_compulsory",
             "frac_compulsory": None if frac_comp is None else round(frac_comp, 4),
+            "frac_table_pass": None if frac_table is None else round(frac_table, 4),
             "frac_traffic": None if frac_traffic is None else round(frac_traffic, 4),
             "algorithmic_over_peak": round(achieved / peak, 4),
             "traffic": traffic, "traffic_source": traffic_src,
             "kernel_ms_per_launch": round(k1_ms, 4),
             "algorithmic_bytes_per_launch": round(alg_bytes / a.gpus),
             "compulsory_bytes_per_launch": round(compulsory),
+            "table_pass_bytes_per_launch": round(table_pass),
             "compulsory": {"pixels_under_row_hulls": int(tp[0]), "index_lines": int(tp[1]), "rows": int(tp[2]),
                            "coordinate_bytes": 8 * n_set},
             "nnz_win_mean": round(pix_per_step / max(n_all, 1), 1),
@@ -484,7 +490,8 @@ def main():
                      "kernel that serves many windows from one LDS-staged region can exceed the HBM peak on it "
                      "(algorithmic_over_peak is NOT a roofline fraction).  frac = measured HBM bytes (rocprofv3 PMC, "
                      "profiles/) / kernel time / peak when a measurement of these kernel sources is on file, else "
-                     "compulsory bytes / kernel time / peak"),
+                     "compulsory bytes / kernel time / peak.  compulsory = bytes of the resident tables under the windows' "
+                     "row hulls (what any kernel must read once); table_pass = every pixel value + the whole index once"),
             "peak_measured_GBps": (None if peak_measured is None else
                                    {k: peak_measured[k] for k in ("read_GBps", "copy_GBps", "triad_GBps")}),
             "staged_regions_per_launch": staged_regions,

@@ -751,12 +751,12 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
             hipLaunchKernelGGL((pup::block_table_kernel<unsigned>), dim3(gb), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
                                (const unsigned*)(c->d_cnt32.p + 1), (long long)n, (const unsigned*)c->d_k32b.p,
                                (const int*)c->d_sr0.p, (const int*)c->d_sc0.p, (const pup::IdxChrom*)c->idx_chrom.p, c->n_chrom,
-                               BR, BC, sh_er, sh_seg, n_eregs, c->d_blocks.p);
+                               BR, BC, sh_er, sh_seg, n_eregs, (const unsigned long long*)c->badbits.p, c->d_blocks.p);
         else
             hipLaunchKernelGGL((pup::block_table_kernel<unsigned long long>), dim3(gb), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
                                (const unsigned*)(c->d_cnt32.p + 1), (long long)n, (const unsigned long long*)c->d_keys2.p,
                                (const int*)c->d_sr0.p, (const int*)c->d_sc0.p, (const pup::IdxChrom*)c->idx_chrom.p, c->n_chrom,
-                               BR, BC, sh_er, sh_seg, n_eregs, c->d_blocks.p);
+                               BR, BC, sh_er, sh_seg, n_eregs, (const unsigned long long*)c->badbits.p, c->d_blocks.p);
         HIPCHK(c, hipGetLastError());
         out.tiled = true; out.paired = paired; out.nseg = nseg;
         out.fact = !(mode & PUP_MODE_OOE) && cnt[ncnt - 1] == 0 && !(c->variant & 4);

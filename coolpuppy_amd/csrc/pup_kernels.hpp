@@ -102,7 +102,7 @@ struct K1Args {
                                    //           so that workgroups b, b+8, b+16, ... (one XCD) share a group
     const int*       block_band;   // [gridDim.x] row band of the window the workgroup owns (banded kernel; else 0)
     // block table of the workgroup-staged kernel (K1q): its chunks are ranges of BLOCKS, chunk_begin / chunk_end index here
-    const void*      blocks;       // [nblocks] BlockEntry {R, C, first window, windows, windows of slot 0, expected region}
+    const void*      blocks;       // [nblocks] BlockEntry: region origin, its windows, staging geometry (one 64-byte line each)
     int              rec_stride;   // K1q with two accumulator sets: partial record of (chunk, slot) = slot * rec_stride + chunk
     // per-chunk partial outputs
     double*   part_f64;   // [nrecords][W2 + 2W]   (sum | cov_start | cov_end)
@@ -717,9 +717,19 @@ __device__ __forceinline__ void lds_pin(double (&v)[N]) {     // later uses of v
 // before choosing this kernel.  Same integers as K1r; sums differ by the order of the f64 additions only.
 constexpr int kSlotBit = 30;                          // bit of c0 (sorted copy) holding the window's accumulator slot
 constexpr int kMaxSegCount = 1024;                    // segments (tile x flip runs) one block-ordered call may have
-// block table entry: origin of the staged region; its windows [start, start + count) in the sorted copy, the first
-// count0 of which go to accumulator slot 0 (the sort is stable: a pair's first tile comes first); expected region
-struct __attribute__((aligned(32))) BlockEntry { int R, C, start, count, count0, ereg, pad0, pad1; };
+// block table entry (one 64-byte line, fetched by the kernel with ONE vector load, a dword per lane): origin of the staged
+// region; its windows [start, start + count) in the sorted copy, the first count0 of which go to accumulator slot 0
+// (the sort is stable: a pair's first tile comes first); expected region; and everything the staging needs to know
+// about the region, worked out once by block_table_kernel instead of by dependent scalar loads in the hot loop: end of
+// the chromosome, index lines per matrix row, index line of (region row 0, region column 0), word / bit of that column
+// inside the line, unmasked-column bits (masked bins and the chromosome's end), masked-row bits.
+struct __attribute__((aligned(64))) BlockEntry {
+    int R, C, start, count, count0, ereg, ch_end, nblk;
+    unsigned line0, ws_sh;
+    unsigned long long colok, rowbad;
+    int pad0, pad1;
+};
+static_assert(sizeof(BlockEntry) == 64, "block table entry must be one 64-byte line");
 
 template <int W, bool OOE, int NW, int ACC, bool FACT, bool EXTRA>
 __global__ __launch_bounds__(kWave * NW) void pileup_wgtile_kernel(K1Args a) {
@@ -778,42 +788,27 @@ __global__ __launch_bounds__(kWave * NW) void pileup_wgtile_kernel(K1Args a) {
     const int fl = a.chunk_flip[ck];
     const BlockEntry* __restrict__ blocks = reinterpret_cast<const BlockEntry*>(a.blocks);
     unsigned long long npix = 0;
-    int ch_start = 0, ch_end = -1, ch_nblk = 0; long long ch_base = 0;
 
     // ---- staging, in pieces (see the pipeline in the block loop) ----------------------------------------------------
     struct Geo { int R, C, start, count, count0, ereg, ch_end, ws, sh, nblk; unsigned long long colok, rowbad, colbad;
                  const IdxBlock* line0; };
     struct Raw { U64x2 h, w; unsigned long long rw; };                     // lane i < RPW: index words of the wave's i-th row
     struct Row { unsigned long long bits, keep, okn; long long pos; };     // lane i < RPW: what they amount to
-    auto geo_of = [&](int b) -> Geo {
-        const BlockEntry e = blocks[b];
-        Geo g; g.R = e.R; g.C = e.C; g.start = e.start; g.count = e.count; g.count0 = e.count0; g.ereg = e.ereg;
-        if (!(g.R >= ch_start && g.R < ch_end)) {        // blocks arrive sorted: rare
-            int lo = 0, hi_k = a.n_chrom;
-            while (lo < hi_k) { const int m = (lo + hi_k) >> 1; if (a.idx_chrom[m].end <= g.R) lo = m + 1; else hi_k = m; }
-            if (lo >= a.n_chrom) lo = a.n_chrom - 1;     // cannot happen: the engine verified every window
-            const IdxChrom cinfo = a.idx_chrom[lo];
-            ch_start = cinfo.start; ch_end = cinfo.end; ch_nblk = cinfo.nblk; ch_base = cinfo.blk_base;
-        }
-        g.ch_end = ch_end; g.nblk = ch_nblk;
-        const int rel = g.C - ch_start;                  // R, C >= ch_start: the block grid is anchored there
-        const int bi = rel / kIdxCols, o = rel - bi * kIdxCols;
-        g.ws = o >> 6; g.sh = o & 63;
-        g.line0 = a.idx + ch_base + (long long)(g.R - ch_start) * ch_nblk + bi;
-        const unsigned long long* cw = a.badbits + (g.C >> 6);
-        const int csh = g.C & 63;
-        unsigned long long colbad = cw[0] >> csh;
-        if (csh) colbad |= cw[1] << (64 - csh);
-        g.colok = ~colbad;
-        const int over = g.C + RS - ch_end;              // columns at / past the chromosome's end are in no eligible window
-        if (over > 0) g.colok &= over >= 64 ? 0ull : (~0ull >> over);
-        g.colbad = colbad; g.rowbad = 0ull;
-        if (FACT) {                                      // masked bins among the region's rows
-            const unsigned long long* rwp = a.badbits + (g.R >> 6);
-            const int rsh = g.R & 63;
-            g.rowbad = rwp[0] >> rsh;
-            if (rsh) g.rowbad |= rwp[1] << (64 - rsh);
-        }
+    // entry of block b: dword (lane & 15) of its 64-byte line — a vector load, so that it can stay in flight across the
+    // window loop (whose LDS waits would otherwise drain a scalar load with them)
+    auto entry_load = [&](int b) __attribute__((always_inline)) -> int {
+        return reinterpret_cast<const int*>(blocks + b)[lane & 15];
+    };
+    auto geo_from = [&](int ev) __attribute__((always_inline)) -> Geo {
+        auto f = [&](int i) __attribute__((always_inline)) { return __builtin_amdgcn_readlane(ev, i); };
+        Geo g;
+        g.R = f(0); g.C = f(1); g.start = f(2); g.count = f(3); g.count0 = f(4); g.ereg = f(5); g.ch_end = f(6); g.nblk = f(7);
+        const unsigned wsh = (unsigned)f(9);
+        g.ws = (int)(wsh & 0xffu); g.sh = (int)(wsh >> 8);
+        g.line0 = a.idx + (unsigned)f(8);
+        g.colok = ((unsigned long long)(unsigned)f(11) << 32) | (unsigned)f(10);
+        g.rowbad = ((unsigned long long)(unsigned)f(13) << 32) | (unsigned)f(12);
+        g.colbad = ~g.colok;                             // (also set past the chromosome's end: no eligible window reaches there)
         return g;
     };
     const int my_rr = wave * RPW + (lane < RPW ? lane : 0);               // region row this lane looks up in phase A
@@ -1010,9 +1005,10 @@ __global__ __launch_bounds__(kWave * NW) void pileup_wgtile_kernel(K1Args a) {
         r0f = lane < g.count ? a.r0[g.start + lane] : 0; c0f = lane < g.count ? a.c0[g.start + lane] : 0;
     };
 
-    // ---- the block loop: region b is piled up while b+1's values and b+2's index lines are on their way -----------
+    // ---- the block loop: region b is piled up while b+1's values, b+2's index lines and b+3's table entry are on their way
     if (bb < be) {
-        Geo g0 = geo_of(bb), g1 = g0, g2 = g0;
+        int ev = entry_load(bb);                         // entries are consumed one stage after their load was issued
+        Geo g0 = geo_from(ev), g1 = g0, g2 = g0;
         Raw x1, x2;
         Row rw0, rw1;
         double v[RPW];
@@ -1021,7 +1017,8 @@ __global__ __launch_bounds__(kWave * NW) void pileup_wgtile_kernel(K1Args a) {
             Raw x0;
             load_raw(g0, x0);
             first_coords(g0, r0f, c0f);
-            if (bb + 1 < be) { g1 = geo_of(bb + 1); load_raw(g1, x1); }
+            if (bb + 1 < be) { g1 = geo_from(entry_load(bb + 1)); load_raw(g1, x1); }
+            if (bb + 2 < be) ev = entry_load(bb + 2);
             rw0 = finish_rows(g0, x0);
             issue_values(rw0, v);
             const ExpSel es0 = exp_of(g0);
@@ -1033,7 +1030,7 @@ __global__ __launch_bounds__(kWave * NW) void pileup_wgtile_kernel(K1Args a) {
         for (int b = bb; b < be; ++b) {
             const bool has1 = b + 1 < be, has2 = b + 2 < be;
             if (has1) { issue_values(rw1, v); first_coords(g1, r1f, c1f); }
-            if (has2) { g2 = geo_of(b + 2); load_raw(g2, x2); }
+            if (has2) { g2 = geo_from(ev); load_raw(g2, x2); if (b + 3 < be) ev = entry_load(b + 3); }
             windows(g0, r0f, c0f);
             if (!has1) break;
             const ExpSel es1 = exp_of(g1);
@@ -1173,14 +1170,15 @@ __global__ __launch_bounds__(256) void segment_blocks_kernel(const unsigned* __r
     }
 }
 
-// block table from the compacted block starts: entry b = {region origin R, C, first window, windows}, and the expected
-// region of the block's windows (decoded from the key)
+// block table from the compacted block starts: entry b = region origin R, C, first window, windows, slot-0 windows,
+// expected region of the block's windows (decoded from the key) and the staging geometry of the region (see BlockEntry)
 template <typename KeyT>
 __global__ __launch_bounds__(256) void block_table_kernel(const unsigned* __restrict__ starts, const unsigned* __restrict__ n_runs,
                                                           long long n, const KeyT* __restrict__ sorted_keys,
                                                           const int* __restrict__ r0s, const int* __restrict__ c0s,
                                                           const IdxChrom* __restrict__ chroms, int n_chrom, int BR, int BC,
                                                           int sh_er, int sh_seg, int n_eregs,
+                                                          const unsigned long long* __restrict__ badbits,
                                                           BlockEntry* __restrict__ blocks) {
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long nr = (long long)n_runs[0];
@@ -1191,7 +1189,8 @@ __global__ __launch_bounds__(256) void block_table_kernel(const unsigned* __rest
     int ca = 0, cb = n_chrom;
     while (ca < cb) { const int m = (ca + cb) >> 1; if (chroms[m].end <= r) ca = m + 1; else cb = m; }
     if (ca >= n_chrom) ca = n_chrom - 1;
-    const int cs = chroms[ca].start;
+    const IdxChrom ch = chroms[ca];
+    const int cs = ch.start;
     BlockEntry be;
     be.R = cs + ((r - cs) / BR) * BR;                  // block grid anchored at the chromosome start
     be.C = cs + ((c - cs) / BC) * BC;
@@ -1207,6 +1206,23 @@ __global__ __launch_bounds__(256) void block_table_kernel(const unsigned* __rest
         const int er = (int)((key >> sh_er) & ((1ull << (sh_seg - sh_er)) - 1ull));
         be.ereg = er < n_eregs ? er : -1;
     }
+    // staging geometry: the region's 64 columns start at bit `sh` of word `ws` of index line `bi` of every region row
+    be.ch_end = ch.end; be.nblk = ch.nblk;
+    const int rel = be.C - cs;
+    const int bi = rel / kIdxCols, o = rel - bi * kIdxCols;
+    be.ws_sh = (unsigned)(o >> 6) | ((unsigned)(o & 63) << 8);
+    be.line0 = (unsigned)(ch.blk_base + (long long)(be.R - cs) * ch.nblk + bi);
+    auto bits64 = [&](int bin) {                        // masked-bin bits of bins [bin, bin + 64)
+        const unsigned long long* w = badbits + (bin >> 6);
+        const int sh = bin & 63;
+        unsigned long long v = w[0] >> sh;
+        if (sh) v |= w[1] << (64 - sh);
+        return v;
+    };
+    be.colok = ~bits64(be.C);
+    const int over = be.C + 64 - ch.end;                // columns at / past the chromosome's end are in no eligible window
+    if (over > 0) be.colok &= over >= 64 ? 0ull : (~0ull >> over);
+    be.rowbad = bits64(be.R);
     blocks[b] = be;
 }
 

@@ -14,7 +14,7 @@ import sys
 import pandas as pd
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 prof = os.path.join(ROOT, "gpurun_out", "prof")
 out = os.path.join(ROOT, "profiles")
 os.makedirs(out, exist_ok=True)
@@ -48,6 +48,10 @@ for d in sorted(glob.glob(os.path.join(prof, "pmc_*"))):
 # the pile-up step may be served by two kernels (block-staged for dense tiles + plain register tile for sparse ones):
 # traffic and time of "K1" are the sums over the pile-up kernels launched once per step
 k1s = [k for k in summary if "pileup_" in k]
+# ... of the timed loop: bench.py also runs ONE statistics-gathering step through another instantiation of the kernel
+k1s = [k for k in k1s if "FETCH_SIZE" in summary[k]["counters"] and "WRITE_SIZE" in summary[k]["counters"]]
+most = max((summary[k]["counters"]["FETCH_SIZE"]["launches"] for k in k1s), default=0)
+k1s = [k for k in k1s if summary[k]["counters"]["FETCH_SIZE"]["launches"] * 2 > most]
 k1 = " + ".join(k1s)
 cal = next((k for k in summary if "balance_pixels" in k), None)
 doc = {"bench_line_under_rocprof": bench, "kernels": summary,
@@ -69,13 +73,15 @@ doc["k1"] = {"kernel": k1, "FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_
              "hbm_bytes_per_launch": hbm,
              "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"]}
 json.dump(doc, open(os.path.join(out, f"{tag}_pmc_summary.json"), "w"), indent=1)
-import hashlib
+sys.path.insert(0, ROOT)
+import bench as bench_mod                                     # workload / kernel-source keys exactly as bench.py computes them
 c = bench["config"]
-# must match bench.workload_key(): w5|chroms|lam|pairs|nshifts|pad  (defaults: 23 chroms, lam 4200)
-key = hashlib.sha1(f"w5|23|4200.0|{c['pairs']}|{c['nshifts']}|{c['pad']}".encode()).hexdigest()[:12]
-json.dump({"workload_key": key, "hbm_bytes_per_launch": hbm, "kernel": k1, "source": f"profiles/{tag}_pmc_summary.json",
+args = bench_mod.parse(["--pairs", str(c["pairs"]), "--nshifts", str(c["nshifts"]), "--pad", str(c["pad"])])
+json.dump({"workload_key": bench_mod.workload_key(args), "source_key": bench_mod.source_key(),
+           "hbm_bytes_per_launch": hbm, "kernel": k1, "source": f"profiles/{tag}_pmc_summary.json",
            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB->bytes, FETCH_SIZE x calibration "
-                     "factor measured on balance_pixels_kernel (known 8 B/pixel stream) in the same run"},
+                     "factor measured on balance_pixels_kernel (known 8 B/pixel stream) in the same run; quoted by "
+                     "bench.py only while coolpuppy_amd/csrc is unchanged (source_key)"},
           open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print(json.dumps(doc["k1"], indent=1)); print(json.dumps(doc.get("calibration"), indent=1))
 print(open(os.path.join(out, f"{tag}_kernel_stats.csv")).read()[:1500])
