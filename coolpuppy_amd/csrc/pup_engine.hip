@@ -60,6 +60,9 @@ struct pup_ctx {
     bool have_bal = false;
     DevBuf<pup::IdxBlock> idx;
     DevBuf<pup::IdxChrom> idx_chrom;
+    std::vector<pup::IdxChrom> h_chroms;    // host copy of idx_chrom
+    DevBuf<unsigned short> bin_chrom;       // [nbins] chromosome (index into idx_chrom) of every bin
+    DevBuf<int> d_brow;                     // [n_chrom] block rows before each chromosome (block-order prepass)
     DevBuf<unsigned> rowseg;               // [nbins][n_chrom+1] search bounds per (row, chromosome), see K1Args
     int n_chrom = 0;
     bool have_idx = false, have_rowseg = false;
@@ -314,6 +317,7 @@ void pup_destroy(pup_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     collect_events(c);
     c->indptr.release(); c->px.release(); c->cnt32.release(); c->bal.release(); c->badbits.release(); c->idx.release(); c->idx_chrom.release(); c->weight.release(); c->cov.release(); c->expv.release(); c->exp_pair.release(); c->exp_regions.release();
+    c->bin_chrom.release(); c->d_brow.release();
     c->acc_f64.release(); c->acc_i64.release();
     c->d_r0.release(); c->d_c0.release(); c->d_h.release(); c->d_w.release(); c->d_geom.release();
     c->d_keys.release(); c->d_keys2.release(); c->d_cnt32.release(); c->d_vals.release(); c->d_vals2.release();
@@ -417,6 +421,14 @@ int pup_build_index(pup_ctx* c, const int64_t* chrom_offset, int32_t n_chroms, i
     HIPCHK(c, c->idx.reserve((size_t)std::max<long long>(nblocks, 1)));
     HIPCHK(c, c->idx_chrom.reserve((size_t)n_chroms));
     HIPCHK(c, hipMemcpy(c->idx_chrom.p, tab.data(), tab.size() * sizeof(pup::IdxChrom), hipMemcpyHostToDevice));
+    c->h_chroms = tab;
+    c->bin_chrom.release();
+    if (n_chroms <= 0xffff) {
+        std::vector<unsigned short> bc((size_t)c->nbins);
+        for (int k = 0; k < n_chroms; ++k) std::fill(bc.begin() + tab[(size_t)k].start, bc.begin() + tab[(size_t)k].end, (unsigned short)k);
+        HIPCHK(c, c->bin_chrom.reserve((size_t)c->nbins));
+        HIPCHK(c, hipMemcpy(c->bin_chrom.p, bc.data(), bc.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+    }
     HIPCHK(c, hipMemsetAsync(c->idx.p, 0, (size_t)nblocks * sizeof(pup::IdxBlock), c->stream));
     const int rows_per_block = 4;
     const unsigned g1 = (unsigned)std::min<long long>((c->nbins + rows_per_block - 1) / rows_per_block, 1 << 20);
@@ -618,18 +630,24 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
     const bool use_idx_t = c->have_idx && !(c->variant & 1);
     if (forbid || rescale || (mode & (PUP_MODE_EXPECTED | PUP_MODE_TRANSPOSE)) || (c->variant & 2) || !use_idx_t ||
         ignore_diags < 0 || !tiled_supported(W) || n >= 0x7fffffffLL || !(force || n >= c->tiled_min) ||
-        2 * T > pup::kMaxSegCount || c->nbins >= (1LL << pup::kSlotBit))
+        2 * T > pup::kMaxSegCount || c->nbins >= (1LL << pup::kSlotBit) || !c->bin_chrom.p ||
+        (int)c->h_chroms.size() != c->n_chrom)
         return PUP_OK;
     const int BR = kWgRegion - W + 1, BC = kWgRegion - W + 1;
     const unsigned long long min_per_block = 8;          // windows per staged region that pay for the staging
     const int n_eregs = ((mode & PUP_MODE_OOE) && c->n_exp_regions > 0 && !c->have_exp_pair) ? c->n_exp_regions : 0;
     auto nbits = [](unsigned long long v) { int b = 1; while ((v >> b) != 0) ++b; return b; };
-    long long max_len = 1;
-    {
-        std::vector<pup::IdxChrom> tab((size_t)c->n_chrom);
-        HIPCHK(c, hipMemcpy(tab.data(), c->idx_chrom.p, tab.size() * sizeof(pup::IdxChrom), hipMemcpyDeviceToHost));
-        for (auto& ch : tab) max_len = std::max<long long>(max_len, ch.end - ch.start);
+    // block rows are numbered compactly over the genome (fewer key bits = fewer radix passes)
+    long long max_len = 1, n_brows = 0;
+    std::vector<int> brow_base((size_t)c->n_chrom);
+    for (int k = 0; k < c->n_chrom; ++k) {
+        const long long len = c->h_chroms[(size_t)k].end - c->h_chroms[(size_t)k].start;
+        max_len = std::max<long long>(max_len, len);
+        brow_base[(size_t)k] = (int)n_brows;
+        n_brows += (len + BR - 1) / BR;
     }
+    HIPCHK(c, c->d_brow.reserve((size_t)c->n_chrom));
+    HIPCHK(c, hipMemcpyAsync(c->d_brow.p, brow_base.data(), brow_base.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     // (tile, flip) runs of the caller's order
     std::vector<long long> seg_end2t;
     for (int t = 0; t < T; ++t) { seg_end2t.push_back(flip_from ? flip_from[t] : tile_ptr[t + 1]); seg_end2t.push_back(tile_ptr[t + 1]); }
@@ -655,14 +673,14 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
             const int f = sg & 1, u = sg >> 1;
             seg_win0[(size_t)sg + 1] = seg_win0[(size_t)sg] + (paired ? run_len(u, f) + run_len(u + H, f) : run_len(u, f));
         }
-        const int bits_bc = nbits((unsigned long long)(max_len / BC + 1)), bits_br = nbits((unsigned long long)c->nbins + 1);
+        const int bits_bc = nbits((unsigned long long)(max_len / BC + 1)), bits_br = nbits((unsigned long long)n_brows + 1);
         const int bits_er = n_eregs > 0 ? nbits((unsigned long long)n_eregs) : 0;
         const int sh_br = bits_bc, sh_er = sh_br + bits_br, sh_seg = sh_er + bits_er;
         const int end_bit = sh_seg + nbits((unsigned long long)(nseg > 1 ? nseg - 1 : 1));
         if (end_bit > 64) { stop_timer(); return PUP_OK; }
         // [0] ineligible windows, [1] blocks, [2 .. 2+nseg] first block of every segment + total, [last] windows a diagonal mask reaches
         const size_t ncnt = 2 + (size_t)nseg + 1 + 1;
-        HIPCHK(c, c->d_keys.reserve((size_t)n)); HIPCHK(c, c->d_vals.reserve((size_t)n)); HIPCHK(c, c->d_vals2.reserve((size_t)n));
+        HIPCHK(c, c->d_vals.reserve((size_t)n)); HIPCHK(c, c->d_vals2.reserve((size_t)n));
         HIPCHK(c, c->d_segend.reserve(seg_end2t.size() + (size_t)nseg + 1)); HIPCHK(c, c->d_cnt32.reserve(ncnt));
         HIPCHK(c, c->d_sr0.reserve((size_t)n)); HIPCHK(c, c->d_sc0.reserve((size_t)n));
         HIPCHK(c, c->d_head.reserve((size_t)n)); HIPCHK(c, c->d_starts.reserve((size_t)n + 1));
@@ -673,18 +691,17 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
         HIPCHK(c, hipMemsetAsync(c->d_cnt32.p, 0, 2 * sizeof(unsigned), c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_cnt32.p + ncnt - 1, 0, sizeof(unsigned), c->stream));
         const unsigned gk = (unsigned)((n + 255) / 256);
-        hipLaunchKernelGGL(pup::block_key_kernel, dim3(gk), dim3(256), 0, c->stream, dr0, dc0, (long long)n,
-                           (const long long*)c->d_segend.p, (int)seg_end2t.size(), H, (const pup::IdxChrom*)c->idx_chrom.p,
-                           c->n_chrom, (const pup::ExpRegion*)(n_eregs > 0 ? c->exp_regions.p : nullptr), n_eregs,
-                           W, BR, BC, sh_br, sh_er, sh_seg, ignore_diags + W - 1, c->d_keys.p, c->d_vals.p, c->d_cnt32.p,
-                           c->d_cnt32.p + ncnt - 1);
         hipError_t se = hipSuccess;
         size_t tmp_bytes = 0;
         const bool k32 = end_bit <= 32;
+        const pup::ExpRegion* d_eregs = n_eregs > 0 ? c->exp_regions.p : nullptr;
         if (k32) {
             HIPCHK(c, c->d_k32.reserve((size_t)n)); HIPCHK(c, c->d_k32b.reserve((size_t)n));
-            hipLaunchKernelGGL(pup::narrow_keys_kernel, dim3(gk), dim3(256), 0, c->stream,
-                               (const unsigned long long*)c->d_keys.p, (long long)n, c->d_k32.p);
+            hipLaunchKernelGGL((pup::block_key_kernel<unsigned>), dim3(gk), dim3(256), 0, c->stream, dr0, dc0, (long long)n,
+                               (const long long*)c->d_segend.p, (int)seg_end2t.size(), H, (const pup::IdxChrom*)c->idx_chrom.p,
+                               c->n_chrom, (const unsigned short*)c->bin_chrom.p, (long long)c->nbins, (const int*)c->d_brow.p,
+                               d_eregs, n_eregs, W, BR, BC, sh_br, sh_er, sh_seg, ignore_diags + W - 1, c->d_k32.p, c->d_vals.p,
+                               c->d_cnt32.p, c->d_cnt32.p + ncnt - 1);
             se = rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_vals.p, c->d_vals2.p,
                                            (size_t)n, 0, end_bit, c->stream);
             if (se == hipSuccess) se = c->d_sorttmp.reserve(tmp_bytes + 16);
@@ -696,7 +713,12 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
                                    (const unsigned*)c->d_vals2.p, (const unsigned*)c->d_k32b.p, (long long)n,
                                    c->d_sr0.p, c->d_sc0.p, c->d_head.p);
         } else {
-            HIPCHK(c, c->d_keys2.reserve((size_t)n));
+            HIPCHK(c, c->d_keys.reserve((size_t)n)); HIPCHK(c, c->d_keys2.reserve((size_t)n));
+            hipLaunchKernelGGL((pup::block_key_kernel<unsigned long long>), dim3(gk), dim3(256), 0, c->stream, dr0, dc0, (long long)n,
+                               (const long long*)c->d_segend.p, (int)seg_end2t.size(), H, (const pup::IdxChrom*)c->idx_chrom.p,
+                               c->n_chrom, (const unsigned short*)c->bin_chrom.p, (long long)c->nbins, (const int*)c->d_brow.p,
+                               d_eregs, n_eregs, W, BR, BC, sh_br, sh_er, sh_seg, ignore_diags + W - 1, c->d_keys.p, c->d_vals.p,
+                               c->d_cnt32.p, c->d_cnt32.p + ncnt - 1);
             se = rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_vals.p, c->d_vals2.p,
                                            (size_t)n, 0, end_bit, c->stream);
             if (se == hipSuccess) se = c->d_sorttmp.reserve(tmp_bytes + 16);

@@ -1092,13 +1092,16 @@ __global__ __launch_bounds__(kWave * NW) void pileup_wgtile_kernel(K1Args a) {
 // snippet is piled up with; `pair_half` = T/2 when tile t shares its pass with tile t + T/2 (then slot = t / (T/2) goes
 // into bit 31 of the value), 0 when every tile has its own pass.  Also checks that the window is one the rank-bitmap
 // index covers (cis, inside one chromosome) and counts the ineligible ones.
+template <typename KeyT>
 __global__ __launch_bounds__(256) void block_key_kernel(const int* __restrict__ r0, const int* __restrict__ c0, long long n,
                                                         const long long* __restrict__ seg_end, int nseg2t, int pair_half,
                                                         const IdxChrom* __restrict__ chroms, int n_chrom,
+                                                        const unsigned short* __restrict__ bin_chrom, long long nbins,
+                                                        const int* __restrict__ brow_base /* [n_chrom] block rows before the chromosome */,
                                                         const ExpRegion* __restrict__ eregs, int n_eregs,
                                                         int W, int BR, int BC, int sh_br, int sh_er, int sh_seg,
                                                         int clear_gap /* igd + W - 1 */,
-                                                        unsigned long long* __restrict__ keys, unsigned* __restrict__ vals,
+                                                        KeyT* __restrict__ keys, unsigned* __restrict__ vals,
                                                         unsigned* __restrict__ counters /* [0] ineligible */,
                                                         unsigned* __restrict__ n_unclear /* windows a diagonal mask reaches */) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1109,15 +1112,14 @@ __global__ __launch_bounds__(256) void block_key_kernel(const int* __restrict__ 
     const int t = lo >> 1, f = lo & 1;                   // tile, flip state of the snippet
     unsigned seg = (unsigned)lo, slot = 0u;
     if (pair_half > 0) { slot = (unsigned)(t / pair_half); seg = (unsigned)((t % pair_half) * 2 + f); }
-    int ca = 0, cb = n_chrom;
-    while (ca < cb) { const int m = (ca + cb) >> 1; if (chroms[m].end <= r) ca = m + 1; else cb = m; }
-    bool ok = r >= 0 && c >= 0 && ca < n_chrom;
+    bool ok = r >= 0 && c >= 0 && (long long)r < nbins;
     unsigned long long br = 0, bc = 0, er = 0;
     if (ok) {
+        const int ca = bin_chrom[r];
         const int cs = chroms[ca].start, ce = chroms[ca].end;
         ok = r >= cs && r + W <= ce && c >= cs && c + W <= ce;
         if (ok) {
-            br = (unsigned long long)cs + (unsigned long long)((r - cs) / BR);  // unique and increasing over the genome
+            br = (unsigned long long)(brow_base[ca] + (r - cs) / BR);           // increasing over the genome, compact
             bc = (unsigned long long)((c - cs) / BC);
         }
     }
@@ -1130,15 +1132,8 @@ __global__ __launch_bounds__(256) void block_key_kernel(const int* __restrict__ 
         const unsigned long long near = __ballot(c - r < clear_gap);
         if (near != 0ull && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)near) - 1)) atomicAdd(n_unclear, (unsigned)__popcll(near));
     }
-    keys[i] = ((unsigned long long)seg << sh_seg) | (er << sh_er) | (br << sh_br) | bc;
+    keys[i] = (KeyT)(((unsigned long long)seg << sh_seg) | (er << sh_er) | (br << sh_br) | bc);
     vals[i] = (unsigned)i | (slot << 31);
-}
-
-// 32-bit copy of the keys (when they fit): halves the radix passes of the block sort
-__global__ __launch_bounds__(256) void narrow_keys_kernel(const unsigned long long* __restrict__ k64, long long n,
-                                                          unsigned* __restrict__ k32) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) k32[i] = (unsigned)k64[i];
 }
 
 // snippets into block order (slot bit moved into bit kSlotBit of c0) + "a new block starts here" flags
