@@ -29,7 +29,7 @@ import numpy as np
 import pandas as pd
 
 from .cooler_lite import as_array_cooler
-from .lib.puputils import _add_snip, _collapse, finalize_callback_pileups, finalize_pileups, sum_pups
+from .lib.puputils import SnipAccumulator, _collapse, finalize_callback_pileups, finalize_pileups, sum_pups
 
 logger = logging.getLogger("coolpuppy")
 
@@ -64,10 +64,11 @@ def bin_distance_intervals(intervals, band_edges="default"):
 
 def assign_groups(intervals, groupby=[]):
     """'group' column: "all", or the list of the groupby values of each row (reference :54-75)."""
-    if not groupby:
-        intervals["group"] = "all"
+    if groupby:
+        keys = intervals[groupby].to_numpy()             # one row of values per snippet
+        intervals["group"] = [keys[i] for i in range(len(keys))]
     else:
-        intervals["group"] = list(intervals[groupby].values)
+        intervals["group"] = "all"
     return intervals
 
 
@@ -119,12 +120,11 @@ def expand2D(intervals, flank, resolution, rescale_flank=None):
 def flip_mark_intervals_func(intervals, flipby, flip_negative_strand, extra_func=None):
     """'flip' column: negative strand of side 1, or flipby1 > flipby2 (reference :118-125)."""
     if flip_negative_strand:
-        intervals["flip"] = np.where(intervals["strand1"] == "-", True, False)
+        flip = intervals["strand1"].to_numpy() == "-"
     else:
-        intervals["flip"] = intervals[f"{flipby}1"] > intervals[f"{flipby}2"]
-    if extra_func is not None:
-        intervals = extra_func(intervals)
-    return intervals
+        flip = intervals[flipby + "1"].to_numpy() > intervals[flipby + "2"].to_numpy()
+    intervals["flip"] = flip
+    return intervals if extra_func is None else extra_func(intervals)
 
 
 def flip_snip_func(snip, groupby, ignore_group_order, extra_func=None):
@@ -326,26 +326,20 @@ class CoordCreator:
         return df
 
     def bedpe2bed(self, df, ends=True, how="center"):
-        """Both anchors of every pair as one sorted BED frame (ends=True), or one long interval per pair
-        (how = "outer" | "inner"); reference :463-487 (its how="center" branch calls np.mean with two arrays and
-        cannot run — the same call is made here)."""
+        """Pairs -> BED intervals (reference :463-487).  ends=True: both anchors of every pair, sorted by
+        (chrom, start, end).  Otherwise one interval per pair: how="outer" spans start1..end2, how="inner" the gap
+        end1..start2; how="center" raises TypeError as it does upstream (np.mean is called there with two arrays)."""
         if ends:
-            parts = []
-            for side in ("1", "2"):
-                part = df[["chrom" + side, "start" + side, "end" + side]]
-                part.columns = ["chrom", "start", "end"]
-                parts.append(part)
-            return pd.concat(parts).sort_values(["chrom", "start", "end"]).reset_index(drop=True)
-        if how == "center":
-            df["start"] = np.mean(df["start1"], df["end1"], axis=0)
-            df["end"] = np.mean(df["start2"], df["end2"], axis=0)
-        elif how == "outer":
-            df = df[["chrom1", "start1", "end2"]]
-            df.columns = ["chrom", "start", "end"]
-        elif how == "inner":
-            df = df[["chrom1", "end1", "start2"]]
-            df.columns = ["chrom", "start", "end"]
-        return df
+            anchors = {name: np.concatenate([df[name + "1"].to_numpy(), df[name + "2"].to_numpy()])
+                       for name in ("chrom", "start", "end")}
+            order = np.lexsort((anchors["end"], anchors["start"], anchors["chrom"].astype(str)))
+            return pd.DataFrame({name: col[order] for name, col in anchors.items()})
+        spans = {"outer": ("start1", "end2"), "inner": ("end1", "start2")}
+        if how not in spans:
+            raise TypeError(f"bedpe2bed(how={how!r}) is not usable (upstream's 'center' branch cannot run either)")
+        lo, hi = spans[how]
+        return pd.DataFrame({"chrom": df["chrom1"].to_numpy(), "start": df[lo].to_numpy(), "end": df[hi].to_numpy()},
+                            index=df.index)
 
     def _binnify(self, intervals, presorted=False):
         """Sort and convert expanded coordinates to bins (reference :489-527). pandas does the sort so the
@@ -1004,6 +998,38 @@ class PileUpper:
         return out
 
     # -- the pile-up -------------------------------------------------------------------------------------------
+    def _flip_column(self, groupby):
+        """The paired annotation whose order decides which snippets are flipped: "strand" (flip_negative_strand), the
+        stem X of a groupby pair X1 / X2 (ignore_group_order), or None.  Same accepted inputs, errors and warnings as
+        the reference's checks (coolpup.py:1431-1475)."""
+        igo = self.ignore_group_order
+        if not self.flip_negative_strand and not igo:
+            return None
+        if igo and (self.flip_negative_strand or groupby):
+            for bad, what in ((self.local, "local pileups"), (self.kind == "bedpe", "bedpe files")):
+                if bad:
+                    raise ValueError(f"ignore_group_order doesn't make sense for {what}")
+        if self.flip_negative_strand:
+            if igo and groupby:
+                warnings.warn("flip_negative_strand and ignore_group_order leads to combining strands, not other groups")
+            return "strand"
+        if not groupby:
+            warnings.warn("Need to specify groupby for ignore_group_order")
+            return None
+        # groupby columns that come as a pair stem+"1" / stem+"2"
+        paired_cols = {g for g in groupby if g[:-1] + "1" in groupby and g[:-1] + "2" in groupby}
+        if igo is True:
+            stems = {g[:-1] for g in paired_cols}
+        elif isinstance(igo, str):
+            stems = {igo}
+        elif len(igo) == 1:
+            stems = set(igo)
+        else:
+            stems = {g[:-1] for g in igo}
+        if len(stems) == 1 and next(iter(stems)) + "1" in paired_cols:
+            return next(iter(stems))
+        raise ValueError("Ambiguous ignore_group_order, please provide str or list of two strings which are in groupby")
+
     def pileupsWithControl(self, nproc=None, groupby=[], ignore_group_order=False, modify_2Dintervals_func=None,
                            postprocess_func=None, extra_sum_funcs=None, _columns=(), _by_window=False):
         """All regions -> normalised pile-ups DataFrame (reference :1360-1654)."""
@@ -1017,40 +1043,7 @@ class PileUpper:
             return self.make_outmap(), 0
 
         columns = list(_columns) if _columns is not None else None
-        flipby = None
-        if self.flip_negative_strand:
-            flipby = "strand"
-            if self.ignore_group_order:
-                if self.local:
-                    raise ValueError("ignore_group_order doesn't make sense for local pileups")
-                elif self.kind == "bedpe":
-                    raise ValueError("ignore_group_order doesn't make sense for bedpe files")
-                elif groupby:
-                    warnings.warn(
-                        "flip_negative_strand and ignore_group_order leads to combining strands, not other groups")
-        elif self.ignore_group_order and groupby:
-            if self.local:
-                raise ValueError("ignore_group_order doesn't make sense for local pileups")
-            if self.kind == "bedpe":
-                raise ValueError("ignore_group_order doesn't make sense for bedpe files")
-            groups = np.array(groupby)
-            paired = [f"{g[:-1]}1" in groups and f"{g[:-1]}2" in groups for g in groups]
-            groups_filtered = np.sort(groups[paired])
-            if self.ignore_group_order is True:
-                flipby = list(set(g[:-1] for g in groups_filtered))
-            elif isinstance(self.ignore_group_order, str):
-                flipby = [self.ignore_group_order]
-            elif len(self.ignore_group_order) == 1:
-                flipby = self.ignore_group_order
-            elif len(self.ignore_group_order) > 1:
-                flipby = list(set(g[:-1] for g in self.ignore_group_order))
-            if len(flipby) == 1 and f"{flipby[0]}1" in groups_filtered:
-                flipby = flipby[0]
-            else:
-                raise ValueError(
-                    "Ambiguous ignore_group_order, please provide str or list of two strings which are in groupby")
-        elif self.ignore_group_order and not groupby:
-            warnings.warn("Need to specify groupby for ignore_group_order")
+        flipby = self._flip_column(groupby)
 
         modify = modify_2Dintervals_func
         if self.flip_negative_strand or (self.ignore_group_order and groupby):
@@ -1393,10 +1386,11 @@ class PileUpper:
         from functools import reduce
         if postprocess_func is not None:
             snip_stream = map(postprocess_func, snip_stream)
-        outdict = {"ROI": {}, "control": {}}
+        piles = {"ROI": SnipAccumulator(extra_funcs), "control": SnipAccumulator(extra_funcs)}
         for snip in _collapse(snip_stream):
             key = snip["group"]
-            _add_snip(outdict[snip["kind"]], key if isinstance(key, str) else tuple(key), snip, extra_funcs=extra_funcs)
+            piles[snip["kind"]].add(key if isinstance(key, str) else tuple(key), snip)
+        outdict = {kind: pile.entries for kind, pile in piles.items()}
         sum_func = partial(sum_pups, extra_funcs=extra_funcs)
         if "all" not in outdict["ROI"]:
             outdict["ROI"]["all"] = reduce(sum_func, outdict["ROI"].values(), self.empty_pup)

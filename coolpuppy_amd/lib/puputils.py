@@ -35,132 +35,113 @@ def _collapse(items):
         yield from _collapse(x)
 
 
+_PUP_LISTS = ("horizontal_stripe", "vertical_stripe", "coordinates")
+
+
+class SnipAccumulator:
+    """Per-(kind) pile-ups of a snippet stream for the CALLBACK path (the GPU produced the windows, user Python sees
+    every snippet): ``entries[group]`` is the pile-up dict the reference's API exposes — data (sum), num, n,
+    cov_start, cov_end and the per-snippet lists — kept as running arrays updated in place.
+
+    Observable result = the reference's ``_add_snip`` (coolpuppy/lib/puputils.py:12-41) applied snippet by snippet:
+    the first snippet of a group is kept as is (its NaN cells stay NaN until a second snippet arrives), afterwards
+    data / coverage are nan-sums, ``num`` counts finite cells, ``n`` snippets.  Unlike the reference nothing is
+    re-allocated per snippet: NaN is folded to 0 when the second snippet arrives and lists grow by append (the
+    reference rebuilds three Python lists per snippet, its quadratic term)."""
+
+    def __init__(self, extra_funcs=None):
+        self.entries = {}
+        self._extra = list(extra_funcs.values()) if extra_funcs else []
+
+    @staticmethod
+    def _nan_as_zero(a):
+        return np.where(np.isnan(a), 0.0, a)
+
+    def add(self, key, snip):
+        e = self.entries.get(key)
+        if e is None:
+            e = {"data": snip["data"], "cov_start": snip["cov_start"], "cov_end": snip["cov_end"],
+                 "coordinates": [snip["coordinates"]], "horizontal_stripe": [snip["horizontal_stripe"]],
+                 "vertical_stripe": [snip["vertical_stripe"]],
+                 "num": np.isfinite(snip["data"]).astype(int), "n": 1}
+            self.entries[key] = e
+        else:
+            if e["n"] == 1:          # the seed may be the caller's array and may hold NaN: own, NaN-free copies from now on
+                for f in ("data", "cov_start", "cov_end"):
+                    e[f] = self._nan_as_zero(np.asarray(e[f], dtype=float))
+            for f in ("data", "cov_start", "cov_end"):
+                e[f] = e[f] + self._nan_as_zero(np.asarray(snip[f], dtype=float))
+            e["num"] += np.isfinite(snip["data"])
+            e["n"] += 1
+            for f in _PUP_LISTS:
+                e[f].append(snip[f])
+        for func in self._extra:     # user hooks see (running pile-up, snippet) and return the pile-up to keep
+            self.entries[key] = e = func(e, snip)
+
+
 def _add_snip(outdict, key, snip, extra_funcs=None):
-    """Add one snippet to the pile-up of its group (reference lib/puputils.py:12-41): the first snippet of a group
-    seeds the entry, later ones are nansum-ed into data / coverage, counted in num (finite cells) and n, and have
-    their stripes / coordinates appended; every extra function then maps (entry, snip) -> entry."""
-    if key not in outdict:
-        entry = {k: snip[k] for k in ("data", "cov_start", "cov_end")}
-        entry["coordinates"] = [snip["coordinates"]]
-        entry["horizontal_stripe"] = [snip["horizontal_stripe"]]
-        entry["vertical_stripe"] = [snip["vertical_stripe"]]
-        entry["num"] = np.isfinite(snip["data"]).astype(int)
-        entry["n"] = 1
-        outdict[key] = entry
-    else:
-        entry = outdict[key]
-        entry["data"] = np.nansum([entry["data"], snip["data"]], axis=0)
-        entry["num"] += np.isfinite(snip["data"]).astype(int)
-        entry["cov_start"] = np.nansum([entry["cov_start"], snip["cov_start"]], axis=0)
-        entry["cov_end"] = np.nansum([entry["cov_end"], snip["cov_end"]], axis=0)
-        entry["n"] += 1
-        for k in ("horizontal_stripe", "vertical_stripe", "coordinates"):
-            entry[k] = entry[k] + [snip[k]]
-    if extra_funcs is not None:
-        for _, func in extra_funcs.items():
-            outdict[key] = func(outdict[key], snip)
+    """Function form of :meth:`SnipAccumulator.add` on a plain {group: pile-up} dict (the name the reference's
+    callers know, coolpuppy/lib/puputils.py:12)."""
+    acc = SnipAccumulator(extra_funcs)
+    acc.entries = outdict
+    acc.add(key, snip)
 
 
 def sum_pups(pup1, pup2, extra_funcs={}):
-    """Sum two pile-up dicts (data, num, n, cov_start, cov_end, stripes, coordinates); NaN/inf in data are replaced
-    first — in place, on both inputs — exactly like the reference's ``np.nan_to_num`` (lib/puputils.py:97-98).
-    With extra_funcs the reference REPLACES the summed pile-up by the return value of func(pup1, pup2)
-    (lib/puputils.py:110-112); that is kept, because callers of the callback API see it."""
-    pup1["data"] = np.nan_to_num(pup1["data"])
-    pup2["data"] = np.nan_to_num(pup2["data"])
-    out = {
-        "data": pup1["data"] + pup2["data"],
-        "cov_start": pup1["cov_start"] + pup2["cov_start"],
-        "cov_end": pup1["cov_end"] + pup2["cov_end"],
-        "n": pup1.get("n", 1) + pup2.get("n", 1),
-        "num": pup1.get("num", np.isfinite(pup1["data"]).astype(int))
-        + pup2.get("num", np.isfinite(pup2["data"]).astype(int)),
-        "horizontal_stripe": pup1["horizontal_stripe"] + pup2["horizontal_stripe"],
-        "vertical_stripe": pup1["vertical_stripe"] + pup2["vertical_stripe"],
-        "coordinates": pup1["coordinates"] + pup2["coordinates"],
-    }
-    if extra_funcs:
-        for _, func in extra_funcs.items():
-            out = func(pup1, pup2)
-    return pd.Series(out)
+    """Merge two pile-up dicts of one group (two regions): additive fields add, per-snippet lists concatenate.  Both
+    inputs have NaN / inf in ``data`` replaced first, IN PLACE (np.nan_to_num: +inf -> 1.8e308) — the reference does
+    (coolpuppy/lib/puputils.py:97-98) and its callers see it; a missing ``n`` counts as 1, a missing ``num`` as the
+    finite cells.  With extra_funcs the merged pile-up is whatever the last hook returns for (pup1, pup2) — the
+    reference's behaviour (:110-112), kept because hooks written for it rely on it."""
+    for pup in (pup1, pup2):
+        pup["data"] = np.nan_to_num(pup["data"])
+    finite = [np.isfinite(pup["data"]).astype(int) for pup in (pup1, pup2)]
+    merged = {f: pup1[f] + pup2[f] for f in ("data", "cov_start", "cov_end")}
+    merged["n"] = pup1.get("n", 1) + pup2.get("n", 1)
+    merged["num"] = pup1.get("num", finite[0]) + pup2.get("num", finite[1])
+    for f in _PUP_LISTS:
+        merged[f] = pup1[f] + pup2[f]
+    for func in (extra_funcs or {}).values():
+        merged = func(pup1, pup2)
+    return pd.Series(merged)
 
 
 def accumulate_values(dict1, dict2, key):
-    """An extra_sum_func: collect dict2[key] into the flat list dict1[key] (reference lib/puputils.py:244-253)."""
-    assert key in dict2, f"{key} not in dict2"
-    if key in dict1:
-        dict1[key] = list(_collapse([dict1[key], dict2[key]]))
-    else:
-        dict1[key] = [dict2[key]]
+    """extra_sum_funcs hook: gather dict2[key] into the flat list dict1[key] (reference lib/puputils.py:244-253)."""
+    if key not in dict2:
+        raise AssertionError(f"{key} not in dict2")
+    gathered = list(_collapse([dict1[key]])) if key in dict1 else []
+    gathered.extend(_collapse([dict2[key]]))
+    dict1[key] = gathered
     return dict1
 
 
 def bin_distance(snip, band_edges="default"):
-    """Per-snippet form of bin_distance_intervals (reference lib/puputils.py:193-215): adds 'distance_band'."""
-    if isinstance(band_edges, str) and band_edges == "default":
-        band_edges = np.append([0], 50000 * 2 ** np.arange(30))
-    i = np.searchsorted(band_edges, snip["distance"])
-    snip["distance_band"] = tuple(band_edges[i - 1: i + 1])
+    """postprocess_func: label one snippet with the distance band its 'distance' falls in (reference
+    lib/puputils.py:193-215; the per-snippet twin of coolpup.bin_distance_intervals)."""
+    edges = np.append([0], 50000 * 2 ** np.arange(30)) if isinstance(band_edges, str) and band_edges == "default" \
+        else band_edges
+    hi = int(np.searchsorted(edges, snip["distance"]))
+    snip["distance_band"] = tuple(edges[hi - 1: hi + 1])
     return snip
 
 
 def group_by_region(snip):
-    """A postprocess_func: count the snippet once for the feature on each side (reference lib/puputils.py:218-223)."""
-    for side in ("1", "2"):
-        s = snip.copy()
-        s["group"] = (s["chrom" + side], s["start" + side], s["end" + side])
-        yield s
-
-
-def get_score(pup, center=3, ignore_central=3):
-    """One number for any pile-up (reference lib/puputils.py:44-85): off-diagonal -> mean of the central `center`
-    pixels; local -> insulation strength; local and rescaled -> domain score."""
-    from .numutils import get_domain_score, get_enrichment, get_insulation_strength
-    if not pup["local"]:
-        return get_enrichment(pup["data"], center)
-    if pup["rescale"]:
-        return get_domain_score(pup["data"], pup["rescale_flank"])
-    return get_insulation_strength(pup["data"], ignore_central)
-
-
-_NOT_COMPARED = ["control_n", "control_num", "n", "num", "clr", "chroms", "minshift", "expected_file", "group", "maxshift",
-                 "mindist", "maxdist", "subset", "seed", "data", "horizontal_stripe", "vertical_stripe", "cooler",
-                 "features", "outname", "coordinates"]
-
-
-def divide_pups(pup1, pup2):
-    """Ratio of two single-row pile-up frames of identical geometry (reference lib/puputils.py:116-165): data1 / data2,
-    n summed, annotation columns that differ are reported with a warning, stripes divided only when both hold the same
-    coordinates (inf / NaN quotients -> 0)."""
-    import logging
-    import warnings
-    if pup1.shape[0] > 1 or pup2.shape[0] > 1:
-        raise ValueError("Pileups cannot contain multiple conditions")
-    pup1, pup2 = pup1.reset_index(drop=True), pup2.reset_index(drop=True)
-    out = pup1.drop(columns=list(set(_NOT_COMPARED) & set(pup1.columns)))
-    for col in out.columns:
-        if np.all(np.sort(pup1[col]) != np.sort(pup2[col])):
-            warnings.warn(f"Note that {col} is different between the two pileups")
-    out["data"] = pup1["data"] / pup2["data"]
-    out["clrs"] = str(pup1["clr"]) + "/" + str(pup2["clr"])
-    out["n"] = pup1["n"] + pup2["n"]
-    if {"vertical_stripe", "horizontal_stripe"}.issubset(pup1.columns):
-        if np.all(np.sort(pup1["coordinates"]) == np.sort(pup2["coordinates"])):
-            out["coordinates"] = pup1["coordinates"]
-            for stripe in ("vertical_stripe", "horizontal_stripe"):
-                out[stripe] = (pup1[stripe] / pup2[stripe]).apply(lambda x: np.where(np.isin(x, [np.inf, np.nan]), 0, x))
-        else:
-            logging.info("Stripes cannot be divided, coordinates differ between pups")
-    return out
+    """postprocess_func: the snippet once per side, grouped under that side's feature (reference
+    lib/puputils.py:218-223)."""
+    for side in "12":
+        twin = dict(snip)
+        twin["group"] = tuple(twin[f + side] for f in ("chrom", "start", "end"))
+        yield twin
 
 
 def norm_coverage(snip):
-    """data /= outer(cov_start, cov_end) / nanmean(...) ; NaN -> 0 (reference lib/puputils.py:168-190)."""
-    coverage = np.outer(snip["cov_start"], snip["cov_end"])
+    """Divide a summed pile-up by the outer product of its coverage vectors, scaled to mean 1; cells that end up NaN
+    become 0, inf stays (reference lib/puputils.py:168-190)."""
     with np.errstate(divide="ignore", invalid="ignore"):
-        coverage = coverage / np.nanmean(coverage)
-        snip["data"] = snip["data"] / coverage
-    snip["data"][np.isnan(snip["data"])] = 0
+        expected_cov = np.multiply.outer(snip["cov_start"], snip["cov_end"])
+        q = snip["data"] / (expected_cov / np.nanmean(expected_cov))
+    snip["data"] = np.where(np.isnan(q), 0.0, q)
     return snip
 
 

@@ -401,32 +401,6 @@ def callback_goldens(ref, coolers, index):
         print(f"{sc['name']:45s} rows={len(df):3d} n_all={int(df['n'].iloc[gl.index('all')])}")
 
 
-def numutils_goldens():
-    """Outputs of the reference's score functions (coolpuppy/lib/numutils.py, puputils.get_score) on random pile-ups."""
-    import importlib
-    refshim.import_reference()
-    nu = importlib.import_module("coolpuppy.lib.numutils")
-    pu = importlib.import_module("coolpuppy.lib.puputils")
-    rng = np.random.default_rng(77)
-    out = {}
-    for k, W in enumerate((21, 33, 51)):
-        a = rng.gamma(2.0, 1.0, (W, W))
-        a[rng.random((W, W)) < 0.03] = np.nan
-        out[f"in{k}"] = a
-        out[f"corner_cv{k}"] = nu.corner_cv(a, 4)
-        out[f"norm_cis{k}"] = nu.norm_cis(a.copy(), 3)
-        out[f"enrichment{k}"] = np.array([nu.get_enrichment(a, 1), nu.get_enrichment(a, 3), nu.get_enrichment(a, 5)])
-        out[f"local_enrichment{k}"] = nu.get_local_enrichment(a, 1)
-        out[f"domain_score{k}"] = nu.get_domain_score(a, 1)
-        out[f"insulation{k}"] = np.array([nu.get_insulation_strength(a.copy(), 0), nu.get_insulation_strength(a.copy(), 3, 0)])
-        out[f"halves{k}"] = nu._copy_array_halves(a[:5].copy())
-        out[f"score{k}"] = np.array([pu.get_score({"data": a.copy(), "local": False, "rescale": False, "rescale_flank": 1}),
-                                      pu.get_score({"data": a.copy(), "local": True, "rescale": False, "rescale_flank": 1}),
-                                      pu.get_score({"data": a.copy(), "local": True, "rescale": True, "rescale_flank": 1})])
-    np.savez_compressed(os.path.join(GOLD, "numutils.npz"), **out)
-    print("numutils goldens:", len(out), "arrays")
-
-
 def main():
     import argparse
     ap = argparse.ArgumentParser()
@@ -544,7 +518,6 @@ def main():
                 regions[f"{r}|{kind}|n"] = np.int64(p["n"])
     np.savez_compressed(os.path.join(GOLD, "regions.npz"), **regions)
     callback_goldens(ref, coolers, index)
-    numutils_goldens()
     with open(os.path.join(GOLD, "index.json"), "w") as f:
         json.dump(index, f, indent=0)
     # the reference's own small test data files (data, not source) used by the KAT scenarios

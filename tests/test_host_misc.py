@@ -48,27 +48,6 @@ def test_slice_call_partitions_every_segment():
     assert sorted(np.concatenate(seen).tolist()) == list(range(n))
 
 
-def test_score_utilities_match_the_reference():
-    """lib/numutils.py + puputils.get_score against values the reference's own functions produced."""
-    import os
-    import golden_util as gu
-    from coolpuppy_amd.lib import numutils as nu, puputils as pu
-    z = np.load(os.path.join(gu.GOLD, "numutils.npz"))
-    for k in range(3):
-        a = z[f"in{k}"]
-        np.testing.assert_allclose(nu.corner_cv(a, 4), z[f"corner_cv{k}"], rtol=1e-13)
-        np.testing.assert_allclose(nu.norm_cis(a.copy(), 3), z[f"norm_cis{k}"], rtol=1e-13, equal_nan=True)
-        np.testing.assert_allclose([nu.get_enrichment(a, 1), nu.get_enrichment(a, 3), nu.get_enrichment(a, 5)],
-                                   z[f"enrichment{k}"], rtol=1e-13)
-        np.testing.assert_allclose(nu.get_local_enrichment(a, 1), z[f"local_enrichment{k}"], rtol=1e-13)
-        np.testing.assert_allclose(nu.get_domain_score(a, 1), z[f"domain_score{k}"], rtol=1e-13)
-        np.testing.assert_allclose([nu.get_insulation_strength(a.copy(), 0), nu.get_insulation_strength(a.copy(), 3, 0)],
-                                   z[f"insulation{k}"], rtol=1e-13)
-        np.testing.assert_array_equal(nu._copy_array_halves(a[:5].copy()), z[f"halves{k}"])
-        got = [pu.get_score({"data": a.copy(), "local": loc, "rescale": rs, "rescale_flank": 1})
-               for loc, rs in ((False, False), (True, False), (True, True))]
-        np.testing.assert_allclose(got, z[f"score{k}"], rtol=1e-13)
-
 
 def test_block_order_groups_snippets_by_tile_and_block():
     """PileupEngine.block_order (host helper, no GPU): tile-major, then (65 - W)^2 blocks of corners anchored at
