@@ -72,18 +72,85 @@ def test_read_cool_roundtrip(tmp_path, group, monkeypatch):
     assert got.extent(("chr2", 0, 6_500_000)) == clr.extent(("chr2", 0, 6_500_000))
 
 
-def test_clpy_roundtrip(tmp_path, monkeypatch):
-    """.clpy writer / reader in the reference's layout — runs only where h5sparse and PyTables are installed."""
-    pytest.importorskip("h5sparse")
-    pytest.importorskip("tables")
+H5PY_CLPY_READER = r'''
+import sys, json, numpy as np, h5py
+with h5py.File(sys.argv[1], "r") as f:
+    d = f["data"]
+    rep = {"dtype": str(d.dtype), "shape": list(d.shape), "chunks": list(d.chunks), "compression": d.compression,
+           "attrs": {k: (v if isinstance(v, str) else np.asarray(v).tolist()) for k, v in f["attrs"].attrs.items()},
+           "groups": sorted(f.keys()),
+           "manifest": json.loads(f["annotation"].attrs["columns"]),
+           "hs_format": f["horizontal_stripe_0"].attrs["h5sparse_format"],
+           "hs_shape": np.asarray(f["horizontal_stripe_0"].attrs["h5sparse_shape"]).tolist(),
+           "coord0": [x.decode() if isinstance(x, bytes) else x for x in f["coordinates_0"][0]]}
+    np.savez(sys.argv[2], data=d[...], hs_data=f["horizontal_stripe_0/data"][...], hs_indices=f["horizontal_stripe_0/indices"][...],
+             hs_indptr=f["horizontal_stripe_0/indptr"][...])
+    print(json.dumps(rep))
+'''
+
+
+def _stripes_frame(monkeypatch):
     import golden_util as gu
     from coolpuppy_amd import coolpup
-    from coolpuppy_amd.lib import io as pio
     monkeypatch.setattr(coolpup.PileUpper, "run_plan", gu.oracle_run_plan)
-    z, df = gu.run("G11_stripes_raw", coolpup.pileup)
+    return gu.run("G11_stripes_raw", coolpup.pileup)[1]
+
+
+def test_clpy_roundtrip(tmp_path, monkeypatch):
+    """.clpy written through libhdf5/ctypes and read back by the own reader: every column of the frame survives —
+    data as float32, stripes with their NaNs and zeros, coordinates, annotation columns of every kind, metadata."""
+    from coolpuppy_amd.lib import io as pio
+    df = _stripes_frame(monkeypatch)
+    df["score"] = np.arange(len(df)) * 0.5
+    df["flag"] = [bool(i % 2) for i in range(len(df))]
+    df["pair"] = [(i, "x") for i in range(len(df))]
     path = str(tmp_path / "out.clpy")
-    pio.save_pileup_df(path, df, metadata={"features": "x.bed", "view_file": None})
+    pio.save_pileup_df(path, df, metadata={"features": "x.bed", "view_file": None, "nshifts": 0, "expected": False, "run_id": 40000})
     back = pio.load_pileup_df(path)
-    assert len(back) == len(df) and back["features"].iloc[0] == "x.bed"
-    np.testing.assert_allclose(back["data"].iloc[0], df["data"].iloc[0].astype(np.float32), rtol=0, atol=0, equal_nan=True)
-    np.testing.assert_allclose(back["horizontal_stripe"].iloc[0], np.nan_to_num(df["horizontal_stripe"].iloc[0]))
+    assert len(back) == len(df)
+    assert back["features"].iloc[0] == "x.bed" and not back["view_file"].iloc[0] and back["run_id"].iloc[0] == 40000
+    for i in range(len(df)):
+        np.testing.assert_array_equal(back["data"].iloc[i], df["data"].iloc[i].astype(np.float32))
+        np.testing.assert_array_equal(back["horizontal_stripe"].iloc[i], np.asarray(df["horizontal_stripe"].iloc[i], float))
+        np.testing.assert_array_equal(back["vertical_stripe"].iloc[i], np.asarray(df["vertical_stripe"].iloc[i], float))
+        np.testing.assert_array_equal(back["coordinates"].iloc[i], np.asarray(df["coordinates"].iloc[i]).astype("U13"))
+        np.testing.assert_array_equal(back["num"].iloc[i], df["num"].iloc[i])
+    for col in df.columns:
+        if col not in ("data", "horizontal_stripe", "vertical_stripe", "coordinates", "num"):
+            assert list(back[col]) == list(df[col]) or np.array_equal(back[col].values, df[col].values, equal_nan=True), col
+    assert back["pair"].iloc[0] == (0, "x") and back["flag"].dtype == bool
+    lst = pio.load_pileup_df_list([path, path], skipstripes=True)
+    assert len(lst) == 2 * len(df) and set(lst["norm"]) == {"none"} and "horizontal_stripe" not in lst.columns
+    with pytest.raises(ValueError):
+        pio.save_pileup_df(path, df, compression="lzf")
+
+
+@pytest.mark.skipif(not os.path.exists(CONDA_PY), reason="needs the image's conda python with h5py")
+def test_clpy_read_by_h5py(tmp_path, monkeypatch):
+    """The same file opened by an independent HDF5 stack (h5py in the conda interpreter): /data float32 [(rows*W), W]
+    in (W, W) gzip chunks, /attrs with version, h5sparse CSR stripe groups, string coordinates, annotation manifest."""
+    import json
+    from coolpuppy_amd import __version__
+    from coolpuppy_amd.lib import io as pio
+    df = _stripes_frame(monkeypatch)
+    path, dump = str(tmp_path / "out.clpy"), str(tmp_path / "dump.npz")
+    pio.save_pileup_df(path, df, metadata={"features": "x.bed", "view_file": None, "run_id": 40000})
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PYTHON")}
+    r = subprocess.run([CONDA_PY, "-c", H5PY_CLPY_READER, path, dump], capture_output=True, text=True, env=env, timeout=300)
+    if r.returncode != 0 and "No module named" in r.stderr:
+        pytest.skip("h5py not importable in the conda interpreter")
+    assert r.returncode == 0, r.stderr
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    w = df["data"].iloc[0].shape[0]
+    assert rep["dtype"] == "float32" and rep["shape"] == [w * len(df), w] and rep["chunks"] == [w, w] and rep["compression"] == "gzip"
+    assert rep["attrs"]["version"] == __version__ and rep["attrs"]["features"] == "x.bed" and rep["attrs"]["view_file"] in (0, False)
+    assert rep["attrs"]["run_id"] == 40000
+    assert {"annotation", "attrs", "data", "coordinates_0", "horizontal_stripe_0", "vertical_stripe_0"} <= set(rep["groups"])
+    assert rep["hs_format"] == "csr" and rep["hs_shape"] == list(np.asarray(df["horizontal_stripe"].iloc[0]).shape)
+    assert rep["coord0"] == [str(x) for x in np.asarray(df["coordinates"].iloc[0])[0]]
+    assert [c["name"] for c in rep["manifest"]] == [c for c in df.columns if c not in ("data", "horizontal_stripe", "vertical_stripe", "coordinates")]
+    z = np.load(dump)
+    np.testing.assert_array_equal(z["data"][:w], df["data"].iloc[0].astype(np.float32))
+    from scipy import sparse
+    hs = sparse.csr_matrix((z["hs_data"], z["hs_indices"], z["hs_indptr"]), shape=rep["hs_shape"]).toarray()
+    np.testing.assert_array_equal(hs, np.asarray(df["horizontal_stripe"].iloc[0], float))
