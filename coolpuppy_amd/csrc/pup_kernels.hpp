@@ -1670,7 +1670,7 @@ __global__ __launch_bounds__(1024) void pileup_rescale_kernel(K1Args a, const in
             }
             return v;
         };
-        // ---- does the window hold any non-NaN cell?  (masks only; with expected also the expected's validity) ----
+        // ---- does the window hold any non-NaN cell? ----
         bool all_nan;
         if (m_exp) {
             all_nan = true;
@@ -1682,13 +1682,17 @@ __global__ __launch_bounds__(1024) void pileup_rescale_kernel(K1Args a, const in
             for (int j = w - 1; j >= 0 && jmax < 0; --j) if (!bin_bad(a, cs + j)) jmax = j;
             all_nan = imin < 0 || jmax < 0 || (igd >= 0 && (cs + jmax) - (rs + imin) < igd);
             if (!all_nan && m_ooe) {
-                // some unmasked diagonal must carry a usable expected value
-                bool any = false;
-                const long long dlo = igd >= 0 ? (igd > (long long)(cs - rs) - (h - 1) ? igd : (long long)(cs - rs) - (h - 1))
-                                               : (long long)(cs - rs) - (h - 1);
-                const long long dhi = (long long)(cs - rs) + (w - 1);
-                for (long long d = dlo; d <= dhi && !any; ++d) { const double e = es.at(d < 0 ? -d : d); if (e == e) any = true; }
-                all_nan = !any;
+                // data / expected: a cell is NaN when masked, when its expected is NaN, and when it is 0 / 0.  If every
+                // expected value on the window's diagonals is usable and non-zero, any unmasked cell is a number;
+                // otherwise the workgroup looks at the cells themselves (reference :1213 tests np.all(np.isnan(data)))
+                bool e_good = true;
+                const long long dlo = (long long)(cs - rs) - (h - 1), dhi = (long long)(cs - rs) + (w - 1);
+                for (long long d = dlo; d <= dhi && e_good; ++d) { const double e = es.at(d < 0 ? -d : d); if (!(e == e) || e == 0.0) e_good = false; }
+                if (!e_good) {
+                    int found = 0;
+                    for (int t = tid; t < h * w && !found; t += nthr) { const int i = t / w; const double v = cell(i, t - i * w); if (v == v) found = 1; }
+                    all_nan = !__syncthreads_or(found);          // h, w, e_good are uniform over the workgroup
+                }
             }
         }
         const int mh = S < h ? (h + S - 1) / S : 1, mw = S < w ? (w + S - 1) / S : 1;
@@ -1750,8 +1754,9 @@ __global__ __launch_bounds__(1024) void pileup_rescale_kernel(K1Args a, const in
                 for (int d = 0; d < m; ++d) {
                     const double y = __dmul_rn((double)(A * m + d), sc);
                     if (y > (double)(n_in - 1)) continue;
-                    const int i0 = (int)y; const double tt = y - (double)i0; const int i1 = i0 + 1 < n_in ? i0 + 1 : n_in - 1;
-                    accv += a.cov[base + i0] * (1.0 - tt) + (tt > 0.0 ? a.cov[base + i1] * tt : 0.0);
+                    const int i0 = (int)y; const double tt = y - (double)i0;
+                    // both taps are always evaluated (scipy: NaN * 0 = NaN); a tap past the end is the constant 0
+                    accv += a.cov[base + i0] * (1.0 - tt) + (i0 + 1 < n_in ? a.cov[base + i0 + 1] * tt : 0.0);
                 }
                 accv /= (double)m;
                 if (emitting) { if (emit_cov) emit_cov[(size_t)s * 2 * S + t] = accv; }

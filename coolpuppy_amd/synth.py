@@ -171,3 +171,20 @@ def random_trans_pairs(clr, n_pairs, seed=43):
     names = np.array(clr.chromnames, dtype=object)
     return pd.DataFrame({"chrom1": names[c1], "start1": s1, "end1": s1 + res,
                          "chrom2": names[c2], "start2": s2, "end2": s2 + res})
+
+
+def patched_cooler(clr, patch):
+    """A copy of the in-memory cooler `clr` with some bins columns overwritten: patch = {column: {value_name: [bins]}},
+    value_name one of "nan", "inf", "-inf", "zero" (JSON-friendly: golden scenarios store the patch in their meta)."""
+    from .cooler_lite import ArrayCooler
+    vals = {"nan": np.nan, "inf": np.inf, "-inf": -np.inf, "zero": 0.0}
+    cols = {}
+    for c in ("weight", "cov_tot_raw", "cov_cis_raw"):
+        try:
+            cols[c] = np.array(clr.bins()[c][:].values, dtype=np.float64)
+        except KeyError:
+            pass
+    for col, edits in (patch or {}).items():
+        for what, where in edits.items():
+            cols[col][np.asarray(where, dtype=np.int64)] = vals[what]
+    return ArrayCooler(clr.chromsizes, clr.binsize, clr.bin1_offset, clr.bin2_id, clr.count, bins=cols, filename=clr.filename)

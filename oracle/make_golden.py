@@ -142,8 +142,9 @@ def scenarios():
 
     S = []
 
-    def add(name, cooler, features, view=None, expected=None, **kw):
-        S.append({"name": name, "cooler": cooler, "features": features, "view": view, "expected": expected, "kw": kw})
+    def add(name, cooler, features, view=None, expected=None, patch=None, **kw):
+        S.append({"name": name, "cooler": cooler, "features": features, "view": view, "expected": expected, "kw": kw,
+                  "patch": patch})
 
     base = dict(features_format="bedpe", flank=100_000)
     add("G1_bedpe_balanced", "small", bedpe, **base)
@@ -174,6 +175,16 @@ def scenarios():
     add("G7c_trans_bedpe_controls", "small", trans_bedpe(clr, 120, 13), features_format="bedpe", trans=True,
         nshifts=2, seed=6, flank=100_000)
     add("G8_exp_zero_inf", "small", bedpe, expected=exp_zero, **base)
+    # +inf cells (expected == 0 under a pixel) in the SAME cells of several regions: sum_pups' nan_to_num makes the merged
+    # value depend on which regions held the inf (lib/puputils.py:97-98); ungrouped, grouped, and with a 4-region view
+    exp_zero_all = exp_chrom.copy()
+    exp_zero_all.loc[(exp_zero_all.dist >= 28) & (exp_zero_all.dist <= 52), "balanced.avg"] = 0.0
+    exp_zero_view = exp_view.copy()
+    exp_zero_view.loc[(exp_zero_view.dist >= 28) & (exp_zero_view.dist <= 52), "balanced.avg"] = 0.0
+    add("G8c_inf_in_several_regions", "small", bedpe, expected=exp_zero_all, **base)
+    add("G8d_inf_in_several_regions_by_strand", "small", bedpe, expected=exp_zero_all, by_strand=True, **base)
+    add("G8e_inf_in_several_regions_view_distance", "small", bedpe, view=view_sub, expected=exp_zero_view, by_distance=True,
+        **base)
     add("G8b_pad3_mindist0", "small", bedpe, features_format="bedpe", flank=30_000, mindist=0, maxdist=2_000_000)
     add("G9_bed_combinations", "small", bed, features_format="bed", flank=100_000, mindist=300_000,
         maxdist=2_500_000)
@@ -212,6 +223,30 @@ def scenarios():
         rescale_flank=1, rescale_size=33, expected=exp_chrom, store_stripes=True)
     add("G12h_rescale_bedpe_stripes_controls", "small", bedpe.iloc[:100], features_format="bedpe", rescale=True,
         rescale_flank=2, rescale_size=15, nshifts=1, seed=23, flank=100_000, store_stripes=True)
+    # rescaled windows that are NaN everywhere because every cell is 0 / 0 (expected == 0 where there is no pixel): the
+    # reference returns a window of zeros for them (coolpup.py:1213-1214); windows holding a pixel there give inf
+    exp_zero_far = exp_chrom.copy()
+    exp_zero_far.loc[exp_zero_far.dist >= 60, "balanced.avg"] = 0.0
+    add("G12i_rescale_bedpe_zero_over_zero", "small", bedpe.iloc[:200], features_format="bedpe", rescale=True,
+        rescale_flank=1, rescale_size=9, expected=exp_zero_far, flank=100_000)
+    # NaN in the coverage column: zoom_array multiplies it by interpolation weight 0 as well (NaN, not 0)
+    nb_small = int(clr.bin1_offset.shape[0] - 1)
+    cov_nan_bins = sorted(int(x) for x in np.random.default_rng(31).choice(nb_small, 260, replace=False))
+    add("G12j_rescale_local_covnorm_nan_coverage", "small", tads, features_format="bed", local=True, rescale=True,
+        rescale_flank=1, rescale_size=33, clr_weight_name=None, coverage_norm=True, min_diag=0,
+        patch={"cov_tot_raw": {"nan": cov_nan_bins}})
+    add("G2c_raw_covnorm_nan_coverage", "small", bedpe, clr_weight_name=None, coverage_norm="total",
+        patch={"cov_tot_raw": {"nan": cov_nan_bins}}, **base)
+    # weights that are +inf, and zero weights beside them: balanced pixels become inf / NaN, which the reference leaves
+    # out of `num` cell by cell (np.isfinite) while empty cells of the same rows still count
+    wrng = np.random.default_rng(37)
+    w_inf = sorted(int(x) for x in wrng.choice(nb_small, 40, replace=False))
+    w_zero = sorted(set(int(x) + int(d) for x in w_inf[:25] for d in (-3, 2, 7) if 0 <= int(x) + int(d) < nb_small) - set(w_inf))
+    add("G14_inf_and_zero_weights", "small", bedpe, patch={"weight": {"inf": w_inf, "zero": w_zero}}, **base)
+    add("G14b_inf_weights_expected_by_strand", "small", bedpe, patch={"weight": {"inf": w_inf, "zero": w_zero}},
+        expected=exp_chrom, by_strand=True, **base)
+    add("G14c_inf_weights_local", "small", bed, features_format="bed", local=True, flank=100_000,
+        patch={"weight": {"inf": w_inf, "zero": w_zero}})
     # ---- randomised option combinations (seeded): interactions no hand-written scenario happens to cover ----------
     frng = np.random.default_rng(20240928)
     for k in range(32):
@@ -429,7 +464,8 @@ def main():
 
     streams, index = {}, []
     for sc in S:
-        clr = refshim.ShimCooler(coolers[sc["cooler"]])
+        clr = refshim.ShimCooler(synth.patched_cooler(coolers[sc["cooler"]], sc["patch"]) if sc.get("patch")
+                                 else coolers[sc["cooler"]])
         kw = dict(sc["kw"])
         if isinstance(kw.get("by_distance"), list):
             kw["by_distance"] = np.array(kw["by_distance"])
@@ -447,6 +483,8 @@ def main():
         rec = record(df, W)
         meta = {"name": sc["name"], "cooler": sc["cooler"], "kw": sc["kw"], "features": csv_text(sc["features"]),
                 "view": csv_text(sc["view"]), "expected": csv_text(sc["expected"])}
+        if sc.get("patch"):
+            meta["patch"] = sc["patch"]
         rec["meta"] = json.dumps(meta)
         np.savez_compressed(os.path.join(GOLD, sc["name"] + ".npz"), **rec)
         index.append(sc["name"])

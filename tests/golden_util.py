@@ -27,6 +27,18 @@ def cooler(name):
     return _coolers[name]
 
 
+def scenario_cooler(meta):
+    """The scenario's cooler: a stored one, with the bins-column patch of the scenario (if any) applied."""
+    base = cooler(meta["cooler"])
+    if not meta.get("patch"):
+        return base
+    from coolpuppy_amd import synth
+    key = meta["cooler"] + "|" + json.dumps(meta["patch"], sort_keys=True)
+    if key not in _coolers:
+        _coolers[key] = synth.patched_cooler(base, meta["patch"])
+    return _coolers[key]
+
+
 def load(name):
     z = np.load(os.path.join(GOLD, name + ".npz"))
     meta = json.loads(str(z["meta"]))
@@ -55,7 +67,7 @@ def run(name, pileup_func):
     z, meta, features, view, expected, kw = load(name)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        df = pileup_func(cooler(meta["cooler"]), features, view_df=view, expected_df=expected, **kw)
+        df = pileup_func(scenario_cooler(meta), features, view_df=view, expected_df=expected, **kw)
     return z, df
 
 
