@@ -1071,9 +1071,30 @@ class PileUpper:
 
         return self._pile_and_finalize(batches, groupby, grouped=bool(groupby) or _by_window)
 
-    def make_plan(self, batches, groupby, grouped=None):
+    def region_groups(self, b, grouped):
+        """Group keys of one region's windows, per kind, in order of first appearance (without "all"); None for a
+        region that yields no window.  This is all the global group table needs to know about a region — under
+        multi-GPU sharding it is what the ranks exchange about the regions they own."""
+        if b is None or b["n"] == 0:
+            return None
+        exp_as_control = bool(self.expected) and not self.ooe
+        want_control = bool(self.control) or exp_as_control
+        out = {KIND_ROI: [], KIND_CONTROL: []}
+        if grouped:
+            for kind in (KIND_ROI, KIND_CONTROL):
+                if kind == KIND_CONTROL and not want_control:
+                    continue
+                # with expected & !ooe every ROI snippet also emits an expected ("control") snippet
+                sel = b["kind"] == (KIND_ROI if (exp_as_control and kind == KIND_CONTROL) else kind)
+                out[kind] = [b["group_keys"][c] for c in pd.unique(b["group_codes"][sel])]
+        return out
+
+    def make_plan(self, batches, groupby, grouped=None, region_groups=None):
         """Turn per-region window tables into a declarative list of engine calls plus the group bookkeeping
-        the finaliser needs.  Pure host code (no GPU): tests replay a plan on the CPU oracle."""
+        the finaliser needs.  Pure host code (no GPU): tests replay a plan on the CPU oracle.
+
+        region_groups: per batch, what region_groups() returns for it — given when some batches are held by other
+        ranks (their entry in `batches` is then (region1, region2, None)); computed here otherwise."""
         from .engine import MODE_COV, MODE_EXPECTED, MODE_OOE, MODE_TRANSPOSE
         MODE_LOCAL = 0x20
         rescale = bool(getattr(self, "rescale", False))
@@ -1083,25 +1104,20 @@ class PileUpper:
         # groups in snippet order, then "all" (coolpup.py:1263-1283, 1511-1531)
         exp_as_control = bool(self.expected) and not self.ooe
         want_control = bool(self.control) or exp_as_control
+        if region_groups is None:
+            region_groups = [self.region_groups(b, grouped) for _, _, b in batches]
         order = {KIND_ROI: [], KIND_CONTROL: []}
         seen = {KIND_ROI: set(), KIND_CONTROL: set()}
-        contrib = {KIND_ROI: {}, KIND_CONTROL: {}}     # key -> number of regions holding it (sum_pups quirks)
 
         def note(kind, key):
             if key not in seen[kind]:
                 seen[kind].add(key)
                 order[kind].append(key)
-            contrib[kind][key] = contrib[kind].get(key, 0) + 1
 
-        for _, _, b in batches:
-            if b is not None and b["n"] > 0 and grouped:
-                for kind in (KIND_ROI, KIND_CONTROL):
-                    # with expected & !ooe every ROI snippet also emits an expected ("control") snippet
-                    sel = b["kind"] == (KIND_ROI if (exp_as_control and kind == KIND_CONTROL) else kind)
-                    if kind == KIND_CONTROL and not want_control:
-                        continue
-                    for c in pd.unique(b["group_codes"][sel]):
-                        note(kind, b["group_keys"][c])
+        for rg in region_groups:
+            for kind in (KIND_ROI, KIND_CONTROL):
+                for key in (rg[kind] if rg is not None else ()):
+                    note(kind, key)
             note(KIND_ROI, "all")
             if want_control:
                 note(KIND_CONTROL, "all")
@@ -1128,7 +1144,7 @@ class PileUpper:
                     exp_table = {"names": names, "start": starts, "end": ends, "pair": None,
                                  "vectors": [self._expected_vectors[k] for k in names]}
         raw = []
-        for region1, region2, b in batches:
+        for bi, (region1, region2, b) in enumerate(batches):
             if b is None or b["n"] == 0:
                 continue
             if grouped:
@@ -1151,11 +1167,11 @@ class PileUpper:
             loc = MODE_LOCAL if (rescale and self.local) else 0
             mode = (MODE_OOE if (self.expected and self.ooe) else 0) | (MODE_COV if self.coverage_norm else 0) | tr | loc
             raw.append((region1, region2, expected, r0, c0, b["flip"], b["kind"].astype(np.int32) * np.int32(G) + g,
-                        igd, mode, hh, ww))
+                        igd, mode, hh, ww, bi))
             if exp_as_control:
                 roi = b["kind"] == KIND_ROI
                 raw.append((region1, region2, expected, r0[roi], c0[roi], b["flip"][roi], G + g[roi], igd,
-                            MODE_EXPECTED | tr | loc, hh[roi], ww[roi]))
+                            MODE_EXPECTED | tr | loc, hh[roi], ww[roi], bi))
         # regions that need no per-region state (no expected vector) and share mode / diagonal mask go to the
         # engine as ONE call: fewer launches, and the engine's interleaved groups span region boundaries
         stripe_jobs = []
@@ -1195,17 +1211,18 @@ class PileUpper:
                 merged.append([item, [fields]])
         calls = [_engine_call_parts(head[0], head[1], head[2], parts, T, head[7], head[8], rescale)
                  for head, parts in merged]
-        return {"T": T, "G": G, "gid": gid, "order": order, "contrib": contrib, "want_control": want_control,
+        return {"T": T, "G": G, "gid": gid, "order": order, "want_control": want_control,
                 "groupby": list(groupby), "grouped": bool(grouped), "calls": calls,
                 "pad": (self.rescale_size - 1) // 2 if rescale else self.pad_bins, "rescale": rescale,
-                "n_regions": len(batches),
+                "n_regions": len(batches), "region_groups": region_groups, "region_items": raw,
                 "expected_table": exp_table, "stripe_jobs": stripe_jobs,
                 "weight_name": self.clr_weight_name if self.clr_weight_name else None,
                 "cov_name": self.coverage_norm if self.coverage_norm else None}
 
-    def run_plan(self, plan):
-        """Execute a plan on this process's GPU (calls sharded over ranks when torch.distributed is
-        initialised, then one all-reduce of the packed accumulators) and fetch the tiles."""
+    def run_plan(self, plan, calls=None, reduce=True):
+        """Execute a plan on this process's GPU (its calls hold the regions this rank owns; with several ranks one
+        all-reduce of the packed accumulators follows) and fetch the tiles.  calls / reduce=False: run just these
+        calls of the plan and return this process's own tiles (per-region tiles for the inf merge rule)."""
         from . import dist as _dist
         eng = _engine_for(self._aclr, _dist.local_device())
         bins = self.clr.bins()
@@ -1215,8 +1232,7 @@ class PileUpper:
         rank, world = _dist.world()
         et = plan.get("expected_table")
         table_set = False
-        for c in plan["calls"]:
-            c = _dist.slice_call(c, rank, world)          # every rank takes an even share of every tile segment
+        for c in (plan["calls"] if calls is None else calls):
             if len(c["r0"]) == 0:
                 continue
             if isinstance(c["expected"], str):
@@ -1232,6 +1248,8 @@ class PileUpper:
             else:
                 eng.accumulate(c["r0"], c["c0"], c["tile_ptr"], flip_from=c["flip_from"],
                                ignore_diags=c["ignore_diags"], mode=c["mode"])
+        if not reduce:
+            return eng.fetch()
         _dist.allreduce_engine(eng)
         acc = eng.fetch()
         if plan.get("stripe_jobs"):
@@ -1264,9 +1282,61 @@ class PileUpper:
                     a = kind * G + gid["all"]
                     for name in ("sum", "num", "n", "cov_start", "cov_end"):
                         acc[name][a] = acc[name][members].sum(axis=0)
+        self._merge_inf_cells(plan, acc)
         stripes = _collect_stripes(plan, acc) if plan.get("stripe_jobs") else None
-        return finalize_pileups(self, acc, order, plan["contrib"], gid, G, plan["groupby"], plan["want_control"],
-                                n_regions=plan["n_regions"], grouped=plan["grouped"], stripes=stripes)
+        return finalize_pileups(self, acc, order, gid, G, plan["groupby"], plan["want_control"],
+                                grouped=plan["grouped"], stripes=stripes)
+
+    def _merge_inf_cells(self, plan, acc):
+        """Cells that hold +inf (a pixel over expected == 0) follow the reference's merge arithmetic instead of plain
+        addition: every merge of two pile-ups passes both through nan_to_num first (sum_pups, lib/puputils.py:97-98), so
+        inf becomes the largest double, two of those add up to inf again, and the value of the cell depends on WHICH
+        regions — and, in a grouped pile-up, which groups of a region (their fold into "all" also rewrites the groups'
+        own tiles, coolpup.py:1271-1282) — held an inf, in order.  Replayed here on per-region tiles, which the engine
+        piles up again region by region; only cells touched by an inf are replaced, everything else keeps the
+        one-pass sums.  Rare (needs expected == 0 under a non-zero pixel), so the second pass is off the fast path."""
+        S = acc["sum"]
+        if not np.isinf(S).any():
+            return
+        from . import dist as _dist
+        G, gid, T = plan["G"], plan["gid"], plan["T"]
+        nreg = plan["n_regions"]
+        items = {}
+        for it in plan["region_items"]:
+            items.setdefault(it[11], []).append(it)
+        if nreg == 1:
+            per = {bi: S.copy() for bi in items}
+        else:
+            per = {}
+            for bi, its in items.items():
+                calls = [_engine_call_parts(it[0], it[1], it[2], [(it[3], it[4], it[5], it[6], it[9], it[10])], T, it[7],
+                                            it[8], plan["rescale"]) for it in its]
+                per[bi] = self.run_plan(plan, calls=calls, reduce=False)["sum"]
+            per = _dist.merge_dicts(per)                       # regions piled up by other ranks
+        nn = np.nan_to_num
+        zero = np.zeros_like(S[0])
+        for kind in (KIND_ROI, KIND_CONTROL):
+            if kind == KIND_CONTROL and not plan["want_control"]:
+                continue
+            state = {}
+            for bi in range(nreg):
+                D, rg = per.get(bi), plan["region_groups"][bi]
+                keys = rg[kind] if rg is not None else []
+                tiles = {}
+                if plan["grouped"]:
+                    run = zero
+                    for k in keys:
+                        tiles[k] = nn(D[kind * G + gid[k]])
+                        run = nn(run) + tiles[k]
+                    tiles["all"] = run
+                else:
+                    tiles["all"] = D[kind * G + gid["all"]] if D is not None else zero
+                for k, d in tiles.items():
+                    state[k] = d if k not in state else nn(state[k]) + nn(d)
+            for k, d in state.items():
+                t = kind * G + gid[k]
+                fix = np.isinf(S[t]) | ~np.isfinite(d)
+                S[t][fix] = d[fix]
 
     def _pile_and_finalize(self, batches, groupby, grouped=None):
         plan = self.make_plan(batches, groupby, grouped=grouped)
@@ -1663,16 +1733,22 @@ def iter_expected_subcalls(plan, call):
 
 
 def _tiles_to_pups(plan, acc):
+    """Tiles of ONE region as the reference's pileup_region dict.  In a grouped pile-up the fold of the groups into
+    "all" (reduce(sum_pups), coolpup.py:1271-1282) passes every tile through nan_to_num — the groups' own included."""
     G, gid, order = plan["G"], plan["gid"], plan["order"]
-    if plan["grouped"]:
-        for kind in (KIND_ROI, KIND_CONTROL):
-            members = [kind * G + gid[k] for k in order[kind] if not (isinstance(k, str) and k == "all")]
-            if members:
-                a = kind * G + gid["all"]
-                for name in ("sum", "num", "n", "cov_start", "cov_end"):
-                    acc[name][a] = acc[name][members].sum(axis=0)
     out = {"ROI": {}, "control": {}}
     for kind, label in ((KIND_ROI, "ROI"), (KIND_CONTROL, "control")):
+        members = [k for k in order[kind] if not (isinstance(k, str) and k == "all")]
+        if plan["grouped"] and members:
+            a = kind * G + gid["all"]
+            run = np.zeros_like(acc["sum"][a])
+            for k in members:
+                t = kind * G + gid[k]
+                acc["sum"][t] = np.nan_to_num(acc["sum"][t])
+                run = np.nan_to_num(run) + acc["sum"][t]
+            acc["sum"][a] = run
+            for name in ("num", "n", "cov_start", "cov_end"):
+                acc[name][a] = acc[name][[kind * G + gid[k] for k in members]].sum(axis=0)
         for key in order[kind]:
             t = kind * G + gid[key]
             out[label][key] = {"data": acc["sum"][t].copy(), "num": acc["num"][t].copy(), "n": int(acc["n"][t]),

@@ -90,6 +90,20 @@ def slice_call(call, rank, world_size):
     return out
 
 
+def merge_dicts(mine):
+    """Union over all ranks of per-rank dicts with disjoint keys (small control-plane objects: group keys of the
+    regions a rank owns, per-region tiles of the rare inf merge) — identical on every rank afterwards."""
+    d = _dist()
+    if d is None or d.get_world_size() == 1:
+        return mine
+    parts = [None] * d.get_world_size()
+    d.all_gather_object(parts, mine)
+    out = {}
+    for p in parts:
+        out.update(p)
+    return out
+
+
 def allreduce_arrays(f64, i64):
     """Sum a float64 and an int64 numpy array over all ranks (in place where possible); returns both."""
     d = _dist()

@@ -145,19 +145,14 @@ def norm_coverage(snip):
     return snip
 
 
-def _tile_frame(acc, kind, order, contrib, gid, G, grouped):
-    """DataFrame indexed by group key (first-appearance order) with the summed tile of each group."""
+def _tile_frame(acc, kind, order, gid, G):
+    """DataFrame indexed by group key (first-appearance order) with the summed tile of each group.  (What sum_pups'
+    nan_to_num does to +inf cells when pile-ups are merged has been applied to acc["sum"] already,
+    PileUpper._merge_inf_cells.)"""
     rows = {}
     for key in order[kind]:
         t = kind * G + gid[key]
-        data = acc["sum"][t].copy()
-        # sum_pups() passes data through nan_to_num whenever >= 2 pile-ups are merged: +inf becomes the
-        # largest double (lib/puputils.py:97-98).  A group held by a single region is never merged; the
-        # "all" row of a grouped pile-up always is (coolpup.py:1271-1282).
-        merged = contrib[kind].get(key, 0) >= 2 or (grouped and key == "all" and acc["n"][t] > 0)
-        if merged:
-            data = np.nan_to_num(data)
-        rows[key] = {"data": data, "num": acc["num"][t].copy(), "n": int(acc["n"][t]),
+        rows[key] = {"data": acc["sum"][t].copy(), "num": acc["num"][t].copy(), "n": int(acc["n"][t]),
                      "cov_start": acc["cov_start"][t].copy(), "cov_end": acc["cov_end"][t].copy()}
     df = pd.DataFrame(list(rows.values()), columns=["data", "num", "n", "cov_start", "cov_end"])
     df["n"] = df["n"].astype(object)     # the reference's frames hold Python ints in object columns
@@ -172,12 +167,12 @@ def _copy_array_halves(x):
     return x
 
 
-def finalize_pileups(pu, acc, order, contrib, gid, G, groupby, want_control, n_regions, grouped=None, stripes=None):
+def finalize_pileups(pu, acc, order, gid, G, groupby, want_control, grouped=None, stripes=None):
     """Tail of pileupsWithControl (coolpup.py:1533-1654) on summed tiles -> annotated DataFrame."""
     if grouped is None:
         grouped = bool(groupby)
-    roi = _tile_frame(acc, KIND_ROI, order, contrib, gid, G, grouped)
-    ctrl = _tile_frame(acc, KIND_CONTROL, order, contrib, gid, G, grouped) if want_control else None
+    roi = _tile_frame(acc, KIND_ROI, order, gid, G)
+    ctrl = _tile_frame(acc, KIND_CONTROL, order, gid, G) if want_control else None
     return _finalize_frames(pu, roi, ctrl, groupby, want_control, stripes)
 
 

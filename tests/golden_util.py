@@ -117,7 +117,7 @@ def compare(z, df, rtol):
             assert str(g) == str(v), f"column {c}: {g!r} != {v!r}"
 
 
-def oracle_run_plan(pu, plan):
+def oracle_run_plan(pu, plan, calls=None, reduce=True):
     """Replay a plan (list of engine calls) on the CPU oracle — CPU stand-in for PileUpper.run_plan in tests."""
     from oracle import pileup_oracle as po
     indptr, col, cnt = pu._aclr.pixel_table()
@@ -127,7 +127,7 @@ def oracle_run_plan(pu, plan):
     acc = po.empty_acc(plan["T"], plan["pad"])
     from coolpuppy_amd.coolpup import iter_expected_subcalls
     big = None
-    for call in plan["calls"]:
+    for call in (plan["calls"] if calls is None else calls):
         for expected, c in iter_expected_subcalls(plan, call):
             if plan.get("rescale"):
                 if big is None:
@@ -138,7 +138,7 @@ def oracle_run_plan(pu, plan):
                 continue
             po.pileup_c(indptr, col, cnt, weight, cov, expected, c["r0"], c["c0"], c["flip"], c["tile"],
                         plan["T"], plan["pad"], c["ignore_diags"], c["mode"], acc=acc)
-    if plan.get("stripe_jobs"):
+    if plan.get("stripe_jobs") and calls is None:
         acc["stripes"] = []
         for job in plan["stripe_jobs"]:
             fake = {"expected": job["expected"], "r0": job["r0"], "c0": job["c0"], "mode": job["mode"],
