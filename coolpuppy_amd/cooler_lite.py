@@ -145,13 +145,32 @@ def from_cooler(clr):
                        filename=clr.filename)
 
 
+_ADAPTED = {}          # id(cooler object) or path -> (weak reference to the object | mtime, ArrayCooler)
+
+
 def as_array_cooler(clr):
     """Return clr if it already exposes ``pixel_table()``; open it when it is a path / cooler URI
-    ("file.cool" or "file.mcool::resolutions/10000"); otherwise adapt a ``cooler.Cooler``."""
+    ("file.cool" or "file.mcool::resolutions/10000"); otherwise adapt a ``cooler.Cooler``.  The adapter of a given
+    cooler object (or unchanged file) is made once and kept, so that repeated pile-ups on it find the pixel table
+    already resident on the GPU (the engine cache is keyed on the adapter)."""
+    import weakref
     if hasattr(clr, "pixel_table"):
         return clr
     if isinstance(clr, (str, os.PathLike)):
         from .cool_io import read_cool
         path, _, group = str(clr).partition("::")
-        return read_cool(path, group=group or "/")
-    return from_cooler(clr)
+        stamp = (os.path.getmtime(path), os.path.getsize(path))
+        hit = _ADAPTED.get(str(clr))
+        if hit is None or hit[0] != stamp:
+            hit = _ADAPTED[str(clr)] = (stamp, read_cool(path, group=group or "/"))
+        return hit[1]
+    hit = _ADAPTED.get(id(clr))
+    if hit is not None and hit[0]() is clr:
+        return hit[1]
+    ac = from_cooler(clr)
+    try:
+        ref = weakref.ref(clr, lambda _r, k=id(clr): _ADAPTED.pop(k, None))
+    except TypeError:                   # not weak-referenceable: adapt every time
+        return ac
+    _ADAPTED[id(clr)] = (ref, ac)
+    return ac

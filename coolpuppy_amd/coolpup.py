@@ -211,6 +211,9 @@ class CoordCreator:
                 self.maxdist = np.inf
         self.local = local
         self.subset = subset
+        if seed is None and (nshifts > 0 or subset > 0):
+            from . import dist as _dist
+            seed = _dist.shared_seed(seed)   # several ranks must draw the same subset and control shifts
         self.seed = seed
         self.process()
 
@@ -371,15 +374,8 @@ class CoordCreator:
         df["kind"] = np.where(out["kind"] == KIND_ROI, "ROI", "control")
         return df
 
-    def _control_cols(self, cols, nshifts):
-        """Column-table form: returns ROI rows followed by nshifts shifted copies, with an int8 'kind'."""
-        n = len(cols)
-        if nshifts <= 0:
-            out = _Cols(cols)
-            out["kind"] = np.full(n, KIND_ROI, np.int8)
-            return out
-        ctrl = cols.tiled(nshifts)
-        m = n * nshifts
+    def _draw_shifts(self, m):
+        """The reference's RNG calls for m control windows (:420-436), in its order: (shift, shift2) in bp."""
         shift = np.random.randint(self.minshift, self.maxshift, m)
         sign = np.random.choice([-1, 1], m)
         shift *= sign
@@ -389,6 +385,23 @@ class CoordCreator:
             shift2 = shift2 * sign2
         else:
             shift2 = shift
+        return shift, shift2
+
+    def _control_cols(self, cols, nshifts):
+        """Column-table form: returns ROI rows followed by nshifts shifted copies, with an int8 'kind'."""
+        n = len(cols)
+        if nshifts <= 0:
+            out = _Cols(cols)
+            out["kind"] = np.full(n, KIND_ROI, np.int8)
+            return out
+        m = n * nshifts
+        if getattr(self, "_draw_only", False):
+            # a region another rank piles up: its windows are not needed here, the generator state after them is
+            if m:
+                self._draw_shifts(m)
+            return _Cols()
+        ctrl = cols.tiled(nshifts)
+        shift, shift2 = self._draw_shifts(m)
         for name in ("exp_start1", "exp_end1", "center1"):
             if name in ctrl:
                 ctrl[name] = ctrl[name] + shift
@@ -559,6 +572,33 @@ class CoordCreator:
         base = ["stBin1", "endBin1", "stBin2", "endBin2"]
         return base + [c for c in want if c not in base]
 
+    def skip_region(self, region1, region2=None, control=False):
+        """Advance the control-shift generator past one region (pair) exactly as generating its windows would, without
+        building them: every rank of a multi-GPU run walks all regions in order and draws-and-discards for the ones it
+        does not own, so the shifts of its own regions are those of the reference's single sequence (:387-453)."""
+        if not control or self.nshifts <= 0:
+            return
+        self._draw_only = True
+        try:
+            self.region_table(region1, region2, control=True, columns=())
+        finally:
+            self._draw_only = False
+
+    def region_weight(self, region1, region2=None):
+        """Cheap, deterministic estimate of the number of ROI windows of a region (pair): what the ranks balance."""
+        if len(self.intervals) == 0 or not hasattr(self, "kind"):
+            return 0
+        if self.kind == "bedpe":
+            rows = self._rows_trans_pairs(tuple(region1), tuple(region2)) if self.trans \
+                else self._rows_pairs_region(tuple(region1))
+            return len(rows)
+        nl = len(self._rows_region(tuple(region1)))
+        if self.local:
+            return nl
+        if region2 is None or tuple(region2) == tuple(region1):
+            return nl * (nl - 1) // 2
+        return nl * len(self._rows_region(tuple(region2)))
+
     def region_table(self, region1, region2=None, control=False, columns=()):
         """All windows of one region (pair) as a column table with 'kind' (0 ROI / 1 control).
 
@@ -626,6 +666,10 @@ class CoordCreator:
                 a = np.flatnonzero(ok)
                 if len(a) == 0:
                     continue                   # size-0 RNG draws do not advance the generator
+                if getattr(self, "_draw_only", False):
+                    if nshifts > 0:
+                        self._draw_shifts(len(a) * nshifts)
+                    continue
                 tbl = _Cols({**{kk: v[a] for kk, v in L.items()}, **{kk: v[a + i] for kk, v in R.items()}})
                 tbl["distance"] = dist[a]
                 parts.append(self._control_cols(tbl, nshifts))
@@ -716,12 +760,15 @@ def _make_viewframe(view_df, chromsizes):
 _ENGINES = {}
 
 
-def _engine_for(clr, device_id):
+def _engine_for(clr, device_id, rows=None):
     """One resident pixel table per (cooler object, device): repeated pile-ups skip the upload.
+    rows: sorted, disjoint (lo, hi) bin ranges — upload only the pixels of these rows (a rank of a multi-GPU run holds
+    the rows of the regions it owns; every other row is present but empty).
     COOLPUPPY_AMD_VARIANT (int, see pup_set_tuning) selects a kernel variant — used by the tests to run whole
     pileup() calls through a kernel the engine would not pick for inputs that small."""
     from .engine import PileupEngine
-    key = (id(clr), device_id)
+    rows = None if rows is None else tuple((int(a), int(b)) for a, b in rows)
+    key = (id(clr), device_id, rows)
     hit = _ENGINES.get(key)
     if hit is not None and hit[0] is clr:
         eng = hit[1]
@@ -729,11 +776,37 @@ def _engine_for(clr, device_id):
         for k in [k for k, v in _ENGINES.items() if k[1] == device_id]:   # one table per device at a time
             _ENGINES.pop(k)[1].close()
         eng = PileupEngine(device_id)
-        eng.load_pixels(*clr.pixel_table())
+        indptr, col, cnt = clr.pixel_table()
+        if rows is not None:
+            indptr, col, cnt = _rows_of_table(indptr, col, cnt, rows)
+        eng.load_pixels(indptr, col, cnt)
         eng.build_index(clr.chrom_offset)      # optional accelerator; False (too large) just means binary search
         _ENGINES[key] = (clr, eng)
     eng.set_tuning(0, int(os.environ.get("COOLPUPPY_AMD_VARIANT", "0") or 0))
     return eng
+
+
+def _rows_of_table(indptr, col, cnt, rows):
+    """The CSR table restricted to the given row ranges: same number of rows, the others empty."""
+    indptr = np.asarray(indptr, np.int64)
+    length = np.zeros(len(indptr) - 1, np.int64)
+    for lo, hi in rows:
+        length[lo:hi] = indptr[lo + 1:hi + 1] - indptr[lo:hi]
+    new_ptr = np.concatenate([[0], np.cumsum(length)]).astype(np.int64)
+    if not rows:
+        return new_ptr, col[:0], cnt[:0]
+    return (new_ptr, np.concatenate([col[indptr[lo]:indptr[hi]] for lo, hi in rows]),
+            np.concatenate([cnt[indptr[lo]:indptr[hi]] for lo, hi in rows]))
+
+
+def _merge_ranges(ranges):
+    out = []
+    for lo, hi in sorted(ranges):
+        if out and lo <= out[-1][1]:
+            out[-1][1] = max(out[-1][1], hi)
+        else:
+            out.append([lo, hi])
+    return [(a, b) for a, b in out]
 
 
 class PileUpper:
@@ -820,7 +893,7 @@ class PileUpper:
         if self.trans and self.view_df["chrom"].unique().shape[0] < 2:
             raise ValueError("Trying to do trans with fewer than two chromosomes")
 
-        bins_columns = list(self.clr.bins().columns)
+        bins_columns = list(self._aclr.bins().columns)     # the adapter: it also holds columns computed here
         if self.coverage_norm is True:
             self.coverage_norm = "cov_tot_raw"
         elif self.coverage_norm == "cis":
@@ -1061,15 +1134,37 @@ class PileUpper:
                        for r1, r2 in self._region_pairs()]
             want_control = bool(self.control) or (bool(self.expected) and not self.ooe)
             return finalize_callback_pileups(self, pileups, groupby, want_control, extra_sum_funcs)
+        # multi-GPU: region (pairs) are dealt to the ranks (longest first, identical on every rank); a rank builds the
+        # windows of its own regions only and steps the control RNG past the others
+        from . import dist as _dist
+        pairs = self._region_pairs()
+        rank, world = _dist.world()
+        owned = None
+        if world > 1:
+            weights = [self.CC.region_weight(self._region_tuple(r1), self._region_tuple(r2)) for r1, r2 in pairs]
+            owned = _dist.shard(len(pairs), weights, rank, world)
+            # rows this rank's engine needs: those of the earlier region of every pair it owns (upper-triangular table)
+            ext = self._global_extents
+            self._owned_rows = _merge_ranges([min(ext[r1][:2], ext[r2][:2]) for i, (r1, r2) in enumerate(pairs) if i in owned])
+        grouped = bool(groupby) or _by_window
         batches = []
-        for region1, region2 in self._region_pairs():
+        for i, (region1, region2) in enumerate(pairs):
+            if owned is not None and i not in owned:
+                self.CC.skip_region(self._region_tuple(region1), None if region2 == region1 else self._region_tuple(region2),
+                                    control=self.control)
+                batches.append((region1, region2, None))
+                continue
             b = self.region_snippets(region1, region2, groupby=groupby, modify_2Dintervals_func=modify,
                                      columns=columns, by_window=_by_window)
             batches.append((region1, region2, b))
             if b is not None and b["n"] > 0:
                 logger.info(f"{region1, region2}: {int((b['kind'] == KIND_ROI).sum())}")
-
-        return self._pile_and_finalize(batches, groupby, grouped=bool(groupby) or _by_window)
+        region_groups = None
+        if owned is not None:
+            # the global group table needs every region's group keys in region order: the ranks swap them (a few keys each)
+            got = _dist.merge_dicts({i: self.region_groups(batches[i][2], grouped) for i in owned})
+            region_groups = [got[i] for i in range(len(pairs))]
+        return self._pile_and_finalize(batches, groupby, grouped=grouped, region_groups=region_groups)
 
     def region_groups(self, b, grouped):
         """Group keys of one region's windows, per kind, in order of first appearance (without "all"); None for a
@@ -1176,7 +1271,7 @@ class PileUpper:
         # engine as ONE call: fewer launches, and the engine's interleaved groups span region boundaries
         stripe_jobs = []
         if self.store_stripes:
-            for region1, region2, b in batches:
+            for bi, (region1, region2, b) in enumerate(batches):
                 if b is None or b["n"] == 0:
                     continue
                 roi = np.flatnonzero(b["kind"] == KIND_ROI)
@@ -1194,7 +1289,8 @@ class PileUpper:
                 job = {"expected": expected, "ignore_diags": -1 if self.trans else int(self.ignore_diags),
                        "mode": (MODE_OOE if (self.expected and self.ooe) else 0) | (MODE_TRANSPOSE if transpose else 0)
                        | (MODE_LOCAL if (rescale and self.local) else 0),
-                       "r0": r0.astype(np.int32), "c0": c0.astype(np.int32), "gid": gk, "coords": b["coords"][roi]}
+                       "r0": r0.astype(np.int32), "c0": c0.astype(np.int32), "gid": gk, "coords": b["coords"][roi],
+                       "region": bi}
                 if rescale:   # stripes of the ZOOMED window (reference :1159-1169): whole windows via pup_extract
                     hh, ww = (b["w"][roi], b["h"][roi]) if transpose else (b["h"][roi], b["w"][roi])
                     job["h"], job["w"] = hh.astype(np.int32), ww.astype(np.int32)
@@ -1215,6 +1311,7 @@ class PileUpper:
                 "groupby": list(groupby), "grouped": bool(grouped), "calls": calls,
                 "pad": (self.rescale_size - 1) // 2 if rescale else self.pad_bins, "rescale": rescale,
                 "n_regions": len(batches), "region_groups": region_groups, "region_items": raw,
+                "store_stripes": bool(self.store_stripes),
                 "expected_table": exp_table, "stripe_jobs": stripe_jobs,
                 "weight_name": self.clr_weight_name if self.clr_weight_name else None,
                 "cov_name": self.coverage_norm if self.coverage_norm else None}
@@ -1224,12 +1321,12 @@ class PileUpper:
         all-reduce of the packed accumulators follows) and fetch the tiles.  calls / reduce=False: run just these
         calls of the plan and return this process's own tiles (per-region tiles for the inf merge rule)."""
         from . import dist as _dist
-        eng = _engine_for(self._aclr, _dist.local_device())
-        bins = self.clr.bins()
+        rank, world = _dist.world()
+        eng = _engine_for(self._aclr, _dist.local_device(), rows=getattr(self, "_owned_rows", None) if world > 1 else None)
+        bins = self._aclr.bins()
         eng.load_bins(bins[plan["weight_name"]][:].values if plan["weight_name"] else None,
                       bins[plan["cov_name"]][:].values if plan["cov_name"] else None)
         eng.reset(plan["T"], plan["pad"])
-        rank, world = _dist.world()
         et = plan.get("expected_table")
         table_set = False
         for c in (plan["calls"] if calls is None else calls):
@@ -1250,11 +1347,13 @@ class PileUpper:
                                ignore_diags=c["ignore_diags"], mode=c["mode"])
         if not reduce:
             return eng.fetch()
+        if world > 1:
+            _dist.check_same_plan(plan)
         _dist.allreduce_engine(eng)
         acc = eng.fetch()
-        if plan.get("stripe_jobs"):
-            # O(n*W) per-snippet output, not a reduction: every rank computes all of it (cheap) so that every rank
-            # ends with the complete result, like the reduced tiles
+        if plan.get("stripe_jobs") or (plan.get("store_stripes") and world > 1):
+            # O(n*W) per-snippet output, not a reduction: a rank extracts the stripes of its own regions and the ranks
+            # swap them, so that every rank ends with the complete result, like the reduced tiles
             acc["stripes"] = []
             for job in plan["stripe_jobs"]:
                 if isinstance(job["expected"], str):
@@ -1270,6 +1369,7 @@ class PileUpper:
                     continue
                 acc["stripes"].append(eng.stripes(job["r0"], job["c0"], plan["pad"], ignore_diags=job["ignore_diags"],
                                                   mode=job["mode"]))
+            _gather_stripes(plan, acc)
         return acc
 
     def finalize_plan(self, plan, acc):
@@ -1283,7 +1383,7 @@ class PileUpper:
                     for name in ("sum", "num", "n", "cov_start", "cov_end"):
                         acc[name][a] = acc[name][members].sum(axis=0)
         self._merge_inf_cells(plan, acc)
-        stripes = _collect_stripes(plan, acc) if plan.get("stripe_jobs") else None
+        stripes = _collect_stripes(plan, acc) if (plan.get("stripe_jobs") or acc.get("stripe_jobs")) else None
         return finalize_pileups(self, acc, order, gid, G, plan["groupby"], plan["want_control"],
                                 grouped=plan["grouped"], stripes=stripes)
 
@@ -1338,8 +1438,8 @@ class PileUpper:
                 fix = np.isinf(S[t]) | ~np.isfinite(d)
                 S[t][fix] = d[fix]
 
-    def _pile_and_finalize(self, batches, groupby, grouped=None):
-        plan = self.make_plan(batches, groupby, grouped=grouped)
+    def _pile_and_finalize(self, batches, groupby, grouped=None, region_groups=None):
+        plan = self.make_plan(batches, groupby, grouped=grouped, region_groups=region_groups)
         return self.finalize_plan(plan, self.run_plan(plan))
 
     def pileup_region(self, region1, region2=None, groupby=[], modify_2Dintervals_func=None, postprocess_func=None,
@@ -1355,6 +1455,7 @@ class PileUpper:
                                          extra_sum_funcs)
         b = self.region_snippets(region1, region2, groupby=groupby, modify_2Dintervals_func=modify_2Dintervals_func,
                                  columns=None)
+        self._owned_rows = None
         plan = self.make_plan([(region1, region2, b)], groupby)
         acc = self.run_plan(plan)
         return _tiles_to_pups(plan, acc)
@@ -1386,7 +1487,7 @@ class PileUpper:
             return src(self, expected, r0, c0, pad, **kw)
         from . import dist as _dist
         eng = _engine_for(self._aclr, _dist.local_device())
-        bins = self.clr.bins()
+        bins = self._aclr.bins()
         eng.load_bins(bins[self.clr_weight_name][:].values if self.clr_weight_name else None,
                       bins[self.coverage_norm][:].values if self.coverage_norm else None)
         if expected is not None:
@@ -1678,6 +1779,18 @@ def _engine_call_parts(region1, region2, expected, parts, T, igd, mode, rescale)
     return call
 
 
+def _gather_stripes(plan, acc):
+    """Multi-GPU: every rank ends up with the stripes of all regions, in region order (acc["stripe_jobs"] /
+    acc["stripes"]); a single process keeps what it has."""
+    from . import dist as _dist
+    if _dist.world()[1] == 1:
+        return
+    mine = {job["region"]: (job["gid"], job["coords"], h, v) for job, (h, v) in zip(plan["stripe_jobs"], acc["stripes"])}
+    every = _dist.merge_dicts(mine)
+    acc["stripe_jobs"] = [{"gid": every[k][0], "coords": every[k][1]} for k in sorted(every)]
+    acc["stripes"] = [(every[k][2], every[k][3]) for k in sorted(every)]
+
+
 def _collect_stripes(plan, acc):
     """Per group key: (coordinates [n,6] str, horizontal [n,W], vertical [n,W]) in the reference's accumulation
     order — regions in order, snippets in stream order; the "all" row of a grouped pile-up concatenates, region by
@@ -1688,7 +1801,7 @@ def _collect_stripes(plan, acc):
     def push(key, co, h, v):
         e = per.setdefault(key, ([], [], []))
         e[0].append(co); e[1].append(h); e[2].append(v)
-    for job, (h, v) in zip(plan["stripe_jobs"], acc["stripes"]):
+    for job, (h, v) in zip(acc.get("stripe_jobs", plan["stripe_jobs"]), acc["stripes"]):
         g = job["gid"]
         if plan["grouped"]:
             for code in pd.unique(g):                       # first-appearance order within the region
@@ -1885,6 +1998,9 @@ def pileup(clr, features, features_format="bed", view_df=None, expected_df=None,
 
     if not rescale:
         rescale_flank = None
+    if nshifts > 0 or subset > 0:
+        from . import dist as _dist
+        seed = _dist.shared_seed(seed)       # several ranks, no seed given: rank 0 draws one for all
     if seed is not None:
         np.random.seed(seed)
     if nproc == 0:

@@ -57,6 +57,9 @@ struct pup_ctx {
     DevBuf<int> cnt32;
     DevBuf<double> bal;
     DevBuf<unsigned long long> badbits;
+    DevBuf<unsigned long long> nf_keys;      // pixels with a non-finite balanced value (see collect_nonfinite_kernel), sorted
+    long long nf_count = 0;
+    DevBuf<long long> nf_tp;                 // tile_ptr | flip_from of the current call, for the fix pass
     bool have_bal = false;
     DevBuf<pup::IdxBlock> idx;
     DevBuf<pup::IdxChrom> idx_chrom;
@@ -528,6 +531,32 @@ int pup_load_bins(pup_ctx* c, const double* weight, const double* cov) {
                        dw, c->badbits.p, c->nbins, nwords);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    // weights of +-inf (never produced by balancing, but legal values of the column): list the pixels they spoil
+    c->nf_count = 0;
+    bool any_inf = false;
+    if (weight) for (long long i = 0; i < c->nbins && !any_inf; ++i) any_inf = std::isinf(weight[i]);
+    if (any_inf) {
+        DevBuf<unsigned long long> cnt;
+        HIPCHK(c, cnt.reserve(1));
+        unsigned long long total = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+            HIPCHK(c, hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), c->stream));
+            hipLaunchKernelGGL(pup::collect_nonfinite_kernel, dim3(gb), dim3(256), 0, c->stream, c->indptr.p, c->px.p, dw, c->nbins,
+                               pass ? c->nf_keys.p : nullptr, total, cnt.p);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipMemcpyAsync(&total, cnt.p, sizeof(total), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (total == 0) break;
+            if (pass == 0) HIPCHK(c, c->nf_keys.reserve((size_t)total));
+        }
+        if (total > 0) {
+            std::vector<unsigned long long> h((size_t)total);
+            HIPCHK(c, hipMemcpy(h.data(), c->nf_keys.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            std::sort(h.begin(), h.end());
+            HIPCHK(c, hipMemcpy(c->nf_keys.p, h.data(), h.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+            c->nf_count = (long long)total;
+        }
+    }
     c->have_bal = true;
     return PUP_OK;
 }
@@ -1202,6 +1231,21 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     hipLaunchKernelGGL(pup::add_counts_kernel, dim3((unsigned)((c->T + 255) / 256)), dim3(256), 0, c->stream,
                        c->acc_i64.p + (size_t)c->T * W2, c->gv.dn, c->T);
     HIPCHK(c, hipGetLastError());
+    if (c->nf_count > 0 && c->have_weight && !rescale && !(mode & PUP_MODE_EXPECTED)) {
+        // take the pixels whose balanced value is inf / NaN out of `num` (see collect_nonfinite_kernel); the rescaled
+        // path counts from the zoomed values themselves
+        HIPCHK(c, c->nf_tp.reserve((size_t)(2 * T + 1)));
+        HIPCHK(c, hipMemcpyAsync(c->nf_tp.p, tile_ptr, (size_t)(T + 1) * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+        if (flip_from) HIPCHK(c, hipMemcpyAsync(c->nf_tp.p + T + 1, flip_from, (size_t)T * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+        pup::K1Args f = a;
+        f.r0 = dr0; f.c0 = dc0;
+        const long long threads = (long long)n * W;
+        hipLaunchKernelGGL(pup::nonfinite_fix_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, f,
+                           c->nf_keys.p, c->nf_count, (long long)n, c->nf_tp.p, flip_from ? c->nf_tp.p + T + 1 : nullptr, T,
+                           c->acc_i64.p);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));      // tile_ptr / flip_from are the caller's
+    }
     if (c->profiling) {
         HIPCHK(c, hipEventRecord(e2, c->stream));
         c->pending.push_back({e0, e1, e2});

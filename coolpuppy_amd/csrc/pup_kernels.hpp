@@ -1799,6 +1799,73 @@ __global__ __launch_bounds__(256) void balance_pixels_kernel(const long long* __
     }
 }
 
+// ---- pixels whose balanced value is not a number although both weights are (weights of +-inf, and 0 * inf) -----------
+// cooler multiplies them out all the same and the reference then leaves those cells out of `num` one by one
+// (np.isfinite, lib/puputils.py:18-29) while the empty cells of the same rows still count.  The pile-up kernels decide
+// validity from the bin masks alone, so such pixels — none at all in a normally balanced table — are listed once per
+// weight column (both orientations, sorted by (row, col)) and a small pass after the reduction takes them out of `num`.
+__global__ __launch_bounds__(256) void collect_nonfinite_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
+                                                                const double* __restrict__ weight, long long nbins,
+                                                                unsigned long long* __restrict__ keys, unsigned long long cap,
+                                                                unsigned long long* __restrict__ count) {
+    const int lane = threadIdx.x & 63;
+    long long r = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long stride = (long long)gridDim.x * (blockDim.x >> 6);
+    for (; r < nbins; r += stride) {
+        const double wr = weight[r];
+        if (wr != wr) continue;
+        const long long b = indptr[r], e = indptr[r + 1];
+        for (long long k = b + lane; k < e; k += 64) {
+            const int2 pc = px[k];
+            const double wc = weight[pc.x];
+            if (wc != wc) continue;
+            const double v = (double)pc.y * wr * wc;
+            if (v == v && !__builtin_isinf(v)) continue;
+            const int both = (pc.x != (int)r) ? 2 : 1;
+            const unsigned long long at = atomicAdd(count, (unsigned long long)both);
+            if (keys != nullptr && at + both <= cap) {
+                keys[at] = ((unsigned long long)r << 32) | (unsigned)pc.x;
+                if (both == 2) keys[at + 1] = ((unsigned long long)(unsigned)pc.x << 32) | (unsigned long long)r;
+            }
+        }
+    }
+}
+
+// one thread per (snippet, window row): the listed pixels under that row are cells the kernels counted as valid
+__global__ __launch_bounds__(256) void nonfinite_fix_kernel(K1Args a, const unsigned long long* __restrict__ keys, long long nkeys,
+                                                            long long n, const long long* __restrict__ tile_ptr,
+                                                            const long long* __restrict__ flip_from, int T,
+                                                            long long* __restrict__ acc_num) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int W = a.W;
+    if (g >= n * W) return;
+    const long long s = g / W;
+    const int i = (int)(g - s * W);
+    const int r0 = a.r0[s], c0 = a.c0[s];
+    const unsigned long long klo = ((unsigned long long)(unsigned)(r0 + i) << 32) | (unsigned)c0;
+    long long lo = 0, hi = nkeys;
+    while (lo < hi) { const long long m = (lo + hi) >> 1; if (keys[m] < klo) lo = m + 1; else hi = m; }
+    if (lo >= nkeys || (keys[lo] >> 32) != (unsigned long long)(r0 + i) || (int)(keys[lo] & 0xffffffffu) >= c0 + W) return;
+    int t0 = 0, t1 = T;                                              // tile of snippet s
+    while (t1 - t0 > 1) { const int m = (t0 + t1) >> 1; if (tile_ptr[m] <= s) t0 = m; else t1 = m; }
+    const int fl = (flip_from != nullptr && s >= flip_from[t0]) ? 1 : 0;
+    const bool m_ooe = a.mode & 0x01u, m_tr = a.mode & 0x08u;
+    const int igd = a.ignore_diags;
+    ExpCache ecache;
+    ExpSel es; es.base = nullptr; es.len = 0; es.scalar = __builtin_nan(""); es.is_scalar = true;
+    if (m_ooe) es = select_expected(a, ecache, r0, c0);
+    for (; lo < nkeys; ++lo) {
+        const unsigned long long k = keys[lo];
+        const int col = (int)(k & 0xffffffffu);
+        if ((k >> 32) != (unsigned long long)(r0 + i) || col >= c0 + W) break;
+        const int dj = col - (r0 + i);
+        if (igd >= 0 && dj < igd) continue;
+        if (m_ooe) { const double e = es.at(dj < 0 ? -(long long)dj : (long long)dj); int e_ok = (e == e) && (e != 0.0); asm volatile("" : "+v"(e_ok)); if (!e_ok) continue; }
+        const int cell = map_cell(i, col - c0, W, m_tr, fl);
+        atomicAdd((unsigned long long*)&acc_num[(size_t)t0 * W * W + cell], ~0ull);      // -1
+    }
+}
+
 __global__ void badbits_kernel(const double* __restrict__ weight, unsigned long long* __restrict__ badbits,
                                long long nbins, long long nwords) {
     const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,10 +1,11 @@
 """Multi-GPU plumbing: one process per GPU, regions sharded, one RCCL all-reduce of the packed tiles.
 
 The reference parallelises with ``multiprocessing.Pool`` over regions and merges per-region dicts with
-``reduce(sum_pups)`` on the host (coolpuppy/coolpup.py:1495-1531).  Here each rank piles up its share of
-the regions on its own GPU and the (kind, group) accumulators — additive by construction — are summed
-across ranks with ``torch.distributed.all_reduce`` (backend "nccl" = RCCL over xGMI; "gloo" on CPU for
-tests).  Message: n_tiles*(W*W+2W) float64 + n_tiles*(W*W+1) int64, ~1 MB at most outside by-window mode,
+``reduce(sum_pups)`` on the host (coolpuppy/coolpup.py:1495-1531).  Here the regions (chromosomes, trans pairs) are
+dealt to the ranks (`shard`), each rank piles up its own on its GPU from the rows of the pixel table it needs, and the
+(kind, group) accumulators — additive by construction — are summed across ranks by one all-reduce (`allreduce_engine`:
+RCCL over xGMI on the engine's stream; "gloo" on CPU for tests).  Control-plane facts (group keys of the regions, the
+seed, stripes) travel as small pickled objects (`merge_dicts`, `shared_seed`).  Message: n_tiles*(W*W+2W) float64 + n_tiles*(W*W+1) int64, ~1 MB at most outside by-window mode,
 so the collective is latency-bound and a single flat all-reduce per dtype is the right shape.
 
 torch is imported lazily and only when a process group exists: single-GPU use has no torch dependency.
@@ -37,6 +38,13 @@ def local_device():
     return 0
 
 
+def _bind_device(d):
+    """Object collectives of the nccl backend stage through the CURRENT CUDA device: make that this rank's GPU."""
+    if d.get_backend() == "nccl":
+        import torch
+        torch.cuda.set_device(local_device())
+
+
 def shard(n_units, weights=None, rank=None, world_size=None):
     """Indices of the units (regions / region pairs) this rank piles up.
 
@@ -58,50 +66,44 @@ def shard(n_units, weights=None, rank=None, world_size=None):
     return mine
 
 
-def slice_call(call, rank, world_size):
-    """This rank's share of one engine call: an even, contiguous slice of every (tile, flip) segment of the
-    call's tile-grouped snippets (deterministic, no communication).  Returns a call dict of the same shape."""
-    if world_size == 1:
-        return call
-    tp = np.asarray(call["tile_ptr"], np.int64)
-    T = len(tp) - 1
-    ff = tp[1:] if call.get("flip_from") is None else np.asarray(call["flip_from"], np.int64)
-    # segment boundaries: [tp[t], ff[t]) as is, [ff[t], tp[t+1]) flipped
-    a = np.stack([tp[:-1], ff], axis=1).ravel()
-    b = np.stack([ff, tp[1:]], axis=1).ravel()
-    n = b - a
-    lo = a + (n * rank) // world_size
-    hi = a + (n * (rank + 1)) // world_size
-    cnt = hi - lo
-    total = int(cnt.sum())
-    if total:
-        starts = np.repeat(lo - np.concatenate([[0], np.cumsum(cnt)[:-1]]), cnt)
-        idx = starts + np.arange(total)
-    else:
-        idx = np.zeros(0, np.int64)
-    per_tile = cnt.reshape(T, 2)
-    new_tp = np.concatenate([[0], np.cumsum(per_tile.sum(axis=1))]).astype(np.int64)
-    out = dict(call)
-    for k in ("r0", "c0", "tile", "flip", "h", "w"):
-        if call.get(k) is not None:
-            out[k] = np.ascontiguousarray(call[k][idx])
-    out["tile_ptr"] = new_tp
-    out["flip_from"] = None if call.get("flip_from") is None else (new_tp[:-1] + per_tile[:, 0]).astype(np.int64)
-    return out
-
-
 def merge_dicts(mine):
     """Union over all ranks of per-rank dicts with disjoint keys (small control-plane objects: group keys of the
     regions a rank owns, per-region tiles of the rare inf merge) — identical on every rank afterwards."""
     d = _dist()
     if d is None or d.get_world_size() == 1:
         return mine
+    _bind_device(d)
     parts = [None] * d.get_world_size()
     d.all_gather_object(parts, mine)
     out = {}
     for p in parts:
         out.update(p)
     return out
+
+
+def check_same_plan(plan):
+    """Before tiles are summed across ranks: every rank must hold the same tile layout (number of tiles, window size,
+    group keys in the same order) — it does by construction (the group table is built from the swapped region keys,
+    the control RNG from a broadcast seed); a mismatch would add unrelated tiles silently, so it is an error here."""
+    import hashlib
+    text = repr((plan["T"], plan["pad"], plan["n_regions"], sorted((repr(k), v) for k, v in plan["gid"].items())))
+    digest = hashlib.sha1(text.encode()).hexdigest()
+    rank, _ = world()
+    seen = merge_dicts({rank: digest})
+    if len(set(seen.values())) != 1:
+        raise RuntimeError(f"multi-GPU pile-up: the ranks built different plans ({seen}); same inputs and seed on every rank?")
+
+
+def shared_seed(seed):
+    """The seed every rank uses: the caller's, or — when it is None and there are several ranks — one drawn by rank 0
+    and broadcast, so that the random control shifts are the same sequence everywhere."""
+    d = _dist()
+    if seed is not None or d is None or d.get_world_size() == 1:
+        return seed
+    _bind_device(d)
+    box = [int(np.random.randint(0, 2**31 - 1)) if d.get_rank() == 0 else None]
+    d.broadcast_object_list(box, src=0)
+    return box[0]
 
 
 def allreduce_arrays(f64, i64):
@@ -125,7 +127,8 @@ _NATIVE_COMMS = {}
 def native_comm(eng):
     """An RCCL communicator (ncclComm_t address) for this engine's device over all ranks, created once: rank 0 draws
     the ncclUniqueId, torch.distributed (any backend) only carries its 128 bytes to the other ranks.  Opt-in path
-    (COOLPUPPY_AMD_NATIVE_RCCL=1): exercised on hardware with a one-rank communicator only in round 1."""
+    Exercised on hardware with a one-rank communicator and with two ranks where a box offers two GPUs (RCCL refuses two
+    ranks on one device)."""
     import ctypes as C
     d = _dist()
     rank, world = d.get_rank(), d.get_world_size()
@@ -158,15 +161,25 @@ def native_comm(eng):
 
 
 def allreduce_engine(eng):
-    """All-reduce the engine's packed accumulators across ranks: device to device with the nccl (= RCCL) backend,
-    through host memory with any other backend."""
+    """All-reduce the engine's packed accumulators across ranks.  With the nccl (= RCCL) backend the engine does it
+    itself: pup_allreduce, in place on its own stream over a communicator of its own — no staging buffers, no host
+    synchronisation (COOLPUPPY_AMD_NATIVE_RCCL=0 selects torch.distributed's all_reduce on exported buffers instead, which
+    is also what is used if the engine's communicator cannot be set up).  Any other backend (gloo: CPU tests, two ranks
+    sharing one GPU) goes through host memory."""
     d = _dist()
     if d is None or d.get_world_size() == 1:
         return
     import torch
-    if os.environ.get("COOLPUPPY_AMD_NATIVE_RCCL", "") == "1":
-        eng.allreduce(native_comm(eng))       # in place on the engine's stream: no staging copies, no host sync
-        return
+    if d.get_backend() == "nccl" and os.environ.get("COOLPUPPY_AMD_NATIVE_RCCL", "1") != "0":
+        try:
+            comm = native_comm(eng)
+        except (RuntimeError, OSError) as e:
+            import warnings
+            warnings.warn(f"engine-side RCCL communicator unavailable ({e}); using torch.distributed.all_reduce")
+            comm = None
+        if comm is not None:
+            eng.allreduce(comm)
+            return
     nf, ni = eng.packed_sizes()
     dev = torch.device("cuda", eng.device_id)
     bf = torch.empty(nf, dtype=torch.float64, device=dev)

@@ -138,7 +138,21 @@ def oracle_run_plan(pu, plan, calls=None, reduce=True):
                 continue
             po.pileup_c(indptr, col, cnt, weight, cov, expected, c["r0"], c["c0"], c["flip"], c["tile"],
                         plan["T"], plan["pad"], c["ignore_diags"], c["mode"], acc=acc)
-    if plan.get("stripe_jobs") and calls is None:
+    from coolpuppy_amd import dist as pdist
+    world = pdist.world()[1]
+    if world > 1 and reduce and calls is None:
+        # what run_plan does between its ranks: same-plan check, then the tiles are summed (here from host arrays)
+        pdist.check_same_plan(plan)
+        T, W = plan["T"], 2 * plan["pad"] + 1
+        f64 = np.concatenate([acc["sum"].ravel(), acc["cov_start"].ravel(), acc["cov_end"].ravel()])
+        i64 = np.concatenate([acc["num"].ravel(), acc["n"].ravel()])
+        f64, i64 = pdist.allreduce_arrays(f64, i64)
+        acc["sum"] = f64[:T * W * W].reshape(T, W, W)
+        acc["cov_start"] = f64[T * W * W:T * W * W + T * W].reshape(T, W)
+        acc["cov_end"] = f64[T * W * W + T * W:].reshape(T, W)
+        acc["num"] = i64[:T * W * W].reshape(T, W, W)
+        acc["n"] = i64[T * W * W:]
+    if (plan.get("stripe_jobs") or (plan.get("store_stripes") and world > 1)) and calls is None:
         acc["stripes"] = []
         for job in plan["stripe_jobs"]:
             fake = {"expected": job["expected"], "r0": job["r0"], "c0": job["c0"], "mode": job["mode"],
@@ -168,6 +182,8 @@ def oracle_run_plan(pu, plan, calls=None, reduce=True):
                     h[sel] = hh[k]; v[sel] = vv[k]
             del pos
             acc["stripes"].append((h, v))
+        from coolpuppy_amd.coolpup import _gather_stripes
+        _gather_stripes(plan, acc)
     return acc
 
 

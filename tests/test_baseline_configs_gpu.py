@@ -1,0 +1,203 @@
+"""The five BASELINE.json configurations as GPU tests, through the public API.
+
+configs[0] / [1] use the reference's own feature files (tests/golden/ref_data: CH12_loops_Rao.bed, Bonev_CTCF+/-.bed.gz)
+on an mm9-sized synthetic 10 kb table (the real Scc1-control.10000.cool is not in the tree) and are compared IN FULL
+with the CPU oracle: the same pileup() call with the engine half of run_plan replaced by the oracle replay.
+configs[2] - [4] run at BASELINE's full size on the human-scale synthetic table; there the oracle checks a strided
+sample of >= 6e4 windows of every engine call, and the whole run is checked through properties that do not depend on the
+size: window counts, additivity over a split of the windows, "all" = sum of the groups, num <= n, and (trans) agreement
+between the kernel the engine picks and the plain per-window kernel.
+
+Bit-exact for n / num; 1e-6 relative (BASELINE north_star) for the float sums — the test passes 1e-9.
+"""
+import gzip
+import os
+import warnings
+from functools import partial
+
+import numpy as np
+import pandas as pd
+import pytest
+
+import golden_util as gu
+from coolpuppy_amd import coolpup, synth
+
+pytestmark = pytest.mark.gpu
+REF = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_data")
+RTOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def mm9(hip_lib):
+    return synth.make_cooler(synth.MM9, binsize=10_000, lam=120, seed=1000, name="synthetic_mm9_10kb", parallel=True)
+
+
+@pytest.fixture(scope="module")
+def hg38(hip_lib):
+    return synth.make_cooler({c: synth.HG38[c] for c in synth.HG38}, binsize=10_000, lam=4200, seed=1000,
+                             name="synthetic_hg38_10kb", parallel=True, trans_nnz=50_000_000)
+
+
+def _frames_equal(gpu, cpu):
+    assert list(gpu.columns) == list(cpu.columns) and len(gpu) == len(cpu)
+    for i in range(len(gpu)):
+        assert int(gpu["n"].iloc[i]) == int(cpu["n"].iloc[i])
+        np.testing.assert_array_equal(np.asarray(gpu["num"].iloc[i]), np.asarray(cpu["num"].iloc[i]))
+        np.testing.assert_allclose(np.asarray(gpu["data"].iloc[i], float), np.asarray(cpu["data"].iloc[i], float),
+                                   rtol=RTOL, atol=0, equal_nan=True)
+
+
+def _both(clr, features, monkeypatch, **kw):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gpu = coolpup.pileup(clr, features, **kw)
+        with monkeypatch.context() as m:
+            m.setattr(coolpup.PileUpper, "run_plan", gu.oracle_run_plan)
+            cpu = coolpup.pileup(clr, features, **kw)
+    return gpu, cpu
+
+
+def test_config0_ch12_loops_full_oracle(mm9, monkeypatch, oracle_mod):
+    """configs[0]: CH12_loops_Rao.bed (as bedpe), pad=10, nshifts=0, balanced — every window against the oracle."""
+    loops = pd.read_csv(os.path.join(REF, "CH12_loops_Rao.bed"), sep="\t", header=None,
+                        names=["chrom1", "start1", "end1", "chrom2", "start2", "end2"])
+    gpu, cpu = _both(mm9, loops, monkeypatch, features_format="bedpe", flank=100_000, nshifts=0)
+    _frames_equal(gpu, cpu)
+    d = np.asarray(gpu["data"].iloc[0])
+    assert d.shape == (21, 21) and not np.isnan(d).any()
+    assert int(gpu["n"].iloc[0]) > 1000           # the file holds 1 388 usable loops on the chromosomes of the table
+
+
+@pytest.mark.parametrize("sign", ["+", "-"])
+def test_config1_ctcf_local_expected_full_oracle(mm9, sign, monkeypatch, oracle_mod):
+    """configs[1]: Bonev_CTCF+/- local cis pile-up, pad=10, observed over expected — every window against the oracle."""
+    with gzip.open(os.path.join(REF, f"Bonev_CTCF{sign}.bed.gz"), "rt") as f:
+        bed = pd.read_csv(f, sep="\t", header=None, names=["chrom", "start", "end"])
+    exp = synth.cis_expected(mm9)
+    gpu, cpu = _both(mm9, bed, monkeypatch, features_format="bed", flank=100_000, local=True, expected_df=exp)
+    _frames_equal(gpu, cpu)
+    # ignore_diags=2 blanks the main diagonal and its neighbours of an on-diagonal window: 21 + 2*20 cells
+    assert int(np.isnan(np.asarray(gpu["data"].iloc[0])).sum()) == 61
+    assert int(gpu["n"].iloc[0]) > 10_000
+
+
+# ---- full-size configurations -------------------------------------------------------------------------------------------
+def _plan(clr, features, seed=None, groupby=(), modify=None, cols=(), **kw):
+    if seed is not None:
+        np.random.seed(seed)
+    cc = coolpup.CoordCreator(features, clr.binsize, features_format="bedpe", flank=kw["flank"], nshifts=kw.get("nshifts", 0),
+                              trans=kw.get("trans", False), chroms=list(clr.chromnames), seed=seed)
+    pu = coolpup.PileUpper(clr, cc, control=kw.get("nshifts", 0) > 0, ignore_diags=2)
+    pu.ignore_group_order = False
+    batches = [(r1, r2, pu.region_snippets(r1, r2, groupby=list(groupby), modify_2Dintervals_func=modify, columns=cols))
+               for r1, r2 in pu._region_pairs()]
+    return pu, pu.make_plan(batches, list(groupby))
+
+
+def _run_calls(pu, plan, calls):
+    eng = coolpup._engine_for(pu._aclr, 0)
+    bins = pu._aclr.bins()
+    eng.load_bins(bins[plan["weight_name"]][:].values, None)
+    eng.reset(plan["T"], plan["pad"])
+    for c in calls:
+        eng.accumulate(c["r0"], c["c0"], c["tile_ptr"], flip_from=c["flip_from"], ignore_diags=c["ignore_diags"], mode=c["mode"])
+    return eng.fetch()
+
+
+def _subset(plan, call, idx):
+    flip = None if call["flip"] is None else call["flip"][idx]
+    return coolpup._engine_call(call["region1"], call["region2"], call["expected"], call["r0"][idx].astype(np.int64),
+                                call["c0"][idx].astype(np.int64), flip, call["tile"][idx].astype(np.int64), plan["T"],
+                                call["ignore_diags"], call["mode"])
+
+
+def _check_full_size(pu, plan, acc, min_sample=60_000):
+    from oracle import pileup_oracle as po
+    T = plan["T"]
+    total = sum(len(c["r0"]) for c in plan["calls"])
+    # window counts: every accepted window is counted once in its tile
+    want_n = np.zeros(T, np.int64)
+    for c in plan["calls"]:
+        want_n += np.diff(c["tile_ptr"])
+    np.testing.assert_array_equal(acc["n"], want_n)
+    assert (acc["num"] <= acc["n"][:, None, None]).all() and (acc["num"] >= 0).all()
+    assert np.isfinite(acc["sum"]).all()
+    # additivity: even windows + odd windows = all windows (integers exactly, sums to rounding)
+    parts = []
+    for k in (0, 1):
+        parts.append(_run_calls(pu, plan, [_subset(plan, c, np.arange(k, len(c["r0"]), 2)) for c in plan["calls"]]))
+    np.testing.assert_array_equal(parts[0]["n"] + parts[1]["n"], acc["n"])
+    np.testing.assert_array_equal(parts[0]["num"] + parts[1]["num"], acc["num"])
+    np.testing.assert_allclose(parts[0]["sum"] + parts[1]["sum"], acc["sum"], rtol=1e-10, atol=0)
+    # strided sample of every call against the oracle
+    step = max(1, total // (min_sample + 2000))
+    calls = [_subset(plan, c, np.arange(0, len(c["r0"]), step)) for c in plan["calls"]]
+    n_s = sum(len(c["r0"]) for c in calls)
+    assert n_s >= min_sample
+    got = _run_calls(pu, plan, calls)
+    indptr, col, cnt = pu._aclr.pixel_table()
+    weight = pu._aclr.bins()[plan["weight_name"]][:].values
+    ref = po.empty_acc(T, plan["pad"])
+    for c in calls:
+        po.pileup_c(indptr, col, cnt, weight, None, None, c["r0"], c["c0"], c["flip"], c["tile"], T, plan["pad"],
+                    c["ignore_diags"], c["mode"], acc=ref)
+    np.testing.assert_array_equal(got["n"], ref["n"])
+    np.testing.assert_array_equal(got["num"], ref["num"])
+    np.testing.assert_allclose(got["sum"], ref["sum"], rtol=RTOL, atol=0)
+    return n_s
+
+
+def test_config2_million_pairs_ten_shifts(hg38, oracle_mod):
+    """configs[2]: 1e6 random cis pairs, nshifts=10 — the benchmark's workload, through the coordinate layer."""
+    feats = synth.random_cis_pairs(hg38, 1_000_000, seed=42, strands=True)
+    pu, plan = _plan(hg38, feats, seed=0, flank=100_000, nshifts=10)
+    acc = _run_calls(pu, plan, plan["calls"])
+    assert plan["T"] == 2 and acc["n"][0] > 990_000 and acc["n"][1] > 9_900_000
+    _check_full_size(pu, plan, acc)
+    # and the public entry point returns the same numbers
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        df = coolpup.pileup(hg38, feats, features_format="bedpe", flank=100_000, nshifts=10, seed=0)
+    assert int(df["n"].iloc[0]) == int(acc["n"][0]) and int(df["control_n"].iloc[0]) == int(acc["n"][1])
+    np.testing.assert_array_equal(np.asarray(df["num"].iloc[0]), acc["num"][0])
+
+
+def test_config3_by_distance_by_strand(hg38, oracle_mod):
+    """configs[3]: the same pairs grouped by distance band and strand pair (42 tiles), nshifts=10."""
+    feats = synth.random_cis_pairs(hg38, 1_000_000, seed=42, strands=True)
+    modify = partial(coolpup.bin_distance_intervals, band_edges="default")
+    pu, plan = _plan(hg38, feats, seed=0, flank=100_000, nshifts=10, groupby=["strand1", "strand2", "distance_band"],
+                     modify=modify, cols=["distance"])
+    assert plan["T"] >= 30
+    acc = _run_calls(pu, plan, plan["calls"])
+    _check_full_size(pu, plan, acc)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        df = coolpup.pileup(hg38, feats, features_format="bedpe", flank=100_000, nshifts=10, seed=0, by_distance=True,
+                            by_strand=True)
+    # "all" = sum of the groups, and the grouped run saw exactly the windows of the ungrouped one
+    rows = df[df["group"].astype(str) != "all"]
+    al = df[df["group"].astype(str) == "all"].iloc[0]
+    assert int(al["n"]) == int(rows["n"].sum()) == int(acc["n"][:plan["G"]].sum())
+    np.testing.assert_array_equal(np.asarray(al["num"]), np.sum([np.asarray(x) for x in rows["num"]], axis=0))
+    assert int(al["control_n"]) == int(acc["n"][plan["G"]:].sum())
+
+
+def test_config4_trans_pairs_pad25(hg38, oracle_mod):
+    """configs[4]: 5e5 inter-chromosomal pairs over all chromosome-pair blocks, 51 x 51 windows."""
+    feats = synth.random_trans_pairs(hg38, 500_000, seed=43)
+    pu, plan = _plan(hg38, feats, flank=250_000, trans=True)
+    assert plan["pad"] == 25
+    acc = _run_calls(pu, plan, plan["calls"])
+    assert int(acc["n"][0]) > 490_000
+    _check_full_size(pu, plan, acc)
+    # the sparse trans kernel against the plain per-window kernel on everything
+    eng = coolpup._engine_for(pu._aclr, 0)
+    os.environ["COOLPUPPY_AMD_VARIANT"] = "32"
+    try:
+        plain = _run_calls(pu, plan, plan["calls"])
+    finally:
+        os.environ.pop("COOLPUPPY_AMD_VARIANT")
+        eng.set_tuning(0, 0)
+    np.testing.assert_array_equal(plain["num"], acc["num"])
+    np.testing.assert_allclose(plain["sum"], acc["sum"], rtol=1e-10, atol=0)

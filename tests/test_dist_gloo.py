@@ -16,79 +16,64 @@ sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests")
 import torch.distributed as dist
 import golden_util as gu
 from coolpuppy_amd import coolpup, dist as pdist
-from oracle import pileup_oracle as po
 
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2)
+rank, world = pdist.world()
+assert world == 2
 
-def run_plan_sharded(pu, plan):
-    """CPU stand-in for PileUpper.run_plan: this rank's share on the oracle, then the real all-reduce."""
-    indptr, col, cnt = pu._aclr.pixel_table()
-    bins = pu.clr.bins()
-    weight = bins[plan["weight_name"]][:].values if plan["weight_name"] else None
-    cov = bins[plan["cov_name"]][:].values if plan["cov_name"] else None
-    acc = po.empty_acc(plan["T"], plan["pad"])
-    rank, world = pdist.world()
-    mine = []
-    for c in plan["calls"]:
-        full = len(c["r0"])
-        c = pdist.slice_call(c, rank, world)
-        mine.append((len(c["r0"]), full))
-        # the engine would rebuild tiles from tile_ptr: check the slice's tile_ptr agrees with its tile array
-        assert np.array_equal(np.concatenate([[0], np.cumsum(np.bincount(c["tile"], minlength=plan["T"]))]), c["tile_ptr"])
-        if c["flip_from"] is not None:
-            fl = c["flip"].astype(bool)
-            for t in range(plan["T"]):
-                seg = fl[c["tile_ptr"][t]:c["tile_ptr"][t + 1]]
-                k = int(c["flip_from"][t] - c["tile_ptr"][t])
-                assert not seg[:k].any() and seg[k:].all()
-        if len(c["r0"]):
-            for expected, sc in coolpup.iter_expected_subcalls(plan, c):
-                po.pileup_c(indptr, col, cnt, weight, cov, expected, sc["r0"], sc["c0"], sc["flip"], sc["tile"],
-                            plan["T"], plan["pad"], sc["ignore_diags"], sc["mode"], acc=acc)
-    T, W = plan["T"], 2 * plan["pad"] + 1
-    f64 = np.concatenate([acc["sum"].ravel(), acc["cov_start"].ravel(), acc["cov_end"].ravel()])
-    i64 = np.concatenate([acc["num"].ravel(), acc["n"].ravel()])
-    f64, i64 = pdist.allreduce_arrays(f64, i64)
-    acc["sum"] = f64[:T*W*W].reshape(T, W, W); acc["cov_start"] = f64[T*W*W:T*W*W+T*W].reshape(T, W)
-    acc["cov_end"] = f64[T*W*W+T*W:].reshape(T, W)
-    acc["num"] = i64[:T*W*W].reshape(T, W, W); acc["n"] = i64[T*W*W:]
-    return acc, mine
-
-shares = {{}}
-def patched(pu, plan):
-    acc, mine = run_plan_sharded(pu, plan)
-    shares[len(shares)] = (mine, len(plan["calls"]))
-    return acc
-coolpup.PileUpper.run_plan = patched
+# CPU stand-in for the engine half of PileUpper.run_plan (tests/golden_util.py): this rank's calls on the oracle, then
+# the library's own same-plan check, all-reduce and stripe exchange
+shares = []
+def run_plan(pu, plan, calls=None, reduce=True):
+    if calls is None:
+        shares.append([int(sum(len(c["r0"]) for c in plan["calls"])), sorted(getattr(pu, "_owned_rows", None) or [])])
+    return gu.oracle_run_plan(pu, plan, calls=calls, reduce=reduce)
+coolpup.PileUpper.run_plan = run_plan
 for name in {names!r}:
     z, df = gu.run(name, coolpup.pileup)
     gu.compare(z, df, rtol=1e-12)
-rank, world = pdist.world()
-assert world == 2
-print("RANK", rank, "OK", json.dumps({{k: v for k, v in shares.items()}}))
+# no seed given: rank 0's draw is used everywhere, so both ranks end with the same control pile-up
+z, meta, features, view, expected, kw = gu.load("G3_nshifts3")
+kw.pop("seed")
+np.random.seed(1000 + rank)                  # the ranks' own generators differ
+df = coolpup.pileup(gu.scenario_cooler(meta), features, view_df=view, expected_df=expected, **kw)
+mine = np.asarray(df["data"].iloc[0], float)
+both = [None, None]
+dist.all_gather_object(both, mine)
+assert np.array_equal(both[0], both[1], equal_nan=True)
+print("RANK", rank, "OK", json.dumps(shares))
 dist.destroy_process_group()
 '''
 
 
 def test_two_rank_gloo_matches_golden(tmp_path, oracle_mod):
-    names = ["G3_nshifts3", "G6c_by_strand_distance_controls", "G4b_expected_not_ooe", "G7_trans_bedpe_expected",
-             "G2b_raw_covnorm_controls"]
+    """Two processes, regions dealt between them: each builds the windows of its own regions only (the control RNG is
+    stepped past the others), the group table comes from the swapped region keys, tiles are all-reduced, stripes and the
+    per-region tiles of the inf merge rule are exchanged — and every rank must end with the reference's golden result."""
+    names = ["G3_nshifts3", "G3b_nshifts10_view", "G6c_by_strand_distance_controls", "G4b_expected_not_ooe",
+             "G7_trans_bedpe_expected", "G7c_trans_bedpe_controls", "G2b_raw_covnorm_controls",
+             "G9b_bed_combinations_controls_strand", "G5c_local_controls", "G11b_stripes_controls_strand",
+             "G8d_inf_in_several_regions_by_strand", "G8e_inf_in_several_regions_view_distance", "G10b_by_window_controls",
+             "G12d_rescale_bedpe_controls"]
     port = 29500 + (os.getpid() % 2000)
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT, port=port, names=names))
     procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                               text=True) for r in range(2)]
-    outs = [p.communicate(timeout=600)[0] for p in procs]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{out[-3000:]}"
         assert f"RANK {r} OK" in out
-    # the two ranks' shares of every call add up to the call and are nearly equal
+    # both ranks got work in every run, and the row ranges they hold are disjoint
     import json
     s0 = json.loads(outs[0].split("OK", 1)[1])
     s1 = json.loads(outs[1].split("OK", 1)[1])
-    for k in s0:
-        for (a, full), (b, _) in zip(s0[k][0], s1[k][0]):
-            assert a + b == full and abs(a - b) <= max(2, full // 50 + 200)
+    assert len(s0) == len(s1) == len(names) + 1
+    for name, (n0, rows0), (n1, rows1) in zip(names + ["G3_nshifts3"], s0, s1):
+        assert n0 > 0 and n1 > 0
+        if "trans" not in name:          # cis: a row belongs to one region; trans pairs on different ranks share rows
+            for a, b in rows0:
+                assert all(b <= c or d <= a for c, d in rows1), name
 
 
 def test_shard_is_deterministic_and_balanced():
@@ -139,3 +124,53 @@ def test_two_ranks_share_one_gpu_and_match_goldens(hip_lib, tmp_path):
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se[-3000:]
     assert any("RESULT" in so for so, _ in outs)
+
+
+RCCL_WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+os.environ["COOLPUPPY_AMD_DEVICE"] = "0"
+import torch, torch.distributed as dist
+import golden_util as gu
+from coolpuppy_amd import coolpup
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2,
+                        device_id=torch.device("cuda", 0))
+for name in {names!r}:
+    z, df = gu.run(name, coolpup.pileup)
+    gu.compare(z, df, rtol=1e-6)
+print("RCCL RANK OK")
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.gpu
+def test_two_ranks_native_rccl_allreduce(hip_lib, tmp_path):
+    """pup_allreduce (the engine's own RCCL all-reduce, the default exchange with the nccl backend) between two real
+    ranks.  A box with a single GPU cannot host it — RCCL refuses two ranks on one device — and the test then says so
+    and is skipped; the gloo-bootstrapped test above covers the same host logic with two processes on one GPU."""
+    import torch
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER.format(root=ROOT, port=29531, names=["G3_nshifts3", "G6c_by_strand_distance_controls"]))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN")
+    if torch.cuda.device_count() >= 2:
+        script.write_text(script.read_text().replace('os.environ["COOLPUPPY_AMD_DEVICE"] = "0"', 'os.environ["COOLPUPPY_AMD_DEVICE"] = sys.argv[1]')
+                          .replace("torch.cuda.set_device(0)", "torch.cuda.set_device(int(sys.argv[1]))")
+                          .replace('torch.device("cuda", 0)', 'torch.device("cuda", int(sys.argv[1]))'))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              text=True, env=env) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=240)[0])
+        except subprocess.TimeoutExpired:
+            p.kill()
+            outs.append(p.communicate()[0] + "\nTIMEOUT")
+    if all(p.returncode == 0 for p in procs):
+        assert all("RCCL RANK OK" in o for o in outs)
+        return
+    text = "\n".join(outs)
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU on this box: RCCL cannot place two ranks on one device — " + text[-300:].replace("\n", " | "))
+    raise AssertionError(text[-3000:])

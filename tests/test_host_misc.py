@@ -26,27 +26,48 @@ def test_snippet_batches_matches_plan():
         assert any(a <= r and r + W <= b and a <= c and c + W <= b for a, b in lo.values())
 
 
-def test_slice_call_partitions_every_segment():
-    from coolpuppy_amd import dist as pdist
+def test_rows_of_table_keeps_only_owned_rows():
+    """A rank's partial pixel table: same number of rows, the rows it does not own empty, the others unchanged."""
     rng = np.random.default_rng(0)
-    n, T = 1000, 5
-    tile = np.sort(rng.integers(0, T, n)).astype(np.int32)
-    flip = np.zeros(n, bool)
-    for t in range(T):                                    # flipped snippets last inside each tile
-        idx = np.flatnonzero(tile == t)
-        flip[idx[len(idx) // 3 * 2:]] = True
-    call = coolpup._engine_call("r", "r", None, np.arange(n), np.arange(n) + 7, flip, tile.astype(np.int64), T, 2, 0)
-    seen = []
-    for rank in range(3):
-        s = pdist.slice_call(call, rank, 3)
-        seen.append(s["r0"])
-        assert np.array_equal(np.concatenate([[0], np.cumsum(np.bincount(s["tile"], minlength=T))]), s["tile_ptr"])
-        for t in range(T):
-            seg = s["flip"][s["tile_ptr"][t]:s["tile_ptr"][t + 1]].astype(bool)
-            k = int(s["flip_from"][t] - s["tile_ptr"][t])
-            assert not seg[:k].any() and seg[k:].all()
-    assert sorted(np.concatenate(seen).tolist()) == list(range(n))
+    lens = rng.integers(0, 9, 50)
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    col = rng.integers(0, 50, indptr[-1]).astype(np.int32)
+    cnt = rng.integers(1, 99, indptr[-1]).astype(np.int32)
+    rows = coolpup._merge_ranges([(30, 41), (5, 12), (10, 14)])
+    assert rows == [(5, 14), (30, 41)]
+    p2, c2, n2 = coolpup._rows_of_table(indptr, col, cnt, rows)
+    assert len(p2) == len(indptr)
+    for r in range(50):
+        own = any(a <= r < b for a, b in rows)
+        got = (c2[p2[r]:p2[r + 1]], n2[p2[r]:p2[r + 1]])
+        if own:
+            assert np.array_equal(got[0], col[indptr[r]:indptr[r + 1]]) and np.array_equal(got[1], cnt[indptr[r]:indptr[r + 1]])
+        else:
+            assert len(got[0]) == 0
+    p3, c3, _ = coolpup._rows_of_table(indptr, col, cnt, [])
+    assert p3[-1] == 0 and len(c3) == 0
 
+
+def test_skip_region_leaves_the_generator_where_the_windows_would():
+    """Draw-and-discard: stepping the control RNG past a region must consume exactly what generating it consumes."""
+    import golden_util as gu
+    for name in ("G3_nshifts3", "G9b_bed_combinations_controls_strand", "G7c_trans_bedpe_controls", "G5c_local_controls"):
+        z, meta, features, view, expected, kw = gu.load(name)
+        clr = gu.scenario_cooler(meta)
+        cc = coolpup.CoordCreator(features, clr.binsize, features_format=kw["features_format"], flank=kw["flank"],
+                                  nshifts=kw["nshifts"], seed=kw["seed"], local=kw.get("local", False),
+                                  trans=kw.get("trans", False), mindist=kw.get("mindist", "auto"), maxdist=kw.get("maxdist"))
+        chroms = list(clr.chromnames)
+        regs = [(c, 0, int(clr.chromsizes[c])) for c in chroms]
+        pairs = [(regs[0], regs[1]), (regs[0], regs[2])] if kw.get("trans") else [(r, None) for r in regs]
+        np.random.seed(5)
+        for a, b in pairs:
+            cc.region_table(a, b, control=True)
+        want = np.random.randint(0, 1 << 30)
+        np.random.seed(5)
+        for a, b in pairs:
+            cc.skip_region(a, b, control=True)
+        assert np.random.randint(0, 1 << 30) == want, name
 
 
 def test_block_order_groups_snippets_by_tile_and_block():
