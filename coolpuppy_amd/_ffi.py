@@ -81,6 +81,13 @@ _SIGNATURES = {
     "pup_event_record": (C.c_int, [C.c_void_p, C.c_int]),
     "pup_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "pup_set_tuning": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "pup_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "pup_host_free": (C.c_int, [C.c_void_p]),
+    "pup_host_windows": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
+                                     C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                     C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    "pup_host_group_tiles": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

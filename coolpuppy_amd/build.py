@@ -5,7 +5,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "pup_engine.hip")
-DEPS = [SRC, os.path.join(_HERE, "csrc", "pup_kernels.hpp"),
+SRC_HOST = os.path.join(_HERE, "csrc", "pup_host.cpp")          # pinned memory + host array passes (no kernels)
+DEPS = [SRC, SRC_HOST, os.path.join(_HERE, "csrc", "pup_kernels.hpp"),
         os.path.join(os.path.dirname(_HERE), "include", "pup_hip.h")]
 OUT = os.path.join(_HERE, "libpup_hip.so")
 
@@ -29,7 +30,7 @@ def build_hip(force=False, verbose=False):
     if not force and not is_stale():
         return OUT
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
-           "-Wall", "-Wno-unused-result", SRC, "-o", OUT]
+           "-Wall", "-Wno-unused-result", "-pthread", SRC, "-x", "hip", SRC_HOST, "-o", OUT]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)

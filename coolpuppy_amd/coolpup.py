@@ -19,6 +19,7 @@ same engine (K3 / K4 / K5).  Per-snippet Python callbacks (``postprocess_func`` 
 windows from the engine (``pup_extract``, K6) and run, with the reference's per-snippet bookkeeping, on the host.
 """
 import itertools
+import threading
 import logging
 import os
 import re
@@ -272,7 +273,7 @@ class CoordCreator:
             iv["center1"] = c1
             iv["center2"] = c2
             iv["distance"] = c2 - c1
-            iv = iv.sort_values(["chrom1", "chrom2", "start1", "start2"])
+            iv = self._sort_pairs(iv)
             presorted = True
             iv = expand2D(iv, self.flank, self.resolution, self.rescale_flank)
         self.intervals = iv
@@ -320,6 +321,23 @@ class CoordCreator:
             raise ValueError("Cannot do local with trans=True")
 
         self.pos_stream = self.get_combinations if self.kind == "bed" else self.get_intervals_stream
+
+    def _sort_pairs(self, iv):
+        """iv.sort_values(["chrom1", "chrom2", "start1", "start2"]) — the same stable order, index labels kept — from
+        integer keys: the chromosome names are factorised once (both columns together; the codes are kept for the region
+        selections, _cache) and ranked in string order, so the sort itself only compares integers."""
+        n = len(iv)
+        s1, s2 = iv["start1"].to_numpy(), iv["start2"].to_numpy()
+        if n == 0 or s1.dtype.kind not in "iu" or s2.dtype.kind not in "iu" or s1.min() < 0 or s1.max() >= 2**31:
+            return iv.sort_values(["chrom1", "chrom2", "start1", "start2"])
+        codes, uniq = pd.factorize(np.concatenate([iv["chrom1"].to_numpy(), iv["chrom2"].to_numpy()]))
+        rank = np.empty(len(uniq), np.int64)
+        rank[np.argsort(np.asarray(uniq, dtype=object), kind="stable")] = np.arange(len(uniq))
+        hi = ((rank[codes[:n]] * len(uniq) + rank[codes[n:]]) << 32) | s1.astype(np.int64)
+        order = np.lexsort((s2, hi))
+        out = iv.take(order)
+        self._sorted_codes = (out, codes[:n][order], codes[n:][order], uniq)      # valid while self.intervals has these rows
+        return out
 
     def _subset(self, df):
         if self.seed is not None:
@@ -373,6 +391,17 @@ class CoordCreator:
         df = out.frame()
         df["kind"] = np.where(out["kind"] == KIND_ROI, "ROI", "control")
         return df
+
+    def _draw_raw(self, m):
+        """The reference's RNG calls for m control windows (:420-436), in its order, un-multiplied: (|shift|, sign) of the
+        draw that moves the BINS of both sides (the second pair of a trans pile-up, which only moves bp columns, is drawn
+        and dropped)."""
+        shift = np.random.randint(self.minshift, self.maxshift, m)
+        sign = np.random.choice([-1, 1], m)
+        if self.trans:
+            np.random.randint(self.minshift, self.maxshift, m)
+            np.random.choice([-1, 1], m)
+        return shift, sign
 
     def _draw_shifts(self, m):
         """The reference's RNG calls for m control windows (:420-436), in its order: (shift, shift2) in bp."""
@@ -473,9 +502,16 @@ class CoordCreator:
         c = {"id": iv, "cols": {}, "gc": {}}
         if self.kind == "bedpe":
             n = len(iv)
-            codes, uniq = pd.factorize(np.concatenate([iv["chrom1"].values, iv["chrom2"].values]))
+            sc = getattr(self, "_sorted_codes", None)
+            probe = np.linspace(0, max(n - 1, 0), num=min(n, 256), dtype=np.int64)
+            if sc is not None and len(sc[1]) == n and n > 0 and np.array_equal(iv.index.values, sc[0].index.values) and \
+                    all(iv["chrom1"].values[i] == sc[3][sc[1][i]] and iv["chrom2"].values[i] == sc[3][sc[2][i]] for i in probe):
+                c1, c2, uniq = sc[1], sc[2], sc[3]          # factorised when the pairs were sorted, rows unchanged since
+            else:
+                codes, uniq = pd.factorize(np.concatenate([iv["chrom1"].values, iv["chrom2"].values]))
+                c1, c2 = codes[:n], codes[n:]
             c["chrom_code"] = {str(u): i for i, u in enumerate(uniq)}
-            c["c1"], c["c2"] = codes[:n], codes[n:]
+            c["c1"], c["c2"] = c1, c2
             for k in ("start1", "end1", "start2", "end2"):
                 c[k] = iv[k].values
         else:
@@ -769,21 +805,44 @@ def _engine_for(clr, device_id, rows=None):
     from .engine import PileupEngine
     rows = None if rows is None else tuple((int(a), int(b)) for a, b in rows)
     key = (id(clr), device_id, rows)
-    hit = _ENGINES.get(key)
-    if hit is not None and hit[0] is clr:
-        eng = hit[1]
-    else:
-        for k in [k for k, v in _ENGINES.items() if k[1] == device_id]:   # one table per device at a time
-            _ENGINES.pop(k)[1].close()
-        eng = PileupEngine(device_id)
-        indptr, col, cnt = clr.pixel_table()
-        if rows is not None:
-            indptr, col, cnt = _rows_of_table(indptr, col, cnt, rows)
-        eng.load_pixels(indptr, col, cnt)
-        eng.build_index(clr.chrom_offset)      # optional accelerator; False (too large) just means binary search
-        _ENGINES[key] = (clr, eng)
-    eng.set_tuning(0, int(os.environ.get("COOLPUPPY_AMD_VARIANT", "0") or 0))
+    with _ENGINE_LOCK:                         # a prefetch (below) may be uploading this very table right now
+        hit = _ENGINES.get(key)
+        if hit is not None and hit[0] is clr:
+            eng = hit[1]
+        else:
+            for k in [k for k, v in _ENGINES.items() if k[1] == device_id]:   # one table per device at a time
+                _ENGINES.pop(k)[1].close()
+            eng = PileupEngine(device_id)
+            indptr, col, cnt = clr.pixel_table()
+            if rows is not None:
+                indptr, col, cnt = _rows_of_table(indptr, col, cnt, rows)
+            eng.load_pixels(indptr, col, cnt)
+            eng.build_index(clr.chrom_offset)      # optional accelerator; False (too large) just means binary search
+            _ENGINES[key] = (clr, eng)
+        eng.set_tuning(0, int(os.environ.get("COOLPUPPY_AMD_VARIANT", "0") or 0))
     return eng
+
+
+_ENGINE_LOCK = threading.RLock()
+
+
+def _prefetch_engine(clr, device_id, rows=None):
+    """Start moving the pixel table to the GPU (and building its index) on a helper thread while the caller works out
+    the window coordinates: the copies and kernels release the interpreter, so the first pile-up on a table pays
+    max(upload, coordinates) instead of their sum.  Errors surface when run_plan asks for the engine itself."""
+    rows_key = None if rows is None else tuple((int(a), int(b)) for a, b in rows)
+    hit = _ENGINES.get((id(clr), device_id, rows_key))
+    if hit is not None and hit[0] is clr:
+        return None
+
+    def work():
+        try:
+            _engine_for(clr, device_id, rows)
+        except Exception:           # noqa: BLE001 - reported by the foreground call
+            pass
+    t = threading.Thread(target=work, name="pup-table-upload", daemon=True)
+    t.start()
+    return t
 
 
 def _rows_of_table(indptr, col, cnt, rows):
@@ -982,6 +1041,8 @@ class PileUpper:
         if region2 is None:
             region2 = region1
         reg1, reg2 = self._region_tuple(region1), self._region_tuple(region2)
+        if self._plain_pairs(modify_2Dintervals_func, by_window, keep_table):
+            return self._pair_snippets(region1, region2, reg1, reg2, groupby, modify_2Dintervals_func)
         carry = columns
         # keep_table (callback path): rows must carry the reference's own column values (e.g. band tuples), so
         # even the built-in modify functions run in their DataFrame form
@@ -1070,6 +1131,66 @@ class PileUpper:
             out["table"] = tbl                 # the accepted rows with every carried column (callback path)
         return out
 
+    def _plain_pairs(self, modify, by_window, keep_table):
+        """True when the windows of a region are plain feature pairs: bedpe features, no rescaling, stripes, flips,
+        by-window grouping or user functions — the case _pair_snippets builds with one fused pass of the library."""
+        if self.CC.kind != "bedpe" or by_window or keep_table or self.store_stripes or getattr(self, "rescale", False):
+            return False
+        if self.flip_negative_strand or getattr(self, "ignore_group_order", False):
+            return False
+        if len(self.CC.intervals) == 0 or self.CC.pos_stream == self.CC.empty_stream:
+            return False
+        return modify is None or modify is bin_distance_intervals or \
+            (isinstance(modify, partial) and modify.func is bin_distance_intervals)
+
+    def _pair_snippets(self, region1, region2, reg1, reg2, groupby, modify):
+        """region_snippets for plain feature pairs (see _plain_pairs).  Same result as the general path — the ROI windows
+        followed by nshifts shifted copies (reference :387-453, same RNG calls in the same order), bounds test (:1105-1114),
+        group keys in order of first appearance — but group codes are worked out on the ROI rows only (a control copy
+        belongs to the group of its ROI window: distance, strands and every other feature column are copied, :405-419) and
+        shifting, bounds test and compaction are one pass of the library (pup_host_windows) into page-locked arrays."""
+        from . import engine as _engine
+        CC = self.CC
+        rows = CC._rows_trans_pairs(tuple(reg1), tuple(reg2)) if CC.trans else CC._rows_pairs_region(tuple(reg1))
+        n = len(rows)
+        if n == 0:
+            return None
+        st1, st2 = CC._col("stBin1")[rows], CC._col("stBin2")[rows]
+        W = 2 * self.pad_bins + 1
+        if not (np.all(CC._col("endBin1")[rows] - st1 == W) and np.all(CC._col("endBin2")[rows] - st2 == W)):
+            raise ValueError("window size differs from 2*pad_bins+1")
+        codes, keys = None, []
+        if groupby:
+            keycols, decs = [], []
+            for g in groupby:
+                if g == "distance_band":
+                    kw = modify.keywords if isinstance(modify, partial) else {}
+                    edges = kw.get("band_edges", "default")
+                    if isinstance(edges, str) and edges == "default":
+                        edges = _default_band_edges()
+                    keycols.append(np.searchsorted(edges, CC._col("distance")[rows], side="right"))
+                    decs.append(lambda i, e=edges: tuple(e[i - 1:i + 1]))
+                    continue
+                name, dec = self._group_source(g)
+                keycols.append(CC.group_codes(name[4:])[0][rows] if name.startswith("_gc_") else CC._col(name)[rows])
+                decs.append(dec)
+            codes, keys = _factorize_rows(keycols, decs)
+        nshifts = self.nshifts if self.control else 0
+        shift = sign = None
+        if nshifts > 0:
+            shift, sign = CC._draw_raw(n * nshifts)
+        lo1, hi1, off1 = self._global_extents[region1]
+        lo2, hi2, off2 = self._global_extents[region2]
+        r0, c0, code_out, n_roi = _engine.host_windows(st1, st2, codes, shift, sign, nshifts, self.resolution, off1, off2,
+                                                       lo1, hi1, lo2, hi2, W, W)
+        m = len(r0)
+        kind = np.empty(m, np.int8)
+        kind[:n_roi] = KIND_ROI
+        kind[n_roi:] = KIND_CONTROL
+        size = np.broadcast_to(np.int32(W), (m,))
+        return {"r0": r0, "c0": c0, "kind": kind, "flip": None, "n": m, "coords": None, "h": size, "w": size,
+                "group_codes": code_out if code_out is not None else np.full(m, -1, np.int64), "group_keys": keys}
+
     # -- the pile-up -------------------------------------------------------------------------------------------
     def _flip_column(self, groupby):
         """The paired annotation whose order decides which snippets are flipped: "strand" (flip_negative_strand), the
@@ -1147,6 +1268,8 @@ class PileUpper:
             ext = self._global_extents
             self._owned_rows = _merge_ranges([min(ext[r1][:2], ext[r2][:2]) for i, (r1, r2) in enumerate(pairs) if i in owned])
         grouped = bool(groupby) or _by_window
+        if getattr(self, "_window_source", None) is None:
+            _prefetch_engine(self._aclr, _dist.local_device(), rows=self._owned_rows if world > 1 else None)
         batches = []
         for i, (region1, region2) in enumerate(pairs):
             if owned is not None and i not in owned:
@@ -1242,8 +1365,8 @@ class PileUpper:
         for bi, (region1, region2, b) in enumerate(batches):
             if b is None or b["n"] == 0:
                 continue
-            if grouped:
-                g = np.array([gid[k] for k in b["group_keys"]], np.int32)[b["group_codes"]]
+            if grouped:     # (a key none of the region's kept windows uses is not in the table: its code never occurs)
+                g = np.array([gid.get(k, -1) for k in b["group_keys"]], np.int32)[b["group_codes"]]
             else:
                 g = np.zeros(b["n"], np.int32)
             expected = None
@@ -1265,7 +1388,8 @@ class PileUpper:
                         igd, mode, hh, ww, bi))
             if exp_as_control:
                 roi = b["kind"] == KIND_ROI
-                raw.append((region1, region2, expected, r0[roi], c0[roi], b["flip"][roi], G + g[roi], igd,
+                raw.append((region1, region2, expected, r0[roi], c0[roi], None if b["flip"] is None else b["flip"][roi],
+                            G + g[roi], igd,
                             MODE_EXPECTED | tr | loc, hh[roi], ww[roi], bi))
         # regions that need no per-region state (no expected vector) and share mode / diagonal mask go to the
         # engine as ONE call: fewer launches, and the engine's interleaved groups span region boundaries
@@ -1734,6 +1858,13 @@ def _engine_call_parts(region1, region2, expected, parts, T, igd, mode, rescale)
     first: each part is grouped by (tile, flip) on its own (cache-sized stable radix sorts), then the segments
     are copied straight to their final place — region order inside a segment is the stable order of the whole."""
     nk = 2 * T
+    if not rescale and all(p[2] is None or not np.any(p[2]) for p in parts):
+        # nothing flipped: one stable counting sort of the library over all parts, into page-locked arrays
+        from . import engine as _engine
+        r0, c0, tile_ptr = _engine.group_tiles([(p[0], p[1], p[3]) for p in parts], T)
+        return {"region1": region1, "region2": region2, "expected": expected, "r0": r0, "c0": c0, "flip": None,
+                "flip_from": None, "tile": np.repeat(np.arange(T, dtype=np.int32), np.diff(tile_ptr)), "tile_ptr": tile_ptr,
+                "ignore_diags": igd, "mode": mode}
     if len(parts) == 1 or nk >= 65536 or nk * len(parts) > 200_000:
         f = [np.concatenate([p[k] for p in parts]) if len(parts) > 1 else parts[0][k] for k in range(6)]
         return _engine_call(region1, region2, expected, f[0], f[1], f[2], f[3], T, igd, mode,

@@ -825,6 +825,19 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
                            int64_t n, const int64_t* tile_ptr, const int64_t* flip_from, int32_t ignore_diags,
                            uint32_t mode);
 
+static bool is_page_locked(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+
+static hipError_t upload_snippets(pup_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (is_page_locked(src)) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+}
+
 int pup_accumulate(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, const int64_t* tile_ptr,
                    const int64_t* flip_from, int32_t ignore_diags, uint32_t mode) {
     if (mode & PUP_MODE_LOCAL) return c ? fail(c, PUP_EINVAL, "pup_accumulate: PUP_MODE_LOCAL only applies to rescaled pile-ups") : PUP_EINVAL;
@@ -881,17 +894,18 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     const int *dr0, *dc0;
     if (mode & PUP_MODE_DEVPTR) { dr0 = r0; dc0 = c0; }
     else {
-        // earlier launches may still read the staging buffers
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        // page-locked source (pup_host_alloc): DMA queued on the context's stream — it starts when the launches that still
+        // read the staging buffers are done, and the caller is not held up.  Pageable source: wait for those launches,
+        // then a blocking copy (the caller may release such an array as soon as this returns).
         HIPCHK(c, c->d_r0.reserve((size_t)n)); HIPCHK(c, c->d_c0.reserve((size_t)n));
-        HIPCHK(c, hipMemcpy(c->d_r0.p, r0, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(c->d_c0.p, c0, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(c, upload_snippets(c, c->d_r0.p, r0, (size_t)n * sizeof(int)));
+        HIPCHK(c, upload_snippets(c, c->d_c0.p, c0, (size_t)n * sizeof(int)));
         dr0 = c->d_r0.p; dc0 = c->d_c0.p;
     }
     if (rescale) {
         HIPCHK(c, c->d_h.reserve((size_t)n)); HIPCHK(c, c->d_w.reserve((size_t)n));
-        HIPCHK(c, hipMemcpy(c->d_h.p, hgt, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(c->d_w.p, wid, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(c, upload_snippets(c, c->d_h.p, hgt, (size_t)n * sizeof(int)));
+        HIPCHK(c, upload_snippets(c, c->d_w.p, wid, (size_t)n * sizeof(int)));
         const size_t need = (size_t)c->W * c->W * 12 + 16 * (size_t)c->W;
         if (need > (size_t)c->max_lds)
             return fail(c, PUP_ENOTSUP, "pup_accumulate_rescaled: a %dx%d output tile needs %zu B of LDS, device offers %d",

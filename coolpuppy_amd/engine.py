@@ -282,3 +282,102 @@ def device_count():
     if n < 0:
         raise PupError(n, _ffi.lib().pup_last_error(None).decode())
     return n
+
+
+# ---- host-side helpers of the library (no GPU work) ---------------------------------------------------------------------
+class _PinnedPool:
+    """Page-locked host blocks from pup_host_alloc, recycled: pinning memory costs about as much as copying it, so freed
+    blocks are kept (up to `keep` bytes) for the next arrays of the same size class (powers of two from 1 MiB)."""
+
+    def __init__(self, keep=2 << 30):
+        self.free, self.kept, self.keep, self.broken = {}, 0, keep, False
+
+    def take(self, nbytes):
+        size = 1 << 20
+        while size < nbytes:
+            size <<= 1
+        lst = self.free.get(size)
+        if lst:
+            self.kept -= size
+            return lst.pop(), size
+        if self.broken:
+            return None, size
+        p = C.c_void_p()
+        try:
+            rc = _ffi.lib().pup_host_alloc(C.byref(p), size)
+        except Exception:
+            rc = -1
+        if rc != 0 or not p.value:
+            self.broken = True              # no HIP runtime / no device here: plain numpy arrays from now on
+            return None, size
+        return p.value, size
+
+    def give(self, ptr, size):
+        if self.kept + size <= self.keep:
+            self.free.setdefault(size, []).append(ptr)
+            self.kept += size
+        else:
+            _ffi.lib().pup_host_free(C.c_void_p(ptr))
+
+
+_POOL = _PinnedPool()
+
+
+class _PinnedBlock:
+    def __init__(self, ptr, size, nbytes):
+        self.ptr, self.size = ptr, size
+        self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
+
+    def __del__(self):
+        try:
+            _POOL.give(self.ptr, self.size)
+        except Exception:
+            pass
+
+
+def pinned_empty(n, dtype=np.int32):
+    """Uninitialised 1-D array in page-locked memory (pup_host_alloc) — pup_accumulate copies such arrays to the device by
+    asynchronous DMA.  The block returns to a pool when the array (and every view of it) is gone.  Falls back to an ordinary
+    numpy array where the HIP runtime cannot pin memory (no device)."""
+    dtype = np.dtype(dtype)
+    nbytes = max(int(n) * dtype.itemsize, 1)
+    ptr, size = _POOL.take(nbytes)
+    if ptr is None:
+        return np.empty(int(n), dtype)
+    return np.asarray(_PinnedBlock(ptr, size, nbytes)).view(dtype)[:int(n)]
+
+
+def host_windows(st1, st2, code, shift, sign, nshifts, resolution, off1, off2, lo1, hi1, lo2, hi2, h, w):
+    """pup_host_windows: ROI windows + shifted control copies of one region, bounds-tested, as (r0, c0, code, n_roi_kept);
+    r0 / c0 are page-locked.  st1 / st2 / code: int32 per ROI row (code may be None); shift / sign: int64, n*nshifts each."""
+    st1, st2 = _as(st1, np.int32), _as(st2, np.int32)
+    n = st1.shape[0]
+    cap = n * (1 + int(nshifts))
+    code = None if code is None else _as(code, np.int32)
+    shift = None if shift is None else _as(shift, np.int64)
+    sign = None if sign is None else _as(sign, np.int64)
+    r0, c0 = pinned_empty(cap), pinned_empty(cap)
+    code_out = np.empty(cap, np.int32) if code is not None else None
+    n_roi = C.c_int64(0)
+    kept = _ffi.lib().pup_host_windows(_ptr(st1), _ptr(st2), _ptr(code), n, _ptr(shift), _ptr(sign), int(nshifts),
+                                       float(resolution), int(off1), int(off2), int(lo1), int(hi1), int(lo2), int(hi2),
+                                       int(h), int(w), _ptr(r0), _ptr(c0), _ptr(code_out), C.byref(n_roi))
+    if kept < 0:
+        raise ValueError("pup_host_windows: bad arguments")
+    return r0[:kept], c0[:kept], (None if code_out is None else code_out[:kept]), int(n_roi.value)
+
+
+def group_tiles(parts, T):
+    """pup_host_group_tiles: [(r0, c0, tile), ...] (int32 arrays per region) -> (r0, c0, tile_ptr) of one engine call,
+    stably grouped by tile; r0 / c0 page-locked."""
+    keep = [(_as(a, np.int32), _as(b, np.int32), _as(t, np.int32)) for a, b, t in parts]
+    P = len(keep)
+    n = sum(a.shape[0] for a, _, _ in keep)
+    arr = lambda k: (C.c_void_p * max(P, 1))(*[x[k].ctypes.data for x in keep])       # noqa: E731
+    lens = np.array([a.shape[0] for a, _, _ in keep], np.int64)
+    r0, c0 = pinned_empty(n), pinned_empty(n)
+    tile_ptr = np.empty(int(T) + 1, np.int64)
+    rc = _ffi.lib().pup_host_group_tiles(P, arr(0), arr(1), arr(2), _ptr(lens), int(T), _ptr(r0), _ptr(c0), _ptr(tile_ptr))
+    if rc != 0:
+        raise ValueError("pup_host_group_tiles: tile id outside [0, T)")
+    return r0, c0, tile_ptr

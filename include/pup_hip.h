@@ -251,6 +251,40 @@ int pup_event_elapsed_ms(pup_ctx* ctx, int slot_begin, int slot_end, float* ms);
  * Results do not depend on which kernel ran (integers exactly, sums up to the order of the f64 additions). */
 int pup_set_tuning(pup_ctx* ctx, int32_t chunk_snippets, int32_t variant);
 
+/*
+ * ---- host-side helpers (no kernel involved) ---------------------------------------------------------------------------
+ *
+ * pup_host_alloc / pup_host_free: page-locked host memory.  Snippet arrays handed to pup_accumulate from such memory
+ * reach the device by asynchronous DMA on the context's stream, ordered behind the kernels already queued — no staging
+ * copy and no host synchronisation (north_star: "cooler HDF5 I/O stays on the host with pinned hipMemcpyAsync overlap").
+ * Pageable arrays keep working: the runtime stages them and the call returns when the staging copy is done.  Either way
+ * the arrays must stay untouched until the next pup_sync / pup_fetch.
+ */
+int pup_host_alloc(void** ptr, size_t bytes);
+int pup_host_free(void* ptr);
+
+/*
+ * pup_host_windows: the windows of one region (pair) — its n ROI windows followed by nshifts shifted control copies
+ * of all of them — as engine input.  Replaces the per-snippet loop of CoordCreator._control_regions
+ * (coolpuppy/coolpup.py:387-453: both sides of copy m move by round(shift[m]*sign[m]/resolution) bins, half-to-even; shift
+ * and sign are the caller's RNG draws, in the reference's order) and the bounds test of _stream_snips (:1105-1114: a window
+ * is kept when lo1 <= r0, r0+h <= hi1, lo2 <= c0, c0+w <= hi2 with r0 = st1+off1, c0 = st2+off2).  Kept windows are written
+ * in order to r0 / c0 (capacity n*(1+nshifts)); code (nullable) is a per-ROI-row value copied to code_out for every kept
+ * window of that row.  Returns the number kept (< 0: bad arguments); *n_roi_kept of them come from the ROI rows.
+ */
+int64_t pup_host_windows(const int32_t* st1, const int32_t* st2, const int32_t* code, int64_t n,
+                         const int64_t* shift, const int64_t* sign, int32_t nshifts, double resolution,
+                         int64_t off1, int64_t off2, int64_t lo1, int64_t hi1, int64_t lo2, int64_t hi2,
+                         int32_t h, int32_t w, int32_t* r0, int32_t* c0, int32_t* code_out, int64_t* n_roi_kept);
+
+/*
+ * pup_host_group_tiles: the windows of several regions gathered into ONE pup_accumulate call — stable grouping by tile id
+ * over the concatenation of the parts (what reduce(sum_pups) over per-region dicts amounts to for the tile layout,
+ * coolpuppy/coolpup.py:1495-1531).  r0_out / c0_out hold sum(len) entries, tile_ptr T+1.
+ */
+int pup_host_group_tiles(int32_t n_parts, const int32_t* const* r0, const int32_t* const* c0, const int32_t* const* tile,
+                         const int64_t* len, int32_t T, int32_t* r0_out, int32_t* c0_out, int64_t* tile_ptr);
+
 #ifdef __cplusplus
 }
 #endif
