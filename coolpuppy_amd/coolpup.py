@@ -334,7 +334,18 @@ class CoordCreator:
         rank = np.empty(len(uniq), np.int64)
         rank[np.argsort(np.asarray(uniq, dtype=object), kind="stable")] = np.arange(len(uniq))
         hi = ((rank[codes[:n]] * len(uniq) + rank[codes[n:]]) << 32) | s1.astype(np.int64)
-        order = np.lexsort((s2, hi))
+        # (pair, start1) is nearly always unique: an unstable vectorised sort on that one key, then the few runs of equal
+        # keys are put in (start2, original position) order — together the stable four-key order
+        order = np.argsort(hi)
+        hs = hi[order]
+        tie = hs[1:] == hs[:-1]
+        if tie.any():
+            in_run = np.zeros(n, bool)
+            in_run[1:] |= tie
+            in_run[:-1] |= tie
+            at = np.flatnonzero(in_run)
+            sub = order[at]
+            order[at] = sub[np.lexsort((sub, s2[sub], hi[sub]))]
         out = iv.take(order)
         self._sorted_codes = (out, codes[:n][order], codes[n:][order], uniq)      # valid while self.intervals has these rows
         return out
@@ -967,8 +978,12 @@ class PileUpper:
             from . import dist as _dist
             if not hasattr(self._aclr, "set_bins_column"):
                 raise ValueError(f"cannot store the computed {self.coverage_norm!r} column in this cooler object")
-            eng = _engine_for(self._aclr, _dist.local_device())
-            cis, tot = eng.coverage(self._aclr.chrom_offset, ignore_diags=self.ignore_diags)
+            src = getattr(self, "_coverage_source", None)      # tests: an oracle stand-in with the same result
+            if src is not None:
+                cis, tot = src(self._aclr, self.ignore_diags)
+            else:
+                eng = _engine_for(self._aclr, _dist.local_device())
+                cis, tot = eng.coverage(self._aclr.chrom_offset, ignore_diags=self.ignore_diags)
             self._aclr.set_bins_column("cov_cis_raw", cis)
             self._aclr.set_bins_column("cov_tot_raw", tot)
         if self.coverage_norm and self.clr_weight_name:
@@ -1188,7 +1203,7 @@ class PileUpper:
         kind[:n_roi] = KIND_ROI
         kind[n_roi:] = KIND_CONTROL
         size = np.broadcast_to(np.int32(W), (m,))
-        return {"r0": r0, "c0": c0, "kind": kind, "flip": None, "n": m, "coords": None, "h": size, "w": size,
+        return {"r0": r0, "c0": c0, "kind": kind, "flip": None, "n": m, "n_roi": n_roi, "coords": None, "h": size, "w": size,
                 "group_codes": code_out if code_out is not None else np.full(m, -1, np.int64), "group_keys": keys}
 
     # -- the pile-up -------------------------------------------------------------------------------------------
@@ -1303,8 +1318,12 @@ class PileUpper:
                 if kind == KIND_CONTROL and not want_control:
                     continue
                 # with expected & !ooe every ROI snippet also emits an expected ("control") snippet
-                sel = b["kind"] == (KIND_ROI if (exp_as_control and kind == KIND_CONTROL) else kind)
-                out[kind] = [b["group_keys"][c] for c in pd.unique(b["group_codes"][sel])]
+                src = KIND_ROI if (exp_as_control and kind == KIND_CONTROL) else kind
+                if "n_roi" in b:       # ROI windows first, then the controls
+                    codes = b["group_codes"][:b["n_roi"]] if src == KIND_ROI else b["group_codes"][b["n_roi"]:]
+                else:
+                    codes = b["group_codes"][b["kind"] == src]
+                out[kind] = [b["group_keys"][c] for c in pd.unique(codes)]
         return out
 
     def make_plan(self, batches, groupby, grouped=None, region_groups=None):
@@ -1384,8 +1403,12 @@ class PileUpper:
             tr = MODE_TRANSPOSE if transpose else 0
             loc = MODE_LOCAL if (rescale and self.local) else 0
             mode = (MODE_OOE if (self.expected and self.ooe) else 0) | (MODE_COV if self.coverage_norm else 0) | tr | loc
-            raw.append((region1, region2, expected, r0, c0, b["flip"], b["kind"].astype(np.int32) * np.int32(G) + g,
-                        igd, mode, hh, ww, bi))
+            if "n_roi" in b:           # ROI windows first, then the controls: tile = group, + G from there on
+                tile = g if g.flags.writeable and g.base is None else g.copy()
+                tile[b["n_roi"]:] += np.int32(G)
+            else:
+                tile = b["kind"].astype(np.int32) * np.int32(G) + g
+            raw.append((region1, region2, expected, r0, c0, b["flip"], tile, igd, mode, hh, ww, bi))
             if exp_as_control:
                 roi = b["kind"] == KIND_ROI
                 raw.append((region1, region2, expected, r0[roi], c0[roi], None if b["flip"] is None else b["flip"][roi],

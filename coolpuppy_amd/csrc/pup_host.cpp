@@ -20,7 +20,7 @@ namespace {
 
 int n_workers(int64_t rows) {
     const unsigned hw = std::thread::hardware_concurrency();
-    int64_t want = rows / 400000 + 1;                     // a thread is worth starting for ~0.4 M rows
+    int64_t want = rows / 150000 + 1;                     // a thread is worth starting for ~0.15 M rows
     want = std::min<int64_t>(want, std::max(1u, std::min(hw, 16u)));
     return (int)want;
 }

@@ -969,7 +969,7 @@ __global__ __launch_bounds__(kWave * NW) void pileup_wgtile_kernel(K1Args a) {
         const unsigned long long lv = __ballot(live && slot == 0);
         if (lane == 0) {
             atomicAdd(&fact_tot[2 * W], (unsigned)__popcll(lv));
-            if (ACC == 2) atomicAdd(&fact_tot[(2 * W + 1) + 2 * W], (unsigned)(nb - __popcll(lv)));
+            if constexpr (ACC == 2) atomicAdd(&fact_tot[(2 * W + 1) + 2 * W], (unsigned)(nb - __popcll(lv)));
         }
         unsigned cc = cbm;
         while (cc) { const int q = __ffs((int)cc) - 1; cc &= cc - 1u; atomicAdd(&fact_tot[tb + W + q], 1u); }
@@ -1982,12 +1982,13 @@ __global__ __launch_bounds__(64 * kRedParts) void reduce_partials_kernel(
 // a workgroup owns kCovRows consecutive rows; row sums are wave-reduced, column sums go to an LDS histogram over
 // the kCovCols columns following the block's first row (where almost all cis mass lies) and to global integer
 // atomics beyond it.  Integer (u64) accumulation: exact and order-independent.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
 constexpr int kCovRows = 64;
-constexpr int kCovCols = 4096;
+constexpr int kCovCols = 2048;      // LDS window of column sums per workgroup (16 KiB: up to 8 workgroups share a CU)
 // cov_cis accumulates intra-chromosomal pixels, cov_trans inter-chromosomal ones (one atomic per pixel either way);
 // the host forms cov_tot = cov_cis + cov_trans.  A wave streams its row with 16-byte loads (two pixels per lane), two
-// loads in flight per lane: the pass is bound by load latency, not by the LDS atomics (the distinct columns of one
-// row never collide).  Columns beyond the block's LDS window and all trans columns take global atomics.
+// loads in flight per lane (see below): the pass is bound by load latency, not by the LDS atomics (the distinct columns
+// of one row never collide).  Columns beyond the block's LDS window and all trans columns take global atomics.
 __global__ __launch_bounds__(256) void coverage_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
                                                        const IdxChrom* __restrict__ chroms, int n_chrom, int ignore_diags,
                                                        unsigned long long* cov_trans, unsigned long long* cov_cis,
@@ -2013,13 +2014,17 @@ __global__ __launch_bounds__(256) void coverage_kernel(const long long* __restri
             if (rel < kCovCols) atomicAdd(&h_cis[rel], w);
             else atomicAdd(&cov_cis[col], w);
         };
-        // pixel pairs at even offsets (16-byte aligned); the table is padded, so the pair straddling e is readable
-        for (long long k = (b & ~1LL) + 2 * lane; k < e; k += 256) {
-            const int4 v0 = *reinterpret_cast<const int4*>(px + k);
-            const bool two = k + 128 < e;
-            const int4 v1 = two ? *reinterpret_cast<const int4*>(px + k + 128) : int4{0, 0, 0, 0};
-            add(k, v0.x, v0.y); add(k + 1, v0.z, v0.w);
-            if (two) { add(k + 128, v1.x, v1.y); add(k + 129, v1.z, v1.w); }
+        // pixel pairs at even offsets (16-byte aligned); the table is padded, so the pair straddling e is readable.
+        // Four 16-byte loads per lane are issued before the first is consumed (4 KiB in flight per wave): the pass is a
+        // pure stream, what limits it is how many bytes the CU keeps outstanding
+        for (long long k = (b & ~1LL) + 2 * lane; k < e; k += 512) {
+            int4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (k + 128 * u < e) { const v4i_t t = __builtin_nontemporal_load(reinterpret_cast<const v4i_t*>(px + k + 128 * u)); v[u] = int4{t.x, t.y, t.z, t.w}; }
+                else v[u] = int4{0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { add(k + 128 * u, v[u].x, v[u].y); add(k + 128 * u + 1, v[u].z, v[u].w); }
         }
         for (int off = 32; off > 0; off >>= 1) { s_trans += __shfl_down(s_trans, off); s_cis += __shfl_down(s_cis, off); }
         if (lane == 0) {

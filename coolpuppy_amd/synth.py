@@ -175,7 +175,8 @@ def random_trans_pairs(clr, n_pairs, seed=43):
 
 def patched_cooler(clr, patch):
     """A copy of the in-memory cooler `clr` with some bins columns overwritten: patch = {column: {value_name: [bins]}},
-    value_name one of "nan", "inf", "-inf", "zero" (JSON-friendly: golden scenarios store the patch in their meta)."""
+    value_name one of "nan", "inf", "-inf", "zero", plus {"drop": [columns]} (JSON-friendly: golden scenarios store the patch
+    in their meta)."""
     from .cooler_lite import ArrayCooler
     vals = {"nan": np.nan, "inf": np.inf, "-inf": -np.inf, "zero": 0.0}
     cols = {}
@@ -184,7 +185,11 @@ def patched_cooler(clr, patch):
             cols[c] = np.array(clr.bins()[c][:].values, dtype=np.float64)
         except KeyError:
             pass
+    for name in (patch or {}).get("drop", []):          # {"drop": [columns]}: a cooler that lacks them
+        cols.pop(name, None)
     for col, edits in (patch or {}).items():
+        if col == "drop":
+            continue
         for what, where in edits.items():
             cols[col][np.asarray(where, dtype=np.int64)] = vals[what]
     return ArrayCooler(clr.chromsizes, clr.binsize, clr.bin1_offset, clr.bin2_id, clr.count, bins=cols, filename=clr.filename)

@@ -237,6 +237,12 @@ def scenarios():
         patch={"cov_tot_raw": {"nan": cov_nan_bins}})
     add("G2c_raw_covnorm_nan_coverage", "small", bedpe, clr_weight_name=None, coverage_norm="total",
         patch={"cov_tot_raw": {"nan": cov_nan_bins}}, **base)
+    # a cooler without coverage columns: the reference computes and stores them (coolpup.py:955-963, through the documented
+    # stand-in for cooltools' coverage()), with ignore_diags of the pile-up; local windows make the diagonal mask matter
+    add("G2d_covnorm_missing_columns", "small", bedpe, clr_weight_name=None, coverage_norm=True,
+        patch={"drop": ["cov_tot_raw", "cov_cis_raw"]}, **base)
+    add("G2e_covnorm_cis_missing_columns_local_diag0", "small", bed, features_format="bed", local=True, flank=100_000,
+        clr_weight_name=None, coverage_norm="cis", min_diag=0, patch={"drop": ["cov_tot_raw", "cov_cis_raw"]})
     # weights that are +inf, and zero weights beside them: balanced pixels become inf / NaN, which the reference leaves
     # out of `num` cell by cell (np.isfinite) while empty cells of the same rows still count
     wrng = np.random.default_rng(37)
@@ -485,6 +491,9 @@ def main():
                 "view": csv_text(sc["view"]), "expected": csv_text(sc["expected"])}
         if sc.get("patch"):
             meta["patch"] = sc["patch"]
+        if sc.get("patch") and sc["patch"].get("drop"):       # what the reference stored in the cooler
+            for name in sc["patch"]["drop"]:
+                rec["stored__" + name] = np.asarray(clr.arr.bins()[name][:].values, float)
         rec["meta"] = json.dumps(meta)
         np.savez_compressed(os.path.join(GOLD, sc["name"] + ".npz"), **rec)
         index.append(sc["name"])

@@ -190,7 +190,20 @@ def install():
                  is_compatible_viewframe=lambda *a, **k: True)
     lib = mod("cooltools.lib", common=common, checks=checks)
     snipping = mod("cooltools.api.snipping", ExpectedSnipper=ExpectedSnipper)
-    coverage = mod("cooltools.api.coverage")
+    def coverage_stand_in(clr, ignore_diags=None, chunksize=None, map=map, use_lock=False, clr_weight_name=None,
+                          store=False, store_prefix="cov"):
+        """cooltools.api.coverage.coverage is NOT part of the reference tree; this stand-in calls the documented
+        restatement oracle.pileup_oracle.coverage_numpy and, with store=True, keeps cov_cis_raw / cov_tot_raw in the
+        cooler object like cooltools stores them in the file.  A golden made through it pins what coolpuppy DOES with the
+        columns (the missing-column branch coolpup.py:955-963 and everything downstream), not cooltools' arithmetic."""
+        indptr, col, cnt = clr.arr.pixel_table()
+        cis, tot = po.coverage_numpy(indptr, col, cnt, clr.arr.chrom_offset, int(ignore_diags or 0))
+        if store:
+            clr.arr.set_bins_column(f"{store_prefix}_cis_raw", cis)
+            clr.arr.set_bins_column(f"{store_prefix}_tot_raw", tot)
+        return cis, tot
+
+    coverage = mod("cooltools.api.coverage", coverage=coverage_stand_in)
     capi = mod("cooltools.api", snipping=snipping, coverage=coverage)
     mod("cooltools", numutils=numutils, lib=lib, api=capi)
     mod("multiprocessing_logging", install_mp_handler=lambda: None, uninstall_mp_handler=lambda: None)

@@ -33,6 +33,8 @@ def scenario_cooler(meta):
     if not meta.get("patch"):
         return base
     from coolpuppy_amd import synth
+    if meta["patch"].get("drop"):          # the run ADDS the dropped columns to the object: a fresh one every time
+        return synth.patched_cooler(base, meta["patch"])
     key = meta["cooler"] + "|" + json.dumps(meta["patch"], sort_keys=True)
     if key not in _coolers:
         _coolers[key] = synth.patched_cooler(base, meta["patch"])
@@ -65,9 +67,13 @@ def key_repr(k):
 
 def run(name, pileup_func):
     z, meta, features, view, expected, kw = load(name)
+    clr = scenario_cooler(meta)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        df = pileup_func(scenario_cooler(meta), features, view_df=view, expected_df=expected, **kw)
+        df = pileup_func(clr, features, view_df=view, expected_df=expected, **kw)
+    for f in z.files:                           # columns the reference computed and stored in its cooler
+        if f.startswith("stored__"):
+            np.testing.assert_array_equal(np.asarray(clr.bins()[f[8:]][:].values, float), z[f])
     return z, df
 
 
