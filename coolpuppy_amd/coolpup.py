@@ -273,7 +273,7 @@ class CoordCreator:
             iv["center1"] = c1
             iv["center2"] = c2
             iv["distance"] = c2 - c1
-            iv = self._sort_pairs(iv)
+            iv = iv.sort_values(["chrom1", "chrom2", "start1", "start2"])
             presorted = True
             iv = expand2D(iv, self.flank, self.resolution, self.rescale_flank)
         self.intervals = iv
@@ -321,34 +321,6 @@ class CoordCreator:
             raise ValueError("Cannot do local with trans=True")
 
         self.pos_stream = self.get_combinations if self.kind == "bed" else self.get_intervals_stream
-
-    def _sort_pairs(self, iv):
-        """iv.sort_values(["chrom1", "chrom2", "start1", "start2"]) — the same stable order, index labels kept — from
-        integer keys: the chromosome names are factorised once (both columns together; the codes are kept for the region
-        selections, _cache) and ranked in string order, so the sort itself only compares integers."""
-        n = len(iv)
-        s1, s2 = iv["start1"].to_numpy(), iv["start2"].to_numpy()
-        if n == 0 or s1.dtype.kind not in "iu" or s2.dtype.kind not in "iu" or s1.min() < 0 or s1.max() >= 2**31:
-            return iv.sort_values(["chrom1", "chrom2", "start1", "start2"])
-        codes, uniq = pd.factorize(np.concatenate([iv["chrom1"].to_numpy(), iv["chrom2"].to_numpy()]))
-        rank = np.empty(len(uniq), np.int64)
-        rank[np.argsort(np.asarray(uniq, dtype=object), kind="stable")] = np.arange(len(uniq))
-        hi = ((rank[codes[:n]] * len(uniq) + rank[codes[n:]]) << 32) | s1.astype(np.int64)
-        # (pair, start1) is nearly always unique: an unstable vectorised sort on that one key, then the few runs of equal
-        # keys are put in (start2, original position) order — together the stable four-key order
-        order = np.argsort(hi)
-        hs = hi[order]
-        tie = hs[1:] == hs[:-1]
-        if tie.any():
-            in_run = np.zeros(n, bool)
-            in_run[1:] |= tie
-            in_run[:-1] |= tie
-            at = np.flatnonzero(in_run)
-            sub = order[at]
-            order[at] = sub[np.lexsort((sub, s2[sub], hi[sub]))]
-        out = iv.take(order)
-        self._sorted_codes = (out, codes[:n][order], codes[n:][order], uniq)      # valid while self.intervals has these rows
-        return out
 
     def _subset(self, df):
         if self.seed is not None:
@@ -513,14 +485,8 @@ class CoordCreator:
         c = {"id": iv, "cols": {}, "gc": {}}
         if self.kind == "bedpe":
             n = len(iv)
-            sc = getattr(self, "_sorted_codes", None)
-            probe = np.linspace(0, max(n - 1, 0), num=min(n, 256), dtype=np.int64)
-            if sc is not None and len(sc[1]) == n and n > 0 and np.array_equal(iv.index.values, sc[0].index.values) and \
-                    all(iv["chrom1"].values[i] == sc[3][sc[1][i]] and iv["chrom2"].values[i] == sc[3][sc[2][i]] for i in probe):
-                c1, c2, uniq = sc[1], sc[2], sc[3]          # factorised when the pairs were sorted, rows unchanged since
-            else:
-                codes, uniq = pd.factorize(np.concatenate([iv["chrom1"].values, iv["chrom2"].values]))
-                c1, c2 = codes[:n], codes[n:]
+            codes, uniq = pd.factorize(np.concatenate([iv["chrom1"].values, iv["chrom2"].values]))
+            c1, c2 = codes[:n], codes[n:]
             c["chrom_code"] = {str(u): i for i, u in enumerate(uniq)}
             c["c1"], c["c2"] = c1, c2
             for k in ("start1", "end1", "start2", "end2"):

@@ -1982,9 +1982,8 @@ __global__ __launch_bounds__(64 * kRedParts) void reduce_partials_kernel(
 // a workgroup owns kCovRows consecutive rows; row sums are wave-reduced, column sums go to an LDS histogram over
 // the kCovCols columns following the block's first row (where almost all cis mass lies) and to global integer
 // atomics beyond it.  Integer (u64) accumulation: exact and order-independent.
-typedef int v4i_t __attribute__((ext_vector_type(4)));
 constexpr int kCovRows = 64;
-constexpr int kCovCols = 2048;      // LDS window of column sums per workgroup (16 KiB: up to 8 workgroups share a CU)
+constexpr int kCovCols = 4096;      // LDS window of column sums per workgroup (32 KiB)
 // cov_cis accumulates intra-chromosomal pixels, cov_trans inter-chromosomal ones (one atomic per pixel either way);
 // the host forms cov_tot = cov_cis + cov_trans.  A wave streams its row with 16-byte loads (two pixels per lane), two
 // loads in flight per lane (see below): the pass is bound by load latency, not by the LDS atomics (the distinct columns
@@ -2021,8 +2020,7 @@ __global__ __launch_bounds__(256) void coverage_kernel(const long long* __restri
             int4 v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (k + 128 * u < e) { const v4i_t t = __builtin_nontemporal_load(reinterpret_cast<const v4i_t*>(px + k + 128 * u)); v[u] = int4{t.x, t.y, t.z, t.w}; }
-                else v[u] = int4{0, 0, 0, 0};
+                v[u] = (k + 128 * u < e) ? *reinterpret_cast<const int4*>(px + k + 128 * u) : int4{0, 0, 0, 0};
 #pragma unroll
             for (int u = 0; u < 4; ++u) { add(k + 128 * u, v[u].x, v[u].y); add(k + 128 * u + 1, v[u].z, v[u].w); }
         }
