@@ -497,6 +497,16 @@ def main():
             "staged_regions_per_launch": staged_regions,
             "prepass_ms_per_launch": round(st.get("prepare_ms", 0.0) / launches, 4),
         }
+        if staged:
+            # what actually limits the staged kernel is not HBM: every window reads its W x W cells (f64) from the staged
+            # region in LDS, every region is written there once (64 x 64 f64).  Analytic byte count (the SQ_INSTS_LDS
+            # counter of profiles/r02_* agrees: 81.3 M wave instructions x 512 B), against ds_read_b64's chip-wide peak
+            lds_bytes = (n_all // a.gpus) * W * W * 8 + staged_regions * 64 * 64 * 8
+            lds_peak = 256 * 256 * 2.4                     # CUs x B/clk/CU (ds_read_b64, MI355X_MICROARCH.md) x GHz = GB/s
+            roofline["lds"] = {"bytes_per_launch": int(lds_bytes), "achieved": round(lds_bytes / (k1_ms * 1e-3) / 1e9, 1),
+                           "peak": round(lds_peak, 1), "unit": "GB/s",
+                           "frac": round(lds_bytes / (k1_ms * 1e-3) / 1e9 / lds_peak, 4),
+                           "note": "the kernel's binding resource together with f64 VALU issue; peak = 256 CUs x 256 B/clk x 2.4 GHz"}
         # ---- CPU baselines + same-run parity on bounded samples (N=1 only) ------------------------------
         cpu = None
         if a.gpus == 1 and a.cpu_sample > 0:

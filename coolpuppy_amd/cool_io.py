@@ -71,7 +71,8 @@ def _hdf5():
     lib.H5Aclose.argtypes = [hid]
     lib.H5Gopen2.restype = hid; lib.H5Gopen2.argtypes = [hid, C.c_char_p, hid]
     lib.H5Gclose.argtypes = [hid]
-    lib.H5Literate.restype = C.c_int
+    lib.H5Lget_name_by_idx.restype = C.c_ssize_t
+    lib.H5Lget_name_by_idx.argtypes = [hid, C.c_char_p, C.c_int, C.c_int, C.c_uint64, C.c_char_p, C.c_size_t, hid]
     lib.H5Eset_auto2.argtypes = [hid, C.c_void_p, C.c_void_p]
     lib.H5open()
     lib.H5Eset_auto2(0, None, None)          # errors are reported through return codes, not stderr spam
@@ -94,6 +95,18 @@ class _File:
         if self.fid >= 0:
             self.lib.H5Fclose(self.fid)
             self.fid = -1
+
+    def children(self, group):
+        """Names of the links in a group (alphabetical)."""
+        out = []
+        g = (group or "/").encode()
+        while True:
+            size = self.lib.H5Lget_name_by_idx(self.fid, g, 0, 0, len(out), None, 0, _H5P_DEFAULT)
+            if size < 0:
+                return out
+            buf = C.create_string_buffer(size + 1)
+            self.lib.H5Lget_name_by_idx(self.fid, g, 0, 0, len(out), buf, size + 1, _H5P_DEFAULT)
+            out.append(buf.value.decode())
 
     def exists(self, name):
         parts = name.strip("/").split("/")
@@ -174,8 +187,7 @@ class _File:
 def read_cool(path, group="/", extra_bins=None):
     """Open ``path`` (optionally a ``group`` inside a multi-resolution file) and return an ArrayCooler.
 
-    Every numeric column of ``bins/`` listed in ``extra_bins`` (default: weight, cov_cis_raw, cov_tot_raw when
-    present) is loaded; the whole pixel table is read into host memory (the engine keeps it in HBM afterwards)."""
+    Every numeric column of ``bins/`` (or just those listed in ``extra_bins``) is loaded; the whole pixel table is read into host memory (the engine keeps it in HBM afterwards)."""
     try:
         import h5py  # noqa: F401
         return _read_cool_h5py(path, group, extra_bins)
@@ -193,16 +205,31 @@ def read_cool(path, group="/", extra_bins=None):
         bin2_id = f.read(f"{g}/pixels/bin2_id")
         count = f.read(f"{g}/pixels/count")
         cols = {}
-        want = extra_bins if extra_bins is not None else ["weight", "cov_cis_raw", "cov_tot_raw"]
-        for c in want:
-            if f.exists(f"{g}/bins/{c}"):
-                cols[c] = f.read(f"{g}/bins/{c}")
+        for c in _bins_columns(f.children(f"{g}/bins"), extra_bins):
+            v = f.read(f"{g}/bins/{c}")
+            if v.dtype.kind in "iuf":
+                cols[c] = v
     finally:
         f.close()
+    return ArrayCooler(pd.Series(lengths, index=names), binsize, bin1_offset, bin2_id, _counts32(count), bins=cols,
+                       filename=path)
+
+
+def _counts32(count):
+    """pixels/count as the engine's int32 — refusing, not wrapping, what does not fit."""
     if not np.issubdtype(count.dtype, np.integer):
         raise NotImplementedError("coolers with non-integer pixel counts are not supported by the GPU engine")
-    return ArrayCooler(pd.Series(lengths, index=names), binsize, bin1_offset, bin2_id, count.astype(np.int32), bins=cols,
-                       filename=path)
+    if count.dtype.itemsize > 4 and count.size and (int(count.max()) > 2**31 - 1 or int(count.min()) < 0):
+        raise OverflowError("pixel counts outside 0 .. 2^31-1 do not fit the engine's int32 pixel table")
+    return count.astype(np.int32)
+
+
+def _bins_columns(names_in_file, extra_bins):
+    """Which bins/ columns to load: the caller's list, else every one that is not part of the bin table itself (so that
+    coverage_norm= / clr_weight_name= can name any numeric column of the file, as with cooler)."""
+    if extra_bins is not None:
+        return [c for c in extra_bins if c in names_in_file]
+    return [c for c in names_in_file if c not in ("chrom", "start", "end")]
 
 
 def _read_cool_h5py(path, group, extra_bins):
@@ -212,7 +239,7 @@ def _read_cool_h5py(path, group, extra_bins):
         names = [x.decode() if isinstance(x, bytes) else str(x) for x in g["chroms/name"][:]]
         lengths = g["chroms/length"][:].astype(np.int64)
         binsize = int(g.attrs["bin-size"])
-        want = extra_bins if extra_bins is not None else ["weight", "cov_cis_raw", "cov_tot_raw"]
-        cols = {c: g["bins"][c][:] for c in want if c in g["bins"]}
+        cols = {c: g["bins"][c][:] for c in _bins_columns(list(g["bins"].keys()), extra_bins)}
+        cols = {c: v for c, v in cols.items() if v.dtype.kind in "iuf"}
         return ArrayCooler(pd.Series(lengths, index=names), binsize, g["indexes/bin1_offset"][:].astype(np.int64),
-                           g["pixels/bin2_id"][:], g["pixels/count"][:].astype(np.int32), bins=cols, filename=path)
+                           g["pixels/bin2_id"][:], _counts32(g["pixels/count"][:]), bins=cols, filename=path)

@@ -74,6 +74,8 @@ class PileupEngine:
         if count.dtype != np.int32:
             if not np.issubdtype(count.dtype, np.integer):
                 raise PupError(-6, f"pixel counts of dtype {count.dtype} are not supported (int32 expected)")
+            if count.size and (int(count.max()) > 2**31 - 1 or int(count.min()) < 0):
+                raise PupError(-5, "pixel counts outside 0 .. 2^31-1 do not fit the engine's int32 pixel table")
             count = count.astype(np.int32)
         nbins = bin1_offset.shape[0] - 1
         nnz = bin2_id.shape[0]
