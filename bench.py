@@ -408,7 +408,7 @@ def main():
 
     out = eng.fetch()
 
-    # ---- secondary: the same snippets pre-sorted into the engine's block order (no device sort in the step) -------
+    # ---- secondary: the same snippets pre-sorted into the engine's block order (the device sort finds them sorted) ---
     preblocked = None
     if world == 1:
         order = PileupEngine.block_order(r0, c0, co, tile=(np.arange(n_local) >= n_roi), pad=a.pad)
@@ -425,7 +425,8 @@ def main():
         torch.cuda.synchronize()
         pdt = time.perf_counter() - t1
         preblocked = {"ms_per_step": round(pdt / psteps * 1e3, 4), "snippets_per_s": round(n_local * psteps / pdt, 1),
-                      "note": "resident set already in the staged kernel's block order: the step skips the device sort"}
+                      "note": "same snippets handed over already in the staged kernel's block order: the device sort still runs (every "
+                              "call does it) but its gather reads sequentially"}
         del p_r0, p_c0
 
     if rank == 0:

@@ -1132,6 +1132,8 @@ __global__ __launch_bounds__(256) void block_key_kernel(const int* __restrict__ 
         const unsigned long long near = __ballot(c - r < clear_gap);
         if (near != 0ull && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)near) - 1)) atomicAdd(n_unclear, (unsigned)__popcll(near));
     }
+    // (walking block rows in pairs — (2k, c), (2k+1, c), (2k, c+1) — so that the row halo is re-read from L2 was measured:
+    // 0.694 ms against 0.678; the column halo of consecutive blocks of one row is worth more)
     keys[i] = (KeyT)(((unsigned long long)seg << sh_seg) | (er << sh_er) | (br << sh_br) | bc);
     vals[i] = (unsigned)i | (slot << 31);
 }

@@ -240,17 +240,18 @@ class PileupEngine:
         self._check(self._lib.pup_set_profiling(self._h, int(enabled)))
 
     def set_tuning(self, chunk_snippets=0, variant=0):
-        """variant bits: 1 ignore the index, 2 LDS-tile kernel, 8 force / 16 forbid the block-staged kernel, see pup_hip.h."""
+        """chunk_snippets: snippets per chunk (blocks per chunk for the staged kernel).  variant bits: 1 ignore the index,
+        2 LDS-tile kernel, 4 no factorised num, 8 force / 16 forbid the workgroup-staged kernel, 32 no sparse trans kernel,
+        64 no tile pairing, 128 eight waves per staged workgroup (W = 21) — see pup_set_tuning in pup_hip.h."""
         self._check(self._lib.pup_set_tuning(self._h, int(chunk_snippets), int(variant)))
 
     REGION = 64                          # kWgRegion of pup_engine.hip: the staged kernel's region is 64 x 64 bins
 
     @staticmethod
     def block_order(r0, c0, chrom_offset, tile=None, block=None, pad=10):
-        """Permutation that puts snippets in the order the block-staged kernel wants inside every tile segment:
+        """Permutation that puts snippets in the order the workgroup-staged kernel walks them inside every tile:
         (tile, block row, block column, r0, c0), blocks of (65 - W)^2 top-left corners (W = 2*pad+1) anchored at the
-        chromosome start.  A resident snippet set kept in this order is piled up without the device-side sort
-        (pup_set_tuning in pup_hip.h)."""
+        chromosome start.  Host mirror of the device-side block sort (tests, and bench.py's "preblocked" measurement)."""
         side = PileupEngine.REGION - (2 * int(pad) + 1) + 1
         br_size, bc_size = block or (side, side)
         r0 = np.asarray(r0, np.int64)
@@ -350,15 +351,14 @@ def pinned_empty(n, dtype=np.int32):
 
 
 def host_windows(st1, st2, code, shift, sign, nshifts, resolution, off1, off2, lo1, hi1, lo2, hi2, h, w):
-    """pup_host_windows: ROI windows + shifted control copies of one region, bounds-tested, as (r0, c0, code, n_roi_kept);
-    r0 / c0 are page-locked.  st1 / st2 / code: int32 per ROI row (code may be None); shift / sign: int64, n*nshifts each."""
+    """pup_host_windows: ROI windows + shifted control copies of one region, bounds-tested, as (r0, c0, code, n_roi_kept).  st1 / st2 / code: int32 per ROI row (code may be None); shift / sign: int64, n*nshifts each."""
     st1, st2 = _as(st1, np.int32), _as(st2, np.int32)
     n = st1.shape[0]
     cap = n * (1 + int(nshifts))
     code = None if code is None else _as(code, np.int32)
     shift = None if shift is None else _as(shift, np.int64)
     sign = None if sign is None else _as(sign, np.int64)
-    r0, c0 = pinned_empty(cap), pinned_empty(cap)
+    r0, c0 = np.empty(cap, np.int32), np.empty(cap, np.int32)      # per-region intermediates: group_tiles makes the DMA source
     code_out = np.empty(cap, np.int32) if code is not None else None
     n_roi = C.c_int64(0)
     kept = _ffi.lib().pup_host_windows(_ptr(st1), _ptr(st2), _ptr(code), n, _ptr(shift), _ptr(sign), int(nshifts),

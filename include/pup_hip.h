@@ -228,7 +228,7 @@ typedef struct pup_stats {
     int64_t pixels_in_windows; /* sum over snippets of nnz inside the window (counted on device) */
     int64_t probe_loads;    /* binary-search probes issued (counted on device) */
     double  coverage_ms;    /* device time of the last pup_coverage kernel, ms */
-    int64_t staged_regions; /* last pup_accumulate: regions staged by the block-staged kernel (0: it did not run) */
+    int64_t staged_regions; /* last pup_accumulate: regions staged by the workgroup-staged kernel (0: it did not run) */
     double  prepare_ms;     /* total device time of the block-key / sort / permute prepass of that kernel, ms */
 } pup_stats;
 /* profiling: bit 0 = every kernel launch is bracketed by HIP events on the context's stream and the pile-up kernels
@@ -240,14 +240,15 @@ int pup_clear_stats(pup_ctx* ctx);
 /* generic stream timer: record slot (0..7) on the context's stream; elapsed between two slots */
 int pup_event_record(pup_ctx* ctx, int slot);
 int pup_event_elapsed_ms(pup_ctx* ctx, int slot_begin, int slot_end, float* ms);
-/* tuning knobs (0 = library default): snippets per chunk (per wave); variant bit 0 = ignore the index (binary
- * search only), bit 1 = LDS-tile kernel for every width, bit 3 = always use the block-staged kernel where it is
- * eligible (tests), bit 4 = never use it, bit 5 = never use the sparse trans kernel, bits 8..23 = waves per
- * interleaved group.
- * Block-staged kernel: a call of >= 1e6 cis windows (W <= 31, every window inside one chromosome, index built) is
- * examined on the device; tile segments whose windows overlap enough (>= 3 windows per 16 x 16 block of top-left
- * corners) are radix-sorted by block into a scratch copy — unless the caller already passes them in that order:
- * (tile, flip, chromosome, (r0 - chrom_start) / 16, (c0 - chrom_start) / 16) — and piled up from LDS-staged regions.
+/* tuning knobs (0 = library default): chunk_snippets = snippets per chunk (per wave) of the per-window kernels and
+ * blocks per chunk (per workgroup) of the staged kernel; variant bits: 1 = ignore the index (binary search only),
+ * 2 = LDS-tile kernel for every width, 4 = no factorised `num` in the staged kernel, 8 = always use the staged kernel where
+ * it is eligible (tests), 16 = never use it, 32 = never use the sparse trans kernel, 64 = no tile pairing in the staged
+ * kernel, 128 = 8 waves per staged workgroup (W = 21 only), bits 8..23 = waves per interleaved group.
+ * Staged kernel: a call of cis windows (W <= 31, every window inside one chromosome, index built) is keyed on the device
+ * by (tile pair, 65-W square block of top-left corners) and radix-sorted by block into a scratch copy; runs of blocks
+ * with >= 8 windows per block and >= 20 000 windows are piled up from 64 x 64 regions staged once in LDS, tile t together
+ * with tile t + T/2 (in coolpuppy's layout a group's ROI and control windows).  Input order inside a tile is free.
  * Results do not depend on which kernel ran (integers exactly, sums up to the order of the f64 additions). */
 int pup_set_tuning(pup_ctx* ctx, int32_t chunk_snippets, int32_t variant);
 
