@@ -84,7 +84,6 @@ struct pup_ctx {
     // block-ordered copy of the snippets for the staged kernel (K1t)
     DevBuf<unsigned long long> d_keys, d_keys2;
     DevBuf<unsigned> d_vals, d_vals2, d_k32, d_k32b, d_cnt32, d_starts;
-    DevBuf<unsigned char> d_head;
     DevBuf<pup::BlockEntry> d_blocks;
     DevBuf<int> d_sr0, d_sc0;
     DevBuf<long long> d_segend;
@@ -324,7 +323,7 @@ void pup_destroy(pup_ctx* c) {
     c->acc_f64.release(); c->acc_i64.release();
     c->d_r0.release(); c->d_c0.release(); c->d_h.release(); c->d_w.release(); c->d_geom.release();
     c->d_keys.release(); c->d_keys2.release(); c->d_cnt32.release(); c->d_vals.release(); c->d_vals2.release();
-    c->d_starts.release(); c->d_head.release(); c->d_blocks.release();
+    c->d_starts.release(); c->d_blocks.release();
     c->d_sr0.release(); c->d_sc0.release(); c->d_segend.release(); c->d_sorttmp.release();
     c->d_k32.release(); c->d_k32b.release();
     c->part_f64.release(); c->slice_f64.release(); c->part_num.release(); c->slice_num.release();
@@ -709,16 +708,17 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
         if (end_bit > 64) { stop_timer(); return PUP_OK; }
         // [0] ineligible windows, [1] blocks, [2 .. 2+nseg] first block of every segment + total, [last] windows a diagonal mask reaches
         const size_t ncnt = 2 + (size_t)nseg + 1 + 1;
+        const int n_spans = (int)((n + pup::kSpan - 1) / pup::kSpan);          // block-start counters follow the ncnt scalars
         HIPCHK(c, c->d_vals.reserve((size_t)n)); HIPCHK(c, c->d_vals2.reserve((size_t)n));
-        HIPCHK(c, c->d_segend.reserve(seg_end2t.size() + (size_t)nseg + 1)); HIPCHK(c, c->d_cnt32.reserve(ncnt));
+        HIPCHK(c, c->d_segend.reserve(seg_end2t.size() + (size_t)nseg + 1)); HIPCHK(c, c->d_cnt32.reserve(ncnt + (size_t)n_spans));
         HIPCHK(c, c->d_sr0.reserve((size_t)n)); HIPCHK(c, c->d_sc0.reserve((size_t)n));
-        HIPCHK(c, c->d_head.reserve((size_t)n)); HIPCHK(c, c->d_starts.reserve((size_t)n + 1));
+        HIPCHK(c, c->d_starts.reserve((size_t)n + 1));
         // host tables of this attempt: the (tile, flip) boundaries for the key kernel, the segment boundaries in sorted order
         std::vector<long long> htab(seg_end2t);
         htab.insert(htab.end(), seg_win0.begin(), seg_win0.end());
         HIPCHK(c, hipMemcpyAsync(c->d_segend.p, htab.data(), htab.size() * 8, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->d_cnt32.p, 0, 2 * sizeof(unsigned), c->stream));
-        HIPCHK(c, hipMemsetAsync(c->d_cnt32.p + ncnt - 1, 0, sizeof(unsigned), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_cnt32.p, 0, (ncnt + (size_t)n_spans) * sizeof(unsigned), c->stream));
+        unsigned* d_spans = c->d_cnt32.p + ncnt;
         const unsigned gk = (unsigned)((n + 255) / 256);
         hipError_t se = hipSuccess;
         size_t tmp_bytes = 0;
@@ -726,7 +726,7 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
         const pup::ExpRegion* d_eregs = n_eregs > 0 ? c->exp_regions.p : nullptr;
         if (k32) {
             HIPCHK(c, c->d_k32.reserve((size_t)n)); HIPCHK(c, c->d_k32b.reserve((size_t)n));
-            hipLaunchKernelGGL((pup::block_key_kernel<unsigned>), dim3(gk), dim3(256), 0, c->stream, dr0, dc0, (long long)n,
+            hipLaunchKernelGGL((BR == 44 ? pup::block_key_kernel<unsigned, 44> : pup::block_key_kernel<unsigned, 0>), dim3(gk), dim3(256), 0, c->stream, dr0, dc0, (long long)n,
                                (const long long*)c->d_segend.p, (int)seg_end2t.size(), H, (const pup::IdxChrom*)c->idx_chrom.p,
                                c->n_chrom, (const unsigned short*)c->bin_chrom.p, (long long)c->nbins, (const int*)c->d_brow.p,
                                d_eregs, n_eregs, W, BR, BC, sh_br, sh_er, sh_seg, ignore_diags + W - 1, c->d_k32.p, c->d_vals.p,
@@ -740,10 +740,13 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
             if (se == hipSuccess)
                 hipLaunchKernelGGL((pup::permute_snippets_kernel<unsigned>), dim3(gk), dim3(256), 0, c->stream, dr0, dc0,
                                    (const unsigned*)c->d_vals2.p, (const unsigned*)c->d_k32b.p, (long long)n,
-                                   c->d_sr0.p, c->d_sc0.p, c->d_head.p);
+                                   c->d_sr0.p, c->d_sc0.p, d_spans);
+            if (se == hipSuccess)
+                hipLaunchKernelGGL((pup::block_starts_kernel<unsigned>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
+                                   (const unsigned*)c->d_k32b.p, (long long)n, (const unsigned*)d_spans, c->d_starts.p);
         } else {
             HIPCHK(c, c->d_keys.reserve((size_t)n)); HIPCHK(c, c->d_keys2.reserve((size_t)n));
-            hipLaunchKernelGGL((pup::block_key_kernel<unsigned long long>), dim3(gk), dim3(256), 0, c->stream, dr0, dc0, (long long)n,
+            hipLaunchKernelGGL((pup::block_key_kernel<unsigned long long, 0>), dim3(gk), dim3(256), 0, c->stream, dr0, dc0, (long long)n,
                                (const long long*)c->d_segend.p, (int)seg_end2t.size(), H, (const pup::IdxChrom*)c->idx_chrom.p,
                                c->n_chrom, (const unsigned short*)c->bin_chrom.p, (long long)c->nbins, (const int*)c->d_brow.p,
                                d_eregs, n_eregs, W, BR, BC, sh_br, sh_er, sh_seg, ignore_diags + W - 1, c->d_keys.p, c->d_vals.p,
@@ -757,24 +760,16 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
             if (se == hipSuccess)
                 hipLaunchKernelGGL((pup::permute_snippets_kernel<unsigned long long>), dim3(gk), dim3(256), 0, c->stream, dr0, dc0,
                                    (const unsigned*)c->d_vals2.p, (const unsigned long long*)c->d_keys2.p, (long long)n,
-                                   c->d_sr0.p, c->d_sc0.p, c->d_head.p);
+                                   c->d_sr0.p, c->d_sc0.p, d_spans);
+            if (se == hipSuccess)
+                hipLaunchKernelGGL((pup::block_starts_kernel<unsigned long long>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
+                                   (const unsigned long long*)c->d_keys2.p, (long long)n, (const unsigned*)d_spans, c->d_starts.p);
         }
         if (se != hipSuccess) return fail(c, PUP_EHIP, "pup_accumulate: block sort: %s", hipGetErrorString(se));
-        // block starts = positions of the flags, compacted in order
-        {
-            size_t sel_bytes = 0;
-            rocprim::counting_iterator<unsigned> pos0(0u);
-            se = rocprim::select(nullptr, sel_bytes, pos0, (const unsigned char*)c->d_head.p, c->d_starts.p, c->d_cnt32.p + 1,
-                                 (size_t)n, c->stream);
-            if (se == hipSuccess) se = c->d_sorttmp.reserve(sel_bytes + 16);
-            if (se == hipSuccess)
-                se = rocprim::select(c->d_sorttmp.p, sel_bytes, pos0, (const unsigned char*)c->d_head.p, c->d_starts.p,
-                                     c->d_cnt32.p + 1, (size_t)n, c->stream);
-            if (se != hipSuccess) return fail(c, PUP_EHIP, "pup_accumulate: block compaction: %s", hipGetErrorString(se));
-        }
+        // (block starts: block_starts_kernel above — an own two-kernel compaction; rocprim::select took 0.10 ms for this)
         hipLaunchKernelGGL(pup::segment_blocks_kernel, dim3(1), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
-                           (const unsigned*)(c->d_cnt32.p + 1), (const long long*)(c->d_segend.p + seg_end2t.size()), nseg,
-                           c->d_cnt32.p + 2);
+                           (const unsigned*)d_spans, n_spans, c->d_cnt32.p + 1,
+                           (const long long*)(c->d_segend.p + seg_end2t.size()), nseg, c->d_cnt32.p + 2);
         std::vector<unsigned> cnt(ncnt, 0);
         HIPCHK(c, hipMemcpyAsync(cnt.data(), c->d_cnt32.p, ncnt * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));      // the one synchronisation (also fences htab)

@@ -1092,7 +1092,7 @@ __global__ __launch_bounds__(kWave * NW, (NW == 4 && FACT && !EXTRA && !OOE ? 4 
 // snippet is piled up with; `pair_half` = T/2 when tile t shares its pass with tile t + T/2 (then slot = t / (T/2) goes
 // into bit 31 of the value), 0 when every tile has its own pass.  Also checks that the window is one the rank-bitmap
 // index covers (cis, inside one chromosome) and counts the ineligible ones.
-template <typename KeyT>
+template <typename KeyT, int SIDE /* block side when known at compile time (division by a constant), else 0 */>
 __global__ __launch_bounds__(256) void block_key_kernel(const int* __restrict__ r0, const int* __restrict__ c0, long long n,
                                                         const long long* __restrict__ seg_end, int nseg2t, int pair_half,
                                                         const IdxChrom* __restrict__ chroms, int n_chrom,
@@ -1119,8 +1119,8 @@ __global__ __launch_bounds__(256) void block_key_kernel(const int* __restrict__ 
         const int cs = chroms[ca].start, ce = chroms[ca].end;
         ok = r >= cs && r + W <= ce && c >= cs && c + W <= ce;
         if (ok) {
-            br = (unsigned long long)(brow_base[ca] + (r - cs) / BR);           // increasing over the genome, compact
-            bc = (unsigned long long)((c - cs) / BC);
+            br = (unsigned long long)(brow_base[ca] + (SIDE ? (r - cs) / SIDE : (r - cs) / BR));   // increasing over the genome, compact
+            bc = (unsigned long long)(SIDE ? (c - cs) / SIDE : (c - cs) / BC);
         }
     }
     if (n_eregs > 0) {                                   // the region whose expected the snippet divides by (that of its first row)
@@ -1138,27 +1138,72 @@ __global__ __launch_bounds__(256) void block_key_kernel(const int* __restrict__ 
     vals[i] = (unsigned)i | (slot << 31);
 }
 
-// snippets into block order (slot bit moved into bit kSlotBit of c0) + "a new block starts here" flags
+// snippets into block order (slot bit moved into bit kSlotBit of c0); the windows that start a block (key differs from
+// the previous one) are counted per span of kSpan windows — block_starts_kernel turns the counts into the ordered list
+constexpr int kSpan = 4096;
 template <typename KeyT>
 __global__ __launch_bounds__(256) void permute_snippets_kernel(const int* __restrict__ r0, const int* __restrict__ c0,
                                                                const unsigned* __restrict__ order,
                                                                const KeyT* __restrict__ sorted_keys, long long n,
                                                                int* __restrict__ r0s, int* __restrict__ c0s,
-                                                               unsigned char* __restrict__ head) {
+                                                               unsigned* __restrict__ span_heads) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const unsigned v = order[i], j = v & 0x7fffffffu;
-    r0s[i] = r0[j];
-    c0s[i] = c0[j] | (int)((v >> 31) << kSlotBit);
-    head[i] = (i == 0 || sorted_keys[i] != sorted_keys[i - 1]) ? 1 : 0;
+    int head = 0;
+    if (i < n) {
+        const unsigned v = order[i], j = v & 0x7fffffffu;
+        r0s[i] = r0[j];
+        c0s[i] = c0[j] | (int)((v >> 31) << kSlotBit);
+        head = (i == 0 || sorted_keys[i] != sorted_keys[i - 1]) ? 1 : 0;
+    }
+    const int cnt = __syncthreads_count(head);
+    if (threadIdx.x == 0 && cnt) atomicAdd(&span_heads[((long long)blockIdx.x * blockDim.x) / kSpan], (unsigned)cnt);
+}
+
+// ordered list of block starts: workgroup g owns windows [g*kSpan, (g+1)*kSpan); its output offset is the number of
+// heads in the spans before it (a few thousand counters: summed by the workgroup itself, no separate scan pass)
+template <typename KeyT>
+__global__ __launch_bounds__(256) void block_starts_kernel(const KeyT* __restrict__ sorted_keys, long long n,
+                                                           const unsigned* __restrict__ span_heads,
+                                                           unsigned* __restrict__ starts) {
+    __shared__ unsigned red[4];
+    __shared__ unsigned wave_cnt[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned part = 0;
+    for (int k = threadIdx.x; k < (int)blockIdx.x; k += blockDim.x) part += span_heads[k];
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off);
+    if (lane == 0) red[wave] = part;
+    __syncthreads();
+    unsigned base = red[0] + red[1] + red[2] + red[3];
+    if (span_heads[blockIdx.x] == 0) return;               // (uniform) nothing starts in this span
+    const long long i0 = (long long)blockIdx.x * kSpan;
+    for (int t = 0; t < kSpan; t += 256) {
+        const long long i = i0 + t + threadIdx.x;
+        const bool head = i < n && (i == 0 || sorted_keys[i] != sorted_keys[i - 1]);
+        const unsigned long long m = __ballot(head);
+        __syncthreads();                                   // wave_cnt of the previous round has been read
+        if (lane == 0) wave_cnt[wave] = (unsigned)__popcll(m);
+        __syncthreads();
+        unsigned before = 0;
+        for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+        if (head) starts[base + before + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (unsigned)i;
+        base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    }
 }
 
 // first block of every segment: seg_blk0[s] = number of block starts before the segment's first window (the segments'
 // window ranges in sorted order are known on the host: seg_win0[0..nseg]); one thread per segment boundary
-__global__ __launch_bounds__(256) void segment_blocks_kernel(const unsigned* __restrict__ starts, const unsigned* __restrict__ n_runs,
+__global__ __launch_bounds__(256) void segment_blocks_kernel(const unsigned* __restrict__ starts, const unsigned* __restrict__ span_heads,
+                                                             int n_spans, unsigned* __restrict__ n_runs,
                                                              const long long* __restrict__ seg_win0, int nseg,
                                                              unsigned* __restrict__ seg_blk0) {
-    const unsigned nr = n_runs[0];
+    __shared__ unsigned red[4];
+    unsigned part = 0;
+    for (int k = threadIdx.x; k < n_spans; k += blockDim.x) part += span_heads[k];
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    const unsigned nr = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) n_runs[0] = nr;
     for (int s = threadIdx.x; s <= nseg; s += blockDim.x) {
         const long long w0 = seg_win0[s];
         unsigned lo = 0, hi = nr;
