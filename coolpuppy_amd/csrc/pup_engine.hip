@@ -11,8 +11,6 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_select.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -83,7 +81,8 @@ struct pup_ctx {
     DevBuf<int> d_r0, d_c0, d_h, d_w;
     // block-ordered copy of the snippets for the staged kernel (K1t)
     DevBuf<unsigned long long> d_keys, d_keys2;
-    DevBuf<unsigned> d_vals, d_vals2, d_k32, d_k32b, d_cnt32, d_starts;
+    DevBuf<unsigned> d_k32, d_k32b, d_cnt32, d_starts;
+    DevBuf<unsigned short> d_win, d_win2;    // window-in-block values before / after the block sort
     DevBuf<pup::BlockEntry> d_blocks;
     DevBuf<int> d_sr0, d_sc0;
     DevBuf<long long> d_segend;
@@ -322,7 +321,7 @@ void pup_destroy(pup_ctx* c) {
     c->bin_chrom.release(); c->d_brow.release();
     c->acc_f64.release(); c->acc_i64.release();
     c->d_r0.release(); c->d_c0.release(); c->d_h.release(); c->d_w.release(); c->d_geom.release();
-    c->d_keys.release(); c->d_keys2.release(); c->d_cnt32.release(); c->d_vals.release(); c->d_vals2.release();
+    c->d_keys.release(); c->d_keys2.release(); c->d_cnt32.release(); c->d_win.release(); c->d_win2.release();
     c->d_starts.release(); c->d_blocks.release();
     c->d_sr0.release(); c->d_sc0.release(); c->d_segend.release(); c->d_sorttmp.release();
     c->d_k32.release(); c->d_k32b.release();
@@ -645,8 +644,9 @@ struct BlockOrder {
     std::vector<char> seg_tiled;        // [nseg]
     std::vector<long long> seg_win0;    // [nseg+1] windows of segment s in launch order: [seg_win0[s], seg_win0[s+1])
     std::vector<int> seg_blk0;          // [nseg+1] blocks of segment s in the block table
-    const int* r0 = nullptr;            // snippets in launch order (device)
+    const int* r0 = nullptr;            // snippets in launch order (device): what the per-window kernels read
     const int* c0 = nullptr;
+    const unsigned short* win = nullptr;   // windows in block order, as corners inside their regions: what K1q reads
 };
 
 static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const int64_t* tile_ptr, const int64_t* flip_from,
@@ -709,9 +709,8 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
         // [0] ineligible windows, [1] blocks, [2 .. 2+nseg] first block of every segment + total, [last] windows a diagonal mask reaches
         const size_t ncnt = 2 + (size_t)nseg + 1 + 1;
         const int n_spans = (int)((n + pup::kSpan - 1) / pup::kSpan);          // block-start counters follow the ncnt scalars
-        HIPCHK(c, c->d_vals.reserve((size_t)n)); HIPCHK(c, c->d_vals2.reserve((size_t)n));
+        HIPCHK(c, c->d_win.reserve((size_t)n)); HIPCHK(c, c->d_win2.reserve((size_t)n));
         HIPCHK(c, c->d_segend.reserve(seg_end2t.size() + (size_t)nseg + 1)); HIPCHK(c, c->d_cnt32.reserve(ncnt + (size_t)n_spans));
-        HIPCHK(c, c->d_sr0.reserve((size_t)n)); HIPCHK(c, c->d_sc0.reserve((size_t)n));
         HIPCHK(c, c->d_starts.reserve((size_t)n + 1));
         // host tables of this attempt: the (tile, flip) boundaries for the key kernel, the segment boundaries in sorted order
         std::vector<long long> htab(seg_end2t);
@@ -729,41 +728,39 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
             hipLaunchKernelGGL((BR == 44 ? pup::block_key_kernel<unsigned, 44> : pup::block_key_kernel<unsigned, 0>), dim3(gk), dim3(256), 0, c->stream, dr0, dc0, (long long)n,
                                (const long long*)c->d_segend.p, (int)seg_end2t.size(), H, (const pup::IdxChrom*)c->idx_chrom.p,
                                c->n_chrom, (const unsigned short*)c->bin_chrom.p, (long long)c->nbins, (const int*)c->d_brow.p,
-                               d_eregs, n_eregs, W, BR, BC, sh_br, sh_er, sh_seg, ignore_diags + W - 1, c->d_k32.p, c->d_vals.p,
+                               d_eregs, n_eregs, W, BR, BC, sh_br, sh_er, sh_seg, ignore_diags + W - 1, c->d_k32.p, c->d_win.p,
                                c->d_cnt32.p, c->d_cnt32.p + ncnt - 1);
-            se = rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_vals.p, c->d_vals2.p,
+            se = rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_win.p, c->d_win2.p,
                                            (size_t)n, 0, end_bit, c->stream);
             if (se == hipSuccess) se = c->d_sorttmp.reserve(tmp_bytes + 16);
             if (se == hipSuccess)
-                se = rocprim::radix_sort_pairs(c->d_sorttmp.p, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_vals.p,
-                                               c->d_vals2.p, (size_t)n, 0, end_bit, c->stream);
-            if (se == hipSuccess)
-                hipLaunchKernelGGL((pup::permute_snippets_kernel<unsigned>), dim3(gk), dim3(256), 0, c->stream, dr0, dc0,
-                                   (const unsigned*)c->d_vals2.p, (const unsigned*)c->d_k32b.p, (long long)n,
-                                   c->d_sr0.p, c->d_sc0.p, d_spans);
-            if (se == hipSuccess)
+                se = rocprim::radix_sort_pairs(c->d_sorttmp.p, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_win.p,
+                                               c->d_win2.p, (size_t)n, 0, end_bit, c->stream);
+            if (se == hipSuccess) {
+                hipLaunchKernelGGL((pup::count_heads_kernel<unsigned>), dim3(gk), dim3(256), 0, c->stream,
+                                   (const unsigned*)c->d_k32b.p, (long long)n, d_spans);
                 hipLaunchKernelGGL((pup::block_starts_kernel<unsigned>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
                                    (const unsigned*)c->d_k32b.p, (long long)n, (const unsigned*)d_spans, c->d_starts.p);
+            }
         } else {
             HIPCHK(c, c->d_keys.reserve((size_t)n)); HIPCHK(c, c->d_keys2.reserve((size_t)n));
             hipLaunchKernelGGL((pup::block_key_kernel<unsigned long long, 0>), dim3(gk), dim3(256), 0, c->stream, dr0, dc0, (long long)n,
                                (const long long*)c->d_segend.p, (int)seg_end2t.size(), H, (const pup::IdxChrom*)c->idx_chrom.p,
                                c->n_chrom, (const unsigned short*)c->bin_chrom.p, (long long)c->nbins, (const int*)c->d_brow.p,
-                               d_eregs, n_eregs, W, BR, BC, sh_br, sh_er, sh_seg, ignore_diags + W - 1, c->d_keys.p, c->d_vals.p,
+                               d_eregs, n_eregs, W, BR, BC, sh_br, sh_er, sh_seg, ignore_diags + W - 1, c->d_keys.p, c->d_win.p,
                                c->d_cnt32.p, c->d_cnt32.p + ncnt - 1);
-            se = rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_vals.p, c->d_vals2.p,
+            se = rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_win.p, c->d_win2.p,
                                            (size_t)n, 0, end_bit, c->stream);
             if (se == hipSuccess) se = c->d_sorttmp.reserve(tmp_bytes + 16);
             if (se == hipSuccess)
-                se = rocprim::radix_sort_pairs(c->d_sorttmp.p, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_vals.p,
-                                               c->d_vals2.p, (size_t)n, 0, end_bit, c->stream);
-            if (se == hipSuccess)
-                hipLaunchKernelGGL((pup::permute_snippets_kernel<unsigned long long>), dim3(gk), dim3(256), 0, c->stream, dr0, dc0,
-                                   (const unsigned*)c->d_vals2.p, (const unsigned long long*)c->d_keys2.p, (long long)n,
-                                   c->d_sr0.p, c->d_sc0.p, d_spans);
-            if (se == hipSuccess)
+                se = rocprim::radix_sort_pairs(c->d_sorttmp.p, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_win.p,
+                                               c->d_win2.p, (size_t)n, 0, end_bit, c->stream);
+            if (se == hipSuccess) {
+                hipLaunchKernelGGL((pup::count_heads_kernel<unsigned long long>), dim3(gk), dim3(256), 0, c->stream,
+                                   (const unsigned long long*)c->d_keys2.p, (long long)n, d_spans);
                 hipLaunchKernelGGL((pup::block_starts_kernel<unsigned long long>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
                                    (const unsigned long long*)c->d_keys2.p, (long long)n, (const unsigned*)d_spans, c->d_starts.p);
+            }
         }
         if (se != hipSuccess) return fail(c, PUP_EHIP, "pup_accumulate: block sort: %s", hipGetErrorString(se));
         // (block starts: block_starts_kernel above — an own two-kernel compaction; rocprim::select took 0.10 ms for this)
@@ -796,18 +793,32 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
         if (k32)
             hipLaunchKernelGGL((pup::block_table_kernel<unsigned>), dim3(gb), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
                                (const unsigned*)(c->d_cnt32.p + 1), (long long)n, (const unsigned*)c->d_k32b.p,
-                               (const int*)c->d_sr0.p, (const int*)c->d_sc0.p, (const pup::IdxChrom*)c->idx_chrom.p, c->n_chrom,
-                               BR, BC, sh_er, sh_seg, n_eregs, (const unsigned long long*)c->badbits.p, c->d_blocks.p);
+                               (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
+                               c->n_chrom, BR, BC, sh_br, sh_er, sh_seg, n_eregs, (const unsigned long long*)c->badbits.p, c->d_blocks.p);
         else
             hipLaunchKernelGGL((pup::block_table_kernel<unsigned long long>), dim3(gb), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
                                (const unsigned*)(c->d_cnt32.p + 1), (long long)n, (const unsigned long long*)c->d_keys2.p,
-                               (const int*)c->d_sr0.p, (const int*)c->d_sc0.p, (const pup::IdxChrom*)c->idx_chrom.p, c->n_chrom,
-                               BR, BC, sh_er, sh_seg, n_eregs, (const unsigned long long*)c->badbits.p, c->d_blocks.p);
+                               (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
+                               c->n_chrom, BR, BC, sh_br, sh_er, sh_seg, n_eregs, (const unsigned long long*)c->badbits.p, c->d_blocks.p);
+        if (!all) {
+            // some segments stay with the per-window kernels: they want position-sorted coordinates — rebuilt from the sorted
+            // keys and values in one streaming pass (never with pairs: a pair is staged whole or not at all)
+            HIPCHK(c, c->d_sr0.reserve((size_t)n)); HIPCHK(c, c->d_sc0.reserve((size_t)n));
+            if (k32)
+                hipLaunchKernelGGL((pup::rebuild_coords_kernel<unsigned>), dim3(gk), dim3(256), 0, c->stream, (const unsigned*)c->d_k32b.p,
+                                   (const unsigned short*)c->d_win2.p, (long long)n, sh_br, sh_er, (const int*)c->d_brow.p,
+                                   (const pup::IdxChrom*)c->idx_chrom.p, c->n_chrom, BR, BC, c->d_sr0.p, c->d_sc0.p);
+            else
+                hipLaunchKernelGGL((pup::rebuild_coords_kernel<unsigned long long>), dim3(gk), dim3(256), 0, c->stream,
+                                   (const unsigned long long*)c->d_keys2.p, (const unsigned short*)c->d_win2.p, (long long)n, sh_br, sh_er,
+                                   (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p, c->n_chrom, BR, BC, c->d_sr0.p, c->d_sc0.p);
+            out.r0 = c->d_sr0.p; out.c0 = c->d_sc0.p;
+        }
         HIPCHK(c, hipGetLastError());
         out.tiled = true; out.paired = paired; out.nseg = nseg;
         out.fact = !(mode & PUP_MODE_OOE) && cnt[ncnt - 1] == 0 && !(c->variant & 4);
         out.seg_tiled = seg_tiled; out.seg_win0 = seg_win0; out.seg_blk0 = seg_blk0;
-        out.r0 = c->d_sr0.p; out.c0 = c->d_sc0.p;
+        out.win = c->d_win2.p;
         c->last_stagings = stagings;
         stop_timer();
         return PUP_OK;
@@ -1145,7 +1156,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     a.nexp = c->nexp; a.nbins = c->nbins;
     a.exp_regions = c->n_exp_regions > 0 ? c->exp_regions.p : nullptr; a.n_exp_regions = c->n_exp_regions;
     a.exp_pair = c->have_exp_pair ? c->exp_pair.p : nullptr;
-    a.r0 = kr0; a.c0 = kc0;
+    a.r0 = kr0; a.c0 = kc0; a.win = order.win;
     a.chunk_begin = c->gv.chunk_begin; a.chunk_end = c->gv.chunk_end; a.chunk_flip = c->gv.chunk_flip;
     a.chunk_stride = c->gv.chunk_stride; a.block_chunk = c->gv.block_chunk; a.block_band = c->gv.block_band;
     a.blocks = tiled ? c->d_blocks.p : nullptr;

@@ -103,6 +103,8 @@ struct K1Args {
     const int*       block_band;   // [gridDim.x] row band of the window the workgroup owns (banded kernel; else 0)
     // block table of the workgroup-staged kernel (K1q): its chunks are ranges of BLOCKS, chunk_begin / chunk_end index here
     const void*      blocks;       // [nblocks] BlockEntry: region origin, its windows, staging geometry (one 64-byte line each)
+    const unsigned short* win;     // K1q: the windows in block order, each as its corner inside its region: dr | dc << 6
+                                   //      (| slot << 12) — the value that rode the block sort; r0 / c0 are not read
     int              rec_stride;   // K1q with two accumulator sets: partial record of (chunk, slot) = slot * rec_stride + chunk
     // per-chunk partial outputs
     double*   part_f64;   // [nrecords][W2 + 2W]   (sum | cov_start | cov_end)
@@ -900,7 +902,6 @@ __global__ __launch_bounds__(kWave * NW, (NW == 4 && FACT && !EXTRA && !OOE ? 4 
     // reads and CH f64 adds (+ the validity bits, or nothing at all when validity factorises).
     const unsigned lane_off8 = (unsigned)(uintptr_t)tile + 8u * (unsigned)(p * LS + k);   // LDS byte address of the lane's first cell
     const unsigned vb_lane8 = (unsigned)(uintptr_t)vbits + 8u * (unsigned)p;               // ... of the validity word of its row
-    constexpr int kCoordMask = (1 << kSlotBit) - 1;
     // windows [j0, j1) of the batch, all of accumulator slot S; window j goes to wave (j - j0) % NW
     auto run = [&](auto slot_tag, const Geo& g, int offv, int drv, int dcv, int j0, int j1) __attribute__((always_inline)) {
         constexpr int S = decltype(slot_tag)::value;
@@ -981,15 +982,16 @@ __global__ __launch_bounds__(kWave * NW, (NW == 4 && FACT && !EXTRA && !OOE ? 4 
         }
       }
     };
-    // the windows [g.start, g.start + g.count) of the staged block; (r0f, c0f) = the first 64 of them, one per lane
-    auto windows = [&](const Geo& g, int r0f, int c0f) __attribute__((always_inline)) {
+    // the windows [g.start, g.start + g.count) of the staged block; wf = the first 64 of them, one per lane, each as its
+    // corner inside the region (dr | dc << 6, the value the block sort carried)
+    auto windows = [&](const Geo& g, int wf) __attribute__((always_inline)) {
         int batch = 0;
         for (int s0 = 0; s0 < g.count; s0 += kWave, ++batch) {
-            const int drv = r0f - g.R, dcv = (c0f & kCoordMask) - g.C;        // per lane: its window's corner inside the region
+            const int drv = wf & 63, dcv = (wf >> 6) & 63;
             const int offv = 8 * (drv * LS + dcv);
             if (s0 + kWave < g.count) {                   // next batch of this block
                 const int sn = s0 + kWave + lane;
-                r0f = sn < g.count ? a.r0[g.start + sn] : 0; c0f = sn < g.count ? a.c0[g.start + sn] : 0;
+                wf = sn < g.count ? (int)a.win[g.start + sn] : 0;
             }
             const int nb = (g.count - s0) < kWave ? (g.count - s0) : kWave;
             int split = g.count0 - s0;                    // windows of the batch before `split` belong to slot 0
@@ -1001,8 +1003,8 @@ __global__ __launch_bounds__(kWave * NW, (NW == 4 && FACT && !EXTRA && !OOE ? 4 
             } else run(std::integral_constant<int, 0>{}, g, offv, drv, dcv, 0, nb);
         }
     };
-    auto first_coords = [&](const Geo& g, int& r0f, int& c0f) __attribute__((always_inline)) {
-        r0f = lane < g.count ? a.r0[g.start + lane] : 0; c0f = lane < g.count ? a.c0[g.start + lane] : 0;
+    auto first_coords = [&](const Geo& g, int& wf) __attribute__((always_inline)) {
+        wf = lane < g.count ? (int)a.win[g.start + lane] : 0;
     };
 
     // ---- the block loop: region b is piled up while b+1's values, b+2's index lines and b+3's table entry are on their way
@@ -1012,11 +1014,11 @@ __global__ __launch_bounds__(kWave * NW, (NW == 4 && FACT && !EXTRA && !OOE ? 4 
         Raw x1, x2;
         Row rw0, rw1;
         double v[RPW];
-        int r0f, c0f, r1f = 0, c1f = 0;
+        int w0f, w1f = 0;
         {   // prologue: stage block bb without overlap, start the lookups of bb+1
             Raw x0;
             load_raw(g0, x0);
-            first_coords(g0, r0f, c0f);
+            first_coords(g0, w0f);
             if (bb + 1 < be) { g1 = geo_from(entry_load(bb + 1)); load_raw(g1, x1); }
             if (bb + 2 < be) ev = entry_load(bb + 2);
             rw0 = finish_rows(g0, x0);
@@ -1029,15 +1031,15 @@ __global__ __launch_bounds__(kWave * NW, (NW == 4 && FACT && !EXTRA && !OOE ? 4 
         }
         for (int b = bb; b < be; ++b) {
             const bool has1 = b + 1 < be, has2 = b + 2 < be;
-            if (has1) { issue_values(rw1, v); first_coords(g1, r1f, c1f); }
+            if (has1) { issue_values(rw1, v); first_coords(g1, w1f); }
             if (has2) { g2 = geo_from(ev); load_raw(g2, x2); if (b + 3 < be) ev = entry_load(b + 3); }
-            windows(g0, r0f, c0f);
+            windows(g0, w0f);
             if (!has1) break;
             const ExpSel es1 = exp_of(g1);
             __syncthreads();                             // every wave is done reading region b
             store_region(g1, rw1, v, es1);
             __syncthreads();
-            g0 = g1; r0f = r1f; c0f = c1f;
+            g0 = g1; w0f = w1f;
             if (has2) { g1 = g2; rw1 = finish_rows(g2, x2); }
         }
     }
@@ -1101,7 +1103,7 @@ __global__ __launch_bounds__(256) void block_key_kernel(const int* __restrict__ 
                                                         const ExpRegion* __restrict__ eregs, int n_eregs,
                                                         int W, int BR, int BC, int sh_br, int sh_er, int sh_seg,
                                                         int clear_gap /* igd + W - 1 */,
-                                                        KeyT* __restrict__ keys, unsigned* __restrict__ vals,
+                                                        KeyT* __restrict__ keys, unsigned short* __restrict__ vals,
                                                         unsigned* __restrict__ counters /* [0] ineligible */,
                                                         unsigned* __restrict__ n_unclear /* windows a diagonal mask reaches */) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1114,13 +1116,16 @@ __global__ __launch_bounds__(256) void block_key_kernel(const int* __restrict__ 
     if (pair_half > 0) { slot = (unsigned)(t / pair_half); seg = (unsigned)((t % pair_half) * 2 + f); }
     bool ok = r >= 0 && c >= 0 && (long long)r < nbins;
     unsigned long long br = 0, bc = 0, er = 0;
+    unsigned inside = 0u;                                // the window's corner inside its block: all the staged kernel needs
     if (ok) {
         const int ca = bin_chrom[r];
         const int cs = chroms[ca].start, ce = chroms[ca].end;
         ok = r >= cs && r + W <= ce && c >= cs && c + W <= ce;
         if (ok) {
-            br = (unsigned long long)(brow_base[ca] + (SIDE ? (r - cs) / SIDE : (r - cs) / BR));   // increasing over the genome, compact
-            bc = (unsigned long long)(SIDE ? (c - cs) / SIDE : (c - cs) / BC);
+            const int qr = SIDE ? (r - cs) / SIDE : (r - cs) / BR, qc = SIDE ? (c - cs) / SIDE : (c - cs) / BC;
+            br = (unsigned long long)(brow_base[ca] + qr);            // increasing over the genome, compact
+            bc = (unsigned long long)qc;
+            inside = (unsigned)((r - cs) - qr * (SIDE ? SIDE : BR)) | ((unsigned)((c - cs) - qc * (SIDE ? SIDE : BC)) << 6);
         }
     }
     if (n_eregs > 0) {                                   // the region whose expected the snippet divides by (that of its first row)
@@ -1135,28 +1140,51 @@ __global__ __launch_bounds__(256) void block_key_kernel(const int* __restrict__ 
     // (walking block rows in pairs — (2k, c), (2k+1, c), (2k, c+1) — so that the row halo is re-read from L2 was measured:
     // 0.694 ms against 0.678; the column halo of consecutive blocks of one row is worth more)
     keys[i] = (KeyT)(((unsigned long long)seg << sh_seg) | (er << sh_er) | (br << sh_br) | bc);
-    vals[i] = (unsigned)i | (slot << 31);
+    // the value that rides the sort is the window itself as the staged kernel wants it (the sort is stable, so windows of
+    // a block keep the caller's order): no index to gather through afterwards
+    vals[i] = (unsigned short)(inside | (slot << 12));
 }
 
-// snippets into block order (slot bit moved into bit kSlotBit of c0); the windows that start a block (key differs from
-// the previous one) are counted per span of kSpan windows — block_starts_kernel turns the counts into the ordered list
+// the windows that start a block (key differs from the previous one), counted per span of kSpan windows —
+// block_starts_kernel turns the counts into the ordered list
 constexpr int kSpan = 4096;
 template <typename KeyT>
-__global__ __launch_bounds__(256) void permute_snippets_kernel(const int* __restrict__ r0, const int* __restrict__ c0,
-                                                               const unsigned* __restrict__ order,
-                                                               const KeyT* __restrict__ sorted_keys, long long n,
-                                                               int* __restrict__ r0s, int* __restrict__ c0s,
-                                                               unsigned* __restrict__ span_heads) {
+__global__ __launch_bounds__(256) void count_heads_kernel(const KeyT* __restrict__ sorted_keys, long long n,
+                                                          unsigned* __restrict__ span_heads) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    int head = 0;
-    if (i < n) {
-        const unsigned v = order[i], j = v & 0x7fffffffu;
-        r0s[i] = r0[j];
-        c0s[i] = c0[j] | (int)((v >> 31) << kSlotBit);
-        head = (i == 0 || sorted_keys[i] != sorted_keys[i - 1]) ? 1 : 0;
-    }
+    const int head = (i < n && (i == 0 || sorted_keys[i] != sorted_keys[i - 1])) ? 1 : 0;
     const int cnt = __syncthreads_count(head);
     if (threadIdx.x == 0 && cnt) atomicAdd(&span_heads[((long long)blockIdx.x * blockDim.x) / kSpan], (unsigned)cnt);
+}
+
+// block origin from a key: (br, bc) -> (R, C); the compact block-row numbering is undone through brow_base
+__device__ __forceinline__ void block_origin(unsigned long long key, int sh_br, int sh_er, const int* __restrict__ brow_base,
+                                             const IdxChrom* __restrict__ chroms, int n_chrom, int BR, int BC,
+                                             int& R, int& C, int& ca_out) {
+    const int br = (int)((key >> sh_br) & ((1ull << (sh_er - sh_br)) - 1ull));
+    const int bc = (int)(key & ((1ull << sh_br) - 1ull));
+    int lo = 0, hi = n_chrom;                              // last chromosome whose first block row is <= br
+    while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (brow_base[m] <= br) lo = m; else hi = m; }
+    const int cs = chroms[lo].start;
+    R = cs + (br - brow_base[lo]) * BR;
+    C = cs + bc * BC;
+    ca_out = lo;
+}
+
+// (r0, c0) of every window in block order, rebuilt from key + value (streaming: no gather) — only for calls that leave
+// some segments to the per-window kernels, which want position-sorted coordinates
+template <typename KeyT>
+__global__ __launch_bounds__(256) void rebuild_coords_kernel(const KeyT* __restrict__ sorted_keys, const unsigned short* __restrict__ win,
+                                                             long long n, int sh_br, int sh_er, const int* __restrict__ brow_base,
+                                                             const IdxChrom* __restrict__ chroms, int n_chrom, int BR, int BC,
+                                                             int* __restrict__ r0s, int* __restrict__ c0s) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int R, C, ca;
+    block_origin((unsigned long long)sorted_keys[i], sh_br, sh_er, brow_base, chroms, n_chrom, BR, BC, R, C, ca);
+    const unsigned w = win[i];
+    r0s[i] = R + (int)(w & 63u);
+    c0s[i] = C + (int)((w >> 6) & 63u);
 }
 
 // ordered list of block starts: workgroup g owns windows [g*kSpan, (g+1)*kSpan); its output offset is the number of
@@ -1217,9 +1245,9 @@ __global__ __launch_bounds__(256) void segment_blocks_kernel(const unsigned* __r
 template <typename KeyT>
 __global__ __launch_bounds__(256) void block_table_kernel(const unsigned* __restrict__ starts, const unsigned* __restrict__ n_runs,
                                                           long long n, const KeyT* __restrict__ sorted_keys,
-                                                          const int* __restrict__ r0s, const int* __restrict__ c0s,
+                                                          const unsigned short* __restrict__ win, const int* __restrict__ brow_base,
                                                           const IdxChrom* __restrict__ chroms, int n_chrom, int BR, int BC,
-                                                          int sh_er, int sh_seg, int n_eregs,
+                                                          int sh_br, int sh_er, int sh_seg, int n_eregs,
                                                           const unsigned long long* __restrict__ badbits,
                                                           BlockEntry* __restrict__ blocks) {
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1227,19 +1255,15 @@ __global__ __launch_bounds__(256) void block_table_kernel(const unsigned* __rest
     if (b >= nr) return;
     const unsigned s = starts[b];
     const long long e = (b + 1 < nr) ? (long long)starts[b + 1] : n;
-    const int r = r0s[s], c = c0s[s] & ((1 << kSlotBit) - 1);
-    int ca = 0, cb = n_chrom;
-    while (ca < cb) { const int m = (ca + cb) >> 1; if (chroms[m].end <= r) ca = m + 1; else cb = m; }
-    if (ca >= n_chrom) ca = n_chrom - 1;
+    BlockEntry be;
+    int ca;
+    block_origin((unsigned long long)sorted_keys[s], sh_br, sh_er, brow_base, chroms, n_chrom, BR, BC, be.R, be.C, ca);
     const IdxChrom ch = chroms[ca];
     const int cs = ch.start;
-    BlockEntry be;
-    be.R = cs + ((r - cs) / BR) * BR;                  // block grid anchored at the chromosome start
-    be.C = cs + ((c - cs) / BC) * BC;
     be.start = (int)s; be.count = (int)(e - (long long)s);
     {   // slot-0 windows come first inside a block (stable sort): find the first window with the slot bit set
         long long lo = (long long)s, hi = e;
-        while (lo < hi) { const long long m = (lo + hi) >> 1; if (((c0s[m] >> kSlotBit) & 1) == 0) lo = m + 1; else hi = m; }
+        while (lo < hi) { const long long m = (lo + hi) >> 1; if (((win[m] >> 12) & 1u) == 0u) lo = m + 1; else hi = m; }
         be.count0 = (int)(lo - (long long)s);
     }
     be.ereg = -1; be.pad0 = 0; be.pad1 = 0;
