@@ -737,7 +737,7 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
                 se = rocprim::radix_sort_pairs(c->d_sorttmp.p, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_win.p,
                                                c->d_win2.p, (size_t)n, 0, end_bit, c->stream);
             if (se == hipSuccess) {
-                hipLaunchKernelGGL((pup::count_heads_kernel<unsigned>), dim3(gk), dim3(256), 0, c->stream,
+                hipLaunchKernelGGL((pup::count_heads_kernel<unsigned>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
                                    (const unsigned*)c->d_k32b.p, (long long)n, d_spans);
                 hipLaunchKernelGGL((pup::block_starts_kernel<unsigned>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
                                    (const unsigned*)c->d_k32b.p, (long long)n, (const unsigned*)d_spans, c->d_starts.p);
@@ -756,7 +756,7 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
                 se = rocprim::radix_sort_pairs(c->d_sorttmp.p, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_win.p,
                                                c->d_win2.p, (size_t)n, 0, end_bit, c->stream);
             if (se == hipSuccess) {
-                hipLaunchKernelGGL((pup::count_heads_kernel<unsigned long long>), dim3(gk), dim3(256), 0, c->stream,
+                hipLaunchKernelGGL((pup::count_heads_kernel<unsigned long long>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
                                    (const unsigned long long*)c->d_keys2.p, (long long)n, d_spans);
                 hipLaunchKernelGGL((pup::block_starts_kernel<unsigned long long>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
                                    (const unsigned long long*)c->d_keys2.p, (long long)n, (const unsigned*)d_spans, c->d_starts.p);

@@ -1151,10 +1151,18 @@ constexpr int kSpan = 4096;
 template <typename KeyT>
 __global__ __launch_bounds__(256) void count_heads_kernel(const KeyT* __restrict__ sorted_keys, long long n,
                                                           unsigned* __restrict__ span_heads) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int head = (i < n && (i == 0 || sorted_keys[i] != sorted_keys[i - 1])) ? 1 : 0;
-    const int cnt = __syncthreads_count(head);
-    if (threadIdx.x == 0 && cnt) atomicAdd(&span_heads[((long long)blockIdx.x * blockDim.x) / kSpan], (unsigned)cnt);
+    __shared__ unsigned red[4];
+    const long long i0 = (long long)blockIdx.x * kSpan;                 // one workgroup per span
+    unsigned cnt = 0;
+#pragma unroll 4
+    for (int t = threadIdx.x; t < kSpan; t += 256) {
+        const long long i = i0 + t;
+        if (i < n && (i == 0 || sorted_keys[i] != sorted_keys[i - 1])) ++cnt;
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) span_heads[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
 // block origin from a key: (br, bc) -> (R, C); the compact block-row numbering is undone through brow_base

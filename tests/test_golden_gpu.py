@@ -13,7 +13,7 @@ def test_reference_golden_on_gpu(name, hip_lib):
     gu.compare(z, df, rtol=1e-6)   # north-star tolerance; integers are compared exactly
 
 
-# every scenario again with the block-staged kernel forced for each eligible engine call (cis, pad <= 15): covers its
+# every scenario again with the workgroup-staged kernel (K1q) forced for each eligible engine call (cis, pad <= 15): covers its
 # expected-table path, sub-chromosomal views, flips and grouped tiles on the reference's own outputs
 @pytest.mark.parametrize("name", gu.SCENARIOS)
 def test_reference_golden_on_gpu_staged_kernel(name, hip_lib, monkeypatch):

@@ -19,7 +19,7 @@ def small_clr():
 @pytest.fixture(scope="module", params=["indexed", "search", "staged"])
 def engine(hip_lib, small_clr, request):
     """All ways of locating a row's pixels must give identical results: the rank-bitmap index (cis windows), the
-    binary search (index ignored: variant 1), and the block-staged kernel (variant 8 forces it — device block sort +
+    binary search (index ignored: variant 1), and the workgroup-staged kernel (variant 8 forces it — device block sort +
     LDS-staged regions — for every eligible call, however small)."""
     from coolpuppy_amd.engine import PileupEngine
     eng = PileupEngine(0)

@@ -105,7 +105,7 @@ def test_oracle_on_strided_sample(eng, big, oracle_mod):
 
 def test_block_staged_kernel_takes_over_large_overlapping_calls(hip_lib):
     """>= 1e6 overlapping cis windows: the engine sorts them by block on the device and piles the dense tile up from
-    LDS-staged regions (K1t), the sparse tile with the plain kernel; same integers, same sums up to addition order.
+    LDS-staged regions (K1q), the sparse tile with the plain kernel; same integers, same sums up to addition order.
     Pre-blocked input (PileupEngine.block_order) takes the same path without the sort."""
     from coolpuppy_amd import synth
     from coolpuppy_amd.engine import PileupEngine
@@ -149,7 +149,7 @@ def test_block_staged_kernel_takes_over_large_overlapping_calls(hip_lib):
 
 @pytest.mark.parametrize("pad", list(range(1, 16)))
 def test_block_staged_kernel_equals_plain_kernel_for_every_width(hip_lib, pad):
-    """All 15 x 2 instantiations of the block-staged kernel (W = 3 .. 31, plain / OOE): forced on, against the plain
+    """All 15 x 2 instantiations of the workgroup-staged kernel (W = 3 .. 31, plain / OOE): forced on, against the plain
     register-tile kernel on the same random inputs — several chromosomes, windows touching chromosome starts and ends,
     windows below the diagonal, flips, three tiles, expected with zeros / NaN, raw counts with coverage."""
     from coolpuppy_amd import synth
