@@ -719,13 +719,14 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
         HIPCHK(c, hipMemsetAsync(c->d_cnt32.p, 0, (ncnt + (size_t)n_spans) * sizeof(unsigned), c->stream));
         unsigned* d_spans = c->d_cnt32.p + ncnt;
         const unsigned gk = (unsigned)((n + 255) / 256);
+        const unsigned gk4 = (unsigned)((n + 1023) / 1024);           // block_key_kernel: four windows per thread
         hipError_t se = hipSuccess;
         size_t tmp_bytes = 0;
         const bool k32 = end_bit <= 32;
         const pup::ExpRegion* d_eregs = n_eregs > 0 ? c->exp_regions.p : nullptr;
         if (k32) {
             HIPCHK(c, c->d_k32.reserve((size_t)n)); HIPCHK(c, c->d_k32b.reserve((size_t)n));
-            hipLaunchKernelGGL((BR == 44 ? pup::block_key_kernel<unsigned, 44> : pup::block_key_kernel<unsigned, 0>), dim3(gk), dim3(256), 0, c->stream, dr0, dc0, (long long)n,
+            hipLaunchKernelGGL((BR == 44 ? pup::block_key_kernel<unsigned, 44> : pup::block_key_kernel<unsigned, 0>), dim3(gk4), dim3(256), 0, c->stream, dr0, dc0, (long long)n,
                                (const long long*)c->d_segend.p, (int)seg_end2t.size(), H, (const pup::IdxChrom*)c->idx_chrom.p,
                                c->n_chrom, (const unsigned short*)c->bin_chrom.p, (long long)c->nbins, (const int*)c->d_brow.p,
                                d_eregs, n_eregs, W, BR, BC, sh_br, sh_er, sh_seg, ignore_diags + W - 1, c->d_k32.p, c->d_win.p,
@@ -744,7 +745,7 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
             }
         } else {
             HIPCHK(c, c->d_keys.reserve((size_t)n)); HIPCHK(c, c->d_keys2.reserve((size_t)n));
-            hipLaunchKernelGGL((pup::block_key_kernel<unsigned long long, 0>), dim3(gk), dim3(256), 0, c->stream, dr0, dc0, (long long)n,
+            hipLaunchKernelGGL((pup::block_key_kernel<unsigned long long, 0>), dim3(gk4), dim3(256), 0, c->stream, dr0, dc0, (long long)n,
                                (const long long*)c->d_segend.p, (int)seg_end2t.size(), H, (const pup::IdxChrom*)c->idx_chrom.p,
                                c->n_chrom, (const unsigned short*)c->bin_chrom.p, (long long)c->nbins, (const int*)c->d_brow.p,
                                d_eregs, n_eregs, W, BR, BC, sh_br, sh_er, sh_seg, ignore_diags + W - 1, c->d_keys.p, c->d_win.p,

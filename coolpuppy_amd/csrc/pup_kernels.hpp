@@ -1106,43 +1106,56 @@ __global__ __launch_bounds__(256) void block_key_kernel(const int* __restrict__ 
                                                         KeyT* __restrict__ keys, unsigned short* __restrict__ vals,
                                                         unsigned* __restrict__ counters /* [0] ineligible */,
                                                         unsigned* __restrict__ n_unclear /* windows a diagonal mask reaches */) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int r = r0[i], c = c0[i];
-    int lo = 0, hi = nseg2t;
-    while (lo < hi) { const int m = (lo + hi) >> 1; if (seg_end[m] <= i) lo = m + 1; else hi = m; }
-    const int t = lo >> 1, f = lo & 1;                   // tile, flip state of the snippet
-    unsigned seg = (unsigned)lo, slot = 0u;
-    if (pair_half > 0) { slot = (unsigned)(t / pair_half); seg = (unsigned)((t % pair_half) * 2 + f); }
-    bool ok = r >= 0 && c >= 0 && (long long)r < nbins;
-    unsigned long long br = 0, bc = 0, er = 0;
-    unsigned inside = 0u;                                // the window's corner inside its block: all the staged kernel needs
-    if (ok) {
-        const int ca = bin_chrom[r];
-        const int cs = chroms[ca].start, ce = chroms[ca].end;
-        ok = r >= cs && r + W <= ce && c >= cs && c + W <= ce;
+    // small tables go to LDS once per workgroup: per window the chain of dependent global loads is r0 -> bin_chrom only
+    constexpr int kMaxChrom = 512, kPer = 4;
+    __shared__ int s_cs[kMaxChrom], s_ce[kMaxChrom], s_bb[kMaxChrom];
+    __shared__ long long s_seg[2 * kMaxSegCount];
+    const bool in_lds = n_chrom <= kMaxChrom;
+    if (in_lds) for (int k = threadIdx.x; k < n_chrom; k += blockDim.x) { s_cs[k] = chroms[k].start; s_ce[k] = chroms[k].end; s_bb[k] = brow_base[k]; }
+    for (int k = threadIdx.x; k < nseg2t; k += blockDim.x) s_seg[k] = seg_end[k];
+    __syncthreads();
+    unsigned bad = 0u;
+    for (int u = 0; u < kPer; ++u) {
+        const long long i = ((long long)blockIdx.x * kPer + u) * blockDim.x + threadIdx.x;
+        const bool live = i < n;
+        const int r = live ? r0[i] : 0, c = live ? c0[i] : 0;
+        int lo = 0, hi = nseg2t;
+        while (lo < hi) { const int m = (lo + hi) >> 1; if (s_seg[m] <= i) lo = m + 1; else hi = m; }
+        const int t = lo >> 1, f = lo & 1;                   // tile, flip state of the snippet
+        unsigned seg = (unsigned)lo, slot = 0u;
+        if (pair_half > 0) { slot = (unsigned)(t / pair_half); seg = (unsigned)((t % pair_half) * 2 + f); }
+        bool ok = r >= 0 && c >= 0 && (long long)r < nbins;
+        unsigned long long br = 0, bc = 0, er = 0;
+        unsigned inside = 0u;                                // the window's corner inside its block: all the staged kernel needs
         if (ok) {
-            const int qr = SIDE ? (r - cs) / SIDE : (r - cs) / BR, qc = SIDE ? (c - cs) / SIDE : (c - cs) / BC;
-            br = (unsigned long long)(brow_base[ca] + qr);            // increasing over the genome, compact
-            bc = (unsigned long long)qc;
-            inside = (unsigned)((r - cs) - qr * (SIDE ? SIDE : BR)) | ((unsigned)((c - cs) - qc * (SIDE ? SIDE : BC)) << 6);
+            const int ca = bin_chrom[r];
+            const int cs = in_lds ? s_cs[ca] : chroms[ca].start, ce = in_lds ? s_ce[ca] : chroms[ca].end;
+            ok = r >= cs && r + W <= ce && c >= cs && c + W <= ce;
+            if (ok) {
+                const int qr = SIDE ? (r - cs) / SIDE : (r - cs) / BR, qc = SIDE ? (c - cs) / SIDE : (c - cs) / BC;
+                br = (unsigned long long)((in_lds ? s_bb[ca] : brow_base[ca]) + qr);     // increasing over the genome, compact
+                bc = (unsigned long long)qc;
+                inside = (unsigned)((r - cs) - qr * (SIDE ? SIDE : BR)) | ((unsigned)((c - cs) - qc * (SIDE ? SIDE : BC)) << 6);
+            }
         }
+        if (n_eregs > 0) {                                   // the region whose expected the snippet divides by (that of its first row)
+            const int e = find_exp_region(eregs, n_eregs, r);
+            er = (unsigned long long)(e < 0 ? n_eregs : e);
+        }
+        if (live && !ok) ++bad;
+        {   // one atomic per wave, not per window (a call of near-diagonal windows would serialise on the counter)
+            const unsigned long long near = __ballot(live && c - r < clear_gap);
+            if (near != 0ull && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)near) - 1)) atomicAdd(n_unclear, (unsigned)__popcll(near));
+        }
+        if (!live) continue;
+        // (walking block rows in pairs — (2k, c), (2k+1, c), (2k, c+1) — so that the row halo is re-read from L2 was
+        // measured: no gain; the column halo of consecutive blocks of one row is already served by L2)
+        keys[i] = (KeyT)(((unsigned long long)seg << sh_seg) | (er << sh_er) | (br << sh_br) | bc);
+        // the value that rides the sort is the window itself as the staged kernel wants it (the sort is stable, so windows
+        // of a block keep the caller's order): no index to gather through afterwards
+        vals[i] = (unsigned short)(inside | (slot << 12));
     }
-    if (n_eregs > 0) {                                   // the region whose expected the snippet divides by (that of its first row)
-        const int e = find_exp_region(eregs, n_eregs, r);
-        er = (unsigned long long)(e < 0 ? n_eregs : e);
-    }
-    if (!ok) atomicAdd(&counters[0], 1u);
-    {   // one atomic per wave, not per window (a call of near-diagonal windows would serialise on the counter)
-        const unsigned long long near = __ballot(c - r < clear_gap);
-        if (near != 0ull && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)near) - 1)) atomicAdd(n_unclear, (unsigned)__popcll(near));
-    }
-    // (walking block rows in pairs — (2k, c), (2k+1, c), (2k, c+1) — so that the row halo is re-read from L2 was measured:
-    // 0.694 ms against 0.678; the column halo of consecutive blocks of one row is worth more)
-    keys[i] = (KeyT)(((unsigned long long)seg << sh_seg) | (er << sh_er) | (br << sh_br) | bc);
-    // the value that rides the sort is the window itself as the staged kernel wants it (the sort is stable, so windows of
-    // a block keep the caller's order): no index to gather through afterwards
-    vals[i] = (unsigned short)(inside | (slot << 12));
+    if (bad) atomicAdd(&counters[0], bad);
 }
 
 // the windows that start a block (key differs from the previous one), counted per span of kSpan windows —
