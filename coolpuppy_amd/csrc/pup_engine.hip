@@ -480,7 +480,7 @@ int pup_coverage(pup_ctx* c, const int64_t* chrom_offset, int32_t n_chroms, int3
         hipEvent_t e0 = nullptr, e1 = nullptr;
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         (void)hipEventRecord(e0, c->stream);
-        hipLaunchKernelGGL(pup::coverage_kernel, dim3((unsigned)((c->nbins + pup::kCovRows - 1) / pup::kCovRows)), dim3(256), 0,
+        hipLaunchKernelGGL(pup::coverage_kernel, dim3((unsigned)((c->nbins + pup::kCovRows - 1) / pup::kCovRows)), dim3(512), 0,
                            c->stream, c->indptr.p, c->px.p, d_tab.p, n_chroms, ignore_diags, d_cov.p, d_cov.p + nb, c->nbins);
         (void)hipEventRecord(e1, c->stream);
         e = hipGetLastError();

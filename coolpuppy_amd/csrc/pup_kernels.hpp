@@ -2080,7 +2080,7 @@ constexpr int kCovCols = 4096;
 // the host forms cov_tot = cov_cis + cov_trans.  A wave streams its row with 16-byte loads (two pixels per lane), two
 // loads in flight per lane: the pass is bound by load latency, not by the LDS atomics (the distinct columns of one
 // row never collide; four loads in flight per lane and a 2048-column window were measured: 0.86 ms and 2.1 ms against 0.78).  Columns beyond the block's LDS window and all trans columns take global atomics.
-__global__ __launch_bounds__(256) void coverage_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
+__global__ __launch_bounds__(512) void coverage_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
                                                        const IdxChrom* __restrict__ chroms, int n_chrom, int ignore_diags,
                                                        unsigned long long* cov_trans, unsigned long long* cov_cis,
                                                        long long nbins) {
