@@ -146,6 +146,13 @@ def flip_snip_func(snip, groupby, ignore_group_order, extra_func=None):
     return snip
 
 
+def _draw_signs(m):
+    """np.random.choice([-1, 1], m) — the reference's call (coolpup.py:421) — without its list conversion and fancy
+    index: the legacy generator implements a uniform choice as randint(0, len(a), m) followed by a[idx], so this draws the
+    same numbers and leaves the generator in the same state (tests/test_host_misc.py pins that for the installed numpy)."""
+    return 2 * np.random.randint(0, 2, m) - 1
+
+
 class _Cols(dict):
     """A column table: name -> 1-D numpy array, all of one length."""
 
@@ -273,7 +280,7 @@ class CoordCreator:
             iv["center1"] = c1
             iv["center2"] = c2
             iv["distance"] = c2 - c1
-            iv = iv.sort_values(["chrom1", "chrom2", "start1", "start2"])
+            iv = self._sort_pairs(iv)
             presorted = True
             iv = expand2D(iv, self.flank, self.resolution, self.rescale_flank)
         self.intervals = iv
@@ -321,6 +328,33 @@ class CoordCreator:
             raise ValueError("Cannot do local with trans=True")
 
         self.pos_stream = self.get_combinations if self.kind == "bed" else self.get_intervals_stream
+
+    def _sort_pairs(self, iv):
+        """iv.sort_values(["chrom1", "chrom2", "start1", "start2"]) — the same stable order, index labels kept — through ONE
+        64-bit key per row: (rank of the chromosome pair in string order | start1 | start2 | row number), the starts divided
+        by their common divisor (bin-aligned anchors).  The row number makes every key unique, so numpy's vectorised
+        unstable sort yields the stable order.  Falls back to pandas when the fields do not fit 63 bits.  The chromosome
+        codes are kept for the region selections (_cache) — the same factorisation would be done there."""
+        n = len(iv)
+        s1, s2 = iv["start1"].to_numpy(), iv["start2"].to_numpy()
+        if n < 2 or s1.dtype.kind not in "iu" or s2.dtype.kind not in "iu" or s1.min() < 0 or s2.min() < 0:
+            return iv.sort_values(["chrom1", "chrom2", "start1", "start2"])
+        codes, uniq = pd.factorize(np.concatenate([iv["chrom1"].to_numpy(), iv["chrom2"].to_numpy()]))
+        if (codes < 0).any():
+            return iv.sort_values(["chrom1", "chrom2", "start1", "start2"])
+        rank = np.empty(len(uniq), np.int64)
+        rank[np.argsort(np.asarray(uniq, dtype=object), kind="stable")] = np.arange(len(uniq))
+        a1 = s1.astype(np.int64) // max(int(np.gcd.reduce(s1)), 1)
+        a2 = s2.astype(np.int64) // max(int(np.gcd.reduce(s2)), 1)
+        width = [int(v).bit_length() for v in (len(uniq) ** 2 - 1, a1.max(), a2.max(), n - 1)]
+        if sum(width) > 63:
+            return iv.sort_values(["chrom1", "chrom2", "start1", "start2"])
+        key = rank[codes[:n]] * len(uniq) + rank[codes[n:]]
+        key = (((key << width[1] | a1) << width[2]) | a2) << width[3] | np.arange(n, dtype=np.int64)
+        order = np.argsort(key)
+        out = iv.take(order)
+        self._sorted_codes = (out.index.values, codes[:n][order], codes[n:][order], uniq)
+        return out
 
     def _subset(self, df):
         if self.seed is not None:
@@ -380,20 +414,20 @@ class CoordCreator:
         draw that moves the BINS of both sides (the second pair of a trans pile-up, which only moves bp columns, is drawn
         and dropped)."""
         shift = np.random.randint(self.minshift, self.maxshift, m)
-        sign = np.random.choice([-1, 1], m)
+        sign = _draw_signs(m)
         if self.trans:
             np.random.randint(self.minshift, self.maxshift, m)
-            np.random.choice([-1, 1], m)
+            _draw_signs(m)
         return shift, sign
 
     def _draw_shifts(self, m):
         """The reference's RNG calls for m control windows (:420-436), in its order: (shift, shift2) in bp."""
         shift = np.random.randint(self.minshift, self.maxshift, m)
-        sign = np.random.choice([-1, 1], m)
+        sign = _draw_signs(m)
         shift *= sign
         if self.trans:   # the two sides move independently in bp ...
             shift2 = np.random.randint(self.minshift, self.maxshift, m)
-            sign2 = np.random.choice([-1, 1], m)
+            sign2 = _draw_signs(m)
             shift2 = shift2 * sign2
         else:
             shift2 = shift
@@ -485,8 +519,14 @@ class CoordCreator:
         c = {"id": iv, "cols": {}, "gc": {}}
         if self.kind == "bedpe":
             n = len(iv)
-            codes, uniq = pd.factorize(np.concatenate([iv["chrom1"].values, iv["chrom2"].values]))
-            c1, c2 = codes[:n], codes[n:]
+            sc = getattr(self, "_sorted_codes", None)
+            probe = np.linspace(0, max(n - 1, 0), num=min(n, 256), dtype=np.int64)
+            if sc is not None and len(sc[1]) == n and n > 0 and np.array_equal(iv.index.values, sc[0]) and \
+                    all(iv["chrom1"].values[i] == sc[3][sc[1][i]] and iv["chrom2"].values[i] == sc[3][sc[2][i]] for i in probe):
+                c1, c2, uniq = sc[1], sc[2], sc[3]          # factorised when the pairs were sorted; same rows since
+            else:
+                codes, uniq = pd.factorize(np.concatenate([iv["chrom1"].values, iv["chrom2"].values]))
+                c1, c2 = codes[:n], codes[n:]
             c["chrom_code"] = {str(u): i for i, u in enumerate(uniq)}
             c["c1"], c["c2"] = c1, c2
             for k in ("start1", "end1", "start2", "end2"):

@@ -85,3 +85,15 @@ def test_block_order_groups_snippets_by_tile_and_block():
         start = chrom_offset[np.searchsorted(chrom_offset, r0, side="right") - 1]
         key = np.stack([tile, start + (r0 - start) // side, (c0 - start) // side, r0, c0], axis=1)[o]
         assert all(tuple(key[i]) <= tuple(key[i + 1]) for i in range(len(key) - 1))
+
+
+def test_sign_draws_equal_numpy_choice():
+    """_draw_signs must stay np.random.choice([-1, 1], m): same values, same generator state afterwards."""
+    for m in (0, 1, 7, 100_003):
+        np.random.seed(123)
+        want = np.random.choice([-1, 1], m)
+        after_want = np.random.randint(0, 1 << 30)
+        np.random.seed(123)
+        got = coolpup._draw_signs(m)
+        assert np.array_equal(got, want) and got.dtype == want.dtype
+        assert np.random.randint(0, 1 << 30) == after_want
