@@ -248,3 +248,36 @@ def test_staged_kernel_many_workgroups(hip_lib, pad):
                         for k in ("sum", "cov_start", "cov_end"):
                             np.testing.assert_allclose(got[k], want[k], rtol=1e-11, atol=0, equal_nan=True)
     eng.close()
+
+
+def test_page_locked_staging_gives_the_same_tiles(hip_lib):
+    """Windows handed over from pup_host_alloc memory (asynchronous DMA on the engine's stream, no staging copy) and from
+    ordinary numpy arrays (blocking copy) pile up to identical tiles; a second call may reuse the staging right away."""
+    from coolpuppy_amd import engine as E
+    from coolpuppy_amd.engine import PileupEngine
+    clr = synth.make_cooler({"chrA": 30_000_000, "chrB": 14_000_000}, lam=120, seed=11)
+    rng = np.random.default_rng(3)
+    n = 300_000
+    r0 = rng.integers(0, 2900, n).astype(np.int32)
+    c0 = (r0 + rng.integers(25, 400, n)).astype(np.int32)
+    keep = c0 + 21 <= 3000
+    r0, c0 = r0[keep], c0[keep]
+    n = len(r0)
+    tile_ptr = np.array([0, n // 3, n], np.int64)
+    pr0, pc0 = E.pinned_empty(n), E.pinned_empty(n)
+    assert E._POOL.broken is False, "pup_host_alloc failed on a GPU box"
+    pr0[:], pc0[:] = r0, c0
+    with PileupEngine(0) as eng:
+        eng.load_pixels(*clr.pixel_table())
+        eng.load_bins(clr.bins()["weight"][:].values, None)
+        eng.build_index(clr.chrom_offset)
+        eng.reset(2, 10)
+        eng.accumulate(r0, c0, tile_ptr, ignore_diags=2, mode=0)
+        want = eng.fetch()
+        eng.reset(2, 10)
+        eng.accumulate(pr0, pc0, tile_ptr, ignore_diags=2, mode=0)
+        eng.accumulate(pr0, pc0, tile_ptr, ignore_diags=2, mode=0)       # queued behind the first call's kernels
+        got = eng.fetch()
+    np.testing.assert_array_equal(got["n"], 2 * want["n"])
+    np.testing.assert_array_equal(got["num"], 2 * want["num"])
+    np.testing.assert_allclose(got["sum"], 2 * want["sum"], rtol=1e-12, atol=0)
