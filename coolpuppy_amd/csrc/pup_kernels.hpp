@@ -734,7 +734,7 @@ struct __attribute__((aligned(64))) BlockEntry {
 static_assert(sizeof(BlockEntry) == 64, "block table entry must be one 64-byte line");
 
 template <int W, bool OOE, int NW, int ACC, bool FACT, bool EXTRA>
-__global__ __launch_bounds__(kWave * NW, (NW == 4 && FACT && !EXTRA && !OOE ? 4 : 1)) void pileup_wgtile_kernel(K1Args a) {
+__global__ __launch_bounds__(kWave * NW, (NW == 4 && FACT && !EXTRA && !OOE && W <= 21 ? 4 : 1)) void pileup_wgtile_kernel(K1Args a) {
     static_assert(W >= 3 && W <= 31, "workgroup-staged kernel serves windows of 3..31 bins");
     static_assert(!(FACT && OOE), "factorised counting needs validity to factorise into row and column masks");
     static_assert(NW == 4 || NW == 8 || NW == 16, "the region's 64 rows are dealt out evenly to the waves");

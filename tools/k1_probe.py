@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--lam", type=float, default=4200.0)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--tiles", type=int, default=0, help="split every kind over this many random groups (many-tile shape)")
+    ap.add_argument("--ooe", action="store_true", help="observed over expected: a synthetic by-diagonal expected per chromosome")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     a.no_cache = False
@@ -50,6 +51,11 @@ def main():
     eng.load_pixels(wl["bin1_offset"], wl["bin2_id"], wl["count"])
     eng.load_bins(wl["weight"], None)
     eng.build_index(wl["chrom_offset"])
+    mode = 0
+    if a.ooe:
+        co = np.asarray(wl["chrom_offset"], np.int64)
+        eng.set_expected_table(co[:-1], co[1:], vectors=[1.0 / (1.0 + np.arange(int(e - s), dtype=np.float64)) for s, e in zip(co[:-1], co[1:])])
+        mode = 1
     d_r0 = torch.from_numpy(np.ascontiguousarray(r0)).cuda()
     d_c0 = torch.from_numpy(np.ascontiguousarray(c0)).cuda()
     torch.cuda.synchronize()
@@ -64,7 +70,7 @@ def main():
             eng.reset(T, a.pad)
             eng.sync()
             t = time.perf_counter()
-            eng.accumulate_device(d_r0.data_ptr(), d_c0.data_ptr(), n, tile_ptr, ignore_diags=2, mode=0)
+            eng.accumulate_device(d_r0.data_ptr(), d_c0.data_ptr(), n, tile_ptr, ignore_diags=2, mode=mode)
             eng.sync()
             wall = (time.perf_counter() - t) * 1e3
             st = eng.stats()
