@@ -102,6 +102,7 @@ struct pup_ctx {
     DevBuf<unsigned long long> counters;   // [2]
     DevBuf<int> d_err;
     // stats / timing
+    bool no_dc_keys = false;     // a call had windows too far from the diagonal for relative block columns in the sort key
     bool profiling = false;      // HIP events around the kernels
     bool count_pixels = false;   // kernels also count the pixels inside the windows (statistics; costs a little)
     pup_stats stats{};
@@ -636,6 +637,11 @@ int pup_reset(pup_ctx* c, int32_t n_tiles, int32_t pad) {
 // Device pipeline, one host synchronisation: keys (segment | expected region | block row | block col) -> radix sort
 // (rocPRIM) -> permuted copy + block-start flags -> compaction of the block starts (rocPRIM select) -> first block of
 // every segment -> [sync: ineligible windows, blocks, blocks per segment] -> block table.
+// ten radix bits per onesweep pass (rocPRIM's default is eight): a pass costs the same here (measured: 8, 9 and 10 bits within
+// 5 %, 11 bits 2.6x — the look-back state outgrows the cache), so 17..20-bit keys take two passes instead of three
+using Radix10 = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>, 10,
+                                        rocprim::block_radix_rank_algorithm::match>>;
 struct BlockOrder {
     bool tiled = false;                 // any segment goes to K1q
     bool paired = false;                // two accumulator sets per chunk
@@ -692,7 +698,12 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
     };
 
     const bool can_pair = T >= 2 && (T % 2) == 0 && !(c->variant & 64);
+    const int seg_shift = flip_from ? 0 : 1;            // no flipped windows: the flip bit is left out of the key
+    // trials: (tile pairs | tiles on their own) x (block column relative to the block row | absolute).  The relative form
+    // needs 7 bits where the absolute one needs 10 for a human chromosome; a window further than 127 blocks from the
+    // diagonal makes the call fall back to absolute columns (and the context remembers)
     for (int attempt = can_pair ? 0 : 1; attempt < 2; ++attempt) {
+      for (int keymode = c->no_dc_keys ? 1 : 0; keymode < 2; ++keymode) {
         const bool paired = attempt == 0;
         const int H = paired ? T / 2 : 0;
         const int nseg = paired ? 2 * H : 2 * T;
@@ -701,13 +712,18 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
             const int f = sg & 1, u = sg >> 1;
             seg_win0[(size_t)sg + 1] = seg_win0[(size_t)sg] + (paired ? run_len(u, f) + run_len(u + H, f) : run_len(u, f));
         }
-        const int bits_bc = nbits((unsigned long long)(max_len / BC + 1)), bits_br = nbits((unsigned long long)n_brows + 1);
+        const int bits_abs = nbits((unsigned long long)(max_len / BC + 1));
+        const int dc_mode = (keymode == 0 && bits_abs > 7) ? 1 : 0;
+        if (keymode == 0 && !dc_mode) continue;           // short chromosomes: absolute columns are as narrow
+        const int bits_bc = dc_mode ? 7 : bits_abs, bits_br = nbits((unsigned long long)n_brows + 1);
         const int bits_er = n_eregs > 0 ? nbits((unsigned long long)n_eregs) : 0;
         const int sh_br = bits_bc, sh_er = sh_br + bits_br, sh_seg = sh_er + bits_er;
-        const int end_bit = sh_seg + nbits((unsigned long long)(nseg > 1 ? nseg - 1 : 1));
+        const int nseg_key = nseg >> seg_shift;
+        const int end_bit = sh_seg + (nseg_key > 1 ? nbits((unsigned long long)(nseg_key - 1)) : 0);
         if (end_bit > 64) { stop_timer(); return PUP_OK; }
-        // [0] ineligible windows, [1] blocks, [2 .. 2+nseg] first block of every segment + total, [last] windows a diagonal mask reaches
-        const size_t ncnt = 2 + (size_t)nseg + 1 + 1;
+        // [0] ineligible windows, [1] blocks, [2 .. 2+nseg] first block of every segment + total, then: windows a diagonal
+        // mask reaches, windows whose relative block column does not fit
+        const size_t ncnt = 2 + (size_t)nseg + 1 + 2;
         const int n_spans = (int)((n + pup::kSpan - 1) / pup::kSpan);          // block-start counters follow the ncnt scalars
         HIPCHK(c, c->d_win.reserve((size_t)n)); HIPCHK(c, c->d_win2.reserve((size_t)n));
         HIPCHK(c, c->d_segend.reserve(seg_end2t.size() + (size_t)nseg + 1)); HIPCHK(c, c->d_cnt32.reserve(ncnt + (size_t)n_spans));
@@ -729,13 +745,13 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
             hipLaunchKernelGGL((BR == 44 ? pup::block_key_kernel<unsigned, 44> : pup::block_key_kernel<unsigned, 0>), dim3(gk4), dim3(256), 0, c->stream, dr0, dc0, (long long)n,
                                (const long long*)c->d_segend.p, (int)seg_end2t.size(), H, (const pup::IdxChrom*)c->idx_chrom.p,
                                c->n_chrom, (const unsigned short*)c->bin_chrom.p, (long long)c->nbins, (const int*)c->d_brow.p,
-                               d_eregs, n_eregs, W, BR, BC, sh_br, sh_er, sh_seg, ignore_diags + W - 1, c->d_k32.p, c->d_win.p,
-                               c->d_cnt32.p, c->d_cnt32.p + ncnt - 1);
-            se = rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_win.p, c->d_win2.p,
+                               d_eregs, n_eregs, W, BR, BC, sh_br, sh_er, sh_seg, seg_shift, dc_mode, ignore_diags + W - 1, c->d_k32.p, c->d_win.p,
+                               c->d_cnt32.p, c->d_cnt32.p + ncnt - 2, c->d_cnt32.p + ncnt - 1);
+            se = rocprim::radix_sort_pairs<Radix10>(nullptr, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_win.p, c->d_win2.p,
                                            (size_t)n, 0, end_bit, c->stream);
             if (se == hipSuccess) se = c->d_sorttmp.reserve(tmp_bytes + 16);
             if (se == hipSuccess)
-                se = rocprim::radix_sort_pairs(c->d_sorttmp.p, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_win.p,
+                se = rocprim::radix_sort_pairs<Radix10>(c->d_sorttmp.p, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_win.p,
                                                c->d_win2.p, (size_t)n, 0, end_bit, c->stream);
             if (se == hipSuccess) {
                 hipLaunchKernelGGL((pup::count_heads_kernel<unsigned>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
@@ -748,13 +764,13 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
             hipLaunchKernelGGL((pup::block_key_kernel<unsigned long long, 0>), dim3(gk4), dim3(256), 0, c->stream, dr0, dc0, (long long)n,
                                (const long long*)c->d_segend.p, (int)seg_end2t.size(), H, (const pup::IdxChrom*)c->idx_chrom.p,
                                c->n_chrom, (const unsigned short*)c->bin_chrom.p, (long long)c->nbins, (const int*)c->d_brow.p,
-                               d_eregs, n_eregs, W, BR, BC, sh_br, sh_er, sh_seg, ignore_diags + W - 1, c->d_keys.p, c->d_win.p,
-                               c->d_cnt32.p, c->d_cnt32.p + ncnt - 1);
-            se = rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_win.p, c->d_win2.p,
+                               d_eregs, n_eregs, W, BR, BC, sh_br, sh_er, sh_seg, seg_shift, dc_mode, ignore_diags + W - 1, c->d_keys.p, c->d_win.p,
+                               c->d_cnt32.p, c->d_cnt32.p + ncnt - 2, c->d_cnt32.p + ncnt - 1);
+            se = rocprim::radix_sort_pairs<Radix10>(nullptr, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_win.p, c->d_win2.p,
                                            (size_t)n, 0, end_bit, c->stream);
             if (se == hipSuccess) se = c->d_sorttmp.reserve(tmp_bytes + 16);
             if (se == hipSuccess)
-                se = rocprim::radix_sort_pairs(c->d_sorttmp.p, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_win.p,
+                se = rocprim::radix_sort_pairs<Radix10>(c->d_sorttmp.p, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_win.p,
                                                c->d_win2.p, (size_t)n, 0, end_bit, c->stream);
             if (se == hipSuccess) {
                 hipLaunchKernelGGL((pup::count_heads_kernel<unsigned long long>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
@@ -772,6 +788,7 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
         HIPCHK(c, hipMemcpyAsync(cnt.data(), c->d_cnt32.p, ncnt * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));      // the one synchronisation (also fences htab)
         if (cnt[0] != 0) { stop_timer(); return PUP_OK; }   // a window the index does not cover: the plain kernels take the call
+        if (cnt[ncnt - 1] != 0) { c->no_dc_keys = true; continue; }     // a window far off the diagonal: absolute block columns
         const long long nblk = (long long)cnt[1];
         std::vector<int> seg_blk0((size_t)nseg + 1);
         for (int sg = 0; sg <= nseg; ++sg) seg_blk0[(size_t)sg] = (int)cnt[2 + (size_t)sg];
@@ -786,7 +803,7 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
             seg_tiled[(size_t)sg] = st;
             if (st) { any = true; covered += len; stagings += (unsigned long long)nb; } else all = false;
         }
-        if (paired && !all) continue;                     // a pair too sparse to stage: plan again with every tile on its own
+        if (paired && !all) break;                        // a pair too sparse to stage: plan again with every tile on its own
         if (!any || (!force && covered * 2 < n)) { stop_timer(); return PUP_OK; }
         // block table (device, asynchronous from here on)
         HIPCHK(c, c->d_blocks.reserve((size_t)std::max<long long>(nblk, 1)));
@@ -795,34 +812,35 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
             hipLaunchKernelGGL((pup::block_table_kernel<unsigned>), dim3(gb), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
                                (const unsigned*)(c->d_cnt32.p + 1), (long long)n, (const unsigned*)c->d_k32b.p,
                                (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
-                               c->n_chrom, BR, BC, sh_br, sh_er, sh_seg, n_eregs, (const unsigned long long*)c->badbits.p, c->d_blocks.p);
+                               c->n_chrom, BR, BC, sh_br, sh_er, sh_seg, dc_mode, n_eregs, (const unsigned long long*)c->badbits.p, c->d_blocks.p);
         else
             hipLaunchKernelGGL((pup::block_table_kernel<unsigned long long>), dim3(gb), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
                                (const unsigned*)(c->d_cnt32.p + 1), (long long)n, (const unsigned long long*)c->d_keys2.p,
                                (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
-                               c->n_chrom, BR, BC, sh_br, sh_er, sh_seg, n_eregs, (const unsigned long long*)c->badbits.p, c->d_blocks.p);
+                               c->n_chrom, BR, BC, sh_br, sh_er, sh_seg, dc_mode, n_eregs, (const unsigned long long*)c->badbits.p, c->d_blocks.p);
         if (!all) {
             // some segments stay with the per-window kernels: they want position-sorted coordinates — rebuilt from the sorted
             // keys and values in one streaming pass (never with pairs: a pair is staged whole or not at all)
             HIPCHK(c, c->d_sr0.reserve((size_t)n)); HIPCHK(c, c->d_sc0.reserve((size_t)n));
             if (k32)
                 hipLaunchKernelGGL((pup::rebuild_coords_kernel<unsigned>), dim3(gk), dim3(256), 0, c->stream, (const unsigned*)c->d_k32b.p,
-                                   (const unsigned short*)c->d_win2.p, (long long)n, sh_br, sh_er, (const int*)c->d_brow.p,
+                                   (const unsigned short*)c->d_win2.p, (long long)n, sh_br, sh_er, dc_mode, (const int*)c->d_brow.p,
                                    (const pup::IdxChrom*)c->idx_chrom.p, c->n_chrom, BR, BC, c->d_sr0.p, c->d_sc0.p);
             else
                 hipLaunchKernelGGL((pup::rebuild_coords_kernel<unsigned long long>), dim3(gk), dim3(256), 0, c->stream,
-                                   (const unsigned long long*)c->d_keys2.p, (const unsigned short*)c->d_win2.p, (long long)n, sh_br, sh_er,
+                                   (const unsigned long long*)c->d_keys2.p, (const unsigned short*)c->d_win2.p, (long long)n, sh_br, sh_er, dc_mode,
                                    (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p, c->n_chrom, BR, BC, c->d_sr0.p, c->d_sc0.p);
             out.r0 = c->d_sr0.p; out.c0 = c->d_sc0.p;
         }
         HIPCHK(c, hipGetLastError());
         out.tiled = true; out.paired = paired; out.nseg = nseg;
-        out.fact = !(mode & PUP_MODE_OOE) && cnt[ncnt - 1] == 0 && !(c->variant & 4);
+        out.fact = !(mode & PUP_MODE_OOE) && cnt[ncnt - 2] == 0 && !(c->variant & 4);
         out.seg_tiled = seg_tiled; out.seg_win0 = seg_win0; out.seg_blk0 = seg_blk0;
         out.win = c->d_win2.p;
         c->last_stagings = stagings;
         stop_timer();
         return PUP_OK;
+      }
     }
     stop_timer();
     return PUP_OK;

@@ -1102,10 +1102,13 @@ __global__ __launch_bounds__(256) void block_key_kernel(const int* __restrict__ 
                                                         const int* __restrict__ brow_base /* [n_chrom] block rows before the chromosome */,
                                                         const ExpRegion* __restrict__ eregs, int n_eregs,
                                                         int W, int BR, int BC, int sh_br, int sh_er, int sh_seg,
+                                                        int seg_shift /* 1: no flipped windows, the flip bit is left out */,
+                                                        int dc_mode /* block column stored relative to the block row */,
                                                         int clear_gap /* igd + W - 1 */,
                                                         KeyT* __restrict__ keys, unsigned short* __restrict__ vals,
                                                         unsigned* __restrict__ counters /* [0] ineligible */,
-                                                        unsigned* __restrict__ n_unclear /* windows a diagonal mask reaches */) {
+                                                        unsigned* __restrict__ n_unclear /* windows a diagonal mask reaches */,
+                                                        unsigned* __restrict__ n_dc_over /* relative columns that do not fit */) {
     // small tables go to LDS once per workgroup: per window the chain of dependent global loads is r0 -> bin_chrom only
     constexpr int kMaxChrom = 512, kPer = 4;
     __shared__ int s_cs[kMaxChrom], s_ce[kMaxChrom], s_bb[kMaxChrom];
@@ -1114,7 +1117,7 @@ __global__ __launch_bounds__(256) void block_key_kernel(const int* __restrict__ 
     if (in_lds) for (int k = threadIdx.x; k < n_chrom; k += blockDim.x) { s_cs[k] = chroms[k].start; s_ce[k] = chroms[k].end; s_bb[k] = brow_base[k]; }
     for (int k = threadIdx.x; k < nseg2t; k += blockDim.x) s_seg[k] = seg_end[k];
     __syncthreads();
-    unsigned bad = 0u;
+    unsigned bad = 0u, dc_over = 0u;
     for (int u = 0; u < kPer; ++u) {
         const long long i = ((long long)blockIdx.x * kPer + u) * blockDim.x + threadIdx.x;
         const bool live = i < n;
@@ -1132,9 +1135,16 @@ __global__ __launch_bounds__(256) void block_key_kernel(const int* __restrict__ 
             const int cs = in_lds ? s_cs[ca] : chroms[ca].start, ce = in_lds ? s_ce[ca] : chroms[ca].end;
             ok = r >= cs && r + W <= ce && c >= cs && c + W <= ce;
             if (ok) {
-                const int qr = SIDE ? (r - cs) / SIDE : (r - cs) / BR, qc = SIDE ? (c - cs) / SIDE : (c - cs) / BC;
+                constexpr int kSide = SIDE ? SIDE : 1;              // (a zero divisor must not even be spelled)
+                const int qr = SIDE ? (r - cs) / kSide : (r - cs) / BR, qc = SIDE ? (c - cs) / kSide : (c - cs) / BC;
                 br = (unsigned long long)((in_lds ? s_bb[ca] : brow_base[ca]) + qr);     // increasing over the genome, compact
                 bc = (unsigned long long)qc;
+                if (dc_mode) {
+                    // windows sit near the diagonal: the block column relative to the block row (+1: a window may start
+                    // a little left of it) needs far fewer bits than the absolute one — fewer radix passes
+                    const int dcv = qc - qr + 1;
+                    if (dcv < 0 || dcv >= (1 << sh_br)) { ++dc_over; bc = 0; } else bc = (unsigned long long)dcv;
+                }
                 inside = (unsigned)((r - cs) - qr * (SIDE ? SIDE : BR)) | ((unsigned)((c - cs) - qc * (SIDE ? SIDE : BC)) << 6);
             }
         }
@@ -1150,12 +1160,13 @@ __global__ __launch_bounds__(256) void block_key_kernel(const int* __restrict__ 
         if (!live) continue;
         // (walking block rows in pairs — (2k, c), (2k+1, c), (2k, c+1) — so that the row halo is re-read from L2 was
         // measured: no gain; the column halo of consecutive blocks of one row is already served by L2)
-        keys[i] = (KeyT)(((unsigned long long)seg << sh_seg) | (er << sh_er) | (br << sh_br) | bc);
+        keys[i] = (KeyT)(((unsigned long long)(seg >> seg_shift) << sh_seg) | (er << sh_er) | (br << sh_br) | bc);
         // the value that rides the sort is the window itself as the staged kernel wants it (the sort is stable, so windows
         // of a block keep the caller's order): no index to gather through afterwards
         vals[i] = (unsigned short)(inside | (slot << 12));
     }
     if (bad) atomicAdd(&counters[0], bad);
+    if (dc_over) atomicAdd(n_dc_over, dc_over);
 }
 
 // the windows that start a block (key differs from the previous one), counted per span of kSpan windows —
@@ -1179,14 +1190,16 @@ __global__ __launch_bounds__(256) void count_heads_kernel(const KeyT* __restrict
 }
 
 // block origin from a key: (br, bc) -> (R, C); the compact block-row numbering is undone through brow_base
-__device__ __forceinline__ void block_origin(unsigned long long key, int sh_br, int sh_er, const int* __restrict__ brow_base,
+__device__ __forceinline__ void block_origin(unsigned long long key, int sh_br, int sh_er, int dc_mode,
+                                             const int* __restrict__ brow_base,
                                              const IdxChrom* __restrict__ chroms, int n_chrom, int BR, int BC,
                                              int& R, int& C, int& ca_out) {
     const int br = (int)((key >> sh_br) & ((1ull << (sh_er - sh_br)) - 1ull));
-    const int bc = (int)(key & ((1ull << sh_br) - 1ull));
+    int bc = (int)(key & ((1ull << sh_br) - 1ull));
     int lo = 0, hi = n_chrom;                              // last chromosome whose first block row is <= br
     while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (brow_base[m] <= br) lo = m; else hi = m; }
     const int cs = chroms[lo].start;
+    if (dc_mode) bc += (br - brow_base[lo]) - 1;           // stored relative to the block row (block_key_kernel)
     R = cs + (br - brow_base[lo]) * BR;
     C = cs + bc * BC;
     ca_out = lo;
@@ -1196,13 +1209,13 @@ __device__ __forceinline__ void block_origin(unsigned long long key, int sh_br, 
 // some segments to the per-window kernels, which want position-sorted coordinates
 template <typename KeyT>
 __global__ __launch_bounds__(256) void rebuild_coords_kernel(const KeyT* __restrict__ sorted_keys, const unsigned short* __restrict__ win,
-                                                             long long n, int sh_br, int sh_er, const int* __restrict__ brow_base,
+                                                             long long n, int sh_br, int sh_er, int dc_mode, const int* __restrict__ brow_base,
                                                              const IdxChrom* __restrict__ chroms, int n_chrom, int BR, int BC,
                                                              int* __restrict__ r0s, int* __restrict__ c0s) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int R, C, ca;
-    block_origin((unsigned long long)sorted_keys[i], sh_br, sh_er, brow_base, chroms, n_chrom, BR, BC, R, C, ca);
+    block_origin((unsigned long long)sorted_keys[i], sh_br, sh_er, dc_mode, brow_base, chroms, n_chrom, BR, BC, R, C, ca);
     const unsigned w = win[i];
     r0s[i] = R + (int)(w & 63u);
     c0s[i] = C + (int)((w >> 6) & 63u);
@@ -1268,7 +1281,7 @@ __global__ __launch_bounds__(256) void block_table_kernel(const unsigned* __rest
                                                           long long n, const KeyT* __restrict__ sorted_keys,
                                                           const unsigned short* __restrict__ win, const int* __restrict__ brow_base,
                                                           const IdxChrom* __restrict__ chroms, int n_chrom, int BR, int BC,
-                                                          int sh_br, int sh_er, int sh_seg, int n_eregs,
+                                                          int sh_br, int sh_er, int sh_seg, int dc_mode, int n_eregs,
                                                           const unsigned long long* __restrict__ badbits,
                                                           BlockEntry* __restrict__ blocks) {
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1278,7 +1291,7 @@ __global__ __launch_bounds__(256) void block_table_kernel(const unsigned* __rest
     const long long e = (b + 1 < nr) ? (long long)starts[b + 1] : n;
     BlockEntry be;
     int ca;
-    block_origin((unsigned long long)sorted_keys[s], sh_br, sh_er, brow_base, chroms, n_chrom, BR, BC, be.R, be.C, ca);
+    block_origin((unsigned long long)sorted_keys[s], sh_br, sh_er, dc_mode, brow_base, chroms, n_chrom, BR, BC, be.R, be.C, ca);
     const IdxChrom ch = chroms[ca];
     const int cs = ch.start;
     be.start = (int)s; be.count = (int)(e - (long long)s);

@@ -281,3 +281,37 @@ def test_page_locked_staging_gives_the_same_tiles(hip_lib):
     np.testing.assert_array_equal(got["n"], 2 * want["n"])
     np.testing.assert_array_equal(got["num"], 2 * want["num"])
     np.testing.assert_allclose(got["sum"], 2 * want["sum"], rtol=1e-12, atol=0)
+
+
+def test_sort_keys_relative_columns_and_their_fallback(hip_lib):
+    """Chromosomes long enough for the block sort to store block columns relative to the block row (7 bits instead of the
+    absolute column's): a call near the diagonal uses them; one with windows more than 127 blocks away from the diagonal
+    falls back to absolute columns (and the context remembers).  Both must equal the per-window kernel."""
+    from coolpuppy_amd.engine import PileupEngine
+    clr = synth.make_cooler({"chrL": 80_000_000, "chrM": 61_000_000}, lam=25, seed=21)
+    nb = int(clr.chrom_offset[1])
+    rng = np.random.default_rng(8)
+    n = 120_000
+    r0 = rng.integers(0, nb - 400, n)
+    near = (r0 + rng.integers(0, 300, n)).astype(np.int32)
+    far = near.copy()
+    pick = rng.choice(n, 500, replace=False)
+    far[pick] = np.minimum(r0[pick] + rng.integers(5700, 7600, 500), nb - 22).astype(np.int32)
+    r0 = r0.astype(np.int32)
+    tile_ptr = np.array([0, n // 2, n], np.int64)
+    with PileupEngine(0) as eng:
+        eng.load_pixels(*clr.pixel_table())
+        eng.load_bins(clr.bins()["weight"][:].values, None)
+        eng.build_index(clr.chrom_offset)
+        for c0 in (near, far, near):                          # the third call runs after the fallback was remembered
+            res = []
+            for variant in (8, 16):
+                eng.set_tuning(0, variant)
+                eng.reset(2, 10)
+                eng.accumulate(r0, c0, tile_ptr, ignore_diags=2, mode=0)
+                res.append((eng.fetch(), eng.stats()["staged_regions"]))
+            (a, staged), (b, _) = res
+            assert staged > 0
+            np.testing.assert_array_equal(a["n"], b["n"])
+            np.testing.assert_array_equal(a["num"], b["num"])
+            np.testing.assert_allclose(a["sum"], b["sum"], rtol=1e-12, atol=0)
