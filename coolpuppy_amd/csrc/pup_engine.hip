@@ -103,6 +103,8 @@ struct pup_ctx {
     DevBuf<int> d_err;
     // stats / timing
     bool no_dc_keys = false;     // a call had windows too far from the diagonal for relative block columns in the sort key
+    std::vector<int> brow_sent;              // what d_brow / d_segend hold (plan_block_order)
+    std::vector<long long> htab_sent;
     bool profiling = false;      // HIP events around the kernels
     bool count_pixels = false;   // kernels also count the pixels inside the windows (statistics; costs a little)
     pup_stats stats{};
@@ -319,12 +321,12 @@ void pup_destroy(pup_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     collect_events(c);
     c->indptr.release(); c->px.release(); c->cnt32.release(); c->bal.release(); c->badbits.release(); c->idx.release(); c->idx_chrom.release(); c->weight.release(); c->cov.release(); c->expv.release(); c->exp_pair.release(); c->exp_regions.release();
-    c->bin_chrom.release(); c->d_brow.release();
+    c->bin_chrom.release(); c->d_brow.release(); c->brow_sent.clear();
     c->acc_f64.release(); c->acc_i64.release();
     c->d_r0.release(); c->d_c0.release(); c->d_h.release(); c->d_w.release(); c->d_geom.release();
     c->d_keys.release(); c->d_keys2.release(); c->d_cnt32.release(); c->d_win.release(); c->d_win2.release();
     c->d_starts.release(); c->d_blocks.release();
-    c->d_sr0.release(); c->d_sc0.release(); c->d_segend.release(); c->d_sorttmp.release();
+    c->d_sr0.release(); c->d_sc0.release(); c->d_segend.release(); c->htab_sent.clear(); c->d_sorttmp.release();
     c->d_k32.release(); c->d_k32b.release();
     c->part_f64.release(); c->slice_f64.release(); c->part_num.release(); c->slice_num.release();
     c->counters.release(); c->d_err.release();
@@ -680,8 +682,14 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
         brow_base[(size_t)k] = (int)n_brows;
         n_brows += (len + BR - 1) / BR;
     }
-    HIPCHK(c, c->d_brow.reserve((size_t)c->n_chrom));
-    HIPCHK(c, hipMemcpyAsync(c->d_brow.p, brow_base.data(), brow_base.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    // small host tables are re-sent only when they differ from what the device holds (steady-state loops: never)
+    if (brow_base != c->brow_sent) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->d_brow.cap < (size_t)c->n_chrom) c->brow_sent.clear();
+        HIPCHK(c, c->d_brow.reserve((size_t)c->n_chrom));
+        HIPCHK(c, hipMemcpy(c->d_brow.p, brow_base.data(), brow_base.size() * sizeof(int), hipMemcpyHostToDevice));
+        c->brow_sent = brow_base;
+    }
     // (tile, flip) runs of the caller's order
     std::vector<long long> seg_end2t;
     for (int t = 0; t < T; ++t) { seg_end2t.push_back(flip_from ? flip_from[t] : tile_ptr[t + 1]); seg_end2t.push_back(tile_ptr[t + 1]); }
@@ -726,12 +734,17 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
         const size_t ncnt = 2 + (size_t)nseg + 1 + 2;
         const int n_spans = (int)((n + pup::kSpan - 1) / pup::kSpan);          // block-start counters follow the ncnt scalars
         HIPCHK(c, c->d_win.reserve((size_t)n)); HIPCHK(c, c->d_win2.reserve((size_t)n));
+        if (c->d_segend.cap < seg_end2t.size() + (size_t)nseg + 1) c->htab_sent.clear();     // the buffer is about to move
         HIPCHK(c, c->d_segend.reserve(seg_end2t.size() + (size_t)nseg + 1)); HIPCHK(c, c->d_cnt32.reserve(ncnt + (size_t)n_spans));
         HIPCHK(c, c->d_starts.reserve((size_t)n + 1));
         // host tables of this attempt: the (tile, flip) boundaries for the key kernel, the segment boundaries in sorted order
         std::vector<long long> htab(seg_end2t);
         htab.insert(htab.end(), seg_win0.begin(), seg_win0.end());
-        HIPCHK(c, hipMemcpyAsync(c->d_segend.p, htab.data(), htab.size() * 8, hipMemcpyHostToDevice, c->stream));
+        if (htab != c->htab_sent) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));     // kernels of an earlier call may still read the old table
+            HIPCHK(c, hipMemcpy(c->d_segend.p, htab.data(), htab.size() * 8, hipMemcpyHostToDevice));
+            c->htab_sent = htab;
+        }
         HIPCHK(c, hipMemsetAsync(c->d_cnt32.p, 0, (ncnt + (size_t)n_spans) * sizeof(unsigned), c->stream));
         unsigned* d_spans = c->d_cnt32.p + ncnt;
         const unsigned gk = (unsigned)((n + 255) / 256);
