@@ -75,7 +75,7 @@ struct pup_ctx {
     long long nbins = 0, nnz = 0, nexp = 0;
     // accumulators (packed layout of the header)
     DevBuf<double> acc_f64;
-    DevBuf<long long> acc_i64;
+    struct { long long* p = nullptr; } acc_i64;   // view: the integer accumulators follow the f64 ones in acc_f64's allocation
     int T = 0, pad = 0, W = 0;
     // workspaces
     DevBuf<int> d_r0, d_c0, d_h, d_w;
@@ -322,7 +322,7 @@ void pup_destroy(pup_ctx* c) {
     collect_events(c);
     c->indptr.release(); c->px.release(); c->cnt32.release(); c->bal.release(); c->badbits.release(); c->idx.release(); c->idx_chrom.release(); c->weight.release(); c->cov.release(); c->expv.release(); c->exp_pair.release(); c->exp_regions.release();
     c->bin_chrom.release(); c->d_brow.release(); c->brow_sent.clear();
-    c->acc_f64.release(); c->acc_i64.release();
+    c->acc_f64.release(); c->acc_i64.p = nullptr;
     c->d_r0.release(); c->d_c0.release(); c->d_h.release(); c->d_w.release(); c->d_geom.release();
     c->d_keys.release(); c->d_keys2.release(); c->d_cnt32.release(); c->d_win.release(); c->d_win2.release();
     c->d_starts.release(); c->d_blocks.release();
@@ -620,10 +620,9 @@ int pup_reset(pup_ctx* c, int32_t n_tiles, int32_t pad) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const size_t W2 = (size_t)W * W;
     const size_t nf = (size_t)n_tiles * (W2 + 2 * (size_t)W), ni = (size_t)n_tiles * (W2 + 1);
-    HIPCHK(c, c->acc_f64.reserve(nf));
-    HIPCHK(c, c->acc_i64.reserve(ni));
-    HIPCHK(c, hipMemsetAsync(c->acc_f64.p, 0, nf * sizeof(double), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->acc_i64.p, 0, ni * sizeof(long long), c->stream));
+    HIPCHK(c, c->acc_f64.reserve(nf + ni));             // one allocation, one memset: f64 [nf] | i64 [ni]
+    c->acc_i64.p = reinterpret_cast<long long*>(c->acc_f64.p + nf);
+    HIPCHK(c, hipMemsetAsync(c->acc_f64.p, 0, (nf + ni) * sizeof(double), c->stream));
     c->T = n_tiles; c->pad = pad; c->W = W;
     return PUP_OK;
 }
