@@ -32,7 +32,7 @@ def engine_time(pu, plan, reps=3):
     bins = pu.clr.bins()
     eng.load_bins(bins[plan["weight_name"]][:].values if plan["weight_name"] else None,
                   bins[plan["cov_name"]][:].values if plan["cov_name"] else None)
-    eng.set_profiling(True)
+    eng.set_profiling(3)          # HIP events only: no pixel statistics inside the timed kernels
     best = None
     for _ in range(reps):
         eng.clear_stats()
