@@ -60,6 +60,10 @@ def parse(argv=None):
                          "set of --pairs pairs on a replicated table")
     ap.add_argument("--no-index", action="store_true", help="binary search only (skip the rank-bitmap index)")
     ap.add_argument("--variant", type=int, default=0, help="pup_set_tuning variant bits (kernel selection; 0 = default)")
+    ap.add_argument("--exchange", default="torch", choices=["torch", "native"],
+                    help="N>1: how the packed tiles are summed every step — torch.distributed.all_reduce on exported buffers "
+                         "(default: the path measured so far) or the engine's own RCCL call pup_allreduce, in place on its "
+                         "stream (the library's default; opt-in here until it has been timed on a multi-GPU node)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo (+ COOLPUPPY_AMD_BENCH_DEVICE=0) lets several ranks share ONE GPU "
                          "to smoke-test the N>1 code path on a single-GPU box")
@@ -360,11 +364,19 @@ def main():
     buf_i = torch.zeros(ni, dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
 
+    native_comm = None
+    if world > 1 and a.exchange == "native" and a.backend == "nccl":
+        from coolpuppy_amd import dist as pdist
+        native_comm = pdist.native_comm(eng)
+
     def make_step(p_r0, p_c0, n, tptr):
         def step():
             eng.reset(2, a.pad)
             eng.accumulate_device(p_r0, p_c0, n, tptr, ignore_diags=2, mode=0)
-            if world > 1:
+            if world > 1 and native_comm is not None:
+                eng.allreduce(native_comm)
+                eng.sync()
+            elif world > 1:
                 eng.export_to(buf_f.data_ptr(), buf_i.data_ptr())
                 allreduce(buf_f)
                 allreduce(buf_i)
@@ -573,7 +585,7 @@ def main():
                 "order": "reference stream",
                 "nnz": int(wl["bin2_id"].shape[0]), "nbins": int(wl["bin1_offset"].shape[0] - 1),
                 "pairs": a.pairs, "nshifts": a.nshifts, "pad": a.pad, "snippets_per_step": n_all,
-                "parallelism": f"{a.gpus} rank(s); {sharding}; RCCL all-reduce of the packed tiles every step (N>1)",
+                "parallelism": f"{a.gpus} rank(s); {sharding}; RCCL all-reduce of the packed tiles every step (N>1, exchange={a.exchange})",
                 "variant": a.variant,
             },
             "roofline": roofline, "cpu_baseline": cpu, "preblocked": preblocked,
