@@ -942,7 +942,8 @@ __global__ __launch_bounds__(kWave * NW, (NW == 4 && FACT && !EXTRA && !OOE && W
             double va[CH], vb[CH], wa, wb; unsigned a0, a1, a2, a3;
             gather(jj, va, wa, a0, a1);
             gather(jj + NW, vb, wb, a2, a3);
-            lds_wait_all(a0, a1, a2, a3); lds_pin(va); lds_pin(vb); lds_pin1(wa); lds_pin1(wb);
+            lds_wait_all(a0, a1, a2, a3); lds_pin(va); lds_pin(vb);
+            if constexpr (!FACT) { lds_pin1(wa); lds_pin1(wb); }     // (FACT: no validity word was read — pinning would materialise a zero)
             add(va, bits_of(jj, wa));
             add(vb, bits_of(jj + NW, wb));
             if (EXTRA) { extra(jj); extra(jj + NW); }
@@ -950,7 +951,8 @@ __global__ __launch_bounds__(kWave * NW, (NW == 4 && FACT && !EXTRA && !OOE && W
         if (jj < j1) {
             double va[CH], wa; unsigned a0, a1;
             gather(jj, va, wa, a0, a1);
-            lds_wait_all(a0, a1, a0, a1); lds_pin(va); lds_pin1(wa);
+            lds_wait_all(a0, a1, a0, a1); lds_pin(va);
+            if constexpr (!FACT) lds_pin1(wa);
             add(va, bits_of(jj, wa));
             if (EXTRA) extra(jj);
         }
