@@ -1369,10 +1369,10 @@ __global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
     unsigned long long npix = 0, nprobe = 0;
     const bool rowlane = lane < W;
 
-    // one window's state between its phases; two windows are in flight per wave (their dependent load chains —
+    // one window's state between its phases; four windows are in flight per wave (their dependent load chains —
     // bin masks / row bounds, bisection probes, pixels — interleave, the kernel being latency-bound)
     struct Win { int r0, c0, myrow; bool valid, rbad, cbad, e_ok; unsigned long long rowmask, colmask; double e;
-                 long long lo, b, hi; };
+                 long long lo, b, hi; int first_x; double first_v; };
     auto begin = [&](Win& w, int r0, int c0, bool have) __attribute__((always_inline)) {
         w.valid = false; w.lo = 0; w.b = 0; w.hi = 0;
         if (!have) return;
@@ -1426,11 +1426,12 @@ __global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
         }
         if (rowlane) {
             for (long long k = w.lo; k < w.hi; ++k) {                 // pixels of this lane's matrix row inside [c0, c0 + W)
-                const int q = a.px[k].x - w.c0;
+                // the first candidate of every window in flight was requested together (first_x / first_v)
+                const int q = (k == w.lo ? w.first_x : a.px[k].x) - w.c0;
                 if (q >= W) break;
                 ++npix;
                 if (w.rbad || ((w.colmask >> q) & 1ull)) continue;    // masked bin: contributes nothing
-                const double v = a.bal[k];
+                const double v = k == w.lo ? w.first_v : a.bal[k];
                 const double x = OOE ? v / w.e : v;
                 if (x == x) tsum[lane * W + q] += x;                 // lane owns row `lane` of the tile: no race
             }
@@ -1445,20 +1446,35 @@ __global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
         r0n = coord(s0 + (long long)kWave * cstep, a.r0); c0n = coord(s0 + (long long)kWave * cstep, a.c0);
         const long long left = (ce - s0 + cstep - 1) / cstep;
         const int nb = (int)(left < kWave ? left : kWave);
-        for (int j = 0; j < nb; j += 2) {
-            Win A, B;
-            begin(A, __builtin_amdgcn_readlane(r0v, j), __builtin_amdgcn_readlane(c0v, j), true);
-            const int j1 = j + 1 < nb ? j + 1 : j;
-            begin(B, __builtin_amdgcn_readlane(r0v, j1), __builtin_amdgcn_readlane(c0v, j1), j + 1 < nb);
-            // both bisections in lockstep: the two probes of a step are independent loads
-            while (__ballot(A.lo < A.b || B.lo < B.b)) {
-                const long long mA = (A.lo + A.b) >> 1, mB = (B.lo + B.b) >> 1;
-                const int xA = a.px[mA].x, xB = a.px[mB].x;           // padded table: reading at a row's end is harmless
-                if (A.lo < A.b) { if (xA < A.c0) A.lo = mA + 1; else A.b = mA; ++nprobe; }
-                if (B.lo < B.b) { if (xB < B.c0) B.lo = mB + 1; else B.b = mB; ++nprobe; }
+        constexpr int NWIN = 4;                                       // windows in flight per wave
+        for (int j = 0; j < nb; j += NWIN) {
+            Win w[NWIN];
+#pragma unroll
+            for (int u = 0; u < NWIN; ++u) {
+                const int ju = j + u < nb ? j + u : j;
+                begin(w[u], __builtin_amdgcn_readlane(r0v, ju), __builtin_amdgcn_readlane(c0v, ju), j + u < nb);
             }
-            finish(A);
-            finish(B);
+            // the bisections in lockstep: the probes of a step are independent loads
+            for (;;) {
+                bool any = false;
+#pragma unroll
+                for (int u = 0; u < NWIN; ++u) any = any || (w[u].lo < w[u].b);
+                if (!__ballot(any)) break;
+                int x[NWIN]; long long m[NWIN];
+#pragma unroll
+                for (int u = 0; u < NWIN; ++u) { m[u] = (w[u].lo + w[u].b) >> 1; x[u] = a.px[m[u]].x; }   // padded table: reading at a row's end is harmless
+#pragma unroll
+                for (int u = 0; u < NWIN; ++u)
+                    if (w[u].lo < w[u].b) { if (x[u] < w[u].c0) w[u].lo = m[u] + 1; else w[u].b = m[u]; ++nprobe; }
+            }
+#pragma unroll
+            for (int u = 0; u < NWIN; ++u) {                          // first pixel at / after the window's first column (padded table)
+                const bool has = rowlane && w[u].valid && w[u].lo < w[u].hi;
+                w[u].first_x = has ? a.px[w[u].lo].x : 0x7fffffff;
+                w[u].first_v = has ? a.bal[w[u].lo] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < NWIN; ++u) finish(w[u]);
         }
     }
     __syncthreads();
