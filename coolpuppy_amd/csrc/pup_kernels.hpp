@@ -1337,8 +1337,9 @@ __global__ __launch_bounds__(256) void block_table_kernel(const unsigned* __rest
 // often both were (sparse: ~1 bad row x ~1 bad column per window).  Per window the wave therefore does O(W) work: one
 // lane per window row searches its matrix row (bounded by the per-chromosome segment table) and adds the few pixels
 // it finds to a per-wave LDS tile.  Same chunk flush and reduction as the other K1 kernels.
-// LDS per wave: W^2 * 12 + W * 24 bytes (W = 51: 32 KB).
-__host__ __device__ inline size_t k1s_lds_bytes(int W) { return (size_t)W * W * 12 + (size_t)W * 24; }
+// LDS per wave: W^2 * 8 + W * 24 bytes (W = 51: 22 KB, seven waves per CU); the sparse RC counts go straight to the chunk's
+// output record in global memory (a window with both a masked row and a masked column is rare).
+__host__ __device__ inline size_t k1s_lds_bytes(int W) { return (size_t)W * W * 8 + (size_t)W * 24; }
 
 template <bool OOE>
 __global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
@@ -1346,12 +1347,12 @@ __global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
     const int W = a.W, W2 = W * W;
     double*   tsum = reinterpret_cast<double*>(smem_raw);            // [W2]
     double*   tcov = tsum + W2;                                      // [2W]
-    unsigned* trc  = reinterpret_cast<unsigned*>(tcov + 2 * W);      // [W2]  RC
-    unsigned* trb  = trc + W2;                                       // [W]   R
+    unsigned* trb  = reinterpret_cast<unsigned*>(tcov + 2 * W);      // [W]   R
     unsigned* tcb  = trb + W;                                        // [W]   C
     const int lane = threadIdx.x;
     const int ck = a.block_chunk[blockIdx.x];
     if (ck < 0) return;
+    unsigned* trc = a.part_num + (size_t)ck * W2;                    // [W2]  RC, already in the ACCUMULATOR frame, in the chunk's own record
     for (int t = lane; t < W2; t += kWave) { tsum[t] = 0.0; trc[t] = 0u; }
     for (int t = lane; t < 2 * W; t += kWave) tcov[t] = 0.0;
     for (int t = lane; t < W; t += kWave) { trb[t] = 0u; tcb[t] = 0u; }
@@ -1414,7 +1415,7 @@ __global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
                 unsigned long long rm = w.rowmask;
                 while (rm) {                                          // wave-uniform loop over the (rare) masked rows
                     const int p = __ffsll((long long)rm) - 1; rm &= rm - 1;
-                    if (w.cbad) trc[p * W + lane] += 1u;
+                    if (w.cbad) atomicAdd(&trc[map_cell(p, lane, W, m_tr, fl)], 1u);     // (L2 atomic: rare, and coherent for the flush)
                 }
             }
         }
@@ -1486,7 +1487,9 @@ __global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
         const int p = t / W, q = t - p * W;
         const int cell = map_cell(p, q, W, m_tr, fl);
         of[cell] = tsum[t];
-        on[cell] = n_e - trb[p] - tcb[q] + trc[t];
+        // RC was counted in place (accumulator frame); read it where the atomics put it, past the L1
+        const unsigned rc = __hip_atomic_load(&on[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        on[cell] = n_e - trb[p] - tcb[q] + rc;
     }
     for (int t = lane; t < 2 * W; t += kWave) of[W2 + t] = m_cov ? tcov[t] : 0.0;
     for (int off = 32; off > 0; off >>= 1) { npix += __shfl_down(npix, off); nprobe += __shfl_down(nprobe, off); }
