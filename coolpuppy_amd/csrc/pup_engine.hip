@@ -989,9 +989,10 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
                              !(c->variant & 32) && pup::k1s_lds_bytes(c->W) <= (size_t)c->max_lds &&
                              (!(mode & PUP_MODE_OOE) || c->nexp == 1 || c->have_exp_pair);
     if (sparse_geom && c->chunk_snippets <= 0) {
-        // a sparse-kernel window is cheap, a chunk is not (zeroing and flushing a W^2 tile): two chunks per wave slot
+        // a sparse-kernel window is cheap, a chunk is not (zeroing and flushing a W^2 tile, one more record for K2): three
+        // chunks per wave slot (measured on 4.9e5 51 x 51 windows: 2 per slot 1.64 ms K1s + K2, 3: 1.37, 4: 1.43, 8: 1.67)
         const long long slots = (long long)c->n_cu * std::max<long long>(1, (160 * 1024) / (long long)pup::k1s_lds_bytes(c->W));
-        C = std::max<long long>(64, (n + 2 * slots - 1) / (2 * slots));
+        C = std::max<long long>(64, (n + 3 * slots - 1) / (3 * slots));
     }
     const int S_plain = c->group_waves > 0 ? c->group_waves : 128;
     const int n_xcd = 8;
