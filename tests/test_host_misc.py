@@ -1,5 +1,6 @@
 """CPU tests of host-side helpers that the benchmark and the tools rely on."""
 import numpy as np
+import pytest
 
 from coolpuppy_amd import coolpup, synth
 
@@ -97,3 +98,41 @@ def test_sign_draws_equal_numpy_choice():
         got = coolpup._draw_signs(m)
         assert np.array_equal(got, want) and got.dtype == want.dtype
         assert np.random.randint(0, 1 << 30) == after_want
+
+
+def test_library_window_pass_equals_numpy():
+    """pup_host_windows (shift, bounds test, compaction; no GPU needed) against the numpy statement of the same rules —
+    np.round's half-to-even included — for several shapes; pup_host_group_tiles against a stable argsort."""
+    from coolpuppy_amd import engine as E
+    rng = np.random.default_rng(0)
+    for n, ns, res in ((0, 3, 10_000), (1, 0, 10_000), (1000, 3, 10_000), (257, 10, 5_000), (40_000, 2, 20_000)):
+        st1 = rng.integers(0, 5000, n).astype(np.int32)
+        st2 = (st1 + rng.integers(-5, 300, n)).astype(np.int32)
+        code = rng.integers(0, 7, n).astype(np.int32)
+        shift = rng.integers(100_000, 1_000_000, n * ns)
+        shift[: min(len(shift), 50)] = res * rng.integers(10, 90, min(len(shift), 50)) + res // 2      # exact halves: rounding rule
+        sign = rng.choice([-1, 1], n * ns)
+        for use_code in (True, False):
+            r0, c0, co, nroi = E.host_windows(st1, st2, code if use_code else None, shift if ns else None, sign if ns else None,
+                                              ns, res, 100, 100, 150, 5000, 150, 5200, 21, 21)
+            d = np.round(shift * sign / res).astype(int).astype(np.int32)
+            R = np.concatenate([st1, np.tile(st1, ns) + d]) + 100
+            C = np.concatenate([st2, np.tile(st2, ns) + d]) + 100
+            ok = (R >= 150) & (R + 21 <= 5000) & (C >= 150) & (C + 21 <= 5200)
+            assert np.array_equal(r0, R[ok]) and np.array_equal(c0, C[ok]) and nroi == int(ok[:n].sum())
+            if use_code:
+                assert np.array_equal(co, np.concatenate([code, np.tile(code, ns)])[ok])
+            else:
+                assert co is None
+    n = 30_000
+    r0 = rng.integers(0, 9999, n).astype(np.int32)
+    c0 = rng.integers(0, 9999, n).astype(np.int32)
+    tile = rng.integers(0, 11, n).astype(np.int32)
+    cuts = [0, 7, 7, 12_000, 29_999, n]                                   # parts of very different sizes, one empty
+    parts = [(r0[a:b], c0[a:b], tile[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    a, b, tp = E.group_tiles(parts, 11)
+    o = np.argsort(tile, kind="stable")
+    assert np.array_equal(a, r0[o]) and np.array_equal(b, c0[o])
+    assert np.array_equal(tp, np.concatenate([[0], np.cumsum(np.bincount(tile, minlength=11))]))
+    with pytest.raises(ValueError):
+        E.group_tiles([(r0[:5], c0[:5], np.array([0, 1, 2, 11, 3], np.int32))], 11)
