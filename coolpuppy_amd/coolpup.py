@@ -712,12 +712,17 @@ class CoordCreator:
             c1, c2 = L["center1"], R["center2"]
             # the reference loops offsets up to the TOTAL number of features (:682); offsets >= m select
             # nothing and draw nothing
+            # features sorted by centre (the usual BED case): the separation at offset i only grows with i, so the first
+            # offset at which every pair is beyond maxdist ends the walk (the reference keeps looping; it finds nothing there)
+            ordered = m > 1 and bool(np.all(c1[1:] >= c1[:-1]))
             for i in range(1, min(self.intervals.shape[0], m)):
                 k = m - i
                 dist = c2[i:i + k] - c1[:k]
                 ok = (self.mindist <= np.abs(dist)) & (np.abs(dist) <= self.maxdist)
                 a = np.flatnonzero(ok)
                 if len(a) == 0:
+                    if ordered and dist.min() > self.maxdist:
+                        break
                     continue                   # size-0 RNG draws do not advance the generator
                 if getattr(self, "_draw_only", False):
                     if nshifts > 0:
