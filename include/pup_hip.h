@@ -29,12 +29,18 @@
  *   pup_fetch / pup_export / pup_import
  *                                     <- sum_pups cross-region merge   coolpuppy/lib/puputils.py:88-113
  *                                        and the reduce at             coolpuppy/coolpup.py:1511-1531
+ *   pup_host_windows                  <- CoordCreator._control_regions (shifted control copies) + the bounds test of
+ *                                        _stream_snips, as one host pass  coolpuppy/coolpup.py:387-453, 1105-1114
+ *   pup_host_group_tiles              <- the per-group dicts of accumulate_stream as a grouping of windows by tile
+ *                                                                      coolpuppy/coolpup.py:1263-1283
+ *   pup_host_alloc / pup_host_free    <- (no counterpart: page-locked staging for asynchronous host-to-device copies)
  *
  * Conventions
  *   - plain C: pointers + sizes only; no C++/torch types cross this line.
  *   - every function returns 0 on success or a negative PUP_E* code; the text
  *     of the last failure is available from pup_last_error().  Nothing throws.
- *   - all host buffers are caller-owned; the library copies what it needs.
+ *   - all host buffers are caller-owned; the library copies what it needs (snippet arrays from pup_host_alloc memory are
+ *     copied asynchronously: leave them untouched until the next pup_sync / pup_fetch).
  *   - one context per GPU; calls on one context must be serialised by the
  *     caller; different contexts are independent.
  *   - "bin" always means a GLOBAL bin id of the cooler bin table (chromosome
