@@ -854,7 +854,7 @@ def _prefetch_engine(clr, device_id, rows=None):
     max(upload, coordinates) instead of their sum.  Errors surface when run_plan asks for the engine itself."""
     rows_key = None if rows is None else tuple((int(a), int(b)) for a, b in rows)
     hit = _ENGINES.get((id(clr), device_id, rows_key))
-    if hit is not None and hit[0] is clr:
+    if (hit is not None and hit[0] is clr) or os.environ.get("COOLPUPPY_AMD_NO_PREFETCH", "") == "1":
         return None
 
     def work():
