@@ -16,12 +16,18 @@ import numpy as np
 
 
 def _dist():
+    """torch.distributed when THIS process has initialised a process group, else None — without importing torch: a group
+    can only exist if the caller imported torch.distributed already (importing it here cost every single-GPU pileup()
+    its first 3 s)."""
+    import sys
+    dist = sys.modules.get("torch.distributed")
+    if dist is None:
+        return None
     try:
-        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist
     except Exception:
         return None
-    if dist.is_available() and dist.is_initialized():
-        return dist
     return None
 
 
