@@ -35,7 +35,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from coolpuppy_amd import synth  # noqa: E402  (numpy only; torch is imported after generation)
+import synth  # noqa: E402  (numpy only; torch is imported after generation)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 TB/s achievable)
 

@@ -75,6 +75,7 @@ _SIGNATURES = {
     "pup_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pup_import": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pup_allreduce": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pup_rccl_path": (C.c_int, [C.c_char_p, C.c_size_t]),
     "pup_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "pup_get_stats": (C.c_int, [C.c_void_p, C.POINTER(PupStats)]),
     "pup_clear_stats": (C.c_int, [C.c_void_p]),
@@ -102,7 +103,7 @@ def _prefer_torch_hip_runtime():
     imported first) keeps both on the runtime torch ships.  Without torch the system ROCm runtime is used."""
     import importlib.util
     import sys
-    if "torch" in sys.modules:
+    if "torch" in sys.modules or os.environ.get("COOLPUPPY_AMD_SYSTEM_HIP", "") == "1":
         return
     try:
         spec = importlib.util.find_spec("torch")
@@ -136,6 +137,49 @@ def lib():
             fn.argtypes = args
         _lib = handle
     return _lib
+
+
+_rccl = None
+
+
+def _torch_before_rccl():
+    """Load order matters on ROCm: a process that maps librccl (and with it librocm_smi64) FIRST and imports PyTorch-ROCm
+    LATER dies at exit with a double free in a static destructor of librocm_smi64 — with either ROCm stack, measured on
+    the GPU box (tools/exit_scenarios.py; this was GPUTEST_r02's rc 134: a test imported torch after the single-rank RCCL
+    test).  torch first, RCCL second is clean.  In the library's own multi-GPU path torch.distributed is imported long
+    before a communicator is made; for direct users of pup_allreduce the import is done here when torch is installed."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("COOLPUPPY_AMD_NO_TORCH_PRELOAD", "") == "1":
+        return
+    try:
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
+    except Exception:       # noqa: BLE001 - a broken torch install must not keep RCCL from loading
+        pass
+
+
+def rccl():
+    """ctypes handle of THE librccl of this process: the copy beside the HIP runtime the engine runs on (pup_rccl_path),
+    so that communicators handed to pup_allreduce, the engine's own dlopen and torch (when imported) share one ROCm
+    stack.  Loading the system librccl into a process that holds torch's libamdhip64 aborts at interpreter exit."""
+    global _rccl
+    if _rccl is None:
+        _torch_before_rccl()
+        buf = C.create_string_buffer(4096)
+        n = lib().pup_rccl_path(buf, len(buf))
+        if n < 0:
+            raise PupError(n, "pup_rccl_path failed")
+        _rccl = C.CDLL(buf.value.decode(), mode=C.RTLD_GLOBAL)
+    return _rccl
+
+
+def rccl_path():
+    buf = C.create_string_buffer(4096)
+    n = lib().pup_rccl_path(buf, len(buf))
+    if n < 0:
+        raise PupError(n, "pup_rccl_path failed")
+    return buf.value.decode()
 
 
 def declared_symbols():

@@ -863,8 +863,32 @@ def _prefetch_engine(clr, device_id, rows=None):
         except Exception:           # noqa: BLE001 - reported by the foreground call
             pass
     t = threading.Thread(target=work, name="pup-table-upload", daemon=True)
+    _PREFETCH_THREADS[:] = [x for x in _PREFETCH_THREADS if x.is_alive()]
+    _PREFETCH_THREADS.append(t)
     t.start()
     return t
+
+
+_PREFETCH_THREADS = []
+
+
+def _shutdown_engines():
+    """Interpreter exit, step 1: no helper thread may still be inside the HIP runtime (coolpuppy_amd.shutdown)."""
+    while _PREFETCH_THREADS:
+        t = _PREFETCH_THREADS.pop()
+        if t.is_alive():
+            t.join(timeout=60)
+
+
+def _close_engines():
+    """Interpreter exit, step 2 (after the RCCL communicators are gone): destroy the cached engines explicitly instead of
+    leaving it to __del__ during module teardown, when the HIP runtime may already be unloading."""
+    with _ENGINE_LOCK:
+        for k in list(_ENGINES):
+            try:
+                _ENGINES.pop(k)[1].close()
+            except Exception:       # noqa: BLE001 - shutting down
+                pass
 
 
 def _rows_of_table(indptr, col, cnt, rows):
@@ -1067,7 +1091,7 @@ class PileUpper:
         if region2 is None:
             region2 = region1
         reg1, reg2 = self._region_tuple(region1), self._region_tuple(region2)
-        if self._plain_pairs(modify_2Dintervals_func, by_window, keep_table):
+        if self._plain_pairs(modify_2Dintervals_func, by_window, keep_table, groupby):
             return self._pair_snippets(region1, region2, reg1, reg2, groupby, modify_2Dintervals_func)
         carry = columns
         # keep_table (callback path): rows must carry the reference's own column values (e.g. band tuples), so
@@ -1157,7 +1181,7 @@ class PileUpper:
             out["table"] = tbl                 # the accepted rows with every carried column (callback path)
         return out
 
-    def _plain_pairs(self, modify, by_window, keep_table):
+    def _plain_pairs(self, modify, by_window, keep_table, groupby=()):
         """True when the windows of a region are plain feature pairs: bedpe features, no rescaling, stripes, flips,
         by-window grouping or user functions — the case _pair_snippets builds with one fused pass of the library."""
         if self.CC.kind != "bedpe" or by_window or keep_table or self.store_stripes or getattr(self, "rescale", False):
@@ -1166,8 +1190,11 @@ class PileUpper:
             return False
         if len(self.CC.intervals) == 0 or self.CC.pos_stream == self.CC.empty_stream:
             return False
-        return modify is None or modify is bin_distance_intervals or \
+        is_banding = modify is bin_distance_intervals or \
             (isinstance(modify, partial) and modify.func is bin_distance_intervals)
+        if "distance_band" in (groupby or ()) and not is_banding:
+            return False            # a distance_band column of the caller's own: the general path groups by the column itself
+        return modify is None or is_banding
 
     def _pair_snippets(self, region1, region2, reg1, reg2, groupby, modify):
         """region_snippets for plain feature pairs (see _plain_pairs).  Same result as the general path — the ROI windows

@@ -7,6 +7,7 @@
 // (reference coolpuppy/coolpup.py:1024-1057, 1059-1191, 1236-1283) — see the header for the map.
 #include "../../include/pup_hip.h"
 #include "pup_kernels.hpp"
+#include "pup_staged.hpp"
 
 #include <hip/hip_runtime.h>
 #include <cstring>
@@ -79,16 +80,28 @@ struct pup_ctx {
     int T = 0, pad = 0, W = 0;
     // workspaces
     DevBuf<int> d_r0, d_c0, d_h, d_w;
-    // block-ordered copy of the snippets for the staged kernel (K1t)
+    // block-ordered copy of the snippets for the workgroup-staged kernel (K1q, pup_staged.hpp)
     DevBuf<unsigned long long> d_keys, d_keys2;
     DevBuf<unsigned> d_k32, d_k32b, d_cnt32, d_starts;
     DevBuf<unsigned short> d_win, d_win2;    // window-in-block values before / after the block sort
-    DevBuf<pup::BlockEntry> d_blocks;
-    DevBuf<int> d_sr0, d_sc0;
+    DevBuf<pup::StagedBlock> d_blocks;
+    DevBuf<int> d_wgfirst;
+    DevBuf<unsigned char> d_recvalid;
     DevBuf<long long> d_segend;
     DevBuf<unsigned char> d_sorttmp;
     long long tiled_min = 1000000;          // fewer snippets: the whole pile-up is a fraction of a millisecond anyway
-    unsigned long long last_stagings = 0;   // diagnostics: region stagings of the last K1t launch (0: K1r ran)
+    // the key kernel's verdict (ineligible windows, windows a diagonal mask reaches) reaches the host through mapped
+    // page-locked memory while the sort is already running; the block count of the last staged call comes back the same way
+    volatile unsigned* h_flags = nullptr;    // [0] ineligible [1] unclear [2] ticket   [4] blocks of the last staged call [6] its ticket
+    unsigned* d_flags = nullptr;             // device address of h_flags
+    hipEvent_t ev_key = nullptr;
+    unsigned ticket = 0;
+    // density of the last call with this signature: decides staged / per-window without a host round trip (see staged_run)
+    std::vector<long long> hint_sig;
+    long long hint_blocks = -1;              // -1: unknown
+    unsigned hint_ticket = 0;                // ticket whose block count h_flags[4] will hold
+    unsigned long long last_stagings = 0;   // diagnostics: regions staged by the last K1q launch (0: it did not run)
+    bool last_staged = false;
     // launch geometry: ONE device blob (one H2D copy per new geometry), the typed views below point into it
     DevBuf<unsigned char> d_geom;
     struct GeomView {
@@ -102,13 +115,12 @@ struct pup_ctx {
     DevBuf<unsigned long long> counters;   // [2]
     DevBuf<int> d_err;
     // stats / timing
-    bool no_dc_keys = false;     // a call had windows too far from the diagonal for relative block columns in the sort key
     std::vector<int> brow_sent;              // what d_brow / d_segend hold (plan_block_order)
     std::vector<long long> htab_sent;
     bool profiling = false;      // HIP events around the kernels
     bool count_pixels = false;   // kernels also count the pixels inside the windows (statistics; costs a little)
     pup_stats stats{};
-    struct EvTriple { hipEvent_t a, b, c; };   // K1 = a..b, reduction = b..c
+    struct EvTriple { hipEvent_t a, b, c, p; };   // K1 = a..b, reduction = b..c, block-order prepass = p..a (p may be null)
     std::vector<EvTriple> pending;             // awaiting a stream sync
     hipEvent_t slots[8] = {};
     int chunk_snippets = 0, variant = 0, group_waves = 0;
@@ -145,7 +157,9 @@ void collect_events(pup_ctx* c) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { c->stats.k1_ms += ms; c->stats.k1_launches += 1; }
         if (hipEventElapsedTime(&ms, p.b, p.c) == hipSuccess) c->stats.reduce_ms += ms;
+        if (p.p && hipEventElapsedTime(&ms, p.p, p.a) == hipSuccess) c->stats.prepare_ms += ms;
         (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); (void)hipEventDestroy(p.c);
+        if (p.p) (void)hipEventDestroy(p.p);
     }
     c->pending.clear();
 }
@@ -177,52 +191,50 @@ void launch_k1r(const pup::K1Args& a, int nchunks, hipStream_t s) {
 
 bool tiled_supported(int W) { return W >= 3 && W <= 31 && (W & 1); }
 
-// workgroup-staged kernel (K1q): a workgroup of NW waves shares one 64 x 64 region = a (65-W)^2 block of corners;
-// ACC = 2 when two tiles share the pass
-constexpr int kWgRegion = 64;
+// workgroup-staged kernel (K1q, pup_staged.hpp): persistent workgroups over the device-built block table.  The region
+// geometry is a property of the instantiation (StagedGeom) and only depends on facts the host knows BEFORE the prepass
+// (window width, observed-over-expected, coverage / statistics riding along) — the block size of the prepass follows from it.
+struct StagedGeo { int RSR, RSC, NW; };
+StagedGeo staged_geometry(int W, bool ooe, bool extra) {
+    const bool big = W <= 21 && !ooe && !extra;
+    return StagedGeo{big ? 128 : 64, 128, big ? 16 : 8};
+}
 // fact: every window is clear of the diagonal mask and nothing is divided by expected -> validity factorises (FACT)
 // extra: coverage vectors and / or pixel statistics ride along (kept out of the plain instantiation's window loop)
-template <int W, int NW, int ACC, bool EXTRA>
-void launch_k1q__(const pup::K1Args& a, int nchunks, bool fact, hipStream_t s) {
-    const size_t dyn = 0;
-    if (a.mode & PUP_MODE_OOE)
-        hipLaunchKernelGGL((pup::pileup_wgtile_kernel<W, true, NW, ACC, false, EXTRA>), dim3(nchunks), dim3(pup::kWave * NW), dyn, s, a);
-    else if (fact)
-        hipLaunchKernelGGL((pup::pileup_wgtile_kernel<W, false, NW, ACC, true, EXTRA>), dim3(nchunks), dim3(pup::kWave * NW), dyn, s, a);
-    else
-        hipLaunchKernelGGL((pup::pileup_wgtile_kernel<W, false, NW, ACC, false, EXTRA>), dim3(nchunks), dim3(pup::kWave * NW), dyn, s, a);
+template <int W, bool OOE, int ACC, bool FACT, bool EXTRA>
+void launch_staged___(const pup::K1Args& a, const pup::StagedArgs& sa, int G, hipStream_t s) {
+    using Geo = pup::StagedGeom<W, OOE, EXTRA>;
+    hipLaunchKernelGGL((pup::pileup_staged_kernel<W, OOE, Geo::RSR, Geo::RSC, Geo::NW, ACC, FACT, EXTRA>), dim3(G),
+                       dim3(pup::kWave * Geo::NW), 0, s, a, sa);
 }
-template <int W, int NW, int ACC>
-void launch_k1q_(const pup::K1Args& a, int nchunks, bool fact, hipStream_t s) {
-    const bool extra = ((a.mode & PUP_MODE_COV) && a.cov != nullptr) || a.counters != nullptr;
-    if (extra) launch_k1q__<W, NW, ACC, true>(a, nchunks, fact, s); else launch_k1q__<W, NW, ACC, false>(a, nchunks, fact, s);
+template <int W, int ACC, bool EXTRA>
+void launch_staged__(const pup::K1Args& a, const pup::StagedArgs& sa, int G, bool fact, hipStream_t s) {
+    if (a.mode & PUP_MODE_OOE) launch_staged___<W, true, ACC, false, EXTRA>(a, sa, G, s);
+    else if (fact) launch_staged___<W, false, ACC, true, EXTRA>(a, sa, G, s);
+    else launch_staged___<W, false, ACC, false, EXTRA>(a, sa, G, s);
 }
 template <int W>
-void launch_k1q(const pup::K1Args& a, int nchunks, int nw, int acc, bool fact, hipStream_t s) {
-    if (W == 21 && nw == 8) {             // tuning probe (variant bit 7): 8-wave workgroups, built for the headline width only
-        if (acc == 2) launch_k1q_<21, 8, 2>(a, nchunks, fact, s); else launch_k1q_<21, 8, 1>(a, nchunks, fact, s);
-        return;
-    }
-    if (acc == 2) launch_k1q_<W, 4, 2>(a, nchunks, fact, s); else launch_k1q_<W, 4, 1>(a, nchunks, fact, s);
+void launch_staged_(const pup::K1Args& a, const pup::StagedArgs& sa, int G, int acc, bool fact, bool extra, hipStream_t s) {
+    if (extra) { if (acc == 2) launch_staged__<W, 2, true>(a, sa, G, fact, s); else launch_staged__<W, 1, true>(a, sa, G, fact, s); }
+    else       { if (acc == 2) launch_staged__<W, 2, false>(a, sa, G, fact, s); else launch_staged__<W, 1, false>(a, sa, G, fact, s); }
 }
-
-bool launch_wgtiled(int W, const pup::K1Args& a, int nchunks, int nw, int acc, bool fact, hipStream_t s) {
+bool launch_staged(int W, const pup::K1Args& a, const pup::StagedArgs& sa, int G, int acc, bool fact, bool extra, hipStream_t s) {
     switch (W) {
-        case 3:  launch_k1q<3>(a, nchunks, nw, acc, fact, s);  return true;
-        case 5:  launch_k1q<5>(a, nchunks, nw, acc, fact, s);  return true;
-        case 7:  launch_k1q<7>(a, nchunks, nw, acc, fact, s);  return true;
-        case 9:  launch_k1q<9>(a, nchunks, nw, acc, fact, s);  return true;
-        case 11: launch_k1q<11>(a, nchunks, nw, acc, fact, s); return true;
-        case 13: launch_k1q<13>(a, nchunks, nw, acc, fact, s); return true;
-        case 15: launch_k1q<15>(a, nchunks, nw, acc, fact, s); return true;
-        case 17: launch_k1q<17>(a, nchunks, nw, acc, fact, s); return true;
-        case 19: launch_k1q<19>(a, nchunks, nw, acc, fact, s); return true;
-        case 21: launch_k1q<21>(a, nchunks, nw, acc, fact, s); return true;
-        case 23: launch_k1q<23>(a, nchunks, nw, acc, fact, s); return true;
-        case 25: launch_k1q<25>(a, nchunks, nw, acc, fact, s); return true;
-        case 27: launch_k1q<27>(a, nchunks, nw, acc, fact, s); return true;
-        case 29: launch_k1q<29>(a, nchunks, nw, acc, fact, s); return true;
-        case 31: launch_k1q<31>(a, nchunks, nw, acc, fact, s); return true;
+        case 3:  launch_staged_<3>(a, sa, G, acc, fact, extra, s);  return true;
+        case 5:  launch_staged_<5>(a, sa, G, acc, fact, extra, s);  return true;
+        case 7:  launch_staged_<7>(a, sa, G, acc, fact, extra, s);  return true;
+        case 9:  launch_staged_<9>(a, sa, G, acc, fact, extra, s);  return true;
+        case 11: launch_staged_<11>(a, sa, G, acc, fact, extra, s); return true;
+        case 13: launch_staged_<13>(a, sa, G, acc, fact, extra, s); return true;
+        case 15: launch_staged_<15>(a, sa, G, acc, fact, extra, s); return true;
+        case 17: launch_staged_<17>(a, sa, G, acc, fact, extra, s); return true;
+        case 19: launch_staged_<19>(a, sa, G, acc, fact, extra, s); return true;
+        case 21: launch_staged_<21>(a, sa, G, acc, fact, extra, s); return true;
+        case 23: launch_staged_<23>(a, sa, G, acc, fact, extra, s); return true;
+        case 25: launch_staged_<25>(a, sa, G, acc, fact, extra, s); return true;
+        case 27: launch_staged_<27>(a, sa, G, acc, fact, extra, s); return true;
+        case 29: launch_staged_<29>(a, sa, G, acc, fact, extra, s); return true;
+        case 31: launch_staged_<31>(a, sa, G, acc, fact, extra, s); return true;
         default: return false;
     }
 }
@@ -309,6 +321,14 @@ int pup_create(int device_id, pup_ctx** out) {
         pup_destroy(c);
         return fail(nullptr, PUP_ENOMEM, "pup_create: device allocation failed");
     }
+    {   // mapped page-locked flags: what the staged path's prepass tells the host without a blocking copy (staged_run)
+        void* hp = nullptr; void* dp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+            std::memset(hp, 0, 64);
+            c->h_flags = static_cast<volatile unsigned*>(hp); c->d_flags = static_cast<unsigned*>(dp);
+            if (hipEventCreateWithFlags(&c->ev_key, hipEventDisableTiming) != hipSuccess) c->ev_key = nullptr;
+        } else { if (hp) (void)hipHostFree(hp); (void)hipGetLastError(); }
+    }
     (void)hipMemset(c->counters.p, 0, 2 * sizeof(unsigned long long));
     (void)hipMemset(c->d_err.p, 0, sizeof(int));
     *out = c;
@@ -326,7 +346,9 @@ void pup_destroy(pup_ctx* c) {
     c->d_r0.release(); c->d_c0.release(); c->d_h.release(); c->d_w.release(); c->d_geom.release();
     c->d_keys.release(); c->d_keys2.release(); c->d_cnt32.release(); c->d_win.release(); c->d_win2.release();
     c->d_starts.release(); c->d_blocks.release();
-    c->d_sr0.release(); c->d_sc0.release(); c->d_segend.release(); c->htab_sent.clear(); c->d_sorttmp.release();
+    c->d_wgfirst.release(); c->d_recvalid.release(); c->d_segend.release(); c->htab_sent.clear(); c->d_sorttmp.release();
+    if (c->ev_key) (void)hipEventDestroy(c->ev_key);
+    if (c->h_flags) (void)hipHostFree(const_cast<unsigned*>(c->h_flags));
     c->d_k32.release(); c->d_k32b.release();
     c->part_f64.release(); c->slice_f64.release(); c->part_num.release(); c->slice_num.release();
     c->counters.release(); c->d_err.release();
@@ -617,9 +639,11 @@ int pup_reset(pup_ctx* c, int32_t n_tiles, int32_t pad) {
         return fail(c, PUP_ENOTSUP, "pup_reset: window %dx%d is wider than the banded kernel serves (255) and needs "
                     "%zu B of LDS per wave, device offers %d", W, W, pup::k1_lds_bytes(W), c->max_lds);
     int rc = bind(c); if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     const size_t W2 = (size_t)W * W;
     const size_t nf = (size_t)n_tiles * (W2 + 2 * (size_t)W), ni = (size_t)n_tiles * (W2 + 1);
+    // (no synchronisation unless the buffer must grow: the memset below is ordered behind whatever still uses the
+    // accumulators on the stream, so back-to-back reset / accumulate loops keep the GPU's queue filled)
+    if (nf + ni > c->acc_f64.cap) HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, c->acc_f64.reserve(nf + ni));             // one allocation, one memset: f64 [nf] | i64 [ni]
     c->acc_i64.p = reinterpret_cast<long long*>(c->acc_f64.p + nf);
     HIPCHK(c, hipMemsetAsync(c->acc_f64.p, 0, (nf + ni) * sizeof(double), c->stream));
@@ -627,51 +651,98 @@ int pup_reset(pup_ctx* c, int32_t n_tiles, int32_t pad) {
     return PUP_OK;
 }
 
-// ---- block-order prepass of the workgroup-staged kernel (K1q) ---------------------------------------------------
-// Decides, per segment of one pup_accumulate call, whether its windows overlap enough to be piled up from LDS-staged
-// regions, and provides the snippets in block order plus the block table the kernel walks.  Eligible calls:
-// register-tile widths, plain / OOE modes, cis (ignore_diags >= 0), rank-bitmap index present and covering every
-// window.  Everything else leaves `tiled` false at no cost.
+// ---- the workgroup-staged path (K1q, pup_staged.hpp): block-order prepass + persistent kernel + reduction -----------
+// Eligible calls: register-tile widths, plain / OOE modes, cis (ignore_diags >= 0), rank-bitmap index present and covering
+// every window, at least `tiled_min` windows, and windows dense enough that a staged region serves many of them.
 //   segment = the snippets that share a pass: (tile, flip) — or, when tiles are PAIRED (T even: tile t with tile
 //   t + T/2, the ROI and the control tile of one group in the host layer's numbering), (pair, flip) with the tile's
 //   half as a per-window slot bit, so that a sparse tile rides on the regions its dense partner stages anyway.
-// Device pipeline, one host synchronisation: keys (segment | expected region | block row | block col) -> radix sort
-// (rocPRIM) -> permuted copy + block-start flags -> compaction of the block starts (rocPRIM select) -> first block of
-// every segment -> [sync: ineligible windows, blocks, blocks per segment] -> block table.
+// Device pipeline, NO host round trip on its critical path:
+//   keys (segment | expected region | block row | block col) + window-in-block values  -> publish the key kernel's verdict to
+//   mapped host memory, record an event -> radix sort (rocPRIM) -> block starts (own ordered compaction) -> block table +
+//   workgroup ranges (grid-stride over a block count only the device knows) -> [the host waits for the EVENT — the key
+//   kernel is long done, the sort still runs — and picks the kernel: any ineligible window sends the call to the per-window
+//   kernels, any window a diagonal mask reaches rules out the factorised count] -> K1q on its fixed persistent grid ->
+//   reduction of the partial records.
+// What the host cannot know without waiting for the sort is the number of blocks, i.e. whether staging pays (a region
+// must serve enough windows).  It is learnt once per call SIGNATURE (window counts per tile, width, mode): the first call with
+// a signature waits for the count, later ones reuse the verdict and refresh it from the count the previous call left in
+// mapped memory — steady-state loops never synchronise.
 // ten radix bits per onesweep pass (rocPRIM's default is eight): a pass costs the same here (measured: 8, 9 and 10 bits within
 // 5 %, 11 bits 2.6x — the look-back state outgrows the cache), so 17..20-bit keys take two passes instead of three
 using Radix10 = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
     rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>, 10,
                                         rocprim::block_radix_rank_algorithm::match>>;
-struct BlockOrder {
-    bool tiled = false;                 // any segment goes to K1q
-    bool paired = false;                // two accumulator sets per chunk
-    bool fact = false;                  // no window is reached by the diagonal mask, nothing divided by expected: FACT kernel
-    int  nseg = 0;
-    std::vector<char> seg_tiled;        // [nseg]
-    std::vector<long long> seg_win0;    // [nseg+1] windows of segment s in launch order: [seg_win0[s], seg_win0[s+1])
-    std::vector<int> seg_blk0;          // [nseg+1] blocks of segment s in the block table
-    const int* r0 = nullptr;            // snippets in launch order (device): what the per-window kernels read
-    const int* c0 = nullptr;
-    const unsigned short* win = nullptr;   // windows in block order, as corners inside their regions: what K1q reads
-};
 
-static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const int64_t* tile_ptr, const int64_t* flip_from,
-                     int32_t ignore_diags, uint32_t mode, bool rescale, BlockOrder& out) {
+extern "C++" {
+template <typename KeyT>
+static void launch_key_kernel(pup_ctx* c, int BR, int BC, unsigned grid, const int* dr0, const int* dc0, long long n, int nseg2t, int H,
+                              const pup::ExpRegion* d_eregs, int n_eregs, int W, int sh_br, int sh_er, int sh_seg, int seg_shift,
+                              int clear_gap, KeyT* keys) {
+#define PUP_KEY_ARGS dr0, dc0, n, (const long long*)c->d_segend.p, nseg2t, H, (const pup::IdxChrom*)c->idx_chrom.p, c->n_chrom, \
+        (const unsigned short*)c->bin_chrom.p, (long long)c->nbins, (const int*)c->d_brow.p, d_eregs, n_eregs, W, BR, BC, sh_br, \
+        sh_er, sh_seg, seg_shift, clear_gap, keys, c->d_win.p, c->d_cnt32.p
+    if (BR == 108 && BC == 108)
+        hipLaunchKernelGGL((pup::staged_key_kernel<KeyT, 108, 108>), dim3(grid), dim3(256), 0, c->stream, PUP_KEY_ARGS);
+    else if (BR == 44 && BC == 108)
+        hipLaunchKernelGGL((pup::staged_key_kernel<KeyT, 44, 108>), dim3(grid), dim3(256), 0, c->stream, PUP_KEY_ARGS);
+    else
+        hipLaunchKernelGGL((pup::staged_key_kernel<KeyT, 0, 0>), dim3(grid), dim3(256), 0, c->stream, PUP_KEY_ARGS);
+#undef PUP_KEY_ARGS
+}
+}   // extern "C++"
+
+static void fill_k1_args(pup_ctx* c, pup::K1Args& a, int32_t ignore_diags, uint32_t mode) {
+    a.indptr = c->indptr.p; a.px = c->px.p; a.cnt32 = c->cnt32.p;
+    a.bal = c->bal.p; a.badbits = c->badbits.p;
+    const bool use_idx = c->have_idx && !(c->variant & 1);
+    a.idx = use_idx ? c->idx.p : nullptr; a.idx_chrom = use_idx ? c->idx_chrom.p : nullptr;
+    a.n_chrom = use_idx ? c->n_chrom : 0;
+    a.rowseg = (use_idx && c->have_rowseg) ? c->rowseg.p : nullptr;
+    a.weight = c->have_weight ? c->weight.p : nullptr;
+    a.cov = c->have_cov ? c->cov.p : nullptr;
+    a.expv = (c->nexp > 0 || (c->n_exp_regions > 0 && !c->have_exp_pair)) ? c->expv.p : nullptr;
+    a.nexp = c->nexp; a.nbins = c->nbins;
+    a.exp_regions = c->n_exp_regions > 0 ? c->exp_regions.p : nullptr; a.n_exp_regions = c->n_exp_regions;
+    a.exp_pair = c->have_exp_pair ? c->exp_pair.p : nullptr;
+    a.part_f64 = c->part_f64.p; a.part_num = c->part_num.p;
+    a.counters = c->count_pixels ? c->counters.p : nullptr; a.err = c->d_err.p;
+    a.W = c->W; a.ignore_diags = ignore_diags; a.mode = mode;
+}
+
+// returns PUP_OK when the call was piled up here (K1q + reduction enqueued), 1 when the per-window kernels must take it,
+// a negative code on error.  ev[0..2]: optional timing events (prepass start, K1 start, K1 end).
+static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const int64_t* tile_ptr, const int64_t* flip_from,
+                      int32_t ignore_diags, uint32_t mode, bool rescale, hipEvent_t* ev) {
     const int W = c->W, T = c->T;
-    out.tiled = false; out.paired = false; out.r0 = dr0; out.c0 = dc0;
-    c->last_stagings = 0;
+    c->last_stagings = 0; c->last_staged = false;
     const bool force = (c->variant & 8) != 0, forbid = (c->variant & 16) != 0;
     const bool use_idx_t = c->have_idx && !(c->variant & 1);
     if (forbid || rescale || (mode & (PUP_MODE_EXPECTED | PUP_MODE_TRANSPOSE)) || (c->variant & 2) || !use_idx_t ||
         ignore_diags < 0 || !tiled_supported(W) || n >= 0x7fffffffLL || !(force || n >= c->tiled_min) ||
-        2 * T > pup::kMaxSegCount || c->nbins >= (1LL << pup::kSlotBit) || !c->bin_chrom.p ||
+        2 * T > pup::kMaxSegCount || T > pup::kMaxStagedTiles || !c->bin_chrom.p || !c->h_flags || !c->ev_key ||
         (int)c->h_chroms.size() != c->n_chrom)
-        return PUP_OK;
-    const int BR = kWgRegion - W + 1, BC = kWgRegion - W + 1;
-    const unsigned long long min_per_block = 8;          // windows per staged region that pay for the staging
+        return 1;
+    const bool extra = ((mode & PUP_MODE_COV) && c->have_cov) || c->count_pixels;
+    const StagedGeo geo = staged_geometry(W, (mode & PUP_MODE_OOE) != 0, extra);
+    const int BR = geo.RSR - W + 1, BC = geo.RSC - W + 1;
+    const int G = c->n_cu * (geo.RSR * geo.RSC > 64 * 128 ? 1 : 2);            // persistent workgroups (one / two per CU by LDS)
+    // a staged region must serve this many windows on average to pay for its staging
+    const long long min_per_block = 8LL * (geo.RSR * geo.RSC) / (64 * 64);
     const int n_eregs = ((mode & PUP_MODE_OOE) && c->n_exp_regions > 0 && !c->have_exp_pair) ? c->n_exp_regions : 0;
     auto nbits = [](unsigned long long v) { int b = 1; while ((v >> b) != 0) ++b; return b; };
+
+    // ---- what the last call with this signature found: staged or not, without waiting ---------------------------------
+    std::vector<long long> sig;
+    sig.reserve(8 + 2 * (size_t)T);
+    sig.push_back(n); sig.push_back(T); sig.push_back(W); sig.push_back((long long)(mode & (PUP_MODE_OOE | PUP_MODE_COV)));
+    sig.push_back(ignore_diags); sig.push_back(flip_from ? 1 : 0); sig.push_back(c->variant & (4 | 64)); sig.push_back(extra ? 1 : 0);
+    for (int t = 0; t <= T; ++t) sig.push_back(tile_ptr[t]);
+    if (flip_from) for (int t = 0; t < T; ++t) sig.push_back(flip_from[t]);
+    const bool known = (sig == c->hint_sig) && c->hint_blocks >= 0;
+    if (known && c->h_flags[6] == c->hint_ticket) c->hint_blocks = (long long)c->h_flags[4];   // the previous call's count has landed
+    if (known && !force && c->hint_blocks * min_per_block > n) return 1;    // too sparse last time: per-window kernels
+
     // block rows are numbered compactly over the genome (fewer key bits = fewer radix passes)
     long long max_len = 1, n_brows = 0;
     std::vector<int> brow_base((size_t)c->n_chrom);
@@ -689,172 +760,127 @@ static int plan_block_order(pup_ctx* c, const int* dr0, const int* dc0, int64_t 
         HIPCHK(c, hipMemcpy(c->d_brow.p, brow_base.data(), brow_base.size() * sizeof(int), hipMemcpyHostToDevice));
         c->brow_sent = brow_base;
     }
-    // (tile, flip) runs of the caller's order
-    std::vector<long long> seg_end2t;
-    for (int t = 0; t < T; ++t) { seg_end2t.push_back(flip_from ? flip_from[t] : tile_ptr[t + 1]); seg_end2t.push_back(tile_ptr[t + 1]); }
-    auto run_len = [&](int t, int f) { const long long b = tile_ptr[t], e = tile_ptr[t + 1], m = flip_from ? flip_from[t] : e; return f ? e - m : m - b; };
-
-    hipEvent_t ep0 = nullptr, ep1 = nullptr;
-    if (c->profiling) { HIPCHK(c, hipEventCreate(&ep0)); HIPCHK(c, hipEventCreate(&ep1)); HIPCHK(c, hipEventRecord(ep0, c->stream)); }
-    auto stop_timer = [&]() {
-        if (!ep0) return;
-        float ms = 0.f;
-        if (hipEventRecord(ep1, c->stream) == hipSuccess && hipEventSynchronize(ep1) == hipSuccess &&
-            hipEventElapsedTime(&ms, ep0, ep1) == hipSuccess) c->stats.prepare_ms += ms;
-        (void)hipEventDestroy(ep0); (void)hipEventDestroy(ep1); ep0 = ep1 = nullptr;
-    };
-
-    const bool can_pair = T >= 2 && (T % 2) == 0 && !(c->variant & 64);
+    const bool paired = T >= 2 && (T % 2) == 0 && !(c->variant & 64);
+    const int H = paired ? T / 2 : 0, U = paired ? H : T, ACC = paired ? 2 : 1;
+    const int nseg = 2 * U;
     const int seg_shift = flip_from ? 0 : 1;            // no flipped windows: the flip bit is left out of the key
-    // trials: (tile pairs | tiles on their own) x (block column relative to the block row | absolute).  The relative form
-    // needs 7 bits where the absolute one needs 10 for a human chromosome; a window further than 127 blocks from the
-    // diagonal makes the call fall back to absolute columns (and the context remembers)
-    for (int attempt = can_pair ? 0 : 1; attempt < 2; ++attempt) {
-      for (int keymode = c->no_dc_keys ? 1 : 0; keymode < 2; ++keymode) {
-        const bool paired = attempt == 0;
-        const int H = paired ? T / 2 : 0;
-        const int nseg = paired ? 2 * H : 2 * T;
-        std::vector<long long> seg_win0((size_t)nseg + 1, 0);
-        for (int sg = 0; sg < nseg; ++sg) {
-            const int f = sg & 1, u = sg >> 1;
-            seg_win0[(size_t)sg + 1] = seg_win0[(size_t)sg] + (paired ? run_len(u, f) + run_len(u + H, f) : run_len(u, f));
-        }
-        const int bits_abs = nbits((unsigned long long)(max_len / BC + 1));
-        const int dc_mode = (keymode == 0 && bits_abs > 7) ? 1 : 0;
-        if (keymode == 0 && !dc_mode) continue;           // short chromosomes: absolute columns are as narrow
-        const int bits_bc = dc_mode ? 7 : bits_abs, bits_br = nbits((unsigned long long)n_brows + 1);
-        const int bits_er = n_eregs > 0 ? nbits((unsigned long long)n_eregs) : 0;
-        const int sh_br = bits_bc, sh_er = sh_br + bits_br, sh_seg = sh_er + bits_er;
-        const int nseg_key = nseg >> seg_shift;
-        const int end_bit = sh_seg + (nseg_key > 1 ? nbits((unsigned long long)(nseg_key - 1)) : 0);
-        if (end_bit > 64) { stop_timer(); return PUP_OK; }
-        // [0] ineligible windows, [1] blocks, [2 .. 2+nseg] first block of every segment + total, then: windows a diagonal
-        // mask reaches, windows whose relative block column does not fit
-        const size_t ncnt = 2 + (size_t)nseg + 1 + 2;
-        const int n_spans = (int)((n + pup::kSpan - 1) / pup::kSpan);          // block-start counters follow the ncnt scalars
-        HIPCHK(c, c->d_win.reserve((size_t)n)); HIPCHK(c, c->d_win2.reserve((size_t)n));
-        if (c->d_segend.cap < seg_end2t.size() + (size_t)nseg + 1) c->htab_sent.clear();     // the buffer is about to move
-        HIPCHK(c, c->d_segend.reserve(seg_end2t.size() + (size_t)nseg + 1)); HIPCHK(c, c->d_cnt32.reserve(ncnt + (size_t)n_spans));
-        HIPCHK(c, c->d_starts.reserve((size_t)n + 1));
-        // host tables of this attempt: the (tile, flip) boundaries for the key kernel, the segment boundaries in sorted order
-        std::vector<long long> htab(seg_end2t);
-        htab.insert(htab.end(), seg_win0.begin(), seg_win0.end());
-        if (htab != c->htab_sent) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));     // kernels of an earlier call may still read the old table
-            HIPCHK(c, hipMemcpy(c->d_segend.p, htab.data(), htab.size() * 8, hipMemcpyHostToDevice));
-            c->htab_sent = htab;
-        }
-        HIPCHK(c, hipMemsetAsync(c->d_cnt32.p, 0, (ncnt + (size_t)n_spans) * sizeof(unsigned), c->stream));
-        unsigned* d_spans = c->d_cnt32.p + ncnt;
-        const unsigned gk = (unsigned)((n + 255) / 256);
-        const unsigned gk4 = (unsigned)((n + 1023) / 1024);           // block_key_kernel: four windows per thread
-        hipError_t se = hipSuccess;
-        size_t tmp_bytes = 0;
-        const bool k32 = end_bit <= 32;
-        const pup::ExpRegion* d_eregs = n_eregs > 0 ? c->exp_regions.p : nullptr;
-        if (k32) {
-            HIPCHK(c, c->d_k32.reserve((size_t)n)); HIPCHK(c, c->d_k32b.reserve((size_t)n));
-            hipLaunchKernelGGL((BR == 44 ? pup::block_key_kernel<unsigned, 44> : pup::block_key_kernel<unsigned, 0>), dim3(gk4), dim3(256), 0, c->stream, dr0, dc0, (long long)n,
-                               (const long long*)c->d_segend.p, (int)seg_end2t.size(), H, (const pup::IdxChrom*)c->idx_chrom.p,
-                               c->n_chrom, (const unsigned short*)c->bin_chrom.p, (long long)c->nbins, (const int*)c->d_brow.p,
-                               d_eregs, n_eregs, W, BR, BC, sh_br, sh_er, sh_seg, seg_shift, dc_mode, ignore_diags + W - 1, c->d_k32.p, c->d_win.p,
-                               c->d_cnt32.p, c->d_cnt32.p + ncnt - 2, c->d_cnt32.p + ncnt - 1);
-            se = rocprim::radix_sort_pairs<Radix10>(nullptr, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_win.p, c->d_win2.p,
-                                           (size_t)n, 0, end_bit, c->stream);
-            if (se == hipSuccess) se = c->d_sorttmp.reserve(tmp_bytes + 16);
-            if (se == hipSuccess)
-                se = rocprim::radix_sort_pairs<Radix10>(c->d_sorttmp.p, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_win.p,
-                                               c->d_win2.p, (size_t)n, 0, end_bit, c->stream);
-            if (se == hipSuccess) {
-                hipLaunchKernelGGL((pup::count_heads_kernel<unsigned>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
-                                   (const unsigned*)c->d_k32b.p, (long long)n, d_spans);
-                hipLaunchKernelGGL((pup::block_starts_kernel<unsigned>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
-                                   (const unsigned*)c->d_k32b.p, (long long)n, (const unsigned*)d_spans, c->d_starts.p);
-            }
-        } else {
-            HIPCHK(c, c->d_keys.reserve((size_t)n)); HIPCHK(c, c->d_keys2.reserve((size_t)n));
-            hipLaunchKernelGGL((pup::block_key_kernel<unsigned long long, 0>), dim3(gk4), dim3(256), 0, c->stream, dr0, dc0, (long long)n,
-                               (const long long*)c->d_segend.p, (int)seg_end2t.size(), H, (const pup::IdxChrom*)c->idx_chrom.p,
-                               c->n_chrom, (const unsigned short*)c->bin_chrom.p, (long long)c->nbins, (const int*)c->d_brow.p,
-                               d_eregs, n_eregs, W, BR, BC, sh_br, sh_er, sh_seg, seg_shift, dc_mode, ignore_diags + W - 1, c->d_keys.p, c->d_win.p,
-                               c->d_cnt32.p, c->d_cnt32.p + ncnt - 2, c->d_cnt32.p + ncnt - 1);
-            se = rocprim::radix_sort_pairs<Radix10>(nullptr, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_win.p, c->d_win2.p,
-                                           (size_t)n, 0, end_bit, c->stream);
-            if (se == hipSuccess) se = c->d_sorttmp.reserve(tmp_bytes + 16);
-            if (se == hipSuccess)
-                se = rocprim::radix_sort_pairs<Radix10>(c->d_sorttmp.p, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_win.p,
-                                               c->d_win2.p, (size_t)n, 0, end_bit, c->stream);
-            if (se == hipSuccess) {
-                hipLaunchKernelGGL((pup::count_heads_kernel<unsigned long long>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
-                                   (const unsigned long long*)c->d_keys2.p, (long long)n, d_spans);
-                hipLaunchKernelGGL((pup::block_starts_kernel<unsigned long long>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
-                                   (const unsigned long long*)c->d_keys2.p, (long long)n, (const unsigned*)d_spans, c->d_starts.p);
-            }
-        }
-        if (se != hipSuccess) return fail(c, PUP_EHIP, "pup_accumulate: block sort: %s", hipGetErrorString(se));
-        // (block starts: block_starts_kernel above — an own two-kernel compaction; rocprim::select took 0.10 ms for this)
-        hipLaunchKernelGGL(pup::segment_blocks_kernel, dim3(1), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
-                           (const unsigned*)d_spans, n_spans, c->d_cnt32.p + 1,
-                           (const long long*)(c->d_segend.p + seg_end2t.size()), nseg, c->d_cnt32.p + 2);
-        std::vector<unsigned> cnt(ncnt, 0);
-        HIPCHK(c, hipMemcpyAsync(cnt.data(), c->d_cnt32.p, ncnt * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));      // the one synchronisation (also fences htab)
-        if (cnt[0] != 0) { stop_timer(); return PUP_OK; }   // a window the index does not cover: the plain kernels take the call
-        if (cnt[ncnt - 1] != 0) { c->no_dc_keys = true; continue; }     // a window far off the diagonal: absolute block columns
-        const long long nblk = (long long)cnt[1];
-        std::vector<int> seg_blk0((size_t)nseg + 1);
-        for (int sg = 0; sg <= nseg; ++sg) seg_blk0[(size_t)sg] = (int)cnt[2 + (size_t)sg];
-        // a segment is worth staging when a staged region serves >= min_per_block windows on average
-        std::vector<char> seg_tiled((size_t)nseg, 0);
-        bool any = false, all = true; long long covered = 0; unsigned long long stagings = 0;
-        for (int sg = 0; sg < nseg; ++sg) {
-            const long long len = seg_win0[(size_t)sg + 1] - seg_win0[(size_t)sg];
-            const long long nb = seg_blk0[(size_t)sg + 1] - seg_blk0[(size_t)sg];
-            if (len <= 0) continue;
-            const bool st = force || (len >= 20000 && (unsigned long long)nb * min_per_block <= (unsigned long long)len);
-            seg_tiled[(size_t)sg] = st;
-            if (st) { any = true; covered += len; stagings += (unsigned long long)nb; } else all = false;
-        }
-        if (paired && !all) break;                        // a pair too sparse to stage: plan again with every tile on its own
-        if (!any || (!force && covered * 2 < n)) { stop_timer(); return PUP_OK; }
-        // block table (device, asynchronous from here on)
-        HIPCHK(c, c->d_blocks.reserve((size_t)std::max<long long>(nblk, 1)));
-        const unsigned gb = (unsigned)((nblk + 255) / 256);
-        if (k32)
-            hipLaunchKernelGGL((pup::block_table_kernel<unsigned>), dim3(gb), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
-                               (const unsigned*)(c->d_cnt32.p + 1), (long long)n, (const unsigned*)c->d_k32b.p,
-                               (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
-                               c->n_chrom, BR, BC, sh_br, sh_er, sh_seg, dc_mode, n_eregs, (const unsigned long long*)c->badbits.p, c->d_blocks.p);
-        else
-            hipLaunchKernelGGL((pup::block_table_kernel<unsigned long long>), dim3(gb), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
-                               (const unsigned*)(c->d_cnt32.p + 1), (long long)n, (const unsigned long long*)c->d_keys2.p,
-                               (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
-                               c->n_chrom, BR, BC, sh_br, sh_er, sh_seg, dc_mode, n_eregs, (const unsigned long long*)c->badbits.p, c->d_blocks.p);
-        if (!all) {
-            // some segments stay with the per-window kernels: they want position-sorted coordinates — rebuilt from the sorted
-            // keys and values in one streaming pass (never with pairs: a pair is staged whole or not at all)
-            HIPCHK(c, c->d_sr0.reserve((size_t)n)); HIPCHK(c, c->d_sc0.reserve((size_t)n));
-            if (k32)
-                hipLaunchKernelGGL((pup::rebuild_coords_kernel<unsigned>), dim3(gk), dim3(256), 0, c->stream, (const unsigned*)c->d_k32b.p,
-                                   (const unsigned short*)c->d_win2.p, (long long)n, sh_br, sh_er, dc_mode, (const int*)c->d_brow.p,
-                                   (const pup::IdxChrom*)c->idx_chrom.p, c->n_chrom, BR, BC, c->d_sr0.p, c->d_sc0.p);
-            else
-                hipLaunchKernelGGL((pup::rebuild_coords_kernel<unsigned long long>), dim3(gk), dim3(256), 0, c->stream,
-                                   (const unsigned long long*)c->d_keys2.p, (const unsigned short*)c->d_win2.p, (long long)n, sh_br, sh_er, dc_mode,
-                                   (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p, c->n_chrom, BR, BC, c->d_sr0.p, c->d_sc0.p);
-            out.r0 = c->d_sr0.p; out.c0 = c->d_sc0.p;
-        }
-        HIPCHK(c, hipGetLastError());
-        out.tiled = true; out.paired = paired; out.nseg = nseg;
-        out.fact = !(mode & PUP_MODE_OOE) && cnt[ncnt - 2] == 0 && !(c->variant & 4);
-        out.seg_tiled = seg_tiled; out.seg_win0 = seg_win0; out.seg_blk0 = seg_blk0;
-        out.win = c->d_win2.p;
-        c->last_stagings = stagings;
-        stop_timer();
-        return PUP_OK;
-      }
+    // (tile, flip) runs of the caller's order, for the key kernel
+    std::vector<long long> htab;
+    for (int t = 0; t < T; ++t) { htab.push_back(flip_from ? flip_from[t] : tile_ptr[t + 1]); htab.push_back(tile_ptr[t + 1]); }
+    const int nseg2t = (int)htab.size();
+    const int bits_bc = nbits((unsigned long long)(max_len / BC + 1)), bits_br = nbits((unsigned long long)n_brows + 1);
+    const int bits_er = n_eregs > 0 ? nbits((unsigned long long)n_eregs) : 0;
+    const int sh_br = bits_bc, sh_er = sh_br + bits_br, sh_seg = sh_er + bits_er;
+    const int nseg_key = nseg >> seg_shift;
+    const int end_bit = sh_seg + (nseg_key > 1 ? nbits((unsigned long long)(nseg_key - 1)) : 0);
+    if (end_bit > 64) return 1;
+    const bool k32 = end_bit <= 32;
+
+    // ---- buffers (grow-only: steady-state calls allocate nothing) -----------------------------------------------------
+    const int n_spans = (int)((n + pup::kSpan - 1) / pup::kSpan);
+    const size_t ncnt = 4;                               // [0] ineligible [1] unclear [2] blocks [3] -, then the span counters
+    const size_t W2 = (size_t)W * W, Lf = W2 + 2 * (size_t)W;
+    const size_t nrec = (size_t)T * 2 * (size_t)G;       // record ((slot * U + unit) * 2 + flip) * G + workgroup = (tile * 2 + flip) * G + workgroup
+    HIPCHK(c, c->d_win.reserve((size_t)n)); HIPCHK(c, c->d_win2.reserve((size_t)n));
+    if (c->d_segend.cap < htab.size()) c->htab_sent.clear();          // the buffer is about to move
+    HIPCHK(c, c->d_segend.reserve(htab.size()));
+    HIPCHK(c, c->d_cnt32.reserve(ncnt + (size_t)n_spans));
+    HIPCHK(c, c->d_starts.reserve((size_t)n + 1));
+    HIPCHK(c, c->d_blocks.reserve((size_t)std::min<long long>(n, (n_brows + 1) * (max_len / BC + 2) * (long long)std::max(nseg_key, 1) * (n_eregs + 1))));   // distinct keys at most
+    HIPCHK(c, c->d_wgfirst.reserve((size_t)G + 1));
+    HIPCHK(c, c->d_recvalid.reserve(nrec));
+    HIPCHK(c, c->part_f64.reserve(nrec * Lf)); HIPCHK(c, c->part_num.reserve(nrec * W2));
+    if (k32) { HIPCHK(c, c->d_k32.reserve((size_t)n)); HIPCHK(c, c->d_k32b.reserve((size_t)n)); }
+    else     { HIPCHK(c, c->d_keys.reserve((size_t)n)); HIPCHK(c, c->d_keys2.reserve((size_t)n)); }
+    if (htab != c->htab_sent) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));     // kernels of an earlier call may still read the old table
+        HIPCHK(c, hipMemcpy(c->d_segend.p, htab.data(), htab.size() * 8, hipMemcpyHostToDevice));
+        c->htab_sent = htab;
     }
-    stop_timer();
+    size_t tmp_bytes = 0;
+    hipError_t se = k32 ? rocprim::radix_sort_pairs<Radix10>(nullptr, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_win.p, c->d_win2.p, (size_t)n, 0, end_bit, c->stream)
+                        : rocprim::radix_sort_pairs<Radix10>(nullptr, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_win.p, c->d_win2.p, (size_t)n, 0, end_bit, c->stream);
+    if (se == hipSuccess) se = c->d_sorttmp.reserve(tmp_bytes + 16);
+    if (se != hipSuccess) return fail(c, PUP_EHIP, "pup_accumulate: block sort: %s", hipGetErrorString(se));
+
+    // ---- prepass, all on the stream -------------------------------------------------------------------------------------
+    if (ev) HIPCHK(c, hipEventRecord(ev[0], c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_cnt32.p, 0, (ncnt + (size_t)n_spans) * sizeof(unsigned), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_recvalid.p, 0, nrec, c->stream));
+    const unsigned gk4 = (unsigned)((n + 1023) / 1024);               // key kernel: four windows per thread
+    const pup::ExpRegion* d_eregs = n_eregs > 0 ? c->exp_regions.p : nullptr;
+    const unsigned ticket = ++c->ticket;
+    if (k32) launch_key_kernel<unsigned>(c, BR, BC, gk4, dr0, dc0, (long long)n, nseg2t, H, d_eregs, n_eregs, W, sh_br, sh_er, sh_seg,
+                                         seg_shift, ignore_diags + W - 1, c->d_k32.p);
+    else launch_key_kernel<unsigned long long>(c, BR, BC, gk4, dr0, dc0, (long long)n, nseg2t, H, d_eregs, n_eregs, W, sh_br, sh_er,
+                                               sh_seg, seg_shift, ignore_diags + W - 1, c->d_keys.p);
+    hipLaunchKernelGGL(pup::staged_publish_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned*)c->d_cnt32.p,
+                       (volatile unsigned*)c->d_flags, ticket);
+    HIPCHK(c, hipEventRecord(c->ev_key, c->stream));
+    unsigned* d_spans = c->d_cnt32.p + ncnt;
+    const unsigned gt = (unsigned)std::min<long long>(4096, (n + 255) / 256);
+    if (k32) {
+        se = rocprim::radix_sort_pairs<Radix10>(c->d_sorttmp.p, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_win.p, c->d_win2.p,
+                                                (size_t)n, 0, end_bit, c->stream);
+        if (se != hipSuccess) return fail(c, PUP_EHIP, "pup_accumulate: block sort: %s", hipGetErrorString(se));
+        hipLaunchKernelGGL((pup::count_heads_kernel<unsigned>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
+                           (const unsigned*)c->d_k32b.p, (long long)n, d_spans);
+        hipLaunchKernelGGL((pup::block_starts_kernel<unsigned>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
+                           (const unsigned*)c->d_k32b.p, (long long)n, (const unsigned*)d_spans, c->d_starts.p, c->d_cnt32.p + 2);
+        hipLaunchKernelGGL((pup::staged_table_kernel<unsigned>), dim3(gt), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
+                           (const unsigned*)(c->d_cnt32.p + 2), (long long)n, (const unsigned*)c->d_k32b.p,
+                           (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
+                           c->n_chrom, W, geo.RSR, geo.RSC, sh_br, sh_er, sh_seg, seg_shift, n_eregs,
+                           (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G);
+    } else {
+        se = rocprim::radix_sort_pairs<Radix10>(c->d_sorttmp.p, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_win.p, c->d_win2.p,
+                                                (size_t)n, 0, end_bit, c->stream);
+        if (se != hipSuccess) return fail(c, PUP_EHIP, "pup_accumulate: block sort: %s", hipGetErrorString(se));
+        hipLaunchKernelGGL((pup::count_heads_kernel<unsigned long long>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
+                           (const unsigned long long*)c->d_keys2.p, (long long)n, d_spans);
+        hipLaunchKernelGGL((pup::block_starts_kernel<unsigned long long>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
+                           (const unsigned long long*)c->d_keys2.p, (long long)n, (const unsigned*)d_spans, c->d_starts.p, c->d_cnt32.p + 2);
+        hipLaunchKernelGGL((pup::staged_table_kernel<unsigned long long>), dim3(gt), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
+                           (const unsigned*)(c->d_cnt32.p + 2), (long long)n, (const unsigned long long*)c->d_keys2.p,
+                           (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
+                           c->n_chrom, W, geo.RSR, geo.RSC, sh_br, sh_er, sh_seg, seg_shift, n_eregs,
+                           (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G);
+    }
+    // leave the block count where the NEXT call with this signature finds it without waiting
+    hipLaunchKernelGGL(pup::staged_publish_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned*)(c->d_cnt32.p + 2),
+                       (volatile unsigned*)(c->d_flags + 4), ticket);
+    HIPCHK(c, hipGetLastError());
+
+    // ---- the host's part: the key kernel's verdict (an event long reached: the sort is still running) -----------------
+    HIPCHK(c, hipEventSynchronize(c->ev_key));
+    if (c->h_flags[2] != ticket) return fail(c, PUP_EHIP, "pup_accumulate: the key kernel's verdict did not arrive");
+    if (c->h_flags[0] != 0) return 1;                    // a window the index does not cover: the per-window kernels take the call
+    const bool fact = !(mode & PUP_MODE_OOE) && c->h_flags[1] == 0 && !(c->variant & 4);
+    if (!known) {
+        // first call with this signature: wait for the block count once and decide whether staging pays
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->hint_sig = sig;
+        c->hint_blocks = (long long)c->h_flags[4];
+        if (!force && c->hint_blocks * min_per_block > n) { c->hint_ticket = ticket; return 1; }
+    }
+    c->hint_ticket = ticket;
+
+    // ---- K1q + reduction ---------------------------------------------------------------------------------------------------
+    pup::K1Args a{};
+    fill_k1_args(c, a, ignore_diags, mode);
+    pup::StagedArgs sa{};
+    sa.blocks = c->d_blocks.p; sa.win = c->d_win2.p; sa.wg_first = c->d_wgfirst.p; sa.U = U; sa.rec_valid = c->d_recvalid.p;
+    if (ev) HIPCHK(c, hipEventRecord(ev[1], c->stream));
+    if (!launch_staged(W, a, sa, G, ACC, fact, extra, c->stream))
+        return fail(c, PUP_ENOTSUP, "pup_accumulate: staged kernel not built for W=%d", W);
+    HIPCHK(c, hipGetLastError());
+    if (ev) HIPCHK(c, hipEventRecord(ev[2], c->stream));
+    const int Li = (int)W2;
+    hipLaunchKernelGGL(pup::reduce_staged_kernel, dim3((unsigned)((Lf + Li + 63) / 64), (unsigned)T), dim3(64, pup::kRedParts), 0,
+                       c->stream, (const double*)c->part_f64.p, (const unsigned*)c->part_num.p,
+                       (const unsigned char*)c->d_recvalid.p, 2 * G, (int)Lf, Li, c->acc_f64.p, c->acc_i64.p);
+    HIPCHK(c, hipGetLastError());
+    c->last_staged = true;
     return PUP_OK;
 }
 
@@ -949,36 +975,40 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
                         c->W, c->W, need, c->max_lds);
     }
 
-    // ---- many overlapping cis windows: block order + workgroup-staged kernel (K1q), see plan_block_order -----------
-    BlockOrder order;
-    { const int prc = plan_block_order(c, dr0, dc0, n, tile_ptr, flip_from, ignore_diags, mode, rescale, order); if (prc) return prc; }
-    const bool tiled = order.tiled, paired = order.tiled && order.paired;
-    const int *kr0 = order.r0, *kc0 = order.c0;
-    const int T = c->T, H = paired ? T / 2 : 0;
-    const int nw_q = (c->variant & 128) ? 8 : 4;          // waves per K1q workgroup
+    const int T = c->T;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, ep = nullptr;
+    if (c->profiling) {
+        HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1)); HIPCHK(c, hipEventCreate(&e2)); HIPCHK(c, hipEventCreate(&ep));
+    }
+    // ---- many overlapping cis windows: block order + workgroup-staged kernel (K1q), see staged_run --------------------
+    bool staged = false;
+    {
+        hipEvent_t evs[3] = {ep, e0, e1};
+        const int src = staged_run(c, dr0, dc0, n, tile_ptr, flip_from, ignore_diags, mode, rescale, c->profiling ? evs : nullptr);
+        if (src < 0) return src;
+        staged = src == PUP_OK;
+    }
+    const int *kr0 = dr0, *kc0 = dc0;
+    if (!staged) {
 
     // launch geometry (chunk / group / reduction tables) depends only on the snippet COUNTS per tile, the blocks per
     // segment and the tuning: when it repeats (steady-state loops, benchmarks) the device tables of the last call are reused
     std::vector<long long> gkey;
     gkey.reserve(16 + 4 * (size_t)T);
     gkey.push_back(n); gkey.push_back(T); gkey.push_back(c->W); gkey.push_back(c->chunk_snippets);
-    gkey.push_back(c->group_waves); gkey.push_back(c->variant & (2 | 64 | 128)); gkey.push_back((mode & PUP_MODE_EXPECTED) ? 1 : 0);
+    gkey.push_back(c->group_waves); gkey.push_back(c->variant & 2); gkey.push_back((mode & PUP_MODE_EXPECTED) ? 1 : 0);
     gkey.push_back(flip_from ? 1 : 0); gkey.push_back(rescale ? 1 : 0); gkey.push_back((ignore_diags < 0 ? 1 : 0) | (c->variant & 32) | ((c->nexp == 1 || c->have_exp_pair) ? 2 : 0) | ((mode & PUP_MODE_OOE) ? 4 : 0));
-    gkey.push_back(tiled ? (paired ? 2 : 1) + (order.fact ? 4 : 0) : 0);
-    if (tiled) { for (char f : order.seg_tiled) gkey.push_back(f); for (int b : order.seg_blk0) gkey.push_back(b); }
     for (int t = 0; t <= T; ++t) gkey.push_back(tile_ptr[t]);
     if (flip_from) for (int t = 0; t < T; ++t) gkey.push_back(flip_from[t]);
     const bool geom_hit = (gkey == c->geom_key);
     if (!geom_hit) {
     c->geom_key.clear();
     // ---- chunk table -------------------------------------------------------------------------------------
-    // A chunk = what one wave (K1r and friends) or one workgroup (K1q) accumulates: one tile (K1q with paired tiles: one
-    // pair) and one flip state; it writes one partial record per accumulator set.
+    // A chunk = what one wave accumulates: one tile and one flip state; it writes one partial record.
     // Plain chunks come in GROUPS: a group owns a contiguous range of the (position-sorted) snippets and its S chunks
     // interleave over it (chunk j takes range[j], range[j+S], ...), so the waves of a group walk the same few matrix
     // rows together and the rows stay in the XCD's L2.  Groups are dealt round-robin to the 8 XCDs; workgroup b runs on
     // XCD b % 8 (observed dispatch rule, used for speed only), so a group's chunks get ids b = xcd + 8*i.
-    // K1q chunks are ranges of BLOCKS of the block table (chunk_begin / chunk_end index it).
     long long C = c->chunk_snippets;
     if (C <= 0) {
         const long long target = (long long)std::max(c->n_cu, 64) * 32 * 4;   // ~4 chunks per wave slot
@@ -1003,22 +1033,12 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     const bool sparse_kernel = sparse_geom;
     const bool band_kernel = !lds_kernel && !sparse_kernel && c->W > 31;
     const int nbands = band_kernel ? (c->W + (pup::kWave / band_nch(c->W)) - 1) / (pup::kWave / band_nch(c->W)) : 1;
-    // blocks per K1q chunk: ~4 rounds of 4 workgroups per CU, at least 4 regions per workgroup (the first one is not overlapped)
-    long long BPC = 4;
-    if (tiled) {
-        long long staged_blocks = 0;
-        for (int sg = 0; sg < order.nseg; ++sg)
-            if (order.seg_tiled[(size_t)sg]) staged_blocks += order.seg_blk0[(size_t)sg + 1] - order.seg_blk0[(size_t)sg];
-        BPC = c->chunk_snippets > 0 ? c->chunk_snippets
-                                    : std::max<long long>(4, (staged_blocks + (long long)c->n_cu * 16 - 1) / ((long long)c->n_cu * 16));
-    }
-    const int U = paired ? H : T;                                   // pass units: pairs or tiles
+    const int U = T;
     std::vector<long long> cb, ce, unit_chunk_ptr((size_t)U + 1, 0), dn((size_t)T);
     std::vector<unsigned char> cf;
     std::vector<int> cs;
     std::vector<std::vector<int>> xcd_list((size_t)n_xcd);       // entries: chunk * nbands + band
-    std::vector<std::vector<int>> xcd_list_t((size_t)n_xcd);     // the same for the chunks the staged kernel runs
-    struct Group { long long key; int first_chunk, waves; bool staged; };
+    struct Group { long long key; int first_chunk, waves; };
     std::vector<Group> groups;
     const bool host_pos = !(mode & PUP_MODE_DEVPTR) && kr0 == dr0;   // host order == launch order
     std::vector<long long> group_start;                             // DEVPTR: first snippet of every group
@@ -1027,47 +1047,29 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
             const long long g1 = std::min(e, g0 + (long long)S_plain * C);
             const int waves = (int)std::min<long long>(S_plain, std::max<long long>(1, (g1 - g0 + 15) / 16));
             if (!host_pos) group_start.push_back(g0);
-            groups.push_back(Group{host_pos ? (long long)r0[g0] : (long long)groups.size(), (int)cb.size(), waves, false});
+            groups.push_back(Group{host_pos ? (long long)r0[g0] : (long long)groups.size(), (int)cb.size(), waves});
             for (int j = 0; j < waves; ++j) {
                 cb.push_back(g0 + j); ce.push_back(g1); cs.push_back(waves); cf.push_back(flip);
             }
         }
     };
-    auto add_blocks = [&](long long b, long long e, unsigned char flip) {       // K1q chunks over blocks [b, e)
-        for (long long g0 = b; g0 < e; g0 += BPC) {
-            if (!host_pos) group_start.push_back(0);
-            groups.push_back(Group{(long long)groups.size(), (int)cb.size(), 1, true});
-            cb.push_back(g0); ce.push_back(std::min(e, g0 + BPC)); cs.push_back(1); cf.push_back(flip);
-        }
-    };
     for (int t = 0; t < T; ++t) dn[(size_t)t] = tile_ptr[t + 1] - tile_ptr[t];
     for (int u = 0; u < U; ++u) {
         for (int f = 0; f < 2; ++f) {
-            if (tiled) {
-                const int sg = 2 * u + f;                           // segments are (unit, flip) in this order
-                if (order.seg_tiled[(size_t)sg]) add_blocks(order.seg_blk0[(size_t)sg], order.seg_blk0[(size_t)sg + 1], (unsigned char)f);
-                else add_run(order.seg_win0[(size_t)sg], order.seg_win0[(size_t)sg + 1], (unsigned char)f);   // never with pairs
-            } else {
-                const long long b = tile_ptr[u], e = tile_ptr[u + 1], m = flip_from ? flip_from[u] : e;
-                if (f == 0) add_run(b, m, 0); else add_run(m, e, 1);
-            }
+            const long long b = tile_ptr[u], e = tile_ptr[u + 1], m = flip_from ? flip_from[u] : e;
+            if (f == 0) add_run(b, m, 0); else add_run(m, e, 1);
         }
         unit_chunk_ptr[(size_t)u + 1] = (long long)cb.size();
     }
     const long long nchunks = (long long)cb.size();
-    // records: chunk ck writes record ck (+ nchunks for the second accumulator set of a pair): tile t's records are contiguous
-    const long long nrec = paired ? 2 * nchunks : nchunks;
-    std::vector<long long> tile_rec_ptr((size_t)T + 1, 0);
-    for (int t = 0; t <= T; ++t)
-        tile_rec_ptr[(size_t)t] = !paired ? unit_chunk_ptr[(size_t)t]
-                                          : (t < H ? unit_chunk_ptr[(size_t)t] : nchunks + unit_chunk_ptr[(size_t)(t - H)]);
+    // records: chunk ck writes record ck: tile t's records are contiguous
+    const long long nrec = nchunks;
+    const std::vector<long long>& tile_rec_ptr = unit_chunk_ptr;
     // Launch order = matrix position, across tiles: with many tiles (by-distance x by-strand ...) every tile walks
     // the whole genome, so running the tiles one after the other re-reads every matrix row once per tile from HBM;
     // dealing the groups out by the row of their first snippet lets the groups that are in flight together — of
     // whatever tile — share rows in L2 / MALL.  (Chunk numbering, hence the reduction, stays tile-contiguous.)
-    bool any_plain = false;
-    for (auto& g : groups) any_plain = any_plain || !g.staged;
-    if (!host_pos && any_plain && T > 1 && !groups.empty()) {
+    if (!host_pos && T > 1 && !groups.empty()) {
         // snippets are device-resident: fetch just the first row of every group
         const int ng = (int)groups.size();
         DevBuf<long long> d_pos; DevBuf<int> d_key;
@@ -1083,16 +1085,14 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         if (ge == hipSuccess) ge = hipMemcpy(keys.data(), d_key.p, (size_t)ng * 4, hipMemcpyDeviceToHost);
         d_pos.release(); d_key.release();
         if (ge != hipSuccess) return fail(c, PUP_EHIP, "pup_accumulate: %s", hipGetErrorString(ge));
-        for (int g = 0; g < ng; ++g) if (!groups[(size_t)g].staged) groups[(size_t)g].key = keys[(size_t)g];
+        for (int g = 0; g < ng; ++g) groups[(size_t)g].key = keys[(size_t)g];
     }
-    if (T > 1 && any_plain)
-        std::stable_sort(groups.begin(), groups.end(), [](const Group& x, const Group& y) { return (x.staged ? 0 : x.key) < (y.staged ? 0 : y.key); });
+    if (T > 1)
+        std::stable_sort(groups.begin(), groups.end(), [](const Group& x, const Group& y) { return x.key < y.key; });
     {
-        size_t gp = 0, gt = 0;
+        size_t gp = 0;
         for (size_t g = 0; g < groups.size(); ++g) {
-            // K1q chunks are block ranges in genome order: deal them out in runs of 8, so that neighbouring block rows —
-            // whose staged regions overlap in W-1 of 64 matrix rows — meet in the same XCD's L2
-            auto& lst = groups[g].staged ? xcd_list_t[(gt++ / 8) % (size_t)n_xcd] : xcd_list[gp++ % (size_t)n_xcd];
+            auto& lst = xcd_list[gp++ % (size_t)n_xcd];
             for (int j = 0; j < groups[g].waves; ++j)
                 for (int b = 0; b < nbands; ++b) lst.push_back((groups[g].first_chunk + j) * nbands + b);
         }
@@ -1108,10 +1108,8 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
                 bb[i * (size_t)n_xcd + (size_t)x] = e % nbands;
             }
     };
-    std::vector<int> block_chunk, block_band, block_chunk_t, block_band_t;
+    std::vector<int> block_chunk, block_band;
     deal(xcd_list, block_chunk, block_band);
-    deal(xcd_list_t, block_chunk_t, block_band_t);
-    const long long nblocks_t = (long long)block_chunk_t.size();
     const long long nblocks = (long long)block_chunk.size();
     if (nrec > 0x7fffffffLL || nblocks > 0x7fffffffLL) return fail(c, PUP_ENOTSUP, "pup_accumulate: too many chunks");
     if (C > 0xffffffffLL) return fail(c, PUP_ENOTSUP, "pup_accumulate: chunk too long for 32-bit num partials");
@@ -1151,7 +1149,6 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         const size_t o_s1 = put(seg1.data(), seg1.size() * 8);
         const size_t o_cs = put(cs.data(), (size_t)nchunks * 4);
         const size_t o_bc = put(block_chunk.data(), (size_t)nblocks * 4), o_bb = put(block_band.data(), (size_t)nblocks * 4);
-        const size_t o_bt = put(block_chunk_t.data(), (size_t)nblocks_t * 4);
         const size_t o_cf = put(cf.data(), (size_t)nchunks);
         HIPCHK(c, c->d_geom.reserve(blob.size() + 8));
         HIPCHK(c, hipMemcpy(c->d_geom.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
@@ -1164,45 +1161,23 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         c->gv.chunk_stride = reinterpret_cast<const int*>(g + o_cs);
         c->gv.block_chunk = reinterpret_cast<const int*>(g + o_bc);
         c->gv.block_band = reinterpret_cast<const int*>(g + o_bb);
-        c->gv.block_chunk_t = reinterpret_cast<const int*>(g + o_bt);
         c->gv.chunk_flip = g + o_cf;
     }
-    c->g_nblocks_t = nblocks_t;
     c->g_nchunks = nchunks; c->g_nblocks = nblocks; c->g_two_level = two_level; c->g_nslices = nslices;
     c->geom_key = gkey;
     }   // !geom_hit
-    const long long nchunks = c->g_nchunks, nblocks = c->g_nblocks, nslices = c->g_nslices;
+    const long long nblocks = c->g_nblocks, nslices = c->g_nslices;
     const bool two_level = c->g_two_level;
 
     // ---- K1 ---------------------------------------------------------------------------------------
     pup::K1Args a{};
-    a.indptr = c->indptr.p; a.px = c->px.p; a.cnt32 = c->cnt32.p;
-    a.bal = c->bal.p; a.badbits = c->badbits.p;
-    const bool use_idx = c->have_idx && !(c->variant & 1);
-    a.idx = use_idx ? c->idx.p : nullptr; a.idx_chrom = use_idx ? c->idx_chrom.p : nullptr;
-    a.n_chrom = use_idx ? c->n_chrom : 0;
-    a.rowseg = (use_idx && c->have_rowseg) ? c->rowseg.p : nullptr;
-    a.weight = c->have_weight ? c->weight.p : nullptr;
-    a.cov = c->have_cov ? c->cov.p : nullptr;
-    a.expv = (c->nexp > 0 || (c->n_exp_regions > 0 && !c->have_exp_pair)) ? c->expv.p : nullptr;
-    a.nexp = c->nexp; a.nbins = c->nbins;
-    a.exp_regions = c->n_exp_regions > 0 ? c->exp_regions.p : nullptr; a.n_exp_regions = c->n_exp_regions;
-    a.exp_pair = c->have_exp_pair ? c->exp_pair.p : nullptr;
-    a.r0 = kr0; a.c0 = kc0; a.win = order.win;
+    fill_k1_args(c, a, ignore_diags, mode);
+    a.r0 = kr0; a.c0 = kc0;
     a.chunk_begin = c->gv.chunk_begin; a.chunk_end = c->gv.chunk_end; a.chunk_flip = c->gv.chunk_flip;
     a.chunk_stride = c->gv.chunk_stride; a.block_chunk = c->gv.block_chunk; a.block_band = c->gv.block_band;
-    a.blocks = tiled ? c->d_blocks.p : nullptr;
-    a.rec_stride = (int)nchunks;
-    a.part_f64 = c->part_f64.p; a.part_num = c->part_num.p;
-    a.counters = c->count_pixels ? c->counters.p : nullptr; a.err = c->d_err.p;
-    a.W = W; a.ignore_diags = ignore_diags; a.mode = mode;
     const size_t lds = pup::k1_lds_bytes(W);
 
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-    if (c->profiling) {
-        HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1)); HIPCHK(c, hipEventCreate(&e2));
-        HIPCHK(c, hipEventRecord(e0, c->stream));
-    }
+    if (c->profiling) HIPCHK(c, hipEventRecord(e0, c->stream));
     // small windows: register-tile kernel; wide windows: banded register-tile kernel; EXPECTED-only passes and
     // variant&2: LDS-tile kernel (needs the whole tile in LDS)
     const bool lds_kernel2 = m_exp || (c->variant & 2);
@@ -1213,23 +1188,6 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         hipLaunchKernelGGL(pup::pileup_rescale_kernel, dim3((unsigned)nblocks), dim3(rs_threads), rs_lds, c->stream, a,
                            (const int*)c->d_h.p, (const int*)c->d_w.p, (double*)nullptr, (double*)nullptr, 0LL);
         launched = true;
-    }
-    if (!launched && tiled && c->g_nblocks_t > 0) {
-        // the segments whose windows overlap enough go to the staged kernel, the rest to the plain one — side by
-        // side on a second stream
-        pup::K1Args at = a;
-        at.block_chunk = c->gv.block_chunk_t;
-        const bool side = nblocks > 0 && c->stream2 && c->ev_fork && c->ev_join;
-        if (side) {
-            HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-            launch_regtile(W, a, (int)nblocks, c->stream2);
-            HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
-        }
-        if (!launch_wgtiled(W, at, (int)c->g_nblocks_t, nw_q, paired ? 2 : 1, order.fact, c->stream))
-            return fail(c, PUP_ENOTSUP, "pup_accumulate: staged kernel not built for W=%d", W);
-        if (side) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-        if (side || nblocks == 0) launched = true;
     }
     const bool sparse_launch = !lds_kernel2 && !rescale && ignore_diags < 0 && W <= 63 && !(c->variant & 32) &&
                                pup::k1s_lds_bytes(W) <= (size_t)c->max_lds &&
@@ -1283,13 +1241,21 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     hipLaunchKernelGGL(pup::add_counts_kernel, dim3((unsigned)((c->T + 255) / 256)), dim3(256), 0, c->stream,
                        c->acc_i64.p + (size_t)c->T * W2, c->gv.dn, c->T);
     HIPCHK(c, hipGetLastError());
+    }   // !staged
+    else {
+        // windows per tile straight from the (tile, flip) boundaries the key kernel used
+        hipLaunchKernelGGL(pup::add_counts_from_ends_kernel, dim3((unsigned)((c->T + 255) / 256)), dim3(256), 0, c->stream,
+                           c->acc_i64.p + (size_t)c->T * W2, (const long long*)c->d_segend.p, c->T);
+        HIPCHK(c, hipGetLastError());
+    }
     if (c->nf_count > 0 && c->have_weight && !rescale && !(mode & PUP_MODE_EXPECTED)) {
         // take the pixels whose balanced value is inf / NaN out of `num` (see collect_nonfinite_kernel); the rescaled
         // path counts from the zoomed values themselves
         HIPCHK(c, c->nf_tp.reserve((size_t)(2 * T + 1)));
         HIPCHK(c, hipMemcpyAsync(c->nf_tp.p, tile_ptr, (size_t)(T + 1) * sizeof(long long), hipMemcpyHostToDevice, c->stream));
         if (flip_from) HIPCHK(c, hipMemcpyAsync(c->nf_tp.p + T + 1, flip_from, (size_t)T * sizeof(long long), hipMemcpyHostToDevice, c->stream));
-        pup::K1Args f = a;
+        pup::K1Args f{};
+        fill_k1_args(c, f, ignore_diags, mode);
         f.r0 = dr0; f.c0 = dc0;
         const long long threads = (long long)n * W;
         hipLaunchKernelGGL(pup::nonfinite_fix_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, f,
@@ -1300,7 +1266,8 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     }
     if (c->profiling) {
         HIPCHK(c, hipEventRecord(e2, c->stream));
-        c->pending.push_back({e0, e1, e2});
+        if (!staged) { (void)hipEventDestroy(ep); ep = nullptr; }
+        c->pending.push_back({e0, e1, e2, ep});
     }
     c->stats.snippets += n;
     return PUP_OK;
@@ -1502,13 +1469,31 @@ struct RcclApi {
     bool tried = false;
 };
 RcclApi g_rccl;
+// ONE ROCm stack per process: the RCCL to use is the one that sits beside the HIP runtime this library is running on
+// (torch ships its own libamdhip64 + librccl; the system ROCm has another pair).  Mixing them — a system librccl inside
+// a process whose libamdhip64 is torch's — corrupts the heap at exit (GPUTEST_r02: rc 134).  dladdr of a HIP entry point
+// names the runtime that is actually mapped; its directory is searched first, the bare sonames only after it.
+static std::string rccl_near_hip_runtime() {
+    Dl_info info;
+    if (!dladdr(reinterpret_cast<const void*>(&hipGetDeviceCount), &info) || !info.dli_fname) return "";
+    std::string dir(info.dli_fname);
+    const size_t slash = dir.rfind('/');
+    if (slash == std::string::npos) return "";
+    dir.resize(slash + 1);
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+        const std::string cand = dir + name;
+        if (FILE* f = std::fopen(cand.c_str(), "rb")) { std::fclose(f); return cand; }
+    }
+    return "";
+}
 static bool load_rccl() {
     if (g_rccl.tried) return g_rccl.AllReduce != nullptr;
     g_rccl.tried = true;
-    // the soname first: if the process already holds an RCCL (e.g. the copy bundled with torch) that one is reused
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"}) {
-        g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    const std::string near = rccl_near_hip_runtime();
+    if (!near.empty()) g_rccl.lib = dlopen(near.c_str(), RTLD_NOW | RTLD_GLOBAL);
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
         if (g_rccl.lib) break;
+        g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     }
     if (!g_rccl.lib) return false;
     g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(g_rccl.lib, "ncclAllReduce"));
@@ -1519,6 +1504,15 @@ static bool load_rccl() {
     return true;
 }
 }  // namespace
+
+int pup_rccl_path(char* buf, size_t cap) {
+    if (!buf || cap == 0) return PUP_EINVAL;
+    std::string path = rccl_near_hip_runtime();
+    if (path.empty()) path = "librccl.so.1";             // no copy beside the runtime: the loader's search path decides
+    if (path.size() + 1 > cap) return PUP_ERANGE;
+    std::memcpy(buf, path.c_str(), path.size() + 1);
+    return (int)path.size();
+}
 
 int pup_allreduce(pup_ctx* c, void* rccl_comm) {
     if (!c) return PUP_EINVAL;
@@ -1551,7 +1545,8 @@ int pup_get_stats(pup_ctx* c, pup_stats* out) {
     c->stats.pixels_in_windows = (int64_t)h[0];
     c->stats.probe_loads = (int64_t)h[1];
     c->stats.coverage_ms = c->last_coverage_ms;
-    c->stats.staged_regions = (int64_t)c->last_stagings;
+    // regions the last staged call piled up from: the count its prepass left in mapped memory (the stream is idle now)
+    c->stats.staged_regions = (c->last_staged && c->h_flags && c->h_flags[6] == c->hint_ticket) ? (int64_t)c->h_flags[4] : 0;
     *out = c->stats;
     return PUP_OK;
 }

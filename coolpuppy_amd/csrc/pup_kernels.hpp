@@ -7,7 +7,7 @@
 //                           expected, and add into a per-wave LDS tile (sum f64, num u32, cov f64).
 //                           The tile is written out once per chunk as a partial.
 //                           Two ways to find a row's pixels: (a) rank-bitmap index (one 64-B block holds
-//                           the absolute position of its first pixel + 448 presence bits: one cache line
+//                           the absolute position of its first pixel + 320 presence bits: one cache line
 //                           replaces a ~10-probe binary search, popcounts give every pixel's position),
 //                           built once per table for cis windows; (b) binary search, any window.
 // K2  reduce_partials_kernel deterministic segmented reduction of partial tiles (fixed order), used
@@ -101,11 +101,6 @@ struct K1Args {
     const int*       block_chunk;  // [gridDim.x] chunk executed by each workgroup (-1: none); groups are laid out
                                    //           so that workgroups b, b+8, b+16, ... (one XCD) share a group
     const int*       block_band;   // [gridDim.x] row band of the window the workgroup owns (banded kernel; else 0)
-    // block table of the workgroup-staged kernel (K1q): its chunks are ranges of BLOCKS, chunk_begin / chunk_end index here
-    const void*      blocks;       // [nblocks] BlockEntry: region origin, its windows, staging geometry (one 64-byte line each)
-    const unsigned short* win;     // K1q: the windows in block order, each as its corner inside its region: dr | dc << 6
-                                   //      (| slot << 12) — the value that rode the block sort; r0 / c0 are not read
-    int              rec_stride;   // K1q with two accumulator sets: partial record of (chunk, slot) = slot * rec_stride + chunk
     // per-chunk partial outputs
     double*   part_f64;   // [nrecords][W2 + 2W]   (sum | cov_start | cov_end)
     unsigned* part_num;   // [nrecords][W2]
@@ -689,644 +684,7 @@ __device__ __forceinline__ void lds_pin(double (&v)[N]) {     // later uses of v
     for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));
 }
 
-// ---- K1q: workgroup-staged register tile (many OVERLAPPING cis windows) -------------------------------------------
-// When a pile-up is large its windows OVERLAP: 1e7 control windows on a human 10 kb map put ~135 top-left corners
-// into every 44 x 44 block of the matrix.  K1r fetches every window on its own (index line + pixel values per row,
-// ~75 L2 lines per window).  K1q has the engine sort the snippets by BLOCK of corners on the device and build a
-// block table {R, C, first window, windows}; a workgroup of NW waves then walks a range of blocks and for each one
-// STAGES the 64 x 64 region of bins its windows live in ONCE into LDS, as final cell values: everything the
-// reference does to a cell depends on its absolute (row, col) only — balanced value, masked bins, ignored
-// diagonals, expected of |col-row| — so the staged cell already is what gets summed (0 where nothing is to be added)
-// and one validity bit per cell says whether it counts in num.  Per window a wave then does CH LDS reads + CH f64 adds
-// per lane instead of ~180 VALU instructions and 6 global loads.
-//   * block = (65-W) x (65-W) corners (W = 21: 44 x 44): every matrix cell is staged 2.1 times;
-//   * staging is wave64-shaped: a WAVE per region row, a LANE per region column.  The row's 64 presence bits are one
-//     slice of an index line; the pixels under them are contiguous in `bal`, lane l's being the mbcnt(bits, l)-th of
-//     the run: ONE coalesced value load per row, masks applied as 64-bit lane predicates, conflict-free LDS store;
-//   * staging is software-pipelined over the block table: while the windows of block b are piled up, the value loads
-//     of block b+1 and the index-line loads of block b+2 are in flight (registers), so a region costs its issue
-//     slots, not two memory round trips;
-//   * the block's windows are dealt out to the waves (window j to wave j % NW), each wave keeping K1r's register
-//     accumulators; the waves' tiles are merged in a fixed order at the end of the chunk (one partial per workgroup);
-//   * ACC = 2: the snippets of TWO tiles (the engine pairs tile t with tile t + T/2: ROI and control of one group) share
-//     the pass — a slot bit per window (bit 30 of c0 in the sorted copy) picks the accumulator set — so a sparse ROI
-//     tile rides on the regions its dense control tile stages anyway;
-//   * cells of a lane are INTERLEAVED: lane (p, k) owns columns k, k + NCH, k + 2 NCH, ... of window row p, and the
-//     region's row stride is LS = 64 + NCH doubles, so the 8-byte address of lane l in any of its reads is
-//     const + 64 p + l: the 32 lanes of an LDS lane group hit 32 different bank pairs — ds_read_b64 at its
-//     conflict-free rate of 256 B/clk for every window offset and width.
-// Only windows the rank-bitmap index covers (cis, inside one chromosome) are eligible — the engine checks all of them
-// before choosing this kernel.  Same integers as K1r; sums differ by the order of the f64 additions only.
-constexpr int kSlotBit = 30;                          // bit of c0 (sorted copy) holding the window's accumulator slot
-constexpr int kMaxSegCount = 1024;                    // segments (tile x flip runs) one block-ordered call may have
-// block table entry (one 64-byte line, fetched by the kernel with ONE vector load, a dword per lane): origin of the staged
-// region; its windows [start, start + count) in the sorted copy, the first count0 of which go to accumulator slot 0
-// (the sort is stable: a pair's first tile comes first); expected region; and everything the staging needs to know
-// about the region, worked out once by block_table_kernel instead of by dependent scalar loads in the hot loop: end of
-// the chromosome, index lines per matrix row, index line of (region row 0, region column 0), word / bit of that column
-// inside the line, unmasked-column bits (masked bins and the chromosome's end), masked-row bits.
-struct __attribute__((aligned(64))) BlockEntry {
-    int R, C, start, count, count0, ereg, ch_end, nblk;
-    unsigned line0, ws_sh;
-    unsigned long long colok, rowbad;
-    int pad0, pad1;
-};
-static_assert(sizeof(BlockEntry) == 64, "block table entry must be one 64-byte line");
-
-template <int W, bool OOE, int NW, int ACC, bool FACT, bool EXTRA>
-__global__ __launch_bounds__(kWave * NW, (NW == 4 && FACT && !EXTRA && !OOE && W <= 21 ? 4 : 1)) void pileup_wgtile_kernel(K1Args a) {
-    static_assert(W >= 3 && W <= 31, "workgroup-staged kernel serves windows of 3..31 bins");
-    static_assert(!(FACT && OOE), "factorised counting needs validity to factorise into row and column masks");
-    static_assert(NW == 4 || NW == 8 || NW == 16, "the region's 64 rows are dealt out evenly to the waves");
-    static_assert(ACC == 1 || ACC == 2, "one or two accumulator sets");
-    constexpr int NCH = kWave / W;
-    constexpr int CH  = (W + NCH - 1) / NCH;
-    constexpr int W2  = W * W;
-    constexpr int RS  = 64;                              // staged region: RS x RS bins
-    constexpr int LS  = RS + ((NCH % 32) ? (NCH % 32) : 32);   // row stride, LS % 32 == NCH % 32 (see above)
-    constexpr int RPW = RS / NW;                         // region rows staged by each wave
-    constexpr int NTHR = kWave * NW;
-    static_assert(RS == kWave, "one lane per region column");
-    static_assert((size_t)W2 * 12 <= (size_t)RS * LS * 8, "merge scratch must fit the region buffer");
-    __shared__ double tile[RS * LS];
-    __shared__ unsigned long long vbits[RS];             // bit c: cell (row, c) counts in num
-    __shared__ unsigned long long pbits[RS];             // bit c: cell holds a pixel (statistics only)
-    __shared__ double cov_lds[NW][ACC][2 * W];
-    // FACT: num[p][q] = N - R[p] - C[q] + RC[p][q] (see fact_batch): the sparse both-masked pairs, and the totals
-    __shared__ unsigned rc_lds[ACC][FACT ? W2 : 1];
-    __shared__ unsigned fact_tot[FACT ? ACC * (2 * W + 1) : 1];     // per slot: R[W] | C[W] | N
-    const int tid  = threadIdx.x;
-    const int lane = tid & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int p_raw = lane / NCH;
-    const int k  = lane - p_raw * NCH;
-    const bool row_ok = p_raw < W;
-    const int p  = row_ok ? p_raw : W - 1;               // idle lanes shadow the last row, flush nothing
-    unsigned chmask = 0u;                                // bit i: the lane owns window cell (p, k + NCH * i)
-#pragma unroll
-    for (int i = 0; i < CH; ++i) if (row_ok && k + NCH * i < W) chmask |= 1u << i;
-
-    const bool m_cov   = EXTRA && (a.mode & 0x04u) && a.cov != nullptr;
-    const bool use_exp = OOE && ((a.expv != nullptr && a.nexp > 0) || a.n_exp_regions > 0);
-    const int  igd     = a.ignore_diags;
-    const bool stats   = EXTRA && a.counters != nullptr;
-    const double qnan = __builtin_nan("");
-
-    const int ck = a.block_chunk[blockIdx.x];
-    if (ck < 0) return;                                  // padding workgroup (uniform)
-    double   sum[ACC][CH];
-    unsigned num[ACC][CH];
-#pragma unroll
-    for (int s = 0; s < ACC; ++s)
-#pragma unroll
-        for (int i = 0; i < CH; ++i) { sum[s][i] = 0.0; num[s][i] = 0u; }
-    if (m_cov) for (int t = lane; t < ACC * 2 * W; t += kWave) (&cov_lds[wave][0][0])[t] = 0.0;
-    if constexpr (FACT) {                                // visible after the prologue's barrier
-        for (int t = tid; t < ACC * W2; t += NTHR) (&rc_lds[0][0])[t] = 0u;
-        for (int t = tid; t < ACC * (2 * W + 1); t += NTHR) fact_tot[t] = 0u;
-    }
-
-    const int bb = (int)a.chunk_begin[ck], be = (int)a.chunk_end[ck];     // blocks [bb, be) of the block table
-    const int fl = a.chunk_flip[ck];
-    const BlockEntry* __restrict__ blocks = reinterpret_cast<const BlockEntry*>(a.blocks);
-    unsigned long long npix = 0;
-
-    // ---- staging, in pieces (see the pipeline in the block loop) ----------------------------------------------------
-    struct Geo { int R, C, start, count, count0, ereg, ch_end, ws, sh, nblk; unsigned long long colok, rowbad, colbad;
-                 const IdxBlock* line0; };
-    struct Raw { U64x2 h, w; unsigned long long rw; };                     // lane i < RPW: index words of the wave's i-th row
-    struct Row { unsigned long long bits, keep, okn; long long pos; };     // lane i < RPW: what they amount to
-    // entry of block b: dword (lane & 15) of its 64-byte line — a vector load, so that it can stay in flight across the
-    // window loop (whose LDS waits would otherwise drain a scalar load with them)
-    auto entry_load = [&](int b) __attribute__((always_inline)) -> int {
-        return reinterpret_cast<const int*>(blocks + b)[lane & 15];
-    };
-    auto geo_from = [&](int ev) __attribute__((always_inline)) -> Geo {
-        auto f = [&](int i) __attribute__((always_inline)) { return __builtin_amdgcn_readlane(ev, i); };
-        Geo g;
-        g.R = f(0); g.C = f(1); g.start = f(2); g.count = f(3); g.count0 = f(4); g.ereg = f(5); g.ch_end = f(6); g.nblk = f(7);
-        const unsigned wsh = (unsigned)f(9);
-        g.ws = (int)(wsh & 0xffu); g.sh = (int)(wsh >> 8);
-        g.line0 = a.idx + (unsigned)f(8);
-        g.colok = ((unsigned long long)(unsigned)f(11) << 32) | (unsigned)f(10);
-        g.rowbad = ((unsigned long long)(unsigned)f(13) << 32) | (unsigned)f(12);
-        g.colbad = ~g.colok;                             // (also set past the chromosome's end: no eligible window reaches there)
-        return g;
-    };
-    const int my_rr = wave * RPW + (lane < RPW ? lane : 0);               // region row this lane looks up in phase A
-    auto load_raw = [&](const Geo& g, Raw& x) __attribute__((always_inline)) {
-        x.h.a = 0ull; x.h.b = 0ull; x.w.a = 0ull; x.w.b = 0ull; x.rw = ~0ull;
-        const int row = g.R + my_rr;
-        if (lane < RPW && row < g.ch_end) {
-            const char* line = reinterpret_cast<const char*>(g.line0 + (long long)my_rr * g.nblk);
-            x.h = *reinterpret_cast<const U64x2*>(line);                       // {pos, cum[4]}
-            x.w = *reinterpret_cast<const U64x2*>(line + 16 + 8 * g.ws);       // {bits[ws], bits[ws+1] | next0}
-            if (!FACT) x.rw = a.badbits[row >> 6];
-        }
-    };
-    auto finish_rows = [&](const Geo& g, const Raw& x) __attribute__((always_inline)) -> Row {
-        Row r;
-        const int row = g.R + my_rr;
-        const bool live = lane < RPW && row < g.ch_end;
-        r.bits = x.w.a >> g.sh;
-        if (g.sh) r.bits |= x.w.b << (64 - g.sh);
-        const unsigned cum = g.ws ? (unsigned)(x.h.b >> ((g.ws - 1) * 16)) & 0xffffu : 0u;
-        r.pos = (long long)(x.h.a + cum + (unsigned long long)__popcll(x.w.a & ((1ull << g.sh) - 1ull)));
-        unsigned long long ok = ((x.rw >> (row & 63)) & 1ull) ? 0ull : g.colok;
-        if (igd >= 0) {
-            const int t0 = igd - (g.C - row);           // column C + l is on or above the first kept diagonal iff l >= t0
-            ok &= t0 <= 0 ? ~0ull : (t0 >= 64 ? 0ull : ~((1ull << t0) - 1ull));
-        }
-        if (!live) { r.bits = 0ull; ok = 0ull; r.pos = 0; }
-        // FACT: every window of the call is clear of the diagonal mask and `bal` is 0 on masked bins: a cell holds its
-        // pixel's value or 0, no mask needed; validity is counted from the row / column masks instead
-        r.okn = ok; r.keep = FACT ? r.bits : (r.bits & ok);
-        return r;
-    };
-    auto bcast64 = [&](unsigned long long v, int i) __attribute__((always_inline)) -> unsigned long long {
-        const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, i), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), i);
-        return ((unsigned long long)hi << 32) | lo;
-    };
-    auto issue_values = [&](const Row& r, double (&v)[RPW]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const unsigned long long bits = bcast64(r.bits, i);
-            const long long pos = (long long)bcast64((unsigned long long)r.pos, i);
-            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bits >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bits, 0u));
-            v[i] = a.bal[pos + rank];                    // bal is padded: a lane without a pixel reads a neighbour, discarded
-        }
-    };
-    auto exp_of = [&](const Geo& g) -> ExpSel {
-        ExpSel es; es.base = a.expv; es.len = 0; es.scalar = qnan; es.is_scalar = true;
-        if (!use_exp) return es;
-        if (a.n_exp_regions <= 0) {
-            es.len = a.nexp; es.is_scalar = (a.nexp == 1);
-            es.scalar = (a.nexp == 1 && a.expv) ? a.expv[0] : qnan;
-            if (!a.expv || a.nexp <= 0) { es.is_scalar = true; es.scalar = qnan; }
-            return es;
-        }
-        const int er = g.ereg;                           // expected region of the block's windows (part of the sort key)
-        es.is_scalar = false;
-        if (er >= 0 && er < a.n_exp_regions) { const ExpRegion g = a.exp_regions[er]; es.base = a.expv + g.off; es.len = g.len; }
-        return es;
-    };
-    auto store_region = [&](const Geo& g, Row& r, const double (&v)[RPW], const ExpSel& es) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const int rr = wave * RPW + i;
-            const bool keep = __builtin_amdgcn_inverse_ballot_w64(bcast64(r.keep, i));
-            double val = v[i];
-            bool good = keep;
-            if (OOE) {
-                const int row = g.R + rr;
-                long long ad = (long long)(g.C + lane) - row; if (ad < 0) ad = -ad;
-                const double e = use_exp ? es.at(ad) : qnan;
-                val = val / e;
-                good = keep && (val == val);            // NaN quotients are skipped, inf is kept
-                // usable expected = neither NaN nor zero.  The predicate goes through a register the compiler cannot see
-                // through: hipcc (ROCm 7.2) folds __ballot(e == e && e != 0.0) — and the equivalent v_cmp_class test —
-                // into v_cmp_neq_f64, the UNORDERED not-equal, which lets NaN pass
-                int e_ok = (e == e && e != 0.0) ? 1 : 0;
-                asm volatile("" : "+v"(e_ok));
-                const unsigned long long eok = __ballot(e_ok);
-                if (lane == i) r.okn &= eok;
-            }
-            tile[rr * LS + lane] = good ? val : 0.0;
-        }
-        if (lane < RPW) { if (!FACT) vbits[wave * RPW + lane] = r.okn; if (stats) pbits[wave * RPW + lane] = r.bits; }
-    };
-
-    // ---- the windows of the staged block ---------------------------------------------------------------------------
-    // Per batch of 64 windows (one per lane, every wave holds the same batch) the LDS byte offset of each window's
-    // corner is worked out once, in vector form; per window a wave then needs one readlane, one address add, CH LDS
-    // reads and CH f64 adds (+ the validity bits, or nothing at all when validity factorises).
-    const unsigned lane_off8 = (unsigned)(uintptr_t)tile + 8u * (unsigned)(p * LS + k);   // LDS byte address of the lane's first cell
-    const unsigned vb_lane8 = (unsigned)(uintptr_t)vbits + 8u * (unsigned)p;               // ... of the validity word of its row
-    // windows [j0, j1) of the batch, all of accumulator slot S; window j goes to wave (j - j0) % NW
-    auto run = [&](auto slot_tag, const Geo& g, int offv, int drv, int dcv, int j0, int j1) __attribute__((always_inline)) {
-        constexpr int S = decltype(slot_tag)::value;
-        // validity word of the window's row p: read like the cells (lds_read_b64), shifted to the lane's first column
-        // once the data is there (`bits_of`)
-        auto gather = [&](int jj, double (&v)[CH], double& vraw, unsigned& ad0, unsigned& ad1) __attribute__((always_inline)) {
-            // single ds_read_b64 each (see lds_read_b64); cells the lane does not own read padding, never flushed
-            ad0 = lane_off8 + (unsigned)__builtin_amdgcn_readlane(offv, jj);
-            LdsReadRow<0, CH, 8 * NCH>::go(v, ad0);
-            vraw = 0.0; ad1 = ad0;
-            if (!FACT) { ad1 = vb_lane8 + 8u * (unsigned)__builtin_amdgcn_readlane(drv, jj); lds_read_b64<0>(vraw, ad1); }
-        };
-        auto bits_of = [&](int jj, double vraw) __attribute__((always_inline)) -> unsigned {
-            if (FACT) return 0u;
-            return (unsigned)((unsigned long long)__double_as_longlong(vraw) >> (__builtin_amdgcn_readlane(dcv, jj) + k));
-        };
-        auto extra = [&](int jj) __attribute__((always_inline)) {          // coverage vectors, pixel statistics
-            const int dr = __builtin_amdgcn_readlane(drv, jj), dc = __builtin_amdgcn_readlane(dcv, jj);
-            if (m_cov && row_ok && k == 0) {
-                const double vs = a.cov[g.R + dr + p], ve = a.cov[g.C + dc + p];
-                if (vs == vs) cov_lds[wave][S][p] += vs;
-                if (ve == ve) cov_lds[wave][S][W + p] += ve;
-            }
-            if (stats) {
-                const unsigned pw = (unsigned)(pbits[dr + p] >> (dc + k));
-                unsigned m = 0u;
-#pragma unroll
-                for (int i = 0; i < CH; ++i) if ((chmask >> i) & 1u) m += (pw >> (NCH * i)) & 1u;
-                npix += m;
-            }
-        };
-        auto add = [&](const double (&v)[CH], unsigned vw) __attribute__((always_inline)) {
-#pragma unroll
-            for (int i = 0; i < CH; ++i) { sum[S][i] += v[i]; if (!FACT) num[S][i] += (vw >> (NCH * i)) & 1u; }
-        };
-        int jj = j0 + wave;
-        for (; jj + NW < j1; jj += 2 * NW) {              // two windows in flight: both gathered before either is added
-            double va[CH], vb[CH], wa, wb; unsigned a0, a1, a2, a3;
-            gather(jj, va, wa, a0, a1);
-            gather(jj + NW, vb, wb, a2, a3);
-            lds_wait_all(a0, a1, a2, a3); lds_pin(va); lds_pin(vb);
-            if constexpr (!FACT) { lds_pin1(wa); lds_pin1(wb); }     // (FACT: no validity word was read — pinning would materialise a zero)
-            add(va, bits_of(jj, wa));
-            add(vb, bits_of(jj + NW, wb));
-            if (EXTRA) { extra(jj); extra(jj + NW); }
-        }
-        if (jj < j1) {
-            double va[CH], wa; unsigned a0, a1;
-            gather(jj, va, wa, a0, a1);
-            lds_wait_all(a0, a1, a0, a1); lds_pin(va);
-            if constexpr (!FACT) lds_pin1(wa);
-            add(va, bits_of(jj, wa));
-            if (EXTRA) extra(jj);
-        }
-    };
-    // FACT bookkeeping of one batch, by ONE wave, a lane per window: validity of cell (p, q) of a window factorises (no
-    // diagonal mask reaches it): valid = !rowbad[p] & !colbad[q], so over the chunk num[p][q] = N - R[p] - C[q] + RC[p][q].
-    // fact_tot[slot] = {R[W], C[W], N}; rc_lds[slot] = RC (masked row meets masked column: rare).  Integer LDS atomics:
-    // exact and order-independent.
-    auto fact_batch = [&](const Geo& g, int drv, int dcv, int nb, int split) __attribute__((always_inline)) {
-      if constexpr (FACT) {
-        constexpr unsigned WMASK = (1u << W) - 1u;
-        const bool live = lane < nb;
-        const int slot = (ACC == 2 && lane >= split) ? 1 : 0;
-        unsigned rb = live ? (unsigned)(g.rowbad >> (drv & 63)) & WMASK : 0u;
-        const unsigned cbm = live ? (unsigned)(g.colbad >> (dcv & 63)) & WMASK : 0u;
-        const int tb = slot * (2 * W + 1);
-        const unsigned long long lv = __ballot(live && slot == 0);
-        if (lane == 0) {
-            atomicAdd(&fact_tot[2 * W], (unsigned)__popcll(lv));
-            if constexpr (ACC == 2) atomicAdd(&fact_tot[(2 * W + 1) + 2 * W], (unsigned)(nb - __popcll(lv)));
-        }
-        unsigned cc = cbm;
-        while (cc) { const int q = __ffs((int)cc) - 1; cc &= cc - 1u; atomicAdd(&fact_tot[tb + W + q], 1u); }
-        while (rb) {
-            const int pp = __ffs((int)rb) - 1; rb &= rb - 1u;
-            atomicAdd(&fact_tot[tb + pp], 1u);
-            unsigned c2 = cbm;
-            while (c2) { const int q = __ffs((int)c2) - 1; c2 &= c2 - 1u; atomicAdd(&rc_lds[slot][pp * W + q], 1u); }
-        }
-      }
-    };
-    // the windows [g.start, g.start + g.count) of the staged block; wf = the first 64 of them, one per lane, each as its
-    // corner inside the region (dr | dc << 6, the value the block sort carried)
-    auto windows = [&](const Geo& g, int wf) __attribute__((always_inline)) {
-        int batch = 0;
-        for (int s0 = 0; s0 < g.count; s0 += kWave, ++batch) {
-            const int drv = wf & 63, dcv = (wf >> 6) & 63;
-            const int offv = 8 * (drv * LS + dcv);
-            if (s0 + kWave < g.count) {                   // next batch of this block
-                const int sn = s0 + kWave + lane;
-                wf = sn < g.count ? (int)a.win[g.start + sn] : 0;
-            }
-            const int nb = (g.count - s0) < kWave ? (g.count - s0) : kWave;
-            int split = g.count0 - s0;                    // windows of the batch before `split` belong to slot 0
-            split = split < 0 ? 0 : (split > nb ? nb : split);
-            if (FACT && (batch % NW) == wave) fact_batch(g, drv, dcv, nb, split);
-            if (ACC == 2) {
-                run(std::integral_constant<int, 0>{}, g, offv, drv, dcv, 0, split);
-                run(std::integral_constant<int, ACC - 1>{}, g, offv, drv, dcv, split, nb);
-            } else run(std::integral_constant<int, 0>{}, g, offv, drv, dcv, 0, nb);
-        }
-    };
-    auto first_coords = [&](const Geo& g, int& wf) __attribute__((always_inline)) {
-        wf = lane < g.count ? (int)a.win[g.start + lane] : 0;
-    };
-
-    // ---- the block loop: region b is piled up while b+1's values, b+2's index lines and b+3's table entry are on their way
-    if (bb < be) {
-        int ev = entry_load(bb);                         // entries are consumed one stage after their load was issued
-        Geo g0 = geo_from(ev), g1 = g0, g2 = g0;
-        Raw x1, x2;
-        Row rw0, rw1;
-        double v[RPW];
-        int w0f, w1f = 0;
-        {   // prologue: stage block bb without overlap, start the lookups of bb+1
-            Raw x0;
-            load_raw(g0, x0);
-            first_coords(g0, w0f);
-            if (bb + 1 < be) { g1 = geo_from(entry_load(bb + 1)); load_raw(g1, x1); }
-            if (bb + 2 < be) ev = entry_load(bb + 2);
-            rw0 = finish_rows(g0, x0);
-            issue_values(rw0, v);
-            const ExpSel es0 = exp_of(g0);
-            __syncthreads();
-            store_region(g0, rw0, v, es0);
-            __syncthreads();
-            if (bb + 1 < be) rw1 = finish_rows(g1, x1);
-        }
-        for (int b = bb; b < be; ++b) {
-            const bool has1 = b + 1 < be, has2 = b + 2 < be;
-            if (has1) { issue_values(rw1, v); first_coords(g1, w1f); }
-            if (has2) { g2 = geo_from(ev); load_raw(g2, x2); if (b + 3 < be) ev = entry_load(b + 3); }
-            windows(g0, w0f);
-            if (!has1) break;
-            const ExpSel es1 = exp_of(g1);
-            __syncthreads();                             // every wave is done reading region b
-            store_region(g1, rw1, v, es1);
-            __syncthreads();
-            g0 = g1; w0f = w1f;
-            if (has2) { g1 = g2; rw1 = finish_rows(g2, x2); }
-        }
-    }
-
-    // ---- merge the waves' register tiles in wave order (fixed summation order): one partial per slot and workgroup ----
-    const size_t L = (size_t)W2 + 2 * (size_t)W;
-    double*   mf = tile;
-    unsigned* mn = reinterpret_cast<unsigned*>(tile + W2);
-#pragma unroll
-    for (int s = 0; s < ACC; ++s) {
-        __syncthreads();
-        for (int w = 0; w < NW; ++w) {
-            if (wave == w) {
-#pragma unroll
-                for (int i = 0; i < CH; ++i) {
-                    if ((chmask >> i) & 1u) {
-                        const int cell = map_cell(p, k + NCH * i, W, false, fl);
-                        if (w == 0) { mf[cell] = sum[s][i]; mn[cell] = num[s][i]; }
-                        else        { mf[cell] += sum[s][i]; mn[cell] += num[s][i]; }
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        const size_t rec = (size_t)s * (size_t)a.rec_stride + (size_t)ck;
-        double*   of = a.part_f64 + rec * L;
-        unsigned* on = a.part_num + rec * W2;
-        if constexpr (FACT) {
-            // num of every cell from the factorised counts, in the accumulator frame
-            const unsigned* tot = fact_tot + s * (2 * W + 1);
-            for (int t = tid; t < W2; t += NTHR) {
-                const int pp = t / W, qq = t - pp * W;
-                mn[map_cell(pp, qq, W, false, fl)] = tot[2 * W] - tot[pp] - tot[W + qq] + rc_lds[s][t];
-            }
-            __syncthreads();
-        }
-        for (int t = tid; t < W2; t += NTHR) { of[t] = mf[t]; on[t] = mn[t]; }
-        for (int t = tid; t < 2 * W; t += NTHR) {
-            double acc = 0.0;
-            if (m_cov) for (int w = 0; w < NW; ++w) acc += cov_lds[w][s][t];
-            of[W2 + t] = acc;
-        }
-    }
-    if (stats) {
-        for (int off = 32; off > 0; off >>= 1) npix += __shfl_down(npix, off);
-        if (lane == 0) atomicAdd(&a.counters[0], npix);
-    }
-}
-
-// ---- block-order prepass of K1q ------------------------------------------------------------------------------------
-// key of a snippet: (segment, expected region, block row, block col).  Segment = the (tile pair | tile, flip) run the
-// snippet is piled up with; `pair_half` = T/2 when tile t shares its pass with tile t + T/2 (then slot = t / (T/2) goes
-// into bit 31 of the value), 0 when every tile has its own pass.  Also checks that the window is one the rank-bitmap
-// index covers (cis, inside one chromosome) and counts the ineligible ones.
-template <typename KeyT, int SIDE /* block side when known at compile time (division by a constant), else 0 */>
-__global__ __launch_bounds__(256) void block_key_kernel(const int* __restrict__ r0, const int* __restrict__ c0, long long n,
-                                                        const long long* __restrict__ seg_end, int nseg2t, int pair_half,
-                                                        const IdxChrom* __restrict__ chroms, int n_chrom,
-                                                        const unsigned short* __restrict__ bin_chrom, long long nbins,
-                                                        const int* __restrict__ brow_base /* [n_chrom] block rows before the chromosome */,
-                                                        const ExpRegion* __restrict__ eregs, int n_eregs,
-                                                        int W, int BR, int BC, int sh_br, int sh_er, int sh_seg,
-                                                        int seg_shift /* 1: no flipped windows, the flip bit is left out */,
-                                                        int dc_mode /* block column stored relative to the block row */,
-                                                        int clear_gap /* igd + W - 1 */,
-                                                        KeyT* __restrict__ keys, unsigned short* __restrict__ vals,
-                                                        unsigned* __restrict__ counters /* [0] ineligible */,
-                                                        unsigned* __restrict__ n_unclear /* windows a diagonal mask reaches */,
-                                                        unsigned* __restrict__ n_dc_over /* relative columns that do not fit */) {
-    // small tables go to LDS once per workgroup: per window the chain of dependent global loads is r0 -> bin_chrom only
-    constexpr int kMaxChrom = 512, kPer = 4;
-    __shared__ int s_cs[kMaxChrom], s_ce[kMaxChrom], s_bb[kMaxChrom];
-    __shared__ long long s_seg[2 * kMaxSegCount];
-    const bool in_lds = n_chrom <= kMaxChrom;
-    if (in_lds) for (int k = threadIdx.x; k < n_chrom; k += blockDim.x) { s_cs[k] = chroms[k].start; s_ce[k] = chroms[k].end; s_bb[k] = brow_base[k]; }
-    for (int k = threadIdx.x; k < nseg2t; k += blockDim.x) s_seg[k] = seg_end[k];
-    __syncthreads();
-    unsigned bad = 0u, dc_over = 0u;
-    for (int u = 0; u < kPer; ++u) {
-        const long long i = ((long long)blockIdx.x * kPer + u) * blockDim.x + threadIdx.x;
-        const bool live = i < n;
-        const int r = live ? r0[i] : 0, c = live ? c0[i] : 0;
-        int lo = 0, hi = nseg2t;
-        while (lo < hi) { const int m = (lo + hi) >> 1; if (s_seg[m] <= i) lo = m + 1; else hi = m; }
-        const int t = lo >> 1, f = lo & 1;                   // tile, flip state of the snippet
-        unsigned seg = (unsigned)lo, slot = 0u;
-        if (pair_half > 0) { slot = (unsigned)(t / pair_half); seg = (unsigned)((t % pair_half) * 2 + f); }
-        bool ok = r >= 0 && c >= 0 && (long long)r < nbins;
-        unsigned long long br = 0, bc = 0, er = 0;
-        unsigned inside = 0u;                                // the window's corner inside its block: all the staged kernel needs
-        if (ok) {
-            const int ca = bin_chrom[r];
-            const int cs = in_lds ? s_cs[ca] : chroms[ca].start, ce = in_lds ? s_ce[ca] : chroms[ca].end;
-            ok = r >= cs && r + W <= ce && c >= cs && c + W <= ce;
-            if (ok) {
-                constexpr int kSide = SIDE ? SIDE : 1;              // (a zero divisor must not even be spelled)
-                const int qr = SIDE ? (r - cs) / kSide : (r - cs) / BR, qc = SIDE ? (c - cs) / kSide : (c - cs) / BC;
-                br = (unsigned long long)((in_lds ? s_bb[ca] : brow_base[ca]) + qr);     // increasing over the genome, compact
-                bc = (unsigned long long)qc;
-                if (dc_mode) {
-                    // windows sit near the diagonal: the block column relative to the block row (+1: a window may start
-                    // a little left of it) needs far fewer bits than the absolute one — fewer radix passes
-                    const int dcv = qc - qr + 1;
-                    if (dcv < 0 || dcv >= (1 << sh_br)) { ++dc_over; bc = 0; } else bc = (unsigned long long)dcv;
-                }
-                inside = (unsigned)((r - cs) - qr * (SIDE ? SIDE : BR)) | ((unsigned)((c - cs) - qc * (SIDE ? SIDE : BC)) << 6);
-            }
-        }
-        if (n_eregs > 0) {                                   // the region whose expected the snippet divides by (that of its first row)
-            const int e = find_exp_region(eregs, n_eregs, r);
-            er = (unsigned long long)(e < 0 ? n_eregs : e);
-        }
-        if (live && !ok) ++bad;
-        {   // one atomic per wave, not per window (a call of near-diagonal windows would serialise on the counter)
-            const unsigned long long near = __ballot(live && c - r < clear_gap);
-            if (near != 0ull && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)near) - 1)) atomicAdd(n_unclear, (unsigned)__popcll(near));
-        }
-        if (!live) continue;
-        // (walking block rows in pairs — (2k, c), (2k+1, c), (2k, c+1) — so that the row halo is re-read from L2 was
-        // measured: no gain; the column halo of consecutive blocks of one row is already served by L2)
-        keys[i] = (KeyT)(((unsigned long long)(seg >> seg_shift) << sh_seg) | (er << sh_er) | (br << sh_br) | bc);
-        // the value that rides the sort is the window itself as the staged kernel wants it (the sort is stable, so windows
-        // of a block keep the caller's order): no index to gather through afterwards
-        vals[i] = (unsigned short)(inside | (slot << 12));
-    }
-    if (bad) atomicAdd(&counters[0], bad);
-    if (dc_over) atomicAdd(n_dc_over, dc_over);
-}
-
-// the windows that start a block (key differs from the previous one), counted per span of kSpan windows —
-// block_starts_kernel turns the counts into the ordered list
-constexpr int kSpan = 4096;
-template <typename KeyT>
-__global__ __launch_bounds__(256) void count_heads_kernel(const KeyT* __restrict__ sorted_keys, long long n,
-                                                          unsigned* __restrict__ span_heads) {
-    __shared__ unsigned red[4];
-    const long long i0 = (long long)blockIdx.x * kSpan;                 // one workgroup per span
-    unsigned cnt = 0;
-#pragma unroll 4
-    for (int t = threadIdx.x; t < kSpan; t += 256) {
-        const long long i = i0 + t;
-        if (i < n && (i == 0 || sorted_keys[i] != sorted_keys[i - 1])) ++cnt;
-    }
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) span_heads[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-}
-
-// block origin from a key: (br, bc) -> (R, C); the compact block-row numbering is undone through brow_base
-__device__ __forceinline__ void block_origin(unsigned long long key, int sh_br, int sh_er, int dc_mode,
-                                             const int* __restrict__ brow_base,
-                                             const IdxChrom* __restrict__ chroms, int n_chrom, int BR, int BC,
-                                             int& R, int& C, int& ca_out) {
-    const int br = (int)((key >> sh_br) & ((1ull << (sh_er - sh_br)) - 1ull));
-    int bc = (int)(key & ((1ull << sh_br) - 1ull));
-    int lo = 0, hi = n_chrom;                              // last chromosome whose first block row is <= br
-    while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (brow_base[m] <= br) lo = m; else hi = m; }
-    const int cs = chroms[lo].start;
-    if (dc_mode) bc += (br - brow_base[lo]) - 1;           // stored relative to the block row (block_key_kernel)
-    R = cs + (br - brow_base[lo]) * BR;
-    C = cs + bc * BC;
-    ca_out = lo;
-}
-
-// (r0, c0) of every window in block order, rebuilt from key + value (streaming: no gather) — only for calls that leave
-// some segments to the per-window kernels, which want position-sorted coordinates
-template <typename KeyT>
-__global__ __launch_bounds__(256) void rebuild_coords_kernel(const KeyT* __restrict__ sorted_keys, const unsigned short* __restrict__ win,
-                                                             long long n, int sh_br, int sh_er, int dc_mode, const int* __restrict__ brow_base,
-                                                             const IdxChrom* __restrict__ chroms, int n_chrom, int BR, int BC,
-                                                             int* __restrict__ r0s, int* __restrict__ c0s) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int R, C, ca;
-    block_origin((unsigned long long)sorted_keys[i], sh_br, sh_er, dc_mode, brow_base, chroms, n_chrom, BR, BC, R, C, ca);
-    const unsigned w = win[i];
-    r0s[i] = R + (int)(w & 63u);
-    c0s[i] = C + (int)((w >> 6) & 63u);
-}
-
-// ordered list of block starts: workgroup g owns windows [g*kSpan, (g+1)*kSpan); its output offset is the number of
-// heads in the spans before it (a few thousand counters: summed by the workgroup itself, no separate scan pass)
-template <typename KeyT>
-__global__ __launch_bounds__(256) void block_starts_kernel(const KeyT* __restrict__ sorted_keys, long long n,
-                                                           const unsigned* __restrict__ span_heads,
-                                                           unsigned* __restrict__ starts) {
-    __shared__ unsigned red[4];
-    __shared__ unsigned wave_cnt[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned part = 0;
-    for (int k = threadIdx.x; k < (int)blockIdx.x; k += blockDim.x) part += span_heads[k];
-    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off);
-    if (lane == 0) red[wave] = part;
-    __syncthreads();
-    unsigned base = red[0] + red[1] + red[2] + red[3];
-    if (span_heads[blockIdx.x] == 0) return;               // (uniform) nothing starts in this span
-    const long long i0 = (long long)blockIdx.x * kSpan;
-    for (int t = 0; t < kSpan; t += 256) {
-        const long long i = i0 + t + threadIdx.x;
-        const bool head = i < n && (i == 0 || sorted_keys[i] != sorted_keys[i - 1]);
-        const unsigned long long m = __ballot(head);
-        __syncthreads();                                   // wave_cnt of the previous round has been read
-        if (lane == 0) wave_cnt[wave] = (unsigned)__popcll(m);
-        __syncthreads();
-        unsigned before = 0;
-        for (int w = 0; w < wave; ++w) before += wave_cnt[w];
-        if (head) starts[base + before + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (unsigned)i;
-        base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-    }
-}
-
-// first block of every segment: seg_blk0[s] = number of block starts before the segment's first window (the segments'
-// window ranges in sorted order are known on the host: seg_win0[0..nseg]); one thread per segment boundary
-__global__ __launch_bounds__(256) void segment_blocks_kernel(const unsigned* __restrict__ starts, const unsigned* __restrict__ span_heads,
-                                                             int n_spans, unsigned* __restrict__ n_runs,
-                                                             const long long* __restrict__ seg_win0, int nseg,
-                                                             unsigned* __restrict__ seg_blk0) {
-    __shared__ unsigned red[4];
-    unsigned part = 0;
-    for (int k = threadIdx.x; k < n_spans; k += blockDim.x) part += span_heads[k];
-    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
-    __syncthreads();
-    const unsigned nr = red[0] + red[1] + red[2] + red[3];
-    if (threadIdx.x == 0) n_runs[0] = nr;
-    for (int s = threadIdx.x; s <= nseg; s += blockDim.x) {
-        const long long w0 = seg_win0[s];
-        unsigned lo = 0, hi = nr;
-        while (lo < hi) { const unsigned m = (lo + hi) >> 1; if ((long long)starts[m] < w0) lo = m + 1; else hi = m; }
-        seg_blk0[s] = lo;
-    }
-}
-
-// block table from the compacted block starts: entry b = region origin R, C, first window, windows, slot-0 windows,
-// expected region of the block's windows (decoded from the key) and the staging geometry of the region (see BlockEntry)
-template <typename KeyT>
-__global__ __launch_bounds__(256) void block_table_kernel(const unsigned* __restrict__ starts, const unsigned* __restrict__ n_runs,
-                                                          long long n, const KeyT* __restrict__ sorted_keys,
-                                                          const unsigned short* __restrict__ win, const int* __restrict__ brow_base,
-                                                          const IdxChrom* __restrict__ chroms, int n_chrom, int BR, int BC,
-                                                          int sh_br, int sh_er, int sh_seg, int dc_mode, int n_eregs,
-                                                          const unsigned long long* __restrict__ badbits,
-                                                          BlockEntry* __restrict__ blocks) {
-    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long nr = (long long)n_runs[0];
-    if (b >= nr) return;
-    const unsigned s = starts[b];
-    const long long e = (b + 1 < nr) ? (long long)starts[b + 1] : n;
-    BlockEntry be;
-    int ca;
-    block_origin((unsigned long long)sorted_keys[s], sh_br, sh_er, dc_mode, brow_base, chroms, n_chrom, BR, BC, be.R, be.C, ca);
-    const IdxChrom ch = chroms[ca];
-    const int cs = ch.start;
-    be.start = (int)s; be.count = (int)(e - (long long)s);
-    {   // slot-0 windows come first inside a block (stable sort): find the first window with the slot bit set
-        long long lo = (long long)s, hi = e;
-        while (lo < hi) { const long long m = (lo + hi) >> 1; if (((win[m] >> 12) & 1u) == 0u) lo = m + 1; else hi = m; }
-        be.count0 = (int)(lo - (long long)s);
-    }
-    be.ereg = -1; be.pad0 = 0; be.pad1 = 0;
-    if (n_eregs > 0) {
-        const unsigned long long key = (unsigned long long)sorted_keys[s];
-        const int er = (int)((key >> sh_er) & ((1ull << (sh_seg - sh_er)) - 1ull));
-        be.ereg = er < n_eregs ? er : -1;
-    }
-    // staging geometry: the region's 64 columns start at bit `sh` of word `ws` of index line `bi` of every region row
-    be.ch_end = ch.end; be.nblk = ch.nblk;
-    const int rel = be.C - cs;
-    const int bi = rel / kIdxCols, o = rel - bi * kIdxCols;
-    be.ws_sh = (unsigned)(o >> 6) | ((unsigned)(o & 63) << 8);
-    be.line0 = (unsigned)(ch.blk_base + (long long)(be.R - cs) * ch.nblk + bi);
-    auto bits64 = [&](int bin) {                        // masked-bin bits of bins [bin, bin + 64)
-        const unsigned long long* w = badbits + (bin >> 6);
-        const int sh = bin & 63;
-        unsigned long long v = w[0] >> sh;
-        if (sh) v |= w[1] << (64 - sh);
-        return v;
-    };
-    be.colok = ~bits64(be.C);
-    const int over = be.C + 64 - ch.end;                // columns at / past the chromosome's end are in no eligible window
-    if (over > 0) be.colok &= over >= 64 ? 0ull : (~0ull >> over);
-    be.rowbad = bits64(be.R);
-    blocks[b] = be;
-}
+// (K1q, the workgroup-staged kernel for many overlapping cis windows, and its block-order prepass: pup_staged.hpp)
 
 // ---- K1s: sparse kernel for inter-chromosomal (trans) windows, W <= 63 ---------------------------------------
 // A trans window holds a handful of pixels (5e7 trans pixels under 4.6e10 cells: ~3 per 51 x 51 window), yet a dense
@@ -2279,6 +1637,12 @@ __global__ void add_counts_kernel(long long* n, const long long* dn, int T) {
 }
 
 // interleave bin2/count into {col,count} pairs (upload helper), 64-bit or 32-bit column ids
+// the same from the (tile, flip) run boundaries {flip_from | tile end, tile end} per tile (the staged path's host table)
+__global__ void add_counts_from_ends_kernel(long long* n, const long long* seg_end, int T) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < T) n[t] += seg_end[2 * t + 1] - (t ? seg_end[2 * t - 1] : 0);
+}
+
 template <typename ColT>
 __global__ void pack_pixels_kernel(const ColT* __restrict__ col, const int* __restrict__ cnt,
                                    int2* __restrict__ out, int* __restrict__ out_cnt, long long n) {

@@ -1,0 +1,760 @@
+// pup_staged.hpp — K1q, the workgroup-staged pile-up kernel for many OVERLAPPING cis windows, and its device-side
+// block-order prepass.  gfx950 (CDNA4) only.
+//
+// When a pile-up is large its windows overlap: 1.1e7 windows (1e6 pairs + 10 shifted controls each) on a human 10 kb map put
+// ~750 top-left corners into every 108 x 108 block of the matrix near the diagonal.  The per-window kernel (K1r) fetches every
+// window on its own (~75 L2 lines).  K1q has the engine sort the windows by BLOCK of corners on the device; a PERSISTENT
+// workgroup then walks a contiguous range of blocks and for each one STAGES the RSR x RSC region of bins the block's windows
+// live in ONCE into LDS, as final cell values — everything the reference does to a cell depends on its absolute (row, col)
+// only: balanced value, masked bins, ignored diagonals, expected of |col-row| (coolpuppy/coolpup.py:1104-1157) — so the
+// staged cell already is what gets summed (0 where nothing is to be added) and one validity bit per cell says whether it
+// counts in num (coolpuppy/lib/puputils.py:18-29).  Per window a wave then does CH LDS reads + CH f64 adds per lane.
+//
+// Round 3 geometry (round 2: 64 x 64 regions, 4 waves, 4 workgroups per CU, one launch-time chunk table):
+//   * region = RSR x RSC bins, up to 128 x 128 f64 = 128 KiB of the CU's 160 KiB LDS, block = (RSR-W+1) x (RSC-W+1)
+//     corners (W = 21: 108 x 108).  Every matrix cell is staged (128/108)^2 = 1.4 times instead of (64/44)^2 = 2.1: the halo
+//     re-reads that made the round-2 kernel fetch 2.3 x its compulsory HBM bytes shrink accordingly, and one staging (two
+//     barriers, one table entry, one pipeline step) now serves ~750 windows instead of ~125;
+//   * ONE workgroup of NW = 16 waves per CU (the big region leaves room for nothing else), persistent: workgroup g walks the
+//     blocks [wg_first[g], wg_first[g+1]) — a contiguous range of the block table holding 1/G of the call's windows, worked
+//     out on the device by the prepass — so there is no launch-time chunk table, no host round trip between sort and pile-up,
+//     and one prologue / epilogue per workgroup instead of one per 4 regions;
+//   * a range may cross SEGMENTS (tile pair x flip state): the accumulators are flushed into the partial record
+//     (segment, slot, workgroup) at every change of segment; records carry a valid flag, the reduction skips the others;
+//   * staging is wave64-shaped as before: a WAVE per region row, a LANE per column of a 64-column half; the row's presence
+//     bits come from its rank-bitmap index line, the pixels under them are contiguous in `bal`, lane l's being the
+//     mbcnt(bits, l)-th of the run: one coalesced value load per row half, masks as 64-bit lane predicates, conflict-free LDS
+//     store; software-pipelined over the block table (values of block b+1, index lines of b+2, table entry of b+3 in flight
+//     while block b is piled up);
+//   * blocks with few windows stage only the rows their windows touch (row hull in the table entry);
+//   * cells of a lane are INTERLEAVED (lane (p, k) owns columns k, k + NCH, ... of window row p) and the row stride is
+//     LS = RSC + NCH doubles: ds_read_b64 at its conflict-free rate of 256 B/clk for every window offset and width.
+// Same integers as K1r; sums differ by the order of the f64 additions only (fixed: bit-reproducible run to run).
+#pragma once
+#include "pup_kernels.hpp"
+
+namespace pup {
+
+// block table entry: 128 bytes, fetched with ONE vector load (dword lane & 31 per lane) that can stay in flight across the
+// window loop; fields are pulled out with readlane when a pipeline stage needs them
+struct __attribute__((aligned(128))) StagedBlock {
+    int R, C;                    //  0  1  region origin (global bins)
+    int start, count;            //  2  3  its windows [start, start + count) in the sorted copy
+    int count0;                  //  4     the first count0 of them go to accumulator slot 0 (stable sort: a pair's first tile first)
+    int ereg;                    //  5     expected region of the block's windows (-1: none)
+    int ch_end;                  //  6     end of the chromosome (global bin)
+    int nblk;                    //  7     index lines per matrix row
+    unsigned line0[2];           //  8  9  index line of (region row 0, region column 0 / 64)
+    unsigned ws_sh[2];           // 10 11  word | bit << 8 of that column inside its line
+    unsigned colok[4];           // 12-15  unmasked-column bits of columns 0..63 (lo, hi), 64..127 (lo, hi)
+    unsigned rowbad[4];          // 16-19  masked-row bits of rows 0..63, 64..127
+    int seg;                     // 20     segment = unit * 2 + flip (unit: tile pair or tile)
+    int row_lo, row_hi;          // 21 22  region rows any window of the block touches: only these are staged
+    int pad[9];
+};
+static_assert(sizeof(StagedBlock) == 128, "block table entry must be two 64-byte lines");
+
+struct StagedArgs {
+    const StagedBlock*    blocks;
+    const unsigned short* win;        // windows in block order, each as its corner inside its region: dr | dc << 7 | slot << 14
+    const int*            wg_first;   // [G + 1] first block of every workgroup's range
+    int                   U;          // pass units (tile pairs, or tiles when unpaired)
+    unsigned char*        rec_valid;  // [ACC * U * 2 * G] set when record ((slot * U + unit) * 2 + flip) * G + workgroup was written
+};
+
+constexpr int kWinShift = 7;                          // bits of dr / dc in a window value
+constexpr int kWinSlotBit = 14;
+constexpr int kMaxSegCount = 1024;                    // (tile, flip) runs one block-ordered call may have (key kernel LDS table)
+constexpr int kMaxStagedTiles = 64;                   // partial records are (tile, flip, workgroup): keep the table small
+
+__device__ __forceinline__ void lds_read2_b32(unsigned long long& dst, unsigned addr) {     // dwords at addr, addr + 4
+    asm volatile("ds_read2_b32 %0, %1 offset0:0 offset1:1" : "=&v"(dst) : "v"(addr));
+}
+__device__ __forceinline__ void lds_pin_u64(unsigned long long& v) { asm volatile("" : "+v"(v)); }
+
+// geometry of an instantiation (host and device agree through these)
+template <int W> constexpr bool staged_big() { return W <= 21; }      // 128 x 128 regions, 16 waves: register budget of CH <= 7 cells
+template <int W, bool OOE, bool EXTRA> struct StagedGeom {
+    static constexpr bool big = staged_big<W>() && !OOE && !EXTRA;
+    static constexpr int RSR = big ? 128 : 64;
+    static constexpr int RSC = 128;
+    static constexpr int NW  = big ? 16 : 8;
+};
+
+template <int W, bool OOE, int RSR, int RSC, int NW, int ACC, bool FACT, bool EXTRA>
+__global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, StagedArgs sa) {
+    static_assert(W >= 3 && W <= 31, "workgroup-staged kernel serves windows of 3..31 bins");
+    static_assert(!(FACT && OOE), "factorised counting needs validity to factorise into row and column masks");
+    static_assert(ACC == 1 || ACC == 2, "one or two accumulator sets");
+    static_assert(RSC == 64 || RSC == 128, "a lane per column of a 64-column half");
+    static_assert(RSR % NW == 0 && RSR <= 128 && RSC <= 128, "rows are dealt out evenly to the waves; corners need 7 bits");
+    constexpr int NCH = kWave / W;
+    constexpr int CH  = (W + NCH - 1) / NCH;
+    constexpr int W2  = W * W;
+    constexpr int NH  = RSC / 64;                        // 64-column halves of a region row
+    constexpr int LS  = RSC + ((NCH % 32) ? (NCH % 32) : 32);   // row stride in doubles, LS % 32 == NCH % 32 (see above)
+    constexpr int RPW = RSR / NW;                        // region rows staged by each wave
+    constexpr int NRH = RPW * NH;                        // row halves staged by each wave: one lane each in the lookup phase
+    constexpr int NTHR = kWave * NW;
+    constexpr int VBW = NH + 1;                          // validity words per row (+1: the dword-pair read may run one dword over)
+    static_assert(NRH <= 32, "row halves of a wave must fit the value registers");
+    static_assert((size_t)NW / 2 * CH * kWave * 12 <= (size_t)RSR * LS * 8, "merge scratch must fit the region buffer");
+    __shared__ double tile[RSR * LS];
+    __shared__ unsigned long long vbits[FACT ? 1 : RSR * VBW];      // bit c of row r: cell (r, c) counts in num
+    __shared__ unsigned long long pbits[EXTRA ? RSR * VBW : 1];     // bit c: cell holds a pixel (statistics only)
+    __shared__ double cov_lds[EXTRA ? NW : 1][ACC][2 * W];
+    // FACT: num[p][q] = N - R[p] - C[q] + RC[p][q] (see fact_batch): the sparse both-masked pairs, and the totals
+    __shared__ unsigned rc_lds[ACC][FACT ? W2 : 1];
+    __shared__ unsigned fact_tot[FACT ? ACC * (2 * W + 1) : 1];     // per slot: R[W] | C[W] | N
+    const int tid  = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p_raw = lane / NCH;
+    const int k  = lane - p_raw * NCH;
+    const bool row_ok = p_raw < W;
+    const int p  = row_ok ? p_raw : W - 1;               // idle lanes shadow the last row, flush nothing
+    unsigned chmask = 0u;                                // bit i: the lane owns window cell (p, k + NCH * i)
+#pragma unroll
+    for (int i = 0; i < CH; ++i) if (row_ok && k + NCH * i < W) chmask |= 1u << i;
+
+    const bool m_cov   = EXTRA && (a.mode & 0x04u) && a.cov != nullptr;
+    const bool use_exp = OOE && ((a.expv != nullptr && a.nexp > 0) || a.n_exp_regions > 0);
+    const int  igd     = a.ignore_diags;
+    const bool stats   = EXTRA && a.counters != nullptr;
+    const double qnan = __builtin_nan("");
+
+    const int G = (int)gridDim.x, g_id = (int)blockIdx.x;
+    const int bb = sa.wg_first[g_id], be = sa.wg_first[g_id + 1];   // blocks [bb, be) of the block table
+    if (bb >= be) return;                                // (uniform) more workgroups than blocks
+    double   sum[ACC][CH];
+    unsigned num[ACC][CH];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < ACC; ++s)
+#pragma unroll
+            for (int i = 0; i < CH; ++i) { sum[s][i] = 0.0; num[s][i] = 0u; }
+        if (m_cov) for (int t = lane; t < ACC * 2 * W; t += kWave) (&cov_lds[wave][0][0])[t] = 0.0;
+        if constexpr (FACT) {                            // visible after the next barrier
+            for (int t = tid; t < ACC * W2; t += NTHR) (&rc_lds[0][0])[t] = 0u;
+            for (int t = tid; t < ACC * (2 * W + 1); t += NTHR) fact_tot[t] = 0u;
+        }
+    };
+    zero_acc();
+    if constexpr (!FACT) for (int t = tid; t < RSR * VBW; t += NTHR) vbits[t] = 0ull;     // the pad words stay zero
+    if (EXTRA) for (int t = tid; t < RSR * VBW; t += NTHR) pbits[t] = 0ull;
+
+    const StagedBlock* __restrict__ blocks = sa.blocks;
+    unsigned long long npix = 0;
+
+    // ---- staging, in pieces (see the pipeline in the block loop) ----------------------------------------------------
+    struct Raw { U64x2 h, w; unsigned long long rw; };                     // lane i < NRH: index words of the wave's i-th row half
+    struct Row { unsigned long long bits, keep, okn; long long pos; };     // lane i < NRH: what they amount to
+    auto entry_load = [&](int b) __attribute__((always_inline)) -> int {
+        return reinterpret_cast<const int*>(blocks + b)[lane & 31];
+    };
+    auto fld = [&](int ev, int i) __attribute__((always_inline)) -> int { return __builtin_amdgcn_readlane(ev, i); };
+    auto fld64 = [&](int ev, int i) __attribute__((always_inline)) -> unsigned long long {
+        return ((unsigned long long)(unsigned)fld(ev, i + 1) << 32) | (unsigned)fld(ev, i);
+    };
+    // the row half this lane looks up: row my_rr of the region, columns [64 * my_h, 64 * my_h + 64)
+    const int my_rh = lane < NRH ? lane : 0;
+    const int my_rr = wave * RPW + my_rh / NH;
+    const int my_h  = my_rh % NH;
+    auto load_raw = [&](int ev, Raw& x) __attribute__((always_inline)) {
+        x.h.a = 0ull; x.h.b = 0ull; x.w.a = 0ull; x.w.b = 0ull; x.rw = ~0ull;
+        const int R = fld(ev, 0), ch_end = fld(ev, 6), nblk = fld(ev, 7), row_lo = fld(ev, 21), row_hi = fld(ev, 22);
+        const unsigned l0 = (NH == 2 && my_h) ? (unsigned)fld(ev, 9) : (unsigned)fld(ev, 8);
+        const unsigned wsh = (NH == 2 && my_h) ? (unsigned)fld(ev, 11) : (unsigned)fld(ev, 10);
+        const int row = R + my_rr;
+        if (lane < NRH && row < ch_end && my_rr >= row_lo && my_rr < row_hi) {
+            const char* line = reinterpret_cast<const char*>(a.idx + l0 + (long long)my_rr * nblk);
+            x.h = *reinterpret_cast<const U64x2*>(line);                               // {pos, cum[4]}
+            x.w = *reinterpret_cast<const U64x2*>(line + 16 + 8 * (int)(wsh & 0xffu)); // {bits[ws], bits[ws+1] | next0}
+            if (!FACT) x.rw = a.badbits[row >> 6];
+        }
+    };
+    auto finish_rows = [&](int ev, const Raw& x) __attribute__((always_inline)) -> Row {
+        Row r;
+        const int R = fld(ev, 0), C = fld(ev, 1), ch_end = fld(ev, 6), row_lo = fld(ev, 21), row_hi = fld(ev, 22);
+        const unsigned wsh = (NH == 2 && my_h) ? (unsigned)fld(ev, 11) : (unsigned)fld(ev, 10);
+        const unsigned long long colok = (NH == 2 && my_h) ? fld64(ev, 14) : fld64(ev, 12);
+        const int ws = (int)(wsh & 0xffu), sh = (int)(wsh >> 8);
+        const int row = R + my_rr;
+        const bool live = lane < NRH && row < ch_end && my_rr >= row_lo && my_rr < row_hi;
+        r.bits = x.w.a >> sh;
+        if (sh) r.bits |= x.w.b << (64 - sh);
+        const unsigned cum = ws ? (unsigned)(x.h.b >> ((ws - 1) * 16)) & 0xffffu : 0u;
+        r.pos = (long long)(x.h.a + cum + (unsigned long long)__popcll(x.w.a & ((1ull << sh) - 1ull)));
+        unsigned long long ok = ((x.rw >> (row & 63)) & 1ull) ? 0ull : colok;
+        if (igd >= 0) {
+            const int t0 = igd - (C + 64 * my_h - row);  // column C + 64 h + l is on or above the first kept diagonal iff l >= t0
+            ok &= t0 <= 0 ? ~0ull : (t0 >= 64 ? 0ull : ~((1ull << t0) - 1ull));
+        }
+        if (!live) { r.bits = 0ull; ok = 0ull; r.pos = 0; }
+        // FACT: every window of the call is clear of the diagonal mask and `bal` is 0 on masked bins: a cell holds its
+        // pixel's value or 0, no mask needed; validity is counted from the row / column masks instead
+        r.okn = ok; r.keep = FACT ? r.bits : (r.bits & ok);
+        return r;
+    };
+    auto bcast64 = [&](unsigned long long v, int i) __attribute__((always_inline)) -> unsigned long long {
+        const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, i), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), i);
+        return ((unsigned long long)hi << 32) | lo;
+    };
+    auto issue_values = [&](const Row& r, double (&v)[NRH]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NRH; ++i) {
+            const unsigned long long bits = bcast64(r.bits, i);
+            const long long pos = (long long)bcast64((unsigned long long)r.pos, i);
+            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bits >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bits, 0u));
+            // unconditional (a branch around an element of a register array makes hipcc copy — and spill — the whole array at
+            // the join): bal is padded, a lane without a pixel reads a neighbour that is then discarded; a row half outside
+            // the staged rows has bits == 0 and pos == 0 and reads the table's first line
+            v[i] = a.bal[pos + rank];
+        }
+    };
+    auto exp_of = [&](int ev) -> ExpSel {
+        ExpSel es; es.base = a.expv; es.len = 0; es.scalar = qnan; es.is_scalar = true;
+        if (!use_exp) return es;
+        if (a.n_exp_regions <= 0) {
+            es.len = a.nexp; es.is_scalar = (a.nexp == 1);
+            es.scalar = (a.nexp == 1 && a.expv) ? a.expv[0] : qnan;
+            if (!a.expv || a.nexp <= 0) { es.is_scalar = true; es.scalar = qnan; }
+            return es;
+        }
+        const int er = fld(ev, 5);                       // expected region of the block's windows (part of the sort key)
+        es.is_scalar = false;
+        if (er >= 0 && er < a.n_exp_regions) { const ExpRegion g = a.exp_regions[er]; es.base = a.expv + g.off; es.len = g.len; }
+        return es;
+    };
+    auto store_region = [&](int ev, Row& r, const double (&v)[NRH], const ExpSel& es) __attribute__((always_inline)) {
+        const int R = fld(ev, 0), C = fld(ev, 1), row_lo = fld(ev, 21), row_hi = fld(ev, 22);
+#pragma unroll
+        for (int i = 0; i < NRH; ++i) {
+            const int rr = wave * RPW + i / NH;
+            const int hh = i % NH;
+            if (rr < row_lo || rr >= row_hi) continue;   // (uniform) no window of the block reads this row
+            const bool keep = __builtin_amdgcn_inverse_ballot_w64(bcast64(r.keep, i));
+            double val = v[i];
+            bool good = keep;
+            if (OOE) {
+                const int row = R + rr;
+                long long ad = (long long)(C + 64 * hh + lane) - row; if (ad < 0) ad = -ad;
+                const double e = use_exp ? es.at(ad) : qnan;
+                val = val / e;
+                good = keep && (val == val);            // NaN quotients are skipped, inf is kept
+                // usable expected = neither NaN nor zero.  The predicate goes through a register the compiler cannot see
+                // through: hipcc (ROCm 7.2) folds __ballot(e == e && e != 0.0) — and the equivalent v_cmp_class test —
+                // into v_cmp_neq_f64, the UNORDERED not-equal, which lets NaN pass
+                int e_ok = (e == e && e != 0.0) ? 1 : 0;
+                asm volatile("" : "+v"(e_ok));
+                const unsigned long long eok = __ballot(e_ok);
+                if (lane == i) r.okn &= eok;
+            }
+            tile[rr * LS + 64 * hh + lane] = good ? val : 0.0;
+        }
+        if (lane < NRH && my_rr >= row_lo && my_rr < row_hi) {
+            if constexpr (!FACT) vbits[my_rr * VBW + my_h] = r.okn;
+            if (stats) pbits[my_rr * VBW + my_h] = r.bits;
+        }
+    };
+
+    // ---- the windows of the staged block ---------------------------------------------------------------------------
+    // Per batch of 64 windows (one per lane, every wave holds the same batch) the LDS byte offset of each window's
+    // corner is worked out once, in vector form; per window a wave then needs one readlane, one address add, CH LDS
+    // reads and CH f64 adds (+ the validity bits, or nothing at all when validity factorises).
+    struct Cur { int R, C, start, count, count0; unsigned long long rowbad[2], colbad[2]; };
+    const unsigned lane_off8 = (unsigned)(uintptr_t)tile + 8u * (unsigned)(p * LS + k);   // LDS byte address of the lane's first cell
+    const unsigned vb_base = (unsigned)(uintptr_t)vbits;
+    // windows [j0, j1) of the batch, all of accumulator slot S; window j goes to wave (j - j0) % NW
+    auto run = [&](auto slot_tag, const Cur& g, int offv, int drv, int dcv, int j0, int j1) __attribute__((always_inline)) {
+        constexpr int S = decltype(slot_tag)::value;
+        auto gather = [&](int jj, double (&v)[CH], unsigned long long& vraw, unsigned& ad0, unsigned& ad1) __attribute__((always_inline)) {
+            // single ds_read_b64 each (see lds_read_b64); cells the lane does not own read padding, never flushed
+            ad0 = lane_off8 + (unsigned)__builtin_amdgcn_readlane(offv, jj);
+            LdsReadRow<0, CH, 8 * NCH>::go(v, ad0);
+            vraw = 0ull; ad1 = ad0;
+            if constexpr (!FACT) {
+                // validity bits of the window's row p from column dc + k on: the dword pair holding bit dc + k
+                const int dr = __builtin_amdgcn_readlane(drv, jj), dc = __builtin_amdgcn_readlane(dcv, jj);
+                ad1 = vb_base + (unsigned)((dr + p) * (VBW * 8)) + 4u * ((unsigned)(dc + k) >> 5);
+                lds_read2_b32(vraw, ad1);
+            }
+        };
+        auto bits_of = [&](int jj, unsigned long long vraw) __attribute__((always_inline)) -> unsigned {
+            if (FACT) return 0u;
+            return (unsigned)(vraw >> ((__builtin_amdgcn_readlane(dcv, jj) + k) & 31));
+        };
+        auto extra = [&](int jj) __attribute__((always_inline)) {          // coverage vectors, pixel statistics
+            const int dr = __builtin_amdgcn_readlane(drv, jj), dc = __builtin_amdgcn_readlane(dcv, jj);
+            if (m_cov && row_ok && k == 0) {
+                const double vs = a.cov[g.R + dr + p], ve = a.cov[g.C + dc + p];
+                if (vs == vs) cov_lds[wave][S][p] += vs;
+                if (ve == ve) cov_lds[wave][S][W + p] += ve;
+            }
+            if (stats) {
+                const unsigned c = (unsigned)(dc + k);
+                const unsigned* pb = reinterpret_cast<const unsigned*>(pbits + (dr + p) * VBW) + (c >> 5);
+                const unsigned long long two = ((unsigned long long)pb[1] << 32) | pb[0];
+                const unsigned pw = (unsigned)(two >> (c & 31));
+                unsigned m = 0u;
+#pragma unroll
+                for (int i = 0; i < CH; ++i) if ((chmask >> i) & 1u) m += (pw >> (NCH * i)) & 1u;
+                npix += m;
+            }
+        };
+        auto add = [&](const double (&v)[CH], unsigned vw) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) { sum[S][i] += v[i]; if (!FACT) num[S][i] += (vw >> (NCH * i)) & 1u; }
+        };
+        int jj = j0 + wave;
+        for (; jj + NW < j1; jj += 2 * NW) {              // two windows in flight: both gathered before either is added
+            double va[CH], vb[CH]; unsigned long long wa, wb; unsigned a0, a1, a2, a3;
+            gather(jj, va, wa, a0, a1);
+            gather(jj + NW, vb, wb, a2, a3);
+            lds_wait_all(a0, a1, a2, a3); lds_pin(va); lds_pin(vb);
+            if constexpr (!FACT) { lds_pin_u64(wa); lds_pin_u64(wb); }   // (FACT: no validity word was read — pinning would materialise a zero)
+            add(va, bits_of(jj, wa));
+            add(vb, bits_of(jj + NW, wb));
+            if (EXTRA) { extra(jj); extra(jj + NW); }
+        }
+        if (jj < j1) {
+            double va[CH]; unsigned long long wa; unsigned a0, a1;
+            gather(jj, va, wa, a0, a1);
+            lds_wait_all(a0, a1, a0, a1); lds_pin(va);
+            if constexpr (!FACT) lds_pin_u64(wa);
+            add(va, bits_of(jj, wa));
+            if (EXTRA) extra(jj);
+        }
+    };
+    // bits [s, s + 32) of the 128-bit mask hi:lo, s in [0, 127]
+    auto mask_at = [&](const unsigned long long (&m)[2], int s) __attribute__((always_inline)) -> unsigned {
+        const int t = s & 63;
+        unsigned long long v;
+        if (NH == 1 && RSR <= 64) { v = m[0] >> t; return (unsigned)v; }
+        if (s < 64) { v = m[0] >> t; if (t) v |= m[1] << (64 - t); } else v = m[1] >> t;
+        return (unsigned)v;
+    };
+    // FACT bookkeeping of one batch, by ONE wave, a lane per window: validity of cell (p, q) of a window factorises (no
+    // diagonal mask reaches it): valid = !rowbad[p] & !colbad[q], so over the segment num[p][q] = N - R[p] - C[q] + RC[p][q].
+    // fact_tot[slot] = {R[W], C[W], N}; rc_lds[slot] = RC (masked row meets masked column: rare).  Integer LDS atomics:
+    // exact and order-independent.
+    auto fact_batch = [&](const Cur& g, int drv, int dcv, int nb, int split) __attribute__((always_inline)) {
+      if constexpr (FACT) {
+        constexpr unsigned WMASK = (1u << W) - 1u;
+        const bool live = lane < nb;
+        const int slot = (ACC == 2 && lane >= split) ? 1 : 0;
+        unsigned rb = live ? mask_at(g.rowbad, drv) & WMASK : 0u;
+        const unsigned cbm = live ? mask_at(g.colbad, dcv) & WMASK : 0u;
+        const int tb = slot * (2 * W + 1);
+        const unsigned long long lv = __ballot(live && slot == 0);
+        if (lane == 0) {
+            atomicAdd(&fact_tot[2 * W], (unsigned)__popcll(lv));
+            if constexpr (ACC == 2) atomicAdd(&fact_tot[(2 * W + 1) + 2 * W], (unsigned)(nb - __popcll(lv)));
+        }
+        unsigned cc = cbm;
+        while (cc) { const int q = __ffs((int)cc) - 1; cc &= cc - 1u; atomicAdd(&fact_tot[tb + W + q], 1u); }
+        while (rb) {
+            const int pp = __ffs((int)rb) - 1; rb &= rb - 1u;
+            atomicAdd(&fact_tot[tb + pp], 1u);
+            unsigned c2 = cbm;
+            while (c2) { const int q = __ffs((int)c2) - 1; c2 &= c2 - 1u; atomicAdd(&rc_lds[slot][pp * W + q], 1u); }
+        }
+      }
+    };
+    // the windows [g.start, g.start + g.count) of the staged block; wf = the first 64 of them, one per lane, each as its
+    // corner inside the region (the value the block sort carried)
+    auto windows = [&](const Cur& g, int wf) __attribute__((always_inline)) {
+        int batch = 0;
+        for (int s0 = 0; s0 < g.count; s0 += kWave, ++batch) {
+            const int drv = wf & ((1 << kWinShift) - 1), dcv = (wf >> kWinShift) & ((1 << kWinShift) - 1);
+            const int offv = 8 * (drv * LS + dcv);
+            if (s0 + kWave < g.count) {                   // next batch of this block
+                const int sn = s0 + kWave + lane;
+                wf = sn < g.count ? (int)sa.win[g.start + sn] : 0;
+            }
+            const int nb = (g.count - s0) < kWave ? (g.count - s0) : kWave;
+            int split = g.count0 - s0;                    // windows of the batch before `split` belong to slot 0
+            split = split < 0 ? 0 : (split > nb ? nb : split);
+            if (FACT && (batch % NW) == wave) fact_batch(g, drv, dcv, nb, split);
+            if (ACC == 2) {
+                run(std::integral_constant<int, 0>{}, g, offv, drv, dcv, 0, split);
+                run(std::integral_constant<int, ACC - 1>{}, g, offv, drv, dcv, split, nb);
+            } else run(std::integral_constant<int, 0>{}, g, offv, drv, dcv, 0, nb);
+        }
+    };
+    auto first_coords = [&](int ev, int& wf) __attribute__((always_inline)) {
+        const int start = fld(ev, 2), count = fld(ev, 3);
+        wf = lane < count ? (int)sa.win[start + lane] : 0;
+    };
+    auto cur_of = [&](int ev) __attribute__((always_inline)) -> Cur {
+        Cur c;
+        c.R = fld(ev, 0); c.C = fld(ev, 1); c.start = fld(ev, 2); c.count = fld(ev, 3); c.count0 = fld(ev, 4);
+        c.rowbad[0] = fld64(ev, 16); c.rowbad[1] = fld64(ev, 18);
+        c.colbad[0] = ~fld64(ev, 12); c.colbad[1] = ~fld64(ev, 14);     // (also set past the chromosome's end: no eligible window reaches there)
+        return c;
+    };
+
+    // ---- flush of a segment: merge the waves' register tiles (fixed binary tree: bit-reproducible), write the partial
+    // records (segment, slot, workgroup), clear the accumulators.  Uses the region buffer as scratch: every wave is done
+    // reading the staged region when this is called, and the next region is stored after it.
+    const size_t L = (size_t)W2 + 2 * (size_t)W;
+    auto flush = [&](int seg) __attribute__((always_inline)) {
+        const int fl = seg & 1, unit = seg >> 1;
+        double*   mf = tile;                                              // [NW/2][CH][64] doubles, then the same in u32
+        unsigned* mn = reinterpret_cast<unsigned*>(tile + (NW / 2) * CH * kWave);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < ACC; ++s) {
+            for (int step = 1; step < NW; step <<= 1) {
+                const int slot_w = wave / (2 * step);
+                if ((wave & (2 * step - 1)) == step) {
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) {
+                        mf[(slot_w * CH + i) * kWave + lane] = sum[s][i];
+                        if (!FACT) mn[(slot_w * CH + i) * kWave + lane] = num[s][i];
+                    }
+                }
+                __syncthreads();
+                if ((wave & (2 * step - 1)) == 0 && wave + step < NW) {
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) {
+                        sum[s][i] += mf[(slot_w * CH + i) * kWave + lane];
+                        if (!FACT) num[s][i] += mn[(slot_w * CH + i) * kWave + lane];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < ACC; ++s) {
+            const size_t rec = ((size_t)(s * sa.U + unit) * 2 + (size_t)fl) * (size_t)G + (size_t)g_id;
+            double*   of = a.part_f64 + rec * L;
+            unsigned* on = a.part_num + rec * W2;
+            if (wave == 0) {
+#pragma unroll
+                for (int i = 0; i < CH; ++i)
+                    if ((chmask >> i) & 1u) {
+                        const int cell = map_cell(p, k + NCH * i, W, false, fl);
+                        of[cell] = sum[s][i];
+                        if (!FACT) on[cell] = num[s][i];
+                    }
+            }
+            if constexpr (FACT) {
+                // num of every cell from the factorised counts, in the accumulator frame
+                const unsigned* tot = fact_tot + s * (2 * W + 1);
+                for (int t = tid; t < W2; t += NTHR) {
+                    const int pp = t / W, qq = t - pp * W;
+                    on[map_cell(pp, qq, W, false, fl)] = tot[2 * W] - tot[pp] - tot[W + qq] + rc_lds[s][t];
+                }
+            }
+            for (int t = tid; t < 2 * W; t += NTHR) {
+                double acc = 0.0;
+                if (m_cov) for (int w = 0; w < NW; ++w) acc += cov_lds[w][s][t];
+                of[W2 + t] = acc;
+            }
+            if (tid == 0) sa.rec_valid[rec] = 1;
+        }
+        __syncthreads();                                 // fact_tot / rc_lds / cov_lds have been read
+        zero_acc();
+        __syncthreads();
+    };
+
+    // ---- the block loop: region b is piled up while b+1's values, b+2's index lines and b+3's table entry are on their way
+    {
+        int ev0 = entry_load(bb), ev1 = ev0, ev2 = ev0, evn = ev0;   // entries are consumed one stage after their load was issued
+        Raw x1, x2;
+        Row rw0, rw1;
+        double v[NRH];
+        int w0f, w1f = 0;
+        {   // prologue: stage block bb without overlap, start the lookups of bb+1
+            Raw x0;
+            load_raw(ev0, x0);
+            first_coords(ev0, w0f);
+            if (bb + 1 < be) { ev1 = entry_load(bb + 1); load_raw(ev1, x1); }
+            if (bb + 2 < be) evn = entry_load(bb + 2);
+            rw0 = finish_rows(ev0, x0);
+            issue_values(rw0, v);
+            const ExpSel es0 = exp_of(ev0);
+            __syncthreads();
+            store_region(ev0, rw0, v, es0);
+            __syncthreads();
+            if (bb + 1 < be) rw1 = finish_rows(ev1, x1);
+        }
+        for (int b = bb; b < be; ++b) {
+            const bool has1 = b + 1 < be, has2 = b + 2 < be;
+            if (has1) { issue_values(rw1, v); first_coords(ev1, w1f); }
+            if (has2) { ev2 = evn; load_raw(ev2, x2); if (b + 3 < be) evn = entry_load(b + 3); }
+            const Cur c0 = cur_of(ev0);
+            windows(c0, w0f);
+            const int seg0 = fld(ev0, 20);
+            if (!has1) { flush(seg0); break; }
+            const ExpSel es1 = exp_of(ev1);
+            if (fld(ev1, 20) != seg0) flush(seg0);       // (uniform) the next block belongs to another segment
+            else __syncthreads();                        // every wave is done reading region b
+            store_region(ev1, rw1, v, es1);
+            __syncthreads();
+            ev0 = ev1; w0f = w1f;
+            if (has2) { ev1 = ev2; rw1 = finish_rows(ev2, x2); }
+        }
+    }
+    if (stats) {
+        for (int off = 32; off > 0; off >>= 1) npix += __shfl_down(npix, off);
+        if (lane == 0) atomicAdd(&a.counters[0], npix);
+    }
+}
+
+// ---- block-order prepass of K1q ------------------------------------------------------------------------------------
+// key of a snippet: (segment, expected region, block row, block col).  Segment = the (tile pair | tile, flip) run the
+// snippet is piled up with; `pair_half` = T/2 when tile t shares its pass with tile t + T/2 (then slot = t / (T/2) goes
+// into bit kWinSlotBit of the value), 0 when every tile has its own pass.  Also checks that the window is one the
+// rank-bitmap index covers (cis, inside one chromosome), counts the others, and counts the windows a diagonal mask reaches.
+template <typename KeyT, int SIDE_R, int SIDE_C /* block sides when known at compile time (division by a constant), else 0 */>
+__global__ __launch_bounds__(256) void staged_key_kernel(const int* __restrict__ r0, const int* __restrict__ c0, long long n,
+                                                         const long long* __restrict__ seg_end, int nseg2t, int pair_half,
+                                                         const IdxChrom* __restrict__ chroms, int n_chrom,
+                                                         const unsigned short* __restrict__ bin_chrom, long long nbins,
+                                                         const int* __restrict__ brow_base /* [n_chrom] block rows before the chromosome */,
+                                                         const ExpRegion* __restrict__ eregs, int n_eregs,
+                                                         int W, int BR, int BC, int sh_br, int sh_er, int sh_seg,
+                                                         int seg_shift /* 1: no flipped windows, the flip bit is left out */,
+                                                         int clear_gap /* igd + W - 1 */,
+                                                         KeyT* __restrict__ keys, unsigned short* __restrict__ vals,
+                                                         unsigned* __restrict__ counters /* [0] ineligible, [1] windows a diagonal mask reaches */) {
+    // small tables go to LDS once per workgroup: per window the chain of dependent global loads is r0 -> bin_chrom only
+    constexpr int kMaxChrom = 512, kPer = 4;
+    __shared__ int s_cs[kMaxChrom], s_ce[kMaxChrom], s_bb[kMaxChrom];
+    __shared__ long long s_seg[2 * kMaxSegCount];
+    const bool in_lds = n_chrom <= kMaxChrom;
+    if (in_lds) for (int k = threadIdx.x; k < n_chrom; k += blockDim.x) { s_cs[k] = chroms[k].start; s_ce[k] = chroms[k].end; s_bb[k] = brow_base[k]; }
+    for (int k = threadIdx.x; k < nseg2t; k += blockDim.x) s_seg[k] = seg_end[k];
+    __syncthreads();
+    unsigned bad = 0u;
+    for (int u = 0; u < kPer; ++u) {
+        const long long i = ((long long)blockIdx.x * kPer + u) * blockDim.x + threadIdx.x;
+        const bool live = i < n;
+        const int r = live ? r0[i] : 0, c = live ? c0[i] : 0;
+        int lo = 0, hi = nseg2t;
+        while (lo < hi) { const int m = (lo + hi) >> 1; if (s_seg[m] <= i) lo = m + 1; else hi = m; }
+        const int t = lo >> 1, f = lo & 1;                   // tile, flip state of the snippet
+        unsigned seg = (unsigned)lo, slot = 0u;
+        if (pair_half > 0) { slot = (unsigned)(t / pair_half); seg = (unsigned)((t % pair_half) * 2 + f); }
+        bool ok = r >= 0 && c >= 0 && (long long)r < nbins;
+        unsigned long long br = 0, bc = 0, er = 0;
+        unsigned inside = 0u;                                // the window's corner inside its block: all the staged kernel needs
+        if (ok) {
+            const int ca = bin_chrom[r];
+            const int cs = in_lds ? s_cs[ca] : chroms[ca].start, ce = in_lds ? s_ce[ca] : chroms[ca].end;
+            ok = r >= cs && r + W <= ce && c >= cs && c + W <= ce;
+            if (ok) {
+                constexpr int kR = SIDE_R ? SIDE_R : 1, kC = SIDE_C ? SIDE_C : 1;   // (a zero divisor must not even be spelled)
+                const int qr = SIDE_R ? (r - cs) / kR : (r - cs) / BR, qc = SIDE_C ? (c - cs) / kC : (c - cs) / BC;
+                br = (unsigned long long)((in_lds ? s_bb[ca] : brow_base[ca]) + qr);     // increasing over the genome, compact
+                bc = (unsigned long long)qc;
+                inside = (unsigned)((r - cs) - qr * (SIDE_R ? SIDE_R : BR)) | ((unsigned)((c - cs) - qc * (SIDE_C ? SIDE_C : BC)) << kWinShift);
+            }
+        }
+        if (n_eregs > 0) {                                   // the region whose expected the snippet divides by (that of its first row)
+            const int e = find_exp_region(eregs, n_eregs, r);
+            er = (unsigned long long)(e < 0 ? n_eregs : e);
+        }
+        if (live && !ok) ++bad;
+        {   // one atomic per wave, not per window (a call of near-diagonal windows would serialise on the counter)
+            const unsigned long long near = __ballot(live && c - r < clear_gap);
+            if (near != 0ull && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)near) - 1)) atomicAdd(&counters[1], (unsigned)__popcll(near));
+        }
+        if (!live) continue;
+        keys[i] = (KeyT)(((unsigned long long)(seg >> seg_shift) << sh_seg) | (er << sh_er) | (br << sh_br) | bc);
+        // the value that rides the sort is the window itself as the staged kernel wants it (the sort is stable, so windows
+        // of a block keep the caller's order): no index to gather through afterwards
+        vals[i] = (unsigned short)(inside | (slot << kWinSlotBit));
+    }
+    if (bad) atomicAdd(&counters[0], bad);
+}
+
+// hand the key kernel's verdict to the host without stalling the stream: one thread copies the two counters into mapped
+// page-locked host memory; the host waits on an event recorded right behind this kernel while the sort is already running
+__global__ void staged_publish_kernel(const unsigned* __restrict__ counters, volatile unsigned* host_flags, unsigned ticket) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        host_flags[0] = counters[0];
+        host_flags[1] = counters[1];
+        __threadfence_system();
+        host_flags[2] = ticket;
+        __threadfence_system();
+    }
+}
+
+// the windows that start a block (key differs from the previous one), counted per span of kSpan windows —
+// block_starts_kernel turns the counts into the ordered list
+constexpr int kSpan = 4096;
+template <typename KeyT>
+__global__ __launch_bounds__(256) void count_heads_kernel(const KeyT* __restrict__ sorted_keys, long long n,
+                                                          unsigned* __restrict__ span_heads) {
+    __shared__ unsigned red[4];
+    const long long i0 = (long long)blockIdx.x * kSpan;                 // one workgroup per span
+    unsigned cnt = 0;
+#pragma unroll 4
+    for (int t = threadIdx.x; t < kSpan; t += 256) {
+        const long long i = i0 + t;
+        if (i < n && (i == 0 || sorted_keys[i] != sorted_keys[i - 1])) ++cnt;
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) span_heads[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// ordered list of block starts: workgroup g owns windows [g*kSpan, (g+1)*kSpan); its output offset is the number of
+// heads in the spans before it (a few thousand counters: summed by the workgroup itself, no separate scan pass).  The
+// last workgroup also publishes the total (n_runs).
+template <typename KeyT>
+__global__ __launch_bounds__(256) void block_starts_kernel(const KeyT* __restrict__ sorted_keys, long long n,
+                                                           const unsigned* __restrict__ span_heads,
+                                                           unsigned* __restrict__ starts, unsigned* __restrict__ n_runs) {
+    __shared__ unsigned red[4];
+    __shared__ unsigned wave_cnt[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned part = 0;
+    for (int k = threadIdx.x; k < (int)blockIdx.x; k += blockDim.x) part += span_heads[k];
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off);
+    if (lane == 0) red[wave] = part;
+    __syncthreads();
+    unsigned base = red[0] + red[1] + red[2] + red[3];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) n_runs[0] = base + span_heads[blockIdx.x];
+    if (span_heads[blockIdx.x] == 0) return;               // (uniform) nothing starts in this span
+    const long long i0 = (long long)blockIdx.x * kSpan;
+    for (int t = 0; t < kSpan; t += 256) {
+        const long long i = i0 + t + threadIdx.x;
+        const bool head = i < n && (i == 0 || sorted_keys[i] != sorted_keys[i - 1]);
+        const unsigned long long m = __ballot(head);
+        __syncthreads();                                   // wave_cnt of the previous round has been read
+        if (lane == 0) wave_cnt[wave] = (unsigned)__popcll(m);
+        __syncthreads();
+        unsigned before = 0;
+        for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+        if (head) starts[base + before + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (unsigned)i;
+        base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    }
+}
+
+// block table from the compacted block starts (grid-stride: the number of blocks is only known on the device): entry b =
+// region origin, its windows, slot-0 windows, segment and expected region decoded from the key, the staging geometry of the
+// region (see StagedBlock), the row hull of sparse blocks — and the first block of every workgroup's range: workgroup g of
+// the G persistent ones takes the blocks whose first window lies in [g n / G, (g + 1) n / G).
+template <typename KeyT>
+__global__ __launch_bounds__(256) void staged_table_kernel(const unsigned* __restrict__ starts, const unsigned* __restrict__ n_runs,
+                                                           long long n, const KeyT* __restrict__ sorted_keys,
+                                                           const unsigned short* __restrict__ win, const int* __restrict__ brow_base,
+                                                           const IdxChrom* __restrict__ chroms, int n_chrom, int W, int RSR, int RSC,
+                                                           int sh_br, int sh_er, int sh_seg, int seg_shift, int n_eregs,
+                                                           const unsigned long long* __restrict__ badbits,
+                                                           StagedBlock* __restrict__ blocks, int* __restrict__ wg_first, int G) {
+    const long long nr = (long long)n_runs[0];
+    const int BR = RSR - W + 1, BC = RSC - W + 1;
+    for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < nr; b += (long long)gridDim.x * blockDim.x) {
+        const unsigned s = starts[b];
+        const long long e = (b + 1 < nr) ? (long long)starts[b + 1] : n;
+        const unsigned long long key = (unsigned long long)sorted_keys[s];
+        StagedBlock be;
+        const int br = (int)((key >> sh_br) & ((1ull << (sh_er - sh_br)) - 1ull));
+        const int bc = (int)(key & ((1ull << sh_br) - 1ull));
+        int lo = 0, hi = n_chrom;                              // last chromosome whose first block row is <= br
+        while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (brow_base[m] <= br) lo = m; else hi = m; }
+        const IdxChrom ch = chroms[lo];
+        const int cs = ch.start;
+        be.R = cs + (br - brow_base[lo]) * BR;
+        be.C = cs + bc * BC;
+        be.start = (int)s; be.count = (int)(e - (long long)s);
+        {   // slot-0 windows come first inside a block (stable sort): find the first window with the slot bit set
+            long long l2 = (long long)s, h2 = e;
+            while (l2 < h2) { const long long m = (l2 + h2) >> 1; if (((win[m] >> kWinSlotBit) & 1u) == 0u) l2 = m + 1; else h2 = m; }
+            be.count0 = (int)(l2 - (long long)s);
+        }
+        be.ereg = -1;
+        if (n_eregs > 0) {
+            const int er = (int)((key >> sh_er) & ((1ull << (sh_seg - sh_er)) - 1ull));
+            be.ereg = er < n_eregs ? er : -1;
+        }
+        be.seg = (int)(key >> sh_seg) << seg_shift;
+        be.ch_end = ch.end; be.nblk = ch.nblk;
+        auto bits64 = [&](int bin) {                        // masked-bin bits of bins [bin, bin + 64)
+            const unsigned long long* w = badbits + (bin >> 6);
+            const int sh = bin & 63;
+            unsigned long long v = w[0] >> sh;
+            if (sh) v |= w[1] << (64 - sh);
+            return v;
+        };
+        for (int h = 0; h < 2; ++h) {
+            const int c_h = be.C + 64 * h;
+            unsigned long long colok = 0ull;
+            unsigned line = be.line0[0], wssh = be.ws_sh[0];
+            if (h == 0 || (64 * h < RSC && c_h < ch.end)) {
+                // staging geometry: the half's 64 columns start at bit `sh` of word `ws` of index line `bi` of every region row
+                const int rel = c_h - cs;
+                const int bi = rel / kIdxCols, o = rel - bi * kIdxCols;
+                wssh = (unsigned)(o >> 6) | ((unsigned)(o & 63) << 8);
+                line = (unsigned)(ch.blk_base + (long long)(be.R - cs) * ch.nblk + bi);
+                colok = ~bits64(c_h);
+                const int over = c_h + 64 - ch.end;         // columns at / past the chromosome's end are in no eligible window
+                if (over > 0) colok &= over >= 64 ? 0ull : (~0ull >> over);
+            }
+            be.line0[h] = line; be.ws_sh[h] = wssh;
+            be.colok[2 * h] = (unsigned)colok; be.colok[2 * h + 1] = (unsigned)(colok >> 32);
+            const unsigned long long rb = (64 * h < RSR && be.R + 64 * h < ch.end) ? bits64(be.R + 64 * h) : 0ull;
+            be.rowbad[2 * h] = (unsigned)rb; be.rowbad[2 * h + 1] = (unsigned)(rb >> 32);
+        }
+        be.row_lo = 0; be.row_hi = RSR;
+        if (be.count <= 32) {                               // sparse block: stage only the rows its windows touch
+            int mn = RSR, mx = 0;
+            for (long long m = (long long)s; m < e; ++m) {
+                const int dr = (int)(win[m] & ((1u << kWinShift) - 1u));
+                mn = dr < mn ? dr : mn; mx = dr > mx ? dr : mx;
+            }
+            be.row_lo = mn; be.row_hi = mx + W < RSR ? mx + W : RSR;
+        }
+        for (int q = 0; q < 9; ++q) be.pad[q] = 0;
+        blocks[b] = be;
+        // ranges of the persistent workgroups
+        const int g_cur = (int)(((unsigned long long)s * (unsigned long long)G) / (unsigned long long)n);
+        const int g_prev = b == 0 ? -1 : (int)(((unsigned long long)starts[b - 1] * (unsigned long long)G) / (unsigned long long)n);
+        for (int g = g_prev + 1; g <= g_cur; ++g) wg_first[g] = (int)b;
+        if (b + 1 == nr) for (int g = g_cur + 1; g <= G; ++g) wg_first[g] = (int)nr;
+    }
+    if (nr == 0 && blockIdx.x == 0) for (int g = threadIdx.x; g <= G; g += blockDim.x) wg_first[g] = 0;
+}
+
+// fixed-order reduction of the staged kernel's partial records into the running accumulators: tile t owns the records
+// [t * 2G, (t + 1) * 2G) (flip 0 of every workgroup, then flip 1); records nobody wrote are skipped through their flag.
+// Same shape as reduce_partials_kernel: 64 record elements x kRedParts interleaved partial sums in fixed order.
+__global__ __launch_bounds__(64 * kRedParts) void reduce_staged_kernel(
+        const double* __restrict__ in_f64, const unsigned* __restrict__ in_num, const unsigned char* __restrict__ valid,
+        int per_tile, int Lf, int Li, double* out_f64, long long* out_num) {
+    __shared__ double    sf[kRedParts][64];
+    __shared__ long long si[kRedParts][64];
+    const int g = blockIdx.y;
+    const int cx = threadIdx.x, py = threadIdx.y;
+    const int idx = blockIdx.x * 64 + cx;
+    const long long b = (long long)g * per_tile, e = b + per_tile;
+    double accf = 0.0; long long acci = 0;
+    if (idx < Lf) {
+        for (long long c = b + py; c < e; c += kRedParts) if (valid[c]) accf += in_f64[(size_t)c * Lf + idx];
+    } else if (idx < Lf + Li) {
+        const int k = idx - Lf;
+        for (long long c = b + py; c < e; c += kRedParts) if (valid[c]) acci += (long long)in_num[(size_t)c * Li + k];
+    }
+    sf[py][cx] = accf; si[py][cx] = acci;
+    __syncthreads();
+    if (py != 0 || idx >= Lf + Li) return;
+    if (idx < Lf) {
+        double t = 0.0;
+#pragma unroll
+        for (int y = 0; y < kRedParts; ++y) t += sf[y][cx];
+        out_f64[(size_t)g * Lf + idx] += t;
+    } else {
+        long long t = 0;
+#pragma unroll
+        for (int y = 0; y < kRedParts; ++y) t += si[y][cx];
+        out_num[(size_t)g * Li + (idx - Lf)] += t;
+    }
+}
+
+}  // namespace pup

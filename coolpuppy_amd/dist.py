@@ -127,31 +127,50 @@ def allreduce_arrays(f64, i64):
     return tf.cpu().numpy(), ti.cpu().numpy()
 
 
-_NATIVE_COMMS = {}
+_NATIVE_COMMS = {}     # (device, world) -> (ncclComm_t address | None, librccl handle | None); None: the ranks agreed to do without
+
+
+def _all_ok(d, ok, device_id):
+    """True when `ok` holds on EVERY rank (one small all-reduce on the process group): the ranks must take the same
+    exchange path — a rank that fell back on its own would sit in torch.distributed.all_reduce while the others wait in
+    ncclAllReduce on the private communicator."""
+    import torch
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    if d.get_backend() == "nccl":
+        t = t.cuda(device_id)
+    d.all_reduce(t, op=d.ReduceOp.MIN)
+    return bool(int(t.cpu()[0]))
 
 
 def native_comm(eng):
-    """An RCCL communicator (ncclComm_t address) for this engine's device over all ranks, created once: rank 0 draws
-    the ncclUniqueId, torch.distributed (any backend) only carries its 128 bytes to the other ranks.  Opt-in path
-    Exercised on hardware with a one-rank communicator and with two ranks where a box offers two GPUs (RCCL refuses two
-    ranks on one device)."""
+    """An RCCL communicator (ncclComm_t address) for this engine's device over all ranks, created once, or None when the
+    ranks agree that it cannot be had.  The librccl is the one beside the HIP runtime this process runs on (`_ffi.rccl`,
+    pup_rccl_path): one ROCm stack per process.  Rank 0 draws the ncclUniqueId; torch.distributed (any backend) only
+    carries its 128 bytes.  Every step that can fail on one rank alone (dlopen, ncclGetUniqueId, ncclCommInitRank) is
+    followed by an agreement over the process group, so either every rank returns a communicator or every rank returns
+    None — never a mixture (which would dead-lock the exchange)."""
     import ctypes as C
+    import torch
+    from . import _ffi
     d = _dist()
     rank, world = d.get_rank(), d.get_world_size()
     key = (eng.device_id, world)
     if key in _NATIVE_COMMS:
         return _NATIVE_COMMS[key][0]
-    try:
-        rccl = C.CDLL("librccl.so.1")
-    except OSError:
-        rccl = C.CDLL("librccl.so")
 
     class UniqueId(C.Structure):
         _fields_ = [("internal", C.c_char * 128)]
     uid = UniqueId()
-    if rank == 0 and rccl.ncclGetUniqueId(C.byref(uid)) != 0:
-        raise RuntimeError("ncclGetUniqueId failed")
-    import torch
+    rccl, why = None, ""
+    try:
+        rccl = _ffi.rccl()
+        if rank == 0 and rccl.ncclGetUniqueId(C.byref(uid)) != 0:
+            rccl, why = None, "ncclGetUniqueId failed"
+    except OSError as e:
+        why = str(e)
+    if not _all_ok(d, rccl is not None, eng.device_id):      # rank 0's failure reaches everybody BEFORE the broadcast
+        _NATIVE_COMMS[key] = (None, None)
+        raise RuntimeError(why or "librccl unavailable on another rank")
     t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).clone()
     if d.get_backend() == "nccl":
         t = t.cuda(eng.device_id)
@@ -159,11 +178,43 @@ def native_comm(eng):
     C.memmove(C.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
     comm = C.c_void_p()
     rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
-    torch.cuda.set_device(eng.device_id)
-    if rccl.ncclCommInitRank(C.byref(comm), world, uid, rank) != 0:
-        raise RuntimeError("ncclCommInitRank failed")
+    if torch.cuda.is_available():
+        torch.cuda.set_device(eng.device_id)
+    eng.sync()                                               # binds the engine's device in the HIP runtime
+    rc = rccl.ncclCommInitRank(C.byref(comm), world, uid, rank)
+    if not _all_ok(d, rc == 0 and bool(comm.value), eng.device_id):
+        if rc == 0 and comm.value:
+            rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+            rccl.ncclCommDestroy(comm)
+        _NATIVE_COMMS[key] = (None, None)
+        raise RuntimeError("ncclCommInitRank failed" + ("" if rc else " on another rank"))
     _NATIVE_COMMS[key] = (comm.value, rccl)
     return comm.value
+
+
+def comm_ranks(comm):
+    """ncclCommCount of a communicator made by `native_comm` (diagnostics: bench.py prints it)."""
+    import ctypes as C
+    from . import _ffi
+    n = C.c_int(0)
+    rccl = _ffi.rccl()
+    rccl.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    if rccl.ncclCommCount(C.c_void_p(comm), C.byref(n)) != 0:
+        return -1
+    return n.value
+
+
+def destroy_native_comms():
+    """ncclCommDestroy every communicator `native_comm` made (interpreter exit; tests)."""
+    import ctypes as C
+    for key in list(_NATIVE_COMMS):
+        comm, rccl = _NATIVE_COMMS.pop(key)
+        if comm and rccl is not None:
+            try:
+                rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+                rccl.ncclCommDestroy(C.c_void_p(comm))
+            except Exception:       # noqa: BLE001 - shutting down
+                pass
 
 
 def allreduce_engine(eng):
@@ -178,7 +229,7 @@ def allreduce_engine(eng):
     import torch
     if d.get_backend() == "nccl" and os.environ.get("COOLPUPPY_AMD_NATIVE_RCCL", "1") != "0":
         try:
-            comm = native_comm(eng)
+            comm = native_comm(eng)         # all ranks get one, or all ranks get None / the exception (agreed inside)
         except (RuntimeError, OSError) as e:
             import warnings
             warnings.warn(f"engine-side RCCL communicator unavailable ({e}); using torch.distributed.all_reduce")

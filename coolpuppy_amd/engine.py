@@ -6,6 +6,8 @@ inner part of ``PileUpper.pileup_region`` — ``get_data`` + ``_stream_snips`` +
 (reference coolpuppy/coolpup.py:1024-1057, 1059-1191, 1236-1283).
 """
 import ctypes as C
+import os
+import weakref
 
 import numpy as np
 
@@ -21,6 +23,17 @@ def _as(a, dtype):
     return np.ascontiguousarray(a, dtype=dtype)
 
 
+_LIVE = weakref.WeakSet()      # engines not closed yet: coolpuppy_amd.shutdown() closes them before the HIP runtime goes
+
+
+def close_all():
+    for eng in list(_LIVE):
+        try:
+            eng.close()
+        except Exception:       # noqa: BLE001 - shutting down
+            pass
+
+
 class PileupEngine:
     """Device-resident pixel table + running (kind, group) accumulators on one MI355X."""
 
@@ -31,6 +44,7 @@ class PileupEngine:
         if rc != 0:
             raise PupError(rc, self._lib.pup_last_error(None).decode())
         self._h = h
+        _LIVE.add(self)
         self.device_id = int(device_id)
         self.n_tiles = 0
         self.pad = 0
@@ -240,20 +254,28 @@ class PileupEngine:
         self._check(self._lib.pup_set_profiling(self._h, int(enabled)))
 
     def set_tuning(self, chunk_snippets=0, variant=0):
-        """chunk_snippets: snippets per chunk (blocks per chunk for the staged kernel).  variant bits: 1 ignore the index,
-        2 LDS-tile kernel, 4 no factorised num, 8 force / 16 forbid the workgroup-staged kernel, 32 no sparse trans kernel,
-        64 no tile pairing, 128 eight waves per staged workgroup (W = 21) — see pup_set_tuning in pup_hip.h."""
+        """chunk_snippets: snippets per chunk of the per-window kernels.  variant bits: 1 ignore the index, 2 LDS-tile
+        kernel, 4 no factorised num, 8 force / 16 forbid the workgroup-staged kernel, 32 no sparse trans kernel, 64 no tile
+        pairing (128: no effect since round 3) — see pup_set_tuning in pup_hip.h."""
         self._check(self._lib.pup_set_tuning(self._h, int(chunk_snippets), int(variant)))
 
-    REGION = 64                          # kWgRegion of pup_engine.hip: the staged kernel's region is 64 x 64 bins
+    @staticmethod
+    def staged_region(pad, ooe=False, extra=False):
+        """(rows, columns) of the region the workgroup-staged kernel keeps in LDS — staged_geometry() of pup_engine.hip /
+        StagedGeom of pup_staged.hpp: 128 x 128 bins for plain pile-ups of windows up to 21 bins, 64 x 128 otherwise
+        (observed over expected, coverage / statistics riding along, wider windows: their register budget)."""
+        big = 2 * int(pad) + 1 <= 21 and not ooe and not extra
+        return (128 if big else 64), 128
 
     @staticmethod
-    def block_order(r0, c0, chrom_offset, tile=None, block=None, pad=10):
+    def block_order(r0, c0, chrom_offset, tile=None, block=None, pad=10, ooe=False, extra=False):
         """Permutation that puts snippets in the order the workgroup-staged kernel walks them inside every tile:
-        (tile, block row, block column, r0, c0), blocks of (65 - W)^2 top-left corners (W = 2*pad+1) anchored at the
-        chromosome start.  Host mirror of the device-side block sort (tests, and bench.py's "preblocked" measurement)."""
-        side = PileupEngine.REGION - (2 * int(pad) + 1) + 1
-        br_size, bc_size = block or (side, side)
+        (tile, block row, block column, r0, c0), blocks of (rows - W + 1) x (columns - W + 1) top-left corners
+        (W = 2*pad+1, region as staged_region says) anchored at the chromosome start.  Host mirror of the device-side
+        block sort (tests, and bench.py's "preblocked" measurement)."""
+        W = 2 * int(pad) + 1
+        rows, cols = PileupEngine.staged_region(pad, ooe, extra)
+        br_size, bc_size = block or (rows - W + 1, cols - W + 1)
         r0 = np.asarray(r0, np.int64)
         c0 = np.asarray(c0, np.int64)
         co = np.asarray(chrom_offset, np.int64)
@@ -323,7 +345,19 @@ class _PinnedPool:
             _ffi.lib().pup_host_free(C.c_void_p(ptr))
 
 
-_POOL = _PinnedPool()
+    def drain(self):
+        """hipHostFree every kept block (interpreter exit: while the HIP runtime is still loaded)."""
+        for size, lst in list(self.free.items()):
+            while lst:
+                try:
+                    _ffi.lib().pup_host_free(C.c_void_p(lst.pop()))
+                except Exception:       # noqa: BLE001 - shutting down
+                    pass
+        self.free, self.kept = {}, 0
+        self.keep = 0                   # blocks still held by live arrays are freed, not pooled, when they go
+
+
+_POOL = _PinnedPool(keep=int(os.environ.get("COOLPUPPY_AMD_PINNED_POOL_MB", "1024")) << 20)
 
 
 class _PinnedBlock:

@@ -34,6 +34,7 @@
  *   pup_host_group_tiles              <- the per-group dicts of accumulate_stream as a grouping of windows by tile
  *                                                                      coolpuppy/coolpup.py:1263-1283
  *   pup_host_alloc / pup_host_free    <- (no counterpart: page-locked staging for asynchronous host-to-device copies)
+ *   pup_rccl_path                     <- (no counterpart: which librccl the communicator of pup_allreduce must come from)
  *
  * Conventions
  *   - plain C: pointers + sizes only; no C++/torch types cross this line.
@@ -50,6 +51,7 @@
 #ifndef PUP_HIP_H
 #define PUP_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -105,10 +107,10 @@ int pup_load_pixels(pup_ctx* ctx, const int64_t* bin1_offset, const void* bin2_i
 int pup_load_bins(pup_ctx* ctx, const double* weight, const double* cov);
 /*
  * Optional accelerator: build a rank-bitmap index over the cis part of the loaded table (one 64-byte block
- * per 448 columns per row: first-pixel position + presence bits).  chrom_offset = indexes/chrom_offset
+ * per 320 columns per row: first-pixel position + presence bits).  chrom_offset = indexes/chrom_offset
  * (int64[n_chroms+1], chrom_offset[0] == 0, chrom_offset[n_chroms] == nbins).  Windows whose rows and columns
  * lie inside one chromosome then cost one cache line per row instead of a binary search; all other windows
- * (trans) keep using the binary search.  Memory: sum_k nb_k * ceil(nb_k/448) * 64 bytes; returns PUP_ENOMEM
+ * (trans) keep using the binary search.  Memory: sum_k nb_k * ceil(nb_k/320) * 64 bytes; returns PUP_ENOMEM
  * (and leaves the engine usable without index) when that exceeds max_bytes (0 = no limit).
  * Results never depend on whether the index exists.
  */
@@ -225,6 +227,15 @@ int pup_import(pup_ctx* ctx, const void* dev_f64, const void* dev_i64);
  */
 int pup_allreduce(pup_ctx* ctx, void* rccl_comm);
 
+/*
+ * Path of the librccl that pup_allreduce opens: the copy that sits beside the HIP runtime mapped into this process
+ * (one ROCm stack per process: a PyTorch-ROCm wheel bundles its own libamdhip64 + librccl, the system ROCm another
+ * pair, and mixing them corrupts the heap at exit), or the bare soname "librccl.so.1" when there is none there.  The
+ * caller creates its ncclComm_t with THIS library (ncclGetUniqueId / ncclCommInitRank).  Writes a NUL-terminated string,
+ * returns its length; PUP_ERANGE when `cap` is too small.  No counterpart in the reference (it merges on the host).
+ */
+int pup_rccl_path(char* buf, size_t cap);
+
 /* measurement ------------------------------------------------------------------------------------- */
 typedef struct pup_stats {
     double  k1_ms;          /* total device time of the pile-up kernel (HIP events), ms */
@@ -246,15 +257,17 @@ int pup_clear_stats(pup_ctx* ctx);
 /* generic stream timer: record slot (0..7) on the context's stream; elapsed between two slots */
 int pup_event_record(pup_ctx* ctx, int slot);
 int pup_event_elapsed_ms(pup_ctx* ctx, int slot_begin, int slot_end, float* ms);
-/* tuning knobs (0 = library default): chunk_snippets = snippets per chunk (per wave) of the per-window kernels and
- * blocks per chunk (per workgroup) of the staged kernel; variant bits: 1 = ignore the index (binary search only),
- * 2 = LDS-tile kernel for every width, 4 = no factorised `num` in the staged kernel, 8 = always use the staged kernel where
- * it is eligible (tests), 16 = never use it, 32 = never use the sparse trans kernel, 64 = no tile pairing in the staged
- * kernel, 128 = 8 waves per staged workgroup (W = 21 only), bits 8..23 = waves per interleaved group.
- * Staged kernel: a call of cis windows (W <= 31, every window inside one chromosome, index built) is keyed on the device
- * by (tile pair, 65-W square block of top-left corners) and radix-sorted by block into a scratch copy; runs of blocks
- * with >= 8 windows per block and >= 20 000 windows are piled up from 64 x 64 regions staged once in LDS, tile t together
- * with tile t + T/2 (in coolpuppy's layout a group's ROI and control windows).  Input order inside a tile is free.
+/* tuning knobs (0 = library default): chunk_snippets = snippets per chunk (per wave) of the per-window kernels;
+ * variant bits: 1 = ignore the index (binary search only), 2 = LDS-tile kernel for every width, 4 = no factorised `num`
+ * in the staged kernel, 8 = always use the staged kernel where it is eligible (tests), 16 = never use it, 32 = never use
+ * the sparse trans kernel, 64 = no tile pairing in the staged kernel (128: no effect), bits 8..23 = waves per interleaved
+ * group.
+ * Staged kernel: a call of >= 1e6 cis windows (W <= 31, every window inside one chromosome, index built, at most 64 tiles) is
+ * keyed on the device by (tile pair, block of top-left corners) and radix-sorted by block into a scratch copy; when a block
+ * holds enough windows on average the call is piled up from LDS-staged regions — 128 x 128 bins for plain pile-ups of
+ * windows up to 21 bins (blocks of 108 x 108 corners at W = 21), 64 x 128 otherwise — by persistent workgroups, tile t
+ * together with tile t + T/2 (in coolpuppy's layout a group's ROI and control windows).  No host synchronisation on the
+ * way once a call shape has been seen (its block density is remembered).  Input order inside a tile is free.
  * Results do not depend on which kernel ran (integers exactly, sums up to the order of the f64 additions). */
 int pup_set_tuning(pup_ctx* ctx, int32_t chunk_snippets, int32_t variant);
 

@@ -21,7 +21,8 @@ import numpy as np, pandas as pd
 from oracle import refshim, make_golden as mg
 ref = refshim.import_reference()
 import golden_util as gu
-from coolpuppy_amd import coolpup, synth
+from coolpuppy_amd import coolpup
+import synth
 coolpup.PileUpper.run_plan = gu.oracle_run_plan
 coolpup.PileUpper._window_source = staticmethod(gu.oracle_windows)
 clr = mg.small_cooler()

@@ -25,7 +25,7 @@ import pandas as pd
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from coolpuppy_amd import synth  # noqa: E402
+import synth  # noqa: E402
 from coolpuppy_amd.cooler_lite import ArrayCooler  # noqa: E402
 from oracle import refshim  # noqa: E402
 

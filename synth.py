@@ -7,7 +7,7 @@ weights with masked bins and a ``cov_tot_raw`` column.  Generation is determinis
 import numpy as np
 import pandas as pd
 
-from .cooler_lite import ArrayCooler
+from coolpuppy_amd.cooler_lite import ArrayCooler
 
 # chromosome lengths (bp) of the assemblies the BASELINE configs name
 MM9 = {
@@ -177,7 +177,7 @@ def patched_cooler(clr, patch):
     """A copy of the in-memory cooler `clr` with some bins columns overwritten: patch = {column: {value_name: [bins]}},
     value_name one of "nan", "inf", "-inf", "zero", plus {"drop": [columns]} (JSON-friendly: golden scenarios store the patch
     in their meta)."""
-    from .cooler_lite import ArrayCooler
+    from coolpuppy_amd.cooler_lite import ArrayCooler
     vals = {"nan": np.nan, "inf": np.inf, "-inf": -np.inf, "zero": 0.0}
     cols = {}
     for c in ("weight", "cov_tot_raw", "cov_cis_raw"):

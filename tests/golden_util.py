@@ -32,7 +32,7 @@ def scenario_cooler(meta):
     base = cooler(meta["cooler"])
     if not meta.get("patch"):
         return base
-    from coolpuppy_amd import synth
+    import synth
     if meta["patch"].get("drop"):          # the run ADDS the dropped columns to the object: a fresh one every time
         return synth.patched_cooler(base, meta["patch"])
     key = meta["cooler"] + "|" + json.dumps(meta["patch"], sort_keys=True)

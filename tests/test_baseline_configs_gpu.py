@@ -3,9 +3,10 @@
 configs[0] / [1] use the reference's own feature files (tests/golden/ref_data: CH12_loops_Rao.bed, Bonev_CTCF+/-.bed.gz)
 on an mm9-sized synthetic 10 kb table (the real Scc1-control.10000.cool is not in the tree) and are compared IN FULL
 with the CPU oracle: the same pileup() call with the engine half of run_plan replaced by the oracle replay.
-configs[2] - [4] run at BASELINE's full size on the human-scale synthetic table; there the oracle checks a strided
-sample of >= 6e4 windows of every engine call, and the whole run is checked through properties that do not depend on the
-size: window counts, additivity over a split of the windows, "all" = sum of the groups, num <= n, and (trans) agreement
+configs[2] - [4] run at BASELINE's full size on the human-scale synthetic table; configs[2] / [3] compare EVERY window
+with the oracle (its row-sliced OpenMP form) and assert that the workgroup-staged kernel K1q served them; in addition the
+oracle checks a strided sample of >= 6e4 windows of every engine call (which the engine serves with K1r), and the whole
+run is checked through properties that do not depend on the size: window counts, additivity over a split of the windows, "all" = sum of the groups, num <= n, and (trans) agreement
 between the kernel the engine picks and the plain per-window kernel.
 
 Bit-exact for n / num; 1e-6 relative (BASELINE north_star) for the float sums — the test passes 1e-9.
@@ -20,7 +21,8 @@ import pandas as pd
 import pytest
 
 import golden_util as gu
-from coolpuppy_amd import coolpup, synth
+from coolpuppy_amd import coolpup
+import synth
 
 pytestmark = pytest.mark.gpu
 REF = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_data")
@@ -147,12 +149,35 @@ def _check_full_size(pu, plan, acc, min_sample=60_000):
     return n_s
 
 
+def _check_every_window_vs_oracle(pu, plan, acc, expect_staged=True):
+    """ALL windows of the plan against the oracle (row-sliced OpenMP form of oracle/pileup_oracle.c, ~1-2 s for 1.1e7
+    windows), and the engine must have taken the workgroup-staged kernel (K1q) for them: a strided sample is too small for
+    the engine to choose K1q, so only this comparison puts K1q itself — at full size — against the oracle."""
+    from oracle import pileup_oracle as po
+    eng = coolpup._engine_for(pu._aclr, 0)
+    st = eng.stats()
+    if expect_staged:
+        assert st["staged_regions"] > 0, "the engine did not take the workgroup-staged kernel at full size"
+    indptr, col, cnt = pu._aclr.pixel_table()
+    weight = pu._aclr.bins()[plan["weight_name"]][:].values
+    T = plan["T"]
+    ref = po.empty_acc(T, plan["pad"])
+    nthr = max(1, min(os.cpu_count() or 1, 64))
+    for c in plan["calls"]:
+        po.pileup_c_mt(indptr, col, cnt, weight, None, None, c["r0"], c["c0"], c["flip"], c["tile"], T, plan["pad"],
+                       c["ignore_diags"], c["mode"], nthr, acc=ref)
+    np.testing.assert_array_equal(acc["n"], ref["n"])
+    np.testing.assert_array_equal(acc["num"], ref["num"])
+    np.testing.assert_allclose(acc["sum"], ref["sum"], rtol=RTOL, atol=0)
+
+
 def test_config2_million_pairs_ten_shifts(hg38, oracle_mod):
     """configs[2]: 1e6 random cis pairs, nshifts=10 — the benchmark's workload, through the coordinate layer."""
     feats = synth.random_cis_pairs(hg38, 1_000_000, seed=42, strands=True)
     pu, plan = _plan(hg38, feats, seed=0, flank=100_000, nshifts=10)
     acc = _run_calls(pu, plan, plan["calls"])
     assert plan["T"] == 2 and acc["n"][0] > 990_000 and acc["n"][1] > 9_900_000
+    _check_every_window_vs_oracle(pu, plan, acc)
     _check_full_size(pu, plan, acc)
     # and the public entry point returns the same numbers
     with warnings.catch_warnings():
@@ -160,6 +185,39 @@ def test_config2_million_pairs_ten_shifts(hg38, oracle_mod):
         df = coolpup.pileup(hg38, feats, features_format="bedpe", flank=100_000, nshifts=10, seed=0)
     assert int(df["n"].iloc[0]) == int(acc["n"][0]) and int(df["control_n"].iloc[0]) == int(acc["n"][1])
     np.testing.assert_array_equal(np.asarray(df["num"].iloc[0]), acc["num"][0])
+
+
+@pytest.mark.parametrize("case", ["ooe_expected_table", "flip_negative_strand"])
+def test_staged_kernel_full_size_ooe_and_flip_vs_oracle(hg38, oracle_mod, case):
+    """The workgroup-staged kernel at >= 1e6 windows in its two other shapes, EVERY window against the oracle
+    (reference coolpup.py:1104-1157, lib/puputils.py:12-41): observed over the per-chromosome expected (the expected
+    table: one engine call spanning all regions, OOE instantiation, no factorised num) and strand-flipped windows (flip
+    segments, anti-transposed flush).  The plan is replayed on the C oracle by golden_util.oracle_run_plan."""
+    ooe = case == "ooe_expected_table"           # (expected and control shifts exclude each other, reference :1437-1442)
+    feats = synth.random_cis_pairs(hg38, 1_200_000 if ooe else 600_000, seed=7, strands=True)
+    np.random.seed(3)
+    cc = coolpup.CoordCreator(feats, hg38.binsize, features_format="bedpe", flank=100_000, nshifts=0 if ooe else 1,
+                              chroms=list(hg38.chromnames), seed=3)
+    kw = dict(expected=synth.cis_expected(hg38), ooe=True, control=False) if ooe else \
+        dict(flip_negative_strand=True, control=True)
+    pu = coolpup.PileUpper(hg38, cc, ignore_diags=2, **kw)
+    pu.ignore_group_order = False
+    # what pileupsWithControl passes on for flip_negative_strand (reference :1431-1475): the interval-marking function
+    modify = None if ooe else partial(coolpup.flip_mark_intervals_func, flipby="strand", flip_negative_strand=True,
+                                      extra_func=None)
+    batches = [(r1, r2, pu.region_snippets(r1, r2, groupby=[], modify_2Dintervals_func=modify,
+                                           columns=() if ooe else ["strand1"]))
+               for r1, r2 in pu._region_pairs()]
+    plan = pu.make_plan(batches, [])
+    assert sum(len(c["r0"]) for c in plan["calls"]) >= 1_000_000
+    if case == "flip_negative_strand":
+        assert any(c["flip"] is not None and c["flip"].any() for c in plan["calls"])
+    got = pu.run_plan(plan, reduce=False)
+    assert coolpup._engine_for(pu._aclr, 0).stats()["staged_regions"] > 0, "K1q did not run"
+    ref = gu.oracle_run_plan(pu, plan, reduce=False)
+    np.testing.assert_array_equal(got["n"], ref["n"])
+    np.testing.assert_array_equal(got["num"], ref["num"])
+    np.testing.assert_allclose(got["sum"], ref["sum"], rtol=RTOL, atol=0)
 
 
 def test_config3_by_distance_by_strand(hg38, oracle_mod):
@@ -170,6 +228,7 @@ def test_config3_by_distance_by_strand(hg38, oracle_mod):
                      modify=modify, cols=["distance"])
     assert plan["T"] >= 30
     acc = _run_calls(pu, plan, plan["calls"])
+    _check_every_window_vs_oracle(pu, plan, acc)
     _check_full_size(pu, plan, acc)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")

@@ -22,7 +22,7 @@ _SC = None
 def _scenarios():
     global _SC
     if _SC is None:
-        from coolpuppy_amd import synth
+        import synth
         small = gu.cooler("small")
         _SC = {s["name"]: s for s in cbs.scenarios(mg.bedpe_features(small), mg.bed_features(small), mg.tad_features(),
                                                    synth.cis_expected(small))}
@@ -77,7 +77,7 @@ def test_callbacks_gpu_vs_reference(name, hip_lib):
 def test_extract_matches_oracle_windows(hip_lib):
     """pup_extract alone: plain, OOE, EXPECTED, TRANSPOSE and coverage windows, bit-for-bit against the oracle."""
     from coolpuppy_amd.engine import MODE_COV, MODE_EXPECTED, MODE_OOE, MODE_TRANSPOSE, PileupEngine
-    from coolpuppy_amd import synth
+    import synth
     clr = gu.cooler("small")
     indptr, col, cnt = clr.pixel_table()
     weight = clr.bins()["weight"][:].values

@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from coolpuppy_amd import synth
+import synth
 
 CONDA_PY = "/opt/conda/bin/python3.9"
 

@@ -2,7 +2,8 @@
 import numpy as np
 import pytest
 
-from coolpuppy_amd import coolpup, synth
+from coolpuppy_amd import coolpup
+import synth
 
 pytestmark = pytest.mark.gpu
 
@@ -48,12 +49,10 @@ def test_native_rccl_allreduce_single_rank(hip_lib):
     runs on the engine's stream and leaves the accumulators as they were (sum over one rank)."""
     import ctypes as C
     import numpy as np
-    from coolpuppy_amd import synth
+    import synth
     from coolpuppy_amd.engine import PileupEngine
-    try:
-        rccl = C.CDLL("librccl.so")
-    except OSError:
-        rccl = C.CDLL("/opt/rocm/lib/librccl.so")
+    from coolpuppy_amd import _ffi
+    rccl = _ffi.rccl()            # the librccl beside the HIP runtime of this process (pup_rccl_path): one ROCm stack
 
     class UniqueId(C.Structure):
         _fields_ = [("internal", C.c_char * 128)]
@@ -79,3 +78,56 @@ def test_native_rccl_allreduce_single_rank(hip_lib):
     eng.close()
     rccl.ncclCommDestroy.argtypes = [C.c_void_p]
     rccl.ncclCommDestroy(comm)
+
+
+FRESH = r"""
+import ctypes as C, sys
+sys.path.insert(0, {root!r})
+import numpy as np
+from coolpuppy_amd import _ffi
+from coolpuppy_amd.engine import PileupEngine
+import synth
+rccl = _ffi.rccl()
+class UniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+uid = UniqueId()
+assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+comm = C.c_void_p()
+rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+eng = PileupEngine(0)
+assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+clr = synth.make_cooler({{"chrA": 8_000_000}}, lam=60, seed=3)
+eng.load_pixels(*clr.pixel_table()); eng.load_bins(clr.bins()["weight"][:].values, None)
+eng.reset(1, 10)
+eng.accumulate(np.arange(100, dtype=np.int32), np.arange(100, dtype=np.int32) + 30, np.array([0, 100]))
+eng.allreduce(comm); eng.sync()
+print("PATH", _ffi.rccl_path())
+{tail}
+print("FRESH OK")
+"""
+
+
+@pytest.mark.parametrize("tidy", [True, False])
+def test_fresh_interpreter_with_rccl_exits_cleanly(hip_lib, tidy):
+    """GPUTEST_r02 died AFTER its last test: the interpreter aborted at exit (rc 134) with the system ROCm's librccl
+    loaded into a process running on torch's libamdhip64, and engines / communicators only released from __del__.  A
+    fresh interpreter that does the single-rank RCCL case must exit 0 — whether the script tidies up itself or leaves
+    everything to the package's atexit hook — and the librccl it used must sit beside the mapped HIP runtime."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tail = ("rccl.ncclCommDestroy.argtypes = [C.c_void_p]; rccl.ncclCommDestroy(comm); eng.close()" if tidy
+            else "import coolpuppy_amd.dist as D; D._NATIVE_COMMS[(0, 1)] = (comm.value, rccl)")
+    code = FRESH.format(root=root, tail=tail)
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, (res.returncode, res.stdout[-2000:], res.stderr[-2000:])
+    assert "FRESH OK" in res.stdout
+    path = [ln for ln in res.stdout.splitlines() if ln.startswith("PATH ")][0][5:]
+    # the child is gone; this interpreter resolves the same way, and its own mappings can be inspected
+    from coolpuppy_amd import _ffi
+    assert path == _ffi.rccl_path()
+    with open("/proc/self/maps") as f:
+        hip = [ln.split()[-1] for ln in f if "libamdhip64" in ln]
+    assert hip, "no HIP runtime mapped?"
+    assert os.path.dirname(os.path.realpath(path)) == os.path.dirname(os.path.realpath(hip[0])) or not os.path.isabs(path)

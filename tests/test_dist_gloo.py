@@ -150,11 +150,11 @@ def test_two_ranks_native_rccl_allreduce(hip_lib, tmp_path):
     """pup_allreduce (the engine's own RCCL all-reduce, the default exchange with the nccl backend) between two real
     ranks.  A box with a single GPU cannot host it — RCCL refuses two ranks on one device — and the test then says so
     and is skipped; the gloo-bootstrapped test above covers the same host logic with two processes on one GPU."""
-    import torch
+    from coolpuppy_amd.engine import device_count       # (not torch.cuda.device_count(): torch stays out of this process)
     script = tmp_path / "rccl_worker.py"
     script.write_text(RCCL_WORKER.format(root=ROOT, port=29531, names=["G3_nshifts3", "G6c_by_strand_distance_controls"]))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN")
-    if torch.cuda.device_count() >= 2:
+    if device_count() >= 2:
         script.write_text(script.read_text().replace('os.environ["COOLPUPPY_AMD_DEVICE"] = "0"', 'os.environ["COOLPUPPY_AMD_DEVICE"] = sys.argv[1]')
                           .replace("torch.cuda.set_device(0)", "torch.cuda.set_device(int(sys.argv[1]))")
                           .replace('torch.device("cuda", 0)', 'torch.device("cuda", int(sys.argv[1]))'))
@@ -171,6 +171,6 @@ def test_two_ranks_native_rccl_allreduce(hip_lib, tmp_path):
         assert all("RCCL RANK OK" in o for o in outs)
         return
     text = "\n".join(outs)
-    if torch.cuda.device_count() < 2:
+    if device_count() < 2:
         pytest.skip("one GPU on this box: RCCL cannot place two ranks on one device — " + text[-300:].replace("\n", " | "))
     raise AssertionError(text[-3000:])

@@ -2,7 +2,8 @@
 import numpy as np
 import pytest
 
-from coolpuppy_amd import coolpup, synth
+from coolpuppy_amd import coolpup
+import synth
 
 
 def test_snippet_batches_matches_plan():
@@ -72,19 +73,20 @@ def test_skip_region_leaves_the_generator_where_the_windows_would():
 
 
 def test_block_order_groups_snippets_by_tile_and_block():
-    """PileupEngine.block_order (host helper, no GPU): tile-major, then (65 - W)^2 blocks of corners anchored at
-    chromosome starts, position inside a block; it is a permutation."""
+    """PileupEngine.block_order (host helper, no GPU): tile-major, then blocks of (rows - W + 1) x (columns - W + 1) corners
+    of the staged kernel's LDS region (128 x 128 up to W = 21, else 64 x 128) anchored at chromosome starts, position inside
+    a block; it is a permutation."""
     from coolpuppy_amd.engine import PileupEngine
     rng = np.random.default_rng(4)
     chrom_offset = np.array([0, 1000, 1700, 2500])
     r0 = rng.integers(0, 2400, 5000)
     c0 = r0 + rng.integers(0, 90, 5000)
     tile = rng.integers(0, 3, 5000)
-    for pad, side in ((10, 44), (3, 58), (15, 34)):
+    for pad, (side_r, side_c) in ((10, (108, 108)), (3, (122, 122)), (15, (34, 98))):
         o = PileupEngine.block_order(r0, c0, chrom_offset, tile=tile, pad=pad)
         assert sorted(o.tolist()) == list(range(5000))
         start = chrom_offset[np.searchsorted(chrom_offset, r0, side="right") - 1]
-        key = np.stack([tile, start + (r0 - start) // side, (c0 - start) // side, r0, c0], axis=1)[o]
+        key = np.stack([tile, start + (r0 - start) // side_r, (c0 - start) // side_c, r0, c0], axis=1)[o]
         assert all(tuple(key[i]) <= tuple(key[i + 1]) for i in range(len(key) - 1))
 
 

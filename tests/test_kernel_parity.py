@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from coolpuppy_amd import synth
+import synth
 
 pytestmark = pytest.mark.gpu
 

@@ -6,7 +6,7 @@ the flip (anti-transpose) and transpose identities, and agreement with the oracl
 import numpy as np
 import pytest
 
-from coolpuppy_amd import synth
+import synth
 
 pytestmark = pytest.mark.gpu
 
@@ -107,7 +107,7 @@ def test_block_staged_kernel_takes_over_large_overlapping_calls(hip_lib):
     """>= 1e6 overlapping cis windows: the engine sorts them by block on the device and piles the dense tile up from
     LDS-staged regions (K1q), the sparse tile with the plain kernel; same integers, same sums up to addition order.
     Pre-blocked input (PileupEngine.block_order) takes the same path without the sort."""
-    from coolpuppy_amd import synth
+    import synth
     from coolpuppy_amd.engine import PileupEngine
     clr = synth.make_cooler({"chrA": 40_000_000, "chrB": 25_000_000}, lam=120, seed=5)
     rng = np.random.default_rng(9)
@@ -152,7 +152,7 @@ def test_block_staged_kernel_equals_plain_kernel_for_every_width(hip_lib, pad):
     """All 15 x 2 instantiations of the workgroup-staged kernel (W = 3 .. 31, plain / OOE): forced on, against the plain
     register-tile kernel on the same random inputs — several chromosomes, windows touching chromosome starts and ends,
     windows below the diagonal, flips, three tiles, expected with zeros / NaN, raw counts with coverage."""
-    from coolpuppy_amd import synth
+    import synth
     from coolpuppy_amd.engine import MODE_COV, MODE_OOE, PileupEngine
     clr = synth.make_cooler({"chrA": 12_000_000, "chrB": 7_000_000, "chrC": 3_000_000}, lam=60, seed=21)
     W, T, n = 2 * pad + 1, 3, 6000
@@ -209,7 +209,7 @@ def test_staged_kernel_many_workgroups(hip_lib, pad):
     lds_read_b64 in pup_kernels.hpp) while every single-workgroup-per-CU case passed.  Plain / OOE / coverage, paired
     and single tiles, windows near and far from the diagonal (per-cell and factorised validity), against the plain
     register-tile kernel; repeated, because the fault was timing dependent."""
-    from coolpuppy_amd import synth
+    import synth
     from coolpuppy_amd.engine import MODE_COV, MODE_OOE, PileupEngine
     clr = synth.make_cooler({"chrA": 60_000_000, "chrB": 15_000_000}, lam=40, seed=31)
     W = 2 * pad + 1

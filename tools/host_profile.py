@@ -13,7 +13,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from coolpuppy_amd import coolpup, synth  # noqa: E402
+from coolpuppy_amd import coolpup
+import synth  # noqa: E402
 
 
 def main():

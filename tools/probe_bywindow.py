@@ -2,7 +2,8 @@
 import gzip, os, sys, time, warnings
 import numpy as np, pandas as pd
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-from coolpuppy_amd import coolpup, synth
+from coolpuppy_amd import coolpup
+import synth
 warnings.simplefilter("ignore")
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 clr = synth.make_cooler(synth.MM9, binsize=10_000, lam=120, seed=1000, name="mm9_like", parallel=True)

@@ -9,7 +9,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from coolpuppy_amd import synth  # noqa: E402
+import synth  # noqa: E402
 from coolpuppy_amd.engine import PileupEngine  # noqa: E402
 
 

@@ -2,7 +2,8 @@
 table upload prefetched on a helper thread (default) and without (COOLPUPPY_AMD_NO_PREFETCH=1)."""
 import os, sys, time, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from coolpuppy_amd import coolpup, synth
+from coolpuppy_amd import coolpup
+import synth
 from coolpuppy_amd.engine import PileupEngine
 warnings.simplefilter("ignore")
 hg = synth.make_cooler({c: synth.HG38[c] for c in synth.HG38}, binsize=10_000, lam=4200, seed=1000, name="synthetic_hg38_10kb", parallel=True)

@@ -2,7 +2,7 @@
 import os, sys, time
 import numpy as np, pandas as pd
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from coolpuppy_amd import synth
+import synth
 hg = synth.make_cooler({c: synth.HG38[c] for c in synth.HG38}, binsize=10_000, lam=2, seed=1000, name="s", parallel=True)
 f = synth.random_cis_pairs(hg, 1_000_000, seed=42, strands=True)
 n = len(f)

@@ -8,7 +8,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from coolpuppy_amd import synth  # noqa: E402
+import synth  # noqa: E402
 from coolpuppy_amd.engine import PileupEngine  # noqa: E402
 
 

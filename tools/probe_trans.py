@@ -2,7 +2,8 @@
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from coolpuppy_amd import coolpup, synth
+from coolpuppy_amd import coolpup
+import synth
 
 hg = synth.make_cooler({c: synth.HG38[c] for c in synth.HG38}, binsize=10_000, lam=float(os.environ.get("LAM", "4200")), seed=1000,
                        name="synthetic_hg38_10kb", parallel=True, trans_nnz=50_000_000)

@@ -20,7 +20,8 @@ import pandas as pd
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from coolpuppy_amd import coolpup, synth  # noqa: E402
+from coolpuppy_amd import coolpup
+import synth  # noqa: E402
 from coolpuppy_amd.coolpup import _engine_for  # noqa: E402
 from oracle import pileup_oracle as po  # noqa: E402
 
