@@ -123,7 +123,7 @@ struct pup_ctx {
     struct EvTriple { hipEvent_t a, b, c, p; };   // K1 = a..b, reduction = b..c, block-order prepass = p..a (p may be null)
     std::vector<EvTriple> pending;             // awaiting a stream sync
     hipEvent_t slots[8] = {};
-    int chunk_snippets = 0, variant = 0, group_waves = 0;
+    int chunk_snippets = 0, variant = 0, group_waves = 0, debug_phases = 0;
     std::vector<long long> geom_key;            // launch-geometry cache (see pup_accumulate)
     long long g_nchunks = 0, g_nblocks = 0, g_nblocks_t = 0, g_nslices = 0;
     bool g_two_level = false;
@@ -195,46 +195,54 @@ bool tiled_supported(int W) { return W >= 3 && W <= 31 && (W & 1); }
 // geometry is a property of the instantiation (StagedGeom) and only depends on facts the host knows BEFORE the prepass
 // (window width, observed-over-expected, coverage / statistics riding along) — the block size of the prepass follows from it.
 struct StagedGeo { int RSR, RSC, NW; };
-StagedGeo staged_geometry(int W, bool ooe, bool extra) {
-    const bool big = W <= 21 && !ooe && !extra;
-    return StagedGeo{big ? 128 : 64, 128, big ? 16 : 8};
+StagedGeo staged_geometry(int W, bool ooe, bool extra, bool small21) {
+    const bool big = W <= 21 && !ooe && !extra && !(small21 && W == 21);
+    return StagedGeo{big ? 128 : 64, 128, 8};
 }
 // fact: every window is clear of the diagonal mask and nothing is divided by expected -> validity factorises (FACT)
 // extra: coverage vectors and / or pixel statistics ride along (kept out of the plain instantiation's window loop)
 template <int W, bool OOE, int ACC, bool FACT, bool EXTRA>
-void launch_staged___(const pup::K1Args& a, const pup::StagedArgs& sa, int G, hipStream_t s) {
+void launch_staged___(const pup::K1Args& a, const pup::StagedArgs& sa, int G, bool small21, hipStream_t s) {
     using Geo = pup::StagedGeom<W, OOE, EXTRA>;
+    if constexpr (W == 21 && !OOE && !EXTRA) {          // tuning probe (variant bit 7): the plain 21-bin kernel on 64 x 128 regions
+        if (small21) {
+            using GeoS = pup::StagedGeom<W, OOE, EXTRA, true>;
+            hipLaunchKernelGGL((pup::pileup_staged_kernel<W, OOE, GeoS::RSR, GeoS::RSC, GeoS::NW, ACC, FACT, EXTRA>), dim3(G),
+                               dim3(pup::kWave * GeoS::NW), 0, s, a, sa);
+            return;
+        }
+    }
     hipLaunchKernelGGL((pup::pileup_staged_kernel<W, OOE, Geo::RSR, Geo::RSC, Geo::NW, ACC, FACT, EXTRA>), dim3(G),
                        dim3(pup::kWave * Geo::NW), 0, s, a, sa);
 }
 template <int W, int ACC, bool EXTRA>
-void launch_staged__(const pup::K1Args& a, const pup::StagedArgs& sa, int G, bool fact, hipStream_t s) {
-    if (a.mode & PUP_MODE_OOE) launch_staged___<W, true, ACC, false, EXTRA>(a, sa, G, s);
-    else if (fact) launch_staged___<W, false, ACC, true, EXTRA>(a, sa, G, s);
-    else launch_staged___<W, false, ACC, false, EXTRA>(a, sa, G, s);
+void launch_staged__(const pup::K1Args& a, const pup::StagedArgs& sa, int G, bool fact, bool small21, hipStream_t s) {
+    if (a.mode & PUP_MODE_OOE) launch_staged___<W, true, ACC, false, EXTRA>(a, sa, G, small21, s);
+    else if (fact) launch_staged___<W, false, ACC, true, EXTRA>(a, sa, G, small21, s);
+    else launch_staged___<W, false, ACC, false, EXTRA>(a, sa, G, small21, s);
 }
 template <int W>
-void launch_staged_(const pup::K1Args& a, const pup::StagedArgs& sa, int G, int acc, bool fact, bool extra, hipStream_t s) {
-    if (extra) { if (acc == 2) launch_staged__<W, 2, true>(a, sa, G, fact, s); else launch_staged__<W, 1, true>(a, sa, G, fact, s); }
-    else       { if (acc == 2) launch_staged__<W, 2, false>(a, sa, G, fact, s); else launch_staged__<W, 1, false>(a, sa, G, fact, s); }
+void launch_staged_(const pup::K1Args& a, const pup::StagedArgs& sa, int G, int acc, bool fact, bool extra, bool small21, hipStream_t s) {
+    if (extra) { if (acc == 2) launch_staged__<W, 2, true>(a, sa, G, fact, small21, s); else launch_staged__<W, 1, true>(a, sa, G, fact, small21, s); }
+    else       { if (acc == 2) launch_staged__<W, 2, false>(a, sa, G, fact, small21, s); else launch_staged__<W, 1, false>(a, sa, G, fact, small21, s); }
 }
-bool launch_staged(int W, const pup::K1Args& a, const pup::StagedArgs& sa, int G, int acc, bool fact, bool extra, hipStream_t s) {
+bool launch_staged(int W, const pup::K1Args& a, const pup::StagedArgs& sa, int G, int acc, bool fact, bool extra, bool small21, hipStream_t s) {
     switch (W) {
-        case 3:  launch_staged_<3>(a, sa, G, acc, fact, extra, s);  return true;
-        case 5:  launch_staged_<5>(a, sa, G, acc, fact, extra, s);  return true;
-        case 7:  launch_staged_<7>(a, sa, G, acc, fact, extra, s);  return true;
-        case 9:  launch_staged_<9>(a, sa, G, acc, fact, extra, s);  return true;
-        case 11: launch_staged_<11>(a, sa, G, acc, fact, extra, s); return true;
-        case 13: launch_staged_<13>(a, sa, G, acc, fact, extra, s); return true;
-        case 15: launch_staged_<15>(a, sa, G, acc, fact, extra, s); return true;
-        case 17: launch_staged_<17>(a, sa, G, acc, fact, extra, s); return true;
-        case 19: launch_staged_<19>(a, sa, G, acc, fact, extra, s); return true;
-        case 21: launch_staged_<21>(a, sa, G, acc, fact, extra, s); return true;
-        case 23: launch_staged_<23>(a, sa, G, acc, fact, extra, s); return true;
-        case 25: launch_staged_<25>(a, sa, G, acc, fact, extra, s); return true;
-        case 27: launch_staged_<27>(a, sa, G, acc, fact, extra, s); return true;
-        case 29: launch_staged_<29>(a, sa, G, acc, fact, extra, s); return true;
-        case 31: launch_staged_<31>(a, sa, G, acc, fact, extra, s); return true;
+        case 3:  launch_staged_<3>(a, sa, G, acc, fact, extra, small21, s);  return true;
+        case 5:  launch_staged_<5>(a, sa, G, acc, fact, extra, small21, s);  return true;
+        case 7:  launch_staged_<7>(a, sa, G, acc, fact, extra, small21, s);  return true;
+        case 9:  launch_staged_<9>(a, sa, G, acc, fact, extra, small21, s);  return true;
+        case 11: launch_staged_<11>(a, sa, G, acc, fact, extra, small21, s); return true;
+        case 13: launch_staged_<13>(a, sa, G, acc, fact, extra, small21, s); return true;
+        case 15: launch_staged_<15>(a, sa, G, acc, fact, extra, small21, s); return true;
+        case 17: launch_staged_<17>(a, sa, G, acc, fact, extra, small21, s); return true;
+        case 19: launch_staged_<19>(a, sa, G, acc, fact, extra, small21, s); return true;
+        case 21: launch_staged_<21>(a, sa, G, acc, fact, extra, small21, s); return true;
+        case 23: launch_staged_<23>(a, sa, G, acc, fact, extra, small21, s); return true;
+        case 25: launch_staged_<25>(a, sa, G, acc, fact, extra, small21, s); return true;
+        case 27: launch_staged_<27>(a, sa, G, acc, fact, extra, small21, s); return true;
+        case 29: launch_staged_<29>(a, sa, G, acc, fact, extra, small21, s); return true;
+        case 31: launch_staged_<31>(a, sa, G, acc, fact, extra, small21, s); return true;
         default: return false;
     }
 }
@@ -724,7 +732,8 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
         (int)c->h_chroms.size() != c->n_chrom)
         return 1;
     const bool extra = ((mode & PUP_MODE_COV) && c->have_cov) || c->count_pixels;
-    const StagedGeo geo = staged_geometry(W, (mode & PUP_MODE_OOE) != 0, extra);
+    const bool small21 = (c->variant & 128) != 0;
+    const StagedGeo geo = staged_geometry(W, (mode & PUP_MODE_OOE) != 0, extra, small21);
     const int BR = geo.RSR - W + 1, BC = geo.RSC - W + 1;
     const int G = c->n_cu * (geo.RSR * geo.RSC > 64 * 128 ? 1 : 2);            // persistent workgroups (one / two per CU by LDS)
     // a staged region must serve this many windows on average to pay for its staging
@@ -736,7 +745,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     std::vector<long long> sig;
     sig.reserve(8 + 2 * (size_t)T);
     sig.push_back(n); sig.push_back(T); sig.push_back(W); sig.push_back((long long)(mode & (PUP_MODE_OOE | PUP_MODE_COV)));
-    sig.push_back(ignore_diags); sig.push_back(flip_from ? 1 : 0); sig.push_back(c->variant & (4 | 64)); sig.push_back(extra ? 1 : 0);
+    sig.push_back(ignore_diags); sig.push_back(flip_from ? 1 : 0); sig.push_back(c->variant & (4 | 64 | 128)); sig.push_back(extra ? 1 : 0);
     for (int t = 0; t <= T; ++t) sig.push_back(tile_ptr[t]);
     if (flip_from) for (int t = 0; t < T; ++t) sig.push_back(flip_from[t]);
     const bool known = (sig == c->hint_sig) && c->hint_blocks >= 0;
@@ -781,7 +790,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     const size_t ncnt = 4;                               // [0] ineligible [1] unclear [2] blocks [3] -, then the span counters
     const size_t W2 = (size_t)W * W, Lf = W2 + 2 * (size_t)W;
     const size_t nrec = (size_t)T * 2 * (size_t)G;       // record ((slot * U + unit) * 2 + flip) * G + workgroup = (tile * 2 + flip) * G + workgroup
-    HIPCHK(c, c->d_win.reserve((size_t)n)); HIPCHK(c, c->d_win2.reserve((size_t)n));
+    HIPCHK(c, c->d_win.reserve((size_t)n + 8)); HIPCHK(c, c->d_win2.reserve((size_t)n + 8));   // +8: K1q fetches four window values at a time
     if (c->d_segend.cap < htab.size()) c->htab_sent.clear();          // the buffer is about to move
     HIPCHK(c, c->d_segend.reserve(htab.size()));
     HIPCHK(c, c->d_cnt32.reserve(ncnt + (size_t)n_spans));
@@ -870,8 +879,9 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     fill_k1_args(c, a, ignore_diags, mode);
     pup::StagedArgs sa{};
     sa.blocks = c->d_blocks.p; sa.win = c->d_win2.p; sa.wg_first = c->d_wgfirst.p; sa.U = U; sa.rec_valid = c->d_recvalid.p;
+    sa.debug = c->debug_phases;                          // timing experiments (tools/k1_probe.py): variant bits 24 / 25
     if (ev) HIPCHK(c, hipEventRecord(ev[1], c->stream));
-    if (!launch_staged(W, a, sa, G, ACC, fact, extra, c->stream))
+    if (!launch_staged(W, a, sa, G, ACC, fact, extra, small21, c->stream))
         return fail(c, PUP_ENOTSUP, "pup_accumulate: staged kernel not built for W=%d", W);
     HIPCHK(c, hipGetLastError());
     if (ev) HIPCHK(c, hipEventRecord(ev[2], c->stream));
@@ -1580,6 +1590,7 @@ int pup_set_tuning(pup_ctx* c, int32_t chunk_snippets, int32_t variant) {
     if (!c) return PUP_EINVAL;
     if (chunk_snippets < 0) return fail(c, PUP_EINVAL, "pup_set_tuning: negative chunk size");
     c->chunk_snippets = chunk_snippets; c->variant = variant & 0xff; c->group_waves = (variant >> 8) & 0xffff;
+    c->debug_phases = (variant >> 24) & 3;
     return PUP_OK;
 }
 

@@ -60,11 +60,13 @@ struct StagedArgs {
     const int*            wg_first;   // [G + 1] first block of every workgroup's range
     int                   U;          // pass units (tile pairs, or tiles when unpaired)
     unsigned char*        rec_valid;  // [ACC * U * 2 * G] set when record ((slot * U + unit) * 2 + flip) * G + workgroup was written
+    int                   debug;      // timing experiments only (results are wrong): 1 = skip the window loop, 2 = skip the staging
 };
 
 constexpr int kWinShift = 7;                          // bits of dr / dc in a window value
 constexpr int kWinSlotBit = 14;
 constexpr int kMaxSegCount = 1024;                    // (tile, flip) runs one block-ordered call may have (key kernel LDS table)
+constexpr int kBlockCost = 400;                       // staging one region, in windows' worth of time (workgroup ranges)
 constexpr int kMaxStagedTiles = 64;                   // partial records are (tile, flip, workgroup): keep the table small
 
 __device__ __forceinline__ void lds_read2_b32(unsigned long long& dst, unsigned addr) {     // dwords at addr, addr + 4
@@ -74,11 +76,12 @@ __device__ __forceinline__ void lds_pin_u64(unsigned long long& v) { asm volatil
 
 // geometry of an instantiation (host and device agree through these)
 template <int W> constexpr bool staged_big() { return W <= 21; }      // 128 x 128 regions, 16 waves: register budget of CH <= 7 cells
-template <int W, bool OOE, bool EXTRA> struct StagedGeom {
-    static constexpr bool big = staged_big<W>() && !OOE && !EXTRA;
+template <int W, bool OOE, bool EXTRA, bool SMALL = false> struct StagedGeom {
+    static constexpr bool big = staged_big<W>() && !OOE && !EXTRA && !SMALL;
     static constexpr int RSR = big ? 128 : 64;
     static constexpr int RSC = 128;
-    static constexpr int NW  = big ? 16 : 8;
+    static constexpr int NW  = 8;                        // 8 waves of up to 256 registers: the prefetched next region (counts,
+                                                         // index words, row descriptors) stays in registers across the window loop
 };
 
 template <int W, bool OOE, int RSR, int RSC, int NW, int ACC, bool FACT, bool EXTRA>
@@ -97,6 +100,7 @@ __global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, 
     constexpr int NRH = RPW * NH;                        // row halves staged by each wave: one lane each in the lookup phase
     constexpr int NTHR = kWave * NW;
     constexpr int VBW = NH + 1;                          // validity words per row (+1: the dword-pair read may run one dword over)
+    constexpr int WIF = (NTHR <= 512 && CH <= 7 && FACT && !EXTRA) ? 4 : 2;   // windows in flight per wave (register budget)
     static_assert(NRH <= 32, "row halves of a wave must fit the value registers");
     static_assert((size_t)NW / 2 * CH * kWave * 12 <= (size_t)RSR * LS * 8, "merge scratch must fit the region buffer");
     __shared__ double tile[RSR * LS];
@@ -147,8 +151,8 @@ __global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, 
     unsigned long long npix = 0;
 
     // ---- staging, in pieces (see the pipeline in the block loop) ----------------------------------------------------
-    struct Raw { U64x2 h, w; unsigned long long rw; };                     // lane i < NRH: index words of the wave's i-th row half
-    struct Row { unsigned long long bits, keep, okn; long long pos; };     // lane i < NRH: what they amount to
+    struct Raw { U64x2 h, w; unsigned long long rw; double wr; };          // lane i < NRH: index words of the wave's i-th row half, its row's weight
+    struct Row { unsigned long long bits, keep, okn; long long pos; double wr; };   // lane i < NRH: what they amount to
     auto entry_load = [&](int b) __attribute__((always_inline)) -> int {
         return reinterpret_cast<const int*>(blocks + b)[lane & 31];
     };
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, 
     const int my_rr = wave * RPW + my_rh / NH;
     const int my_h  = my_rh % NH;
     auto load_raw = [&](int ev, Raw& x) __attribute__((always_inline)) {
-        x.h.a = 0ull; x.h.b = 0ull; x.w.a = 0ull; x.w.b = 0ull; x.rw = ~0ull;
+        x.h.a = 0ull; x.h.b = 0ull; x.w.a = 0ull; x.w.b = 0ull; x.rw = ~0ull; x.wr = 1.0;
         const int R = fld(ev, 0), ch_end = fld(ev, 6), nblk = fld(ev, 7), row_lo = fld(ev, 21), row_hi = fld(ev, 22);
         const unsigned l0 = (NH == 2 && my_h) ? (unsigned)fld(ev, 9) : (unsigned)fld(ev, 8);
         const unsigned wsh = (NH == 2 && my_h) ? (unsigned)fld(ev, 11) : (unsigned)fld(ev, 10);
@@ -171,6 +175,7 @@ __global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, 
             x.h = *reinterpret_cast<const U64x2*>(line);                               // {pos, cum[4]}
             x.w = *reinterpret_cast<const U64x2*>(line + 16 + 8 * (int)(wsh & 0xffu)); // {bits[ws], bits[ws+1] | next0}
             if (!FACT) x.rw = a.badbits[row >> 6];
+            if (a.weight) x.wr = a.weight[row];
         }
     };
     auto finish_rows = [&](int ev, const Raw& x) __attribute__((always_inline)) -> Row {
@@ -194,22 +199,35 @@ __global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, 
         // FACT: every window of the call is clear of the diagonal mask and `bal` is 0 on masked bins: a cell holds its
         // pixel's value or 0, no mask needed; validity is counted from the row / column masks instead
         r.okn = ok; r.keep = FACT ? r.bits : (r.bits & ok);
+        r.wr = x.wr;
         return r;
     };
     auto bcast64 = [&](unsigned long long v, int i) __attribute__((always_inline)) -> unsigned long long {
         const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, i), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), i);
         return ((unsigned long long)hi << 32) | lo;
     };
-    auto issue_values = [&](const Row& r, double (&v)[NRH]) __attribute__((always_inline)) {
+    // the pixels of the region are fetched as their 4-byte COUNTS and balanced here, (count * w[row]) * w[col] in the order
+    // balance_pixels_kernel (and cooler) multiplies, NaN -> 0: the same doubles as the resident `bal` table at half the HBM
+    // bytes — with 128 x 128 regions the kernel is bound by what it pulls from HBM (round 2, at 64 x 64, it was not)
+    auto issue_values = [&](int ev, const Row& r, int (&v)[NRH], double (&wc)[NH]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NRH; ++i) {
             const unsigned long long bits = bcast64(r.bits, i);
             const long long pos = (long long)bcast64((unsigned long long)r.pos, i);
             const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bits >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bits, 0u));
             // unconditional (a branch around an element of a register array makes hipcc copy — and spill — the whole array at
-            // the join): bal is padded, a lane without a pixel reads a neighbour that is then discarded; a row half outside
+            // the join): cnt32 is padded, a lane without a pixel reads a neighbour that is then discarded; a row half outside
             // the staged rows has bits == 0 and pos == 0 and reads the table's first line
-            v[i] = a.bal[pos + rank];
+            v[i] = a.cnt32[pos + rank];
+        }
+        // column weights (1.0 when raw — branch-free: the load then reads the row offsets, a table of the same length)
+        const int C = fld(ev, 1);
+        const double* wsrc = a.weight ? a.weight : reinterpret_cast<const double*>(a.indptr);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const long long col = (long long)C + 64 * h + lane;
+            const double w = wsrc[col < a.nbins ? col : a.nbins - 1];                 // (columns past the table are in no window)
+            wc[h] = a.weight ? w : 1.0;
         }
     };
     auto exp_of = [&](int ev) -> ExpSel {
@@ -226,7 +244,7 @@ __global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, 
         if (er >= 0 && er < a.n_exp_regions) { const ExpRegion g = a.exp_regions[er]; es.base = a.expv + g.off; es.len = g.len; }
         return es;
     };
-    auto store_region = [&](int ev, Row& r, const double (&v)[NRH], const ExpSel& es) __attribute__((always_inline)) {
+    auto store_region = [&](int ev, Row& r, const int (&v)[NRH], const double (&wc)[NH], const ExpSel& es) __attribute__((always_inline)) {
         const int R = fld(ev, 0), C = fld(ev, 1), row_lo = fld(ev, 21), row_hi = fld(ev, 22);
 #pragma unroll
         for (int i = 0; i < NRH; ++i) {
@@ -234,7 +252,10 @@ __global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, 
             const int hh = i % NH;
             if (rr < row_lo || rr >= row_hi) continue;   // (uniform) no window of the block reads this row
             const bool keep = __builtin_amdgcn_inverse_ballot_w64(bcast64(r.keep, i));
-            double val = v[i];
+            // balanced value (raw: both weights are 1.0); NaN (a masked bin) is stored as 0
+            const double wr = __longlong_as_double((long long)bcast64((unsigned long long)__double_as_longlong(r.wr), i));
+            double val = (double)v[i] * wr * wc[hh];
+            val = (val == val) ? val : 0.0;
             bool good = keep;
             if (OOE) {
                 const int row = R + rr;
@@ -259,14 +280,24 @@ __global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, 
     };
 
     // ---- the windows of the staged block ---------------------------------------------------------------------------
-    // Per batch of 64 windows (one per lane, every wave holds the same batch) the LDS byte offset of each window's
-    // corner is worked out once, in vector form; per window a wave then needs one readlane, one address add, CH LDS
-    // reads and CH f64 adds (+ the validity bits, or nothing at all when validity factorises).
+    // Every wave owns a contiguous SLICE of the block's windows — wave w the windows [w M, (w + 1) M), M = ceil(count / NW) —
+    // and walks it in batches of 64, a lane per window: one 2-byte load per lane fetches a batch (the first batch of a block
+    // while the previous block is still being piled up, the next batch of a long slice while the current one is), the LDS
+    // byte offset of each window's corner is worked out once per batch in vector form, and per window the wave then needs
+    // one readlane, one address add, CH LDS reads and CH f64 adds (+ the validity bits, or nothing at all when validity
+    // factorises).  Slices are equally long, so the waves reach the block's closing barrier together; the slot-0 windows
+    // of a pair come first in a block (stable sort), so at most one wave sees both slots.  (Round 2 dealt windows out
+    // round robin from batches every wave held; with one workgroup per CU the per-batch fetch then stalled the whole CU,
+    // and the factorised-count bookkeeping of a batch fell on one wave.)
     struct Cur { int R, C, start, count, count0; unsigned long long rowbad[2], colbad[2]; };
     const unsigned lane_off8 = (unsigned)(uintptr_t)tile + 8u * (unsigned)(p * LS + k);   // LDS byte address of the lane's first cell
     const unsigned vb_base = (unsigned)(uintptr_t)vbits;
-    // windows [j0, j1) of the batch, all of accumulator slot S; window j goes to wave (j - j0) % NW
-    auto run = [&](auto slot_tag, const Cur& g, int offv, int drv, int dcv, int j0, int j1) __attribute__((always_inline)) {
+    // window `at + lane` of the block, for the lanes below `end`
+    auto load_batch = [&](int start, int at, int end) __attribute__((always_inline)) -> int {
+        return at + lane < end ? (int)sa.win[start + at + lane] : 0;
+    };
+    // windows jb <= j < je of the wave's current batch (window j sits in lane j), all of accumulator slot S
+    auto run = [&](auto slot_tag, const Cur& g, int offv, int drv, int dcv, int jb, int je) __attribute__((always_inline)) {
         constexpr int S = decltype(slot_tag)::value;
         auto gather = [&](int jj, double (&v)[CH], unsigned long long& vraw, unsigned& ad0, unsigned& ad1) __attribute__((always_inline)) {
             // single ds_read_b64 each (see lds_read_b64); cells the lane does not own read padding, never flushed
@@ -306,18 +337,35 @@ __global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, 
 #pragma unroll
             for (int i = 0; i < CH; ++i) { sum[S][i] += v[i]; if (!FACT) num[S][i] += (vw >> (NCH * i)) & 1u; }
         };
-        int jj = j0 + wave;
-        for (; jj + NW < j1; jj += 2 * NW) {              // two windows in flight: both gathered before either is added
+        int jj = jb;
+        if constexpr (WIF == 4) {
+            for (; jj + 3 < je; jj += 4) {                // four windows in flight: all gathered before any is added
+                double va[CH], vb[CH], vc[CH], vd[CH]; unsigned long long wa, wb, wc2, wd; unsigned a0, a1, a2, a3, a4, a5, a6, a7;
+                gather(jj, va, wa, a0, a1);
+                gather(jj + 1, vb, wb, a2, a3);
+                gather(jj + 2, vc, wc2, a4, a5);
+                gather(jj + 3, vd, wd, a6, a7);
+                lds_wait_all(a0, a1, a2, a3); lds_wait_all(a4, a5, a6, a7);
+                lds_pin(va); lds_pin(vb); lds_pin(vc); lds_pin(vd);
+                if constexpr (!FACT) { lds_pin_u64(wa); lds_pin_u64(wb); lds_pin_u64(wc2); lds_pin_u64(wd); }
+                add(va, bits_of(jj, wa));
+                add(vb, bits_of(jj + 1, wb));
+                add(vc, bits_of(jj + 2, wc2));
+                add(vd, bits_of(jj + 3, wd));
+                if (EXTRA) { extra(jj); extra(jj + 1); extra(jj + 2); extra(jj + 3); }
+            }
+        }
+        for (; jj + 1 < je; jj += 2) {                    // two windows in flight: both gathered before either is added
             double va[CH], vb[CH]; unsigned long long wa, wb; unsigned a0, a1, a2, a3;
             gather(jj, va, wa, a0, a1);
-            gather(jj + NW, vb, wb, a2, a3);
+            gather(jj + 1, vb, wb, a2, a3);
             lds_wait_all(a0, a1, a2, a3); lds_pin(va); lds_pin(vb);
             if constexpr (!FACT) { lds_pin_u64(wa); lds_pin_u64(wb); }   // (FACT: no validity word was read — pinning would materialise a zero)
             add(va, bits_of(jj, wa));
-            add(vb, bits_of(jj + NW, wb));
-            if (EXTRA) { extra(jj); extra(jj + NW); }
+            add(vb, bits_of(jj + 1, wb));
+            if (EXTRA) { extra(jj); extra(jj + 1); }
         }
-        if (jj < j1) {
+        if (jj < je) {
             double va[CH]; unsigned long long wa; unsigned a0, a1;
             gather(jj, va, wa, a0, a1);
             lds_wait_all(a0, a1, a0, a1); lds_pin(va);
@@ -330,27 +378,26 @@ __global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, 
     auto mask_at = [&](const unsigned long long (&m)[2], int s) __attribute__((always_inline)) -> unsigned {
         const int t = s & 63;
         unsigned long long v;
-        if (NH == 1 && RSR <= 64) { v = m[0] >> t; return (unsigned)v; }
         if (s < 64) { v = m[0] >> t; if (t) v |= m[1] << (64 - t); } else v = m[1] >> t;
         return (unsigned)v;
     };
-    // FACT bookkeeping of one batch, by ONE wave, a lane per window: validity of cell (p, q) of a window factorises (no
-    // diagonal mask reaches it): valid = !rowbad[p] & !colbad[q], so over the segment num[p][q] = N - R[p] - C[q] + RC[p][q].
+    // FACT bookkeeping of a batch, a lane per window: validity of cell (p, q) of a window factorises (no diagonal mask
+    // reaches it): valid = !rowbad[p] & !colbad[q], so over the segment num[p][q] = N - R[p] - C[q] + RC[p][q].
     // fact_tot[slot] = {R[W], C[W], N}; rc_lds[slot] = RC (masked row meets masked column: rare).  Integer LDS atomics:
     // exact and order-independent.
     auto fact_batch = [&](const Cur& g, int drv, int dcv, int nb, int split) __attribute__((always_inline)) {
       if constexpr (FACT) {
         constexpr unsigned WMASK = (1u << W) - 1u;
+        if (lane == 0) {
+            if (ACC == 1 || split > 0) atomicAdd(&fact_tot[2 * W], (unsigned)(ACC == 2 ? split : nb));
+            if constexpr (ACC == 2) if (nb > split) atomicAdd(&fact_tot[(2 * W + 1) + 2 * W], (unsigned)(nb - split));
+        }
+        if ((g.rowbad[0] | g.rowbad[1] | g.colbad[0] | g.colbad[1]) == 0ull) return;     // (uniform) no masked bin in the region
         const bool live = lane < nb;
         const int slot = (ACC == 2 && lane >= split) ? 1 : 0;
         unsigned rb = live ? mask_at(g.rowbad, drv) & WMASK : 0u;
         const unsigned cbm = live ? mask_at(g.colbad, dcv) & WMASK : 0u;
         const int tb = slot * (2 * W + 1);
-        const unsigned long long lv = __ballot(live && slot == 0);
-        if (lane == 0) {
-            atomicAdd(&fact_tot[2 * W], (unsigned)__popcll(lv));
-            if constexpr (ACC == 2) atomicAdd(&fact_tot[(2 * W + 1) + 2 * W], (unsigned)(nb - __popcll(lv)));
-        }
         unsigned cc = cbm;
         while (cc) { const int q = __ffs((int)cc) - 1; cc &= cc - 1u; atomicAdd(&fact_tot[tb + W + q], 1u); }
         while (rb) {
@@ -361,21 +408,24 @@ __global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, 
         }
       }
     };
-    // the windows [g.start, g.start + g.count) of the staged block; wf = the first 64 of them, one per lane, each as its
-    // corner inside the region (the value the block sort carried)
+    // this wave's slice of the block's windows [lo, hi); wf = its first batch, one window per lane, each as its corner
+    // inside the region (the value the block sort carried)
+    auto slice_of = [&](int count, int& lo, int& hi) __attribute__((always_inline)) {
+        const int M = (count + NW - 1) / NW;
+        lo = wave * M; hi = lo + M < count ? lo + M : count;
+        if (lo > hi) lo = hi;
+    };
     auto windows = [&](const Cur& g, int wf) __attribute__((always_inline)) {
-        int batch = 0;
-        for (int s0 = 0; s0 < g.count; s0 += kWave, ++batch) {
+        int lo, hi;
+        slice_of(g.count, lo, hi);
+        for (int s0 = lo; s0 < hi; s0 += kWave) {
             const int drv = wf & ((1 << kWinShift) - 1), dcv = (wf >> kWinShift) & ((1 << kWinShift) - 1);
             const int offv = 8 * (drv * LS + dcv);
-            if (s0 + kWave < g.count) {                   // next batch of this block
-                const int sn = s0 + kWave + lane;
-                wf = sn < g.count ? (int)sa.win[g.start + sn] : 0;
-            }
-            const int nb = (g.count - s0) < kWave ? (g.count - s0) : kWave;
+            if (s0 + kWave < hi) wf = load_batch(g.start, s0 + kWave, hi);         // next batch of a long slice
+            const int nb = (hi - s0) < kWave ? (hi - s0) : kWave;
             int split = g.count0 - s0;                    // windows of the batch before `split` belong to slot 0
             split = split < 0 ? 0 : (split > nb ? nb : split);
-            if (FACT && (batch % NW) == wave) fact_batch(g, drv, dcv, nb, split);
+            fact_batch(g, drv, dcv, nb, split);
             if (ACC == 2) {
                 run(std::integral_constant<int, 0>{}, g, offv, drv, dcv, 0, split);
                 run(std::integral_constant<int, ACC - 1>{}, g, offv, drv, dcv, split, nb);
@@ -383,8 +433,9 @@ __global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, 
         }
     };
     auto first_coords = [&](int ev, int& wf) __attribute__((always_inline)) {
-        const int start = fld(ev, 2), count = fld(ev, 3);
-        wf = lane < count ? (int)sa.win[start + lane] : 0;
+        int lo, hi;
+        slice_of(fld(ev, 3), lo, hi);
+        wf = load_batch(fld(ev, 2), lo, hi);
     };
     auto cur_of = [&](int ev) __attribute__((always_inline)) -> Cur {
         Cur c;
@@ -464,7 +515,8 @@ __global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, 
         int ev0 = entry_load(bb), ev1 = ev0, ev2 = ev0, evn = ev0;   // entries are consumed one stage after their load was issued
         Raw x1, x2;
         Row rw0, rw1;
-        double v[NRH];
+        int v[NRH];
+        double wc[NH];
         int w0f, w1f = 0;
         {   // prologue: stage block bb without overlap, start the lookups of bb+1
             Raw x0;
@@ -473,25 +525,25 @@ __global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, 
             if (bb + 1 < be) { ev1 = entry_load(bb + 1); load_raw(ev1, x1); }
             if (bb + 2 < be) evn = entry_load(bb + 2);
             rw0 = finish_rows(ev0, x0);
-            issue_values(rw0, v);
+            issue_values(ev0, rw0, v, wc);
             const ExpSel es0 = exp_of(ev0);
             __syncthreads();
-            store_region(ev0, rw0, v, es0);
+            store_region(ev0, rw0, v, wc, es0);
             __syncthreads();
             if (bb + 1 < be) rw1 = finish_rows(ev1, x1);
         }
         for (int b = bb; b < be; ++b) {
             const bool has1 = b + 1 < be, has2 = b + 2 < be;
-            if (has1) { issue_values(rw1, v); first_coords(ev1, w1f); }
+            if (has1) { if (!(sa.debug & 2)) issue_values(ev1, rw1, v, wc); first_coords(ev1, w1f); }
             if (has2) { ev2 = evn; load_raw(ev2, x2); if (b + 3 < be) evn = entry_load(b + 3); }
             const Cur c0 = cur_of(ev0);
-            windows(c0, w0f);
+            if (!(sa.debug & 1)) windows(c0, w0f);
             const int seg0 = fld(ev0, 20);
             if (!has1) { flush(seg0); break; }
             const ExpSel es1 = exp_of(ev1);
             if (fld(ev1, 20) != seg0) flush(seg0);       // (uniform) the next block belongs to another segment
             else __syncthreads();                        // every wave is done reading region b
-            store_region(ev1, rw1, v, es1);
+            if (!(sa.debug & 2)) store_region(ev1, rw1, v, wc, es1);
             __syncthreads();
             ev0 = ev1; w0f = w1f;
             if (has2) { ev1 = ev2; rw1 = finish_rows(ev2, x2); }
@@ -639,7 +691,7 @@ __global__ __launch_bounds__(256) void block_starts_kernel(const KeyT* __restric
 // block table from the compacted block starts (grid-stride: the number of blocks is only known on the device): entry b =
 // region origin, its windows, slot-0 windows, segment and expected region decoded from the key, the staging geometry of the
 // region (see StagedBlock), the row hull of sparse blocks — and the first block of every workgroup's range: workgroup g of
-// the G persistent ones takes the blocks whose first window lies in [g n / G, (g + 1) n / G).
+// the G persistent ones takes an equal share of (windows + kBlockCost per block).
 template <typename KeyT>
 __global__ __launch_bounds__(256) void staged_table_kernel(const unsigned* __restrict__ starts, const unsigned* __restrict__ n_runs,
                                                            long long n, const KeyT* __restrict__ sorted_keys,
@@ -713,9 +765,13 @@ __global__ __launch_bounds__(256) void staged_table_kernel(const unsigned* __res
         }
         for (int q = 0; q < 9; ++q) be.pad[q] = 0;
         blocks[b] = be;
-        // ranges of the persistent workgroups
-        const int g_cur = (int)(((unsigned long long)s * (unsigned long long)G) / (unsigned long long)n);
-        const int g_prev = b == 0 ? -1 : (int)(((unsigned long long)starts[b - 1] * (unsigned long long)G) / (unsigned long long)n);
+        // ranges of the persistent workgroups: equal shares of the call's COST, a block costing its windows plus kBlockCost
+        // window-equivalents for its staging (a range of many sparse blocks would otherwise take far longer than one of a
+        // few dense ones: staging a region is an HBM round trip plus ~2000 clocks of LDS stores, a window ~15 clocks)
+        const unsigned long long total = (unsigned long long)n + (unsigned long long)kBlockCost * (unsigned long long)nr;
+        const int g_cur = (int)((((unsigned long long)s + (unsigned long long)kBlockCost * (unsigned long long)b) * (unsigned long long)G) / total);
+        const int g_prev = b == 0 ? -1 : (int)((((unsigned long long)starts[b - 1] + (unsigned long long)kBlockCost * (unsigned long long)(b - 1)) *
+                                                (unsigned long long)G) / total);
         for (int g = g_prev + 1; g <= g_cur; ++g) wg_first[g] = (int)b;
         if (b + 1 == nr) for (int g = g_cur + 1; g <= G; ++g) wg_first[g] = (int)nr;
     }

@@ -79,7 +79,7 @@ with h5py.File(sys.argv[1], "r") as f:
     rep = {"dtype": str(d.dtype), "shape": list(d.shape), "chunks": list(d.chunks), "compression": d.compression,
            "attrs": {k: (v if isinstance(v, str) else np.asarray(v).tolist()) for k, v in f["attrs"].attrs.items()},
            "groups": sorted(f.keys()),
-           "manifest": json.loads(f["annotation"].attrs["columns"]),
+           "manifest": [{"name": x.decode()} for x in f["annotation/axis0"][...]],
            "hs_format": f["horizontal_stripe_0"].attrs["h5sparse_format"],
            "hs_shape": np.asarray(f["horizontal_stripe_0"].attrs["h5sparse_shape"]).tolist(),
            "coord0": [x.decode() if isinstance(x, bytes) else x for x in f["coordinates_0"][0]]}
@@ -123,6 +123,18 @@ def test_clpy_roundtrip(tmp_path, monkeypatch):
     assert len(lst) == 2 * len(df) and set(lst["norm"]) == {"none"} and "horizontal_stripe" not in lst.columns
     with pytest.raises(ValueError):
         pio.save_pileup_df(path, df, compression="lzf")
+    # the pickle-free column layout of round 2 stays available and reads back the same
+    path2 = str(tmp_path / "cols.clpy")
+    pio.save_pileup_df(path2, df, metadata={"nshifts": 0, "expected": False}, layout="columns")
+    back2 = pio.load_pileup_df(path2)
+    assert list(back2["pair"]) == list(df["pair"]) and back2["flag"].dtype == bool
+    for i in range(len(df)):
+        np.testing.assert_array_equal(back2["num"].iloc[i], df["num"].iloc[i])
+    # mode="a" on a file that does not exist yet creates it; list-valued and None metadata survive
+    path3 = str(tmp_path / "new.clpy")
+    pio.save_pileup_df(path3, df, metadata={"names": ["a", "b"], "view_file": None}, mode="a")
+    back3 = pio.load_pileup_df(path3, skipstripes=True)
+    assert back3["view_file"].iloc[0] is np.False_ or back3["view_file"].iloc[0] is False
 
 
 @pytest.mark.skipif(not os.path.exists(CONDA_PY), reason="needs the image's conda python with h5py")
@@ -154,3 +166,115 @@ def test_clpy_read_by_h5py(tmp_path, monkeypatch):
     from scipy import sparse
     hs = sparse.csr_matrix((z["hs_data"], z["hs_indices"], z["hs_indptr"]), shape=rep["hs_shape"]).toarray()
     np.testing.assert_array_equal(hs, np.asarray(df["horizontal_stripe"].iloc[0], float))
+
+
+# the frame both interpreters build: every kind of column the pile-up output holds (ints, floats with NaN, bools, strings,
+# tuples, per-row integer arrays)
+FRAME_SRC = r"""
+import numpy as np, pandas as pd
+def frame():
+    n = 4
+    return pd.DataFrame({
+        "group": [("+", "-"), ("-", "+"), "all", (0.0, 50000.0)], "orientation": ["+-", "-+", "all", "+-"],
+        "n": np.array([10, 20, 30, 40], np.int64), "flank": np.int64(100000), "resolution": np.int64(10000),
+        "score": [1.5, np.nan, 0.25, 4.0], "expected": False, "store_stripes": False, "flag": [False, True, False, False],
+        "num": [np.arange(9).reshape(3, 3) * (i + 1) for i in range(n)], "name": ["a", "bb", "ccc", ""],
+        "cov_start": [np.linspace(0, 1, 3) for _ in range(n)],
+    })
+"""
+
+PANDAS_COMPARE = r"""
+import sys, pickle, json, warnings
+warnings.simplefilter("ignore")
+import numpy
+numpy.typeDict = numpy.sctypeDict            # PyTables 3.6 of this conda env predates numpy 1.24 (import-time alias only)
+import tables, pandas, h5py
+import pandas.compat._optional as opt
+opt.VERSIONS["tables"] = tables.__version__   # pandas' minimum-version gate; the writer calls are the same
+exec(open(sys.argv[3]).read())
+ref = sys.argv[2]
+frame().to_hdf(ref, key="annotation", mode="w")
+def dump(path):
+    out = {}
+    with h5py.File(path, "r") as f:
+        def node(name, obj):
+            at = {}
+            for k in obj.attrs:
+                aid = h5py.h5a.open(obj.id, k.encode())
+                t, sp = aid.get_type(), aid.get_space()
+                v = obj.attrs[k]
+                at[k] = [int(t.get_class()), int(t.get_size()), int(sp.get_simple_extent_type()),
+                         None if isinstance(v, h5py.Empty) else numpy.asarray(v).tolist()]
+            rec = {"attrs": at}
+            if isinstance(obj, h5py.Dataset):
+                t = obj.id.get_type()
+                rec.update(shape=list(obj.shape), tclass=int(t.get_class()), tsize=int(t.get_size()), maxshape=[m for m in obj.maxshape])
+                if obj.dtype == object:
+                    arr = pickle.loads(obj[0].tobytes())
+                    rec["pickled"] = [[repr(x) for x in row] for row in arr.tolist()] if arr.dtype == object else None
+                    rec["pickled_shape"] = list(arr.shape)
+                else:
+                    rec["data"] = [x.decode() if isinstance(x, bytes) else x for x in numpy.asarray(obj[...]).ravel().tolist()]
+            out[name] = rec
+        node("annotation", f["annotation"])
+        f["annotation"].visititems(lambda n, o: node("annotation/" + n, o))
+        out["/"] = {"attrs": {k: (None if isinstance(f.attrs[k], h5py.Empty) else numpy.asarray(f.attrs[k]).tolist())
+                              for k in ("CLASS", "VERSION", "TITLE", "PYTABLES_FORMAT_VERSION")}}
+    return out
+print(json.dumps({"mine": dump(sys.argv[1]), "pandas": dump(ref)}, default=str))
+"""
+
+
+@pytest.mark.skipif(not os.path.exists(CONDA_PY), reason="needs the image's conda python (pandas + PyTables + h5py)")
+def test_annotation_is_the_store_pandas_writes(tmp_path):
+    """/annotation against the real thing: pandas.DataFrame.to_hdf(..., "annotation") — the call the reference makes
+    (coolpuppy/lib/io.py:47-53) — run in the image's conda interpreter (pandas 2.3 + PyTables 3.6 + h5py), and both files
+    dumped node by node with h5py: same nodes, same shapes and HDF5 type classes / sizes, same PyTables attributes (value,
+    type class, size, dataspace kind), same data, and the pickled object blocks unpickle to the same cells.  Then this
+    package's reader on pandas' own file."""
+    import json
+    from coolpuppy_amd.lib import io as pio
+    src = tmp_path / "frame_src.py"
+    src.write_text(FRAME_SRC)
+    ns = {}
+    exec(FRAME_SRC, ns)
+    df = ns["frame"]()
+    mine, ref = str(tmp_path / "mine.clpy"), str(tmp_path / "pandas.h5")
+    full = df.copy()
+    full["data"] = [np.eye(3) * i for i in range(len(df))]
+    pio.save_pileup_df(mine, full, metadata={})
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PYTHON")}
+    r = subprocess.run([CONDA_PY, "-c", PANDAS_COMPARE, mine, ref, str(src)], capture_output=True, text=True, env=env, timeout=600)
+    if r.returncode != 0 and ("No module named" in r.stderr or "ImportError" in r.stderr):
+        pytest.skip("pandas + PyTables + h5py not usable in the conda interpreter: " + r.stderr[-300:])
+    assert r.returncode == 0, r.stderr[-3000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    a, b = rep["mine"], rep["pandas"]
+    assert a["/"] == b["/"]
+    assert a["annotation"]["attrs"] == b["annotation"]["attrs"]
+    # pandas orders its blocks by its internal manager; match blocks through their item lists
+    def blocks(d):
+        out = {}
+        for k, v in d.items():
+            if k.endswith("_items"):
+                out[tuple(v["data"])] = (v, d[k.replace("_items", "_values")])
+        return out
+    ba, bb = blocks(a), blocks(b)
+    assert set(ba) == set(bb), (sorted(ba), sorted(bb))
+    for key in bb:
+        for x, y in zip(ba[key], bb[key]):
+            assert x == y, (key, x, y)
+    for k in ("annotation/axis0", "annotation/axis1"):
+        assert a[k] == b[k], k
+    # and the other direction: the file pandas wrote, through this package's reader
+    with pio._H5(ref, "r") as h5:
+        back = pio._read_annotation_pytables(h5)
+    assert list(back.columns) == list(df.columns) and len(back) == len(df)
+    for c in df.columns:
+        for i in range(len(df)):
+            x, y = back[c].iloc[i], df[c].iloc[i]
+            if isinstance(y, np.ndarray):
+                np.testing.assert_array_equal(x, y)
+            else:
+                assert x == y or (isinstance(y, float) and np.isnan(y) and np.isnan(x)), (c, i, x, y)
+    assert back["n"].dtype == np.int64 and back["flag"].dtype == bool and list(back["flag"]) == [False, True, False, False] and back["score"].dtype == np.float64

@@ -25,6 +25,20 @@ def test_coverage_exact(hip_lib, oracle_mod, ignore_diags):
         np.testing.assert_array_equal(cis, clr.bins()["cov_cis_raw"][:].values)
 
 
+@pytest.mark.parametrize("ignore_diags", [0, 1, 2, 3])
+def test_coverage_known_answers(hip_lib, ignore_diags):
+    """K3 against hand-derived numbers (tests/coverage_kat.py), not against the package's own numpy restatement."""
+    import coverage_kat as kat
+    from coolpuppy_amd.engine import PileupEngine
+    indptr, col, cnt = kat.table()
+    with PileupEngine(0) as eng:
+        eng.load_pixels(indptr, col, cnt)
+        cis, tot = eng.coverage(kat.CHROM_OFFSET, ignore_diags=ignore_diags)
+    want_cis, want_tot = kat.ANSWERS[ignore_diags]
+    np.testing.assert_array_equal(cis, np.array(want_cis, float))
+    np.testing.assert_array_equal(tot, np.array(want_tot, float))
+
+
 def test_pileup_computes_missing_coverage_column(hip_lib, oracle_mod):
     """coverage_norm=True on a cooler without cov_tot_raw: the column is computed (K3) and stored, and the
     pile-up equals the one obtained with the column supplied up front."""

@@ -138,3 +138,15 @@ def test_library_window_pass_equals_numpy():
     assert np.array_equal(tp, np.concatenate([[0], np.cumsum(np.bincount(tile, minlength=11))]))
     with pytest.raises(ValueError):
         E.group_tiles([(r0[:5], c0[:5], np.array([0, 1, 2, 11, 3], np.int32))], 11)
+
+
+def test_coverage_restatement_matches_hand_derived_answers():
+    """oracle.coverage_numpy against the hand-worked table of tests/coverage_kat.py (cooltools' documented semantics:
+    both bins of a pixel, the diagonal twice, ignore_diags on global ids incl. trans pixels, cis vs total)."""
+    import coverage_kat as kat
+    from oracle import pileup_oracle as po
+    indptr, col, cnt = kat.table()
+    for igd, (cis, tot) in kat.ANSWERS.items():
+        got_cis, got_tot = po.coverage_numpy(indptr, col, cnt, kat.CHROM_OFFSET, igd)
+        np.testing.assert_array_equal(got_cis, np.array(cis, float), err_msg=f"cis, ignore_diags={igd}")
+        np.testing.assert_array_equal(got_tot, np.array(tot, float), err_msg=f"tot, ignore_diags={igd}")

@@ -243,7 +243,7 @@ def test_staged_kernel_many_workgroups(hip_lib, pad):
                         eng.reset(T, pad)
                         eng.accumulate(r0, c0, tile_ptr, ignore_diags=igd, mode=mode)
                         got = eng.fetch()
-                        assert eng.stats()["staged_regions"] > 700
+                        assert eng.stats()["staged_regions"] > 150
                         for k in ("n", "num"):
                             np.testing.assert_array_equal(got[k], want[k], err_msg=f"{label} T={T} mode={mode} variant={variant}")
                         for k in ("sum", "cov_start", "cov_end"):
