@@ -1914,6 +1914,20 @@ def _engine_call(region1, region2, expected, r0, c0, flip, tile, T, igd, mode, e
     return call
 
 
+class _Call(dict):
+    """One engine call of a plan.  The per-window `tile` array follows from `tile_ptr` (windows are grouped by tile); only
+    the oracle replay of the tests and the rare inf-cell merge ask for it, so it is built on first use — np.repeat over
+    1.1e7 windows cost more than the GPU's whole pile-up."""
+
+    def __missing__(self, key):
+        if key != "tile":
+            raise KeyError(key)
+        tp = self["tile_ptr"]
+        val = np.repeat(np.arange(len(tp) - 1, dtype=np.int32), np.diff(tp))
+        self[key] = val
+        return val
+
+
 def _engine_call_parts(region1, region2, expected, parts, T, igd, mode, rescale):
     """_engine_call over the concatenation of per-region parts (r0, c0, flip, tile, h, w) WITHOUT concatenating
     first: each part is grouped by (tile, flip) on its own (cache-sized stable radix sorts), then the segments
@@ -1923,9 +1937,8 @@ def _engine_call_parts(region1, region2, expected, parts, T, igd, mode, rescale)
         # nothing flipped: one stable counting sort of the library over all parts, into page-locked arrays
         from . import engine as _engine
         r0, c0, tile_ptr = _engine.group_tiles([(p[0], p[1], p[3]) for p in parts], T)
-        return {"region1": region1, "region2": region2, "expected": expected, "r0": r0, "c0": c0, "flip": None,
-                "flip_from": None, "tile": np.repeat(np.arange(T, dtype=np.int32), np.diff(tile_ptr)), "tile_ptr": tile_ptr,
-                "ignore_diags": igd, "mode": mode}
+        return _Call({"region1": region1, "region2": region2, "expected": expected, "r0": r0, "c0": c0, "flip": None,
+                      "flip_from": None, "tile_ptr": tile_ptr, "ignore_diags": igd, "mode": mode})
     if len(parts) == 1 or nk >= 65536 or nk * len(parts) > 200_000:
         f = [np.concatenate([p[k] for p in parts]) if len(parts) > 1 else parts[0][k] for k in range(6)]
         return _engine_call(region1, region2, expected, f[0], f[1], f[2], f[3], T, igd, mode,
@@ -2025,7 +2038,8 @@ def iter_expected_subcalls(plan, call):
         else:
             expected = et["vectors"][i] if i < len(et["end"]) else np.array([np.nan, np.nan])
         sub = dict(call)
-        for name in ("r0", "c0", "tile", "flip", "h", "w"):
+        sub["tile"] = call["tile"][sel]                  # (built on first use: _Call)
+        for name in ("r0", "c0", "flip", "h", "w"):
             if call.get(name) is not None:
                 sub[name] = call[name][sel]
         T = len(call["tile_ptr"]) - 1

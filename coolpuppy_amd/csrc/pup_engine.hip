@@ -86,6 +86,7 @@ struct pup_ctx {
     DevBuf<unsigned short> d_win, d_win2;    // window-in-block values before / after the block sort
     DevBuf<pup::StagedBlock> d_blocks;
     DevBuf<int> d_wgfirst;
+    DevBuf<long long> d_timing; int timing_G = 0;
     DevBuf<unsigned char> d_recvalid;
     DevBuf<long long> d_segend;
     DevBuf<unsigned char> d_sorttmp;
@@ -197,16 +198,16 @@ bool tiled_supported(int W) { return W >= 3 && W <= 31 && (W & 1); }
 struct StagedGeo { int RSR, RSC, NW; };
 StagedGeo staged_geometry(int W, bool ooe, bool extra, bool small21) {
     const bool big = W <= 21 && !ooe && !extra && !(small21 && W == 21);
-    return StagedGeo{big ? 128 : 64, 128, 8};
+    return StagedGeo{big ? 128 : 64, 128, big ? 16 : 8};
 }
 // fact: every window is clear of the diagonal mask and nothing is divided by expected -> validity factorises (FACT)
 // extra: coverage vectors and / or pixel statistics ride along (kept out of the plain instantiation's window loop)
 template <int W, bool OOE, int ACC, bool FACT, bool EXTRA>
 void launch_staged___(const pup::K1Args& a, const pup::StagedArgs& sa, int G, bool small21, hipStream_t s) {
-    using Geo = pup::StagedGeom<W, OOE, EXTRA>;
+    using Geo = pup::StagedGeom<W, OOE, EXTRA, false, FACT>;
     if constexpr (W == 21 && !OOE && !EXTRA) {          // tuning probe (variant bit 7): the plain 21-bin kernel on 64 x 128 regions
         if (small21) {
-            using GeoS = pup::StagedGeom<W, OOE, EXTRA, true>;
+            using GeoS = pup::StagedGeom<W, OOE, EXTRA, true, FACT>;
             hipLaunchKernelGGL((pup::pileup_staged_kernel<W, OOE, GeoS::RSR, GeoS::RSC, GeoS::NW, ACC, FACT, EXTRA>), dim3(G),
                                dim3(pup::kWave * GeoS::NW), 0, s, a, sa);
             return;
@@ -715,6 +716,7 @@ static void fill_k1_args(pup_ctx* c, pup::K1Args& a, int32_t ignore_diags, uint3
     a.exp_pair = c->have_exp_pair ? c->exp_pair.p : nullptr;
     a.part_f64 = c->part_f64.p; a.part_num = c->part_num.p;
     a.counters = c->count_pixels ? c->counters.p : nullptr; a.err = c->d_err.p;
+    a.nf_pixels = c->nf_count > 0 ? 1 : 0; a.nnz = c->nnz;
     a.W = c->W; a.ignore_diags = ignore_diags; a.mode = mode;
 }
 
@@ -729,6 +731,8 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     if (forbid || rescale || (mode & (PUP_MODE_EXPECTED | PUP_MODE_TRANSPOSE)) || (c->variant & 2) || !use_idx_t ||
         ignore_diags < 0 || !tiled_supported(W) || n >= 0x7fffffffLL || !(force || n >= c->tiled_min) ||
         2 * T > pup::kMaxSegCount || T > pup::kMaxStagedTiles || !c->bin_chrom.p || !c->h_flags || !c->ev_key ||
+        c->nnz + 64 >= (1LL << 30) ||                    // the staged kernel addresses the count table by 32-bit byte offsets
+
         (int)c->h_chroms.size() != c->n_chrom)
         return 1;
     const bool extra = ((mode & PUP_MODE_COV) && c->have_cov) || c->count_pixels;
@@ -879,7 +883,20 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     fill_k1_args(c, a, ignore_diags, mode);
     pup::StagedArgs sa{};
     sa.blocks = c->d_blocks.p; sa.win = c->d_win2.p; sa.wg_first = c->d_wgfirst.p; sa.U = U; sa.rec_valid = c->d_recvalid.p;
-    sa.debug = c->debug_phases;                          // timing experiments (tools/k1_probe.py): variant bits 24 / 25
+    {   // paired tiles: the waves of a workgroup split into two teams in proportion to the windows of the two halves
+        long long n_first = 0;
+        for (int t = 0; t < H; ++t) n_first += tile_ptr[t + 1] - tile_ptr[t];
+        const int nw = (geo.NW == 16 && !fact) ? 8 : geo.NW;      // (StagedGeom: 16 waves only with factorised counts)
+        const int n0 = (int)((n_first * nw + n - 1) / std::max<long long>(n, 1));
+        sa.n0 = paired ? std::min(std::max(n0, 1), nw - 1) : 0;
+    }
+    sa.debug = c->debug_phases & 3;
+    sa.timing = nullptr;
+    if (c->debug_phases & 4) {                           // phase clocks (diagnostics): [G][16][8] long long, read by pup_debug_timing
+        HIPCHK(c, c->d_timing.reserve((size_t)G * 16 * 8));
+        HIPCHK(c, hipMemsetAsync(c->d_timing.p, 0, (size_t)G * 16 * 8 * sizeof(long long), c->stream));
+        sa.timing = c->d_timing.p; c->timing_G = G;
+    }                          // timing experiments (tools/k1_probe.py): variant bits 24 / 25
     if (ev) HIPCHK(c, hipEventRecord(ev[1], c->stream));
     if (!launch_staged(W, a, sa, G, ACC, fact, extra, small21, c->stream))
         return fail(c, PUP_ENOTSUP, "pup_accumulate: staged kernel not built for W=%d", W);
@@ -1311,6 +1328,7 @@ int pup_stripes(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, int
         a.exp_regions = c->n_exp_regions > 0 ? c->exp_regions.p : nullptr; a.n_exp_regions = c->n_exp_regions;
         a.exp_pair = c->have_exp_pair ? c->exp_pair.p : nullptr;
         a.r0 = c->d_r0.p; a.c0 = c->d_c0.p; a.err = c->d_err.p;
+        a.nf_pixels = c->nf_count > 0 ? 1 : 0;
         a.W = W; a.ignore_diags = ignore_diags; a.mode = mode;
         const unsigned grid = (unsigned)std::min<int64_t>(n, 65536);
         hipLaunchKernelGGL(pup::stripes_kernel, dim3(grid), dim3(pup::kWave), 0, c->stream, a, (long long)n,
@@ -1374,6 +1392,7 @@ int pup_extract(pup_ctx* c, const int32_t* r0, const int32_t* c0, const int32_t*
         a.exp_regions = c->n_exp_regions > 0 ? c->exp_regions.p : nullptr; a.n_exp_regions = c->n_exp_regions;
         a.exp_pair = c->have_exp_pair ? c->exp_pair.p : nullptr;
         a.r0 = c->d_r0.p; a.c0 = c->d_c0.p; a.err = c->d_err.p; a.counters = c->counters.p;
+        a.nf_pixels = c->nf_count > 0 ? 1 : 0;
         a.W = W; a.ignore_diags = ignore_diags; a.mode = mode;
         const unsigned grid = (unsigned)std::min<int64_t>(n, 16384);
         if (rescale) {
@@ -1577,6 +1596,16 @@ int pup_event_record(pup_ctx* c, int slot) {
     return PUP_OK;
 }
 
+int pup_debug_timing(pup_ctx* c, int64_t* out, int64_t cap) {
+    if (!c || !out) return PUP_EINVAL;
+    int rc = pup_sync(c); if (rc) return rc;
+    const int64_t n = (int64_t)c->timing_G * 16 * 8;
+    if (n == 0 || !c->d_timing.p) return 0;
+    if (cap < n) return fail(c, PUP_ERANGE, "pup_debug_timing: needs room for %lld values", (long long)n);
+    HIPCHK(c, hipMemcpy(out, c->d_timing.p, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost));
+    return (int)c->timing_G;
+}
+
 int pup_event_elapsed_ms(pup_ctx* c, int a, int b, float* ms) {
     if (!c || !ms) return PUP_EINVAL;
     if (a < 0 || a >= 8 || b < 0 || b >= 8) return fail(c, PUP_EINVAL, "pup_event_elapsed_ms: bad slot");
@@ -1590,7 +1619,7 @@ int pup_set_tuning(pup_ctx* c, int32_t chunk_snippets, int32_t variant) {
     if (!c) return PUP_EINVAL;
     if (chunk_snippets < 0) return fail(c, PUP_EINVAL, "pup_set_tuning: negative chunk size");
     c->chunk_snippets = chunk_snippets; c->variant = variant & 0xff; c->group_waves = (variant >> 8) & 0xffff;
-    c->debug_phases = (variant >> 24) & 3;
+    c->debug_phases = (variant >> 24) & 7;
     return PUP_OK;
 }
 

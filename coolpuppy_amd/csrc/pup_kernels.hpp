@@ -107,6 +107,10 @@ struct K1Args {
     // diagnostics
     unsigned long long* counters;  // [0] pixels inside windows, [1] search probes
     int*                err;       // set to 1 when a window leaves the bin table
+    long long nnz;                 // pixels in the table (cnt32 / bal are padded by 64 zeros from here on)
+    int      nf_pixels;            // != 0: some pixels have a non-finite balanced value although both their weights are numbers
+                                   //       (weights of +-inf): per-snippet outputs then multiply count * w[row] * w[col] out
+                                   //       themselves — `bal` stores NaN products as 0 (see lookup_bal)
     int      W;
     int      ignore_diags;         // < 0: no diagonal mask
     unsigned mode;                 // PUP_MODE_* bits
@@ -1066,6 +1070,14 @@ __global__ __launch_bounds__(kWave, 3) void pileup_band_kernel(K1Args a) {
 // millions, so the gather is not staged.
 struct RsGeom { int ch_start, ch_end, ch_nblk; long long ch_base; bool have; };
 
+// balanced value of the stored pixel at `pos` as a per-snippet output shows it: the `bal` table — except when the weight
+// column holds +-inf: cooler multiplies such pixels out to +-inf or NaN (0 * inf) and the reference's windows carry exactly
+// that (coolpuppy/coolpup.py:1115-1123), while `bal` keeps NaN products as 0 for the accumulating kernels
+__device__ __forceinline__ double pixel_value(const K1Args& a, long long pos, int row, int col) {
+    if (a.nf_pixels && a.weight) return (double)a.cnt32[pos] * a.weight[row] * a.weight[col];
+    return a.bal[pos];
+}
+
 __device__ __forceinline__ double lookup_bal(const K1Args& a, const RsGeom& g, int row, int col) {
     if (g.have && row >= g.ch_start && row < g.ch_end && col >= g.ch_start && col < g.ch_end) {
         const int rel = col - g.ch_start;
@@ -1076,12 +1088,12 @@ __device__ __forceinline__ double lookup_bal(const K1Args& a, const RsGeom& g, i
         if (!((wbits >> sh) & 1ull)) return 0.0;
         const unsigned cum = ws ? blk->cum[ws - 1] : 0u;
         const long long pos = (long long)(blk->pos + cum + (unsigned long long)__popcll(wbits & ((1ull << sh) - 1ull)));
-        return a.bal[pos];
+        return pixel_value(a, pos, row, col);
     }
     long long lo = a.indptr[row], hi = a.indptr[row + 1];
     const long long end = hi;
     while (lo < hi) { const long long m = (lo + hi) >> 1; if (a.px[m].x < col) lo = m + 1; else hi = m; }
-    return (lo < end && a.px[lo].x == col) ? a.bal[lo] : 0.0;
+    return (lo < end && a.px[lo].x == col) ? pixel_value(a, lo, row, col) : 0.0;
 }
 
 __device__ __forceinline__ bool bin_bad(const K1Args& a, int bin) { return (a.badbits[bin >> 6] >> (bin & 63)) & 1ull; }
@@ -1523,11 +1535,12 @@ __global__ __launch_bounds__(512) void coverage_kernel(const long long* __restri
 // (coolpup.py:1164-1169): horizontal = data[pad, :], vertical = data[:, pad][::-1].  Output is O(n*W), not a
 // reduction: one wave per snippet, lanes 0..W-1 look up the row cells, lanes W..2W-1 the column cells, each by a
 // binary search of its matrix row (2W cells per snippet: the index would save nothing worth its code here).
-__device__ __forceinline__ int find_count(const K1Args& a, int row, int col) {
+__device__ __forceinline__ int find_count(const K1Args& a, int row, int col, bool& found) {
     long long lo = a.indptr[row], hi = a.indptr[row + 1];
     const long long end = hi;
     while (lo < hi) { const long long m = (lo + hi) >> 1; if (a.px[m].x < col) lo = m + 1; else hi = m; }
-    return (lo < end && a.px[lo].x == col) ? a.px[lo].y : 0;
+    found = lo < end && a.px[lo].x == col;
+    return found ? a.px[lo].y : 0;
 }
 
 __global__ __launch_bounds__(kWave) void stripes_kernel(K1Args a, long long n, double* __restrict__ h_out,
@@ -1555,10 +1568,13 @@ __global__ __launch_bounds__(kWave) void stripes_kernel(K1Args a, long long n, d
             if (!m_tr) { p = horiz ? pad : (W - 1 - i); q = horiz ? i : pad; }
             else       { p = horiz ? i : pad;           q = horiz ? pad : (W - 1 - i); }
             const int row = r0s + p, col = c0s + q;
-            double v = (double)find_count(a, row, col);
+            bool found;
+            double v = (double)find_count(a, row, col, found);
             if (a.weight) {
                 const double wr = a.weight[row], wc = a.weight[col];
-                v = (wr == wr && wc == wc) ? (v != 0.0 ? v * wr * wc : 0.0) : qn;
+                // cooler multiplies stored pixels out (a stored 0 next to an infinite weight is NaN); cells without a
+                // stored pixel are 0 whatever the weights
+                v = (wr == wr && wc == wc) ? (found ? v * wr * wc : 0.0) : qn;
             }
             if (a.ignore_diags >= 0 && (col - row) < a.ignore_diags) v = qn;
             if (m_ooe) { long long ad = (long long)col - row; if (ad < 0) ad = -ad; v = v / es.at(ad); }

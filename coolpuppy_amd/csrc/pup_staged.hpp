@@ -60,7 +60,10 @@ struct StagedArgs {
     const int*            wg_first;   // [G + 1] first block of every workgroup's range
     int                   U;          // pass units (tile pairs, or tiles when unpaired)
     unsigned char*        rec_valid;  // [ACC * U * 2 * G] set when record ((slot * U + unit) * 2 + flip) * G + workgroup was written
+    int                   n0;         // paired tiles: waves [0, n0) pile up the windows of a pair's first tile (slot 0), the
+                                      // others those of its second — in proportion to the two tiles' window counts
     int                   debug;      // timing experiments only (results are wrong): 1 = skip the window loop, 2 = skip the staging
+    long long*            timing;     // phase clocks per wave, [G][NW][8] (tools/k1_probe.py --phases), or nullptr
 };
 
 constexpr int kWinShift = 7;                          // bits of dr / dc in a window value
@@ -73,19 +76,27 @@ __device__ __forceinline__ void lds_read2_b32(unsigned long long& dst, unsigned 
     asm volatile("ds_read2_b32 %0, %1 offset0:0 offset1:1" : "=&v"(dst) : "v"(addr));
 }
 __device__ __forceinline__ void lds_pin_u64(unsigned long long& v) { asm volatile("" : "+v"(v)); }
+// wait until at most N LDS operations of this wave are outstanding (they return in order: everything older is complete);
+// the address registers of the reads waited for stay untouched until here (see lds_wait_all in pup_kernels.hpp)
+template <int N>
+__device__ __forceinline__ void lds_wait_but(unsigned a0, unsigned a1) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" :: "v"(a0), "v"(a1), "n"(N) : "memory");
+}
 
 // geometry of an instantiation (host and device agree through these)
 template <int W> constexpr bool staged_big() { return W <= 21; }      // 128 x 128 regions, 16 waves: register budget of CH <= 7 cells
-template <int W, bool OOE, bool EXTRA, bool SMALL = false> struct StagedGeom {
+template <int W, bool OOE, bool EXTRA, bool SMALL = false, bool FACT = true> struct StagedGeom {
     static constexpr bool big = staged_big<W>() && !OOE && !EXTRA && !SMALL;
     static constexpr int RSR = big ? 128 : 64;
     static constexpr int RSC = 128;
-    static constexpr int NW  = 8;                        // 8 waves of up to 256 registers: the prefetched next region (counts,
-                                                         // index words, row descriptors) stays in registers across the window loop
+    static constexpr int NW  = (big && FACT) ? 16 : 8;   // 16 waves of 128 registers where the kernel fits them (factorised
+                                                         // counts, one accumulator set per wave); the other instantiations
+                                                         // need up to 256 registers: 8 waves on the same regions
 };
 
 template <int W, bool OOE, int RSR, int RSC, int NW, int ACC, bool FACT, bool EXTRA>
-__global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, StagedArgs sa) {
+__global__ __launch_bounds__(kWave * NW, (RSR == 64 && NW == 8 && FACT && !OOE && !EXTRA && W <= 21) ? 2 : 1)
+void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     static_assert(W >= 3 && W <= 31, "workgroup-staged kernel serves windows of 3..31 bins");
     static_assert(!(FACT && OOE), "factorised counting needs validity to factorise into row and column masks");
     static_assert(ACC == 1 || ACC == 2, "one or two accumulator sets");
@@ -100,13 +111,12 @@ __global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, 
     constexpr int NRH = RPW * NH;                        // row halves staged by each wave: one lane each in the lookup phase
     constexpr int NTHR = kWave * NW;
     constexpr int VBW = NH + 1;                          // validity words per row (+1: the dword-pair read may run one dword over)
-    constexpr int WIF = (NTHR <= 512 && CH <= 7 && FACT && !EXTRA) ? 4 : 2;   // windows in flight per wave (register budget)
-    static_assert(NRH <= 32, "row halves of a wave must fit the value registers");
+    static_assert(NRH <= 32 && RPW <= 32, "row halves of a wave must fit the value registers");
     static_assert((size_t)NW / 2 * CH * kWave * 12 <= (size_t)RSR * LS * 8, "merge scratch must fit the region buffer");
     __shared__ double tile[RSR * LS];
     __shared__ unsigned long long vbits[FACT ? 1 : RSR * VBW];      // bit c of row r: cell (r, c) counts in num
     __shared__ unsigned long long pbits[EXTRA ? RSR * VBW : 1];     // bit c: cell holds a pixel (statistics only)
-    __shared__ double cov_lds[EXTRA ? NW : 1][ACC][2 * W];
+    __shared__ double cov_lds[EXTRA ? NW : 1][2 * W];
     // FACT: num[p][q] = N - R[p] - C[q] + RC[p][q] (see fact_batch): the sparse both-masked pairs, and the totals
     __shared__ unsigned rc_lds[ACC][FACT ? W2 : 1];
     __shared__ unsigned fact_tot[FACT ? ACC * (2 * W + 1) : 1];     // per slot: R[W] | C[W] | N
@@ -130,14 +140,29 @@ __global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, 
     const int G = (int)gridDim.x, g_id = (int)blockIdx.x;
     const int bb = sa.wg_first[g_id], be = sa.wg_first[g_id + 1];   // blocks [bb, be) of the block table
     if (bb >= be) return;                                // (uniform) more workgroups than blocks
-    double   sum[ACC][CH];
-    unsigned num[ACC][CH];
+    // ONE accumulator set per wave.  With paired tiles (ACC == 2) the waves split into two teams — waves [0, n0) take a
+    // block's slot-0 windows (the pair's first tile: they come first in a block, stable sort), the others its slot-1
+    // windows — sized by the host to the tiles' shares of the call's windows.  (Two sets per wave, round 2's way, cost
+    // 2 * CH more double registers: the difference between 16 and 8 waves per CU, and a wave may have at most 15 LDS
+    // reads in flight — it takes 16 waves to keep the LDS busy.)
+    const int my_slot = (ACC == 2 && wave >= sa.n0) ? 1 : 0;
+    const int team_lo = ACC == 2 ? (my_slot ? sa.n0 : 0) : 0, team_n = ACC == 2 ? (my_slot ? NW - sa.n0 : sa.n0) : NW;
+    const float team_inv = 1.0f / (float)(team_n > 0 ? team_n : 1);
+    double   sum[CH];
+    unsigned num[CH];
+    // the SIMD favours its oldest wave; left alone the youngest of the four finishes its (equal) share of a block's windows
+    // 40 % later than the oldest and everybody waits for it at the barrier (phase clocks, round 3): priorities against age
+    // (uniform) 0 = the oldest wave of its SIMD.  The priorities are swapped half way through every block's windows (see
+    // `windows`): favoured first, then disfavoured, or the other way round — the four waves of a SIMD finish together
+    const int age = NW == 16 ? (wave >> 2) : (NW == 8 ? 2 * (wave >> 2) : 0);
+    auto set_prio = [&](int pr) __attribute__((always_inline)) {
+        if (pr == 0) __builtin_amdgcn_s_setprio(0); else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+        else if (pr == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
+    };
     auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int s = 0; s < ACC; ++s)
-#pragma unroll
-            for (int i = 0; i < CH; ++i) { sum[s][i] = 0.0; num[s][i] = 0u; }
-        if (m_cov) for (int t = lane; t < ACC * 2 * W; t += kWave) (&cov_lds[wave][0][0])[t] = 0.0;
+        for (int i = 0; i < CH; ++i) { sum[i] = 0.0; num[i] = 0u; }
+        if (m_cov) for (int t = lane; t < 2 * W; t += kWave) cov_lds[wave][t] = 0.0;
         if constexpr (FACT) {                            // visible after the next barrier
             for (int t = tid; t < ACC * W2; t += NTHR) (&rc_lds[0][0])[t] = 0u;
             for (int t = tid; t < ACC * (2 * W + 1); t += NTHR) fact_tot[t] = 0u;
@@ -151,8 +176,15 @@ __global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, 
     unsigned long long npix = 0;
 
     // ---- staging, in pieces (see the pipeline in the block loop) ----------------------------------------------------
-    struct Raw { U64x2 h, w; unsigned long long rw; double wr; };          // lane i < NRH: index words of the wave's i-th row half, its row's weight
-    struct Row { unsigned long long bits, keep, okn; long long pos; double wr; };   // lane i < NRH: what they amount to
+    // A lane i < RPW looks up row i of the wave's RPW region rows (both 64-column halves); what the row amounts to is then
+    // handed to all lanes with readlanes, row by row.  VALU instructions are what the staging costs (counters, round 3:
+    // half of the kernel's VALU work was staging), so everything that is uniform per (row, half) is worked out on the
+    // SCALAR unit from the broadcast words: the position of half 1's first pixel (half 0's + popcount of its bits), the
+    // keep mask (column mask of the table entry, masked-row bit, diagonal mask) — and the mask is applied to the LOAD
+    // ADDRESS: a lane without a pixel to keep fetches the zero that pads the count table, so the stored value needs no
+    // select at all.
+    struct Raw { U64x2 h, w[NH]; unsigned long long rw; double wr; };      // lane i < RPW: index words of the wave's i-th row, its weight
+    struct Row { unsigned long long bits[NH], okn[NH]; long long pos; double wr; };    // lane i < RPW: what they amount to
     auto entry_load = [&](int b) __attribute__((always_inline)) -> int {
         return reinterpret_cast<const int*>(blocks + b)[lane & 31];
     };
@@ -160,65 +192,88 @@ __global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, 
     auto fld64 = [&](int ev, int i) __attribute__((always_inline)) -> unsigned long long {
         return ((unsigned long long)(unsigned)fld(ev, i + 1) << 32) | (unsigned)fld(ev, i);
     };
-    // the row half this lane looks up: row my_rr of the region, columns [64 * my_h, 64 * my_h + 64)
-    const int my_rh = lane < NRH ? lane : 0;
-    const int my_rr = wave * RPW + my_rh / NH;
-    const int my_h  = my_rh % NH;
+    const bool nf = a.nf_pixels != 0;                    // (uniform) weights of +-inf in the table: products may be NaN
+    const int my_rr = wave * RPW + (lane < RPW ? lane : 0);      // the region row this lane looks up
     auto load_raw = [&](int ev, Raw& x) __attribute__((always_inline)) {
-        x.h.a = 0ull; x.h.b = 0ull; x.w.a = 0ull; x.w.b = 0ull; x.rw = ~0ull; x.wr = 1.0;
+        x.h.a = 0ull; x.h.b = 0ull; x.rw = ~0ull; x.wr = 1.0;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) { x.w[h].a = 0ull; x.w[h].b = 0ull; }
         const int R = fld(ev, 0), ch_end = fld(ev, 6), nblk = fld(ev, 7), row_lo = fld(ev, 21), row_hi = fld(ev, 22);
-        const unsigned l0 = (NH == 2 && my_h) ? (unsigned)fld(ev, 9) : (unsigned)fld(ev, 8);
-        const unsigned wsh = (NH == 2 && my_h) ? (unsigned)fld(ev, 11) : (unsigned)fld(ev, 10);
         const int row = R + my_rr;
-        if (lane < NRH && row < ch_end && my_rr >= row_lo && my_rr < row_hi) {
-            const char* line = reinterpret_cast<const char*>(a.idx + l0 + (long long)my_rr * nblk);
-            x.h = *reinterpret_cast<const U64x2*>(line);                               // {pos, cum[4]}
-            x.w = *reinterpret_cast<const U64x2*>(line + 16 + 8 * (int)(wsh & 0xffu)); // {bits[ws], bits[ws+1] | next0}
+        if (lane < RPW && row < ch_end && my_rr >= row_lo && my_rr < row_hi) {
+            const char* line = reinterpret_cast<const char*>(a.idx + (unsigned)fld(ev, 8) + (long long)my_rr * nblk);
+            x.h = *reinterpret_cast<const U64x2*>(line);                                   // {pos, cum[4]}
+            x.w[0] = *reinterpret_cast<const U64x2*>(line + 16 + 8 * (int)((unsigned)fld(ev, 10) & 0xffu));   // {bits[ws], bits[ws+1] | next0}
+            if constexpr (NH == 2) {
+                const char* line1 = reinterpret_cast<const char*>(a.idx + (unsigned)fld(ev, 9) + (long long)my_rr * nblk);
+                x.w[1] = *reinterpret_cast<const U64x2*>(line1 + 16 + 8 * (int)((unsigned)fld(ev, 11) & 0xffu));
+            }
             if (!FACT) x.rw = a.badbits[row >> 6];
             if (a.weight) x.wr = a.weight[row];
         }
     };
-    auto finish_rows = [&](int ev, const Raw& x) __attribute__((always_inline)) -> Row {
-        Row r;
-        const int R = fld(ev, 0), C = fld(ev, 1), ch_end = fld(ev, 6), row_lo = fld(ev, 21), row_hi = fld(ev, 22);
-        const unsigned wsh = (NH == 2 && my_h) ? (unsigned)fld(ev, 11) : (unsigned)fld(ev, 10);
-        const unsigned long long colok = (NH == 2 && my_h) ? fld64(ev, 14) : fld64(ev, 12);
-        const int ws = (int)(wsh & 0xffu), sh = (int)(wsh >> 8);
-        const int row = R + my_rr;
-        const bool live = lane < NRH && row < ch_end && my_rr >= row_lo && my_rr < row_hi;
-        r.bits = x.w.a >> sh;
-        if (sh) r.bits |= x.w.b << (64 - sh);
-        const unsigned cum = ws ? (unsigned)(x.h.b >> ((ws - 1) * 16)) & 0xffffu : 0u;
-        r.pos = (long long)(x.h.a + cum + (unsigned long long)__popcll(x.w.a & ((1ull << sh) - 1ull)));
-        unsigned long long ok = ((x.rw >> (row & 63)) & 1ull) ? 0ull : colok;
+    // unmasked cells of (region row rr, half h): column mask of the table entry, masked-row bit, diagonal mask — uniform
+    auto ok_mask = [&](int ev, int rr, int h, bool row_bad) __attribute__((always_inline)) -> unsigned long long {
+        unsigned long long ok = row_bad ? 0ull : fld64(ev, 12 + 2 * h);
         if (igd >= 0) {
-            const int t0 = igd - (C + 64 * my_h - row);  // column C + 64 h + l is on or above the first kept diagonal iff l >= t0
+            const int t0 = igd - (fld(ev, 1) + 64 * h - (fld(ev, 0) + rr));   // column C + 64 h + l is on or above the first kept diagonal iff l >= t0
             ok &= t0 <= 0 ? ~0ull : (t0 >= 64 ? 0ull : ~((1ull << t0) - 1ull));
         }
-        if (!live) { r.bits = 0ull; ok = 0ull; r.pos = 0; }
-        // FACT: every window of the call is clear of the diagonal mask and `bal` is 0 on masked bins: a cell holds its
-        // pixel's value or 0, no mask needed; validity is counted from the row / column masks instead
-        r.okn = ok; r.keep = FACT ? r.bits : (r.bits & ok);
-        r.wr = x.wr;
+        return ok;
+    };
+    auto finish_rows = [&](int ev, const Raw& x) __attribute__((always_inline)) -> Row {
+        Row r;
+        const int R = fld(ev, 0), ch_end = fld(ev, 6), row_lo = fld(ev, 21), row_hi = fld(ev, 22);
+        const int row = R + my_rr;
+        const bool live = lane < RPW && row < ch_end && my_rr >= row_lo && my_rr < row_hi;
+        const bool row_bad = (x.rw >> (row & 63)) & 1ull;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const unsigned wsh = (unsigned)fld(ev, 10 + h);
+            const int sh = (int)(wsh >> 8);
+            r.bits[h] = x.w[h].a >> sh;
+            if (sh) r.bits[h] |= x.w[h].b << (64 - sh);
+            r.okn[h] = ok_mask(ev, my_rr, h, row_bad);   // (per lane here: my_rr differs by lane; kept for the validity words)
+            if (!live) { r.bits[h] = 0ull; r.okn[h] = 0ull; }
+        }
+        const unsigned wsh0 = (unsigned)fld(ev, 10);
+        const int ws = (int)(wsh0 & 0xffu), sh0 = (int)(wsh0 >> 8);
+        const unsigned cum = ws ? (unsigned)(x.h.b >> ((ws - 1) * 16)) & 0xffffu : 0u;
+        r.pos = live ? (long long)(x.h.a + cum + (unsigned long long)__popcll(x.w[0].a & ((1ull << sh0) - 1ull))) : 0;
+        // a NaN weight (masked bin) contributes 0, as in the `bal` table — unless the table holds infinite weights, whose
+        // products cooler leaves as inf / NaN: those are sorted out value by value (store_region)
+        r.wr = (nf || x.wr == x.wr) ? x.wr : 0.0;
         return r;
     };
     auto bcast64 = [&](unsigned long long v, int i) __attribute__((always_inline)) -> unsigned long long {
         const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, i), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), i);
         return ((unsigned long long)hi << 32) | lo;
     };
-    // the pixels of the region are fetched as their 4-byte COUNTS and balanced here, (count * w[row]) * w[col] in the order
-    // balance_pixels_kernel (and cooler) multiplies, NaN -> 0: the same doubles as the resident `bal` table at half the HBM
+    // the pixels of the region are fetched as their 4-byte COUNTS and balanced at store time, (count * w[row]) * w[col] in
+    // the order balance_pixels_kernel (and cooler) multiplies: the same doubles as the resident `bal` table at half the HBM
     // bytes — with 128 x 128 regions the kernel is bound by what it pulls from HBM (round 2, at 64 x 64, it was not)
     auto issue_values = [&](int ev, const Row& r, int (&v)[NRH], double (&wc)[NH]) __attribute__((always_inline)) {
+        // pixel positions as 32-bit BYTE offsets from the table's base (the engine only stages tables below 2^30 pixels):
+        // one add, one select, one shift per lane and half, and a load with scalar base + 32-bit vector offset
+        const unsigned zero_at = (unsigned)a.nnz;        // cnt32[nnz .. nnz + 63] are zeros
+        const char* cbase = reinterpret_cast<const char*>(a.cnt32);
 #pragma unroll
-        for (int i = 0; i < NRH; ++i) {
-            const unsigned long long bits = bcast64(r.bits, i);
-            const long long pos = (long long)bcast64((unsigned long long)r.pos, i);
-            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bits >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bits, 0u));
-            // unconditional (a branch around an element of a register array makes hipcc copy — and spill — the whole array at
-            // the join): cnt32 is padded, a lane without a pixel reads a neighbour that is then discarded; a row half outside
-            // the staged rows has bits == 0 and pos == 0 and reads the table's first line
-            v[i] = a.cnt32[pos + rank];
+        for (int i = 0; i < RPW; ++i) {
+            const int rr = wave * RPW + i;
+            unsigned pos = (unsigned)__builtin_amdgcn_readlane((unsigned)r.pos, i);
+            const bool row_bad = !FACT && ((fld64(ev, 16 + 2 * (rr >> 6)) >> (rr & 63)) & 1ull);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const unsigned long long bits = bcast64(r.bits[h], i);
+                // FACT: validity is counted elsewhere and masked bins multiply to 0 — only the columns past the chromosome's
+                // end (whose "bits" belong to another row) must go; else the full mask
+                const unsigned long long keep = bits & (FACT ? fld64(ev, 12 + 2 * h) : ok_mask(ev, rr, h, row_bad));
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bits >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bits, 0u));
+                const bool has = __builtin_amdgcn_inverse_ballot_w64(keep);
+                const unsigned off = (has ? pos + rank : zero_at) << 2;
+                v[i * NH + h] = *reinterpret_cast<const int*>(cbase + off);
+                pos += (unsigned)__builtin_popcountll(bits);     // (scalar) half 1's pixels follow half 0's
+            }
         }
         // column weights (1.0 when raw — branch-free: the load then reads the row offsets, a table of the same length)
         const int C = fld(ev, 1);
@@ -227,7 +282,7 @@ __global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, 
         for (int h = 0; h < NH; ++h) {
             const long long col = (long long)C + 64 * h + lane;
             const double w = wsrc[col < a.nbins ? col : a.nbins - 1];                 // (columns past the table are in no window)
-            wc[h] = a.weight ? w : 1.0;
+            wc[h] = a.weight ? ((nf || w == w) ? w : 0.0) : 1.0;
         }
     };
     auto exp_of = [&](int ev) -> ExpSel {
@@ -244,38 +299,42 @@ __global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, 
         if (er >= 0 && er < a.n_exp_regions) { const ExpRegion g = a.exp_regions[er]; es.base = a.expv + g.off; es.len = g.len; }
         return es;
     };
-    auto store_region = [&](int ev, Row& r, const int (&v)[NRH], const double (&wc)[NH], const ExpSel& es) __attribute__((always_inline)) {
+    auto store_region = [&](auto nf_tag, int ev, Row& r, const int (&v)[NRH], const double (&wc)[NH], const ExpSel& es) __attribute__((always_inline)) {
+        constexpr bool NFP = decltype(nf_tag)::value;    // the table holds infinite weights: NaN products are stored as 0
         const int R = fld(ev, 0), C = fld(ev, 1), row_lo = fld(ev, 21), row_hi = fld(ev, 22);
 #pragma unroll
-        for (int i = 0; i < NRH; ++i) {
-            const int rr = wave * RPW + i / NH;
-            const int hh = i % NH;
+        for (int i = 0; i < RPW; ++i) {
+            const int rr = wave * RPW + i;
             if (rr < row_lo || rr >= row_hi) continue;   // (uniform) no window of the block reads this row
-            const bool keep = __builtin_amdgcn_inverse_ballot_w64(bcast64(r.keep, i));
-            // balanced value (raw: both weights are 1.0); NaN (a masked bin) is stored as 0
             const double wr = __longlong_as_double((long long)bcast64((unsigned long long)__double_as_longlong(r.wr), i));
-            double val = (double)v[i] * wr * wc[hh];
-            val = (val == val) ? val : 0.0;
-            bool good = keep;
-            if (OOE) {
-                const int row = R + rr;
-                long long ad = (long long)(C + 64 * hh + lane) - row; if (ad < 0) ad = -ad;
-                const double e = use_exp ? es.at(ad) : qnan;
-                val = val / e;
-                good = keep && (val == val);            // NaN quotients are skipped, inf is kept
-                // usable expected = neither NaN nor zero.  The predicate goes through a register the compiler cannot see
-                // through: hipcc (ROCm 7.2) folds __ballot(e == e && e != 0.0) — and the equivalent v_cmp_class test —
-                // into v_cmp_neq_f64, the UNORDERED not-equal, which lets NaN pass
-                int e_ok = (e == e && e != 0.0) ? 1 : 0;
-                asm volatile("" : "+v"(e_ok));
-                const unsigned long long eok = __ballot(e_ok);
-                if (lane == i) r.okn &= eok;
+#pragma unroll
+            for (int hh = 0; hh < NH; ++hh) {
+                // balanced value (raw: both weights are 1.0; lanes with nothing to keep loaded a zero count)
+                double val = (double)v[i * NH + hh] * wr * wc[hh];
+                if (NFP) val = (val == val) ? val : 0.0;
+                if (OOE) {
+                    const int row = R + rr;
+                    long long ad = (long long)(C + 64 * hh + lane) - row; if (ad < 0) ad = -ad;
+                    const double e = use_exp ? es.at(ad) : qnan;
+                    val = val / e;
+                    val = (val == val) ? val : 0.0;         // NaN quotients are skipped, inf is kept
+                    // usable expected = neither NaN nor zero.  The predicate goes through a register the compiler cannot see
+                    // through: hipcc (ROCm 7.2) folds __ballot(e == e && e != 0.0) — and the equivalent v_cmp_class test —
+                    // into v_cmp_neq_f64, the UNORDERED not-equal, which lets NaN pass
+                    int e_ok = (e == e && e != 0.0) ? 1 : 0;
+                    asm volatile("" : "+v"(e_ok));
+                    const unsigned long long eok = __ballot(e_ok);
+                    if (lane == i) r.okn[hh] &= eok;
+                }
+                tile[rr * LS + 64 * hh + lane] = val;
             }
-            tile[rr * LS + 64 * hh + lane] = good ? val : 0.0;
         }
-        if (lane < NRH && my_rr >= row_lo && my_rr < row_hi) {
-            if constexpr (!FACT) vbits[my_rr * VBW + my_h] = r.okn;
-            if (stats) pbits[my_rr * VBW + my_h] = r.bits;
+        if (lane < RPW && my_rr >= row_lo && my_rr < row_hi) {
+#pragma unroll
+            for (int hh = 0; hh < NH; ++hh) {
+                if constexpr (!FACT) vbits[my_rr * VBW + hh] = r.okn[hh];
+                if (stats) pbits[my_rr * VBW + hh] = r.bits[hh];
+            }
         }
     };
 
@@ -297,8 +356,7 @@ __global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, 
         return at + lane < end ? (int)sa.win[start + at + lane] : 0;
     };
     // windows jb <= j < je of the wave's current batch (window j sits in lane j), all of accumulator slot S
-    auto run = [&](auto slot_tag, const Cur& g, int offv, int drv, int dcv, int jb, int je) __attribute__((always_inline)) {
-        constexpr int S = decltype(slot_tag)::value;
+    auto run = [&](const Cur& g, int offv, int drv, int dcv, int jb, int je) __attribute__((always_inline)) {
         auto gather = [&](int jj, double (&v)[CH], unsigned long long& vraw, unsigned& ad0, unsigned& ad1) __attribute__((always_inline)) {
             // single ds_read_b64 each (see lds_read_b64); cells the lane does not own read padding, never flushed
             ad0 = lane_off8 + (unsigned)__builtin_amdgcn_readlane(offv, jj);
@@ -319,8 +377,8 @@ __global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, 
             const int dr = __builtin_amdgcn_readlane(drv, jj), dc = __builtin_amdgcn_readlane(dcv, jj);
             if (m_cov && row_ok && k == 0) {
                 const double vs = a.cov[g.R + dr + p], ve = a.cov[g.C + dc + p];
-                if (vs == vs) cov_lds[wave][S][p] += vs;
-                if (ve == ve) cov_lds[wave][S][W + p] += ve;
+                if (vs == vs) cov_lds[wave][p] += vs;
+                if (ve == ve) cov_lds[wave][W + p] += ve;
             }
             if (stats) {
                 const unsigned c = (unsigned)(dc + k);
@@ -335,43 +393,56 @@ __global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, 
         };
         auto add = [&](const double (&v)[CH], unsigned vw) __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < CH; ++i) { sum[S][i] += v[i]; if (!FACT) num[S][i] += (vw >> (NCH * i)) & 1u; }
+            for (int i = 0; i < CH; ++i) { sum[i] += v[i]; if (!FACT) num[i] += (vw >> (NCH * i)) & 1u; }
         };
-        int jj = jb;
-        if constexpr (WIF == 4) {
-            for (; jj + 3 < je; jj += 4) {                // four windows in flight: all gathered before any is added
-                double va[CH], vb[CH], vc[CH], vd[CH]; unsigned long long wa, wb, wc2, wd; unsigned a0, a1, a2, a3, a4, a5, a6, a7;
+        constexpr int NB = CH + (FACT ? 0 : 1);            // LDS operations of one window's gather
+        if constexpr (!EXTRA && NB <= 15) {
+            // software pipeline over the windows: the reads of window j + 1 are in flight while window j is added, so the
+            // LDS always has a window's worth of reads queued per wave (8 waves per CU: there is no other wave on the SIMD
+            // to fill the gap).  `s_waitcnt lgkmcnt(NB)` = "all but the NB youngest LDS operations have returned" — LDS
+            // operations return in order, so the older window is complete.  Past the run's last window the pipeline reads
+            // that window once more (never added): no branch around the register arrays.
+            int jj = jb;
+            if (jj < je) {
+                double va[CH], vb[CH]; unsigned long long wa, wb; unsigned a0, a1, b0, b1;
+                gather(jj, va, wa, a0, a1);
+                for (;;) {
+                    gather(jj + 1 < je ? jj + 1 : jj, vb, wb, b0, b1);
+                    lds_wait_but<NB>(a0, a1); lds_pin(va);
+                    if constexpr (!FACT) lds_pin_u64(wa);
+                    add(va, bits_of(jj, wa));
+                    if (jj + 1 >= je) break;
+                    gather(jj + 2 < je ? jj + 2 : jj + 1, va, wa, a0, a1);
+                    lds_wait_but<NB>(b0, b1); lds_pin(vb);
+                    if constexpr (!FACT) lds_pin_u64(wb);
+                    add(vb, bits_of(jj + 1, wb));
+                    if (jj + 2 >= je) break;
+                    jj += 2;
+                }
+                // drain the trailing read: its destination registers stay reserved until the data has landed
+                lds_wait_all(a0, a1, b0, b1); lds_pin(va); lds_pin(vb);
+                if constexpr (!FACT) { lds_pin_u64(wa); lds_pin_u64(wb); }
+            }
+        } else {
+            int jj = jb;
+            for (; jj + 1 < je; jj += 2) {                // two windows in flight: both gathered before either is added
+                double va[CH], vb[CH]; unsigned long long wa, wb; unsigned a0, a1, a2, a3;
                 gather(jj, va, wa, a0, a1);
                 gather(jj + 1, vb, wb, a2, a3);
-                gather(jj + 2, vc, wc2, a4, a5);
-                gather(jj + 3, vd, wd, a6, a7);
-                lds_wait_all(a0, a1, a2, a3); lds_wait_all(a4, a5, a6, a7);
-                lds_pin(va); lds_pin(vb); lds_pin(vc); lds_pin(vd);
-                if constexpr (!FACT) { lds_pin_u64(wa); lds_pin_u64(wb); lds_pin_u64(wc2); lds_pin_u64(wd); }
+                lds_wait_all(a0, a1, a2, a3); lds_pin(va); lds_pin(vb);
+                if constexpr (!FACT) { lds_pin_u64(wa); lds_pin_u64(wb); }   // (FACT: no validity word was read — pinning would materialise a zero)
                 add(va, bits_of(jj, wa));
                 add(vb, bits_of(jj + 1, wb));
-                add(vc, bits_of(jj + 2, wc2));
-                add(vd, bits_of(jj + 3, wd));
-                if (EXTRA) { extra(jj); extra(jj + 1); extra(jj + 2); extra(jj + 3); }
+                if (EXTRA) { extra(jj); extra(jj + 1); }
             }
-        }
-        for (; jj + 1 < je; jj += 2) {                    // two windows in flight: both gathered before either is added
-            double va[CH], vb[CH]; unsigned long long wa, wb; unsigned a0, a1, a2, a3;
-            gather(jj, va, wa, a0, a1);
-            gather(jj + 1, vb, wb, a2, a3);
-            lds_wait_all(a0, a1, a2, a3); lds_pin(va); lds_pin(vb);
-            if constexpr (!FACT) { lds_pin_u64(wa); lds_pin_u64(wb); }   // (FACT: no validity word was read — pinning would materialise a zero)
-            add(va, bits_of(jj, wa));
-            add(vb, bits_of(jj + 1, wb));
-            if (EXTRA) { extra(jj); extra(jj + 1); }
-        }
-        if (jj < je) {
-            double va[CH]; unsigned long long wa; unsigned a0, a1;
-            gather(jj, va, wa, a0, a1);
-            lds_wait_all(a0, a1, a0, a1); lds_pin(va);
-            if constexpr (!FACT) lds_pin_u64(wa);
-            add(va, bits_of(jj, wa));
-            if (EXTRA) extra(jj);
+            if (jj < je) {
+                double va[CH]; unsigned long long wa; unsigned a0, a1;
+                gather(jj, va, wa, a0, a1);
+                lds_wait_all(a0, a1, a0, a1); lds_pin(va);
+                if constexpr (!FACT) lds_pin_u64(wa);
+                add(va, bits_of(jj, wa));
+                if (EXTRA) extra(jj);
+            }
         }
     };
     // bits [s, s + 32) of the 128-bit mask hi:lo, s in [0, 127]
@@ -385,19 +456,16 @@ __global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, 
     // reaches it): valid = !rowbad[p] & !colbad[q], so over the segment num[p][q] = N - R[p] - C[q] + RC[p][q].
     // fact_tot[slot] = {R[W], C[W], N}; rc_lds[slot] = RC (masked row meets masked column: rare).  Integer LDS atomics:
     // exact and order-independent.
-    auto fact_batch = [&](const Cur& g, int drv, int dcv, int nb, int split) __attribute__((always_inline)) {
+    auto fact_batch = [&](const Cur& g, int drv, int dcv, int nb) __attribute__((always_inline)) {
       if constexpr (FACT) {
         constexpr unsigned WMASK = (1u << W) - 1u;
-        if (lane == 0) {
-            if (ACC == 1 || split > 0) atomicAdd(&fact_tot[2 * W], (unsigned)(ACC == 2 ? split : nb));
-            if constexpr (ACC == 2) if (nb > split) atomicAdd(&fact_tot[(2 * W + 1) + 2 * W], (unsigned)(nb - split));
-        }
+        const int tb = my_slot * (2 * W + 1);
+        if (lane == 0) atomicAdd(&fact_tot[tb + 2 * W], (unsigned)nb);
         if ((g.rowbad[0] | g.rowbad[1] | g.colbad[0] | g.colbad[1]) == 0ull) return;     // (uniform) no masked bin in the region
         const bool live = lane < nb;
-        const int slot = (ACC == 2 && lane >= split) ? 1 : 0;
+        const int slot = my_slot;
         unsigned rb = live ? mask_at(g.rowbad, drv) & WMASK : 0u;
         const unsigned cbm = live ? mask_at(g.colbad, dcv) & WMASK : 0u;
-        const int tb = slot * (2 * W + 1);
         unsigned cc = cbm;
         while (cc) { const int q = __ffs((int)cc) - 1; cc &= cc - 1u; atomicAdd(&fact_tot[tb + W + q], 1u); }
         while (rb) {
@@ -408,33 +476,55 @@ __global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, 
         }
       }
     };
-    // this wave's slice of the block's windows [lo, hi); wf = its first batch, one window per lane, each as its corner
-    // inside the region (the value the block sort carried)
-    auto slice_of = [&](int count, int& lo, int& hi) __attribute__((always_inline)) {
-        const int M = (count + NW - 1) / NW;
-        lo = wave * M; hi = lo + M < count ? lo + M : count;
-        if (lo > hi) lo = hi;
+    // this wave's slice [lo, hi) of the block's windows: an equal share of its team's windows (the whole block, or the
+    // slot-0 / slot-1 part of it); wf = its first batch, one window per lane, each as its corner inside the region (the
+    // value the block sort carried)
+    auto slice_of = [&](int count, int count0, int& lo, int& hi) __attribute__((always_inline)) {
+        const int first = ACC == 2 ? (my_slot ? count0 : 0) : 0;
+        const int n = ACC == 2 ? (my_slot ? count - count0 : count0) : count;
+        // M = ceil(n / team_n) without an integer division (a block holds fewer than 2^24 windows)
+        int M = (int)((float)n * team_inv);
+        M += (M * team_n < n) ? 1 : 0;
+        M -= ((M - 1) * team_n >= n && M > 0) ? 1 : 0;
+        const int r = wave - team_lo;
+        lo = r * M < n ? r * M : n; hi = lo + M < n ? lo + M : n;
+        lo += first; hi += first;
     };
-    auto windows = [&](const Cur& g, int wf) __attribute__((always_inline)) {
+    // `mid` = the look-ahead work of the pipeline (lookups and loads for the next blocks: VALU and address arithmetic, no
+    // LDS): every wave does it once, INSIDE its first batch, after 0, 1/6, 2/6 or 3/6 of the batch's windows by its number
+    // — so that of the four waves of a SIMD one at a time is busy with it while the others keep the LDS reading.  (All
+    // sixteen doing it back to back before the window loop, as in round 2, cost 28 % of the kernel: phase clocks.)
+    auto windows = [&](const Cur& g, int wf, auto&& mid) __attribute__((always_inline)) {
         int lo, hi;
-        slice_of(g.count, lo, hi);
-        for (int s0 = lo; s0 < hi; s0 += kWave) {
+        slice_of(g.count, g.count0, lo, hi);
+        {   // the first batch (possibly empty), with the look-ahead work inside it: `mid` is spelled ONCE — two copies joined
+            // by a branch would make hipcc shuttle the register arrays it fills through scratch
+            const int drv = wf & ((1 << kWinShift) - 1), dcv = (wf >> kWinShift) & ((1 << kWinShift) - 1);
+            const int offv = 8 * (drv * LS + dcv);
+            if (lo + kWave < hi) wf = load_batch(g.start, lo + kWave, hi);
+            const int nb = (hi - lo) < kWave ? (hi - lo) : kWave;
+            fact_batch(g, drv, dcv, nb);
+            const int cut = (nb * (wave & 3) * 43) >> 8;                           // ~ nb * (wave & 3) / 6
+            const int half = nb >> 1;
+            set_prio(age);
+            run(g, offv, drv, dcv, 0, cut);
+            mid();
+            run(g, offv, drv, dcv, cut, cut > half ? cut : half);
+            set_prio(3 - age);
+            run(g, offv, drv, dcv, cut > half ? cut : half, nb);
+        }
+        for (int s0 = lo + kWave; s0 < hi; s0 += kWave) {
             const int drv = wf & ((1 << kWinShift) - 1), dcv = (wf >> kWinShift) & ((1 << kWinShift) - 1);
             const int offv = 8 * (drv * LS + dcv);
             if (s0 + kWave < hi) wf = load_batch(g.start, s0 + kWave, hi);         // next batch of a long slice
             const int nb = (hi - s0) < kWave ? (hi - s0) : kWave;
-            int split = g.count0 - s0;                    // windows of the batch before `split` belong to slot 0
-            split = split < 0 ? 0 : (split > nb ? nb : split);
-            fact_batch(g, drv, dcv, nb, split);
-            if (ACC == 2) {
-                run(std::integral_constant<int, 0>{}, g, offv, drv, dcv, 0, split);
-                run(std::integral_constant<int, ACC - 1>{}, g, offv, drv, dcv, split, nb);
-            } else run(std::integral_constant<int, 0>{}, g, offv, drv, dcv, 0, nb);
+            fact_batch(g, drv, dcv, nb);
+            run(g, offv, drv, dcv, 0, nb);
         }
     };
     auto first_coords = [&](int ev, int& wf) __attribute__((always_inline)) {
         int lo, hi;
-        slice_of(fld(ev, 3), lo, hi);
+        slice_of(fld(ev, 3), fld(ev, 4), lo, hi);
         wf = load_batch(fld(ev, 2), lo, hi);
     };
     auto cur_of = [&](int ev) __attribute__((always_inline)) -> Cur {
@@ -454,40 +544,42 @@ __global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, 
         double*   mf = tile;                                              // [NW/2][CH][64] doubles, then the same in u32
         unsigned* mn = reinterpret_cast<unsigned*>(tile + (NW / 2) * CH * kWave);
         __syncthreads();
+        // every team merges its waves' tiles into its first wave: binary tree over the position inside the team (both teams
+        // at once: their scratch slots are disjoint — the absolute wave number picks the slot)
+        const int r = wave - team_lo;
+        for (int step = 1; step < NW; step <<= 1) {
+            const int slot_w = wave >> 1;
+            if ((r & (2 * step - 1)) == step) {
 #pragma unroll
-        for (int s = 0; s < ACC; ++s) {
-            for (int step = 1; step < NW; step <<= 1) {
-                const int slot_w = wave / (2 * step);
-                if ((wave & (2 * step - 1)) == step) {
-#pragma unroll
-                    for (int i = 0; i < CH; ++i) {
-                        mf[(slot_w * CH + i) * kWave + lane] = sum[s][i];
-                        if (!FACT) mn[(slot_w * CH + i) * kWave + lane] = num[s][i];
-                    }
+                for (int i = 0; i < CH; ++i) {
+                    mf[(slot_w * CH + i) * kWave + lane] = sum[i];
+                    if (!FACT) mn[(slot_w * CH + i) * kWave + lane] = num[i];
                 }
-                __syncthreads();
-                if ((wave & (2 * step - 1)) == 0 && wave + step < NW) {
-#pragma unroll
-                    for (int i = 0; i < CH; ++i) {
-                        sum[s][i] += mf[(slot_w * CH + i) * kWave + lane];
-                        if (!FACT) num[s][i] += mn[(slot_w * CH + i) * kWave + lane];
-                    }
-                }
-                __syncthreads();
             }
+            __syncthreads();
+            if ((r & (2 * step - 1)) == 0 && r + step < team_n) {
+                const int from = (wave + step) >> 1;
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    sum[i] += mf[(from * CH + i) * kWave + lane];
+                    if (!FACT) num[i] += mn[(from * CH + i) * kWave + lane];
+                }
+            }
+            __syncthreads();
         }
 #pragma unroll
         for (int s = 0; s < ACC; ++s) {
             const size_t rec = ((size_t)(s * sa.U + unit) * 2 + (size_t)fl) * (size_t)G + (size_t)g_id;
             double*   of = a.part_f64 + rec * L;
             unsigned* on = a.part_num + rec * W2;
-            if (wave == 0) {
+            const int lead = ACC == 2 ? (s ? sa.n0 : 0) : 0;              // the team's first wave holds its merged tile
+            if (wave == lead) {
 #pragma unroll
                 for (int i = 0; i < CH; ++i)
                     if ((chmask >> i) & 1u) {
                         const int cell = map_cell(p, k + NCH * i, W, false, fl);
-                        of[cell] = sum[s][i];
-                        if (!FACT) on[cell] = num[s][i];
+                        of[cell] = sum[i];
+                        if (!FACT) on[cell] = num[i];
                     }
             }
             if constexpr (FACT) {
@@ -498,9 +590,10 @@ __global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, 
                     on[map_cell(pp, qq, W, false, fl)] = tot[2 * W] - tot[pp] - tot[W + qq] + rc_lds[s][t];
                 }
             }
+            const int w_lo = ACC == 2 ? (s ? sa.n0 : 0) : 0, w_hi = ACC == 2 ? (s ? NW : sa.n0) : NW;
             for (int t = tid; t < 2 * W; t += NTHR) {
                 double acc = 0.0;
-                if (m_cov) for (int w = 0; w < NW; ++w) acc += cov_lds[w][s][t];
+                if (m_cov) for (int w = w_lo; w < w_hi; ++w) acc += cov_lds[w][t];
                 of[W2 + t] = acc;
             }
             if (tid == 0) sa.rec_valid[rec] = 1;
@@ -528,25 +621,42 @@ __global__ __launch_bounds__(kWave * NW, 1) void pileup_staged_kernel(K1Args a, 
             issue_values(ev0, rw0, v, wc);
             const ExpSel es0 = exp_of(ev0);
             __syncthreads();
-            store_region(ev0, rw0, v, wc, es0);
+            if (nf) store_region(std::true_type{}, ev0, rw0, v, wc, es0); else store_region(std::false_type{}, ev0, rw0, v, wc, es0);
             __syncthreads();
-            if (bb + 1 < be) rw1 = finish_rows(ev1, x1);
         }
+        // (diagnostics: per-wave clocks of the phases of the loop below, only when sa.timing is set)
+        long long tk[6] = {0, 0, 0, 0, 0, 0};
+        const bool timed = sa.timing != nullptr;
+        auto tick = [&]() __attribute__((always_inline)) -> long long { return timed ? (long long)__builtin_readcyclecounter() : 0; };
         for (int b = bb; b < be; ++b) {
             const bool has1 = b + 1 < be, has2 = b + 2 < be;
-            if (has1) { if (!(sa.debug & 2)) issue_values(ev1, rw1, v, wc); first_coords(ev1, w1f); }
-            if (has2) { ev2 = evn; load_raw(ev2, x2); if (b + 3 < be) evn = entry_load(b + 3); }
+            const long long t0 = tick();
+            auto lookahead = [&]() __attribute__((always_inline)) {
+                if (has1) { rw1 = finish_rows(ev1, x1); if (!(sa.debug & 2)) issue_values(ev1, rw1, v, wc); first_coords(ev1, w1f); }
+                if (has2) { ev2 = evn; load_raw(ev2, x2); if (b + 3 < be) evn = entry_load(b + 3); }
+            };
             const Cur c0 = cur_of(ev0);
-            if (!(sa.debug & 1)) windows(c0, w0f);
+            const long long t1 = tick();
+            windows(c0, w0f, lookahead);
+            const long long t2 = tick();
             const int seg0 = fld(ev0, 20);
             if (!has1) { flush(seg0); break; }
             const ExpSel es1 = exp_of(ev1);
             if (fld(ev1, 20) != seg0) flush(seg0);       // (uniform) the next block belongs to another segment
             else __syncthreads();                        // every wave is done reading region b
-            if (!(sa.debug & 2)) store_region(ev1, rw1, v, wc, es1);
+            const long long t3 = tick();
+            if (!(sa.debug & 2)) { if (nf) store_region(std::true_type{}, ev1, rw1, v, wc, es1); else store_region(std::false_type{}, ev1, rw1, v, wc, es1); }
+            const long long t4 = tick();
             __syncthreads();
+            const long long t5 = tick();
             ev0 = ev1; w0f = w1f;
-            if (has2) { ev1 = ev2; rw1 = finish_rows(ev2, x2); }
+            if (has2) { ev1 = ev2; x1 = x2; }
+            if (timed) { tk[0] += t1 - t0; tk[1] += t2 - t1; tk[2] += t3 - t2; tk[3] += t4 - t3; tk[4] += t5 - t4; tk[5] += tick() - t5; }
+        }
+        if (timed && lane == 0) {
+            long long* o = sa.timing + ((size_t)g_id * NW + wave) * 8;
+            for (int i = 0; i < 6; ++i) o[i] = tk[i];
+            o[6] = be - bb; o[7] = 0;
         }
     }
     if (stats) {

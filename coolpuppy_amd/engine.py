@@ -290,6 +290,14 @@ class PileupEngine:
         self._check(self._lib.pup_get_stats(self._h, C.byref(s)))
         return {k: getattr(s, k) for k, _ in _ffi.PupStats._fields_}
 
+    def debug_timing(self):
+        """Per-wave phase clocks of the staged kernel's last launch, [workgroups, 16, 8] (set_tuning variant bit 26), or None."""
+        buf = np.zeros(4096 * 16 * 8, np.int64)
+        g = self._lib.pup_debug_timing(self._h, _ptr(buf), buf.shape[0])
+        if g < 0:
+            self._check(g)
+        return None if g == 0 else buf[:g * 16 * 8].reshape(g, 16, 8)
+
     def clear_stats(self):
         self._check(self._lib.pup_clear_stats(self._h))
 

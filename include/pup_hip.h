@@ -35,6 +35,7 @@
  *                                                                      coolpuppy/coolpup.py:1263-1283
  *   pup_host_alloc / pup_host_free    <- (no counterpart: page-locked staging for asynchronous host-to-device copies)
  *   pup_rccl_path                     <- (no counterpart: which librccl the communicator of pup_allreduce must come from)
+ *   pup_debug_timing                  <- (no counterpart: phase clocks of the staged kernel, development aid)
  *
  * Conventions
  *   - plain C: pointers + sizes only; no C++/torch types cross this line.
@@ -254,6 +255,11 @@ typedef struct pup_stats {
 int pup_set_profiling(pup_ctx* ctx, int enabled);
 int pup_get_stats(pup_ctx* ctx, pup_stats* out);   /* implies pup_sync */
 int pup_clear_stats(pup_ctx* ctx);
+/* diagnostics of the staged kernel (variant bit 26 of pup_set_tuning switches the collection on): per-wave clock totals of
+ * its phases in the last pup_accumulate — out[workgroup][16 waves][8] = {issue, windows, barrier, store, barrier, rows, blocks,
+ * 0}.  Returns the number of workgroups (0: nothing collected).  Development aid (tools/k1_probe.py --phases); no counterpart
+ * in the reference. */
+int pup_debug_timing(pup_ctx* ctx, int64_t* out, int64_t cap);
 /* generic stream timer: record slot (0..7) on the context's stream; elapsed between two slots */
 int pup_event_record(pup_ctx* ctx, int slot);
 int pup_event_elapsed_ms(pup_ctx* ctx, int slot_begin, int slot_end, float* ms);

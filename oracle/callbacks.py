@@ -44,13 +44,14 @@ def band_group(putils):
     return f
 
 
-def scenarios(bedpe, bed, tads, exp_chrom):
+def scenarios(bedpe, bed, tads, exp_chrom, inf_patch=None):
     """name -> dict(features, cc=CoordCreator kwargs, pu=PileUpper kwargs, expected, call=pileupsWithControl kwargs as
     NAMES resolved by run())."""
     S = []
 
-    def add(name, features, cc, pu=None, expected=None, **call):
-        S.append({"name": name, "features": features, "cc": cc, "pu": pu or {}, "expected": expected, "call": call})
+    def add(name, features, cc, pu=None, expected=None, patch=None, **call):
+        S.append({"name": name, "features": features, "cc": cc, "pu": pu or {}, "expected": expected, "call": call,
+                  "patch": patch})
 
     add("G13a_bedpe_controls_collect_centre", bedpe.iloc[:160], dict(features_format="bedpe", flank=100_000, nshifts=2,
                                                                      seed=3), dict(control=True),
@@ -74,6 +75,11 @@ def scenarios(bedpe, bed, tads, exp_chrom):
         postprocess="centre_mean", groupby=["strand1", "strand2"], ignore_group_order=True)
     add("G13i_raw_covnorm_double", bedpe.iloc[:150], dict(features_format="bedpe", flank=100_000, nshifts=2, seed=8),
         dict(control=True, clr_weight_name=None, coverage_norm="cov_tot_raw"), postprocess="double_data")
+    if inf_patch is not None:
+        # weights of +inf (and zeros beside them): the windows a callback sees carry cooler's inf / NaN products
+        add("G14e_inf_weights_callback_centre", bedpe.iloc[:220], dict(features_format="bedpe", flank=100_000, nshifts=1,
+                                                                       seed=6), dict(control=True), patch=inf_patch,
+            postprocess="centre_mean", extra={"centre": "collect_centre"})
     return S
 
 

@@ -245,14 +245,18 @@ def scenarios():
         clr_weight_name=None, coverage_norm="cis", min_diag=0, patch={"drop": ["cov_tot_raw", "cov_cis_raw"]})
     # weights that are +inf, and zero weights beside them: balanced pixels become inf / NaN, which the reference leaves
     # out of `num` cell by cell (np.isfinite) while empty cells of the same rows still count
-    wrng = np.random.default_rng(37)
-    w_inf = sorted(int(x) for x in wrng.choice(nb_small, 40, replace=False))
-    w_zero = sorted(set(int(x) + int(d) for x in w_inf[:25] for d in (-3, 2, 7) if 0 <= int(x) + int(d) < nb_small) - set(w_inf))
+    inf_patch = inf_weight_patch(nb_small)
+    w_inf, w_zero = inf_patch["weight"]["inf"], inf_patch["weight"]["zero"]
     add("G14_inf_and_zero_weights", "small", bedpe, patch={"weight": {"inf": w_inf, "zero": w_zero}}, **base)
     add("G14b_inf_weights_expected_by_strand", "small", bedpe, patch={"weight": {"inf": w_inf, "zero": w_zero}},
         expected=exp_chrom, by_strand=True, **base)
     add("G14c_inf_weights_local", "small", bed, features_format="bed", local=True, flank=100_000,
         patch={"weight": {"inf": w_inf, "zero": w_zero}})
+    # ... and in the per-snippet outputs: stored stripes carry the inf / NaN products themselves (coolpup.py:1164-1182)
+    add("G14d_inf_weights_stripes", "small", bedpe, patch={"weight": {"inf": w_inf, "zero": w_zero}}, store_stripes=True,
+        **base)
+    add("G14f_inf_weights_stripes_expected_local", "small", bed, features_format="bed", local=True, flank=100_000,
+        expected=exp_chrom, store_stripes=True, patch={"weight": {"inf": w_inf, "zero": w_zero}})
     # ---- randomised option combinations (seeded): interactions no hand-written scenario happens to cover ----------
     frng = np.random.default_rng(20240928)
     for k in range(32):
@@ -423,14 +427,23 @@ def record_extra(df, rec, key):
     rec[f"extra__{key}__is_list"] = np.array(is_list, np.int8)
 
 
+def inf_weight_patch(nb):
+    """Bins whose weight becomes +inf, and zero weights beside them (scenarios G14*)."""
+    wrng = np.random.default_rng(37)
+    w_inf = sorted(int(x) for x in wrng.choice(nb, 40, replace=False))
+    w_zero = sorted(set(int(x) + int(d) for x in w_inf[:25] for d in (-3, 2, 7) if 0 <= int(x) + int(d) < nb) - set(w_inf))
+    return {"weight": {"inf": w_inf, "zero": w_zero}}
+
+
 def callback_goldens(ref, coolers, index):
     """Scenarios that drive PileUpper.pileupsWithControl with per-snippet callbacks (oracle/callbacks.py)."""
     import importlib
     from oracle import callbacks as cbs
     ref_putils = importlib.import_module("coolpuppy.lib.puputils")
     small = coolers["small"]
-    clr = refshim.ShimCooler(small)
-    for sc in cbs.scenarios(bedpe_features(small), bed_features(small), tad_features(), synth.cis_expected(small)):
+    for sc in cbs.scenarios(bedpe_features(small), bed_features(small), tad_features(), synth.cis_expected(small),
+                            inf_patch=inf_weight_patch(int(small.bin1_offset.shape[0] - 1))):
+        clr = refshim.ShimCooler(synth.patched_cooler(small, sc["patch"]) if sc.get("patch") else small)
         df = cbs.run(ref, ref_putils, clr, sc)
         W = sc["pu"]["rescale_size"] if sc["pu"].get("rescale") else 2 * (sc["cc"]["flank"] // clr.binsize) + 1
         rec = record(df, W)

@@ -25,13 +25,21 @@ def _scenarios():
         import synth
         small = gu.cooler("small")
         _SC = {s["name"]: s for s in cbs.scenarios(mg.bedpe_features(small), mg.bed_features(small), mg.tad_features(),
-                                                   synth.cis_expected(small))}
+                                                   synth.cis_expected(small),
+                                                   inf_patch=mg.inf_weight_patch(int(small.nbins)))}
     return _SC
+
+
+def _cooler(sc):
+    import synth
+    small = gu.cooler("small")
+    return synth.patched_cooler(small, sc["patch"]) if sc.get("patch") else small
 
 
 NAMES = ["G13a_bedpe_controls_collect_centre", "G13b_rescale_local_expected_domain_score", "G13c_bedpe_double_data",
          "G13d_bed_strand_flip_double", "G13e_bedpe_group_by_region", "G13f_expected_not_ooe_stripes_centre",
-         "G13g_band_group_postprocess", "G13h_ignore_group_order_strands", "G13i_raw_covnorm_double"]
+         "G13g_band_group_postprocess", "G13h_ignore_group_order_strands", "G13i_raw_covnorm_double",
+         "G14e_inf_weights_callback_centre"]
 
 
 def _check(name, df, rtol):
@@ -62,14 +70,14 @@ class _HostMod:
 
 @pytest.mark.parametrize("name", NAMES)
 def test_callbacks_host_logic_vs_reference(name):
-    df = cbs.run(_HostMod, puputils, gu.cooler("small"), _scenarios()[name])
+    df = cbs.run(_HostMod, puputils, _cooler(_scenarios()[name]), _scenarios()[name])
     _check(name, df, rtol=1e-9)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", NAMES)
 def test_callbacks_gpu_vs_reference(name, hip_lib):
-    df = cbs.run(coolpup, puputils, gu.cooler("small"), _scenarios()[name])
+    df = cbs.run(coolpup, puputils, _cooler(_scenarios()[name]), _scenarios()[name])
     _check(name, df, rtol=1e-9)
 
 

@@ -83,6 +83,21 @@ def main():
         else:
             agree = bool(np.array_equal(out["n"], ref["n"]) and np.array_equal(out["num"], ref["num"]) and
                          np.allclose(out["sum"], ref["sum"], rtol=1e-12, atol=0))
+        if v & (4 << 24):            # phase clocks of the staged kernel (variant bit 26)
+            tm = eng.debug_timing()
+            if tm is not None:
+                names = ["issue", "windows", "barrier1", "store", "barrier2", "rows"]
+                live = tm[:, :, 6].max(axis=1) > 0
+                per_wave = tm[live][:, :, :6].astype(float)
+                tot = per_wave.sum(axis=2)                       # clocks per wave
+                k = per_wave.shape[1] if (per_wave[:, 8:, :].sum() > 0) else 8
+                per_wave = per_wave[:, :k]
+                print(json.dumps({"phases_mean_clk_per_wave": {n: round(float(per_wave[:, :, i].mean())) for i, n in enumerate(names)},
+                                  "waves": int(k), "workgroups": int(live.sum()),
+                                  "wave_total_min_mean_max": [round(float(x)) for x in (per_wave.sum(axis=2).min(), per_wave.sum(axis=2).mean(), per_wave.sum(axis=2).max())],
+                                  "wg_total_min_mean_max": [round(float(x)) for x in (per_wave.sum(axis=2).max(axis=1).min(), per_wave.sum(axis=2).max(axis=1).mean(), per_wave.sum(axis=2).max(axis=1).max())],
+                                  "windows_by_wave_mean": [round(float(x)) for x in per_wave[:, :, 1].mean(axis=0)],
+                                  "blocks_per_wg_min_mean_max": [int(tm[live][:, 0, 6].min()), float(tm[live][:, 0, 6].mean()), int(tm[live][:, 0, 6].max())]}), flush=True)
         best = min(rows, key=lambda x: x["wall_ms"])
         res[str(v)] = {"best": best, "all": rows, "agrees_with_first": agree, "n": out["n"].tolist()[:4]}
         print(json.dumps({"variant": v, **best, "agree": agree}), flush=True)
