@@ -31,6 +31,8 @@ def build_hip(force=False, verbose=False):
         return OUT
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
            "-Wall", "-Wno-unused-result", "-pthread", SRC, "-x", "hip", SRC_HOST, "-o", OUT]
+    if os.environ.get("COOLPUPPY_AMD_DEV_W21", "") == "1":      # development only: see launch_staged in pup_engine.hip
+        cmd.insert(1, "-DPUP_DEV_W21")
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)

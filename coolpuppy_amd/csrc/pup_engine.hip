@@ -66,6 +66,8 @@ struct pup_ctx {
     DevBuf<unsigned short> bin_chrom;       // [nbins] chromosome (index into idx_chrom) of every bin
     DevBuf<int> d_brow;                     // [n_chrom] block rows before each chromosome (block-order prepass)
     DevBuf<unsigned> rowseg;               // [nbins][n_chrom+1] search bounds per (row, chromosome), see K1Args
+    DevBuf<int> band;                       // dense band of counts near the diagonal (staged kernel), [nbins][band_w] + zeros
+    int band_w = 0;                         // 0: no band table
     int n_chrom = 0;
     bool have_idx = false, have_rowseg = false;
     long long idx_bytes = 0;
@@ -93,7 +95,7 @@ struct pup_ctx {
     long long tiled_min = 1000000;          // fewer snippets: the whole pile-up is a fraction of a millisecond anyway
     // the key kernel's verdict (ineligible windows, windows a diagonal mask reaches) reaches the host through mapped
     // page-locked memory while the sort is already running; the block count of the last staged call comes back the same way
-    volatile unsigned* h_flags = nullptr;    // [0] ineligible [1] unclear [2] ticket   [4] blocks of the last staged call [6] its ticket
+    volatile unsigned* h_flags = nullptr;    // [0] ineligible [1] unclear [2] outside the band [3] ticket   [4] blocks of the last staged call [5] its ticket
     unsigned* d_flags = nullptr;             // device address of h_flags
     hipEvent_t ev_key = nullptr;
     unsigned ticket = 0;
@@ -203,8 +205,15 @@ StagedGeo staged_geometry(int W, bool ooe, bool extra, bool small21) {
 // fact: every window is clear of the diagonal mask and nothing is divided by expected -> validity factorises (FACT)
 // extra: coverage vectors and / or pixel statistics ride along (kept out of the plain instantiation's window loop)
 template <int W, bool OOE, int ACC, bool FACT, bool EXTRA>
-void launch_staged___(const pup::K1Args& a, const pup::StagedArgs& sa, int G, bool small21, hipStream_t s) {
+void launch_staged___(const pup::K1Args& a, const pup::StagedArgs& sa, int G, bool small21, bool band, hipStream_t s) {
     using Geo = pup::StagedGeom<W, OOE, EXTRA, false, FACT>;
+    if constexpr (!EXTRA) {
+        if (band && !(W == 21 && !OOE && small21)) {     // regions staged from the dense band of counts
+            hipLaunchKernelGGL((pup::pileup_staged_kernel<W, OOE, Geo::RSR, Geo::RSC, Geo::NW, ACC, FACT, EXTRA, true>), dim3(G),
+                               dim3(pup::kWave * Geo::NW), 0, s, a, sa);
+            return;
+        }
+    }
     if constexpr (W == 21 && !OOE && !EXTRA) {          // tuning probe (variant bit 7): the plain 21-bin kernel on 64 x 128 regions
         if (small21) {
             using GeoS = pup::StagedGeom<W, OOE, EXTRA, true, FACT>;
@@ -217,33 +226,37 @@ void launch_staged___(const pup::K1Args& a, const pup::StagedArgs& sa, int G, bo
                        dim3(pup::kWave * Geo::NW), 0, s, a, sa);
 }
 template <int W, int ACC, bool EXTRA>
-void launch_staged__(const pup::K1Args& a, const pup::StagedArgs& sa, int G, bool fact, bool small21, hipStream_t s) {
-    if (a.mode & PUP_MODE_OOE) launch_staged___<W, true, ACC, false, EXTRA>(a, sa, G, small21, s);
-    else if (fact) launch_staged___<W, false, ACC, true, EXTRA>(a, sa, G, small21, s);
-    else launch_staged___<W, false, ACC, false, EXTRA>(a, sa, G, small21, s);
+void launch_staged__(const pup::K1Args& a, const pup::StagedArgs& sa, int G, bool fact, bool small21, bool band, hipStream_t s) {
+    if (a.mode & PUP_MODE_OOE) launch_staged___<W, true, ACC, false, EXTRA>(a, sa, G, small21, band, s);
+    else if (fact) launch_staged___<W, false, ACC, true, EXTRA>(a, sa, G, small21, band, s);
+    else launch_staged___<W, false, ACC, false, EXTRA>(a, sa, G, small21, band, s);
 }
 template <int W>
-void launch_staged_(const pup::K1Args& a, const pup::StagedArgs& sa, int G, int acc, bool fact, bool extra, bool small21, hipStream_t s) {
-    if (extra) { if (acc == 2) launch_staged__<W, 2, true>(a, sa, G, fact, small21, s); else launch_staged__<W, 1, true>(a, sa, G, fact, small21, s); }
-    else       { if (acc == 2) launch_staged__<W, 2, false>(a, sa, G, fact, small21, s); else launch_staged__<W, 1, false>(a, sa, G, fact, small21, s); }
+void launch_staged_(const pup::K1Args& a, const pup::StagedArgs& sa, int G, int acc, bool fact, bool extra, bool small21, bool band, hipStream_t s) {
+    if (extra) { if (acc == 2) launch_staged__<W, 2, true>(a, sa, G, fact, small21, band, s); else launch_staged__<W, 1, true>(a, sa, G, fact, small21, band, s); }
+    else       { if (acc == 2) launch_staged__<W, 2, false>(a, sa, G, fact, small21, band, s); else launch_staged__<W, 1, false>(a, sa, G, fact, small21, band, s); }
 }
-bool launch_staged(int W, const pup::K1Args& a, const pup::StagedArgs& sa, int G, int acc, bool fact, bool extra, bool small21, hipStream_t s) {
+bool launch_staged(int W, const pup::K1Args& a, const pup::StagedArgs& sa, int G, int acc, bool fact, bool extra, bool small21, bool band, hipStream_t s) {
     switch (W) {
-        case 3:  launch_staged_<3>(a, sa, G, acc, fact, extra, small21, s);  return true;
-        case 5:  launch_staged_<5>(a, sa, G, acc, fact, extra, small21, s);  return true;
-        case 7:  launch_staged_<7>(a, sa, G, acc, fact, extra, small21, s);  return true;
-        case 9:  launch_staged_<9>(a, sa, G, acc, fact, extra, small21, s);  return true;
-        case 11: launch_staged_<11>(a, sa, G, acc, fact, extra, small21, s); return true;
-        case 13: launch_staged_<13>(a, sa, G, acc, fact, extra, small21, s); return true;
-        case 15: launch_staged_<15>(a, sa, G, acc, fact, extra, small21, s); return true;
-        case 17: launch_staged_<17>(a, sa, G, acc, fact, extra, small21, s); return true;
-        case 19: launch_staged_<19>(a, sa, G, acc, fact, extra, small21, s); return true;
-        case 21: launch_staged_<21>(a, sa, G, acc, fact, extra, small21, s); return true;
-        case 23: launch_staged_<23>(a, sa, G, acc, fact, extra, small21, s); return true;
-        case 25: launch_staged_<25>(a, sa, G, acc, fact, extra, small21, s); return true;
-        case 27: launch_staged_<27>(a, sa, G, acc, fact, extra, small21, s); return true;
-        case 29: launch_staged_<29>(a, sa, G, acc, fact, extra, small21, s); return true;
-        case 31: launch_staged_<31>(a, sa, G, acc, fact, extra, small21, s); return true;
+#ifndef PUP_DEV_W21      // development builds (COOLPUPPY_AMD_DEV_W21=1) keep only the 21-bin staged kernels: a tenth of the compile time
+        case 3:  launch_staged_<3>(a, sa, G, acc, fact, extra, small21, band, s);  return true;
+        case 5:  launch_staged_<5>(a, sa, G, acc, fact, extra, small21, band, s);  return true;
+        case 7:  launch_staged_<7>(a, sa, G, acc, fact, extra, small21, band, s);  return true;
+        case 9:  launch_staged_<9>(a, sa, G, acc, fact, extra, small21, band, s);  return true;
+        case 11: launch_staged_<11>(a, sa, G, acc, fact, extra, small21, band, s); return true;
+        case 13: launch_staged_<13>(a, sa, G, acc, fact, extra, small21, band, s); return true;
+        case 15: launch_staged_<15>(a, sa, G, acc, fact, extra, small21, band, s); return true;
+        case 17: launch_staged_<17>(a, sa, G, acc, fact, extra, small21, band, s); return true;
+        case 19: launch_staged_<19>(a, sa, G, acc, fact, extra, small21, band, s); return true;
+#endif
+        case 21: launch_staged_<21>(a, sa, G, acc, fact, extra, small21, band, s); return true;
+#ifndef PUP_DEV_W21
+        case 23: launch_staged_<23>(a, sa, G, acc, fact, extra, small21, band, s); return true;
+        case 25: launch_staged_<25>(a, sa, G, acc, fact, extra, small21, band, s); return true;
+        case 27: launch_staged_<27>(a, sa, G, acc, fact, extra, small21, band, s); return true;
+        case 29: launch_staged_<29>(a, sa, G, acc, fact, extra, small21, band, s); return true;
+        case 31: launch_staged_<31>(a, sa, G, acc, fact, extra, small21, band, s); return true;
+#endif
         default: return false;
     }
 }
@@ -350,7 +363,7 @@ void pup_destroy(pup_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     collect_events(c);
     c->indptr.release(); c->px.release(); c->cnt32.release(); c->bal.release(); c->badbits.release(); c->idx.release(); c->idx_chrom.release(); c->weight.release(); c->cov.release(); c->expv.release(); c->exp_pair.release(); c->exp_regions.release();
-    c->bin_chrom.release(); c->d_brow.release(); c->brow_sent.clear();
+    c->bin_chrom.release(); c->d_brow.release(); c->brow_sent.clear(); c->band.release(); c->rowseg.release();
     c->acc_f64.release(); c->acc_i64.p = nullptr;
     c->d_r0.release(); c->d_c0.release(); c->d_h.release(); c->d_w.release(); c->d_geom.release();
     c->d_keys.release(); c->d_keys2.release(); c->d_cnt32.release(); c->d_win.release(); c->d_win2.release();
@@ -480,6 +493,23 @@ int pup_build_index(pup_ctx* c, const int64_t* chrom_offset, int32_t n_chroms, i
         hipLaunchKernelGGL(pup::rowseg_kernel, dim3((unsigned)((seg_entries + 255) / 256)), dim3(256), 0, c->stream,
                            c->indptr.p, c->px.p, c->idx_chrom.p, n_chroms, c->rowseg.p, c->nbins);
         c->have_rowseg = true;
+    }
+    // dense band of counts for the staged kernel: band[row][j] = count(row, row + j), j < 1024 (10 Mb at 10 kb) — 4 KiB per
+    // matrix row of the 288 GB; skipped when it would not fit 32-bit byte offsets or a quarter of the free memory
+    c->band_w = 0;
+    {
+        const long long BWd = 1024;
+        const long long cells = c->nbins * BWd + BWd;
+        size_t fb = 0, tb = 0;
+        const bool fits = cells < (1LL << 30) && hipMemGetInfo(&fb, &tb) == hipSuccess &&
+                          (size_t)cells * 4 <= fb / 4 + c->band.cap * sizeof(int);
+        if (fits && !(c->variant & 256)) {
+            HIPCHK(c, c->band.reserve((size_t)cells));
+            HIPCHK(c, hipMemsetAsync(c->band.p, 0, (size_t)cells * sizeof(int), c->stream));
+            const unsigned gb2 = (unsigned)std::min<long long>((c->nbins + 3) / 4, 1 << 20);
+            hipLaunchKernelGGL(pup::band_fill_kernel, dim3(gb2), dim3(256), 0, c->stream, c->indptr.p, c->px.p, c->band.p, (int)BWd, c->nbins);
+            c->band_w = (int)BWd;
+        }
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -690,7 +720,7 @@ static void launch_key_kernel(pup_ctx* c, int BR, int BC, unsigned grid, const i
                               int clear_gap, KeyT* keys) {
 #define PUP_KEY_ARGS dr0, dc0, n, (const long long*)c->d_segend.p, nseg2t, H, (const pup::IdxChrom*)c->idx_chrom.p, c->n_chrom, \
         (const unsigned short*)c->bin_chrom.p, (long long)c->nbins, (const int*)c->d_brow.p, d_eregs, n_eregs, W, BR, BC, sh_br, \
-        sh_er, sh_seg, seg_shift, clear_gap, keys, c->d_win.p, c->d_cnt32.p
+        sh_er, sh_seg, seg_shift, clear_gap, (c->band_w > 0 && !(c->variant & 256)) ? c->band_w : 0, keys, c->d_win.p, c->d_cnt32.p
     if (BR == 108 && BC == 108)
         hipLaunchKernelGGL((pup::staged_key_kernel<KeyT, 108, 108>), dim3(grid), dim3(256), 0, c->stream, PUP_KEY_ARGS);
     else if (BR == 44 && BC == 108)
@@ -717,6 +747,7 @@ static void fill_k1_args(pup_ctx* c, pup::K1Args& a, int32_t ignore_diags, uint3
     a.part_f64 = c->part_f64.p; a.part_num = c->part_num.p;
     a.counters = c->count_pixels ? c->counters.p : nullptr; a.err = c->d_err.p;
     a.nf_pixels = c->nf_count > 0 ? 1 : 0; a.nnz = c->nnz;
+    a.band = c->band_w > 0 ? c->band.p : nullptr; a.band_w = c->band_w; a.band_zero = (unsigned)(c->nbins * (long long)c->band_w);
     a.W = c->W; a.ignore_diags = ignore_diags; a.mode = mode;
 }
 
@@ -749,11 +780,11 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     std::vector<long long> sig;
     sig.reserve(8 + 2 * (size_t)T);
     sig.push_back(n); sig.push_back(T); sig.push_back(W); sig.push_back((long long)(mode & (PUP_MODE_OOE | PUP_MODE_COV)));
-    sig.push_back(ignore_diags); sig.push_back(flip_from ? 1 : 0); sig.push_back(c->variant & (4 | 64 | 128)); sig.push_back(extra ? 1 : 0);
+    sig.push_back(ignore_diags); sig.push_back(flip_from ? 1 : 0); sig.push_back(c->variant & (4 | 64 | 128 | 256)); sig.push_back(extra ? 1 : 0);
     for (int t = 0; t <= T; ++t) sig.push_back(tile_ptr[t]);
     if (flip_from) for (int t = 0; t < T; ++t) sig.push_back(flip_from[t]);
     const bool known = (sig == c->hint_sig) && c->hint_blocks >= 0;
-    if (known && c->h_flags[6] == c->hint_ticket) c->hint_blocks = (long long)c->h_flags[4];   // the previous call's count has landed
+    if (known && c->h_flags[5] == c->hint_ticket) c->hint_blocks = (long long)c->h_flags[4];   // the previous call's count has landed
     if (known && !force && c->hint_blocks * min_per_block > n) return 1;    // too sparse last time: per-window kernels
 
     // block rows are numbered compactly over the genome (fewer key bits = fewer radix passes)
@@ -791,7 +822,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
 
     // ---- buffers (grow-only: steady-state calls allocate nothing) -----------------------------------------------------
     const int n_spans = (int)((n + pup::kSpan - 1) / pup::kSpan);
-    const size_t ncnt = 4;                               // [0] ineligible [1] unclear [2] blocks [3] -, then the span counters
+    const size_t ncnt = 4;                               // [0] ineligible [1] unclear [2] outside the band [3] blocks, then the span counters
     const size_t W2 = (size_t)W * W, Lf = W2 + 2 * (size_t)W;
     const size_t nrec = (size_t)T * 2 * (size_t)G;       // record ((slot * U + unit) * 2 + flip) * G + workgroup = (tile * 2 + flip) * G + workgroup
     HIPCHK(c, c->d_win.reserve((size_t)n + 8)); HIPCHK(c, c->d_win2.reserve((size_t)n + 8));   // +8: K1q fetches four window values at a time
@@ -827,7 +858,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
                                          seg_shift, ignore_diags + W - 1, c->d_k32.p);
     else launch_key_kernel<unsigned long long>(c, BR, BC, gk4, dr0, dc0, (long long)n, nseg2t, H, d_eregs, n_eregs, W, sh_br, sh_er,
                                                sh_seg, seg_shift, ignore_diags + W - 1, c->d_keys.p);
-    hipLaunchKernelGGL(pup::staged_publish_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned*)c->d_cnt32.p,
+    hipLaunchKernelGGL(pup::staged_publish_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned*)c->d_cnt32.p, 3,
                        (volatile unsigned*)c->d_flags, ticket);
     HIPCHK(c, hipEventRecord(c->ev_key, c->stream));
     unsigned* d_spans = c->d_cnt32.p + ncnt;
@@ -839,9 +870,9 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
         hipLaunchKernelGGL((pup::count_heads_kernel<unsigned>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
                            (const unsigned*)c->d_k32b.p, (long long)n, d_spans);
         hipLaunchKernelGGL((pup::block_starts_kernel<unsigned>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
-                           (const unsigned*)c->d_k32b.p, (long long)n, (const unsigned*)d_spans, c->d_starts.p, c->d_cnt32.p + 2);
+                           (const unsigned*)c->d_k32b.p, (long long)n, (const unsigned*)d_spans, c->d_starts.p, c->d_cnt32.p + 3);
         hipLaunchKernelGGL((pup::staged_table_kernel<unsigned>), dim3(gt), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
-                           (const unsigned*)(c->d_cnt32.p + 2), (long long)n, (const unsigned*)c->d_k32b.p,
+                           (const unsigned*)(c->d_cnt32.p + 3), (long long)n, (const unsigned*)c->d_k32b.p,
                            (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
                            c->n_chrom, W, geo.RSR, geo.RSC, sh_br, sh_er, sh_seg, seg_shift, n_eregs,
                            (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G);
@@ -852,21 +883,22 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
         hipLaunchKernelGGL((pup::count_heads_kernel<unsigned long long>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
                            (const unsigned long long*)c->d_keys2.p, (long long)n, d_spans);
         hipLaunchKernelGGL((pup::block_starts_kernel<unsigned long long>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
-                           (const unsigned long long*)c->d_keys2.p, (long long)n, (const unsigned*)d_spans, c->d_starts.p, c->d_cnt32.p + 2);
+                           (const unsigned long long*)c->d_keys2.p, (long long)n, (const unsigned*)d_spans, c->d_starts.p, c->d_cnt32.p + 3);
         hipLaunchKernelGGL((pup::staged_table_kernel<unsigned long long>), dim3(gt), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
-                           (const unsigned*)(c->d_cnt32.p + 2), (long long)n, (const unsigned long long*)c->d_keys2.p,
+                           (const unsigned*)(c->d_cnt32.p + 3), (long long)n, (const unsigned long long*)c->d_keys2.p,
                            (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
                            c->n_chrom, W, geo.RSR, geo.RSC, sh_br, sh_er, sh_seg, seg_shift, n_eregs,
                            (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G);
     }
     // leave the block count where the NEXT call with this signature finds it without waiting
-    hipLaunchKernelGGL(pup::staged_publish_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned*)(c->d_cnt32.p + 2),
+    hipLaunchKernelGGL(pup::staged_publish_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned*)(c->d_cnt32.p + 3), 1,
                        (volatile unsigned*)(c->d_flags + 4), ticket);
     HIPCHK(c, hipGetLastError());
 
     // ---- the host's part: the key kernel's verdict (an event long reached: the sort is still running) -----------------
     HIPCHK(c, hipEventSynchronize(c->ev_key));
-    if (c->h_flags[2] != ticket) return fail(c, PUP_EHIP, "pup_accumulate: the key kernel's verdict did not arrive");
+    if (c->h_flags[3] != ticket) return fail(c, PUP_EHIP, "pup_accumulate: the key kernel's verdict did not arrive");
+    const bool band = c->band_w > 0 && !(c->variant & 256) && !extra && c->h_flags[2] == 0;    // every window inside the dense band
     if (c->h_flags[0] != 0) return 1;                    // a window the index does not cover: the per-window kernels take the call
     const bool fact = !(mode & PUP_MODE_OOE) && c->h_flags[1] == 0 && !(c->variant & 4);
     if (!known) {
@@ -890,7 +922,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
         const int n0 = (int)((n_first * nw + n - 1) / std::max<long long>(n, 1));
         sa.n0 = paired ? std::min(std::max(n0, 1), nw - 1) : 0;
     }
-    sa.debug = c->debug_phases & 3;
+    sa.debug = c->debug_phases & 0x3;
     sa.timing = nullptr;
     if (c->debug_phases & 4) {                           // phase clocks (diagnostics): [G][16][8] long long, read by pup_debug_timing
         HIPCHK(c, c->d_timing.reserve((size_t)G * 16 * 8));
@@ -898,7 +930,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
         sa.timing = c->d_timing.p; c->timing_G = G;
     }                          // timing experiments (tools/k1_probe.py): variant bits 24 / 25
     if (ev) HIPCHK(c, hipEventRecord(ev[1], c->stream));
-    if (!launch_staged(W, a, sa, G, ACC, fact, extra, small21, c->stream))
+    if (!launch_staged(W, a, sa, G, ACC, fact, extra, small21, band, c->stream))
         return fail(c, PUP_ENOTSUP, "pup_accumulate: staged kernel not built for W=%d", W);
     HIPCHK(c, hipGetLastError());
     if (ev) HIPCHK(c, hipEventRecord(ev[2], c->stream));
@@ -1575,7 +1607,7 @@ int pup_get_stats(pup_ctx* c, pup_stats* out) {
     c->stats.probe_loads = (int64_t)h[1];
     c->stats.coverage_ms = c->last_coverage_ms;
     // regions the last staged call piled up from: the count its prepass left in mapped memory (the stream is idle now)
-    c->stats.staged_regions = (c->last_staged && c->h_flags && c->h_flags[6] == c->hint_ticket) ? (int64_t)c->h_flags[4] : 0;
+    c->stats.staged_regions = (c->last_staged && c->h_flags && c->h_flags[5] == c->hint_ticket) ? (int64_t)c->h_flags[4] : 0;
     *out = c->stats;
     return PUP_OK;
 }
@@ -1618,8 +1650,8 @@ int pup_event_elapsed_ms(pup_ctx* c, int a, int b, float* ms) {
 int pup_set_tuning(pup_ctx* c, int32_t chunk_snippets, int32_t variant) {
     if (!c) return PUP_EINVAL;
     if (chunk_snippets < 0) return fail(c, PUP_EINVAL, "pup_set_tuning: negative chunk size");
-    c->chunk_snippets = chunk_snippets; c->variant = variant & 0xff; c->group_waves = (variant >> 8) & 0xffff;
-    c->debug_phases = (variant >> 24) & 7;
+    c->chunk_snippets = chunk_snippets; c->variant = (variant & 0xff) | ((variant >> 19) & 0x100);   // bit 27 -> 256: never stage from the dense band c->group_waves = (variant >> 8) & 0xffff;
+    c->debug_phases = (variant >> 24) & 0x7;
     return PUP_OK;
 }
 

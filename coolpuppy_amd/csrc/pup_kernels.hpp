@@ -108,6 +108,9 @@ struct K1Args {
     unsigned long long* counters;  // [0] pixels inside windows, [1] search probes
     int*                err;       // set to 1 when a window leaves the bin table
     long long nnz;                 // pixels in the table (cnt32 / bal are padded by 64 zeros from here on)
+    const int* band;               // dense band of counts near the diagonal, band[row * band_w + j] = count(row, row + j), or nullptr
+    int      band_w;               // columns of the band (0: none)
+    unsigned band_zero;            // index of >= 64 zeros behind the band
     int      nf_pixels;            // != 0: some pixels have a non-finite balanced value although both their weights are numbers
                                    //       (weights of +-inf): per-snippet outputs then multiply count * w[row] * w[col] out
                                    //       themselves — `bal` stores NaN products as 0 (see lookup_bal)
@@ -1653,6 +1656,28 @@ __global__ void add_counts_kernel(long long* n, const long long* dn, int T) {
 }
 
 // interleave bin2/count into {col,count} pairs (upload helper), 64-bit or 32-bit column ids
+// dense band of counts (staged kernel, see pup_staged.hpp): one wave per row copies the row's pixels with
+// col - row < band_w (they are the first ones of the row: columns ascend) to band[row * band_w + (col - row)]
+__global__ __launch_bounds__(256) void band_fill_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
+                                                        int* __restrict__ band, int band_w, long long nbins) {
+    const int lane = threadIdx.x & 63;
+    long long r = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long stride = (long long)gridDim.x * (blockDim.x >> 6);
+    for (; r < nbins; r += stride) {
+        const long long b = indptr[r], e = indptr[r + 1];
+        for (long long k0 = b; k0 < e; k0 += 64) {
+            const long long k = k0 + lane;
+            bool more = false;
+            if (k < e) {
+                const int2 pc = px[k];
+                const long long j = (long long)pc.x - r;
+                if (j >= 0 && j < band_w) { band[r * band_w + j] = pc.y; more = true; }
+            }
+            if (__ballot(more) == 0ull) break;           // (uniform) the rest of the row lies right of the band
+        }
+    }
+}
+
 // the same from the (tile, flip) run boundaries {flip_from | tile end, tile end} per tile (the staged path's host table)
 __global__ void add_counts_from_ends_kernel(long long* n, const long long* seg_end, int T) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;

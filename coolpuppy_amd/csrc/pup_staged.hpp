@@ -94,9 +94,10 @@ template <int W, bool OOE, bool EXTRA, bool SMALL = false, bool FACT = true> str
                                                          // need up to 256 registers: 8 waves on the same regions
 };
 
-template <int W, bool OOE, int RSR, int RSC, int NW, int ACC, bool FACT, bool EXTRA>
+template <int W, bool OOE, int RSR, int RSC, int NW, int ACC, bool FACT, bool EXTRA, bool BAND = false>
 __global__ __launch_bounds__(kWave * NW, (RSR == 64 && NW == 8 && FACT && !OOE && !EXTRA && W <= 21) ? 2 : 1)
 void pileup_staged_kernel(K1Args a, StagedArgs sa) {
+    static_assert(!(BAND && EXTRA), "pixel statistics need the presence bits of the index: sparse staging");
     static_assert(W >= 3 && W <= 31, "workgroup-staged kernel serves windows of 3..31 bins");
     static_assert(!(FACT && OOE), "factorised counting needs validity to factorise into row and column masks");
     static_assert(ACC == 1 || ACC == 2, "one or two accumulator sets");
@@ -338,6 +339,92 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
         }
     };
 
+    // ---- staging from the dense BAND of counts (K1Args::band: band[row][j] = count(row, row + j), j < band_w) -----------
+    // The sparse-to-dense conversion above — index words, presence bits, ranks: ~20 VALU instructions per row half — is
+    // done once per TABLE instead of once per staged region: a region row is then 128 consecutive counts of the band, one
+    // coalesced load per half with an address that is a scalar plus the lane number.  (Counters, round 3: with 128 x 128
+    // regions the staged kernel is bound by VALU issue, half of it the per-region lookups.)  Lanes whose cell is masked
+    // (non-FACT), below the diagonal or outside the staged rows read the zero behind the band.
+    auto band_issue = [&](int ev, int (&v)[NRH], double (&wc)[NH], double& wrv) __attribute__((always_inline)) {
+        const int R = fld(ev, 0), C = fld(ev, 1), ch_end = fld(ev, 6), row_lo = fld(ev, 21), row_hi = fld(ev, 22);
+        const unsigned zero_at = (unsigned)a.band_zero;  // index of BAND zeros behind the last row
+        const char* bbase = reinterpret_cast<const char*>(a.band);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int rr = wave * RPW + i;
+            const int row = R + rr;
+            const bool live = row < ch_end && rr >= row_lo && rr < row_hi;
+            const bool row_bad = !FACT && ((fld64(ev, 16 + 2 * (rr >> 6)) >> (rr & 63)) & 1ull);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                // FACT: only the cells below the first kept diagonal must go (they lie left of the band); else the full mask
+                unsigned long long keep;
+                if constexpr (FACT) {                    // (masked bins multiply to 0 anyway: no column / row mask)
+                    const int t0 = igd - (C + 64 * h - row);
+                    keep = t0 <= 0 ? ~0ull : (t0 >= 64 ? 0ull : ~((1ull << t0) - 1ull));
+                } else keep = ok_mask(ev, rr, h, row_bad);
+                if (!live) keep = 0ull;
+                const bool has = __builtin_amdgcn_inverse_ballot_w64(keep);
+                const unsigned cell = (unsigned)row * (unsigned)a.band_w + (unsigned)(C + 64 * h - row);   // (scalar) j of lane 0
+                const unsigned off = (has ? cell + (unsigned)lane : zero_at) << 2;
+                v[i * NH + h] = *reinterpret_cast<const int*>(bbase + off);
+            }
+        }
+        const double* wsrc = a.weight ? a.weight : reinterpret_cast<const double*>(a.indptr);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const long long col = (long long)C + 64 * h + lane;
+            const double w = wsrc[col < a.nbins ? col : a.nbins - 1];
+            wc[h] = a.weight ? ((nf || w == w) ? w : 0.0) : 1.0;
+        }
+        {   // row weights: lane i < RPW holds its row's, broadcast at store time
+            const long long row = (long long)R + my_rr;
+            const double w = wsrc[row < a.nbins ? row : a.nbins - 1];
+            wrv = a.weight ? ((nf || w == w) ? w : 0.0) : 1.0;
+        }
+    };
+    auto band_store = [&](auto nf_tag, int ev, const int (&v)[NRH], const double (&wc)[NH], double wrv, const ExpSel& es) __attribute__((always_inline)) {
+        constexpr bool NFP = decltype(nf_tag)::value;
+        const int R = fld(ev, 0), C = fld(ev, 1), ch_end = fld(ev, 6), row_lo = fld(ev, 21), row_hi = fld(ev, 22);
+        unsigned long long okn[NH];                      // lane i < RPW: validity bits of its row (non-FACT)
+        if constexpr (!FACT) {
+            const int row = R + my_rr;
+            const bool live = lane < RPW && row < ch_end && my_rr >= row_lo && my_rr < row_hi;
+            const bool row_bad = (a.badbits[(row < a.nbins ? row : 0) >> 6] >> (row & 63)) & 1ull;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) okn[h] = live ? ok_mask(ev, my_rr, h, row_bad) : 0ull;
+        }
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int rr = wave * RPW + i;
+            if (rr < row_lo || rr >= row_hi) continue;   // (uniform) no window of the block reads this row
+            const double wr = __longlong_as_double((long long)bcast64((unsigned long long)__double_as_longlong(wrv), i));
+#pragma unroll
+            for (int hh = 0; hh < NH; ++hh) {
+                double val = (double)v[i * NH + hh] * wr * wc[hh];
+                if (NFP) val = (val == val) ? val : 0.0;
+                if (OOE) {
+                    const int row = R + rr;
+                    long long ad = (long long)(C + 64 * hh + lane) - row; if (ad < 0) ad = -ad;
+                    const double e = use_exp ? es.at(ad) : qnan;
+                    val = val / e;
+                    val = (val == val) ? val : 0.0;         // NaN quotients are skipped, inf is kept
+                    int e_ok = (e == e && e != 0.0) ? 1 : 0;     // (through a register the compiler cannot fold: see store_region)
+                    asm volatile("" : "+v"(e_ok));
+                    const unsigned long long eok = __ballot(e_ok);
+                    if (lane == i) okn[hh] &= eok;
+                }
+                tile[rr * LS + 64 * hh + lane] = val;
+            }
+        }
+        if constexpr (!FACT) {
+            if (lane < RPW && my_rr >= row_lo && my_rr < row_hi) {
+#pragma unroll
+                for (int hh = 0; hh < NH; ++hh) vbits[my_rr * VBW + hh] = okn[hh];
+            }
+        }
+    };
+
     // ---- the windows of the staged block ---------------------------------------------------------------------------
     // Every wave owns a contiguous SLICE of the block's windows — wave w the windows [w M, (w + 1) M), M = ceil(count / NW) —
     // and walks it in batches of 64, a lane per window: one 2-byte load per lane fetches a batch (the first batch of a block
@@ -504,6 +591,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
             if (lo + kWave < hi) wf = load_batch(g.start, lo + kWave, hi);
             const int nb = (hi - lo) < kWave ? (hi - lo) : kWave;
             fact_batch(g, drv, dcv, nb);
+            // (measured: without the split and the priority flip the kernel is 5 % slower — tools/k1_probe.py history in DESIGN §4)
             const int cut = (nb * (wave & 3) * 43) >> 8;                           // ~ nb * (wave & 3) / 6
             const int half = nb >> 1;
             set_prio(age);
@@ -603,6 +691,54 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
         __syncthreads();
     };
 
+    // ---- the block loop, band staging: region b is piled up while b+1's counts and b+2's table entry are on their way --------
+    if constexpr (BAND) {
+        int ev0 = entry_load(bb), ev1 = ev0, evn = ev0;
+        int v[NRH];
+        double wc[NH], wrv = 1.0;
+        int w0f, w1f = 0;
+        {   // prologue: stage block bb without overlap
+            band_issue(ev0, v, wc, wrv);
+            first_coords(ev0, w0f);
+            if (bb + 1 < be) ev1 = entry_load(bb + 1);
+            const ExpSel es0 = exp_of(ev0);
+            __syncthreads();
+            if (nf) band_store(std::true_type{}, ev0, v, wc, wrv, es0); else band_store(std::false_type{}, ev0, v, wc, wrv, es0);
+            __syncthreads();
+        }
+        long long tk[6] = {0, 0, 0, 0, 0, 0};
+        const bool timed = sa.timing != nullptr;
+        auto tick = [&]() __attribute__((always_inline)) -> long long { return timed ? (long long)__builtin_readcyclecounter() : 0; };
+        for (int b = bb; b < be; ++b) {
+            const bool has1 = b + 1 < be, has2 = b + 2 < be;
+            const long long t0 = tick();
+            auto lookahead = [&]() __attribute__((always_inline)) {
+                if (has1) { if (!(sa.debug & 2)) band_issue(ev1, v, wc, wrv); first_coords(ev1, w1f); }
+                if (has2) evn = entry_load(b + 2);
+            };
+            const Cur c0 = cur_of(ev0);
+            const long long t1 = tick();
+            windows(c0, w0f, lookahead);
+            const long long t2 = tick();
+            const int seg0 = fld(ev0, 20);
+            if (!has1) { flush(seg0); break; }
+            const ExpSel es1 = exp_of(ev1);
+            if (fld(ev1, 20) != seg0) flush(seg0);       // (uniform) the next block belongs to another segment
+            else __syncthreads();                        // every wave is done reading region b
+            const long long t3 = tick();
+            if (!(sa.debug & 2)) { if (nf) band_store(std::true_type{}, ev1, v, wc, wrv, es1); else band_store(std::false_type{}, ev1, v, wc, wrv, es1); }
+            const long long t4 = tick();
+            __syncthreads();
+            const long long t5 = tick();
+            ev0 = ev1; w0f = w1f; ev1 = evn;
+            if (timed) { tk[0] += t1 - t0; tk[1] += t2 - t1; tk[2] += t3 - t2; tk[3] += t4 - t3; tk[4] += t5 - t4; tk[5] += tick() - t5; }
+        }
+        if (timed && lane == 0) {
+            long long* o = sa.timing + ((size_t)g_id * NW + wave) * 8;
+            for (int i = 0; i < 6; ++i) o[i] = tk[i];
+            o[6] = be - bb; o[7] = 0;
+        }
+    } else
     // ---- the block loop: region b is piled up while b+1's values, b+2's index lines and b+3's table entry are on their way
     {
         int ev0 = entry_load(bb), ev1 = ev0, ev2 = ev0, evn = ev0;   // entries are consumed one stage after their load was issued
@@ -679,9 +815,10 @@ __global__ __launch_bounds__(256) void staged_key_kernel(const int* __restrict__
                                                          const ExpRegion* __restrict__ eregs, int n_eregs,
                                                          int W, int BR, int BC, int sh_br, int sh_er, int sh_seg,
                                                          int seg_shift /* 1: no flipped windows, the flip bit is left out */,
-                                                         int clear_gap /* igd + W - 1 */,
+                                                         int clear_gap /* igd + W - 1 */, int band_w /* 0: no band table */,
                                                          KeyT* __restrict__ keys, unsigned short* __restrict__ vals,
-                                                         unsigned* __restrict__ counters /* [0] ineligible, [1] windows a diagonal mask reaches */) {
+                                                         unsigned* __restrict__ counters /* [0] ineligible, [1] windows a diagonal mask
+                                                                                            reaches, [2] windows leaving the dense band */) {
     // small tables go to LDS once per workgroup: per window the chain of dependent global loads is r0 -> bin_chrom only
     constexpr int kMaxChrom = 512, kPer = 4;
     __shared__ int s_cs[kMaxChrom], s_ce[kMaxChrom], s_bb[kMaxChrom];
@@ -723,6 +860,8 @@ __global__ __launch_bounds__(256) void staged_key_kernel(const int* __restrict__
         {   // one atomic per wave, not per window (a call of near-diagonal windows would serialise on the counter)
             const unsigned long long near = __ballot(live && c - r < clear_gap);
             if (near != 0ull && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)near) - 1)) atomicAdd(&counters[1], (unsigned)__popcll(near));
+            const unsigned long long far = __ballot(live && band_w > 0 && (c + W - 1) - r >= band_w);
+            if (far != 0ull && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)far) - 1)) atomicAdd(&counters[2], (unsigned)__popcll(far));
         }
         if (!live) continue;
         keys[i] = (KeyT)(((unsigned long long)(seg >> seg_shift) << sh_seg) | (er << sh_er) | (br << sh_br) | bc);
@@ -735,12 +874,11 @@ __global__ __launch_bounds__(256) void staged_key_kernel(const int* __restrict__
 
 // hand the key kernel's verdict to the host without stalling the stream: one thread copies the two counters into mapped
 // page-locked host memory; the host waits on an event recorded right behind this kernel while the sort is already running
-__global__ void staged_publish_kernel(const unsigned* __restrict__ counters, volatile unsigned* host_flags, unsigned ticket) {
+__global__ void staged_publish_kernel(const unsigned* __restrict__ counters, int n, volatile unsigned* host_flags, unsigned ticket) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        host_flags[0] = counters[0];
-        host_flags[1] = counters[1];
+        for (int i = 0; i < n; ++i) host_flags[i] = counters[i];
         __threadfence_system();
-        host_flags[2] = ticket;
+        host_flags[n] = ticket;                          // behind the values: the host trusts them only under their ticket
         __threadfence_system();
     }
 }
