@@ -1,14 +1,26 @@
-"""Build the gfx950 shared library in-tree (explicit hipcc; no JIT cache, no CUDA-compat layer)."""
+"""Build the gfx950 shared library in-tree (explicit hipcc; no JIT cache, no CUDA-compat layer).
+
+The library is compiled as separate translation units — the engine, the host array passes, and eight units holding the
+instantiations of the workgroup-staged kernel (csrc/pup_staged_tu.hip, one per group of window widths) — side by side
+(one hipcc process per unit), then linked.  Objects live in csrc/_obj and are reused while their sources are older.
+"""
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(_HERE, "csrc", "pup_engine.hip")
-SRC_HOST = os.path.join(_HERE, "csrc", "pup_host.cpp")          # pinned memory + host array passes (no kernels)
-DEPS = [SRC, SRC_HOST, os.path.join(_HERE, "csrc", "pup_kernels.hpp"),
-        os.path.join(os.path.dirname(_HERE), "include", "pup_hip.h")]
+_CSRC = os.path.join(_HERE, "csrc")
+_OBJ = os.path.join(_CSRC, "_obj")
+SRC = os.path.join(_CSRC, "pup_engine.hip")
+SRC_HOST = os.path.join(_CSRC, "pup_host.cpp")          # pinned memory + host array passes (no kernels)
+SRC_TU = os.path.join(_CSRC, "pup_staged_tu.hip")
+N_STAGED_PARTS = 8                                       # = pup::kStagedParts (csrc/pup_staged_launch.hpp)
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "pup_hip.h")
+_KERNEL_HEADERS = [os.path.join(_CSRC, h) for h in ("pup_kernels.hpp", "pup_staged.hpp", "pup_staged_launch.hpp")]
+DEPS = [SRC, SRC_HOST, SRC_TU, HEADER] + _KERNEL_HEADERS
 OUT = os.path.join(_HERE, "libpup_hip.so")
+_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-result", "-pthread"]
 
 
 def hipcc_path():
@@ -25,19 +37,37 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build_hip(force=False, verbose=False):
+def _units():
+    """(object file, compile arguments after the flags, sources it depends on)"""
+    units = [(os.path.join(_OBJ, "pup_engine.o"), [SRC], [SRC, HEADER] + _KERNEL_HEADERS),
+             (os.path.join(_OBJ, "pup_host.o"), ["-x", "hip", SRC_HOST], [SRC_HOST, HEADER])]
+    for k in range(N_STAGED_PARTS):
+        units.append((os.path.join(_OBJ, f"pup_staged_tu{k}.o"), [f"-DPUP_TU_PART={k}", SRC_TU], [SRC_TU, HEADER] + _KERNEL_HEADERS))
+    return units
+
+
+def build_hip(force=False, verbose=False, jobs=None):
     """Compile coolpuppy_amd/libpup_hip.so for gfx950. Returns the path."""
     if not force and not is_stale():
         return OUT
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
-           "-Wall", "-Wno-unused-result", "-pthread", SRC, "-x", "hip", SRC_HOST, "-o", OUT]
-    if os.environ.get("COOLPUPPY_AMD_DEV_W21", "") == "1":      # development only: see launch_staged in pup_engine.hip
-        cmd.insert(1, "-DPUP_DEV_W21")
-    if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError(f"hipcc failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
+    os.makedirs(_OBJ, exist_ok=True)
+    hipcc = hipcc_path()
+    todo = []
+    for obj, args, deps in _units():
+        if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps):
+            todo.append([hipcc] + _FLAGS + ["-c"] + args + ["-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"hipcc failed ({res.returncode}): {' '.join(cmd)}\n{res.stdout}\n{res.stderr}")
+
+    jobs = jobs or int(os.environ.get("COOLPUPPY_AMD_BUILD_JOBS", "0")) or max(1, min(len(todo), os.cpu_count() or 1))
+    with ThreadPoolExecutor(max_workers=max(1, jobs)) as pool:
+        list(pool.map(run, todo))
+    run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-pthread"] + [u[0] for u in _units()] + ["-o", OUT])
     return OUT
 
 

@@ -1397,6 +1397,18 @@ class PileUpper:
             if want_control:
                 note(KIND_CONTROL, "all")
         keys_all = list(dict.fromkeys(order[KIND_ROI] + order[KIND_CONTROL]))
+        # Tile numbers are the engine's business (results are looked up through `gid`, the output follows `order`): the
+        # staged kernel piles up FOUR consecutive groups from one staging of the matrix (pup_staged.hpp, sets of tile
+        # pairs), so groups whose windows lie at the same distance from the diagonal get neighbouring numbers
+        gb = [g for g in (groupby or [])]
+        if "distance_band" in gb and len(keys_all) > 4:
+            di = gb.index("distance_band")
+
+            def band_rank(k):
+                comp = k[di] if isinstance(k, tuple) and len(k) > di else None
+                return (0, tuple(comp)) if isinstance(comp, tuple) and len(comp) else (1, ())
+
+            keys_all = sorted(keys_all, key=band_rank)        # (stable: first-appearance order inside a band)
         gid = {k: i for i, k in enumerate(keys_all)}
         G = len(keys_all)
         T = 2 * G

@@ -8,6 +8,7 @@
 #include "../../include/pup_hip.h"
 #include "pup_kernels.hpp"
 #include "pup_staged.hpp"
+#include "pup_staged_launch.hpp"
 
 #include <hip/hip_runtime.h>
 #include <cstring>
@@ -89,7 +90,7 @@ struct pup_ctx {
     DevBuf<pup::StagedBlock> d_blocks;
     DevBuf<int> d_wgfirst;
     DevBuf<long long> d_timing; int timing_G = 0;
-    DevBuf<unsigned char> d_recvalid;
+    DevBuf<unsigned char> d_recvalid, d_teams;
     DevBuf<long long> d_segend;
     DevBuf<unsigned char> d_sorttmp;
     long long tiled_min = 1000000;          // fewer snippets: the whole pile-up is a fraction of a millisecond anyway
@@ -120,6 +121,7 @@ struct pup_ctx {
     // stats / timing
     std::vector<int> brow_sent;              // what d_brow / d_segend hold (plan_block_order)
     std::vector<long long> htab_sent;
+    std::vector<unsigned char> teams_sent;
     bool profiling = false;      // HIP events around the kernels
     bool count_pixels = false;   // kernels also count the pixels inside the windows (statistics; costs a little)
     pup_stats stats{};
@@ -197,68 +199,12 @@ bool tiled_supported(int W) { return W >= 3 && W <= 31 && (W & 1); }
 // workgroup-staged kernel (K1q, pup_staged.hpp): persistent workgroups over the device-built block table.  The region
 // geometry is a property of the instantiation (StagedGeom) and only depends on facts the host knows BEFORE the prepass
 // (window width, observed-over-expected, coverage / statistics riding along) — the block size of the prepass follows from it.
+// The instantiations themselves live in their own translation units (pup_staged_tu.hip, compiled once per group of window
+// widths, in parallel): pup::launch_staged picks the one for a call.
 struct StagedGeo { int RSR, RSC, NW; };
 StagedGeo staged_geometry(int W, bool ooe, bool extra, bool small21) {
     const bool big = W <= 21 && !ooe && !extra && !(small21 && W == 21);
     return StagedGeo{big ? 128 : 64, 128, big ? 16 : 8};
-}
-// fact: every window is clear of the diagonal mask and nothing is divided by expected -> validity factorises (FACT)
-// extra: coverage vectors and / or pixel statistics ride along (kept out of the plain instantiation's window loop)
-template <int W, bool OOE, int ACC, bool FACT, bool EXTRA>
-void launch_staged___(const pup::K1Args& a, const pup::StagedArgs& sa, int G, bool small21, bool band, hipStream_t s) {
-    using Geo = pup::StagedGeom<W, OOE, EXTRA, false, FACT>;
-    if constexpr (!EXTRA) {
-        if (band && !(W == 21 && !OOE && small21)) {     // regions staged from the dense band of counts
-            hipLaunchKernelGGL((pup::pileup_staged_kernel<W, OOE, Geo::RSR, Geo::RSC, Geo::NW, ACC, FACT, EXTRA, true>), dim3(G),
-                               dim3(pup::kWave * Geo::NW), 0, s, a, sa);
-            return;
-        }
-    }
-    if constexpr (W == 21 && !OOE && !EXTRA) {          // tuning probe (variant bit 7): the plain 21-bin kernel on 64 x 128 regions
-        if (small21) {
-            using GeoS = pup::StagedGeom<W, OOE, EXTRA, true, FACT>;
-            hipLaunchKernelGGL((pup::pileup_staged_kernel<W, OOE, GeoS::RSR, GeoS::RSC, GeoS::NW, ACC, FACT, EXTRA>), dim3(G),
-                               dim3(pup::kWave * GeoS::NW), 0, s, a, sa);
-            return;
-        }
-    }
-    hipLaunchKernelGGL((pup::pileup_staged_kernel<W, OOE, Geo::RSR, Geo::RSC, Geo::NW, ACC, FACT, EXTRA>), dim3(G),
-                       dim3(pup::kWave * Geo::NW), 0, s, a, sa);
-}
-template <int W, int ACC, bool EXTRA>
-void launch_staged__(const pup::K1Args& a, const pup::StagedArgs& sa, int G, bool fact, bool small21, bool band, hipStream_t s) {
-    if (a.mode & PUP_MODE_OOE) launch_staged___<W, true, ACC, false, EXTRA>(a, sa, G, small21, band, s);
-    else if (fact) launch_staged___<W, false, ACC, true, EXTRA>(a, sa, G, small21, band, s);
-    else launch_staged___<W, false, ACC, false, EXTRA>(a, sa, G, small21, band, s);
-}
-template <int W>
-void launch_staged_(const pup::K1Args& a, const pup::StagedArgs& sa, int G, int acc, bool fact, bool extra, bool small21, bool band, hipStream_t s) {
-    if (extra) { if (acc == 2) launch_staged__<W, 2, true>(a, sa, G, fact, small21, band, s); else launch_staged__<W, 1, true>(a, sa, G, fact, small21, band, s); }
-    else       { if (acc == 2) launch_staged__<W, 2, false>(a, sa, G, fact, small21, band, s); else launch_staged__<W, 1, false>(a, sa, G, fact, small21, band, s); }
-}
-bool launch_staged(int W, const pup::K1Args& a, const pup::StagedArgs& sa, int G, int acc, bool fact, bool extra, bool small21, bool band, hipStream_t s) {
-    switch (W) {
-#ifndef PUP_DEV_W21      // development builds (COOLPUPPY_AMD_DEV_W21=1) keep only the 21-bin staged kernels: a tenth of the compile time
-        case 3:  launch_staged_<3>(a, sa, G, acc, fact, extra, small21, band, s);  return true;
-        case 5:  launch_staged_<5>(a, sa, G, acc, fact, extra, small21, band, s);  return true;
-        case 7:  launch_staged_<7>(a, sa, G, acc, fact, extra, small21, band, s);  return true;
-        case 9:  launch_staged_<9>(a, sa, G, acc, fact, extra, small21, band, s);  return true;
-        case 11: launch_staged_<11>(a, sa, G, acc, fact, extra, small21, band, s); return true;
-        case 13: launch_staged_<13>(a, sa, G, acc, fact, extra, small21, band, s); return true;
-        case 15: launch_staged_<15>(a, sa, G, acc, fact, extra, small21, band, s); return true;
-        case 17: launch_staged_<17>(a, sa, G, acc, fact, extra, small21, band, s); return true;
-        case 19: launch_staged_<19>(a, sa, G, acc, fact, extra, small21, band, s); return true;
-#endif
-        case 21: launch_staged_<21>(a, sa, G, acc, fact, extra, small21, band, s); return true;
-#ifndef PUP_DEV_W21
-        case 23: launch_staged_<23>(a, sa, G, acc, fact, extra, small21, band, s); return true;
-        case 25: launch_staged_<25>(a, sa, G, acc, fact, extra, small21, band, s); return true;
-        case 27: launch_staged_<27>(a, sa, G, acc, fact, extra, small21, band, s); return true;
-        case 29: launch_staged_<29>(a, sa, G, acc, fact, extra, small21, band, s); return true;
-        case 31: launch_staged_<31>(a, sa, G, acc, fact, extra, small21, band, s); return true;
-#endif
-        default: return false;
-    }
 }
 
 // banded register-tile kernel: NCH column chunks of 16 cells -> windows up to 16*NCH wide
@@ -716,9 +662,9 @@ using Radix10 = rocprim::radix_sort_config<rocprim::default_config, rocprim::def
 extern "C++" {
 template <typename KeyT>
 static void launch_key_kernel(pup_ctx* c, int BR, int BC, unsigned grid, const int* dr0, const int* dc0, long long n, int nseg2t, int H,
-                              const pup::ExpRegion* d_eregs, int n_eregs, int W, int sh_br, int sh_er, int sh_seg, int seg_shift,
-                              int clear_gap, KeyT* keys) {
-#define PUP_KEY_ARGS dr0, dc0, n, (const long long*)c->d_segend.p, nseg2t, H, (const pup::IdxChrom*)c->idx_chrom.p, c->n_chrom, \
+                              int set_pairs, const pup::ExpRegion* d_eregs, int n_eregs, int W, int sh_br, int sh_er, int sh_seg,
+                              int seg_shift, int clear_gap, KeyT* keys) {
+#define PUP_KEY_ARGS dr0, dc0, n, (const long long*)c->d_segend.p, nseg2t, H, set_pairs, (const pup::IdxChrom*)c->idx_chrom.p, c->n_chrom, \
         (const unsigned short*)c->bin_chrom.p, (long long)c->nbins, (const int*)c->d_brow.p, d_eregs, n_eregs, W, BR, BC, sh_br, \
         sh_er, sh_seg, seg_shift, clear_gap, (c->band_w > 0 && !(c->variant & 256)) ? c->band_w : 0, keys, c->d_win.p, c->d_cnt32.p
     if (BR == 108 && BC == 108)
@@ -780,7 +726,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     std::vector<long long> sig;
     sig.reserve(8 + 2 * (size_t)T);
     sig.push_back(n); sig.push_back(T); sig.push_back(W); sig.push_back((long long)(mode & (PUP_MODE_OOE | PUP_MODE_COV)));
-    sig.push_back(ignore_diags); sig.push_back(flip_from ? 1 : 0); sig.push_back(c->variant & (4 | 64 | 128 | 256)); sig.push_back(extra ? 1 : 0);
+    sig.push_back(ignore_diags); sig.push_back(flip_from ? 1 : 0); sig.push_back(c->variant & (4 | 64 | 128 | 256 | 512)); sig.push_back(extra ? 1 : 0);
     for (int t = 0; t <= T; ++t) sig.push_back(tile_ptr[t]);
     if (flip_from) for (int t = 0; t < T; ++t) sig.push_back(flip_from[t]);
     const bool known = (sig == c->hint_sig) && c->hint_blocks >= 0;
@@ -805,7 +751,13 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
         c->brow_sent = brow_base;
     }
     const bool paired = T >= 2 && (T % 2) == 0 && !(c->variant & 64);
-    const int H = paired ? T / 2 : 0, U = paired ? H : T, ACC = paired ? 2 : 1;
+    const int H = paired ? T / 2 : 0;
+    // several tile pairs (grouped pile-ups: by strand, by distance, ...): four pairs share a pass — a staged region then serves
+    // the windows of eight tiles, each piled up by its own team of waves — instead of every pair staging the matrix again
+    const bool sets = paired && H >= 2 && W <= 21 && !(mode & PUP_MODE_OOE) && !extra && !small21 && !(c->variant & 512);
+    const int ACC = sets ? 8 : (paired ? 2 : 1), set_pairs = sets ? pup::kSetPairs : 1;
+    const int U = sets ? (H + set_pairs - 1) / set_pairs : (paired ? H : T);
+    const int slot_bits = sets ? pup::kSetSlotBits : 0;
     const int nseg = 2 * U;
     const int seg_shift = flip_from ? 0 : 1;            // no flipped windows: the flip bit is left out of the key
     // (tile, flip) runs of the caller's order, for the key kernel
@@ -816,7 +768,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     const int bits_er = n_eregs > 0 ? nbits((unsigned long long)n_eregs) : 0;
     const int sh_br = bits_bc, sh_er = sh_br + bits_br, sh_seg = sh_er + bits_er;
     const int nseg_key = nseg >> seg_shift;
-    const int end_bit = sh_seg + (nseg_key > 1 ? nbits((unsigned long long)(nseg_key - 1)) : 0);
+    const int end_bit = slot_bits + sh_seg + (nseg_key > 1 ? nbits((unsigned long long)(nseg_key - 1)) : 0);
     if (end_bit > 64) return 1;
     const bool k32 = end_bit <= 32;
 
@@ -824,7 +776,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     const int n_spans = (int)((n + pup::kSpan - 1) / pup::kSpan);
     const size_t ncnt = 4;                               // [0] ineligible [1] unclear [2] outside the band [3] blocks, then the span counters
     const size_t W2 = (size_t)W * W, Lf = W2 + 2 * (size_t)W;
-    const size_t nrec = (size_t)T * 2 * (size_t)G;       // record ((slot * U + unit) * 2 + flip) * G + workgroup = (tile * 2 + flip) * G + workgroup
+    const size_t nrec = (size_t)T * 2 * (size_t)G;       // record (tile * 2 + flip) * G + workgroup
     HIPCHK(c, c->d_win.reserve((size_t)n + 8)); HIPCHK(c, c->d_win2.reserve((size_t)n + 8));   // +8: K1q fetches four window values at a time
     if (c->d_segend.cap < htab.size()) c->htab_sent.clear();          // the buffer is about to move
     HIPCHK(c, c->d_segend.reserve(htab.size()));
@@ -841,6 +793,42 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
         HIPCHK(c, hipMemcpy(c->d_segend.p, htab.data(), htab.size() * 8, hipMemcpyHostToDevice));
         c->htab_sent = htab;
     }
+    // wave teams (StagedArgs::teams): per pass unit, the waves of a workgroup are dealt to the unit's tiles in proportion to
+    // the tiles' windows (every tile with windows gets a wave; then whoever has the most windows per wave gets the next).
+    // Two tables: for the 16-wave kernels (factorised counts) and for the 8-wave ones — which it will be is only known
+    // after the key kernel.
+    const int nw_fact = geo.NW, nw_full = geo.NW == 16 ? 8 : geo.NW;
+    std::vector<unsigned char> teams((size_t)2 * U * 16, 0);
+    if (ACC > 1)
+        for (int v = 0; v < 2; ++v) {
+            const int nw = v ? nw_full : nw_fact;
+            for (int u = 0; u < U; ++u) {
+                long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                int nwv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, used = 0;
+                for (int q = 0; q < ACC; ++q) {
+                    const int t = ACC == 8 ? pup::staged_tile<8>(u, q, H) : pup::staged_tile<2>(u, q, H);
+                    cnt[q] = t >= 0 ? tile_ptr[t + 1] - tile_ptr[t] : 0;
+                    if (cnt[q] > 0) { nwv[q] = 1; ++used; }
+                }
+                for (; used > 0 && used < nw; ++used) {
+                    int best = -1;
+                    for (int q = 0; q < ACC; ++q)
+                        if (nwv[q] > 0 && (best < 0 || cnt[q] * nwv[best] > cnt[best] * nwv[q])) best = q;
+                    ++nwv[best];
+                }
+                unsigned char* row = teams.data() + ((size_t)v * U + u) * 16;
+                int at = 0;
+                for (int q = 0; q <= ACC; ++q) { row[q] = (unsigned char)at; if (q < ACC) at += nwv[q]; }
+                for (int q = ACC + 1; q < 16; ++q) row[q] = (unsigned char)at;
+            }
+        }
+    if (ACC > 1 && teams != c->teams_sent) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->d_teams.cap < teams.size()) c->teams_sent.clear();
+        HIPCHK(c, c->d_teams.reserve(teams.size()));
+        HIPCHK(c, hipMemcpy(c->d_teams.p, teams.data(), teams.size(), hipMemcpyHostToDevice));
+        c->teams_sent = teams;
+    }
     size_t tmp_bytes = 0;
     hipError_t se = k32 ? rocprim::radix_sort_pairs<Radix10>(nullptr, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_win.p, c->d_win2.p, (size_t)n, 0, end_bit, c->stream)
                         : rocprim::radix_sort_pairs<Radix10>(nullptr, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_win.p, c->d_win2.p, (size_t)n, 0, end_bit, c->stream);
@@ -854,10 +842,10 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     const unsigned gk4 = (unsigned)((n + 1023) / 1024);               // key kernel: four windows per thread
     const pup::ExpRegion* d_eregs = n_eregs > 0 ? c->exp_regions.p : nullptr;
     const unsigned ticket = ++c->ticket;
-    if (k32) launch_key_kernel<unsigned>(c, BR, BC, gk4, dr0, dc0, (long long)n, nseg2t, H, d_eregs, n_eregs, W, sh_br, sh_er, sh_seg,
-                                         seg_shift, ignore_diags + W - 1, c->d_k32.p);
-    else launch_key_kernel<unsigned long long>(c, BR, BC, gk4, dr0, dc0, (long long)n, nseg2t, H, d_eregs, n_eregs, W, sh_br, sh_er,
-                                               sh_seg, seg_shift, ignore_diags + W - 1, c->d_keys.p);
+    if (k32) launch_key_kernel<unsigned>(c, BR, BC, gk4, dr0, dc0, (long long)n, nseg2t, H, set_pairs, d_eregs, n_eregs, W, sh_br, sh_er,
+                                         sh_seg, seg_shift, ignore_diags + W - 1, c->d_k32.p);
+    else launch_key_kernel<unsigned long long>(c, BR, BC, gk4, dr0, dc0, (long long)n, nseg2t, H, set_pairs, d_eregs, n_eregs, W, sh_br,
+                                               sh_er, sh_seg, seg_shift, ignore_diags + W - 1, c->d_keys.p);
     hipLaunchKernelGGL(pup::staged_publish_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned*)c->d_cnt32.p, 3,
                        (volatile unsigned*)c->d_flags, ticket);
     HIPCHK(c, hipEventRecord(c->ev_key, c->stream));
@@ -868,26 +856,26 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
                                                 (size_t)n, 0, end_bit, c->stream);
         if (se != hipSuccess) return fail(c, PUP_EHIP, "pup_accumulate: block sort: %s", hipGetErrorString(se));
         hipLaunchKernelGGL((pup::count_heads_kernel<unsigned>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
-                           (const unsigned*)c->d_k32b.p, (long long)n, d_spans);
+                           (const unsigned*)c->d_k32b.p, (long long)n, slot_bits, d_spans);
         hipLaunchKernelGGL((pup::block_starts_kernel<unsigned>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
-                           (const unsigned*)c->d_k32b.p, (long long)n, (const unsigned*)d_spans, c->d_starts.p, c->d_cnt32.p + 3);
+                           (const unsigned*)c->d_k32b.p, (long long)n, slot_bits, (const unsigned*)d_spans, c->d_starts.p, c->d_cnt32.p + 3);
         hipLaunchKernelGGL((pup::staged_table_kernel<unsigned>), dim3(gt), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
                            (const unsigned*)(c->d_cnt32.p + 3), (long long)n, (const unsigned*)c->d_k32b.p,
                            (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
-                           c->n_chrom, W, geo.RSR, geo.RSC, sh_br, sh_er, sh_seg, seg_shift, n_eregs,
+                           c->n_chrom, W, geo.RSR, geo.RSC, sh_br, sh_er, sh_seg, seg_shift, slot_bits, n_eregs,
                            (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G);
     } else {
         se = rocprim::radix_sort_pairs<Radix10>(c->d_sorttmp.p, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_win.p, c->d_win2.p,
                                                 (size_t)n, 0, end_bit, c->stream);
         if (se != hipSuccess) return fail(c, PUP_EHIP, "pup_accumulate: block sort: %s", hipGetErrorString(se));
         hipLaunchKernelGGL((pup::count_heads_kernel<unsigned long long>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
-                           (const unsigned long long*)c->d_keys2.p, (long long)n, d_spans);
+                           (const unsigned long long*)c->d_keys2.p, (long long)n, slot_bits, d_spans);
         hipLaunchKernelGGL((pup::block_starts_kernel<unsigned long long>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
-                           (const unsigned long long*)c->d_keys2.p, (long long)n, (const unsigned*)d_spans, c->d_starts.p, c->d_cnt32.p + 3);
+                           (const unsigned long long*)c->d_keys2.p, (long long)n, slot_bits, (const unsigned*)d_spans, c->d_starts.p, c->d_cnt32.p + 3);
         hipLaunchKernelGGL((pup::staged_table_kernel<unsigned long long>), dim3(gt), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
                            (const unsigned*)(c->d_cnt32.p + 3), (long long)n, (const unsigned long long*)c->d_keys2.p,
                            (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
-                           c->n_chrom, W, geo.RSR, geo.RSC, sh_br, sh_er, sh_seg, seg_shift, n_eregs,
+                           c->n_chrom, W, geo.RSR, geo.RSC, sh_br, sh_er, sh_seg, seg_shift, slot_bits, n_eregs,
                            (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G);
     }
     // leave the block count where the NEXT call with this signature finds it without waiting
@@ -914,14 +902,8 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     pup::K1Args a{};
     fill_k1_args(c, a, ignore_diags, mode);
     pup::StagedArgs sa{};
-    sa.blocks = c->d_blocks.p; sa.win = c->d_win2.p; sa.wg_first = c->d_wgfirst.p; sa.U = U; sa.rec_valid = c->d_recvalid.p;
-    {   // paired tiles: the waves of a workgroup split into two teams in proportion to the windows of the two halves
-        long long n_first = 0;
-        for (int t = 0; t < H; ++t) n_first += tile_ptr[t + 1] - tile_ptr[t];
-        const int nw = (geo.NW == 16 && !fact) ? 8 : geo.NW;      // (StagedGeom: 16 waves only with factorised counts)
-        const int n0 = (int)((n_first * nw + n - 1) / std::max<long long>(n, 1));
-        sa.n0 = paired ? std::min(std::max(n0, 1), nw - 1) : 0;
-    }
+    sa.blocks = c->d_blocks.p; sa.win = c->d_win2.p; sa.wg_first = c->d_wgfirst.p; sa.U = U; sa.PH = H; sa.rec_valid = c->d_recvalid.p;
+    sa.teams = ACC > 1 ? c->d_teams.p + (fact ? 0 : (size_t)U * 16) : nullptr;      // (StagedGeom: 16 waves only with factorised counts)
     sa.debug = c->debug_phases & 0x3;
     sa.timing = nullptr;
     if (c->debug_phases & 4) {                           // phase clocks (diagnostics): [G][16][8] long long, read by pup_debug_timing
@@ -930,7 +912,8 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
         sa.timing = c->d_timing.p; c->timing_G = G;
     }                          // timing experiments (tools/k1_probe.py): variant bits 24 / 25
     if (ev) HIPCHK(c, hipEventRecord(ev[1], c->stream));
-    if (!launch_staged(W, a, sa, G, ACC, fact, extra, small21, band, c->stream))
+    const pup::StagedLaunch sl{W, G, ACC, fact, extra, small21, band};
+    if (!pup::launch_staged(sl, a, sa, c->stream))
         return fail(c, PUP_ENOTSUP, "pup_accumulate: staged kernel not built for W=%d", W);
     HIPCHK(c, hipGetLastError());
     if (ev) HIPCHK(c, hipEventRecord(ev[2], c->stream));
@@ -1650,7 +1633,9 @@ int pup_event_elapsed_ms(pup_ctx* c, int a, int b, float* ms) {
 int pup_set_tuning(pup_ctx* c, int32_t chunk_snippets, int32_t variant) {
     if (!c) return PUP_EINVAL;
     if (chunk_snippets < 0) return fail(c, PUP_EINVAL, "pup_set_tuning: negative chunk size");
-    c->chunk_snippets = chunk_snippets; c->variant = (variant & 0xff) | ((variant >> 19) & 0x100);   // bit 27 -> 256: never stage from the dense band c->group_waves = (variant >> 8) & 0xffff;
+    c->chunk_snippets = chunk_snippets;
+    c->variant = (variant & 0xff) | ((variant >> 19) & 0x300);   // bit 27 -> 256: never stage from the dense band; bit 28 -> 512: tile pairs one by one
+    c->group_waves = (variant >> 8) & 0xffff;
     c->debug_phases = (variant >> 24) & 0x7;
     return PUP_OK;
 }

@@ -19,6 +19,11 @@
 //   anti-transpose for flipped snippets                                    coolpuppy/coolpup.py:128-131
 // No MFMA: this is a gather/reduce bounded by memory latency and bandwidth, not a contraction.
 #pragma once
+// kernels that are not templates are defined in every translation unit that includes this header: the units holding only
+// instantiations of the staged kernel (pup_staged_tu.hip) define PUP_KERNEL as `static __global__` and never reference them
+#ifndef PUP_KERNEL
+#define PUP_KERNEL __global__
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
@@ -420,7 +425,7 @@ __device__ __forceinline__ int chrom_of(const K1Args& a, ChromOf& cc, int c) {
 }
 
 // one thread per (row, chromosome boundary): rowseg[row][k] = pixels of the row with column < start of chromosome k
-__global__ __launch_bounds__(256) void rowseg_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
+PUP_KERNEL __launch_bounds__(256) void rowseg_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
                                                      const IdxChrom* __restrict__ chroms, int n_chrom,
                                                      unsigned* __restrict__ rowseg, long long nbins) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1105,7 +1110,7 @@ __device__ __forceinline__ bool bin_bad(const K1Args& a, int bin) { return (a.ba
 // Emission mode (emit != nullptr, pup_extract): nothing is accumulated; the zoomed S x S tile of snippet s is written
 // to emit[s] (reference frame, i.e. TRANSPOSE undone; NaN where the reference's zoomed NaN mask is set) and its zoomed
 // coverage vectors to emit_cov[s] = {cov_start[S], cov_end[S]}.  Blocks then stride over snippets 0..emit_n.
-__global__ __launch_bounds__(1024) void pileup_rescale_kernel(K1Args a, const int* __restrict__ hs, const int* __restrict__ wsz,
+PUP_KERNEL __launch_bounds__(1024) void pileup_rescale_kernel(K1Args a, const int* __restrict__ hs, const int* __restrict__ wsz,
                                                              double* __restrict__ emit, double* __restrict__ emit_cov,
                                                              long long emit_n) {
 #pragma clang fp contract(off)      // zoom coordinates must be plain IEEE products (see below)
@@ -1280,7 +1285,7 @@ __global__ __launch_bounds__(1024) void pileup_rescale_kernel(K1Args a, const in
 // balanced value of every pixel (one wave per row) — the product PileUpper.get_data() obtains from
 // cooler's matrix(balance=w) once per region (coolpup.py:1053-1055), evaluated in the same order
 // (count * w[row]) * w[col]; NaN (masked bin) is stored as 0 and masked through badbits instead
-__global__ __launch_bounds__(256) void balance_pixels_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
+PUP_KERNEL __launch_bounds__(256) void balance_pixels_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
                                                              const double* __restrict__ weight, double* __restrict__ bal,
                                                              long long nbins) {
     const int lane = threadIdx.x & 63;
@@ -1303,7 +1308,7 @@ __global__ __launch_bounds__(256) void balance_pixels_kernel(const long long* __
 // (np.isfinite, lib/puputils.py:18-29) while the empty cells of the same rows still count.  The pile-up kernels decide
 // validity from the bin masks alone, so such pixels — none at all in a normally balanced table — are listed once per
 // weight column (both orientations, sorted by (row, col)) and a small pass after the reduction takes them out of `num`.
-__global__ __launch_bounds__(256) void collect_nonfinite_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
+PUP_KERNEL __launch_bounds__(256) void collect_nonfinite_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
                                                                 const double* __restrict__ weight, long long nbins,
                                                                 unsigned long long* __restrict__ keys, unsigned long long cap,
                                                                 unsigned long long* __restrict__ count) {
@@ -1331,7 +1336,7 @@ __global__ __launch_bounds__(256) void collect_nonfinite_kernel(const long long*
 }
 
 // one thread per (snippet, window row): the listed pixels under that row are cells the kernels counted as valid
-__global__ __launch_bounds__(256) void nonfinite_fix_kernel(K1Args a, const unsigned long long* __restrict__ keys, long long nkeys,
+PUP_KERNEL __launch_bounds__(256) void nonfinite_fix_kernel(K1Args a, const unsigned long long* __restrict__ keys, long long nkeys,
                                                             long long n, const long long* __restrict__ tile_ptr,
                                                             const long long* __restrict__ flip_from, int T,
                                                             long long* __restrict__ acc_num) {
@@ -1365,7 +1370,7 @@ __global__ __launch_bounds__(256) void nonfinite_fix_kernel(K1Args a, const unsi
     }
 }
 
-__global__ void badbits_kernel(const double* __restrict__ weight, unsigned long long* __restrict__ badbits,
+PUP_KERNEL void badbits_kernel(const double* __restrict__ weight, unsigned long long* __restrict__ badbits,
                                long long nbins, long long nwords) {
     const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= nwords) return;
@@ -1380,7 +1385,7 @@ __global__ void badbits_kernel(const double* __restrict__ weight, unsigned long 
 
 // ---- index construction (once per pixel table) ---------------------------------------------------------
 // one wave per row: set the presence bit of every cis pixel of the row
-__global__ __launch_bounds__(256) void index_fill_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
+PUP_KERNEL __launch_bounds__(256) void index_fill_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
                                                          const IdxChrom* __restrict__ chroms, int n_chrom,
                                                          IdxBlock* __restrict__ idx, long long nbins) {
     const int lane = threadIdx.x & 63;
@@ -1406,7 +1411,7 @@ __global__ __launch_bounds__(256) void index_fill_kernel(const long long* __rest
 
 // one thread per row: per block the absolute position of its first pixel, the in-block cumulative counts,
 // and the copy of the following block's first word
-__global__ __launch_bounds__(256) void index_rank_kernel(const long long* __restrict__ indptr,
+PUP_KERNEL __launch_bounds__(256) void index_rank_kernel(const long long* __restrict__ indptr,
                                                          const IdxChrom* __restrict__ chroms, int n_chrom,
                                                          IdxBlock* __restrict__ idx, long long nbins) {
     long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1487,7 +1492,7 @@ constexpr int kCovCols = 4096;
 // the host forms cov_tot = cov_cis + cov_trans.  A wave streams its row with 16-byte loads (two pixels per lane), two
 // loads in flight per lane: the pass is bound by load latency, not by the LDS atomics (the distinct columns of one
 // row never collide; four loads in flight per lane and a 2048-column window were measured: 0.86 ms and 2.1 ms against 0.78).  Columns beyond the block's LDS window and all trans columns take global atomics.
-__global__ __launch_bounds__(512) void coverage_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
+PUP_KERNEL __launch_bounds__(512) void coverage_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
                                                        const IdxChrom* __restrict__ chroms, int n_chrom, int ignore_diags,
                                                        unsigned long long* cov_trans, unsigned long long* cov_cis,
                                                        long long nbins) {
@@ -1546,7 +1551,7 @@ __device__ __forceinline__ int find_count(const K1Args& a, int row, int col, boo
     return found ? a.px[lo].y : 0;
 }
 
-__global__ __launch_bounds__(kWave) void stripes_kernel(K1Args a, long long n, double* __restrict__ h_out,
+PUP_KERNEL __launch_bounds__(kWave) void stripes_kernel(K1Args a, long long n, double* __restrict__ h_out,
                                                        double* __restrict__ v_out) {
     const int W = a.W, pad = W / 2;
     const int lane = threadIdx.x;
@@ -1593,7 +1598,7 @@ __global__ __launch_bounds__(kWave) void stripes_kernel(K1Args a, long long n, d
 // per-snippet post-processing step in the reference, coolpup.py:128-131).  Exists for the per-snippet Python
 // callbacks (postprocess_func / extra_sum_funcs), whose cost per snippet dwarfs this gather: one 256-thread
 // workgroup per snippet, every cell looked up on its own through the rank-bitmap index (or a binary search).
-__global__ __launch_bounds__(256) void extract_windows_kernel(K1Args a, long long n, double* __restrict__ out,
+PUP_KERNEL __launch_bounds__(256) void extract_windows_kernel(K1Args a, long long n, double* __restrict__ out,
                                                               double* __restrict__ cov_out) {
     const int W = a.W, W2 = W * W;
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -1644,13 +1649,13 @@ __global__ __launch_bounds__(256) void extract_windows_kernel(K1Args a, long lon
 }
 
 // out[i] = src[pos[i]] (first-snippet rows of the launch groups when the snippets already live on the device)
-__global__ void gather_int_kernel(const int* __restrict__ src, const long long* __restrict__ pos, int* __restrict__ out, int n) {
+PUP_KERNEL void gather_int_kernel(const int* __restrict__ src, const long long* __restrict__ pos, int* __restrict__ out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = src[pos[i]];
 }
 
 // n[t] += dn[t]
-__global__ void add_counts_kernel(long long* n, const long long* dn, int T) {
+PUP_KERNEL void add_counts_kernel(long long* n, const long long* dn, int T) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < T) n[t] += dn[t];
 }
@@ -1658,7 +1663,7 @@ __global__ void add_counts_kernel(long long* n, const long long* dn, int T) {
 // interleave bin2/count into {col,count} pairs (upload helper), 64-bit or 32-bit column ids
 // dense band of counts (staged kernel, see pup_staged.hpp): one wave per row copies the row's pixels with
 // col - row < band_w (they are the first ones of the row: columns ascend) to band[row * band_w + (col - row)]
-__global__ __launch_bounds__(256) void band_fill_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
+PUP_KERNEL __launch_bounds__(256) void band_fill_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
                                                         int* __restrict__ band, int band_w, long long nbins) {
     const int lane = threadIdx.x & 63;
     long long r = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -1679,7 +1684,7 @@ __global__ __launch_bounds__(256) void band_fill_kernel(const long long* __restr
 }
 
 // the same from the (tile, flip) run boundaries {flip_from | tile end, tile end} per tile (the staged path's host table)
-__global__ void add_counts_from_ends_kernel(long long* n, const long long* seg_end, int T) {
+PUP_KERNEL void add_counts_from_ends_kernel(long long* n, const long long* seg_end, int T) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < T) n[t] += seg_end[2 * t + 1] - (t ? seg_end[2 * t - 1] : 0);
 }

@@ -40,7 +40,7 @@ namespace pup {
 struct __attribute__((aligned(128))) StagedBlock {
     int R, C;                    //  0  1  region origin (global bins)
     int start, count;            //  2  3  its windows [start, start + count) in the sorted copy
-    int count0;                  //  4     the first count0 of them go to accumulator slot 0 (stable sort: a pair's first tile first)
+    int count0;                  //  4     (= bnd[0]) the first count0 of them go to accumulator slot 0
     int ereg;                    //  5     expected region of the block's windows (-1: none)
     int ch_end;                  //  6     end of the chromosome (global bin)
     int nblk;                    //  7     index lines per matrix row
@@ -50,7 +50,10 @@ struct __attribute__((aligned(128))) StagedBlock {
     unsigned rowbad[4];          // 16-19  masked-row bits of rows 0..63, 64..127
     int seg;                     // 20     segment = unit * 2 + flip (unit: tile pair or tile)
     int row_lo, row_hi;          // 21 22  region rows any window of the block touches: only these are staged
-    int pad[9];
+    int bnd[7];                  // 23-29  bnd[s] = end of the slot-s windows, s < 7 (slot 7 ends at count): inside a block the windows
+                                 //        are in slot order (stable sort of a tile-major stream; with > 2 slots the slot is the key's
+                                 //        lowest digit as well, so that the table kernel can find the boundaries)
+    int pad[2];
 };
 static_assert(sizeof(StagedBlock) == 128, "block table entry must be two 64-byte lines");
 
@@ -58,16 +61,19 @@ struct StagedArgs {
     const StagedBlock*    blocks;
     const unsigned short* win;        // windows in block order, each as its corner inside its region: dr | dc << 7 | slot << 14
     const int*            wg_first;   // [G + 1] first block of every workgroup's range
-    int                   U;          // pass units (tile pairs, or tiles when unpaired)
-    unsigned char*        rec_valid;  // [ACC * U * 2 * G] set when record ((slot * U + unit) * 2 + flip) * G + workgroup was written
-    int                   n0;         // paired tiles: waves [0, n0) pile up the windows of a pair's first tile (slot 0), the
-                                      // others those of its second — in proportion to the two tiles' window counts
+    int                   U;          // pass units: tiles (ACC = 1), tile pairs (2), or sets of 4 pairs (8) — see staged_tile
+    int                   PH;         // paired tiles: tile t < PH shares its pass with tile t + PH (its control); 0 when unpaired
+    unsigned char*        rec_valid;  // [T * 2 * G] set when record (tile * 2 + flip) * G + workgroup was written
+    const unsigned char*  teams;      // [U][16]: waves [teams[u][s], teams[u][s+1]) pile up the slot-s windows of unit u's blocks —
+                                      // teams sized by the host in proportion to the tiles' window counts (none for an empty tile)
     int                   debug;      // timing experiments only (results are wrong): 1 = skip the window loop, 2 = skip the staging
     long long*            timing;     // phase clocks per wave, [G][NW][8] (tools/k1_probe.py --phases), or nullptr
 };
 
 constexpr int kWinShift = 7;                          // bits of dr / dc in a window value
-constexpr int kWinSlotBit = 14;
+constexpr int kWinSlotBit = 14;                      // slot of a window of a tile PAIR (sets of pairs: lowest bits of the key)
+constexpr int kSetPairs = 4;                          // tile pairs piled up together in one pass of an ACC = 8 kernel
+constexpr int kSetSlotBits = 3;
 constexpr int kMaxSegCount = 1024;                    // (tile, flip) runs one block-ordered call may have (key kernel LDS table)
 constexpr int kBlockCost = 400;                       // staging one region, in windows' worth of time (workgroup ranges)
 constexpr int kMaxStagedTiles = 64;                   // partial records are (tile, flip, workgroup): keep the table small
@@ -81,6 +87,16 @@ __device__ __forceinline__ void lds_pin_u64(unsigned long long& v) { asm volatil
 template <int N>
 __device__ __forceinline__ void lds_wait_but(unsigned a0, unsigned a1) {
     asm volatile("s_waitcnt lgkmcnt(%2)" :: "v"(a0), "v"(a1), "n"(N) : "memory");
+}
+
+// accumulator slots of a pass unit -> tiles.  ACC = 1: the unit is the tile.  Paired (tile t with t + PH): ACC = 2 — unit u =
+// pair u, slot = which of the two; ACC = 8 — unit u = pairs [4u, 4u + 4), slots 0..3 their first tiles, 4..7 their second.
+template <int ACC>
+__host__ __device__ inline int staged_tile(int unit, int slot, int PH) {
+    if (ACC == 1) return unit;
+    constexpr int SP = ACC / 2;
+    const int g = unit * SP + slot % SP;
+    return g < PH ? (slot / SP) * PH + g : -1;
 }
 
 // geometry of an instantiation (host and device agree through these)
@@ -100,7 +116,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     static_assert(!(BAND && EXTRA), "pixel statistics need the presence bits of the index: sparse staging");
     static_assert(W >= 3 && W <= 31, "workgroup-staged kernel serves windows of 3..31 bins");
     static_assert(!(FACT && OOE), "factorised counting needs validity to factorise into row and column masks");
-    static_assert(ACC == 1 || ACC == 2, "one or two accumulator sets");
+    static_assert(ACC == 1 || ACC == 2 || ACC == 8, "accumulator slots of a pass: a tile, a tile pair, four pairs");
     static_assert(RSC == 64 || RSC == 128, "a lane per column of a 64-column half");
     static_assert(RSR % NW == 0 && RSR <= 128 && RSC <= 128, "rows are dealt out evenly to the waves; corners need 7 bits");
     constexpr int NCH = kWave / W;
@@ -146,9 +162,22 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     // windows — sized by the host to the tiles' shares of the call's windows.  (Two sets per wave, round 2's way, cost
     // 2 * CH more double registers: the difference between 16 and 8 waves per CU, and a wave may have at most 15 LDS
     // reads in flight — it takes 16 waves to keep the LDS busy.)
-    const int my_slot = (ACC == 2 && wave >= sa.n0) ? 1 : 0;
-    const int team_lo = ACC == 2 ? (my_slot ? sa.n0 : 0) : 0, team_n = ACC == 2 ? (my_slot ? NW - sa.n0 : sa.n0) : NW;
-    const float team_inv = 1.0f / (float)(team_n > 0 ? team_n : 1);
+    int my_slot = 0, team_lo = 0, team_n = NW;
+    float team_inv = 1.0f / (float)NW;
+    unsigned team_w[4] = {0u, 0u, 0u, 0u};               // the unit's team table, 16 bytes
+    auto team_at = [&](int s) __attribute__((always_inline)) -> int { return (int)((team_w[s >> 2] >> ((s & 3) * 8)) & 0xffu); };
+    auto set_team = [&](int unit) __attribute__((always_inline)) {
+        if constexpr (ACC > 1) {
+            const uint4 t = *reinterpret_cast<const uint4*>(sa.teams + 16 * (size_t)unit);
+            team_w[0] = __builtin_amdgcn_readfirstlane(t.x); team_w[1] = __builtin_amdgcn_readfirstlane(t.y);
+            team_w[2] = __builtin_amdgcn_readfirstlane(t.z); team_w[3] = __builtin_amdgcn_readfirstlane(t.w);
+            my_slot = 0;
+#pragma unroll
+            for (int s = 1; s < ACC; ++s) my_slot += wave >= team_at(s) ? 1 : 0;     // (teams are contiguous, empty ones have equal ends)
+            team_lo = team_at(my_slot); team_n = team_at(my_slot + 1) - team_lo;
+            team_inv = 1.0f / (float)(team_n > 0 ? team_n : 1);
+        }
+    };
     double   sum[CH];
     unsigned num[CH];
     // the SIMD favours its oldest wave; left alone the youngest of the four finishes its (equal) share of a block's windows
@@ -435,7 +464,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     // of a pair come first in a block (stable sort), so at most one wave sees both slots.  (Round 2 dealt windows out
     // round robin from batches every wave held; with one workgroup per CU the per-batch fetch then stalled the whole CU,
     // and the factorised-count bookkeeping of a batch fell on one wave.)
-    struct Cur { int R, C, start, count, count0; unsigned long long rowbad[2], colbad[2]; };
+    struct Cur { int R, C, start, first, n; unsigned long long rowbad[2], colbad[2]; };   // first, n: the windows of this wave's slot
     const unsigned lane_off8 = (unsigned)(uintptr_t)tile + 8u * (unsigned)(p * LS + k);   // LDS byte address of the lane's first cell
     const unsigned vb_base = (unsigned)(uintptr_t)vbits;
     // window `at + lane` of the block, for the lanes below `end`
@@ -566,9 +595,11 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     // this wave's slice [lo, hi) of the block's windows: an equal share of its team's windows (the whole block, or the
     // slot-0 / slot-1 part of it); wf = its first batch, one window per lane, each as its corner inside the region (the
     // value the block sort carried)
-    auto slice_of = [&](int count, int count0, int& lo, int& hi) __attribute__((always_inline)) {
-        const int first = ACC == 2 ? (my_slot ? count0 : 0) : 0;
-        const int n = ACC == 2 ? (my_slot ? count - count0 : count0) : count;
+    auto slot_range = [&](int ev, int& first, int& n) __attribute__((always_inline)) {
+        first = (ACC > 1 && my_slot > 0) ? fld(ev, 22 + my_slot) : 0;
+        n = ((ACC > 1 && my_slot < ACC - 1) ? fld(ev, 23 + my_slot) : fld(ev, 3)) - first;
+    };
+    auto slice_of = [&](int first, int n, int& lo, int& hi) __attribute__((always_inline)) {
         // M = ceil(n / team_n) without an integer division (a block holds fewer than 2^24 windows)
         int M = (int)((float)n * team_inv);
         M += (M * team_n < n) ? 1 : 0;
@@ -583,7 +614,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     // sixteen doing it back to back before the window loop, as in round 2, cost 28 % of the kernel: phase clocks.)
     auto windows = [&](const Cur& g, int wf, auto&& mid) __attribute__((always_inline)) {
         int lo, hi;
-        slice_of(g.count, g.count0, lo, hi);
+        slice_of(g.first, g.n, lo, hi);
         {   // the first batch (possibly empty), with the look-ahead work inside it: `mid` is spelled ONCE — two copies joined
             // by a branch would make hipcc shuttle the register arrays it fills through scratch
             const int drv = wf & ((1 << kWinShift) - 1), dcv = (wf >> kWinShift) & ((1 << kWinShift) - 1);
@@ -611,13 +642,14 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
         }
     };
     auto first_coords = [&](int ev, int& wf) __attribute__((always_inline)) {
-        int lo, hi;
-        slice_of(fld(ev, 3), fld(ev, 4), lo, hi);
+        int first, n, lo, hi;
+        slot_range(ev, first, n);
+        slice_of(first, n, lo, hi);
         wf = load_batch(fld(ev, 2), lo, hi);
     };
     auto cur_of = [&](int ev) __attribute__((always_inline)) -> Cur {
         Cur c;
-        c.R = fld(ev, 0); c.C = fld(ev, 1); c.start = fld(ev, 2); c.count = fld(ev, 3); c.count0 = fld(ev, 4);
+        c.R = fld(ev, 0); c.C = fld(ev, 1); c.start = fld(ev, 2); slot_range(ev, c.first, c.n);
         c.rowbad[0] = fld64(ev, 16); c.rowbad[1] = fld64(ev, 18);
         c.colbad[0] = ~fld64(ev, 12); c.colbad[1] = ~fld64(ev, 14);     // (also set past the chromosome's end: no eligible window reaches there)
         return c;
@@ -657,10 +689,12 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
         }
 #pragma unroll
         for (int s = 0; s < ACC; ++s) {
-            const size_t rec = ((size_t)(s * sa.U + unit) * 2 + (size_t)fl) * (size_t)G + (size_t)g_id;
+            const int tl = staged_tile<ACC>(unit, s, sa.PH);
+            const int lead = ACC > 1 ? team_at(s) : 0, w_hi = ACC > 1 ? team_at(s + 1) : NW;   // the team's first wave holds its merged tile
+            if (tl < 0 || lead >= w_hi) continue;                         // (uniform) no such tile / none of its windows in this call
+            const size_t rec = ((size_t)tl * 2 + (size_t)fl) * (size_t)G + (size_t)g_id;
             double*   of = a.part_f64 + rec * L;
             unsigned* on = a.part_num + rec * W2;
-            const int lead = ACC == 2 ? (s ? sa.n0 : 0) : 0;              // the team's first wave holds its merged tile
             if (wave == lead) {
 #pragma unroll
                 for (int i = 0; i < CH; ++i)
@@ -678,10 +712,9 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
                     on[map_cell(pp, qq, W, false, fl)] = tot[2 * W] - tot[pp] - tot[W + qq] + rc_lds[s][t];
                 }
             }
-            const int w_lo = ACC == 2 ? (s ? sa.n0 : 0) : 0, w_hi = ACC == 2 ? (s ? NW : sa.n0) : NW;
             for (int t = tid; t < 2 * W; t += NTHR) {
                 double acc = 0.0;
-                if (m_cov) for (int w = w_lo; w < w_hi; ++w) acc += cov_lds[w][t];
+                if (m_cov) for (int w = lead; w < w_hi; ++w) acc += cov_lds[w][t];
                 of[W2 + t] = acc;
             }
             if (tid == 0) sa.rec_valid[rec] = 1;
@@ -699,6 +732,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
         int w0f, w1f = 0;
         {   // prologue: stage block bb without overlap
             band_issue(ev0, v, wc, wrv);
+            set_team(fld(ev0, 20) >> 1);
             first_coords(ev0, w0f);
             if (bb + 1 < be) ev1 = entry_load(bb + 1);
             const ExpSel es0 = exp_of(ev0);
@@ -723,8 +757,11 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
             const int seg0 = fld(ev0, 20);
             if (!has1) { flush(seg0); break; }
             const ExpSel es1 = exp_of(ev1);
-            if (fld(ev1, 20) != seg0) flush(seg0);       // (uniform) the next block belongs to another segment
-            else __syncthreads();                        // every wave is done reading region b
+            const int seg1 = fld(ev1, 20);
+            if (seg1 != seg0) {                          // (uniform) the next block belongs to another segment
+                flush(seg0);
+                if (ACC > 1 && (seg1 >> 1) != (seg0 >> 1)) { set_team(seg1 >> 1); first_coords(ev1, w1f); }   // other unit: other teams
+            } else __syncthreads();                      // every wave is done reading region b
             const long long t3 = tick();
             if (!(sa.debug & 2)) { if (nf) band_store(std::true_type{}, ev1, v, wc, wrv, es1); else band_store(std::false_type{}, ev1, v, wc, wrv, es1); }
             const long long t4 = tick();
@@ -750,6 +787,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
         {   // prologue: stage block bb without overlap, start the lookups of bb+1
             Raw x0;
             load_raw(ev0, x0);
+            set_team(fld(ev0, 20) >> 1);
             first_coords(ev0, w0f);
             if (bb + 1 < be) { ev1 = entry_load(bb + 1); load_raw(ev1, x1); }
             if (bb + 2 < be) evn = entry_load(bb + 2);
@@ -778,8 +816,11 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
             const int seg0 = fld(ev0, 20);
             if (!has1) { flush(seg0); break; }
             const ExpSel es1 = exp_of(ev1);
-            if (fld(ev1, 20) != seg0) flush(seg0);       // (uniform) the next block belongs to another segment
-            else __syncthreads();                        // every wave is done reading region b
+            const int seg1 = fld(ev1, 20);
+            if (seg1 != seg0) {                          // (uniform) the next block belongs to another segment
+                flush(seg0);
+                if (ACC > 1 && (seg1 >> 1) != (seg0 >> 1)) { set_team(seg1 >> 1); first_coords(ev1, w1f); }   // other unit: other teams
+            } else __syncthreads();                      // every wave is done reading region b
             const long long t3 = tick();
             if (!(sa.debug & 2)) { if (nf) store_region(std::true_type{}, ev1, rw1, v, wc, es1); else store_region(std::false_type{}, ev1, rw1, v, wc, es1); }
             const long long t4 = tick();
@@ -803,12 +844,13 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
 
 // ---- block-order prepass of K1q ------------------------------------------------------------------------------------
 // key of a snippet: (segment, expected region, block row, block col).  Segment = the (tile pair | tile, flip) run the
-// snippet is piled up with; `pair_half` = T/2 when tile t shares its pass with tile t + T/2 (then slot = t / (T/2) goes
-// into bit kWinSlotBit of the value), 0 when every tile has its own pass.  Also checks that the window is one the
+// snippet is piled up with; `pair_half` = T/2 when tile t shares its pass with tile t + T/2, 0 when every tile has its own
+// pass.  Pairs go through the kernel one by one (`set_pairs` = 1: slot = t / (T/2) in bit kWinSlotBit of the value) or in
+// sets of kSetPairs (the slot, 0..7, is then the key's lowest digit: see staged_tile).  Also checks that the window is one the
 // rank-bitmap index covers (cis, inside one chromosome), counts the others, and counts the windows a diagonal mask reaches.
 template <typename KeyT, int SIDE_R, int SIDE_C /* block sides when known at compile time (division by a constant), else 0 */>
 __global__ __launch_bounds__(256) void staged_key_kernel(const int* __restrict__ r0, const int* __restrict__ c0, long long n,
-                                                         const long long* __restrict__ seg_end, int nseg2t, int pair_half,
+                                                         const long long* __restrict__ seg_end, int nseg2t, int pair_half, int set_pairs,
                                                          const IdxChrom* __restrict__ chroms, int n_chrom,
                                                          const unsigned short* __restrict__ bin_chrom, long long nbins,
                                                          const int* __restrict__ brow_base /* [n_chrom] block rows before the chromosome */,
@@ -836,7 +878,12 @@ __global__ __launch_bounds__(256) void staged_key_kernel(const int* __restrict__
         while (lo < hi) { const int m = (lo + hi) >> 1; if (s_seg[m] <= i) lo = m + 1; else hi = m; }
         const int t = lo >> 1, f = lo & 1;                   // tile, flip state of the snippet
         unsigned seg = (unsigned)lo, slot = 0u;
-        if (pair_half > 0) { slot = (unsigned)(t / pair_half); seg = (unsigned)((t % pair_half) * 2 + f); }
+        unsigned kslot = 0u, kbits = 0u;                     // slot digit of the key (sets of pairs)
+        if (pair_half > 0) {
+            const int kind = t / pair_half, g = t - kind * pair_half;
+            if (set_pairs > 1) { kslot = (unsigned)(kind * set_pairs + g % set_pairs); kbits = kSetSlotBits; seg = (unsigned)((g / set_pairs) * 2 + f); }
+            else { slot = (unsigned)kind; seg = (unsigned)(g * 2 + f); }
+        }
         bool ok = r >= 0 && c >= 0 && (long long)r < nbins;
         unsigned long long br = 0, bc = 0, er = 0;
         unsigned inside = 0u;                                // the window's corner inside its block: all the staged kernel needs
@@ -864,7 +911,7 @@ __global__ __launch_bounds__(256) void staged_key_kernel(const int* __restrict__
             if (far != 0ull && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)far) - 1)) atomicAdd(&counters[2], (unsigned)__popcll(far));
         }
         if (!live) continue;
-        keys[i] = (KeyT)(((unsigned long long)(seg >> seg_shift) << sh_seg) | (er << sh_er) | (br << sh_br) | bc);
+        keys[i] = (KeyT)(((((unsigned long long)(seg >> seg_shift) << sh_seg) | (er << sh_er) | (br << sh_br) | bc) << kbits) | kslot);
         // the value that rides the sort is the window itself as the staged kernel wants it (the sort is stable, so windows
         // of a block keep the caller's order): no index to gather through afterwards
         vals[i] = (unsigned short)(inside | (slot << kWinSlotBit));
@@ -874,7 +921,7 @@ __global__ __launch_bounds__(256) void staged_key_kernel(const int* __restrict__
 
 // hand the key kernel's verdict to the host without stalling the stream: one thread copies the two counters into mapped
 // page-locked host memory; the host waits on an event recorded right behind this kernel while the sort is already running
-__global__ void staged_publish_kernel(const unsigned* __restrict__ counters, int n, volatile unsigned* host_flags, unsigned ticket) {
+PUP_KERNEL void staged_publish_kernel(const unsigned* __restrict__ counters, int n, volatile unsigned* host_flags, unsigned ticket) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         for (int i = 0; i < n; ++i) host_flags[i] = counters[i];
         __threadfence_system();
@@ -887,7 +934,7 @@ __global__ void staged_publish_kernel(const unsigned* __restrict__ counters, int
 // block_starts_kernel turns the counts into the ordered list
 constexpr int kSpan = 4096;
 template <typename KeyT>
-__global__ __launch_bounds__(256) void count_heads_kernel(const KeyT* __restrict__ sorted_keys, long long n,
+__global__ __launch_bounds__(256) void count_heads_kernel(const KeyT* __restrict__ sorted_keys, long long n, int slot_bits,
                                                           unsigned* __restrict__ span_heads) {
     __shared__ unsigned red[4];
     const long long i0 = (long long)blockIdx.x * kSpan;                 // one workgroup per span
@@ -895,7 +942,7 @@ __global__ __launch_bounds__(256) void count_heads_kernel(const KeyT* __restrict
 #pragma unroll 4
     for (int t = threadIdx.x; t < kSpan; t += 256) {
         const long long i = i0 + t;
-        if (i < n && (i == 0 || sorted_keys[i] != sorted_keys[i - 1])) ++cnt;
+        if (i < n && (i == 0 || (sorted_keys[i] >> slot_bits) != (sorted_keys[i - 1] >> slot_bits))) ++cnt;
     }
     for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
@@ -907,7 +954,7 @@ __global__ __launch_bounds__(256) void count_heads_kernel(const KeyT* __restrict
 // heads in the spans before it (a few thousand counters: summed by the workgroup itself, no separate scan pass).  The
 // last workgroup also publishes the total (n_runs).
 template <typename KeyT>
-__global__ __launch_bounds__(256) void block_starts_kernel(const KeyT* __restrict__ sorted_keys, long long n,
+__global__ __launch_bounds__(256) void block_starts_kernel(const KeyT* __restrict__ sorted_keys, long long n, int slot_bits,
                                                            const unsigned* __restrict__ span_heads,
                                                            unsigned* __restrict__ starts, unsigned* __restrict__ n_runs) {
     __shared__ unsigned red[4];
@@ -924,7 +971,7 @@ __global__ __launch_bounds__(256) void block_starts_kernel(const KeyT* __restric
     const long long i0 = (long long)blockIdx.x * kSpan;
     for (int t = 0; t < kSpan; t += 256) {
         const long long i = i0 + t + threadIdx.x;
-        const bool head = i < n && (i == 0 || sorted_keys[i] != sorted_keys[i - 1]);
+        const bool head = i < n && (i == 0 || (sorted_keys[i] >> slot_bits) != (sorted_keys[i - 1] >> slot_bits));
         const unsigned long long m = __ballot(head);
         __syncthreads();                                   // wave_cnt of the previous round has been read
         if (lane == 0) wave_cnt[wave] = (unsigned)__popcll(m);
@@ -945,7 +992,7 @@ __global__ __launch_bounds__(256) void staged_table_kernel(const unsigned* __res
                                                            long long n, const KeyT* __restrict__ sorted_keys,
                                                            const unsigned short* __restrict__ win, const int* __restrict__ brow_base,
                                                            const IdxChrom* __restrict__ chroms, int n_chrom, int W, int RSR, int RSC,
-                                                           int sh_br, int sh_er, int sh_seg, int seg_shift, int n_eregs,
+                                                           int sh_br, int sh_er, int sh_seg, int seg_shift, int slot_bits, int n_eregs,
                                                            const unsigned long long* __restrict__ badbits,
                                                            StagedBlock* __restrict__ blocks, int* __restrict__ wg_first, int G) {
     const long long nr = (long long)n_runs[0];
@@ -953,7 +1000,7 @@ __global__ __launch_bounds__(256) void staged_table_kernel(const unsigned* __res
     for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < nr; b += (long long)gridDim.x * blockDim.x) {
         const unsigned s = starts[b];
         const long long e = (b + 1 < nr) ? (long long)starts[b + 1] : n;
-        const unsigned long long key = (unsigned long long)sorted_keys[s];
+        const unsigned long long key = (unsigned long long)sorted_keys[s] >> slot_bits;
         StagedBlock be;
         const int br = (int)((key >> sh_br) & ((1ull << (sh_er - sh_br)) - 1ull));
         const int bc = (int)(key & ((1ull << sh_br) - 1ull));
@@ -964,10 +1011,21 @@ __global__ __launch_bounds__(256) void staged_table_kernel(const unsigned* __res
         be.R = cs + (br - brow_base[lo]) * BR;
         be.C = cs + bc * BC;
         be.start = (int)s; be.count = (int)(e - (long long)s);
-        {   // slot-0 windows come first inside a block (stable sort): find the first window with the slot bit set
-            long long l2 = (long long)s, h2 = e;
-            while (l2 < h2) { const long long m = (l2 + h2) >> 1; if (((win[m] >> kWinSlotBit) & 1u) == 0u) l2 = m + 1; else h2 = m; }
-            be.count0 = (int)(l2 - (long long)s);
+        {   // the windows of a block are in slot order (see StagedBlock::bnd): end of slot q = first window of a higher slot
+            const unsigned smask = (1u << slot_bits) - 1u;
+            auto slot_of = [&](long long m) -> unsigned {
+                return slot_bits ? (unsigned)sorted_keys[m] & smask : ((unsigned)win[m] >> kWinSlotBit) & 1u;
+            };
+            long long from = (long long)s;
+            for (int q = 0; q < 7; ++q) {
+                long long l2 = from, h2 = e;
+                if (q < (slot_bits ? (1 << slot_bits) - 1 : 1))
+                    while (l2 < h2) { const long long m = (l2 + h2) >> 1; if (slot_of(m) <= (unsigned)q) l2 = m + 1; else h2 = m; }
+                else l2 = e;
+                be.bnd[q] = (int)(l2 - (long long)s);
+                from = l2;
+            }
+            be.count0 = be.bnd[0];
         }
         be.ereg = -1;
         if (n_eregs > 0) {
@@ -1011,7 +1069,7 @@ __global__ __launch_bounds__(256) void staged_table_kernel(const unsigned* __res
             }
             be.row_lo = mn; be.row_hi = mx + W < RSR ? mx + W : RSR;
         }
-        for (int q = 0; q < 9; ++q) be.pad[q] = 0;
+        be.pad[0] = 0; be.pad[1] = 0;
         blocks[b] = be;
         // ranges of the persistent workgroups: equal shares of the call's COST, a block costing its windows plus kBlockCost
         // window-equivalents for its staging (a range of many sparse blocks would otherwise take far longer than one of a
@@ -1029,7 +1087,7 @@ __global__ __launch_bounds__(256) void staged_table_kernel(const unsigned* __res
 // fixed-order reduction of the staged kernel's partial records into the running accumulators: tile t owns the records
 // [t * 2G, (t + 1) * 2G) (flip 0 of every workgroup, then flip 1); records nobody wrote are skipped through their flag.
 // Same shape as reduce_partials_kernel: 64 record elements x kRedParts interleaved partial sums in fixed order.
-__global__ __launch_bounds__(64 * kRedParts) void reduce_staged_kernel(
+PUP_KERNEL __launch_bounds__(64 * kRedParts) void reduce_staged_kernel(
         const double* __restrict__ in_f64, const unsigned* __restrict__ in_num, const unsigned char* __restrict__ valid,
         int per_tile, int Lf, int Li, double* out_f64, long long* out_num) {
     __shared__ double    sf[kRedParts][64];

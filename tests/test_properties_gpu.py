@@ -202,6 +202,65 @@ def test_block_staged_kernel_equals_plain_kernel_for_every_width(hip_lib, pad):
     eng.close()
 
 
+@pytest.mark.parametrize("pad,T", [(10, 10), (10, 42), (3, 4), (7, 16), (10, 8)])
+def test_staged_kernel_sets_of_tile_pairs(hip_lib, pad, T):
+    """Grouped pile-ups (T/2 groups, each a ROI tile t and its control tile t + T/2): four pairs share a pass of the staged
+    kernel — one staging of a region serves eight tiles, each piled up by its own team of waves (key digit = slot, team
+    table per unit, partial last set, empty tiles, tiles of very different sizes, flips) — against the plain register-tile
+    kernel and against the same call with the pairs piled up one by one (tuning bit 28); windows far from the diagonal
+    (factorised counts, 16 waves) and near it (per-cell validity, 8 waves); repeated: bit-identical."""
+    import synth
+    from coolpuppy_amd.engine import PileupEngine
+    clr = synth.make_cooler({"chrA": 30_000_000, "chrB": 9_000_000}, lam=50, seed=33)
+    W = 2 * pad + 1
+    H = T // 2
+    rng = np.random.default_rng(900 + pad + T)
+    n = 40_000
+    w = clr.bins()["weight"][:].values
+    eng = PileupEngine(0)
+    eng.load_pixels(*clr.pixel_table())
+    eng.build_index(clr.chrom_offset)
+    eng.load_bins(w, None)
+    for label, near in (("far", False), ("near", True)):
+        r0l, c0l = [], []
+        for ch in clr.chromnames:
+            lo, hi = clr.extent(ch)
+            m = n // 2
+            r = rng.integers(lo, hi - W + 1, m)
+            c = np.clip(r + (rng.integers(-4, 300, m) if near else rng.integers(W + 2, 300, m)), lo, hi - W)
+            r0l.append(r); c0l.append(c)
+        r0 = np.concatenate(r0l).astype(np.int32); c0 = np.concatenate(c0l).astype(np.int32)
+        if not near:
+            keep = c0 - r0 >= W + 2                              # (the clip at the chromosome end may have pulled some in)
+            r0, c0 = r0[keep], c0[keep]
+        # group g: ROI tile g (few windows), control tile H + g (ten times as many); group sizes differ, one group is empty
+        share = rng.random(H) ** 2
+        if H >= 3:
+            share[1] = 0.0
+        grp = rng.choice(H, size=len(r0), p=share / share.sum())
+        tile = np.where(rng.random(len(r0)) < 1 / 11, grp, H + grp).astype(np.int32)
+        flip = rng.random(len(r0)) < 0.25
+        o = np.argsort(tile.astype(np.int64) * 2 + flip, kind="stable")
+        r0, c0, tile, flip = r0[o], c0[o], tile[o], flip[o]
+        tile_ptr = np.concatenate([[0], np.cumsum(np.bincount(tile, minlength=T))]).astype(np.int64)
+        flip_from = tile_ptr[1:] - np.bincount(tile[flip], minlength=T)
+        res = {}
+        for name, variant in (("plain", 16), ("sets", 8), ("pairs", 8 | (1 << 28)), ("sets again", 8), ("sets sparse", 8 | (1 << 27))):
+            eng.set_tuning(0, variant)
+            eng.reset(T, pad)
+            eng.accumulate(r0, c0, tile_ptr, flip_from=flip_from, ignore_diags=2)
+            res[name] = (eng.fetch(), eng.stats()["staged_regions"])
+        assert res["plain"][1] == 0
+        assert 0 < res["sets"][1] < res["pairs"][1] or H < 2, (res["sets"][1], res["pairs"][1])
+        for name in ("sets", "pairs", "sets sparse"):
+            for k in ("n", "num"):
+                np.testing.assert_array_equal(res[name][0][k], res["plain"][0][k], err_msg=f"{label} {name} {k}")
+            np.testing.assert_allclose(res[name][0]["sum"], res["plain"][0]["sum"], rtol=1e-11, atol=0, equal_nan=True,
+                                       err_msg=f"{label} {name}")
+        np.testing.assert_array_equal(res["sets again"][0]["sum"], res["sets"][0]["sum"])
+    eng.close()
+
+
 @pytest.mark.parametrize("pad", [2, 10, 15])
 def test_staged_kernel_many_workgroups(hip_lib, pad):
     """The workgroup-staged kernel with several workgroups sharing every CU (one block per workgroup, ~1500 of them):
