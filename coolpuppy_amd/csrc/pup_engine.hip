@@ -445,7 +445,9 @@ int pup_build_index(pup_ctx* c, const int64_t* chrom_offset, int32_t n_chroms, i
     c->band_w = 0;
     {
         const long long BWd = 1024;
-        const long long cells = c->nbins * BWd + BWd;
+        // pads: kBandFront cells before row 0 and 129 rows of zeros behind the last one — the staged kernel's factorised
+        // variant reads whole region rows without masking (cells left of the diagonal, rows past the table)
+        const long long cells = pup::kBandFront + (c->nbins + 129) * BWd;
         size_t fb = 0, tb = 0;
         const bool fits = cells < (1LL << 30) && hipMemGetInfo(&fb, &tb) == hipSuccess &&
                           (size_t)cells * 4 <= fb / 4 + c->band.cap * sizeof(int);
@@ -453,7 +455,7 @@ int pup_build_index(pup_ctx* c, const int64_t* chrom_offset, int32_t n_chroms, i
             HIPCHK(c, c->band.reserve((size_t)cells));
             HIPCHK(c, hipMemsetAsync(c->band.p, 0, (size_t)cells * sizeof(int), c->stream));
             const unsigned gb2 = (unsigned)std::min<long long>((c->nbins + 3) / 4, 1 << 20);
-            hipLaunchKernelGGL(pup::band_fill_kernel, dim3(gb2), dim3(256), 0, c->stream, c->indptr.p, c->px.p, c->band.p, (int)BWd, c->nbins);
+            hipLaunchKernelGGL(pup::band_fill_kernel, dim3(gb2), dim3(256), 0, c->stream, c->indptr.p, c->px.p, c->band.p + pup::kBandFront, (int)BWd, c->nbins);
             c->band_w = (int)BWd;
         }
     }
@@ -693,7 +695,7 @@ static void fill_k1_args(pup_ctx* c, pup::K1Args& a, int32_t ignore_diags, uint3
     a.part_f64 = c->part_f64.p; a.part_num = c->part_num.p;
     a.counters = c->count_pixels ? c->counters.p : nullptr; a.err = c->d_err.p;
     a.nf_pixels = c->nf_count > 0 ? 1 : 0; a.nnz = c->nnz;
-    a.band = c->band_w > 0 ? c->band.p : nullptr; a.band_w = c->band_w; a.band_zero = (unsigned)(c->nbins * (long long)c->band_w);
+    a.band = c->band_w > 0 ? c->band.p + pup::kBandFront : nullptr; a.band_w = c->band_w; a.band_zero = (unsigned)(c->nbins * (long long)c->band_w);
     a.W = c->W; a.ignore_diags = ignore_diags; a.mode = mode;
 }
 

@@ -74,6 +74,7 @@ constexpr int kWinShift = 7;                          // bits of dr / dc in a wi
 constexpr int kWinSlotBit = 14;                      // slot of a window of a tile PAIR (sets of pairs: lowest bits of the key)
 constexpr int kSetPairs = 4;                          // tile pairs piled up together in one pass of an ACC = 8 kernel
 constexpr int kSetSlotBits = 3;
+constexpr int kBandFront = 256;                       // cells in front of the band table's row 0 (see band_issue)
 constexpr int kMaxSegCount = 1024;                    // (tile, flip) runs one block-ordered call may have (key kernel LDS table)
 constexpr int kBlockCost = 400;                       // staging one region, in windows' worth of time (workgroup ranges)
 constexpr int kMaxStagedTiles = 64;                   // partial records are (tile, flip, workgroup): keep the table small
@@ -311,9 +312,16 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             const long long col = (long long)C + 64 * h + lane;
-            const double w = wsrc[col < a.nbins ? col : a.nbins - 1];                 // (columns past the table are in no window)
-            wc[h] = a.weight ? ((nf || w == w) ? w : 0.0) : 1.0;
+            wc[h] = wsrc[col < a.nbins ? col : a.nbins - 1];                          // (columns past the table are in no window)
         }
+        // NOTHING here may look at a loaded value: the memory counter is in-order, so one compare of a weight would park the
+        // wave — in the middle of its windows — until every count load above has come back from HBM (round 3: a third of the
+        // kernel).  NaN weights are turned into 0 at store time (weight_of)
+    };
+    // a loaded weight as the factor it stands for: 1.0 when raw, 0 for a masked bin (NaN) unless the table holds infinite
+    // weights, whose NaN products are sorted out value by value
+    auto weight_of = [&](double w) __attribute__((always_inline)) -> double {
+        return a.weight ? ((nf || w == w) ? w : 0.0) : 1.0;
     };
     auto exp_of = [&](int ev) -> ExpSel {
         ExpSel es; es.base = a.expv; es.len = 0; es.scalar = qnan; es.is_scalar = true;
@@ -332,6 +340,9 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     auto store_region = [&](auto nf_tag, int ev, Row& r, const int (&v)[NRH], const double (&wc)[NH], const ExpSel& es) __attribute__((always_inline)) {
         constexpr bool NFP = decltype(nf_tag)::value;    // the table holds infinite weights: NaN products are stored as 0
         const int R = fld(ev, 0), C = fld(ev, 1), row_lo = fld(ev, 21), row_hi = fld(ev, 22);
+        double wcs[NH];
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) wcs[hh] = weight_of(wc[hh]);
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
             const int rr = wave * RPW + i;
@@ -340,7 +351,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
 #pragma unroll
             for (int hh = 0; hh < NH; ++hh) {
                 // balanced value (raw: both weights are 1.0; lanes with nothing to keep loaded a zero count)
-                double val = (double)v[i * NH + hh] * wr * wc[hh];
+                double val = (double)v[i * NH + hh] * wr * wcs[hh];
                 if (NFP) val = (val == val) ? val : 0.0;
                 if (OOE) {
                     const int row = R + rr;
@@ -378,6 +389,32 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
         const int R = fld(ev, 0), C = fld(ev, 1), ch_end = fld(ev, 6), row_lo = fld(ev, 21), row_hi = fld(ev, 22);
         const unsigned zero_at = (unsigned)a.band_zero;  // index of BAND zeros behind the last row
         const char* bbase = reinterpret_cast<const char*>(a.band);
+        if constexpr (FACT) {
+            // Factorised counts = every window of the call is clear of the diagonal mask, so NO cell a window reads lies left
+            // of the first kept diagonal (a window at (r, c) has c - r >= igd + W - 1), and the engine only stages from the band
+            // when no window leaves it: the cells that would need masking are never read.  (Masked bins multiply to zero
+            // through their weight.)  A region row is then a plain run of the band: scalar row base + 4 * lane, no vector
+            // arithmetic, no predicate — two scalar adds per load.  Cells outside the band's row (left of the diagonal, past its
+            // width) read neighbouring rows or the pads around the table (pup_build_index): finite garbage nobody looks at.
+            // (32-bit byte offsets from the table's base: the engine builds no band of 2^30 cells or more)
+            const unsigned lane4 = 4u * (unsigned)lane;
+            const int row0 = R + wave * RPW;
+            const unsigned step = 4u * ((unsigned)a.band_w - 1u);                      // (row + 1, C) - (row, C) in bytes
+            // offsets count from the front pad (a region near the diagonal starts up to ~212 cells left of its first row's band)
+            const char* b0 = bbase - 4 * kBandFront;
+            const unsigned base0 = 4u * (unsigned)((long long)kBandFront + (long long)row0 * a.band_w + (long long)(C - row0));
+            const unsigned zero4 = 4u * (zero_at + (unsigned)kBandFront);
+            const int hi2 = (ch_end - R) < row_hi ? (ch_end - R) : row_hi;             // live rows of the region: [row_lo, hi2)
+            const unsigned i_lo = (unsigned)(row_lo - wave * RPW), n_live = (unsigned)(hi2 > row_lo ? hi2 - row_lo : 0);
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) {
+                const bool live = (unsigned)i - i_lo < n_live;                          // (uniform) else: zeros, all rows the same lines
+                const unsigned off = (live ? base0 + (unsigned)i * step : zero4) + lane4;
+#pragma unroll
+                for (int h = 0; h < NH; ++h)
+                    v[i * NH + h] = *reinterpret_cast<const int*>(b0 + (size_t)off + 256 * h);
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
             const int rr = wave * RPW + i;
@@ -403,18 +440,20 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             const long long col = (long long)C + 64 * h + lane;
-            const double w = wsrc[col < a.nbins ? col : a.nbins - 1];
-            wc[h] = a.weight ? ((nf || w == w) ? w : 0.0) : 1.0;
+            wc[h] = wsrc[col < a.nbins ? col : a.nbins - 1];      // raw: see issue_values — no loaded value is looked at before the store
         }
         {   // row weights: lane i < RPW holds its row's, broadcast at store time
             const long long row = (long long)R + my_rr;
-            const double w = wsrc[row < a.nbins ? row : a.nbins - 1];
-            wrv = a.weight ? ((nf || w == w) ? w : 0.0) : 1.0;
+            wrv = wsrc[row < a.nbins ? row : a.nbins - 1];
         }
     };
     auto band_store = [&](auto nf_tag, int ev, const int (&v)[NRH], const double (&wc)[NH], double wrv, const ExpSel& es) __attribute__((always_inline)) {
         constexpr bool NFP = decltype(nf_tag)::value;
         const int R = fld(ev, 0), C = fld(ev, 1), ch_end = fld(ev, 6), row_lo = fld(ev, 21), row_hi = fld(ev, 22);
+        double wcs[NH];
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) wcs[hh] = weight_of(wc[hh]);
+        const double wrs = weight_of(wrv);
         unsigned long long okn[NH];                      // lane i < RPW: validity bits of its row (non-FACT)
         if constexpr (!FACT) {
             const int row = R + my_rr;
@@ -427,10 +466,10 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
         for (int i = 0; i < RPW; ++i) {
             const int rr = wave * RPW + i;
             if (rr < row_lo || rr >= row_hi) continue;   // (uniform) no window of the block reads this row
-            const double wr = __longlong_as_double((long long)bcast64((unsigned long long)__double_as_longlong(wrv), i));
+            const double wr = __longlong_as_double((long long)bcast64((unsigned long long)__double_as_longlong(wrs), i));
 #pragma unroll
             for (int hh = 0; hh < NH; ++hh) {
-                double val = (double)v[i * NH + hh] * wr * wc[hh];
+                double val = (double)v[i * NH + hh] * wr * wcs[hh];
                 if (NFP) val = (val == val) ? val : 0.0;
                 if (OOE) {
                     const int row = R + rr;
@@ -740,15 +779,17 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
             if (nf) band_store(std::true_type{}, ev0, v, wc, wrv, es0); else band_store(std::false_type{}, ev0, v, wc, wrv, es0);
             __syncthreads();
         }
-        long long tk[6] = {0, 0, 0, 0, 0, 0};
+        long long tk[6] = {0, 0, 0, 0, 0, 0}, tmid = 0;
         const bool timed = sa.timing != nullptr;
         auto tick = [&]() __attribute__((always_inline)) -> long long { return timed ? (long long)__builtin_readcyclecounter() : 0; };
         for (int b = bb; b < be; ++b) {
             const bool has1 = b + 1 < be, has2 = b + 2 < be;
             const long long t0 = tick();
             auto lookahead = [&]() __attribute__((always_inline)) {
+                const long long m0 = tick();
                 if (has1) { if (!(sa.debug & 2)) band_issue(ev1, v, wc, wrv); first_coords(ev1, w1f); }
                 if (has2) evn = entry_load(b + 2);
+                tmid += tick() - m0;
             };
             const Cur c0 = cur_of(ev0);
             const long long t1 = tick();
@@ -773,7 +814,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
         if (timed && lane == 0) {
             long long* o = sa.timing + ((size_t)g_id * NW + wave) * 8;
             for (int i = 0; i < 6; ++i) o[i] = tk[i];
-            o[6] = be - bb; o[7] = 0;
+            o[6] = be - bb; o[7] = tmid;
         }
     } else
     // ---- the block loop: region b is piled up while b+1's values, b+2's index lines and b+3's table entry are on their way
@@ -799,15 +840,17 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
             __syncthreads();
         }
         // (diagnostics: per-wave clocks of the phases of the loop below, only when sa.timing is set)
-        long long tk[6] = {0, 0, 0, 0, 0, 0};
+        long long tk[6] = {0, 0, 0, 0, 0, 0}, tmid = 0;
         const bool timed = sa.timing != nullptr;
         auto tick = [&]() __attribute__((always_inline)) -> long long { return timed ? (long long)__builtin_readcyclecounter() : 0; };
         for (int b = bb; b < be; ++b) {
             const bool has1 = b + 1 < be, has2 = b + 2 < be;
             const long long t0 = tick();
             auto lookahead = [&]() __attribute__((always_inline)) {
+                const long long m0 = tick();
                 if (has1) { rw1 = finish_rows(ev1, x1); if (!(sa.debug & 2)) issue_values(ev1, rw1, v, wc); first_coords(ev1, w1f); }
                 if (has2) { ev2 = evn; load_raw(ev2, x2); if (b + 3 < be) evn = entry_load(b + 3); }
+                tmid += tick() - m0;
             };
             const Cur c0 = cur_of(ev0);
             const long long t1 = tick();
@@ -833,7 +876,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
         if (timed && lane == 0) {
             long long* o = sa.timing + ((size_t)g_id * NW + wave) * 8;
             for (int i = 0; i < 6; ++i) o[i] = tk[i];
-            o[6] = be - bb; o[7] = 0;
+            o[6] = be - bb; o[7] = tmid;
         }
     }
     if (stats) {

@@ -96,6 +96,8 @@ def main():
                                   "waves": int(k), "workgroups": int(live.sum()),
                                   "wave_total_min_mean_max": [round(float(x)) for x in (per_wave.sum(axis=2).min(), per_wave.sum(axis=2).mean(), per_wave.sum(axis=2).max())],
                                   "wg_total_min_mean_max": [round(float(x)) for x in (per_wave.sum(axis=2).max(axis=1).min(), per_wave.sum(axis=2).max(axis=1).mean(), per_wave.sum(axis=2).max(axis=1).max())],
+                                  "lookahead_inside_windows_mean": round(float(tm[live][:, :k, 7].mean())),
+                                  "lookahead_by_wave_mean": [round(float(x)) for x in tm[live][:, :k, 7].mean(axis=0)],
                                   "windows_by_wave_mean": [round(float(x)) for x in per_wave[:, :, 1].mean(axis=0)],
                                   "blocks_per_wg_min_mean_max": [int(tm[live][:, 0, 6].min()), float(tm[live][:, 0, 6].mean()), int(tm[live][:, 0, 6].max())]}), flush=True)
         best = min(rows, key=lambda x: x["wall_ms"])
