@@ -88,6 +88,8 @@ _SIGNATURES = {
     "pup_host_windows": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
                                      C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                      C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    "pup_host_mt_randint": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                      C.c_void_p, C.c_int32]),
     "pup_host_group_tiles": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
 }

@@ -30,6 +30,14 @@ def hipcc_path():
     raise RuntimeError("hipcc not found (looked on PATH and in /opt/rocm/bin)")
 
 
+def _rocm_include():
+    root = os.path.dirname(os.path.dirname(os.path.realpath(hipcc_path())))
+    for cand in (os.path.join(root, "include"), "/opt/rocm/include"):
+        if os.path.exists(os.path.join(cand, "hip", "hip_runtime.h")):
+            return cand
+    return "/opt/rocm/include"
+
+
 def is_stale():
     if not os.path.exists(OUT):
         return True
@@ -40,7 +48,7 @@ def is_stale():
 def _units():
     """(object file, compile arguments after the flags, sources it depends on)"""
     units = [(os.path.join(_OBJ, "pup_engine.o"), [SRC], [SRC, HEADER] + _KERNEL_HEADERS),
-             (os.path.join(_OBJ, "pup_host.o"), ["-x", "hip", SRC_HOST], [SRC_HOST, HEADER])]
+             (os.path.join(_OBJ, "pup_host.o"), ["-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I" + _rocm_include(), SRC_HOST], [SRC_HOST, HEADER])]        # host only: plain C++ with the HIP runtime API
     for k in range(N_STAGED_PARTS):
         units.append((os.path.join(_OBJ, f"pup_staged_tu{k}.o"), [f"-DPUP_TU_PART={k}", SRC_TU], [SRC_TU, HEADER] + _KERNEL_HEADERS))
     return units

@@ -146,11 +146,43 @@ def flip_snip_func(snip, groupby, ignore_group_order, extra_func=None):
     return snip
 
 
-def _draw_signs(m):
+def _draw_signs(m, dtype=np.int64):
     """np.random.choice([-1, 1], m) — the reference's call (coolpup.py:421) — without its list conversion and fancy
     index: the legacy generator implements a uniform choice as randint(0, len(a), m) followed by a[idx], so this draws the
     same numbers and leaves the generator in the same state (tests/test_host_misc.py pins that for the installed numpy)."""
-    return 2 * np.random.randint(0, 2, m) - 1
+    from .engine import legacy_randint
+    return legacy_randint(0, 2, m, scale=2, offset=-1, dtype=dtype)
+
+
+def _draw_ints(low, high, m, discard=False, dtype=np.int64):
+    """np.random.randint(low, high, m) of the legacy generator (coolpup.py:420), drawn by the library."""
+    from .engine import legacy_randint
+    return legacy_randint(low, high, m, discard=discard, dtype=dtype)
+
+
+def _factorize_pair(a, b):
+    """pd.factorize(np.concatenate([a, b])) — codes of both columns in one table of uniques, in order of first
+    appearance — at the price of one column when the two are equal row by row (cis pairs: the usual case), and of two
+    separate factorisations otherwise (no 2n-row concatenation of object pointers)."""
+    n = len(a)
+    ca, ua = pd.factorize(a)
+    try:
+        same = n > 0 and bool(np.all(a == b))
+    except Exception:                                   # noqa: BLE001 — exotic element types: the plain way
+        same = False
+    if same:
+        return np.concatenate([ca, ca]), ua
+    cb, ub = pd.factorize(b)
+    table = {u: i for i, u in enumerate(ua)}
+    uniq = list(ua)
+    remap = np.empty(len(ub), np.int64)
+    for j, u in enumerate(ub):
+        if u not in table:
+            table[u] = len(uniq)
+            uniq.append(u)
+        remap[j] = table[u]
+    cb2 = np.where(cb >= 0, remap[np.maximum(cb, 0)], -1) if len(ub) else cb
+    return np.concatenate([ca, cb2]), np.asarray(uniq, dtype=object)
 
 
 class _Cols(dict):
@@ -299,10 +331,15 @@ class CoordCreator:
         else:
             if self.local:
                 raise ValueError("Can't make local with both sides of loops defined")
-            if self.trans:
-                base = set(self.intervals["chrom1"].unique().tolist() + self.intervals["chrom2"].unique().tolist())
+            sc = getattr(self, "_sorted_codes", None)
+            if sc is not None and len(sc[1]) == len(self.intervals):
+                # chromosome names present on either side, from the factorisation the sort made (hashing a million
+                # strings into a set twice cost as much as the sort)
+                u1 = {sc[3][i] for i in np.unique(sc[1])}
+                u2 = {sc[3][i] for i in np.unique(sc[2])}
             else:
-                base = set(self.intervals["chrom1"]).intersection(set(self.intervals["chrom2"]))
+                u1, u2 = set(self.intervals["chrom1"].unique().tolist()), set(self.intervals["chrom2"].unique().tolist())
+            base = (u1 | u2) if self.trans else (u1 & u2)
         self.basechroms = natsorted(list(base))
         if isinstance(self.chroms, str) and self.chroms == "all":
             self.final_chroms = natsorted(list(base))
@@ -339,7 +376,7 @@ class CoordCreator:
         s1, s2 = iv["start1"].to_numpy(), iv["start2"].to_numpy()
         if n < 2 or s1.dtype.kind not in "iu" or s2.dtype.kind not in "iu" or s1.min() < 0 or s2.min() < 0:
             return iv.sort_values(["chrom1", "chrom2", "start1", "start2"])
-        codes, uniq = pd.factorize(np.concatenate([iv["chrom1"].to_numpy(), iv["chrom2"].to_numpy()]))
+        codes, uniq = _factorize_pair(iv["chrom1"].to_numpy(), iv["chrom2"].to_numpy())
         if (codes < 0).any():
             return iv.sort_values(["chrom1", "chrom2", "start1", "start2"])
         rank = np.empty(len(uniq), np.int64)
@@ -413,20 +450,21 @@ class CoordCreator:
         """The reference's RNG calls for m control windows (:420-436), in its order, un-multiplied: (|shift|, sign) of the
         draw that moves the BINS of both sides (the second pair of a trans pile-up, which only moves bp columns, is drawn
         and dropped)."""
-        shift = np.random.randint(self.minshift, self.maxshift, m)
-        sign = _draw_signs(m)
+        narrow = np.int32 if max(abs(int(self.minshift)), abs(int(self.maxshift))) < 2 ** 31 else np.int64
+        shift = _draw_ints(self.minshift, self.maxshift, m, dtype=narrow)
+        sign = _draw_signs(m, dtype=narrow)
         if self.trans:
-            np.random.randint(self.minshift, self.maxshift, m)
-            _draw_signs(m)
+            _draw_ints(self.minshift, self.maxshift, m, discard=True)
+            _draw_ints(0, 2, m, discard=True)
         return shift, sign
 
     def _draw_shifts(self, m):
         """The reference's RNG calls for m control windows (:420-436), in its order: (shift, shift2) in bp."""
-        shift = np.random.randint(self.minshift, self.maxshift, m)
+        shift = _draw_ints(self.minshift, self.maxshift, m)
         sign = _draw_signs(m)
         shift *= sign
         if self.trans:   # the two sides move independently in bp ...
-            shift2 = np.random.randint(self.minshift, self.maxshift, m)
+            shift2 = _draw_ints(self.minshift, self.maxshift, m)
             sign2 = _draw_signs(m)
             shift2 = shift2 * sign2
         else:

@@ -57,7 +57,7 @@ PUP_EXPORT int pup_host_free(void* ptr) {
 // region(s): lo1 <= r0 and r0 + h <= hi1, same for columns.  Outputs are compacted in order; returns the number kept and
 // *n_roi_kept of them are ROI windows.  code (may be NULL) is carried along: code_out[k] = code of the window's ROI row.
 PUP_EXPORT int64_t pup_host_windows(const int32_t* st1, const int32_t* st2, const int32_t* code, int64_t n,
-                                    const int64_t* shift, const int64_t* sign, int32_t nshifts, double resolution,
+                                    const int32_t* shift, const int32_t* sign, int32_t nshifts, double resolution,
                                     int64_t off1, int64_t off2, int64_t lo1, int64_t hi1, int64_t lo2, int64_t hi2,
                                     int32_t h, int32_t w, int32_t* r0, int32_t* c0, int32_t* code_out, int64_t* n_roi_kept) {
     if (n < 0 || nshifts < 0 || (n > 0 && (!st1 || !st2 || !r0 || !c0)) || (nshifts > 0 && n > 0 && (!shift || !sign))) return -1;
@@ -68,7 +68,7 @@ PUP_EXPORT int64_t pup_host_windows(const int32_t* st1, const int32_t* st2, cons
         if (k >= n) {
             const int64_t m = k - n;
             row = m % n;
-            d = (int64_t)std::nearbyint((double)(shift[m] * sign[m]) / resolution);
+            d = (int64_t)std::nearbyint((double)((int64_t)shift[m] * (int64_t)sign[m]) / resolution);
         }
         r = (int64_t)(int32_t)(st1[row] + (int32_t)d) + off1;
         c = (int64_t)(int32_t)(st2[row] + (int32_t)d) + off2;
@@ -92,6 +92,132 @@ PUP_EXPORT int64_t pup_host_windows(const int32_t* st1, const int32_t* st2, cons
     });
     if (n_roi_kept) { int64_t s = 0; for (int64_t v : kept_roi) s += v; *n_roi_kept = s; }
     return kept[(size_t)workers];
+}
+
+// ---- the reference's random draws, at memory speed ----------------------------------------------------------------------
+// CoordCreator._control_regions (coolpuppy/coolpup.py:420-436) draws the shifts of the control windows with the LEGACY numpy
+// generator — np.random.randint(minshift, maxshift, m) and np.random.choice([-1, 1], m), m = windows x nshifts — and a seeded
+// pile-up is only reproducible if exactly those numbers come out.  numpy produces them one call per number (~5 ns each:
+// 0.1 s of a 0.37 s pile-up of 10^7 control windows).  The stream is fully specified: MT19937 (Matsumoto & Nishimura 1998,
+// numpy/random/src/mt19937), one tempered 32-bit word per candidate, `& mask` with the smallest all-ones mask covering
+// rng = high - low - 1, candidates above rng rejected (numpy/random/src/distributions: random_bounded_uint64_fill with
+// use_masked, the legacy RandomState path).  Here the raw state words are generated block by block (the twist vectorises),
+// tempered / masked / counted by several threads, and the accepted candidates written in order; the generator state
+// (key[624], pos) is returned as numpy would have left it.
+namespace {
+
+constexpr int kMtN = 624, kMtM = 397;
+
+// next block of raw state words from the previous one (out of place: every term of the recurrence is either an old word or
+// a new word at least 227 places back, so the loops vectorise)
+__attribute__((target_clones("avx512f", "avx2", "default")))
+void mt_twist(const uint32_t* __restrict__ old, uint32_t* __restrict__ nw) {
+    auto mix = [](uint32_t a, uint32_t b, uint32_t c) -> uint32_t {
+        const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+        return c ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
+    };
+    for (int k = 0; k < kMtN - kMtM; ++k) nw[k] = mix(old[k], old[k + 1], old[k + kMtM]);
+    for (int k = kMtN - kMtM; k < kMtN - 1; ++k) nw[k] = mix(old[k], old[k + 1], nw[k - (kMtN - kMtM)]);
+    nw[kMtN - 1] = mix(old[kMtN - 1], nw[0], nw[kMtM - 1]);
+}
+
+inline uint32_t mt_temper(uint32_t y) {
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
+}
+
+// how many of raw[a, b) give a candidate within the range (the raw words stay: they are the generator's state)
+__attribute__((target_clones("avx512f", "avx2", "default")))
+int64_t mt_temper_count(const uint32_t* __restrict__ raw, int64_t a, int64_t b, uint32_t mask, uint32_t rng) {
+    int64_t c = 0;
+    for (int64_t i = a; i < b; ++i) c += ((mt_temper(raw[i]) & mask) <= rng);
+    return c;
+}
+
+// scratch for the raw words, kept between calls (a fresh 40 MB buffer costs its page faults every time)
+std::vector<uint32_t>& mt_scratch() { static thread_local std::vector<uint32_t> v; return v; }
+
+}  // namespace
+
+// out[i] = offset + scale * (low + d_i), d_i the i-th number np.random.randint(low, high, m) would draw from the legacy
+// generator whose state is (key[624], *pos); out: int32 or int64 elements (out_bytes), or NULL (draw and discard).  The state is advanced exactly as numpy
+// advances it.  Returns 0, or < 0 for bad arguments (needs 0 < high - low <= 2^32, 0 <= *pos <= 624).
+PUP_EXPORT int pup_host_mt_randint(uint32_t* key, int32_t* pos, int64_t low, int64_t high, int64_t m, int64_t scale,
+                                   int64_t offset, void* out_any, int32_t out_bytes) {
+    if (out_any && out_bytes != 4 && out_bytes != 8) return PUP_EINVAL;
+    int64_t* out = (out_any && out_bytes == 8) ? static_cast<int64_t*>(out_any) : nullptr;
+    int32_t* out32 = (out_any && out_bytes == 4) ? static_cast<int32_t*>(out_any) : nullptr;
+    if (!key || !pos || *pos < 0 || *pos > kMtN || m < 0 || high <= low || (uint64_t)(high - low - 1) > 0xffffffffull) return PUP_EINVAL;
+    if (m == 0) return PUP_OK;
+    const uint64_t rng = (uint64_t)(high - low - 1);
+    if (rng == 0) {                                       // numpy draws nothing for a single-valued range
+        if (out) for (int64_t i = 0; i < m; ++i) out[i] = offset + scale * low;
+        if (out32) for (int64_t i = 0; i < m; ++i) out32[i] = (int32_t)(offset + scale * low);
+        return PUP_OK;
+    }
+    uint32_t mask = (uint32_t)rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    const bool all = rng == 0xffffffffull;               // (numpy takes the words as they come)
+    // raw words: the unread tail of the current block, then freshly twisted blocks, in rounds until m candidates are accepted
+    std::vector<uint32_t>& raw = mt_scratch();
+    const double p_accept = ((double)rng + 1.0) / ((double)mask + 1.0);
+    int64_t done = 0;                                     // accepted so far
+    int64_t consumed = 0;                                 // raw words consumed so far (over all rounds)
+    std::vector<uint32_t> cur(key, key + kMtN);           // the block the generator currently reads from
+    int cur_pos = *pos;
+    while (done < m) {
+        const int64_t need = m - done;
+        int64_t want = (int64_t)((double)need / p_accept * 1.002) + 4096;          // words to look at this round
+        const int64_t tail = kMtN - cur_pos;
+        const int64_t nblocks = want > tail ? (want - tail + kMtN - 1) / kMtN : 0;
+        const int64_t words = tail + nblocks * kMtN;
+        if (raw.size() < (size_t)words) raw.resize((size_t)words);
+        std::memcpy(raw.data(), cur.data() + cur_pos, (size_t)tail * 4);
+        {
+            const uint32_t* prev = cur.data();
+            for (int64_t b = 0; b < nblocks; ++b) {
+                uint32_t* nw = raw.data() + tail + b * kMtN;
+                mt_twist(prev, nw);
+                prev = nw;
+            }
+        }
+        // accepted candidates per chunk, then their places
+        const int workers = n_workers(words);
+        std::vector<int64_t> acc((size_t)workers + 1, 0);
+        parallel_chunks(words, workers, [&](int k, int64_t a, int64_t b) {
+            acc[(size_t)k + 1] = mt_temper_count(raw.data(), a, b, mask, (uint32_t)rng);   // (rng = 2^32 - 1: everything counts)
+        });
+        for (int k = 0; k < workers; ++k) acc[(size_t)k + 1] += acc[(size_t)k];
+        // the chunk in which the last needed candidate falls ends the round; chunks behind it are not consumed
+        std::vector<int64_t> last_word((size_t)workers, -1);     // per chunk: index of the word that completed the request
+        parallel_chunks(words, workers, [&](int k, int64_t a, int64_t b) {
+            int64_t o = acc[(size_t)k];
+            if (o >= need) return;
+            for (int64_t i = a; i < b; ++i) {
+                const uint32_t v = mt_temper(raw[(size_t)i]) & mask;
+                if (!all && (uint64_t)v > rng) continue;
+                if (out) out[done + o] = offset + scale * (low + (int64_t)v);
+                if (out32) out32[done + o] = (int32_t)(offset + scale * (low + (int64_t)v));
+                if (++o == need) { last_word[(size_t)k] = i; return; }
+            }
+        });
+        int64_t used = words;                              // all looked at, unless the request completed inside
+        const int64_t got = std::min<int64_t>(acc[(size_t)workers], need);
+        for (int k = 0; k < workers; ++k) if (last_word[(size_t)k] >= 0) used = last_word[(size_t)k] + 1;
+        done += got; consumed += used;
+        // the block the generator reads from after `used` words of this round
+        if (used <= tail) cur_pos += (int)used;
+        else {
+            const int64_t u = used - tail, b = (u - 1) / kMtN;
+            std::vector<uint32_t> nb(raw.begin() + tail + b * kMtN, raw.begin() + tail + (b + 1) * kMtN);
+            cur.swap(nb);
+            cur_pos = (int)(u - b * kMtN);
+        }
+    }
+    (void)consumed;
+    std::memcpy(key, cur.data(), (size_t)kMtN * 4);
+    *pos = cur_pos;
+    return PUP_OK;
 }
 
 // Gather the windows of several regions into one engine call: stable counting sort by tile id over the concatenation of

@@ -393,13 +393,13 @@ def pinned_empty(n, dtype=np.int32):
 
 
 def host_windows(st1, st2, code, shift, sign, nshifts, resolution, off1, off2, lo1, hi1, lo2, hi2, h, w):
-    """pup_host_windows: ROI windows + shifted control copies of one region, bounds-tested, as (r0, c0, code, n_roi_kept).  st1 / st2 / code: int32 per ROI row (code may be None); shift / sign: int64, n*nshifts each."""
+    """pup_host_windows: ROI windows + shifted control copies of one region, bounds-tested, as (r0, c0, code, n_roi_kept).  st1 / st2 / code: int32 per ROI row (code may be None); shift / sign: int32, n*nshifts each."""
     st1, st2 = _as(st1, np.int32), _as(st2, np.int32)
     n = st1.shape[0]
     cap = n * (1 + int(nshifts))
     code = None if code is None else _as(code, np.int32)
-    shift = None if shift is None else _as(shift, np.int64)
-    sign = None if sign is None else _as(sign, np.int64)
+    shift = None if shift is None else _as(shift, np.int32)
+    sign = None if sign is None else _as(sign, np.int32)
     r0, c0 = np.empty(cap, np.int32), np.empty(cap, np.int32)      # per-region intermediates: group_tiles makes the DMA source
     code_out = np.empty(cap, np.int32) if code is not None else None
     n_roi = C.c_int64(0)
@@ -409,6 +409,27 @@ def host_windows(st1, st2, code, shift, sign, nshifts, resolution, off1, off2, l
     if kept < 0:
         raise ValueError("pup_host_windows: bad arguments")
     return r0[:kept], c0[:kept], (None if code_out is None else code_out[:kept]), int(n_roi.value)
+
+
+def legacy_randint(low, high, m, scale=1, offset=0, discard=False, dtype=np.int64):
+    """offset + scale * np.random.randint(low, high, m) of numpy's LEGACY global generator, drawn by the library
+    (pup_host_mt_randint: same numbers, same generator state afterwards, several threads instead of one call per number).
+    discard=True only advances the generator.  Falls back to numpy itself for tiny requests, ranges wider than 2^32 or a
+    global generator that is not MT19937."""
+    m = int(m)
+    st = np.random.get_state(legacy=True) if m >= 2048 and 0 < int(high) - int(low) <= (1 << 32) else None
+    if st is None or st[0] != "MT19937":
+        d = np.random.randint(low, high, m)
+        return None if discard else (d if (scale == 1 and offset == 0) else offset + scale * d).astype(dtype, copy=False)
+    key = np.array(st[1], dtype=np.uint32, copy=True)
+    pos = C.c_int32(int(st[2]))
+    out = None if discard else np.empty(m, dtype)
+    rc = _ffi.lib().pup_host_mt_randint(_ptr(key), C.byref(pos), int(low), int(high), m, int(scale), int(offset), _ptr(out),
+                                        0 if out is None else out.dtype.itemsize)
+    if rc != 0:
+        raise ValueError("pup_host_mt_randint: bad arguments")
+    np.random.set_state(("MT19937", key, int(pos.value), st[3], st[4]))
+    return out
 
 
 def group_tiles(parts, T):

@@ -29,6 +29,8 @@
  *   pup_fetch / pup_export / pup_import
  *                                     <- sum_pups cross-region merge   coolpuppy/lib/puputils.py:88-113
  *                                        and the reduce at             coolpuppy/coolpup.py:1511-1531
+ *   pup_host_mt_randint               <- np.random.randint / np.random.choice draws of CoordCreator._control_regions
+ *                                                                      coolpuppy/coolpup.py:420-436
  *   pup_host_windows                  <- CoordCreator._control_regions (shifted control copies) + the bounds test of
  *                                        _stream_snips, as one host pass  coolpuppy/coolpup.py:387-453, 1105-1114
  *   pup_host_group_tiles              <- the per-group dicts of accumulate_stream as a grouping of windows by tile
@@ -299,9 +301,22 @@ int pup_host_free(void* ptr);
  * window of that row.  Returns the number kept (< 0: bad arguments); *n_roi_kept of them come from the ROI rows.
  */
 int64_t pup_host_windows(const int32_t* st1, const int32_t* st2, const int32_t* code, int64_t n,
-                         const int64_t* shift, const int64_t* sign, int32_t nshifts, double resolution,
+                         const int32_t* shift, const int32_t* sign, int32_t nshifts, double resolution,
                          int64_t off1, int64_t off2, int64_t lo1, int64_t hi1, int64_t lo2, int64_t hi2,
                          int32_t h, int32_t w, int32_t* r0, int32_t* c0, int32_t* code_out, int64_t* n_roi_kept);
+
+/*
+ * pup_host_mt_randint: the reference's random draws for the control windows — np.random.randint(low, high, m) of the LEGACY
+ * numpy generator (coolpuppy/coolpup.py:420-436: randint(minshift, maxshift, m), and np.random.choice([-1, 1], m), which the
+ * legacy generator implements as randint(0, 2, m)) — produced from the generator's state (key[624] and *pos as
+ * np.random.get_state() returns them) and advancing it exactly as numpy does: MT19937 words, tempered, masked, rejected
+ * above the range.  out[i] = offset + scale * draw_i, elements of out_bytes = 4 or 8 bytes (out may be NULL: draw and discard —
+ * regions another rank piles up).
+ * Returns PUP_OK or PUP_EINVAL (needs 0 < high - low <= 2^32).  tests/test_host_misc.py checks numbers and final state
+ * against the installed numpy.
+ */
+int pup_host_mt_randint(uint32_t* key, int32_t* pos, int64_t low, int64_t high, int64_t m, int64_t scale, int64_t offset,
+                        void* out, int32_t out_bytes);
 
 /*
  * pup_host_group_tiles: the windows of several regions gathered into ONE pup_accumulate call — stable grouping by tile id

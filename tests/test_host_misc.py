@@ -102,6 +102,36 @@ def test_sign_draws_equal_numpy_choice():
         assert np.random.randint(0, 1 << 30) == after_want
 
 
+def test_library_draws_equal_the_legacy_generator():
+    """pup_host_mt_randint against np.random.randint of the installed numpy: the numbers, the generator state afterwards
+    (key and position — hence every later draw), for ranges with and without rejection, a power-of-two range, the full
+    32-bit range, negative bounds, a single-valued range, requests that end inside the current block / on a block boundary /
+    many blocks later, several starting positions, int32 and int64 outputs, and draw-and-discard."""
+    from coolpuppy_amd import engine as E
+    cases = [((100_000, 1_000_000), 300_000), ((0, 2), 250_001), ((0, 1 << 32), 70_000), ((-50, 77), 5_000), ((5, 6), 4_000),
+             ((0, 1 << 31), 50_000), ((10, 4_000_000_000), 20_000), ((0, 3), 2_048), ((0, 1 << 20), 624 * 8), ((7, 1000), 2_500)]
+    for k, ((lo, hi), m) in enumerate(cases):
+        for burn in (0, 1, 623, 624, 1000 + k):
+            np.random.seed(1000 + k)
+            np.random.randint(0, 1 << 30, burn)                   # some position inside a block
+            st0 = np.random.get_state()
+            want = np.random.randint(lo, hi, m)
+            after = np.random.get_state()
+            for dtype, discard in ((np.int64, False), (np.int32, False), (np.int64, True)):
+                if dtype == np.int32 and max(abs(lo), abs(hi)) >= 2 ** 31:
+                    continue
+                np.random.set_state(st0)
+                got = E.legacy_randint(lo, hi, m, discard=discard, dtype=dtype)
+                now = np.random.get_state()
+                assert np.array_equal(now[1], after[1]) and now[2] == after[2], (lo, hi, m, burn)
+                if not discard:
+                    assert got.dtype == dtype and np.array_equal(got, want), (lo, hi, m, burn)
+    np.random.seed(5)
+    want = 2 * np.random.randint(0, 2, 10_000) - 1
+    np.random.seed(5)
+    assert np.array_equal(E.legacy_randint(0, 2, 10_000, scale=2, offset=-1), want)
+
+
 def test_library_window_pass_equals_numpy():
     """pup_host_windows (shift, bounds test, compaction; no GPU needed) against the numpy statement of the same rules —
     np.round's half-to-even included — for several shapes; pup_host_group_tiles against a stable argsort."""
