@@ -146,6 +146,7 @@ def from_cooler(clr):
 
 
 _ADAPTED = {}          # id(cooler object) or path -> (weak reference to the object | mtime, ArrayCooler)
+_MAX_PATH_ADAPTERS = 4  # tables read from paths stay alive through this cache only: keep the most recent few (a table is GBs)
 
 
 def as_array_cooler(clr):
@@ -160,9 +161,13 @@ def as_array_cooler(clr):
         from .cool_io import read_cool
         path, _, group = str(clr).partition("::")
         stamp = (os.path.getmtime(path), os.path.getsize(path))
-        hit = _ADAPTED.get(str(clr))
+        hit = _ADAPTED.pop(str(clr), None)
         if hit is None or hit[0] != stamp:
-            hit = _ADAPTED[str(clr)] = (stamp, read_cool(path, group=group or "/"))
+            hit = (stamp, read_cool(path, group=group or "/"))
+        _ADAPTED[str(clr)] = hit                            # (re-inserted: dicts keep insertion order = recency)
+        paths = [k for k in _ADAPTED if isinstance(k, str)]
+        for k in paths[:max(0, len(paths) - _MAX_PATH_ADAPTERS)]:
+            del _ADAPTED[k]
         return hit[1]
     hit = _ADAPTED.get(id(clr))
     if hit is not None and hit[0]() is clr:

@@ -122,6 +122,24 @@ struct pup_ctx {
     std::vector<int> brow_sent;              // what d_brow / d_segend hold (plan_block_order)
     std::vector<long long> htab_sent;
     std::vector<unsigned char> teams_sent;
+    // by-diagonal expected as the host handed it over (a copy, with the regions' {offset, length}): when every diagonal a
+    // window reaches has a usable expected (neither NaN nor 0), dividing by expected leaves cell validity a matter of row /
+    // column masks only (factorised counts, see staged_run).  exp_far(igd) = the first unusable diagonal at or after igd
+    // over all regions (the vectors' ends count as unusable), cached per igd
+    std::vector<double> h_exp;
+    std::vector<std::pair<long long, long long>> h_exp_reg;
+    long long exp_far_igd = -1, exp_far_val = 0;
+    long long exp_far(long long igd) {
+        if (exp_far_igd == igd) return exp_far_val;
+        long long far = 0x7fffffffffffffffLL;
+        for (const auto& g : h_exp_reg) {
+            long long d = std::min(igd, g.second);
+            for (; d < g.second; ++d) { const double e = h_exp[(size_t)(g.first + d)]; if (!(e == e) || e == 0.0) break; }
+            far = std::min(far, d);
+        }
+        exp_far_igd = igd; exp_far_val = h_exp_reg.empty() ? 0 : far;
+        return exp_far_val;
+    }
     bool profiling = false;      // HIP events around the kernels
     bool count_pixels = false;   // kernels also count the pixels inside the windows (statistics; costs a little)
     pup_stats stats{};
@@ -203,7 +221,7 @@ bool tiled_supported(int W) { return W >= 3 && W <= 31 && (W & 1); }
 // widths, in parallel): pup::launch_staged picks the one for a call.
 struct StagedGeo { int RSR, RSC, NW; };
 StagedGeo staged_geometry(int W, bool ooe, bool extra, bool small21) {
-    const bool big = W <= 21 && !ooe && !extra && !(small21 && W == 21);
+    const bool big = W <= 21 && !extra && !(small21 && W == 21 && !ooe);
     return StagedGeo{big ? 128 : 64, 128, big ? 16 : 8};
 }
 
@@ -577,10 +595,12 @@ int pup_set_expected(pup_ctx* c, const double* expected, int64_t n) {
     int rc = bind(c); if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));   // earlier launches may still read the old vector
     c->nexp = 0; c->n_exp_regions = 0; c->have_exp_pair = false;
+    c->h_exp.clear(); c->h_exp_reg.clear(); c->exp_far_igd = -1;
     if (n > 0) {
         HIPCHK(c, c->expv.reserve((size_t)n));
         HIPCHK(c, hipMemcpy(c->expv.p, expected, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
         c->nexp = n;
+        c->h_exp.assign(expected, expected + n); c->h_exp_reg.emplace_back(0, n);
     }
     return PUP_OK;
 }
@@ -604,6 +624,7 @@ int pup_set_expected_table(pup_ctx* c, const int32_t* start, const int32_t* end,
     int rc = bind(c); if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->nexp = 0; c->n_exp_regions = 0; c->have_exp_pair = false;
+    c->h_exp.clear(); c->h_exp_reg.clear(); c->exp_far_igd = -1;
     HIPCHK(c, c->exp_regions.reserve((size_t)n_regions));
     HIPCHK(c, hipMemcpy(c->exp_regions.p, tab.data(), tab.size() * sizeof(pup::ExpRegion), hipMemcpyHostToDevice));
     if (pair) {
@@ -613,6 +634,8 @@ int pup_set_expected_table(pup_ctx* c, const int32_t* start, const int32_t* end,
     } else {
         HIPCHK(c, c->expv.reserve((size_t)n_values));
         HIPCHK(c, hipMemcpy(c->expv.p, values, (size_t)n_values * sizeof(double), hipMemcpyHostToDevice));
+        c->h_exp.assign(values, values + n_values);
+        for (const pup::ExpRegion& g : tab) c->h_exp_reg.emplace_back(g.off, g.len);
     }
     c->n_exp_regions = n_regions;
     return PUP_OK;
@@ -665,10 +688,10 @@ extern "C++" {
 template <typename KeyT>
 static void launch_key_kernel(pup_ctx* c, int BR, int BC, unsigned grid, const int* dr0, const int* dc0, long long n, int nseg2t, int H,
                               int set_pairs, const pup::ExpRegion* d_eregs, int n_eregs, int W, int sh_br, int sh_er, int sh_seg,
-                              int seg_shift, int clear_gap, KeyT* keys) {
+                              int seg_shift, int clear_gap, int far_gap, KeyT* keys) {
 #define PUP_KEY_ARGS dr0, dc0, n, (const long long*)c->d_segend.p, nseg2t, H, set_pairs, (const pup::IdxChrom*)c->idx_chrom.p, c->n_chrom, \
         (const unsigned short*)c->bin_chrom.p, (long long)c->nbins, (const int*)c->d_brow.p, d_eregs, n_eregs, W, BR, BC, sh_br, \
-        sh_er, sh_seg, seg_shift, clear_gap, (c->band_w > 0 && !(c->variant & 256)) ? c->band_w : 0, keys, c->d_win.p, c->d_cnt32.p
+        sh_er, sh_seg, seg_shift, clear_gap, far_gap, (c->band_w > 0 && !(c->variant & 256)) ? c->band_w : 0, keys, c->d_win.p, c->d_cnt32.p
     if (BR == 108 && BC == 108)
         hipLaunchKernelGGL((pup::staged_key_kernel<KeyT, 108, 108>), dim3(grid), dim3(256), 0, c->stream, PUP_KEY_ARGS);
     else if (BR == 44 && BC == 108)
@@ -844,10 +867,25 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     const unsigned gk4 = (unsigned)((n + 1023) / 1024);               // key kernel: four windows per thread
     const pup::ExpRegion* d_eregs = n_eregs > 0 ? c->exp_regions.p : nullptr;
     const unsigned ticket = ++c->ticket;
+    // observed over expected with a by-diagonal expected whose unusable diagonals are all ignored ones: a cell's validity is
+    // then its row / column masks, as without expected — provided no window reaches past the end of its expected vector
+    // (counted by the key kernel together with the windows a diagonal mask reaches)
+    const bool ooe = (mode & PUP_MODE_OOE) != 0;
+    const bool ooe_vec = ooe && !c->have_exp_pair && (c->nexp > 1 || c->n_exp_regions > 0);
+    bool ooe_clean = false;
+    int far_gap = 0x7fffffff;                            // a window reaching this diagonal rules the factorised count out
+    if (ooe && !c->have_exp_pair && !extra && !c->h_exp.empty()) {
+        if (c->nexp == 1) ooe_clean = c->h_exp[0] == c->h_exp[0] && c->h_exp[0] != 0.0;     // one scalar for every cell
+        else if (ooe_vec) {
+            const long long far = c->exp_far(ignore_diags);
+            ooe_clean = far > (long long)ignore_diags + W;                   // (some room for windows at all)
+            if (ooe_clean) far_gap = (int)std::min<long long>(far, 0x7fffffff);
+        }
+    }
     if (k32) launch_key_kernel<unsigned>(c, BR, BC, gk4, dr0, dc0, (long long)n, nseg2t, H, set_pairs, d_eregs, n_eregs, W, sh_br, sh_er,
-                                         sh_seg, seg_shift, ignore_diags + W - 1, c->d_k32.p);
+                                         sh_seg, seg_shift, ignore_diags + W - 1, far_gap, c->d_k32.p);
     else launch_key_kernel<unsigned long long>(c, BR, BC, gk4, dr0, dc0, (long long)n, nseg2t, H, set_pairs, d_eregs, n_eregs, W, sh_br,
-                                               sh_er, sh_seg, seg_shift, ignore_diags + W - 1, c->d_keys.p);
+                                               sh_er, sh_seg, seg_shift, ignore_diags + W - 1, far_gap, c->d_keys.p);
     hipLaunchKernelGGL(pup::staged_publish_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned*)c->d_cnt32.p, 3,
                        (volatile unsigned*)c->d_flags, ticket);
     HIPCHK(c, hipEventRecord(c->ev_key, c->stream));
@@ -890,7 +928,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     if (c->h_flags[3] != ticket) return fail(c, PUP_EHIP, "pup_accumulate: the key kernel's verdict did not arrive");
     const bool band = c->band_w > 0 && !(c->variant & 256) && !extra && c->h_flags[2] == 0;    // every window inside the dense band
     if (c->h_flags[0] != 0) return 1;                    // a window the index does not cover: the per-window kernels take the call
-    const bool fact = !(mode & PUP_MODE_OOE) && c->h_flags[1] == 0 && !(c->variant & 4);
+    const bool fact = (!ooe || ooe_clean) && c->h_flags[1] == 0 && !(c->variant & 4);
     if (!known) {
         // first call with this signature: wait for the block count once and decide whether staging pays
         HIPCHK(c, hipStreamSynchronize(c->stream));

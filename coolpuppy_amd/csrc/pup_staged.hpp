@@ -103,7 +103,7 @@ __host__ __device__ inline int staged_tile(int unit, int slot, int PH) {
 // geometry of an instantiation (host and device agree through these)
 template <int W> constexpr bool staged_big() { return W <= 21; }      // 128 x 128 regions, 16 waves: register budget of CH <= 7 cells
 template <int W, bool OOE, bool EXTRA, bool SMALL = false, bool FACT = true> struct StagedGeom {
-    static constexpr bool big = staged_big<W>() && !OOE && !EXTRA && !SMALL;
+    static constexpr bool big = staged_big<W>() && !EXTRA && !SMALL;
     static constexpr int RSR = big ? 128 : 64;
     static constexpr int RSC = 128;
     static constexpr int NW  = (big && FACT) ? 16 : 8;   // 16 waves of 128 registers where the kernel fits them (factorised
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kWave * NW, (RSR == 64 && NW == 8 && FACT && !OOE &
 void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     static_assert(!(BAND && EXTRA), "pixel statistics need the presence bits of the index: sparse staging");
     static_assert(W >= 3 && W <= 31, "workgroup-staged kernel serves windows of 3..31 bins");
-    static_assert(!(FACT && OOE), "factorised counting needs validity to factorise into row and column masks");
+    // (FACT && OOE: the engine has checked that every diagonal a window reaches has a usable expected — staged_run)
     static_assert(ACC == 1 || ACC == 2 || ACC == 8, "accumulator slots of a pass: a tile, a tile pair, four pairs");
     static_assert(RSC == 64 || RSC == 128, "a lane per column of a 64-column half");
     static_assert(RSR % NW == 0 && RSR <= 128 && RSC <= 128, "rows are dealt out evenly to the waves; corners need 7 bits");
@@ -362,10 +362,12 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
                     // usable expected = neither NaN nor zero.  The predicate goes through a register the compiler cannot see
                     // through: hipcc (ROCm 7.2) folds __ballot(e == e && e != 0.0) — and the equivalent v_cmp_class test —
                     // into v_cmp_neq_f64, the UNORDERED not-equal, which lets NaN pass
-                    int e_ok = (e == e && e != 0.0) ? 1 : 0;
-                    asm volatile("" : "+v"(e_ok));
-                    const unsigned long long eok = __ballot(e_ok);
-                    if (lane == i) r.okn[hh] &= eok;
+                    if constexpr (!FACT) {
+                        int e_ok = (e == e && e != 0.0) ? 1 : 0;
+                        asm volatile("" : "+v"(e_ok));
+                        const unsigned long long eok = __ballot(e_ok);
+                        if (lane == i) r.okn[hh] &= eok;
+                    }
                 }
                 tile[rr * LS + 64 * hh + lane] = val;
             }
@@ -477,10 +479,12 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
                     const double e = use_exp ? es.at(ad) : qnan;
                     val = val / e;
                     val = (val == val) ? val : 0.0;         // NaN quotients are skipped, inf is kept
-                    int e_ok = (e == e && e != 0.0) ? 1 : 0;     // (through a register the compiler cannot fold: see store_region)
-                    asm volatile("" : "+v"(e_ok));
-                    const unsigned long long eok = __ballot(e_ok);
-                    if (lane == i) okn[hh] &= eok;
+                    if constexpr (!FACT) {
+                        int e_ok = (e == e && e != 0.0) ? 1 : 0;     // (through a register the compiler cannot fold: see store_region)
+                        asm volatile("" : "+v"(e_ok));
+                        const unsigned long long eok = __ballot(e_ok);
+                        if (lane == i) okn[hh] &= eok;
+                    }
                 }
                 tile[rr * LS + 64 * hh + lane] = val;
             }
@@ -900,7 +904,8 @@ __global__ __launch_bounds__(256) void staged_key_kernel(const int* __restrict__
                                                          const ExpRegion* __restrict__ eregs, int n_eregs,
                                                          int W, int BR, int BC, int sh_br, int sh_er, int sh_seg,
                                                          int seg_shift /* 1: no flipped windows, the flip bit is left out */,
-                                                         int clear_gap /* igd + W - 1 */, int band_w /* 0: no band table */,
+                                                         int clear_gap /* igd + W - 1 */, int far_gap /* shortest expected vector */,
+                                                         int band_w /* 0: no band table */,
                                                          KeyT* __restrict__ keys, unsigned short* __restrict__ vals,
                                                          unsigned* __restrict__ counters /* [0] ineligible, [1] windows a diagonal mask
                                                                                             reaches, [2] windows leaving the dense band */) {
@@ -948,7 +953,7 @@ __global__ __launch_bounds__(256) void staged_key_kernel(const int* __restrict__
         }
         if (live && !ok) ++bad;
         {   // one atomic per wave, not per window (a call of near-diagonal windows would serialise on the counter)
-            const unsigned long long near = __ballot(live && c - r < clear_gap);
+            const unsigned long long near = __ballot(live && (c - r < clear_gap || (c + W - 1) - r >= far_gap));
             if (near != 0ull && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)near) - 1)) atomicAdd(&counters[1], (unsigned)__popcll(near));
             const unsigned long long far = __ballot(live && band_w > 0 && (c + W - 1) - r >= band_w);
             if (far != 0ull && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)far) - 1)) atomicAdd(&counters[2], (unsigned)__popcll(far));

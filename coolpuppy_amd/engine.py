@@ -262,9 +262,9 @@ class PileupEngine:
     @staticmethod
     def staged_region(pad, ooe=False, extra=False):
         """(rows, columns) of the region the workgroup-staged kernel keeps in LDS — staged_geometry() of pup_engine.hip /
-        StagedGeom of pup_staged.hpp: 128 x 128 bins for plain pile-ups of windows up to 21 bins, 64 x 128 otherwise
-        (observed over expected, coverage / statistics riding along, wider windows: their register budget)."""
-        big = 2 * int(pad) + 1 <= 21 and not ooe and not extra
+        StagedGeom of pup_staged.hpp: 128 x 128 bins for windows up to 21 bins, 64 x 128 otherwise (coverage / statistics riding along,
+        wider windows: their register budget)."""
+        big = 2 * int(pad) + 1 <= 21 and not extra
         return (128 if big else 64), 128
 
     @staticmethod

@@ -261,6 +261,65 @@ def test_staged_kernel_sets_of_tile_pairs(hip_lib, pad, T):
     eng.close()
 
 
+@pytest.mark.parametrize("pad", [3, 10])
+def test_staged_kernel_observed_over_expected_with_factorised_counts(hip_lib, pad):
+    """Observed over expected where every unusable diagonal of the expected is an ignored one: the staged kernel then counts
+    `num` from row / column masks as it does without expected (16 waves, big regions).  Against the plain register-tile
+    kernel: a clean expected vector and a per-region table (factorised), a vector with a NaN on a kept diagonal, windows
+    reaching past the end of a short vector, and a scalar expected (each must fall back to per-cell validity or stay exact)."""
+    import synth
+    from coolpuppy_amd.engine import MODE_OOE, PileupEngine
+    clr = synth.make_cooler({"chrA": 40_000_000, "chrB": 12_000_000}, lam=50, seed=35)
+    W = 2 * pad + 1
+    rng = np.random.default_rng(77 + pad)
+    n = 30_000
+    r0l, c0l = [], []
+    for ch in clr.chromnames:
+        lo, hi = clr.extent(ch)
+        r = rng.integers(lo, hi - W - 400, n // 2)
+        c = np.clip(r + rng.integers(W + 2, 380, n // 2), lo, hi - W)
+        keep = c - r >= W + 2
+        r0l.append(r[keep]); c0l.append(c[keep])
+    r0 = np.concatenate(r0l).astype(np.int32); c0 = np.concatenate(c0l).astype(np.int32)
+    m = len(r0)
+    tile_ptr = np.array([0, m // 6, m], np.int64)
+    w = clr.bins()["weight"][:].values
+    e = synth.cis_expected(clr)
+    vecA = e[e.region1 == "chrA"]["balanced.avg"].values.copy()
+    vecB = e[e.region1 == "chrB"]["balanced.avg"].values.copy()
+    vecA[:2] = np.nan; vecB[:2] = 0.0                       # the ignored diagonals: unusable, as cooltools leaves them
+    far = int(np.argmax(~(np.isfinite(vecA[2:]) & (vecA[2:] != 0)))) + 2 if not (np.isfinite(vecA[2:]) & (vecA[2:] != 0)).all() else len(vecA)
+    assert far > 400, far                                   # usable on every diagonal the windows below reach
+    eng = PileupEngine(0)
+    eng.load_pixels(*clr.pixel_table())
+    eng.build_index(clr.chrom_offset)
+    eng.load_bins(w, None)
+    loA, hiA = clr.extent("chrA"); loB, hiB = clr.extent("chrB")
+    dirty = vecA.copy(); dirty[9] = np.nan
+    cases = {
+        "clean vector": lambda: eng.set_expected(vecA),
+        "clean table": lambda: eng.set_expected_table([loA, loB], [hiA, hiB], vectors=[vecA, vecB]),
+        "NaN on a kept diagonal": lambda: eng.set_expected(dirty),
+        "short vector": lambda: eng.set_expected(vecA[:200]),
+        "scalar": lambda: eng.set_expected(np.array([2.5])),
+    }
+    for name, setter in cases.items():
+        res = {}
+        for label, variant in (("plain", 16), ("staged", 8), ("staged sparse", 8 | (1 << 27)), ("staged per-cell", 8 | 4)):
+            eng.set_tuning(0, variant)
+            setter()
+            eng.reset(2, pad)
+            eng.accumulate(r0, c0, tile_ptr, ignore_diags=2, mode=MODE_OOE)
+            res[label] = (eng.fetch(), eng.stats()["staged_regions"])
+        assert res["plain"][1] == 0 and res["staged"][1] > 0
+        for label in ("staged", "staged sparse", "staged per-cell"):
+            for k in ("n", "num"):
+                np.testing.assert_array_equal(res[label][0][k], res["plain"][0][k], err_msg=f"{name} {label} {k}")
+            np.testing.assert_allclose(res[label][0]["sum"], res["plain"][0]["sum"], rtol=1e-11, atol=0, equal_nan=True,
+                                       err_msg=f"{name} {label}")
+    eng.close()
+
+
 @pytest.mark.parametrize("pad", [2, 10, 15])
 def test_staged_kernel_many_workgroups(hip_lib, pad):
     """The workgroup-staged kernel with several workgroups sharing every CU (one block per workgroup, ~1500 of them):
