@@ -779,7 +779,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     const int H = paired ? T / 2 : 0;
     // several tile pairs (grouped pile-ups: by strand, by distance, ...): four pairs share a pass — a staged region then serves
     // the windows of eight tiles, each piled up by its own team of waves — instead of every pair staging the matrix again
-    const bool sets = paired && H >= 2 && W <= 21 && !(mode & PUP_MODE_OOE) && !extra && !small21 && !(c->variant & 512);
+    const bool sets = paired && H >= 2 && W <= 21 && !extra && !small21 && !(c->variant & 512);
     const int ACC = sets ? 8 : (paired ? 2 : 1), set_pairs = sets ? pup::kSetPairs : 1;
     const int U = sets ? (H + set_pairs - 1) / set_pairs : (paired ? H : T);
     const int slot_bits = sets ? pup::kSetSlotBits : 0;

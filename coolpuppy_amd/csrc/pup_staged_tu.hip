@@ -36,8 +36,7 @@ void launch_kernel(const StagedLaunch& l, const K1Args& a, const StagedArgs& sa,
 template <int W, int ACC, bool EXTRA>
 bool pick_mode(const StagedLaunch& l, const K1Args& a, const StagedArgs& sa, hipStream_t s) {
     if (a.mode & PUP_MODE_OOE) {
-        if constexpr (ACC > 2) return false;
-        else if constexpr (!EXTRA) { if (l.fact) launch_kernel<W, true, ACC, true, EXTRA>(l, a, sa, s); else launch_kernel<W, true, ACC, false, EXTRA>(l, a, sa, s); }
+        if constexpr (!EXTRA) { if (l.fact) launch_kernel<W, true, ACC, true, EXTRA>(l, a, sa, s); else launch_kernel<W, true, ACC, false, EXTRA>(l, a, sa, s); }
         else launch_kernel<W, true, ACC, false, EXTRA>(l, a, sa, s);
     } else if (l.fact) launch_kernel<W, false, ACC, true, EXTRA>(l, a, sa, s);
     else launch_kernel<W, false, ACC, false, EXTRA>(l, a, sa, s);

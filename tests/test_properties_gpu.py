@@ -210,7 +210,7 @@ def test_staged_kernel_sets_of_tile_pairs(hip_lib, pad, T):
     kernel and against the same call with the pairs piled up one by one (tuning bit 28); windows far from the diagonal
     (factorised counts, 16 waves) and near it (per-cell validity, 8 waves); repeated: bit-identical."""
     import synth
-    from coolpuppy_amd.engine import PileupEngine
+    from coolpuppy_amd.engine import MODE_OOE, PileupEngine
     clr = synth.make_cooler({"chrA": 30_000_000, "chrB": 9_000_000}, lam=50, seed=33)
     W = 2 * pad + 1
     H = T // 2
@@ -244,20 +244,29 @@ def test_staged_kernel_sets_of_tile_pairs(hip_lib, pad, T):
         r0, c0, tile, flip = r0[o], c0[o], tile[o], flip[o]
         tile_ptr = np.concatenate([[0], np.cumsum(np.bincount(tile, minlength=T))]).astype(np.int64)
         flip_from = tile_ptr[1:] - np.bincount(tile[flip], minlength=T)
-        res = {}
-        for name, variant in (("plain", 16), ("sets", 8), ("pairs", 8 | (1 << 28)), ("sets again", 8), ("sets sparse", 8 | (1 << 27))):
-            eng.set_tuning(0, variant)
-            eng.reset(T, pad)
-            eng.accumulate(r0, c0, tile_ptr, flip_from=flip_from, ignore_diags=2)
-            res[name] = (eng.fetch(), eng.stats()["staged_regions"])
-        assert res["plain"][1] == 0
-        assert 0 < res["sets"][1] < res["pairs"][1] or H < 2, (res["sets"][1], res["pairs"][1])
-        for name in ("sets", "pairs", "sets sparse"):
-            for k in ("n", "num"):
-                np.testing.assert_array_equal(res[name][0][k], res["plain"][0][k], err_msg=f"{label} {name} {k}")
-            np.testing.assert_allclose(res[name][0]["sum"], res["plain"][0]["sum"], rtol=1e-11, atol=0, equal_nan=True,
-                                       err_msg=f"{label} {name}")
-        np.testing.assert_array_equal(res["sets again"][0]["sum"], res["sets"][0]["sum"])
+        e = synth.cis_expected(clr)
+        clean = e[e.region1 == "chrA"]["balanced.avg"].values.copy()
+        clean[:2] = np.nan
+        dirty = clean.copy(); dirty[40] = 0.0
+        # plain; observed over expected with a usable expected (factorised counts) and with a zero on a kept diagonal
+        for what, mode, expv in (("plain", 0, None), ("ooe", MODE_OOE, clean), ("ooe dirty", MODE_OOE, dirty)):
+            if what != "plain" and (T, pad) not in ((10, 10), (16, 7)):
+                continue
+            res = {}
+            for name, variant in (("plain", 16), ("sets", 8), ("pairs", 8 | (1 << 28)), ("sets again", 8), ("sets sparse", 8 | (1 << 27))):
+                eng.set_tuning(0, variant)
+                eng.set_expected(expv)
+                eng.reset(T, pad)
+                eng.accumulate(r0, c0, tile_ptr, flip_from=flip_from, ignore_diags=2, mode=mode)
+                res[name] = (eng.fetch(), eng.stats()["staged_regions"])
+            assert res["plain"][1] == 0
+            assert 0 < res["sets"][1] < res["pairs"][1] or H < 2, (res["sets"][1], res["pairs"][1])
+            for name in ("sets", "pairs", "sets sparse"):
+                for k in ("n", "num"):
+                    np.testing.assert_array_equal(res[name][0][k], res["plain"][0][k], err_msg=f"{label} {what} {name} {k}")
+                np.testing.assert_allclose(res[name][0]["sum"], res["plain"][0]["sum"], rtol=1e-11, atol=0, equal_nan=True,
+                                           err_msg=f"{label} {what} {name}")
+            np.testing.assert_array_equal(res["sets again"][0]["sum"], res["sets"][0]["sum"])
     eng.close()
 
 
