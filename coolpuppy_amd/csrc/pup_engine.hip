@@ -67,6 +67,7 @@ struct pup_ctx {
     DevBuf<unsigned short> bin_chrom;       // [nbins] chromosome (index into idx_chrom) of every bin
     DevBuf<int> d_brow;                     // [n_chrom] block rows before each chromosome (block-order prepass)
     DevBuf<unsigned> rowseg;               // [nbins][n_chrom+1] search bounds per (row, chromosome), see K1Args
+    DevBuf<uint2> rowabs;                  // [n_chrom][nbins] the same as absolute positions, chromosome-major (sparse trans kernel)
     DevBuf<int> band;                       // dense band of counts near the diagonal (staged kernel), [nbins][band_w] + zeros
     int band_w = 0;                         // 0: no band table
     int n_chrom = 0;
@@ -327,7 +328,7 @@ void pup_destroy(pup_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     collect_events(c);
     c->indptr.release(); c->px.release(); c->cnt32.release(); c->bal.release(); c->badbits.release(); c->idx.release(); c->idx_chrom.release(); c->weight.release(); c->cov.release(); c->expv.release(); c->exp_pair.release(); c->exp_regions.release();
-    c->bin_chrom.release(); c->d_brow.release(); c->brow_sent.clear(); c->band.release(); c->rowseg.release();
+    c->bin_chrom.release(); c->d_brow.release(); c->brow_sent.clear(); c->band.release(); c->rowseg.release(); c->rowabs.release();
     c->acc_f64.release(); c->acc_i64.p = nullptr;
     c->d_r0.release(); c->d_c0.release(); c->d_h.release(); c->d_w.release(); c->d_geom.release();
     c->d_keys.release(); c->d_keys2.release(); c->d_cnt32.release(); c->d_win.release(); c->d_win2.release();
@@ -457,6 +458,9 @@ int pup_build_index(pup_ctx* c, const int64_t* chrom_offset, int32_t n_chroms, i
         hipLaunchKernelGGL(pup::rowseg_kernel, dim3((unsigned)((seg_entries + 255) / 256)), dim3(256), 0, c->stream,
                            c->indptr.p, c->px.p, c->idx_chrom.p, n_chroms, c->rowseg.p, c->nbins);
         c->have_rowseg = true;
+        HIPCHK(c, c->rowabs.reserve((size_t)c->nbins * (size_t)n_chroms));
+        hipLaunchKernelGGL(pup::rowabs_kernel, dim3((unsigned)((c->nbins * (long long)n_chroms + 255) / 256)), dim3(256), 0, c->stream,
+                           c->indptr.p, c->px.p, c->idx_chrom.p, n_chroms, c->rowabs.p, c->nbins);
     }
     // dense band of counts for the staged kernel: band[row][j] = count(row, row + j), j < 1024 (10 Mb at 10 kb) — 4 KiB per
     // matrix row of the 288 GB; skipped when it would not fit 32-bit byte offsets or a quarter of the free memory
@@ -709,6 +713,7 @@ static void fill_k1_args(pup_ctx* c, pup::K1Args& a, int32_t ignore_diags, uint3
     a.idx = use_idx ? c->idx.p : nullptr; a.idx_chrom = use_idx ? c->idx_chrom.p : nullptr;
     a.n_chrom = use_idx ? c->n_chrom : 0;
     a.rowseg = (use_idx && c->have_rowseg) ? c->rowseg.p : nullptr;
+    a.rowabs = (use_idx && c->have_rowseg) ? c->rowabs.p : nullptr;
     a.weight = c->have_weight ? c->weight.p : nullptr;
     a.cov = c->have_cov ? c->cov.p : nullptr;
     a.expv = (c->nexp > 0 || (c->n_exp_regions > 0 && !c->have_exp_pair)) ? c->expv.p : nullptr;
@@ -1101,10 +1106,9 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
                              !(c->variant & 32) && pup::k1s_lds_bytes(c->W) <= (size_t)c->max_lds &&
                              (!(mode & PUP_MODE_OOE) || c->nexp == 1 || c->have_exp_pair);
     if (sparse_geom && c->chunk_snippets <= 0) {
-        // a sparse-kernel window is cheap, a chunk is not (zeroing and flushing a W^2 tile, one more record for K2): three
-        // chunks per wave slot (measured on 4.9e5 51 x 51 windows: 2 per slot 1.64 ms K1s + K2, 3: 1.37, 4: 1.43, 8: 1.67)
-        const long long slots = (long long)c->n_cu * std::max<long long>(1, (160 * 1024) / (long long)pup::k1s_lds_bytes(c->W));
-        C = std::max<long long>(64, (n + 3 * slots - 1) / (3 * slots));
+        // a sparse-kernel window is cheap, a chunk is not (zeroing and finishing a W^2 record, one more record for K2)
+        const long long slots = (long long)c->n_cu * 20;             // wave slots: 5 waves per SIMD (the kernel's registers)
+        C = std::max<long long>(96, (n + slots - 1) / slots);         // (measured: 100-200 windows per chunk best)
     }
     const int S_plain = c->group_waves > 0 ? c->group_waves : 128;
     const int n_xcd = 8;
@@ -1440,6 +1444,7 @@ int pup_extract(pup_ctx* c, const int32_t* r0, const int32_t* c0, const int32_t*
         a.idx = use_idx ? c->idx.p : nullptr; a.idx_chrom = use_idx ? c->idx_chrom.p : nullptr;
         a.n_chrom = use_idx ? c->n_chrom : 0;
     a.rowseg = (use_idx && c->have_rowseg) ? c->rowseg.p : nullptr;
+    a.rowabs = (use_idx && c->have_rowseg) ? c->rowabs.p : nullptr;
         a.weight = c->have_weight ? c->weight.p : nullptr;
         a.cov = c->have_cov ? c->cov.p : nullptr;
         a.expv = (c->nexp > 0 || (c->n_exp_regions > 0 && !c->have_exp_pair)) ? c->expv.p : nullptr;

@@ -85,6 +85,8 @@ struct K1Args {
     const unsigned*  rowseg;   // [nbins][n_chrom+1] or nullptr: offset, from the row's first pixel, of its first pixel
                                //          in chromosome k (entry n_chrom = row length): bounds the binary search
                                //          of a window that the rank-bitmap index does not cover (trans)
+    const uint2*     rowabs;   // [n_chrom][nbins] or nullptr: {first, end} of the row's pixels in chromosome k as ABSOLUTE positions in
+                               //          the pixel table, chromosome-major (the sparse trans kernel: one load per window row)
     const double*    weight;   // [nbins] or nullptr (raw)
     const double*    cov;      // [nbins] or nullptr
     const double*    expv;     // [nexp] or nullptr: ONE by-diagonal vector (nexp >= 2) or ONE scalar (nexp == 1) ...
@@ -441,6 +443,25 @@ PUP_KERNEL __launch_bounds__(256) void rowseg_kernel(const long long* __restrict
     rowseg[t] = (unsigned)(lo - base);
 }
 
+// one thread per (chromosome, row): rowabs[k][row] = absolute positions {first pixel of the row in chromosome k, one past its
+// last}.  Chromosome-major: the lanes of a wave look up consecutive rows of one chromosome's column range, so their entries
+// share cache lines; absolute: the row's offset (indptr) is not needed on top
+PUP_KERNEL __launch_bounds__(256) void rowabs_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
+                                                     const IdxChrom* __restrict__ chroms, int n_chrom,
+                                                     uint2* __restrict__ rowabs, long long nbins) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nbins * n_chrom) return;
+    const int k = (int)(t / nbins);
+    const long long r = t - (long long)k * nbins;
+    const long long base = indptr[r], end = indptr[r + 1];
+    auto first_at = [&](int col) {
+        long long lo = base, hi = end;
+        while (lo < hi) { const long long m = (lo + hi) >> 1; if (px[m].x < col) lo = m + 1; else hi = m; }
+        return (unsigned)lo;
+    };
+    rowabs[t] = make_uint2(first_at(chroms[k].start), k + 1 < n_chrom ? first_at(chroms[k + 1].start) : (unsigned)end);
+}
+
 // ---- K1r: register-tile variant for small windows (W <= 32) ----------------------------------------------
 // Lane (p, k) owns the CH = ceil(W / NCH) cells of window row p, columns [k*CH, (k+1)*CH), NCH = 64 / W, for
 // EVERY snippet of the chunk: sum (f64) and num (u32) of those cells live in registers, so the hot loop has no
@@ -706,26 +727,34 @@ __device__ __forceinline__ void lds_pin(double (&v)[N]) {     // later uses of v
 // with N_e the windows whose expected is usable, R / C how often window row p / column q was a masked bin, and RC how
 // often both were (sparse: ~1 bad row x ~1 bad column per window).  Per window the wave therefore does O(W) work: one
 // lane per window row searches its matrix row (bounded by the per-chromosome segment table) and adds the few pixels
-// it finds to a per-wave LDS tile.  Same chunk flush and reduction as the other K1 kernels.
-// LDS per wave: W^2 * 8 + W * 24 bytes (W = 51: 22 KB, seven waves per CU); the sparse RC counts go straight to the chunk's
-// output record in global memory (a window with both a masked row and a masked column is rare).
-__host__ __device__ inline size_t k1s_lds_bytes(int W) { return (size_t)W * W * 8 + (size_t)W * 24; }
+// it finds to the chunk's partial tile.  Same chunk records and reduction as the other K1 kernels.
+// Round 3.  What bounds this kernel is the texture-address unit: a vector load whose lanes go to different places costs
+// about a cycle per lane whatever it fetches (counters: TA busy 73 %, 8.3 M load instructions x 64 lanes = the busy cycles),
+// and round 2's kernel — a W^2 f64 tile per wave in LDS: seven waves per CU — sat behind that with too few windows in
+// flight to fill it.  Now: (1) the tile lives in the chunk's OUTPUT RECORD in global memory; a lane adds the few pixels of
+// its row with hardware f64 atomics that return nothing (20+ waves per CU; per cell and window there is one adder);
+// (2) loads per window row cut from ~17 to ~4: masked-bin words by scalar loads, the row's pixel range in one load
+// (`rowabs`), a bisection probe only while the range is longer than a LEAF of four pixels, the leaf in two 16-byte loads,
+// a value load only for a pixel inside the window (3 % of the rows).
+// LDS per wave: 24 W bytes (masked-row / masked-column counts, coverage).
+__host__ __device__ inline size_t k1s_lds_bytes(int W) { return (size_t)W * 24; }
 
 template <bool OOE>
 __global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int W = a.W, W2 = W * W;
-    double*   tsum = reinterpret_cast<double*>(smem_raw);            // [W2]
-    double*   tcov = tsum + W2;                                      // [2W]
+    double*   tcov = reinterpret_cast<double*>(smem_raw);            // [2W]
     unsigned* trb  = reinterpret_cast<unsigned*>(tcov + 2 * W);      // [W]   R
     unsigned* tcb  = trb + W;                                        // [W]   C
     const int lane = threadIdx.x;
     const int ck = a.block_chunk[blockIdx.x];
     if (ck < 0) return;
     unsigned* trc = a.part_num + (size_t)ck * W2;                    // [W2]  RC, already in the ACCUMULATOR frame, in the chunk's own record
+    double*   tsum = a.part_f64 + (size_t)ck * ((size_t)W2 + 2 * (size_t)W);   // [W2] the chunk's sums, ACCUMULATOR frame (map_cell)
     for (int t = lane; t < W2; t += kWave) { tsum[t] = 0.0; trc[t] = 0u; }
     for (int t = lane; t < 2 * W; t += kWave) tcov[t] = 0.0;
     for (int t = lane; t < W; t += kWave) { trb[t] = 0u; tcb[t] = 0u; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");               // the zeros have reached L2 before any atomic of this wave gets there
     __syncthreads();
 
     const bool m_cov = (a.mode & 0x04u) && a.cov != nullptr;
@@ -739,13 +768,28 @@ __global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
     unsigned n_e = 0;                                                // wave-uniform
     unsigned long long npix = 0, nprobe = 0;
     const bool rowlane = lane < W;
+    const unsigned long long wmask = W >= 64 ? ~0ull : ((1ull << W) - 1ull);
 
-    // one window's state between its phases; four windows are in flight per wave (their dependent load chains —
-    // bin masks / row bounds, bisection probes, pixels — interleave, the kernel being latency-bound)
-    struct Win { int r0, c0, myrow; bool valid, rbad, cbad, e_ok; unsigned long long rowmask, colmask; double e;
-                 long long lo, b, hi; int first_x; double first_v; };
-    auto begin = [&](Win& w, int r0, int c0, bool have) __attribute__((always_inline)) {
-        w.valid = false; w.lo = 0; w.b = 0; w.hi = 0;
+    // one window's state between its phases; four windows are in flight per wave (their load chains interleave)
+    constexpr int LEAF = 4;                                          // pixels of a row looked at in registers (two 16-byte loads)
+    struct Win { int r0, c0; bool valid, e_ok; unsigned long long rowmask, colmask; double e; long long lo, b, hi; int x[LEAF];
+                 int first; double first_v; };                       // first pixel of the leaf inside the window (-1: none), its value
+    // masked-bin bits of bins [bin, bin + 64).  Worked out per BATCH, a lane per window (vector loads, all in flight together),
+    // and handed to the window's turn by readlane: as scalar loads inside the window's turn they were sixteen dependent
+    // round trips per four windows — 0.4 ms of the kernel (phases switched off one by one, round 3)
+    auto bits64 = [&](int bin) __attribute__((always_inline)) -> unsigned long long {
+        const unsigned long long* wd = a.badbits + (bin >> 6);
+        const int sh = bin & 63;
+        unsigned long long v = wd[0] >> sh;
+        if (sh) v |= wd[1] << (64 - sh);
+        return v;
+    };
+    auto lane64 = [&](unsigned long long v, int j) __attribute__((always_inline)) -> unsigned long long {
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), j) << 32) |
+               (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, j);
+    };
+    auto begin = [&](Win& w, int r0, int c0, unsigned long long rowmask, unsigned long long colmask, int kc, bool have) __attribute__((always_inline)) {
+        w.valid = false; w.lo = 0; w.b = 0; w.hi = 0; w.rowmask = 0ull; w.colmask = 0ull;
         if (!have) return;
         if (r0 < 0 || c0 < 0 || (long long)r0 + W > a.nbins || (long long)c0 + W > a.nbins) {
             if (lane == 0) atomicExch(a.err, 1);
@@ -759,33 +803,28 @@ __global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
             w.e = es.is_scalar ? es.scalar : qnan;
             w.e_ok = (w.e == w.e) && (w.e != 0.0);
         }
-        // masked bins of the window's rows (lane = row) and columns (lane = column)
-        w.myrow = r0 + (rowlane ? lane : 0);
-        const int mycol = c0 + (rowlane ? lane : 0);
-        w.rbad = rowlane && ((a.badbits[w.myrow >> 6] >> (w.myrow & 63)) & 1ull);
-        w.cbad = rowlane && ((a.badbits[mycol >> 6] >> (mycol & 63)) & 1ull);
+        w.rowmask = rowmask; w.colmask = colmask;
         if (rowlane) {
-            const long long base = a.indptr[w.myrow];
-            w.lo = base; w.hi = a.indptr[w.myrow + 1];
-            if (a.rowseg != nullptr) {
-                const unsigned* seg = a.rowseg + (long long)w.myrow * (a.n_chrom + 1) + chrom_of(a, colchrom, c0);
-                w.lo = base + seg[0]; w.hi = base + seg[1];
-            }
+            const long long myrow = (long long)r0 + lane;
+            if (a.rowabs != nullptr) {
+                const uint2 sg = a.rowabs[(long long)kc * a.nbins + myrow];
+                w.lo = sg.x; w.hi = sg.y;
+            } else { w.lo = a.indptr[myrow]; w.hi = a.indptr[myrow + 1]; }
             w.b = w.hi;
         }
     };
     auto finish = [&](Win& w) __attribute__((always_inline)) {
         if (!w.valid) return;                                         // wave-uniform
-        w.rowmask = __ballot(w.rbad); w.colmask = __ballot(w.cbad);
+        const bool rbad = (w.rowmask >> lane) & 1ull, cbad = (w.colmask >> lane) & 1ull;     // (bits past W are clear)
         if (w.e_ok) {
             ++n_e;
-            if (w.rbad) trb[lane] += 1u;
-            if (w.cbad) tcb[lane] += 1u;
+            if (rbad) trb[lane] += 1u;
+            if (cbad) tcb[lane] += 1u;
             if (w.rowmask && w.colmask) {
                 unsigned long long rm = w.rowmask;
                 while (rm) {                                          // wave-uniform loop over the (rare) masked rows
                     const int p = __ffsll((long long)rm) - 1; rm &= rm - 1;
-                    if (w.cbad) atomicAdd(&trc[map_cell(p, lane, W, m_tr, fl)], 1u);     // (L2 atomic: rare, and coherent for the flush)
+                    if (cbad) atomicAdd(&trc[map_cell(p, lane, W, m_tr, fl)], 1u);     // (L2 atomic: rare, and coherent for the flush)
                 }
             }
         }
@@ -796,16 +835,33 @@ __global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
             if (ve == ve) tcov[W + lane] += ve;
         }
         if (rowlane) {
-            for (long long k = w.lo; k < w.hi; ++k) {                 // pixels of this lane's matrix row inside [c0, c0 + W)
-                // the first candidate of every window in flight was requested together (first_x / first_v)
-                const int q = (k == w.lo ? w.first_x : a.px[k].x) - w.c0;
-                if (q >= W) break;
+            // pixels of this lane's matrix row inside [c0, c0 + W): the leaf [lo, lo + LEAF) of every window in flight was
+            // requested together; what lies in front of the window (the bisection stops LEAF short of the lower bound) is
+            // skipped, a pixel inside fetches its value, a row with more candidates than the leaf goes on through the table
+            auto add_pixel = [&](long long k, int q, int i) __attribute__((always_inline)) {
                 ++npix;
-                if (w.rbad || ((w.colmask >> q) & 1ull)) continue;    // masked bin: contributes nothing
-                const double v = k == w.lo ? w.first_v : a.bal[k];
+                if (rbad || ((w.colmask >> q) & 1ull)) return;        // masked bin: contributes nothing
+                // the value of the first pixel inside every window in flight was requested together (a wave would otherwise
+                // stop for a memory round trip in four windows out of five); further pixels of a row are rare
+                const double v = i == w.first ? w.first_v : a.bal[k];
                 const double x = OOE ? v / w.e : v;
-                if (x == x) tsum[lane * W + q] += x;                 // lane owns row `lane` of the tile: no race
+                // lane owns row `lane` of the record, a row's pixels have distinct columns: one adder per cell, and nothing
+                // comes back to wait for
+                if (x == x) unsafeAtomicAdd(&tsum[map_cell(lane, q, W, m_tr, fl)], x);
+            };
+            bool more = true;
+#pragma unroll
+            for (int i = 0; i < LEAF; ++i) {
+                const long long k = w.lo + i;
+                const int q = w.x[i] - w.c0;
+                if (more && k < w.hi) { if (q >= W) more = false; else if (q >= 0) add_pixel(k, q, i); } else more = false;
             }
+            if (more)
+                for (long long k = w.lo + LEAF; k < w.hi; ++k) {
+                    const int q = a.px[k].x - w.c0;
+                    if (q >= W) break;
+                    if (q >= 0) add_pixel(k, q, LEAF);
+                }
         }
     };
 
@@ -817,32 +873,60 @@ __global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
         r0n = coord(s0 + (long long)kWave * cstep, a.r0); c0n = coord(s0 + (long long)kWave * cstep, a.c0);
         const long long left = (ce - s0 + cstep - 1) / cstep;
         const int nb = (int)(left < kWave ? left : kWave);
+        // per batch, a lane per window: masked-bin words of its rows / columns, the chromosome of its columns
+        unsigned long long rmv = 0ull, cmv = 0ull;
+        int kcv = 0;
+        if (lane < nb && r0v >= 0 && c0v >= 0 && (long long)r0v + W <= a.nbins && (long long)c0v + W <= a.nbins) {
+            rmv = bits64(r0v) & wmask; cmv = bits64(c0v) & wmask;
+            if (a.rowabs != nullptr) {
+                int lo = 0, hi = a.n_chrom;
+                while (lo < hi) { const int m = (lo + hi) >> 1; if (a.idx_chrom[m].end <= c0v) lo = m + 1; else hi = m; }
+                kcv = lo < a.n_chrom ? lo : a.n_chrom - 1;
+            }
+        }
         constexpr int NWIN = 4;                                       // windows in flight per wave
         for (int j = 0; j < nb; j += NWIN) {
             Win w[NWIN];
 #pragma unroll
             for (int u = 0; u < NWIN; ++u) {
                 const int ju = j + u < nb ? j + u : j;
-                begin(w[u], __builtin_amdgcn_readlane(r0v, ju), __builtin_amdgcn_readlane(c0v, ju), j + u < nb);
+                begin(w[u], __builtin_amdgcn_readlane(r0v, ju), __builtin_amdgcn_readlane(c0v, ju), lane64(rmv, ju), lane64(cmv, ju),
+                      __builtin_amdgcn_readlane(kcv, ju), j + u < nb);
             }
-            // the bisections in lockstep: the probes of a step are independent loads
+            // the bisections in lockstep, only while a range is longer than the leaf: the probes of a step are independent loads
             for (;;) {
                 bool any = false;
 #pragma unroll
-                for (int u = 0; u < NWIN; ++u) any = any || (w[u].lo < w[u].b);
+                for (int u = 0; u < NWIN; ++u) any = any || (w[u].b - w[u].lo > LEAF);
                 if (!__ballot(any)) break;
                 int x[NWIN]; long long m[NWIN];
 #pragma unroll
                 for (int u = 0; u < NWIN; ++u) { m[u] = (w[u].lo + w[u].b) >> 1; x[u] = a.px[m[u]].x; }   // padded table: reading at a row's end is harmless
 #pragma unroll
                 for (int u = 0; u < NWIN; ++u)
-                    if (w[u].lo < w[u].b) { if (x[u] < w[u].c0) w[u].lo = m[u] + 1; else w[u].b = m[u]; ++nprobe; }
+                    if (w[u].b - w[u].lo > LEAF) { if (x[u] < w[u].c0) w[u].lo = m[u] + 1; else w[u].b = m[u]; ++nprobe; }
             }
 #pragma unroll
-            for (int u = 0; u < NWIN; ++u) {                          // first pixel at / after the window's first column (padded table)
+            for (int u = 0; u < NWIN; ++u) {
+                // the leaf: LEAF pixels {col, count} from lo on, 16 bytes per load at an 8-byte aligned address (global loads
+                // need dword alignment only); the table is padded: reading past a row's end is harmless
                 const bool has = rowlane && w[u].valid && w[u].lo < w[u].hi;
-                w[u].first_x = has ? a.px[w[u].lo].x : 0x7fffffff;
-                w[u].first_v = has ? a.bal[w[u].lo] : 0.0;
+                const int2* src = a.px + (has ? w[u].lo : 0);
+#pragma unroll
+                for (int i = 0; i < LEAF; i += 2) {
+                    const int4 two = *reinterpret_cast<const int4*>(src + i);
+                    w[u].x[i] = has ? two.x : 0x7fffffff; w[u].x[i + 1] = has ? two.z : 0x7fffffff;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NWIN; ++u) {                          // values of the first pixels inside the windows: requested together
+                w[u].first = -1;
+#pragma unroll
+                for (int i = LEAF - 1; i >= 0; --i) {
+                    const int q = w[u].x[i] - w[u].c0;
+                    if (w[u].lo + i < w[u].hi && q >= 0 && q < W) w[u].first = i;
+                }
+                w[u].first_v = w[u].first >= 0 ? a.bal[w[u].lo + w[u].first] : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < NWIN; ++u) finish(w[u]);
@@ -856,8 +940,7 @@ __global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
     for (int t = lane; t < W2; t += kWave) {
         const int p = t / W, q = t - p * W;
         const int cell = map_cell(p, q, W, m_tr, fl);
-        of[cell] = tsum[t];
-        // RC was counted in place (accumulator frame); read it where the atomics put it, past the L1
+        // (the sums are in the record already)  RC was counted in place (accumulator frame); read it where the atomics put it, past the L1
         const unsigned rc = __hip_atomic_load(&on[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         on[cell] = n_e - trb[p] - tcb[q] + rc;
     }

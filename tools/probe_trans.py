@@ -39,7 +39,7 @@ if os.environ.get("SORT_ROWS"):                     # experiment: windows of a t
         c["r0"], c["c0"] = r0, c0
 ref = None
 for C in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "0,100,70,50,35").split(",")]:
-    eng.set_tuning(C, 0)
+    eng.set_tuning(C, int(os.environ.get('VARIANT', '0')))
     eng.set_profiling(3)
     best = None
     for _ in range(4):
