@@ -810,11 +810,11 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     HIPCHK(c, c->d_win.reserve((size_t)n + 8)); HIPCHK(c, c->d_win2.reserve((size_t)n + 8));   // +8: K1q fetches four window values at a time
     if (c->d_segend.cap < htab.size()) c->htab_sent.clear();          // the buffer is about to move
     HIPCHK(c, c->d_segend.reserve(htab.size()));
-    HIPCHK(c, c->d_cnt32.reserve(ncnt + (size_t)n_spans));
+    // (the records' valid flags live behind the counters: one fill clears both)
+    HIPCHK(c, c->d_cnt32.reserve(ncnt + (size_t)n_spans + (nrec + 3) / 4));
     HIPCHK(c, c->d_starts.reserve((size_t)n + 1));
     HIPCHK(c, c->d_blocks.reserve((size_t)std::min<long long>(n, (n_brows + 1) * (max_len / BC + 2) * (long long)std::max(nseg_key, 1) * (n_eregs + 1))));   // distinct keys at most
     HIPCHK(c, c->d_wgfirst.reserve((size_t)G + 1));
-    HIPCHK(c, c->d_recvalid.reserve(nrec));
     HIPCHK(c, c->part_f64.reserve(nrec * Lf)); HIPCHK(c, c->part_num.reserve(nrec * W2));
     if (k32) { HIPCHK(c, c->d_k32.reserve((size_t)n)); HIPCHK(c, c->d_k32b.reserve((size_t)n)); }
     else     { HIPCHK(c, c->d_keys.reserve((size_t)n)); HIPCHK(c, c->d_keys2.reserve((size_t)n)); }
@@ -867,8 +867,8 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
 
     // ---- prepass, all on the stream -------------------------------------------------------------------------------------
     if (ev) HIPCHK(c, hipEventRecord(ev[0], c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_cnt32.p, 0, (ncnt + (size_t)n_spans) * sizeof(unsigned), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_recvalid.p, 0, nrec, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_cnt32.p, 0, (ncnt + (size_t)n_spans + (nrec + 3) / 4) * sizeof(unsigned), c->stream));
+    unsigned char* const d_recvalid = reinterpret_cast<unsigned char*>(c->d_cnt32.p + ncnt + (size_t)n_spans);
     const unsigned gk4 = (unsigned)((n + 1023) / 1024);               // key kernel: four windows per thread
     const pup::ExpRegion* d_eregs = n_eregs > 0 ? c->exp_regions.p : nullptr;
     const unsigned ticket = ++c->ticket;
@@ -947,7 +947,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     pup::K1Args a{};
     fill_k1_args(c, a, ignore_diags, mode);
     pup::StagedArgs sa{};
-    sa.blocks = c->d_blocks.p; sa.win = c->d_win2.p; sa.wg_first = c->d_wgfirst.p; sa.U = U; sa.PH = H; sa.rec_valid = c->d_recvalid.p;
+    sa.blocks = c->d_blocks.p; sa.win = c->d_win2.p; sa.wg_first = c->d_wgfirst.p; sa.U = U; sa.PH = H; sa.rec_valid = d_recvalid;
     sa.teams = ACC > 1 ? c->d_teams.p + (fact ? 0 : (size_t)U * 16) : nullptr;      // (StagedGeom: 16 waves only with factorised counts)
     sa.debug = c->debug_phases & 0x3;
     sa.timing = nullptr;
@@ -965,7 +965,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     const int Li = (int)W2;
     hipLaunchKernelGGL(pup::reduce_staged_kernel, dim3((unsigned)((Lf + Li + 63) / 64), (unsigned)T), dim3(64, pup::kRedParts), 0,
                        c->stream, (const double*)c->part_f64.p, (const unsigned*)c->part_num.p,
-                       (const unsigned char*)c->d_recvalid.p, 2 * G, (int)Lf, Li, c->acc_f64.p, c->acc_i64.p);
+                       (const unsigned char*)d_recvalid, 2 * G, (int)Lf, Li, c->acc_f64.p, c->acc_i64.p);
     HIPCHK(c, hipGetLastError());
     c->last_staged = true;
     return PUP_OK;
