@@ -259,7 +259,7 @@ int pup_get_stats(pup_ctx* ctx, pup_stats* out);   /* implies pup_sync */
 int pup_clear_stats(pup_ctx* ctx);
 /* diagnostics of the staged kernel (variant bit 26 of pup_set_tuning switches the collection on): per-wave clock totals of
  * its phases in the last pup_accumulate — out[workgroup][16 waves][8] = {issue, windows, barrier, store, barrier, rows, blocks,
- * 0}.  Returns the number of workgroups (0: nothing collected).  Development aid (tools/k1_probe.py --phases); no counterpart
+ * look-ahead inside the window phase}.  Returns the number of workgroups (0: nothing collected).  Development aid (tools/k1_probe.py --phases); no counterpart
  * in the reference. */
 int pup_debug_timing(pup_ctx* ctx, int64_t* out, int64_t cap);
 /* generic stream timer: record slot (0..7) on the context's stream; elapsed between two slots */
@@ -268,13 +268,16 @@ int pup_event_elapsed_ms(pup_ctx* ctx, int slot_begin, int slot_end, float* ms);
 /* tuning knobs (0 = library default): chunk_snippets = snippets per chunk (per wave) of the per-window kernels;
  * variant bits: 1 = ignore the index (binary search only), 2 = LDS-tile kernel for every width, 4 = no factorised `num`
  * in the staged kernel, 8 = always use the staged kernel where it is eligible (tests), 16 = never use it, 32 = never use
- * the sparse trans kernel, 64 = no tile pairing in the staged kernel (128: no effect), bits 8..23 = waves per interleaved
- * group.
+ * the sparse trans kernel, 64 = no tile pairing in the staged kernel, 128 = the 21-bin staged kernel on 64 x 128 regions
+ * (tuning probe), bits 8..23 = waves per interleaved group, bit 26 = collect the staged kernel's phase clocks
+ * (pup_debug_timing), bit 27 = never stage from the dense band of counts, bit 28 = pile tile pairs up one by one instead of
+ * four pairs per staging.
  * Staged kernel: a call of >= 1e6 cis windows (W <= 31, every window inside one chromosome, index built, at most 64 tiles) is
  * keyed on the device by (tile pair, block of top-left corners) and radix-sorted by block into a scratch copy; when a block
- * holds enough windows on average the call is piled up from LDS-staged regions — 128 x 128 bins for plain pile-ups of
- * windows up to 21 bins (blocks of 108 x 108 corners at W = 21), 64 x 128 otherwise — by persistent workgroups, tile t
- * together with tile t + T/2 (in coolpuppy's layout a group's ROI and control windows).  No host synchronisation on the
+ * holds enough windows on average the call is piled up from LDS-staged regions — 128 x 128 bins for windows up to 21 bins
+ * (blocks of 108 x 108 corners at W = 21), 64 x 128 otherwise — by persistent workgroups, tile t together with tile
+ * t + T/2 (in coolpuppy's layout a group's ROI and control windows), four such pairs per staging when there are several
+ * (grouped pile-ups: neighbouring tile numbers should belong to groups whose windows lie in the same part of the matrix).  No host synchronisation on the
  * way once a call shape has been seen (its block density is remembered).  Input order inside a tile is free.
  * Results do not depend on which kernel ran (integers exactly, sums up to the order of the f64 additions). */
 int pup_set_tuning(pup_ctx* ctx, int32_t chunk_snippets, int32_t variant);
