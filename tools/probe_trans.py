@@ -51,4 +51,10 @@ for C in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "0,100,70,50,35
         best = rec if best is None or sum(rec) < sum(best) else best
     out = eng.fetch()
     ref = out if ref is None else ref
+    if os.environ.get("PHASES"):
+        eng.set_profiling(1); eng.clear_stats(); eng.reset(plan["T"], plan["pad"])
+        for c in plan["calls"]:
+            eng.accumulate(c["r0"], c["c0"], c["tile_ptr"], flip_from=c["flip_from"], ignore_diags=c["ignore_diags"], mode=c["mode"])
+        eng.sync(); st = eng.stats()
+        print("  clocks A, B summed over waves:", int(st["pixels_in_windows"]), int(st["probe_loads"]), flush=True)
     print("chunk", C, "k1_ms, reduce_ms =", best, "same", bool(np.array_equal(out["num"], ref["num"]) and np.allclose(out["sum"], ref["sum"], rtol=1e-12)), flush=True)
