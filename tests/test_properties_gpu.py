@@ -329,6 +329,39 @@ def test_staged_kernel_observed_over_expected_with_factorised_counts(hip_lib, pa
     eng.close()
 
 
+def test_staged_kernel_with_an_empty_tile_of_a_pair(hip_lib):
+    """A tile pair whose first or second tile has no window at all (a group without controls in this region, or the other way
+    round): its team has no wave, its record stays invalid, the partner gets every wave."""
+    import synth
+    from coolpuppy_amd.engine import PileupEngine
+    clr = synth.make_cooler({"chrA": 30_000_000}, lam=50, seed=37)
+    pad, W = 10, 21
+    rng = np.random.default_rng(5)
+    lo, hi = clr.extent("chrA")
+    n = 25_000
+    r0 = rng.integers(lo, hi - W - 400, n).astype(np.int32)
+    c0 = np.clip(r0 + rng.integers(W + 2, 380, n), lo, hi - W).astype(np.int32)
+    eng = PileupEngine(0)
+    eng.load_pixels(*clr.pixel_table())
+    eng.build_index(clr.chrom_offset)
+    eng.load_bins(clr.bins()["weight"][:].values, None)
+    for tile_ptr in ([0, 0, n], [0, n, n], [0, 0, n // 3, n // 3, n], [0, n // 2, n // 2, n, n]):
+        tile_ptr = np.array(tile_ptr, np.int64)
+        T = len(tile_ptr) - 1
+        res = {}
+        for name, variant in (("plain", 16), ("staged", 8), ("staged sparse", 8 | (1 << 27)), ("pairs one by one", 8 | (1 << 28))):
+            eng.set_tuning(0, variant)
+            eng.reset(T, pad)
+            eng.accumulate(r0, c0, tile_ptr, ignore_diags=2)
+            res[name] = (eng.fetch(), eng.stats()["staged_regions"])
+        assert res["plain"][1] == 0 and res["staged"][1] > 0
+        for name in ("staged", "staged sparse", "pairs one by one"):
+            for k in ("n", "num"):
+                np.testing.assert_array_equal(res[name][0][k], res["plain"][0][k], err_msg=f"{tile_ptr} {name} {k}")
+            np.testing.assert_allclose(res[name][0]["sum"], res["plain"][0]["sum"], rtol=1e-11, atol=0, equal_nan=True)
+    eng.close()
+
+
 @pytest.mark.parametrize("pad", [2, 10, 15])
 def test_staged_kernel_many_workgroups(hip_lib, pad):
     """The workgroup-staged kernel with several workgroups sharing every CU (one block per workgroup, ~1500 of them):
