@@ -388,6 +388,9 @@ class CoordCreator:
             return iv.sort_values(["chrom1", "chrom2", "start1", "start2"])
         key = rank[codes[:n]] * len(uniq) + rank[codes[n:]]
         key = (((key << width[1] | a1) << width[2]) | a2) << width[3] | np.arange(n, dtype=np.int64)
+        if bool(np.all(key[1:] > key[:-1])):                 # already in order (a sorted BEDPE file): nothing to permute
+            self._sorted_codes = (iv.index.values, codes[:n], codes[n:], uniq)
+            return iv
         order = np.argsort(key)
         out = iv.take(order)
         self._sorted_codes = (out.index.values, codes[:n][order], codes[n:][order], uniq)
