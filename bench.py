@@ -478,8 +478,24 @@ def main():
     # pixel statistics (nnz per window, for the algorithmic byte count) are gathered once, outside the timed region
     eng.set_profiling(1)
     eng.clear_stats()
+    # the first step with a collective in it runs under a watchdog: an exchange that never completes (the engine-side RCCL
+    # path has only ever run on one-GPU boxes before the driver's scaling run) must end the job with a message, not hang it
+    watchdog = None
+    if world > 1:
+        import threading
+
+        def _give_up():
+            print(f"[bench] rank {rank}: the first step did not complete within 180 s (exchange: {exchange_used}); "
+                  "re-run with --exchange torch", file=sys.stderr, flush=True)
+            os._exit(3)
+        watchdog = threading.Timer(180.0, _give_up)
+        watchdog.daemon = True
+        watchdog.start()
     step()
     eng.sync()
+    if watchdog is not None:
+        barrier()
+        watchdog.cancel()
     st0 = eng.stats()
     pix_per_step_local = float(st0["pixels_in_windows"])
     eng.set_profiling(0)
