@@ -771,9 +771,9 @@ __global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
     const unsigned long long wmask = W >= 64 ? ~0ull : ((1ull << W) - 1ull);
 
     // one window's state between its phases; four windows are in flight per wave (their load chains interleave)
-    constexpr int LEAF = 4;                                          // pixels of a row looked at in registers (two 16-byte loads)
+    constexpr int LEAF = 4;                                          // pixels of a row looked at in registers (two 16-byte loads; 8: the same time)
     struct Win { int r0, c0; bool valid, e_ok; unsigned long long rowmask, colmask; double e; long long lo, b, hi; int x[LEAF];
-                 int first; double first_v; };                       // first pixel of the leaf inside the window (-1: none), its value
+                 int first, first_q; double first_v; };              // first pixel of the leaf inside the window (-1: none), its column, its value
     // masked-bin bits of bins [bin, bin + 64).  Worked out per BATCH, a lane per window (vector loads, all in flight together),
     // and handed to the window's turn by readlane: as scalar loads inside the window's turn they were sixteen dependent
     // round trips per four windows — 0.4 ms of the kernel (phases switched off one by one, round 3)
@@ -834,33 +834,34 @@ __global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
             if (vs == vs) tcov[lane] += vs;
             if (ve == ve) tcov[W + lane] += ve;
         }
-        if (rowlane) {
-            // pixels of this lane's matrix row inside [c0, c0 + W): the leaf [lo, lo + LEAF) of every window in flight was
-            // requested together; what lies in front of the window (the bisection stops LEAF short of the lower bound) is
-            // skipped, a pixel inside fetches its value, a row with more candidates than the leaf goes on through the table
-            auto add_pixel = [&](long long k, int q, int i) __attribute__((always_inline)) {
+        if (rowlane && w.first >= 0) {
+            // pixels of this lane's matrix row inside [c0, c0 + W).  The bisection leaves the first pixel at or after the
+            // window's first column INSIDE the leaf, so a row without a pixel in the window (97 % of them) is done here without a
+            // load; the value of the first pixel inside was requested for all windows in flight together.  This path must not
+            // contain a load: the wait for it would also wait for the ATOMICS of the windows before (no-return atomics count
+            // in vmcnt on gfx9: a round trip to L2 per window — a third of the kernel, phase clocks)
+            auto add_value = [&](int q, double v) __attribute__((always_inline)) {
                 ++npix;
                 if (rbad || ((w.colmask >> q) & 1ull)) return;        // masked bin: contributes nothing
-                // the value of the first pixel inside every window in flight was requested together (a wave would otherwise
-                // stop for a memory round trip in four windows out of five); further pixels of a row are rare
-                const double v = i == w.first ? w.first_v : a.bal[k];
                 const double x = OOE ? v / w.e : v;
                 // lane owns row `lane` of the record, a row's pixels have distinct columns: one adder per cell, and nothing
                 // comes back to wait for
                 if (x == x) unsafeAtomicAdd(&tsum[map_cell(lane, q, W, m_tr, fl)], x);
             };
+            add_value(w.first_q, w.first_v);
+            // further pixels of the row inside the window (rare): the rest of the leaf, then the table
             bool more = true;
 #pragma unroll
-            for (int i = 0; i < LEAF; ++i) {
-                const long long k = w.lo + i;
-                const int q = w.x[i] - w.c0;
-                if (more && k < w.hi) { if (q >= W) more = false; else if (q >= 0) add_pixel(k, q, i); } else more = false;
-            }
+            for (int i = 1; i < LEAF; ++i)
+                if (i > w.first && more) {
+                    const int q = w.x[i] - w.c0;
+                    if (w.lo + i < w.hi && q < W) add_value(q, a.bal[w.lo + i]); else more = false;
+                }
             if (more)
                 for (long long k = w.lo + LEAF; k < w.hi; ++k) {
                     const int q = a.px[k].x - w.c0;
                     if (q >= W) break;
-                    if (q >= 0) add_pixel(k, q, LEAF);
+                    add_value(q, a.bal[k]);
                 }
         }
     };
@@ -893,18 +894,19 @@ __global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
                 begin(w[u], __builtin_amdgcn_readlane(r0v, ju), __builtin_amdgcn_readlane(c0v, ju), lane64(rmv, ju), lane64(cmv, ju),
                       __builtin_amdgcn_readlane(kcv, ju), j + u < nb);
             }
-            // the bisections in lockstep, only while a range is longer than the leaf: the probes of a step are independent loads
+            // the bisections in lockstep, until the lower bound is known to within LEAF - 1 pixels — the leaf [lo, lo + LEAF) then
+            // holds the first pixel at or after the window's first column; the probes of a step are independent loads
             for (;;) {
                 bool any = false;
 #pragma unroll
-                for (int u = 0; u < NWIN; ++u) any = any || (w[u].b - w[u].lo > LEAF);
+                for (int u = 0; u < NWIN; ++u) any = any || (w[u].b - w[u].lo >= LEAF);
                 if (!__ballot(any)) break;
                 int x[NWIN]; long long m[NWIN];
 #pragma unroll
                 for (int u = 0; u < NWIN; ++u) { m[u] = (w[u].lo + w[u].b) >> 1; x[u] = a.px[m[u]].x; }   // padded table: reading at a row's end is harmless
 #pragma unroll
                 for (int u = 0; u < NWIN; ++u)
-                    if (w[u].b - w[u].lo > LEAF) { if (x[u] < w[u].c0) w[u].lo = m[u] + 1; else w[u].b = m[u]; ++nprobe; }
+                    if (w[u].b - w[u].lo >= LEAF) { if (x[u] < w[u].c0) w[u].lo = m[u] + 1; else w[u].b = m[u]; ++nprobe; }
             }
 #pragma unroll
             for (int u = 0; u < NWIN; ++u) {
@@ -920,11 +922,11 @@ __global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
             }
 #pragma unroll
             for (int u = 0; u < NWIN; ++u) {                          // values of the first pixels inside the windows: requested together
-                w[u].first = -1;
+                w[u].first = -1; w[u].first_q = 0;
 #pragma unroll
                 for (int i = LEAF - 1; i >= 0; --i) {
                     const int q = w[u].x[i] - w[u].c0;
-                    if (w[u].lo + i < w[u].hi && q >= 0 && q < W) w[u].first = i;
+                    if (w[u].lo + i < w[u].hi && q >= 0 && q < W) { w[u].first = i; w[u].first_q = q; }
                 }
                 w[u].first_v = w[u].first >= 0 ? a.bal[w[u].lo + w[u].first] : 0.0;
             }
