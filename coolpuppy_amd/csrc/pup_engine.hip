@@ -68,6 +68,8 @@ struct pup_ctx {
     DevBuf<int> d_brow;                     // [n_chrom] block rows before each chromosome (block-order prepass)
     DevBuf<unsigned> rowseg;               // [nbins][n_chrom+1] search bounds per (row, chromosome), see K1Args
     DevBuf<uint2> rowabs;                  // [n_chrom][nbins] the same as absolute positions, chromosome-major (sparse trans kernel)
+    DevBuf<unsigned long long> tbits;      // [ceil(nbins/64)][nbins] presence bitmap (sparse trans kernel), built on first use
+    int tbits_state = 0;                   // 0: not tried for this table, 1: built, -1: does not fit
     DevBuf<int> band;                       // dense band of counts near the diagonal (staged kernel), [nbins][band_w] + zeros
     int band_w = 0;                         // 0: no band table
     int n_chrom = 0;
@@ -328,7 +330,7 @@ void pup_destroy(pup_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     collect_events(c);
     c->indptr.release(); c->px.release(); c->cnt32.release(); c->bal.release(); c->badbits.release(); c->idx.release(); c->idx_chrom.release(); c->weight.release(); c->cov.release(); c->expv.release(); c->exp_pair.release(); c->exp_regions.release();
-    c->bin_chrom.release(); c->d_brow.release(); c->brow_sent.clear(); c->band.release(); c->rowseg.release(); c->rowabs.release();
+    c->bin_chrom.release(); c->d_brow.release(); c->brow_sent.clear(); c->band.release(); c->rowseg.release(); c->rowabs.release(); c->tbits.release(); c->tbits_state = 0;
     c->acc_f64.release(); c->acc_i64.p = nullptr;
     c->d_r0.release(); c->d_c0.release(); c->d_h.release(); c->d_w.release(); c->d_geom.release();
     c->d_keys.release(); c->d_keys2.release(); c->d_cnt32.release(); c->d_win.release(); c->d_win2.release();
@@ -363,6 +365,7 @@ int pup_load_pixels(pup_ctx* c, const int64_t* bin1_offset, const void* bin2_id,
     int rc = bind(c); if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_px = false; c->have_idx = false;
+    c->tbits_state = 0;                                  // (the bitmap of the previous table: rebuilt on first use; its memory is kept)
     HIPCHK(c, c->indptr.reserve((size_t)nbins + 1));
     HIPCHK(c, c->px.reserve((size_t)nnz + 64));         // +64: K3 reads pixel pairs (16-byte loads) across a row's end
     HIPCHK(c, c->cnt32.reserve((size_t)nnz + 64));     // +64: the register-tile kernel loads counts unconditionally
@@ -1107,8 +1110,10 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
                              (!(mode & PUP_MODE_OOE) || c->nexp == 1 || c->have_exp_pair);
     if (sparse_geom && c->chunk_snippets <= 0) {
         // a sparse-kernel window is cheap, a chunk is not (zeroing and finishing a W^2 record, one more record for K2)
-        const long long slots = (long long)c->n_cu * 20;             // wave slots: 5 waves per SIMD (the kernel's registers)
-        C = std::max<long long>(96, (n + slots - 1) / slots);         // (measured: 100-200 windows per chunk best)
+        // (measured on 4.9e5 51 x 51 windows, K1s + K2 ms: 100 per chunk 0.90, 200: 0.78, 300: 1.01 — fewer chunks than ~10
+        // per CU leave the memory system idle, more pay their fixed cost and load the reduction)
+        const long long slots = (long long)c->n_cu * 10;
+        C = std::max<long long>(96, (n + slots - 1) / slots);
     }
     const int S_plain = c->group_waves > 0 ? c->group_waves : 128;
     const int n_xcd = 8;
@@ -1279,6 +1284,20 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
                                pup::k1s_lds_bytes(W) <= (size_t)c->max_lds &&
                                (!(mode & PUP_MODE_OOE) || c->nexp == 1 || c->have_exp_pair);
     if (!launched && sparse_launch) {
+        // presence bitmap of the table (K1Args::tbits), built the first time a table is used with the sparse kernel: nbins^2 / 8
+        // bytes, taken only when that is at most a quarter of the free memory
+        if (c->tbits_state == 0) {
+            c->tbits_state = -1;
+            const unsigned long long words = (unsigned long long)((c->nbins + 63) / 64) * (unsigned long long)c->nbins;
+            size_t fb = 0, tb = 0;
+            if (!(c->variant & 1) && hipMemGetInfo(&fb, &tb) == hipSuccess && words * 8ull <= fb / 4 && c->tbits.reserve((size_t)words) == hipSuccess) {
+                HIPCHK(c, hipMemsetAsync(c->tbits.p, 0, (size_t)words * 8, c->stream));
+                const unsigned gb3 = (unsigned)std::min<long long>((c->nbins + 3) / 4, 1 << 20);
+                hipLaunchKernelGGL(pup::tbits_fill_kernel, dim3(gb3), dim3(256), 0, c->stream, c->indptr.p, c->px.p, c->tbits.p, c->nbins);
+                c->tbits_state = 1;
+            } else (void)hipGetLastError();
+        }
+        a.tbits = c->tbits_state == 1 ? c->tbits.p : nullptr;
         const size_t sl = pup::k1s_lds_bytes(W);
         if (mode & PUP_MODE_OOE) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pup::pileup_sparse_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl);

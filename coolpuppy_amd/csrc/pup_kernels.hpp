@@ -87,6 +87,9 @@ struct K1Args {
                                //          of a window that the rank-bitmap index does not cover (trans)
     const uint2*     rowabs;   // [n_chrom][nbins] or nullptr: {first, end} of the row's pixels in chromosome k as ABSOLUTE positions in
                                //          the pixel table, chromosome-major (the sparse trans kernel: one load per window row)
+    const unsigned long long* tbits;   // [ceil(nbins / 64)][nbins] or nullptr: bit j of word [cb][row] set <=> the table holds pixel
+                               //          (row, 64 cb + j).  COLUMN-block major: the 64-bit words of consecutive rows for one
+                               //          block of 64 columns are contiguous (the sparse trans kernel, see tbits_fill_kernel)
     const double*    weight;   // [nbins] or nullptr (raw)
     const double*    cov;      // [nbins] or nullptr
     const double*    expv;     // [nexp] or nullptr: ONE by-diagonal vector (nexp >= 2) or ONE scalar (nexp == 1) ...
@@ -462,6 +465,29 @@ PUP_KERNEL __launch_bounds__(256) void rowabs_kernel(const long long* __restrict
     rowabs[t] = make_uint2(first_at(chroms[k].start), k + 1 < n_chrom ? first_at(chroms[k + 1].start) : (unsigned)end);
 }
 
+// Presence bitmap of the whole table for the sparse trans kernel: one wave per matrix row ORs a bit per pixel into
+// tbits[col / 64][row].  nbins^2 / 8 bytes — 11.5 GB for a human genome at 10 kb: this is what 288 GB of HBM are for.  A
+// trans window's W rows then need TWO coalesced loads (the words of W consecutive rows for the one or two 64-column blocks
+// the window's columns fall into) to learn which of its rows hold a pixel inside it and in which columns; without it every
+// (window, row) pair fetched a cache line of the pixel table — 2.5e7 random lines, 3 GB, per 4.9e5 windows — to find, 97 times
+// out of 100, nothing.  Built on the first call that uses the sparse kernel (pup_engine.hip: ensure_tbits).
+PUP_KERNEL __launch_bounds__(256) void tbits_fill_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
+                                                         unsigned long long* __restrict__ tbits, long long nbins) {
+    const int lane = threadIdx.x & 63;
+    long long r = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long stride = (long long)gridDim.x * (blockDim.x >> 6);
+    for (; r < nbins; r += stride) {
+        const long long b = indptr[r], e = indptr[r + 1];
+        for (long long k0 = b; k0 < e; k0 += 64) {
+            const long long k = k0 + lane;
+            if (k < e) {
+                const int col = px[k].x;
+                atomicOr(&tbits[(long long)(col >> 6) * nbins + r], 1ull << (col & 63));
+            }
+        }
+    }
+}
+
 // ---- K1r: register-tile variant for small windows (W <= 32) ----------------------------------------------
 // Lane (p, k) owns the CH = ceil(W / NCH) cells of window row p, columns [k*CH, (k+1)*CH), NCH = 64 / W, for
 // EVERY snippet of the chunk: sum (f64) and num (u32) of those cells live in registers, so the hot loop has no
@@ -772,7 +798,7 @@ __global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
 
     // one window's state between its phases; four windows are in flight per wave (their load chains interleave)
     constexpr int LEAF = 4;                                          // pixels of a row looked at in registers (two 16-byte loads; 8: the same time)
-    struct Win { int r0, c0; bool valid, e_ok; unsigned long long rowmask, colmask; double e; long long lo, b, hi; int x[LEAF];
+    struct Win { int r0, c0; bool valid, e_ok; unsigned long long rowmask, colmask, wa, wb; double e; long long lo, b, hi; int x[LEAF];
                  int first, first_q; double first_v; };              // first pixel of the leaf inside the window (-1: none), its column, its value
     // masked-bin bits of bins [bin, bin + 64).  Worked out per BATCH, a lane per window (vector loads, all in flight together),
     // and handed to the window's turn by readlane: as scalar loads inside the window's turn they were sixteen dependent
@@ -803,15 +829,32 @@ __global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
             w.e = es.is_scalar ? es.scalar : qnan;
             w.e_ok = (w.e == w.e) && (w.e != 0.0);
         }
-        w.rowmask = rowmask; w.colmask = colmask;
-        if (rowlane) {
+        w.rowmask = rowmask; w.colmask = colmask; w.wa = ~0ull; w.wb = ~0ull;
+        if (rowlane && a.tbits != nullptr) {
+            // which columns of this lane's matrix row hold a pixel: the words of the one or two 64-column blocks under the
+            // window (consecutive lanes = consecutive rows = consecutive words: two coalesced loads per window)
             const long long myrow = (long long)r0 + lane;
-            if (a.rowabs != nullptr) {
-                const uint2 sg = a.rowabs[(long long)kc * a.nbins + myrow];
-                w.lo = sg.x; w.hi = sg.y;
-            } else { w.lo = a.indptr[myrow]; w.hi = a.indptr[myrow + 1]; }
-            w.b = w.hi;
+            const long long cbk = c0 >> 6;
+            w.wa = a.tbits[cbk * a.nbins + myrow];
+            w.wb = ((c0 + W - 1) >> 6) > cbk ? a.tbits[(cbk + 1) * a.nbins + myrow] : 0ull;
         }
+    };
+    // phase 2 (the bitmap words of every window in flight have been requested): the pixel range of the rows that hold a pixel
+    // inside the window — three rows in a hundred; the others are done
+    auto ranges = [&](Win& w, int kc) __attribute__((always_inline)) {
+        if (!w.valid || !rowlane) return;
+        if (a.tbits != nullptr) {
+            const int sh = w.c0 & 63;
+            unsigned long long bits = w.wa >> sh;
+            if (sh) bits |= w.wb << (64 - sh);
+            if ((bits & wmask) == 0ull) return;                       // no pixel of this row inside the window
+        }
+        const long long myrow = (long long)w.r0 + lane;
+        if (a.rowabs != nullptr) {
+            const uint2 sg = a.rowabs[(long long)kc * a.nbins + myrow];
+            w.lo = sg.x; w.hi = sg.y;
+        } else { w.lo = a.indptr[myrow]; w.hi = a.indptr[myrow + 1]; }
+        w.b = w.hi;
     };
     auto finish = [&](Win& w) __attribute__((always_inline)) {
         if (!w.valid) return;                                         // wave-uniform
@@ -885,7 +928,7 @@ __global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
                 kcv = lo < a.n_chrom ? lo : a.n_chrom - 1;
             }
         }
-        constexpr int NWIN = 4;                                       // windows in flight per wave
+        constexpr int NWIN = 8;                                       // windows in flight per wave (4: 0.80 ms against 0.75)
         for (int j = 0; j < nb; j += NWIN) {
             Win w[NWIN];
 #pragma unroll
@@ -894,6 +937,8 @@ __global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
                 begin(w[u], __builtin_amdgcn_readlane(r0v, ju), __builtin_amdgcn_readlane(c0v, ju), lane64(rmv, ju), lane64(cmv, ju),
                       __builtin_amdgcn_readlane(kcv, ju), j + u < nb);
             }
+#pragma unroll
+            for (int u = 0; u < NWIN; ++u) ranges(w[u], __builtin_amdgcn_readlane(kcv, j + u < nb ? j + u : j));
             // the bisections in lockstep, until the lower bound is known to within LEAF - 1 pixels — the leaf [lo, lo + LEAF) then
             // holds the first pixel at or after the window's first column; the probes of a step are independent loads
             for (;;) {
