@@ -135,6 +135,12 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     __shared__ unsigned long long vbits[FACT ? 1 : RSR * VBW];      // bit c of row r: cell (r, c) counts in num
     __shared__ unsigned long long pbits[EXTRA ? RSR * VBW : 1];     // bit c: cell holds a pixel (statistics only)
     __shared__ double cov_lds[EXTRA ? NW : 1][2 * W];
+    // observed over expected: the expected of the staged region's RSR + RSC - 1 diagonals, entry t = expected(|C - R - (RSR - 1)
+    // + t|) — fetched by the first 256 threads during the window phase of the block before (one coalesced load), read from
+    // here when the region is stored.  (Fetched per cell at store time, sixteen dependent-latency loads per lane: the store
+    // phase was a third of the observed-over-expected kernel.)
+    __shared__ double exp_lds[OOE ? 256 : 1];
+    static_assert(RSR + RSC - 1 <= 256, "one expected value per diagonal of the region");
     // FACT: num[p][q] = N - R[p] - C[q] + RC[p][q] (see fact_batch): the sparse both-masked pairs, and the totals
     __shared__ unsigned rc_lds[ACC][FACT ? W2 : 1];
     __shared__ unsigned fact_tot[FACT ? ACC * (2 * W + 1) : 1];     // per slot: R[W] | C[W] | N
@@ -337,6 +343,14 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
         if (er >= 0 && er < a.n_exp_regions) { const ExpRegion g = a.exp_regions[er]; es.base = a.expv + g.off; es.len = g.len; }
         return es;
     };
+    // thread t's entry of exp_lds for the region of table entry `ev`
+    auto exp_fetch = [&](int ev) __attribute__((always_inline)) -> double {
+        if (!use_exp || tid >= RSR + RSC - 1) return qnan;
+        const ExpSel es = exp_of(ev);
+        long long d = (long long)fld(ev, 1) - (long long)fld(ev, 0) - (RSR - 1) + tid;
+        if (d < 0) d = -d;
+        return es.at(d);
+    };
     auto store_region = [&](auto nf_tag, int ev, Row& r, const int (&v)[NRH], const double (&wc)[NH], const ExpSel& es) __attribute__((always_inline)) {
         constexpr bool NFP = decltype(nf_tag)::value;    // the table holds infinite weights: NaN products are stored as 0
         const int R = fld(ev, 0), C = fld(ev, 1), row_lo = fld(ev, 21), row_hi = fld(ev, 22);
@@ -354,9 +368,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
                 double val = (double)v[i * NH + hh] * wr * wcs[hh];
                 if (NFP) val = (val == val) ? val : 0.0;
                 if (OOE) {
-                    const int row = R + rr;
-                    long long ad = (long long)(C + 64 * hh + lane) - row; if (ad < 0) ad = -ad;
-                    const double e = use_exp ? es.at(ad) : qnan;
+                    const double e = exp_lds[64 * hh + lane - rr + (RSR - 1)];      // expected of |col - row|
                     val = val / e;
                     val = (val == val) ? val : 0.0;         // NaN quotients are skipped, inf is kept
                     // usable expected = neither NaN nor zero.  The predicate goes through a register the compiler cannot see
@@ -474,9 +486,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
                 double val = (double)v[i * NH + hh] * wr * wcs[hh];
                 if (NFP) val = (val == val) ? val : 0.0;
                 if (OOE) {
-                    const int row = R + rr;
-                    long long ad = (long long)(C + 64 * hh + lane) - row; if (ad < 0) ad = -ad;
-                    const double e = use_exp ? es.at(ad) : qnan;
+                    const double e = exp_lds[64 * hh + lane - rr + (RSR - 1)];      // expected of |col - row|
                     val = val / e;
                     val = (val == val) ? val : 0.0;         // NaN quotients are skipped, inf is kept
                     if constexpr (!FACT) {
@@ -779,11 +789,13 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
             first_coords(ev0, w0f);
             if (bb + 1 < be) ev1 = entry_load(bb + 1);
             const ExpSel es0 = exp_of(ev0);
+            if constexpr (OOE) { if (tid < 256) exp_lds[tid] = exp_fetch(ev0); }
             __syncthreads();
             if (nf) band_store(std::true_type{}, ev0, v, wc, wrv, es0); else band_store(std::false_type{}, ev0, v, wc, wrv, es0);
             __syncthreads();
         }
         long long tk[6] = {0, 0, 0, 0, 0, 0}, tmid = 0;
+        double e_next = 0.0;
         const bool timed = sa.timing != nullptr;
         auto tick = [&]() __attribute__((always_inline)) -> long long { return timed ? (long long)__builtin_readcyclecounter() : 0; };
         for (int b = bb; b < be; ++b) {
@@ -791,6 +803,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
             const long long t0 = tick();
             auto lookahead = [&]() __attribute__((always_inline)) {
                 const long long m0 = tick();
+                if constexpr (OOE) { if (has1) e_next = exp_fetch(ev1); }
                 if (has1) { if (!(sa.debug & 2)) band_issue(ev1, v, wc, wrv); first_coords(ev1, w1f); }
                 if (has2) evn = entry_load(b + 2);
                 tmid += tick() - m0;
@@ -798,6 +811,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
             const Cur c0 = cur_of(ev0);
             const long long t1 = tick();
             windows(c0, w0f, lookahead);
+            if constexpr (OOE) { if (has1 && tid < 256) exp_lds[tid] = e_next; }     // (last read when region b was stored; visible after the barrier below)
             const long long t2 = tick();
             const int seg0 = fld(ev0, 20);
             if (!has1) { flush(seg0); break; }
@@ -839,12 +853,14 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
             rw0 = finish_rows(ev0, x0);
             issue_values(ev0, rw0, v, wc);
             const ExpSel es0 = exp_of(ev0);
+            if constexpr (OOE) { if (tid < 256) exp_lds[tid] = exp_fetch(ev0); }
             __syncthreads();
             if (nf) store_region(std::true_type{}, ev0, rw0, v, wc, es0); else store_region(std::false_type{}, ev0, rw0, v, wc, es0);
             __syncthreads();
         }
         // (diagnostics: per-wave clocks of the phases of the loop below, only when sa.timing is set)
         long long tk[6] = {0, 0, 0, 0, 0, 0}, tmid = 0;
+        double e_next = 0.0;
         const bool timed = sa.timing != nullptr;
         auto tick = [&]() __attribute__((always_inline)) -> long long { return timed ? (long long)__builtin_readcyclecounter() : 0; };
         for (int b = bb; b < be; ++b) {
@@ -852,6 +868,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
             const long long t0 = tick();
             auto lookahead = [&]() __attribute__((always_inline)) {
                 const long long m0 = tick();
+                if constexpr (OOE) { if (has1) e_next = exp_fetch(ev1); }
                 if (has1) { rw1 = finish_rows(ev1, x1); if (!(sa.debug & 2)) issue_values(ev1, rw1, v, wc); first_coords(ev1, w1f); }
                 if (has2) { ev2 = evn; load_raw(ev2, x2); if (b + 3 < be) evn = entry_load(b + 3); }
                 tmid += tick() - m0;
@@ -859,6 +876,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
             const Cur c0 = cur_of(ev0);
             const long long t1 = tick();
             windows(c0, w0f, lookahead);
+            if constexpr (OOE) { if (has1 && tid < 256) exp_lds[tid] = e_next; }     // (last read when region b was stored; visible after the barrier below)
             const long long t2 = tick();
             const int seg0 = fld(ev0, 20);
             if (!has1) { flush(seg0); break; }
