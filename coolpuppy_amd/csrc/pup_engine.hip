@@ -131,6 +131,7 @@ struct pup_ctx {
     // over all regions (the vectors' ends count as unusable), cached per igd
     std::vector<double> h_exp;
     std::vector<std::pair<long long, long long>> h_exp_reg;
+    std::vector<std::pair<int, int>> h_exp_bounds;        // [start, end) global bins of the expected regions
     long long exp_far_igd = -1, exp_far_val = 0;
     long long exp_far(long long igd) {
         if (exp_far_igd == igd) return exp_far_val;
@@ -602,7 +603,7 @@ int pup_set_expected(pup_ctx* c, const double* expected, int64_t n) {
     int rc = bind(c); if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));   // earlier launches may still read the old vector
     c->nexp = 0; c->n_exp_regions = 0; c->have_exp_pair = false;
-    c->h_exp.clear(); c->h_exp_reg.clear(); c->exp_far_igd = -1;
+    c->h_exp.clear(); c->h_exp_reg.clear(); c->h_exp_bounds.clear(); c->exp_far_igd = -1;
     if (n > 0) {
         HIPCHK(c, c->expv.reserve((size_t)n));
         HIPCHK(c, hipMemcpy(c->expv.p, expected, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
@@ -631,7 +632,7 @@ int pup_set_expected_table(pup_ctx* c, const int32_t* start, const int32_t* end,
     int rc = bind(c); if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->nexp = 0; c->n_exp_regions = 0; c->have_exp_pair = false;
-    c->h_exp.clear(); c->h_exp_reg.clear(); c->exp_far_igd = -1;
+    c->h_exp.clear(); c->h_exp_reg.clear(); c->h_exp_bounds.clear(); c->exp_far_igd = -1;
     HIPCHK(c, c->exp_regions.reserve((size_t)n_regions));
     HIPCHK(c, hipMemcpy(c->exp_regions.p, tab.data(), tab.size() * sizeof(pup::ExpRegion), hipMemcpyHostToDevice));
     if (pair) {
@@ -642,7 +643,7 @@ int pup_set_expected_table(pup_ctx* c, const int32_t* start, const int32_t* end,
         HIPCHK(c, c->expv.reserve((size_t)n_values));
         HIPCHK(c, hipMemcpy(c->expv.p, values, (size_t)n_values * sizeof(double), hipMemcpyHostToDevice));
         c->h_exp.assign(values, values + n_values);
-        for (const pup::ExpRegion& g : tab) c->h_exp_reg.emplace_back(g.off, g.len);
+        for (const pup::ExpRegion& g : tab) { c->h_exp_reg.emplace_back(g.off, g.len); c->h_exp_bounds.emplace_back(g.start, g.end); }
     }
     c->n_exp_regions = n_regions;
     return PUP_OK;
@@ -798,7 +799,23 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     for (int t = 0; t < T; ++t) { htab.push_back(flip_from ? flip_from[t] : tile_ptr[t + 1]); htab.push_back(tile_ptr[t + 1]); }
     const int nseg2t = (int)htab.size();
     const int bits_bc = nbits((unsigned long long)(max_len / BC + 1)), bits_br = nbits((unsigned long long)n_brows + 1);
-    const int bits_er = n_eregs > 0 ? nbits((unsigned long long)n_eregs) : 0;
+    // the expected region of a window is part of its key — unless every chromosome lies inside ONE region (or none): a block
+    // never leaves its chromosome, so its region follows from its origin and the key stays short (one radix pass fewer)
+    bool er_in_key = n_eregs > 0;
+    if (er_in_key && (int)c->h_exp_bounds.size() == n_eregs) {
+        bool whole = true;
+        for (const auto& ch : c->h_chroms) {
+            bool inside = false, touched = false;
+            for (const auto& rg : c->h_exp_bounds) {
+                if (rg.first <= ch.start && rg.second >= ch.end) inside = true;
+                else if (rg.first < ch.end && rg.second > ch.start) touched = true;
+            }
+            if (touched && !inside) { whole = false; break; }
+            if (touched && inside) { whole = false; break; }          // (overlapping regions: keep the general way)
+        }
+        if (whole) er_in_key = false;
+    }
+    const int bits_er = er_in_key ? nbits((unsigned long long)n_eregs) : 0;
     const int sh_br = bits_bc, sh_er = sh_br + bits_br, sh_seg = sh_er + bits_er;
     const int nseg_key = nseg >> seg_shift;
     const int end_bit = slot_bits + sh_seg + (nseg_key > 1 ? nbits((unsigned long long)(nseg_key - 1)) : 0);
@@ -890,9 +907,10 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
             if (ooe_clean) far_gap = (int)std::min<long long>(far, 0x7fffffff);
         }
     }
-    if (k32) launch_key_kernel<unsigned>(c, BR, BC, gk4, dr0, dc0, (long long)n, nseg2t, H, set_pairs, d_eregs, n_eregs, W, sh_br, sh_er,
+    const int n_eregs_key = er_in_key ? n_eregs : 0;
+    if (k32) launch_key_kernel<unsigned>(c, BR, BC, gk4, dr0, dc0, (long long)n, nseg2t, H, set_pairs, d_eregs, n_eregs_key, W, sh_br, sh_er,
                                          sh_seg, seg_shift, ignore_diags + W - 1, far_gap, c->d_k32.p);
-    else launch_key_kernel<unsigned long long>(c, BR, BC, gk4, dr0, dc0, (long long)n, nseg2t, H, set_pairs, d_eregs, n_eregs, W, sh_br,
+    else launch_key_kernel<unsigned long long>(c, BR, BC, gk4, dr0, dc0, (long long)n, nseg2t, H, set_pairs, d_eregs, n_eregs_key, W, sh_br,
                                                sh_er, sh_seg, seg_shift, ignore_diags + W - 1, far_gap, c->d_keys.p);
     hipLaunchKernelGGL(pup::staged_publish_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned*)c->d_cnt32.p, 3,
                        (volatile unsigned*)c->d_flags, ticket);
@@ -910,7 +928,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
         hipLaunchKernelGGL((pup::staged_table_kernel<unsigned>), dim3(gt), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
                            (const unsigned*)(c->d_cnt32.p + 3), (long long)n, (const unsigned*)c->d_k32b.p,
                            (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
-                           c->n_chrom, W, geo.RSR, geo.RSC, sh_br, sh_er, sh_seg, seg_shift, slot_bits, n_eregs,
+                           c->n_chrom, W, geo.RSR, geo.RSC, sh_br, sh_er, sh_seg, seg_shift, slot_bits, n_eregs, er_in_key ? 1 : 0, d_eregs,
                            (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G);
     } else {
         se = rocprim::radix_sort_pairs<Radix10>(c->d_sorttmp.p, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_win.p, c->d_win2.p,
@@ -923,7 +941,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
         hipLaunchKernelGGL((pup::staged_table_kernel<unsigned long long>), dim3(gt), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
                            (const unsigned*)(c->d_cnt32.p + 3), (long long)n, (const unsigned long long*)c->d_keys2.p,
                            (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
-                           c->n_chrom, W, geo.RSR, geo.RSC, sh_br, sh_er, sh_seg, seg_shift, slot_bits, n_eregs,
+                           c->n_chrom, W, geo.RSR, geo.RSC, sh_br, sh_er, sh_seg, seg_shift, slot_bits, n_eregs, er_in_key ? 1 : 0, d_eregs,
                            (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G);
     }
     // leave the block count where the NEXT call with this signature finds it without waiting

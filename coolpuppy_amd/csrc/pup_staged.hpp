@@ -1059,6 +1059,7 @@ __global__ __launch_bounds__(256) void staged_table_kernel(const unsigned* __res
                                                            const unsigned short* __restrict__ win, const int* __restrict__ brow_base,
                                                            const IdxChrom* __restrict__ chroms, int n_chrom, int W, int RSR, int RSC,
                                                            int sh_br, int sh_er, int sh_seg, int seg_shift, int slot_bits, int n_eregs,
+                                                           int er_in_key, const ExpRegion* __restrict__ eregs,
                                                            const unsigned long long* __restrict__ badbits,
                                                            StagedBlock* __restrict__ blocks, int* __restrict__ wg_first, int G) {
     const long long nr = (long long)n_runs[0];
@@ -1095,8 +1096,11 @@ __global__ __launch_bounds__(256) void staged_table_kernel(const unsigned* __res
         }
         be.ereg = -1;
         if (n_eregs > 0) {
-            const int er = (int)((key >> sh_er) & ((1ull << (sh_seg - sh_er)) - 1ull));
-            be.ereg = er < n_eregs ? er : -1;
+            // the expected region of the block's windows: part of the key, or — when no chromosome is split between regions —
+            // the region its origin lies in
+            const int er = er_in_key ? (int)((key >> sh_er) & ((1ull << (sh_seg - sh_er)) - 1ull))
+                                     : find_exp_region(eregs, n_eregs, be.R);
+            be.ereg = (er >= 0 && er < n_eregs) ? er : -1;
         }
         be.seg = (int)(key >> sh_seg) << seg_shift;
         be.ch_end = ch.end; be.nblk = ch.nblk;
