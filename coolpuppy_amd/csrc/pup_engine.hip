@@ -12,6 +12,7 @@
 
 #include <hip/hip_runtime.h>
 #include <cstring>
+#include <cstdlib>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <algorithm>
 #include <cmath>
@@ -93,7 +94,7 @@ struct pup_ctx {
     DevBuf<pup::StagedBlock> d_blocks;
     DevBuf<int> d_wgfirst;
     DevBuf<long long> d_timing; int timing_G = 0;
-    DevBuf<unsigned char> d_recvalid, d_teams;
+    DevBuf<unsigned char> d_teams;
     DevBuf<long long> d_segend;
     DevBuf<unsigned char> d_sorttmp;
     long long tiled_min = 1000000;          // fewer snippets: the whole pile-up is a fraction of a millisecond anyway
@@ -336,7 +337,7 @@ void pup_destroy(pup_ctx* c) {
     c->d_r0.release(); c->d_c0.release(); c->d_h.release(); c->d_w.release(); c->d_geom.release();
     c->d_keys.release(); c->d_keys2.release(); c->d_cnt32.release(); c->d_win.release(); c->d_win2.release();
     c->d_starts.release(); c->d_blocks.release();
-    c->d_wgfirst.release(); c->d_recvalid.release(); c->d_segend.release(); c->htab_sent.clear(); c->d_sorttmp.release();
+    c->d_wgfirst.release(); c->d_segend.release(); c->htab_sent.clear(); c->d_sorttmp.release();
     if (c->ev_key) (void)hipEventDestroy(c->ev_key);
     if (c->h_flags) (void)hipHostFree(const_cast<unsigned*>(c->h_flags));
     c->d_k32.release(); c->d_k32b.release();
@@ -470,19 +471,26 @@ int pup_build_index(pup_ctx* c, const int64_t* chrom_offset, int32_t n_chroms, i
     // matrix row of the 288 GB; skipped when it would not fit 32-bit byte offsets or a quarter of the free memory
     c->band_w = 0;
     {
-        const long long BWd = 1024;
+        // widest band of 1024 / 512 / 256 columns that fits (10 Mb at 10 kb; a 2 kb table still gets 1 Mb): a call whose windows
+        // leave the band is staged through the index instead (the key kernel counts them)
         // pads: kBandFront cells before row 0 and 129 rows of zeros behind the last one — the staged kernel's factorised
         // variant reads whole region rows without masking (cells left of the diagonal, rows past the table)
-        const long long cells = pup::kBandFront + (c->nbins + 129) * BWd;
         size_t fb = 0, tb = 0;
-        const bool fits = cells < (1LL << 30) && hipMemGetInfo(&fb, &tb) == hipSuccess &&
-                          (size_t)cells * 4 <= fb / 4 + c->band.cap * sizeof(int);
-        if (fits && !(c->variant & 256)) {
+        const bool have_mem = hipMemGetInfo(&fb, &tb) == hipSuccess;
+        long long widest = 1024;
+        if (const char* e = getenv("COOLPUPPY_AMD_BAND_COLUMNS")) {          // tests: start from a narrower band
+            const long long v = atoll(e);
+            if (v == 256 || v == 512 || v == 1024) widest = v;
+        }
+        for (long long BWd = widest; BWd >= 256 && have_mem && !(c->variant & 256); BWd >>= 1) {
+            const long long cells = pup::kBandFront + (c->nbins + 129) * BWd;
+            if (!(cells < (1LL << 30) && (size_t)cells * 4 <= fb / 4 + c->band.cap * sizeof(int))) continue;
             HIPCHK(c, c->band.reserve((size_t)cells));
             HIPCHK(c, hipMemsetAsync(c->band.p, 0, (size_t)cells * sizeof(int), c->stream));
             const unsigned gb2 = (unsigned)std::min<long long>((c->nbins + 3) / 4, 1 << 20);
             hipLaunchKernelGGL(pup::band_fill_kernel, dim3(gb2), dim3(256), 0, c->stream, c->indptr.p, c->px.p, c->band.p + pup::kBandFront, (int)BWd, c->nbins);
             c->band_w = (int)BWd;
+            break;
         }
     }
     HIPCHK(c, hipGetLastError());

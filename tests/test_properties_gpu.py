@@ -329,6 +329,41 @@ def test_staged_kernel_observed_over_expected_with_factorised_counts(hip_lib, pa
     eng.close()
 
 
+@pytest.mark.parametrize("columns", [256, 512])
+def test_staged_kernel_with_a_narrow_band(hip_lib, columns, monkeypatch):
+    """Tables too large for the 1024-column band of counts get a 512- or 256-column one (here forced through
+    COOLPUPPY_AMD_BAND_COLUMNS): calls whose windows stay inside it are staged from the band, calls with a window beyond it
+    through the index — same results as the plain kernel either way."""
+    import synth
+    from coolpuppy_amd.engine import PileupEngine
+    monkeypatch.setenv("COOLPUPPY_AMD_BAND_COLUMNS", str(columns))
+    clr = synth.make_cooler({"chrA": 30_000_000, "chrB": 6_000_000}, lam=50, seed=39)
+    pad, W = 10, 21
+    rng = np.random.default_rng(columns)
+    n = 30_000
+    eng = PileupEngine(0)
+    eng.load_pixels(*clr.pixel_table())
+    eng.build_index(clr.chrom_offset)
+    eng.load_bins(clr.bins()["weight"][:].values, None)
+    lo, hi = clr.extent("chrA")
+    r0 = rng.integers(lo, hi - W - 1200, n).astype(np.int32)
+    tile_ptr = np.array([0, n // 8, n], np.int64)
+    for reach in (columns - W - 2, columns + 300):           # every window inside the band / some beyond it
+        c0 = np.clip(r0 + rng.integers(W + 2, reach, n), lo, hi - W).astype(np.int32)
+        res = {}
+        for name, variant in (("plain", 16), ("staged", 8), ("staged, no band", 8 | (1 << 27))):
+            eng.set_tuning(0, variant)
+            eng.reset(2, pad)
+            eng.accumulate(r0, c0, tile_ptr, ignore_diags=2)
+            res[name] = (eng.fetch(), eng.stats()["staged_regions"])
+        assert res["plain"][1] == 0 and res["staged"][1] > 0
+        for name in ("staged", "staged, no band"):
+            for k in ("n", "num"):
+                np.testing.assert_array_equal(res[name][0][k], res["plain"][0][k], err_msg=f"{columns} {reach} {name} {k}")
+            np.testing.assert_allclose(res[name][0]["sum"], res["plain"][0]["sum"], rtol=1e-11, atol=0, equal_nan=True)
+    eng.close()
+
+
 def test_staged_kernel_with_an_empty_tile_of_a_pair(hip_lib):
     """A tile pair whose first or second tile has no window at all (a group without controls in this region, or the other way
     round): its team has no wave, its record stays invalid, the partner gets every wave."""
