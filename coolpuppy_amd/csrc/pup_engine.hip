@@ -97,7 +97,9 @@ struct pup_ctx {
     DevBuf<unsigned char> d_teams;
     DevBuf<long long> d_segend;
     DevBuf<unsigned char> d_sorttmp;
-    long long tiled_min = 1000000;          // fewer snippets: the whole pile-up is a fraction of a millisecond anyway
+    // the staged kernel takes calls from this many windows on (measured against the per-window kernel on 21-bin windows, round 3:
+    // plain 3.3e5 windows 0.49 / 0.44 ms, 6.6e5 0.53 / 0.70; observed over expected 1.1e5 0.45 / 0.50, 3.3e5 0.61 / 1.24)
+    long long tiled_min = 400000, tiled_min_ooe = 150000;
     // the key kernel's verdict (ineligible windows, windows a diagonal mask reaches) reaches the host through mapped
     // page-locked memory while the sort is already running; the block count of the last staged call comes back the same way
     volatile unsigned* h_flags = nullptr;    // [0] ineligible [1] unclear [2] outside the band [3] ticket   [4] blocks of the last staged call [5] its ticket
@@ -748,7 +750,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     const bool force = (c->variant & 8) != 0, forbid = (c->variant & 16) != 0;
     const bool use_idx_t = c->have_idx && !(c->variant & 1);
     if (forbid || rescale || (mode & (PUP_MODE_EXPECTED | PUP_MODE_TRANSPOSE)) || (c->variant & 2) || !use_idx_t ||
-        ignore_diags < 0 || !tiled_supported(W) || n >= 0x7fffffffLL || !(force || n >= c->tiled_min) ||
+        ignore_diags < 0 || !tiled_supported(W) || n >= 0x7fffffffLL || !(force || n >= ((mode & PUP_MODE_OOE) ? c->tiled_min_ooe : c->tiled_min)) ||
         2 * T > pup::kMaxSegCount || T > pup::kMaxStagedTiles || !c->bin_chrom.p || !c->h_flags || !c->ev_key ||
         c->nnz + 64 >= (1LL << 30) ||                    // the staged kernel addresses the count table by 32-bit byte offsets
 
@@ -760,7 +762,8 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     const int BR = geo.RSR - W + 1, BC = geo.RSC - W + 1;
     const int G = c->n_cu * (geo.RSR * geo.RSC > 64 * 128 ? 1 : 2);            // persistent workgroups (one / two per CU by LDS)
     // a staged region must serve this many windows on average to pay for its staging
-    const long long min_per_block = 8LL * (geo.RSR * geo.RSC) / (64 * 64);
+    // (per-window division by expected makes the per-window kernel three times dearer: staging pays much earlier there)
+    const long long min_per_block = ((mode & PUP_MODE_OOE) ? 2LL : 8LL) * (geo.RSR * geo.RSC) / (64 * 64);
     const int n_eregs = ((mode & PUP_MODE_OOE) && c->n_exp_regions > 0 && !c->have_exp_pair) ? c->n_exp_regions : 0;
     auto nbits = [](unsigned long long v) { int b = 1; while ((v >> b) != 0) ++b; return b; };
 

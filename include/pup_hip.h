@@ -272,7 +272,7 @@ int pup_event_elapsed_ms(pup_ctx* ctx, int slot_begin, int slot_end, float* ms);
  * (tuning probe), bits 8..23 = waves per interleaved group, bit 26 = collect the staged kernel's phase clocks
  * (pup_debug_timing), bit 27 = never stage from the dense band of counts, bit 28 = pile tile pairs up one by one instead of
  * four pairs per staging.
- * Staged kernel: a call of >= 1e6 cis windows (W <= 31, every window inside one chromosome, index built, at most 64 tiles) is
+ * Staged kernel: a call of >= 4e5 cis windows (1.5e5 with observed over expected; W <= 31, every window inside one chromosome, index built, at most 64 tiles) is
  * keyed on the device by (tile pair, block of top-left corners) and radix-sorted by block into a scratch copy; when a block
  * holds enough windows on average the call is piled up from LDS-staged regions — 128 x 128 bins for windows up to 21 bins
  * (blocks of 108 x 108 corners at W = 21), 64 x 128 otherwise — by persistent workgroups, tile t together with tile
