@@ -170,7 +170,24 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     // 2 * CH more double registers: the difference between 16 and 8 waves per CU, and a wave may have at most 15 LDS
     // reads in flight — it takes 16 waves to keep the LDS busy.)
     int my_slot = 0, team_lo = 0, team_n = NW;
-    float team_inv = 1.0f / (float)NW;
+    // a wave's share of its team's windows: [f_lo, f_hi) of them.  Not equal shares: with sixteen waves the oldest and the
+    // youngest wave of a SIMD get through a window ~8 % slower than the two in between whatever the priorities (phase clocks,
+    // round 3: the workgroup waited 14 % of its time for them at the barrier behind the window loop) — they get 7 % fewer
+    auto wave_weight = [&](int w) __attribute__((always_inline)) -> float {
+        const int ag = w >> 2;
+        return NW != 16 ? 1.0f : (ag == 3 ? 0.87f : (ag == 0 ? 0.90f : 1.0f));
+    };
+    float f_lo = 0.0f, f_hi = 1.0f;
+    auto set_shares = [&]() __attribute__((always_inline)) {
+        float before = 0.0f, mine = 0.0f, total = 0.0f;
+        for (int w = team_lo; w < team_lo + team_n; ++w) {
+            const float x = wave_weight(w);
+            total += x; if (w < wave) before += x; if (w == wave) mine = x;
+        }
+        f_lo = total > 0.0f ? before / total : 0.0f;
+        f_hi = (wave == team_lo + team_n - 1 || total <= 0.0f) ? 1.0f : (before + mine) / total;
+    };
+    set_shares();
     unsigned team_w[4] = {0u, 0u, 0u, 0u};               // the unit's team table, 16 bytes
     auto team_at = [&](int s) __attribute__((always_inline)) -> int { return (int)((team_w[s >> 2] >> ((s & 3) * 8)) & 0xffu); };
     auto set_team = [&](int unit) __attribute__((always_inline)) {
@@ -182,7 +199,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
 #pragma unroll
             for (int s = 1; s < ACC; ++s) my_slot += wave >= team_at(s) ? 1 : 0;     // (teams are contiguous, empty ones have equal ends)
             team_lo = team_at(my_slot); team_n = team_at(my_slot + 1) - team_lo;
-            team_inv = 1.0f / (float)(team_n > 0 ? team_n : 1);
+            set_shares();
         }
     };
     double   sum[CH];
@@ -653,12 +670,9 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
         n = ((ACC > 1 && my_slot < ACC - 1) ? fld(ev, 23 + my_slot) : fld(ev, 3)) - first;
     };
     auto slice_of = [&](int first, int n, int& lo, int& hi) __attribute__((always_inline)) {
-        // M = ceil(n / team_n) without an integer division (a block holds fewer than 2^24 windows)
-        int M = (int)((float)n * team_inv);
-        M += (M * team_n < n) ? 1 : 0;
-        M -= ((M - 1) * team_n >= n && M > 0) ? 1 : 0;
-        const int r = wave - team_lo;
-        lo = r * M < n ? r * M : n; hi = lo + M < n ? lo + M : n;
+        // (both ends by the same formula on neighbouring waves: the slices tile the team's windows exactly)
+        lo = (int)((float)n * f_lo + 0.5f); hi = f_hi >= 1.0f ? n : (int)((float)n * f_hi + 0.5f);
+        lo = lo < n ? lo : n; hi = hi < n ? hi : n; hi = hi > lo ? hi : lo;
         lo += first; hi += first;
     };
     // `mid` = the look-ahead work of the pipeline (lookups and loads for the next blocks: VALU and address arithmetic, no
