@@ -136,6 +136,7 @@ struct pup_ctx {
     std::vector<std::pair<long long, long long>> h_exp_reg;
     std::vector<std::pair<int, int>> h_exp_bounds;        // [start, end) global bins of the expected regions
     long long exp_far_igd = -1, exp_far_val = 0;
+    bool hint_have_verdict = false, hint_fact = false, hint_band = false;   // the last staged call's kernel choice (same hint_sig)
     long long exp_far(long long igd) {
         if (exp_far_igd == igd) return exp_far_val;
         long long far = 0x7fffffffffffffffLL;
@@ -960,41 +961,67 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
                        (volatile unsigned*)(c->d_flags + 4), ticket);
     HIPCHK(c, hipGetLastError());
 
+    // ---- K1q (+ reduction below) ---------------------------------------------------------------------------------------------
+    const size_t Li0 = W2;
+    auto launch_k1 = [&](bool fact, bool band) -> int {
+        pup::K1Args a{};
+        fill_k1_args(c, a, ignore_diags, mode);
+        pup::StagedArgs sa{};
+        sa.blocks = c->d_blocks.p; sa.win = c->d_win2.p; sa.wg_first = c->d_wgfirst.p; sa.U = U; sa.PH = H; sa.rec_valid = d_recvalid;
+        sa.teams = ACC > 1 ? c->d_teams.p + (fact ? 0 : (size_t)U * 16) : nullptr;      // (StagedGeom: 16 waves only with factorised counts)
+        sa.debug = c->debug_phases & 0x3;
+        sa.timing = nullptr;
+        if (c->debug_phases & 4) {                       // phase clocks (diagnostics): [G][16][8] long long, read by pup_debug_timing
+            HIPCHK(c, c->d_timing.reserve((size_t)G * 16 * 8));
+            HIPCHK(c, hipMemsetAsync(c->d_timing.p, 0, (size_t)G * 16 * 8 * sizeof(long long), c->stream));
+            sa.timing = c->d_timing.p; c->timing_G = G;
+        }
+        if (ev) HIPCHK(c, hipEventRecord(ev[1], c->stream));
+        const pup::StagedLaunch sl{W, G, ACC, fact, extra, small21, band};
+        if (!pup::launch_staged(sl, a, sa, c->stream))
+            return fail(c, PUP_ENOTSUP, "pup_accumulate: staged kernel not built for W=%d", W);
+        HIPCHK(c, hipGetLastError());
+        if (ev) HIPCHK(c, hipEventRecord(ev[2], c->stream));
+        return PUP_OK;
+    };
+    // A call shape seen before is launched on the LAST call's verdict, right behind the prepass — before the host has this
+    // call's: the stream then never waits for the host (on a busy host the wait below could outlast the sort, 0.1 ms of idle
+    // GPU per call were measured on one box).  The verdict is checked afterwards; the reduction — the only thing that touches
+    // the accumulators — is launched only once it is known that the right kernel ran (else the records are dropped and the
+    // right one runs)
+    bool speculated = false;
+    const bool spec_fact = c->hint_fact, spec_band = c->hint_band;
+    if (known && c->hint_have_verdict) {
+        const int rc1 = launch_k1(spec_fact, spec_band);
+        if (rc1 != PUP_OK) return rc1;
+        speculated = true;
+    }
+
     // ---- the host's part: the key kernel's verdict (an event long reached: the sort is still running) -----------------
     HIPCHK(c, hipEventSynchronize(c->ev_key));
     if (c->h_flags[3] != ticket) return fail(c, PUP_EHIP, "pup_accumulate: the key kernel's verdict did not arrive");
     const bool band = c->band_w > 0 && !(c->variant & 256) && !extra && c->h_flags[2] == 0;    // every window inside the dense band
-    if (c->h_flags[0] != 0) return 1;                    // a window the index does not cover: the per-window kernels take the call
+    if (c->h_flags[0] != 0) { c->hint_have_verdict = false; return 1; }   // a window the index does not cover: the per-window kernels take the call
     const bool fact = (!ooe || ooe_clean) && c->h_flags[1] == 0 && !(c->variant & 4);
     if (!known) {
         // first call with this signature: wait for the block count once and decide whether staging pays
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->hint_sig = sig;
         c->hint_blocks = (long long)c->h_flags[4];
+        c->hint_have_verdict = false;
         if (!force && c->hint_blocks * min_per_block > n) { c->hint_ticket = ticket; return 1; }
     }
     c->hint_ticket = ticket;
-
-    // ---- K1q + reduction ---------------------------------------------------------------------------------------------------
-    pup::K1Args a{};
-    fill_k1_args(c, a, ignore_diags, mode);
-    pup::StagedArgs sa{};
-    sa.blocks = c->d_blocks.p; sa.win = c->d_win2.p; sa.wg_first = c->d_wgfirst.p; sa.U = U; sa.PH = H; sa.rec_valid = d_recvalid;
-    sa.teams = ACC > 1 ? c->d_teams.p + (fact ? 0 : (size_t)U * 16) : nullptr;      // (StagedGeom: 16 waves only with factorised counts)
-    sa.debug = c->debug_phases & 0x3;
-    sa.timing = nullptr;
-    if (c->debug_phases & 4) {                           // phase clocks (diagnostics): [G][16][8] long long, read by pup_debug_timing
-        HIPCHK(c, c->d_timing.reserve((size_t)G * 16 * 8));
-        HIPCHK(c, hipMemsetAsync(c->d_timing.p, 0, (size_t)G * 16 * 8 * sizeof(long long), c->stream));
-        sa.timing = c->d_timing.p; c->timing_G = G;
-    }                          // timing experiments (tools/k1_probe.py): variant bits 24 / 25
-    if (ev) HIPCHK(c, hipEventRecord(ev[1], c->stream));
-    const pup::StagedLaunch sl{W, G, ACC, fact, extra, small21, band};
-    if (!pup::launch_staged(sl, a, sa, c->stream))
-        return fail(c, PUP_ENOTSUP, "pup_accumulate: staged kernel not built for W=%d", W);
-    HIPCHK(c, hipGetLastError());
-    if (ev) HIPCHK(c, hipEventRecord(ev[2], c->stream));
-    const int Li = (int)W2;
+    if (speculated && (fact != spec_fact || band != spec_band)) {
+        HIPCHK(c, hipMemsetAsync(d_recvalid, 0, nrec, c->stream));     // the wrong kernel's records: dropped
+        speculated = false;
+    }
+    if (!speculated) {
+        const int rc1 = launch_k1(fact, band);
+        if (rc1 != PUP_OK) return rc1;
+    }
+    c->hint_fact = fact; c->hint_band = band; c->hint_have_verdict = true;
+    const int Li = (int)Li0;
     hipLaunchKernelGGL(pup::reduce_staged_kernel, dim3((unsigned)((Lf + Li + 63) / 64), (unsigned)T), dim3(64, pup::kRedParts), 0,
                        c->stream, (const double*)c->part_f64.p, (const unsigned*)c->part_num.p,
                        (const unsigned char*)d_recvalid, 2 * G, (int)Lf, Li, c->acc_f64.p, c->acc_i64.p);
