@@ -364,6 +364,47 @@ def test_staged_kernel_with_a_narrow_band(hip_lib, columns, monkeypatch):
     eng.close()
 
 
+def test_staged_kernel_launched_on_the_previous_verdict(hip_lib):
+    """A call shape seen before is launched on the previous call's verdict before this call's is known.  Calls of ONE shape
+    whose verdicts differ — windows clear of the masked diagonals (factorised counts), windows touching them (per-cell
+    validity), windows beyond the band of counts, a window the index does not cover (per-window kernels take the call) — in
+    an order that makes every guess wrong at least once; every result against the plain kernel's."""
+    import synth
+    from coolpuppy_amd.engine import PileupEngine
+    clr = synth.make_cooler({"chrA": 40_000_000, "chrB": 10_000_000}, lam=50, seed=41)
+    pad, W = 10, 21
+    rng = np.random.default_rng(11)
+    lo, hi = clr.extent("chrA")
+    loB, hiB = clr.extent("chrB")
+    n = 30_000
+    r0 = rng.integers(lo, hi - W - 1500, n).astype(np.int32)
+    tile_ptr = np.array([0, n // 6, n], np.int64)
+    far = np.clip(r0 + rng.integers(W + 2, 380, n), lo, hi - W).astype(np.int32)
+    near = np.clip(r0 + rng.integers(-6, 380, n), lo, hi - W).astype(np.int32)
+    wide = far.copy(); wide[::97] = np.clip(r0[::97] + 1200, lo, hi - W)             # beyond the 1024-column band
+    trans = far.copy(); trans[5] = loB + 100                                           # one inter-chromosomal window
+    cases = {"far": far, "near": near, "wide": wide, "trans": trans}
+    eng = PileupEngine(0)
+    eng.load_pixels(*clr.pixel_table())
+    eng.build_index(clr.chrom_offset)
+    eng.load_bins(clr.bins()["weight"][:].values, None)
+    want = {}
+    eng.set_tuning(0, 16)
+    for name, c0 in cases.items():
+        eng.reset(2, pad)
+        eng.accumulate(r0, c0, tile_ptr, ignore_diags=2 if name != "trans" else 2)
+        want[name] = eng.fetch()
+    eng.set_tuning(0, 8)
+    for name in ("far", "far", "near", "near", "far", "wide", "far", "trans", "far", "near", "trans", "wide", "wide", "far"):
+        eng.reset(2, pad)
+        eng.accumulate(r0, cases[name], tile_ptr, ignore_diags=2)
+        got = eng.fetch()
+        for k in ("n", "num"):
+            np.testing.assert_array_equal(got[k], want[name][k], err_msg=f"{name} {k}")
+        np.testing.assert_allclose(got["sum"], want[name]["sum"], rtol=1e-11, atol=0, equal_nan=True, err_msg=name)
+    eng.close()
+
+
 def test_staged_kernel_with_an_empty_tile_of_a_pair(hip_lib):
     """A tile pair whose first or second tile has no window at all (a group without controls in this region, or the other way
     round): its team has no wave, its record stays invalid, the partner gets every wave."""
