@@ -607,7 +607,8 @@ def main():
             "kernel": (f"pup::pileup_staged_kernel<{W}, false, {reg_rows}, {reg_cols}, {reg_rows // 8}, {1 if a.variant & 64 else 2}, "
                        f"{'false' if a.variant & 4 else 'true'}, false, {'false' if a.variant & (1 << 27) else 'true'}> (persistent workgroups, {reg_rows} x {reg_cols} regions staged "
                        "in LDS, ROI and control tile in one pass)"
-                       if staged else f"pup::pileup_regtile_kernel<{W}, false>"),
+                       if staged else (f"pup::pileup_regtile_kernel<{W}, false>" if W <= 31 else
+                                       f"pup::pileup_band_kernel<{4 if W <= 64 else (8 if W <= 128 else 16)}, false>")),
             "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
             # the physically bounded fraction: COMPULSORY bytes (what any kernel must read once) / kernel time / peak.  (The
             # contract's A/P with the SURVEY 8(d) per-window bytes is algorithmic_over_peak: > 1 by construction for a kernel
