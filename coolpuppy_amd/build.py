@@ -15,10 +15,12 @@ _OBJ = os.path.join(_CSRC, "_obj")
 SRC = os.path.join(_CSRC, "pup_engine.hip")
 SRC_HOST = os.path.join(_CSRC, "pup_host.cpp")          # pinned memory + host array passes (no kernels)
 SRC_TU = os.path.join(_CSRC, "pup_staged_tu.hip")
+SRC_WTU = os.path.join(_CSRC, "pup_wide_tu.hip")
+WIDE_PARTS = range(7, 14)                                # cells per lane of the wide-window staged kernel (csrc/pup_wide.hpp)
 N_STAGED_PARTS = 8                                       # = pup::kStagedParts (csrc/pup_staged_launch.hpp)
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "pup_hip.h")
-_KERNEL_HEADERS = [os.path.join(_CSRC, h) for h in ("pup_kernels.hpp", "pup_staged.hpp", "pup_staged_launch.hpp")]
-DEPS = [SRC, SRC_HOST, SRC_TU, HEADER] + _KERNEL_HEADERS
+_KERNEL_HEADERS = [os.path.join(_CSRC, h) for h in ("pup_kernels.hpp", "pup_staged.hpp", "pup_staged_launch.hpp", "pup_wide.hpp")]
+DEPS = [SRC, SRC_HOST, SRC_TU, SRC_WTU, HEADER] + _KERNEL_HEADERS
 OUT = os.path.join(_HERE, "libpup_hip.so")
 _FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-result", "-pthread"]
 
@@ -51,6 +53,8 @@ def _units():
              (os.path.join(_OBJ, "pup_host.o"), ["-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I" + _rocm_include(), SRC_HOST], [SRC_HOST, HEADER])]        # host only: plain C++ with the HIP runtime API
     for k in range(N_STAGED_PARTS):
         units.append((os.path.join(_OBJ, f"pup_staged_tu{k}.o"), [f"-DPUP_TU_PART={k}", SRC_TU], [SRC_TU, HEADER] + _KERNEL_HEADERS))
+    for k in WIDE_PARTS:
+        units.append((os.path.join(_OBJ, f"pup_wide_tu{k}.o"), [f"-DPUP_TU_PART={k}", SRC_WTU], [SRC_WTU, HEADER] + _KERNEL_HEADERS))
     return units
 
 

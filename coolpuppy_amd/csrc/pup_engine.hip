@@ -9,6 +9,7 @@
 #include "pup_kernels.hpp"
 #include "pup_staged.hpp"
 #include "pup_staged_launch.hpp"
+#include "pup_wide.hpp"
 
 #include <hip/hip_runtime.h>
 #include <cstring>
@@ -97,6 +98,10 @@ struct pup_ctx {
     DevBuf<unsigned char> d_teams;
     DevBuf<long long> d_segend;
     DevBuf<unsigned char> d_sorttmp;
+    // K1w (pup_wide.hpp): partial records of the wide-window staged kernel
+    DevBuf<double> wrec_f64; DevBuf<unsigned> wrec_num, wrec_seg;
+    long long wide_min = 20000;              // calls of at least this many wide cis windows take the staged wide kernel
+    const char* last_kernel = "";            // which pile-up kernel the last pup_accumulate ran (diagnostics)
     // the staged kernel takes calls from this many windows on (measured against the per-window kernel on 21-bin windows, round 3:
     // plain 3.3e5 windows 0.49 / 0.44 ms, 6.6e5 0.53 / 0.70; observed over expected 1.1e5 0.45 / 0.50, 3.3e5 0.61 / 1.24)
     long long tiled_min = 400000, tiled_min_ooe = 150000;
@@ -115,7 +120,7 @@ struct pup_ctx {
     // launch geometry: ONE device blob (one H2D copy per new geometry), the typed views below point into it
     DevBuf<unsigned char> d_geom;
     struct GeomView {
-        const long long *chunk_begin = nullptr, *chunk_end = nullptr, *seg1 = nullptr, *seg2 = nullptr, *dn = nullptr;
+        const long long *chunk_begin = nullptr, *chunk_end = nullptr, *seg1 = nullptr, *seg2 = nullptr, *dn = nullptr, *run_ptr = nullptr;
         const int *chunk_stride = nullptr, *block_chunk = nullptr, *block_band = nullptr, *block_chunk_t = nullptr;
         const unsigned char* chunk_flip = nullptr;
     } gv;
@@ -341,6 +346,7 @@ void pup_destroy(pup_ctx* c) {
     c->d_keys.release(); c->d_keys2.release(); c->d_cnt32.release(); c->d_win.release(); c->d_win2.release();
     c->d_starts.release(); c->d_blocks.release();
     c->d_wgfirst.release(); c->d_segend.release(); c->htab_sent.clear(); c->d_sorttmp.release();
+    c->wrec_f64.release(); c->wrec_num.release(); c->wrec_seg.release();
     if (c->ev_key) (void)hipEventDestroy(c->ev_key);
     if (c->h_flags) (void)hipHostFree(const_cast<unsigned*>(c->h_flags));
     c->d_k32.release(); c->d_k32b.release();
@@ -664,9 +670,7 @@ int pup_reset(pup_ctx* c, int32_t n_tiles, int32_t pad) {
     if (!c) return PUP_EINVAL;
     if (n_tiles <= 0 || pad < 0) return fail(c, PUP_EINVAL, "pup_reset: n_tiles=%d pad=%d", n_tiles, pad);
     const int W = 2 * pad + 1;
-    if (W > 255 && pup::k1_lds_bytes(W) > (size_t)c->max_lds)
-        return fail(c, PUP_ENOTSUP, "pup_reset: window %dx%d is wider than the banded kernel serves (255) and needs "
-                    "%zu B of LDS per wave, device offers %d", W, W, pup::k1_lds_bytes(W), c->max_lds);
+    if ((long long)W * W > 0x3fffffffLL) return fail(c, PUP_ENOTSUP, "pup_reset: window %dx%d does not fit 32-bit cell numbers", W, W);
     int rc = bind(c); if (rc) return rc;
     const size_t W2 = (size_t)W * W;
     const size_t nf = (size_t)n_tiles * (W2 + 2 * (size_t)W), ni = (size_t)n_tiles * (W2 + 1);
@@ -940,7 +944,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
         hipLaunchKernelGGL((pup::staged_table_kernel<unsigned>), dim3(gt), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
                            (const unsigned*)(c->d_cnt32.p + 3), (long long)n, (const unsigned*)c->d_k32b.p,
                            (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
-                           c->n_chrom, W, geo.RSR, geo.RSC, sh_br, sh_er, sh_seg, seg_shift, slot_bits, n_eregs, er_in_key ? 1 : 0, d_eregs,
+                           c->n_chrom, W, W, geo.RSR, geo.RSC, 1, pup::kBlockCost, sh_br, sh_er, sh_seg, seg_shift, slot_bits, n_eregs, er_in_key ? 1 : 0, d_eregs,
                            (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G);
     } else {
         se = rocprim::radix_sort_pairs<Radix10>(c->d_sorttmp.p, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_win.p, c->d_win2.p,
@@ -953,7 +957,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
         hipLaunchKernelGGL((pup::staged_table_kernel<unsigned long long>), dim3(gt), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
                            (const unsigned*)(c->d_cnt32.p + 3), (long long)n, (const unsigned long long*)c->d_keys2.p,
                            (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
-                           c->n_chrom, W, geo.RSR, geo.RSC, sh_br, sh_er, sh_seg, seg_shift, slot_bits, n_eregs, er_in_key ? 1 : 0, d_eregs,
+                           c->n_chrom, W, W, geo.RSR, geo.RSC, 1, pup::kBlockCost, sh_br, sh_er, sh_seg, seg_shift, slot_bits, n_eregs, er_in_key ? 1 : 0, d_eregs,
                            (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G);
     }
     // leave the block count where the NEXT call with this signature finds it without waiting
@@ -1027,6 +1031,192 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
                        (const unsigned char*)d_recvalid, 2 * G, (int)Lf, Li, c->acc_f64.p, c->acc_i64.p);
     HIPCHK(c, hipGetLastError());
     c->last_staged = true;
+    return PUP_OK;
+}
+
+
+// ---- the staged path for WIDE windows (K1w, pup_wide.hpp): sub-window items, block-order prepass, persistent kernel ----
+// Eligible calls: W >= 32 (no upper limit), plain / observed-over-expected, cis with a diagonal mask (ignore_diags >= 0), the
+// dense band table present and holding every window, every window inside one chromosome.  Coverage vectors, pixel
+// statistics, inter-chromosomal and expected-only passes stay with the per-window kernels (any width, see accumulate_impl).
+// returns PUP_OK when the call was piled up here, 1 when the per-window kernels must take it, a negative code on error.
+static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const int64_t* tile_ptr, const int64_t* flip_from,
+                    int32_t ignore_diags, uint32_t mode, bool rescale, hipEvent_t* ev) {
+    const int W = c->W, T = c->T;
+    const bool force = (c->variant & 8) != 0, forbid = (c->variant & 16) != 0;
+    const bool ooe = (mode & PUP_MODE_OOE) != 0;
+    if (forbid || rescale || (mode & (PUP_MODE_EXPECTED | PUP_MODE_TRANSPOSE | PUP_MODE_COV)) || (c->variant & (1 | 2 | 256)) || c->count_pixels ||
+        !c->have_idx || c->band_w <= 0 || ignore_diags < 0 || W < 32 || !(force || n >= c->wide_min) || 2 * T > pup::kMaxSegCount ||
+        !c->bin_chrom.p || !c->h_flags || !c->ev_key || (int)c->h_chroms.size() != c->n_chrom || (ooe && c->have_exp_pair))
+        return 1;
+    const pup::WideGeom geo = pup::wide_geometry(W);
+    const int NG = geo.NGr * geo.NGc;
+    const long long n_items = (long long)n * NG;
+    if (n_items >= 0x7fffffffLL) return 1;
+    const int RS = 128;
+    const int BR = RS - geo.SH + 1, BC = RS - geo.SW + 1;
+    const int G = c->n_cu;                               // persistent workgroups: one per CU (the region takes the LDS)
+    auto nbits = [](unsigned long long v) { int b = 1; while ((v >> b) != 0) ++b; return b; };
+
+    // observed over expected: the by-diagonal vector of a block's windows is that of the region its origin lies in — valid
+    // when no chromosome is split between expected regions (the usual per-chromosome / per-arm-free table); else K1b
+    const int n_eregs = (ooe && c->n_exp_regions > 0 && !c->have_exp_pair) ? c->n_exp_regions : 0;
+    if (n_eregs > 0) {
+        if ((int)c->h_exp_bounds.size() != n_eregs) return 1;
+        for (const auto& ch : c->h_chroms) {
+            bool inside = false, touched = false;
+            for (const auto& rg : c->h_exp_bounds) {
+                if (rg.first <= ch.start && rg.second >= ch.end) inside = true;
+                else if (rg.first < ch.end && rg.second > ch.start) touched = true;
+            }
+            if (touched) return 1;
+            (void)inside;
+        }
+    }
+    long long max_len = 1, n_brows = 0;
+    std::vector<int> brow_base((size_t)c->n_chrom);
+    for (int k = 0; k < c->n_chrom; ++k) {
+        const long long len = c->h_chroms[(size_t)k].end - c->h_chroms[(size_t)k].start;
+        max_len = std::max<long long>(max_len, len);
+        brow_base[(size_t)k] = (int)n_brows;
+        n_brows += (len + BR - 1) / BR;
+    }
+    if (brow_base != c->brow_sent) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->d_brow.cap < (size_t)c->n_chrom) c->brow_sent.clear();
+        HIPCHK(c, c->d_brow.reserve((size_t)c->n_chrom));
+        HIPCHK(c, hipMemcpy(c->d_brow.p, brow_base.data(), brow_base.size() * sizeof(int), hipMemcpyHostToDevice));
+        c->brow_sent = brow_base;
+    }
+    const int seg_shift = flip_from ? 0 : 1;
+    std::vector<long long> htab;
+    for (int t = 0; t < T; ++t) { htab.push_back(flip_from ? flip_from[t] : tile_ptr[t + 1]); htab.push_back(tile_ptr[t + 1]); }
+    const int nseg2t = (int)htab.size();
+    const int bits_bc = nbits((unsigned long long)(max_len / BC + 1)), bits_br = nbits((unsigned long long)n_brows + 1);
+    const int sh_br = bits_bc, sh_seg = sh_br + bits_br;
+    const long long nseg_key = ((long long)(2 * T) >> seg_shift) * NG;
+    const int end_bit = sh_seg + (nseg_key > 1 ? nbits((unsigned long long)(nseg_key - 1)) : 0);
+    if (end_bit > 64) return 1;
+    const bool k32 = end_bit <= 32;
+    const long long nseg_full = 2LL * T * NG;
+    const long long nrec = nseg_full + G;
+    if ((unsigned long long)nrec * pup::kWideRec * 12ull > (8ull << 30)) return 1;      // (by-window sized tile counts: per-window kernels)
+
+    const int n_spans = (int)((n_items + pup::kSpan - 1) / pup::kSpan);
+    const size_t ncnt = 4;
+    HIPCHK(c, c->d_win.reserve((size_t)n_items + 8)); HIPCHK(c, c->d_win2.reserve((size_t)n_items + 8));
+    if (c->d_segend.cap < htab.size()) c->htab_sent.clear();
+    HIPCHK(c, c->d_segend.reserve(htab.size()));
+    HIPCHK(c, c->d_cnt32.reserve(ncnt + (size_t)n_spans));
+    HIPCHK(c, c->d_starts.reserve((size_t)n_items + 1));
+    HIPCHK(c, c->d_blocks.reserve((size_t)std::min<long long>(n_items, (n_brows + 1) * (max_len / BC + 2) * std::max<long long>(nseg_key, 1))));
+    HIPCHK(c, c->d_wgfirst.reserve((size_t)G + 1));
+    HIPCHK(c, c->wrec_f64.reserve((size_t)nrec * pup::kWideRec)); HIPCHK(c, c->wrec_num.reserve((size_t)nrec * pup::kWideRec));
+    HIPCHK(c, c->wrec_seg.reserve((size_t)nrec));
+    if (k32) { HIPCHK(c, c->d_k32.reserve((size_t)n_items)); HIPCHK(c, c->d_k32b.reserve((size_t)n_items)); }
+    else     { HIPCHK(c, c->d_keys.reserve((size_t)n_items)); HIPCHK(c, c->d_keys2.reserve((size_t)n_items)); }
+    if (htab != c->htab_sent) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy(c->d_segend.p, htab.data(), htab.size() * 8, hipMemcpyHostToDevice));
+        c->htab_sent = htab;
+    }
+    size_t tmp_bytes = 0;
+    hipError_t se = k32 ? rocprim::radix_sort_pairs<Radix10>(nullptr, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_win.p, c->d_win2.p, (size_t)n_items, 0, end_bit, c->stream)
+                        : rocprim::radix_sort_pairs<Radix10>(nullptr, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_win.p, c->d_win2.p, (size_t)n_items, 0, end_bit, c->stream);
+    if (se == hipSuccess) se = c->d_sorttmp.reserve(tmp_bytes + 16);
+    if (se != hipSuccess) return fail(c, PUP_EHIP, "pup_accumulate: block sort: %s", hipGetErrorString(se));
+
+    // ---- prepass, all on the stream -------------------------------------------------------------------------------------
+    if (ev) HIPCHK(c, hipEventRecord(ev[0], c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_cnt32.p, 0, (ncnt + (size_t)n_spans) * sizeof(unsigned), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->wrec_seg.p, 0, (size_t)nrec * sizeof(unsigned), c->stream));
+    const unsigned ticket = ++c->ticket;
+    const bool ooe_vec = ooe && !c->have_exp_pair && (c->nexp > 1 || c->n_exp_regions > 0);
+    bool ooe_clean = false;
+    int far_gap = 0x7fffffff;
+    if (ooe && !c->have_exp_pair && !c->h_exp.empty()) {
+        if (c->nexp == 1) ooe_clean = c->h_exp[0] == c->h_exp[0] && c->h_exp[0] != 0.0;
+        else if (ooe_vec) {
+            const long long far = c->exp_far(ignore_diags);
+            ooe_clean = far > (long long)ignore_diags + W;
+            if (ooe_clean) far_gap = (int)std::min<long long>(far, 0x7fffffff);
+        }
+    }
+    const unsigned gk4 = (unsigned)((n_items + 1023) / 1024);
+#define PUP_WKEY_ARGS dr0, dc0, (long long)n, n_items, (const long long*)c->d_segend.p, nseg2t, (const pup::IdxChrom*)c->idx_chrom.p, c->n_chrom, \
+        (const unsigned short*)c->bin_chrom.p, (long long)c->nbins, (const int*)c->d_brow.p, W, NG, geo.NGc, geo.SH, geo.SW, BR, BC, sh_br, sh_seg, \
+        seg_shift, ignore_diags + W - 1, far_gap, c->band_w
+    if (k32) hipLaunchKernelGGL((pup::wide_key_kernel<unsigned>), dim3(gk4), dim3(256), 0, c->stream, PUP_WKEY_ARGS, c->d_k32.p, c->d_win.p, c->d_cnt32.p);
+    else hipLaunchKernelGGL((pup::wide_key_kernel<unsigned long long>), dim3(gk4), dim3(256), 0, c->stream, PUP_WKEY_ARGS, c->d_keys.p, c->d_win.p, c->d_cnt32.p);
+#undef PUP_WKEY_ARGS
+    hipLaunchKernelGGL(pup::staged_publish_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned*)c->d_cnt32.p, 3,
+                       (volatile unsigned*)c->d_flags, ticket);
+    HIPCHK(c, hipEventRecord(c->ev_key, c->stream));
+    unsigned* d_spans = c->d_cnt32.p + ncnt;
+    const unsigned gt = (unsigned)std::min<long long>(4096, (n_items + 255) / 256);
+    const pup::ExpRegion* d_eregs = n_eregs > 0 ? c->exp_regions.p : nullptr;
+    if (k32) {
+        se = rocprim::radix_sort_pairs<Radix10>(c->d_sorttmp.p, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_win.p, c->d_win2.p,
+                                                (size_t)n_items, 0, end_bit, c->stream);
+        if (se != hipSuccess) return fail(c, PUP_EHIP, "pup_accumulate: block sort: %s", hipGetErrorString(se));
+        hipLaunchKernelGGL((pup::count_heads_kernel<unsigned>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
+                           (const unsigned*)c->d_k32b.p, n_items, 0, d_spans);
+        hipLaunchKernelGGL((pup::block_starts_kernel<unsigned>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
+                           (const unsigned*)c->d_k32b.p, n_items, 0, (const unsigned*)d_spans, c->d_starts.p, c->d_cnt32.p + 3);
+        hipLaunchKernelGGL((pup::staged_table_kernel<unsigned>), dim3(gt), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
+                           (const unsigned*)(c->d_cnt32.p + 3), n_items, (const unsigned*)c->d_k32b.p,
+                           (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
+                           c->n_chrom, geo.SH, geo.SW, RS, RS, NG, pup::kWideBlockCost, sh_br, sh_seg, sh_seg, seg_shift, 0, n_eregs, 0, d_eregs,
+                           (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G);
+    } else {
+        se = rocprim::radix_sort_pairs<Radix10>(c->d_sorttmp.p, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_win.p, c->d_win2.p,
+                                                (size_t)n_items, 0, end_bit, c->stream);
+        if (se != hipSuccess) return fail(c, PUP_EHIP, "pup_accumulate: block sort: %s", hipGetErrorString(se));
+        hipLaunchKernelGGL((pup::count_heads_kernel<unsigned long long>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
+                           (const unsigned long long*)c->d_keys2.p, n_items, 0, d_spans);
+        hipLaunchKernelGGL((pup::block_starts_kernel<unsigned long long>), dim3((unsigned)n_spans), dim3(256), 0, c->stream,
+                           (const unsigned long long*)c->d_keys2.p, n_items, 0, (const unsigned*)d_spans, c->d_starts.p, c->d_cnt32.p + 3);
+        hipLaunchKernelGGL((pup::staged_table_kernel<unsigned long long>), dim3(gt), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
+                           (const unsigned*)(c->d_cnt32.p + 3), n_items, (const unsigned long long*)c->d_keys2.p,
+                           (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
+                           c->n_chrom, geo.SH, geo.SW, RS, RS, NG, pup::kWideBlockCost, sh_br, sh_seg, sh_seg, seg_shift, 0, n_eregs, 0, d_eregs,
+                           (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G);
+    }
+    hipLaunchKernelGGL(pup::staged_publish_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned*)(c->d_cnt32.p + 3), 1,
+                       (volatile unsigned*)(c->d_flags + 4), ticket);
+    HIPCHK(c, hipGetLastError());
+
+    // ---- the key kernel's verdict ---------------------------------------------------------------------------------------
+    HIPCHK(c, hipEventSynchronize(c->ev_key));
+    if (c->h_flags[3] != ticket) return fail(c, PUP_EHIP, "pup_accumulate: the key kernel's verdict did not arrive");
+    c->hint_ticket = ticket;
+    if (c->h_flags[0] != 0 || c->h_flags[2] != 0) return 1;      // a window outside one chromosome / outside the band: per-window kernels
+    const bool fact = (!ooe || ooe_clean) && c->h_flags[1] == 0 && !(c->variant & 4);
+
+    pup::K1Args a{};
+    fill_k1_args(c, a, ignore_diags, mode);
+    pup::WideArgs wa{};
+    wa.blocks = c->d_blocks.p; wa.win = c->d_win2.p; wa.wg_first = c->d_wgfirst.p;
+    wa.WF = W; wa.NGc = geo.NGc; wa.NG = NG; wa.SH = geo.SH; wa.SW = geo.SW; wa.NPC = geo.NPC;
+    wa.rec_seg = c->wrec_seg.p; wa.rec_f64 = c->wrec_f64.p; wa.rec_num = c->wrec_num.p;
+    wa.timing = nullptr;
+    if (c->debug_phases & 4) {
+        HIPCHK(c, c->d_timing.reserve((size_t)G * 16 * 8));
+        HIPCHK(c, hipMemsetAsync(c->d_timing.p, 0, (size_t)G * 16 * 8 * sizeof(long long), c->stream));
+        wa.timing = c->d_timing.p; c->timing_G = G;
+    }
+    if (ev) HIPCHK(c, hipEventRecord(ev[1], c->stream));
+    if (!pup::launch_wide(geo.CH, a, wa, G, ooe, fact, c->stream))
+        return fail(c, PUP_ENOTSUP, "pup_accumulate: wide staged kernel not built for %d cells per lane", geo.CH);
+    HIPCHK(c, hipGetLastError());
+    if (ev) HIPCHK(c, hipEventRecord(ev[2], c->stream));
+    const size_t W2 = (size_t)W * W, Lf = W2 + 2 * (size_t)W;
+    hipLaunchKernelGGL(pup::reduce_wide_kernel, dim3((unsigned)((W2 + 63) / 64), (unsigned)T), dim3(64, pup::kRedParts), 0, c->stream,
+                       (const double*)c->wrec_f64.p, (const unsigned*)c->wrec_num.p, (const unsigned*)c->wrec_seg.p, G, W, NG, geo.NGc,
+                       geo.SH, geo.SW, flip_from ? 2 : 1, (int)Lf, c->acc_f64.p, c->acc_i64.p);
+    HIPCHK(c, hipGetLastError());
+    c->last_staged = true;
+    c->last_kernel = fact ? "wide_fact" : "wide";
     return PUP_OK;
 }
 
@@ -1133,6 +1323,12 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         const int src = staged_run(c, dr0, dc0, n, tile_ptr, flip_from, ignore_diags, mode, rescale, c->profiling ? evs : nullptr);
         if (src < 0) return src;
         staged = src == PUP_OK;
+        if (staged) c->last_kernel = "staged";
+        else {
+            const int wrc = wide_run(c, dr0, dc0, n, tile_ptr, flip_from, ignore_diags, mode, rescale, c->profiling ? evs : nullptr);
+            if (wrc < 0) return wrc;
+            staged = wrc == PUP_OK;
+        }
     }
     const int *kr0 = dr0, *kc0 = dc0;
     if (!staged) {
@@ -1179,8 +1375,13 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     // (OOE needs ONE expected value per window there: the trans scalar or the region-pair table)
     const bool sparse_kernel = sparse_geom;
     const bool band_kernel = !lds_kernel && !sparse_kernel && c->W > 31;
-    const int nbands = band_kernel ? (c->W + (pup::kWave / band_nch(c->W)) - 1) / (pup::kWave / band_nch(c->W)) : 1;
+    // banded kernel: a wave owns 64 / NCH window rows x 16 NCH columns; windows wider than 256 bins take several column
+    // panels (a "band" entry of the launch table = row band | column panel << 16)
+    const int nrowbands = band_kernel ? (c->W + (pup::kWave / band_nch(c->W)) - 1) / (pup::kWave / band_nch(c->W)) : 1;
+    const int ncpanels = band_kernel ? (c->W + 16 * band_nch(c->W) - 1) / (16 * band_nch(c->W)) : 1;
+    const int nbands = nrowbands * ncpanels;
     const int U = T;
+    std::vector<long long> run_ptr;                                  // chunk ranges of the (tile, flip) runs, [2T + 1]
     std::vector<long long> cb, ce, unit_chunk_ptr((size_t)U + 1, 0), dn((size_t)T);
     std::vector<unsigned char> cf;
     std::vector<int> cs;
@@ -1204,10 +1405,12 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     for (int u = 0; u < U; ++u) {
         for (int f = 0; f < 2; ++f) {
             const long long b = tile_ptr[u], e = tile_ptr[u + 1], m = flip_from ? flip_from[u] : e;
+            run_ptr.push_back((long long)cb.size());
             if (f == 0) add_run(b, m, 0); else add_run(m, e, 1);
         }
         unit_chunk_ptr[(size_t)u + 1] = (long long)cb.size();
     }
+    run_ptr.push_back((long long)cb.size());
     const long long nchunks = (long long)cb.size();
     // records: chunk ck writes record ck: tile t's records are contiguous
     const long long nrec = nchunks;
@@ -1252,7 +1455,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
             for (size_t i = 0; i < lists[(size_t)x].size(); ++i) {
                 const int e = lists[(size_t)x][i];
                 bc[i * (size_t)n_xcd + (size_t)x] = e / nbands;
-                bb[i * (size_t)n_xcd + (size_t)x] = e % nbands;
+                bb[i * (size_t)n_xcd + (size_t)x] = ((e % nbands) % nrowbands) | (((e % nbands) / nrowbands) << 16);
             }
     };
     std::vector<int> block_chunk, block_band;
@@ -1297,6 +1500,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         const size_t o_cs = put(cs.data(), (size_t)nchunks * 4);
         const size_t o_bc = put(block_chunk.data(), (size_t)nblocks * 4), o_bb = put(block_band.data(), (size_t)nblocks * 4);
         const size_t o_cf = put(cf.data(), (size_t)nchunks);
+        const size_t o_rp = put(run_ptr.data(), run_ptr.size() * 8);
         HIPCHK(c, c->d_geom.reserve(blob.size() + 8));
         HIPCHK(c, hipMemcpy(c->d_geom.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
         const unsigned char* g = c->d_geom.p;
@@ -1309,6 +1513,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         c->gv.block_chunk = reinterpret_cast<const int*>(g + o_bc);
         c->gv.block_band = reinterpret_cast<const int*>(g + o_bb);
         c->gv.chunk_flip = g + o_cf;
+        c->gv.run_ptr = reinterpret_cast<const long long*>(g + o_rp);
     }
     c->g_nchunks = nchunks; c->g_nblocks = nblocks; c->g_two_level = two_level; c->g_nslices = nslices;
     c->geom_key = gkey;
@@ -1329,12 +1534,22 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     // variant&2: LDS-tile kernel (needs the whole tile in LDS)
     const bool lds_kernel2 = m_exp || (c->variant & 2);
     bool launched = false;
+    bool diag_pass = false;
+    if (m_exp && !(c->variant & 2) && !rescale) {
+        // expected-as-control: O(W) per snippet on the 2W - 1 diagonals of the Toeplitz window, any width (pup_wide.hpp)
+        const int ND = 2 * W - 1;
+        for (int d0 = 0; d0 < ND; d0 += pup::kDiagPer * pup::kWave)
+            hipLaunchKernelGGL(pup::expected_diag_kernel, dim3((unsigned)nblocks), dim3(pup::kWave), 0, c->stream, a, d0,
+                               c->part_f64.p, c->part_num.p, ND);
+        launched = true; diag_pass = true;
+        c->last_kernel = "expected_diag";
+    }
     if (rescale) {
         const size_t rs_lds = (size_t)W * W * 12 + 16 * (size_t)W;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pup::pileup_rescale_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_lds);
         hipLaunchKernelGGL(pup::pileup_rescale_kernel, dim3((unsigned)nblocks), dim3(rs_threads), rs_lds, c->stream, a,
                            (const int*)c->d_h.p, (const int*)c->d_w.p, (double*)nullptr, (double*)nullptr, 0LL);
-        launched = true;
+        launched = true; c->last_kernel = "rescale";
     }
     const bool sparse_launch = !lds_kernel2 && !rescale && ignore_diags < 0 && W <= 63 && !(c->variant & 32) &&
                                pup::k1s_lds_bytes(W) <= (size_t)c->max_lds &&
@@ -1362,16 +1577,16 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pup::pileup_sparse_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl);
             hipLaunchKernelGGL((pup::pileup_sparse_kernel<false>), dim3((unsigned)nblocks), dim3(pup::kWave), sl, c->stream, a);
         }
-        launched = true;
+        launched = true; c->last_kernel = "sparse";
     }
-    if (!launched && !lds_kernel2 && W <= 31) launched = launch_regtile(W, a, (int)nblocks, c->stream);
-    if (!launched && !lds_kernel2 && W > 31 && W <= 255) {
+    if (!launched && !lds_kernel2 && W <= 31) { launched = launch_regtile(W, a, (int)nblocks, c->stream); if (launched) c->last_kernel = "regtile"; }
+    if (!launched && !lds_kernel2 && W > 31) {
         switch (band_nch(W)) {
             case 4:  launch_k1b<4>(a, (int)nblocks, c->stream); break;
             case 8:  launch_k1b<8>(a, (int)nblocks, c->stream); break;
             default: launch_k1b<16>(a, (int)nblocks, c->stream); break;
         }
-        launched = true;
+        launched = true; c->last_kernel = "band";
     }
     if (!launched) {
         if (pup::k1_lds_bytes(W) > (size_t)c->max_lds)
@@ -1382,10 +1597,22 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
             case 51: launch_k1<51>(a, (int)nblocks, lds, c->stream); break;
             default: launch_k1<0>(a, (int)nblocks, lds, c->stream); break;
         }
+        c->last_kernel = "lds_tile";
     }
     HIPCHK(c, hipGetLastError());
     if (c->profiling) HIPCHK(c, hipEventRecord(e1, c->stream));
 
+    if (diag_pass) {
+        // records of 2W - 1 diagonals: summed per (tile, flip) run in fixed order, then spread over the W x W accumulators
+        const int ND = 2 * W - 1;
+        HIPCHK(c, c->slice_f64.reserve((size_t)2 * T * ND)); HIPCHK(c, c->slice_num.reserve((size_t)2 * T * ND));
+        hipLaunchKernelGGL((pup::reduce_partials_kernel<unsigned, false>), dim3((unsigned)((2 * ND + 63) / 64), (unsigned)(2 * T)),
+                           dim3(64, pup::kRedParts), 0, c->stream, c->part_f64.p, c->part_num.p, c->gv.run_ptr, ND, ND,
+                           c->slice_f64.p, c->slice_num.p);
+        hipLaunchKernelGGL(pup::expand_diag_kernel, dim3((unsigned)((W2 + 255) / 256), (unsigned)T), dim3(256), 0, c->stream,
+                           (const double*)c->slice_f64.p, (const long long*)c->slice_num.p, W, ND, (mode & PUP_MODE_TRANSPOSE) ? 1 : 0,
+                           (int)Lf, c->acc_f64.p, c->acc_i64.p);
+    } else {
     // ---- K2: partials -> (slices ->) accumulators ---------------------------------------------------
     const int Li = (int)W2;
     const dim3 rb(64, pup::kRedParts), rg1((unsigned)((Lf + Li + 63) / 64), (unsigned)std::max<long long>(nslices, 1));
@@ -1399,6 +1626,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         hipLaunchKernelGGL((pup::reduce_partials_kernel<unsigned, true>), rg2, rb, 0, c->stream,
                            c->part_f64.p, c->part_num.p, c->gv.seg2, (int)Lf, Li, c->acc_f64.p, c->acc_i64.p);
     }
+    }   // !diag_pass
     hipLaunchKernelGGL(pup::add_counts_kernel, dim3((unsigned)((c->T + 255) / 256)), dim3(256), 0, c->stream,
                        c->acc_i64.p + (size_t)c->T * W2, c->gv.dn, c->T);
     HIPCHK(c, hipGetLastError());
@@ -1740,6 +1968,8 @@ int pup_debug_timing(pup_ctx* c, int64_t* out, int64_t cap) {
     HIPCHK(c, hipMemcpy(out, c->d_timing.p, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost));
     return (int)c->timing_G;
 }
+
+const char* pup_last_kernel(const pup_ctx* c) { return c ? c->last_kernel : ""; }
 
 int pup_event_elapsed_ms(pup_ctx* c, int a, int b, float* ms) {
     if (!c || !ms) return PUP_EINVAL;

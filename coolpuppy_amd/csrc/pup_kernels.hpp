@@ -1023,11 +1023,12 @@ __global__ __launch_bounds__(kWave, 3) void pileup_band_kernel(K1Args a) {
     const int lane = threadIdx.x;
     const int ck = a.block_chunk[blockIdx.x];
     if (ck < 0) return;
-    const int band = a.block_band[blockIdx.x];
+    const int band = a.block_band[blockIdx.x] & 0xffff;
+    const int cpanel = a.block_band[blockIdx.x] >> 16;   // windows wider than 16 NCH bins: column panel of this wave
     const int p_in = lane / NCH;
     const int k    = lane - p_in * NCH;
     const int pg_raw = band * H + p_in;              // window row of this lane
-    const int q0 = k * CH;
+    const int q0 = (cpanel * NCH + k) * CH;
     const bool lane_ok = (pg_raw < W) && (q0 < W);
     const int pg = pg_raw < W ? pg_raw : W - 1;
     const int chw = lane_ok ? ((W - q0) < CH ? (W - q0) : CH) : 0;
@@ -1062,7 +1063,7 @@ __global__ __launch_bounds__(kWave, 3) void pileup_band_kernel(K1Args a) {
         g.r0 = __builtin_amdgcn_readfirstlane(a.r0[s]);
         g.c0 = __builtin_amdgcn_readfirstlane(a.c0[s]);
         if (g.r0 < 0 || g.c0 < 0 || (long long)g.r0 + W > a.nbins || (long long)g.c0 + W > a.nbins) {
-            if (lane == 0 && band == 0) atomicExch(a.err, 1);
+            if (lane == 0 && band == 0 && cpanel == 0) atomicExch(a.err, 1);
             return;
         }
         g.valid = true;
@@ -1143,7 +1144,7 @@ __global__ __launch_bounds__(kWave, 3) void pileup_band_kernel(K1Args a) {
                 ev[i] = (es.is_scalar || ad < es.len) ? e : qnan;
             }
         }
-        if (m_cov && lane_ok && k == 0) {
+        if (m_cov && lane_ok && k == 0 && cpanel == 0) {
             const double cr = a.cov[g.r0 + pg], cv = a.cov[g.c0 + pg];
             const double vs = m_tr ? cv : cr, ve = m_tr ? cr : cv;
             if (vs == vs) cov_s += vs;
@@ -1185,7 +1186,7 @@ __global__ __launch_bounds__(kWave, 3) void pileup_band_kernel(K1Args a) {
             on[cell] = num[i];
         }
     }
-    if (lane_ok && k == 0) { of[W2 + pg] = cov_s; of[W2 + W + pg] = cov_e; }
+    if (lane_ok && k == 0 && cpanel == 0) { of[W2 + pg] = cov_s; of[W2 + W + pg] = cov_e; }
     for (int off = 32; off > 0; off >>= 1) {
         npix   += __shfl_down(npix, off);
         nprobe += __shfl_down(nprobe, off);

@@ -1071,13 +1071,15 @@ template <typename KeyT>
 __global__ __launch_bounds__(256) void staged_table_kernel(const unsigned* __restrict__ starts, const unsigned* __restrict__ n_runs,
                                                            long long n, const KeyT* __restrict__ sorted_keys,
                                                            const unsigned short* __restrict__ win, const int* __restrict__ brow_base,
-                                                           const IdxChrom* __restrict__ chroms, int n_chrom, int W, int RSR, int RSC,
+                                                           const IdxChrom* __restrict__ chroms, int n_chrom, int WR, int WC /* (sub-)window rows / columns */,
+                                                           int RSR, int RSC, int NG /* sub-window groups in the key's segment field (K1w), else 1 */,
+                                                           int block_cost /* staging one region, in windows' worth of time */,
                                                            int sh_br, int sh_er, int sh_seg, int seg_shift, int slot_bits, int n_eregs,
                                                            int er_in_key, const ExpRegion* __restrict__ eregs,
                                                            const unsigned long long* __restrict__ badbits,
                                                            StagedBlock* __restrict__ blocks, int* __restrict__ wg_first, int G) {
     const long long nr = (long long)n_runs[0];
-    const int BR = RSR - W + 1, BC = RSC - W + 1;
+    const int BR = RSR - WR + 1, BC = RSC - WC + 1;
     for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < nr; b += (long long)gridDim.x * blockDim.x) {
         const unsigned s = starts[b];
         const long long e = (b + 1 < nr) ? (long long)starts[b + 1] : n;
@@ -1116,7 +1118,7 @@ __global__ __launch_bounds__(256) void staged_table_kernel(const unsigned* __res
                                      : find_exp_region(eregs, n_eregs, be.R);
             be.ereg = (er >= 0 && er < n_eregs) ? er : -1;
         }
-        be.seg = (int)(key >> sh_seg) << seg_shift;
+        be.seg = (int)((key >> sh_seg) / (unsigned long long)NG) << seg_shift;
         be.ch_end = ch.end; be.nblk = ch.nblk;
         auto bits64 = [&](int bin) {                        // masked-bin bits of bins [bin, bin + 64)
             const unsigned long long* w = badbits + (bin >> 6);
@@ -1151,16 +1153,16 @@ __global__ __launch_bounds__(256) void staged_table_kernel(const unsigned* __res
                 const int dr = (int)(win[m] & ((1u << kWinShift) - 1u));
                 mn = dr < mn ? dr : mn; mx = dr > mx ? dr : mx;
             }
-            be.row_lo = mn; be.row_hi = mx + W < RSR ? mx + W : RSR;
+            be.row_lo = mn; be.row_hi = mx + WR < RSR ? mx + WR : RSR;
         }
-        be.pad[0] = 0; be.pad[1] = 0;
+        be.pad[0] = (int)((key >> sh_seg) % (unsigned long long)NG); be.pad[1] = 0;      // K1w: the sub-window group of the block's items
         blocks[b] = be;
         // ranges of the persistent workgroups: equal shares of the call's COST, a block costing its windows plus kBlockCost
         // window-equivalents for its staging (a range of many sparse blocks would otherwise take far longer than one of a
         // few dense ones: staging a region is an HBM round trip plus ~2000 clocks of LDS stores, a window ~15 clocks)
-        const unsigned long long total = (unsigned long long)n + (unsigned long long)kBlockCost * (unsigned long long)nr;
-        const int g_cur = (int)((((unsigned long long)s + (unsigned long long)kBlockCost * (unsigned long long)b) * (unsigned long long)G) / total);
-        const int g_prev = b == 0 ? -1 : (int)((((unsigned long long)starts[b - 1] + (unsigned long long)kBlockCost * (unsigned long long)(b - 1)) *
+        const unsigned long long total = (unsigned long long)n + (unsigned long long)block_cost * (unsigned long long)nr;
+        const int g_cur = (int)((((unsigned long long)s + (unsigned long long)block_cost * (unsigned long long)b) * (unsigned long long)G) / total);
+        const int g_prev = b == 0 ? -1 : (int)((((unsigned long long)starts[b - 1] + (unsigned long long)block_cost * (unsigned long long)(b - 1)) *
                                                 (unsigned long long)G) / total);
         for (int g = g_prev + 1; g <= g_cur; ++g) wg_first[g] = (int)b;
         if (b + 1 == nr) for (int g = g_cur + 1; g <= G; ++g) wg_first[g] = (int)nr;

@@ -1,0 +1,696 @@
+// pup_wide.hpp — K1w, the workgroup-staged pile-up kernel for WIDE cis windows (W >= 32, no upper limit).  gfx950 only.
+//
+// K1q (pup_staged.hpp) stops at 31-bin windows: its lanes own whole window rows side by side (64 / W rows per wave) and a
+// 128 x 128 region holds too few corners of wider windows.  The per-window kernel that served wider windows (K1b) fetches
+// every window on its own: 8e6 windows of 51 x 51 pulled 66 GB from HBM against 1.2 GB of compulsory bytes (round 3
+// counters).  K1w applies the staging idea to windows of ANY width by cutting a W x W window into SUB-WINDOWS of at most
+// 64 rows x 52 columns (a grid of NGr x NGc groups): (window, group) items are block-sorted on the device like K1q's
+// windows — the key carries the group, the corner is the sub-window's — and a persistent 16-wave workgroup stages the
+// 128 x 128 region under a block of sub-window corners ONCE, as final cell values (coolpuppy/coolpup.py:1104-1157 makes
+// a cell's value a function of its absolute (row, col) only), from the dense band of counts (pup_build_index).  Inside the
+// workgroup a LANE owns a sub-window ROW and a WAVE one of NPC column PANELS of CH <= 13 cells (wave w: panel w % NPC);
+// the NW / NPC waves of a panel share the block's windows.  Per window and wave: one readlane, one address add, CH
+// ds_read_b64 (row stride 129 doubles: the 64 rows of a wave hit 64 different bank pairs) and CH f64 adds.
+// What the reference does per snippet (dense slice of any size, coolpuppy/coolpup.py:1115-1121; masks :1122-1149; division by
+// expected :1154-1156; nansum / isfinite accumulation coolpuppy/lib/puputils.py:12-41) is the same arithmetic as in K1q:
+//   FACT   every window of the call clears the masked diagonals (and the expected is usable wherever a window reaches):
+//          validity of cell (p, q) = !rowbad[p] & !colbad[q], so num[p][q] = N - R[p] - C[q] + RC[p][q] from per-batch
+//          mask words (integer LDS atomics, exact) and the window loop touches values only;
+//   !FACT  one validity bit per staged cell rides along (vbits), read with the window's row.
+// Partial records are 64 x 64 sub-window tiles: record id = (tile, flip, group) number + workgroup number — a workgroup's
+// block range is contiguous and the blocks are sorted by (tile, flip, group), so that sum is unique — and
+// reduce_wide_kernel sums the valid ones per accumulator cell in fixed order (bit-reproducible).
+// Same integers as every other kernel of the engine; sums differ by the order of the f64 additions only.
+#pragma once
+#include "pup_staged.hpp"
+
+namespace pup {
+
+constexpr int kWideRec = 64 * 64;                     // cells of a partial record: sub-window row p, column q at p * 64 + q
+constexpr int kWideBlockCost = 24;                    // staging one region, in (sub-)windows' worth of time (workgroup ranges)
+constexpr int kWideMaxRows = 64;                      // sub-window rows: a lane each
+constexpr int kWideMaxCH = 13;                        // cells per lane: register budget of 16 waves x 128 VGPRs
+
+struct WideArgs {
+    const StagedBlock*    blocks;     // block table (pad[0] = sub-window group of the block's items)
+    const unsigned short* win;        // items in block order: corner of the sub-window inside its region, dr | dc << 7
+    const int*            wg_first;   // [G + 1] first block of every workgroup's range
+    int                   WF;         // full window width
+    int                   NGc;        // groups per row of the group grid (group = gi * NGc + gj), NG = NGr * NGc
+    int                   NG;
+    int                   SH, SW;     // nominal sub-window height / width (the last row / column of groups may be smaller)
+    int                   NPC;        // column panels (divides 16): wave w piles up columns [CH * (w % NPC), + CH)
+    unsigned*             rec_seg;    // [nrec] 0, or 1 + (tile * 2 + flip) * NG + group of the record written there
+    double*               rec_f64;    // [nrec][kWideRec]
+    unsigned*             rec_num;    // [nrec][kWideRec]
+    long long*            timing;     // phase clocks per wave, [G][16][8], or nullptr
+};
+
+// geometry of a call, shared by host and device: sub-window grid and column panels for window width W
+struct WideGeom { int NGr, NGc, SH, SW, NPC, CH; };
+__host__ __device__ inline WideGeom wide_geometry(int W) {
+    WideGeom g;
+    g.NGr = (W + kWideMaxRows - 1) / kWideMaxRows;
+    g.SH = (W + g.NGr - 1) / g.NGr;
+    g.NGc = (W + 4 * kWideMaxCH - 1) / (4 * kWideMaxCH);
+    g.SW = (W + g.NGc - 1) / g.NGc;
+    g.NPC = 4;
+    g.CH = (g.SW + g.NPC - 1) / g.NPC;
+    return g;
+}
+
+// one step of K1w's rolling window pipeline per cell: wait for the oldest outstanding LDS read (cell I of the current window),
+// add it, and reissue the register as the destination of cell I of the next window
+template <int I, int N, int NB, bool FACT>
+struct RollRow {
+    static __device__ __forceinline__ void go(double (&v)[N], double (&sum)[N], unsigned (&num)[N], unsigned vw, unsigned ad, unsigned adn) {
+        lds_wait_but<NB - 1>(ad, adn);
+        lds_pin1(v[I]);
+        sum[I] += v[I];
+        if (!FACT) num[I] += (vw >> I) & 1u;
+        lds_read_b64<8 * I>(v[I], adn);
+        RollRow<I + 1, N, NB, FACT>::go(v, sum, num, vw, ad, adn);
+    }
+};
+template <int N, int NB, bool FACT>
+struct RollRow<N, N, NB, FACT> {
+    static __device__ __forceinline__ void go(double (&)[N], double (&)[N], unsigned (&)[N], unsigned, unsigned, unsigned) {}
+};
+
+// the instantiations (cells per lane CH = 7..13, x observed-over-expected x factorised counts) live in their own translation
+// units, one per CH (pup_wide_tu.hip with -DPUP_TU_PART=CH), compiled side by side like K1q's
+constexpr int kWideMinCH = 7;
+#define PUP_WIDE_PART_DECL(k) bool launch_wide_part##k(const K1Args&, const WideArgs&, int G, bool ooe, bool fact, hipStream_t);
+PUP_WIDE_PART_DECL(7) PUP_WIDE_PART_DECL(8) PUP_WIDE_PART_DECL(9) PUP_WIDE_PART_DECL(10) PUP_WIDE_PART_DECL(11) PUP_WIDE_PART_DECL(12) PUP_WIDE_PART_DECL(13)
+#undef PUP_WIDE_PART_DECL
+inline bool launch_wide(int CH, const K1Args& a, const WideArgs& wa, int G, bool ooe, bool fact, hipStream_t s) {
+    switch (CH) {
+        case 7:  return launch_wide_part7(a, wa, G, ooe, fact, s);
+        case 8:  return launch_wide_part8(a, wa, G, ooe, fact, s);
+        case 9:  return launch_wide_part9(a, wa, G, ooe, fact, s);
+        case 10: return launch_wide_part10(a, wa, G, ooe, fact, s);
+        case 11: return launch_wide_part11(a, wa, G, ooe, fact, s);
+        case 12: return launch_wide_part12(a, wa, G, ooe, fact, s);
+        case 13: return launch_wide_part13(a, wa, G, ooe, fact, s);
+        default: return false;
+    }
+}
+
+template <int CH, bool OOE, bool FACT>
+__global__ __launch_bounds__(kWave * 16, 1)
+void pileup_wide_kernel(K1Args a, WideArgs wa) {
+    static_assert(CH >= 1 && CH <= kWideMaxCH, "cells per lane");
+    constexpr int RSR = 128, RSC = 128, NW = 16, LS = RSC + 1, RPW = RSR / NW, NH = 2, NRH = RPW * NH, VBW = 3, NTHR = kWave * NW;
+    static_assert((size_t)(NW / 2) * CH * kWave * 12 <= (size_t)RSR * LS * 8, "merge scratch must fit the region buffer");
+    __shared__ double tile[RSR * LS + 16];                          // (+16: the last panel's unowned cells may run past the last row)
+    __shared__ unsigned long long vbits[FACT ? 1 : RSR * VBW];      // bit c of row r: cell (r, c) counts in num
+    __shared__ double exp_lds[OOE ? 256 : 1];                       // expected of the region's 255 diagonals (see K1q)
+    __shared__ unsigned rc_lds[FACT ? kWideRec : 1];                // masked row meets masked column (rare)
+    __shared__ unsigned fact_tot[FACT ? 2 * 64 + 4 : 1];            // R[64] | C[64] | N
+    const int tid  = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NPC = wa.NPC, nsub = NW / NPC;
+    const int panel = wave % NPC, sub = wave / NPC;
+    const int q0 = panel * CH;
+
+    const bool use_exp = OOE && ((a.expv != nullptr && a.nexp > 0) || a.n_exp_regions > 0);
+    const int  igd     = a.ignore_diags;
+    const double qnan = __builtin_nan("");
+    const bool nf = a.nf_pixels != 0;                    // (uniform) weights of +-inf in the table: NaN products are stored as 0
+
+    const int G = (int)gridDim.x, g_id = (int)blockIdx.x;
+    const int bb = wa.wg_first[g_id], be = wa.wg_first[g_id + 1];
+    if (bb >= be) return;                                // (uniform) more workgroups than blocks
+
+    // geometry of the current sub-window group (changes with the segment)
+    int grp = -1, pr0 = 0, pc0 = 0, sh = 1, sw = 1, p = 0;
+    bool row_ok = false;
+    unsigned chmask = 0u;                                // bit i: the lane owns sub-window cell (p, q0 + i)
+    unsigned lane_off8 = 0u;                             // LDS byte address of the lane's first cell at corner (0, 0)
+    auto set_group = [&](int g) __attribute__((always_inline)) {
+        grp = g;
+        const int gi = g / wa.NGc, gj = g - gi * wa.NGc;
+        pr0 = gi * wa.SH; pc0 = gj * wa.SW;
+        sh = wa.WF - pr0 < wa.SH ? wa.WF - pr0 : wa.SH;
+        sw = wa.WF - pc0 < wa.SW ? wa.WF - pc0 : wa.SW;
+        row_ok = lane < sh;
+        p = row_ok ? lane : sh - 1;                      // idle lanes shadow the last row, flush nothing
+        chmask = 0u;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) if (row_ok && q0 + i < sw) chmask |= 1u << i;
+        lane_off8 = (unsigned)(uintptr_t)tile + 8u * (unsigned)(p * LS + q0);
+    };
+
+    double   sum[CH];
+    unsigned num[CH];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) { sum[i] = 0.0; num[i] = 0u; }
+        if constexpr (FACT) {                            // visible after the next barrier
+            for (int t = tid; t < kWideRec; t += NTHR) rc_lds[t] = 0u;
+            for (int t = tid; t < 2 * 64 + 4; t += NTHR) fact_tot[t] = 0u;
+        }
+    };
+    zero_acc();
+    if constexpr (!FACT) for (int t = tid; t < RSR * VBW; t += NTHR) vbits[t] = 0ull;     // the pad words stay zero
+
+    const StagedBlock* __restrict__ blocks = wa.blocks;
+    auto entry_load = [&](int b) __attribute__((always_inline)) -> int {
+        return reinterpret_cast<const int*>(blocks + b)[lane & 31];
+    };
+    auto fld = [&](int ev, int i) __attribute__((always_inline)) -> int { return __builtin_amdgcn_readlane(ev, i); };
+    auto fld64 = [&](int ev, int i) __attribute__((always_inline)) -> unsigned long long {
+        return ((unsigned long long)(unsigned)fld(ev, i + 1) << 32) | (unsigned)fld(ev, i);
+    };
+    auto bcast64 = [&](unsigned long long v, int i) __attribute__((always_inline)) -> unsigned long long {
+        const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, i), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), i);
+        return ((unsigned long long)hi << 32) | lo;
+    };
+    const int my_rr = wave * RPW + (lane < RPW ? lane : 0);      // the region row whose weight / validity this lane looks after
+    auto weight_of = [&](double w) __attribute__((always_inline)) -> double {
+        return a.weight ? ((nf || w == w) ? w : 0.0) : 1.0;
+    };
+    auto exp_of = [&](int ev) -> ExpSel {
+        ExpSel es; es.base = a.expv; es.len = 0; es.scalar = qnan; es.is_scalar = true;
+        if (!use_exp) return es;
+        if (a.n_exp_regions <= 0) {
+            es.len = a.nexp; es.is_scalar = (a.nexp == 1);
+            es.scalar = (a.nexp == 1 && a.expv) ? a.expv[0] : qnan;
+            if (!a.expv || a.nexp <= 0) { es.is_scalar = true; es.scalar = qnan; }
+            return es;
+        }
+        const int er = fld(ev, 5);                       // expected region of the block (that of its origin: see wide_run)
+        es.is_scalar = false;
+        if (er >= 0 && er < a.n_exp_regions) { const ExpRegion g = a.exp_regions[er]; es.base = a.expv + g.off; es.len = g.len; }
+        return es;
+    };
+    auto exp_fetch = [&](int ev) __attribute__((always_inline)) -> double {
+        if (!use_exp || tid >= RSR + RSC - 1) return qnan;
+        const ExpSel es = exp_of(ev);
+        long long d = (long long)fld(ev, 1) - (long long)fld(ev, 0) - (RSR - 1) + tid;
+        if (d < 0) d = -d;
+        return es.at(d);
+    };
+    // unmasked cells of (region row rr, half h): column mask of the table entry, masked-row bit, diagonal mask — uniform
+    auto ok_mask = [&](int ev, int rr, int h, bool row_bad) __attribute__((always_inline)) -> unsigned long long {
+        unsigned long long ok = row_bad ? 0ull : fld64(ev, 12 + 2 * h);
+        if (igd >= 0) {
+            const int t0 = igd - (fld(ev, 1) + 64 * h - (fld(ev, 0) + rr));   // column C + 64 h + l is on or above the first kept diagonal iff l >= t0
+            ok &= t0 <= 0 ? ~0ull : (t0 >= 64 ? 0ull : ~((1ull << t0) - 1ull));
+        }
+        return ok;
+    };
+
+    // ---- staging from the dense band of counts: band[row][j] = count(row, row + j) ------------------------------------
+    // A region row is 128 consecutive counts of the band: one coalesced load per 64-column half whose address is the row's
+    // (scalar, 64-bit) base plus 4 * lane.  FACT: no cell a window reads needs masking (every window clears the masked
+    // diagonals and lies inside the band; masked bins multiply to zero through their weight), so the loads carry no
+    // predicate; cells left of the diagonal or past the band's width read the neighbouring rows / the pads around the
+    // table: finite garbage nobody looks at.  !FACT: lanes whose cell is masked, below the first kept diagonal or outside
+    // the staged rows read the zeros behind the band.  Nothing here looks at a loaded value (see K1q).
+    const int* const zeros = a.band + (long long)a.nbins * a.band_w;      // >= 129 rows of zeros behind the last row
+    auto band_issue = [&](int ev, int (&v)[NRH], double (&wc)[NH], double& wrv) __attribute__((always_inline)) {
+        const int R = fld(ev, 0), C = fld(ev, 1), ch_end = fld(ev, 6), row_lo = fld(ev, 21), row_hi = fld(ev, 22);
+        const int hi2 = (ch_end - R) < row_hi ? (ch_end - R) : row_hi;             // live rows of the region: [row_lo, hi2)
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int rr = wave * RPW + i;
+            const int row = R + rr;
+            const bool live = rr >= row_lo && rr < hi2;                           // (uniform)
+            const int* rowp = live ? a.band + (long long)row * a.band_w + (C - row) : zeros;
+            if constexpr (FACT) {
+#pragma unroll
+                for (int h = 0; h < NH; ++h) v[i * NH + h] = rowp[64 * h + lane];
+            } else {
+                const bool row_bad = (fld64(ev, 16 + 2 * (rr >> 6)) >> (rr & 63)) & 1ull;
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    // cells past the band's width are in no window (the engine checked); the band's own row ends at band_w
+                    unsigned long long keep = live ? ok_mask(ev, rr, h, row_bad) : 0ull;
+                    const int over = (C + 64 * h + 64) - (row + a.band_w);          // columns at / past the band's end
+                    if (over > 0) keep &= over >= 64 ? 0ull : (~0ull >> over);
+                    const bool has = __builtin_amdgcn_inverse_ballot_w64(keep);
+                    const int* ptr = has ? rowp + 64 * h + lane : zeros + lane;
+                    v[i * NH + h] = *ptr;
+                }
+            }
+        }
+        const double* wsrc = a.weight ? a.weight : reinterpret_cast<const double*>(a.indptr);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const long long col = (long long)C + 64 * h + lane;
+            wc[h] = wsrc[col < a.nbins ? col : a.nbins - 1];      // raw: reads the row offsets, a table of the same length — never looked at
+        }
+        {   // row weights: lane i < RPW holds its row's, broadcast at store time
+            const long long row = (long long)R + my_rr;
+            wrv = wsrc[row < a.nbins ? row : a.nbins - 1];
+        }
+    };
+    auto band_store = [&](int ev, const int (&v)[NRH], const double (&wc)[NH], double wrv) __attribute__((always_inline)) {
+        const int R = fld(ev, 0), ch_end = fld(ev, 6), row_lo = fld(ev, 21), row_hi = fld(ev, 22);
+        double wcs[NH];
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) wcs[hh] = weight_of(wc[hh]);
+        const double wrs = weight_of(wrv);
+        unsigned long long okn[NH];                      // lane i < RPW: validity bits of its row (!FACT)
+        if constexpr (!FACT) {
+            const int row = R + my_rr;
+            const bool live = lane < RPW && row < ch_end && my_rr >= row_lo && my_rr < row_hi;
+            const bool row_bad = (a.badbits[(row < a.nbins ? row : 0) >> 6] >> (row & 63)) & 1ull;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) okn[h] = live ? ok_mask(ev, my_rr, h, row_bad) : 0ull;
+        }
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int rr = wave * RPW + i;
+            if (rr < row_lo || rr >= row_hi) continue;   // (uniform) no window of the block reads this row
+            const double wr = __longlong_as_double((long long)bcast64((unsigned long long)__double_as_longlong(wrs), i));
+#pragma unroll
+            for (int hh = 0; hh < NH; ++hh) {
+                double val = (double)v[i * NH + hh] * wr * wcs[hh];
+                if (nf) val = (val == val) ? val : 0.0;
+                if (OOE) {
+                    const double e = exp_lds[64 * hh + lane - rr + (RSR - 1)];      // expected of |col - row|
+                    val = val / e;
+                    val = (val == val) ? val : 0.0;         // NaN quotients are skipped, inf is kept
+                    if constexpr (!FACT) {
+                        int e_ok = (e == e && e != 0.0) ? 1 : 0;     // (through a register the compiler cannot fold: see K1q's store_region)
+                        asm volatile("" : "+v"(e_ok));
+                        const unsigned long long eok = __ballot(e_ok);
+                        if (lane == i) okn[hh] &= eok;
+                    }
+                }
+                tile[rr * LS + 64 * hh + lane] = val;
+            }
+        }
+        if constexpr (!FACT) {
+            if (lane < RPW && my_rr >= row_lo && my_rr < row_hi) {
+#pragma unroll
+                for (int hh = 0; hh < NH; ++hh) vbits[my_rr * VBW + hh] = okn[hh];
+            }
+        }
+    };
+
+    // ---- the windows of the staged block ---------------------------------------------------------------------------
+    struct Cur { int start, n; unsigned long long rowbad[2], colbad[2]; };
+    const unsigned vb_base = (unsigned)(uintptr_t)vbits;
+    auto load_batch = [&](int start, int at, int end) __attribute__((always_inline)) -> int {
+        return at + lane < end ? (int)wa.win[start + at + lane] : 0;
+    };
+    // windows jb <= j < je of the wave's current batch (window j sits in lane j).  ROLLING pipeline over ONE set of value
+    // registers: the CH (+1) LDS reads of a window are in flight; cell i of window j is waited for (`s_waitcnt lgkmcnt(NB-1)`:
+    // LDS operations return in order, so all but the NB-1 youngest have landed = the oldest one has), added, and its register
+    // is at once the destination of the same cell of window j + 1.  (K1q double-buffers two windows: at CH = 13 that is 52
+    // value registers and the kernel spilled.)  Past the run's last window the pipeline reads that window once more, never added.
+    auto run = [&](int offv, int drv, int dcv, int jb, int je) __attribute__((always_inline)) {
+        if (jb >= je) return;
+        constexpr int NB = CH + (FACT ? 0 : 1);            // LDS operations of one window (<= 14: the counter holds 15)
+        double v[CH];
+        unsigned long long vraw = 0ull;
+        auto addr_of = [&](int jj) __attribute__((always_inline)) -> unsigned { return lane_off8 + (unsigned)__builtin_amdgcn_readlane(offv, jj); };
+        // validity bits of the sub-window's row p from column dc + q0 on: the dword pair holding bit dc + q0
+        auto vaddr_of = [&](int jj) __attribute__((always_inline)) -> unsigned {
+            const int dr = __builtin_amdgcn_readlane(drv, jj), dc = __builtin_amdgcn_readlane(dcv, jj);
+            return vb_base + (unsigned)((dr + p) * (VBW * 8)) + 4u * ((unsigned)(dc + q0) >> 5);
+        };
+        unsigned ad = addr_of(jb), av = 0u;
+        if constexpr (!FACT) { av = vaddr_of(jb); lds_read2_b32(vraw, av); }
+        LdsReadRow<0, CH, 8>::go(v, ad);
+        for (int jj = jb; jj < je; ++jj) {
+            const int nxt = jj + 1 < je ? jj + 1 : jj;
+            const unsigned adn = addr_of(nxt);
+            unsigned vw = 0u, avn = av;
+            if constexpr (!FACT) {
+                avn = vaddr_of(nxt);
+                lds_wait_but<NB - 1>(ad, av); lds_pin_u64(vraw);
+                vw = (unsigned)(vraw >> ((__builtin_amdgcn_readlane(dcv, jj) + q0) & 31));
+                lds_read2_b32(vraw, avn);
+            }
+            RollRow<0, CH, NB, FACT>::go(v, sum, num, vw, ad, adn);
+            ad = adn; av = avn;
+        }
+        lds_wait_all(ad, av, ad, av); lds_pin(v);
+        if constexpr (!FACT) lds_pin_u64(vraw);
+    };
+    // bits [s, s + 64) of the 128-bit mask hi:lo, s in [0, 127]
+    auto mask_at = [&](const unsigned long long (&m)[2], int s) __attribute__((always_inline)) -> unsigned long long {
+        const int t = s & 63;
+        unsigned long long v;
+        if (s < 64) { v = m[0] >> t; if (t) v |= m[1] << (64 - t); } else v = m[1] >> t;
+        return v;
+    };
+    // FACT bookkeeping of a batch, a lane per window (see K1q's fact_batch): fact_tot = {R[64], C[64], N}, rc_lds = RC
+    auto fact_batch = [&](const Cur& g, int drv, int dcv, int nb) __attribute__((always_inline)) {
+      if constexpr (FACT) {
+        if (lane == 0) atomicAdd(&fact_tot[128], (unsigned)nb);
+        if ((g.rowbad[0] | g.rowbad[1] | g.colbad[0] | g.colbad[1]) == 0ull) return;     // (uniform) no masked bin in the region
+        const bool live = lane < nb;
+        const unsigned long long hmask = sh >= 64 ? ~0ull : ((1ull << sh) - 1ull), wmask = sw >= 64 ? ~0ull : ((1ull << sw) - 1ull);
+        unsigned long long rb = live ? mask_at(g.rowbad, drv) & hmask : 0ull;
+        const unsigned long long cbm = live ? mask_at(g.colbad, dcv) & wmask : 0ull;
+        unsigned long long cc = cbm;
+        while (cc) { const int q = __ffsll((long long)cc) - 1; cc &= cc - 1ull; atomicAdd(&fact_tot[64 + q], 1u); }
+        while (rb) {
+            const int pp = __ffsll((long long)rb) - 1; rb &= rb - 1ull;
+            atomicAdd(&fact_tot[pp], 1u);
+            unsigned long long c2 = cbm;
+            while (c2) { const int q = __ffsll((long long)c2) - 1; c2 &= c2 - 1ull; atomicAdd(&rc_lds[pp * 64 + q], 1u); }
+        }
+      }
+    };
+    // the NW / NPC waves of a panel share the block's windows in equal contiguous slices; the NPC waves that own slice `sub`
+    // walk the same batches, and batch t's bookkeeping falls to panel t % NPC
+    auto slice_of = [&](int n, int& lo, int& hi) __attribute__((always_inline)) {
+        lo = (int)(((long long)n * sub) / nsub); hi = (int)(((long long)n * (sub + 1)) / nsub);
+    };
+    auto windows = [&](const Cur& g, int wf, auto&& mid) __attribute__((always_inline)) {
+        int lo, hi;
+        slice_of(g.n, lo, hi);
+        const bool cols_live = q0 < sw;                  // (uniform) a panel past the group's last column has nothing to pile up
+        int t = 0;
+        {
+            const int drv = wf & ((1 << kWinShift) - 1), dcv = (wf >> kWinShift) & ((1 << kWinShift) - 1);
+            const int offv = 8 * (drv * LS + dcv);
+            if (lo + kWave < hi) wf = load_batch(g.start, lo + kWave, hi);
+            const int nb = (hi - lo) < kWave ? (hi - lo) : kWave;
+            if (t % NPC == panel && nb > 0) fact_batch(g, drv, dcv, nb);
+            const int cut = cols_live ? (nb * sub) / (2 * nsub) : 0;      // the look-ahead work sits at a different place in every wave of a SIMD
+            run(offv, drv, dcv, 0, cut);
+            mid();
+            if (cols_live) run(offv, drv, dcv, cut, nb);
+            ++t;
+        }
+        for (int s0 = lo + kWave; s0 < hi; s0 += kWave, ++t) {
+            const int drv = wf & ((1 << kWinShift) - 1), dcv = (wf >> kWinShift) & ((1 << kWinShift) - 1);
+            const int offv = 8 * (drv * LS + dcv);
+            if (s0 + kWave < hi) wf = load_batch(g.start, s0 + kWave, hi);
+            const int nb = (hi - s0) < kWave ? (hi - s0) : kWave;
+            if (t % NPC == panel) fact_batch(g, drv, dcv, nb);
+            if (cols_live) run(offv, drv, dcv, 0, nb);
+        }
+    };
+    auto first_coords = [&](int ev, int& wf) __attribute__((always_inline)) {
+        int lo, hi;
+        slice_of(fld(ev, 3), lo, hi);
+        wf = load_batch(fld(ev, 2), lo, hi);
+    };
+    auto cur_of = [&](int ev) __attribute__((always_inline)) -> Cur {
+        Cur c;
+        c.start = fld(ev, 2); c.n = fld(ev, 3);
+        c.rowbad[0] = fld64(ev, 16); c.rowbad[1] = fld64(ev, 18);
+        c.colbad[0] = ~fld64(ev, 12); c.colbad[1] = ~fld64(ev, 14);
+        return c;
+    };
+
+    // ---- flush of a segment (tile, flip, group): merge the register tiles of the waves that share a panel (fixed binary
+    // tree), write the partial record, clear the accumulators.  The region buffer is scratch here: every wave is done
+    // reading the staged region, and the next region is stored after it.
+    auto flush = [&](int seg) __attribute__((always_inline)) {
+        double*   mf = tile;                                              // [NW/2][CH][64] doubles, then the same in u32
+        unsigned* mn = reinterpret_cast<unsigned*>(tile + (NW / 2) * CH * kWave);
+        __syncthreads();
+        for (int step = 1; step < nsub; step <<= 1) {
+            const int slot_w = panel + NPC * (sub >> 1);                 // writers of one step differ in (panel, sub >> 1)
+            if ((sub & (2 * step - 1)) == step) {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    mf[(slot_w * CH + i) * kWave + lane] = sum[i];
+                    if (!FACT) mn[(slot_w * CH + i) * kWave + lane] = num[i];
+                }
+            }
+            __syncthreads();
+            if ((sub & (2 * step - 1)) == 0 && sub + step < nsub) {
+                const int from = panel + NPC * ((sub + step) >> 1);
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    sum[i] += mf[(from * CH + i) * kWave + lane];
+                    if (!FACT) num[i] += mn[(from * CH + i) * kWave + lane];
+                }
+            }
+            __syncthreads();
+        }
+        const size_t rec = (size_t)seg * (size_t)wa.NG + (size_t)grp + (size_t)g_id;
+        double*   of = wa.rec_f64 + rec * kWideRec;
+        unsigned* on = wa.rec_num + rec * kWideRec;
+        if (sub == 0) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+                if ((chmask >> i) & 1u) {
+                    of[p * 64 + q0 + i] = sum[i];
+                    if (!FACT) on[p * 64 + q0 + i] = num[i];
+                }
+        }
+        if constexpr (FACT) {
+            for (int t = tid; t < sh * 64; t += NTHR) {
+                const int pp = t >> 6, qq = t & 63;
+                if (qq < sw) on[t] = fact_tot[128] - fact_tot[pp] - fact_tot[64 + qq] + rc_lds[t];
+            }
+        }
+        if (tid == 0) wa.rec_seg[rec] = (unsigned)(seg * wa.NG + grp) + 1u;
+        __syncthreads();                                 // fact_tot / rc_lds have been read
+        zero_acc();
+        __syncthreads();
+    };
+
+    // ---- the block loop: region b is piled up while b+1's counts and b+2's table entry are on their way ----------------
+    int ev0 = entry_load(bb), ev1 = ev0, evn = ev0;
+    int v[NRH];
+    double wc[NH], wrv = 1.0;
+    int w0f, w1f = 0;
+    {   // prologue: stage block bb without overlap
+        set_group(fld(ev0, 30));
+        band_issue(ev0, v, wc, wrv);
+        first_coords(ev0, w0f);
+        if (bb + 1 < be) ev1 = entry_load(bb + 1);
+        if constexpr (OOE) { if (tid < 256) exp_lds[tid] = exp_fetch(ev0); }
+        __syncthreads();
+        band_store(ev0, v, wc, wrv);
+        __syncthreads();
+    }
+    long long tk[6] = {0, 0, 0, 0, 0, 0}, tmid = 0;
+    double e_next = 0.0;
+    const bool timed = wa.timing != nullptr;
+    auto tick = [&]() __attribute__((always_inline)) -> long long { return timed ? (long long)__builtin_readcyclecounter() : 0; };
+    for (int b = bb; b < be; ++b) {
+        const bool has1 = b + 1 < be, has2 = b + 2 < be;
+        const long long t0 = tick();
+        auto lookahead = [&]() __attribute__((always_inline)) {
+            const long long m0 = tick();
+            if constexpr (OOE) { if (has1) e_next = exp_fetch(ev1); }
+            if (has1) { band_issue(ev1, v, wc, wrv); first_coords(ev1, w1f); }
+            if (has2) evn = entry_load(b + 2);
+            tmid += tick() - m0;
+        };
+        const Cur c0 = cur_of(ev0);
+        const long long t1 = tick();
+        windows(c0, w0f, lookahead);
+        if constexpr (OOE) { if (has1 && tid < 256) exp_lds[tid] = e_next; }     // (last read when region b was stored; visible after the barrier below)
+        const long long t2 = tick();
+        const int seg0 = fld(ev0, 20), grp0 = fld(ev0, 30);
+        if (!has1) { flush(seg0); break; }
+        const int seg1 = fld(ev1, 20), grp1 = fld(ev1, 30);
+        if (seg1 != seg0 || grp1 != grp0) {              // (uniform) the next block belongs to another (tile, flip, group)
+            flush(seg0);
+            if (grp1 != grp0) set_group(grp1);
+        } else __syncthreads();                          // every wave is done reading region b
+        const long long t3 = tick();
+        band_store(ev1, v, wc, wrv);
+        const long long t4 = tick();
+        __syncthreads();
+        const long long t5 = tick();
+        ev0 = ev1; w0f = w1f; ev1 = evn;
+        if (timed) { tk[0] += t1 - t0; tk[1] += t2 - t1; tk[2] += t3 - t2; tk[3] += t4 - t3; tk[4] += t5 - t4; tk[5] += tick() - t5; }
+    }
+    if (timed && lane == 0) {
+        long long* o = wa.timing + ((size_t)g_id * NW + wave) * 8;
+        for (int i = 0; i < 6; ++i) o[i] = tk[i];
+        o[6] = be - bb; o[7] = tmid;
+    }
+    (void)G;
+}
+
+// ---- block-order prepass of K1w: keys of the (window, group) items ---------------------------------------------------
+// item ii = group * n + window (group-major: consecutive threads read consecutive windows).  key = ((tile, flip) run, group)
+// | block row | block column of the SUB-window's corner; value = that corner inside its block.  The verdict counters are
+// per WINDOW (group 0 counts): [0] windows the band cannot serve (not inside one chromosome), [1] windows a masked
+// diagonal reaches (or that reach past the usable expected), [2] windows leaving the dense band.
+template <typename KeyT>
+__global__ __launch_bounds__(256) void wide_key_kernel(const int* __restrict__ r0, const int* __restrict__ c0, long long n, long long n_items,
+                                                       const long long* __restrict__ seg_end, int nseg2t,
+                                                       const IdxChrom* __restrict__ chroms, int n_chrom,
+                                                       const unsigned short* __restrict__ bin_chrom, long long nbins,
+                                                       const int* __restrict__ brow_base, int W, int NG, int NGc, int SH, int SW,
+                                                       int BR, int BC, int sh_br, int sh_seg, int seg_shift,
+                                                       int clear_gap, int far_gap, int band_w,
+                                                       KeyT* __restrict__ keys, unsigned short* __restrict__ vals,
+                                                       unsigned* __restrict__ counters) {
+    constexpr int kMaxChrom = 512, kPer = 4;
+    __shared__ int s_cs[kMaxChrom], s_ce[kMaxChrom], s_bb[kMaxChrom];
+    __shared__ long long s_seg[2 * kMaxSegCount];
+    const bool in_lds = n_chrom <= kMaxChrom;
+    if (in_lds) for (int k = threadIdx.x; k < n_chrom; k += blockDim.x) { s_cs[k] = chroms[k].start; s_ce[k] = chroms[k].end; s_bb[k] = brow_base[k]; }
+    for (int k = threadIdx.x; k < nseg2t; k += blockDim.x) s_seg[k] = seg_end[k];
+    __syncthreads();
+    unsigned bad = 0u;
+    for (int u = 0; u < kPer; ++u) {
+        const long long ii = ((long long)blockIdx.x * kPer + u) * blockDim.x + threadIdx.x;
+        const bool live = ii < n_items;
+        const int grp = live ? (int)(ii / n) : 0;
+        const long long i = live ? ii - (long long)grp * n : 0;
+        const int r = live ? r0[i] : 0, c = live ? c0[i] : 0;
+        int lo = 0, hi = nseg2t;
+        while (lo < hi) { const int m = (lo + hi) >> 1; if (s_seg[m] <= i) lo = m + 1; else hi = m; }
+        const unsigned seg = (unsigned)(lo >> seg_shift) * (unsigned)NG + (unsigned)grp;
+        bool ok = r >= 0 && c >= 0 && (long long)r < nbins;
+        unsigned long long br = 0, bc = 0;
+        unsigned inside = 0u;
+        if (ok) {
+            const int ca = bin_chrom[r];
+            const int cs = in_lds ? s_cs[ca] : chroms[ca].start, ce = in_lds ? s_ce[ca] : chroms[ca].end;
+            ok = r >= cs && r + W <= ce && c >= cs && c + W <= ce;
+            if (ok) {
+                const int gi = grp / NGc, gj = grp - gi * NGc;
+                const int rs = r + gi * SH - cs, cc = c + gj * SW - cs;       // the sub-window's corner, chromosome-relative
+                const int qr = rs / BR, qc = cc / BC;
+                br = (unsigned long long)((in_lds ? s_bb[ca] : brow_base[ca]) + qr);
+                bc = (unsigned long long)qc;
+                inside = (unsigned)(rs - qr * BR) | ((unsigned)(cc - qc * BC) << kWinShift);
+            }
+        }
+        const bool first = live && grp == 0;
+        if (first && !ok) ++bad;
+        {
+            const unsigned long long near = __ballot(first && (c - r < clear_gap || (c + W - 1) - r >= far_gap));
+            if (near != 0ull && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)near) - 1)) atomicAdd(&counters[1], (unsigned)__popcll(near));
+            const unsigned long long far = __ballot(first && (c + W - 1) - r >= band_w);
+            if (far != 0ull && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)far) - 1)) atomicAdd(&counters[2], (unsigned)__popcll(far));
+        }
+        if (!live) continue;
+        keys[ii] = (KeyT)(((unsigned long long)seg << sh_seg) | (br << sh_br) | bc);
+        vals[ii] = (unsigned short)inside;
+    }
+    if (bad) atomicAdd(&counters[0], bad);
+}
+
+// fixed-order reduction of K1w's partial records into the running accumulators.  Workgroup = (64 accumulator cells, tile),
+// 64 cells x kRedParts interleaved partial sums over the workgroups' records (as reduce_staged_kernel).  An accumulator cell
+// (P, Q) receives sub-window cell (P, Q) of the unflipped records and, anti-transposed (flip_snip_func,
+// coolpuppy/coolpup.py:128-131), cell (W-1-Q, W-1-P) of the flipped ones: flip 0 first, then flip 1, records in workgroup order.
+PUP_KERNEL __launch_bounds__(64 * kRedParts) void reduce_wide_kernel(
+        const double* __restrict__ rec_f64, const unsigned* __restrict__ rec_num, const unsigned* __restrict__ rec_seg,
+        int G, int W, int NG, int NGc, int SH, int SW, int n_flip /* 1: no flipped windows in the call */,
+        int Lf, double* out_f64, long long* out_num) {
+    __shared__ double    sf[kRedParts][64];
+    __shared__ long long si[kRedParts][64];
+    const int t = blockIdx.y;
+    const int cx = threadIdx.x, py = threadIdx.y;
+    const int cell = blockIdx.x * 64 + cx;
+    const int W2 = W * W;
+    double accf = 0.0; long long acci = 0;
+    if (cell < W2) {
+        const int P = cell / W, Q = cell - P * W;
+        for (int fl = 0; fl < n_flip; ++fl) {
+            const int ps = fl ? W - 1 - Q : P, qs = fl ? W - 1 - P : Q;          // the window cell that lands here
+            const int gi = ps / SH, gj = qs / SW;
+            const int seg = (t * 2 + fl) * NG + gi * NGc + gj;
+            const int at = (ps - gi * SH) * 64 + (qs - gj * SW);
+            constexpr int kUn = 4;
+            for (int g0 = py; g0 < G; g0 += kUn * kRedParts) {
+                bool ok[kUn]; double vf[kUn]; unsigned vn[kUn];
+#pragma unroll
+                for (int u = 0; u < kUn; ++u) { const int g = g0 + u * kRedParts; ok[u] = g < G && rec_seg[seg + g] == (unsigned)seg + 1u; }
+#pragma unroll
+                for (int u = 0; u < kUn; ++u) {
+                    const size_t rec = (size_t)(seg + g0 + u * kRedParts);
+                    vf[u] = ok[u] ? rec_f64[rec * kWideRec + at] : 0.0;
+                    vn[u] = ok[u] ? rec_num[rec * kWideRec + at] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < kUn; ++u) if (ok[u]) { accf += vf[u]; acci += (long long)vn[u]; }
+            }
+        }
+    }
+    sf[py][cx] = accf; si[py][cx] = acci;
+    __syncthreads();
+    if (py != 0 || cell >= W2) return;
+    double tf = 0.0; long long ti = 0;
+#pragma unroll
+    for (int y = 0; y < kRedParts; ++y) { tf += sf[y][cx]; ti += si[y][cx]; }
+    out_f64[(size_t)t * Lf + cell] += tf;
+    out_num[(size_t)t * W2 + cell] += ti;
+}
+
+// ---- the expected-as-control pass for windows of any width (PUP_MODE_EXPECTED) ------------------------------------------
+// expected & !ooe: the "control" of a snippet is the unmasked window of its expected matrix (coolpuppy/coolpup.py:1135-1139),
+// a Toeplitz slice: cell (p, q) = E[|c0 + q - r0 - p|] of the region holding the snippet's first row (or the trans scalar of
+// the region pair).  It only depends on q - p: per snippet the 2W - 1 values S[d] = E[|c0 - r0 + d|], d = q - p in (-W, W),
+// are ALL the arithmetic there is — a lane per diagonal instead of a lane per cell, O(W) per snippet, no tile in LDS, no
+// limit on W (the LDS-tile kernel this replaces for the mode stopped at W = 115).  A chunk (one wave, one (tile, flip) run
+// of snippets) keeps sum / count per diagonal in registers and writes one record of 2W - 1 diagonals; expand_diag_kernel
+// sums a tile's records in fixed order and spreads them over the W x W accumulators (transposed / flipped cells keep their
+// diagonal up to sign: map_cell).  nansum semantics as in the LDS-tile kernel: NaN adds nothing, +-inf is summed but not
+// counted in num (coolpuppy/lib/puputils.py:18-29).
+constexpr int kDiagPer = 8;                           // diagonals per lane: windows up to (64 * 8 + 1) / 2 = 256 bins per pass of a chunk
+PUP_KERNEL __launch_bounds__(kWave) void expected_diag_kernel(K1Args a, int d_first /* first diagonal slot of this pass */,
+                                                              double* __restrict__ part_f64, unsigned* __restrict__ part_num, int ND) {
+    const int lane = threadIdx.x;
+    const int ck = a.block_chunk[blockIdx.x];
+    if (ck < 0) return;
+    const int W = a.W;
+    const long long cb = a.chunk_begin[ck], ce = a.chunk_end[ck], cstep = a.chunk_stride[ck];
+    const bool use_exp = (a.expv != nullptr && a.nexp > 0) || a.n_exp_regions > 0;
+    ExpCache ecache;
+    double s[kDiagPer]; unsigned m[kDiagPer];
+#pragma unroll
+    for (int i = 0; i < kDiagPer; ++i) { s[i] = 0.0; m[i] = 0u; }
+    for (long long sn = cb; sn < ce; sn += cstep) {
+        const int r0s = __builtin_amdgcn_readfirstlane(a.r0[sn]);
+        const int c0s = __builtin_amdgcn_readfirstlane(a.c0[sn]);
+        if (r0s < 0 || c0s < 0 || (long long)r0s + W > a.nbins || (long long)c0s + W > a.nbins) {
+            if (lane == 0 && d_first == 0) atomicExch(a.err, 1);
+            continue;
+        }
+        if (!use_exp) continue;
+        const ExpSel es = select_expected(a, ecache, r0s, c0s);
+#pragma unroll
+        for (int i = 0; i < kDiagPer; ++i) {
+            const int slot = d_first + i * kWave + lane;                 // diagonal d = slot - (W - 1)
+            if (slot < ND) {
+                long long ad = (long long)(c0s - r0s) + slot - (W - 1); if (ad < 0) ad = -ad;
+                const double e = es.at(ad);
+                if (e == e) { s[i] += e; if (!__builtin_isinf(e)) m[i] += 1u; }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kDiagPer; ++i) {
+        const int slot = d_first + i * kWave + lane;
+        if (slot < ND) { part_f64[(size_t)ck * ND + slot] = s[i]; part_num[(size_t)ck * ND + slot] = m[i]; }
+    }
+}
+
+// accumulator cell <- diagonal slot of the (tile, flip) run records (the chunk records summed in fixed order by
+// reduce_partials_kernel): run 2t holds tile t's unflipped snippets, run 2t + 1 its flipped ones.
+PUP_KERNEL __launch_bounds__(256) void expand_diag_kernel(const double* __restrict__ run_f64, const long long* __restrict__ run_num,
+                                                          int W, int ND, int transpose, int Lf, double* out_f64, long long* out_num) {
+    const int t = blockIdx.y;
+    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    const int W2 = W * W;
+    if (cell >= W2) return;
+    const int P = cell / W, Q = cell - P * W;
+    double accf = 0.0; long long acci = 0;
+    for (int fl = 0; fl < 2; ++fl) {
+        // invert map_cell: which window cell (p, q) lands in accumulator cell (P, Q)
+        int pp = P, qq = Q;
+        if (fl) { const int tp = W - 1 - qq; qq = W - 1 - pp; pp = tp; }
+        const int p = transpose ? qq : pp, q = transpose ? pp : qq;
+        const int slot = (q - p) + (W - 1);
+        accf += run_f64[(size_t)(2 * t + fl) * ND + slot];
+        acci += run_num[(size_t)(2 * t + fl) * ND + slot];
+    }
+    out_f64[(size_t)t * Lf + cell] += accf;
+    out_num[(size_t)t * W2 + cell] += acci;
+}
+
+}  // namespace pup

@@ -298,6 +298,10 @@ class PileupEngine:
             self._check(g)
         return None if g == 0 else buf[:g * 16 * 8].reshape(g, 16, 8)
 
+    def last_kernel(self):
+        """Kernel family that served the last accumulate call (pup_last_kernel): 'staged', 'wide', 'wide_fact', 'regtile', 'band', ..."""
+        return self._lib.pup_last_kernel(self._h).decode()
+
     def clear_stats(self):
         self._check(self._lib.pup_clear_stats(self._h))
 

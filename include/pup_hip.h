@@ -38,6 +38,7 @@
  *   pup_host_alloc / pup_host_free    <- (no counterpart: page-locked staging for asynchronous host-to-device copies)
  *   pup_rccl_path                     <- (no counterpart: which librccl the communicator of pup_allreduce must come from)
  *   pup_debug_timing                  <- (no counterpart: phase clocks of the staged kernel, development aid)
+ *   pup_last_kernel                   <- (no counterpart: which kernel family served the last call, for tests / benchmarks)
  *
  * Conventions
  *   - plain C: pointers + sizes only; no C++/torch types cross this line.
@@ -70,7 +71,7 @@ typedef struct pup_ctx pup_ctx;
 #define PUP_EHIP       -3   /* a HIP runtime call failed */
 #define PUP_ESTATE     -4   /* call order violated (e.g. accumulate before load) */
 #define PUP_ERANGE     -5   /* a snippet window leaves the bin table (caught on device) */
-#define PUP_ENOTSUP    -6   /* valid request the engine cannot serve (e.g. window too large for LDS) */
+#define PUP_ENOTSUP    -6   /* valid request the engine cannot serve (e.g. a rescaled output tile too large for LDS) */
 
 /* mode bits for pup_accumulate */
 #define PUP_MODE_OOE        0x01u  /* divide each value by expected before summing (ooe=True) */
@@ -262,6 +263,10 @@ int pup_clear_stats(pup_ctx* ctx);
  * look-ahead inside the window phase}.  Returns the number of workgroups (0: nothing collected).  Development aid (tools/k1_probe.py --phases); no counterpart
  * in the reference. */
 int pup_debug_timing(pup_ctx* ctx, int64_t* out, int64_t cap);
+/* name of the pile-up kernel family the last pup_accumulate / pup_accumulate_rescaled of this context ran ("staged" = K1q, "wide" /
+ * "wide_fact" = K1w, "regtile" = K1r, "band" = K1b, "sparse" = K1s, "lds_tile", "expected_diag", "rescale"; "" before the first call).
+ * Results never depend on it; tests and benchmarks assert through it that the kernel they mean to measure is the one that ran.  Never NULL. */
+const char* pup_last_kernel(const pup_ctx* ctx);
 /* generic stream timer: record slot (0..7) on the context's stream; elapsed between two slots */
 int pup_event_record(pup_ctx* ctx, int slot);
 int pup_event_elapsed_ms(pup_ctx* ctx, int slot_begin, int slot_end, float* ms);

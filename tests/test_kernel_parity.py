@@ -64,11 +64,12 @@ def _compare(got, want):
     np.testing.assert_allclose(got["cov_end"], want["cov_end"], rtol=RTOL, atol=0)
 
 
-@pytest.mark.parametrize("pad", [10, 3, 25, 0, 40, 70])
+@pytest.mark.parametrize("pad", [10, 3, 25, 0, 40, 70, 16, 32, 127, 200, 300])
 @pytest.mark.parametrize("scenario", ["balanced", "raw_cov", "ooe", "expected_only", "flip_groups"])
 def test_cis_parity(engine, small_clr, oracle_mod, pad, scenario):
-    if pad == 70 and scenario == "expected_only":
-        pytest.skip("the expected-only pass needs the 141x141 tile in LDS (PUP_ENOTSUP, checked in test_errors)")
+    """Every window width the reference can slice (coolpuppy/coolpup.py:1115-1121 has no limit): pads 127 / 200 / 300 are windows
+    of 255 / 401 / 601 bins — the banded per-window kernel takes them in column panels, the wide staged kernel (K1w, forced by
+    the 'staged' engine) as a grid of sub-windows, the expected-only pass by diagonals."""
     po = oracle_mod
     clr = small_clr
     indptr, col, cnt = clr.pixel_table()
@@ -76,7 +77,7 @@ def test_cis_parity(engine, small_clr, oracle_mod, pad, scenario):
     cov = clr.bins()["cov_tot_raw"][:].values
     lo, hi = clr.extent("chrA")
     rng = np.random.default_rng(100 + pad)
-    n, T = (1500 if pad <= 25 else 300), 4
+    n, T = (1500 if pad <= 25 else (300 if pad <= 70 else 60)), 4
     r0, c0 = _snippets(clr, n, pad, rng, lo, hi)
     tile = rng.integers(0, T, n).astype(np.int32)
     flip = None
@@ -99,11 +100,73 @@ def test_cis_parity(engine, small_clr, oracle_mod, pad, scenario):
     engine.accumulate(r0, c0, tile_ptr, flip_from=ff, ignore_diags=igd, mode=mode)
     got = engine.fetch()
     _compare(got, want)
+    if engine._variant == 8 and pad >= 16 and scenario in ("balanced", "ooe", "flip_groups"):
+        assert engine.last_kernel().startswith("wide"), engine.last_kernel()     # K1w really ran
+    if scenario == "expected_only" and engine._variant != 2:
+        assert engine.last_kernel() == "expected_diag"
     # running accumulation: a second identical call doubles everything exactly for integers
     engine.accumulate(r0, c0, tile_ptr, flip_from=ff, ignore_diags=igd, mode=mode)
     got2 = engine.fetch()
     np.testing.assert_array_equal(got2["num"], 2 * want["num"])
     np.testing.assert_array_equal(got2["n"], 2 * want["n"])
+
+
+@pytest.mark.parametrize("pad", [16, 25, 31, 32, 50, 100, 150])
+@pytest.mark.parametrize("scenario", ["balanced", "ooe", "ooe_scalar", "flip_two_tiles", "raw"])
+def test_wide_staged_factorised(hip_lib, small_clr, oracle_mod, pad, scenario):
+    """K1w with factorised counts: every window clears the masked diagonals (c0 - r0 >= igd + W - 1), so num comes from the
+    per-batch mask words and the window loop touches values only.  Oracle parity and the same integers as the per-window
+    banded kernel (variant 16 forbids the staged kernels)."""
+    from coolpuppy_amd.engine import PileupEngine
+    po = oracle_mod
+    clr = small_clr
+    indptr, col, cnt = clr.pixel_table()
+    w = clr.bins()["weight"][:].values
+    lo, hi = clr.extent("chrA")
+    W, igd = 2 * pad + 1, 2
+    rng = np.random.default_rng(900 + pad)
+    n, T = (4000 if pad <= 32 else 600), 2
+    room = 1024 - (W + igd) - W                       # inside the 1024-column band: c0 + W - 1 - r0 < 1024
+    assert room > 8
+    r0 = rng.integers(lo, hi - 2 * W - igd - room - 2, n)
+    c0 = r0 + W + igd + rng.integers(0, room, n)
+    r0, c0 = r0.astype(np.int32), c0.astype(np.int32)
+    tile = (rng.random(n) < 0.15).astype(np.int32)
+    flip, mode, weight, expv = None, 0, w, None
+    if scenario == "ooe":
+        e = synth.cis_expected(clr)
+        expv = e[e.region1 == "chrA"]["balanced.avg"].values.copy()
+        mode = po.MODE_OOE
+    elif scenario == "ooe_scalar":
+        expv, mode = np.array([2.5e-3]), po.MODE_OOE
+    elif scenario == "flip_two_tiles":
+        flip = (rng.random(n) < 0.5).astype(np.uint8)
+    elif scenario == "raw":
+        weight = None
+    r0, c0, flip, tile, tile_ptr = _group(r0, c0, flip, tile, T)
+    ff = _flip_from(flip, tile, tile_ptr)
+    want = po.pileup_c(indptr, col, cnt, weight, None, expv, r0, c0, flip, tile, T, pad, igd, mode)
+    got = {}
+    for name, variant in (("wide", 8), ("band", 16)):
+        eng = PileupEngine(0)
+        eng.load_pixels(indptr, col, cnt)
+        eng.build_index(clr.chrom_offset)
+        eng.set_tuning(0, variant)
+        eng.load_bins(weight, None)
+        eng.set_expected(expv)
+        eng.reset(T, pad)
+        eng.accumulate(r0, c0, tile_ptr, flip_from=ff, ignore_diags=igd, mode=mode)
+        got[name] = eng.fetch()
+        kern = eng.last_kernel()
+        # bit-reproducible: a second engine pass gives the same doubles
+        eng.reset(T, pad)
+        eng.accumulate(r0, c0, tile_ptr, flip_from=ff, ignore_diags=igd, mode=mode)
+        again = eng.fetch()
+        eng.close()
+        _compare(got[name], want)
+        np.testing.assert_array_equal(again["sum"], got[name]["sum"])
+        assert kern == ("wide_fact" if name == "wide" else "band"), kern
+    np.testing.assert_array_equal(got["wide"]["num"], got["band"]["num"])
 
 
 @pytest.mark.parametrize("transpose", [False, True])
@@ -178,13 +241,15 @@ def test_errors_are_loud(engine, small_clr):
         engine.fetch()
     engine.reset(1, 10)
     engine.fetch()                         # error state cleared
-    with pytest.raises(PupError):          # window wider than any kernel serves
-        engine.reset(1, 400)
+    engine.reset(1, 400)                   # no width ceiling any more (round 4): 801 x 801 is served
+    engine.accumulate(np.array([100], np.int32), np.array([900], np.int32), np.array([0, 1]))
+    assert int(engine.fetch()["n"][0]) == 1
     engine.load_bins(None, None)
     engine.set_expected(np.ones(10))
-    engine.reset(1, 70)                    # 141x141: fine for the banded kernel ...
-    with pytest.raises(PupError):          # ... but the expected-only pass needs the tile in LDS
-        engine.accumulate(np.array([100], np.int32), np.array([100], np.int32), np.array([0, 1]), mode=0x02)
+    engine.reset(1, 70)                    # 141x141 expected-only pass: by diagonals, no LDS tile
+    engine.accumulate(np.array([100], np.int32), np.array([100], np.int32), np.array([0, 1]), mode=0x02)
+    got = engine.fetch()
+    assert int(got["num"][0].sum()) == 141 + 2 * sum(141 - d for d in range(1, 10))      # ones on |d| < 10, NaN beyond
     engine.set_expected(None)
 
 
