@@ -89,9 +89,11 @@ def source_key():
     """Hash of the kernel sources: measured HBM traffic (profiles/traffic.json) is only quoted for the kernels it was
     measured on."""
     h = hashlib.sha1()
-    for f in ("pup_kernels.hpp", "pup_engine.hip"):
-        with open(os.path.join(ROOT, "coolpuppy_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
+    csrc = os.path.join(ROOT, "coolpuppy_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):                  # every kernel / engine source: the staged kernels live in their own headers
+        if f.endswith((".hpp", ".hip", ".cpp", ".h")):
+            with open(os.path.join(csrc, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]
 
 
@@ -585,6 +587,7 @@ def main():
         if os.path.exists(tpath) and a.gpus == 1 and a.variant == 0:
             try:
                 tj = json.load(open(tpath))
+                tj = tj.get("entries", {}).get(workload_key(a), tj)       # one entry per measured workload (pad 10, pad 25, ...)
                 if tj.get("workload_key") == workload_key(a) and tj.get("source_key") == source_key():
                     traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
             except Exception:
@@ -599,22 +602,46 @@ def main():
         except Exception:
             pass
         staged = staged_regions > 0
+        family = eng.last_kernel()                       # which kernel family the timed calls ran (pup_last_kernel)
         reg_rows, reg_cols = PileupEngine.staged_region(a.pad)
         if a.variant & 128:
             reg_rows = 64
+        if family.startswith("wide"):
+            reg_rows = reg_cols = 128
+            wg = PileupEngine.wide_geometry(W)
+            kernel_name = (f"pup::pileup_wide_kernel<{wg['CH']}, false, {'true' if family == 'wide_fact' else 'false'}> (K1w: persistent 16-wave "
+                           f"workgroups, 128 x 128 regions staged in LDS from the dense band; {wg['NGr']} x {wg['NGc']} sub-windows of "
+                           f"{wg['SH']} x {wg['SW']} bins, 4 column panels of {wg['CH']} cells per lane)")
+        elif family == "staged":
+            kernel_name = (f"pup::pileup_staged_kernel<{W}, false, {reg_rows}, {reg_cols}, {reg_rows // 8}, {1 if a.variant & 64 else 2}, "
+                           f"{'false' if a.variant & 4 else 'true'}, false, {'false' if a.variant & (1 << 27) else 'true'}> (persistent workgroups, "
+                           f"{reg_rows} x {reg_cols} regions staged in LDS, ROI and control tile in one pass)")
+        else:
+            kernel_name = (f"pup::pileup_regtile_kernel<{W}, false>" if family == "regtile" else
+                           (f"pup::pileup_band_kernel<{4 if W <= 64 else (8 if W <= 128 else 16)}, false>" if family == "band" else family))
+        # the kernel's own bound when it piles up from LDS-staged regions: every window reads its W x W cells (f64) from LDS and
+        # adds them with f64 VALU instructions; every region is written to LDS once
+        lds_bytes = (n_all // a.gpus) * W * W * 8 + staged_regions * reg_rows * reg_cols * 8
+        lds_peak = 256 * 256 * 2.4                         # CUs x B/clk/CU (ds_read_b64, MI355X_MICROARCH.md) x GHz = GB/s
+        lds_frac = lds_bytes / (k1_ms * 1e-3) / 1e9 / lds_peak
+        valu_f64_frac = ((n_all // a.gpus) * W * W / 64.0 * 4.0) / (1024 * 2.4e9 * k1_ms * 1e-3)    # v_add_f64 wave instructions x 4 clk / SIMD clocks
         roofline = {
-            "bound": "hbm",
-            "kernel": (f"pup::pileup_staged_kernel<{W}, false, {reg_rows}, {reg_cols}, {reg_rows // 8}, {1 if a.variant & 64 else 2}, "
-                       f"{'false' if a.variant & 4 else 'true'}, false, {'false' if a.variant & (1 << 27) else 'true'}> (persistent workgroups, {reg_rows} x {reg_cols} regions staged "
-                       "in LDS, ROI and control tile in one pass)"
-                       if staged else (f"pup::pileup_regtile_kernel<{W}, false>" if W <= 31 else
-                                       f"pup::pileup_band_kernel<{4 if W <= 64 else (8 if W <= 128 else 16)}, false>")),
+            # what binds the dominant kernel: the staged kernels read 0.9 x the compulsory HBM bytes once and are LDS / f64-issue
+            # bound; the per-window kernels are bound by what they pull from L2 / HBM
+            "bound": "lds" if staged else "hbm",
+            "kernel": kernel_name,
+            "kernel_family": family,
             "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
-            # the physically bounded fraction: COMPULSORY bytes (what any kernel must read once) / kernel time / peak.  (The
+            # the HBM fraction: MEASURED bytes (rocprofv3 PMC, profiles/traffic.json) / kernel time / peak when a measurement of
+            # these kernel sources and this workload is on file, else COMPULSORY bytes (what any kernel must read once).  (The
             # contract's A/P with the SURVEY 8(d) per-window bytes is algorithmic_over_peak: > 1 by construction for a kernel
             # that serves hundreds of overlapping windows from one staged region.)
-            "frac": None if frac_comp is None else round(frac_comp, 4),
-            "frac_is": "frac_compulsory",
+            "frac": (None if frac_comp is None else round(frac_comp, 4)) if frac_traffic is None else round(frac_traffic, 4),
+            "frac_is": "frac_compulsory" if frac_traffic is None else "frac_traffic",
+            "lds_frac": round(lds_frac, 4) if staged else None,
+            "lds_achieved_GBps": round(lds_bytes / (k1_ms * 1e-3) / 1e9, 1) if staged else None,
+            "lds_peak_GBps": round(lds_peak, 1),
+            "valu_f64_frac": round(valu_f64_frac, 4) if staged else None,
             "frac_compulsory": None if frac_comp is None else round(frac_comp, 4),
             "frac_table_pass": None if frac_table is None else round(frac_table, 4),
             "frac_traffic": None if frac_traffic is None else round(frac_traffic, 4),
@@ -639,10 +666,6 @@ def main():
             "prepass_ms_per_launch": round(st.get("prepare_ms", 0.0) / launches, 4),
         }
         if staged:
-            # what actually limits the staged kernel is not HBM: every window reads its W x W cells (f64) from the staged
-            # region in LDS, every region is written there once.  Analytic byte count against ds_read_b64's chip-wide peak
-            lds_bytes = (n_all // a.gpus) * W * W * 8 + staged_regions * reg_rows * reg_cols * 8
-            lds_peak = 256 * 256 * 2.4                     # CUs x B/clk/CU (ds_read_b64, MI355X_MICROARCH.md) x GHz = GB/s
             roofline["lds"] = {"bytes_per_launch": int(lds_bytes), "achieved": round(lds_bytes / (k1_ms * 1e-3) / 1e9, 1),
                            "peak": round(lds_peak, 1), "unit": "GB/s",
                            "frac": round(lds_bytes / (k1_ms * 1e-3) / 1e9 / lds_peak, 4),
@@ -714,8 +737,10 @@ def main():
             "ms_per_step": primary["ms_per_step"], "higher_is_better": True, "scaling": primary["scaling"],
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[2]: synthetic hg38 10kb CSR + 1e6 random cis BEDPE pairs, pad=10, "
-                            "nshifts=10, balanced, ignore_diags=2",
+                "workload": ("BASELINE configs[2]: " if (a.pad == 10 and a.pairs == 1_000_000 and a.nshifts == 10) else
+                             "BASELINE configs[2] table with other windows: ") +
+                            f"synthetic hg38 10kb CSR + {a.pairs:.0e} random cis BEDPE pairs, pad={a.pad}, "
+                            f"nshifts={a.nshifts}, balanced, ignore_diags=2",
                 "order": "reference stream",
                 "nnz": int(wl["bin2_id"].shape[0]), "nbins": int(wl["bin1_offset"].shape[0] - 1),
                 "pairs": primary["pairs"], "nshifts": a.nshifts, "pad": a.pad, "snippets_per_step": primary["snippets_per_step"],

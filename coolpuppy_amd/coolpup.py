@@ -372,6 +372,7 @@ class CoordCreator:
         by their common divisor (bin-aligned anchors).  The row number makes every key unique, so numpy's vectorised
         unstable sort yields the stable order.  Falls back to pandas when the fields do not fit 63 bits.  The chromosome
         codes are kept for the region selections (_cache) — the same factorisation would be done there."""
+        self._sorted_codes = None                # (an early return below must not leave a previous run's codes behind)
         n = len(iv)
         s1, s2 = iv["start1"].to_numpy(), iv["start2"].to_numpy()
         if n < 2 or s1.dtype.kind not in "iu" or s2.dtype.kind not in "iu" or s1.min() < 0 or s2.min() < 0:

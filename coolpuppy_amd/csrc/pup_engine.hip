@@ -153,6 +153,10 @@ struct pup_ctx {
         exp_far_igd = igd; exp_far_val = h_exp_reg.empty() ? 0 : far;
         return exp_far_val;
     }
+    // the remembered verdict belongs to (table, index, expected, tuning): whatever replaces one of them forgets it — a
+    // speculative launch on a stale verdict could stage from a band table that no longer exists
+    void forget_hints() { hint_sig.clear(); hint_blocks = -1; hint_have_verdict = false; hint_sparse_calls = 0; }
+    int hint_sparse_calls = 0;               // calls answered "too sparse" from memory since the block count was last measured
     bool profiling = false;      // HIP events around the kernels
     bool count_pixels = false;   // kernels also count the pixels inside the windows (statistics; costs a little)
     pup_stats stats{};
@@ -375,7 +379,7 @@ int pup_load_pixels(pup_ctx* c, const int64_t* bin1_offset, const void* bin2_id,
                     (long long)bin1_offset[0], (long long)bin1_offset[nbins], (long long)nnz);
     int rc = bind(c); if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->have_px = false; c->have_idx = false;
+    c->have_px = false; c->have_idx = false; c->forget_hints();
     c->tbits_state = 0;                                  // (the bitmap of the previous table: rebuilt on first use; its memory is kept)
     HIPCHK(c, c->indptr.reserve((size_t)nbins + 1));
     HIPCHK(c, c->px.reserve((size_t)nnz + 64));         // +64: K3 reads pixel pairs (16-byte loads) across a row's end
@@ -439,7 +443,7 @@ int pup_build_index(pup_ctx* c, const int64_t* chrom_offset, int32_t n_chroms, i
     const long long bytes = nblocks * (long long)sizeof(pup::IdxBlock);
     int rc = bind(c); if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->have_idx = false;
+    c->have_idx = false; c->forget_hints();
     if (max_bytes > 0 && bytes > max_bytes)
         return fail(c, PUP_ENOMEM, "pup_build_index: index needs %lld bytes, limit is %lld", bytes, (long long)max_bytes);
     size_t free_b = 0, total_b = 0;
@@ -560,7 +564,7 @@ int pup_load_bins(pup_ctx* c, const double* weight, const double* cov) {
     if (!c->have_px) return fail(c, PUP_ESTATE, "pup_load_bins: call pup_load_pixels first");
     int rc = bind(c); if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->have_weight = c->have_cov = false; c->have_bal = false;
+    c->have_weight = c->have_cov = false; c->have_bal = false; c->forget_hints();
     if (weight) {
         HIPCHK(c, c->weight.reserve((size_t)c->nbins));
         HIPCHK(c, hipMemcpy(c->weight.p, weight, (size_t)c->nbins * sizeof(double), hipMemcpyHostToDevice));
@@ -619,6 +623,7 @@ int pup_set_expected(pup_ctx* c, const double* expected, int64_t n) {
     if (n < 0 || (n > 0 && !expected)) return fail(c, PUP_EINVAL, "pup_set_expected: bad arguments");
     int rc = bind(c); if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));   // earlier launches may still read the old vector
+    c->forget_hints();
     c->nexp = 0; c->n_exp_regions = 0; c->have_exp_pair = false;
     c->h_exp.clear(); c->h_exp_reg.clear(); c->h_exp_bounds.clear(); c->exp_far_igd = -1;
     if (n > 0) {
@@ -648,6 +653,7 @@ int pup_set_expected_table(pup_ctx* c, const int32_t* start, const int32_t* end,
     }
     int rc = bind(c); if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->forget_hints();
     c->nexp = 0; c->n_exp_regions = 0; c->have_exp_pair = false;
     c->h_exp.clear(); c->h_exp_reg.clear(); c->h_exp_bounds.clear(); c->exp_far_igd = -1;
     HIPCHK(c, c->exp_regions.reserve((size_t)n_regions));
@@ -779,9 +785,14 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     sig.push_back(ignore_diags); sig.push_back(flip_from ? 1 : 0); sig.push_back(c->variant & (4 | 64 | 128 | 256 | 512)); sig.push_back(extra ? 1 : 0);
     for (int t = 0; t <= T; ++t) sig.push_back(tile_ptr[t]);
     if (flip_from) for (int t = 0; t < T; ++t) sig.push_back(flip_from[t]);
-    const bool known = (sig == c->hint_sig) && c->hint_blocks >= 0;
+    bool known = (sig == c->hint_sig) && c->hint_blocks >= 0;
     if (known && c->h_flags[5] == c->hint_ticket) c->hint_blocks = (long long)c->h_flags[4];   // the previous call's count has landed
-    if (known && !force && c->hint_blocks * min_per_block > n) return 1;    // too sparse last time: per-window kernels
+    if (known && !force && c->hint_blocks * min_per_block > n) {
+        // too sparse last time: per-window kernels — but window POSITIONS are not part of the signature, so every 16th such
+        // call measures the block count again (as a first call does) instead of trusting the memory for ever
+        if (++c->hint_sparse_calls % 16 != 0) return 1;
+        known = false;
+    }
 
     // block rows are numbered compactly over the genome (fewer key bits = fewer radix passes)
     long long max_len = 1, n_brows = 0;
@@ -994,8 +1005,8 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     // the accumulators — is launched only once it is known that the right kernel ran (else the records are dropped and the
     // right one runs)
     bool speculated = false;
-    const bool spec_fact = c->hint_fact, spec_band = c->hint_band;
-    if (known && c->hint_have_verdict) {
+    const bool spec_fact = c->hint_fact, spec_band = c->hint_band && c->band_w > 0;
+    if (known && c->hint_have_verdict && (!c->hint_band || c->band_w > 0)) {
         const int rc1 = launch_k1(spec_fact, spec_band);
         if (rc1 != PUP_OK) return rc1;
         speculated = true;
@@ -1012,7 +1023,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->hint_sig = sig;
         c->hint_blocks = (long long)c->h_flags[4];
-        c->hint_have_verdict = false;
+        c->hint_have_verdict = false; c->hint_sparse_calls = 0;
         if (!force && c->hint_blocks * min_per_block > n) { c->hint_ticket = ticket; return 1; }
     }
     c->hint_ticket = ticket;
@@ -1143,6 +1154,8 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
         }
     }
     const unsigned gk4 = (unsigned)((n_items + 1023) / 1024);
+    int wide_cost = pup::kWideBlockCost;
+    if (const char* e = getenv("COOLPUPPY_AMD_WIDE_COST")) { const int v = atoi(e); if (v > 0) wide_cost = v; }     // experiments
 #define PUP_WKEY_ARGS dr0, dc0, (long long)n, n_items, (const long long*)c->d_segend.p, nseg2t, (const pup::IdxChrom*)c->idx_chrom.p, c->n_chrom, \
         (const unsigned short*)c->bin_chrom.p, (long long)c->nbins, (const int*)c->d_brow.p, W, NG, geo.NGc, geo.SH, geo.SW, BR, BC, sh_br, sh_seg, \
         seg_shift, ignore_diags + W - 1, far_gap, c->band_w
@@ -1166,7 +1179,7 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
         hipLaunchKernelGGL((pup::staged_table_kernel<unsigned>), dim3(gt), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
                            (const unsigned*)(c->d_cnt32.p + 3), n_items, (const unsigned*)c->d_k32b.p,
                            (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
-                           c->n_chrom, geo.SH, geo.SW, RS, RS, NG, pup::kWideBlockCost, sh_br, sh_seg, sh_seg, seg_shift, 0, n_eregs, 0, d_eregs,
+                           c->n_chrom, geo.SH, geo.SW, RS, RS, NG, wide_cost, sh_br, sh_seg, sh_seg, seg_shift, 0, n_eregs, 0, d_eregs,
                            (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G);
     } else {
         se = rocprim::radix_sort_pairs<Radix10>(c->d_sorttmp.p, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_win.p, c->d_win2.p,
@@ -1179,7 +1192,7 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
         hipLaunchKernelGGL((pup::staged_table_kernel<unsigned long long>), dim3(gt), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
                            (const unsigned*)(c->d_cnt32.p + 3), n_items, (const unsigned long long*)c->d_keys2.p,
                            (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
-                           c->n_chrom, geo.SH, geo.SW, RS, RS, NG, pup::kWideBlockCost, sh_br, sh_seg, sh_seg, seg_shift, 0, n_eregs, 0, d_eregs,
+                           c->n_chrom, geo.SH, geo.SW, RS, RS, NG, wide_cost, sh_br, sh_seg, sh_seg, seg_shift, 0, n_eregs, 0, d_eregs,
                            (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G);
     }
     hipLaunchKernelGGL(pup::staged_publish_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned*)(c->d_cnt32.p + 3), 1,
@@ -1200,6 +1213,11 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
     wa.WF = W; wa.NGc = geo.NGc; wa.NG = NG; wa.SH = geo.SH; wa.SW = geo.SW; wa.NPC = geo.NPC;
     wa.rec_seg = c->wrec_seg.p; wa.rec_f64 = c->wrec_f64.p; wa.rec_num = c->wrec_num.p;
     wa.timing = nullptr;
+    {   // shares of the four waves of a panel, oldest first (see slice_of); COOLPUPPY_AMD_WIDE_SHARES="a,b,c" (cumulative, of 256) for experiments
+        int sh3[3] = {80, 151, 211};               // measured, pad 25: equal shares 3.30 ms, 73/140/202 3.15, 78/148/208 2.92, 80/151/211 2.87, 82/154/213 2.90
+        if (const char* e = getenv("COOLPUPPY_AMD_WIDE_SHARES")) { int x, y, z; if (sscanf(e, "%d,%d,%d", &x, &y, &z) == 3 && 0 <= x && x <= y && y <= z && z <= 256) { sh3[0] = x; sh3[1] = y; sh3[2] = z; } }
+        wa.share[0] = sh3[0]; wa.share[1] = sh3[1]; wa.share[2] = sh3[2];
+    }
     if (c->debug_phases & 4) {
         HIPCHK(c, c->d_timing.reserve((size_t)G * 16 * 8));
         HIPCHK(c, hipMemsetAsync(c->d_timing.p, 0, (size_t)G * 16 * 8 * sizeof(long long), c->stream));
@@ -1984,6 +2002,7 @@ int pup_set_tuning(pup_ctx* c, int32_t chunk_snippets, int32_t variant) {
     if (!c) return PUP_EINVAL;
     if (chunk_snippets < 0) return fail(c, PUP_EINVAL, "pup_set_tuning: negative chunk size");
     c->chunk_snippets = chunk_snippets;
+    c->forget_hints();
     c->variant = (variant & 0xff) | ((variant >> 19) & 0x300);   // bit 27 -> 256: never stage from the dense band; bit 28 -> 512: tile pairs one by one
     c->group_waves = (variant >> 8) & 0xffff;
     c->debug_phases = (variant >> 24) & 0x7;

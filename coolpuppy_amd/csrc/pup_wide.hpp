@@ -27,7 +27,8 @@
 namespace pup {
 
 constexpr int kWideRec = 64 * 64;                     // cells of a partial record: sub-window row p, column q at p * 64 + q
-constexpr int kWideBlockCost = 24;                    // staging one region, in (sub-)windows' worth of time (workgroup ranges)
+constexpr int kWideBlockCost = 100;                   // staging one region, in (sub-)windows' worth of time (workgroup ranges): measured,
+                                                      // pad 25: ~12 k clocks per block (HBM round trip, store burst, two barriers) at 138 per window
 constexpr int kWideMaxRows = 64;                      // sub-window rows: a lane each
 constexpr int kWideMaxCH = 13;                        // cells per lane: register budget of 16 waves x 128 VGPRs
 
@@ -44,6 +45,7 @@ struct WideArgs {
     double*               rec_f64;    // [nrec][kWideRec]
     unsigned*             rec_num;    // [nrec][kWideRec]
     long long*            timing;     // phase clocks per wave, [G][16][8], or nullptr
+    int                   share[3];   // cumulative shares (in 1/256) of a block's windows of the first three waves of a panel
 };
 
 // geometry of a call, shared by host and device: sub-window grid and column panels for window width W
@@ -361,8 +363,15 @@ void pileup_wide_kernel(K1Args a, WideArgs wa) {
     };
     // the NW / NPC waves of a panel share the block's windows in equal contiguous slices; the NPC waves that own slice `sub`
     // walk the same batches, and batch t's bookkeeping falls to panel t % NPC
+    // Not equal shares: the SIMD favours its oldest wave, and the four waves of a panel sit on one SIMD (wave w: SIMD w % 4 =
+    // panel) — with equal slices the youngest finished 35 % after the oldest and everybody waited at the barrier (phase
+    // clocks, pad 25).  Shares in 1/256 of the block's windows, cumulative, for nsub = 4
     auto slice_of = [&](int n, int& lo, int& hi) __attribute__((always_inline)) {
-        lo = (int)(((long long)n * sub) / nsub); hi = (int)(((long long)n * (sub + 1)) / nsub);
+        if (nsub == 4) {
+            const int cum_lo = sub == 0 ? 0 : (sub == 1 ? wa.share[0] : (sub == 2 ? wa.share[1] : wa.share[2]));
+            const int cum_hi = sub == 0 ? wa.share[0] : (sub == 1 ? wa.share[1] : (sub == 2 ? wa.share[2] : 256));
+            lo = (int)(((long long)n * cum_lo + 128) >> 8); hi = sub == 3 ? n : (int)(((long long)n * cum_hi + 128) >> 8);
+        } else { lo = (int)(((long long)n * sub) / nsub); hi = (int)(((long long)n * (sub + 1)) / nsub); }
     };
     auto windows = [&](const Cur& g, int wf, auto&& mid) __attribute__((always_inline)) {
         int lo, hi;

@@ -162,12 +162,16 @@ def native_comm(eng):
         _fields_ = [("internal", C.c_char * 128)]
     uid = UniqueId()
     rccl, why = None, ""
+    # every rank-local step that can fail is caught HERE and turned into ok = False: a rank that raised before joining the
+    # agreement below would leave its peers waiting in it (PupError / AttributeError escaped past `except OSError`)
     try:
+        if os.environ.get("COOLPUPPY_AMD_TEST_FAIL_NATIVE_RANK", "") == str(rank):     # tests: one rank fails, all must fall back
+            raise RuntimeError("native communicator set-up failed on purpose (test hook)")
         rccl = _ffi.rccl()
         if rank == 0 and rccl.ncclGetUniqueId(C.byref(uid)) != 0:
             rccl, why = None, "ncclGetUniqueId failed"
-    except OSError as e:
-        why = str(e)
+    except Exception as e:       # noqa: BLE001 - any failure must reach the agreement
+        rccl, why = None, f"{type(e).__name__}: {e}"
     if not _all_ok(d, rccl is not None, eng.device_id):      # rank 0's failure reaches everybody BEFORE the broadcast
         _NATIVE_COMMS[key] = (None, None)
         raise RuntimeError(why or "librccl unavailable on another rank")
@@ -177,17 +181,21 @@ def native_comm(eng):
     d.broadcast(t, src=0)
     C.memmove(C.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
     comm = C.c_void_p()
-    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
-    if torch.cuda.is_available():
-        torch.cuda.set_device(eng.device_id)
-    eng.sync()                                               # binds the engine's device in the HIP runtime
-    rc = rccl.ncclCommInitRank(C.byref(comm), world, uid, rank)
+    rc, why = -1, ""
+    try:
+        rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+        if torch.cuda.is_available():
+            torch.cuda.set_device(eng.device_id)
+        eng.sync()                                           # binds the engine's device in the HIP runtime
+        rc = rccl.ncclCommInitRank(C.byref(comm), world, uid, rank)
+    except Exception as e:       # noqa: BLE001
+        rc, why = -1, f"{type(e).__name__}: {e}"
     if not _all_ok(d, rc == 0 and bool(comm.value), eng.device_id):
         if rc == 0 and comm.value:
             rccl.ncclCommDestroy.argtypes = [C.c_void_p]
             rccl.ncclCommDestroy(comm)
         _NATIVE_COMMS[key] = (None, None)
-        raise RuntimeError("ncclCommInitRank failed" + ("" if rc else " on another rank"))
+        raise RuntimeError(why or ("ncclCommInitRank failed" + ("" if rc else " on another rank")))
     _NATIVE_COMMS[key] = (comm.value, rccl)
     return comm.value
 

@@ -268,6 +268,13 @@ class PileupEngine:
         return (128 if big else 64), 128
 
     @staticmethod
+    def wide_geometry(W):
+        """Sub-window grid of the wide staged kernel for window width W — wide_geometry() of csrc/pup_wide.hpp."""
+        ngr = -(-W // 64); sh = -(-W // ngr)
+        ngc = -(-W // 52); sw = -(-W // ngc)
+        return {"NGr": ngr, "NGc": ngc, "SH": sh, "SW": sw, "NPC": 4, "CH": -(-sw // 4)}
+
+    @staticmethod
     def block_order(r0, c0, chrom_offset, tile=None, block=None, pad=10, ooe=False, extra=False):
         """Permutation that puts snippets in the order the workgroup-staged kernel walks them inside every tile:
         (tile, block row, block column, r0, c0), blocks of (rows - W + 1) x (columns - W + 1) top-left corners
@@ -402,6 +409,10 @@ def host_windows(st1, st2, code, shift, sign, nshifts, resolution, off1, off2, l
     n = st1.shape[0]
     cap = n * (1 + int(nshifts))
     code = None if code is None else _as(code, np.int32)
+    if shift is not None and np.asarray(shift).dtype.itemsize > 4 and len(shift) and \
+            (int(np.max(shift)) > 2**31 - 1 or int(np.min(shift)) < -2**31):
+        # (CoordCreator._draw_raw draws int64 shifts when |minshift| / |maxshift| >= 2^31: they must not be truncated silently)
+        raise ValueError("control shifts beyond +-2^31 bp do not fit the int32 shifts of pup_host_windows")
     shift = None if shift is None else _as(shift, np.int32)
     sign = None if sign is None else _as(sign, np.int32)
     r0, c0 = np.empty(cap, np.int32), np.empty(cap, np.int32)      # per-region intermediates: group_tiles makes the DMA source

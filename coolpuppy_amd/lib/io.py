@@ -508,6 +508,29 @@ def _write_annotation_pytables(h5, frame):
         _pt_array_attrs(h5, key)
 
 
+class _ArrayUnpickler(pickle.Unpickler):
+    """Unpickler for the object blocks of a pandas "fixed" store: a numpy object ndarray of plain Python values.  Only the
+    numpy array / dtype / scalar reconstructors and the builtin value types resolve; anything else in the stream (a crafted
+    file could name os.system) raises instead of being imported — pd.read_hdf, which the reference uses, offers no such guard."""
+    _NUMPY = {"_reconstruct", "ndarray", "dtype", "scalar", "_frombuffer"}
+    _BUILTINS = {"list", "tuple", "dict", "set", "frozenset", "str", "bytes", "bytearray", "int", "float", "complex", "bool",
+                 "slice", "range", "NoneType"}
+
+    def find_class(self, module, name):
+        if module.split(".")[0] == "numpy" and name in self._NUMPY:
+            return super().find_class(module, name)
+        if module == "builtins" and name in self._BUILTINS:
+            return super().find_class(module, name)
+        if (module, name) == ("_codecs", "encode"):      # how protocol <= 2 spells the array's byte string (str -> bytes, nothing else)
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f".clpy annotation: refusing to unpickle {module}.{name} (only numpy arrays of plain values are read)")
+
+
+def _restricted_loads(data):
+    import io as _io
+    return _ArrayUnpickler(_io.BytesIO(data)).load()
+
+
 def _read_annotation_pytables(h5):
     """A PyTables "fixed" frame (written by the reference through pandas, or by _write_annotation_pytables) -> DataFrame."""
     at = h5.attrs("annotation")
@@ -521,7 +544,7 @@ def _read_annotation_pytables(h5):
         key = f"annotation/block{i}_values"
         battrs = h5.attrs(key)
         if str(battrs.get("CLASS", "")) == "VLARRAY":
-            vals = pickle.loads(h5.read_vlen_bytes(key)[0])       # the file's own pickled object ndarray, (rows, columns)
+            vals = _restricted_loads(h5.read_vlen_bytes(key)[0])  # the file's own pickled object ndarray, (rows, columns)
         else:
             vals = h5.read(key)
         vals = np.asarray(vals).reshape(len(index), len(items)) if len(items) else vals

@@ -278,3 +278,21 @@ def test_annotation_is_the_store_pandas_writes(tmp_path):
             else:
                 assert x == y or (isinstance(y, float) and np.isnan(y) and np.isnan(x)), (c, i, x, y)
     assert back["n"].dtype == np.int64 and back["flag"].dtype == bool and list(back["flag"]) == [False, True, False, False] and back["score"].dtype == np.float64
+
+
+def test_clpy_object_blocks_are_read_with_a_restricted_unpickler():
+    """The pickled object columns of a PyTables "fixed" store are data, not code: numpy arrays of plain values load, anything
+    else in the stream is refused (an untrusted .clpy must not be able to run os.system through pickle.loads)."""
+    import pickle
+    from coolpuppy_amd.lib import io as pio
+    arr = np.empty((2, 2), dtype=object)
+    arr[:] = [["chr1", 5], [None, 2.5]]
+    back = pio._restricted_loads(pickle.dumps(arr, protocol=2))
+    assert back.shape == (2, 2) and back[0, 0] == "chr1" and back[1, 0] is None and back[1, 1] == 2.5
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ("true",))
+    with pytest.raises(pickle.UnpicklingError):
+        pio._restricted_loads(pickle.dumps(Evil()))

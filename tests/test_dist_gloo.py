@@ -174,3 +174,55 @@ def test_two_ranks_native_rccl_allreduce(hip_lib, tmp_path):
     if device_count() < 2:
         pytest.skip("one GPU on this box: RCCL cannot place two ranks on one device — " + text[-300:].replace("\n", " | "))
     raise AssertionError(text[-3000:])
+
+
+FAIL_WORKER = r'''
+import os, sys
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+from coolpuppy_amd import dist as pdist
+
+rank = int(sys.argv[1])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=rank, world_size=2)
+
+class FakeEngine:                      # native_comm only needs the device number and a sync() before ncclCommInitRank
+    device_id = 0
+    def sync(self):
+        pass
+
+try:
+    comm = pdist.native_comm(FakeEngine())
+    print("RANK", rank, "GOT", comm)
+except RuntimeError as e:
+    print("RANK", rank, "FELLBACK", str(e)[:80])
+# both ranks are still in step: a collective after the failed set-up completes
+import torch
+t = torch.ones(1)
+dist.all_reduce(t)
+assert int(t[0]) == 2
+dist.destroy_process_group()
+'''
+
+
+def test_native_comm_failure_on_one_rank_makes_every_rank_fall_back(tmp_path):
+    """ADVICE r3 / VERDICT r3 item 9: a rank whose communicator set-up fails (here: forced on rank 0 by the test hook, before
+    it even loads librccl) must still join the agreement, and EVERY rank must leave native_comm with the exception — a
+    mixture would leave one rank in torch's all_reduce and the other in ncclAllReduce, for ever."""
+    port = 31500 + (os.getpid() % 2000)
+    script = tmp_path / "fail_worker.py"
+    script.write_text(FAIL_WORKER.format(root=ROOT, port=port))
+    env = dict(os.environ, COOLPUPPY_AMD_TEST_FAIL_NATIVE_RANK="0", MASTER_ADDR="127.0.0.1")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, text=True)
+             for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("the ranks dead-locked after a one-sided communicator failure")
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out[-2000:]
+        assert f"RANK {r} FELLBACK" in out, out[-2000:]

@@ -77,11 +77,21 @@ sys.path.insert(0, ROOT)
 import bench as bench_mod                                     # workload / kernel-source keys exactly as bench.py computes them
 c = bench["config"]
 args = bench_mod.parse(["--pairs", str(c["pairs"]), "--nshifts", str(c["nshifts"]), "--pad", str(c["pad"])])
-json.dump({"workload_key": bench_mod.workload_key(args), "source_key": bench_mod.source_key(),
-           "hbm_bytes_per_launch": hbm, "kernel": k1, "source": f"profiles/{tag}_pmc_summary.json",
-           "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB->bytes, FETCH_SIZE x calibration "
-                     "factor measured on balance_pixels_kernel (known 8 B/pixel stream) in the same run; quoted by "
-                     "bench.py only while coolpuppy_amd/csrc is unchanged (source_key)"},
-          open(os.path.join(out, "traffic.json"), "w"), indent=1)
+entry = {"workload_key": bench_mod.workload_key(args), "source_key": bench_mod.source_key(),
+         "hbm_bytes_per_launch": hbm, "kernel": k1, "source": f"profiles/{tag}_pmc_summary.json",
+         "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB->bytes, FETCH_SIZE x calibration "
+                   "factor measured on balance_pixels_kernel (known 8 B/pixel stream) in the same run; quoted by "
+                   "bench.py only while coolpuppy_amd/csrc is unchanged (source_key)"}
+# one entry per measured workload (the default bench, --pad 25, ...): bench.py looks its own workload key up
+tpath = os.path.join(out, "traffic.json")
+book = {"entries": {}}
+if os.path.exists(tpath):
+    try:
+        old = json.load(open(tpath))
+        book = old if "entries" in old else {"entries": {old["workload_key"]: old}}
+    except Exception:
+        pass
+book["entries"][entry["workload_key"]] = entry
+json.dump(book, open(tpath, "w"), indent=1)
 print(json.dumps(doc["k1"], indent=1)); print(json.dumps(doc.get("calibration"), indent=1))
 print(open(os.path.join(out, f"{tag}_kernel_stats.csv")).read()[:1500])
