@@ -58,6 +58,11 @@ def parse(argv=None):
     ap.add_argument("--ref-algo-sample", type=int, default=300_000,
                     help="snippets timed on the algorithm-faithful scipy restatement, one core (0 = skip)")
     ap.add_argument("--no-cache", action="store_true")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4],
+                    help="BASELINE.json configs[k]: 2 = 1e6 cis pairs + 10 control shifts (default, the headline); 3 = the same pairs by "
+                         "distance band x strand pair (42 tiles); 4 = 5e5 inter-chromosomal pairs, pad 25 — 3 and 4 run through the "
+                         "library's plan path with its region / region-pair sharding (bench_plan.py)")
+    ap.add_argument("--trans-nnz", type=int, default=50_000_000, help="--config 4: inter-chromosomal pixels added to the table")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the timing of the public pileup() call (N=1 only)")
     ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
                     help="which measurement is the JSON line's `value` for N>1 (the other one is the secondary field): "
@@ -361,6 +366,9 @@ def main():
         a.gpus = world
     if a.scaling == "auto" or world == 1:
         a.scaling = "strong"                  # N=1: the whole workload either way
+    if a.config != 2:
+        import bench_plan
+        return bench_plan.main_plan(a, rank, world, local_rank, sys.modules[__name__])
 
     wl = load_workload(a, rank, world)
     ref_algo = ref_keep = None

@@ -1,0 +1,245 @@
+"""bench.py --config 3 | 4: the grouped and the inter-chromosomal BASELINE configurations, timed through the LIBRARY's plan path.
+
+BASELINE.json quotes two configurations on 8 GPUs that the default bench (configs[2]) does not cover:
+  configs[3]  the configs[2] pairs piled up by distance band x strand pair (42 tiles), nshifts = 10, chromosomes sharded;
+  configs[4]  5e5 inter-chromosomal pairs over all chromosome-pair blocks, pad = 25 (51 x 51 windows), region PAIRS sharded.
+Here every rank does what PileUpper.pileupsWithControl does (coolpuppy_amd/coolpup.py; reference coolpuppy/coolpup.py:1416-1429
+region pairs, :1495-1531 the merge): regions / region pairs dealt longest-first (dist.shard), windows of its own regions only
+(the control RNG stepped past the others), group table agreed through the swapped region keys, the rank's rows of the pixel
+table uploaded, one plan (make_plan).  The timed step is the engine half of run_plan on coordinates ALREADY RESIDENT in HBM
+(the contract's "inputs resident when the timed region starts"): pup_reset + pup_accumulate per call + the all-reduce of the
+packed tiles (pup_allreduce = RCCL on the engine's stream with the nccl backend).  One JSON line, same keys as the default bench.
+"""
+import hashlib
+import json
+import os
+import sys
+import time
+import warnings
+from functools import partial
+
+import numpy as np
+
+import synth
+
+
+def _trans_cooler_path(a, tmp):
+    return tmp("coolpuppy_amd_bench_cooler_trans_" + hashlib.sha1(f"t1|{a.chroms}|{a.lam}|{a.trans_nnz}".encode()).hexdigest()[:12] + ".npz")
+
+
+def load_table(a, rank, bench):
+    """configs[3]: the default bench table.  configs[4]: the same generator with a.trans_nnz uniformly placed inter-chromosomal
+    pixels added (~5e7).  Built once by rank 0 BEFORE any GPU runtime exists (the generator forks)."""
+    if a.config == 3:
+        path, build = bench.cooler_path(a), lambda: bench.build_cooler(a)
+    else:
+        path = _trans_cooler_path(a, bench._tmp)
+
+        def build():
+            clr = synth.make_cooler(bench._chromsizes(a), binsize=10_000, lam=a.lam, seed=1000, name="synthetic_hg38_10kb",
+                                    parallel=True, trans_nnz=a.trans_nnz)
+            i, c, v = clr.pixel_table()
+            return {"bin1_offset": i, "bin2_id": c, "count": v, "weight": clr.bins()["weight"][:].values, "chrom_offset": clr.chrom_offset}
+    if rank == 0 and (a.no_cache or not os.path.exists(path)):
+        t = time.time()
+        bench._save(path, **build())
+        print(f"[bench] table of configs[{a.config}] built in {time.time()-t:.1f}s -> {path}", file=sys.stderr, flush=True)
+    bench._wait_for(path)
+    z = np.load(path)
+    return {k: z[k] for k in z.files}
+
+
+def main_plan(a, rank, world, local_rank, bench):
+    cool = load_table(a, rank, bench)
+    pad = a.pad if a.pad != 10 or a.config == 3 else 25                   # configs[4] is quoted on pad 25
+    n_pairs = a.pairs if a.config == 3 or a.pairs != 1_000_000 else 500_000
+    nshifts = a.nshifts if a.config == 3 else 0
+
+    import torch
+    import torch.distributed as dist
+    from coolpuppy_amd.build import build_hip
+    if rank == 0:
+        build_hip()
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    if os.environ.get("COOLPUPPY_AMD_BENCH_DEVICE", "") != "":
+        local_rank = int(os.environ["COOLPUPPY_AMD_BENCH_DEVICE"])
+    os.environ["COOLPUPPY_AMD_DEVICE"] = str(local_rank)                  # what dist.local_device() / _engine_for use
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    if a.exchange == "torch":
+        os.environ["COOLPUPPY_AMD_NATIVE_RCCL"] = "0"
+
+    from coolpuppy_amd import coolpup, dist as pdist
+    from coolpuppy_amd.cooler_lite import ArrayCooler
+    clr = ArrayCooler(bench._chromsizes(a), 10_000, cool["bin1_offset"], cool["bin2_id"], cool["count"],
+                      bins={"weight": cool["weight"]}, filename="synthetic_hg38_10kb.cool")
+    if a.config == 3:
+        feats = synth.random_cis_pairs(clr, n_pairs, min_sep=230_000, max_sep=5_000_000, seed=42, strands=True)
+        groupby, cols = ["strand1", "strand2", "distance_band"], ["distance"]
+        modify = partial(coolpup.bin_distance_intervals, band_edges="default")
+    else:
+        feats = synth.random_trans_pairs(clr, n_pairs, seed=43)
+        groupby, cols, modify = [], (), None
+
+    # ---- the library's own sharding, step by step as PileUpper.pileupsWithControl does it ----------------------------
+    t_host = time.time()
+    np.random.seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cc = coolpup.CoordCreator(feats, clr.binsize, features_format="bedpe", flank=pad * clr.binsize, nshifts=nshifts,
+                                  trans=(a.config == 4), chroms=list(clr.chromnames), seed=0)
+        pu = coolpup.PileUpper(clr, cc, control=nshifts > 0, ignore_diags=2)
+    pu.ignore_group_order = False
+    pairs = pu._region_pairs()
+    owned = None
+    pu._owned_rows = None
+    if world > 1:
+        weights = [cc.region_weight(pu._region_tuple(r1), pu._region_tuple(r2)) for r1, r2 in pairs]
+        owned = pdist.shard(len(pairs), weights, rank, world)
+        ext = pu._global_extents
+        pu._owned_rows = coolpup._merge_ranges([min(ext[r1][:2], ext[r2][:2]) for i, (r1, r2) in enumerate(pairs) if i in owned])
+    batches = []
+    for i, (r1, r2) in enumerate(pairs):
+        if owned is not None and i not in owned:
+            cc.skip_region(pu._region_tuple(r1), None if r2 == r1 else pu._region_tuple(r2), control=pu.control)
+            batches.append((r1, r2, None))
+            continue
+        batches.append((r1, r2, pu.region_snippets(r1, r2, groupby=list(groupby), modify_2Dintervals_func=modify, columns=cols)))
+    grouped = bool(groupby)
+    region_groups = None
+    if owned is not None:
+        got = pdist.merge_dicts({i: pu.region_groups(batches[i][2], grouped) for i in owned})
+        region_groups = [got[i] for i in range(len(pairs))]
+    plan = pu.make_plan(batches, list(groupby), grouped=grouped, region_groups=region_groups)
+    t_host = time.time() - t_host
+    if world > 1:
+        pdist.check_same_plan(plan)
+
+    eng = coolpup._engine_for(pu._aclr, local_rank, rows=pu._owned_rows if world > 1 else None)
+    eng.load_bins(cool["weight"], None)
+    eng.set_tuning(0, a.variant)
+    T, W = plan["T"], 2 * plan["pad"] + 1
+    calls = [c for c in plan["calls"] if len(c["r0"])]
+    dev = []
+    for c in calls:
+        dev.append((torch.from_numpy(np.ascontiguousarray(c["r0"], dtype=np.int32)).cuda(),
+                    torch.from_numpy(np.ascontiguousarray(c["c0"], dtype=np.int32)).cuda()))
+    n_local = int(sum(len(c["r0"]) for c in calls))
+    eng.reset(T, plan["pad"])
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        eng.reset(T, plan["pad"])
+        for c, (d0, d1) in zip(calls, dev):
+            eng.accumulate_device(d0.data_ptr(), d1.data_ptr(), len(c["r0"]), c["tile_ptr"], flip_from=c["flip_from"],
+                                  ignore_diags=c["ignore_diags"], mode=c["mode"])
+        if world > 1:
+            pdist.allreduce_engine(eng)      # pup_allreduce (RCCL on the engine's stream) with nccl, host memory with gloo
+
+    # pixel statistics once, outside the timed region
+    eng.set_profiling(1); eng.clear_stats()
+    step(); eng.sync()
+    pix_local = float(eng.stats()["pixels_in_windows"])
+    families = sorted({eng.last_kernel()})
+    eng.set_profiling(0)
+    for _ in range(a.warmup):
+        step()
+    eng.set_profiling(3); eng.clear_stats()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    st = eng.stats()
+    eng.set_profiling(0)
+    out = eng.fetch()
+
+    n_all, pix_all, k1_ms = n_local, pix_local, st["k1_ms"]
+    if world > 1:
+        nn = torch.tensor([float(n_local), pix_local], dtype=torch.float64)
+        tt = torch.tensor([dt, st["k1_ms"]], dtype=torch.float64)
+        if a.backend == "nccl":
+            nn, tt = nn.cuda(), tt.cuda()
+        dist.all_reduce(nn); dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        n_all, pix_all, dt, k1_ms = int(nn[0].item()), float(nn[1].item()), float(tt[0].item()), float(tt[1].item())
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    launches = max(int(st["k1_launches"]), 1)
+    k1 = k1_ms / launches * len(calls)                      # pile-up kernel time of one step (all calls), slowest rank
+    # SURVEY 8(d) algorithmic bytes per window: row pointers, weights, coordinates (+ the trans scalar) + 8 B per pixel inside
+    alg = n_all * (8 * (W + 1) + 16 * W + 12) + 8.0 * pix_all
+    peak = bench.HBM_PEAK_GBPS * a.gpus
+    achieved = alg / (k1 * 1e-3) / 1e9
+    staged = int(st.get("staged_regions", 0)) > 0
+    lds_bytes = (n_all // a.gpus) * W * W * 8
+    lds_peak = 256 * 256 * 2.4
+    roofline = {
+        "bound": "lds" if staged else "hbm", "kernel_family": "+".join(families),
+        "kernel": ("pup::pileup_staged_kernel (K1q, sets of four tile pairs per staging)" if staged else
+                   ("pup::pileup_sparse_kernel<false> (K1s: O(W) per inter-chromosomal window, presence bitmap)" if "sparse" in families
+                    else "+".join(families))),
+        "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
+        # trans windows share nothing (no reuse): the 8(d) bytes are what the kernel must move and frac is a real fraction;
+        # the grouped cis pile-up serves its windows from LDS-staged regions: its own bound is the LDS read rate
+        "frac": round(lds_bytes / (k1 * 1e-3) / 1e9 / lds_peak, 4) if staged else round(achieved / peak, 4),
+        "frac_is": "lds_frac" if staged else "algorithmic_over_peak",
+        "lds_frac": round(lds_bytes / (k1 * 1e-3) / 1e9 / lds_peak, 4) if staged else None,
+        "algorithmic_over_peak": round(achieved / peak, 4), "traffic": None,
+        "kernel_ms_per_step": round(k1, 4), "prepass_ms_per_step": round(st.get("prepare_ms", 0.0) / launches * len(calls), 4),
+        "reduce_ms_per_step": round(st.get("reduce_ms", 0.0) / launches * len(calls), 4),
+        "algorithmic_bytes_per_step": round(alg / a.gpus), "nnz_win_mean": round(pix_all / max(n_all, 1), 1),
+        "engine_calls_per_step": len(calls), "tiles": int(T),
+    }
+    cpu = None
+    if a.gpus == 1 and a.cpu_sample > 0:
+        from oracle import pileup_oracle as po
+        po.build()
+        nthr = max(1, min(a.cpu_threads if a.cpu_threads > 0 else (os.cpu_count() or 1), 64))
+        ref = po.empty_acc(T, plan["pad"])
+        t = time.perf_counter()
+        for c in calls:
+            po.pileup_c_mt(cool["bin1_offset"], cool["bin2_id"], cool["count"], cool["weight"], None, None, c["r0"], c["c0"],
+                           c["flip"], c["tile"], T, plan["pad"], c["ignore_diags"], c["mode"], nthr, acc=ref)
+        t = time.perf_counter() - t
+        same = bool(np.array_equal(out["n"], ref["n"]) and np.array_equal(out["num"], ref["num"])
+                    and np.allclose(out["sum"], ref["sum"], rtol=1e-6, atol=0))
+        cpu = {"value": round(n_all / t, 1), "unit": "snippets/s", "cores": nthr, "kind": "port",
+               "sample": f"all {n_all} snippets of the step on the best-CPU form of the C oracle (oracle/pileup_oracle.c: row-sliced windows, "
+                         f"{nthr} OpenMP threads), {t:.1f}s", "host_cpu_count": os.cpu_count(), "gpu_matches_oracle_on_sample": same}
+    names = {3: f"BASELINE configs[3]: synthetic hg38 10kb CSR + {n_pairs:.0e} cis BEDPE pairs by distance band x strand pair, pad={pad}, nshifts={nshifts}",
+             4: f"BASELINE configs[4]: synthetic hg38 10kb CSR (+ {a.trans_nnz:.0e} trans pixels), {n_pairs:.0e} inter-chromosomal pairs over all chromosome-pair blocks, pad={pad}"}
+    line = {
+        "metric": f"snippets/sec ({W}x{W} windows @10kb, ROI + control snippets accumulated)",
+        "value": round(n_all * a.steps / dt, 1), "unit": "snippets/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": names[a.config], "order": "reference stream (make_plan)", "nnz": int(cool["bin2_id"].shape[0]),
+                   "nbins": int(cool["bin1_offset"].shape[0] - 1), "pairs": n_pairs, "nshifts": nshifts, "pad": pad,
+                   "snippets_per_step": n_all, "tiles": int(T),
+                   "parallelism": (f"{a.gpus} rank(s); " + ("single GPU" if world == 1 else
+                                   ("chromosomes" if a.config == 3 else "chromosome pairs") + " dealt to the ranks longest first (dist.shard), own rows "
+                                   "of the pixel table per rank, one all-reduce of the packed tiles every step")),
+                   "variant": a.variant},
+        "exchange": "none" if world == 1 else ("pup_allreduce (RCCL on the engine's stream)" if a.backend == "nccl" and a.exchange == "native"
+                                                else "torch.distributed.all_reduce on exported buffers"),
+        "host_coordinates_plan_s": round(t_host, 3),
+        "check": {"n": [int(x) for x in out["n"]], "n_sum": int(out["n"].sum())},
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()

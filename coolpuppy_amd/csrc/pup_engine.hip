@@ -100,8 +100,15 @@ struct pup_ctx {
     DevBuf<unsigned char> d_sorttmp;
     // K1w (pup_wide.hpp): partial records of the wide-window staged kernel
     DevBuf<double> wrec_f64; DevBuf<unsigned> wrec_num, wrec_seg;
+    DevBuf<double> cov_rec; DevBuf<unsigned> cov_owner;     // coverage-vector pass beside the staged kernels (cov_vectors_kernel)
     long long wide_min = 20000;              // calls of at least this many wide cis windows take the staged wide kernel
     const char* last_kernel = "";            // which pile-up kernel the last pup_accumulate ran (diagnostics)
+    unsigned warned = 0;                     // bit per reason: a large call left the staged kernels (said once per context, on stderr)
+    void off_staged(unsigned bit, const char* why, long long n) {
+        if ((warned & bit) || getenv("COOLPUPPY_AMD_QUIET")) return;
+        warned |= bit;
+        fprintf(stderr, "[coolpuppy_amd] a pile-up of %lld windows runs on the per-window kernels (several times slower than the staged ones): %s\n", n, why);
+    }
     // the staged kernel takes calls from this many windows on (measured against the per-window kernel on 21-bin windows, round 3:
     // plain 3.3e5 windows 0.49 / 0.44 ms, 6.6e5 0.53 / 0.70; observed over expected 1.1e5 0.45 / 0.50, 3.3e5 0.61 / 1.24)
     long long tiled_min = 400000, tiled_min_ooe = 150000;
@@ -350,7 +357,7 @@ void pup_destroy(pup_ctx* c) {
     c->d_keys.release(); c->d_keys2.release(); c->d_cnt32.release(); c->d_win.release(); c->d_win2.release();
     c->d_starts.release(); c->d_blocks.release();
     c->d_wgfirst.release(); c->d_segend.release(); c->htab_sent.clear(); c->d_sorttmp.release();
-    c->wrec_f64.release(); c->wrec_num.release(); c->wrec_seg.release();
+    c->wrec_f64.release(); c->wrec_num.release(); c->wrec_seg.release(); c->cov_rec.release(); c->cov_owner.release();
     if (c->ev_key) (void)hipEventDestroy(c->ev_key);
     if (c->h_flags) (void)hipHostFree(const_cast<unsigned*>(c->h_flags));
     c->d_k32.release(); c->d_k32b.release();
@@ -493,11 +500,11 @@ int pup_build_index(pup_ctx* c, const int64_t* chrom_offset, int32_t n_chroms, i
         long long widest = 1024;
         if (const char* e = getenv("COOLPUPPY_AMD_BAND_COLUMNS")) {          // tests: start from a narrower band
             const long long v = atoll(e);
-            if (v == 256 || v == 512 || v == 1024) widest = v;
+            if (v == 256 || v == 512 || v == 1024 || v == 2048 || v == 4096) widest = v;
         }
         for (long long BWd = widest; BWd >= 256 && have_mem && !(c->variant & 256); BWd >>= 1) {
             const long long cells = pup::kBandFront + (c->nbins + 129) * BWd;
-            if (!(cells < (1LL << 30) && (size_t)cells * 4 <= fb / 4 + c->band.cap * sizeof(int))) continue;
+            if (!((size_t)cells * 4 <= fb / 4 + c->band.cap * sizeof(int))) continue;     // (64-bit addressed: no cell-count limit)
             HIPCHK(c, c->band.reserve((size_t)cells));
             HIPCHK(c, hipMemsetAsync(c->band.p, 0, (size_t)cells * sizeof(int), c->stream));
             const unsigned gb2 = (unsigned)std::min<long long>((c->nbins + 3) / 4, 1 << 20);
@@ -752,6 +759,23 @@ static void fill_k1_args(pup_ctx* c, pup::K1Args& a, int32_t ignore_diags, uint3
     a.W = c->W; a.ignore_diags = ignore_diags; a.mode = mode;
 }
 
+
+// coverage vectors of the call as a pass of their own (see cov_vectors_kernel): enqueued behind the staged pile-up, adds into
+// the cov slots of the accumulators.  d_segend holds the call's (tile, flip) run ends.
+static int cov_pass(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, uint32_t mode) {
+    const int W = c->W, T = c->T;
+    const size_t L = 2 * (size_t)W, nchunks = (size_t)((n + pup::kCovChunk - 1) / pup::kCovChunk), nrec = nchunks + (size_t)T;
+    HIPCHK(c, c->cov_rec.reserve(nrec * L)); HIPCHK(c, c->cov_owner.reserve(nrec));
+    HIPCHK(c, hipMemsetAsync(c->cov_owner.p, 0, nrec * sizeof(unsigned), c->stream));
+    hipLaunchKernelGGL(pup::cov_vectors_kernel, dim3((unsigned)nchunks), dim3(256), 4 * L * sizeof(double), c->stream, dr0, dc0, (long long)n,
+                       (const long long*)c->d_segend.p, T, (const double*)c->cov.p, (long long)c->nbins, W, (mode & PUP_MODE_TRANSPOSE) ? 1 : 0,
+                       c->cov_rec.p, c->cov_owner.p);
+    hipLaunchKernelGGL(pup::cov_reduce_kernel, dim3((unsigned)((L + 63) / 64), (unsigned)T), dim3(64), 0, c->stream, (const double*)c->cov_rec.p,
+                       (const unsigned*)c->cov_owner.p, (const long long*)c->d_segend.p, W, (int)((size_t)W * W + L), c->acc_f64.p);
+    HIPCHK(c, hipGetLastError());
+    return PUP_OK;
+}
+
 // returns PUP_OK when the call was piled up here (K1q + reduction enqueued), 1 when the per-window kernels must take it,
 // a negative code on error.  ev[0..2]: optional timing events (prepass start, K1 start, K1 end).
 static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const int64_t* tile_ptr, const int64_t* flip_from,
@@ -763,11 +787,11 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     if (forbid || rescale || (mode & (PUP_MODE_EXPECTED | PUP_MODE_TRANSPOSE)) || (c->variant & 2) || !use_idx_t ||
         ignore_diags < 0 || !tiled_supported(W) || n >= 0x7fffffffLL || !(force || n >= ((mode & PUP_MODE_OOE) ? c->tiled_min_ooe : c->tiled_min)) ||
         2 * T > pup::kMaxSegCount || T > pup::kMaxStagedTiles || !c->bin_chrom.p || !c->h_flags || !c->ev_key ||
-        c->nnz + 64 >= (1LL << 30) ||                    // the staged kernel addresses the count table by 32-bit byte offsets
-
         (int)c->h_chroms.size() != c->n_chrom)
         return 1;
-    const bool extra = ((mode & PUP_MODE_COV) && c->have_cov) || c->count_pixels;
+    // coverage vectors do not ride inside the staged kernel any more (they forced its fat geometry): a pass of their own, below
+    const bool cov_sep = (mode & PUP_MODE_COV) && c->have_cov;
+    const bool extra = c->count_pixels;
     const bool small21 = (c->variant & 128) != 0;
     const StagedGeo geo = staged_geometry(W, (mode & PUP_MODE_OOE) != 0, extra, small21);
     const int BR = geo.RSR - W + 1, BC = geo.RSC - W + 1;
@@ -783,6 +807,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     sig.reserve(8 + 2 * (size_t)T);
     sig.push_back(n); sig.push_back(T); sig.push_back(W); sig.push_back((long long)(mode & (PUP_MODE_OOE | PUP_MODE_COV)));
     sig.push_back(ignore_diags); sig.push_back(flip_from ? 1 : 0); sig.push_back(c->variant & (4 | 64 | 128 | 256 | 512)); sig.push_back(extra ? 1 : 0);
+    mode &= ~(uint32_t)(cov_sep ? PUP_MODE_COV : 0);     // (the kernels below never see the bit)
     for (int t = 0; t <= T; ++t) sig.push_back(tile_ptr[t]);
     if (flip_from) for (int t = 0; t < T; ++t) sig.push_back(flip_from[t]);
     bool known = (sig == c->hint_sig) && c->hint_blocks >= 0;
@@ -853,12 +878,12 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     const int n_spans = (int)((n + pup::kSpan - 1) / pup::kSpan);
     const size_t ncnt = 4;                               // [0] ineligible [1] unclear [2] outside the band [3] blocks, then the span counters
     const size_t W2 = (size_t)W * W, Lf = W2 + 2 * (size_t)W;
-    const size_t nrec = (size_t)T * 2 * (size_t)G;       // record (tile * 2 + flip) * G + workgroup
+    const size_t nrec = 8 * (2 * (size_t)T + (size_t)G);  // record slot * (2T + G) + tile * 2 + flip + workgroup (StagedArgs::rec_owner), slots <= 8
     HIPCHK(c, c->d_win.reserve((size_t)n + 8)); HIPCHK(c, c->d_win2.reserve((size_t)n + 8));   // +8: K1q fetches four window values at a time
     if (c->d_segend.cap < htab.size()) c->htab_sent.clear();          // the buffer is about to move
     HIPCHK(c, c->d_segend.reserve(htab.size()));
     // (the records' valid flags live behind the counters: one fill clears both)
-    HIPCHK(c, c->d_cnt32.reserve(ncnt + (size_t)n_spans + (nrec + 3) / 4));
+    HIPCHK(c, c->d_cnt32.reserve(ncnt + (size_t)n_spans + (nrec + 1) / 2));
     HIPCHK(c, c->d_starts.reserve((size_t)n + 1));
     HIPCHK(c, c->d_blocks.reserve((size_t)std::min<long long>(n, (n_brows + 1) * (max_len / BC + 2) * (long long)std::max(nseg_key, 1) * (n_eregs + 1))));   // distinct keys at most
     HIPCHK(c, c->d_wgfirst.reserve((size_t)G + 1));
@@ -914,8 +939,8 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
 
     // ---- prepass, all on the stream -------------------------------------------------------------------------------------
     if (ev) HIPCHK(c, hipEventRecord(ev[0], c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_cnt32.p, 0, (ncnt + (size_t)n_spans + (nrec + 3) / 4) * sizeof(unsigned), c->stream));
-    unsigned char* const d_recvalid = reinterpret_cast<unsigned char*>(c->d_cnt32.p + ncnt + (size_t)n_spans);
+    HIPCHK(c, hipMemsetAsync(c->d_cnt32.p, 0, (ncnt + (size_t)n_spans + (nrec + 1) / 2) * sizeof(unsigned), c->stream));
+    unsigned short* const d_recvalid = reinterpret_cast<unsigned short*>(c->d_cnt32.p + ncnt + (size_t)n_spans);
     const unsigned gk4 = (unsigned)((n + 1023) / 1024);               // key kernel: four windows per thread
     const pup::ExpRegion* d_eregs = n_eregs > 0 ? c->exp_regions.p : nullptr;
     const unsigned ticket = ++c->ticket;
@@ -982,7 +1007,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
         pup::K1Args a{};
         fill_k1_args(c, a, ignore_diags, mode);
         pup::StagedArgs sa{};
-        sa.blocks = c->d_blocks.p; sa.win = c->d_win2.p; sa.wg_first = c->d_wgfirst.p; sa.U = U; sa.PH = H; sa.rec_valid = d_recvalid;
+        sa.blocks = c->d_blocks.p; sa.win = c->d_win2.p; sa.wg_first = c->d_wgfirst.p; sa.U = U; sa.PH = H; sa.rec_owner = d_recvalid; sa.T = T;
         sa.teams = ACC > 1 ? c->d_teams.p + (fact ? 0 : (size_t)U * 16) : nullptr;      // (StagedGeom: 16 waves only with factorised counts)
         sa.debug = c->debug_phases & 0x3;
         sa.timing = nullptr;
@@ -1016,7 +1041,11 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     HIPCHK(c, hipEventSynchronize(c->ev_key));
     if (c->h_flags[3] != ticket) return fail(c, PUP_EHIP, "pup_accumulate: the key kernel's verdict did not arrive");
     const bool band = c->band_w > 0 && !(c->variant & 256) && !extra && c->h_flags[2] == 0;    // every window inside the dense band
-    if (c->h_flags[0] != 0) { c->hint_have_verdict = false; return 1; }   // a window the index does not cover: the per-window kernels take the call
+    if (c->h_flags[0] != 0) {                                              // a window the index does not cover: the per-window kernels take the call
+        c->hint_have_verdict = false;
+        c->off_staged(1u, "some windows are not inside one chromosome (pass inter-chromosomal windows with ignore_diags < 0)", (long long)n);
+        return 1;
+    }
     const bool fact = (!ooe || ooe_clean) && c->h_flags[1] == 0 && !(c->variant & 4);
     if (!known) {
         // first call with this signature: wait for the block count once and decide whether staging pays
@@ -1028,7 +1057,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     }
     c->hint_ticket = ticket;
     if (speculated && (fact != spec_fact || band != spec_band)) {
-        HIPCHK(c, hipMemsetAsync(d_recvalid, 0, nrec, c->stream));     // the wrong kernel's records: dropped
+        HIPCHK(c, hipMemsetAsync(d_recvalid, 0, nrec * sizeof(unsigned short), c->stream));     // the wrong kernel's records: dropped
         speculated = false;
     }
     if (!speculated) {
@@ -1039,8 +1068,9 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     const int Li = (int)Li0;
     hipLaunchKernelGGL(pup::reduce_staged_kernel, dim3((unsigned)((Lf + Li + 63) / 64), (unsigned)T), dim3(64, pup::kRedParts), 0,
                        c->stream, (const double*)c->part_f64.p, (const unsigned*)c->part_num.p,
-                       (const unsigned char*)d_recvalid, 2 * G, (int)Lf, Li, c->acc_f64.p, c->acc_i64.p);
+                       (const unsigned short*)d_recvalid, G, T, ACC, H, (int)Lf, Li, c->acc_f64.p, c->acc_i64.p);
     HIPCHK(c, hipGetLastError());
+    if (cov_sep) { const int crc = cov_pass(c, dr0, dc0, n, mode); if (crc != PUP_OK) return crc; }
     c->last_staged = true;
     return PUP_OK;
 }
@@ -1056,7 +1086,8 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
     const int W = c->W, T = c->T;
     const bool force = (c->variant & 8) != 0, forbid = (c->variant & 16) != 0;
     const bool ooe = (mode & PUP_MODE_OOE) != 0;
-    if (forbid || rescale || (mode & (PUP_MODE_EXPECTED | PUP_MODE_TRANSPOSE | PUP_MODE_COV)) || (c->variant & (1 | 2 | 256)) || c->count_pixels ||
+    const bool cov_sep = (mode & PUP_MODE_COV) && c->have_cov;
+    if (forbid || rescale || (mode & (PUP_MODE_EXPECTED | PUP_MODE_TRANSPOSE)) || (c->variant & (1 | 2 | 256)) || c->count_pixels ||
         !c->have_idx || c->band_w <= 0 || ignore_diags < 0 || W < 32 || !(force || n >= c->wide_min) || 2 * T > pup::kMaxSegCount ||
         !c->bin_chrom.p || !c->h_flags || !c->ev_key || (int)c->h_chroms.size() != c->n_chrom || (ooe && c->have_exp_pair))
         return 1;
@@ -1203,7 +1234,11 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
     HIPCHK(c, hipEventSynchronize(c->ev_key));
     if (c->h_flags[3] != ticket) return fail(c, PUP_EHIP, "pup_accumulate: the key kernel's verdict did not arrive");
     c->hint_ticket = ticket;
-    if (c->h_flags[0] != 0 || c->h_flags[2] != 0) return 1;      // a window outside one chromosome / outside the band: per-window kernels
+    if (c->h_flags[0] != 0 || c->h_flags[2] != 0) {              // a window outside one chromosome / outside the band: per-window kernels
+        c->off_staged(c->h_flags[0] ? 1u : 2u, c->h_flags[0] ? "some windows are not inside one chromosome" :
+                      "some windows reach beyond the dense band of counts (pup_build_index: its width is what memory allowed)", (long long)n);
+        return 1;
+    }
     const bool fact = (!ooe || ooe_clean) && c->h_flags[1] == 0 && !(c->variant & 4);
 
     pup::K1Args a{};
@@ -1233,6 +1268,7 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
                        (const double*)c->wrec_f64.p, (const unsigned*)c->wrec_num.p, (const unsigned*)c->wrec_seg.p, G, W, NG, geo.NGc,
                        geo.SH, geo.SW, flip_from ? 2 : 1, (int)Lf, c->acc_f64.p, c->acc_i64.p);
     HIPCHK(c, hipGetLastError());
+    if (cov_sep) { const int crc = cov_pass(c, dr0, dc0, n, mode); if (crc != PUP_OK) return crc; }
     c->last_staged = true;
     c->last_kernel = fact ? "wide_fact" : "wide";
     return PUP_OK;

@@ -63,7 +63,11 @@ struct StagedArgs {
     const int*            wg_first;   // [G + 1] first block of every workgroup's range
     int                   U;          // pass units: tiles (ACC = 1), tile pairs (2), or sets of 4 pairs (8) — see staged_tile
     int                   PH;         // paired tiles: tile t < PH shares its pass with tile t + PH (its control); 0 when unpaired
-    unsigned char*        rec_valid;  // [T * 2 * G] set when record (tile * 2 + flip) * G + workgroup was written
+    unsigned short*       rec_owner;  // [ACC * (2 T + G)] 1 + tile * 2 + flip of the record written there, 0: none.  Record of (tile, flip, slot,
+                                      // workgroup g) = slot * (2 T + G) + tile * 2 + flip + g: a workgroup's block range is contiguous and the
+                                      // blocks are sorted by (unit, flip), so within one slot that sum is unique — (2 T + G) records per slot
+                                      // instead of 2 T G (round 3's table capped the staged kernel at 64 tiles)
+    int                   T;          // tiles of the call
     const unsigned char*  teams;      // [U][16]: waves [teams[u][s], teams[u][s+1]) pile up the slot-s windows of unit u's blocks —
                                       // teams sized by the host in proportion to the tiles' window counts (none for an empty tile)
     int                   debug;      // timing experiments only (results are wrong): 1 = skip the window loop, 2 = skip the staging
@@ -77,7 +81,7 @@ constexpr int kSetSlotBits = 3;
 constexpr int kBandFront = 256;                       // cells in front of the band table's row 0 (see band_issue)
 constexpr int kMaxSegCount = 1024;                    // (tile, flip) runs one block-ordered call may have (key kernel LDS table)
 constexpr int kBlockCost = 400;                       // staging one region, in windows' worth of time (workgroup ranges)
-constexpr int kMaxStagedTiles = 64;                   // partial records are (tile, flip, workgroup): keep the table small
+constexpr int kMaxStagedTiles = kMaxSegCount / 2;     // (tile, flip) runs fit the key kernel's LDS table
 
 __device__ __forceinline__ void lds_read2_b32(unsigned long long& dst, unsigned addr) {     // dwords at addr, addr + 4
     asm volatile("ds_read2_b32 %0, %1 offset0:0 offset1:1" : "=&v"(dst) : "v"(addr));
@@ -307,14 +311,14 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     // the order balance_pixels_kernel (and cooler) multiplies: the same doubles as the resident `bal` table at half the HBM
     // bytes — with 128 x 128 regions the kernel is bound by what it pulls from HBM (round 2, at 64 x 64, it was not)
     auto issue_values = [&](int ev, const Row& r, int (&v)[NRH], double (&wc)[NH]) __attribute__((always_inline)) {
-        // pixel positions as 32-bit BYTE offsets from the table's base (the engine only stages tables below 2^30 pixels):
-        // one add, one select, one shift per lane and half, and a load with scalar base + 32-bit vector offset
-        const unsigned zero_at = (unsigned)a.nnz;        // cnt32[nnz .. nnz + 63] are zeros
-        const char* cbase = reinterpret_cast<const char*>(a.cnt32);
+        // pixel positions are 64-bit (tables of 2^30 pixels and more — a deep 10 kb human map — are staged too): the row's first
+        // position is a SCALAR, so the row base is a scalar pointer and a lane adds its 32-bit rank; a lane with nothing to
+        // keep reads one of the 64 zeros behind the table
+        const int* const zeros = a.cnt32 + a.nnz;        // cnt32[nnz .. nnz + 63] are zeros
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
             const int rr = wave * RPW + i;
-            unsigned pos = (unsigned)__builtin_amdgcn_readlane((unsigned)r.pos, i);
+            const int* rowp = a.cnt32 + (long long)bcast64((unsigned long long)r.pos, i);
             const bool row_bad = !FACT && ((fld64(ev, 16 + 2 * (rr >> 6)) >> (rr & 63)) & 1ull);
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
@@ -324,9 +328,9 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
                 const unsigned long long keep = bits & (FACT ? fld64(ev, 12 + 2 * h) : ok_mask(ev, rr, h, row_bad));
                 const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bits >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bits, 0u));
                 const bool has = __builtin_amdgcn_inverse_ballot_w64(keep);
-                const unsigned off = (has ? pos + rank : zero_at) << 2;
-                v[i * NH + h] = *reinterpret_cast<const int*>(cbase + off);
-                pos += (unsigned)__builtin_popcountll(bits);     // (scalar) half 1's pixels follow half 0's
+                const int* ptr = has ? rowp + rank : zeros + lane;
+                v[i * NH + h] = *ptr;
+                rowp += __builtin_popcountll(bits);      // (scalar) half 1's pixels follow half 0's
             }
         }
         // column weights (1.0 when raw — branch-free: the load then reads the row offsets, a table of the same length)
@@ -418,32 +422,26 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     // (non-FACT), below the diagonal or outside the staged rows read the zero behind the band.
     auto band_issue = [&](int ev, int (&v)[NRH], double (&wc)[NH], double& wrv) __attribute__((always_inline)) {
         const int R = fld(ev, 0), C = fld(ev, 1), ch_end = fld(ev, 6), row_lo = fld(ev, 21), row_hi = fld(ev, 22);
-        const unsigned zero_at = (unsigned)a.band_zero;  // index of BAND zeros behind the last row
-        const char* bbase = reinterpret_cast<const char*>(a.band);
+        // (64-bit row bases, all scalar: tables of a million bins and more have bands beyond 2^30 cells)
+        const int* const zeros = a.band + (long long)a.nbins * a.band_w;      // >= 129 rows of zeros behind the last row
         if constexpr (FACT) {
             // Factorised counts = every window of the call is clear of the diagonal mask, so NO cell a window reads lies left
             // of the first kept diagonal (a window at (r, c) has c - r >= igd + W - 1), and the engine only stages from the band
             // when no window leaves it: the cells that would need masking are never read.  (Masked bins multiply to zero
             // through their weight.)  A region row is then a plain run of the band: scalar row base + 4 * lane, no vector
-            // arithmetic, no predicate — two scalar adds per load.  Cells outside the band's row (left of the diagonal, past its
-            // width) read neighbouring rows or the pads around the table (pup_build_index): finite garbage nobody looks at.
-            // (32-bit byte offsets from the table's base: the engine builds no band of 2^30 cells or more)
-            const unsigned lane4 = 4u * (unsigned)lane;
+            // arithmetic, no predicate.  Cells outside the band's row (left of the diagonal, past its width) read neighbouring
+            // rows or the pads around the table (pup_build_index): finite garbage nobody looks at.
             const int row0 = R + wave * RPW;
-            const unsigned step = 4u * ((unsigned)a.band_w - 1u);                      // (row + 1, C) - (row, C) in bytes
-            // offsets count from the front pad (a region near the diagonal starts up to ~212 cells left of its first row's band)
-            const char* b0 = bbase - 4 * kBandFront;
-            const unsigned base0 = 4u * (unsigned)((long long)kBandFront + (long long)row0 * a.band_w + (long long)(C - row0));
-            const unsigned zero4 = 4u * (zero_at + (unsigned)kBandFront);
             const int hi2 = (ch_end - R) < row_hi ? (ch_end - R) : row_hi;             // live rows of the region: [row_lo, hi2)
             const unsigned i_lo = (unsigned)(row_lo - wave * RPW), n_live = (unsigned)(hi2 > row_lo ? hi2 - row_lo : 0);
+            const int* rowp = a.band + (long long)row0 * a.band_w + (C - row0);        // (row + 1, C) sits band_w - 1 cells further
 #pragma unroll
             for (int i = 0; i < RPW; ++i) {
                 const bool live = (unsigned)i - i_lo < n_live;                          // (uniform) else: zeros, all rows the same lines
-                const unsigned off = (live ? base0 + (unsigned)i * step : zero4) + lane4;
+                const int* src = live ? rowp : zeros;
 #pragma unroll
-                for (int h = 0; h < NH; ++h)
-                    v[i * NH + h] = *reinterpret_cast<const int*>(b0 + (size_t)off + 256 * h);
+                for (int h = 0; h < NH; ++h) v[i * NH + h] = src[64 * h + lane];
+                rowp += a.band_w - 1;
             }
         } else
 #pragma unroll
@@ -452,19 +450,13 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
             const int row = R + rr;
             const bool live = row < ch_end && rr >= row_lo && rr < row_hi;
             const bool row_bad = !FACT && ((fld64(ev, 16 + 2 * (rr >> 6)) >> (rr & 63)) & 1ull);
+            const int* rowp = a.band + (long long)row * a.band_w + (C - row);         // (scalar) cell (row, C)
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
-                // FACT: only the cells below the first kept diagonal must go (they lie left of the band); else the full mask
-                unsigned long long keep;
-                if constexpr (FACT) {                    // (masked bins multiply to 0 anyway: no column / row mask)
-                    const int t0 = igd - (C + 64 * h - row);
-                    keep = t0 <= 0 ? ~0ull : (t0 >= 64 ? 0ull : ~((1ull << t0) - 1ull));
-                } else keep = ok_mask(ev, rr, h, row_bad);
-                if (!live) keep = 0ull;
+                unsigned long long keep = live ? ok_mask(ev, rr, h, row_bad) : 0ull;
                 const bool has = __builtin_amdgcn_inverse_ballot_w64(keep);
-                const unsigned cell = (unsigned)row * (unsigned)a.band_w + (unsigned)(C + 64 * h - row);   // (scalar) j of lane 0
-                const unsigned off = (has ? cell + (unsigned)lane : zero_at) << 2;
-                v[i * NH + h] = *reinterpret_cast<const int*>(bbase + off);
+                const int* ptr = has ? rowp + 64 * h + lane : zeros + lane;
+                v[i * NH + h] = *ptr;
             }
         }
         const double* wsrc = a.weight ? a.weight : reinterpret_cast<const double*>(a.indptr);
@@ -759,7 +751,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
             const int tl = staged_tile<ACC>(unit, s, sa.PH);
             const int lead = ACC > 1 ? team_at(s) : 0, w_hi = ACC > 1 ? team_at(s + 1) : NW;   // the team's first wave holds its merged tile
             if (tl < 0 || lead >= w_hi) continue;                         // (uniform) no such tile / none of its windows in this call
-            const size_t rec = ((size_t)tl * 2 + (size_t)fl) * (size_t)G + (size_t)g_id;
+            const size_t rec = (size_t)s * (size_t)(2 * sa.T + G) + (size_t)tl * 2 + (size_t)fl + (size_t)g_id;
             double*   of = a.part_f64 + rec * L;
             unsigned* on = a.part_num + rec * W2;
             if (wave == lead) {
@@ -784,7 +776,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
                 if (m_cov) for (int w = lead; w < w_hi; ++w) acc += cov_lds[w][t];
                 of[W2 + t] = acc;
             }
-            if (tid == 0) sa.rec_valid[rec] = 1;
+            if (tid == 0) sa.rec_owner[rec] = (unsigned short)(tl * 2 + fl + 1);
         }
         __syncthreads();                                 // fact_tot / rc_lds / cov_lds have been read
         zero_acc();
@@ -1170,40 +1162,45 @@ __global__ __launch_bounds__(256) void staged_table_kernel(const unsigned* __res
     if (nr == 0 && blockIdx.x == 0) for (int g = threadIdx.x; g <= G; g += blockDim.x) wg_first[g] = 0;
 }
 
-// fixed-order reduction of the staged kernel's partial records into the running accumulators: tile t owns the records
-// [t * 2G, (t + 1) * 2G) (flip 0 of every workgroup, then flip 1); records nobody wrote are skipped through their flag.
+// fixed-order reduction of the staged kernel's partial records into the running accumulators: tile t gathers the records its
+// owner mark names (see StagedArgs::rec_owner) — flip 0 of every workgroup in order, then flip 1.
 // Same shape as reduce_partials_kernel: 64 record elements x kRedParts interleaved partial sums in fixed order.
 PUP_KERNEL __launch_bounds__(64 * kRedParts) void reduce_staged_kernel(
-        const double* __restrict__ in_f64, const unsigned* __restrict__ in_num, const unsigned char* __restrict__ valid,
-        int per_tile, int Lf, int Li, double* out_f64, long long* out_num) {
+        const double* __restrict__ in_f64, const unsigned* __restrict__ in_num, const unsigned short* __restrict__ owner,
+        int G, int T, int ACC, int PH, int Lf, int Li, double* out_f64, long long* out_num) {
     __shared__ double    sf[kRedParts][64];
     __shared__ long long si[kRedParts][64];
-    const int g = blockIdx.y;
+    const int t = blockIdx.y;
     const int cx = threadIdx.x, py = threadIdx.y;
     const int idx = blockIdx.x * 64 + cx;
-    const long long b = (long long)g * per_tile, e = b + per_tile;
+    // the accumulator slot tile t is piled up in (inverse of staged_tile)
+    const int slot = ACC == 1 ? 0 : (ACC == 2 ? t / PH : (t / PH) * (ACC / 2) + (t % PH) % (ACC / 2));
+    const size_t base = (size_t)slot * (size_t)(2 * T + G) + (size_t)t * 2;
+    const long long e = 2LL * G;                          // virtual records c = flip * G + workgroup
     double accf = 0.0; long long acci = 0;
-    // eight records per round: their flags, then their values, are independent loads (one at a time, a thread waited out a
-    // memory round trip per record: 26 us for 4 MB); the additions keep the order of the plain loop
+    // eight records per round: their marks, then their values, are independent loads (one at a time, a thread waited out a
+    // memory round trip per record); the additions keep the order of the plain loop
     constexpr int kUn = 8;
+    auto rec_of = [&](long long c) -> size_t { const int fl = c >= G ? 1 : 0; return base + (size_t)fl + (size_t)(c - (long long)fl * G); };
+    auto mine = [&](long long c) -> bool { return c < e && owner[rec_of(c)] == (unsigned short)(t * 2 + (c >= G ? 1 : 0) + 1); };
     if (idx < Lf) {
-        for (long long c0 = b + py; c0 < e; c0 += (long long)kUn * kRedParts) {
+        for (long long c0 = py; c0 < e; c0 += (long long)kUn * kRedParts) {
             bool ok[kUn]; double v[kUn];
 #pragma unroll
-            for (int u = 0; u < kUn; ++u) { const long long c = c0 + (long long)u * kRedParts; ok[u] = c < e && valid[c]; }
+            for (int u = 0; u < kUn; ++u) ok[u] = mine(c0 + (long long)u * kRedParts);
 #pragma unroll
-            for (int u = 0; u < kUn; ++u) { const long long c = c0 + (long long)u * kRedParts; v[u] = ok[u] ? in_f64[(size_t)c * Lf + idx] : 0.0; }
+            for (int u = 0; u < kUn; ++u) v[u] = ok[u] ? in_f64[rec_of(c0 + (long long)u * kRedParts) * Lf + idx] : 0.0;
 #pragma unroll
             for (int u = 0; u < kUn; ++u) if (ok[u]) accf += v[u];
         }
     } else if (idx < Lf + Li) {
         const int k = idx - Lf;
-        for (long long c0 = b + py; c0 < e; c0 += (long long)kUn * kRedParts) {
+        for (long long c0 = py; c0 < e; c0 += (long long)kUn * kRedParts) {
             bool ok[kUn]; unsigned v[kUn];
 #pragma unroll
-            for (int u = 0; u < kUn; ++u) { const long long c = c0 + (long long)u * kRedParts; ok[u] = c < e && valid[c]; }
+            for (int u = 0; u < kUn; ++u) ok[u] = mine(c0 + (long long)u * kRedParts);
 #pragma unroll
-            for (int u = 0; u < kUn; ++u) { const long long c = c0 + (long long)u * kRedParts; v[u] = ok[u] ? in_num[(size_t)c * Li + k] : 0u; }
+            for (int u = 0; u < kUn; ++u) v[u] = ok[u] ? in_num[rec_of(c0 + (long long)u * kRedParts) * Li + k] : 0u;
 #pragma unroll
             for (int u = 0; u < kUn; ++u) acci += (long long)v[u];
         }
@@ -1212,15 +1209,15 @@ PUP_KERNEL __launch_bounds__(64 * kRedParts) void reduce_staged_kernel(
     __syncthreads();
     if (py != 0 || idx >= Lf + Li) return;
     if (idx < Lf) {
-        double t = 0.0;
+        double tt = 0.0;
 #pragma unroll
-        for (int y = 0; y < kRedParts; ++y) t += sf[y][cx];
-        out_f64[(size_t)g * Lf + idx] += t;
+        for (int y = 0; y < kRedParts; ++y) tt += sf[y][cx];
+        out_f64[(size_t)t * Lf + idx] += tt;
     } else {
-        long long t = 0;
+        long long tt = 0;
 #pragma unroll
-        for (int y = 0; y < kRedParts; ++y) t += si[y][cx];
-        out_num[(size_t)g * Li + (idx - Lf)] += t;
+        for (int y = 0; y < kRedParts; ++y) tt += si[y][cx];
+        out_num[(size_t)t * Li + (idx - Lf)] += tt;
     }
 }
 

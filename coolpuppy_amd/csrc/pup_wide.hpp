@@ -630,6 +630,66 @@ PUP_KERNEL __launch_bounds__(64 * kRedParts) void reduce_wide_kernel(
     out_num[(size_t)t * W2 + cell] += ti;
 }
 
+
+// ---- coverage vectors of a pile-up, on their own (PUP_MODE_COV beside the staged kernels) ---------------------------------------
+// cov_start / cov_end of a tile are plain sums over its windows of cov[r0 .. r0 + W) and cov[c0 .. c0 + W) (NaN adds nothing;
+// the flip leaves them alone; under TRANSPOSE the two swap: coolpuppy/coolpup.py:1151-1153, lib/puputils.py:30-38) — nothing in
+// them depends on the pixels.  Riding inside the staged kernel they forced its fat 8-wave geometry (EXTRA); as a pass of their
+// own — O(W) per window from a 2.4 MB vector that lives in L2 — the pile-up keeps the lean kernel.  Deterministic: fixed chunks
+// of kCovChunk windows of the caller's order; a (chunk, tile) piece is summed by four waves (wave w: windows w, w + 4, ...; a
+// lane per vector entry), the waves in order, into record chunk + tile (unique: both grow along the stream);
+// cov_reduce_kernel adds a tile's records in chunk order.
+constexpr int kCovChunk = 2048;
+PUP_KERNEL __launch_bounds__(256) void cov_vectors_kernel(const int* __restrict__ r0, const int* __restrict__ c0, long long n,
+                                                          const long long* __restrict__ seg_end /* [2T]: entry 2t + 1 = end of tile t */, int T,
+                                                          const double* __restrict__ cov, long long nbins, int W, int transpose,
+                                                          double* __restrict__ rec /* [nchunks + T][2W] */, unsigned* __restrict__ rec_owner) {
+    extern __shared__ double sacc[];                      // [4][2W]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int L = 2 * W;
+    const long long cb = (long long)blockIdx.x * kCovChunk, ce = cb + kCovChunk < n ? cb + kCovChunk : n;
+    // first tile that ends behind the chunk's first window
+    int lo = 0, hi = T;
+    while (lo < hi) { const int m = (lo + hi) >> 1; if (seg_end[2 * m + 1] <= cb) lo = m + 1; else hi = m; }
+    for (int t = lo; t < T; ++t) {
+        const long long tb = t ? seg_end[2 * t - 1] : 0, te = seg_end[2 * t + 1];
+        if (tb >= ce) break;
+        const long long b = tb > cb ? tb : cb, e = te < ce ? te : ce;
+        if (b >= e) continue;
+        for (int k = threadIdx.x; k < 4 * L; k += 256) sacc[k] = 0.0;
+        __syncthreads();
+        for (long long j = b + wave; j < e; j += 4) {
+            const int rs = __builtin_amdgcn_readfirstlane(transpose ? c0[j] : r0[j]);
+            const int cs = __builtin_amdgcn_readfirstlane(transpose ? r0[j] : c0[j]);
+            if (rs < 0 || cs < 0 || (long long)rs + W > nbins || (long long)cs + W > nbins) continue;      // (reported by the pile-up kernel)
+            for (int k = lane; k < L; k += kWave) {
+                const double v = cov[k < W ? rs + k : cs + (k - W)];
+                if (v == v) sacc[wave * L + k] += v;     // one lane per entry: no race
+            }
+        }
+        __syncthreads();
+        const size_t id = (size_t)blockIdx.x + (size_t)t;
+        for (int k = threadIdx.x; k < L; k += 256) rec[id * L + k] = ((sacc[k] + sacc[L + k]) + sacc[2 * L + k]) + sacc[3 * L + k];
+        if (threadIdx.x == 0) rec_owner[id] = (unsigned)t + 1u;
+        __syncthreads();
+    }
+}
+
+PUP_KERNEL __launch_bounds__(64) void cov_reduce_kernel(const double* __restrict__ rec, const unsigned* __restrict__ rec_owner,
+                                                        const long long* __restrict__ seg_end, int W, int Lf, double* out_f64) {
+    const int t = blockIdx.y, L = 2 * W;
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= L) return;
+    const long long tb = t ? seg_end[2 * t - 1] : 0, te = seg_end[2 * t + 1];
+    if (te <= tb) return;
+    double acc = 0.0;
+    for (long long ch = tb / kCovChunk; ch <= (te - 1) / kCovChunk; ++ch) {
+        const size_t id = (size_t)ch + (size_t)t;
+        if (rec_owner[id] == (unsigned)t + 1u) acc += rec[id * L + k];
+    }
+    out_f64[(size_t)t * Lf + (size_t)W * W + k] += acc;
+}
+
 // ---- the expected-as-control pass for windows of any width (PUP_MODE_EXPECTED) ------------------------------------------
 // expected & !ooe: the "control" of a snippet is the unmasked window of its expected matrix (coolpuppy/coolpup.py:1135-1139),
 // a Toeplitz slice: cell (p, q) = E[|c0 + q - r0 - p|] of the region holding the snippet's first row (or the trans scalar of

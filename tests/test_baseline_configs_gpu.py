@@ -249,9 +249,11 @@ def test_config4_trans_pairs_pad25(hg38, oracle_mod):
     assert plan["pad"] == 25
     acc = _run_calls(pu, plan, plan["calls"])
     assert int(acc["n"][0]) > 490_000
+    eng = coolpup._engine_for(pu._aclr, 0)
+    assert eng.last_kernel() == "sparse", eng.last_kernel()       # K1s served the calls ...
+    _check_every_window_vs_oracle(pu, plan, acc, expect_staged=False)     # ... and EVERY window of them matches the oracle
     _check_full_size(pu, plan, acc)
     # the sparse trans kernel against the plain per-window kernel on everything
-    eng = coolpup._engine_for(pu._aclr, 0)
     os.environ["COOLPUPPY_AMD_VARIANT"] = "32"
     try:
         plain = _run_calls(pu, plan, plan["calls"])
@@ -260,3 +262,48 @@ def test_config4_trans_pairs_pad25(hg38, oracle_mod):
         eng.set_tuning(0, 0)
     np.testing.assert_array_equal(plain["num"], acc["num"])
     np.testing.assert_allclose(plain["sum"], acc["sum"], rtol=1e-10, atol=0)
+
+
+def test_dense_trans_table_sparse_kernel_every_window(hip_lib, oracle_mod):
+    """K1s away from its sweet spot: a trans table with ~30 pixels per 51 x 51 window (the human-scale synthetic one holds
+    ~3) — its O(W) lookup then finds a pixel in most rows it probes.  Every window against the oracle, K1s asserted, and the
+    same integers as the dense per-window kernel."""
+    sizes = {f"chr{k}": 60_000_000 for k in range(1, 7)}
+    clr = synth.make_cooler(sizes, binsize=10_000, lam=200, seed=77, name="dense_trans", parallel=True, trans_nnz=8_000_000)
+    feats = synth.random_trans_pairs(clr, 300_000, seed=5)
+    pu, plan = _plan(clr, feats, flank=250_000, trans=True)
+    acc = _run_calls(pu, plan, plan["calls"])
+    eng = coolpup._engine_for(pu._aclr, 0)
+    assert eng.last_kernel() == "sparse", eng.last_kernel()
+    st = eng.stats()
+    _check_every_window_vs_oracle(pu, plan, acc, expect_staged=False)
+    # pixels per window of this table (counted by the statistics pass of the plain kernel)
+    eng.set_tuning(0, 32); eng.set_profiling(1); eng.clear_stats()
+    plain = _run_calls(pu, plan, plan["calls"])
+    per_window = eng.stats()["pixels_in_windows"] / max(int(plain["n"].sum()), 1)
+    eng.set_profiling(0); eng.set_tuning(0, 0)
+    assert per_window >= 25, per_window
+    np.testing.assert_array_equal(plain["num"], acc["num"])
+    np.testing.assert_allclose(plain["sum"], acc["sum"], rtol=1e-10, atol=0)
+    del st
+
+
+@pytest.mark.parametrize("case", ["controls_flip", "expected_ooe", "expected_as_control"])
+@pytest.mark.parametrize("flank", [1_270_000, 2_000_000])
+def test_wide_windows_through_pileup_full_oracle(hip_lib, monkeypatch, oracle_mod, case, flank):
+    """Windows of 255 and 401 bins through the PUBLIC entry point with everything that rides on them: random-shift controls
+    and strand flips, observed over expected, expected as control (coolpuppy/coolpup.py:1115-1157, 1127-1139, 999-1005) — the same
+    pileup() call with the engine half replaced by the oracle replay must give the same frame."""
+    clr = synth.make_cooler({"chrA": 60_000_000, "chrB": 45_000_000}, binsize=10_000, lam=150, seed=31, name="wide_api")
+    feats = synth.random_cis_pairs(clr, 400, min_sep=2 * flank + 200_000, max_sep=2 * flank + 3_000_000, seed=9, strands=True)
+    kw = dict(features_format="bedpe", flank=flank)
+    if case == "controls_flip":
+        kw.update(nshifts=2, seed=4, flip_negative_strand=True, maxshift=2_000_000)
+    else:
+        kw.update(expected_df=synth.cis_expected(clr), ooe=(case == "expected_ooe"), nshifts=0)
+    gpu, cpu = _both(clr, feats, monkeypatch, **kw)
+    _frames_equal(gpu, cpu)
+    assert np.asarray(gpu["data"].iloc[0]).shape == (2 * (flank // 10_000) + 1,) * 2
+    assert int(gpu["n"].iloc[0]) > 100
+    if case != "expected_ooe":
+        np.testing.assert_array_equal(np.asarray(gpu["control_num"].iloc[0]), np.asarray(cpu["control_num"].iloc[0]))

@@ -72,3 +72,21 @@ def test_bench_two_ranks_on_one_gpu_match_one_rank(hip_lib, tmp_path):
     assert w["scaling"] == "weak" and w["pairs"] == 60000 and sum(w["check_n"]) == w["snippets_per_step"]
     assert w["snippets_per_step"] > 1.9 * one["config"]["snippets_per_step"]
     assert two["exchange"].startswith("torch.distributed")                     # gloo: no RCCL between ranks sharing a GPU
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", [3, 4])
+def test_bench_config_3_and_4_two_ranks_on_one_gpu_match_one_rank(hip_lib, tmp_path, config):
+    """`bench.py --config 3` (grouped: chromosomes sharded) and `--config 4` (trans: region PAIRS sharded)
+    through the library's plan path with two gloo ranks on GPU 0 — the all-reduced tiles must hold exactly the windows of the
+    one-rank run, tile by tile."""
+    common = ["--config", str(config), "--steps", "2", "--warmup", "1", "--pairs", "30000", "--chroms", "5", "--lam", "400",
+              "--cpu-sample", "0", "--trans-nnz", "400000"]
+    env = {"TMPDIR": str(tmp_path)}
+    one = _bench(["--gpus", "1"] + common, env)
+    two = _bench(["--gpus", "2", "--backend", "gloo"] + common, dict(env, COOLPUPPY_AMD_BENCH_DEVICE="0"), nproc=2, port=29571 + config)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["check"]["n"] == one["check"]["n"] and sum(one["check"]["n"]) > 20000
+    assert two["config"]["snippets_per_step"] == one["config"]["snippets_per_step"] == one["check"]["n_sum"]
+    assert one["config"]["tiles"] == two["config"]["tiles"] and (one["config"]["tiles"] >= 30 if config == 3 else one["config"]["tiles"] <= 2)
+    assert one["roofline"]["kernel_family"] and one["cpu_baseline"] is None
