@@ -57,6 +57,8 @@ _SIGNATURES = {
     "pup_build_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64]),
     "pup_coverage": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "pup_load_bins": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pup_load_pixels_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
+                                       C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "pup_set_expected": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "pup_set_expected_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_void_p, C.c_int64, C.c_void_p]),
@@ -94,6 +96,8 @@ _SIGNATURES = {
     "pup_host_group_tiles": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
 }
+
+FILL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p)     # pup_fill_fn
 
 _lib = None
 

@@ -53,6 +53,9 @@ def _hdf5():
     lib.H5Dget_type.restype = hid; lib.H5Dget_type.argtypes = [hid]
     lib.H5Sget_simple_extent_npoints.restype = C.c_int64; lib.H5Sget_simple_extent_npoints.argtypes = [hid]
     lib.H5Sclose.argtypes = [hid]
+    lib.H5Screate_simple.restype = hid; lib.H5Screate_simple.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.H5Sselect_hyperslab.restype = C.c_int
+    lib.H5Sselect_hyperslab.argtypes = [hid, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.H5Tget_class.restype = C.c_int; lib.H5Tget_class.argtypes = [hid]
     lib.H5Tget_size.restype = C.c_size_t; lib.H5Tget_size.argtypes = [hid]
     lib.H5Tget_sign.restype = C.c_int; lib.H5Tget_sign.argtypes = [hid]
@@ -171,6 +174,50 @@ class _File:
         finally:
             lib.H5Dclose(did)
 
+    def dataset_info(self, name):
+        """(number of elements, numpy dtype) of an integer / float dataset, without reading it."""
+        lib = self.lib
+        did = lib.H5Dopen2(self.fid, name.encode(), _H5P_DEFAULT)
+        if did < 0:
+            raise KeyError(f"dataset {name!r} not found")
+        try:
+            sid = lib.H5Dget_space(did)
+            n = lib.H5Sget_simple_extent_npoints(sid)
+            lib.H5Sclose(sid)
+            tid = lib.H5Dget_type(did)
+            cls, size = lib.H5Tget_class(tid), lib.H5Tget_size(tid)
+            signed = lib.H5Tget_sign(tid) != 0 if cls == _H5T_INTEGER else True
+            lib.H5Tclose(tid)
+            if cls == _H5T_INTEGER:
+                return int(n), np.dtype(f"<{'i' if signed else 'u'}{size}")
+            if cls == _H5T_FLOAT:
+                return int(n), np.dtype(f"<f{size}")
+            raise NotImplementedError(f"{name}: HDF5 type class {cls} is not a number")
+        finally:
+            lib.H5Dclose(did)
+
+    def read_into(self, name, first, out):
+        """Elements [first, first + len(out)) of a 1-D numeric dataset straight into the (contiguous) array `out` — a hyperslab
+        read with the array's own dtype as the memory type: no intermediate copy (`out` may be a view of page-locked memory)."""
+        lib = self.lib
+        did = lib.H5Dopen2(self.fid, name.encode(), _H5P_DEFAULT)
+        if did < 0:
+            raise KeyError(f"dataset {name!r} not found")
+        try:
+            kind, size = out.dtype.kind, out.dtype.itemsize
+            mem = _native(lib, {("i", 4): "H5T_NATIVE_INT32_g", ("i", 8): "H5T_NATIVE_INT64_g", ("u", 4): "H5T_NATIVE_UINT32_g",
+                                ("u", 8): "H5T_NATIVE_UINT64_g", ("f", 8): "H5T_NATIVE_DOUBLE_g", ("f", 4): "H5T_NATIVE_FLOAT_g"}[(kind, size)])
+            fsp = lib.H5Dget_space(did)
+            start, count = (C.c_uint64 * 1)(int(first)), (C.c_uint64 * 1)(int(out.shape[0]))
+            msp = lib.H5Screate_simple(1, count, None)
+            ok = lib.H5Sselect_hyperslab(fsp, 0, start, None, count, None) >= 0 and \
+                lib.H5Dread(did, mem, msp, fsp, _H5P_DEFAULT, out.ctypes.data_as(C.c_void_p)) >= 0
+            lib.H5Sclose(msp); lib.H5Sclose(fsp)
+            if not ok:
+                raise OSError(f"hyperslab read of {name!r} [{first}, +{out.shape[0]}) failed")
+        finally:
+            lib.H5Dclose(did)
+
     def attr_int(self, obj, name):
         lib = self.lib
         aid = lib.H5Aopen_by_name(self.fid, obj.encode(), name.encode(), _H5P_DEFAULT, _H5P_DEFAULT)
@@ -184,10 +231,109 @@ class _File:
         return int(v.value)
 
 
-def read_cool(path, group="/", extra_bins=None):
+class StreamedCooler(ArrayCooler):
+    """An ArrayCooler whose pixel table stays in the FILE: bins, chromosomes and the row pointer are in memory, pixels/bin2_id
+    and pixels/count are streamed to the GPU in row-range chunks through page-locked slabs when an engine is first needed
+    (stream_pixels_into) — the table never sits in pageable host memory.  Whoever asks for the arrays themselves (multi-rank
+    row subsets, the test oracle) gets them read in full, once."""
+
+    def __init__(self, chromsizes, binsize, bin1_offset, source, bins=None, filename="in_memory.cool"):
+        self._pixel_source = source                      # {"path", "group", "nnz", "bin2_dtype", "count_dtype"}
+        self._b2 = self._ct = None
+        super().__init__(chromsizes, binsize, bin1_offset, np.empty(0, np.int32), np.empty(0, np.int32), bins=bins, filename=filename)
+        self._b2 = self._ct = None
+
+    def _load_pixels(self):
+        if self._b2 is None:
+            src = self._pixel_source
+            f = _File(src["path"])
+            try:
+                self._b2 = f.read(f"{src['group']}/pixels/bin2_id")
+                self._ct = _counts32(f.read(f"{src['group']}/pixels/count"))
+            finally:
+                f.close()
+
+    @property
+    def pixels_in_memory(self):
+        return self._b2 is not None
+
+    @property
+    def bin2_id(self):
+        self._load_pixels()
+        return self._b2
+
+    @bin2_id.setter
+    def bin2_id(self, v):
+        self._b2 = v
+
+    @property
+    def count(self):
+        self._load_pixels()
+        return self._ct
+
+    @count.setter
+    def count(self, v):
+        self._ct = v
+
+    @property
+    def nnz(self):
+        return int(self._pixel_source["nnz"])
+
+
+def stream_pixels_into(eng, clr, slab_pixels=0):
+    """Upload the pixel table of a StreamedCooler from its file: the library's page-locked slabs are filled by hyperslab reads of
+    pixels/bin2_id and pixels/count (pup_load_pixels_stream), each slab copied asynchronously while the next is read.
+    Returns the copy statistics of PileupEngine.load_pixels_stream."""
+    src = clr._pixel_source
+    f = _File(src["path"])
+    g = src["group"]
+    cdt = np.dtype(src["count_dtype"])
+    if cdt.kind not in "iu":
+        f.close()
+        raise NotImplementedError("coolers with non-integer pixel counts are not supported by the GPU engine")
+    b2dt = np.dtype(np.int64) if np.dtype(src["bin2_dtype"]).itemsize == 8 else np.dtype(np.int32)
+
+    def fill(first, m, colv, cntv):
+        f.read_into(f"{g}/pixels/bin2_id", first, colv)
+        if cdt == np.dtype(np.int32):
+            f.read_into(f"{g}/pixels/count", first, cntv)
+        else:                                            # wider / unsigned counts: range-checked, then narrowed (never wrapped)
+            tmp = np.empty(m, np.int64)
+            f.read_into(f"{g}/pixels/count", first, tmp)
+            cntv[:] = _counts32(tmp)
+    try:
+        return eng.load_pixels_stream(clr.bin1_offset, src["nnz"], b2dt, fill, slab_pixels=slab_pixels)
+    finally:
+        f.close()
+
+
+def read_cool(path, group="/", extra_bins=None, stream_pixels=False):
     """Open ``path`` (optionally a ``group`` inside a multi-resolution file) and return an ArrayCooler.
 
-    Every numeric column of ``bins/`` (or just those listed in ``extra_bins``) is loaded; the whole pixel table is read into host memory (the engine keeps it in HBM afterwards)."""
+    Every numeric column of ``bins/`` (or just those listed in ``extra_bins``) is loaded.  stream_pixels=False: the whole pixel
+    table is read into host memory.  stream_pixels=True: a StreamedCooler — the pixel table goes from the file to the GPU in
+    chunks through page-locked memory when the first pile-up needs it (the engine keeps it in HBM afterwards)."""
+    if stream_pixels:
+        g = "/" + group.strip("/")
+        g = "" if g == "/" else g
+        f = _File(path)
+        try:
+            names = [x.decode() if isinstance(x, bytes) else str(x) for x in f.read(f"{g}/chroms/name")]
+            names = [x.rstrip("\x00") for x in names]
+            lengths = f.read(f"{g}/chroms/length").astype(np.int64)
+            binsize = f.attr_int(g or "/", "bin-size")
+            bin1_offset = f.read(f"{g}/indexes/bin1_offset").astype(np.int64)
+            nnz, b2dt = f.dataset_info(f"{g}/pixels/bin2_id")
+            _, cdt = f.dataset_info(f"{g}/pixels/count")
+            cols = {}
+            for c in _bins_columns(f.children(f"{g}/bins"), extra_bins):
+                v = f.read(f"{g}/bins/{c}")
+                if v.dtype.kind in "iuf":
+                    cols[c] = v
+        finally:
+            f.close()
+        return StreamedCooler(pd.Series(lengths, index=names), binsize, bin1_offset,
+                              {"path": path, "group": g, "nnz": nnz, "bin2_dtype": str(b2dt), "count_dtype": str(cdt)}, bins=cols, filename=path)
     try:
         import h5py  # noqa: F401
         return _read_cool_h5py(path, group, extra_bins)
@@ -243,3 +389,42 @@ def _read_cool_h5py(path, group, extra_bins):
         cols = {c: v for c, v in cols.items() if v.dtype.kind in "iuf"}
         return ArrayCooler(pd.Series(lengths, index=names), binsize, g["indexes/bin1_offset"][:].astype(np.int64),
                            g["pixels/bin2_id"][:], _counts32(g["pixels/count"][:]), bins=cols, filename=path)
+
+
+def write_cool(path, clr, group="/", chunks=None, gzip=None):
+    """Write an ArrayCooler as a single-resolution ``.cool`` (the datasets read_cool consumes, cooler's schema: chroms/{name,length},
+    bins/{chrom,start,end,<columns>}, pixels/{bin1_id,bin2_id,count}, indexes/{bin1_offset,chrom_offset}, attrs bin-size /
+    format / nbins / nnz).  A utility for tests and benchmarks (the reference only ever reads coolers; `cooler` writes them):
+    chunks / gzip as cooler does when given, else contiguous datasets."""
+    from .lib.io import _H5
+    g = "/" + group.strip("/")
+    g = "" if g == "/" else g
+    indptr, col, cnt = clr.pixel_table()
+    with _H5(path, "w") as h5:
+        cur = ""
+        for part in [p for p in g.split("/") if p]:
+            cur += "/" + part
+            h5.group(cur)
+        for sub in ("chroms", "bins", "pixels", "indexes"):
+            h5.group(f"{g}/{sub}")
+        h5.write_fixed_strings(f"{g}/chroms/name", [str(c) for c in clr.chromnames])
+        h5.write(f"{g}/chroms/length", clr.chromsizes.values.astype(np.int32))
+        nb = np.diff(clr.chrom_offset)
+        b = clr.bins()
+        h5.write(f"{g}/bins/chrom", np.repeat(np.arange(len(nb), dtype=np.int32), nb))
+        h5.write(f"{g}/bins/start", b["start"][:].values.astype(np.int32))
+        h5.write(f"{g}/bins/end", b["end"][:].values.astype(np.int32))
+        for c in b.columns:
+            if c not in ("chrom", "start", "end"):
+                h5.write(f"{g}/bins/{c}", np.asarray(b[c][:].values))
+        ck = None if chunks is None else (int(chunks),)
+        h5.write(f"{g}/pixels/bin1_id", np.repeat(np.arange(clr.nbins, dtype=np.int64), np.diff(indptr)), chunks=ck, gzip=gzip)
+        h5.write(f"{g}/pixels/bin2_id", np.asarray(col, np.int64), chunks=ck, gzip=gzip)
+        h5.write(f"{g}/pixels/count", np.asarray(cnt, np.int32), chunks=ck, gzip=gzip)
+        h5.write(f"{g}/indexes/bin1_offset", np.asarray(indptr, np.int64))
+        h5.write(f"{g}/indexes/chrom_offset", np.asarray(clr.chrom_offset, np.int64))
+        root = g or "/"
+        h5.set_attr(root, "bin-size", int(clr.binsize))
+        h5.set_attr(root, "format", "HDF5::Cooler")
+        h5.set_attr(root, "nbins", int(clr.nbins))
+        h5.set_attr(root, "nnz", int(len(col)))

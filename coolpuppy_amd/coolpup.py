@@ -877,10 +877,15 @@ def _engine_for(clr, device_id, rows=None):
             for k in [k for k, v in _ENGINES.items() if k[1] == device_id]:   # one table per device at a time
                 _ENGINES.pop(k)[1].close()
             eng = PileupEngine(device_id)
-            indptr, col, cnt = clr.pixel_table()
-            if rows is not None:
-                indptr, col, cnt = _rows_of_table(indptr, col, cnt, rows)
-            eng.load_pixels(indptr, col, cnt)
+            if rows is None and getattr(clr, "_pixel_source", None) is not None and not clr.pixels_in_memory:
+                # a cooler opened with read_cool(..., stream_pixels=True): file -> page-locked slabs -> HBM, chunk by chunk
+                from .cool_io import stream_pixels_into
+                clr._last_stream_stats = stream_pixels_into(eng, clr)
+            else:
+                indptr, col, cnt = clr.pixel_table()
+                if rows is not None:
+                    indptr, col, cnt = _rows_of_table(indptr, col, cnt, rows)
+                eng.load_pixels(indptr, col, cnt)
             eng.build_index(clr.chrom_offset)      # optional accelerator; False (too large) just means binary search
             _ENGINES[key] = (clr, eng)
         eng.set_tuning(0, int(os.environ.get("COOLPUPPY_AMD_VARIANT", "0") or 0))

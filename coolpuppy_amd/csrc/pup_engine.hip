@@ -429,6 +429,100 @@ int pup_load_pixels(pup_ctx* c, const int64_t* bin1_offset, const void* bin2_id,
     return PUP_OK;
 }
 
+
+int pup_load_pixels_stream(pup_ctx* c, const int64_t* bin1_offset, int64_t nbins, int64_t nnz, int bin2_bytes,
+                           int64_t slab_pixels, pup_fill_fn fill, void* user, double* h2d_ms, int64_t* h2d_bytes) {
+    if (!c) return PUP_EINVAL;
+    if (!bin1_offset || nbins <= 0 || nnz < 0 || !fill)
+        return fail(c, PUP_EINVAL, "pup_load_pixels_stream: NULL table / reader or bad sizes (nbins=%lld nnz=%lld)", (long long)nbins, (long long)nnz);
+    if (bin2_bytes != 4 && bin2_bytes != 8) return fail(c, PUP_EINVAL, "pup_load_pixels_stream: bin2_bytes must be 4 or 8, got %d", bin2_bytes);
+    if (nbins > 0x7fffffffLL - 4096) return fail(c, PUP_ENOTSUP, "pup_load_pixels_stream: nbins %lld does not fit int32 bin ids", (long long)nbins);
+    if (bin1_offset[0] != 0 || bin1_offset[nbins] != nnz)
+        return fail(c, PUP_EINVAL, "pup_load_pixels_stream: bin1_offset[0]=%lld, bin1_offset[nbins]=%lld, expected 0 and nnz=%lld",
+                    (long long)bin1_offset[0], (long long)bin1_offset[nbins], (long long)nnz);
+    int rc = bind(c); if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_px = false; c->have_idx = false; c->forget_hints();
+    c->tbits_state = 0;
+    HIPCHK(c, c->indptr.reserve((size_t)nbins + 1));
+    HIPCHK(c, c->px.reserve((size_t)nnz + 64));
+    HIPCHK(c, c->cnt32.reserve((size_t)nnz + 64));
+    HIPCHK(c, hipMemset(c->cnt32.p + nnz, 0, 64 * sizeof(int)));
+    HIPCHK(c, hipMemcpy(c->indptr.p, bin1_offset, ((size_t)nbins + 1) * sizeof(long long), hipMemcpyHostToDevice));
+    const size_t slab = (size_t)std::max<int64_t>(1, std::min<int64_t>(slab_pixels > 0 ? slab_pixels : ((int64_t)1 << 25), std::max<int64_t>(nnz, 1)));
+    hipStream_t cs = c->stream2 ? c->stream2 : c->stream;                 // the copy stream
+    // two page-locked slabs {bin2_id | count} and two device staging slabs: slab k % 2 is refilled once the pack kernel of slab
+    // k - 2 is done with it; the reader fills one while the other is in flight
+    char* h_slab[2] = {nullptr, nullptr}; char* d_slab[2] = {nullptr, nullptr};
+    hipEvent_t ev_done[2] = {nullptr, nullptr}, ev_t0[2] = {nullptr, nullptr}, ev_t1[2] = {nullptr, nullptr};
+    const size_t slab_bytes = slab * ((size_t)bin2_bytes + sizeof(int));
+    int status = PUP_OK;
+    double ms_total = 0.0; long long bytes_total = 0;
+    auto cleanup = [&]() {
+        for (int s = 0; s < 2; ++s) {
+            if (h_slab[s]) (void)hipHostFree(h_slab[s]);
+            if (d_slab[s]) (void)hipFree(d_slab[s]);
+            if (ev_done[s]) (void)hipEventDestroy(ev_done[s]);
+            if (ev_t0[s]) (void)hipEventDestroy(ev_t0[s]);
+            if (ev_t1[s]) (void)hipEventDestroy(ev_t1[s]);
+        }
+    };
+    for (int s = 0; s < 2 && status == PUP_OK && nnz > 0; ++s) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&h_slab[s]), slab_bytes, hipHostMallocDefault) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&d_slab[s]), slab_bytes) != hipSuccess ||
+            hipEventCreate(&ev_done[s]) != hipSuccess || hipEventCreate(&ev_t0[s]) != hipSuccess || hipEventCreate(&ev_t1[s]) != hipSuccess)
+            status = fail(c, PUP_ENOMEM, "pup_load_pixels_stream: staging allocation failed (%zu bytes per slab)", slab_bytes);
+    }
+    bool used[2] = {false, false};
+    auto harvest = [&](int s) {                           // copy time of the slab's previous trip (its events are complete)
+        float ms = 0.f;
+        if (used[s] && hipEventElapsedTime(&ms, ev_t0[s], ev_t1[s]) == hipSuccess) ms_total += ms;
+    };
+    int k = 0;
+    for (int64_t off = 0; off < nnz && status == PUP_OK; off += (int64_t)slab, ++k) {
+        const int s = k & 1;
+        const size_t m = (size_t)std::min<int64_t>((int64_t)slab, nnz - off);
+        if (used[s]) {
+            hipError_t e = hipEventSynchronize(ev_done[s]);
+            if (e != hipSuccess) { status = fail(c, PUP_EHIP, "pup_load_pixels_stream: %s", hipGetErrorString(e)); break; }
+            harvest(s);
+        }
+        void* hcol = h_slab[s]; int* hcnt = reinterpret_cast<int*>(h_slab[s] + slab * (size_t)bin2_bytes);
+        if (fill(user, off, (int64_t)m, hcol, hcnt) != 0) { status = fail(c, PUP_EINVAL, "pup_load_pixels_stream: the reader failed at pixel %lld", (long long)off); break; }
+        void* dcol = d_slab[s]; int* dcnt = reinterpret_cast<int*>(d_slab[s] + slab * (size_t)bin2_bytes);
+        hipError_t e = hipEventRecord(ev_t0[s], cs);
+        if (e == hipSuccess) e = hipMemcpyAsync(dcol, hcol, m * (size_t)bin2_bytes, hipMemcpyHostToDevice, cs);
+        if (e == hipSuccess) e = hipMemcpyAsync(dcnt, hcnt, m * sizeof(int), hipMemcpyHostToDevice, cs);
+        if (e == hipSuccess) e = hipEventRecord(ev_t1[s], cs);
+        if (e == hipSuccess) {
+            const int blocks = (int)std::min<size_t>((m + 255) / 256, 65536);
+            if (bin2_bytes == 8)
+                hipLaunchKernelGGL(pup::pack_pixels_kernel<long long>, dim3(blocks), dim3(256), 0, cs,
+                                   static_cast<const long long*>(dcol), dcnt, c->px.p + off, c->cnt32.p + off, (long long)m);
+            else
+                hipLaunchKernelGGL(pup::pack_pixels_kernel<int>, dim3(blocks), dim3(256), 0, cs,
+                                   static_cast<const int*>(dcol), dcnt, c->px.p + off, c->cnt32.p + off, (long long)m);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipEventRecord(ev_done[s], cs);
+        if (e != hipSuccess) { status = fail(c, PUP_EHIP, "pup_load_pixels_stream: upload failed: %s", hipGetErrorString(e)); break; }
+        used[s] = true;
+        bytes_total += (long long)(m * ((size_t)bin2_bytes + sizeof(int)));
+    }
+    {
+        hipError_t e = hipStreamSynchronize(cs);
+        if (e != hipSuccess && status == PUP_OK) status = fail(c, PUP_EHIP, "pup_load_pixels_stream: %s", hipGetErrorString(e));
+        for (int s = 0; s < 2; ++s) harvest(s);
+    }
+    cleanup();
+    if (status != PUP_OK) return status;
+    if (h2d_ms) *h2d_ms = ms_total;
+    if (h2d_bytes) *h2d_bytes = bytes_total;
+    c->nbins = nbins; c->nnz = nnz; c->have_px = true;
+    c->have_weight = c->have_cov = false; c->have_bal = false;
+    return PUP_OK;
+}
+
 int pup_build_index(pup_ctx* c, const int64_t* chrom_offset, int32_t n_chroms, int64_t max_bytes) {
     if (!c) return PUP_EINVAL;
     if (!c->have_px) return fail(c, PUP_ESTATE, "pup_build_index: call pup_load_pixels first");

@@ -99,6 +99,38 @@ class PileupEngine:
                                               _ptr(count), nbins, nnz))
         self.nbins, self.nnz = nbins, nnz
 
+    def load_pixels_stream(self, bin1_offset, nnz, bin2_dtype, fill, slab_pixels=0):
+        """The pixel table streamed in (pup_load_pixels_stream): ``fill(first, m, bin2_view, count_view)`` writes pixels
+        [first, first + m) into two numpy views of a PAGE-LOCKED slab of the library (bin2_view: dtype bin2_dtype, count_view:
+        int32) — e.g. straight from hyperslabs of a .cool file — while the previous slab is on its way to the GPU.
+        Returns {"h2d_ms", "h2d_bytes", "h2d_GBps"} of the copies alone."""
+        bin1_offset = _as(bin1_offset, np.int64)
+        bin2_dtype = np.dtype(bin2_dtype)
+        if bin2_dtype not in (np.dtype(np.int32), np.dtype(np.int64)):
+            raise ValueError("bin2_id must be streamed as int32 or int64")
+        nbins = bin1_offset.shape[0] - 1
+        err = []
+
+        def _cb(user, first, m, p_col, p_cnt):
+            try:
+                colv = np.ctypeslib.as_array(C.cast(p_col, C.POINTER(C.c_int64 if bin2_dtype.itemsize == 8 else C.c_int32)), shape=(m,))
+                cntv = np.ctypeslib.as_array(C.cast(p_cnt, C.POINTER(C.c_int32)), shape=(m,))
+                fill(int(first), int(m), colv, cntv)
+                return 0
+            except Exception as e:      # noqa: BLE001 - must not propagate through the C frame
+                err.append(e)
+                return 1
+        cb = _ffi.FILL_FN(_cb)
+        ms, nbytes = C.c_double(0.0), C.c_int64(0)
+        rc = self._lib.pup_load_pixels_stream(self._h, _ptr(bin1_offset), nbins, int(nnz), bin2_dtype.itemsize, int(slab_pixels),
+                                              C.cast(cb, C.c_void_p), None, C.byref(ms), C.byref(nbytes))
+        if err:
+            raise err[0]
+        self._check(rc)
+        self.nbins, self.nnz = nbins, int(nnz)
+        return {"h2d_ms": ms.value, "h2d_bytes": nbytes.value,
+                "h2d_GBps": (nbytes.value / (ms.value * 1e-3) / 1e9) if ms.value > 0 else None}
+
     def build_index(self, chrom_offset, max_bytes=0):
         """Rank-bitmap index over the cis part of the table (chrom_offset = the cooler's indexes/chrom_offset).
         Returns True when built, False when it does not fit (the engine then keeps using binary search)."""

@@ -7,7 +7,8 @@
  * (it is pure Python); each entry point below names the reference code it
  * replaces (paths are relative to the coolpuppy source tree):
  *
- *   pup_load_pixels / pup_load_bins   <- PileUpper.get_data            coolpuppy/coolpup.py:1024-1057
+ *   pup_load_pixels / pup_load_pixels_stream / pup_load_bins
+ *                                     <- PileUpper.get_data            coolpuppy/coolpup.py:1024-1057
  *                                        + weight / coverage columns   coolpuppy/coolpup.py:1081-1098
  *   pup_build_index                   <- (no counterpart: device-side search structure over the same table;
  *                                        chromosome partition = cooler's indexes/chrom_offset, the extents the
@@ -104,6 +105,20 @@ int  pup_device_count(void);
  */
 int pup_load_pixels(pup_ctx* ctx, const int64_t* bin1_offset, const void* bin2_id, int bin2_bytes,
                     const int32_t* count, int64_t nbins, int64_t nnz);
+/*
+ * The same table STREAMED in: the caller hands over a reader instead of whole arrays.  The library owns two page-locked slabs and
+ * calls fill(user, first, m, bin2_id, count) to have pixels [first, first + m) written into one of them (bin2_id: m values of
+ * bin2_bytes bytes; count: m x int32; return 0, anything else aborts the load with PUP_EINVAL) while the previous slab is on
+ * its way: hipMemcpyAsync from page-locked memory on a copy stream, interleaved on the device by the same kernel as
+ * pup_load_pixels.  fill is called from the calling thread, in order, with m <= slab_pixels (0 = library default, 32 Mi).
+ * This is the reader side of "cooler HDF5 I/O stays on the host with pinned hipMemcpyAsync overlap": cool_io.py fills the slabs
+ * straight from pixels/bin2_id and pixels/count hyperslabs of the .cool file, so the pixel table never exists in pageable
+ * host memory (the reference reaches the same bytes through cooler's matrix().fetch() per region, coolpuppy/coolpup.py:1053-1057).
+ * h2d_ms (nullable): device time of the host-to-device copies alone; h2d_bytes (nullable): bytes they moved.
+ */
+typedef int (*pup_fill_fn)(void* user, int64_t first, int64_t m, void* bin2_id, int32_t* count);
+int pup_load_pixels_stream(pup_ctx* ctx, const int64_t* bin1_offset, int64_t nbins, int64_t nnz, int bin2_bytes,
+                           int64_t slab_pixels, pup_fill_fn fill, void* user, double* h2d_ms, int64_t* h2d_bytes);
 /*
  * Per-bin vectors (float64[nbins]).  weight: balancing weights, NaN = masked bin; NULL = raw counts
  * (clr_weight_name falsy: no bin is masked).  cov: coverage column for coverage_norm; NULL = none.

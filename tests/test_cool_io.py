@@ -296,3 +296,68 @@ def test_clpy_object_blocks_are_read_with_a_restricted_unpickler():
             return (os.system, ("true",))
     with pytest.raises(pickle.UnpicklingError):
         pio._restricted_loads(pickle.dumps(Evil()))
+
+
+@pytest.mark.parametrize("group,gz", [("/", None), ("resolutions/10000", 4)])
+def test_streamed_cooler_reads_row_range_chunks(tmp_path, group, gz):
+    """read_cool(..., stream_pixels=True): everything but the pixel table is in memory, pixel chunks come out of the file by
+    hyperslab reads straight into caller-provided (page-locked, on the GPU path) arrays — at any offset, for contiguous and
+    for chunked + gzip datasets, and the lazily loaded whole arrays equal the eager reader's."""
+    from coolpuppy_amd import cool_io
+    clr = synth.make_cooler({"chr1": 9_000_000, "chr2": 6_500_000, "chrX": 3_000_000}, lam=30, seed=5, trans_nnz=2000)
+    path = str(tmp_path / "t.cool")
+    cool_io.write_cool(path, clr, group=group, chunks=None if gz is None else 4096, gzip=gz)
+    eager = cool_io.read_cool(path, group=group)
+    np.testing.assert_array_equal(eager.bin2_id, clr.pixel_table()[1])
+    lazy = cool_io.read_cool(path, group=group, stream_pixels=True)
+    assert isinstance(lazy, cool_io.StreamedCooler) and not lazy.pixels_in_memory
+    assert lazy.nnz == clr.nnz and lazy.nbins == clr.nbins and lazy.chromnames == clr.chromnames
+    np.testing.assert_array_equal(lazy.bin1_offset, clr.pixel_table()[0])
+    np.testing.assert_array_equal(lazy.bins()["weight"][:].values, clr.bins()["weight"][:].values)
+    f = cool_io._File(path)
+    g = "" if group == "/" else "/" + group
+    assert clr.nnz > 20000
+    for first, m in ((0, 1), (0, 5000), (4095, 3), (1234, clr.nnz - 5000), (clr.nnz - 7, 7)):
+        col = np.empty(m, np.int64); cnt = np.empty(m, np.int32)
+        f.read_into(f"{g}/pixels/bin2_id", first, col)
+        f.read_into(f"{g}/pixels/count", first, cnt)
+        np.testing.assert_array_equal(col, clr.pixel_table()[1][first:first + m])
+        np.testing.assert_array_equal(cnt, clr.pixel_table()[2][first:first + m])
+    f.close()
+    assert not lazy.pixels_in_memory
+    np.testing.assert_array_equal(lazy.pixel_table()[1], clr.pixel_table()[1])      # whoever asks for the arrays gets them
+    np.testing.assert_array_equal(lazy.pixel_table()[2], clr.pixel_table()[2])
+    assert lazy.pixels_in_memory
+
+
+@pytest.mark.gpu
+def test_streamed_cooler_upload_matches_the_eager_one(tmp_path, hip_lib):
+    """The pixel table streamed file -> page-locked slabs -> HBM (pup_load_pixels_stream, several slabs) gives the same engine
+    state as the whole-array upload: identical pile-ups through pileup(), and the copy statistics are reported."""
+    from coolpuppy_amd import cool_io, coolpup
+    from coolpuppy_amd.engine import PileupEngine
+    clr = synth.make_cooler({"chr1": 90_000_000, "chr2": 65_000_000}, lam=150, seed=8)
+    path = str(tmp_path / "s.cool")
+    cool_io.write_cool(path, clr, chunks=65536, gzip=1)
+    lazy = cool_io.read_cool(path, stream_pixels=True)
+    pairs = synth.random_cis_pairs(clr, 20_000, seed=2)
+    kw = dict(features_format="bedpe", flank=100_000, nshifts=2, seed=1)
+    a = coolpup.pileup(clr, pairs, **kw)
+    b = coolpup.pileup(lazy, pairs, **kw)
+    assert not lazy.pixels_in_memory and lazy._last_stream_stats["h2d_bytes"] == clr.nnz * 12
+    np.testing.assert_array_equal(np.asarray(a["num"].iloc[0]), np.asarray(b["num"].iloc[0]))
+    np.testing.assert_array_equal(np.asarray(a["data"].iloc[0]), np.asarray(b["data"].iloc[0]))
+    # small slabs: many trips through the two page-locked buffers
+    eng = PileupEngine(0)
+    st = cool_io.stream_pixels_into(eng, lazy, slab_pixels=100_003)
+    assert st["h2d_bytes"] == clr.nnz * 12 and st["h2d_ms"] > 0
+    eng.build_index(clr.chrom_offset)
+    eng.load_bins(clr.bins()["weight"][:].values, None)
+    ref = PileupEngine(0)
+    ref.load_pixels(*clr.pixel_table()); ref.build_index(clr.chrom_offset); ref.load_bins(clr.bins()["weight"][:].values, None)
+    r0 = np.arange(100, 8000, 3, dtype=np.int32); c0 = (r0 + 40).astype(np.int32)
+    for e in (eng, ref):
+        e.reset(1, 10); e.accumulate(r0, c0, np.array([0, len(r0)], np.int64))
+    x, y = eng.fetch(), ref.fetch()
+    np.testing.assert_array_equal(x["num"], y["num"]); np.testing.assert_array_equal(x["sum"], y["sum"])
+    eng.close(); ref.close()
