@@ -100,6 +100,7 @@ struct pup_ctx {
     DevBuf<unsigned char> d_sorttmp;
     // K1w (pup_wide.hpp): partial records of the wide-window staged kernel
     DevBuf<double> wrec_f64; DevBuf<unsigned> wrec_num, wrec_seg;
+    DevBuf<double> rs_scratch;               // K5: one slab of window cells per workgroup (see pileup_rescale_kernel)
     DevBuf<double> cov_rec; DevBuf<unsigned> cov_owner;     // coverage-vector pass beside the staged kernels (cov_vectors_kernel)
     long long wide_min = 20000;              // calls of at least this many wide cis windows take the staged wide kernel
     const char* last_kernel = "";            // which pile-up kernel the last pup_accumulate ran (diagnostics)
@@ -172,7 +173,7 @@ struct pup_ctx {
     hipEvent_t slots[8] = {};
     int chunk_snippets = 0, variant = 0, group_waves = 0, debug_phases = 0;
     std::vector<long long> geom_key;            // launch-geometry cache (see pup_accumulate)
-    long long g_nchunks = 0, g_nblocks = 0, g_nblocks_t = 0, g_nslices = 0;
+    long long g_nchunks = 0, g_nblocks = 0, g_nblocks_t = 0, g_nslices = 0, g_max_per_tile = 0;
     bool g_two_level = false;
     int max_lds = 0, n_cu = 0;
     float last_coverage_ms = 0.f;
@@ -357,7 +358,7 @@ void pup_destroy(pup_ctx* c) {
     c->d_keys.release(); c->d_keys2.release(); c->d_cnt32.release(); c->d_win.release(); c->d_win2.release();
     c->d_starts.release(); c->d_blocks.release();
     c->d_wgfirst.release(); c->d_segend.release(); c->htab_sent.clear(); c->d_sorttmp.release();
-    c->wrec_f64.release(); c->wrec_num.release(); c->wrec_seg.release(); c->cov_rec.release(); c->cov_owner.release();
+    c->wrec_f64.release(); c->wrec_num.release(); c->wrec_seg.release(); c->cov_rec.release(); c->cov_owner.release(); c->rs_scratch.release();
     if (c->ev_key) (void)hipEventDestroy(c->ev_key);
     if (c->h_flags) (void)hipHostFree(const_cast<unsigned*>(c->h_flags));
     c->d_k32.release(); c->d_k32b.release();
@@ -1663,7 +1664,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         c->gv.chunk_flip = g + o_cf;
         c->gv.run_ptr = reinterpret_cast<const long long*>(g + o_rp);
     }
-    c->g_nchunks = nchunks; c->g_nblocks = nblocks; c->g_two_level = two_level; c->g_nslices = nslices;
+    c->g_nchunks = nchunks; c->g_nblocks = nblocks; c->g_two_level = two_level; c->g_nslices = nslices; c->g_max_per_tile = max_per_tile;
     c->geom_key = gkey;
     }   // !geom_hit
     const long long nblocks = c->g_nblocks, nslices = c->g_nslices;
@@ -1695,8 +1696,15 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     if (rescale) {
         const size_t rs_lds = (size_t)W * W * 12 + 16 * (size_t)W;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pup::pileup_rescale_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_lds);
+        // a slab per workgroup for the gathered window: the largest window of the call, as long as the slabs stay below 8 GB
+        long long max_cells = 0;
+        for (int64_t i = 0; i < n; ++i) max_cells = std::max(max_cells, (long long)hgt[i] * (long long)wid[i]);
+        long long slab_cells = (max_cells + 63) & ~63LL;
+        if (slab_cells <= 0 || (unsigned long long)slab_cells * 8ull * (unsigned long long)nblocks > (8ull << 30) ||
+            c->rs_scratch.reserve((size_t)slab_cells * (size_t)nblocks) != hipSuccess) { slab_cells = 0; (void)hipGetLastError(); }
         hipLaunchKernelGGL(pup::pileup_rescale_kernel, dim3((unsigned)nblocks), dim3(rs_threads), rs_lds, c->stream, a,
-                           (const int*)c->d_h.p, (const int*)c->d_w.p, (double*)nullptr, (double*)nullptr, 0LL);
+                           (const int*)c->d_h.p, (const int*)c->d_w.p, (double*)nullptr, (double*)nullptr, 0LL,
+                           slab_cells ? c->rs_scratch.p : (double*)nullptr, slab_cells);
         launched = true; c->last_kernel = "rescale";
     }
     const bool sparse_launch = !lds_kernel2 && !rescale && ignore_diags < 0 && W <= 63 && !(c->variant & 32) &&
@@ -1714,7 +1722,14 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
                 const unsigned gb3 = (unsigned)std::min<long long>((c->nbins + 3) / 4, 1 << 20);
                 hipLaunchKernelGGL(pup::tbits_fill_kernel, dim3(gb3), dim3(256), 0, c->stream, c->indptr.p, c->px.p, c->tbits.p, c->nbins);
                 c->tbits_state = 1;
-            } else (void)hipGetLastError();
+            } else {
+                (void)hipGetLastError();
+                if (!(c->warned & 4u) && !getenv("COOLPUPPY_AMD_QUIET")) {
+                    c->warned |= 4u;
+                    fprintf(stderr, "[coolpuppy_amd] inter-chromosomal pile-up without the presence bitmap of the table (%.1f GB for %lld bins do not fit a quarter of the free memory): "
+                                    "the sparse kernel bisects every window row instead (about 1.5x slower)\n", (double)words * 8e-9, c->nbins);
+                }
+            }
         }
         a.tbits = c->tbits_state == 1 ? c->tbits.p : nullptr;
         const size_t sl = pup::k1s_lds_bytes(W);
@@ -1770,6 +1785,10 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
                            c->part_f64.p, c->part_num.p, c->gv.seg1, (int)Lf, Li, c->slice_f64.p, c->slice_num.p);
         hipLaunchKernelGGL((pup::reduce_partials_kernel<long long, true>), rg2, rb, 0, c->stream,
                            c->slice_f64.p, c->slice_num.p, c->gv.seg2, (int)Lf, Li, c->acc_f64.p, c->acc_i64.p);
+    } else if (c->T >= 1024 && c->g_nchunks <= 4LL * c->T && c->g_max_per_tile <= 512) {
+        // many tiles with a few records each (by-window): thread per element, records in order
+        hipLaunchKernelGGL((pup::reduce_partials_small_kernel<unsigned>), dim3((unsigned)((Lf + Li + 255) / 256), (unsigned)c->T), dim3(256), 0,
+                           c->stream, c->part_f64.p, c->part_num.p, c->gv.seg2, (int)Lf, Li, c->acc_f64.p, c->acc_i64.p);
     } else {
         hipLaunchKernelGGL((pup::reduce_partials_kernel<unsigned, true>), rg2, rb, 0, c->stream,
                            c->part_f64.p, c->part_num.p, c->gv.seg2, (int)Lf, Li, c->acc_f64.p, c->acc_i64.p);
@@ -1911,9 +1930,14 @@ int pup_extract(pup_ctx* c, const int32_t* r0, const int32_t* c0, const int32_t*
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pup::pileup_rescale_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_lds);
             if (cov_start && !(mode & PUP_MODE_COV)) e = hipMemsetAsync(d_cov.p, 0xff, (size_t)n * 2 * W * 8, c->stream);  // NaN
+            long long max_cells = 0;
+            for (int64_t i = 0; i < n; ++i) max_cells = std::max(max_cells, (long long)height[i] * (long long)width[i]);
+            long long slab_cells = (max_cells + 63) & ~63LL;
+            if (slab_cells <= 0 || (unsigned long long)slab_cells * 8ull * grid > (8ull << 30) ||
+                c->rs_scratch.reserve((size_t)slab_cells * grid) != hipSuccess) { slab_cells = 0; (void)hipGetLastError(); }
             hipLaunchKernelGGL(pup::pileup_rescale_kernel, dim3(grid), dim3(256), rs_lds, c->stream, a,
                                (const int*)c->d_h.p, (const int*)c->d_w.p, d_out.p, cov_start ? d_cov.p : (double*)nullptr,
-                               (long long)n);
+                               (long long)n, slab_cells ? c->rs_scratch.p : (double*)nullptr, slab_cells);
         } else {
             hipLaunchKernelGGL(pup::extract_windows_kernel, dim3(grid), dim3(256), 0, c->stream, a, (long long)n, d_out.p,
                                cov_start ? d_cov.p : (double*)nullptr);

@@ -95,7 +95,8 @@ def test_windows_leaving_their_region_are_skipped_not_clipped(monkeypatch):
 
 @pytest.mark.gpu
 def test_widest_supported_window_and_beyond(hip_lib):
-    """W = 255 (pad 127) is the banded kernel's limit: parity against the oracle; wider windows fail loudly."""
+    """W = 255 (pad 127) was the banded kernel's limit until round 3; the reference slices any width (coolpuppy/coolpup.py:1115-1121)
+    and so does the engine now: parity against the oracle at 255 and at 257 / 351 bins (column panels of the banded kernel)."""
     from coolpuppy_amd.engine import PileupEngine, PupError
     from oracle import pileup_oracle as po
     clr = gu.cooler("small")
@@ -118,9 +119,17 @@ def test_widest_supported_window_and_beyond(hip_lib):
     want = po.pileup_c(indptr, col, cnt, weight, None, None, r0, c0, None, tile, 1, pad, 2, 0)
     np.testing.assert_array_equal(got["num"], want["num"])
     np.testing.assert_allclose(got["sum"], want["sum"], rtol=1e-12, atol=0)
-    with pytest.raises(PupError):
-        eng.reset(1, 128)
-        eng.accumulate(r0, c0, np.array([0, 40]), ignore_diags=2, mode=0)
+    for pad in (128, 175):
+        W = 2 * pad + 1
+        r0 = rng.integers(0, hiA - 2 * W, 30).astype(np.int32)
+        c0 = (r0 + rng.integers(0, W, 30)).astype(np.int32)
+        eng.reset(1, pad)
+        eng.accumulate(r0, c0, np.array([0, 30]), ignore_diags=2, mode=0)
+        got = eng.fetch()
+        want = po.pileup_c(indptr, col, cnt, weight, None, None, r0, c0, None, np.zeros(30, np.int32), 1, pad, 2, 0)
+        np.testing.assert_array_equal(got["num"], want["num"])
+        np.testing.assert_allclose(got["sum"], want["sum"], rtol=1e-12, atol=0)
+    del PupError
     eng.close()
 
 
