@@ -10,6 +10,7 @@
 #include "pup_staged.hpp"
 #include "pup_staged_launch.hpp"
 #include "pup_wide.hpp"
+#include "pup_bin.hpp"
 
 #include <hip/hip_runtime.h>
 #include <cstring>
@@ -100,6 +101,9 @@ struct pup_ctx {
     DevBuf<unsigned char> d_sorttmp;
     // K1w (pup_wide.hpp): partial records of the wide-window staged kernel
     DevBuf<double> wrec_f64; DevBuf<unsigned> wrec_num, wrec_seg;
+    // hand-written block binning (pup_bin.hpp): digit counts / bucket bases / ticket / per-bucket block counts, tile descriptors of the
+    // partition pass, the buckets' block lists, the packed block keys, the sorted low digits (sets of tile pairs)
+    DevBuf<unsigned> d_binmeta, d_bindesc, d_blkkey, d_bkeys; DevBuf<unsigned short> d_low;
     DevBuf<double> rs_scratch;               // K5: one slab of window cells per workgroup (see pileup_rescale_kernel)
     DevBuf<double> cov_rec; DevBuf<unsigned> cov_owner;     // coverage-vector pass beside the staged kernels (cov_vectors_kernel)
     long long wide_min = 20000;              // calls of at least this many wide cis windows take the staged wide kernel
@@ -359,6 +363,7 @@ void pup_destroy(pup_ctx* c) {
     c->d_starts.release(); c->d_blocks.release();
     c->d_wgfirst.release(); c->d_segend.release(); c->htab_sent.clear(); c->d_sorttmp.release();
     c->wrec_f64.release(); c->wrec_num.release(); c->wrec_seg.release(); c->cov_rec.release(); c->cov_owner.release(); c->rs_scratch.release();
+    c->d_binmeta.release(); c->d_bindesc.release(); c->d_blkkey.release(); c->d_bkeys.release(); c->d_low.release();
     if (c->ev_key) (void)hipEventDestroy(c->ev_key);
     if (c->h_flags) (void)hipHostFree(const_cast<unsigned*>(c->h_flags));
     c->d_k32.release(); c->d_k32b.release();
@@ -819,16 +824,18 @@ extern "C++" {
 template <typename KeyT>
 static void launch_key_kernel(pup_ctx* c, int BR, int BC, unsigned grid, const int* dr0, const int* dc0, long long n, int nseg2t, int H,
                               int set_pairs, const pup::ExpRegion* d_eregs, int n_eregs, int W, int sh_br, int sh_er, int sh_seg,
-                              int seg_shift, int clear_gap, int far_gap, KeyT* keys) {
+                              int seg_shift, int clear_gap, int far_gap, KeyT* keys, unsigned* hi_hist = nullptr, int hi_shift = 0, int hi_bins = 0) {
+    const int per_thread = hi_hist ? pup::kBinTile / 256 : 4;       // with the binning prepass a workgroup keys one of its tiles
 #define PUP_KEY_ARGS dr0, dc0, n, (const long long*)c->d_segend.p, nseg2t, H, set_pairs, (const pup::IdxChrom*)c->idx_chrom.p, c->n_chrom, \
         (const unsigned short*)c->bin_chrom.p, (long long)c->nbins, (const int*)c->d_brow.p, d_eregs, n_eregs, W, BR, BC, sh_br, \
-        sh_er, sh_seg, seg_shift, clear_gap, far_gap, (c->band_w > 0 && !(c->variant & 256)) ? c->band_w : 0, keys, c->d_win.p, c->d_cnt32.p
+        sh_er, sh_seg, seg_shift, clear_gap, far_gap, (c->band_w > 0 && !(c->variant & 256)) ? c->band_w : 0, keys, c->d_win.p, c->d_cnt32.p, hi_hist, hi_shift, hi_bins, per_thread
+    const size_t lds = (size_t)nseg2t * sizeof(long long) + (size_t)hi_bins * sizeof(unsigned);
     if (BR == 108 && BC == 108)
-        hipLaunchKernelGGL((pup::staged_key_kernel<KeyT, 108, 108>), dim3(grid), dim3(256), 0, c->stream, PUP_KEY_ARGS);
+        hipLaunchKernelGGL((pup::staged_key_kernel<KeyT, 108, 108>), dim3(grid), dim3(256), lds, c->stream, PUP_KEY_ARGS);
     else if (BR == 44 && BC == 108)
-        hipLaunchKernelGGL((pup::staged_key_kernel<KeyT, 44, 108>), dim3(grid), dim3(256), 0, c->stream, PUP_KEY_ARGS);
+        hipLaunchKernelGGL((pup::staged_key_kernel<KeyT, 44, 108>), dim3(grid), dim3(256), lds, c->stream, PUP_KEY_ARGS);
     else
-        hipLaunchKernelGGL((pup::staged_key_kernel<KeyT, 0, 0>), dim3(grid), dim3(256), 0, c->stream, PUP_KEY_ARGS);
+        hipLaunchKernelGGL((pup::staged_key_kernel<KeyT, 0, 0>), dim3(grid), dim3(256), lds, c->stream, PUP_KEY_ARGS);
 #undef PUP_KEY_ARGS
 }
 }   // extern "C++"
@@ -854,6 +861,55 @@ static void fill_k1_args(pup_ctx* c, pup::K1Args& a, int32_t ignore_diags, uint3
     a.W = c->W; a.ignore_diags = ignore_diags; a.mode = mode;
 }
 
+
+
+// ---- the hand-written block binning of the staged kernels' prepass (pup_bin.hpp) -------------------------------------------
+// Digit split of a key of `end_bit` bits whose lowest `slot_bits` hold the accumulator slot: false when the key is too wide
+struct BinPlan { int DL, DH; long long ntiles; };
+static bool bin_plan(int end_bit, int slot_bits, long long n_items, BinPlan& bp) {
+    // a bucket is ordered by ONE wave: many small buckets — the high digit takes the larger half of the key
+    int DH = std::min((end_bit + 2) / 2, pup::kBinMaxDigit);
+    int DL = std::max(end_bit - DH, 0);
+    if (DL < slot_bits) { DL = slot_bits; DH = std::max(end_bit - DL, 0); }
+    if (DL > pup::kBinMaxDigit) return false;
+    if (DH > pup::kBinMaxDigit || n_items >= 0x3fffffffLL) return false;
+    bp.DL = DL; bp.DH = DH; bp.ntiles = (n_items + pup::kBinTile - 1) / pup::kBinTile;
+    return true;
+}
+// buffers of a binning run (nothing to clear: every table is written in full by the kernel before its reader)
+static int bin_prepare(pup_ctx* c, const BinPlan& bp, long long n_items, bool want_low) {
+    const size_t nd = (size_t)1 << bp.DH;
+    const size_t nchunks = (size_t)((bp.ntiles + pup::kBinChunk - 1) / pup::kBinChunk);
+    HIPCHK(c, c->d_binmeta.reserve(2 * nd + 8 + nchunks * nd));      // base[nd + 1] | blk_count[nd] | chunksum[nchunks][nd]
+    HIPCHK(c, c->d_bindesc.reserve((size_t)bp.ntiles * nd));         // tilehist[ntiles][nd]: the key kernel's workgroups write their rows
+    HIPCHK(c, c->d_blkkey.reserve((size_t)n_items + 1)); HIPCHK(c, c->d_bkeys.reserve((size_t)n_items + 1));
+    if (want_low) HIPCHK(c, c->d_low.reserve((size_t)n_items + 8));
+    return PUP_OK;
+}
+// keys (u32) / vals (u16) of n_items windows -> vals in block order (vals_out), block starts + keys (d_starts / d_bkeys), block count
+// (n_runs).  keys_scratch: n_items dwords the partition pass writes (low digit | value); the keys themselves are free afterwards
+static int bin_run(pup_ctx* c, const BinPlan& bp, long long n_items, int slot_bits, unsigned* keys, const unsigned short* vals,
+                   unsigned* keys_scratch, unsigned short* vals_out, bool want_low, unsigned* n_runs) {
+    const int nd = 1 << bp.DH, nl = 1 << bp.DL;
+    const int nchunks = (int)((bp.ntiles + pup::kBinChunk - 1) / pup::kBinChunk);
+    unsigned* base = c->d_binmeta.p; unsigned* blk_count = base + nd + 1; unsigned* chunksum = blk_count + nd + 7;
+    const unsigned* tilehist = c->d_bindesc.p;
+    hipLaunchKernelGGL(pup::bin_chunksum_kernel, dim3((unsigned)nchunks, (unsigned)((nd + 1023) / 1024)), dim3(nd < 1024 ? nd : 1024), 0, c->stream,
+                       tilehist, bp.ntiles, nd, chunksum);
+    hipLaunchKernelGGL(pup::bin_scan_kernel, dim3(1), dim3(1024), 0, c->stream, chunksum, nchunks, nd, base);
+    const size_t lds1 = (size_t)pup::kBinWaves * nd * sizeof(unsigned short), lds2 = (size_t)pup::kBucketWaves * 2 * nl * sizeof(unsigned);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pup::bin_partition_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    hipLaunchKernelGGL(pup::bin_partition_kernel, dim3((unsigned)bp.ntiles), dim3(pup::kWave * pup::kBinWaves), lds1, c->stream,
+                       (const unsigned*)keys, vals, n_items, bp.DL, bp.DH, (const unsigned*)base, (const unsigned*)chunksum, tilehist, keys_scratch);
+    // (the keys are dead now: their buffer takes the buckets' block starts)
+    hipLaunchKernelGGL(pup::bin_bucket_kernel, dim3((unsigned)((nd + pup::kBucketWaves - 1) / pup::kBucketWaves)), dim3(pup::kWave * pup::kBucketWaves), lds2,
+                       c->stream, (const unsigned*)keys_scratch, (const unsigned*)base, bp.DL, bp.DH, slot_bits, vals_out,
+                       want_low ? c->d_low.p : (unsigned short*)nullptr, keys, c->d_blkkey.p, blk_count);
+    hipLaunchKernelGGL(pup::bin_compact_kernel, dim3((unsigned)nd), dim3(256), 0, c->stream, (const unsigned*)base, (const unsigned*)blk_count, nd,
+                       (const unsigned*)keys, (const unsigned*)c->d_blkkey.p, c->d_starts.p, c->d_bkeys.p, n_runs);
+    HIPCHK(c, hipGetLastError());
+    return PUP_OK;
+}
 
 // coverage vectors of the call as a pass of their own (see cov_vectors_kernel): enqueued behind the staged pile-up, adds into
 // the cov slots of the accumulators.  d_segend holds the call's (tile, flip) run ends.
@@ -1026,17 +1082,24 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
         HIPCHK(c, hipMemcpy(c->d_teams.p, teams.data(), teams.size(), hipMemcpyHostToDevice));
         c->teams_sent = teams;
     }
+    // block order: the hand-written binning (pup_bin.hpp) for keys of up to 22 bits, else (or with variant bit 29) the library's radix sort
+    BinPlan bp{};
+    const bool use_bin = k32 && !(c->variant & 1024) && bin_plan(end_bit, slot_bits, (long long)n, bp);
     size_t tmp_bytes = 0;
-    hipError_t se = k32 ? rocprim::radix_sort_pairs<Radix10>(nullptr, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_win.p, c->d_win2.p, (size_t)n, 0, end_bit, c->stream)
-                        : rocprim::radix_sort_pairs<Radix10>(nullptr, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_win.p, c->d_win2.p, (size_t)n, 0, end_bit, c->stream);
-    if (se == hipSuccess) se = c->d_sorttmp.reserve(tmp_bytes + 16);
-    if (se != hipSuccess) return fail(c, PUP_EHIP, "pup_accumulate: block sort: %s", hipGetErrorString(se));
+    hipError_t se = hipSuccess;
+    if (!use_bin) {
+        se = k32 ? rocprim::radix_sort_pairs<Radix10>(nullptr, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_win.p, c->d_win2.p, (size_t)n, 0, end_bit, c->stream)
+                 : rocprim::radix_sort_pairs<Radix10>(nullptr, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_win.p, c->d_win2.p, (size_t)n, 0, end_bit, c->stream);
+        if (se == hipSuccess) se = c->d_sorttmp.reserve(tmp_bytes + 16);
+        if (se != hipSuccess) return fail(c, PUP_EHIP, "pup_accumulate: block sort: %s", hipGetErrorString(se));
+    }
 
     // ---- prepass, all on the stream -------------------------------------------------------------------------------------
     if (ev) HIPCHK(c, hipEventRecord(ev[0], c->stream));
+    if (use_bin) { const int brc = bin_prepare(c, bp, (long long)n, slot_bits > 0); if (brc != PUP_OK) return brc; }
     HIPCHK(c, hipMemsetAsync(c->d_cnt32.p, 0, (ncnt + (size_t)n_spans + (nrec + 1) / 2) * sizeof(unsigned), c->stream));
     unsigned short* const d_recvalid = reinterpret_cast<unsigned short*>(c->d_cnt32.p + ncnt + (size_t)n_spans);
-    const unsigned gk4 = (unsigned)((n + 1023) / 1024);               // key kernel: four windows per thread
+    const unsigned gk4 = use_bin ? (unsigned)bp.ntiles : (unsigned)((n + 1023) / 1024);      // key kernel: four windows per thread, or a binning tile per workgroup
     const pup::ExpRegion* d_eregs = n_eregs > 0 ? c->exp_regions.p : nullptr;
     const unsigned ticket = ++c->ticket;
     // observed over expected with a by-diagonal expected whose unusable diagonals are all ignored ones: a cell's validity is
@@ -1056,7 +1119,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     }
     const int n_eregs_key = er_in_key ? n_eregs : 0;
     if (k32) launch_key_kernel<unsigned>(c, BR, BC, gk4, dr0, dc0, (long long)n, nseg2t, H, set_pairs, d_eregs, n_eregs_key, W, sh_br, sh_er,
-                                         sh_seg, seg_shift, ignore_diags + W - 1, far_gap, c->d_k32.p);
+                                         sh_seg, seg_shift, ignore_diags + W - 1, far_gap, c->d_k32.p, use_bin ? c->d_bindesc.p : nullptr, bp.DL, 1 << bp.DH);
     else launch_key_kernel<unsigned long long>(c, BR, BC, gk4, dr0, dc0, (long long)n, nseg2t, H, set_pairs, d_eregs, n_eregs_key, W, sh_br,
                                                sh_er, sh_seg, seg_shift, ignore_diags + W - 1, far_gap, c->d_keys.p);
     hipLaunchKernelGGL(pup::staged_publish_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned*)c->d_cnt32.p, 3,
@@ -1064,7 +1127,16 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     HIPCHK(c, hipEventRecord(c->ev_key, c->stream));
     unsigned* d_spans = c->d_cnt32.p + ncnt;
     const unsigned gt = (unsigned)std::min<long long>(4096, (n + 255) / 256);
-    if (k32) {
+    if (use_bin) {
+        const int brc = bin_run(c, bp, (long long)n, slot_bits, c->d_k32.p, c->d_win.p, c->d_k32b.p, c->d_win2.p, slot_bits > 0, c->d_cnt32.p + 3);
+        if (brc != PUP_OK) return brc;
+        hipLaunchKernelGGL((pup::staged_table_kernel<unsigned>), dim3(gt), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
+                           (const unsigned*)(c->d_cnt32.p + 3), (long long)n, (const unsigned*)nullptr,
+                           (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
+                           c->n_chrom, W, W, geo.RSR, geo.RSC, 1, pup::kBlockCost, sh_br, sh_er, sh_seg, seg_shift, slot_bits, n_eregs, er_in_key ? 1 : 0, d_eregs,
+                           (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G, (const unsigned*)c->d_bkeys.p,
+                           slot_bits > 0 ? (const unsigned short*)c->d_low.p : (const unsigned short*)nullptr);
+    } else if (k32) {
         se = rocprim::radix_sort_pairs<Radix10>(c->d_sorttmp.p, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_win.p, c->d_win2.p,
                                                 (size_t)n, 0, end_bit, c->stream);
         if (se != hipSuccess) return fail(c, PUP_EHIP, "pup_accumulate: block sort: %s", hipGetErrorString(se));
@@ -1076,7 +1148,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
                            (const unsigned*)(c->d_cnt32.p + 3), (long long)n, (const unsigned*)c->d_k32b.p,
                            (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
                            c->n_chrom, W, W, geo.RSR, geo.RSC, 1, pup::kBlockCost, sh_br, sh_er, sh_seg, seg_shift, slot_bits, n_eregs, er_in_key ? 1 : 0, d_eregs,
-                           (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G);
+                           (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G, (const unsigned*)nullptr, (const unsigned short*)nullptr);
     } else {
         se = rocprim::radix_sort_pairs<Radix10>(c->d_sorttmp.p, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_win.p, c->d_win2.p,
                                                 (size_t)n, 0, end_bit, c->stream);
@@ -1089,7 +1161,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
                            (const unsigned*)(c->d_cnt32.p + 3), (long long)n, (const unsigned long long*)c->d_keys2.p,
                            (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
                            c->n_chrom, W, W, geo.RSR, geo.RSC, 1, pup::kBlockCost, sh_br, sh_er, sh_seg, seg_shift, slot_bits, n_eregs, er_in_key ? 1 : 0, d_eregs,
-                           (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G);
+                           (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G, (const unsigned*)nullptr, (const unsigned short*)nullptr);
     }
     // leave the block count where the NEXT call with this signature finds it without waiting
     hipLaunchKernelGGL(pup::staged_publish_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned*)(c->d_cnt32.p + 3), 1,
@@ -1257,16 +1329,22 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
         HIPCHK(c, hipMemcpy(c->d_segend.p, htab.data(), htab.size() * 8, hipMemcpyHostToDevice));
         c->htab_sent = htab;
     }
+    BinPlan bp{};
+    const bool use_bin = k32 && !(c->variant & 1024) && bin_plan(end_bit, 0, n_items, bp);      // (pup_bin.hpp; else the library's radix sort)
     size_t tmp_bytes = 0;
-    hipError_t se = k32 ? rocprim::radix_sort_pairs<Radix10>(nullptr, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_win.p, c->d_win2.p, (size_t)n_items, 0, end_bit, c->stream)
-                        : rocprim::radix_sort_pairs<Radix10>(nullptr, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_win.p, c->d_win2.p, (size_t)n_items, 0, end_bit, c->stream);
-    if (se == hipSuccess) se = c->d_sorttmp.reserve(tmp_bytes + 16);
-    if (se != hipSuccess) return fail(c, PUP_EHIP, "pup_accumulate: block sort: %s", hipGetErrorString(se));
+    hipError_t se = hipSuccess;
+    if (!use_bin) {
+        se = k32 ? rocprim::radix_sort_pairs<Radix10>(nullptr, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_win.p, c->d_win2.p, (size_t)n_items, 0, end_bit, c->stream)
+                 : rocprim::radix_sort_pairs<Radix10>(nullptr, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_win.p, c->d_win2.p, (size_t)n_items, 0, end_bit, c->stream);
+        if (se == hipSuccess) se = c->d_sorttmp.reserve(tmp_bytes + 16);
+        if (se != hipSuccess) return fail(c, PUP_EHIP, "pup_accumulate: block sort: %s", hipGetErrorString(se));
+    }
 
     // ---- prepass, all on the stream -------------------------------------------------------------------------------------
     if (ev) HIPCHK(c, hipEventRecord(ev[0], c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_cnt32.p, 0, (ncnt + (size_t)n_spans) * sizeof(unsigned), c->stream));
     HIPCHK(c, hipMemsetAsync(c->wrec_seg.p, 0, (size_t)nrec * sizeof(unsigned), c->stream));
+    if (use_bin) { const int brc = bin_prepare(c, bp, n_items, false); if (brc != PUP_OK) return brc; }
     const unsigned ticket = ++c->ticket;
     const bool ooe_vec = ooe && !c->have_exp_pair && (c->nexp > 1 || c->n_exp_regions > 0);
     bool ooe_clean = false;
@@ -1279,14 +1357,16 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
             if (ooe_clean) far_gap = (int)std::min<long long>(far, 0x7fffffff);
         }
     }
-    const unsigned gk4 = (unsigned)((n_items + 1023) / 1024);
+    const unsigned gk4 = use_bin ? (unsigned)bp.ntiles : (unsigned)((n_items + 1023) / 1024);
+    const int wkey_per = use_bin ? pup::kBinTile / 256 : 4;
     int wide_cost = pup::kWideBlockCost;
     if (const char* e = getenv("COOLPUPPY_AMD_WIDE_COST")) { const int v = atoi(e); if (v > 0) wide_cost = v; }     // experiments
 #define PUP_WKEY_ARGS dr0, dc0, (long long)n, n_items, (const long long*)c->d_segend.p, nseg2t, (const pup::IdxChrom*)c->idx_chrom.p, c->n_chrom, \
         (const unsigned short*)c->bin_chrom.p, (long long)c->nbins, (const int*)c->d_brow.p, W, NG, geo.NGc, geo.SH, geo.SW, BR, BC, sh_br, sh_seg, \
         seg_shift, ignore_diags + W - 1, far_gap, c->band_w
-    if (k32) hipLaunchKernelGGL((pup::wide_key_kernel<unsigned>), dim3(gk4), dim3(256), 0, c->stream, PUP_WKEY_ARGS, c->d_k32.p, c->d_win.p, c->d_cnt32.p);
-    else hipLaunchKernelGGL((pup::wide_key_kernel<unsigned long long>), dim3(gk4), dim3(256), 0, c->stream, PUP_WKEY_ARGS, c->d_keys.p, c->d_win.p, c->d_cnt32.p);
+    const size_t wkey_lds = (size_t)nseg2t * sizeof(long long) + (use_bin ? ((size_t)1 << bp.DH) : 0) * sizeof(unsigned);
+    if (k32) hipLaunchKernelGGL((pup::wide_key_kernel<unsigned>), dim3(gk4), dim3(256), wkey_lds, c->stream, PUP_WKEY_ARGS, c->d_k32.p, c->d_win.p, c->d_cnt32.p, use_bin ? c->d_bindesc.p : (unsigned*)nullptr, bp.DL, 1 << bp.DH, wkey_per);
+    else hipLaunchKernelGGL((pup::wide_key_kernel<unsigned long long>), dim3(gk4), dim3(256), wkey_lds, c->stream, PUP_WKEY_ARGS, c->d_keys.p, c->d_win.p, c->d_cnt32.p, (unsigned*)nullptr, 0, 0, 4);
 #undef PUP_WKEY_ARGS
     hipLaunchKernelGGL(pup::staged_publish_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned*)c->d_cnt32.p, 3,
                        (volatile unsigned*)c->d_flags, ticket);
@@ -1294,7 +1374,16 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
     unsigned* d_spans = c->d_cnt32.p + ncnt;
     const unsigned gt = (unsigned)std::min<long long>(4096, (n_items + 255) / 256);
     const pup::ExpRegion* d_eregs = n_eregs > 0 ? c->exp_regions.p : nullptr;
-    if (k32) {
+    if (use_bin) {
+        const int brc = bin_run(c, bp, n_items, 0, c->d_k32.p, c->d_win.p, c->d_k32b.p, c->d_win2.p, false, c->d_cnt32.p + 3);
+        if (brc != PUP_OK) return brc;
+        hipLaunchKernelGGL((pup::staged_table_kernel<unsigned>), dim3(gt), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
+                           (const unsigned*)(c->d_cnt32.p + 3), n_items, (const unsigned*)nullptr,
+                           (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
+                           c->n_chrom, geo.SH, geo.SW, RS, RS, NG, wide_cost, sh_br, sh_seg, sh_seg, seg_shift, 0, n_eregs, 0, d_eregs,
+                           (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G, (const unsigned*)c->d_bkeys.p,
+                           (const unsigned short*)nullptr);
+    } else if (k32) {
         se = rocprim::radix_sort_pairs<Radix10>(c->d_sorttmp.p, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_win.p, c->d_win2.p,
                                                 (size_t)n_items, 0, end_bit, c->stream);
         if (se != hipSuccess) return fail(c, PUP_EHIP, "pup_accumulate: block sort: %s", hipGetErrorString(se));
@@ -1306,7 +1395,7 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
                            (const unsigned*)(c->d_cnt32.p + 3), n_items, (const unsigned*)c->d_k32b.p,
                            (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
                            c->n_chrom, geo.SH, geo.SW, RS, RS, NG, wide_cost, sh_br, sh_seg, sh_seg, seg_shift, 0, n_eregs, 0, d_eregs,
-                           (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G);
+                           (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G, (const unsigned*)nullptr, (const unsigned short*)nullptr);
     } else {
         se = rocprim::radix_sort_pairs<Radix10>(c->d_sorttmp.p, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_win.p, c->d_win2.p,
                                                 (size_t)n_items, 0, end_bit, c->stream);
@@ -1319,7 +1408,7 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
                            (const unsigned*)(c->d_cnt32.p + 3), n_items, (const unsigned long long*)c->d_keys2.p,
                            (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
                            c->n_chrom, geo.SH, geo.SW, RS, RS, NG, wide_cost, sh_br, sh_seg, sh_seg, seg_shift, 0, n_eregs, 0, d_eregs,
-                           (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G);
+                           (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G, (const unsigned*)nullptr, (const unsigned short*)nullptr);
     }
     hipLaunchKernelGGL(pup::staged_publish_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned*)(c->d_cnt32.p + 3), 1,
                        (volatile unsigned*)(c->d_flags + 4), ticket);
@@ -2157,7 +2246,7 @@ int pup_set_tuning(pup_ctx* c, int32_t chunk_snippets, int32_t variant) {
     if (chunk_snippets < 0) return fail(c, PUP_EINVAL, "pup_set_tuning: negative chunk size");
     c->chunk_snippets = chunk_snippets;
     c->forget_hints();
-    c->variant = (variant & 0xff) | ((variant >> 19) & 0x300);   // bit 27 -> 256: never stage from the dense band; bit 28 -> 512: tile pairs one by one
+    c->variant = (variant & 0xff) | ((variant >> 19) & 0x700);   // bit 27 -> 256: never stage from the dense band; bit 28 -> 512: tile pairs one by one; bit 29 -> 1024: library sort in the prepass
     c->group_waves = (variant >> 8) & 0xffff;
     c->debug_phases = (variant >> 24) & 0x7;
     return PUP_OK;

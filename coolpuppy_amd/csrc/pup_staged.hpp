@@ -932,14 +932,21 @@ __global__ __launch_bounds__(256) void staged_key_kernel(const int* __restrict__
                                                          int band_w /* 0: no band table */,
                                                          KeyT* __restrict__ keys, unsigned short* __restrict__ vals,
                                                          unsigned* __restrict__ counters /* [0] ineligible, [1] windows a diagonal mask
-                                                                                            reaches, [2] windows leaving the dense band */) {
+                                                                                            reaches, [2] windows leaving the dense band */,
+                                                         unsigned* __restrict__ hi_hist /* nullable: tilehist[workgroup][hi_bins], counts of key >> hi_shift (pup_bin.hpp) */,
+                                                         int hi_shift, int hi_bins, int per_thread /* windows per thread: 4, or 32 = a binning tile per workgroup */) {
     // small tables go to LDS once per workgroup: per window the chain of dependent global loads is r0 -> bin_chrom only
-    constexpr int kMaxChrom = 512, kPer = 4;
+    constexpr int kMaxChrom = 512;
+    const int kPer = per_thread;
     __shared__ int s_cs[kMaxChrom], s_ce[kMaxChrom], s_bb[kMaxChrom];
-    __shared__ long long s_seg[2 * kMaxSegCount];
+    // (dynamic LDS: the (tile, flip) run ends, then the high-digit counts of this workgroup's windows — sized by what the call
+    // needs: 32 bytes + 4 KB for the headline workload instead of 24 KB, and the kernel lives on occupancy)
+    extern __shared__ long long s_seg[];
+    unsigned* const s_hh = reinterpret_cast<unsigned*>(s_seg + nseg2t);
     const bool in_lds = n_chrom <= kMaxChrom;
     if (in_lds) for (int k = threadIdx.x; k < n_chrom; k += blockDim.x) { s_cs[k] = chroms[k].start; s_ce[k] = chroms[k].end; s_bb[k] = brow_base[k]; }
     for (int k = threadIdx.x; k < nseg2t; k += blockDim.x) s_seg[k] = seg_end[k];
+    if (hi_hist) for (int k = threadIdx.x; k < hi_bins; k += blockDim.x) s_hh[k] = 0u;
     __syncthreads();
     unsigned bad = 0u;
     for (int u = 0; u < kPer; ++u) {
@@ -982,13 +989,32 @@ __global__ __launch_bounds__(256) void staged_key_kernel(const int* __restrict__
             const unsigned long long far = __ballot(live && band_w > 0 && (c + W - 1) - r >= band_w);
             if (far != 0ull && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)far) - 1)) atomicAdd(&counters[2], (unsigned)__popcll(far));
         }
-        if (!live) continue;
-        keys[i] = (KeyT)(((((unsigned long long)(seg >> seg_shift) << sh_seg) | (er << sh_er) | (br << sh_br) | bc) << kbits) | kslot);
+        unsigned key_hi = 0u; bool counted = false;
+        if (live) {
+        const unsigned long long key = ((((unsigned long long)(seg >> seg_shift) << sh_seg) | (er << sh_er) | (br << sh_br) | bc) << kbits) | kslot;
+        keys[i] = (KeyT)key;
+        key_hi = (unsigned)(key >> hi_shift); counted = hi_hist != nullptr;
         // the value that rides the sort is the window itself as the staged kernel wants it (the sort is stable, so windows
         // of a block keep the caller's order): no index to gather through afterwards
         vals[i] = (unsigned short)(inside | (slot << kWinSlotBit));
+        }
+        {   // the workgroup's high-digit counts: ONE LDS atomic per distinct digit of the wave (the stream is nearly sorted by block row:
+            // 64 lanes adding to one counter cost more than the whole key computation)
+            unsigned long long todo = __ballot(counted);
+            while (todo) {
+                const int l = __ffsll((long long)todo) - 1;
+                const unsigned d0 = __shfl(key_hi, l);
+                const unsigned long long m = __ballot(counted && key_hi == d0);
+                if ((int)(threadIdx.x & 63) == l) atomicAdd(&s_hh[d0], (unsigned)__popcll(m));
+                todo &= ~m;
+            }
+        }
     }
     if (bad) atomicAdd(&counters[0], bad);
+    if (hi_hist) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < hi_bins; k += blockDim.x) hi_hist[(size_t)blockIdx.x * hi_bins + k] = s_hh[k];
+    }
 }
 
 // hand the key kernel's verdict to the host without stalling the stream: one thread copies the two counters into mapped
@@ -1069,13 +1095,15 @@ __global__ __launch_bounds__(256) void staged_table_kernel(const unsigned* __res
                                                            int sh_br, int sh_er, int sh_seg, int seg_shift, int slot_bits, int n_eregs,
                                                            int er_in_key, const ExpRegion* __restrict__ eregs,
                                                            const unsigned long long* __restrict__ badbits,
-                                                           StagedBlock* __restrict__ blocks, int* __restrict__ wg_first, int G) {
+                                                           StagedBlock* __restrict__ blocks, int* __restrict__ wg_first, int G,
+                                                           const unsigned* __restrict__ block_keys /* nullable: key >> slot_bits of block b (pup_bin.hpp) */,
+                                                           const unsigned short* __restrict__ sorted_low /* with block_keys and slot_bits > 0: low digits in block order */) {
     const long long nr = (long long)n_runs[0];
     const int BR = RSR - WR + 1, BC = RSC - WC + 1;
     for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < nr; b += (long long)gridDim.x * blockDim.x) {
         const unsigned s = starts[b];
         const long long e = (b + 1 < nr) ? (long long)starts[b + 1] : n;
-        const unsigned long long key = (unsigned long long)sorted_keys[s] >> slot_bits;
+        const unsigned long long key = block_keys ? (unsigned long long)block_keys[b] : (unsigned long long)sorted_keys[s] >> slot_bits;
         StagedBlock be;
         const int br = (int)((key >> sh_br) & ((1ull << (sh_er - sh_br)) - 1ull));
         const int bc = (int)(key & ((1ull << sh_br) - 1ull));
@@ -1089,7 +1117,7 @@ __global__ __launch_bounds__(256) void staged_table_kernel(const unsigned* __res
         {   // the windows of a block are in slot order (see StagedBlock::bnd): end of slot q = first window of a higher slot
             const unsigned smask = (1u << slot_bits) - 1u;
             auto slot_of = [&](long long m) -> unsigned {
-                return slot_bits ? (unsigned)sorted_keys[m] & smask : ((unsigned)win[m] >> kWinSlotBit) & 1u;
+                return slot_bits ? (block_keys ? (unsigned)sorted_low[m] : (unsigned)sorted_keys[m]) & smask : ((unsigned)win[m] >> kWinSlotBit) & 1u;
             };
             long long from = (long long)s;
             for (int q = 0; q < 7; ++q) {

@@ -533,13 +533,18 @@ __global__ __launch_bounds__(256) void wide_key_kernel(const int* __restrict__ r
                                                        int BR, int BC, int sh_br, int sh_seg, int seg_shift,
                                                        int clear_gap, int far_gap, int band_w,
                                                        KeyT* __restrict__ keys, unsigned short* __restrict__ vals,
-                                                       unsigned* __restrict__ counters) {
-    constexpr int kMaxChrom = 512, kPer = 4;
+                                                       unsigned* __restrict__ counters,
+                                                       unsigned* __restrict__ hi_hist /* nullable: tilehist[workgroup][hi_bins] (pup_bin.hpp) */,
+                                                       int hi_shift, int hi_bins, int per_thread) {
+    constexpr int kMaxChrom = 512;
+    const int kPer = per_thread;
     __shared__ int s_cs[kMaxChrom], s_ce[kMaxChrom], s_bb[kMaxChrom];
-    __shared__ long long s_seg[2 * kMaxSegCount];
+    extern __shared__ long long s_seg[];                  // (dynamic: run ends, then the high-digit counts; see staged_key_kernel)
+    unsigned* const s_hh = reinterpret_cast<unsigned*>(s_seg + nseg2t);
     const bool in_lds = n_chrom <= kMaxChrom;
     if (in_lds) for (int k = threadIdx.x; k < n_chrom; k += blockDim.x) { s_cs[k] = chroms[k].start; s_ce[k] = chroms[k].end; s_bb[k] = brow_base[k]; }
     for (int k = threadIdx.x; k < nseg2t; k += blockDim.x) s_seg[k] = seg_end[k];
+    if (hi_hist) for (int k = threadIdx.x; k < hi_bins; k += blockDim.x) s_hh[k] = 0u;
     __syncthreads();
     unsigned bad = 0u;
     for (int u = 0; u < kPer; ++u) {
@@ -575,11 +580,30 @@ __global__ __launch_bounds__(256) void wide_key_kernel(const int* __restrict__ r
             const unsigned long long far = __ballot(first && (c + W - 1) - r >= band_w);
             if (far != 0ull && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)far) - 1)) atomicAdd(&counters[2], (unsigned)__popcll(far));
         }
-        if (!live) continue;
-        keys[ii] = (KeyT)(((unsigned long long)seg << sh_seg) | (br << sh_br) | bc);
+        unsigned key_hi = 0u; bool counted = false;
+        if (live) {
+        const unsigned long long key = ((unsigned long long)seg << sh_seg) | (br << sh_br) | bc;
+        keys[ii] = (KeyT)key;
+        key_hi = (unsigned)(key >> hi_shift); counted = hi_hist != nullptr;
         vals[ii] = (unsigned short)inside;
+        }
+        {   // the workgroup's high-digit counts: ONE LDS atomic per distinct digit of the wave (the stream is nearly sorted by block row:
+            // 64 lanes adding to one counter cost more than the whole key computation)
+            unsigned long long todo = __ballot(counted);
+            while (todo) {
+                const int l = __ffsll((long long)todo) - 1;
+                const unsigned d0 = __shfl(key_hi, l);
+                const unsigned long long m = __ballot(counted && key_hi == d0);
+                if ((int)(threadIdx.x & 63) == l) atomicAdd(&s_hh[d0], (unsigned)__popcll(m));
+                todo &= ~m;
+            }
+        }
     }
     if (bad) atomicAdd(&counters[0], bad);
+    if (hi_hist) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < hi_bins; k += blockDim.x) hi_hist[(size_t)blockIdx.x * hi_bins + k] = s_hh[k];
+    }
 }
 
 // fixed-order reduction of K1w's partial records into the running accumulators.  Workgroup = (64 accumulator cells, tile),
