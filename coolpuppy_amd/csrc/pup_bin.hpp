@@ -179,98 +179,96 @@ __device__ __forceinline__ void block_excl_scan2(unsigned a, unsigned b, unsigne
 // a maximal run of low digits that agree above `slot_bits` (sets of tile pairs keep the slot in the key's lowest digit); the
 // bucket writes its blocks' (start, key >> slot_bits) to blk_start / blk_key AT ITS OWN SPAN (a bucket of c windows has at most
 // c blocks) and their number to blk_count[h].  out_low (nullable): the sorted low digits (the table kernel reads the slot there).
-// ONE WAVE per bucket (a workgroup of kBucketWaves waves = that many buckets side by side, nothing shared, no barrier): the wave
-// counts the bucket's digits (sweep 1), scans them (starts, blocks, dense numbers of the digits that occur), and places its windows
-// in order (sweep 2: who else in my round has my digit? — ballots over the bits of the DENSE number, a few dozen digits occur).
-// Eight rounds of loads are in flight at a time.  (Workgroup-wide variants — 4 and 16 waves per bucket, per-wave counters — all sat
-// at 60 - 100 us: 64 lanes adding to ~6 LDS counters serialise, and ~700 buckets are too few workgroups to hide anything.)
+// A workgroup of kBucketWaves = 4 waves per bucket: every wave owns a contiguous share, counts its digits (sweep 1: plain LDS adds,
+// integer counts are order-free), the waves' counts are scanned into starts / blocks / dense numbers of the digits that occur, and
+// every wave places its windows in order (sweep 2: who else in my round has my digit? — ballots over the bits of the DENSE number:
+// a few dozen of the 2^DL digits occur in a bucket).  Eight rounds of loads are in flight at a time.  Measured on the headline
+// workload (1.1e7 windows, 702 buckets): 4 waves 61 us, 16 waves 68 us, one wave per bucket (2048 buckets) 93 us.
 constexpr int kBucketWaves = 4;
 PUP_KERNEL __launch_bounds__(kWave * kBucketWaves) void bin_bucket_kernel(
         const unsigned* __restrict__ in, const unsigned* __restrict__ base, int DL, int DH, int slot_bits,
         unsigned short* __restrict__ out_val, unsigned short* __restrict__ out_low,
         unsigned* __restrict__ blk_start, unsigned* __restrict__ blk_key, unsigned* __restrict__ blk_count) {
-    extern __shared__ unsigned lds_all[];                  // per wave: cnt[2^DL] (counts, then the digit's next position) | dense[2^DL]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    extern __shared__ unsigned wcnt[];                     // [kBucketWaves][2^DL] per-wave digit counts, then exclusive over the waves | tot[2^DL] | dstart[2^DL]
+    __shared__ unsigned scratch[2 * kBinWaves];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nl = 1 << DL;
-    unsigned* const cnt = lds_all + (size_t)wave * 2 * nl;
-    unsigned* const dense = cnt + nl;
-    const int per = (nl + 63) / 64;                        // digits per lane, blocked: lane l owns [l per, (l + 1) per)
+    unsigned* const tot = wcnt + kBucketWaves * nl;        // windows per low digit, later the digit's dense number
+    unsigned* const dstart = tot + nl;                     // where the digit's run starts (bucket-relative)
+    const int per = (nl + (int)blockDim.x - 1) / (int)blockDim.x;          // digits per thread, blocked: thread t owns [t per, (t + 1) per)
+    unsigned* mine = wcnt + wave * nl;
     constexpr int U = 8;
-    for (int h = blockIdx.x * kBucketWaves + wave; h < (1 << DH); h += gridDim.x * kBucketWaves) {
+    for (int h = blockIdx.x; h < (1 << DH); h += gridDim.x) {
         const unsigned b0 = base[h], b1 = base[h + 1];
-        if (b0 == b1) { if (lane == 0) blk_count[h] = 0u; continue; }       // (uniform over the wave)
-        const unsigned n = b1 - b0;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        for (int k = lane; k < nl; k += 64) cnt[k] = 0u;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // sweep 1: counts (LDS adds of one wave: integer, order-free)
-        for (unsigned i0 = 0; i0 < n; i0 += U * 64) {
+        if (b0 == b1) { if (tid == 0) blk_count[h] = 0u; continue; }        // (uniform)
+        const unsigned cnt = b1 - b0;
+        const unsigned share = ((cnt + kBucketWaves - 1) / kBucketWaves + 63u) & ~63u;        // whole rounds of 64
+        const unsigned w0 = (unsigned)wave * share < cnt ? (unsigned)wave * share : cnt;
+        const unsigned w1 = w0 + share < cnt ? w0 + share : cnt;
+        __syncthreads();
+        for (int k = tid; k < kBucketWaves * nl; k += blockDim.x) wcnt[k] = 0u;
+        __syncthreads();
+        for (unsigned i0 = w0; i0 < w1; i0 += U * 64) {       // sweep 1
             unsigned it[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) { const unsigned i = i0 + (unsigned)u * 64 + lane; it[u] = i < n ? in[b0 + i] : 0xffffffffu; }
+            for (int u = 0; u < U; ++u) { const unsigned i = i0 + (unsigned)u * 64 + lane; it[u] = i < w1 ? in[b0 + i] : 0xffffffffu; }
 #pragma unroll
-            for (int u = 0; u < U; ++u) if (it[u] != 0xffffffffu) atomicAdd(&cnt[it[u] >> 16], 1u);
+            for (int u = 0; u < U; ++u) if (it[u] != 0xffffffffu) atomicAdd(&mine[it[u] >> 16], 1u);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // scan over the digits: run starts, block heads, dense numbers
-        unsigned csum = 0, heads = 0, nz = 0;
-        for (int k = 0; k < per; ++k) {
-            const int d = lane * per + k;
-            if (d >= nl || !cnt[d]) continue;
-            csum += cnt[d]; ++nz;
-            bool head = true;                               // no non-empty digit before it shares its bits above slot_bits
-            for (int e = (d >> slot_bits) << slot_bits; e < d; ++e) if (cnt[e]) { head = false; break; }
-            heads += head ? 1u : 0u;
+        __syncthreads();
+        for (int d = tid; d < nl; d += blockDim.x) {          // exclusive over the waves; the bucket's count of the digit
+            unsigned run = 0;
+            for (int w = 0; w < kBucketWaves; ++w) { const unsigned t = wcnt[w * nl + d]; wcnt[w * nl + d] = run; run += t; }
+            tot[d] = run;
         }
-        unsigned ic = csum, ih = heads, iz = nz;
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned vc = __shfl_up(ic, off), vh = __shfl_up(ih, off), vz = __shfl_up(iz, off);
-            if (lane >= off) { ic += vc; ih += vh; iz += vz; }
-        }
-        const unsigned nblk = __shfl(ih, 63), ndist = __shfl(iz, 63);
-        unsigned run = ic - csum, at = ih - heads, id = iz - nz;
-        // (heads look at neighbouring lanes' counts: all of that is read before any count is overwritten)
-        unsigned hmask = 0u;                               // bit k: digit lane * per + k starts a block
-        for (int k = 0; k < per && k < 32; ++k) {
-            const int d = lane * per + k;
-            if (d >= nl || !cnt[d]) continue;
-            bool head = true;
-            for (int e = (d >> slot_bits) << slot_bits; e < d; ++e) if (cnt[e]) { head = false; break; }
-            if (head) hmask |= 1u << k;
-        }
-        for (int k = 0; k < per && k < 32; ++k) {
-            const int d = lane * per + k;
-            if (d >= nl) break;
-            const unsigned c = cnt[d];
-            if (c) {
-                if ((hmask >> k) & 1u) { blk_start[b0 + at] = b0 + run; blk_key[b0 + at] = ((unsigned)h << (DL - slot_bits)) | ((unsigned)d >> slot_bits); ++at; }
-                dense[d] = id++;
+        __syncthreads();
+        {   // digit starts (exclusive prefix of the counts), the bucket's block list, dense numbers of the digits that occur
+            unsigned csum = 0, heads = 0, nz = 0, hmask = 0u;
+            for (int k = 0; k < per; ++k) {
+                const int d = tid * per + k;
+                if (d >= nl || !tot[d]) continue;
+                csum += tot[d]; ++nz;
+                bool head = true;                           // no non-empty digit before it shares its bits above slot_bits
+                for (int e = (d >> slot_bits) << slot_bits; e < d; ++e) if (tot[e]) { head = false; break; }
+                if (head) { ++heads; hmask |= 1u << k; }
             }
-            cnt[d] = run;                                   // from here on: where the digit's next window goes (bucket-relative)
-            run += c;
+            unsigned run, at, tc, th, id, dz, nd_, dz2;
+            block_excl_scan2(csum, heads, scratch, run, at, tc, th);
+            block_excl_scan2(nz, 0u, scratch, id, dz, nd_, dz2);
+            __syncthreads();                                // every thread has read the neighbours' counts it needs
+            for (int k = 0; k < per; ++k) {
+                const int d = tid * per + k;
+                if (d >= nl) break;
+                const unsigned c = tot[d];
+                if (c) {
+                    if ((hmask >> k) & 1u) { blk_start[b0 + at] = b0 + run; blk_key[b0 + at] = ((unsigned)h << (DL - slot_bits)) | ((unsigned)d >> slot_bits); ++at; }
+                    tot[d] = id++;
+                }
+                dstart[d] = run;
+                run += c;
+            }
+            if (tid == 0) { blk_count[h] = th; scratch[2 * kBinWaves - 1] = nd_; }
         }
-        if (lane == 0) blk_count[h] = nblk;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __syncthreads();
         int idbits = 0;
-        while ((1u << idbits) < ndist) ++idbits;
-        // sweep 2: placement, in order
-        for (unsigned i0 = 0; i0 < n; i0 += U * 64) {
+        { const unsigned ndist = scratch[2 * kBinWaves - 1]; while ((1u << idbits) < ndist) ++idbits; }
+        for (unsigned i0 = w0; i0 < w1; i0 += U * 64) {       // sweep 2
             unsigned itv[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) { const unsigned i = i0 + (unsigned)u * 64 + lane; itv[u] = i < n ? in[b0 + i] : 0xffffffffu; }
+            for (int u = 0; u < U; ++u) { const unsigned i = i0 + (unsigned)u * 64 + lane; itv[u] = i < w1 ? in[b0 + i] : 0xffffffffu; }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (i0 + (unsigned)u * 64 >= n) break;       // (uniform)
+                if (i0 + (unsigned)u * 64 >= w1) break;      // (uniform)
                 const unsigned it = itv[u];
                 const bool live = it != 0xffffffffu;
                 const unsigned d = live ? it >> 16 : 0u;
-                const unsigned long long m = match_digit(live ? dense[d] : 0u, idbits, live);
+                const unsigned long long m = match_digit(live ? tot[d] : 0u, idbits, live);
                 const int lead = m ? __ffsll((long long)m) - 1 : 0;
                 unsigned prev = 0;
-                if (live && lane == lead) { prev = cnt[d]; cnt[d] = prev + (unsigned)__popcll(m); }
+                if (live && lane == lead) { prev = mine[d]; mine[d] = prev + (unsigned)__popcll(m); }
                 prev = __shfl(prev, lead);
                 if (live) {
-                    const unsigned pos = b0 + prev + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                    const unsigned pos = b0 + dstart[d] + prev + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
                     out_val[pos] = (unsigned short)(it & 0xffffu);
                     if (out_low) out_low[pos] = (unsigned short)d;
                 }

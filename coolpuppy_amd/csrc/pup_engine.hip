@@ -867,11 +867,9 @@ static void fill_k1_args(pup_ctx* c, pup::K1Args& a, int32_t ignore_diags, uint3
 // Digit split of a key of `end_bit` bits whose lowest `slot_bits` hold the accumulator slot: false when the key is too wide
 struct BinPlan { int DL, DH; long long ntiles; };
 static bool bin_plan(int end_bit, int slot_bits, long long n_items, BinPlan& bp) {
-    // a bucket is ordered by ONE wave: many small buckets — the high digit takes the larger half of the key
-    int DH = std::min((end_bit + 2) / 2, pup::kBinMaxDigit);
-    int DL = std::max(end_bit - DH, 0);
-    if (DL < slot_bits) { DL = slot_bits; DH = std::max(end_bit - DL, 0); }
-    if (DL > pup::kBinMaxDigit) return false;
+    int DL = std::min(std::max((end_bit + 1) / 2, slot_bits), pup::kBinMaxDigit);
+    const int DH = std::max(end_bit - DL, 0);
+    if (DH > pup::kBinMaxDigit) return false;
     if (DH > pup::kBinMaxDigit || n_items >= 0x3fffffffLL) return false;
     bp.DL = DL; bp.DH = DH; bp.ntiles = (n_items + pup::kBinTile - 1) / pup::kBinTile;
     return true;
@@ -897,12 +895,12 @@ static int bin_run(pup_ctx* c, const BinPlan& bp, long long n_items, int slot_bi
     hipLaunchKernelGGL(pup::bin_chunksum_kernel, dim3((unsigned)nchunks, (unsigned)((nd + 1023) / 1024)), dim3(nd < 1024 ? nd : 1024), 0, c->stream,
                        tilehist, bp.ntiles, nd, chunksum);
     hipLaunchKernelGGL(pup::bin_scan_kernel, dim3(1), dim3(1024), 0, c->stream, chunksum, nchunks, nd, base);
-    const size_t lds1 = (size_t)pup::kBinWaves * nd * sizeof(unsigned short), lds2 = (size_t)pup::kBucketWaves * 2 * nl * sizeof(unsigned);
+    const size_t lds1 = (size_t)pup::kBinWaves * nd * sizeof(unsigned short), lds2 = (size_t)(pup::kBucketWaves + 2) * nl * sizeof(unsigned);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pup::bin_partition_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
     hipLaunchKernelGGL(pup::bin_partition_kernel, dim3((unsigned)bp.ntiles), dim3(pup::kWave * pup::kBinWaves), lds1, c->stream,
                        (const unsigned*)keys, vals, n_items, bp.DL, bp.DH, (const unsigned*)base, (const unsigned*)chunksum, tilehist, keys_scratch);
     // (the keys are dead now: their buffer takes the buckets' block starts)
-    hipLaunchKernelGGL(pup::bin_bucket_kernel, dim3((unsigned)((nd + pup::kBucketWaves - 1) / pup::kBucketWaves)), dim3(pup::kWave * pup::kBucketWaves), lds2,
+    hipLaunchKernelGGL(pup::bin_bucket_kernel, dim3((unsigned)nd), dim3(pup::kWave * pup::kBucketWaves), lds2,
                        c->stream, (const unsigned*)keys_scratch, (const unsigned*)base, bp.DL, bp.DH, slot_bits, vals_out,
                        want_low ? c->d_low.p : (unsigned short*)nullptr, keys, c->d_blkkey.p, blk_count);
     hipLaunchKernelGGL(pup::bin_compact_kernel, dim3((unsigned)nd), dim3(256), 0, c->stream, (const unsigned*)base, (const unsigned*)blk_count, nd,
