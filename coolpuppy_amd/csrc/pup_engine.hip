@@ -825,17 +825,20 @@ template <typename KeyT>
 static void launch_key_kernel(pup_ctx* c, int BR, int BC, unsigned grid, const int* dr0, const int* dc0, long long n, int nseg2t, int H,
                               int set_pairs, const pup::ExpRegion* d_eregs, int n_eregs, int W, int sh_br, int sh_er, int sh_seg,
                               int seg_shift, int clear_gap, int far_gap, KeyT* keys, unsigned* hi_hist = nullptr, int hi_shift = 0, int hi_bins = 0) {
-    const int per_thread = hi_hist ? pup::kBinTile / 256 : 4;       // with the binning prepass a workgroup keys one of its tiles
+    // with the binning prepass a workgroup keys one of its tiles of 8192 windows: 256 threads x 32 (measured: 68 us; 1024 threads x 8: 85 us;
+    // round 3's 256 x 4 without the digit counts: 58 us)
+    const int threads = 256;
+    const int per_thread = hi_hist ? pup::kBinTile / 256 : 4;
 #define PUP_KEY_ARGS dr0, dc0, n, (const long long*)c->d_segend.p, nseg2t, H, set_pairs, (const pup::IdxChrom*)c->idx_chrom.p, c->n_chrom, \
         (const unsigned short*)c->bin_chrom.p, (long long)c->nbins, (const int*)c->d_brow.p, d_eregs, n_eregs, W, BR, BC, sh_br, \
         sh_er, sh_seg, seg_shift, clear_gap, far_gap, (c->band_w > 0 && !(c->variant & 256)) ? c->band_w : 0, keys, c->d_win.p, c->d_cnt32.p, hi_hist, hi_shift, hi_bins, per_thread
     const size_t lds = (size_t)nseg2t * sizeof(long long) + (size_t)hi_bins * sizeof(unsigned);
     if (BR == 108 && BC == 108)
-        hipLaunchKernelGGL((pup::staged_key_kernel<KeyT, 108, 108>), dim3(grid), dim3(256), lds, c->stream, PUP_KEY_ARGS);
+        hipLaunchKernelGGL((pup::staged_key_kernel<KeyT, 108, 108>), dim3(grid), dim3(threads), lds, c->stream, PUP_KEY_ARGS);
     else if (BR == 44 && BC == 108)
-        hipLaunchKernelGGL((pup::staged_key_kernel<KeyT, 44, 108>), dim3(grid), dim3(256), lds, c->stream, PUP_KEY_ARGS);
+        hipLaunchKernelGGL((pup::staged_key_kernel<KeyT, 44, 108>), dim3(grid), dim3(threads), lds, c->stream, PUP_KEY_ARGS);
     else
-        hipLaunchKernelGGL((pup::staged_key_kernel<KeyT, 0, 0>), dim3(grid), dim3(256), lds, c->stream, PUP_KEY_ARGS);
+        hipLaunchKernelGGL((pup::staged_key_kernel<KeyT, 0, 0>), dim3(grid), dim3(threads), lds, c->stream, PUP_KEY_ARGS);
 #undef PUP_KEY_ARGS
 }
 }   // extern "C++"
@@ -1356,15 +1359,15 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
         }
     }
     const unsigned gk4 = use_bin ? (unsigned)bp.ntiles : (unsigned)((n_items + 1023) / 1024);
-    const int wkey_per = use_bin ? pup::kBinTile / 256 : 4;
+    const int wkey_threads = 256, wkey_per = use_bin ? pup::kBinTile / 256 : 4;
     int wide_cost = pup::kWideBlockCost;
     if (const char* e = getenv("COOLPUPPY_AMD_WIDE_COST")) { const int v = atoi(e); if (v > 0) wide_cost = v; }     // experiments
 #define PUP_WKEY_ARGS dr0, dc0, (long long)n, n_items, (const long long*)c->d_segend.p, nseg2t, (const pup::IdxChrom*)c->idx_chrom.p, c->n_chrom, \
         (const unsigned short*)c->bin_chrom.p, (long long)c->nbins, (const int*)c->d_brow.p, W, NG, geo.NGc, geo.SH, geo.SW, BR, BC, sh_br, sh_seg, \
         seg_shift, ignore_diags + W - 1, far_gap, c->band_w
     const size_t wkey_lds = (size_t)nseg2t * sizeof(long long) + (use_bin ? ((size_t)1 << bp.DH) : 0) * sizeof(unsigned);
-    if (k32) hipLaunchKernelGGL((pup::wide_key_kernel<unsigned>), dim3(gk4), dim3(256), wkey_lds, c->stream, PUP_WKEY_ARGS, c->d_k32.p, c->d_win.p, c->d_cnt32.p, use_bin ? c->d_bindesc.p : (unsigned*)nullptr, bp.DL, 1 << bp.DH, wkey_per);
-    else hipLaunchKernelGGL((pup::wide_key_kernel<unsigned long long>), dim3(gk4), dim3(256), wkey_lds, c->stream, PUP_WKEY_ARGS, c->d_keys.p, c->d_win.p, c->d_cnt32.p, (unsigned*)nullptr, 0, 0, 4);
+    if (k32) hipLaunchKernelGGL((pup::wide_key_kernel<unsigned>), dim3(gk4), dim3(wkey_threads), wkey_lds, c->stream, PUP_WKEY_ARGS, c->d_k32.p, c->d_win.p, c->d_cnt32.p, use_bin ? c->d_bindesc.p : (unsigned*)nullptr, bp.DL, 1 << bp.DH, wkey_per);
+    else hipLaunchKernelGGL((pup::wide_key_kernel<unsigned long long>), dim3(gk4), dim3(wkey_threads), wkey_lds, c->stream, PUP_WKEY_ARGS, c->d_keys.p, c->d_win.p, c->d_cnt32.p, (unsigned*)nullptr, 0, 0, 4);
 #undef PUP_WKEY_ARGS
     hipLaunchKernelGGL(pup::staged_publish_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned*)c->d_cnt32.p, 3,
                        (volatile unsigned*)c->d_flags, ticket);
