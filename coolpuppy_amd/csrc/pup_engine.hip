@@ -73,6 +73,7 @@ struct pup_ctx {
     DevBuf<uint2> rowabs;                  // [n_chrom][nbins] the same as absolute positions, chromosome-major (sparse trans kernel)
     DevBuf<unsigned long long> tbits;      // [ceil(nbins/64)][nbins] presence bitmap (sparse trans kernel), built on first use
     int tbits_state = 0;                   // 0: not tried for this table, 1: built, -1: does not fit
+    int tbits_shift = 0;                   // columns per bit of the bitmap = 1 << tbits_shift (a coarser filter when the exact one does not fit)
     DevBuf<int> band;                       // dense band of counts near the diagonal (staged kernel), [nbins][band_w] + zeros
     int band_w = 0;                         // 0: no band table
     int n_chrom = 0;
@@ -1805,23 +1806,34 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         // bytes, taken only when that is at most a quarter of the free memory
         if (c->tbits_state == 0) {
             c->tbits_state = -1;
-            const unsigned long long words = (unsigned long long)((c->nbins + 63) / 64) * (unsigned long long)c->nbins;
+            // the exact bitmap (a bit per column) when it fits a quarter of the free memory, else the coarsest-needed filter: a bit per
+            // 2, 4, ... columns (COOLPUPPY_AMD_TBITS_SHIFT forces a coarseness: tests)
             size_t fb = 0, tb = 0;
-            if (!(c->variant & 1) && hipMemGetInfo(&fb, &tb) == hipSuccess && words * 8ull <= fb / 4 && c->tbits.reserve((size_t)words) == hipSuccess) {
+            const bool have_mem = !(c->variant & 1) && hipMemGetInfo(&fb, &tb) == hipSuccess;
+            int sh0 = 0;
+            if (const char* e = getenv("COOLPUPPY_AMD_TBITS_SHIFT")) sh0 = std::max(0, std::min(16, atoi(e)));
+            for (int sh = sh0; have_mem && sh <= 16; ++sh) {
+                const unsigned long long words = (unsigned long long)((((c->nbins + (1LL << sh) - 1) >> sh) + 63) / 64 + 1) * (unsigned long long)c->nbins;
+                if (words * 8ull > fb / 4 + c->tbits.cap * 8ull) continue;
+                if (c->tbits.reserve((size_t)words) != hipSuccess) { (void)hipGetLastError(); break; }
                 HIPCHK(c, hipMemsetAsync(c->tbits.p, 0, (size_t)words * 8, c->stream));
                 const unsigned gb3 = (unsigned)std::min<long long>((c->nbins + 3) / 4, 1 << 20);
-                hipLaunchKernelGGL(pup::tbits_fill_kernel, dim3(gb3), dim3(256), 0, c->stream, c->indptr.p, c->px.p, c->tbits.p, c->nbins);
-                c->tbits_state = 1;
-            } else {
-                (void)hipGetLastError();
-                if (!(c->warned & 4u) && !getenv("COOLPUPPY_AMD_QUIET")) {
+                hipLaunchKernelGGL(pup::tbits_fill_kernel, dim3(gb3), dim3(256), 0, c->stream, c->indptr.p, c->px.p, c->tbits.p, c->nbins, sh);
+                c->tbits_state = 1; c->tbits_shift = sh;
+                if (sh > sh0 && !(c->warned & 4u) && !getenv("COOLPUPPY_AMD_QUIET")) {
                     c->warned |= 4u;
-                    fprintf(stderr, "[coolpuppy_amd] inter-chromosomal pile-up without the presence bitmap of the table (%.1f GB for %lld bins do not fit a quarter of the free memory): "
-                                    "the sparse kernel bisects every window row instead (about 1.5x slower)\n", (double)words * 8e-9, c->nbins);
+                    fprintf(stderr, "[coolpuppy_amd] inter-chromosomal pile-up: the presence bitmap of %lld bins is kept at %d columns per bit (%.1f GB; "
+                                    "the exact one needs %.1f GB)\n", c->nbins, 1 << sh, (double)words * 8e-9, (double)c->nbins * (double)c->nbins / 8e9);
                 }
+                break;
+            }
+            if (c->tbits_state != 1 && !(c->warned & 4u) && !getenv("COOLPUPPY_AMD_QUIET")) {
+                c->warned |= 4u;
+                fprintf(stderr, "[coolpuppy_amd] inter-chromosomal pile-up without a presence bitmap of the table (%lld bins): the sparse kernel bisects every "
+                                "window row instead (about 1.5x slower)\n", c->nbins);
             }
         }
-        a.tbits = c->tbits_state == 1 ? c->tbits.p : nullptr;
+        a.tbits = c->tbits_state == 1 ? c->tbits.p : nullptr; a.tshift = c->tbits_state == 1 ? c->tbits_shift : 0;
         const size_t sl = pup::k1s_lds_bytes(W);
         if (mode & PUP_MODE_OOE) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pup::pileup_sparse_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl);

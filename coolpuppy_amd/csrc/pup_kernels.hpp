@@ -87,6 +87,7 @@ struct K1Args {
                                //          of a window that the rank-bitmap index does not cover (trans)
     const uint2*     rowabs;   // [n_chrom][nbins] or nullptr: {first, end} of the row's pixels in chromosome k as ABSOLUTE positions in
                                //          the pixel table, chromosome-major (the sparse trans kernel: one load per window row)
+    int              tshift;   // columns per bit of tbits = 1 << tshift (0: exact; > 0: a coarser FILTER for tables whose exact bitmap would not fit)
     const unsigned long long* tbits;   // [ceil(nbins / 64)][nbins] or nullptr: bit j of word [cb][row] set <=> the table holds pixel
                                //          (row, 64 cb + j).  COLUMN-block major: the 64-bit words of consecutive rows for one
                                //          block of 64 columns are contiguous (the sparse trans kernel, see tbits_fill_kernel)
@@ -471,8 +472,12 @@ PUP_KERNEL __launch_bounds__(256) void rowabs_kernel(const long long* __restrict
 // the window's columns fall into) to learn which of its rows hold a pixel inside it and in which columns; without it every
 // (window, row) pair fetched a cache line of the pixel table — 2.5e7 random lines, 3 GB, per 4.9e5 windows — to find, 97 times
 // out of 100, nothing.  Built on the first call that uses the sparse kernel (pup_engine.hip: ensure_tbits).
+// Round 4: the bitmap is a FILTER — a set bit only sends the row to the real lookup — so for tables whose exact bitmap does not fit
+// (1.2e6 bins: 180 GB; a 1 kb human map: 1.2 TB) a bit stands for 2^tshift consecutive columns: the memory shrinks by that factor, the
+// loads stay two per window, and at trans densities (1e-4 and below) a handful of extra columns per window row changes the hit rate
+// from 0.36 % to 0.4 %.
 PUP_KERNEL __launch_bounds__(256) void tbits_fill_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
-                                                         unsigned long long* __restrict__ tbits, long long nbins) {
+                                                         unsigned long long* __restrict__ tbits, long long nbins, int tshift) {
     const int lane = threadIdx.x & 63;
     long long r = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long stride = (long long)gridDim.x * (blockDim.x >> 6);
@@ -481,7 +486,7 @@ PUP_KERNEL __launch_bounds__(256) void tbits_fill_kernel(const long long* __rest
         for (long long k0 = b; k0 < e; k0 += 64) {
             const long long k = k0 + lane;
             if (k < e) {
-                const int col = px[k].x;
+                const int col = px[k].x >> tshift;
                 atomicOr(&tbits[(long long)(col >> 6) * nbins + r], 1ull << (col & 63));
             }
         }
@@ -834,9 +839,10 @@ __global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
             // which columns of this lane's matrix row hold a pixel: the words of the one or two 64-column blocks under the
             // window (consecutive lanes = consecutive rows = consecutive words: two coalesced loads per window)
             const long long myrow = (long long)r0 + lane;
-            const long long cbk = c0 >> 6;
+            const int cc0 = c0 >> a.tshift, cc1 = (c0 + W - 1) >> a.tshift;       // the window's (coarse) filter columns
+            const long long cbk = cc0 >> 6;
             w.wa = a.tbits[cbk * a.nbins + myrow];
-            w.wb = ((c0 + W - 1) >> 6) > cbk ? a.tbits[(cbk + 1) * a.nbins + myrow] : 0ull;
+            w.wb = (cc1 >> 6) > cbk ? a.tbits[(cbk + 1) * a.nbins + myrow] : 0ull;
         }
     };
     // phase 2 (the bitmap words of every window in flight have been requested): the pixel range of the rows that hold a pixel
@@ -844,10 +850,12 @@ __global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
     auto ranges = [&](Win& w, int kc) __attribute__((always_inline)) {
         if (!w.valid || !rowlane) return;
         if (a.tbits != nullptr) {
-            const int sh = w.c0 & 63;
+            const int cc0 = w.c0 >> a.tshift, span = ((w.c0 + W - 1) >> a.tshift) - cc0 + 1;
+            const int sh = cc0 & 63;
             unsigned long long bits = w.wa >> sh;
             if (sh) bits |= w.wb << (64 - sh);
-            if ((bits & wmask) == 0ull) return;                       // no pixel of this row inside the window
+            const unsigned long long fm = a.tshift ? (span >= 64 ? ~0ull : ((1ull << span) - 1ull)) : wmask;
+            if ((bits & fm) == 0ull) return;                          // no pixel of this row inside the window
         }
         const long long myrow = (long long)w.r0 + lane;
         if (a.rowabs != nullptr) {

@@ -352,7 +352,13 @@ def test_trans_sparse_kernel_vs_oracle_and_dense(hip_lib, small_clr, oracle_mod,
     ff = _flip_from(flip, tile, tile_ptr)
     want = po.pileup_c(indptr, col, cnt, weight, covv, expv, r0, c0, flip, tile, T, pad, -1, mode)
     got = {}
-    for name, variant in (("sparse", 0), ("dense", 32)):
+    import os
+    for name, variant in (("sparse", 0), ("sparse_coarse_filter", 0), ("dense", 32)):
+        # (round 4: the presence bitmap is a filter and may hold a bit per 2^k columns when the exact one would not fit: forced here)
+        if name == "sparse_coarse_filter":
+            os.environ["COOLPUPPY_AMD_TBITS_SHIFT"] = "3"
+        else:
+            os.environ.pop("COOLPUPPY_AMD_TBITS_SHIFT", None)
         eng = PileupEngine(0)
         eng.load_pixels(indptr, col, cnt)
         eng.build_index(clr.chrom_offset)
@@ -362,6 +368,11 @@ def test_trans_sparse_kernel_vs_oracle_and_dense(hip_lib, small_clr, oracle_mod,
         eng.reset(T, pad)
         eng.accumulate(r0, c0, tile_ptr, flip_from=ff, ignore_diags=-1, mode=mode)
         got[name] = eng.fetch()
+        if variant == 0:
+            assert eng.last_kernel() == "sparse"
         eng.close()
         _compare(got[name], want)
+    os.environ.pop("COOLPUPPY_AMD_TBITS_SHIFT", None)
     np.testing.assert_array_equal(got["sparse"]["num"], got["dense"]["num"])
+    np.testing.assert_array_equal(got["sparse_coarse_filter"]["num"], got["dense"]["num"])
+    np.testing.assert_array_equal(got["sparse_coarse_filter"]["sum"], got["sparse"]["sum"])
