@@ -1810,7 +1810,11 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
             // 2, 4, ... columns (COOLPUPPY_AMD_TBITS_SHIFT forces a coarseness: tests)
             size_t fb = 0, tb = 0;
             const bool have_mem = !(c->variant & 1) && hipMemGetInfo(&fb, &tb) == hipSuccess;
-            int sh0 = 0;
+            // Measured (tools/probe_trans_bins.py, bench.py --config 4): the kernel is as fast or faster with 4 ... 64 columns per bit as
+            // with the exact bitmap (0.767 against 0.793 ms: fewer bitmap bytes, and at Hi-C's inter-chromosomal densities a window row
+            // with no pixel has none in the 16-column blocks around it either), so 16 columns per bit is where the search starts:
+            // 0.7 GB instead of 11.5 GB for a human 10 kb table, and a first call of ~3 ms instead of 22.
+            int sh0 = 4;
             if (const char* e = getenv("COOLPUPPY_AMD_TBITS_SHIFT")) sh0 = std::max(0, std::min(16, atoi(e)));
             for (int sh = sh0; have_mem && sh <= 16; ++sh) {
                 const unsigned long long words = (unsigned long long)((((c->nbins + (1LL << sh) - 1) >> sh) + 63) / 64 + 1) * (unsigned long long)c->nbins;
@@ -1822,15 +1826,15 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
                 c->tbits_state = 1; c->tbits_shift = sh;
                 if (sh > sh0 && !(c->warned & 4u) && !getenv("COOLPUPPY_AMD_QUIET")) {
                     c->warned |= 4u;
-                    fprintf(stderr, "[coolpuppy_amd] inter-chromosomal pile-up: the presence bitmap of %lld bins is kept at %d columns per bit (%.1f GB; "
-                                    "the exact one needs %.1f GB)\n", c->nbins, 1 << sh, (double)words * 8e-9, (double)c->nbins * (double)c->nbins / 8e9);
+                    fprintf(stderr, "[coolpuppy_amd] inter-chromosomal pile-up: the presence bitmap of %lld bins is kept at %d columns per bit (%.1f GB) "
+                                    "instead of %d: what fits a quarter of the free device memory\n", c->nbins, 1 << sh, (double)words * 8e-9, 1 << sh0);
                 }
                 break;
             }
             if (c->tbits_state != 1 && !(c->warned & 4u) && !getenv("COOLPUPPY_AMD_QUIET")) {
                 c->warned |= 4u;
                 fprintf(stderr, "[coolpuppy_amd] inter-chromosomal pile-up without a presence bitmap of the table (%lld bins): the sparse kernel bisects every "
-                                "window row instead (about 1.5x slower)\n", c->nbins);
+                                "window row instead (1.5x to 5x slower)\n", c->nbins);
             }
         }
         a.tbits = c->tbits_state == 1 ? c->tbits.p : nullptr; a.tshift = c->tbits_state == 1 ? c->tbits_shift : 0;

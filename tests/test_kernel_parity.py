@@ -353,12 +353,12 @@ def test_trans_sparse_kernel_vs_oracle_and_dense(hip_lib, small_clr, oracle_mod,
     want = po.pileup_c(indptr, col, cnt, weight, covv, expv, r0, c0, flip, tile, T, pad, -1, mode)
     got = {}
     import os
-    for name, variant in (("sparse", 0), ("sparse_coarse_filter", 0), ("dense", 32)):
-        # (round 4: the presence bitmap is a filter and may hold a bit per 2^k columns when the exact one would not fit: forced here)
-        if name == "sparse_coarse_filter":
-            os.environ["COOLPUPPY_AMD_TBITS_SHIFT"] = "3"
-        else:
+    for name, variant, shift in (("sparse", 0, None), ("sparse_exact_bitmap", 0, "0"), ("sparse_coarse_filter", 0, "7"), ("dense", 32, None)):
+        # (round 4: the presence bitmap is a filter of 2^k columns per bit — 16 by default, coarser when that does not fit; forced here)
+        if shift is None:
             os.environ.pop("COOLPUPPY_AMD_TBITS_SHIFT", None)
+        else:
+            os.environ["COOLPUPPY_AMD_TBITS_SHIFT"] = shift
         eng = PileupEngine(0)
         eng.load_pixels(indptr, col, cnt)
         eng.build_index(clr.chrom_offset)
@@ -374,5 +374,6 @@ def test_trans_sparse_kernel_vs_oracle_and_dense(hip_lib, small_clr, oracle_mod,
         _compare(got[name], want)
     os.environ.pop("COOLPUPPY_AMD_TBITS_SHIFT", None)
     np.testing.assert_array_equal(got["sparse"]["num"], got["dense"]["num"])
-    np.testing.assert_array_equal(got["sparse_coarse_filter"]["num"], got["dense"]["num"])
-    np.testing.assert_array_equal(got["sparse_coarse_filter"]["sum"], got["sparse"]["sum"])
+    for k in ("sparse_exact_bitmap", "sparse_coarse_filter"):
+        np.testing.assert_array_equal(got[k]["num"], got["dense"]["num"])
+        np.testing.assert_array_equal(got[k]["sum"], got["sparse"]["sum"])

@@ -161,3 +161,36 @@ def test_coverage_vectors_beside_the_lean_staged_kernel(hip_lib, oracle_mod, pad
     _compare(got, want)
     assert np.abs(got["cov_start"]).sum() > 0
     eng.close()
+
+
+def test_trans_filter_on_a_genome_whose_exact_bitmap_does_not_fit(hip_lib, oracle_mod):
+    """1.2e6 bins (a 2.5 kb human map): the exact presence bitmap of the inter-chromosomal kernel would take nbins^2 / 8 = 180 GB.
+    Round 3 dropped to bisection per window row; now the filter holds a bit per 2^s columns, s the smallest that fits a quarter
+    of the free memory — the kernel stays K1s and every window equals the oracle's.  The table (1e8 uniformly placed
+    inter-chromosomal pixels) is made on the GPU with torch: sorting it on one host core would take minutes."""
+    import torch
+    from coolpuppy_amd.engine import PileupEngine
+    sys_path_tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("probe_trans_bins", os.path.join(sys_path_tools, "probe_trans_bins.py"))
+    probe = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(probe)
+    po = oracle_mod
+    co, indptr, col, cnt, w = probe.make_table(1_200_000, 100_000_000, 5)
+    torch.cuda.empty_cache()
+    pad, n = 25, 100_000
+    r0, c0 = probe.windows(co, n, pad, 9)
+    tile = np.zeros(n, np.int32)
+    want = po.pileup_c_mt(indptr, col, cnt, w, None, None, r0, c0, None, tile, 1, pad, -1, 0, max(1, min(os.cpu_count() or 1, 64)))
+    assert want["sum"].sum() > 0
+    eng = PileupEngine(0)
+    eng.load_pixels(indptr, col, cnt)
+    eng.build_index(co)
+    eng.load_bins(w, None)
+    for rep in range(2):
+        eng.reset(1, pad)
+        eng.accumulate(r0, c0, np.array([0, n], np.int64), ignore_diags=-1, mode=0)
+        got = eng.fetch()
+        assert eng.last_kernel() == "sparse"
+        _compare(got, want)
+    eng.close()
