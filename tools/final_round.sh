@@ -13,6 +13,7 @@ timeout 400 python bench.py --pad 100 --steps 10 --warmup 2 --cpu-sample 0 --no-
 timeout 400 python bench.py --config 3 --steps 50 > "$OUT/r04_bench_config3.json" 2> "$OUT/r04_bench_config3.err"
 timeout 400 python bench.py --config 4 --steps 50 > "$OUT/r04_bench_config4.json" 2> "$OUT/r04_bench_config4.err"
 timeout 900 python tools/run_configs.py --out "$OUT/r04_configs.json" > "$OUT/r04_configs.log" 2>&1
+timeout 600 python tools/probe_trans_bins.py "$OUT/r04_trans_bins.json" > "$OUT/r04_trans_bins.log" 2>&1
 cat "$OUT/${TAG}_gputests.txt"
 python - <<PY
 import json
