@@ -61,14 +61,22 @@ __device__ __forceinline__ unsigned long long match_runs(unsigned d, int bits, b
 // of digits it holds.  (A decoupled look-back over all 2^DH digits — the onesweep scheme, tried first — spent 33 of the
 // partition pass's 77 us walking descriptors: with 512 tiles in flight a tile's predecessors are mostly unfinished.)
 constexpr int kBinChunk = 64;
-PUP_KERNEL __launch_bounds__(1024) void bin_chunksum_kernel(const unsigned* __restrict__ tilehist, long long ntiles, int nd, unsigned* __restrict__ chunksum) {
+// (tilehist is rewritten in place as the EXCLUSIVE prefix over the tiles of the chunk: the partition pass then needs one load per
+// digit a tile holds.  At first it summed the rows of its chunk before it itself: up to 63 loads one after the other in a handful
+// of threads — half of that kernel's 65 us)
+PUP_KERNEL __launch_bounds__(1024) void bin_chunksum_kernel(unsigned* __restrict__ tilehist, long long ntiles, int nd, unsigned* __restrict__ chunksum) {
     const int c = blockIdx.x;
     const int d = blockIdx.y * blockDim.x + threadIdx.x;
     if (d >= nd) return;
     const long long t0 = (long long)c * kBinChunk, t1 = t0 + kBinChunk < ntiles ? t0 + kBinChunk : ntiles;
     unsigned s = 0;
-#pragma unroll 8
-    for (long long t = t0; t < t1; ++t) s += tilehist[(size_t)t * nd + d];
+    for (long long tb = t0; tb < t1; tb += 16) {
+        unsigned v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = tb + k < t1 ? tilehist[(size_t)(tb + k) * nd + d] : 0u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { if (tb + k < t1) tilehist[(size_t)(tb + k) * nd + d] = s; s += v[k]; }
+    }
     chunksum[(size_t)c * nd + d] = s;
 }
 // one workgroup: per digit the exclusive prefix over the chunks (in place) and the digit's total; then the digits' bases
@@ -140,14 +148,11 @@ PUP_KERNEL __launch_bounds__(kWave * kBinWaves) void bin_partition_kernel(
     __syncthreads();
     // per digit: exclusive over the waves; for the digits the tile holds, where they start: the digit's base + the chunks before
     // + the tiles of this chunk before
-    const long long tc0 = (long long)(tile / kBinChunk) * kBinChunk;
     for (int d = tid; d < nd; d += blockDim.x) {
         unsigned run = 0;
         for (int w = 0; w < kBinWaves; ++w) { const unsigned t = whist[w * nd + d]; whist[w * nd + d] = (unsigned short)run; run += t; }
         if (run == 0u) continue;
-        unsigned at = base[d] + chunkexcl[(size_t)(tile / kBinChunk) * nd + d];
-        for (long long t = tc0; t < (long long)tile; ++t) at += tilehist[(size_t)t * nd + d];
-        gbase[d] = at;
+        gbase[d] = base[d] + chunkexcl[(size_t)(tile / kBinChunk) * nd + d] + tilehist[(size_t)tile * nd + d];    // (tilehist: exclusive within the chunk by now)
     }
     __syncthreads();
 #pragma unroll
@@ -179,12 +184,14 @@ __device__ __forceinline__ void block_excl_scan2(unsigned a, unsigned b, unsigne
 // a maximal run of low digits that agree above `slot_bits` (sets of tile pairs keep the slot in the key's lowest digit); the
 // bucket writes its blocks' (start, key >> slot_bits) to blk_start / blk_key AT ITS OWN SPAN (a bucket of c windows has at most
 // c blocks) and their number to blk_count[h].  out_low (nullable): the sorted low digits (the table kernel reads the slot there).
-// A workgroup of kBucketWaves = 4 waves per bucket: every wave owns a contiguous share, counts its digits (sweep 1: plain LDS adds,
+// A workgroup of kBucketWaves = 8 waves per bucket: every wave owns a contiguous share, counts its digits (sweep 1: plain LDS adds,
 // integer counts are order-free), the waves' counts are scanned into starts / blocks / dense numbers of the digits that occur, and
 // every wave places its windows in order (sweep 2: who else in my round has my digit? — ballots over the bits of the DENSE number:
 // a few dozen of the 2^DL digits occur in a bucket).  Eight rounds of loads are in flight at a time.  Measured on the headline
-// workload (1.1e7 windows, 702 buckets): 4 waves 61 us, 16 waves 68 us, one wave per bucket (2048 buckets) 93 us.
-constexpr int kBucketWaves = 4;
+// workload (1.1e7 windows, 702 buckets): 8 waves 51 us, 4 waves 60 us, 16 waves 65 us, one wave per bucket (2048 buckets) 93 us — the
+// buckets are uneven and the biggest one's workgroup is the kernel's tail.  (Measured and dropped, round 4: the next eight rounds' loads
+// issued before this eight's LDS work; the leaders' read-modify-write as LDS atomics with return, batched per eight rounds: no change.)
+constexpr int kBucketWaves = 8;
 PUP_KERNEL __launch_bounds__(kWave * kBucketWaves) void bin_bucket_kernel(
         const unsigned* __restrict__ in, const unsigned* __restrict__ base, int DL, int DH, int slot_bits,
         unsigned short* __restrict__ out_val, unsigned short* __restrict__ out_low,

@@ -128,6 +128,7 @@ struct pup_ctx {
     std::vector<long long> hint_sig;
     long long hint_blocks = -1;              // -1: unknown
     unsigned hint_ticket = 0;                // ticket whose block count h_flags[4] will hold
+    bool counts_added = false;               // this call's reduction kernel has added the windows-per-tile counts
     unsigned long long last_stagings = 0;   // diagnostics: regions staged by the last K1q launch (0: it did not run)
     bool last_staged = false;
     // launch geometry: ONE device blob (one H2D copy per new geometry), the typed views below point into it
@@ -252,7 +253,7 @@ bool tiled_supported(int W) { return W >= 3 && W <= 31 && (W & 1); }
 struct StagedGeo { int RSR, RSC, NW; };
 StagedGeo staged_geometry(int W, bool ooe, bool extra, bool small21) {
     const bool big = W <= 21 && !extra && !(small21 && W == 21 && !ooe);
-    return StagedGeo{big ? 128 : 64, 128, big ? 16 : 8};
+    return StagedGeo{big ? 128 : ((small21 && W == 21 && !ooe && !extra) ? pup::kSmallRows : 64), 128, big ? 16 : 8};
 }
 
 // banded register-tile kernel: NCH column chunks of 16 cells -> windows up to 16*NCH wide
@@ -833,11 +834,13 @@ static void launch_key_kernel(pup_ctx* c, int BR, int BC, unsigned grid, const i
 #define PUP_KEY_ARGS dr0, dc0, n, (const long long*)c->d_segend.p, nseg2t, H, set_pairs, (const pup::IdxChrom*)c->idx_chrom.p, c->n_chrom, \
         (const unsigned short*)c->bin_chrom.p, (long long)c->nbins, (const int*)c->d_brow.p, d_eregs, n_eregs, W, BR, BC, sh_br, \
         sh_er, sh_seg, seg_shift, clear_gap, far_gap, (c->band_w > 0 && !(c->variant & 256)) ? c->band_w : 0, keys, c->d_win.p, c->d_cnt32.p, hi_hist, hi_shift, hi_bins, per_thread
-    const size_t lds = (size_t)nseg2t * sizeof(long long) + (size_t)hi_bins * sizeof(unsigned);
+    const size_t lds = (((size_t)nseg2t + (size_t)hi_bins + 3 * (size_t)c->n_chrom) * 4 + 15) & ~(size_t)15;      // run ends | digit counts | chromosome table
     if (BR == 108 && BC == 108)
         hipLaunchKernelGGL((pup::staged_key_kernel<KeyT, 108, 108>), dim3(grid), dim3(threads), lds, c->stream, PUP_KEY_ARGS);
     else if (BR == 44 && BC == 108)
         hipLaunchKernelGGL((pup::staged_key_kernel<KeyT, 44, 108>), dim3(grid), dim3(threads), lds, c->stream, PUP_KEY_ARGS);
+    else if (BR == pup::kSmallRows - 20 && BC == 108)
+        hipLaunchKernelGGL((pup::staged_key_kernel<KeyT, pup::kSmallRows - 20, 108>), dim3(grid), dim3(threads), lds, c->stream, PUP_KEY_ARGS);
     else
         hipLaunchKernelGGL((pup::staged_key_kernel<KeyT, 0, 0>), dim3(grid), dim3(threads), lds, c->stream, PUP_KEY_ARGS);
 #undef PUP_KEY_ARGS
@@ -872,6 +875,10 @@ static void fill_k1_args(pup_ctx* c, pup::K1Args& a, int32_t ignore_diags, uint3
 struct BinPlan { int DL, DH; long long ntiles; };
 static bool bin_plan(int end_bit, int slot_bits, long long n_items, BinPlan& bp) {
     int DL = std::min(std::max((end_bit + 1) / 2, slot_bits), pup::kBinMaxDigit);
+    if (const char* e = getenv("COOLPUPPY_AMD_BIN_DH")) {        // experiments: bits of the high digit
+        const int dh = std::max(0, std::min(atoi(e), std::min(end_bit, pup::kBinMaxDigit)));
+        DL = std::min(std::max(end_bit - dh, slot_bits), pup::kBinMaxDigit);
+    }
     const int DH = std::max(end_bit - DL, 0);
     if (DH > pup::kBinMaxDigit) return false;
     if (DH > pup::kBinMaxDigit || n_items >= 0x3fffffffLL) return false;
@@ -895,14 +902,14 @@ static int bin_run(pup_ctx* c, const BinPlan& bp, long long n_items, int slot_bi
     const int nd = 1 << bp.DH, nl = 1 << bp.DL;
     const int nchunks = (int)((bp.ntiles + pup::kBinChunk - 1) / pup::kBinChunk);
     unsigned* base = c->d_binmeta.p; unsigned* blk_count = base + nd + 1; unsigned* chunksum = blk_count + nd + 7;
-    const unsigned* tilehist = c->d_bindesc.p;
+    unsigned* tilehist = c->d_bindesc.p;
     hipLaunchKernelGGL(pup::bin_chunksum_kernel, dim3((unsigned)nchunks, (unsigned)((nd + 1023) / 1024)), dim3(nd < 1024 ? nd : 1024), 0, c->stream,
                        tilehist, bp.ntiles, nd, chunksum);
     hipLaunchKernelGGL(pup::bin_scan_kernel, dim3(1), dim3(1024), 0, c->stream, chunksum, nchunks, nd, base);
-    const size_t lds1 = (size_t)pup::kBinWaves * nd * sizeof(unsigned short), lds2 = (size_t)(pup::kBucketWaves + 2) * nl * sizeof(unsigned);
+    const size_t lds1 = (size_t)pup::kBinWaves * (nd < 2 ? 2 : nd) * sizeof(unsigned short), lds2 = (size_t)(pup::kBucketWaves + 2) * nl * sizeof(unsigned);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pup::bin_partition_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
     hipLaunchKernelGGL(pup::bin_partition_kernel, dim3((unsigned)bp.ntiles), dim3(pup::kWave * pup::kBinWaves), lds1, c->stream,
-                       (const unsigned*)keys, vals, n_items, bp.DL, bp.DH, (const unsigned*)base, (const unsigned*)chunksum, tilehist, keys_scratch);
+                       (const unsigned*)keys, vals, n_items, bp.DL, bp.DH, (const unsigned*)base, (const unsigned*)chunksum, (const unsigned*)tilehist, keys_scratch);
     // (the keys are dead now: their buffer takes the buckets' block starts)
     hipLaunchKernelGGL(pup::bin_bucket_kernel, dim3((unsigned)nd), dim3(pup::kWave * pup::kBucketWaves), lds2,
                        c->stream, (const unsigned*)keys_scratch, (const unsigned*)base, bp.DL, bp.DH, slot_bits, vals_out,
@@ -938,7 +945,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     const bool force = (c->variant & 8) != 0, forbid = (c->variant & 16) != 0;
     const bool use_idx_t = c->have_idx && !(c->variant & 1);
     if (forbid || rescale || (mode & (PUP_MODE_EXPECTED | PUP_MODE_TRANSPOSE)) || (c->variant & 2) || !use_idx_t ||
-        ignore_diags < 0 || !tiled_supported(W) || n >= 0x7fffffffLL || !(force || n >= ((mode & PUP_MODE_OOE) ? c->tiled_min_ooe : c->tiled_min)) ||
+        ignore_diags < 0 || !tiled_supported(W) || n >= 0x7fff0000LL || c->n_chrom > pup::kKeyMaxChrom || !(force || n >= ((mode & PUP_MODE_OOE) ? c->tiled_min_ooe : c->tiled_min)) ||
         2 * T > pup::kMaxSegCount || T > pup::kMaxStagedTiles || !c->bin_chrom.p || !c->h_flags || !c->ev_key ||
         (int)c->h_chroms.size() != c->n_chrom)
         return 1;
@@ -948,7 +955,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     const bool small21 = (c->variant & 128) != 0;
     const StagedGeo geo = staged_geometry(W, (mode & PUP_MODE_OOE) != 0, extra, small21);
     const int BR = geo.RSR - W + 1, BC = geo.RSC - W + 1;
-    const int G = c->n_cu * (geo.RSR * geo.RSC > 64 * 128 ? 1 : 2);            // persistent workgroups (one / two per CU by LDS)
+    const int G = c->n_cu * (geo.RSR * geo.RSC > pup::kSmallRows * 128 ? 1 : 2);            // persistent workgroups (one / two per CU by LDS)
     // a staged region must serve this many windows on average to pay for its staging
     // (per-window division by expected makes the per-window kernel three times dearer: staging pays much earlier there)
     const long long min_per_block = ((mode & PUP_MODE_OOE) ? 2LL : 8LL) * (geo.RSR * geo.RSC) / (64 * 64);
@@ -1137,7 +1144,8 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
                            (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
                            c->n_chrom, W, W, geo.RSR, geo.RSC, 1, pup::kBlockCost, sh_br, sh_er, sh_seg, seg_shift, slot_bits, n_eregs, er_in_key ? 1 : 0, d_eregs,
                            (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G, (const unsigned*)c->d_bkeys.p,
-                           slot_bits > 0 ? (const unsigned short*)c->d_low.p : (const unsigned short*)nullptr);
+                           slot_bits > 0 ? (const unsigned short*)c->d_low.p : (const unsigned short*)nullptr,
+                           (volatile unsigned*)(c->d_flags + 4), ticket);
     } else if (k32) {
         se = rocprim::radix_sort_pairs<Radix10>(c->d_sorttmp.p, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_win.p, c->d_win2.p,
                                                 (size_t)n, 0, end_bit, c->stream);
@@ -1150,7 +1158,8 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
                            (const unsigned*)(c->d_cnt32.p + 3), (long long)n, (const unsigned*)c->d_k32b.p,
                            (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
                            c->n_chrom, W, W, geo.RSR, geo.RSC, 1, pup::kBlockCost, sh_br, sh_er, sh_seg, seg_shift, slot_bits, n_eregs, er_in_key ? 1 : 0, d_eregs,
-                           (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G, (const unsigned*)nullptr, (const unsigned short*)nullptr);
+                           (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G, (const unsigned*)nullptr, (const unsigned short*)nullptr,
+                           (volatile unsigned*)(c->d_flags + 4), ticket);
     } else {
         se = rocprim::radix_sort_pairs<Radix10>(c->d_sorttmp.p, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_win.p, c->d_win2.p,
                                                 (size_t)n, 0, end_bit, c->stream);
@@ -1163,11 +1172,9 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
                            (const unsigned*)(c->d_cnt32.p + 3), (long long)n, (const unsigned long long*)c->d_keys2.p,
                            (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
                            c->n_chrom, W, W, geo.RSR, geo.RSC, 1, pup::kBlockCost, sh_br, sh_er, sh_seg, seg_shift, slot_bits, n_eregs, er_in_key ? 1 : 0, d_eregs,
-                           (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G, (const unsigned*)nullptr, (const unsigned short*)nullptr);
+                           (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G, (const unsigned*)nullptr, (const unsigned short*)nullptr,
+                           (volatile unsigned*)(c->d_flags + 4), ticket);
     }
-    // leave the block count where the NEXT call with this signature finds it without waiting
-    hipLaunchKernelGGL(pup::staged_publish_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned*)(c->d_cnt32.p + 3), 1,
-                       (volatile unsigned*)(c->d_flags + 4), ticket);
     HIPCHK(c, hipGetLastError());
 
     // ---- K1q (+ reduction below) ---------------------------------------------------------------------------------------------
@@ -1237,7 +1244,9 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     const int Li = (int)Li0;
     hipLaunchKernelGGL(pup::reduce_staged_kernel, dim3((unsigned)((Lf + Li + 63) / 64), (unsigned)T), dim3(64, pup::kRedParts), 0,
                        c->stream, (const double*)c->part_f64.p, (const unsigned*)c->part_num.p,
-                       (const unsigned short*)d_recvalid, G, T, ACC, H, (int)Lf, Li, c->acc_f64.p, c->acc_i64.p);
+                       (const unsigned short*)d_recvalid, G, T, ACC, H, (int)Lf, Li, c->acc_f64.p, c->acc_i64.p,
+                       c->acc_i64.p + (size_t)T * W2, (const long long*)c->d_segend.p);
+    c->counts_added = true;
     HIPCHK(c, hipGetLastError());
     if (cov_sep) { const int crc = cov_pass(c, dr0, dc0, n, mode); if (crc != PUP_OK) return crc; }
     c->last_staged = true;
@@ -1263,7 +1272,7 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
     const pup::WideGeom geo = pup::wide_geometry(W);
     const int NG = geo.NGr * geo.NGc;
     const long long n_items = (long long)n * NG;
-    if (n_items >= 0x7fffffffLL) return 1;
+    if (n_items >= 0x7fff0000LL || c->n_chrom > pup::kKeyMaxChrom) return 1;
     const int RS = 128;
     const int BR = RS - geo.SH + 1, BC = RS - geo.SW + 1;
     const int G = c->n_cu;                               // persistent workgroups: one per CU (the region takes the LDS)
@@ -1366,7 +1375,7 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
 #define PUP_WKEY_ARGS dr0, dc0, (long long)n, n_items, (const long long*)c->d_segend.p, nseg2t, (const pup::IdxChrom*)c->idx_chrom.p, c->n_chrom, \
         (const unsigned short*)c->bin_chrom.p, (long long)c->nbins, (const int*)c->d_brow.p, W, NG, geo.NGc, geo.SH, geo.SW, BR, BC, sh_br, sh_seg, \
         seg_shift, ignore_diags + W - 1, far_gap, c->band_w
-    const size_t wkey_lds = (size_t)nseg2t * sizeof(long long) + (use_bin ? ((size_t)1 << bp.DH) : 0) * sizeof(unsigned);
+    const size_t wkey_lds = (((size_t)nseg2t + (use_bin ? ((size_t)1 << bp.DH) : 0) + 3 * (size_t)c->n_chrom) * 4 + 15) & ~(size_t)15;
     if (k32) hipLaunchKernelGGL((pup::wide_key_kernel<unsigned>), dim3(gk4), dim3(wkey_threads), wkey_lds, c->stream, PUP_WKEY_ARGS, c->d_k32.p, c->d_win.p, c->d_cnt32.p, use_bin ? c->d_bindesc.p : (unsigned*)nullptr, bp.DL, 1 << bp.DH, wkey_per);
     else hipLaunchKernelGGL((pup::wide_key_kernel<unsigned long long>), dim3(gk4), dim3(wkey_threads), wkey_lds, c->stream, PUP_WKEY_ARGS, c->d_keys.p, c->d_win.p, c->d_cnt32.p, (unsigned*)nullptr, 0, 0, 4);
 #undef PUP_WKEY_ARGS
@@ -1384,7 +1393,8 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
                            (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
                            c->n_chrom, geo.SH, geo.SW, RS, RS, NG, wide_cost, sh_br, sh_seg, sh_seg, seg_shift, 0, n_eregs, 0, d_eregs,
                            (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G, (const unsigned*)c->d_bkeys.p,
-                           (const unsigned short*)nullptr);
+                           (const unsigned short*)nullptr,
+                           (volatile unsigned*)(c->d_flags + 4), ticket);
     } else if (k32) {
         se = rocprim::radix_sort_pairs<Radix10>(c->d_sorttmp.p, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_win.p, c->d_win2.p,
                                                 (size_t)n_items, 0, end_bit, c->stream);
@@ -1397,7 +1407,8 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
                            (const unsigned*)(c->d_cnt32.p + 3), n_items, (const unsigned*)c->d_k32b.p,
                            (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
                            c->n_chrom, geo.SH, geo.SW, RS, RS, NG, wide_cost, sh_br, sh_seg, sh_seg, seg_shift, 0, n_eregs, 0, d_eregs,
-                           (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G, (const unsigned*)nullptr, (const unsigned short*)nullptr);
+                           (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G, (const unsigned*)nullptr, (const unsigned short*)nullptr,
+                           (volatile unsigned*)(c->d_flags + 4), ticket);
     } else {
         se = rocprim::radix_sort_pairs<Radix10>(c->d_sorttmp.p, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_win.p, c->d_win2.p,
                                                 (size_t)n_items, 0, end_bit, c->stream);
@@ -1410,10 +1421,9 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
                            (const unsigned*)(c->d_cnt32.p + 3), n_items, (const unsigned long long*)c->d_keys2.p,
                            (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
                            c->n_chrom, geo.SH, geo.SW, RS, RS, NG, wide_cost, sh_br, sh_seg, sh_seg, seg_shift, 0, n_eregs, 0, d_eregs,
-                           (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G, (const unsigned*)nullptr, (const unsigned short*)nullptr);
+                           (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G, (const unsigned*)nullptr, (const unsigned short*)nullptr,
+                           (volatile unsigned*)(c->d_flags + 4), ticket);
     }
-    hipLaunchKernelGGL(pup::staged_publish_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned*)(c->d_cnt32.p + 3), 1,
-                       (volatile unsigned*)(c->d_flags + 4), ticket);
     HIPCHK(c, hipGetLastError());
 
     // ---- the key kernel's verdict ---------------------------------------------------------------------------------------
@@ -1452,7 +1462,9 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
     const size_t W2 = (size_t)W * W, Lf = W2 + 2 * (size_t)W;
     hipLaunchKernelGGL(pup::reduce_wide_kernel, dim3((unsigned)((W2 + 63) / 64), (unsigned)T), dim3(64, pup::kRedParts), 0, c->stream,
                        (const double*)c->wrec_f64.p, (const unsigned*)c->wrec_num.p, (const unsigned*)c->wrec_seg.p, G, W, NG, geo.NGc,
-                       geo.SH, geo.SW, flip_from ? 2 : 1, (int)Lf, c->acc_f64.p, c->acc_i64.p);
+                       geo.SH, geo.SW, flip_from ? 2 : 1, (int)Lf, c->acc_f64.p, c->acc_i64.p,
+                       c->acc_i64.p + (size_t)T * W2, (const long long*)c->d_segend.p);
+    c->counts_added = true;
     HIPCHK(c, hipGetLastError());
     if (cov_sep) { const int crc = cov_pass(c, dr0, dc0, n, mode); if (crc != PUP_OK) return crc; }
     c->last_staged = true;
@@ -1558,6 +1570,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     }
     // ---- many overlapping cis windows: block order + workgroup-staged kernel (K1q), see staged_run --------------------
     bool staged = false;
+    c->counts_added = false;
     {
         hipEvent_t evs[3] = {ep, e0, e1};
         const int src = staged_run(c, dr0, dc0, n, tile_ptr, flip_from, ignore_diags, mode, rescale, c->profiling ? evs : nullptr);
@@ -1904,8 +1917,8 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
                        c->acc_i64.p + (size_t)c->T * W2, c->gv.dn, c->T);
     HIPCHK(c, hipGetLastError());
     }   // !staged
-    else {
-        // windows per tile straight from the (tile, flip) boundaries the key kernel used
+    else if (!c->counts_added) {
+        // windows per tile straight from the (tile, flip) boundaries the key kernel used (the staged kernels' reductions add them)
         hipLaunchKernelGGL(pup::add_counts_from_ends_kernel, dim3((unsigned)((c->T + 255) / 256)), dim3(256), 0, c->stream,
                            c->acc_i64.p + (size_t)c->T * W2, (const long long*)c->d_segend.p, c->T);
         HIPCHK(c, hipGetLastError());

@@ -82,6 +82,8 @@ constexpr int kBandFront = 256;                       // cells in front of the b
 constexpr int kMaxSegCount = 1024;                    // (tile, flip) runs one block-ordered call may have (key kernel LDS table)
 constexpr int kBlockCost = 400;                       // staging one region, in windows' worth of time (workgroup ranges)
 constexpr int kMaxStagedTiles = kMaxSegCount / 2;     // (tile, flip) runs fit the key kernel's LDS table
+constexpr int kKeyMaxChrom = 3072;                    // chromosomes whose table (12 bytes each) the key kernels keep in LDS; assemblies of more
+                                                      // scaffolds take the per-window kernels
 
 __device__ __forceinline__ void lds_read2_b32(unsigned long long& dst, unsigned addr) {     // dwords at addr, addr + 4
     asm volatile("ds_read2_b32 %0, %1 offset0:0 offset1:1" : "=&v"(dst) : "v"(addr));
@@ -106,9 +108,13 @@ __host__ __device__ inline int staged_tile(int unit, int slot, int PH) {
 
 // geometry of an instantiation (host and device agree through these)
 template <int W> constexpr bool staged_big() { return W <= 21; }      // 128 x 128 regions, 16 waves: register budget of CH <= 7 cells
+#ifndef PUP_SMALL_ROWS
+#define PUP_SMALL_ROWS 72
+#endif
+constexpr int kSmallRows = PUP_SMALL_ROWS;            // rows of the two-workgroups-per-CU geometry (probe): 72 x 131 doubles + the rest < 80 KB
 template <int W, bool OOE, bool EXTRA, bool SMALL = false, bool FACT = true> struct StagedGeom {
     static constexpr bool big = staged_big<W>() && !EXTRA && !SMALL;
-    static constexpr int RSR = big ? 128 : 64;
+    static constexpr int RSR = big ? 128 : (SMALL ? kSmallRows : 64);
     static constexpr int RSC = 128;
     static constexpr int NW  = (big && FACT) ? 16 : 8;   // 16 waves of 128 registers where the kernel fits them (factorised
                                                          // counts, one accumulator set per wave); the other instantiations
@@ -116,7 +122,7 @@ template <int W, bool OOE, bool EXTRA, bool SMALL = false, bool FACT = true> str
 };
 
 template <int W, bool OOE, int RSR, int RSC, int NW, int ACC, bool FACT, bool EXTRA, bool BAND = false>
-__global__ __launch_bounds__(kWave * NW, (RSR == 64 && NW == 8 && FACT && !OOE && !EXTRA && W <= 21) ? 2 : 1)
+__global__ __launch_bounds__(kWave * NW, (RSR <= kSmallRows && NW == 8 && FACT && !OOE && !EXTRA && W <= 21) ? 2 : 1)
 void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     static_assert(!(BAND && EXTRA), "pixel statistics need the presence bits of the index: sparse staging");
     static_assert(W >= 3 && W <= 31, "workgroup-staged kernel serves windows of 3..31 bins");
@@ -935,82 +941,137 @@ __global__ __launch_bounds__(256) void staged_key_kernel(const int* __restrict__
                                                                                             reaches, [2] windows leaving the dense band */,
                                                          unsigned* __restrict__ hi_hist /* nullable: tilehist[workgroup][hi_bins], counts of key >> hi_shift (pup_bin.hpp) */,
                                                          int hi_shift, int hi_bins, int per_thread /* windows per thread: 4, or 32 = a binning tile per workgroup */) {
-    // small tables go to LDS once per workgroup: per window the chain of dependent global loads is r0 -> bin_chrom only
-    constexpr int kMaxChrom = 512;
+    // Small tables go to LDS once per workgroup (the chromosome table in chunks of the call's dynamic LDS: 12 bytes per chromosome,
+    // the launch sizes it — see launch_key_kernel), so per window the chain of dependent global loads is r0 -> bin_chrom only.
+    // What the kernel costs is VALU issue (counters, round 4: 156 vector instructions per 64 windows, 4 clocks each on a SIMD, made
+    // 45 of its 68 us; a select between an LDS and a global table had turned every table read into a FLAT load behind
+    // `s_waitcnt vmcnt(0)` — a wait for the previous window's stores): all index arithmetic is 32-bit (n < 2^31: staged_run),
+    // the key is put together in 32 bits when it is 32 bits wide, broadcasts are readlanes.
     const int kPer = per_thread;
-    __shared__ int s_cs[kMaxChrom], s_ce[kMaxChrom], s_bb[kMaxChrom];
-    // (dynamic LDS: the (tile, flip) run ends, then the high-digit counts of this workgroup's windows — sized by what the call
-    // needs: 32 bytes + 4 KB for the headline workload instead of 24 KB, and the kernel lives on occupancy)
-    extern __shared__ long long s_seg[];
-    unsigned* const s_hh = reinterpret_cast<unsigned*>(s_seg + nseg2t);
-    const bool in_lds = n_chrom <= kMaxChrom;
-    if (in_lds) for (int k = threadIdx.x; k < n_chrom; k += blockDim.x) { s_cs[k] = chroms[k].start; s_ce[k] = chroms[k].end; s_bb[k] = brow_base[k]; }
-    for (int k = threadIdx.x; k < nseg2t; k += blockDim.x) s_seg[k] = seg_end[k];
+    extern __shared__ long long s_dyn[];
+    int* const s_seg = reinterpret_cast<int*>(s_dyn);                 // [nseg2t] (tile, flip) run ends
+    unsigned* const s_hh = reinterpret_cast<unsigned*>(s_seg + nseg2t);           // [hi_bins] high-digit counts of this workgroup's windows
+    int* const s_cs = reinterpret_cast<int*>(s_hh + hi_bins);         // [n_chrom] first bin | [n_chrom] end | [n_chrom] block rows before
+    int* const s_ce = s_cs + n_chrom;
+    int* const s_bb = s_ce + n_chrom;
+    for (int k = threadIdx.x; k < n_chrom; k += blockDim.x) { s_cs[k] = chroms[k].start; s_ce[k] = chroms[k].end; s_bb[k] = brow_base[k]; }
+    for (int k = threadIdx.x; k < nseg2t; k += blockDim.x) s_seg[k] = (int)seg_end[k];
     if (hi_hist) for (int k = threadIdx.x; k < hi_bins; k += blockDim.x) s_hh[k] = 0u;
     __syncthreads();
-    unsigned bad = 0u;
-    for (int u = 0; u < kPer; ++u) {
-        const long long i = ((long long)blockIdx.x * kPer + u) * blockDim.x + threadIdx.x;
-        const bool live = i < n;
-        const int r = live ? r0[i] : 0, c = live ? c0[i] : 0;
+    unsigned bad = 0u, near_c = 0u, far_c = 0u;
+    const int lane = threadIdx.x & 63;
+    const int n32 = (int)n, n_last = n32 - 1, nb_last = (int)nbins - 1;
+    // the (tile, flip) run of a window and what follows from it — pass segment, accumulator slot, slot digit of the key — depend on
+    // the window's NUMBER only, and a workgroup's 8192 consecutive windows nearly always lie in one run: found once per workgroup
+    // (per window, the bisection of the run ends and two integer divisions were a third of the kernel's vector instructions)
+    struct SegInfo { unsigned seg, slot, kslot, kbits; };
+    auto run_of = [&](int i) -> int {
         int lo = 0, hi = nseg2t;
         while (lo < hi) { const int m = (lo + hi) >> 1; if (s_seg[m] <= i) lo = m + 1; else hi = m; }
+        return lo;
+    };
+    auto seg_of = [&](int lo) -> SegInfo {
         const int t = lo >> 1, f = lo & 1;                   // tile, flip state of the snippet
-        unsigned seg = (unsigned)lo, slot = 0u;
-        unsigned kslot = 0u, kbits = 0u;                     // slot digit of the key (sets of pairs)
+        SegInfo si; si.seg = (unsigned)lo; si.slot = 0u; si.kslot = 0u; si.kbits = 0u;
         if (pair_half > 0) {
             const int kind = t / pair_half, g = t - kind * pair_half;
-            if (set_pairs > 1) { kslot = (unsigned)(kind * set_pairs + g % set_pairs); kbits = kSetSlotBits; seg = (unsigned)((g / set_pairs) * 2 + f); }
-            else { slot = (unsigned)kind; seg = (unsigned)(g * 2 + f); }
+            if (set_pairs > 1) { si.kslot = (unsigned)(kind * set_pairs + g % set_pairs); si.kbits = kSetSlotBits; si.seg = (unsigned)((g / set_pairs) * 2 + f); }
+            else { si.slot = (unsigned)kind; si.seg = (unsigned)(g * 2 + f); }
         }
-        bool ok = r >= 0 && c >= 0 && (long long)r < nbins;
-        unsigned long long br = 0, bc = 0, er = 0;
+        return si;
+    };
+    const int tile_first = blockIdx.x * kPer * (int)blockDim.x;
+    int tile_last = tile_first + kPer * (int)blockDim.x - 1;
+    tile_last = tile_last < n_last ? tile_last : n_last;
+    const int lo_a = __builtin_amdgcn_readfirstlane(run_of(tile_first)), lo_b = __builtin_amdgcn_readfirstlane(run_of(tile_last));
+    const bool one_run = lo_a == lo_b;                       // (uniform)
+    const SegInfo si_a = seg_of(lo_a);
+    // Windows are taken kKeyBatch at a time: first ALL their coordinate loads, then ALL their chromosome lookups, then the
+    // arithmetic — and no loaded value is looked at (not even selected against a default) before the last load of its kind is
+    // issued: indices are clamped instead of predicated.
+    constexpr int kKeyBatch = 8;
+    for (int u0 = 0; u0 < kPer; u0 += kKeyBatch) {
+    int rb[kKeyBatch], cb[kKeyBatch], cab[kKeyBatch];
+    const int i_base = (blockIdx.x * kPer + u0) * (int)blockDim.x + (int)threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < kKeyBatch; ++k) {
+        int i = i_base + k * (int)blockDim.x;
+        i = i < n_last ? i : n_last;
+        rb[k] = r0[i]; cb[k] = c0[i];
+    }
+#pragma unroll
+    for (int k = 0; k < kKeyBatch; ++k) {
+        int rc = rb[k] > 0 ? rb[k] : 0;
+        rc = rc < nb_last ? rc : nb_last;
+        cab[k] = (int)bin_chrom[rc];
+    }
+#pragma unroll
+    for (int k = 0; k < kKeyBatch; ++k) {
+        if (u0 + k >= kPer) break;                           // (uniform)
+        const int i = i_base + k * (int)blockDim.x;
+        const bool live = i < n32;
+        const int r = live ? rb[k] : 0, c = live ? cb[k] : 0;
+        SegInfo si = si_a;
+        if (!one_run) si = seg_of(run_of(i));
+        const unsigned seg = si.seg, slot = si.slot, kslot = si.kslot, kbits = si.kbits;
+        bool ok = r >= 0 && c >= 0 && r <= nb_last;
+        unsigned br = 0, bc = 0, er = 0;
         unsigned inside = 0u;                                // the window's corner inside its block: all the staged kernel needs
         if (ok) {
-            const int ca = bin_chrom[r];
-            const int cs = in_lds ? s_cs[ca] : chroms[ca].start, ce = in_lds ? s_ce[ca] : chroms[ca].end;
+            const int ca = cab[k];
+            const int cs = s_cs[ca], ce = s_ce[ca];
             ok = r >= cs && r + W <= ce && c >= cs && c + W <= ce;
             if (ok) {
                 constexpr int kR = SIDE_R ? SIDE_R : 1, kC = SIDE_C ? SIDE_C : 1;   // (a zero divisor must not even be spelled)
                 const int qr = SIDE_R ? (r - cs) / kR : (r - cs) / BR, qc = SIDE_C ? (c - cs) / kC : (c - cs) / BC;
-                br = (unsigned long long)((in_lds ? s_bb[ca] : brow_base[ca]) + qr);     // increasing over the genome, compact
-                bc = (unsigned long long)qc;
+                br = (unsigned)(s_bb[ca] + qr);             // increasing over the genome, compact
+                bc = (unsigned)qc;
                 inside = (unsigned)((r - cs) - qr * (SIDE_R ? SIDE_R : BR)) | ((unsigned)((c - cs) - qc * (SIDE_C ? SIDE_C : BC)) << kWinShift);
             }
         }
         if (n_eregs > 0) {                                   // the region whose expected the snippet divides by (that of its first row)
             const int e = find_exp_region(eregs, n_eregs, r);
-            er = (unsigned long long)(e < 0 ? n_eregs : e);
+            er = (unsigned)(e < 0 ? n_eregs : e);
         }
         if (live && !ok) ++bad;
-        {   // one atomic per wave, not per window (a call of near-diagonal windows would serialise on the counter)
-            const unsigned long long near = __ballot(live && (c - r < clear_gap || (c + W - 1) - r >= far_gap));
-            if (near != 0ull && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)near) - 1)) atomicAdd(&counters[1], (unsigned)__popcll(near));
-            const unsigned long long far = __ballot(live && band_w > 0 && (c + W - 1) - r >= band_w);
-            if (far != 0ull && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)far) - 1)) atomicAdd(&counters[2], (unsigned)__popcll(far));
-        }
+        // (counted per thread, summed per wave behind the loop: one atomic per wave and counter — a call of near-diagonal windows
+        // would serialise on the counter)
+        near_c += (live && (c - r < clear_gap || (c + W - 1) - r >= far_gap)) ? 1u : 0u;
+        far_c += (live && band_w > 0 && (c + W - 1) - r >= band_w) ? 1u : 0u;
         unsigned key_hi = 0u; bool counted = false;
         if (live) {
-        const unsigned long long key = ((((unsigned long long)(seg >> seg_shift) << sh_seg) | (er << sh_er) | (br << sh_br) | bc) << kbits) | kslot;
-        keys[i] = (KeyT)key;
-        key_hi = (unsigned)(key >> hi_shift); counted = hi_hist != nullptr;
-        // the value that rides the sort is the window itself as the staged kernel wants it (the sort is stable, so windows
-        // of a block keep the caller's order): no index to gather through afterwards
-        vals[i] = (unsigned short)(inside | (slot << kWinSlotBit));
+            if constexpr (sizeof(KeyT) == 4) {
+                const unsigned key = (((((seg >> seg_shift) << sh_seg) | (er << sh_er) | (br << sh_br) | bc) << kbits) | kslot);
+                keys[i] = (KeyT)key;
+                key_hi = key >> hi_shift;
+            } else {
+                const unsigned long long key = ((((unsigned long long)(seg >> seg_shift) << sh_seg) | ((unsigned long long)er << sh_er) |
+                                                 ((unsigned long long)br << sh_br) | bc) << kbits) | kslot;
+                keys[i] = (KeyT)key;
+                key_hi = (unsigned)(key >> hi_shift);
+            }
+            counted = hi_hist != nullptr;
+            // the value that rides the sort is the window itself as the staged kernel wants it (the sort is stable, so windows
+            // of a block keep the caller's order): no index to gather through afterwards
+            vals[i] = (unsigned short)(inside | (slot << kWinSlotBit));
         }
         {   // the workgroup's high-digit counts: ONE LDS atomic per distinct digit of the wave (the stream is nearly sorted by block row:
             // 64 lanes adding to one counter cost more than the whole key computation)
             unsigned long long todo = __ballot(counted);
             while (todo) {
                 const int l = __ffsll((long long)todo) - 1;
-                const unsigned d0 = __shfl(key_hi, l);
+                const unsigned d0 = (unsigned)__builtin_amdgcn_readlane((int)key_hi, l);
                 const unsigned long long m = __ballot(counted && key_hi == d0);
-                if ((int)(threadIdx.x & 63) == l) atomicAdd(&s_hh[d0], (unsigned)__popcll(m));
+                if (lane == l) atomicAdd(&s_hh[d0], (unsigned)__popcll(m));
                 todo &= ~m;
             }
         }
     }
+    }   // batches
     if (bad) atomicAdd(&counters[0], bad);
+    for (int off = 32; off > 0; off >>= 1) { near_c += __shfl_down(near_c, off); far_c += __shfl_down(far_c, off); }
+    if (lane == 0 && near_c) atomicAdd(&counters[1], near_c);
+    if (lane == 0 && far_c) atomicAdd(&counters[2], far_c);
     if (hi_hist) {
         __syncthreads();
         for (int k = threadIdx.x; k < hi_bins; k += blockDim.x) hi_hist[(size_t)blockIdx.x * hi_bins + k] = s_hh[k];
@@ -1097,8 +1158,17 @@ __global__ __launch_bounds__(256) void staged_table_kernel(const unsigned* __res
                                                            const unsigned long long* __restrict__ badbits,
                                                            StagedBlock* __restrict__ blocks, int* __restrict__ wg_first, int G,
                                                            const unsigned* __restrict__ block_keys /* nullable: key >> slot_bits of block b (pup_bin.hpp) */,
-                                                           const unsigned short* __restrict__ sorted_low /* with block_keys and slot_bits > 0: low digits in block order */) {
+                                                           const unsigned short* __restrict__ sorted_low /* with block_keys and slot_bits > 0: low digits in block order */,
+                                                           volatile unsigned* host_flags /* nullable: the block count goes there under `ticket` (was a launch of its own) */,
+                                                           unsigned ticket) {
     const long long nr = (long long)n_runs[0];
+    if (host_flags && blockIdx.x == 0 && threadIdx.x == 0) {
+        // leave the block count where the NEXT call with this signature finds it without waiting
+        host_flags[0] = n_runs[0];
+        __threadfence_system();
+        host_flags[1] = ticket;
+        __threadfence_system();
+    }
     const int BR = RSR - WR + 1, BC = RSC - WC + 1;
     for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < nr; b += (long long)gridDim.x * blockDim.x) {
         const unsigned s = starts[b];
@@ -1195,20 +1265,23 @@ __global__ __launch_bounds__(256) void staged_table_kernel(const unsigned* __res
 // Same shape as reduce_partials_kernel: 64 record elements x kRedParts interleaved partial sums in fixed order.
 PUP_KERNEL __launch_bounds__(64 * kRedParts) void reduce_staged_kernel(
         const double* __restrict__ in_f64, const unsigned* __restrict__ in_num, const unsigned short* __restrict__ owner,
-        int G, int T, int ACC, int PH, int Lf, int Li, double* out_f64, long long* out_num) {
+        int G, int T, int ACC, int PH, int Lf, int Li, double* out_f64, long long* out_num,
+        long long* out_n /* nullable: windows per tile, added from the (tile, flip) run ends (was a launch of its own) */, const long long* __restrict__ seg_end) {
     __shared__ double    sf[kRedParts][64];
     __shared__ long long si[kRedParts][64];
     const int t = blockIdx.y;
     const int cx = threadIdx.x, py = threadIdx.y;
+    if (out_n && blockIdx.x == 0 && cx == 0 && py == 0) out_n[t] += seg_end[2 * t + 1] - (t ? seg_end[2 * t - 1] : 0);
     const int idx = blockIdx.x * 64 + cx;
     // the accumulator slot tile t is piled up in (inverse of staged_tile)
     const int slot = ACC == 1 ? 0 : (ACC == 2 ? t / PH : (t / PH) * (ACC / 2) + (t % PH) % (ACC / 2));
     const size_t base = (size_t)slot * (size_t)(2 * T + G) + (size_t)t * 2;
     const long long e = 2LL * G;                          // virtual records c = flip * G + workgroup
     double accf = 0.0; long long acci = 0;
-    // eight records per round: their marks, then their values, are independent loads (one at a time, a thread waited out a
-    // memory round trip per record); the additions keep the order of the plain loop
-    constexpr int kUn = 8;
+    // sixteen records per round: their marks, then their values, are independent loads (one at a time, a thread waited out a
+    // memory round trip per record; 256 workgroups x 2 flips = 512 records are two rounds of the 16 parts); the additions keep
+    // the order of the plain loop
+    constexpr int kUn = 16;
     auto rec_of = [&](long long c) -> size_t { const int fl = c >= G ? 1 : 0; return base + (size_t)fl + (size_t)(c - (long long)fl * G); };
     auto mine = [&](long long c) -> bool { return c < e && owner[rec_of(c)] == (unsigned short)(t * 2 + (c >= G ? 1 : 0) + 1); };
     if (idx < Lf) {

@@ -536,69 +536,112 @@ __global__ __launch_bounds__(256) void wide_key_kernel(const int* __restrict__ r
                                                        unsigned* __restrict__ counters,
                                                        unsigned* __restrict__ hi_hist /* nullable: tilehist[workgroup][hi_bins] (pup_bin.hpp) */,
                                                        int hi_shift, int hi_bins, int per_thread) {
-    constexpr int kMaxChrom = 512;
+    // (32-bit index arithmetic — n_items < 2^31: wide_run —, tables in dynamic LDS, loads of a batch first: see staged_key_kernel)
     const int kPer = per_thread;
-    __shared__ int s_cs[kMaxChrom], s_ce[kMaxChrom], s_bb[kMaxChrom];
-    extern __shared__ long long s_seg[];                  // (dynamic: run ends, then the high-digit counts; see staged_key_kernel)
-    unsigned* const s_hh = reinterpret_cast<unsigned*>(s_seg + nseg2t);
-    const bool in_lds = n_chrom <= kMaxChrom;
-    if (in_lds) for (int k = threadIdx.x; k < n_chrom; k += blockDim.x) { s_cs[k] = chroms[k].start; s_ce[k] = chroms[k].end; s_bb[k] = brow_base[k]; }
-    for (int k = threadIdx.x; k < nseg2t; k += blockDim.x) s_seg[k] = seg_end[k];
+    extern __shared__ long long s_dyn[];
+    int* const s_seg = reinterpret_cast<int*>(s_dyn);                 // [nseg2t] (tile, flip) run ends
+    unsigned* const s_hh = reinterpret_cast<unsigned*>(s_seg + nseg2t);           // [hi_bins] high-digit counts of this workgroup's items
+    int* const s_cs = reinterpret_cast<int*>(s_hh + hi_bins);         // [n_chrom] first bin | end | block rows before
+    int* const s_ce = s_cs + n_chrom;
+    int* const s_bb = s_ce + n_chrom;
+    for (int k = threadIdx.x; k < n_chrom; k += blockDim.x) { s_cs[k] = chroms[k].start; s_ce[k] = chroms[k].end; s_bb[k] = brow_base[k]; }
+    for (int k = threadIdx.x; k < nseg2t; k += blockDim.x) s_seg[k] = (int)seg_end[k];
     if (hi_hist) for (int k = threadIdx.x; k < hi_bins; k += blockDim.x) s_hh[k] = 0u;
     __syncthreads();
-    unsigned bad = 0u;
-    for (int u = 0; u < kPer; ++u) {
-        const long long ii = ((long long)blockIdx.x * kPer + u) * blockDim.x + threadIdx.x;
-        const bool live = ii < n_items;
-        const int grp = live ? (int)(ii / n) : 0;
-        const long long i = live ? ii - (long long)grp * n : 0;
-        const int r = live ? r0[i] : 0, c = live ? c0[i] : 0;
+    unsigned bad = 0u, near_c = 0u, far_c = 0u;
+    const int lane = threadIdx.x & 63;
+    const int n32 = (int)n, ni32 = (int)n_items, ni_last = ni32 - 1, nb_last = (int)nbins - 1;
+    // group and (tile, flip) run of an item depend on its NUMBER only; a workgroup's 8192 consecutive items nearly always share
+    // them: worked out once per workgroup (per item: a division by n and a bisection)
+    auto run_of = [&](int i) -> int {
         int lo = 0, hi = nseg2t;
         while (lo < hi) { const int m = (lo + hi) >> 1; if (s_seg[m] <= i) lo = m + 1; else hi = m; }
+        return lo;
+    };
+    const int tile_first = blockIdx.x * kPer * (int)blockDim.x;
+    int tile_last = tile_first + kPer * (int)blockDim.x - 1;
+    tile_last = tile_last < ni_last ? tile_last : ni_last;
+    const int grp_a = tile_first / n32, grp_b = tile_last / n32;
+    const int lo_a = __builtin_amdgcn_readfirstlane(run_of(tile_first - grp_a * n32)), lo_b = __builtin_amdgcn_readfirstlane(run_of(tile_last - grp_b * n32));
+    const bool one_run = grp_a == grp_b && lo_a == lo_b;     // (uniform)
+    constexpr int kKeyBatch = 8;
+    for (int u0 = 0; u0 < kPer; u0 += kKeyBatch) {
+    int rb[kKeyBatch], cb[kKeyBatch], cab[kKeyBatch], gb[kKeyBatch], ib[kKeyBatch];
+    const int ii_base = (blockIdx.x * kPer + u0) * (int)blockDim.x + (int)threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < kKeyBatch; ++k) {
+        int ii = ii_base + k * (int)blockDim.x;
+        ii = ii < ni_last ? ii : ni_last;
+        gb[k] = one_run ? grp_a : ii / n32;
+        ib[k] = ii - gb[k] * n32;
+        rb[k] = r0[ib[k]]; cb[k] = c0[ib[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < kKeyBatch; ++k) {
+        int rc = rb[k] > 0 ? rb[k] : 0;
+        rc = rc < nb_last ? rc : nb_last;
+        cab[k] = (int)bin_chrom[rc];
+    }
+#pragma unroll
+    for (int k = 0; k < kKeyBatch; ++k) {
+        if (u0 + k >= kPer) break;                           // (uniform)
+        const int ii = ii_base + k * (int)blockDim.x;
+        const bool live = ii < ni32;
+        const int grp = live ? gb[k] : 0;
+        const int i = live ? ib[k] : 0;
+        const int r = live ? rb[k] : 0, c = live ? cb[k] : 0;
+        const int lo = one_run ? lo_a : run_of(i);
         const unsigned seg = (unsigned)(lo >> seg_shift) * (unsigned)NG + (unsigned)grp;
-        bool ok = r >= 0 && c >= 0 && (long long)r < nbins;
-        unsigned long long br = 0, bc = 0;
+        bool ok = r >= 0 && c >= 0 && r <= nb_last;
+        unsigned br = 0, bc = 0;
         unsigned inside = 0u;
         if (ok) {
-            const int ca = bin_chrom[r];
-            const int cs = in_lds ? s_cs[ca] : chroms[ca].start, ce = in_lds ? s_ce[ca] : chroms[ca].end;
+            const int ca = cab[k];
+            const int cs = s_cs[ca], ce = s_ce[ca];
             ok = r >= cs && r + W <= ce && c >= cs && c + W <= ce;
             if (ok) {
                 const int gi = grp / NGc, gj = grp - gi * NGc;
                 const int rs = r + gi * SH - cs, cc = c + gj * SW - cs;       // the sub-window's corner, chromosome-relative
                 const int qr = rs / BR, qc = cc / BC;
-                br = (unsigned long long)((in_lds ? s_bb[ca] : brow_base[ca]) + qr);
-                bc = (unsigned long long)qc;
+                br = (unsigned)(s_bb[ca] + qr);
+                bc = (unsigned)qc;
                 inside = (unsigned)(rs - qr * BR) | ((unsigned)(cc - qc * BC) << kWinShift);
             }
         }
         const bool first = live && grp == 0;
         if (first && !ok) ++bad;
-        {
-            const unsigned long long near = __ballot(first && (c - r < clear_gap || (c + W - 1) - r >= far_gap));
-            if (near != 0ull && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)near) - 1)) atomicAdd(&counters[1], (unsigned)__popcll(near));
-            const unsigned long long far = __ballot(first && (c + W - 1) - r >= band_w);
-            if (far != 0ull && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)far) - 1)) atomicAdd(&counters[2], (unsigned)__popcll(far));
-        }
+        near_c += (first && (c - r < clear_gap || (c + W - 1) - r >= far_gap)) ? 1u : 0u;
+        far_c += (first && (c + W - 1) - r >= band_w) ? 1u : 0u;
         unsigned key_hi = 0u; bool counted = false;
         if (live) {
-        const unsigned long long key = ((unsigned long long)seg << sh_seg) | (br << sh_br) | bc;
-        keys[ii] = (KeyT)key;
-        key_hi = (unsigned)(key >> hi_shift); counted = hi_hist != nullptr;
-        vals[ii] = (unsigned short)inside;
+            if constexpr (sizeof(KeyT) == 4) {
+                const unsigned key = (seg << sh_seg) | (br << sh_br) | bc;
+                keys[ii] = (KeyT)key;
+                key_hi = key >> hi_shift;
+            } else {
+                const unsigned long long key = ((unsigned long long)seg << sh_seg) | ((unsigned long long)br << sh_br) | bc;
+                keys[ii] = (KeyT)key;
+                key_hi = (unsigned)(key >> hi_shift);
+            }
+            counted = hi_hist != nullptr;
+            vals[ii] = (unsigned short)inside;
         }
         {   // the workgroup's high-digit counts: ONE LDS atomic per distinct digit of the wave (the stream is nearly sorted by block row:
             // 64 lanes adding to one counter cost more than the whole key computation)
             unsigned long long todo = __ballot(counted);
             while (todo) {
                 const int l = __ffsll((long long)todo) - 1;
-                const unsigned d0 = __shfl(key_hi, l);
+                const unsigned d0 = (unsigned)__builtin_amdgcn_readlane((int)key_hi, l);
                 const unsigned long long m = __ballot(counted && key_hi == d0);
-                if ((int)(threadIdx.x & 63) == l) atomicAdd(&s_hh[d0], (unsigned)__popcll(m));
+                if (lane == l) atomicAdd(&s_hh[d0], (unsigned)__popcll(m));
                 todo &= ~m;
             }
         }
     }
+    }   // batches
+    for (int off = 32; off > 0; off >>= 1) { near_c += __shfl_down(near_c, off); far_c += __shfl_down(far_c, off); }
+    if (lane == 0 && near_c) atomicAdd(&counters[1], near_c);
+    if (lane == 0 && far_c) atomicAdd(&counters[2], far_c);
     if (bad) atomicAdd(&counters[0], bad);
     if (hi_hist) {
         __syncthreads();
@@ -613,11 +656,12 @@ __global__ __launch_bounds__(256) void wide_key_kernel(const int* __restrict__ r
 PUP_KERNEL __launch_bounds__(64 * kRedParts) void reduce_wide_kernel(
         const double* __restrict__ rec_f64, const unsigned* __restrict__ rec_num, const unsigned* __restrict__ rec_seg,
         int G, int W, int NG, int NGc, int SH, int SW, int n_flip /* 1: no flipped windows in the call */,
-        int Lf, double* out_f64, long long* out_num) {
+        int Lf, double* out_f64, long long* out_num, long long* out_n /* nullable: windows per tile, from the run ends */, const long long* __restrict__ seg_end) {
     __shared__ double    sf[kRedParts][64];
     __shared__ long long si[kRedParts][64];
     const int t = blockIdx.y;
     const int cx = threadIdx.x, py = threadIdx.y;
+    if (out_n && blockIdx.x == 0 && cx == 0 && py == 0) out_n[t] += seg_end[2 * t + 1] - (t ? seg_end[2 * t - 1] : 0);
     const int cell = blockIdx.x * 64 + cx;
     const int W2 = W * W;
     double accf = 0.0; long long acci = 0;
