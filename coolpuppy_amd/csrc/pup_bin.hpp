@@ -191,7 +191,7 @@ __device__ __forceinline__ void block_excl_scan2(unsigned a, unsigned b, unsigne
 // workload (1.1e7 windows, 702 buckets): 8 waves 51 us, 4 waves 60 us, 16 waves 65 us, one wave per bucket (2048 buckets) 93 us — the
 // buckets are uneven and the biggest one's workgroup is the kernel's tail.  (Measured and dropped, round 4: the next eight rounds' loads
 // issued before this eight's LDS work; the leaders' read-modify-write as LDS atomics with return, batched per eight rounds: no change.)
-constexpr int kBucketWaves = 8;
+constexpr int kBucketWaves = 8;                      // most waves of a bucket's workgroup (the launch picks: bin_run)
 PUP_KERNEL __launch_bounds__(kWave * kBucketWaves) void bin_bucket_kernel(
         const unsigned* __restrict__ in, const unsigned* __restrict__ base, int DL, int DH, int slot_bits,
         unsigned short* __restrict__ out_val, unsigned short* __restrict__ out_low,
@@ -200,7 +200,8 @@ PUP_KERNEL __launch_bounds__(kWave * kBucketWaves) void bin_bucket_kernel(
     __shared__ unsigned scratch[2 * kBinWaves];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nl = 1 << DL;
-    unsigned* const tot = wcnt + kBucketWaves * nl;        // windows per low digit, later the digit's dense number
+    const int NWV = (int)(blockDim.x >> 6);                // waves of the workgroup (<= kBucketWaves)
+    unsigned* const tot = wcnt + NWV * nl;        // windows per low digit, later the digit's dense number
     unsigned* const dstart = tot + nl;                     // where the digit's run starts (bucket-relative)
     const int per = (nl + (int)blockDim.x - 1) / (int)blockDim.x;          // digits per thread, blocked: thread t owns [t per, (t + 1) per)
     unsigned* mine = wcnt + wave * nl;
@@ -209,11 +210,11 @@ PUP_KERNEL __launch_bounds__(kWave * kBucketWaves) void bin_bucket_kernel(
         const unsigned b0 = base[h], b1 = base[h + 1];
         if (b0 == b1) { if (tid == 0) blk_count[h] = 0u; continue; }        // (uniform)
         const unsigned cnt = b1 - b0;
-        const unsigned share = ((cnt + kBucketWaves - 1) / kBucketWaves + 63u) & ~63u;        // whole rounds of 64
+        const unsigned share = ((cnt + (unsigned)NWV - 1u) / (unsigned)NWV + 63u) & ~63u;        // whole rounds of 64
         const unsigned w0 = (unsigned)wave * share < cnt ? (unsigned)wave * share : cnt;
         const unsigned w1 = w0 + share < cnt ? w0 + share : cnt;
         __syncthreads();
-        for (int k = tid; k < kBucketWaves * nl; k += blockDim.x) wcnt[k] = 0u;
+        for (int k = tid; k < NWV * nl; k += blockDim.x) wcnt[k] = 0u;
         __syncthreads();
         for (unsigned i0 = w0; i0 < w1; i0 += U * 64) {       // sweep 1
             unsigned it[U];
@@ -225,7 +226,7 @@ PUP_KERNEL __launch_bounds__(kWave * kBucketWaves) void bin_bucket_kernel(
         __syncthreads();
         for (int d = tid; d < nl; d += blockDim.x) {          // exclusive over the waves; the bucket's count of the digit
             unsigned run = 0;
-            for (int w = 0; w < kBucketWaves; ++w) { const unsigned t = wcnt[w * nl + d]; wcnt[w * nl + d] = run; run += t; }
+            for (int w = 0; w < NWV; ++w) { const unsigned t = wcnt[w * nl + d]; wcnt[w * nl + d] = run; run += t; }
             tot[d] = run;
         }
         __syncthreads();

@@ -906,12 +906,18 @@ static int bin_run(pup_ctx* c, const BinPlan& bp, long long n_items, int slot_bi
     hipLaunchKernelGGL(pup::bin_chunksum_kernel, dim3((unsigned)nchunks, (unsigned)((nd + 1023) / 1024)), dim3(nd < 1024 ? nd : 1024), 0, c->stream,
                        tilehist, bp.ntiles, nd, chunksum);
     hipLaunchKernelGGL(pup::bin_scan_kernel, dim3(1), dim3(1024), 0, c->stream, chunksum, nchunks, nd, base);
-    const size_t lds1 = (size_t)pup::kBinWaves * (nd < 2 ? 2 : nd) * sizeof(unsigned short), lds2 = (size_t)(pup::kBucketWaves + 2) * nl * sizeof(unsigned);
+    const size_t lds1 = (size_t)pup::kBinWaves * (nd < 2 ? 2 : nd) * sizeof(unsigned short), lds2_unused = 0;
+    (void)lds2_unused;
+    // waves per bucket: what a bucket costs beside its windows is clearing and scanning waves x 2^DL counters — eight waves for low digits
+    // of up to 10 bits (the headline workload: 51 us against 60 with four), four beyond (pad 25, DL = 11: 95 us with eight)
+    int bwaves = nl >= 2048 ? 4 : pup::kBucketWaves;
+    if (const char* e = getenv("COOLPUPPY_AMD_BUCKET_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= pup::kBucketWaves) bwaves = v; }
+    const size_t lds2 = (size_t)(bwaves + 2) * nl * sizeof(unsigned);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pup::bin_partition_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
     hipLaunchKernelGGL(pup::bin_partition_kernel, dim3((unsigned)bp.ntiles), dim3(pup::kWave * pup::kBinWaves), lds1, c->stream,
                        (const unsigned*)keys, vals, n_items, bp.DL, bp.DH, (const unsigned*)base, (const unsigned*)chunksum, (const unsigned*)tilehist, keys_scratch);
     // (the keys are dead now: their buffer takes the buckets' block starts)
-    hipLaunchKernelGGL(pup::bin_bucket_kernel, dim3((unsigned)nd), dim3(pup::kWave * pup::kBucketWaves), lds2,
+    hipLaunchKernelGGL(pup::bin_bucket_kernel, dim3((unsigned)nd), dim3(pup::kWave * bwaves), lds2,
                        c->stream, (const unsigned*)keys_scratch, (const unsigned*)base, bp.DL, bp.DH, slot_bits, vals_out,
                        want_low ? c->d_low.p : (unsigned short*)nullptr, keys, c->d_blkkey.p, blk_count);
     hipLaunchKernelGGL(pup::bin_compact_kernel, dim3((unsigned)nd), dim3(256), 0, c->stream, (const unsigned*)base, (const unsigned*)blk_count, nd,
