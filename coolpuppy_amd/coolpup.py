@@ -214,6 +214,50 @@ class _Cols(dict):
 # ------------------------------------------------------------------------------------------------------
 # CoordCreator
 # ------------------------------------------------------------------------------------------------------
+class _DrawAhead:
+    """The control shifts of the regions to come, drawn on a helper thread while the main thread turns the regions already
+    drawn into windows.  The reference draws region by region as its stream is consumed (coolpup.py:420-436: randint then choice,
+    m = rows x nshifts numbers each); the legacy generator is sequential, so the numbers themselves cannot be drawn in parallel
+    — but they need not be drawn by the thread that uses them: the draws (pup_host_mt_randint, 2 ns per number, the GIL released)
+    were the largest single item of a 1e6-pair pile-up's host time.  The helper owns numpy's global generator from start() to
+    close(): it issues exactly the calls, in exactly the order, the main thread would have (`sizes` = the m of every region in
+    stream order), at most `depth` regions ahead.  close() joins it (and, after an error in the main thread, lets it finish the
+    sequence so that the generator ends where a serial run would have left it)."""
+
+    def __init__(self, cc, sizes, depth=3):
+        import queue
+        import threading
+        self._cc, self._sizes = cc, list(sizes)
+        self._q = queue.Queue(maxsize=depth)
+        self._err = None
+        self._th = threading.Thread(target=self._run, name="coolpuppy_amd-draws", daemon=True)
+        self._th.start()
+
+    def _run(self):
+        try:
+            for m in self._sizes:
+                self._q.put((m, self._cc._draw_raw_now(m)))
+        except BaseException as e:       # noqa: BLE001 — handed to the consumer
+            self._err = e
+            self._q.put((None, None))
+
+    def take(self, m):
+        got, val = self._q.get()
+        if self._err is not None:
+            raise self._err
+        if got != m:
+            raise RuntimeError(f"control draws out of step: region needs {m} numbers, {got} were drawn for it")
+        return val
+
+    def close(self):
+        while self._th.is_alive():       # (an aborted run: drain, so that the helper is never left blocked on a full queue)
+            try:
+                self._q.get(timeout=0.05)
+            except Exception:            # noqa: BLE001
+                pass
+        self._th.join()
+
+
 class CoordCreator:
     """Turns BED / BEDPE features into pile-up windows in bin units (reference coolpup.py:150-749).
 
@@ -309,10 +353,14 @@ class CoordCreator:
             # the reference sorts in _binnify (:489-527), after it has attached ~10 derived columns; every one of them is
             # a row-wise function of the input columns, so sorting NOW (same keys, same stable pandas sort, index labels
             # kept) gives the same frame while permuting half as many columns
-            iv["center1"] = c1
-            iv["center2"] = c2
-            iv["distance"] = c2 - c1
+            # (the three derived columns are attached AFTER the sort, recomputed from the sorted anchors — the same doubles: three
+            # sequential passes instead of three more random gathers of a million rows)
             iv = self._sort_pairs(iv)
+            s1 = (iv["start1"].values + iv["end1"].values) / 2
+            s2 = (iv["start2"].values + iv["end2"].values) / 2
+            iv["center1"] = s1
+            iv["center2"] = s2
+            iv["distance"] = s2 - s1
             presorted = True
             iv = expand2D(iv, self.flank, self.resolution, self.rescale_flank)
         self.intervals = iv
@@ -403,8 +451,11 @@ class CoordCreator:
         """iv.take(order) with the chromosome columns rebuilt from their factorisation: gathering a million object pointers at
         random positions is what made pandas' take of this frame slow (0.06 of the 0.11 s of the sort); indexing the handful of
         distinct names by the sorted codes touches one small array.  Same frame: same columns, dtypes, index labels."""
+        from .engine import take_rows
         names = np.asarray(uniq, dtype=object)
-        cols = {c: (names[coded[c]] if c in coded else iv[c].to_numpy()[order]) for c in iv.columns}
+        plain = [c for c in iv.columns if c not in coded]
+        taken = dict(zip(plain, take_rows([iv[c].to_numpy() for c in plain], order)))      # (one multi-threaded pass of the library)
+        cols = {c: (names[coded[c]] if c in coded else taken[c]) for c in iv.columns}
         return pd.DataFrame(cols, index=iv.index.take(order), copy=False)
 
     def _subset(self, df):
@@ -463,7 +514,13 @@ class CoordCreator:
     def _draw_raw(self, m):
         """The reference's RNG calls for m control windows (:420-436), in its order, un-multiplied: (|shift|, sign) of the
         draw that moves the BINS of both sides (the second pair of a trans pile-up, which only moves bp columns, is drawn
-        and dropped)."""
+        and dropped).  With a draw-ahead running (see _DrawAhead) the numbers come from its queue: same calls, same order."""
+        ahead = getattr(self, "_draw_ahead", None)
+        if ahead is not None:
+            return ahead.take(m)
+        return self._draw_raw_now(m)
+
+    def _draw_raw_now(self, m):
         narrow = np.int32 if max(abs(int(self.minshift)), abs(int(self.maxshift))) < 2 ** 31 else np.int64
         shift = _draw_ints(self.minshift, self.maxshift, m, dtype=narrow)
         sign = _draw_signs(m, dtype=narrow)
@@ -1382,6 +1439,35 @@ class PileUpper:
         if getattr(self, "_window_source", None) is None:
             _prefetch_engine(self._aclr, _dist.local_device(), rows=self._owned_rows if world > 1 else None)
         batches = []
+        ahead = None
+        nsh = self.nshifts if self.control else 0
+        if owned is None and nsh > 0 and len(pairs) > 1 and not os.environ.get("COOLPUPPY_AMD_NO_DRAW_AHEAD") and \
+                self._plain_pairs(modify, _by_window, False, groupby):
+            # every region takes _pair_snippets: the helper thread draws the regions' control shifts ahead (see _DrawAhead)
+            CC = self.CC
+            sizes = []
+            for region1, region2 in pairs:
+                reg1, reg2 = self._region_tuple(region1), self._region_tuple(region2)
+                rows = CC._rows_trans_pairs(tuple(reg1), tuple(reg2)) if CC.trans else CC._rows_pairs_region(tuple(reg1))
+                if len(rows):
+                    sizes.append(len(rows) * nsh)
+            if sum(sizes) >= 200_000:
+                ahead = CC._draw_ahead = _DrawAhead(CC, sizes)
+        try:
+            batches = self._region_batches(pairs, owned, groupby, modify, columns, _by_window)
+        finally:
+            if ahead is not None:
+                self.CC._draw_ahead = None
+                ahead.close()
+        region_groups = None
+        if owned is not None:
+            # the global group table needs every region's group keys in region order: the ranks swap them (a few keys each)
+            got = _dist.merge_dicts({i: self.region_groups(batches[i][2], grouped) for i in owned})
+            region_groups = [got[i] for i in range(len(pairs))]
+        return self._pile_and_finalize(batches, groupby, grouped=grouped, region_groups=region_groups)
+
+    def _region_batches(self, pairs, owned, groupby, modify, columns, _by_window):
+        batches = []
         for i, (region1, region2) in enumerate(pairs):
             if owned is not None and i not in owned:
                 self.CC.skip_region(self._region_tuple(region1), None if region2 == region1 else self._region_tuple(region2),
@@ -1393,12 +1479,7 @@ class PileUpper:
             batches.append((region1, region2, b))
             if b is not None and b["n"] > 0:
                 logger.info(f"{region1, region2}: {int((b['kind'] == KIND_ROI).sum())}")
-        region_groups = None
-        if owned is not None:
-            # the global group table needs every region's group keys in region order: the ranks swap them (a few keys each)
-            got = _dist.merge_dicts({i: self.region_groups(batches[i][2], grouped) for i in owned})
-            region_groups = [got[i] for i in range(len(pairs))]
-        return self._pile_and_finalize(batches, groupby, grouped=grouped, region_groups=region_groups)
+        return batches
 
     def region_groups(self, b, grouped):
         """Group keys of one region's windows, per kind, in order of first appearance (without "all"); None for a

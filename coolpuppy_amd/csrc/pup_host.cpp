@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstring>
 #include <thread>
+#include <atomic>
 #include <vector>
 
 #include "../../include/pup_hip.h"
@@ -20,7 +21,7 @@ namespace {
 
 int n_workers(int64_t rows) {
     const unsigned hw = std::thread::hardware_concurrency();
-    int64_t want = rows / 150000 + 1;                     // a thread is worth starting for ~0.15 M rows
+    int64_t want = rows / 60000 + 1;                      // a thread is worth starting for ~60 k rows (~0.1 ms of work against ~20 us)
     want = std::min<int64_t>(want, std::max(1u, std::min(hw, 16u)));
     return (int)want;
 }
@@ -63,35 +64,71 @@ PUP_EXPORT int64_t pup_host_windows(const int32_t* st1, const int32_t* st2, cons
     if (n < 0 || nshifts < 0 || (n > 0 && (!st1 || !st2 || !r0 || !c0)) || (nshifts > 0 && n > 0 && (!shift || !sign))) return -1;
     const int64_t total = n * (1 + (int64_t)nshifts);
     const int workers = n_workers(total);
-    auto window = [&](int64_t k, int64_t& r, int64_t& c) -> bool {
-        int64_t row = k, d = 0;
-        if (k >= n) {
-            const int64_t m = k - n;
-            row = m % n;
-            d = (int64_t)std::nearbyint((double)((int64_t)shift[m] * (int64_t)sign[m]) / resolution);
-        }
-        r = (int64_t)(int32_t)(st1[row] + (int32_t)d) + off1;
-        c = (int64_t)(int32_t)(st2[row] + (int32_t)d) + off2;
-        return r >= lo1 && r + h <= hi1 && c >= lo2 && c + w <= hi2;
-    };
-    std::vector<int64_t> kept((size_t)workers + 1, 0), kept_roi((size_t)workers, 0);
+    // ONE pass: every worker writes the windows of its share at their uncompacted positions and counts the kept ones; nearly
+    // always every window is kept (a control copy only falls off a chromosome's ends) and that is all.  Otherwise the shares
+    // are closed up in order (a worker's kept windows move left, never past a share that has not moved yet).  The copies are
+    // walked copy by copy, row by row: no division per window.  (Two passes with an `m % n` each: 26 of the 280 ms of a pile-up.)
+    std::vector<int64_t> kept((size_t)workers + 1, 0), kept_roi((size_t)workers, 0), lo((size_t)workers + 1, 0);
+    for (int k = 0; k <= workers; ++k) lo[(size_t)k] = workers <= 1 ? (k ? total : 0) : total * k / workers;
     parallel_chunks(total, workers, [&](int k, int64_t a, int64_t b) {
-        int64_t cnt = 0, roi = 0, r, c;
-        for (int64_t i = a; i < b; ++i) if (window(i, r, c)) { ++cnt; roi += (i < n); }
-        kept[(size_t)k + 1] = cnt; kept_roi[(size_t)k] = roi;
-    });
-    for (int k = 0; k < workers; ++k) kept[(size_t)k + 1] += kept[(size_t)k];
-    parallel_chunks(total, workers, [&](int k, int64_t a, int64_t b) {
-        int64_t o = kept[(size_t)k], r, c;
-        for (int64_t i = a; i < b; ++i) {
-            if (!window(i, r, c)) continue;
-            r0[o] = (int32_t)r; c0[o] = (int32_t)c;
-            if (code_out) code_out[o] = code ? code[i < n ? i : (i - n) % n] : -1;
-            ++o;
+        int64_t o = a, roi = 0;
+        int64_t i = a;
+        while (i < b) {
+            const int64_t copy = i / n, row0 = i - copy * n;                  // (once per run of rows)
+            const int64_t run_end = std::min<int64_t>(b, (copy + 1) * n);
+            for (int64_t row = row0; i < run_end; ++i, ++row) {
+                int64_t d = 0;
+                if (copy > 0) {
+                    const int64_t m = i - n;
+                    d = (int64_t)std::nearbyint((double)((int64_t)shift[m] * (int64_t)sign[m]) / resolution);
+                }
+                const int64_t r = (int64_t)(int32_t)(st1[row] + (int32_t)d) + off1;
+                const int64_t c = (int64_t)(int32_t)(st2[row] + (int32_t)d) + off2;
+                if (!(r >= lo1 && r + h <= hi1 && c >= lo2 && c + w <= hi2)) continue;
+                r0[o] = (int32_t)r; c0[o] = (int32_t)c;
+                if (code_out) code_out[o] = code ? code[row] : -1;
+                ++o; roi += copy == 0;
+            }
         }
+        kept[(size_t)k + 1] = o - a; kept_roi[(size_t)k] = roi;
     });
+    {
+        int64_t at = kept[1];                                                 // share 0 is in place
+        for (int k = 1; k < workers; ++k) {
+            const int64_t a = lo[(size_t)k], cnt = kept[(size_t)k + 1];
+            if (at != a && cnt > 0) {
+                std::memmove(r0 + at, r0 + a, (size_t)cnt * sizeof(int32_t));
+                std::memmove(c0 + at, c0 + a, (size_t)cnt * sizeof(int32_t));
+                if (code_out) std::memmove(code_out + at, code_out + a, (size_t)cnt * sizeof(int32_t));
+            }
+            at += cnt;
+        }
+        kept[(size_t)workers] = at;
+    }
     if (n_roi_kept) { int64_t s = 0; for (int64_t v : kept_roi) s += v; *n_roi_kept = s; }
     return kept[(size_t)workers];
+}
+
+// iv.take(order) of a frame's numeric columns: dst[c][i] = src[c][order[i]], elements of esize[c] = 1, 2, 4 or 8 bytes, all columns
+// in one call, rows shared out to the workers.  (numpy gathers a column at a time on one thread: a random read per element —
+// seven columns of 10^6 rows were 55 of the 280 ms of a pile-up.)
+PUP_EXPORT int pup_host_take_rows(int32_t ncols, const void* const* src, void* const* dst, const int32_t* esize,
+                                  const int64_t* order, int64_t n, int64_t n_src) {
+    if (ncols < 0 || n < 0 || (ncols > 0 && n > 0 && (!src || !dst || !esize || !order))) return PUP_EINVAL;
+    for (int c = 0; c < ncols; ++c) if (esize[c] != 1 && esize[c] != 2 && esize[c] != 4 && esize[c] != 8) return PUP_EINVAL;
+    std::atomic<int> bad{0};
+    parallel_chunks(n, n_workers(n * std::max(ncols, 1) / 2), [&](int, int64_t a, int64_t b) {
+        for (int64_t i = a; i < b; ++i) if (order[i] < 0 || order[i] >= n_src) { bad.store(1); return; }
+        for (int c = 0; c < ncols; ++c) {
+            switch (esize[c]) {
+                case 8: { const uint64_t* s = (const uint64_t*)src[c]; uint64_t* d = (uint64_t*)dst[c]; for (int64_t i = a; i < b; ++i) d[i] = s[order[i]]; break; }
+                case 4: { const uint32_t* s = (const uint32_t*)src[c]; uint32_t* d = (uint32_t*)dst[c]; for (int64_t i = a; i < b; ++i) d[i] = s[order[i]]; break; }
+                case 2: { const uint16_t* s = (const uint16_t*)src[c]; uint16_t* d = (uint16_t*)dst[c]; for (int64_t i = a; i < b; ++i) d[i] = s[order[i]]; break; }
+                default: { const uint8_t* s = (const uint8_t*)src[c]; uint8_t* d = (uint8_t*)dst[c]; for (int64_t i = a; i < b; ++i) d[i] = s[order[i]]; break; }
+            }
+        }
+    });
+    return bad.load() ? PUP_EINVAL : PUP_OK;
 }
 
 // ---- the reference's random draws, at memory speed ----------------------------------------------------------------------

@@ -479,6 +479,32 @@ def legacy_randint(low, high, m, scale=1, offset=0, discard=False, dtype=np.int6
     return out
 
 
+def take_rows(columns, order):
+    """[col[order] for col in columns] (1-D numeric arrays of one length) through pup_host_take_rows: every column in one
+    multi-threaded pass.  Columns the library cannot gather (object dtype, odd element sizes, non-contiguous) go through numpy."""
+    order = np.ascontiguousarray(order, np.int64)
+    n = order.shape[0]
+    out = [None] * len(columns)
+    src, dst, es, idx = [], [], [], []
+    for j, col in enumerate(columns):
+        col = np.asarray(col)
+        if col.ndim == 1 and col.dtype.kind in "iufb" and col.dtype.itemsize in (1, 2, 4, 8) and col.flags.c_contiguous and n >= 4096:
+            o = np.empty(n, col.dtype)
+            src.append(col); dst.append(o); es.append(col.dtype.itemsize); idx.append(j)
+        else:
+            out[j] = col[order]
+    if idx:
+        n_src = min(c.shape[0] for c in src)
+        ps = (C.c_void_p * len(idx))(*[c.ctypes.data for c in src])
+        pd_ = (C.c_void_p * len(idx))(*[c.ctypes.data for c in dst])
+        rc = _ffi.lib().pup_host_take_rows(len(idx), ps, pd_, _ptr(np.array(es, np.int32)), _ptr(order), n, n_src)
+        if rc != 0:
+            raise IndexError("take_rows: index out of bounds")
+        for j, o in zip(idx, dst):
+            out[j] = o
+    return out
+
+
 def group_tiles(parts, T):
     """pup_host_group_tiles: [(r0, c0, tile), ...] (int32 arrays per region) -> (r0, c0, tile_ptr) of one engine call,
     stably grouped by tile; r0 / c0 page-locked."""

@@ -34,6 +34,7 @@
  *                                                                      coolpuppy/coolpup.py:420-436
  *   pup_host_windows                  <- CoordCreator._control_regions (shifted control copies) + the bounds test of
  *                                        _stream_snips, as one host pass  coolpuppy/coolpup.py:387-453, 1105-1114
+ *   pup_host_take_rows                <- the sort of the feature frame in CoordCreator._binnify  coolpuppy/coolpup.py:489-527
  *   pup_host_group_tiles              <- the per-group dicts of accumulate_stream as a grouping of windows by tile
  *                                                                      coolpuppy/coolpup.py:1263-1283
  *   pup_host_alloc / pup_host_free    <- (no counterpart: page-locked staging for asynchronous host-to-device copies)
@@ -340,6 +341,15 @@ int64_t pup_host_windows(const int32_t* st1, const int32_t* st2, const int32_t* 
  */
 int pup_host_mt_randint(uint32_t* key, int32_t* pos, int64_t low, int64_t high, int64_t m, int64_t scale, int64_t offset,
                         void* out, int32_t out_bytes);
+
+/*
+ * pup_host_take_rows: frame.take(order) for the numeric columns of the feature frame CoordCreator sorts (the stable sort of
+ * _binnify, coolpuppy/coolpup.py:489-527, permutes every column): dst[c][i] = src[c][order[i]] for ncols columns of n_src
+ * elements of esize[c] (1, 2, 4 or 8) bytes, i < n, on several threads.  PUP_EINVAL for an index outside [0, n_src) or an
+ * unsupported element size.
+ */
+int pup_host_take_rows(int32_t ncols, const void* const* src, void* const* dst, const int32_t* esize, const int64_t* order,
+                       int64_t n, int64_t n_src);
 
 /*
  * pup_host_group_tiles: the windows of several regions gathered into ONE pup_accumulate call — stable grouping by tile id

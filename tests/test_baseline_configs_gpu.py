@@ -185,6 +185,17 @@ def test_config2_million_pairs_ten_shifts(hg38, oracle_mod):
         df = coolpup.pileup(hg38, feats, features_format="bedpe", flank=100_000, nshifts=10, seed=0)
     assert int(df["n"].iloc[0]) == int(acc["n"][0]) and int(df["control_n"].iloc[0]) == int(acc["n"][1])
     np.testing.assert_array_equal(np.asarray(df["num"].iloc[0]), acc["num"][0])
+    # (pileup() draws the control shifts on a helper thread, the plan above on the calling thread: same windows — and the
+    # same pile-up, bit for bit, with the helper switched off)
+    os.environ["COOLPUPPY_AMD_NO_DRAW_AHEAD"] = "1"
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            df2 = coolpup.pileup(hg38, feats, features_format="bedpe", flank=100_000, nshifts=10, seed=0)
+    finally:
+        os.environ.pop("COOLPUPPY_AMD_NO_DRAW_AHEAD", None)
+    np.testing.assert_array_equal(np.asarray(df["data"].iloc[0]), np.asarray(df2["data"].iloc[0]))
+    assert int(df2["control_n"].iloc[0]) == int(df["control_n"].iloc[0])
 
 
 @pytest.mark.parametrize("case", ["ooe_expected_table", "flip_negative_strand"])

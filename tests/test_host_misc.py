@@ -137,7 +137,7 @@ def test_library_window_pass_equals_numpy():
     np.round's half-to-even included — for several shapes; pup_host_group_tiles against a stable argsort."""
     from coolpuppy_amd import engine as E
     rng = np.random.default_rng(0)
-    for n, ns, res in ((0, 3, 10_000), (1, 0, 10_000), (1000, 3, 10_000), (257, 10, 5_000), (40_000, 2, 20_000)):
+    for n, ns, res in ((0, 3, 10_000), (1, 0, 10_000), (1000, 3, 10_000), (257, 10, 5_000), (40_000, 2, 20_000), (150_001, 4, 10_000)):
         st1 = rng.integers(0, 5000, n).astype(np.int32)
         st2 = (st1 + rng.integers(-5, 300, n)).astype(np.int32)
         code = rng.integers(0, 7, n).astype(np.int32)
@@ -168,6 +168,59 @@ def test_library_window_pass_equals_numpy():
     assert np.array_equal(tp, np.concatenate([[0], np.cumsum(np.bincount(tile, minlength=11))]))
     with pytest.raises(ValueError):
         E.group_tiles([(r0[:5], c0[:5], np.array([0, 1, 2, 11, 3], np.int32))], 11)
+
+
+def test_draw_ahead_thread_issues_the_serial_draws():
+    """_DrawAhead (control shifts drawn on a helper thread, a few regions ahead) hands out the numbers the main thread would
+    have drawn itself, region by region, and leaves numpy's legacy generator in the same state; a consumer out of step is an
+    error, and close() after an abandoned run still ends the sequence where a serial run would."""
+    from coolpuppy_amd import coolpup
+
+    class CC:
+        minshift, maxshift, trans = 100_000, 1_000_000, False
+        _draw_raw_now = coolpup.CoordCreator._draw_raw_now
+    sizes = [5000, 1, 70_000, 2048, 300_000, 12]
+    for trans in (False, True):
+        cc = CC()
+        cc.trans = trans
+        np.random.seed(7)
+        want = [cc._draw_raw_now(m) for m in sizes]
+        end = np.random.get_state()
+        np.random.seed(7)
+        ahead = coolpup._DrawAhead(cc, sizes, depth=2)
+        got = [ahead.take(m) for m in sizes]
+        ahead.close()
+        for (a, b), (c, d) in zip(want, got):
+            assert np.array_equal(a, c) and np.array_equal(b, d)
+        now = np.random.get_state()
+        assert now[2] == end[2] and np.array_equal(now[1], end[1])
+        np.random.seed(7)
+        ahead = coolpup._DrawAhead(cc, sizes, depth=2)
+        ahead.take(5000)
+        with pytest.raises(RuntimeError):
+            ahead.take(99)
+        ahead.close()
+        now = np.random.get_state()
+        assert now[2] == end[2] and np.array_equal(now[1], end[1])
+
+
+def test_library_take_rows_equals_numpy_take():
+    """pup_host_take_rows (the permutation of the feature frame's numeric columns, several threads) against numpy's fancy
+    index, every element size; object columns and short frames go through numpy; a bad index raises."""
+    from coolpuppy_amd import engine as E
+    rng = np.random.default_rng(3)
+    n_src, n = 300_000, 250_000
+    order = rng.integers(0, n_src, n)
+    cols = [rng.integers(-2**40, 2**40, n_src), rng.random(n_src), rng.integers(0, 2**31 - 1, n_src).astype(np.int32),
+            rng.integers(0, 60000, n_src).astype(np.uint16), rng.random(n_src) < 0.5, rng.random(n_src).astype(np.float32),
+            np.array([f"chr{k % 7}" for k in range(n_src)], dtype=object), rng.random((n_src, 2))[:, 0]]
+    got = E.take_rows(cols, order)
+    for c, g in zip(cols, got):
+        assert g.dtype == c.dtype and np.array_equal(g, c[order])
+    small = E.take_rows([cols[0][:100]], np.array([5, 3, 99]))
+    assert np.array_equal(small[0], cols[0][[5, 3, 99]])
+    with pytest.raises(IndexError):
+        E.take_rows([cols[0]], np.full(10_000, n_src))
 
 
 def test_coverage_restatement_matches_hand_derived_answers():
