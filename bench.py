@@ -18,10 +18,11 @@ Scaling: N=1 is the whole workload on one GPU.  For N>1 the library's own multi-
 "chromosomes shard across the GPUs with a final RCCL all-reduce"; coolpuppy_amd.PileUpper.run_plan): rank r owns the
 chromosomes an LPT assignment by snippet count gives it, holds only THEIR rows of the pixel table, piles up only their
 snippets, and the step ends with ONE in-place all-reduce of the packed tiles by the engine itself (pup_allreduce: RCCL on
-the engine's stream; `--exchange torch` = torch.distributed.all_reduce on exported buffers instead).  The JSON line is the
-STRONG-scaling measurement of the fixed BASELINE workload (1e6 pairs); a WEAK-scaling measurement of the same sharded path
-— N x 1e6 pairs, so that the per-GPU work stays that of N=1 — follows in the same run and is reported as the secondary field
-`weak` (`--scaling weak` makes it the primary one).
+the engine's stream; `--exchange torch` = torch.distributed.all_reduce on exported buffers instead).  For N>1 the JSON line's
+`value` is the WEAK-scaling measurement of that sharded path — N x 1e6 pairs, one bigger pile-up, so that the per-GPU work stays
+that of N=1 (`"scaling": "weak"`) — and the STRONG-scaling measurement of the fixed BASELINE workload (the same 1e6 pairs split
+over the ranks: a 0.75 ms job, bounded by its fixed per-call cost and the all-reduce latency) rides along in the field `strong`;
+`--scaling strong` makes that one the primary.
 
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (pile-up kernels, HIP-event timed
 inside this process) and `cpu_baseline` (N=1 only).
@@ -410,8 +411,10 @@ def main():
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         a.gpus = world
-    if a.scaling == "auto" or world == 1:
+    if world == 1:
         a.scaling = "strong"                  # N=1: the whole workload either way
+    elif a.scaling == "auto":
+        a.scaling = "weak"                    # N>1: per-GPU work as at N=1 (the strong reading of the 1e6-pair job rides along)
     if a.config != 2:
         import bench_plan
         return bench_plan.main_plan(a, rank, world, local_rank, sys.modules[__name__])

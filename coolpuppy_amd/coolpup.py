@@ -440,7 +440,12 @@ class CoordCreator:
         if bool(np.all(key[1:] > key[:-1])):                 # already in order (a sorted BEDPE file): nothing to permute
             self._sorted_codes = (iv.index.values, codes[:n], codes[n:], uniq)
             return iv
-        order = np.argsort(key)
+        if n >= 50_000:
+            from .engine import stable_argsort
+            # (multi-threaded radix sort of the library, stable: the row-number bits that make the keys unique need not be sorted)
+            order = stable_argsort(key >> width[3], sum(width[:3]))
+        else:
+            order = np.argsort(key)
         c1s, c2s = codes[:n][order], codes[n:][order]
         out = self._take_rows(iv, order, {"chrom1": c1s, "chrom2": c2s}, uniq)
         self._sorted_codes = (out.index.values, c1s, c2s, uniq)

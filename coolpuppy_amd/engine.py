@@ -479,6 +479,15 @@ def legacy_randint(low, high, m, scale=1, offset=0, discard=False, dtype=np.int6
     return out
 
 
+def stable_argsort(keys, bits):
+    """np.argsort(keys, kind="stable") for non-negative integer keys below 2**bits, by the library's multi-threaded radix sort."""
+    keys = np.ascontiguousarray(keys).view(np.uint64) if np.asarray(keys).dtype.itemsize == 8 else np.ascontiguousarray(keys, np.uint64)
+    order = np.empty(keys.shape[0], np.int64)
+    if _ffi.lib().pup_host_argsort(_ptr(keys), keys.shape[0], int(bits), _ptr(order)) != 0:
+        raise ValueError("pup_host_argsort: bad arguments")
+    return order
+
+
 def take_rows(columns, order):
     """[col[order] for col in columns] (1-D numeric arrays of one length) through pup_host_take_rows: every column in one
     multi-threaded pass.  Columns the library cannot gather (object dtype, odd element sizes, non-contiguous) go through numpy."""

@@ -34,6 +34,7 @@
  *                                                                      coolpuppy/coolpup.py:420-436
  *   pup_host_windows                  <- CoordCreator._control_regions (shifted control copies) + the bounds test of
  *                                        _stream_snips, as one host pass  coolpuppy/coolpup.py:387-453, 1105-1114
+ *   pup_host_argsort                  <- the same sort's order (one packed key per row)
  *   pup_host_take_rows                <- the sort of the feature frame in CoordCreator._binnify  coolpuppy/coolpup.py:489-527
  *   pup_host_group_tiles              <- the per-group dicts of accumulate_stream as a grouping of windows by tile
  *                                                                      coolpuppy/coolpup.py:1263-1283
@@ -350,6 +351,13 @@ int pup_host_mt_randint(uint32_t* key, int32_t* pos, int64_t low, int64_t high, 
  */
 int pup_host_take_rows(int32_t ncols, const void* const* src, void* const* dst, const int32_t* esize, const int64_t* order,
                        int64_t n, int64_t n_src);
+
+/*
+ * pup_host_argsort: order[i] = index of the i-th smallest of n keys of `bits` significant bits, equal keys in index order —
+ * the stable sort of the feature frame by (chrom1, chrom2, start1, start2) in CoordCreator._binnify (coolpuppy/coolpup.py:489-527)
+ * on one packed key per row.  Multi-threaded LSD radix sort.  PUP_OK / PUP_EINVAL.
+ */
+int pup_host_argsort(const uint64_t* keys, int64_t n, int32_t bits, int64_t* order);
 
 /*
  * pup_host_group_tiles: the windows of several regions gathered into ONE pup_accumulate call — stable grouping by tile id

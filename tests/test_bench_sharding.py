@@ -62,8 +62,8 @@ def test_bench_two_ranks_on_one_gpu_match_one_rank(hip_lib, tmp_path):
     common = ["--steps", "3", "--warmup", "1", "--pairs", "30000", "--chroms", "5", "--lam", "400", "--cpu-sample", "0"]
     env = {"TMPDIR": str(tmp_path)}
     one = _bench(["--gpus", "1"] + common, env)
-    two = _bench(["--gpus", "2", "--backend", "gloo"] + common, dict(env, COOLPUPPY_AMD_BENCH_DEVICE="0"), nproc=2)
-    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
+    two = _bench(["--gpus", "2", "--backend", "gloo", "--scaling", "strong"] + common, dict(env, COOLPUPPY_AMD_BENCH_DEVICE="0"), nproc=2)
+    assert one["n_gpus"] == 1 and one["scaling"] == "strong" and two["n_gpus"] == 2 and two["scaling"] == "strong"
     assert two["check"]["n"] == one["check"]["n"]                               # all-reduced tiles = the single-GPU tiles
     assert abs(two["check"]["center_roi_over_ctrl"] / one["check"]["center_roi_over_ctrl"] - 1) < 1e-12
     assert two["config"]["snippets_per_step"] == one["config"]["snippets_per_step"] == sum(one["check"]["n"])
@@ -72,6 +72,10 @@ def test_bench_two_ranks_on_one_gpu_match_one_rank(hip_lib, tmp_path):
     assert w["scaling"] == "weak" and w["pairs"] == 60000 and sum(w["check_n"]) == w["snippets_per_step"]
     assert w["snippets_per_step"] > 1.9 * one["config"]["snippets_per_step"]
     assert two["exchange"].startswith("torch.distributed")                     # gloo: no RCCL between ranks sharing a GPU
+    # the default N > 1 line: weak scaling (per-GPU work as at N = 1) as `value`, the strong reading beside it
+    dflt = _bench(["--gpus", "2", "--backend", "gloo"] + common, dict(env, COOLPUPPY_AMD_BENCH_DEVICE="0"), nproc=2, port=29563)
+    assert dflt["scaling"] == "weak" and dflt["value"] == dflt["weak"]["value"] and dflt["steps"] == 3
+    assert dflt["config"]["pairs"] == 60000 and dflt["strong"]["snippets_per_step"] == one["config"]["snippets_per_step"]
 
 
 @pytest.mark.gpu

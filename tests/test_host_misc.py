@@ -204,6 +204,15 @@ def test_draw_ahead_thread_issues_the_serial_draws():
         assert now[2] == end[2] and np.array_equal(now[1], end[1])
 
 
+def test_library_argsort_equals_numpy_stable_argsort():
+    from coolpuppy_amd import engine as E
+    rng = np.random.default_rng(5)
+    for n, bits in ((1, 1), (1000, 7), (200_000, 23), (300_001, 40), (150_000, 63)):
+        keys = rng.integers(0, 2 ** min(bits, 62), n, dtype=np.int64)
+        keys[:: 7] = keys[0]                                  # ties: index order
+        assert np.array_equal(E.stable_argsort(keys, bits), np.argsort(keys, kind="stable"))
+
+
 def test_library_take_rows_equals_numpy_take():
     """pup_host_take_rows (the permutation of the feature frame's numeric columns, several threads) against numpy's fancy
     index, every element size; object columns and short frames go through numpy; a bad index raises."""
