@@ -3,7 +3,7 @@
 // Round 3 sorted the (block key, window) pairs with rocPRIM's radix sort: histogram + two onesweep passes (0.18 of the 0.31 ms
 // prepass of the headline step), then two more kernels over the sorted keys to find the block starts.  What the staged kernels
 // need is less than a sort: the windows GROUPED by block key, blocks in key order, the order inside a block deterministic
-// (the caller's order: sums then do not depend on timing).  This file does exactly that for keys of up to 22 bits
+// (the caller's order: sums then do not depend on timing).  This file does exactly that for keys of up to 23 bits
 // (hg38 at 10 kb: 20), split into a high digit of DH and a low digit of DL bits (both <= 11):
 //   0. the key kernels (staged_key_kernel / wide_key_kernel) also count the high digits of their workgroup's 8192 windows (LDS
 //      histogram, one add per distinct digit of a wave) and write the counts as the tile's row of tilehist;
@@ -18,13 +18,14 @@
 //      per digit, then every wave places its contiguous share; reads are sequential, writes land in the bucket's own span.  The same kernel emits the bucket's blocks (start, key): a block
 //      IS a non-empty run of low digits, no second look at sorted keys;
 //   4. bin_compact_kernel: the buckets' block lists packed into one (a scan over <= 2048 bucket counts).
-// Keys wider than 22 bits (hundreds of tiles x expected regions) keep the library sort (staged_run / wide_run decide).
+// Keys wider than 23 bits (hundreds of tiles x expected regions) keep the library sort (staged_run / wide_run decide).
 #pragma once
 #include "pup_kernels.hpp"
 
 namespace pup {
 
-constexpr int kBinMaxDigit = 11;                      // bits of a digit: 2048 counters
+constexpr int kBinMaxDigit = 11;                      // bits of the HIGH digit: 2048 counters per wave of the partition pass
+constexpr int kBinMaxLow = 12;                        // bits of the LOW digit: (waves + 2) x 4096 counters of a bucket's workgroup (96 KB with four waves)
 constexpr int kBinTile = 8192;                        // windows per tile of the partition pass: 16 waves x 8 rounds x 64 lanes
 constexpr int kBinWaves = 16;
 

@@ -874,10 +874,10 @@ static void fill_k1_args(pup_ctx* c, pup::K1Args& a, int32_t ignore_diags, uint3
 // Digit split of a key of `end_bit` bits whose lowest `slot_bits` hold the accumulator slot: false when the key is too wide
 struct BinPlan { int DL, DH; long long ntiles; };
 static bool bin_plan(int end_bit, int slot_bits, long long n_items, BinPlan& bp) {
-    int DL = std::min(std::max((end_bit + 1) / 2, slot_bits), pup::kBinMaxDigit);
+    int DL = std::min(std::max(std::max((end_bit + 1) / 2, end_bit - pup::kBinMaxDigit), slot_bits), pup::kBinMaxLow);
     if (const char* e = getenv("COOLPUPPY_AMD_BIN_DH")) {        // experiments: bits of the high digit
         const int dh = std::max(0, std::min(atoi(e), std::min(end_bit, pup::kBinMaxDigit)));
-        DL = std::min(std::max(end_bit - dh, slot_bits), pup::kBinMaxDigit);
+        DL = std::min(std::max(end_bit - dh, slot_bits), pup::kBinMaxLow);
     }
     const int DH = std::max(end_bit - DL, 0);
     if (DH > pup::kBinMaxDigit) return false;
@@ -913,6 +913,7 @@ static int bin_run(pup_ctx* c, const BinPlan& bp, long long n_items, int slot_bi
     int bwaves = nl >= 2048 ? 4 : pup::kBucketWaves;
     if (const char* e = getenv("COOLPUPPY_AMD_BUCKET_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= pup::kBucketWaves) bwaves = v; }
     const size_t lds2 = (size_t)(bwaves + 2) * nl * sizeof(unsigned);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pup::bin_bucket_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pup::bin_partition_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
     hipLaunchKernelGGL(pup::bin_partition_kernel, dim3((unsigned)bp.ntiles), dim3(pup::kWave * pup::kBinWaves), lds1, c->stream,
                        (const unsigned*)keys, vals, n_items, bp.DL, bp.DH, (const unsigned*)base, (const unsigned*)chunksum, (const unsigned*)tilehist, keys_scratch);
@@ -1097,7 +1098,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
         HIPCHK(c, hipMemcpy(c->d_teams.p, teams.data(), teams.size(), hipMemcpyHostToDevice));
         c->teams_sent = teams;
     }
-    // block order: the hand-written binning (pup_bin.hpp) for keys of up to 22 bits, else (or with variant bit 29) the library's radix sort
+    // block order: the hand-written binning (pup_bin.hpp) for keys of up to 23 bits, else (or with variant bit 29) the library's radix sort
     BinPlan bp{};
     const bool use_bin = k32 && !(c->variant & 1024) && bin_plan(end_bit, slot_bits, (long long)n, bp);
     size_t tmp_bytes = 0;

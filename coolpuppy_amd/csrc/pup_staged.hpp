@@ -1290,7 +1290,7 @@ PUP_KERNEL __launch_bounds__(64 * kRedParts) void reduce_staged_kernel(
 #pragma unroll
             for (int u = 0; u < kUn; ++u) ok[u] = mine(c0 + (long long)u * kRedParts);
 #pragma unroll
-            for (int u = 0; u < kUn; ++u) v[u] = ok[u] ? in_f64[rec_of(c0 + (long long)u * kRedParts) * Lf + idx] : 0.0;
+            for (int u = 0; u < kUn; ++u) { const long long c = c0 + (long long)u * kRedParts; v[u] = in_f64[rec_of(c < e ? c : 0) * Lf + idx]; }   // (not waiting for the marks: a record nobody owns holds old numbers, never added)
 #pragma unroll
             for (int u = 0; u < kUn; ++u) if (ok[u]) accf += v[u];
         }
@@ -1301,9 +1301,9 @@ PUP_KERNEL __launch_bounds__(64 * kRedParts) void reduce_staged_kernel(
 #pragma unroll
             for (int u = 0; u < kUn; ++u) ok[u] = mine(c0 + (long long)u * kRedParts);
 #pragma unroll
-            for (int u = 0; u < kUn; ++u) v[u] = ok[u] ? in_num[rec_of(c0 + (long long)u * kRedParts) * Li + k] : 0u;
+            for (int u = 0; u < kUn; ++u) { const long long c = c0 + (long long)u * kRedParts; v[u] = in_num[rec_of(c < e ? c : 0) * Li + k]; }
 #pragma unroll
-            for (int u = 0; u < kUn; ++u) acci += (long long)v[u];
+            for (int u = 0; u < kUn; ++u) if (ok[u]) acci += (long long)v[u];
         }
     }
     sf[py][cx] = accf; si[py][cx] = acci;
