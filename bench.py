@@ -662,13 +662,13 @@ def main():
         family = eng.last_kernel()                       # which kernel family the timed calls ran (pup_last_kernel)
         reg_rows, reg_cols = PileupEngine.staged_region(a.pad)
         if a.variant & 128:
-            reg_rows = 64
+            reg_rows = 72
         if family.startswith("wide"):
             reg_rows = reg_cols = 128
             wg = PileupEngine.wide_geometry(W)
-            kernel_name = (f"pup::pileup_wide_kernel<{wg['CH']}, false, {'true' if family == 'wide_fact' else 'false'}> (K1w: persistent 16-wave "
+            kernel_name = (f"pup::pileup_wide_kernel<{wg['CH']}, {wg['NCH']}, false, {'true' if family == 'wide_fact' else 'false'}> (K1w: persistent 16-wave "
                            f"workgroups, 128 x 128 regions staged in LDS from the dense band; {wg['NGr']} x {wg['NGc']} sub-windows of "
-                           f"{wg['SH']} x {wg['SW']} bins, 4 column panels of {wg['CH']} cells per lane)")
+                           f"{wg['SH']} x {wg['SW']} bins on the 256 lanes of four waves: {wg['NCH']} column chunks per row, {wg['CH']} cells per lane)")
         elif family == "staged":
             kernel_name = (f"pup::pileup_staged_kernel<{W}, false, {reg_rows}, {reg_cols}, {reg_rows // 8}, {1 if a.variant & 64 else 2}, "
                            f"{'false' if a.variant & 4 else 'true'}, false, {'false' if a.variant & (1 << 27) else 'true'}> (persistent workgroups, "

@@ -16,7 +16,7 @@ SRC = os.path.join(_CSRC, "pup_engine.hip")
 SRC_HOST = os.path.join(_CSRC, "pup_host.cpp")          # pinned memory + host array passes (no kernels)
 SRC_TU = os.path.join(_CSRC, "pup_staged_tu.hip")
 SRC_WTU = os.path.join(_CSRC, "pup_wide_tu.hip")
-WIDE_PARTS = range(7, 14)                                # cells per lane of the wide-window staged kernel (csrc/pup_wide.hpp)
+WIDE_PARTS = range(0, 9)                                 # lane shapes of the wide-window staged kernel (csrc/pup_wide.hpp: wide_shape_ch / _nch)
 N_STAGED_PARTS = 8                                       # = pup::kStagedParts (csrc/pup_staged_launch.hpp)
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "pup_hip.h")
 _KERNEL_HEADERS = [os.path.join(_CSRC, h) for h in ("pup_kernels.hpp", "pup_staged.hpp", "pup_staged_launch.hpp", "pup_wide.hpp")]

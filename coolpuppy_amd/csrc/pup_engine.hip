@@ -1462,8 +1462,8 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
         wa.timing = c->d_timing.p; c->timing_G = G;
     }
     if (ev) HIPCHK(c, hipEventRecord(ev[1], c->stream));
-    if (!pup::launch_wide(geo.CH, a, wa, G, ooe, fact, c->stream))
-        return fail(c, PUP_ENOTSUP, "pup_accumulate: wide staged kernel not built for %d cells per lane", geo.CH);
+    if (!pup::launch_wide(geo.shape, a, wa, G, ooe, fact, c->stream))
+        return fail(c, PUP_ENOTSUP, "pup_accumulate: wide staged kernel not built for lane shape %d", geo.shape);
     HIPCHK(c, hipGetLastError());
     if (ev) HIPCHK(c, hipEventRecord(ev[2], c->stream));
     const size_t W2 = (size_t)W * W, Lf = W2 + 2 * (size_t)W;

@@ -88,6 +88,9 @@ constexpr int kKeyMaxChrom = 3072;                    // chromosomes whose table
 __device__ __forceinline__ void lds_read2_b32(unsigned long long& dst, unsigned addr) {     // dwords at addr, addr + 4
     asm volatile("ds_read2_b32 %0, %1 offset0:0 offset1:1" : "=&v"(dst) : "v"(addr));
 }
+__device__ __forceinline__ void lds_read2_b32_23(unsigned long long& dst, unsigned addr) {  // dwords at addr + 8, addr + 12
+    asm volatile("ds_read2_b32 %0, %1 offset0:2 offset1:3" : "=&v"(dst) : "v"(addr));
+}
 __device__ __forceinline__ void lds_pin_u64(unsigned long long& v) { asm volatile("" : "+v"(v)); }
 // wait until at most N LDS operations of this wave are outstanding (they return in order: everything older is complete);
 // the address registers of the reads waited for stay untouched until here (see lds_wait_all in pup_kernels.hpp)

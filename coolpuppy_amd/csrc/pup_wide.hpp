@@ -48,64 +48,83 @@ struct WideArgs {
     int                   share[3];   // cumulative shares (in 1/256) of a block's windows of the first three waves of a panel
 };
 
-// geometry of a call, shared by host and device: sub-window grid and column panels for window width W
-struct WideGeom { int NGr, NGc, SH, SW, NPC, CH; };
+// geometry of a call, shared by host and device: sub-window grid and lane mapping for window width W.
+// A sub-window of sh x sw cells is dealt to the 4 x 64 lanes of the NPC = 4 waves that pile it up together as SLOTS: slot
+// s = 64 * panel + lane owns row p = s / NCH and the CH cells (p, k + NCH * i), k = s % NCH, i < CH — NCH interleaved column chunks
+// per row, as K1q deals a row to its lanes.  (Round 4 began with lane = row, wave = contiguous column panel — NCH = 4 with rows up to
+// 64: a 41-bin window kept 41 of 64 lanes busy, a 51-bin window 51.  The shapes below fill 94 % and 92 % of the lanes for those:
+// (CH 7, NCH 6) is 42 rows x 42 columns, (CH 11, NCH 5) 51 x 55, (CH 7..13, NCH 4) 64 x 28..52.)  The cost of a window in LDS
+// instructions is groups x 4 x CH: the shape and the group grid with the lowest cost win, fewer groups on a tie.
+struct WideGeom { int NGr, NGc, SH, SW, NPC, CH, NCH, shape; };
+constexpr int kWideShapes = 9;
+__host__ __device__ constexpr int wide_shape_ch(int k) { return k < 7 ? 7 + k : (k == 7 ? 11 : 7); }
+__host__ __device__ constexpr int wide_shape_nch(int k) { return k < 7 ? 4 : (k == 7 ? 5 : 6); }
 __host__ __device__ inline WideGeom wide_geometry(int W) {
-    WideGeom g;
-    g.NGr = (W + kWideMaxRows - 1) / kWideMaxRows;
-    g.SH = (W + g.NGr - 1) / g.NGr;
-    g.NGc = (W + 4 * kWideMaxCH - 1) / (4 * kWideMaxCH);
-    g.SW = (W + g.NGc - 1) / g.NGc;
-    g.NPC = 4;
-    g.CH = (g.SW + g.NPC - 1) / g.NPC;
-    return g;
+    WideGeom best{1, 1, W, W, 4, 13, 4, 6};
+    long long best_cost = -1;
+    for (int k = 0; k < kWideShapes; ++k) {
+        const int CH = wide_shape_ch(k), NCH = wide_shape_nch(k);
+        const int max_rows = (4 * 64) / NCH < kWideMaxRows ? (4 * 64) / NCH : kWideMaxRows, max_cols = CH * NCH;
+        const int NGr = (W + max_rows - 1) / max_rows, NGc = (W + max_cols - 1) / max_cols;
+        const long long cost = (long long)NGr * NGc * 4 * CH, ng = (long long)NGr * NGc;
+        if (best_cost < 0 || cost < best_cost || (cost == best_cost && ng < (long long)best.NGr * best.NGc)) {
+            best_cost = cost;
+            best.NGr = NGr; best.NGc = NGc; best.SH = (W + NGr - 1) / NGr; best.SW = (W + NGc - 1) / NGc; best.NPC = 4; best.CH = CH; best.NCH = NCH; best.shape = k;
+        }
+    }
+    return best;
 }
 
 // one step of K1w's rolling window pipeline per cell: wait for the oldest outstanding LDS read (cell I of the current window),
 // add it, and reissue the register as the destination of cell I of the next window
-template <int I, int N, int NB, bool FACT>
+template <int I, int N, int NB, bool FACT, int NCH>
 struct RollRow {
-    static __device__ __forceinline__ void go(double (&v)[N], double (&sum)[N], unsigned (&num)[N], unsigned vw, unsigned ad, unsigned adn) {
+    static __device__ __forceinline__ void go(double (&v)[N], double (&sum)[N], unsigned (&num)[N], unsigned long long vw, unsigned ad, unsigned adn) {
         lds_wait_but<NB - 1>(ad, adn);
         lds_pin1(v[I]);
         sum[I] += v[I];
-        if (!FACT) num[I] += (vw >> I) & 1u;
-        lds_read_b64<8 * I>(v[I], adn);
-        RollRow<I + 1, N, NB, FACT>::go(v, sum, num, vw, ad, adn);
+        if (!FACT) num[I] += (unsigned)(vw >> (NCH * I)) & 1u;
+        lds_read_b64<8 * NCH * I>(v[I], adn);
+        RollRow<I + 1, N, NB, FACT, NCH>::go(v, sum, num, vw, ad, adn);
     }
 };
-template <int N, int NB, bool FACT>
-struct RollRow<N, N, NB, FACT> {
-    static __device__ __forceinline__ void go(double (&)[N], double (&)[N], unsigned (&)[N], unsigned, unsigned, unsigned) {}
+template <int N, int NB, bool FACT, int NCH>
+struct RollRow<N, N, NB, FACT, NCH> {
+    static __device__ __forceinline__ void go(double (&)[N], double (&)[N], unsigned (&)[N], unsigned long long, unsigned, unsigned) {}
 };
 
-// the instantiations (cells per lane CH = 7..13, x observed-over-expected x factorised counts) live in their own translation
-// units, one per CH (pup_wide_tu.hip with -DPUP_TU_PART=CH), compiled side by side like K1q's
-constexpr int kWideMinCH = 7;
+// the instantiations (the kWideShapes lane shapes x observed-over-expected x factorised counts) live in their own translation
+// units, one per shape (pup_wide_tu.hip with -DPUP_TU_PART=shape), compiled side by side like K1q's
 #define PUP_WIDE_PART_DECL(k) bool launch_wide_part##k(const K1Args&, const WideArgs&, int G, bool ooe, bool fact, hipStream_t);
-PUP_WIDE_PART_DECL(7) PUP_WIDE_PART_DECL(8) PUP_WIDE_PART_DECL(9) PUP_WIDE_PART_DECL(10) PUP_WIDE_PART_DECL(11) PUP_WIDE_PART_DECL(12) PUP_WIDE_PART_DECL(13)
+PUP_WIDE_PART_DECL(0) PUP_WIDE_PART_DECL(1) PUP_WIDE_PART_DECL(2) PUP_WIDE_PART_DECL(3) PUP_WIDE_PART_DECL(4) PUP_WIDE_PART_DECL(5)
+PUP_WIDE_PART_DECL(6) PUP_WIDE_PART_DECL(7) PUP_WIDE_PART_DECL(8)
 #undef PUP_WIDE_PART_DECL
-inline bool launch_wide(int CH, const K1Args& a, const WideArgs& wa, int G, bool ooe, bool fact, hipStream_t s) {
-    switch (CH) {
-        case 7:  return launch_wide_part7(a, wa, G, ooe, fact, s);
-        case 8:  return launch_wide_part8(a, wa, G, ooe, fact, s);
-        case 9:  return launch_wide_part9(a, wa, G, ooe, fact, s);
-        case 10: return launch_wide_part10(a, wa, G, ooe, fact, s);
-        case 11: return launch_wide_part11(a, wa, G, ooe, fact, s);
-        case 12: return launch_wide_part12(a, wa, G, ooe, fact, s);
-        case 13: return launch_wide_part13(a, wa, G, ooe, fact, s);
+inline bool launch_wide(int shape, const K1Args& a, const WideArgs& wa, int G, bool ooe, bool fact, hipStream_t s) {
+    switch (shape) {
+        case 0: return launch_wide_part0(a, wa, G, ooe, fact, s);
+        case 1: return launch_wide_part1(a, wa, G, ooe, fact, s);
+        case 2: return launch_wide_part2(a, wa, G, ooe, fact, s);
+        case 3: return launch_wide_part3(a, wa, G, ooe, fact, s);
+        case 4: return launch_wide_part4(a, wa, G, ooe, fact, s);
+        case 5: return launch_wide_part5(a, wa, G, ooe, fact, s);
+        case 6: return launch_wide_part6(a, wa, G, ooe, fact, s);
+        case 7: return launch_wide_part7(a, wa, G, ooe, fact, s);
+        case 8: return launch_wide_part8(a, wa, G, ooe, fact, s);
         default: return false;
     }
 }
 
-template <int CH, bool OOE, bool FACT>
+template <int CH, int NCH, bool OOE, bool FACT>
 __global__ __launch_bounds__(kWave * 16, 1)
 void pileup_wide_kernel(K1Args a, WideArgs wa) {
     static_assert(CH >= 1 && CH <= kWideMaxCH, "cells per lane");
-    constexpr int RSR = 128, RSC = 128, NW = 16, LS = RSC + 1, RPW = RSR / NW, NH = 2, NRH = RPW * NH, VBW = 3, NTHR = kWave * NW;
+    static_assert(NCH >= 1 && NCH <= 8 && NCH * (CH - 1) < 64, "column chunks per row; a lane's validity bits fit one 64-bit word");
+    // row stride LS = RSC + NCH doubles: slot s reads double p * LS + k + NCH * i = s + NCH * i (mod 32 bank pairs) — the 32 lanes of
+    // a half wave hit 32 different bank pairs
+    constexpr int RSR = 128, RSC = 128, NW = 16, LS = RSC + NCH, RPW = RSR / NW, NH = 2, NRH = RPW * NH, VBW = 3, NTHR = kWave * NW;
     static_assert((size_t)(NW / 2) * CH * kWave * 12 <= (size_t)RSR * LS * 8, "merge scratch must fit the region buffer");
     __shared__ double tile[RSR * LS + 16];                          // (+16: the last panel's unowned cells may run past the last row)
-    __shared__ unsigned long long vbits[FACT ? 1 : RSR * VBW];      // bit c of row r: cell (r, c) counts in num
+    __shared__ unsigned long long vbits[FACT ? 1 : RSR * VBW + 2];  // bit c of row r: cell (r, c) counts in num (+2: the four-dword read of the last row)
     __shared__ double exp_lds[OOE ? 256 : 1];                       // expected of the region's 255 diagonals (see K1q)
     __shared__ unsigned rc_lds[FACT ? kWideRec : 1];                // masked row meets masked column (rare)
     __shared__ unsigned fact_tot[FACT ? 2 * 64 + 4 : 1];            // R[64] | C[64] | N
@@ -114,7 +133,8 @@ void pileup_wide_kernel(K1Args a, WideArgs wa) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NPC = wa.NPC, nsub = NW / NPC;
     const int panel = wave % NPC, sub = wave / NPC;
-    const int q0 = panel * CH;
+    const int slot = panel * kWave + lane;               // the lane's slot of the sub-window: row slot / NCH, column chunk slot % NCH
+    const int p_raw = slot / NCH, kk = slot - p_raw * NCH;
 
     const bool use_exp = OOE && ((a.expv != nullptr && a.nexp > 0) || a.n_exp_regions > 0);
     const int  igd     = a.ignore_diags;
@@ -128,7 +148,7 @@ void pileup_wide_kernel(K1Args a, WideArgs wa) {
     // geometry of the current sub-window group (changes with the segment)
     int grp = -1, pr0 = 0, pc0 = 0, sh = 1, sw = 1, p = 0;
     bool row_ok = false;
-    unsigned chmask = 0u;                                // bit i: the lane owns sub-window cell (p, q0 + i)
+    unsigned chmask = 0u;                                // bit i: the lane owns sub-window cell (p, kk + NCH * i)
     unsigned lane_off8 = 0u;                             // LDS byte address of the lane's first cell at corner (0, 0)
     auto set_group = [&](int g) __attribute__((always_inline)) {
         grp = g;
@@ -136,12 +156,12 @@ void pileup_wide_kernel(K1Args a, WideArgs wa) {
         pr0 = gi * wa.SH; pc0 = gj * wa.SW;
         sh = wa.WF - pr0 < wa.SH ? wa.WF - pr0 : wa.SH;
         sw = wa.WF - pc0 < wa.SW ? wa.WF - pc0 : wa.SW;
-        row_ok = lane < sh;
-        p = row_ok ? lane : sh - 1;                      // idle lanes shadow the last row, flush nothing
+        row_ok = p_raw < sh;
+        p = row_ok ? p_raw : sh - 1;                     // idle lanes shadow the last row, flush nothing
         chmask = 0u;
 #pragma unroll
-        for (int i = 0; i < CH; ++i) if (row_ok && q0 + i < sw) chmask |= 1u << i;
-        lane_off8 = (unsigned)(uintptr_t)tile + 8u * (unsigned)(p * LS + q0);
+        for (int i = 0; i < CH; ++i) if (row_ok && kk + NCH * i < sw) chmask |= 1u << i;
+        lane_off8 = (unsigned)(uintptr_t)tile + 8u * (unsigned)(p * LS + kk);
     };
 
     double   sum[CH];
@@ -307,33 +327,39 @@ void pileup_wide_kernel(K1Args a, WideArgs wa) {
     // value registers and the kernel spilled.)  Past the run's last window the pipeline reads that window once more, never added.
     auto run = [&](int offv, int drv, int dcv, int jb, int je) __attribute__((always_inline)) {
         if (jb >= je) return;
-        constexpr int NB = CH + (FACT ? 0 : 1);            // LDS operations of one window (<= 14: the counter holds 15)
+        constexpr int NB = CH + (FACT ? 0 : 2);            // LDS operations of one window (<= 15: what the counter holds)
         double v[CH];
-        unsigned long long vraw = 0ull;
+        unsigned long long vraw = 0ull, vraw2 = 0ull;
         auto addr_of = [&](int jj) __attribute__((always_inline)) -> unsigned { return lane_off8 + (unsigned)__builtin_amdgcn_readlane(offv, jj); };
-        // validity bits of the sub-window's row p from column dc + q0 on: the dword pair holding bit dc + q0
+        // validity bits of the sub-window's row p from column dc + kk on: the FOUR dwords from the one holding bit dc + kk (the lane's
+        // cells sit NCH columns apart: up to NCH * (CH - 1) + 31 < 96 bits behind the first dword's bit 0)
         auto vaddr_of = [&](int jj) __attribute__((always_inline)) -> unsigned {
             const int dr = __builtin_amdgcn_readlane(drv, jj), dc = __builtin_amdgcn_readlane(dcv, jj);
-            return vb_base + (unsigned)((dr + p) * (VBW * 8)) + 4u * ((unsigned)(dc + q0) >> 5);
+            return vb_base + (unsigned)((dr + p) * (VBW * 8)) + 4u * ((unsigned)(dc + kk) >> 5);
+        };
+        auto bits_of = [&](int jj) __attribute__((always_inline)) -> unsigned long long {
+            const int sft = (__builtin_amdgcn_readlane(dcv, jj) + kk) & 31;
+            return (vraw >> sft) | (sft ? vraw2 << (64 - sft) : 0ull);
         };
         unsigned ad = addr_of(jb), av = 0u;
-        if constexpr (!FACT) { av = vaddr_of(jb); lds_read2_b32(vraw, av); }
-        LdsReadRow<0, CH, 8>::go(v, ad);
+        if constexpr (!FACT) { av = vaddr_of(jb); lds_read2_b32(vraw, av); lds_read2_b32_23(vraw2, av); }
+        LdsReadRow<0, CH, 8 * NCH>::go(v, ad);
         for (int jj = jb; jj < je; ++jj) {
             const int nxt = jj + 1 < je ? jj + 1 : jj;
             const unsigned adn = addr_of(nxt);
-            unsigned vw = 0u, avn = av;
+            unsigned long long vw = 0ull;
+            unsigned avn = av;
             if constexpr (!FACT) {
                 avn = vaddr_of(nxt);
-                lds_wait_but<NB - 1>(ad, av); lds_pin_u64(vraw);
-                vw = (unsigned)(vraw >> ((__builtin_amdgcn_readlane(dcv, jj) + q0) & 31));
-                lds_read2_b32(vraw, avn);
+                lds_wait_but<NB - 2>(ad, av); lds_pin_u64(vraw); lds_pin_u64(vraw2);
+                vw = bits_of(jj);
+                lds_read2_b32(vraw, avn); lds_read2_b32_23(vraw2, avn);
             }
-            RollRow<0, CH, NB, FACT>::go(v, sum, num, vw, ad, adn);
+            RollRow<0, CH, NB, FACT, NCH>::go(v, sum, num, vw, ad, adn);
             ad = adn; av = avn;
         }
         lds_wait_all(ad, av, ad, av); lds_pin(v);
-        if constexpr (!FACT) lds_pin_u64(vraw);
+        if constexpr (!FACT) { lds_pin_u64(vraw); lds_pin_u64(vraw2); }
     };
     // bits [s, s + 64) of the 128-bit mask hi:lo, s in [0, 127]
     auto mask_at = [&](const unsigned long long (&m)[2], int s) __attribute__((always_inline)) -> unsigned long long {
@@ -376,7 +402,7 @@ void pileup_wide_kernel(K1Args a, WideArgs wa) {
     auto windows = [&](const Cur& g, int wf, auto&& mid) __attribute__((always_inline)) {
         int lo, hi;
         slice_of(g.n, lo, hi);
-        const bool cols_live = q0 < sw;                  // (uniform) a panel past the group's last column has nothing to pile up
+        const bool cols_live = (panel * kWave) / NCH < sh;     // (uniform) a panel whose first slot lies past the group's last row has nothing to pile up
         int t = 0;
         {
             const int drv = wf & ((1 << kWinShift) - 1), dcv = (wf >> kWinShift) & ((1 << kWinShift) - 1);
@@ -446,8 +472,8 @@ void pileup_wide_kernel(K1Args a, WideArgs wa) {
 #pragma unroll
             for (int i = 0; i < CH; ++i)
                 if ((chmask >> i) & 1u) {
-                    of[p * 64 + q0 + i] = sum[i];
-                    if (!FACT) on[p * 64 + q0 + i] = num[i];
+                    of[p * 64 + kk + NCH * i] = sum[i];
+                    if (!FACT) on[p * 64 + kk + NCH * i] = num[i];
                 }
         }
         if constexpr (FACT) {

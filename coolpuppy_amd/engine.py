@@ -302,9 +302,15 @@ class PileupEngine:
     @staticmethod
     def wide_geometry(W):
         """Sub-window grid of the wide staged kernel for window width W — wide_geometry() of csrc/pup_wide.hpp."""
-        ngr = -(-W // 64); sh = -(-W // ngr)
-        ngc = -(-W // 52); sw = -(-W // ngc)
-        return {"NGr": ngr, "NGc": ngc, "SH": sh, "SW": sw, "NPC": 4, "CH": -(-sw // 4)}
+        best = None
+        for k in range(9):                                   # the lane shapes (cells per lane, column chunks per row): wide_shape_ch / _nch
+            ch, nch = (7 + k, 4) if k < 7 else ((11, 5) if k == 7 else (7, 6))
+            max_rows, max_cols = min(256 // nch, 64), ch * nch
+            ngr, ngc = -(-W // max_rows), -(-W // max_cols)
+            cost = ngr * ngc * 4 * ch
+            if best is None or cost < best[0] or (cost == best[0] and ngr * ngc < best[1]["NGr"] * best[1]["NGc"]):
+                best = (cost, {"NGr": ngr, "NGc": ngc, "SH": -(-W // ngr), "SW": -(-W // ngc), "NPC": 4, "CH": ch, "NCH": nch, "shape": k})
+        return best[1]
 
     @staticmethod
     def block_order(r0, c0, chrom_offset, tile=None, block=None, pad=10, ooe=False, extra=False):
