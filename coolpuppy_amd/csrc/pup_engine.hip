@@ -169,7 +169,8 @@ struct pup_ctx {
     }
     // the remembered verdict belongs to (table, index, expected, tuning): whatever replaces one of them forgets it — a
     // speculative launch on a stale verdict could stage from a band table that no longer exists
-    void forget_hints() { hint_sig.clear(); hint_blocks = -1; hint_have_verdict = false; hint_sparse_calls = 0; }
+    bool no_rel_bc = false;                  // a call of this table had windows beyond the band: block columns keep the plain numbering
+    void forget_hints() { hint_sig.clear(); hint_blocks = -1; hint_have_verdict = false; hint_sparse_calls = 0; no_rel_bc = false; }
     int hint_sparse_calls = 0;               // calls answered "too sparse" from memory since the block count was last measured
     bool profiling = false;      // HIP events around the kernels
     bool count_pixels = false;   // kernels also count the pixels inside the windows (statistics; costs a little)
@@ -826,14 +827,14 @@ extern "C++" {
 template <typename KeyT>
 static void launch_key_kernel(pup_ctx* c, int BR, int BC, unsigned grid, const int* dr0, const int* dc0, long long n, int nseg2t, int H,
                               int set_pairs, const pup::ExpRegion* d_eregs, int n_eregs, int W, int sh_br, int sh_er, int sh_seg,
-                              int seg_shift, int clear_gap, int far_gap, KeyT* keys, unsigned* hi_hist = nullptr, int hi_shift = 0, int hi_bins = 0) {
+                              int seg_shift, int clear_gap, int far_gap, KeyT* keys, int rel_bc, unsigned* hi_hist = nullptr, int hi_shift = 0, int hi_bins = 0) {
     // with the binning prepass a workgroup keys one of its tiles of 8192 windows: 256 threads x 32 (measured: 68 us; 1024 threads x 8: 85 us;
     // round 3's 256 x 4 without the digit counts: 58 us)
     const int threads = 256;
     const int per_thread = hi_hist ? pup::kBinTile / 256 : 4;
 #define PUP_KEY_ARGS dr0, dc0, n, (const long long*)c->d_segend.p, nseg2t, H, set_pairs, (const pup::IdxChrom*)c->idx_chrom.p, c->n_chrom, \
         (const unsigned short*)c->bin_chrom.p, (long long)c->nbins, (const int*)c->d_brow.p, d_eregs, n_eregs, W, BR, BC, sh_br, \
-        sh_er, sh_seg, seg_shift, clear_gap, far_gap, (c->band_w > 0 && !(c->variant & 256)) ? c->band_w : 0, keys, c->d_win.p, c->d_cnt32.p, hi_hist, hi_shift, hi_bins, per_thread
+        sh_er, sh_seg, seg_shift, clear_gap, far_gap, (c->band_w > 0 && !(c->variant & 256)) ? c->band_w : 0, keys, c->d_win.p, c->d_cnt32.p, hi_hist, hi_shift, hi_bins, per_thread, rel_bc
     const size_t lds = (((size_t)nseg2t + (size_t)hi_bins + 3 * (size_t)c->n_chrom) * 4 + 15) & ~(size_t)15;      // run ends | digit counts | chromosome table
     if (BR == 108 && BC == 108)
         hipLaunchKernelGGL((pup::staged_key_kernel<KeyT, 108, 108>), dim3(grid), dim3(threads), lds, c->stream, PUP_KEY_ARGS);
@@ -874,7 +875,10 @@ static void fill_k1_args(pup_ctx* c, pup::K1Args& a, int32_t ignore_diags, uint3
 // Digit split of a key of `end_bit` bits whose lowest `slot_bits` hold the accumulator slot: false when the key is too wide
 struct BinPlan { int DL, DH; long long ntiles; };
 static bool bin_plan(int end_bit, int slot_bits, long long n_items, BinPlan& bp) {
-    int DL = std::min(std::max(std::max((end_bit + 1) / 2, end_bit - pup::kBinMaxDigit), slot_bits), pup::kBinMaxLow);
+    // high digit: 10 bits for keys of up to 20 (as many, as small buckets as the partition pass's per-wave counters take without slowing
+    // down — the bucket pass's time is its biggest bucket; measured on the 16-bit keys of the headline call: 8 bits 0.206, 9 0.183,
+    // 10 0.171, 11 0.187 ms of prepass), 11 beyond (22-bit keys of a grouped call: 0.264 against 0.346 with 10 + 12)
+    int DL = std::min(std::max(end_bit - (end_bit <= 20 ? 10 : pup::kBinMaxDigit), slot_bits), pup::kBinMaxLow);
     if (const char* e = getenv("COOLPUPPY_AMD_BIN_DH")) {        // experiments: bits of the high digit
         const int dh = std::max(0, std::min(atoi(e), std::min(end_bit, pup::kBinMaxDigit)));
         DL = std::min(std::max(end_bit - dh, slot_bits), pup::kBinMaxLow);
@@ -1017,7 +1021,16 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     std::vector<long long> htab;
     for (int t = 0; t < T; ++t) { htab.push_back(flip_from ? flip_from[t] : tile_ptr[t + 1]); htab.push_back(tile_ptr[t + 1]); }
     const int nseg2t = (int)htab.size();
-    const int bits_bc = nbits((unsigned long long)(max_len / BC + 1)), bits_br = nbits((unsigned long long)n_brows + 1);
+    // Column blocks: numbered from the chromosome's start (a chromosome's width / block side: 8 bits at 10 kb) — or, while the table has a
+    // dense band and no call has said otherwise, from the one under the block row's first bin (+ a bias of two blocks to the left): a
+    // window inside the band then needs (band + block) / block + 4 numbers, 4 bits, which brings grouped calls (tile sets: 3 slot +
+    // 3 segment bits on top of 12 row bits) within the 23 bits of the hand-written binning.  The key kernel reports a window that does
+    // not fit together with those that leave the band; the call is then redone with the plain numbering (below) and the table
+    // remembers it (no_rel_bc: a workload of far-apart windows pays the second prepass once).
+    const int rel_bias = (W + BC - 1) / BC + 1;
+    const int rel_bc = (c->band_w > 0 && !(c->variant & 256) && !extra && !c->no_rel_bc) ? rel_bias + 1 : 0;
+    const int bits_bc = rel_bc ? nbits((unsigned long long)((c->band_w + BR) / BC + 2 + rel_bias)) : nbits((unsigned long long)(max_len / BC + 1));
+    const int bits_br = nbits((unsigned long long)n_brows + 1);
     // the expected region of a window is part of its key — unless every chromosome lies inside ONE region (or none): a block
     // never leaves its chromosome, so its region follows from its origin and the key stays short (one radix pass fewer)
     bool er_in_key = n_eregs > 0;
@@ -1135,9 +1148,9 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     }
     const int n_eregs_key = er_in_key ? n_eregs : 0;
     if (k32) launch_key_kernel<unsigned>(c, BR, BC, gk4, dr0, dc0, (long long)n, nseg2t, H, set_pairs, d_eregs, n_eregs_key, W, sh_br, sh_er,
-                                         sh_seg, seg_shift, ignore_diags + W - 1, far_gap, c->d_k32.p, use_bin ? c->d_bindesc.p : nullptr, bp.DL, 1 << bp.DH);
+                                         sh_seg, seg_shift, ignore_diags + W - 1, far_gap, c->d_k32.p, rel_bc, use_bin ? c->d_bindesc.p : nullptr, bp.DL, 1 << bp.DH);
     else launch_key_kernel<unsigned long long>(c, BR, BC, gk4, dr0, dc0, (long long)n, nseg2t, H, set_pairs, d_eregs, n_eregs_key, W, sh_br,
-                                               sh_er, sh_seg, seg_shift, ignore_diags + W - 1, far_gap, c->d_keys.p);
+                                               sh_er, sh_seg, seg_shift, ignore_diags + W - 1, far_gap, c->d_keys.p, rel_bc);
     hipLaunchKernelGGL(pup::staged_publish_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned*)c->d_cnt32.p, 3,
                        (volatile unsigned*)c->d_flags, ticket);
     HIPCHK(c, hipEventRecord(c->ev_key, c->stream));
@@ -1152,7 +1165,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
                            c->n_chrom, W, W, geo.RSR, geo.RSC, 1, pup::kBlockCost, sh_br, sh_er, sh_seg, seg_shift, slot_bits, n_eregs, er_in_key ? 1 : 0, d_eregs,
                            (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G, (const unsigned*)c->d_bkeys.p,
                            slot_bits > 0 ? (const unsigned short*)c->d_low.p : (const unsigned short*)nullptr,
-                           (volatile unsigned*)(c->d_flags + 4), ticket);
+                           (volatile unsigned*)(c->d_flags + 4), ticket, rel_bc);
     } else if (k32) {
         se = rocprim::radix_sort_pairs<Radix10>(c->d_sorttmp.p, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_win.p, c->d_win2.p,
                                                 (size_t)n, 0, end_bit, c->stream);
@@ -1166,7 +1179,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
                            (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
                            c->n_chrom, W, W, geo.RSR, geo.RSC, 1, pup::kBlockCost, sh_br, sh_er, sh_seg, seg_shift, slot_bits, n_eregs, er_in_key ? 1 : 0, d_eregs,
                            (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G, (const unsigned*)nullptr, (const unsigned short*)nullptr,
-                           (volatile unsigned*)(c->d_flags + 4), ticket);
+                           (volatile unsigned*)(c->d_flags + 4), ticket, rel_bc);
     } else {
         se = rocprim::radix_sort_pairs<Radix10>(c->d_sorttmp.p, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_win.p, c->d_win2.p,
                                                 (size_t)n, 0, end_bit, c->stream);
@@ -1180,7 +1193,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
                            (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
                            c->n_chrom, W, W, geo.RSR, geo.RSC, 1, pup::kBlockCost, sh_br, sh_er, sh_seg, seg_shift, slot_bits, n_eregs, er_in_key ? 1 : 0, d_eregs,
                            (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G, (const unsigned*)nullptr, (const unsigned short*)nullptr,
-                           (volatile unsigned*)(c->d_flags + 4), ticket);
+                           (volatile unsigned*)(c->d_flags + 4), ticket, rel_bc);
     }
     HIPCHK(c, hipGetLastError());
 
@@ -1223,6 +1236,14 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     // ---- the host's part: the key kernel's verdict (an event long reached: the sort is still running) -----------------
     HIPCHK(c, hipEventSynchronize(c->ev_key));
     if (c->h_flags[3] != ticket) return fail(c, PUP_EHIP, "pup_accumulate: the key kernel's verdict did not arrive");
+    if (rel_bc && c->h_flags[2] != 0 && c->h_flags[0] == 0) {
+        // a window beyond the band (or below the diagonal): its column block did not fit the diagonal-relative field — the block order of
+        // this prepass is void.  Once more with the plain numbering; nothing of this attempt has touched the accumulators (a kernel
+        // launched on the last call's verdict wrote records nobody will own: the next prepass clears the marks).
+        c->no_rel_bc = true;
+        c->hint_have_verdict = false;
+        return staged_run(c, dr0, dc0, n, tile_ptr, flip_from, ignore_diags, mode | (cov_sep ? PUP_MODE_COV : 0u), rescale, ev);
+    }
     const bool band = c->band_w > 0 && !(c->variant & 256) && !extra && c->h_flags[2] == 0;    // every window inside the dense band
     if (c->h_flags[0] != 0) {                                              // a window the index does not cover: the per-window kernels take the call
         c->hint_have_verdict = false;
@@ -1319,7 +1340,12 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
     std::vector<long long> htab;
     for (int t = 0; t < T; ++t) { htab.push_back(flip_from ? flip_from[t] : tile_ptr[t + 1]); htab.push_back(tile_ptr[t + 1]); }
     const int nseg2t = (int)htab.size();
-    const int bits_bc = nbits((unsigned long long)(max_len / BC + 1)), bits_br = nbits((unsigned long long)n_brows + 1);
+    // column blocks are numbered from the one under the block row's first bin (+ a bias for sub-windows left of it): every window K1w
+    // serves lies inside the band, so the field is (band + block) / block + bias wide instead of a chromosome's width — 5 bits
+    // instead of 8 at 10 kb, which keeps 16-group calls (201-bin windows) within the hand-written binning's 23 bits.  A window that does
+    // not fit is counted with those that leave the band: the call goes to the per-window kernel, as it would anyway.
+    const int rel_bias = (W + BC - 1) / BC + 2, rel_bc = rel_bias + 1;
+    const int bits_bc = nbits((unsigned long long)((c->band_w + BR) / BC + 2 + rel_bias)), bits_br = nbits((unsigned long long)n_brows + 1);
     const int sh_br = bits_bc, sh_seg = sh_br + bits_br;
     const long long nseg_key = ((long long)(2 * T) >> seg_shift) * NG;
     const int end_bit = sh_seg + (nseg_key > 1 ? nbits((unsigned long long)(nseg_key - 1)) : 0);
@@ -1383,8 +1409,8 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
         (const unsigned short*)c->bin_chrom.p, (long long)c->nbins, (const int*)c->d_brow.p, W, NG, geo.NGc, geo.SH, geo.SW, BR, BC, sh_br, sh_seg, \
         seg_shift, ignore_diags + W - 1, far_gap, c->band_w
     const size_t wkey_lds = (((size_t)nseg2t + (use_bin ? ((size_t)1 << bp.DH) : 0) + 3 * (size_t)c->n_chrom) * 4 + 15) & ~(size_t)15;
-    if (k32) hipLaunchKernelGGL((pup::wide_key_kernel<unsigned>), dim3(gk4), dim3(wkey_threads), wkey_lds, c->stream, PUP_WKEY_ARGS, c->d_k32.p, c->d_win.p, c->d_cnt32.p, use_bin ? c->d_bindesc.p : (unsigned*)nullptr, bp.DL, 1 << bp.DH, wkey_per);
-    else hipLaunchKernelGGL((pup::wide_key_kernel<unsigned long long>), dim3(gk4), dim3(wkey_threads), wkey_lds, c->stream, PUP_WKEY_ARGS, c->d_keys.p, c->d_win.p, c->d_cnt32.p, (unsigned*)nullptr, 0, 0, 4);
+    if (k32) hipLaunchKernelGGL((pup::wide_key_kernel<unsigned>), dim3(gk4), dim3(wkey_threads), wkey_lds, c->stream, PUP_WKEY_ARGS, c->d_k32.p, c->d_win.p, c->d_cnt32.p, use_bin ? c->d_bindesc.p : (unsigned*)nullptr, bp.DL, 1 << bp.DH, wkey_per, rel_bc);
+    else hipLaunchKernelGGL((pup::wide_key_kernel<unsigned long long>), dim3(gk4), dim3(wkey_threads), wkey_lds, c->stream, PUP_WKEY_ARGS, c->d_keys.p, c->d_win.p, c->d_cnt32.p, (unsigned*)nullptr, 0, 0, 4, rel_bc);
 #undef PUP_WKEY_ARGS
     hipLaunchKernelGGL(pup::staged_publish_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned*)c->d_cnt32.p, 3,
                        (volatile unsigned*)c->d_flags, ticket);
@@ -1401,7 +1427,7 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
                            c->n_chrom, geo.SH, geo.SW, RS, RS, NG, wide_cost, sh_br, sh_seg, sh_seg, seg_shift, 0, n_eregs, 0, d_eregs,
                            (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G, (const unsigned*)c->d_bkeys.p,
                            (const unsigned short*)nullptr,
-                           (volatile unsigned*)(c->d_flags + 4), ticket);
+                           (volatile unsigned*)(c->d_flags + 4), ticket, rel_bc);
     } else if (k32) {
         se = rocprim::radix_sort_pairs<Radix10>(c->d_sorttmp.p, tmp_bytes, c->d_k32.p, c->d_k32b.p, c->d_win.p, c->d_win2.p,
                                                 (size_t)n_items, 0, end_bit, c->stream);
@@ -1415,7 +1441,7 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
                            (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
                            c->n_chrom, geo.SH, geo.SW, RS, RS, NG, wide_cost, sh_br, sh_seg, sh_seg, seg_shift, 0, n_eregs, 0, d_eregs,
                            (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G, (const unsigned*)nullptr, (const unsigned short*)nullptr,
-                           (volatile unsigned*)(c->d_flags + 4), ticket);
+                           (volatile unsigned*)(c->d_flags + 4), ticket, rel_bc);
     } else {
         se = rocprim::radix_sort_pairs<Radix10>(c->d_sorttmp.p, tmp_bytes, c->d_keys.p, c->d_keys2.p, c->d_win.p, c->d_win2.p,
                                                 (size_t)n_items, 0, end_bit, c->stream);
@@ -1429,7 +1455,7 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
                            (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
                            c->n_chrom, geo.SH, geo.SW, RS, RS, NG, wide_cost, sh_br, sh_seg, sh_seg, seg_shift, 0, n_eregs, 0, d_eregs,
                            (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G, (const unsigned*)nullptr, (const unsigned short*)nullptr,
-                           (volatile unsigned*)(c->d_flags + 4), ticket);
+                           (volatile unsigned*)(c->d_flags + 4), ticket, rel_bc);
     }
     HIPCHK(c, hipGetLastError());
 

@@ -943,7 +943,8 @@ __global__ __launch_bounds__(256) void staged_key_kernel(const int* __restrict__
                                                          unsigned* __restrict__ counters /* [0] ineligible, [1] windows a diagonal mask
                                                                                             reaches, [2] windows leaving the dense band */,
                                                          unsigned* __restrict__ hi_hist /* nullable: tilehist[workgroup][hi_bins], counts of key >> hi_shift (pup_bin.hpp) */,
-                                                         int hi_shift, int hi_bins, int per_thread /* windows per thread: 4, or 32 = a binning tile per workgroup */) {
+                                                         int hi_shift, int hi_bins, int per_thread /* windows per thread: 4, or 32 = a binning tile per workgroup */,
+                                                         int rel_bc /* > 0: the key's column block is counted from the block row's own diagonal, biased by rel_bc - 1 (see staged_run) */) {
     // Small tables go to LDS once per workgroup (the chromosome table in chunks of the call's dynamic LDS: 12 bytes per chromosome,
     // the launch sizes it — see launch_key_kernel), so per window the chain of dependent global loads is r0 -> bin_chrom only.
     // What the kernel costs is VALU issue (counters, round 4: 156 vector instructions per 64 windows, 4 clocks each on a SIMD, made
@@ -1018,6 +1019,7 @@ __global__ __launch_bounds__(256) void staged_key_kernel(const int* __restrict__
         if (!one_run) si = seg_of(run_of(i));
         const unsigned seg = si.seg, slot = si.slot, kslot = si.kslot, kbits = si.kbits;
         bool ok = r >= 0 && c >= 0 && r <= nb_last;
+        bool rel_over = false;
         unsigned br = 0, bc = 0, er = 0;
         unsigned inside = 0u;                                // the window's corner inside its block: all the staged kernel needs
         if (ok) {
@@ -1029,6 +1031,14 @@ __global__ __launch_bounds__(256) void staged_key_kernel(const int* __restrict__
                 const int qr = SIDE_R ? (r - cs) / kR : (r - cs) / BR, qc = SIDE_C ? (c - cs) / kC : (c - cs) / BC;
                 br = (unsigned)(s_bb[ca] + qr);             // increasing over the genome, compact
                 bc = (unsigned)qc;
+                if (rel_bc) {
+                    // column blocks counted from the one under the block row's first bin: a window inside the band is at most
+                    // (band + block side) / block side of them away — 4 bits instead of the 8 a chromosome's width takes; a window
+                    // whose number does not fit the field (beyond the band, or below the diagonal) is reported with the windows
+                    // that leave the band: the host then redoes the call with the plain numbering
+                    const int rel = qc - (SIDE_R ? (qr * kR) / kC : (qr * BR) / BC) + (rel_bc - 1);      // (rel_bc - 1 = blocks a window may lie LEFT of that one)
+                    if ((unsigned)rel >= (1u << sh_br)) { rel_over = true; bc = 0u; } else bc = (unsigned)rel;
+                }
                 inside = (unsigned)((r - cs) - qr * (SIDE_R ? SIDE_R : BR)) | ((unsigned)((c - cs) - qc * (SIDE_C ? SIDE_C : BC)) << kWinShift);
             }
         }
@@ -1040,7 +1050,7 @@ __global__ __launch_bounds__(256) void staged_key_kernel(const int* __restrict__
         // (counted per thread, summed per wave behind the loop: one atomic per wave and counter — a call of near-diagonal windows
         // would serialise on the counter)
         near_c += (live && (c - r < clear_gap || (c + W - 1) - r >= far_gap)) ? 1u : 0u;
-        far_c += (live && band_w > 0 && (c + W - 1) - r >= band_w) ? 1u : 0u;
+        far_c += (live && ((band_w > 0 && (c + W - 1) - r >= band_w) || rel_over)) ? 1u : 0u;
         unsigned key_hi = 0u; bool counted = false;
         if (live) {
             if constexpr (sizeof(KeyT) == 4) {
@@ -1163,7 +1173,7 @@ __global__ __launch_bounds__(256) void staged_table_kernel(const unsigned* __res
                                                            const unsigned* __restrict__ block_keys /* nullable: key >> slot_bits of block b (pup_bin.hpp) */,
                                                            const unsigned short* __restrict__ sorted_low /* with block_keys and slot_bits > 0: low digits in block order */,
                                                            volatile unsigned* host_flags /* nullable: the block count goes there under `ticket` (was a launch of its own) */,
-                                                           unsigned ticket) {
+                                                           unsigned ticket, int rel_bc /* > 0: the key's column block is relative to the block row's diagonal, biased by rel_bc - 1 */) {
     const long long nr = (long long)n_runs[0];
     if (host_flags && blockIdx.x == 0 && threadIdx.x == 0) {
         // leave the block count where the NEXT call with this signature finds it without waiting
@@ -1179,11 +1189,12 @@ __global__ __launch_bounds__(256) void staged_table_kernel(const unsigned* __res
         const unsigned long long key = block_keys ? (unsigned long long)block_keys[b] : (unsigned long long)sorted_keys[s] >> slot_bits;
         StagedBlock be;
         const int br = (int)((key >> sh_br) & ((1ull << (sh_er - sh_br)) - 1ull));
-        const int bc = (int)(key & ((1ull << sh_br) - 1ull));
+        int bc = (int)(key & ((1ull << sh_br) - 1ull));
         int lo = 0, hi = n_chrom;                              // last chromosome whose first block row is <= br
         while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (brow_base[m] <= br) lo = m; else hi = m; }
         const IdxChrom ch = chroms[lo];
         const int cs = ch.start;
+        if (rel_bc) bc += ((br - brow_base[lo]) * BR) / BC - (rel_bc - 1);
         be.R = cs + (br - brow_base[lo]) * BR;
         be.C = cs + bc * BC;
         be.start = (int)s; be.count = (int)(e - (long long)s);

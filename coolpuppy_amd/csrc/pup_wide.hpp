@@ -54,7 +54,9 @@ struct WideArgs {
 // per row, as K1q deals a row to its lanes.  (Round 4 began with lane = row, wave = contiguous column panel — NCH = 4 with rows up to
 // 64: a 41-bin window kept 41 of 64 lanes busy, a 51-bin window 51.  The shapes below fill 94 % and 92 % of the lanes for those:
 // (CH 7, NCH 6) is 42 rows x 42 columns, (CH 11, NCH 5) 51 x 55, (CH 7..13, NCH 4) 64 x 28..52.)  The cost of a window in LDS
-// instructions is groups x 4 x CH: the shape and the group grid with the lowest cost win, fewer groups on a tie.
+// instructions is groups x 4 x CH — but what a (window, group) item costs beside its cells (its share of the prepass and of the
+// staged blocks) weighs like ~100 of them: the FEWEST GROUPS win, the cheapest shape among those.  (201-bin windows as 5 x 5 groups
+// of 41 x 41 instead of 4 x 4 of 51 x 51 — 700 against 704 instructions — took 29 ms instead of 22.)
 struct WideGeom { int NGr, NGc, SH, SW, NPC, CH, NCH, shape; };
 constexpr int kWideShapes = 9;
 __host__ __device__ constexpr int wide_shape_ch(int k) { return k < 7 ? 7 + k : (k == 7 ? 11 : 7); }
@@ -67,7 +69,8 @@ __host__ __device__ inline WideGeom wide_geometry(int W) {
         const int max_rows = (4 * 64) / NCH < kWideMaxRows ? (4 * 64) / NCH : kWideMaxRows, max_cols = CH * NCH;
         const int NGr = (W + max_rows - 1) / max_rows, NGc = (W + max_cols - 1) / max_cols;
         const long long cost = (long long)NGr * NGc * 4 * CH, ng = (long long)NGr * NGc;
-        if (best_cost < 0 || cost < best_cost || (cost == best_cost && ng < (long long)best.NGr * best.NGc)) {
+        const long long best_ng = (long long)best.NGr * best.NGc;
+        if (best_cost < 0 || ng < best_ng || (ng == best_ng && cost < best_cost)) {
             best_cost = cost;
             best.NGr = NGr; best.NGc = NGc; best.SH = (W + NGr - 1) / NGr; best.SW = (W + NGc - 1) / NGc; best.NPC = 4; best.CH = CH; best.NCH = NCH; best.shape = k;
         }
@@ -561,7 +564,7 @@ __global__ __launch_bounds__(256) void wide_key_kernel(const int* __restrict__ r
                                                        KeyT* __restrict__ keys, unsigned short* __restrict__ vals,
                                                        unsigned* __restrict__ counters,
                                                        unsigned* __restrict__ hi_hist /* nullable: tilehist[workgroup][hi_bins] (pup_bin.hpp) */,
-                                                       int hi_shift, int hi_bins, int per_thread) {
+                                                       int hi_shift, int hi_bins, int per_thread, int rel_bc /* see staged_key_kernel */) {
     // (32-bit index arithmetic — n_items < 2^31: wide_run —, tables in dynamic LDS, loads of a batch first: see staged_key_kernel)
     const int kPer = per_thread;
     extern __shared__ long long s_dyn[];
@@ -619,6 +622,7 @@ __global__ __launch_bounds__(256) void wide_key_kernel(const int* __restrict__ r
         const int lo = one_run ? lo_a : run_of(i);
         const unsigned seg = (unsigned)(lo >> seg_shift) * (unsigned)NG + (unsigned)grp;
         bool ok = r >= 0 && c >= 0 && r <= nb_last;
+        bool rel_over = false;
         unsigned br = 0, bc = 0;
         unsigned inside = 0u;
         if (ok) {
@@ -631,13 +635,17 @@ __global__ __launch_bounds__(256) void wide_key_kernel(const int* __restrict__ r
                 const int qr = rs / BR, qc = cc / BC;
                 br = (unsigned)(s_bb[ca] + qr);
                 bc = (unsigned)qc;
+                if (rel_bc) {                                // (a window whose number does not fit leaves the band: the whole call goes to K1b)
+                    const int rel = qc - (qr * BR) / BC + (rel_bc - 1);
+                    if ((unsigned)rel >= (1u << sh_br)) { rel_over = true; bc = 0u; } else bc = (unsigned)rel;
+                }
                 inside = (unsigned)(rs - qr * BR) | ((unsigned)(cc - qc * BC) << kWinShift);
             }
         }
         const bool first = live && grp == 0;
         if (first && !ok) ++bad;
         near_c += (first && (c - r < clear_gap || (c + W - 1) - r >= far_gap)) ? 1u : 0u;
-        far_c += (first && (c + W - 1) - r >= band_w) ? 1u : 0u;
+        far_c += ((first && (c + W - 1) - r >= band_w) || (live && rel_over)) ? 1u : 0u;
         unsigned key_hi = 0u; bool counted = false;
         if (live) {
             if constexpr (sizeof(KeyT) == 4) {

@@ -308,7 +308,8 @@ class PileupEngine:
             max_rows, max_cols = min(256 // nch, 64), ch * nch
             ngr, ngc = -(-W // max_rows), -(-W // max_cols)
             cost = ngr * ngc * 4 * ch
-            if best is None or cost < best[0] or (cost == best[0] and ngr * ngc < best[1]["NGr"] * best[1]["NGc"]):
+            ng_best = None if best is None else best[1]["NGr"] * best[1]["NGc"]
+            if best is None or ngr * ngc < ng_best or (ngr * ngc == ng_best and cost < best[0]):      # fewest groups, then fewest LDS instructions
                 best = (cost, {"NGr": ngr, "NGc": ngc, "SH": -(-W // ngr), "SW": -(-W // ngc), "NPC": 4, "CH": ch, "NCH": nch, "shape": k})
         return best[1]
 

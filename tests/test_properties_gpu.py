@@ -405,6 +405,46 @@ def test_staged_kernel_launched_on_the_previous_verdict(hip_lib):
     eng.close()
 
 
+def test_block_columns_renumbered_when_a_window_leaves_the_band(hip_lib):
+    """Block columns are numbered from the block row's own diagonal while every window lies inside the dense band (fewer key bits:
+    grouped calls stay within the hand-written binning).  A FIRST call on a fresh engine with windows beyond the band — and windows
+    below the diagonal — makes the engine redo its prepass with the plain numbering; the engine remembers that for the table, a new
+    index forgets it.  Every result against the per-window kernels; grouped calls (eight tiles: tile sets) included."""
+    import synth
+    from coolpuppy_amd.engine import PileupEngine
+    clr = synth.make_cooler({"chrA": 40_000_000, "chrB": 10_000_000}, lam=50, seed=43)
+    pad, W = 10, 21
+    rng = np.random.default_rng(12)
+    lo, hi = clr.extent("chrA")
+    n = 40_000
+    r0 = rng.integers(lo + 200, hi - W - 1600, n).astype(np.int32)
+    inside = (r0 + rng.integers(W + 2, 900, n)).astype(np.int32)
+    beyond = inside.copy(); beyond[::53] = r0[::53] + 1300                              # beyond the 1024-column band
+    below = inside.copy(); below[::41] = r0[::41] - 150                                 # well below the diagonal
+    for T in (2, 8):
+        tile = np.sort(rng.integers(0, T, n)).astype(np.int64)
+        tile_ptr = np.concatenate([[0], np.cumsum(np.bincount(tile, minlength=T))]).astype(np.int64)
+        eng = PileupEngine(0)
+        eng.load_pixels(*clr.pixel_table())
+        eng.build_index(clr.chrom_offset)
+        eng.load_bins(clr.bins()["weight"][:].values, None)
+        for order in (("beyond", "inside", "below"), ("inside", "below", "inside", "beyond", "inside")):
+            eng.build_index(clr.chrom_offset)                 # (forgets what earlier calls taught the engine about this table)
+            for name in order:
+                c0 = {"inside": inside, "beyond": beyond, "below": below}[name]
+                res = {}
+                for variant in (16, 8):
+                    eng.set_tuning(0, variant)
+                    eng.reset(T, pad)
+                    eng.accumulate(r0, c0, tile_ptr, ignore_diags=2)
+                    res[variant] = (eng.fetch(), eng.stats()["staged_regions"], eng.last_kernel())
+                assert res[8][1] > 0 and res[8][2] == "staged", (T, name, res[8][1:])
+                for k in ("n", "num"):
+                    np.testing.assert_array_equal(res[8][0][k], res[16][0][k], err_msg=f"{T} {name} {k}")
+                np.testing.assert_allclose(res[8][0]["sum"], res[16][0]["sum"], rtol=1e-11, atol=0, equal_nan=True, err_msg=f"{T} {name}")
+        eng.close()
+
+
 def test_staged_kernel_with_an_empty_tile_of_a_pair(hip_lib):
     """A tile pair whose first or second tile has no window at all (a group without controls in this region, or the other way
     round): its team has no wave, its record stays invalid, the partner gets every wave."""
