@@ -4,7 +4,7 @@
 set -u
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"; TAG="${1:-r04_v2}"; OUT="$REPO/gpurun_out/prof_out"
 mkdir -p "$OUT"; cd "$REPO"
-timeout 900 python -m pytest tests -q -m gpu 2>&1 | tail -4 > "$OUT/${TAG}_gputests.txt"
+timeout 1200 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3 > "$OUT/${TAG}_gputests.txt"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 >> "$OUT/${TAG}_gputests.txt"
 timeout 1500 bash tools/profile_round.sh "$TAG" > /dev/null 2>&1
 timeout 400 python bench.py > "$OUT/r04_bench.json" 2> "$OUT/r04_bench.err"
