@@ -782,6 +782,7 @@ int pup_set_expected_table(pup_ctx* c, const int32_t* start, const int32_t* end,
     return PUP_OK;
 }
 
+static hipError_t clear_async(pup_ctx* c, void* p, size_t bytes);      // (below: small clears by a plain kernel)
 int pup_reset(pup_ctx* c, int32_t n_tiles, int32_t pad) {
     if (!c) return PUP_EINVAL;
     if (n_tiles <= 0 || pad < 0) return fail(c, PUP_EINVAL, "pup_reset: n_tiles=%d pad=%d", n_tiles, pad);
@@ -795,7 +796,7 @@ int pup_reset(pup_ctx* c, int32_t n_tiles, int32_t pad) {
     if (nf + ni > c->acc_f64.cap) HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, c->acc_f64.reserve(nf + ni));             // one allocation, one memset: f64 [nf] | i64 [ni]
     c->acc_i64.p = reinterpret_cast<long long*>(c->acc_f64.p + nf);
-    HIPCHK(c, hipMemsetAsync(c->acc_f64.p, 0, (nf + ni) * sizeof(double), c->stream));
+    HIPCHK(c, clear_async(c, c->acc_f64.p, (nf + ni) * sizeof(double)));
     c->T = n_tiles; c->pad = pad; c->W = W;
     return PUP_OK;
 }
@@ -870,6 +871,15 @@ static void fill_k1_args(pup_ctx* c, pup::K1Args& a, int32_t ignore_diags, uint3
 }
 
 
+
+// clear `bytes` (a multiple of 4) at p on the engine's stream: small ranges by a plain kernel, large ones by the runtime's memset
+static hipError_t clear_async(pup_ctx* c, void* p, size_t bytes) {
+    if (bytes == 0) return hipSuccess;
+    if (bytes > (1u << 20) || (bytes & 3u) || (reinterpret_cast<uintptr_t>(p) & 3u)) return hipMemsetAsync(p, 0, bytes, c->stream);
+    const long long nw = (long long)(bytes / 4);
+    hipLaunchKernelGGL(pup::zero_words_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, c->stream, reinterpret_cast<unsigned*>(p), nw);
+    return hipGetLastError();
+}
 
 // ---- the hand-written block binning of the staged kernels' prepass (pup_bin.hpp) -------------------------------------------
 // Digit split of a key of `end_bit` bits whose lowest `slot_bits` hold the accumulator slot: false when the key is too wide
@@ -955,6 +965,8 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     c->last_stagings = 0; c->last_staged = false;
     const bool force = (c->variant & 8) != 0, forbid = (c->variant & 16) != 0;
     const bool use_idx_t = c->have_idx && !(c->variant & 1);
+    if (c->n_chrom > pup::kKeyMaxChrom && !forbid && !rescale && ignore_diags >= 0 && n >= c->tiled_min)
+        c->off_staged(8u, "the table has more chromosomes / scaffolds than the staged kernels' key pass keeps in LDS (3072)", (long long)n);
     if (forbid || rescale || (mode & (PUP_MODE_EXPECTED | PUP_MODE_TRANSPOSE)) || (c->variant & 2) || !use_idx_t ||
         ignore_diags < 0 || !tiled_supported(W) || n >= 0x7fff0000LL || c->n_chrom > pup::kKeyMaxChrom || !(force || n >= ((mode & PUP_MODE_OOE) ? c->tiled_min_ooe : c->tiled_min)) ||
         2 * T > pup::kMaxSegCount || T > pup::kMaxStagedTiles || !c->bin_chrom.p || !c->h_flags || !c->ev_key ||
@@ -1126,7 +1138,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     // ---- prepass, all on the stream -------------------------------------------------------------------------------------
     if (ev) HIPCHK(c, hipEventRecord(ev[0], c->stream));
     if (use_bin) { const int brc = bin_prepare(c, bp, (long long)n, slot_bits > 0); if (brc != PUP_OK) return brc; }
-    HIPCHK(c, hipMemsetAsync(c->d_cnt32.p, 0, (ncnt + (size_t)n_spans + (nrec + 1) / 2) * sizeof(unsigned), c->stream));
+    HIPCHK(c, clear_async(c, c->d_cnt32.p, (ncnt + (size_t)n_spans + (nrec + 1) / 2) * sizeof(unsigned)));
     unsigned short* const d_recvalid = reinterpret_cast<unsigned short*>(c->d_cnt32.p + ncnt + (size_t)n_spans);
     const unsigned gk4 = use_bin ? (unsigned)bp.ntiles : (unsigned)((n + 1023) / 1024);      // key kernel: four windows per thread, or a binning tile per workgroup
     const pup::ExpRegion* d_eregs = n_eregs > 0 ? c->exp_regions.p : nullptr;
@@ -1386,8 +1398,8 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
 
     // ---- prepass, all on the stream -------------------------------------------------------------------------------------
     if (ev) HIPCHK(c, hipEventRecord(ev[0], c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_cnt32.p, 0, (ncnt + (size_t)n_spans) * sizeof(unsigned), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->wrec_seg.p, 0, (size_t)nrec * sizeof(unsigned), c->stream));
+    HIPCHK(c, clear_async(c, c->d_cnt32.p, (ncnt + (size_t)n_spans) * sizeof(unsigned)));
+    HIPCHK(c, clear_async(c, c->wrec_seg.p, (size_t)nrec * sizeof(unsigned)));
     if (use_bin) { const int brc = bin_prepare(c, bp, n_items, false); if (brc != PUP_OK) return brc; }
     const unsigned ticket = ++c->ticket;
     const bool ooe_vec = ooe && !c->have_exp_pair && (c->nexp > 1 || c->n_exp_regions > 0);

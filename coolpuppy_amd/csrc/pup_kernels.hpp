@@ -1831,6 +1831,13 @@ PUP_KERNEL void gather_int_kernel(const int* __restrict__ src, const long long* 
     if (i < n) out[i] = src[pos[i]];
 }
 
+// small clears on the hot path (counters of a call, the accumulators of a reset: 10-20 KB): the runtime's fill kernel takes ~7 us per
+// call for these, a plain kernel ~2
+PUP_KERNEL __launch_bounds__(256) void zero_words_kernel(unsigned* __restrict__ p, long long n_words) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_words) p[i] = 0u;
+}
+
 // n[t] += dn[t]
 PUP_KERNEL void add_counts_kernel(long long* n, const long long* dn, int T) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
