@@ -131,6 +131,34 @@ PUP_EXPORT int pup_host_take_rows(int32_t ncols, const void* const* src, void* c
     return bad.load() ? PUP_EINVAL : PUP_OK;
 }
 
+// Factorisation of an array of POINTERS by identity: codes[i] = number (in order of first appearance) of the distinct pointer
+// values, first[j] = index of the first occurrence of value j.  The chromosome columns of a feature frame are object arrays whose
+// million entries point at a few dozen string objects (pandas' readers box equal strings once; so does numpy's fancy indexing of
+// a name table): hashing the pointers costs ~3 ns each, hashing the strings through pandas' object table 17 ms per million.  The
+// caller merges distinct objects that compare equal (it factorises the `n_uniq` representatives themselves).  Returns n_uniq, or
+// -1 when there are more than max_uniq distinct pointers (the caller then takes the general way), -2 for bad arguments.
+PUP_EXPORT int64_t pup_host_factorize_ptr(const uintptr_t* ptrs, int64_t n, int32_t* codes, int64_t* first, int64_t max_uniq) {
+    if (n < 0 || max_uniq < 1 || (n > 0 && (!ptrs || !codes || !first))) return -2;
+    size_t cap = 64;
+    while (cap < (size_t)max_uniq * 4) cap <<= 1;
+    std::vector<uintptr_t> keys(cap, 0);
+    std::vector<int32_t> vals(cap, -1);
+    int64_t nu = 0;
+    uintptr_t last = 0; int32_t last_code = -1;                       // (runs of one value: the usual case after a sort by chromosome)
+    for (int64_t i = 0; i < n; ++i) {
+        const uintptr_t p = ptrs[i];
+        if (last_code >= 0 && p == last) { codes[i] = last_code; continue; }
+        size_t h = (size_t)((p >> 4) * 0x9E3779B97F4A7C15ull) & (cap - 1);
+        while (vals[h] >= 0 && keys[h] != p) h = (h + 1) & (cap - 1);
+        if (vals[h] < 0) {
+            if (nu >= max_uniq) return -1;
+            keys[h] = p; vals[h] = (int32_t)nu; first[nu] = i; ++nu;
+        }
+        codes[i] = last_code = vals[h]; last = p;
+    }
+    return nu;
+}
+
 // Stable argsort of n keys of `bits` significant bits: order[i] = index of the i-th smallest key, equal keys in index order
 // (numpy's argsort(kind="stable")) — a least-significant-digit radix sort, 11 bits per pass, rows shared out to the workers
 // (per-worker digit counts, one prefix over digits x workers, a stable scatter).  CoordCreator sorts 10^6 features by one packed

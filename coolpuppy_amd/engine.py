@@ -486,6 +486,26 @@ def legacy_randint(low, high, m, scale=1, offset=0, discard=False, dtype=np.int6
     return out
 
 
+def factorize_objects(a):
+    """pd.factorize(a) (codes int64 with -1 for missing values, uniques in order of first appearance) for a 1-D object array whose
+    entries point at few distinct objects: the pointers are factorised by identity in the library (pup_host_factorize_ptr), pandas
+    only sees one representative per distinct object.  Arrays with more than 65 536 distinct objects, short or non-object arrays go
+    to pandas as they are."""
+    import pandas as pd
+    a = np.asarray(a)
+    n = a.shape[0]
+    if a.dtype != object or a.ndim != 1 or n < 50_000 or not a.flags.c_contiguous:
+        return pd.factorize(a)
+    codes32 = np.empty(n, np.int32)
+    first = np.empty(65_536, np.int64)
+    nu = _ffi.lib().pup_host_factorize_ptr(a.ctypes.data, n, _ptr(codes32), _ptr(first), first.shape[0])
+    if nu < 0:
+        return pd.factorize(a)
+    reps = a[first[:nu]]
+    rcodes, uniq = pd.factorize(reps)                           # distinct objects that are equal strings share a code; missing: -1
+    return rcodes.astype(np.int64)[codes32], uniq
+
+
 def stable_argsort(keys, bits):
     """np.argsort(keys, kind="stable") for non-negative integer keys below 2**bits, by the library's multi-threaded radix sort."""
     keys = np.ascontiguousarray(keys).view(np.uint64) if np.asarray(keys).dtype.itemsize == 8 else np.ascontiguousarray(keys, np.uint64)

@@ -34,6 +34,7 @@
  *                                                                      coolpuppy/coolpup.py:420-436
  *   pup_host_windows                  <- CoordCreator._control_regions (shifted control copies) + the bounds test of
  *                                        _stream_snips, as one host pass  coolpuppy/coolpup.py:387-453, 1105-1114
+ *   pup_host_factorize_ptr            <- the same sort's chromosome codes (object columns factorised by identity)
  *   pup_host_argsort                  <- the same sort's order (one packed key per row)
  *   pup_host_take_rows                <- the sort of the feature frame in CoordCreator._binnify  coolpuppy/coolpup.py:489-527
  *   pup_host_group_tiles              <- the per-group dicts of accumulate_stream as a grouping of windows by tile
@@ -351,6 +352,14 @@ int pup_host_mt_randint(uint32_t* key, int32_t* pos, int64_t low, int64_t high, 
  */
 int pup_host_take_rows(int32_t ncols, const void* const* src, void* const* dst, const int32_t* esize, const int64_t* order,
                        int64_t n, int64_t n_src);
+
+/*
+ * pup_host_factorize_ptr: codes of n pointer values by identity, in order of first appearance (first[j] = index of the first
+ * occurrence of value j) — the chromosome columns of the feature frame CoordCreator sorts (coolpuppy/coolpup.py:489-527) are object
+ * arrays pointing at a few dozen string objects.  Returns the number of distinct pointers, -1 when there are more than max_uniq
+ * (nothing usable in the outputs), -2 for bad arguments.
+ */
+int64_t pup_host_factorize_ptr(const uintptr_t* ptrs, int64_t n, int32_t* codes, int64_t* first, int64_t max_uniq);
 
 /*
  * pup_host_argsort: order[i] = index of the i-th smallest of n keys of `bits` significant bits, equal keys in index order —

@@ -204,6 +204,36 @@ def test_draw_ahead_thread_issues_the_serial_draws():
         assert now[2] == end[2] and np.array_equal(now[1], end[1])
 
 
+def test_coordcreator_leaves_the_callers_frame_alone_and_factorises_by_identity():
+    """CoordCreator works on a shallow copy of the feature frame: the caller's frame keeps its columns, dtypes and values whatever
+    the options.  The chromosome columns are factorised by object identity in the library: same codes and uniques as pandas,
+    missing values and equal-but-distinct string objects included."""
+    import pandas as pd
+    import synth
+    from coolpuppy_amd import coolpup, engine as E
+    clr = synth.make_cooler({"chr1": 30_000_000, "chr2": 20_000_000, "chrX": 9_000_000}, lam=5, seed=2)
+    feats = synth.random_cis_pairs(clr, 80_000, seed=3, strands=True)
+    feats = feats.sample(frac=1.0, random_state=1).reset_index(drop=True)          # unsorted: the sort permutes a new frame
+    for kw in (dict(nshifts=3, seed=1), dict(nshifts=0, subset=1000, seed=2), dict(nshifts=2, mindist=0, maxdist=3_000_000, seed=3)):
+        before = feats.copy()
+        arrays = {c: feats[c].to_numpy() for c in feats.columns}
+        coolpup.CoordCreator(feats, clr.binsize, features_format="bedpe", flank=50_000, **kw)
+        assert list(feats.columns) == list(before.columns)
+        pd.testing.assert_frame_equal(feats, before)
+        for c in feats.columns:
+            assert feats[c].to_numpy() is arrays[c] or np.array_equal(feats[c].to_numpy(), arrays[c])
+    names = np.array([f"chr{k}" for k in range(23)] + [None, float("nan")], dtype=object)
+    a = names[np.random.default_rng(0).integers(0, 25, 120_000)]
+    a[5] = "chr" + "1"                                       # a distinct object equal to an existing string
+    c1, u1 = E.factorize_objects(a)
+    c2, u2 = pd.factorize(a)
+    assert np.array_equal(c1, c2) and list(u1) == list(u2) and (c1 < 0).any()
+    many = np.array([f"s{k % 90_000}" for k in range(100_000)], dtype=object)       # too many distinct objects: pandas takes it
+    c1, u1 = E.factorize_objects(many)
+    c2, u2 = pd.factorize(many)
+    assert np.array_equal(c1, c2) and list(u1) == list(u2)
+
+
 def test_library_argsort_equals_numpy_stable_argsort():
     from coolpuppy_amd import engine as E
     rng = np.random.default_rng(5)
