@@ -783,6 +783,13 @@ int pup_set_expected_table(pup_ctx* c, const int32_t* start, const int32_t* end,
 }
 
 static hipError_t clear_async(pup_ctx* c, void* p, size_t bytes);      // (below: small clears by a plain kernel)
+// zoom weights per output row / column the rescaling kernel can keep in LDS beside its S x S tile (0: per-sample zoom)
+static int rescale_sep_k(const pup_ctx* c, size_t tile_lds, int S) {
+    if ((c->variant & 2048) || S <= 0) return 0;
+    const long long room = (long long)c->max_lds - (long long)tile_lds - 8 - 2LL * S * (long long)sizeof(int);
+    const long long k = room / (2LL * S * (long long)sizeof(double));
+    return k < 3 ? 0 : (int)std::min<long long>(k, pup::kRescaleSepK);
+}
 int pup_reset(pup_ctx* c, int32_t n_tiles, int32_t pad) {
     if (!c) return PUP_EINVAL;
     if (n_tiles <= 0 || pad < 0) return fail(c, PUP_EINVAL, "pup_reset: n_tiles=%d pad=%d", n_tiles, pad);
@@ -1583,8 +1590,11 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     // rescaled windows are heavy (10^5 input cells each) and their S^2 output tile lives in LDS: as many workgroups per CU
     // as that allows, ~4 rounds of them, 1024 threads each when only one or two fit (latency hiding comes from waves)
     const size_t rs_tile = (size_t)c->W * c->W * 12 + 16 * (size_t)c->W;
-    const int rs_wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(rs_tile, 1)));
-    const int rs_threads = rs_wg_per_cu <= 2 ? 1024 : 512;
+    // (the kernel needs its 128 registers: 16 waves per CU whatever the tile size — one workgroup of 1024 threads per CU; with
+    // 512-thread workgroups for small tiles a 51 x 51 output took 15.8 ms where 99 x 99 took 10)
+    const int rs_wg_per_cu = 1;
+    const int rs_threads = 1024;
+    (void)rs_tile;
 
     // ---- snippets to device ----------------------------------------------------------------------
     const int *dr0, *dc0;
@@ -1691,7 +1701,10 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     auto add_run = [&](long long b, long long e, unsigned char flip) {          // plain chunks over snippets [b, e)
         for (long long g0 = b; g0 < e; g0 += (long long)S_plain * C) {
             const long long g1 = std::min(e, g0 + (long long)S_plain * C);
-            const int waves = (int)std::min<long long>(S_plain, std::max<long long>(1, (g1 - g0 + 15) / 16));
+            // (chunks of >= 16 windows — except rescaled pile-ups, whose windows are 10^5 cells each: C of them per chunk, ~4 rounds of
+            // workgroups per CU; with 16 per chunk 5 000 windows made 320 workgroups on 256 CUs: a quarter of the second round's time was idle CUs)
+            const long long per_chunk = rescale ? C : 16;
+            const int waves = (int)std::min<long long>(S_plain, std::max<long long>(1, (g1 - g0 + per_chunk - 1) / per_chunk));
             if (!host_pos) group_start.push_back(g0);
             groups.push_back(Group{host_pos ? (long long)r0[g0] : (long long)groups.size(), (int)cb.size(), waves});
             for (int j = 0; j < waves; ++j) {
@@ -1843,7 +1856,11 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         c->last_kernel = "expected_diag";
     }
     if (rescale) {
-        const size_t rs_lds = (size_t)W * W * 12 + 16 * (size_t)W;
+        size_t rs_lds = (size_t)W * W * 12 + 16 * (size_t)W;
+        // room for the separable zoom's weights: as many per output row and column as LDS has left, up to kRescaleSepK (a window
+        // h times the output size needs h + 2; 99 x 99 outputs: 27, small outputs: 64)
+        const int sep_k = rescale_sep_k(c, rs_lds, W);
+        if (sep_k) rs_lds += 8 + 2 * (size_t)W * ((size_t)sep_k * sizeof(double) + sizeof(int));
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pup::pileup_rescale_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_lds);
         // a slab per workgroup for the gathered window: the largest window of the call, as long as the slabs stay below 8 GB
         long long max_cells = 0;
@@ -1853,7 +1870,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
             c->rs_scratch.reserve((size_t)slab_cells * (size_t)nblocks) != hipSuccess) { slab_cells = 0; (void)hipGetLastError(); }
         hipLaunchKernelGGL(pup::pileup_rescale_kernel, dim3((unsigned)nblocks), dim3(rs_threads), rs_lds, c->stream, a,
                            (const int*)c->d_h.p, (const int*)c->d_w.p, (double*)nullptr, (double*)nullptr, 0LL,
-                           slab_cells ? c->rs_scratch.p : (double*)nullptr, slab_cells);
+                           slab_cells ? c->rs_scratch.p : (double*)nullptr, slab_cells, sep_k);
         launched = true; c->last_kernel = "rescale";
     }
     const bool sparse_launch = !lds_kernel2 && !rescale && ignore_diags < 0 && W <= 63 && !(c->variant & 32) &&
@@ -2090,7 +2107,9 @@ int pup_extract(pup_ctx* c, const int32_t* r0, const int32_t* c0, const int32_t*
         a.W = W; a.ignore_diags = ignore_diags; a.mode = mode;
         const unsigned grid = (unsigned)std::min<int64_t>(n, 16384);
         if (rescale) {
-            const size_t rs_lds = W2 * 12 + 16 * (size_t)W;
+            size_t rs_lds = W2 * 12 + 16 * (size_t)W;
+            const int sep_k = rescale_sep_k(c, rs_lds, W);
+            if (sep_k) rs_lds += 8 + 2 * (size_t)W * ((size_t)sep_k * sizeof(double) + sizeof(int));
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pup::pileup_rescale_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)rs_lds);
             if (cov_start && !(mode & PUP_MODE_COV)) e = hipMemsetAsync(d_cov.p, 0xff, (size_t)n * 2 * W * 8, c->stream);  // NaN
@@ -2101,7 +2120,7 @@ int pup_extract(pup_ctx* c, const int32_t* r0, const int32_t* c0, const int32_t*
                 c->rs_scratch.reserve((size_t)slab_cells * grid) != hipSuccess) { slab_cells = 0; (void)hipGetLastError(); }
             hipLaunchKernelGGL(pup::pileup_rescale_kernel, dim3(grid), dim3(256), rs_lds, c->stream, a,
                                (const int*)c->d_h.p, (const int*)c->d_w.p, d_out.p, cov_start ? d_cov.p : (double*)nullptr,
-                               (long long)n, slab_cells ? c->rs_scratch.p : (double*)nullptr, slab_cells);
+                               (long long)n, slab_cells ? c->rs_scratch.p : (double*)nullptr, slab_cells, sep_k);
         } else {
             hipLaunchKernelGGL(pup::extract_windows_kernel, dim3(grid), dim3(256), 0, c->stream, a, (long long)n, d_out.p,
                                cov_start ? d_cov.p : (double*)nullptr);

@@ -1216,6 +1216,7 @@ __global__ __launch_bounds__(kWave, 3) void pileup_band_kernel(K1Args a) {
 // cell is fetched on demand (rank-bitmap index or binary search) — rescaled pile-ups are thousands of windows, not
 // millions, so the gather is not staged.
 struct RsGeom { int ch_start, ch_end, ch_nblk; long long ch_base; bool have; };
+constexpr int kRescaleSepK = 64;                      // most zoom weights kept per output row / column (separable zoom): windows up to 62 x the output
 
 // balanced value of the stored pixel at `pos` as a per-snippet output shows it: the `bal` table — except when the weight
 // column holds +-inf: cooler multiplies such pixels out to +-inf or NaN (0 * inf) and the reference's windows carry exactly
@@ -1226,6 +1227,15 @@ __device__ __forceinline__ double pixel_value(const K1Args& a, long long pos, in
 }
 
 __device__ __forceinline__ double lookup_bal(const K1Args& a, const RsGeom& g, int row, int col) {
+    // near the diagonal the count comes from the dense band (one load, nothing depends on it but the product; the index path below
+    // is a chain of two loads and a popcount): rescaled pile-ups are windows ON the diagonal.  Same double as the `bal` table:
+    // (count * w[row]) * w[col], NaN -> 0 unless the weights hold infinities (pixel_value)
+    if (a.band != nullptr && col >= row && col - row < a.band_w && g.have && row >= g.ch_start && col < g.ch_end) {
+        const int cnt = a.band[(long long)row * a.band_w + (col - row)];
+        double v = (double)cnt;
+        if (a.weight) { v = v * a.weight[row] * a.weight[col]; if (!a.nf_pixels && !(v == v)) v = 0.0; }
+        return cnt ? v : 0.0;
+    }
     if (g.have && row >= g.ch_start && row < g.ch_end && col >= g.ch_start && col < g.ch_end) {
         const int rel = col - g.ch_start;
         const int b = rel / kIdxCols, o = rel - b * kIdxCols;
@@ -1251,13 +1261,18 @@ __device__ __forceinline__ bool bin_bad(const K1Args& a, int bin) { return (a.ba
 // coverage vectors to emit_cov[s] = {cov_start[S], cov_end[S]}.  Blocks then stride over snippets 0..emit_n.
 PUP_KERNEL __launch_bounds__(1024) void pileup_rescale_kernel(K1Args a, const int* __restrict__ hs, const int* __restrict__ wsz,
                                                              double* __restrict__ emit, double* __restrict__ emit_cov,
-                                                             long long emit_n, double* __restrict__ scratch, long long scratch_cells) {
+                                                             long long emit_n, double* __restrict__ scratch, long long scratch_cells,
+                                                             int sep_k /* > 0: LDS holds room for sep_k zoom weights per output row / column */) {
 #pragma clang fp contract(off)      // zoom coordinates must be plain IEEE products (see below)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int S = a.W, S2 = S * S;
     double*   tsum = reinterpret_cast<double*>(smem_raw);
     double*   tcov = tsum + S2;                               // [2S]
     unsigned* tnum = reinterpret_cast<unsigned*>(tcov + 2 * S);
+    // zoom weights of the current window (see below): Wy[S][sep_k] | Wx[S][sep_k] doubles, first input row / column of every output
+    // row / column (2S ints)
+    double* const wsep = reinterpret_cast<double*>(smem_raw + (((size_t)S2 * 12 + 16 * (size_t)S + 7) & ~(size_t)7));
+    int* const wlo = reinterpret_cast<int*>(wsep + 2 * (size_t)S * (sep_k > 0 ? sep_k : 0));
     const bool emitting = emit != nullptr;
     const int ck = emitting ? (int)blockIdx.x : a.block_chunk[blockIdx.x];
     if (ck < 0) return;
@@ -1323,7 +1338,23 @@ PUP_KERNEL __launch_bounds__(1024) void pileup_rescale_kernel(K1Args a, const in
         double* const slab = staged_win ? scratch + (size_t)blockIdx.x * (size_t)scratch_cells : nullptr;
         if (staged_win) {
             __syncthreads();                                  // the previous window's taps have been read
-            for (int t = tid; t < h * w; t += nthr) { const int i = t / w; slab[t] = cell_sym(i, t - i * w); }
+            if (m_local && h == w) {
+                // the symmetrised window is symmetric: its upper triangle is worked out, every value stored twice.  Rows a and
+                // h - 1 - a together hold h + 1 cells of the triangle: the pairs of rows make a ceil(h / 2) x (h + 1) rectangle every
+                // lane of which has a cell to fetch
+                const int half = (h + 1) / 2, span = h + 1;
+                for (int t = tid; t < half * span; t += nthr) {
+                    const int ra = t / span, b = t - ra * span;
+                    int i, j;
+                    if (b < h - ra) { i = ra; j = ra + b; }
+                    else { i = h - 1 - ra; j = i + (b - (h - ra)); if (i == ra) continue; }      // (odd h: the middle row pairs with itself)
+                    const double v = cell_sym(i, j);
+                    slab[i * w + j] = v; slab[j * w + i] = v;
+                }
+            } else {
+                const int hw = h * w;
+                for (int t = tid; t < hw; t += nthr) { const int i = t / w; slab[t] = cell_sym(i, t - i * w); }
+            }
             __syncthreads();
         }
         auto tap = [&](int i, int j) -> double { return staged_win ? slab[i * w + j] : cell_sym(i, j); };
@@ -1342,9 +1373,12 @@ PUP_KERNEL __launch_bounds__(1024) void pileup_rescale_kernel(K1Args a, const in
                 // data / expected: a cell is NaN when masked, when its expected is NaN, and when it is 0 / 0.  If every
                 // expected value on the window's diagonals is usable and non-zero, any unmasked cell is a number;
                 // otherwise the workgroup looks at the cells themselves (reference :1213 tests np.all(np.isnan(data)))
-                bool e_good = true;
+                // (the window's h + w - 1 diagonals shared out to the threads: every thread walking all of them, one dependent load
+                // after the other, was a quarter of a window's time)
+                int e_bad = 0;
                 const long long dlo = (long long)(cs - rs) - (h - 1), dhi = (long long)(cs - rs) + (w - 1);
-                for (long long d = dlo; d <= dhi && e_good; ++d) { const double e = es.at(d < 0 ? -d : d); if (!(e == e) || e == 0.0) e_good = false; }
+                for (long long d = dlo + tid; d <= dhi; d += nthr) { const double e = es.at(d < 0 ? -d : d); if (!(e == e) || e == 0.0) e_bad = 1; }
+                const bool e_good = !__syncthreads_or(e_bad);
                 if (!e_good) {
                     int found = 0;
                     // (the symmetrised window holds a number exactly when the plain one does: nanmean of (v, u) is NaN iff both are)
@@ -1360,10 +1394,63 @@ PUP_KERNEL __launch_bounds__(1024) void pileup_rescale_kernel(K1Args a, const in
         const double sy = th > 1 ? __ddiv_rn((double)(h - 1), (double)(th - 1)) : 0.0;
         const double sx = tw > 1 ? __ddiv_rn((double)(w - 1), (double)(tw - 1)) : 0.0;
         const double inv = 1.0 / ((double)mh * (double)mw);
+        // ---- round 4: the zoom as TWO SETS OF WEIGHTS.  Bilinear interpolation and the block mean are both separable, so the value of
+        // output cell (A, B) is  inv * sum_i sum_j Wy[A][i] Wx[B][j] v[i][j]  with Wy[A][i] = the summed interpolation weights of input
+        // row i over the mh sample rows of output row A (at most mh + 2 input rows: the samples of one output row span < mh of
+        // them), Wx likewise — 25-40 window cells per output cell instead of 4 mh mw taps (144 at a threefold reduction), the weights
+        // worked out once per window by 2S threads.  A sample outside the input contributes nothing (it gets no weight on its
+        // axis: the product form is exact); an input NaN taints the output cell exactly when both its weights are non-zero, which is
+        // the per-tap rule below.  Same sums up to the order of the additions.  Windows whose mh + 2 exceeds the LDS room (sep_k)
+        // take the per-sample loop.
+        const bool sep = sep_k > 0 && !all_nan && mh + 2 <= sep_k && mw + 2 <= sep_k;
+        if (sep) {
+            __syncthreads();                                  // the previous window's weights have been read
+            for (int t = tid; t < 2 * S; t += nthr) {
+                const bool ax_y = t < S;
+                const int A = ax_y ? t : t - S;
+                const int n_in = ax_y ? h : w, m = ax_y ? mh : mw;
+                const double sc = ax_y ? sy : sx;
+                double* Wr = wsep + (size_t)t * sep_k;
+                for (int k = 0; k < sep_k; ++k) Wr[k] = 0.0;
+                int lo = -1;
+                for (int d = 0; d < m; ++d) {
+                    const double y = __dmul_rn((double)(A * m + d), sc);
+                    if (y > (double)(n_in - 1)) continue;     // constant-mode sample outside the input: 0
+                    const int i0 = (int)y;
+                    const double tt = y - (double)i0;
+                    if (lo < 0) lo = i0;                      // (coordinates ascend: the first sample's row is the lowest)
+                    Wr[i0 - lo] += 1.0 - tt;
+                    if (tt > 0.0) Wr[(i0 + 1 < n_in ? i0 + 1 : n_in - 1) - lo] += tt;
+                }
+                wlo[t] = lo < 0 ? 0 : lo;
+            }
+            __syncthreads();
+        }
         for (int t = tid; t < S2; t += nthr) {
             const int A = t / S, B = t - A * S;
             double acc = 0.0; bool anynan = false;
-            if (!all_nan) {
+            if (sep) {
+                const double* Wy = wsep + (size_t)A * sep_k;
+                const double* Wx = wsep + (size_t)(S + B) * sep_k;
+                const int i_lo = wlo[A], j_lo = wlo[S + B];
+                for (int ki = 0; ki < mh + 2; ++ki) {
+                    const double wy = Wy[ki];
+                    const int i = i_lo + ki;
+                    if (!(wy > 0.0) || i >= h) continue;
+                    double rowacc = 0.0;
+                    for (int kj = 0; kj < mw + 2; ++kj) {
+                        const double wx = Wx[kj];
+                        const int j = j_lo + kj;
+                        if (!(wx > 0.0) || j >= w) continue;
+                        double v = tap(i, j);
+                        if (v != v) { anynan = true; v = 0.0; }
+                        v = v > DBLMAX ? DBLMAX : (v < -DBLMAX ? -DBLMAX : v);
+                        rowacc += v * wx;
+                    }
+                    acc += rowacc * wy;
+                }
+                acc *= inv;
+            } else if (!all_nan) {
                 for (int da = 0; da < mh; ++da) {
                     const double ya = __dmul_rn((double)(A * mh + da), sy);
                     const bool oob_y = ya > (double)(h - 1);

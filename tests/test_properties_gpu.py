@@ -445,6 +445,54 @@ def test_block_columns_renumbered_when_a_window_leaves_the_band(hip_lib):
         eng.close()
 
 
+@pytest.mark.parametrize("S", [11, 33, 99])
+def test_rescaled_zoom_by_weights_equals_the_per_sample_zoom(hip_lib, S):
+    """The rescaled pile-up's zoom as two sets of weights (separable bilinear interpolation + block mean) against the per-sample
+    loop it replaced (tuning bit 11 switches the weights off): windows smaller than the output (upsampling), equal, up to 9 x
+    larger, rectangular, local (symmetrised) and plain, with masked bins inside, observed over expected; accumulated tiles and
+    per-window emission.  Same NaN pattern and counts; sums within rounding of the different addition order."""
+    import synth
+    from coolpuppy_amd.engine import PileupEngine, MODE_OOE
+    clr = synth.make_cooler({"chrA": 30_000_000, "chrB": 12_000_000}, lam=60, seed=71)
+    w = clr.bins()["weight"][:].values
+    rng = np.random.default_rng(S)
+    lo, hi = clr.extent("chrA")
+    n = 400
+    hgt = rng.integers(3, 9 * S, n).astype(np.int32)
+    hgt[:40] = S; hgt[40:60] = rng.integers(2, S, 20)
+    wid = hgt.copy()
+    wid[n // 2:] = np.maximum(2, (hgt[n // 2:] * rng.uniform(0.3, 1.5, n - n // 2)).astype(np.int32))
+    r0 = rng.integers(lo + 5, hi - 9 * S - 1500, n).astype(np.int32)
+    c0 = r0.copy()
+    c0[n // 2:] += rng.integers(0, 300, n - n // 2).astype(np.int32)
+    tile_ptr = np.array([0, n // 2, n], np.int64)
+    e = synth.cis_expected(clr)
+    expv = e[e.region1 == "chrA"]["balanced.avg"].values.copy()
+    pad = (S - 1) // 2
+    for mode, igd in ((0x20, 2), (0, 0), (MODE_OOE | 0x20, 2)):
+        res = {}
+        for variant in (0, 2048):
+            eng = PileupEngine(0)
+            eng.load_pixels(*clr.pixel_table())
+            eng.build_index(clr.chrom_offset)
+            eng.load_bins(w, None)
+            eng.set_expected(expv if mode & MODE_OOE else None)
+            eng.set_tuning(0, variant)
+            eng.reset(2, pad)
+            eng.accumulate_rescaled(r0, c0, hgt, wid, tile_ptr, ignore_diags=igd, mode=mode)
+            acc = eng.fetch()
+            snips = eng.extract(r0[:60], c0[:60], pad, height=hgt[:60], width=wid[:60], ignore_diags=igd, mode=mode)
+            res[variant] = (acc, snips[0] if isinstance(snips, tuple) else snips)
+            eng.close()
+        a, b = res[0], res[2048]
+        np.testing.assert_array_equal(a[0]["num"], b[0]["num"])
+        np.testing.assert_array_equal(a[0]["n"], b[0]["n"])
+        np.testing.assert_allclose(a[0]["sum"], b[0]["sum"], rtol=1e-11, atol=0)
+        np.testing.assert_array_equal(np.isnan(a[1]), np.isnan(b[1]))
+        np.testing.assert_allclose(a[1], b[1], rtol=1e-12, atol=1e-300, equal_nan=True)
+        assert a[0]["num"].sum() > 0 and np.isfinite(a[1]).any()
+
+
 def test_staged_kernel_with_an_empty_tile_of_a_pair(hip_lib):
     """A tile pair whose first or second tile has no window at all (a group without controls in this region, or the other way
     round): its team has no wave, its record stays invalid, the partner gets every wave."""
