@@ -1582,8 +1582,11 @@ class PileUpper:
         for bi, (region1, region2, b) in enumerate(batches):
             if b is None or b["n"] == 0:
                 continue
+            run_tile = (not grouped) and ("n_roi" in b) and not exp_as_control and b.get("flip") is None and not rescale
             if grouped:     # (a key none of the region's kept windows uses is not in the table: its code never occurs)
                 g = np.array([gid.get(k, -1) for k in b["group_keys"]], np.int32)[b["group_codes"]]
+            elif run_tile:
+                g = None    # (no per-window array at all: tile 0 for the ROI windows, G for the controls — engine.RunTile)
             else:
                 g = np.zeros(b["n"], np.int32)
             expected = None
@@ -1601,7 +1604,10 @@ class PileUpper:
             tr = MODE_TRANSPOSE if transpose else 0
             loc = MODE_LOCAL if (rescale and self.local) else 0
             mode = (MODE_OOE if (self.expected and self.ooe) else 0) | (MODE_COV if self.coverage_norm else 0) | tr | loc
-            if "n_roi" in b:           # ROI windows first, then the controls: tile = group, + G from there on
+            if run_tile:
+                from .engine import RunTile
+                tile = RunTile(b["n_roi"], b["n"], 0, G)
+            elif "n_roi" in b:         # ROI windows first, then the controls: tile = group, + G from there on
                 tile = g if g.flags.writeable and g.base is None else g.copy()
                 tile[b["n_roi"]:] += np.int32(G)
             else:
@@ -2099,6 +2105,7 @@ def _engine_call_parts(region1, region2, expected, parts, T, igd, mode, rescale)
         r0, c0, tile_ptr = _engine.group_tiles([(p[0], p[1], p[3]) for p in parts], T)
         return _Call({"region1": region1, "region2": region2, "expected": expected, "r0": r0, "c0": c0, "flip": None,
                       "flip_from": None, "tile_ptr": tile_ptr, "ignore_diags": igd, "mode": mode})
+    parts = [(p[0], p[1], p[2], np.asarray(p[3]), p[4], p[5]) for p in parts]      # (run-coded tiles as arrays from here on)
     if len(parts) == 1 or nk >= 65536 or nk * len(parts) > 200_000:
         f = [np.concatenate([p[k] for p in parts]) if len(parts) > 1 else parts[0][k] for k in range(6)]
         return _engine_call(region1, region2, expected, f[0], f[1], f[2], f[3], T, igd, mode,

@@ -541,17 +541,44 @@ def take_rows(columns, order):
     return out
 
 
+class RunTile:
+    """Tile numbers of a region's windows as two runs: the first `split` windows belong to tile `a`, the other `n - split` to
+    tile `b` (an ungrouped region with controls: ROI windows, then the shifted copies).  group_tiles hands the runs to the library
+    as they are; np.asarray() gives the per-window array for the callers that want one (oracle replays, the flipped-window paths)."""
+    __slots__ = ("split", "n", "a", "b")
+
+    def __init__(self, split, n, a, b):
+        self.split, self.n, self.a, self.b = int(split), int(n), int(a), int(b)
+
+    def __len__(self):
+        return self.n
+
+    def __array__(self, dtype=None, copy=None):
+        out = np.empty(self.n, np.int32)
+        out[:self.split] = self.a
+        out[self.split:] = self.b
+        return out if dtype is None else out.astype(dtype, copy=False)
+
+
 def group_tiles(parts, T):
-    """pup_host_group_tiles: [(r0, c0, tile), ...] (int32 arrays per region) -> (r0, c0, tile_ptr) of one engine call,
-    stably grouped by tile; r0 / c0 page-locked."""
-    keep = [(_as(a, np.int32), _as(b, np.int32), _as(t, np.int32)) for a, b, t in parts]
+    """pup_host_group_tiles(_runs): [(r0, c0, tile), ...] (int32 arrays per region; tile may be a RunTile) -> (r0, c0, tile_ptr)
+    of one engine call, stably grouped by tile; r0 / c0 page-locked."""
+    keep = [(_as(a, np.int32), _as(b, np.int32), t if isinstance(t, RunTile) else _as(t, np.int32)) for a, b, t in parts]
     P = len(keep)
     n = sum(a.shape[0] for a, _, _ in keep)
     arr = lambda k: (C.c_void_p * max(P, 1))(*[x[k].ctypes.data for x in keep])       # noqa: E731
+    tiles = (C.c_void_p * max(P, 1))(*[None if isinstance(x[2], RunTile) else x[2].ctypes.data for x in keep])
     lens = np.array([a.shape[0] for a, _, _ in keep], np.int64)
+    for a, _, t in keep:
+        if len(t) != a.shape[0]:
+            raise ValueError("group_tiles: tile numbers and windows differ in length")
+    split = np.array([x[2].split if isinstance(x[2], RunTile) else 0 for x in keep], np.int64)
+    ta = np.array([x[2].a if isinstance(x[2], RunTile) else 0 for x in keep], np.int32)
+    tb = np.array([x[2].b if isinstance(x[2], RunTile) else 0 for x in keep], np.int32)
     r0, c0 = pinned_empty(n), pinned_empty(n)
     tile_ptr = np.empty(int(T) + 1, np.int64)
-    rc = _ffi.lib().pup_host_group_tiles(P, arr(0), arr(1), arr(2), _ptr(lens), int(T), _ptr(r0), _ptr(c0), _ptr(tile_ptr))
+    rc = _ffi.lib().pup_host_group_tiles_runs(P, arr(0), arr(1), tiles, _ptr(split), _ptr(ta), _ptr(tb), _ptr(lens), int(T),
+                                              _ptr(r0), _ptr(c0), _ptr(tile_ptr))
     if rc != 0:
         raise ValueError("pup_host_group_tiles: tile id outside [0, T)")
     return r0, c0, tile_ptr

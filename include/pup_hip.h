@@ -37,7 +37,7 @@
  *   pup_host_factorize_ptr            <- the same sort's chromosome codes (object columns factorised by identity)
  *   pup_host_argsort                  <- the same sort's order (one packed key per row)
  *   pup_host_take_rows                <- the sort of the feature frame in CoordCreator._binnify  coolpuppy/coolpup.py:489-527
- *   pup_host_group_tiles              <- the per-group dicts of accumulate_stream as a grouping of windows by tile
+ *   pup_host_group_tiles(_runs)       <- the per-group dicts of accumulate_stream as a grouping of windows by tile
  *                                                                      coolpuppy/coolpup.py:1263-1283
  *   pup_host_alloc / pup_host_free    <- (no counterpart: page-locked staging for asynchronous host-to-device copies)
  *   pup_rccl_path                     <- (no counterpart: which librccl the communicator of pup_allreduce must come from)
@@ -375,6 +375,16 @@ int pup_host_argsort(const uint64_t* keys, int64_t n, int32_t bits, int64_t* ord
  */
 int pup_host_group_tiles(int32_t n_parts, const int32_t* const* r0, const int32_t* const* c0, const int32_t* const* tile,
                          const int64_t* len, int32_t T, int32_t* r0_out, int32_t* c0_out, int64_t* tile_ptr);
+
+/*
+ * pup_host_group_tiles_runs: the same with RUN-CODED parts — tile[p] == NULL: windows [0, split[p]) of part p belong to tile
+ * tile_a[p], the others to tile_b[p] (an ungrouped region with controls: ROI windows, then the shifted copies,
+ * coolpuppy/coolpup.py:387-453) — for which no per-window tile array exists.  split / tile_a / tile_b may be NULL when no part is
+ * run-coded.
+ */
+int pup_host_group_tiles_runs(int32_t n_parts, const int32_t* const* r0, const int32_t* const* c0, const int32_t* const* tile,
+                              const int64_t* split, const int32_t* tile_a, const int32_t* tile_b, const int64_t* len, int32_t T,
+                              int32_t* r0_out, int32_t* c0_out, int64_t* tile_ptr);
 
 #ifdef __cplusplus
 }

@@ -168,6 +168,17 @@ def test_library_window_pass_equals_numpy():
     assert np.array_equal(tp, np.concatenate([[0], np.cumsum(np.bincount(tile, minlength=11))]))
     with pytest.raises(ValueError):
         E.group_tiles([(r0[:5], c0[:5], np.array([0, 1, 2, 11, 3], np.int32))], 11)
+    # run-coded parts (engine.RunTile: the first `split` windows of a part in one tile, the rest in another) mixed with array-coded ones
+    runs = [E.RunTile(0, 7, 3, 9), None, E.RunTile(5000, 11_993, 2, 10), E.RunTile(17_999, 17_999, 0, 99), None]
+    mixed = [(p[0], p[1], p[2] if rt is None else rt) for p, rt in zip(parts, runs)]
+    plain = [(p[0], p[1], p[2] if rt is None else np.asarray(rt)) for p, rt in zip(parts, runs)]
+    got, want = E.group_tiles(mixed, 11), E.group_tiles(plain, 11)
+    assert all(np.array_equal(x, y) for x, y in zip(got, want))
+    tile_all = np.concatenate([p[2] for p in plain])
+    o = np.argsort(tile_all, kind="stable")
+    assert np.array_equal(got[0], r0[o]) and np.array_equal(got[2], np.concatenate([[0], np.cumsum(np.bincount(tile_all, minlength=11))]))
+    with pytest.raises(ValueError):
+        E.group_tiles([(r0[:5], c0[:5], E.RunTile(2, 5, 0, 11))], 11)
 
 
 def test_draw_ahead_thread_issues_the_serial_draws():
