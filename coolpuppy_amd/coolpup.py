@@ -73,13 +73,7 @@ def assign_groups(intervals, groupby=[]):
     return intervals
 
 
-def _scaled_interval(start, end, scale):
-    """bioframe.expand(df, scale=...): grow an interval by 0.5*(scale-1)*length on both sides, rounded (np.round,
-    half to even) back to the integer dtype of the input — what the reference calls for rescaled pile-ups."""
-    start = np.asarray(start)
-    end = np.asarray(end)
-    pads = 0.5 * (scale - 1) * (end - start)
-    return np.round(start - pads).astype(start.dtype), np.round(end + pads).astype(end.dtype)
+from .intervals import scaled_interval as _scaled_interval  # noqa: E402
 
 
 def expand(intervals, flank, resolution, rescale_flank=None):
@@ -160,32 +154,6 @@ def _draw_ints(low, high, m, discard=False, dtype=np.int64):
     return legacy_randint(low, high, m, discard=discard, dtype=dtype)
 
 
-def _factorize_pair(a, b):
-    """pd.factorize(np.concatenate([a, b])) — codes of both columns in one table of uniques, in order of first
-    appearance — at the price of one column when the two are equal row by row (cis pairs: the usual case), and of two
-    separate factorisations otherwise (no 2n-row concatenation of object pointers)."""
-    from .engine import factorize_objects
-    n = len(a)
-    ca, ua = factorize_objects(a)
-    try:
-        same = n > 0 and bool(np.all(a == b))
-    except Exception:                                   # noqa: BLE001 — exotic element types: the plain way
-        same = False
-    if same:
-        return np.concatenate([ca, ca]), ua
-    cb, ub = factorize_objects(b)
-    table = {u: i for i, u in enumerate(ua)}
-    uniq = list(ua)
-    remap = np.empty(len(ub), np.int64)
-    for j, u in enumerate(ub):
-        if u not in table:
-            table[u] = len(uniq)
-            uniq.append(u)
-        remap[j] = table[u]
-    cb2 = np.where(cb >= 0, remap[np.maximum(cb, 0)], -1) if len(ub) else cb
-    return np.concatenate([ca, cb2]), np.asarray(uniq, dtype=object)
-
-
 class _Cols(dict):
     """A column table: name -> 1-D numpy array, all of one length."""
 
@@ -210,6 +178,18 @@ class _Cols(dict):
     @staticmethod
     def from_frame(df):
         return _Cols({c: df[c].values for c in df.columns})
+
+
+def _nrows(rows):
+    """Number of table rows in a selection (a slice of the sorted table or an index array)."""
+    return rows.stop - rows.start if isinstance(rows, slice) else len(rows)
+
+
+def _rows_where(rows, mask):
+    """The rows of a selection a boolean mask over it keeps, as an index array."""
+    if isinstance(rows, slice):
+        return np.flatnonzero(mask) + rows.start
+    return rows[mask]
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -270,10 +250,11 @@ class CoordCreator:
     def __init__(self, features, resolution, *, features_format="auto", flank=100000, rescale_flank=None,
                  chroms="all", minshift=10**5, maxshift=10**6, nshifts=10, mindist="auto", maxdist=None,
                  local=False, subset=0, trans=False, seed=None):
-        # (a frame of its own, the caller's column arrays shared until a column is replaced: process() only ever ASSIGNS whole
-        # columns and builds new frames — it never writes into an array —, so the caller's frame keeps its columns and values;
-        # a deep copy of 10^6 rows of object and integer columns was 10 ms of every pile-up.  tests/test_host_misc.py checks.)
-        self.intervals = features.copy(deep=False)
+        # (the caller's frame is only ever READ: the processed table is a column store of its own, intervals.py, and the frame
+        # behind `.intervals` is assembled from it on first access — tests/test_host_misc.py checks the caller's frame stays as it was)
+        self._src = features
+        self._tbl = None
+        self._fc = None
         self.resolution = resolution
         self.features_format = features_format
         self.flank = flank
@@ -305,11 +286,26 @@ class CoordCreator:
         self.seed = seed
         self.process()
 
+    # -- the processed table -------------------------------------------------------------------------------------
+    @property
+    def intervals(self):
+        """The processed feature frame (reference attribute): filtered, sorted, with the derived columns — assembled from the
+        column store on first access (intervals.ArrayTable.frame); a pile-up never asks for it."""
+        return self._tbl.frame()
+
+    @intervals.setter
+    def intervals(self, frame):
+        from .intervals import FrameTable
+        kind = getattr(self, "kind", None) or ("bedpe" if "chrom1" in frame.columns else "bed")
+        self._tbl = FrameTable(frame, kind)
+        self._fc = None
+
     # -- construction-time processing (reference :259-385) -------------------------------------------
     def process(self):
         bedpe_cols = ["chrom1", "start1", "end1", "chrom2", "start2", "end2"]
         bed_cols = ["chrom", "start", "end"]
-        have = set(self.intervals.columns)
+        src = self._src
+        have = set(src.columns)
         if self.features_format is None or self.features_format == "auto":
             if have.issuperset(bedpe_cols):
                 self.kind = "bedpe"
@@ -331,67 +327,33 @@ class CoordCreator:
                 "would not be 2*(flank//resolution)+1 bins wide")
 
         if self.subset > 0:
-            self.intervals = self._subset(self.intervals)
-
-        presorted = False
-        iv = self.intervals
+            src = self._subset(src)
         if self.kind == "bed":
             assert have.issuperset(bed_cols), "Column names must include chrom, start, and end"
-            iv["chrom"] = iv["chrom"].astype(str)
-            iv["center"] = (iv["start"] + iv["end"]) / 2
-            iv = expand(iv, self.flank, self.resolution, self.rescale_flank)
         else:
             assert have.issuperset(bedpe_cols), \
                 "Column names must include chrom1, start1, end1, chrom2, start2, and end2"
-            # same columns / filter as the reference (:296-321), but the distance filter runs BEFORE the new
-            # columns are attached: filtering a freshly widened frame makes pandas re-consolidate every block
-            c1 = (iv["start1"].values + iv["end1"].values) / 2
-            c2 = (iv["start2"].values + iv["end2"].values) / 2
-            absd = np.abs(c2 - c1)
-            keep = (self.mindist <= absd) & (absd <= self.maxdist)
-            if not keep.all():
-                iv = iv[keep].reset_index(drop=True)
-                c1, c2 = c1[keep], c2[keep]
-            iv["chrom1"] = iv["chrom1"].astype(str)
-            iv["chrom2"] = iv["chrom2"].astype(str)
-            # the reference sorts in _binnify (:489-527), after it has attached ~10 derived columns; every one of them is
-            # a row-wise function of the input columns, so sorting NOW (same keys, same stable pandas sort, index labels
-            # kept) gives the same frame while permuting half as many columns
-            # (the three derived columns are attached AFTER the sort, recomputed from the sorted anchors — the same doubles: three
-            # sequential passes instead of three more random gathers of a million rows)
-            iv = self._sort_pairs(iv)
-            s1 = (iv["start1"].values + iv["end1"].values) / 2
-            s2 = (iv["start2"].values + iv["end2"].values) / 2
-            iv["center1"] = s1
-            iv["center2"] = s2
-            iv["distance"] = s2 - s1
-            presorted = True
-            iv = expand2D(iv, self.flank, self.resolution, self.rescale_flank)
-        self.intervals = iv
 
-        if iv.shape[0] == 0:
-            warnings.warn("No regions in features (maybe all below mindist?), returning empty output", stacklevel=2)
-            self.pos_stream = self.empty_stream
-            self.final_chroms = []
-            return
-
-        if self.nshifts > 0 and self.kind == "bedpe":
-            self.intervals = self._control_regions(self.intervals)   # nshifts=0: only tags kind="ROI"
-
+        # the array path (intervals.build_table): same rows, order and columns as the pandas steps below, without the frame
+        from .intervals import build_table
+        tbl = None
+        if not os.environ.get("COOLPUPPY_AMD_FRAME_PATH"):
+            tbl = build_table(src, self.kind, self.resolution, self.flank, self.rescale_flank, self.mindist, self.maxdist,
+                              tag_kind=self.nshifts > 0 and self.kind == "bedpe")
+        if tbl is None:
+            return self._process_frame(src)
+        self._tbl, self._fc = tbl, None
+        codes, names = tbl.chrom_codes()
+        present = [{names[i] for i in np.flatnonzero(np.bincount(c, minlength=len(names)))} for c in codes]
         if self.kind == "bed":
-            base = set(self.intervals["chrom"])
+            base = present[0]
         else:
             if self.local:
                 raise ValueError("Can't make local with both sides of loops defined")
-            sc = getattr(self, "_sorted_codes", None)
-            if sc is not None and len(sc[1]) == len(self.intervals):
-                # chromosome names present on either side, from the factorisation the sort made (hashing a million
-                # strings into a set twice cost as much as the sort)
-                u1 = {sc[3][i] for i in np.unique(sc[1])}
-                u2 = {sc[3][i] for i in np.unique(sc[2])}
-            else:
-                u1, u2 = set(self.intervals["chrom1"].unique().tolist()), set(self.intervals["chrom2"].unique().tolist())
-            base = (u1 | u2) if self.trans else (u1 & u2)
+            base = (present[0] | present[1]) if self.trans else (present[0] & present[1])
+        self._finish_process(base)
+
+    def _finish_process(self, base):
         self.basechroms = natsorted(list(base))
         if isinstance(self.chroms, str) and self.chroms == "all":
             self.final_chroms = natsorted(list(base))
@@ -404,68 +366,69 @@ class CoordCreator:
                    format, e.g. starting with "chr"?
                    """
             )
-
-        self.intervals = self._binnify(self.intervals, presorted=presorted)
-
-        keys = ["stBin", "endBin"] if self.kind == "bed" else ["stBin1", "endBin1", "stBin2", "endBin2"]
-        dups = self.intervals.duplicated(subset=keys) if logger.isEnabledFor(logging.DEBUG) else np.zeros(0, bool)
-        if dups.any():
-            logger.debug(f"{dups.mean() * 100:.2f}% of intervals fall within the same bin as another interval. "
-                         "These are all included in the pileup.")
+        if logger.isEnabledFor(logging.DEBUG):
+            keys = ["stBin", "endBin"] if self.kind == "bed" else ["stBin1", "endBin1", "stBin2", "endBin2"]
+            dups = self.intervals.duplicated(subset=keys)
+            if dups.any():
+                logger.debug(f"{dups.mean() * 100:.2f}% of intervals fall within the same bin as another interval. "
+                             "These are all included in the pileup.")
 
         if self.trans & self.local:
             raise ValueError("Cannot do local with trans=True")
 
         self.pos_stream = self.get_combinations if self.kind == "bed" else self.get_intervals_stream
 
-    def _sort_pairs(self, iv):
-        """iv.sort_values(["chrom1", "chrom2", "start1", "start2"]) — the same stable order, index labels kept — through ONE
-        64-bit key per row: (rank of the chromosome pair in string order | start1 | start2 | row number), the starts divided
-        by their common divisor (bin-aligned anchors).  The row number makes every key unique, so numpy's vectorised
-        unstable sort yields the stable order.  Falls back to pandas when the fields do not fit 63 bits.  The chromosome
-        codes are kept for the region selections (_cache) — the same factorisation would be done there."""
-        self._sorted_codes = None                # (an early return below must not leave a previous run's codes behind)
-        n = len(iv)
-        s1, s2 = iv["start1"].to_numpy(), iv["start2"].to_numpy()
-        if n < 2 or s1.dtype.kind not in "iu" or s2.dtype.kind not in "iu" or s1.min() < 0 or s2.min() < 0:
-            return iv.sort_values(["chrom1", "chrom2", "start1", "start2"])
-        codes, uniq = _factorize_pair(iv["chrom1"].to_numpy(), iv["chrom2"].to_numpy())
-        if (codes < 0).any():
-            return iv.sort_values(["chrom1", "chrom2", "start1", "start2"])
-        rank = np.empty(len(uniq), np.int64)
-        rank[np.argsort(np.asarray(uniq, dtype=object), kind="stable")] = np.arange(len(uniq))
-        a1 = s1.astype(np.int64) // max(int(np.gcd.reduce(s1)), 1)
-        a2 = s2.astype(np.int64) // max(int(np.gcd.reduce(s2)), 1)
-        width = [int(v).bit_length() for v in (len(uniq) ** 2 - 1, a1.max(), a2.max(), n - 1)]
-        if sum(width) > 63:
-            return iv.sort_values(["chrom1", "chrom2", "start1", "start2"])
-        key = rank[codes[:n]] * len(uniq) + rank[codes[n:]]
-        key = (((key << width[1] | a1) << width[2]) | a2) << width[3] | np.arange(n, dtype=np.int64)
-        if bool(np.all(key[1:] > key[:-1])):                 # already in order (a sorted BEDPE file): nothing to permute
-            self._sorted_codes = (iv.index.values, codes[:n], codes[n:], uniq)
-            return iv
-        if n >= 50_000:
-            from .engine import stable_argsort
-            # (multi-threaded radix sort of the library, stable: the row-number bits that make the keys unique need not be sorted)
-            order = stable_argsort(key >> width[3], sum(width[:3]))
+    def _process_frame(self, src):
+        """The reference's own steps on a pandas frame (:259-385) — the general path, for inputs the array path declines
+        (non-integer coordinates or resolution, missing chromosome names, negative starts, nothing left after the distance
+        filter).  The caller's frame is not written to: a shallow copy whose columns are only ever replaced whole."""
+        iv = src.copy(deep=False)
+        if self.kind == "bed":
+            iv["chrom"] = iv["chrom"].astype(str)
+            iv["center"] = (iv["start"] + iv["end"]) / 2
+            iv = expand(iv, self.flank, self.resolution, self.rescale_flank)
         else:
-            order = np.argsort(key)
-        c1s, c2s = codes[:n][order], codes[n:][order]
-        out = self._take_rows(iv, order, {"chrom1": c1s, "chrom2": c2s}, uniq)
-        self._sorted_codes = (out.index.values, c1s, c2s, uniq)
-        return out
+            # same columns / filter as the reference (:296-321), but the distance filter runs BEFORE the new
+            # columns are attached: filtering a freshly widened frame makes pandas re-consolidate every block
+            c1 = (iv["start1"].values + iv["end1"].values) / 2
+            c2 = (iv["start2"].values + iv["end2"].values) / 2
+            absd = np.abs(c2 - c1)
+            keep = (self.mindist <= absd) & (absd <= self.maxdist)
+            if not keep.all():
+                iv = iv[keep].reset_index(drop=True)
+                c1, c2 = c1[keep], c2[keep]
+            iv["chrom1"] = iv["chrom1"].astype(str)
+            iv["chrom2"] = iv["chrom2"].astype(str)
+            iv["center1"] = c1
+            iv["center2"] = c2
+            iv["distance"] = c2 - c1
+            iv = expand2D(iv, self.flank, self.resolution, self.rescale_flank)
+        self.intervals = iv
 
-    @staticmethod
-    def _take_rows(iv, order, coded, uniq):
-        """iv.take(order) with the chromosome columns rebuilt from their factorisation: gathering a million object pointers at
-        random positions is what made pandas' take of this frame slow (0.06 of the 0.11 s of the sort); indexing the handful of
-        distinct names by the sorted codes touches one small array.  Same frame: same columns, dtypes, index labels."""
-        from .engine import take_rows
-        names = np.asarray(uniq, dtype=object)
-        plain = [c for c in iv.columns if c not in coded]
-        taken = dict(zip(plain, take_rows([iv[c].to_numpy() for c in plain], order)))      # (one multi-threaded pass of the library)
-        cols = {c: (names[coded[c]] if c in coded else taken[c]) for c in iv.columns}
-        return pd.DataFrame(cols, index=iv.index.take(order), copy=False)
+        if iv.shape[0] == 0:
+            warnings.warn("No regions in features (maybe all below mindist?), returning empty output", stacklevel=2)
+            self.pos_stream = self.empty_stream
+            self.final_chroms = []
+            return
+
+        if self.nshifts > 0 and self.kind == "bedpe":
+            iv = self._control_regions(iv)   # nshifts=0: only tags kind="ROI"
+
+        if self.kind == "bed":
+            base = set(iv["chrom"])
+        else:
+            if self.local:
+                raise ValueError("Can't make local with both sides of loops defined")
+            u1, u2 = set(iv["chrom1"].unique().tolist()), set(iv["chrom2"].unique().tolist())
+            base = (u1 | u2) if self.trans else (u1 & u2)
+        self.intervals = iv
+        # (final_chroms are settled before the sort, as in the reference; an error below leaves the unsorted frame behind)
+        basechroms = natsorted(list(base))
+        final = basechroms if (isinstance(self.chroms, str) and self.chroms == "all") else \
+            natsorted(list(set(self.chroms).intersection(set(basechroms))))
+        if len(final):
+            self.intervals = self._binnify(iv)
+        self._finish_process(base)
 
     def _subset(self, df):
         if self.seed is not None:
@@ -490,7 +453,7 @@ class CoordCreator:
         return pd.DataFrame({"chrom": df["chrom1"].to_numpy(), "start": df[lo].to_numpy(), "end": df[hi].to_numpy()},
                             index=df.index)
 
-    def _binnify(self, intervals, presorted=False):
+    def _binnify(self, intervals):
         """Sort and convert expanded coordinates to bins (reference :489-527). pandas does the sort so the
         row order (hence the control-shift assignment) is the reference's."""
         res = self.resolution
@@ -498,8 +461,7 @@ class CoordCreator:
             intervals = intervals.sort_values(["chrom", "start"])
             sides = [""]
         else:
-            if not presorted:
-                intervals = intervals.sort_values(["chrom1", "chrom2", "start1", "start2"])
+            intervals = intervals.sort_values(["chrom1", "chrom2", "start1", "start2"])
             sides = ["1", "2"]
         for s in sides:
             intervals["stBin" + s] = np.floor(intervals["exp_start" + s] / res).astype(int)
@@ -629,74 +591,78 @@ class CoordCreator:
 
     # -- cached numpy views for fast region selection / grouping -------------------------------------------------
     def _cache(self):
-        """Integer chromosome codes and coordinate arrays of self.intervals (rebuilt if the frame is replaced)."""
-        c = getattr(self, "_fc", None)
-        if c is not None and c["id"] is self.intervals:
+        """Integer chromosome codes and coordinate arrays of the processed table (rebuilt if the table is replaced)."""
+        c = self._fc
+        tbl = self._tbl
+        if c is not None and c["id"] is tbl:
             return c
-        iv = self.intervals
-        c = {"id": iv, "cols": {}, "gc": {}}
+        codes, names = tbl.chrom_codes()
+        c = {"id": tbl, "cols": {}, "gc": {}, "chrom_code": {str(u): i for i, u in enumerate(names)}}
         if self.kind == "bedpe":
-            n = len(iv)
-            sc = getattr(self, "_sorted_codes", None)
-            probe = np.linspace(0, max(n - 1, 0), num=min(n, 256), dtype=np.int64)
-            if sc is not None and len(sc[1]) == n and n > 0 and np.array_equal(iv.index.values, sc[0]) and \
-                    all(iv["chrom1"].values[i] == sc[3][sc[1][i]] and iv["chrom2"].values[i] == sc[3][sc[2][i]] for i in probe):
-                c1, c2, uniq = sc[1], sc[2], sc[3]          # factorised when the pairs were sorted; same rows since
-            else:
-                codes, uniq = pd.factorize(np.concatenate([iv["chrom1"].values, iv["chrom2"].values]))
-                c1, c2 = codes[:n], codes[n:]
-            c["chrom_code"] = {str(u): i for i, u in enumerate(uniq)}
-            c["c1"], c["c2"] = c1, c2
+            c["c1"], c["c2"] = codes
             for k in ("start1", "end1", "start2", "end2"):
-                c[k] = iv[k].values
+                c[k] = tbl.col(k)
         else:
-            codes, uniq = pd.factorize(iv["chrom"].values)
-            c["chrom_code"] = {str(u): i for i, u in enumerate(uniq)}
-            c["c"] = codes
-            c["start"], c["end"] = iv["start"].values, iv["end"].values
+            c["c"] = codes[0]
+            c["start"], c["end"] = tbl.col("start"), tbl.col("end")
         self._fc = c
         return c
 
     def _col(self, name):
         c = self._cache()
-        if name not in c["cols"]:
-            v = self.intervals[name].values
-            if name.startswith(("stBin", "endBin")) and v.dtype.kind in "iu" and len(v) and \
-                    -2**31 < int(v.min()) and int(v.max()) < 2**31 - 2**24:
-                v = v.astype(np.int32)      # bins: every later pass (tile x nshifts, shift, filter) moves half the bytes
+        v = c["cols"].get(name)
+        if v is None:
+            is_bin = name.startswith(("stBin", "endBin"))
+            v = self._tbl.bins32(name) if is_bin else None
+            if v is None:
+                v = self._tbl.col(name)
+                if is_bin and v.dtype.kind in "iu" and len(v) and -2**31 < int(v.min()) and int(v.max()) < 2**31 - 2**24:
+                    v = v.astype(np.int32)      # bins: every later pass (tile x nshifts, shift, filter) moves half the bytes
             c["cols"][name] = v
-        return c["cols"][name]
+        return v
 
     def group_codes(self, name):
-        """(int codes over self.intervals rows, uniques) of a grouping column.  Paired bedpe columns X1 / X2 share
+        """(int codes over the table's rows, uniques) of a grouping column.  Paired bedpe columns X1 / X2 share
         one dictionary (needed when flipped snippets swap them); bed column X serves X1 and X2."""
         c = self._cache()
         if name in c["gc"]:
             return c["gc"][name]
-        iv = self.intervals
-        if self.kind == "bedpe" and name[-1:] in "12" and (name[:-1] + "1") in iv.columns and (name[:-1] + "2") in iv.columns:
-            a, b = iv[name[:-1] + "1"].values, iv[name[:-1] + "2"].values
-            codes, uniq = pd.factorize(np.concatenate([a, b]))
-            c["gc"][name[:-1] + "1"] = (codes[:len(a)].astype(np.int64), uniq)
-            c["gc"][name[:-1] + "2"] = (codes[len(a):].astype(np.int64), uniq)
+        tbl = self._tbl
+        stem = name[:-1]
+        if self.kind == "bedpe" and name[-1:] in "12" and tbl.has(stem + "1") and tbl.has(stem + "2"):
+            (ca, cb), uniq = tbl.group_codes(stem + "1", stem + "2")
+            c["gc"][stem + "1"] = (ca, uniq)
+            c["gc"][stem + "2"] = (cb, uniq)
         else:
-            codes, uniq = pd.factorize(iv[name].values)
-            c["gc"][name] = (codes.astype(np.int64), uniq)
+            (ca,), uniq = tbl.group_codes(name)
+            c["gc"][name] = (ca, uniq)
         return c["gc"][name]
 
     def _pair_bucket(self, k1, k2):
-        """Rows of self.intervals with (chrom1, chrom2) codes (k1, k2), ascending — from one stable sort of the
-        pair codes, so selecting the rows of every region (pair) costs O(rows of that pair), not O(all rows)."""
+        """Rows of the table with (chrom1, chrom2) codes (k1, k2), ascending: a slice of the sorted table (the array path sorts
+        by chromosome pair first, so a pair's rows are one run), else an index array from one stable sort of the pair codes —
+        selecting the rows of every region (pair) costs O(rows of that pair), not O(all rows)."""
         c = self._cache()
-        if "pair_order" not in c:
+        if "pair_nc" not in c:
             nc = len(c["chrom_code"]) + 1
             code = c["c1"].astype(np.int64) * nc + c["c2"]
-            c["pair_order"] = np.argsort(code, kind="stable")
-            c["pair_ptr"] = np.concatenate([[0], np.cumsum(np.bincount(code, minlength=nc * nc))])
             c["pair_nc"] = nc
+            runs = None
+            if self._tbl.sorted_pairs:
+                cuts = np.flatnonzero(code[1:] != code[:-1]) + 1
+                bounds = np.concatenate([[0], cuts, [len(code)]])
+                heads = code[bounds[:-1]] if len(code) else code[:0]
+                if len(np.unique(heads)) == len(heads):
+                    runs = {int(h): slice(int(a), int(b)) for h, a, b in zip(heads, bounds[:-1], bounds[1:])}
+            c["pair_runs"] = runs
+            if runs is None:
+                c["pair_order"] = np.argsort(code, kind="stable")
+                c["pair_ptr"] = np.concatenate([[0], np.cumsum(np.bincount(code, minlength=nc * nc))])
         if k1 < 0 or k2 < 0:
-            return np.zeros(0, np.int64)
+            return slice(0, 0)
         code = k1 * c["pair_nc"] + k2
+        if c["pair_runs"] is not None:
+            return c["pair_runs"].get(code, slice(0, 0))
         return c["pair_order"][c["pair_ptr"][code]:c["pair_ptr"][code + 1]]
 
     def _rows_pairs_region(self, region):
@@ -706,7 +672,7 @@ class CoordCreator:
         rows = self._pair_bucket(k, k)
         m = ((c["start1"][rows] >= start) & (c["end1"][rows] < end) & (c["start2"][rows] >= start)
              & (c["end2"][rows] < end))
-        return rows if m.all() else rows[m]
+        return rows if m.all() else _rows_where(rows, m)
 
     def _rows_trans_pairs(self, region1, region2):
         c1n, s1, e1 = region1
@@ -714,9 +680,11 @@ class CoordCreator:
         c = self._cache()
         k1, k2 = c["chrom_code"].get(str(c1n), -1), c["chrom_code"].get(str(c2n), -1)
         f = self._pair_bucket(k1, k2)
-        fwd = f[(c["start1"][f] >= s1) & (c["end1"][f] < e1) & (c["start2"][f] >= s2) & (c["end2"][f] < e2)]
+        fwd = _rows_where(f, (c["start1"][f] >= s1) & (c["end1"][f] < e1) & (c["start2"][f] >= s2) & (c["end2"][f] < e2))
         r = self._pair_bucket(k2, k1)
-        rev = r[(c["start2"][r] >= s1) & (c["end2"][r] < e1) & (c["start1"][r] >= s2) & (c["end1"][r] < e2)]
+        rev = _rows_where(r, (c["start2"][r] >= s1) & (c["end2"][r] < e1) & (c["start1"][r] >= s2) & (c["end1"][r] < e2))
+        if len(rev) == 0 and isinstance(f, slice) and len(fwd) == f.stop - f.start:
+            return f
         return np.concatenate([fwd, rev])      # same order as the reference's concat
 
     def _rows_region(self, region):
@@ -757,12 +725,12 @@ class CoordCreator:
 
     def region_weight(self, region1, region2=None):
         """Cheap, deterministic estimate of the number of ROI windows of a region (pair): what the ranks balance."""
-        if len(self.intervals) == 0 or not hasattr(self, "kind"):
+        if not hasattr(self, "kind") or self._tbl.n == 0:
             return 0
         if self.kind == "bedpe":
             rows = self._rows_trans_pairs(tuple(region1), tuple(region2)) if self.trans \
                 else self._rows_pairs_region(tuple(region1))
-            return len(rows)
+            return _nrows(rows)
         nl = len(self._rows_region(tuple(region1)))
         if self.local:
             return nl
@@ -778,17 +746,17 @@ class CoordCreator:
         (reference get_intervals_stream :716-746 / get_combinations :598-714) up to, not including,
         ``modify_2Dintervals_func`` and ``assign_groups``.
         """
-        if len(self.intervals) == 0 or not hasattr(self, "kind") or self.pos_stream == self.empty_stream:
+        if not hasattr(self, "kind") or self._tbl.n == 0 or self.pos_stream == self.empty_stream:
             return None
         nshifts = self.nshifts * bool(control)
-        have = set(self.intervals.columns)
+        have = set(self._tbl.names)
         if self.kind == "bedpe":
             rows = self._rows_trans_pairs(tuple(region1), tuple(region2)) if self.trans \
                 else self._rows_pairs_region(tuple(region1))
-            if len(rows) == 0:
+            if _nrows(rows) == 0:
                 return None
             keep = self._needed(columns)
-            names = list(self.intervals.columns) if keep is None else \
+            names = list(self._tbl.names) if keep is None else \
                 [c for c in keep if c in have or (c.startswith("_gc_") and c[4:] in have)]
             return self._control_cols(_Cols(self._take(rows, names)), nshifts)
         # ---- bed: combinations ----
@@ -798,14 +766,14 @@ class CoordCreator:
 
     def _combination_table(self, rows_l, rows_r, nshifts, columns):
         """Windows of all feature pairs (left feature from rows_l, right one from rows_r; row ids into self.intervals)."""
-        have = set(self.intervals.columns)
+        have = set(self._tbl.names)
         want = None if columns is None else set(columns) | {"center1", "center2"}
 
         def side(rows, s):
             if want is None:
-                names = list(self.intervals.columns)
+                names = list(self._tbl.names)
             else:
-                names = [c for c in self.intervals.columns if c + s in want or c in ("stBin", "endBin", "center")]
+                names = [c for c in self._tbl.names if c + s in want or c in ("stBin", "endBin", "center")]
                 names += ["_gc_" + w[4:-1] for w in want if w.startswith("_gc_") and w.endswith(s) and w[4:-1] in have]
             return self._take(rows, names, suffix=s)
 
@@ -833,7 +801,7 @@ class CoordCreator:
             # features sorted by centre (the usual BED case): the separation at offset i only grows with i, so the first
             # offset at which every pair is beyond maxdist ends the walk (the reference keeps looping; it finds nothing there)
             ordered = m > 1 and bool(np.all(c1[1:] >= c1[:-1]))
-            for i in range(1, min(self.intervals.shape[0], m)):
+            for i in range(1, min(self._tbl.n, m)):
                 k = m - i
                 dist = c2[i:i + k] - c1[:k]
                 ok = (self.mindist <= np.abs(dist)) & (np.abs(dist) <= self.maxdist)
@@ -926,10 +894,10 @@ def _make_viewframe(view_df, chromsizes):
     df = df[["chrom", "start", "end", "name"]].reset_index(drop=True)
     if df["name"].duplicated().any():
         raise ValueError("view_df is not a valid viewframe: region names are not unique")
-    for _, r in df.iterrows():
-        if r["chrom"] not in chromsizes.index or r["start"] < 0 or r["end"] > int(chromsizes[r["chrom"]]) \
-                or r["start"] >= r["end"]:
-            raise ValueError(f"view_df is not a valid viewframe or incompatible: region {tuple(r)} out of bounds")
+    sizes = {str(c): int(v) for c, v in zip(chromsizes.index, chromsizes.values)}
+    for r in zip(df["chrom"].tolist(), df["start"].tolist(), df["end"].tolist(), df["name"].tolist()):
+        if r[0] not in sizes or r[1] < 0 or r[2] > sizes[r[0]] or r[1] >= r[2]:
+            raise ValueError(f"view_df is not a valid viewframe or incompatible: region {r} out of bounds")
     return df
 
 
@@ -1073,41 +1041,58 @@ class PileUpper:
             need = {"region1", "region2", self.expected_value_col}
             if not isinstance(exp, pd.DataFrame) or not need.issubset(exp.columns):
                 raise ValueError("provided expected is not valid")
-            exp = exp[exp["region1"].isin(self.view_df["name"]) & exp["region2"].isin(self.view_df["name"])] \
-                .reset_index(drop=True)
             if self.control:
                 warnings.warn("Can't do both expected and control shifts; defaulting to expected", stacklevel=2)
                 self.control = False
+            # rows of the table by view region, without building the filtered frames (a by-diagonal table has one row per
+            # region and diagonal: 3e5 rows for a genome; the frames `expected_df` names are assembled on first access)
+            names = self.view_df["name"].tolist()
+            where = {nm: i for i, nm in enumerate(names)}
+
+            def view_index(col):
+                from .engine import factorize_objects
+                codes, uniq = factorize_objects(np.ascontiguousarray(np.asarray(exp[col].to_numpy(), dtype=object)))
+                lut = np.array([where.get(u, -1) for u in uniq] + [-1], np.int64)
+                return lut[codes]
+
+            v1, v2 = view_index("region1"), view_index("region2")
+            inview = (v1 >= 0) & (v2 >= 0)
             if self.trans:
-                if (exp["region1"] == exp["region2"]).all() and len(exp):
+                if len(exp) and inview.any() and bool(np.all(v1[inview] == v2[inview])):
                     raise ValueError("provided expected is not valid")
-                self.expected_df = exp
+                self._expected_rows = inview
+                rows = np.flatnonzero(inview)
+                vals = exp[self.expected_value_col].to_numpy()[rows]
+                self._trans_expected = {}
+                for a, b, v in zip(v1[rows].tolist(), v2[rows].tolist(), vals.tolist()):
+                    self._trans_expected.setdefault((names[a], names[b]), []).append(v)
             else:
-                exp = exp[exp["region1"] == exp["region2"]].reset_index(drop=True)
                 if "dist" not in exp.columns:
                     raise ValueError("provided expected is not valid")
-                # by-diagonal vector of every view region in table order (ExpectedSnipper.select -> LazyToeplitz);
-                # one factorisation instead of a string comparison of the whole table per region
-                codes, uniq = pd.factorize(exp["region1"].values)
-                order = np.argsort(codes, kind="stable")
-                ptr = np.concatenate([[0], np.cumsum(np.bincount(codes, minlength=len(uniq)))])
-                where = {u: i for i, u in enumerate(uniq)}
-                values = exp[self.expected_value_col].values.astype(np.float64)
-                for name in self.view_df["name"]:
-                    i = where.get(name)
-                    if i is None or ptr[i + 1] == ptr[i]:
+                # by-diagonal vector of every view region in table order (ExpectedSnipper.select -> LazyToeplitz)
+                self._expected_rows = inview & (v1 == v2)
+                rows = np.flatnonzero(self._expected_rows)
+                vv = v1[rows]
+                order = np.argsort(vv, kind="stable")
+                ptr = np.concatenate([[0], np.cumsum(np.bincount(vv, minlength=len(names)))])
+                values = exp[self.expected_value_col].to_numpy()[rows].astype(np.float64)
+                for i, name in enumerate(names):
+                    if ptr[i + 1] == ptr[i]:
                         raise ValueError("provided expected is not valid")
                     self._expected_vectors[name] = values[order[ptr[i]:ptr[i + 1]]]
-                self.expected_df = exp
+            self._expected_src = exp
             self.expected = True
         self.view_df = self.view_df.set_index("name")
         self.view_df_extents = {}
         self._global_extents = {}
-        for region_name, region in self.view_df.iterrows():
-            lo, hi = self._aclr.extent((region["chrom"], region["start"], region["end"]))
-            chroffset = self._aclr.offset(region["chrom"])
+        self._region_tuples = {}
+        for region_name, chrom, start, end in zip(self.view_df.index.tolist(), self.view_df["chrom"].tolist(),
+                                                  self.view_df["start"].tolist(), self.view_df["end"].tolist()):
+            lo, hi = self._aclr.extent((chrom, start, end))
+            chroffset = self._aclr.offset(chrom)
             self.view_df_extents[region_name] = lo - chroffset, hi - chroffset
             self._global_extents[region_name] = (lo, hi, chroffset)
+            self._region_tuples[region_name] = (chrom, start, end)
 
         self.chroms = natsorted(list(set(self.CC.final_chroms) & set(self.clr.chromnames)))
         self.view_df = self.view_df[self.view_df["chrom"].isin(self.chroms)]
@@ -1167,9 +1152,24 @@ class PileUpper:
         }
 
     # -- small pieces kept from the reference API ------------------------------------------------------------
+    @property
+    def expected_df(self):
+        """The rows of the caller's expected table this pile-up uses (reference attribute): both regions in the view, and for
+        cis pile-ups region1 == region2.  Assembled on first access."""
+        if "_expected_df" not in self.__dict__:
+            self.__dict__["_expected_df"] = self._expected_src[self._expected_rows].reset_index(drop=True)
+        return self.__dict__["_expected_df"]
+
     def get_expected_trans(self, region1, region2):
-        sel = (self.expected_df["region1"] == region1) & (self.expected_df["region2"] == region2)
-        return self.expected_df.loc[sel, self.expected_value_col].item()
+        got = self._trans_expected.get((region1, region2), [])
+        if len(got) != 1:
+            raise ValueError("can only convert an array of size 1 to a Python scalar")
+        return got[0]
+
+    @property
+    def intervals(self):
+        """The CoordCreator's processed feature frame (the reference copies the attribute over, coolpup.py:838)."""
+        return self.CC.intervals
 
     def make_outmap(self):
         n = self.rescale_size if self.rescale else 2 * self.pad_bins + 1
@@ -1179,15 +1179,16 @@ class PileUpper:
         """(chrom, start, end) of a view region; cached — a trans pile-up asks 2 x 253 times."""
         cache = self.__dict__.setdefault("_region_tuples", {})
         if name not in cache:
-            cache[name] = tuple(self.view_df.loc[name, ["chrom", "start", "end"]])
+            cache[name] = tuple(self.view_df.loc[name, ["chrom", "start", "end"]].tolist())
         return cache[name]
 
     # -- host side of pileup_region: windows of one region (pair) as engine inputs ----------------------------
     def _region_pairs(self):
         if self.trans:
             r1, r2 = [], []
+            chrom_of = dict(zip(self.view_df.index.tolist(), self.view_df["chrom"].tolist()))
             for a, b in itertools.combinations(self.view_df.index, 2):
-                if self.view_df.loc[a, "chrom"] != self.view_df.loc[b, "chrom"]:
+                if chrom_of[a] != chrom_of[b]:
                     r1.append(a)
                     r2.append(b)
             return list(zip(r1, r2))
@@ -1196,9 +1197,9 @@ class PileUpper:
     def _group_source(self, g):
         """Column to carry for grouping by g: integer codes ('_gc_' + g) for string-like feature columns, the
         column itself otherwise; plus the decoder that turns a stored value back into the key element."""
-        iv = self.CC.intervals
+        tbl = self.CC._tbl
         base = g if self.CC.kind == "bedpe" else g[:-1]
-        if base in iv.columns and iv[base].dtype == object:
+        if tbl.has(base) and tbl.dtype(base) == object:
             uniq = self.CC.group_codes(g if self.CC.kind == "bedpe" else base)[1]
             return "_gc_" + g, (lambda i, u=uniq: u[i])
         return g, None
@@ -1311,7 +1312,7 @@ class PileUpper:
             return False
         if self.flip_negative_strand or getattr(self, "ignore_group_order", False):
             return False
-        if len(self.CC.intervals) == 0 or self.CC.pos_stream == self.CC.empty_stream:
+        if self.CC._tbl.n == 0 or self.CC.pos_stream == self.CC.empty_stream:
             return False
         is_banding = modify is bin_distance_intervals or \
             (isinstance(modify, partial) and modify.func is bin_distance_intervals)
@@ -1328,7 +1329,7 @@ class PileUpper:
         from . import engine as _engine
         CC = self.CC
         rows = CC._rows_trans_pairs(tuple(reg1), tuple(reg2)) if CC.trans else CC._rows_pairs_region(tuple(reg1))
-        n = len(rows)
+        n = _nrows(rows)
         if n == 0:
             return None
         st1, st2 = CC._col("stBin1")[rows], CC._col("stBin2")[rows]
@@ -1458,8 +1459,8 @@ class PileUpper:
             for region1, region2 in pairs:
                 reg1, reg2 = self._region_tuple(region1), self._region_tuple(region2)
                 rows = CC._rows_trans_pairs(tuple(reg1), tuple(reg2)) if CC.trans else CC._rows_pairs_region(tuple(reg1))
-                if len(rows):
-                    sizes.append(len(rows) * nsh)
+                if _nrows(rows):
+                    sizes.append(_nrows(rows) * nsh)
             if sum(sizes) >= 200_000:
                 ahead = CC._draw_ahead = _DrawAhead(CC, sizes)
         try:
@@ -1728,11 +1729,16 @@ class PileUpper:
         G, gid, order = plan["G"], plan["gid"], plan["order"]
         if plan["grouped"]:   # "all" of a grouped pile-up = sum of its groups (reference :1271-1282)
             for kind in (KIND_ROI, KIND_CONTROL):
-                members = [kind * G + gid[k] for k in order[kind] if not (isinstance(k, str) and k == "all")]
-                if members:
+                members = np.array([kind * G + gid[k] for k in order[kind] if not (isinstance(k, str) and k == "all")], np.int64)
+                if len(members):
                     a = kind * G + gid["all"]
+                    # groups numbered in output order (the usual case) and the whole kind present: the "all" tile itself still
+                    # holds zeros, so the members' sum in their order IS the sum over the kind's slice — no gather of every tile
+                    # (a by-window pile-up has one per feature)
+                    whole = len(members) == G - 1 and bool(np.all(np.diff(members) > 0)) and not acc["n"][a] \
+                        and not acc["sum"][a].any()
                     for name in ("sum", "num", "n", "cov_start", "cov_end"):
-                        acc[name][a] = acc[name][members].sum(axis=0)
+                        acc[name][a] = acc[name][kind * G:(kind + 1) * G].sum(axis=0) if whole else acc[name][members].sum(axis=0)
         self._merge_inf_cells(plan, acc)
         stripes = _collect_stripes(plan, acc) if (plan.get("stripe_jobs") or acc.get("stripe_jobs")) else None
         return finalize_pileups(self, acc, order, gid, G, plan["groupby"], plan["want_control"],
