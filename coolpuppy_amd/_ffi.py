@@ -95,6 +95,9 @@ _SIGNATURES = {
                                       C.c_void_p, C.c_int32]),
     "pup_host_factorize_ptr": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]),
     "pup_host_argsort": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "pup_host_sort_pairs": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                        C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "pup_host_take_rows": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
     "pup_host_group_tiles_runs": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

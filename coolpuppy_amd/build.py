@@ -19,8 +19,9 @@ SRC_WTU = os.path.join(_CSRC, "pup_wide_tu.hip")
 WIDE_PARTS = range(0, 9)                                 # lane shapes of the wide-window staged kernel (csrc/pup_wide.hpp: wide_shape_ch / _nch)
 N_STAGED_PARTS = 8                                       # = pup::kStagedParts (csrc/pup_staged_launch.hpp)
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "pup_hip.h")
-_KERNEL_HEADERS = [os.path.join(_CSRC, h) for h in ("pup_kernels.hpp", "pup_staged.hpp", "pup_staged_launch.hpp", "pup_wide.hpp")]
-DEPS = [SRC, SRC_HOST, SRC_TU, SRC_WTU, HEADER] + _KERNEL_HEADERS
+# (every header under csrc/: a new one must make the library stale without anybody remembering to list it — tests/test_abi.py)
+_KERNEL_HEADERS = sorted(os.path.join(_CSRC, h) for h in os.listdir(_CSRC) if h.endswith((".hpp", ".h")))
+DEPS = sorted(os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".cpp", ".hpp", ".h"))) + [HEADER]
 OUT = os.path.join(_HERE, "libpup_hip.so")
 _FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-result", "-pthread"]
 

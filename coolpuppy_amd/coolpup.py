@@ -668,11 +668,16 @@ class CoordCreator:
     def _rows_pairs_region(self, region):
         chrom, start, end = region
         c = self._cache()
+        memo = c.setdefault("rows_pairs", {})
+        hit = memo.get(region)
+        if hit is not None:
+            return hit
         k = c["chrom_code"].get(str(chrom), -1)
         rows = self._pair_bucket(k, k)
         m = ((c["start1"][rows] >= start) & (c["end1"][rows] < end) & (c["start2"][rows] >= start)
              & (c["end2"][rows] < end))
-        return rows if m.all() else _rows_where(rows, m)
+        memo[region] = out = rows if m.all() else _rows_where(rows, m)
+        return out
 
     def _rows_trans_pairs(self, region1, region2):
         c1n, s1, e1 = region1
@@ -693,11 +698,28 @@ class CoordCreator:
         k = c["chrom_code"].get(str(chrom), -1)
         return np.flatnonzero((c["c"] == k) & (c["start"] >= start) & (c["end"] < end))
 
+    def feature_ids(self):
+        """(uid, rep) of a BED table: uid[row] numbers the distinct (chrom, start, end) features, rep[u] is a row holding feature
+        u.  By-window pile-ups group every window under the feature on each of its sides (lib/puputils.py:218-223): the integer
+        stands in for the reference's (chrom, start, end) tuple until the output frame is written."""
+        c = self._cache()
+        if "uid" not in c:
+            order = np.lexsort((c["end"], c["start"], c["c"]))
+            cs, ss, es = c["c"][order], c["start"][order], c["end"][order]
+            new = np.ones(len(order), bool)
+            new[1:] = (cs[1:] != cs[:-1]) | (ss[1:] != ss[:-1]) | (es[1:] != es[:-1])
+            uid = np.empty(len(order), np.int64)
+            uid[order] = np.cumsum(new) - 1
+            c["uid"], c["uid_rep"] = uid, order[new]
+        return c["uid"], c["uid_rep"]
+
     def _take(self, rows, names, suffix=""):
-        """Column table of the given rows. '_gc_X' names yield the integer group codes of column X."""
+        """Column table of the given rows. '_gc_X' names yield the integer group codes of column X, '_uid' the feature ids."""
         out = {}
         for name in names:
-            if name.startswith("_gc_"):
+            if name == "_uid":
+                out[name + suffix] = self.feature_ids()[0][rows]
+            elif name.startswith("_gc_"):
                 out[name + suffix] = self.group_codes(name[4:])[0][rows]
             else:
                 out[name + suffix] = self._col(name)[rows]
@@ -775,6 +797,7 @@ class CoordCreator:
             else:
                 names = [c for c in self._tbl.names if c + s in want or c in ("stBin", "endBin", "center")]
                 names += ["_gc_" + w[4:-1] for w in want if w.startswith("_gc_") and w.endswith(s) and w[4:-1] in have]
+                names += ["_uid"] if "_uid" + s in want else []
             return self._take(rows, names, suffix=s)
 
         left, right = rows_l, rows_r
@@ -1225,7 +1248,7 @@ class PileUpper:
         if carry is not None and builtin:
             carry = list(carry)
             if by_window:
-                carry += ["_gc_chrom1", "start1", "end1", "_gc_chrom2", "start2", "end2"]
+                carry += ["_uid1", "_uid2"]
             if self.store_stripes:
                 carry += ["chrom1", "start1", "end1", "chrom2", "start2", "end2"]
             for g in groupby:
@@ -1289,11 +1312,11 @@ class PileUpper:
         elif by_window:
             # every snippet is counted once for the feature on each side (group_by_region, lib/puputils.py:218-223):
             # emit it twice, side 1 then side 2, keyed by (chrom, start, end) of that side's feature
-            chrom_u = self.CC.group_codes("chrom")[1]
+            # The key is the feature's number (CoordCreator.feature_ids) — the (chrom, start, end) tuple it stands for is written
+            # out by pileupsByWindowWithControl: a genome's worth of features made 10^5 tuples per pile-up
             two = lambda a, b: np.stack([a, b], axis=1).ravel()      # noqa: E731  interleave side 1 / side 2
-            kc = [two(tbl["_gc_chrom1"], tbl["_gc_chrom2"]), two(tbl["start1"], tbl["start2"]),
-                  two(tbl["end1"], tbl["end2"])]
-            codes, keys = _factorize_rows(kc, [lambda i, u=chrom_u: u[i], None, None])
+            codes, uniq = pd.factorize(two(tbl["_uid1"], tbl["_uid2"]))
+            codes, keys = codes.astype(np.int64), uniq.tolist()
             dup = np.repeat(np.arange(n), 2)
             return {"r0": r0[dup], "c0": c0[dup], "kind": tbl["kind"].astype(np.int8)[dup], "flip": flip[dup],
                     "group_codes": codes, "group_keys": keys, "n": 2 * n, "h": hh[dup], "w": ww[dup], "coords": None}
@@ -1560,7 +1583,9 @@ class PileUpper:
             keys_all = sorted(keys_all, key=band_rank)        # (stable: first-appearance order inside a band)
         gid = {k: i for i, k in enumerate(keys_all)}
         G = len(keys_all)
-        T = 2 * G
+        # (tile = kind * G + group; a pile-up of many groups without a control — by-window: a tile per feature — does not pay for a
+        # second, empty half of accumulators: their reduction, their 300 MB on the way back and through the finaliser)
+        T = G if (G > 64 and not want_control) else 2 * G
         # expected of every view region in ONE device table, so that a single engine call can span regions
         exp_table = None
         if self.expected:
@@ -1753,10 +1778,12 @@ class PileUpper:
         piles up again region by region; only cells touched by an inf are replaced, everything else keeps the
         one-pass sums.  Rare (needs expected == 0 under a non-zero pixel), so the second pass is off the fast path."""
         S = acc["sum"]
-        if not np.isinf(S).any():
+        G, gid, T = plan["G"], plan["gid"], plan["T"]
+        # every window is counted under "all" (the fold of the groups has happened): an inf anywhere shows there
+        alls = [t for t in (gid["all"], G + gid["all"]) if t < len(S)]
+        if np.isfinite(S[alls]).all() or not np.isinf(S).any():
             return
         from . import dist as _dist
-        G, gid, T = plan["G"], plan["gid"], plan["T"]
         nreg = plan["n_regions"]
         items = {}
         for it in plan["region_items"]:
@@ -1977,6 +2004,9 @@ class PileUpper:
             pups = self.pileupsWithControl(nproc=nproc, postprocess_func=group_by_region)
         else:
             pups = self.pileupsWithControl(nproc=nproc, _by_window=True)
+            grp = pups["group"].to_numpy()
+            if all(isinstance(g, (int, np.integer)) or (isinstance(g, str) and g == "all") for g in grp):
+                return self._by_window_frame(pups, grp)
         is_all = pups["group"].apply(lambda g: isinstance(g, str) and g == "all")
         coords = pd.DataFrame([("all", -1, -1) if a else tuple(g) for a, g in zip(is_all, pups["group"])],
                               index=pups.index, columns=["chrom", "start", "end"])
@@ -1990,6 +2020,33 @@ class PileUpper:
         key = pups["chrom"].map(lambda c: rank.get(c, len(rank)))
         pups = pups.assign(_k=key).sort_values(["_k", "start", "end"], kind="stable").drop(columns="_k")
         return pups.reset_index(drop=True)
+
+    def _by_window_frame(self, pups, grp):
+        """The by-window output frame from rows keyed by feature number: chrom / start / end columns in front, "all" as
+        ("all", -1, -1), rows in bioframe.sort_bedframe order (the view's chromosome order, then start, end; "all" — not in the
+        view — last).  The reference does this per row (coolpup.py:1729-1755)."""
+        n = len(grp)
+        is_all = np.fromiter((isinstance(g, str) for g in grp), bool, n)
+        u = np.fromiter((-1 if a else g for a, g in zip(is_all, grp)), np.int64, n)
+        _, rep = self.CC.feature_ids()
+        c = self.CC._cache()
+        names = np.asarray(list(c["chrom_code"]), dtype=object)
+        row = rep[np.maximum(u, 0)]
+        code = c["c"][row]
+        chrom = names[code]
+        chrom[is_all] = "all"
+        start = np.where(is_all, -1, c["start"][row]).astype(np.int64)
+        end = np.where(is_all, -1, c["end"][row]).astype(np.int64)
+        view_chroms = list(dict.fromkeys(self.view_df["chrom"]))
+        rank_of = {ch: i for i, ch in enumerate(view_chroms)}
+        rank = np.array([rank_of.get(ch, len(rank_of)) for ch in names.tolist()], np.int64)[code]
+        rank[is_all] = len(rank_of)
+        order = np.lexsort((end, start, rank))
+        cols = {"chrom": chrom[order], "start": start[order], "end": end[order]}
+        for name in pups.columns:
+            if name != "group":
+                cols[name] = pups[name].to_numpy()[order]
+        return pd.DataFrame(cols, copy=False)
 
     def _distance_edges(self, distance_edges):
         if not (isinstance(distance_edges, str) and distance_edges == "default"):

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <new>
 #include <thread>
 #include <atomic>
 #include <vector>
@@ -29,12 +30,19 @@ int n_workers(int64_t rows) {
 template <class F> void parallel_chunks(int64_t n, int workers, F&& f) {
     if (workers <= 1) { f(0, (int64_t)0, n); return; }
     std::vector<std::thread> th;
+    std::atomic<int> failed{0};
     th.reserve((size_t)workers);
-    for (int k = 0; k < workers; ++k) {
-        const int64_t a = n * k / workers, b = n * (k + 1) / workers;
-        th.emplace_back([&f, k, a, b] { f(k, a, b); });
+    try {
+        for (int k = 0; k < workers; ++k) {
+            const int64_t a = n * k / workers, b = n * (k + 1) / workers;
+            th.emplace_back([&f, &failed, k, a, b] { try { f(k, a, b); } catch (...) { failed.store(1); } });
+        }
+    } catch (...) {                       // a thread could not be started: let the started ones finish, then report (PUP_HOST_GUARD)
+        for (auto& t : th) t.join();
+        throw;
     }
     for (auto& t : th) t.join();
+    if (failed.load()) throw std::bad_alloc();
 }
 
 }  // namespace
@@ -57,7 +65,7 @@ PUP_EXPORT int pup_host_free(void* ptr) {
 // by round(shift * sign / resolution) bins (half-to-even, numpy's round).  A window is kept when it lies inside its
 // region(s): lo1 <= r0 and r0 + h <= hi1, same for columns.  Outputs are compacted in order; returns the number kept and
 // *n_roi_kept of them are ROI windows.  code (may be NULL) is carried along: code_out[k] = code of the window's ROI row.
-PUP_EXPORT int64_t pup_host_windows(const int32_t* st1, const int32_t* st2, const int32_t* code, int64_t n,
+static int64_t pup_host_windows_impl(const int32_t* st1, const int32_t* st2, const int32_t* code, int64_t n,
                                     const int32_t* shift, const int32_t* sign, int32_t nshifts, double resolution,
                                     int64_t off1, int64_t off2, int64_t lo1, int64_t hi1, int64_t lo2, int64_t hi2,
                                     int32_t h, int32_t w, int32_t* r0, int32_t* c0, int32_t* code_out, int64_t* n_roi_kept) {
@@ -112,7 +120,7 @@ PUP_EXPORT int64_t pup_host_windows(const int32_t* st1, const int32_t* st2, cons
 // iv.take(order) of a frame's numeric columns: dst[c][i] = src[c][order[i]], elements of esize[c] = 1, 2, 4 or 8 bytes, all columns
 // in one call, rows shared out to the workers.  (numpy gathers a column at a time on one thread: a random read per element —
 // seven columns of 10^6 rows were 55 of the 280 ms of a pile-up.)
-PUP_EXPORT int pup_host_take_rows(int32_t ncols, const void* const* src, void* const* dst, const int32_t* esize,
+static int pup_host_take_rows_impl(int32_t ncols, const void* const* src, void* const* dst, const int32_t* esize,
                                   const int64_t* order, int64_t n, int64_t n_src) {
     if (ncols < 0 || n < 0 || (ncols > 0 && n > 0 && (!src || !dst || !esize || !order))) return PUP_EINVAL;
     for (int c = 0; c < ncols; ++c) if (esize[c] != 1 && esize[c] != 2 && esize[c] != 4 && esize[c] != 8) return PUP_EINVAL;
@@ -137,33 +145,75 @@ PUP_EXPORT int pup_host_take_rows(int32_t ncols, const void* const* src, void* c
 // a name table): hashing the pointers costs ~3 ns each, hashing the strings through pandas' object table 17 ms per million.  The
 // caller merges distinct objects that compare equal (it factorises the `n_uniq` representatives themselves).  Returns n_uniq, or
 // -1 when there are more than max_uniq distinct pointers (the caller then takes the general way), -2 for bad arguments.
-PUP_EXPORT int64_t pup_host_factorize_ptr(const uintptr_t* ptrs, int64_t n, int32_t* codes, int64_t* first, int64_t max_uniq) {
-    if (n < 0 || max_uniq < 1 || (n > 0 && (!ptrs || !codes || !first))) return -2;
-    size_t cap = 64;
-    while (cap < (size_t)max_uniq * 4) cap <<= 1;
-    std::vector<uintptr_t> keys(cap, 0);
-    std::vector<int32_t> vals(cap, -1);
-    int64_t nu = 0;
-    uintptr_t last = 0; int32_t last_code = -1;                       // (runs of one value: the usual case after a sort by chromosome)
-    for (int64_t i = 0; i < n; ++i) {
-        const uintptr_t p = ptrs[i];
-        if (last_code >= 0 && p == last) { codes[i] = last_code; continue; }
+namespace {
+
+// open-addressing table pointer -> small code, in order of first appearance
+struct PtrTable {
+    std::vector<uintptr_t> keys; std::vector<int32_t> vals; std::vector<int64_t> first; std::vector<uintptr_t> uniq; size_t cap;
+    explicit PtrTable(size_t c) : keys(c, 0), vals(c, -1), cap(c) {}
+    // code of p (a new one when unseen); -1 when that would exceed max_uniq
+    int32_t code(uintptr_t p, int64_t at, int64_t max_uniq) {
         size_t h = (size_t)((p >> 4) * 0x9E3779B97F4A7C15ull) & (cap - 1);
         while (vals[h] >= 0 && keys[h] != p) h = (h + 1) & (cap - 1);
         if (vals[h] < 0) {
-            if (nu >= max_uniq) return -1;
-            keys[h] = p; vals[h] = (int32_t)nu; first[nu] = i; ++nu;
+            if ((int64_t)uniq.size() >= max_uniq) return -1;
+            keys[h] = p; vals[h] = (int32_t)uniq.size(); uniq.push_back(p); first.push_back(at);
         }
-        codes[i] = last_code = vals[h]; last = p;
+        return vals[h];
     }
-    return nu;
+};
+
+}  // namespace
+
+static int64_t pup_host_factorize_ptr_impl(const uintptr_t* ptrs, int64_t n, int32_t* codes, int64_t* first, int64_t max_uniq) {
+    if (n < 0 || max_uniq < 1 || (n > 0 && (!ptrs || !codes || !first))) return -2;
+    size_t cap = 64;
+    while (cap < (size_t)max_uniq * 4) cap <<= 1;
+    // every worker numbers the pointers of its share on its own (runs of one value — the usual case after a sort by chromosome —
+    // skip the table); the shares' dictionaries are then merged in order, which keeps the numbering that of first appearance
+    // over the whole array, and the shares' codes are renumbered.  (One thread: 7 ms per 10^6 pointers.)
+    const int workers = n_workers(n);
+    std::vector<PtrTable> tabs; tabs.reserve((size_t)workers);
+    for (int k = 0; k < workers; ++k) tabs.emplace_back(cap);
+    std::vector<int> over((size_t)workers, 0);
+    parallel_chunks(n, workers, [&](int k, int64_t a, int64_t b) {
+        PtrTable& t = tabs[(size_t)k];
+        uintptr_t last = 0; int32_t last_code = -1;
+        for (int64_t i = a; i < b; ++i) {
+            const uintptr_t p = ptrs[i];
+            if (last_code >= 0 && p == last) { codes[i] = last_code; continue; }
+            const int32_t c = t.code(p, i, max_uniq);
+            if (c < 0) { over[(size_t)k] = 1; return; }
+            codes[i] = last_code = c; last = p;
+        }
+    });
+    for (int k = 0; k < workers; ++k) if (over[(size_t)k]) return -1;
+    PtrTable all(cap);
+    std::vector<std::vector<int32_t>> remap((size_t)workers);
+    bool changed = false;
+    for (int k = 0; k < workers; ++k) {
+        const PtrTable& t = tabs[(size_t)k];
+        remap[(size_t)k].resize(t.uniq.size());
+        for (size_t j = 0; j < t.uniq.size(); ++j) {
+            const int32_t c = all.code(t.uniq[j], t.first[j], max_uniq);
+            if (c < 0) return -1;
+            remap[(size_t)k][j] = c; changed |= c != (int32_t)j;
+        }
+    }
+    if (changed)
+        parallel_chunks(n, workers, [&](int k, int64_t a, int64_t b) {
+            const int32_t* r = remap[(size_t)k].data();
+            for (int64_t i = a; i < b; ++i) codes[i] = r[codes[i]];
+        });
+    for (size_t j = 0; j < all.uniq.size(); ++j) first[j] = all.first[j];
+    return (int64_t)all.uniq.size();
 }
 
 // Stable argsort of n keys of `bits` significant bits: order[i] = index of the i-th smallest key, equal keys in index order
 // (numpy's argsort(kind="stable")) — a least-significant-digit radix sort, 11 bits per pass, rows shared out to the workers
 // (per-worker digit counts, one prefix over digits x workers, a stable scatter).  CoordCreator sorts 10^6 features by one packed
 // key per row (chromosome pair | start1 | start2): numpy's single-threaded sort of those was 13 ms of a pile-up.
-PUP_EXPORT int pup_host_argsort(const uint64_t* keys, int64_t n, int32_t bits, int64_t* order) {
+static int pup_host_argsort_impl(const uint64_t* keys, int64_t n, int32_t bits, int64_t* order) {
     if (n < 0 || bits < 0 || bits > 64 || (n > 0 && (!keys || !order))) return PUP_EINVAL;
     if (n == 0) return PUP_OK;
     constexpr int RB = 11, NB = 1 << RB;
@@ -198,6 +248,96 @@ PUP_EXPORT int pup_host_argsort(const uint64_t* keys, int64_t n, int32_t bits, i
         osrc = odst; odst = (odst == order) ? ob.data() : order;
     }
     return PUP_OK;
+}
+
+// CoordCreator.process for BEDPE features in one call (coolpuppy/coolpup.py:296-321 centres and the mindist / maxdist filter,
+// :489-527 the sort by (chrom1, chrom2, start1, start2)): which rows stay, in which order, and the coordinate / chromosome-code
+// columns in that order.  The numpy form was ~20 passes over the 10^6 rows (two gcd reductions among them); here: one pass
+// for the filter and the key ranges, one for the keys, the radix sort above, one gather.
+//   c = (start + end) / 2 in double, as numpy computes it; a row stays when mindist <= |c2 - c1| <= maxdist;
+//   key = (rank[c1] * nu + rank[c2]) | start1 / g1 | start2 / g2   (g: the greatest common divisor of the kept starts — bin-aligned
+//   anchors need fewer bits), sorted stably: rows[i] = source row of sorted row i.
+// Returns the number of rows kept; -1 bad arguments; -6 (PUP_ENOTSUP) when a start is negative, a code is out of range or the
+// key does not fit 63 bits — the caller then sorts the general way.  *flags: bit 0 = the filter dropped rows, bit 1 = the kept
+// rows were not in order already.
+static int64_t pup_host_sort_pairs_impl(const int64_t* s1, const int64_t* e1, const int64_t* s2, const int64_t* e2,
+                                       const int32_t* c1, const int32_t* c2, int64_t n, const int64_t* rank, int32_t nu,
+                                       double mindist, double maxdist, int64_t* rows, int64_t* s1o, int64_t* e1o, int64_t* s2o,
+                                       int64_t* e2o, int32_t* c1o, int32_t* c2o, int32_t* flags) {
+    if (n < 0 || nu < 1 || !rank || !flags || (n > 0 && (!s1 || !e1 || !s2 || !e2 || !c1 || !c2 || !rows || !s1o || !e1o || !s2o || !e2o || !c1o || !c2o)))
+        return PUP_EINVAL;
+    *flags = 0;
+    if (n == 0) return 0;
+    const int workers = n_workers(n);
+    struct Part { int64_t kept = 0, max1 = 0, max2 = 0, g1 = 0, g2 = 0; int bad = 0; };
+    std::vector<Part> part((size_t)workers);
+    auto stays = [&](int64_t i) {
+        const double a = (double)(s1[i] + e1[i]) / 2.0, b = (double)(s2[i] + e2[i]) / 2.0, d = std::fabs(b - a);
+        return mindist <= d && d <= maxdist;
+    };
+    auto gcd64 = [](int64_t a, int64_t b) { while (b) { const int64_t t = a % b; a = b; b = t; } return a; };
+    parallel_chunks(n, workers, [&](int k, int64_t a, int64_t b) {
+        Part p;
+        for (int64_t i = a; i < b; ++i) {
+            if (!stays(i)) continue;
+            if (s1[i] < 0 || s2[i] < 0 || c1[i] < 0 || c1[i] >= nu || c2[i] < 0 || c2[i] >= nu) { p.bad = 1; break; }
+            ++p.kept;
+            p.max1 = std::max(p.max1, s1[i]); p.max2 = std::max(p.max2, s2[i]);
+            if (p.g1 != 1) p.g1 = gcd64(s1[i], p.g1);
+            if (p.g2 != 1) p.g2 = gcd64(s2[i], p.g2);
+        }
+        part[(size_t)k] = p;
+    });
+    int64_t kept = 0, max1 = 0, max2 = 0, g1 = 0, g2 = 0;
+    std::vector<int64_t> at((size_t)workers + 1, 0);
+    for (int k = 0; k < workers; ++k) {
+        const Part& p = part[(size_t)k];
+        if (p.bad) return -6;
+        at[(size_t)k + 1] = at[(size_t)k] + p.kept;
+        kept += p.kept; max1 = std::max(max1, p.max1); max2 = std::max(max2, p.max2);
+        g1 = gcd64(p.g1, g1); g2 = gcd64(p.g2, g2);
+    }
+    if (kept == 0) { *flags = 1; return 0; }
+    g1 = std::max<int64_t>(g1, 1); g2 = std::max<int64_t>(g2, 1);
+    auto bits = [](uint64_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b; };
+    const int w0 = bits((uint64_t)nu * (uint64_t)nu - 1), w1 = bits((uint64_t)(max1 / g1)), w2 = bits((uint64_t)(max2 / g2));
+    if (w0 + w1 + w2 > 63) return -6;
+    std::vector<uint64_t> key((size_t)kept);
+    std::vector<int64_t> idx((size_t)kept);
+    std::vector<int> unsorted((size_t)workers, 0);
+    parallel_chunks(n, workers, [&](int k, int64_t a, int64_t b) {
+        int64_t o = at[(size_t)k];
+        uint64_t prev = 0; bool have = false;
+        for (int64_t i = a; i < b; ++i) {
+            if (!stays(i)) continue;
+            const uint64_t kk = ((((uint64_t)rank[c1[i]] * (uint64_t)nu + (uint64_t)rank[c2[i]]) << w1 | (uint64_t)(s1[i] / g1)) << w2) | (uint64_t)(s2[i] / g2);
+            if (have && kk < prev) unsorted[(size_t)k] = 1;
+            prev = kk; have = true;
+            key[(size_t)o] = kk; idx[(size_t)o] = i; ++o;
+        }
+    });
+    bool permute = false;
+    for (int k = 0; k < workers; ++k) permute |= unsorted[(size_t)k] != 0;
+    for (int k = 1; k < workers && !permute; ++k) {                                  // across the shares' borders
+        const int64_t a = at[(size_t)k];
+        if (a > 0 && a < kept && part[(size_t)k].kept > 0 && key[(size_t)a] < key[(size_t)a - 1]) permute = true;
+    }
+    if (permute) {
+        std::vector<int64_t> ord((size_t)kept);
+        const int rc = pup_host_argsort(key.data(), kept, w0 + w1 + w2, ord.data());
+        if (rc != PUP_OK) return rc;
+        parallel_chunks(kept, workers, [&](int, int64_t a, int64_t b) { for (int64_t i = a; i < b; ++i) rows[i] = idx[(size_t)ord[(size_t)i]]; });
+    } else {
+        std::memcpy(rows, idx.data(), (size_t)kept * sizeof(int64_t));
+    }
+    parallel_chunks(kept, workers, [&](int, int64_t a, int64_t b) {
+        for (int64_t i = a; i < b; ++i) {
+            const int64_t r = rows[i];
+            s1o[i] = s1[r]; e1o[i] = e1[r]; s2o[i] = s2[r]; e2o[i] = e2[r]; c1o[i] = c1[r]; c2o[i] = c2[r];
+        }
+    });
+    *flags = (kept != n ? 1 : 0) | (permute ? 2 : 0);
+    return kept;
 }
 
 // ---- the reference's random draws, at memory speed ----------------------------------------------------------------------
@@ -248,7 +388,7 @@ std::vector<uint32_t>& mt_scratch() { static thread_local std::vector<uint32_t> 
 // out[i] = offset + scale * (low + d_i), d_i the i-th number np.random.randint(low, high, m) would draw from the legacy
 // generator whose state is (key[624], *pos); out: int32 or int64 elements (out_bytes), or NULL (draw and discard).  The state is advanced exactly as numpy
 // advances it.  Returns 0, or < 0 for bad arguments (needs 0 < high - low <= 2^32, 0 <= *pos <= 624).
-PUP_EXPORT int pup_host_mt_randint(uint32_t* key, int32_t* pos, int64_t low, int64_t high, int64_t m, int64_t scale,
+static int pup_host_mt_randint_impl(uint32_t* key, int32_t* pos, int64_t low, int64_t high, int64_t m, int64_t scale,
                                    int64_t offset, void* out_any, int32_t out_bytes) {
     if (out_any && out_bytes != 4 && out_bytes != 8) return PUP_EINVAL;
     int64_t* out = (out_any && out_bytes == 8) ? static_cast<int64_t*>(out_any) : nullptr;
@@ -331,7 +471,7 @@ PUP_EXPORT int pup_host_mt_randint(uint32_t* key, int32_t* pos, int64_t low, int
 // Parts whose tile array is NULL are RUN-CODED: windows [0, split[p]) of part p belong to tile tile_a[p], the rest to tile_b[p] (an
 // ungrouped region with controls: its ROI windows, then their shifted copies) — no per-window tile array is built or read for them,
 // and their windows move as two block copies.  (np.zeros + an in-place add of 1.1e7 tile numbers was 30 ms of a pile-up's host time.)
-PUP_EXPORT int pup_host_group_tiles_runs(int32_t n_parts, const int32_t* const* r0, const int32_t* const* c0,
+static int pup_host_group_tiles_runs_impl(int32_t n_parts, const int32_t* const* r0, const int32_t* const* c0,
                                          const int32_t* const* tile, const int64_t* split, const int32_t* tile_a, const int32_t* tile_b,
                                          const int64_t* len, int32_t T, int32_t* r0_out, int32_t* c0_out, int64_t* tile_ptr) {
     if (n_parts < 0 || T <= 0 || !tile_ptr || (n_parts > 0 && (!r0 || !c0 || !tile || !len))) return PUP_EINVAL;
@@ -380,4 +520,36 @@ PUP_EXPORT int pup_host_group_tiles(int32_t n_parts, const int32_t* const* r0, c
                                     int32_t* r0_out, int32_t* c0_out, int64_t* tile_ptr) {
     for (int p = 0; p < n_parts; ++p) if (tile && !tile[p]) return PUP_EINVAL;
     return pup_host_group_tiles_runs(n_parts, r0, c0, tile, nullptr, nullptr, nullptr, len, T, r0_out, c0_out, tile_ptr);
+}
+
+// No exception may cross the C boundary (a std::bad_alloc of the scratch vectors, a std::system_error of a thread that could not
+// be started inside a container's limits): the entry points catch everything and report an error code; the callers fall back to numpy.
+#define PUP_HOST_GUARD(call, err) try { return call; } catch (...) { return err; }
+
+PUP_EXPORT int64_t pup_host_windows(const int32_t* st1, const int32_t* st2, const int32_t* code, int64_t n, const int32_t* shift, const int32_t* sign, int32_t nshifts, double resolution, int64_t off1, int64_t off2, int64_t lo1, int64_t hi1, int64_t lo2, int64_t hi2, int32_t h, int32_t w, int32_t* r0, int32_t* c0, int32_t* code_out, int64_t* n_roi_kept) {
+    PUP_HOST_GUARD(pup_host_windows_impl(st1, st2, code, n, shift, sign, nshifts, resolution, off1, off2, lo1, hi1, lo2, hi2, h, w, r0, c0, code_out, n_roi_kept), PUP_ENOMEM);
+}
+
+PUP_EXPORT int pup_host_take_rows(int32_t ncols, const void* const* src, void* const* dst, const int32_t* esize, const int64_t* order, int64_t n, int64_t n_src) {
+    PUP_HOST_GUARD(pup_host_take_rows_impl(ncols, src, dst, esize, order, n, n_src), PUP_ENOMEM);
+}
+
+PUP_EXPORT int64_t pup_host_factorize_ptr(const uintptr_t* ptrs, int64_t n, int32_t* codes, int64_t* first, int64_t max_uniq) {
+    PUP_HOST_GUARD(pup_host_factorize_ptr_impl(ptrs, n, codes, first, max_uniq), -2);
+}
+
+PUP_EXPORT int pup_host_argsort(const uint64_t* keys, int64_t n, int32_t bits, int64_t* order) {
+    PUP_HOST_GUARD(pup_host_argsort_impl(keys, n, bits, order), PUP_ENOMEM);
+}
+
+PUP_EXPORT int64_t pup_host_sort_pairs(const int64_t* s1, const int64_t* e1, const int64_t* s2, const int64_t* e2, const int32_t* c1, const int32_t* c2, int64_t n, const int64_t* rank, int32_t nu, double mindist, double maxdist, int64_t* rows, int64_t* s1o, int64_t* e1o, int64_t* s2o, int64_t* e2o, int32_t* c1o, int32_t* c2o, int32_t* flags) {
+    PUP_HOST_GUARD(pup_host_sort_pairs_impl(s1, e1, s2, e2, c1, c2, n, rank, nu, mindist, maxdist, rows, s1o, e1o, s2o, e2o, c1o, c2o, flags), PUP_ENOMEM);
+}
+
+PUP_EXPORT int pup_host_mt_randint(uint32_t* key, int32_t* pos, int64_t low, int64_t high, int64_t m, int64_t scale, int64_t offset, void* out_any, int32_t out_bytes) {
+    PUP_HOST_GUARD(pup_host_mt_randint_impl(key, pos, low, high, m, scale, offset, out_any, out_bytes), PUP_ENOMEM);
+}
+
+PUP_EXPORT int pup_host_group_tiles_runs(int32_t n_parts, const int32_t* const* r0, const int32_t* const* c0, const int32_t* const* tile, const int64_t* split, const int32_t* tile_a, const int32_t* tile_b, const int64_t* len, int32_t T, int32_t* r0_out, int32_t* c0_out, int64_t* tile_ptr) {
+    PUP_HOST_GUARD(pup_host_group_tiles_runs_impl(n_parts, r0, c0, tile, split, tile_a, tile_b, len, T, r0_out, c0_out, tile_ptr), PUP_ENOMEM);
 }

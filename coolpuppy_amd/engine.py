@@ -510,9 +510,32 @@ def stable_argsort(keys, bits):
     """np.argsort(keys, kind="stable") for non-negative integer keys below 2**bits, by the library's multi-threaded radix sort."""
     keys = np.ascontiguousarray(keys).view(np.uint64) if np.asarray(keys).dtype.itemsize == 8 else np.ascontiguousarray(keys, np.uint64)
     order = np.empty(keys.shape[0], np.int64)
-    if _ffi.lib().pup_host_argsort(_ptr(keys), keys.shape[0], int(bits), _ptr(order)) != 0:
+    rc = _ffi.lib().pup_host_argsort(_ptr(keys), keys.shape[0], int(bits), _ptr(order))
+    if rc == -2:                             # PUP_ENOMEM: no scratch memory / no thread to be had — numpy does the same sort
+        return np.argsort(keys, kind="stable")
+    if rc != 0:
         raise ValueError("pup_host_argsort: bad arguments")
     return order
+
+
+def sort_pairs(s1, e1, s2, e2, c1, c2, rank, mindist, maxdist):
+    """pup_host_sort_pairs: the distance filter and the (chrom1, chrom2, start1, start2) sort of a BEDPE table in one call.
+    s1 .. e2: int64 columns, c1 / c2: int32 chromosome codes, rank[code]: the chromosome's place in sort order.  Returns None when
+    the library declines (negative starts, keys beyond 63 bits, no scratch memory), else (rows, s1, e1, s2, e2, c1, c2, filtered,
+    permuted): rows[i] = source row of sorted row i, the columns in sorted order."""
+    n = s1.shape[0]
+    rank = _as(rank, np.int64)
+    cols = [_as(v, np.int64) for v in (s1, e1, s2, e2)] + [_as(v, np.int32) for v in (c1, c2)]
+    rows = np.empty(n, np.int64)
+    outs = [np.empty(n, np.int64) for _ in range(4)] + [np.empty(n, np.int32) for _ in range(2)]
+    flags = C.c_int32(0)
+    kept = _ffi.lib().pup_host_sort_pairs(*[_ptr(v) for v in cols], n, _ptr(rank), int(rank.shape[0]), float(mindist), float(maxdist),
+                                          _ptr(rows), *[_ptr(v) for v in outs], C.byref(flags))
+    if kept < 0:
+        if kept == -1:
+            raise ValueError("pup_host_sort_pairs: bad arguments")
+        return None
+    return (rows[:kept], *[v[:kept] for v in outs], bool(flags.value & 1), bool(flags.value & 2))
 
 
 def take_rows(columns, order):
@@ -534,7 +557,9 @@ def take_rows(columns, order):
         ps = (C.c_void_p * len(idx))(*[c.ctypes.data for c in src])
         pd_ = (C.c_void_p * len(idx))(*[c.ctypes.data for c in dst])
         rc = _ffi.lib().pup_host_take_rows(len(idx), ps, pd_, _ptr(np.array(es, np.int32)), _ptr(order), n, n_src)
-        if rc != 0:
+        if rc == -2:                         # PUP_ENOMEM (no thread to be had): numpy gathers the columns
+            dst = [c[order] for c in src]
+        elif rc != 0:
             raise IndexError("take_rows: index out of bounds")
         for j, o in zip(idx, dst):
             out[j] = o

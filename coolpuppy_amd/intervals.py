@@ -143,8 +143,9 @@ class ArrayTable:
     """Columns of the processed table, produced on demand from the source frame (see the module docstring)."""
     lazy = True
 
-    def __init__(self, src, kind, keep, order, n, ready, codes, chrom_names, resolution, flank, rescale_flank, tag_kind):
-        self.src, self.kind, self.keep, self.order, self.n = src, kind, keep, order, int(n)
+    def __init__(self, src, kind, rows, filtered, n, ready, codes, chrom_names, resolution, flank, rescale_flank, tag_kind):
+        # rows[i] = source row of table row i (None: the source rows as they are); filtered: the distance filter dropped rows
+        self.src, self.kind, self.rows, self.filtered, self.n = src, kind, rows, bool(filtered), int(n)
         self._cols = dict(ready)                 # sorted columns worked out so far: starts / ends (int64)
         self._codes = codes                      # chromosome codes per side, sorted rows
         self.chrom_names = list(chrom_names)
@@ -179,10 +180,8 @@ class ArrayTable:
         return ("1", "2") if self.kind == "bedpe" else ("",)
 
     def _gather(self, v):
-        if self.keep is not None:
-            v = v[self.keep]
-        if self.order is not None:
-            v = _take([v], self.order)[0] if isinstance(v, np.ndarray) else v.take(self.order)
+        if self.rows is not None:
+            v = _take([v], self.rows)[0] if isinstance(v, np.ndarray) else v.take(self.rows)
         return v
 
     def _cbin(self, s):
@@ -192,13 +191,24 @@ class ArrayTable:
         return (self.col("start" + s) + self.col("end" + s)) // (2 * self.resolution)
 
     def bins32(self, name):
-        """stBin* / endBin* as int32 (what the window passes consume); None when a bin does not fit."""
+        """stBin* / endBin* as int32 (what the window passes consume), worked out without an int64 detour; None when a bin does
+        not fit or the frame has been materialised."""
         v = self._bins32.get(name)
-        if v is None and name in self._derived and name[:5] in ("stBin", "endBi"):
-            full = self.col(name)
-            if len(full) and not (-2**31 < int(full.min()) and int(full.max()) < 2**31 - 2**24):
+        if v is None and self._frame is None and name in self._derived and name[:5] in ("stBin", "endBi"):
+            s = name[-1] if name[-1] in "12" else ""
+            if self.rescale_flank is not None:
+                full = self.col(name)
+                if len(full) and not (-2**31 < int(full.min()) and int(full.max()) < 2**31 - 2**24):
+                    return None
+                v = self._bins32[name] = full.astype(np.int32)
+                return v
+            cb = self._cbin(s)
+            if len(cb) and not (-2**30 < int(cb.min()) and int(cb.max()) < 2**30):
                 return None
-            v = self._bins32[name] = full.astype(np.int32)
+            cb = cb.astype(np.int32)
+            pad = np.int32(int(self.flank) // self.resolution)
+            self._bins32["stBin" + s], self._bins32["endBin" + s] = cb - pad, cb + (pad + np.int32(1))
+            v = self._bins32[name]
         return v
 
     def col(self, name):
@@ -285,8 +295,16 @@ class ArrayTable:
         """The frame the reference's process() ends with: the caller's columns (chromosome names as str) filtered and sorted, the
         derived columns behind them — built once, in one construction."""
         if self._frame is None:
-            base = self.src.index if self.keep is None else pd.RangeIndex(int(np.count_nonzero(self.keep)))
-            index = base if self.order is None else base.take(self.order)
+            # index labels: the caller's, permuted — or, when the distance filter dropped rows, the kept rows renumbered from 0
+            # before the sort (the reference resets the index after its filter, coolpup.py:321)
+            if self.rows is None:
+                index = self.src.index
+            elif not self.filtered:
+                index = self.src.index.take(self.rows)
+            else:
+                kept = np.zeros(len(self.src), np.int64)
+                kept[self.rows] = 1
+                index = pd.Index((np.cumsum(kept) - 1)[self.rows])
             cols = {}
             for name in self.names:
                 v = self.col(name)
@@ -295,6 +313,17 @@ class ArrayTable:
                 cols[name] = v
             self._frame = pd.DataFrame(cols, index=index, copy=False)
         return self._frame
+
+
+def _same_objects(a, b):
+    """True when two object columns hold the same object in every row (a cis BEDPE table's chrom1 / chrom2 as pandas' readers
+    box them): one memcmp of the pointer arrays."""
+    if a.dtype != object or b.dtype != object or a.shape != b.shape or not (a.flags.c_contiguous and b.flags.c_contiguous):
+        return False
+    import ctypes
+    memcmp = ctypes.CDLL(None).memcmp
+    memcmp.argtypes, memcmp.restype = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t], ctypes.c_int
+    return a.nbytes == 0 or memcmp(a.ctypes.data, b.ctypes.data, a.nbytes) == 0
 
 
 def build_table(src, kind, resolution, flank, rescale_flank, mindist, maxdist, tag_kind):
@@ -317,54 +346,47 @@ def build_table(src, kind, resolution, flank, rescale_flank, mindist, maxdist, t
                 if v.dtype == np.uint64 and len(v) and int(v.max()) >= 2**62:
                     return None
                 v = v.astype(np.int64)
-            dst.append(v)
-    if any(len(v) and int(v.min()) < 0 for v in S):
+            dst.append(np.ascontiguousarray(v))
+    if any(len(v) and (int(v.max()) >= 2**52) for v in E):
         return None
-    if any(len(v) and (int(v.max()) >= 2**52) for v in S + E):
+    first = _string_codes(src["chrom" + sides[0]])
+    if first is None:
         return None
-    got = [_string_codes(src["chrom" + s]) for s in sides]
-    if any(g is None for g in got):
-        return None
-    codes = [got[0][0]]
-    names = got[0][1]
+    codes, names = [first[0]], first[1]
     if kind == "bedpe":
-        c2, names = _merge_dictionaries(got[1][0], names, got[1][1])
-        codes.append(c2)
-    keep = None
-    if kind == "bedpe":
-        c1 = (S[0] + E[0]) / 2
-        c2 = (S[1] + E[1]) / 2
-        absd = np.abs(c2 - c1)
-        ok = (mindist <= absd) & (absd <= maxdist)
-        if not ok.all():
-            keep = ok
-            S = [v[ok] for v in S]
-            E = [v[ok] for v in E]
-            codes = [v[ok] for v in codes]
-    n = len(S[0])
-    if n == 0:
-        return None
-    # the reference's sort: (chrom1, chrom2, start1, start2) / (chrom, start), stable, chromosome names in string order
+        if _same_objects(src["chrom1"].to_numpy(), src["chrom2"].to_numpy()):
+            codes.append(codes[0])
+        else:
+            second = _string_codes(src["chrom2"])
+            if second is None:
+                return None
+            c2, names = _merge_dictionaries(second[0], names, second[1])
+            codes.append(c2)
     nu = len(names)
     rank = np.empty(nu, np.int64)
     rank[np.argsort(np.asarray(names, dtype=object), kind="stable")] = np.arange(nu)
-    starts = [v // max(int(np.gcd.reduce(v)), 1) for v in S]              # bin-aligned anchors: fewer key bits
     if kind == "bedpe":
-        width = [int(v).bit_length() for v in (nu * nu - 1, starts[0].max(), starts[1].max())]
-        if sum(width) > 63:
+        # the reference's filter and sort — (chrom1, chrom2, start1, start2), stable, chromosome names in string order — in one
+        # call of the library
+        from .engine import sort_pairs
+        got = sort_pairs(S[0], E[0], S[1], E[1], codes[0], codes[1], rank, mindist, maxdist)
+        if got is None or len(got[0]) == 0:
             return None
-        key = ((rank[codes[0]] * nu + rank[codes[1]]) << width[1] | starts[0]) << width[2] | starts[1]
-    else:
-        width = [int(v).bit_length() for v in (nu - 1, starts[0].max())]
-        if sum(width) > 63:
+        rows, s1, e1, s2, e2, c1, c2, filtered, permuted = got
+        if s1.max() >= 2**52 or s2.max() >= 2**52:
             return None
-        key = rank[codes[0]] << width[1] | starts[0]
-    order = _stable_order(key, sum(width))
+        ready = {"start1": s1, "end1": e1, "start2": s2, "end2": e2}
+        return ArrayTable(src, kind, rows if (filtered or permuted) else None, filtered, len(rows), ready, (c1, c2), names, res, flank,
+                          rescale_flank, tag_kind)
+    # bed: (chrom, start), stable
+    if len(S[0]) and (int(S[0].min()) < 0 or int(S[0].max()) >= 2**52):
+        return None
+    starts = S[0] // max(int(np.gcd.reduce(S[0])), 1)              # bin-aligned anchors: fewer key bits
+    width = [int(v).bit_length() for v in (nu - 1, starts.max())]
+    if sum(width) > 63:
+        return None
+    order = _stable_order(rank[codes[0]] << width[1] | starts, sum(width))
+    code = codes[0].astype(np.int32)
     if order is not None:
-        moved = _take(S + E + [c.astype(np.int32) for c in codes], order)
-        S, E, codes = moved[:len(S)], moved[len(S):2 * len(S)], moved[2 * len(S):]
-    ready = {}
-    for s, a, b in zip(sides, S, E):
-        ready["start" + s], ready["end" + s] = a, b
-    return ArrayTable(src, kind, keep, order, n, ready, tuple(np.asarray(c) for c in codes), names, res, flank, rescale_flank,
-                      tag_kind)
+        S[0], E[0], code = _take([S[0], E[0], code], order)
+    return ArrayTable(src, kind, order, False, len(code), {"start": S[0], "end": E[0]}, (code,), names, res, flank, rescale_flank, tag_kind)

@@ -36,6 +36,8 @@
  *                                        _stream_snips, as one host pass  coolpuppy/coolpup.py:387-453, 1105-1114
  *   pup_host_factorize_ptr            <- the same sort's chromosome codes (object columns factorised by identity)
  *   pup_host_argsort                  <- the same sort's order (one packed key per row)
+ *   pup_host_sort_pairs               <- CoordCreator.process for BEDPE features: centres, mindist / maxdist filter and the sort
+ *                                        by (chrom1, chrom2, start1, start2)          coolpuppy/coolpup.py:296-321, 489-527
  *   pup_host_take_rows                <- the sort of the feature frame in CoordCreator._binnify  coolpuppy/coolpup.py:489-527
  *   pup_host_group_tiles(_runs)       <- the per-group dicts of accumulate_stream as a grouping of windows by tile
  *                                                                      coolpuppy/coolpup.py:1263-1283
@@ -367,6 +369,20 @@ int64_t pup_host_factorize_ptr(const uintptr_t* ptrs, int64_t n, int32_t* codes,
  * on one packed key per row.  Multi-threaded LSD radix sort.  PUP_OK / PUP_EINVAL.
  */
 int pup_host_argsort(const uint64_t* keys, int64_t n, int32_t bits, int64_t* order);
+
+/*
+ * pup_host_sort_pairs: what CoordCreator.process does to a BEDPE feature table before any window exists — centres
+ * c = (start + end) / 2 (double), the distance filter mindist <= |c2 - c1| <= maxdist (coolpuppy/coolpup.py:296-321), the stable
+ * sort by (chrom1, chrom2, start1, start2) of _binnify (:489-527; chromosome order given as rank[code], nu codes) — as one call:
+ * rows[i] = source row of sorted row i, and the six columns in that order (s1o .. c2o; capacity n each).  Returns the number of
+ * rows kept (0 .. n), PUP_EINVAL, or PUP_ENOTSUP when a start is negative, a code lies outside [0, nu) or the packed key
+ * (chromosome pair | start1 / gcd | start2 / gcd) exceeds 63 bits — the caller then takes its general path.  *flags: bit 0 = rows
+ * were dropped, bit 1 = the kept rows were out of order.
+ */
+int64_t pup_host_sort_pairs(const int64_t* s1, const int64_t* e1, const int64_t* s2, const int64_t* e2, const int32_t* c1,
+                            const int32_t* c2, int64_t n, const int64_t* rank, int32_t nu, double mindist, double maxdist,
+                            int64_t* rows, int64_t* s1o, int64_t* e1o, int64_t* s2o, int64_t* e2o, int32_t* c1o, int32_t* c2o,
+                            int32_t* flags);
 
 /*
  * pup_host_group_tiles: the windows of several regions gathered into ONE pup_accumulate call — stable grouping by tile id

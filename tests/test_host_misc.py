@@ -283,3 +283,39 @@ def test_coverage_restatement_matches_hand_derived_answers():
         got_cis, got_tot = po.coverage_numpy(indptr, col, cnt, kat.CHROM_OFFSET, igd)
         np.testing.assert_array_equal(got_cis, np.array(cis, float), err_msg=f"cis, ignore_diags={igd}")
         np.testing.assert_array_equal(got_tot, np.array(tot, float), err_msg=f"tot, ignore_diags={igd}")
+
+
+def test_library_sort_pairs_equals_the_numpy_filter_and_sort():
+    """pup_host_sort_pairs (centres, mindist / maxdist filter, stable sort by (chrom1, chrom2, start1, start2)) against numpy's
+    statement of the same steps: rows kept, their order (ties in file order), the gathered columns, the two flags; inputs it must
+    decline (negative start, keys beyond 63 bits)."""
+    from coolpuppy_amd import engine as E
+    rng = np.random.default_rng(11)
+    for n, nu, lo, hi, unit in ((0, 3, 0, np.inf, 1), (1, 1, 0, np.inf, 1), (5000, 4, 50_000, 900_000, 10_000),
+                                (200_000, 24, 230_000, np.inf, 10_000), (150_001, 7, 0, 2_000_000, 1)):
+        s1 = rng.integers(0, 20_000, n) * unit
+        s2 = s1 + rng.integers(-30, 200, n) * unit
+        s2 = np.abs(s2)
+        e1, e2 = s1 + rng.integers(1, 3, n) * unit, s2 + rng.integers(1, 3, n) * unit
+        c1 = rng.integers(0, nu, n).astype(np.int32)
+        c2 = np.where(rng.random(n) < 0.9, c1, rng.integers(0, nu, n)).astype(np.int32)
+        if n > 100:
+            s1[50:60], s2[50:60], c1[50:60], c2[50:60] = s1[40], s2[40], c1[40], c2[40]          # ties: file order
+        rank = rng.permutation(nu).astype(np.int64)
+        got = E.sort_pairs(s1, e1, s2, e2, c1, c2, rank, lo, hi)
+        ca, cb = (s1 + e1) / 2, (s2 + e2) / 2
+        keep = (lo <= np.abs(cb - ca)) & (np.abs(cb - ca) <= hi)
+        idx = np.flatnonzero(keep)
+        order = idx[np.lexsort((s2[idx], s1[idx], rank[c2[idx]], rank[c1[idx]]))]
+        rows, a1, b1, a2, b2, k1, k2, filtered, permuted = got
+        assert np.array_equal(rows, order)
+        for g, w in ((a1, s1), (b1, e1), (a2, s2), (b2, e2), (k1, c1), (k2, c2)):
+            assert np.array_equal(g, w[order]) and g.dtype == w.dtype
+        assert filtered == (len(idx) != n) and permuted == (not np.array_equal(order, idx))
+    s = np.arange(10, dtype=np.int64) * 1000
+    got = E.sort_pairs(s, s + 10, s + 5000, s + 5010, np.zeros(10, np.int32), np.zeros(10, np.int32), np.zeros(1, np.int64), 0, np.inf)
+    assert np.array_equal(got[0], np.arange(10)) and not got[7] and not got[8]                     # in order already
+    neg = s.copy(); neg[3] = -5
+    assert E.sort_pairs(neg, s + 10, s + 5000, s + 5010, np.zeros(10, np.int32), np.zeros(10, np.int32), np.zeros(1, np.int64), 0, np.inf) is None
+    big = rng.integers(0, 2**40, 1000) | 1                                                         # odd: no common divisor
+    assert E.sort_pairs(big, big + 1, big + 7, big + 9, np.zeros(1000, np.int32), np.zeros(1000, np.int32), np.zeros(1, np.int64), 0, np.inf) is None
