@@ -77,6 +77,9 @@ _SIGNATURES = {
     "pup_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pup_import": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pup_allreduce": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pup_pack_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "pup_unpack_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32]),
+    "pup_allgather_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "pup_rccl_path": (C.c_int, [C.c_char_p, C.c_size_t]),
     "pup_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "pup_get_stats": (C.c_int, [C.c_void_p, C.POINTER(PupStats)]),
@@ -91,6 +94,9 @@ _SIGNATURES = {
     "pup_host_windows": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
                                      C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                      C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    "pup_host_control_windows": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
+                                             C.c_double, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                             C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pup_host_mt_randint": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                       C.c_void_p, C.c_int32]),
     "pup_host_factorize_ptr": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]),

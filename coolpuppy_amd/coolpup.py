@@ -1486,18 +1486,100 @@ class PileUpper:
                     sizes.append(_nrows(rows) * nsh)
             if sum(sizes) >= 200_000:
                 ahead = CC._draw_ahead = _DrawAhead(CC, sizes)
+        fused = (owned is None and nsh > 0 and not grouped and not self.expected and not self.trans and not self.rescale
+                 and self._plain_pairs(modify, _by_window, False, groupby) and not os.environ.get("COOLPUPPY_AMD_NO_FUSED_WINDOWS"))
+        plan = None
         try:
-            batches = self._region_batches(pairs, owned, groupby, modify, columns, _by_window)
+            if fused:
+                plan = self._fused_plan(pairs)
+            else:
+                batches = self._region_batches(pairs, owned, groupby, modify, columns, _by_window)
         finally:
             if ahead is not None:
                 self.CC._draw_ahead = None
                 ahead.close()
+        if plan is not None:
+            return self.finalize_plan(plan, self.run_plan(plan))
         region_groups = None
         if owned is not None:
             # the global group table needs every region's group keys in region order: the ranks swap them (a few keys each)
             got = _dist.merge_dicts({i: self.region_groups(batches[i][2], grouped) for i in owned})
             region_groups = [got[i] for i in range(len(pairs))]
         return self._pile_and_finalize(batches, groupby, grouped=grouped, region_groups=region_groups)
+
+    def _fused_plan(self, pairs):
+        """The plan of an UNGROUPED pile-up of plain feature pairs with random-shift controls (the headline shape: BEDPE features,
+        nshifts > 0, no expected), written in one go: every region's ROI windows first — they need no draw —, then region after
+        region, as the reference's draws arrive (coolpup.py:420-436, same calls in the same order), its shifted copies, each pass
+        of the library (pup_host_windows / pup_host_control_windows: shift, bounds test :1105-1114, compaction) writing straight
+        behind the previous one in the page-locked arrays the engine call reads.  Same windows in the same (tile, region, stream)
+        order as region_snippets -> make_plan -> group_tiles produce, without the per-region arrays and the pass that gathers them
+        (88 MB written twice and page-faulted once per 10^7 windows)."""
+        from . import engine as _engine
+        from .engine import MODE_COV
+        CC = self.CC
+        W = 2 * self.pad_bins + 1
+        nsh = int(self.nshifts)
+        regs = []
+        for bi, (region1, region2) in enumerate(pairs):
+            rows = CC._rows_pairs_region(tuple(self._region_tuple(region1)))
+            regs.append((bi, region1, rows, _nrows(rows)))
+        total = sum(r[3] for r in regs)
+        st1c, st2c = CC._col("stBin1"), CC._col("stBin2")
+        if total and not (np.all(CC._col("endBin1") - st1c == W) and np.all(CC._col("endBin2") - st2c == W)):
+            raise ValueError("window size differs from 2*pad_bins+1")
+        r0, c0 = _engine.pinned_empty(total * (1 + nsh)), _engine.pinned_empty(total * (1 + nsh))
+        res = self.resolution
+        pos = 0
+        spans = {}                               # region -> [roi start, roi end, control start, control end] in r0 / c0
+        for bi, region1, rows, n in regs:
+            if n == 0:
+                continue
+            lo, hi, off = self._global_extents[region1]
+            k = _engine.host_windows_into(r0, c0, pos, st1c[rows], st2c[rows], None, None, 0, res, off, off, lo, hi, lo, hi, W, W)
+            spans[bi] = [pos, pos + k, 0, 0]
+            pos += k
+        roi_total = pos
+        for bi, region1, rows, n in regs:
+            if n == 0:
+                continue
+            shift, sign = CC._draw_raw(n * nsh)
+            lo, hi, off = self._global_extents[region1]
+            k = _engine.host_windows_into(r0, c0, pos, st1c[rows], st2c[rows], shift, sign, nsh, res, off, off, lo, hi, lo, hi, W, W,
+                                          controls_only=True)
+            spans[bi][2:] = [pos, pos + k]
+            pos += k
+            logger.info(f"{region1, region1}: {spans[bi][1] - spans[bi][0]}")
+        G, T = 1, 2
+        igd = int(self.ignore_diags)
+        mode = MODE_COV if self.coverage_norm else 0
+        live = [bi for bi in spans if spans[bi][1] - spans[bi][0] + spans[bi][3] - spans[bi][2] > 0]
+        calls = []
+        if live:
+            head = pairs[live[0]][0]
+            calls.append(_Call({"region1": head, "region2": head, "expected": None, "r0": r0[:pos], "c0": c0[:pos], "flip": None,
+                                "flip_from": None, "tile_ptr": np.array([0, roi_total, pos], np.int64), "ignore_diags": igd, "mode": mode}))
+
+        def region_items():
+            from .engine import RunTile
+            size = lambda m: np.broadcast_to(np.int32(W), (m,))      # noqa: E731
+            items = []
+            for bi in live:
+                a, b, c, d = spans[bi]
+                m = (b - a) + (d - c)
+                items.append((pairs[bi][0], pairs[bi][0], None, np.concatenate([r0[a:b], r0[c:d]]), np.concatenate([c0[a:b], c0[c:d]]),
+                              None, RunTile(b - a, m, 0, G), igd, mode, size(m), size(m), bi))
+            return items
+
+        plan = _Plan({"T": T, "G": G, "gid": {"all": 0}, "order": {KIND_ROI: ["all"], KIND_CONTROL: ["all"]}, "want_control": True,
+                      "groupby": [], "grouped": False, "calls": calls, "pad": self.pad_bins, "rescale": False,
+                      "n_regions": len(pairs),
+                      "region_groups": [({KIND_ROI: [], KIND_CONTROL: []} if bi in live else None) for bi in range(len(pairs))],
+                      "store_stripes": False, "expected_table": None, "stripe_jobs": [],
+                      "weight_name": self.clr_weight_name if self.clr_weight_name else None,
+                      "cov_name": self.coverage_norm if self.coverage_norm else None})
+        plan.lazy["region_items"] = region_items
+        return plan
 
     def _region_batches(self, pairs, owned, groupby, modify, columns, _by_window):
         batches = []
@@ -1726,7 +1808,12 @@ class PileUpper:
             return eng.fetch()
         if world > 1:
             _dist.check_same_plan(plan)
-        _dist.allreduce_engine(eng)
+        if world > 1 and plan["grouped"] and plan["T"] >= _dist.sparse_exchange_min_tiles():
+            # many groups (by-window: a tile per feature), each piled up where its region lives: the ranks swap the tiles they
+            # hold instead of all-reducing every accumulator ("all" is folded from the groups on the host, finalize_plan)
+            plan["exchange_bytes"] = _dist.exchange_tiles(eng, plan_tiles_with_windows(plan))
+        else:
+            _dist.allreduce_engine(eng)
         acc = eng.fetch()
         if plan.get("stripe_jobs") or (plan.get("store_stripes") and world > 1):
             # O(n*W) per-snippet output, not a reduction: a rank extracts the stripes of its own regions and the ranks
@@ -2110,6 +2197,14 @@ class PileUpper:
         return pups
 
 
+def plan_tiles_with_windows(plan):
+    """Sorted numbers of the tiles this process's engine calls pile windows into (what it contributes to a by-window exchange)."""
+    held = np.zeros(plan["T"], bool)
+    for c in plan["calls"]:
+        held |= np.diff(np.asarray(c["tile_ptr"])) > 0
+    return np.flatnonzero(held).astype(np.int32)
+
+
 def _engine_call(region1, region2, expected, r0, c0, flip, tile, T, igd, mode, extra=None):
     """One pup_accumulate call: snippets grouped by (tile, flip) — stable, so genome order is kept inside a
     group; within a tile the anti-transposed snippets come last (flip_from marks where they start)."""
@@ -2141,6 +2236,20 @@ def _engine_call(region1, region2, expected, r0, c0, flip, tile, T, igd, mode, e
     for k, v in (extra or {}).items():
         call[k] = np.ascontiguousarray(v, np.int32)
     return call
+
+
+class _Plan(dict):
+    """A plan whose rarely used entries (the per-region window tables the inf-cell merge replays) are built on first use."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.lazy = {}
+
+    def __missing__(self, key):
+        if key not in self.lazy:
+            raise KeyError(key)
+        val = self[key] = self.lazy[key]()
+        return val
 
 
 class _Call(dict):

@@ -61,6 +61,9 @@ struct pup_ctx {
     DevBuf<double> bal;
     DevBuf<unsigned long long> badbits;
     DevBuf<unsigned long long> nf_keys;      // pixels with a non-finite balanced value (see collect_nonfinite_kernel), sorted
+    DevBuf<int> xt_ids;                      // pup_pack_tiles / pup_unpack_tiles / pup_allgather_tiles: tile numbers on the device
+    DevBuf<double> xt_f64;                   // pup_allgather_tiles: the ranks' tile blocks (f64 / i64 parts)
+    DevBuf<long long> xt_i64;
     long long nf_count = 0;
     DevBuf<long long> nf_tp;                 // tile_ptr | flip_from of the current call, for the fix pass
     bool have_bal = false;
@@ -253,8 +256,9 @@ bool tiled_supported(int W) { return W >= 3 && W <= 31 && (W & 1); }
 // widths, in parallel): pup::launch_staged picks the one for a call.
 struct StagedGeo { int RSR, RSC, NW; };
 StagedGeo staged_geometry(int W, bool ooe, bool extra, bool small21) {
-    const bool big = W <= 21 && !extra && !(small21 && W == 21 && !ooe);
-    return StagedGeo{big ? 128 : ((small21 && W == 21 && !ooe && !extra) ? pup::kSmallRows : 64), 128, big ? 16 : 8};
+    const bool two_buffers = small21 && W == 21 && !ooe && !extra;     // tuning bit 7: two 64-row buffers, sixteen waves (pup_staged.hpp: DB)
+    const bool big = W <= 21 && !extra && !two_buffers;
+    return StagedGeo{big ? 128 : (two_buffers ? pup::kSmallRows : 64), 128, (big || two_buffers) ? 16 : 8};
 }
 
 // banded register-tile kernel: NCH column chunks of 16 cells -> windows up to 16*NCH wide
@@ -985,7 +989,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     const bool small21 = (c->variant & 128) != 0;
     const StagedGeo geo = staged_geometry(W, (mode & PUP_MODE_OOE) != 0, extra, small21);
     const int BR = geo.RSR - W + 1, BC = geo.RSC - W + 1;
-    const int G = c->n_cu * (geo.RSR * geo.RSC > pup::kSmallRows * 128 ? 1 : 2);            // persistent workgroups (one / two per CU by LDS)
+    const int G = c->n_cu * ((small21 || geo.RSR * geo.RSC > pup::kSmallRows * 128) ? 1 : 2);   // persistent workgroups (one / two per CU by LDS; the two-buffer geometry: one)
     // a staged region must serve this many windows on average to pay for its staging
     // (per-window division by expected makes the per-window kernel three times dearer: staging pays much earlier there)
     const long long min_per_block = ((mode & PUP_MODE_OOE) ? 2LL : 8LL) * (geo.RSR * geo.RSC) / (64 * 64);
@@ -2210,6 +2214,7 @@ namespace {
 struct RcclApi {
     void* lib = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
@@ -2244,6 +2249,7 @@ static bool load_rccl() {
     }
     if (!g_rccl.lib) return false;
     g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(g_rccl.lib, "ncclAllReduce"));
+    g_rccl.Broadcast = reinterpret_cast<decltype(g_rccl.Broadcast)>(dlsym(g_rccl.lib, "ncclBroadcast"));
     g_rccl.GroupStart = reinterpret_cast<decltype(g_rccl.GroupStart)>(dlsym(g_rccl.lib, "ncclGroupStart"));
     g_rccl.GroupEnd = reinterpret_cast<decltype(g_rccl.GroupEnd)>(dlsym(g_rccl.lib, "ncclGroupEnd"));
     g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(g_rccl.lib, "ncclGetErrorString"));
@@ -2275,6 +2281,122 @@ int pup_allreduce(pup_ctx* c, void* rccl_comm) {
     const int r2 = g_rccl.GroupEnd();
     if (r != 0 || r2 != 0) return fail(c, PUP_EHIP, "pup_allreduce: %s", err(r != 0 ? r : r2));
     return PUP_OK;                       // asynchronous: ordered on the context's stream like every other call
+}
+
+// ---- exchange of SOME tiles (by-window pile-ups: a tile per feature, non-zero on the rank that owns the feature's region) ---------
+// The reference merges only what a region produced (coolpuppy/coolpup.py:1511-1531: reduce(sum_pups) over the per-region dicts,
+// lib/puputils.py:218-223 puts a snippet under its features' keys).  A flat all-reduce of every accumulator moves T tiles per rank
+// whatever they hold — 550 MB for a genome's CTCF sites, nearly all zeros; here a rank sends the tiles it piled windows into, once.
+namespace pup {
+// block k of `out` = the packed accumulators of tile ids[k]: f64 [W2 sum | W cov_start | W cov_end], i64 [W2 num | n]
+static __global__ __launch_bounds__(256) void pack_tiles_kernel(const double* __restrict__ acc_f64, const long long* __restrict__ acc_i64, int T,
+                                                         int W2, int Lf, const int* __restrict__ ids, double* __restrict__ out_f64,
+                                                         long long* __restrict__ out_i64) {
+    const int k = blockIdx.y, t = ids[k], e = blockIdx.x * 256 + threadIdx.x;
+    if (e < Lf) out_f64[(size_t)k * Lf + e] = acc_f64[(size_t)t * Lf + e];
+    if (e < W2) out_i64[(size_t)k * (W2 + 1) + e] = acc_i64[(size_t)t * W2 + e];
+    if (e == W2) out_i64[(size_t)k * (W2 + 1) + W2] = acc_i64[(size_t)T * W2 + t];
+}
+// mode 0: overwrite, 1: add, 2: clear (the sources are not read)
+static __global__ __launch_bounds__(256) void unpack_tiles_kernel(double* __restrict__ acc_f64, long long* __restrict__ acc_i64, int T, int W2, int Lf,
+                                                           const int* __restrict__ ids, const double* __restrict__ in_f64,
+                                                           const long long* __restrict__ in_i64, int mode) {
+    const int k = blockIdx.y, t = ids[k], e = blockIdx.x * 256 + threadIdx.x;
+    if (e < Lf) { double& d = acc_f64[(size_t)t * Lf + e]; d = mode == 2 ? 0.0 : (mode == 1 ? d + in_f64[(size_t)k * Lf + e] : in_f64[(size_t)k * Lf + e]); }
+    if (e <= W2) {
+        long long& d = e < W2 ? acc_i64[(size_t)t * W2 + e] : acc_i64[(size_t)T * W2 + t];
+        const long long v = mode == 2 ? 0 : in_i64[(size_t)k * (W2 + 1) + e];
+        d = mode == 1 ? d + v : v;
+    }
+}
+}  // namespace pup
+
+// tile numbers to the device (validated: every id in [0, T)); at = offset into xt_ids
+static int send_tile_ids(pup_ctx* c, const int32_t* ids, int64_t n, const char* who) {
+    for (int64_t i = 0; i < n; ++i)
+        if (ids[i] < 0 || ids[i] >= c->T) return fail(c, PUP_ERANGE, "%s: tile %d outside [0, %d)", who, (int)ids[i], c->T);
+    HIPCHK(c, c->xt_ids.reserve((size_t)std::max<int64_t>(n, 1)));
+    if (n > 0) HIPCHK(c, hipMemcpyAsync(c->xt_ids.p, ids, (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));          // (the caller's array may be pageable)
+    return PUP_OK;
+}
+static void launch_unpack(pup_ctx* c, const int* d_ids, int64_t n, const double* f, const long long* i, int mode) {
+    const int W2 = c->W * c->W, Lf = W2 + 2 * c->W;
+    for (int64_t at = 0; at < n; at += 65535) {          // (grid.y limit)
+        const unsigned ny = (unsigned)std::min<int64_t>(65535, n - at);
+        hipLaunchKernelGGL(pup::unpack_tiles_kernel, dim3((unsigned)((Lf + 255) / 256), ny), dim3(256), 0, c->stream, c->acc_f64.p, c->acc_i64.p,
+                           c->T, W2, Lf, d_ids + at, f ? f + (size_t)at * Lf : nullptr, i ? i + (size_t)at * (W2 + 1) : nullptr, mode);
+    }
+}
+static void launch_pack(pup_ctx* c, const int* d_ids, int64_t n, double* f, long long* i) {
+    const int W2 = c->W * c->W, Lf = W2 + 2 * c->W;
+    for (int64_t at = 0; at < n; at += 65535) {
+        const unsigned ny = (unsigned)std::min<int64_t>(65535, n - at);
+        hipLaunchKernelGGL(pup::pack_tiles_kernel, dim3((unsigned)((Lf + 255) / 256), ny), dim3(256), 0, c->stream, (const double*)c->acc_f64.p,
+                           (const long long*)c->acc_i64.p, c->T, W2, Lf, d_ids + at, f + (size_t)at * Lf, i + (size_t)at * (W2 + 1));
+    }
+}
+
+int pup_pack_tiles(pup_ctx* c, const int32_t* tile_ids, int64_t n, void* dev_f64, void* dev_i64) {
+    if (!c) return PUP_EINVAL;
+    if (c->T <= 0) return fail(c, PUP_ESTATE, "pup_pack_tiles: call pup_reset first");
+    if (n < 0 || (n > 0 && (!tile_ids || !dev_f64 || !dev_i64))) return fail(c, PUP_EINVAL, "pup_pack_tiles: bad arguments");
+    int rc = bind(c); if (rc) return rc;
+    if (n == 0) return pup_sync(c);
+    rc = send_tile_ids(c, tile_ids, n, "pup_pack_tiles"); if (rc) return rc;
+    launch_pack(c, c->xt_ids.p, n, static_cast<double*>(dev_f64), static_cast<long long*>(dev_i64));
+    HIPCHK(c, hipGetLastError());
+    return pup_sync(c);
+}
+
+int pup_unpack_tiles(pup_ctx* c, const int32_t* tile_ids, int64_t n, const void* dev_f64, const void* dev_i64, int32_t mode) {
+    if (!c) return PUP_EINVAL;
+    if (c->T <= 0) return fail(c, PUP_ESTATE, "pup_unpack_tiles: call pup_reset first");
+    if (n < 0 || mode < 0 || mode > 2 || (n > 0 && (!tile_ids || (mode != 2 && (!dev_f64 || !dev_i64))))) return fail(c, PUP_EINVAL, "pup_unpack_tiles: bad arguments");
+    int rc = bind(c); if (rc) return rc;
+    if (n == 0) return PUP_OK;
+    rc = send_tile_ids(c, tile_ids, n, "pup_unpack_tiles"); if (rc) return rc;
+    launch_unpack(c, c->xt_ids.p, n, static_cast<const double*>(dev_f64), static_cast<const long long*>(dev_i64), mode);
+    HIPCHK(c, hipGetLastError());
+    return pup_sync(c);                                   // the sources may be released as soon as this returns
+}
+
+int pup_allgather_tiles(pup_ctx* c, void* rccl_comm, const int32_t* tile_ids, const int64_t* rank_ptr, int32_t n_ranks, int32_t my_rank) {
+    if (!c) return PUP_EINVAL;
+    if (!rccl_comm || !rank_ptr || n_ranks < 1 || my_rank < 0 || my_rank >= n_ranks) return fail(c, PUP_EINVAL, "pup_allgather_tiles: bad arguments");
+    if (c->T <= 0) return fail(c, PUP_ESTATE, "pup_allgather_tiles: call pup_reset first");
+    const int64_t total = rank_ptr[n_ranks];
+    if (rank_ptr[0] != 0 || total < 0 || (total > 0 && !tile_ids)) return fail(c, PUP_EINVAL, "pup_allgather_tiles: bad tile lists");
+    for (int r = 0; r < n_ranks; ++r) if (rank_ptr[r + 1] < rank_ptr[r]) return fail(c, PUP_EINVAL, "pup_allgather_tiles: bad tile lists");
+    if (!load_rccl() || !g_rccl.Broadcast) return fail(c, PUP_ENOTSUP, "pup_allgather_tiles: librccl.so could not be loaded");
+    int rc = bind(c); if (rc) return rc;
+    if (total == 0) return PUP_OK;
+    rc = send_tile_ids(c, tile_ids, total, "pup_allgather_tiles"); if (rc) return rc;
+    const size_t W2 = (size_t)c->W * c->W, Lf = W2 + 2 * (size_t)c->W, Li = W2 + 1;
+    HIPCHK(c, c->xt_f64.reserve((size_t)total * Lf)); HIPCHK(c, c->xt_i64.reserve((size_t)total * Li));
+    const int64_t a = rank_ptr[my_rank], mine = rank_ptr[my_rank + 1] - a;
+    // own tiles into this rank's block, then cleared: every listed tile becomes the sum of the blocks that list it, added in
+    // RANK order on every rank — the same doubles everywhere, also where regions (hence owners) of a feature overlap
+    if (mine > 0) {
+        launch_pack(c, c->xt_ids.p + a, mine, c->xt_f64.p + (size_t)a * Lf, c->xt_i64.p + (size_t)a * Li);
+        launch_unpack(c, c->xt_ids.p + a, mine, nullptr, nullptr, 2);
+    }
+    auto err = [&](int r) { return g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "rccl error"; };
+    int r = g_rccl.GroupStart();
+    for (int k = 0; k < n_ranks && r == 0; ++k) {
+        const int64_t b = rank_ptr[k], cnt = rank_ptr[k + 1] - b;
+        if (cnt == 0) continue;
+        r = g_rccl.Broadcast(c->xt_f64.p + (size_t)b * Lf, c->xt_f64.p + (size_t)b * Lf, (size_t)cnt * Lf, /*ncclFloat64*/ 8, k, rccl_comm, c->stream);
+        if (r == 0) r = g_rccl.Broadcast(c->xt_i64.p + (size_t)b * Li, c->xt_i64.p + (size_t)b * Li, (size_t)cnt * Li, /*ncclInt64*/ 4, k, rccl_comm, c->stream);
+    }
+    const int r2 = g_rccl.GroupEnd();
+    if (r != 0 || r2 != 0) return fail(c, PUP_EHIP, "pup_allgather_tiles: %s", err(r != 0 ? r : r2));
+    for (int k = 0; k < n_ranks; ++k) {
+        const int64_t b = rank_ptr[k], cnt = rank_ptr[k + 1] - b;
+        if (cnt > 0) launch_unpack(c, c->xt_ids.p + b, cnt, c->xt_f64.p + (size_t)b * Lf, c->xt_i64.p + (size_t)b * Li, 1);
+    }
+    HIPCHK(c, hipGetLastError());
+    return PUP_OK;                       // asynchronous, like pup_allreduce
 }
 
 int pup_set_profiling(pup_ctx* c, int enabled) {

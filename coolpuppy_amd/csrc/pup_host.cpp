@@ -45,6 +45,10 @@ template <class F> void parallel_chunks(int64_t n, int workers, F&& f) {
     if (failed.load()) throw std::bad_alloc();
 }
 
+// scratch vectors of the calling thread, kept between calls (a pile-up sorts its features once per call, always from the same thread)
+std::vector<uint64_t>& scratch_u64(int slot) { static thread_local std::vector<uint64_t> v[3]; return v[slot]; }
+std::vector<int64_t>& scratch_i64(int slot) { static thread_local std::vector<int64_t> v[3]; return v[slot]; }
+
 }  // namespace
 
 PUP_EXPORT int pup_host_alloc(void** ptr, size_t bytes) {
@@ -65,12 +69,14 @@ PUP_EXPORT int pup_host_free(void* ptr) {
 // by round(shift * sign / resolution) bins (half-to-even, numpy's round).  A window is kept when it lies inside its
 // region(s): lo1 <= r0 and r0 + h <= hi1, same for columns.  Outputs are compacted in order; returns the number kept and
 // *n_roi_kept of them are ROI windows.  code (may be NULL) is carried along: code_out[k] = code of the window's ROI row.
-static int64_t pup_host_windows_impl(const int32_t* st1, const int32_t* st2, const int32_t* code, int64_t n,
-                                    const int32_t* shift, const int32_t* sign, int32_t nshifts, double resolution,
-                                    int64_t off1, int64_t off2, int64_t lo1, int64_t hi1, int64_t lo2, int64_t hi2,
-                                    int32_t h, int32_t w, int32_t* r0, int32_t* c0, int32_t* code_out, int64_t* n_roi_kept) {
+// first_copy = 0: the ROI windows, then the copies; 1: the shifted copies only (pup_host_control_windows)
+static int64_t host_windows_from(int first_copy, const int32_t* st1, const int32_t* st2, const int32_t* code, int64_t n,
+                                 const int32_t* shift, const int32_t* sign, int32_t nshifts, double resolution,
+                                 int64_t off1, int64_t off2, int64_t lo1, int64_t hi1, int64_t lo2, int64_t hi2,
+                                 int32_t h, int32_t w, int32_t* r0, int32_t* c0, int32_t* code_out, int64_t* n_roi_kept) {
     if (n < 0 || nshifts < 0 || (n > 0 && (!st1 || !st2 || !r0 || !c0)) || (nshifts > 0 && n > 0 && (!shift || !sign))) return -1;
-    const int64_t total = n * (1 + (int64_t)nshifts);
+    const int64_t skip = first_copy ? n : 0;             // windows of the full sequence left out in front
+    const int64_t total = n * (1 + (int64_t)nshifts) - skip;
     const int workers = n_workers(total);
     // ONE pass: every worker writes the windows of its share at their uncompacted positions and counts the kept ones; nearly
     // always every window is kept (a control copy only falls off a chromosome's ends) and that is all.  Otherwise the shares
@@ -80,10 +86,11 @@ static int64_t pup_host_windows_impl(const int32_t* st1, const int32_t* st2, con
     for (int k = 0; k <= workers; ++k) lo[(size_t)k] = workers <= 1 ? (k ? total : 0) : total * k / workers;
     parallel_chunks(total, workers, [&](int k, int64_t a, int64_t b) {
         int64_t o = a, roi = 0;
-        int64_t i = a;
-        while (i < b) {
+        int64_t i = a + skip;                                                 // (i: position in the full sequence; o: where it is written)
+        const int64_t b_full = b + skip;
+        while (i < b_full) {
             const int64_t copy = i / n, row0 = i - copy * n;                  // (once per run of rows)
-            const int64_t run_end = std::min<int64_t>(b, (copy + 1) * n);
+            const int64_t run_end = std::min<int64_t>(b_full, (copy + 1) * n);
             for (int64_t row = row0; i < run_end; ++i, ++row) {
                 int64_t d = 0;
                 if (copy > 0) {
@@ -115,6 +122,24 @@ static int64_t pup_host_windows_impl(const int32_t* st1, const int32_t* st2, con
     }
     if (n_roi_kept) { int64_t s = 0; for (int64_t v : kept_roi) s += v; *n_roi_kept = s; }
     return kept[(size_t)workers];
+}
+
+static int64_t pup_host_windows_impl(const int32_t* st1, const int32_t* st2, const int32_t* code, int64_t n,
+                                     const int32_t* shift, const int32_t* sign, int32_t nshifts, double resolution,
+                                     int64_t off1, int64_t off2, int64_t lo1, int64_t hi1, int64_t lo2, int64_t hi2,
+                                     int32_t h, int32_t w, int32_t* r0, int32_t* c0, int32_t* code_out, int64_t* n_roi_kept) {
+    return host_windows_from(0, st1, st2, code, n, shift, sign, nshifts, resolution, off1, off2, lo1, hi1, lo2, hi2, h, w, r0, c0, code_out, n_roi_kept);
+}
+
+// The shifted control copies alone (capacity n * nshifts): a whole pile-up's windows can then be written where the engine call
+// wants them — every region's ROI windows first (no draw needed), then region after region its copies as the draws arrive —
+// straight into page-locked memory, without a per-region intermediate and the pass that gathers those by tile.
+static int64_t pup_host_control_windows_impl(const int32_t* st1, const int32_t* st2, const int32_t* code, int64_t n,
+                                             const int32_t* shift, const int32_t* sign, int32_t nshifts, double resolution,
+                                             int64_t off1, int64_t off2, int64_t lo1, int64_t hi1, int64_t lo2, int64_t hi2,
+                                             int32_t h, int32_t w, int32_t* r0, int32_t* c0, int32_t* code_out) {
+    if (nshifts <= 0 || n <= 0) return n < 0 || nshifts < 0 ? -1 : 0;
+    return host_windows_from(1, st1, st2, code, n, shift, sign, nshifts, resolution, off1, off2, lo1, hi1, lo2, hi2, h, w, r0, c0, code_out, nullptr);
 }
 
 // iv.take(order) of a frame's numeric columns: dst[c][i] = src[c][order[i]], elements of esize[c] = 1, 2, 4 or 8 bytes, all columns
@@ -219,8 +244,12 @@ static int pup_host_argsort_impl(const uint64_t* keys, int64_t n, int32_t bits, 
     constexpr int RB = 11, NB = 1 << RB;
     const int passes = std::max(1, (bits + RB - 1) / RB);
     const int workers = n_workers(n);
-    std::vector<uint64_t> ka((size_t)n), kb((size_t)n);
-    std::vector<int64_t> ob((size_t)n);
+    // (scratch kept between calls: three fresh 8 MB vectors per million keys cost more in page faults than the passes themselves)
+    std::vector<uint64_t>&ka = scratch_u64(0), &kb = scratch_u64(1);
+    std::vector<int64_t>& ob = scratch_i64(0);
+    if (ka.size() < (size_t)n) ka.resize((size_t)n);
+    if (kb.size() < (size_t)n) kb.resize((size_t)n);
+    if (ob.size() < (size_t)n) ob.resize((size_t)n);
     std::vector<int64_t> hist((size_t)workers * NB);
     const uint64_t* ksrc = keys; uint64_t* kdst = ka.data();
     int64_t* osrc = nullptr; int64_t* odst = (passes & 1) ? order : ob.data();     // the last pass must land in `order`
@@ -302,8 +331,10 @@ static int64_t pup_host_sort_pairs_impl(const int64_t* s1, const int64_t* e1, co
     auto bits = [](uint64_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b; };
     const int w0 = bits((uint64_t)nu * (uint64_t)nu - 1), w1 = bits((uint64_t)(max1 / g1)), w2 = bits((uint64_t)(max2 / g2));
     if (w0 + w1 + w2 > 63) return -6;
-    std::vector<uint64_t> key((size_t)kept);
-    std::vector<int64_t> idx((size_t)kept);
+    std::vector<uint64_t>& key = scratch_u64(2);
+    std::vector<int64_t>& idx = scratch_i64(1);
+    if (key.size() < (size_t)kept) key.resize((size_t)kept);
+    if (idx.size() < (size_t)kept) idx.resize((size_t)kept);
     std::vector<int> unsorted((size_t)workers, 0);
     parallel_chunks(n, workers, [&](int k, int64_t a, int64_t b) {
         int64_t o = at[(size_t)k];
@@ -323,7 +354,8 @@ static int64_t pup_host_sort_pairs_impl(const int64_t* s1, const int64_t* e1, co
         if (a > 0 && a < kept && part[(size_t)k].kept > 0 && key[(size_t)a] < key[(size_t)a - 1]) permute = true;
     }
     if (permute) {
-        std::vector<int64_t> ord((size_t)kept);
+        std::vector<int64_t>& ord = scratch_i64(2);
+        if (ord.size() < (size_t)kept) ord.resize((size_t)kept);
         const int rc = pup_host_argsort(key.data(), kept, w0 + w1 + w2, ord.data());
         if (rc != PUP_OK) return rc;
         parallel_chunks(kept, workers, [&](int, int64_t a, int64_t b) { for (int64_t i = a; i < b; ++i) rows[i] = idx[(size_t)ord[(size_t)i]]; });
@@ -552,4 +584,8 @@ PUP_EXPORT int pup_host_mt_randint(uint32_t* key, int32_t* pos, int64_t low, int
 
 PUP_EXPORT int pup_host_group_tiles_runs(int32_t n_parts, const int32_t* const* r0, const int32_t* const* c0, const int32_t* const* tile, const int64_t* split, const int32_t* tile_a, const int32_t* tile_b, const int64_t* len, int32_t T, int32_t* r0_out, int32_t* c0_out, int64_t* tile_ptr) {
     PUP_HOST_GUARD(pup_host_group_tiles_runs_impl(n_parts, r0, c0, tile, split, tile_a, tile_b, len, T, r0_out, c0_out, tile_ptr), PUP_ENOMEM);
+}
+
+PUP_EXPORT int64_t pup_host_control_windows(const int32_t* st1, const int32_t* st2, const int32_t* code, int64_t n, const int32_t* shift, const int32_t* sign, int32_t nshifts, double resolution, int64_t off1, int64_t off2, int64_t lo1, int64_t hi1, int64_t lo2, int64_t hi2, int32_t h, int32_t w, int32_t* r0, int32_t* c0, int32_t* code_out) {
+    PUP_HOST_GUARD(pup_host_control_windows_impl(st1, st2, code, n, shift, sign, nshifts, resolution, off1, off2, lo1, hi1, lo2, hi2, h, w, r0, c0, code_out), PUP_ENOMEM);
 }

@@ -112,22 +112,27 @@ __host__ __device__ inline int staged_tile(int unit, int slot, int PH) {
 // geometry of an instantiation (host and device agree through these)
 template <int W> constexpr bool staged_big() { return W <= 21; }      // 128 x 128 regions, 16 waves: register budget of CH <= 7 cells
 #ifndef PUP_SMALL_ROWS
-#define PUP_SMALL_ROWS 72
+#define PUP_SMALL_ROWS 64
 #endif
-constexpr int kSmallRows = PUP_SMALL_ROWS;            // rows of the two-workgroups-per-CU geometry (probe): 72 x 131 doubles + the rest < 80 KB
+constexpr int kSmallRows = PUP_SMALL_ROWS;            // rows of the DOUBLE-BUFFERED geometry (tuning bit 7): two regions of 64 x 131 doubles = 134 KB
 template <int W, bool OOE, bool EXTRA, bool SMALL = false, bool FACT = true> struct StagedGeom {
     static constexpr bool big = staged_big<W>() && !EXTRA && !SMALL;
     static constexpr int RSR = big ? 128 : (SMALL ? kSmallRows : 64);
     static constexpr int RSC = 128;
-    static constexpr int NW  = (big && FACT) ? 16 : 8;   // 16 waves of 128 registers where the kernel fits them (factorised
+    static constexpr int NW  = ((big || SMALL) && FACT) ? 16 : 8;   // 16 waves of 128 registers where the kernel fits them (factorised
                                                          // counts, one accumulator set per wave); the other instantiations
                                                          // need up to 256 registers: 8 waves on the same regions
 };
 
-template <int W, bool OOE, int RSR, int RSC, int NW, int ACC, bool FACT, bool EXTRA, bool BAND = false>
-__global__ __launch_bounds__(kWave * NW, (RSR <= kSmallRows && NW == 8 && FACT && !OOE && !EXTRA && W <= 21) ? 2 : 1)
+// DB (round 5): TWO region buffers of RSR = 64 rows.  Block b is piled up from one buffer while every wave — at a staggered point
+// inside its slice of windows — stores its rows of block b + 1 into the other (their counts were requested a block earlier) and
+// requests those of block b + 2: the store burst is hidden behind the other waves' LDS reads and ONE barrier per block is left
+// (with one buffer: barrier, store burst, barrier — 14 + 10 + 5 % of the kernel by the phase clocks of round 3).
+template <int W, bool OOE, int RSR, int RSC, int NW, int ACC, bool FACT, bool EXTRA, bool BAND = false, bool DB = false>
+__global__ __launch_bounds__(kWave * NW, 1)
 void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     static_assert(!(BAND && EXTRA), "pixel statistics need the presence bits of the index: sparse staging");
+    static_assert(!DB || (BAND && FACT && !OOE && !EXTRA), "double-buffered regions: band staging, factorised counts, no expected");
     static_assert(W >= 3 && W <= 31, "workgroup-staged kernel serves windows of 3..31 bins");
     // (FACT && OOE: the engine has checked that every diagonal a window reaches has a usable expected — staged_run)
     static_assert(ACC == 1 || ACC == 2 || ACC == 8, "accumulator slots of a pass: a tile, a tile pair, four pairs");
@@ -144,7 +149,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     constexpr int VBW = NH + 1;                          // validity words per row (+1: the dword-pair read may run one dword over)
     static_assert(NRH <= 32 && RPW <= 32, "row halves of a wave must fit the value registers");
     static_assert((size_t)NW / 2 * CH * kWave * 12 <= (size_t)RSR * LS * 8, "merge scratch must fit the region buffer");
-    __shared__ double tile[RSR * LS];
+    __shared__ double tile[(DB ? 2 : 1) * RSR * LS];
     __shared__ unsigned long long vbits[FACT ? 1 : RSR * VBW];      // bit c of row r: cell (r, c) counts in num
     __shared__ unsigned long long pbits[EXTRA ? RSR * VBW : 1];     // bit c: cell holds a pixel (statistics only)
     __shared__ double cov_lds[EXTRA ? NW : 1][2 * W];
@@ -188,7 +193,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     // round 3: the workgroup waited 14 % of its time for them at the barrier behind the window loop) — they get 7 % fewer
     auto wave_weight = [&](int w) __attribute__((always_inline)) -> float {
         const int ag = w >> 2;
-        return NW != 16 ? 1.0f : (ag == 3 ? 0.87f : (ag == 0 ? 0.90f : 1.0f));
+        return NW != 16 ? 1.0f : (ag == 3 ? 0.83f : (ag == 0 ? 0.89f : (ag == 1 ? 1.02f : 1.0f)));     // (round 5: re-measured, phase clocks of profiles/r05_k1q_phases.json)
     };
     float f_lo = 0.0f, f_hi = 1.0f;
     auto set_shares = [&]() __attribute__((always_inline)) {
@@ -444,12 +449,21 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
             const int hi2 = (ch_end - R) < row_hi ? (ch_end - R) : row_hi;             // live rows of the region: [row_lo, hi2)
             const unsigned i_lo = (unsigned)(row_lo - wave * RPW), n_live = (unsigned)(hi2 > row_lo ? hi2 - row_lo : 0);
             const int* rowp = a.band + (long long)row0 * a.band_w + (C - row0);        // (row + 1, C) sits band_w - 1 cells further
+            // round 5: a lane takes the NEIGHBOURING columns 2 l and 2 l + 1 of a row — one 8-byte load per row instead of a
+            // 4-byte load per half, and at store time one ds_write2_b64: half the memory and LDS instructions of the staging,
+            // whose store burst is bound by vector-instruction issue (sixteen waves at once: phase clocks)
 #pragma unroll
             for (int i = 0; i < RPW; ++i) {
                 const bool live = (unsigned)i - i_lo < n_live;                          // (uniform) else: zeros, all rows the same lines
                 const int* src = live ? rowp : zeros;
+                if constexpr (NH == 2) {
+                    int2 two;
+                    __builtin_memcpy(&two, src + 2 * lane, sizeof(two));                // (4-byte aligned: global_load_dwordx2)
+                    v[i * NH] = two.x; v[i * NH + 1] = two.y;
+                } else {
 #pragma unroll
-                for (int h = 0; h < NH; ++h) v[i * NH + h] = src[64 * h + lane];
+                    for (int h = 0; h < NH; ++h) v[i * NH + h] = src[64 * h + lane];
+                }
                 rowp += a.band_w - 1;
             }
         } else
@@ -471,7 +485,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
         const double* wsrc = a.weight ? a.weight : reinterpret_cast<const double*>(a.indptr);
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-            const long long col = (long long)C + 64 * h + lane;
+            const long long col = (FACT && NH == 2) ? (long long)C + 2 * lane + h : (long long)C + 64 * h + lane;      // (FACT: columns 2 l, 2 l + 1)
             wc[h] = wsrc[col < a.nbins ? col : a.nbins - 1];      // raw: see issue_values — no loaded value is looked at before the store
         }
         {   // row weights: lane i < RPW holds its row's, broadcast at store time
@@ -479,8 +493,9 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
             wrv = wsrc[row < a.nbins ? row : a.nbins - 1];
         }
     };
-    auto band_store = [&](auto nf_tag, int ev, const int (&v)[NRH], const double (&wc)[NH], double wrv, const ExpSel& es) __attribute__((always_inline)) {
+    auto band_store = [&](auto nf_tag, int ev, const int (&v)[NRH], const double (&wc)[NH], double wrv, const ExpSel& es, double* dst = nullptr) __attribute__((always_inline)) {
         constexpr bool NFP = decltype(nf_tag)::value;
+        double* const out = DB ? dst : tile;
         const int R = fld(ev, 0), C = fld(ev, 1), ch_end = fld(ev, 6), row_lo = fld(ev, 21), row_hi = fld(ev, 22);
         double wcs[NH];
 #pragma unroll
@@ -501,10 +516,12 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
             const double wr = __longlong_as_double((long long)bcast64((unsigned long long)__double_as_longlong(wrs), i));
 #pragma unroll
             for (int hh = 0; hh < NH; ++hh) {
+                constexpr bool PAIRS = FACT && NH == 2;      // (band_issue: the lane's two values are columns 2 l and 2 l + 1)
+                const int colx = PAIRS ? 2 * lane + hh : 64 * hh + lane;
                 double val = (double)v[i * NH + hh] * wr * wcs[hh];
                 if (NFP) val = (val == val) ? val : 0.0;
                 if (OOE) {
-                    const double e = exp_lds[64 * hh + lane - rr + (RSR - 1)];      // expected of |col - row|
+                    const double e = exp_lds[colx - rr + (RSR - 1)];      // expected of |col - row|
                     val = val / e;
                     val = (val == val) ? val : 0.0;         // NaN quotients are skipped, inf is kept
                     if constexpr (!FACT) {
@@ -514,7 +531,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
                         if (lane == i) okn[hh] &= eok;
                     }
                 }
-                tile[rr * LS + 64 * hh + lane] = val;
+                out[rr * LS + colx] = val;
             }
         }
         if constexpr (!FACT) {
@@ -536,7 +553,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     // round robin from batches every wave held; with one workgroup per CU the per-batch fetch then stalled the whole CU,
     // and the factorised-count bookkeeping of a batch fell on one wave.)
     struct Cur { int R, C, start, first, n; unsigned long long rowbad[2], colbad[2]; };   // first, n: the windows of this wave's slot
-    const unsigned lane_off8 = (unsigned)(uintptr_t)tile + 8u * (unsigned)(p * LS + k);   // LDS byte address of the lane's first cell
+    unsigned lane_off8 = (unsigned)(uintptr_t)tile + 8u * (unsigned)(p * LS + k);   // LDS byte address of the lane's first cell (DB: in the buffer being read)
     const unsigned vb_base = (unsigned)(uintptr_t)vbits;
     // window `at + lane` of the block, for the lanes below `end`
     auto load_batch = [&](int start, int at, int end) __attribute__((always_inline)) -> int {
@@ -727,10 +744,10 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     // records (segment, slot, workgroup), clear the accumulators.  Uses the region buffer as scratch: every wave is done
     // reading the staged region when this is called, and the next region is stored after it.
     const size_t L = (size_t)W2 + 2 * (size_t)W;
-    auto flush = [&](int seg) __attribute__((always_inline)) {
+    auto flush = [&](int seg, double* scratch = nullptr) __attribute__((always_inline)) {
         const int fl = seg & 1, unit = seg >> 1;
-        double*   mf = tile;                                              // [NW/2][CH][64] doubles, then the same in u32
-        unsigned* mn = reinterpret_cast<unsigned*>(tile + (NW / 2) * CH * kWave);
+        double*   mf = DB ? scratch : tile;                               // [NW/2][CH][64] doubles, then the same in u32
+        unsigned* mn = reinterpret_cast<unsigned*>(mf + (NW / 2) * CH * kWave);
         __syncthreads();
         // every team merges its waves' tiles into its first wave: binary tree over the position inside the team (both teams
         // at once: their scratch slots are disjoint — the absolute wave number picks the slot)
@@ -792,6 +809,66 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
         __syncthreads();
     };
 
+    // ---- the block loop, two buffers: region b is piled up from one buffer while b+1 is stored into the other (its counts were
+    // requested while b-1 was piled up), b+2's counts are requested and b+3's table entry is on its way -------------------------
+    if constexpr (DB) {
+        constexpr int BUF = RSR * LS;                    // doubles per buffer
+        int ev0 = entry_load(bb), ev1 = ev0, ev2 = ev0, evn = ev0;
+        int v[NRH];
+        double wc[NH], wrv = 1.0;
+        int w0f, w1f = 0;
+        int cur = 0;
+        const ExpSel es_none = exp_of(ev0);              // (no expected in this instantiation)
+        {   // prologue: stage block bb into buffer 0 without overlap, request the counts of bb + 1
+            band_issue(ev0, v, wc, wrv);
+            set_team(fld(ev0, 20) >> 1);
+            first_coords(ev0, w0f);
+            if (bb + 1 < be) ev1 = entry_load(bb + 1);
+            if (bb + 2 < be) evn = entry_load(bb + 2);
+            __syncthreads();
+            if (nf) band_store(std::true_type{}, ev0, v, wc, wrv, es_none, tile); else band_store(std::false_type{}, ev0, v, wc, wrv, es_none, tile);
+            if (bb + 1 < be) band_issue(ev1, v, wc, wrv);
+            __syncthreads();
+        }
+        long long tk[6] = {0, 0, 0, 0, 0, 0}, tmid = 0;
+        const bool timed = sa.timing != nullptr;
+        auto tick = [&]() __attribute__((always_inline)) -> long long { return timed ? (long long)__builtin_readcyclecounter() : 0; };
+        for (int b = bb; b < be; ++b) {
+            const bool has1 = b + 1 < be, has2 = b + 2 < be;
+            const long long t0 = tick();
+            double* const other = tile + (cur ^ 1) * BUF;
+            auto lookahead = [&]() __attribute__((always_inline)) {
+                const long long m0 = tick();
+                if (has1) {
+                    first_coords(ev1, w1f);
+                    if (!(sa.debug & 2)) { if (nf) band_store(std::true_type{}, ev1, v, wc, wrv, es_none, other); else band_store(std::false_type{}, ev1, v, wc, wrv, es_none, other); }
+                }
+                if (has2) { ev2 = evn; if (!(sa.debug & 2)) band_issue(ev2, v, wc, wrv); if (b + 3 < be) evn = entry_load(b + 3); }
+                tmid += tick() - m0;
+            };
+            const Cur c0 = cur_of(ev0);
+            const long long t1 = tick();
+            windows(c0, w0f, lookahead);
+            const long long t2 = tick();
+            const int seg0 = fld(ev0, 20);
+            if (!has1) { flush(seg0, tile + cur * BUF); break; }
+            const int seg1 = fld(ev1, 20);
+            if (seg1 != seg0) {                          // (uniform) the next block belongs to another segment
+                flush(seg0, tile + cur * BUF);           // (its barriers also close block b: region b + 1 sits complete in the other buffer)
+                if (ACC > 1 && (seg1 >> 1) != (seg0 >> 1)) { set_team(seg1 >> 1); first_coords(ev1, w1f); }   // other unit: other teams
+            } else __syncthreads();                      // every wave is done reading region b and has stored its rows of b + 1
+            const long long t3 = tick();
+            cur ^= 1;
+            lane_off8 = (unsigned)(uintptr_t)(tile + cur * BUF) + 8u * (unsigned)(p * LS + k);
+            ev0 = ev1; w0f = w1f; ev1 = ev2;
+            if (timed) { tk[0] += t1 - t0; tk[1] += t2 - t1; tk[2] += t3 - t2; tk[5] += tick() - t3; }
+        }
+        if (timed && lane == 0) {
+            long long* o = sa.timing + ((size_t)g_id * NW + wave) * 8;
+            for (int i = 0; i < 6; ++i) o[i] = tk[i];
+            o[6] = be - bb; o[7] = tmid;
+        }
+    } else
     // ---- the block loop, band staging: region b is piled up while b+1's counts and b+2's table entry are on their way --------
     if constexpr (BAND) {
         int ev0 = entry_load(bb), ev1 = ev0, evn = ev0;

@@ -24,6 +24,13 @@ void launch_kernel(const StagedLaunch& l, const K1Args& a, const StagedArgs& sa,
     if constexpr (W == 21 && !OOE && !EXTRA && ACC <= 2) {
         if (l.small21) {
             using GeoS = StagedGeom<W, OOE, EXTRA, true, FACT>;
+            if constexpr (FACT) {
+                if (l.band) {                                // two buffers of 64 rows, sixteen waves (pup_staged.hpp: DB)
+                    hipLaunchKernelGGL((pileup_staged_kernel<W, OOE, GeoS::RSR, GeoS::RSC, GeoS::NW, ACC, FACT, EXTRA, true, true>), dim3(l.G),
+                                       dim3(kWave * GeoS::NW), 0, s, a, sa);
+                    return;
+                }
+            }
             if (l.band)
                 hipLaunchKernelGGL((pileup_staged_kernel<W, OOE, GeoS::RSR, GeoS::RSC, GeoS::NW, ACC, FACT, EXTRA, true>), dim3(l.G),
                                    dim3(kWave * GeoS::NW), 0, s, a, sa);

@@ -165,8 +165,6 @@ def native_comm(eng):
     # every rank-local step that can fail is caught HERE and turned into ok = False: a rank that raised before joining the
     # agreement below would leave its peers waiting in it (PupError / AttributeError escaped past `except OSError`)
     try:
-        if os.environ.get("COOLPUPPY_AMD_TEST_FAIL_NATIVE_RANK", "") == str(rank):     # tests: one rank fails, all must fall back
-            raise RuntimeError("native communicator set-up failed on purpose (test hook)")
         rccl = _ffi.rccl()
         if rank == 0 and rccl.ncclGetUniqueId(C.byref(uid)) != 0:
             rccl, why = None, "ncclGetUniqueId failed"
@@ -262,3 +260,91 @@ def allreduce_engine(eng):
         bi.copy_(hi)
     torch.cuda.synchronize(dev)
     eng.import_from(bf.data_ptr(), bi.data_ptr())
+
+
+def sparse_exchange_min_tiles():
+    """Plans of at least this many tiles swap the tiles each rank piled windows into (`exchange_tiles`) instead of all-reducing
+    every accumulator: below it the flat all-reduce is one latency-bound call and cannot be beaten."""
+    return int(os.environ.get("COOLPUPPY_AMD_SPARSE_EXCHANGE_MIN_TILES", "1024"))
+
+
+def gather_tile_lists(mine):
+    """(tile numbers of all ranks concatenated in rank order, rank_ptr) from this rank's sorted list — control plane, a few
+    thousand integers per rank."""
+    d = _dist()
+    _bind_device(d)
+    parts = [None] * d.get_world_size()
+    d.all_gather_object(parts, np.asarray(mine, np.int32))
+    ptr = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
+    ids = np.concatenate(parts).astype(np.int32) if ptr[-1] else np.zeros(0, np.int32)
+    return ids, ptr
+
+
+def exchange_tiles(eng, mine):
+    """By-window exchange (reference: the per-feature pile-ups of the worker processes, coolpup.py:1696-1755, merged key by key):
+    every rank contributes the tiles it piled windows into (`mine`, sorted tile numbers); afterwards every such tile holds, on
+    every rank, the sum over the ranks that list it, added in rank order.  With the nccl backend the engine does it itself
+    (pup_allgather_tiles: a broadcast of each rank's block on its stream); otherwise the blocks travel through
+    torch.distributed (gloo: through host memory) and pup_unpack_tiles adds them.  Returns the bytes this rank sent."""
+    d = _dist()
+    if d is None or d.get_world_size() == 1:
+        return 0
+    import torch
+    rank, world_size = d.get_rank(), d.get_world_size()
+    ids, ptr = gather_tile_lists(mine)
+    nf_mine, ni_mine = eng.tile_block_sizes(int(ptr[rank + 1] - ptr[rank]))
+    sent = 8 * (nf_mine + ni_mine)
+    if ptr[-1] == 0:
+        return 0
+    if d.get_backend() == "nccl" and os.environ.get("COOLPUPPY_AMD_NATIVE_RCCL", "1") != "0":
+        try:
+            comm = native_comm(eng)
+        except (RuntimeError, OSError) as e:
+            import warnings
+            warnings.warn(f"engine-side RCCL communicator unavailable ({e}); using torch.distributed broadcasts")
+            comm = None
+        if comm is not None:
+            eng.allgather_tiles(comm, ids, ptr, rank)
+            return sent
+    dev = torch.device("cuda", eng.device_id)
+    on_host = d.get_backend() != "nccl"
+    blocks = []
+    for r in range(world_size):
+        nf, ni = eng.tile_block_sizes(int(ptr[r + 1] - ptr[r]))
+        bf = torch.empty(max(nf, 1), dtype=torch.float64, device=dev)
+        bi = torch.empty(max(ni, 1), dtype=torch.int64, device=dev)
+        if r == rank and nf:
+            eng.pack_tiles(ids[ptr[r]:ptr[r + 1]], bf.data_ptr(), bi.data_ptr())
+        blocks.append((bf, bi, nf))
+    eng.unpack_tiles(ids[ptr[rank]:ptr[rank + 1]], mode=2)          # own tiles cleared: every block is ADDED below, in rank order
+    for r, (bf, bi, nf) in enumerate(blocks):
+        if not nf:
+            continue
+        if on_host:
+            hf, hi = bf.cpu(), bi.cpu()
+            d.broadcast(hf, src=r)
+            d.broadcast(hi, src=r)
+            bf.copy_(hf)
+            bi.copy_(hi)
+        else:
+            d.broadcast(bf, src=r)
+            d.broadcast(bi, src=r)
+        torch.cuda.synchronize(dev)
+        eng.unpack_tiles(ids[ptr[r]:ptr[r + 1]], bf.data_ptr(), bi.data_ptr(), mode=1)
+    return sent
+
+
+def exchange_tile_arrays(acc, mine):
+    """exchange_tiles on host arrays (the CPU stand-in of the tests): acc = dict of [T, ...] arrays (sum, num, n, cov_start,
+    cov_end); same rule — a listed tile becomes the sum of the listing ranks' tiles, added in rank order."""
+    d = _dist()
+    if d is None or d.get_world_size() == 1:
+        return
+    mine = np.asarray(mine, np.int64)
+    parts = [None] * d.get_world_size()
+    d.all_gather_object(parts, (mine, {k: np.ascontiguousarray(v[mine]) for k, v in acc.items()}))
+    for v in acc.values():
+        v[mine] = 0
+    for ids, block in parts:
+        for k, v in acc.items():
+            np.add.at(v, ids, block[k])

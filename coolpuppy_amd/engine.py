@@ -281,6 +281,27 @@ class PileupEngine:
         addr = rccl_comm.value if isinstance(rccl_comm, C.c_void_p) else int(rccl_comm)
         self._check(self._lib.pup_allreduce(self._h, C.c_void_p(addr)))
 
+    def tile_block_sizes(self, n):
+        """(f64 elements, i64 elements) of a block of n packed tiles (pup_pack_tiles layout)."""
+        W2 = self.W * self.W
+        return n * (W2 + 2 * self.W), n * (W2 + 1)
+
+    def pack_tiles(self, tile_ids, dev_f64_ptr, dev_i64_ptr):
+        ids = _as(tile_ids, np.int32)
+        self._check(self._lib.pup_pack_tiles(self._h, _ptr(ids), ids.shape[0], C.c_void_p(dev_f64_ptr), C.c_void_p(dev_i64_ptr)))
+
+    def unpack_tiles(self, tile_ids, dev_f64_ptr=None, dev_i64_ptr=None, mode=1):
+        """mode 0: overwrite the tiles from the block, 1: add the block to them, 2: clear them."""
+        ids = _as(tile_ids, np.int32)
+        self._check(self._lib.pup_unpack_tiles(self._h, _ptr(ids), ids.shape[0], C.c_void_p(dev_f64_ptr or 0), C.c_void_p(dev_i64_ptr or 0), int(mode)))
+
+    def allgather_tiles(self, rccl_comm, tile_ids, rank_ptr, my_rank):
+        """pup_allgather_tiles: tile_ids[rank_ptr[r]:rank_ptr[r+1]] = the tiles rank r holds; afterwards every listed tile is the
+        sum over the ranks that list it (asynchronous on the engine's stream)."""
+        addr = rccl_comm.value if isinstance(rccl_comm, C.c_void_p) else int(rccl_comm)
+        ids, ptr = _as(tile_ids, np.int32), _as(rank_ptr, np.int64)
+        self._check(self._lib.pup_allgather_tiles(self._h, C.c_void_p(addr), _ptr(ids), _ptr(ptr), ptr.shape[0] - 1, int(my_rank)))
+
     def set_profiling(self, enabled=True):
         """True / 1: HIP-event timing of the kernels + pixel statistics; 3: timing only; False / 0: off."""
         self._check(self._lib.pup_set_profiling(self._h, int(enabled)))
@@ -463,6 +484,28 @@ def host_windows(st1, st2, code, shift, sign, nshifts, resolution, off1, off2, l
     if kept < 0:
         raise ValueError("pup_host_windows: bad arguments")
     return r0[:kept], c0[:kept], (None if code_out is None else code_out[:kept]), int(n_roi.value)
+
+
+def host_windows_into(r0, c0, at, st1, st2, shift, sign, nshifts, resolution, off1, off2, lo1, hi1, lo2, hi2, h, w, controls_only=False):
+    """pup_host_windows / pup_host_control_windows writing at position `at` of the caller's (page-locked) r0 / c0 arrays: the ROI
+    windows of a region (shift / sign None, nshifts 0) or its shifted control copies alone.  Returns the number of windows written."""
+    st1, st2 = _as(st1, np.int32), _as(st2, np.int32)
+    n = st1.shape[0]
+    cap = n * int(nshifts) if controls_only else n * (1 + int(nshifts))
+    if at + cap > r0.shape[0] or r0.dtype != np.int32 or c0.dtype != np.int32:
+        raise ValueError("host_windows_into: output arrays too small")
+    if shift is not None and np.asarray(shift).dtype.itemsize > 4 and len(shift) and \
+            (int(np.max(shift)) > 2**31 - 1 or int(np.min(shift)) < -2**31):
+        raise ValueError("control shifts beyond +-2^31 bp do not fit the int32 shifts of pup_host_windows")
+    shift = None if shift is None else _as(shift, np.int32)
+    sign = None if sign is None else _as(sign, np.int32)
+    pr, pc = C.c_void_p(r0.ctypes.data + 4 * int(at)), C.c_void_p(c0.ctypes.data + 4 * int(at))
+    args = (_ptr(st1), _ptr(st2), None, n, _ptr(shift), _ptr(sign), int(nshifts), float(resolution), int(off1), int(off2),
+            int(lo1), int(hi1), int(lo2), int(hi2), int(h), int(w), pr, pc, None)
+    kept = _ffi.lib().pup_host_control_windows(*args) if controls_only else _ffi.lib().pup_host_windows(*args, None)
+    if kept < 0:
+        raise ValueError("pup_host_windows: bad arguments" if kept == -1 else "pup_host_windows: out of memory")
+    return int(kept)
 
 
 def legacy_randint(low, high, m, scale=1, offset=0, discard=False, dtype=np.int64):

@@ -24,6 +24,8 @@
  *                                        PileUpper.__init__ when cov_*_raw is missing     coolpuppy/coolpup.py:955-963
  *   pup_accumulate_rescaled           <- the same loop with _rescale_snip               coolpuppy/coolpup.py:1159-1162, 1193-1234
  *   pup_export / pup_import / pup_allreduce <- reduce(sum_pups) over worker processes  coolpuppy/coolpup.py:1495-1531
+ *   pup_allgather_tiles / pup_pack_tiles / pup_unpack_tiles <- the same merge for by-window pile-ups, whose per-feature
+ *                                        pile-ups exist on one worker each        coolpuppy/coolpup.py:1696-1755
  *   pup_stripes                       <- the store_stripes branch of _stream_snips   coolpuppy/coolpup.py:1164-1182
  *   pup_extract                       <- _stream_snips as a producer of per-snippet windows for the Python callbacks
  *                                        (postprocess_func / extra_sum_funcs)          coolpuppy/coolpup.py:1104-1162, 1261-1262
@@ -33,7 +35,7 @@
  *   pup_host_mt_randint               <- np.random.randint / np.random.choice draws of CoordCreator._control_regions
  *                                                                      coolpuppy/coolpup.py:420-436
  *   pup_host_windows                  <- CoordCreator._control_regions (shifted control copies) + the bounds test of
- *                                        _stream_snips, as one host pass  coolpuppy/coolpup.py:387-453, 1105-1114
+ *   pup_host_control_windows             _stream_snips, as one host pass  coolpuppy/coolpup.py:387-453, 1105-1114
  *   pup_host_factorize_ptr            <- the same sort's chromosome codes (object columns factorised by identity)
  *   pup_host_argsort                  <- the same sort's order (one packed key per row)
  *   pup_host_sort_pairs               <- CoordCreator.process for BEDPE features: centres, mindist / maxdist filter and the sort
@@ -252,6 +254,24 @@ int pup_import(pup_ctx* ctx, const void* dev_f64, const void* dev_i64);
 int pup_allreduce(pup_ctx* ctx, void* rccl_comm);
 
 /*
+ * Exchange of SOME tiles — by-window pile-ups (coolpuppy/coolpup.py:1696-1755: one pile-up per feature; lib/puputils.py:218-223
+ * files a snippet under its two features) keep a tile per feature, and a feature's tile is non-zero only on the rank(s) that
+ * piled up its region: a flat all-reduce would move every tile of every rank.
+ *   pup_allgather_tiles: tile_ids[rank_ptr[r] .. rank_ptr[r+1]) = the tiles rank r piled windows into (the same lists on every
+ *     rank).  Afterwards every listed tile holds, on every rank, the sum of the listing ranks' accumulators for it, added in rank
+ *     order (identical doubles everywhere); tiles nobody lists are left alone.  A rank sends its own tiles once (ncclBroadcast
+ *     per rank inside one group, on the context's stream, asynchronous like pup_allreduce): message = own tiles, not all tiles.
+ *   pup_pack_tiles / pup_unpack_tiles: the two halves for callers that carry the blocks themselves (torch.distributed on
+ *     exported buffers, tests): block k of the DEVICE buffers = tile tile_ids[k] in the packed layout (f64: W*W sum, W cov_start,
+ *     W cov_end; i64: W*W num, n).  unpack mode 0 overwrites the tiles, 1 adds to them, 2 clears them (buffers may be NULL).
+ * PUP_ERANGE for a tile number outside [0, n_tiles).
+ */
+int pup_pack_tiles(pup_ctx* ctx, const int32_t* tile_ids, int64_t n, void* dev_f64, void* dev_i64);
+int pup_unpack_tiles(pup_ctx* ctx, const int32_t* tile_ids, int64_t n, const void* dev_f64, const void* dev_i64, int32_t mode);
+int pup_allgather_tiles(pup_ctx* ctx, void* rccl_comm, const int32_t* tile_ids, const int64_t* rank_ptr, int32_t n_ranks,
+                        int32_t my_rank);
+
+/*
  * Path of the librccl that pup_allreduce opens: the copy that sits beside the HIP runtime mapped into this process
  * (one ROCm stack per process: a PyTorch-ROCm wheel bundles its own libamdhip64 + librccl, the system ROCm another
  * pair, and mixing them corrupts the heap at exit), or the bare soname "librccl.so.1" when there is none there.  The
@@ -332,6 +352,17 @@ int64_t pup_host_windows(const int32_t* st1, const int32_t* st2, const int32_t* 
                          const int32_t* shift, const int32_t* sign, int32_t nshifts, double resolution,
                          int64_t off1, int64_t off2, int64_t lo1, int64_t hi1, int64_t lo2, int64_t hi2,
                          int32_t h, int32_t w, int32_t* r0, int32_t* c0, int32_t* code_out, int64_t* n_roi_kept);
+
+/*
+ * pup_host_control_windows: the nshifts shifted control copies of pup_host_windows ALONE (same arguments and rules, capacity
+ * n * nshifts, no ROI windows in front).  With it the windows of a whole pile-up are written straight to where one
+ * pup_accumulate call wants them — every region's ROI windows first (they need no draw), then, region after region as the
+ * reference's draws arrive (coolpuppy/coolpup.py:420-436), its copies — in page-locked memory, without per-region arrays.
+ */
+int64_t pup_host_control_windows(const int32_t* st1, const int32_t* st2, const int32_t* code, int64_t n,
+                                 const int32_t* shift, const int32_t* sign, int32_t nshifts, double resolution,
+                                 int64_t off1, int64_t off2, int64_t lo1, int64_t hi1, int64_t lo2, int64_t hi2,
+                                 int32_t h, int32_t w, int32_t* r0, int32_t* c0, int32_t* code_out);
 
 /*
  * pup_host_mt_randint: the reference's random draws for the control windows — np.random.randint(low, high, m) of the LEGACY

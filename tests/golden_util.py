@@ -146,7 +146,12 @@ def oracle_run_plan(pu, plan, calls=None, reduce=True):
                         plan["T"], plan["pad"], c["ignore_diags"], c["mode"], acc=acc)
     from coolpuppy_amd import dist as pdist
     world = pdist.world()[1]
-    if world > 1 and reduce and calls is None:
+    if world > 1 and reduce and calls is None and plan["grouped"] and plan["T"] >= pdist.sparse_exchange_min_tiles():
+        # many groups: the ranks swap the tiles they hold (dist.exchange_tiles; here its host-array form)
+        from coolpuppy_amd.coolpup import plan_tiles_with_windows
+        pdist.check_same_plan(plan)
+        pdist.exchange_tile_arrays(acc, plan_tiles_with_windows(plan))
+    elif world > 1 and reduce and calls is None:
         # what run_plan does between its ranks: same-plan check, then the tiles are summed (here from host arrays)
         pdist.check_same_plan(plan)
         T, W = plan["T"], 2 * plan["pad"] + 1

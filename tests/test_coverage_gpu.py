@@ -94,6 +94,73 @@ def test_native_rccl_allreduce_single_rank(hip_lib):
     rccl.ncclCommDestroy(comm)
 
 
+def test_tile_blocks_and_single_rank_allgather(hip_lib):
+    """pup_pack_tiles / pup_unpack_tiles (the by-window exchange's two halves) and pup_allgather_tiles over a one-rank RCCL
+    communicator: a packed block holds the listed tiles in the documented layout, unpack overwrites / adds / clears exactly those
+    tiles, and the all-gather of a rank's own tiles leaves every accumulator as it was (pack, clear, broadcast to itself, add)."""
+    import ctypes as C
+    import torch
+    from coolpuppy_amd.engine import PileupEngine, PupError
+    from coolpuppy_amd import _ffi
+    clr = synth.make_cooler({"chrA": 8_000_000, "chrB": 5_000_000}, lam=60, seed=3)
+    eng = PileupEngine(0)
+    eng.load_pixels(*clr.pixel_table())
+    eng.load_bins(clr.bins()["weight"][:].values, clr.bins()["cov_tot_raw"][:].values)
+    rng = np.random.default_rng(0)
+    T, pad, W = 7, 4, 9
+    n = 3000
+    r0 = rng.integers(0, 700, n).astype(np.int32)
+    c0 = (r0 + rng.integers(0, 60, n)).astype(np.int32)
+    tp = np.array([0, 400, 400, 900, 1500, 1500, 2200, n])           # tiles 1 and 4 stay empty
+    eng.reset(T, pad)
+    eng.accumulate(r0, c0, tp, ignore_diags=2, mode=4)                # (coverage vectors ride along: the cov part of a block)
+    before = eng.fetch()
+    ids = np.array([5, 0, 3], np.int32)
+    nf, ni = eng.tile_block_sizes(len(ids))
+    assert (nf, ni) == (3 * (W * W + 2 * W), 3 * (W * W + 1))
+    bf = torch.zeros(nf, dtype=torch.float64, device="cuda:0")
+    bi = torch.zeros(ni, dtype=torch.int64, device="cuda:0")
+    eng.pack_tiles(ids, bf.data_ptr(), bi.data_ptr())
+    hf, hi = bf.cpu().numpy().reshape(3, -1), bi.cpu().numpy().reshape(3, -1)
+    for k, t in enumerate(ids):
+        assert np.array_equal(hf[k, :W * W], before["sum"][t].ravel()) and np.array_equal(hf[k, W * W:W * W + W], before["cov_start"][t])
+        assert np.array_equal(hf[k, W * W + W:], before["cov_end"][t])
+        assert np.array_equal(hi[k, :W * W], before["num"][t].ravel()) and hi[k, W * W] == before["n"][t]
+    eng.unpack_tiles(ids, bf.data_ptr(), bi.data_ptr(), mode=1)       # add: the listed tiles double, the others stay
+    twice = eng.fetch()
+    for t in range(T):
+        f = 2 if t in ids else 1
+        assert np.array_equal(twice["sum"][t], f * before["sum"][t]) and np.array_equal(twice["num"][t], f * before["num"][t])
+        assert twice["n"][t] == f * before["n"][t] and np.array_equal(twice["cov_end"][t], f * before["cov_end"][t])
+    eng.unpack_tiles(ids[:2], mode=2)                                  # clear two of them
+    eng.unpack_tiles(ids[2:], bf[2 * (W * W + 2 * W):].data_ptr(), bi[2 * (W * W + 1):].data_ptr(), mode=0)   # overwrite the third
+    got = eng.fetch()
+    assert not got["sum"][5].any() and not got["num"][0].any() and got["n"][5] == 0
+    assert np.array_equal(got["sum"][3], before["sum"][3]) and np.array_equal(got["sum"][6], before["sum"][6])
+    with pytest.raises(PupError):
+        eng.pack_tiles(np.array([T], np.int32), bf.data_ptr(), bi.data_ptr())
+    # the collective itself, one rank
+    rccl = _ffi.rccl()
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    eng.reset(T, pad)
+    eng.accumulate(r0, c0, tp, ignore_diags=2, mode=4)
+    mine = np.flatnonzero(np.diff(tp) > 0).astype(np.int32)
+    eng.allgather_tiles(comm, mine, np.array([0, len(mine)], np.int64), 0)
+    after = eng.fetch()
+    for k in before:
+        np.testing.assert_array_equal(before[k], after[k])
+    eng.close()
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    rccl.ncclCommDestroy(comm)
+
+
 FRESH = r"""
 import ctypes as C, sys
 sys.path.insert(0, {root!r})

@@ -319,3 +319,44 @@ def test_library_sort_pairs_equals_the_numpy_filter_and_sort():
     assert E.sort_pairs(neg, s + 10, s + 5000, s + 5010, np.zeros(10, np.int32), np.zeros(10, np.int32), np.zeros(1, np.int64), 0, np.inf) is None
     big = rng.integers(0, 2**40, 1000) | 1                                                         # odd: no common divisor
     assert E.sort_pairs(big, big + 1, big + 7, big + 9, np.zeros(1000, np.int32), np.zeros(1000, np.int32), np.zeros(1, np.int64), 0, np.inf) is None
+
+
+def test_fused_plan_equals_the_per_region_plan():
+    """PileUpper._fused_plan (ROI windows of every region, then the regions' control copies as the draws arrive, written straight
+    into the engine call's arrays) against region_snippets -> make_plan -> group_tiles: same windows in the same order, same tile
+    boundaries, same generator state afterwards, same lazily built per-region items — on whole chromosomes and on a view whose
+    regions cut features and shifted copies off."""
+    import pandas as pd
+    clr = synth.make_cooler({"chr1": 30_000_000, "chr2": 20_000_000, "chrX": 9_000_000}, lam=3, seed=2)
+    feats = synth.random_cis_pairs(clr, 30_000, seed=3).sample(frac=1.0, random_state=1)
+    view = pd.DataFrame({"chrom": ["chr1", "chr1", "chr2"], "start": [0, 16_000_000, 1_000_000], "end": [15_000_000, 30_000_000, 18_000_000],
+                         "name": ["a", "b", "c"]})
+    for view_df in (None, view):
+        plans = []
+        for fused in (True, False):
+            np.random.seed(11)
+            cc = coolpup.CoordCreator(feats, clr.binsize, features_format="bedpe", flank=100_000, nshifts=4, seed=11)
+            pu = coolpup.PileUpper(clr, cc, view_df=view_df, control=True)
+            pu.ignore_group_order = False
+            pairs = pu._region_pairs()
+            if fused:
+                plan = pu._fused_plan(pairs)
+            else:
+                batches = [(a, b, pu.region_snippets(a, b)) for a, b in pairs]
+                plan = pu.make_plan(batches, [])
+            plans.append((plan, np.random.randint(0, 1 << 30)))
+        (pf, sf), (pp, sp) = plans
+        assert sf == sp
+        assert len(pf["calls"]) == len(pp["calls"]) == 1
+        cf, cp = pf["calls"][0], pp["calls"][0]
+        for k in ("r0", "c0", "tile_ptr"):
+            assert np.array_equal(cf[k], cp[k]), k
+        assert cf["region1"] == cp["region1"] and cf["mode"] == cp["mode"] and cf["ignore_diags"] == cp["ignore_diags"]
+        for k in ("T", "G", "gid", "order", "want_control", "grouped", "pad", "n_regions", "region_groups", "weight_name", "cov_name"):
+            assert pf[k] == pp[k], k
+        assert len(pf["region_items"]) == len(pp["region_items"])
+        for a, b in zip(pf["region_items"], pp["region_items"]):
+            assert a[0] == b[0] and a[11] == b[11] and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+            assert np.array_equal(np.asarray(a[6]), np.asarray(b[6]))
+        if view_df is not None:
+            assert int(cf["tile_ptr"][2]) < 5 * int(cf["tile_ptr"][1]) + 5 * 30_000      # (windows were dropped somewhere)

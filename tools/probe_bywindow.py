@@ -34,7 +34,11 @@ for rep in range(3):
                 "prepass_ms": round(st["prepare_ms"], 3), "launches": int(st["k1_launches"]), "kernel_family": eng.last_kernel(),
                 "tiles_per_s_engine": round(eng.n_tiles / max((st["k1_ms"] + st["reduce_ms"]) * 1e-3, 1e-9)),
                 "windows_per_s_engine": round(st["snippets"] / max((st["k1_ms"] + st["reduce_ms"]) * 1e-3, 1e-9)),
-                "allreduce_message_bytes": int(8 * (nf + ni))})
+                # what a multi-GPU run exchanges: a flat all-reduce of every accumulator (round 4), or — dist.exchange_tiles, round 5 —
+                # every tile once from the rank that piled it up (a rank of N sends about 1/N of this and receives the rest)
+                "allreduce_message_bytes": int(8 * (nf + ni)),
+                "exchange_tiles_total_bytes": int(8 * sum(eng.tile_block_sizes(int(rows.shape[0])))),
+                "exchange_bytes_per_rank_of_8": int(8 * sum(eng.tile_block_sizes((int(rows.shape[0]) + 7) // 8)))})
     print(json.dumps(res[-1]), flush=True)
 if a.out:
     json.dump({"what": "by-window pile-up, Bonev CTCF+ sites on the mm9-like synthetic 10 kb table (tools/probe_bywindow.py)", "runs": res},
