@@ -86,6 +86,7 @@ _SIGNATURES = {
     "pup_clear_stats": (C.c_int, [C.c_void_p]),
     "pup_debug_timing": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "pup_last_kernel": (C.c_char_p, [C.c_void_p]),
+    "pup_last_prepass": (C.c_char_p, [C.c_void_p]),
     "pup_event_record": (C.c_int, [C.c_void_p, C.c_int]),
     "pup_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "pup_set_tuning": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),

@@ -140,18 +140,21 @@ def flip_snip_func(snip, groupby, ignore_group_order, extra_func=None):
     return snip
 
 
-def _draw_signs(m, dtype=np.int64):
+_DRAW_BUFFERS = {}      # dtype -> [shift buffer, sign buffer]: the draw-ahead's outputs, kept between pile-ups (80 MB of page faults per 10^7 draws otherwise)
+
+
+def _draw_signs(m, dtype=np.int64, out=None):
     """np.random.choice([-1, 1], m) — the reference's call (coolpup.py:421) — without its list conversion and fancy
     index: the legacy generator implements a uniform choice as randint(0, len(a), m) followed by a[idx], so this draws the
     same numbers and leaves the generator in the same state (tests/test_host_misc.py pins that for the installed numpy)."""
     from .engine import legacy_randint
-    return legacy_randint(0, 2, m, scale=2, offset=-1, dtype=dtype)
+    return legacy_randint(0, 2, m, scale=2, offset=-1, dtype=dtype, out=out)
 
 
-def _draw_ints(low, high, m, discard=False, dtype=np.int64):
+def _draw_ints(low, high, m, discard=False, dtype=np.int64, out=None):
     """np.random.randint(low, high, m) of the legacy generator (coolpup.py:420), drawn by the library."""
     from .engine import legacy_randint
-    return legacy_randint(low, high, m, discard=discard, dtype=dtype)
+    return legacy_randint(low, high, m, discard=discard, dtype=dtype, out=out)
 
 
 class _Cols(dict):
@@ -209,6 +212,16 @@ class _DrawAhead:
         import queue
         import threading
         self._cc, self._sizes = cc, list(sizes)
+        # every region's numbers go to their own stretch of two arrays kept between pile-ups (nobody holds a region's draws beyond
+        # its window pass, and a pile-up is over before the next one draws)
+        narrow = np.dtype(cc._draw_dtype()) if hasattr(cc, "_draw_dtype") else None
+        self._bufs = None
+        if narrow is not None:
+            total = int(sum(self._sizes))
+            bufs = _DRAW_BUFFERS.get(narrow)
+            if bufs is None or len(bufs[0]) < total:
+                bufs = _DRAW_BUFFERS[narrow] = [np.empty(total, narrow), np.empty(total, narrow)]
+            self._bufs, self._at = bufs, 0
         self._q = queue.Queue(maxsize=depth)
         self._err = None
         self._th = threading.Thread(target=self._run, name="coolpuppy_amd-draws", daemon=True)
@@ -217,7 +230,12 @@ class _DrawAhead:
     def _run(self):
         try:
             for m in self._sizes:
-                self._q.put((m, self._cc._draw_raw_now(m)))
+                if self._bufs is not None:
+                    a = self._at
+                    self._at += m
+                    self._q.put((m, self._cc._draw_raw_now(m, out=(self._bufs[0][a:a + m], self._bufs[1][a:a + m]))))
+                else:
+                    self._q.put((m, self._cc._draw_raw_now(m)))
         except BaseException as e:       # noqa: BLE001 — handed to the consumer
             self._err = e
             self._q.put((None, None))
@@ -491,10 +509,13 @@ class CoordCreator:
             return ahead.take(m)
         return self._draw_raw_now(m)
 
-    def _draw_raw_now(self, m):
-        narrow = np.int32 if max(abs(int(self.minshift)), abs(int(self.maxshift))) < 2 ** 31 else np.int64
-        shift = _draw_ints(self.minshift, self.maxshift, m, dtype=narrow)
-        sign = _draw_signs(m, dtype=narrow)
+    def _draw_dtype(self):
+        return np.int32 if max(abs(int(self.minshift)), abs(int(self.maxshift))) < 2 ** 31 else np.int64
+
+    def _draw_raw_now(self, m, out=None):
+        narrow = self._draw_dtype()
+        shift = _draw_ints(self.minshift, self.maxshift, m, dtype=narrow, out=None if out is None else out[0])
+        sign = _draw_signs(m, dtype=narrow, out=None if out is None else out[1])
         if self.trans:
             _draw_ints(self.minshift, self.maxshift, m, discard=True)
             _draw_ints(0, 2, m, discard=True)

@@ -112,6 +112,7 @@ struct pup_ctx {
     DevBuf<double> cov_rec; DevBuf<unsigned> cov_owner;     // coverage-vector pass beside the staged kernels (cov_vectors_kernel)
     long long wide_min = 20000;              // calls of at least this many wide cis windows take the staged wide kernel
     const char* last_kernel = "";            // which pile-up kernel the last pup_accumulate ran (diagnostics)
+    const char* last_prepass = "";           // block order of the last staged call: "binning" (pup_bin.hpp) or "library_sort" (rocPRIM); "" when none ran
     unsigned warned = 0;                     // bit per reason: a large call left the staged kernels (said once per context, on stderr)
     void off_staged(unsigned bit, const char* why, long long n) {
         if ((warned & bit) || getenv("COOLPUPPY_AMD_QUIET")) return;
@@ -1137,6 +1138,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
     // block order: the hand-written binning (pup_bin.hpp) for keys of up to 23 bits, else (or with variant bit 29) the library's radix sort
     BinPlan bp{};
     const bool use_bin = k32 && !(c->variant & 1024) && bin_plan(end_bit, slot_bits, (long long)n, bp);
+    c->last_prepass = use_bin ? "binning" : "library_sort";
     size_t tmp_bytes = 0;
     hipError_t se = hipSuccess;
     if (!use_bin) {
@@ -1398,6 +1400,7 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
     }
     BinPlan bp{};
     const bool use_bin = k32 && !(c->variant & 1024) && bin_plan(end_bit, 0, n_items, bp);      // (pup_bin.hpp; else the library's radix sort)
+    c->last_prepass = use_bin ? "binning" : "library_sort";
     size_t tmp_bytes = 0;
     hipError_t se = hipSuccess;
     if (!use_bin) {
@@ -2157,16 +2160,12 @@ int pup_fetch(pup_ctx* c, double* sum, int64_t* num, int64_t* n, double* cov_sta
     if (c->T <= 0) return fail(c, PUP_ESTATE, "pup_fetch: call pup_reset first");
     int rc = pup_sync(c); if (rc) return rc;
     const int W = c->W; const size_t W2 = (size_t)W * W, Lf = W2 + 2 * (size_t)W, T = (size_t)c->T;
-    if (sum || cov_start || cov_end) {
-        std::vector<double> h(T * Lf);
-        HIPCHK(c, hipMemcpy(h.data(), c->acc_f64.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
-        for (size_t t = 0; t < T; ++t) {
-            const double* rec = h.data() + t * Lf;
-            if (sum) std::memcpy(sum + t * W2, rec, W2 * sizeof(double));
-            if (cov_start) std::memcpy(cov_start + t * W, rec + W2, (size_t)W * sizeof(double));
-            if (cov_end) std::memcpy(cov_end + t * W, rec + W2 + W, (size_t)W * sizeof(double));
-        }
-    }
+    // the three parts of a tile's record straight to their arrays (strided device rows -> dense host rows): a by-window pile-up
+    // fetches a tile per feature — a zero-filled 140 MB staging vector and a second pass over it were half of its fetch
+    const size_t pitch = Lf * sizeof(double);
+    if (sum) HIPCHK(c, hipMemcpy2D(sum, W2 * sizeof(double), c->acc_f64.p, pitch, W2 * sizeof(double), T, hipMemcpyDeviceToHost));
+    if (cov_start) HIPCHK(c, hipMemcpy2D(cov_start, (size_t)W * sizeof(double), c->acc_f64.p + W2, pitch, (size_t)W * sizeof(double), T, hipMemcpyDeviceToHost));
+    if (cov_end) HIPCHK(c, hipMemcpy2D(cov_end, (size_t)W * sizeof(double), c->acc_f64.p + W2 + W, pitch, (size_t)W * sizeof(double), T, hipMemcpyDeviceToHost));
     if (num) HIPCHK(c, hipMemcpy(num, c->acc_i64.p, T * W2 * sizeof(long long), hipMemcpyDeviceToHost));
     if (n) HIPCHK(c, hipMemcpy(n, c->acc_i64.p + T * W2, T * sizeof(long long), hipMemcpyDeviceToHost));
     return PUP_OK;
@@ -2447,6 +2446,7 @@ int pup_debug_timing(pup_ctx* c, int64_t* out, int64_t cap) {
 }
 
 const char* pup_last_kernel(const pup_ctx* c) { return c ? c->last_kernel : ""; }
+const char* pup_last_prepass(const pup_ctx* c) { return (c && c->last_staged) ? c->last_prepass : ""; }
 
 int pup_event_elapsed_ms(pup_ctx* c, int a, int b, float* ms) {
     if (!c || !ms) return PUP_EINVAL;

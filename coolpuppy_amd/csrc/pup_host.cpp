@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <atomic>
@@ -175,13 +176,25 @@ namespace {
 // open-addressing table pointer -> small code, in order of first appearance
 struct PtrTable {
     std::vector<uintptr_t> keys; std::vector<int32_t> vals; std::vector<int64_t> first; std::vector<uintptr_t> uniq; size_t cap;
-    explicit PtrTable(size_t c) : keys(c, 0), vals(c, -1), cap(c) {}
-    // code of p (a new one when unseen); -1 when that would exceed max_uniq
-    int32_t code(uintptr_t p, int64_t at, int64_t max_uniq) {
+    // (starts small and grows: a chromosome column holds a few dozen names — sixteen tables sized for the 65 536 the interface allows
+    // cost more to clear than a million pointers to hash)
+    PtrTable() : keys(256, 0), vals(256, -1), cap(256) {}
+    size_t slot(uintptr_t p) const {
         size_t h = (size_t)((p >> 4) * 0x9E3779B97F4A7C15ull) & (cap - 1);
         while (vals[h] >= 0 && keys[h] != p) h = (h + 1) & (cap - 1);
+        return h;
+    }
+    void grow() {
+        cap <<= 2;
+        keys.assign(cap, 0); vals.assign(cap, -1);
+        for (size_t j = 0; j < uniq.size(); ++j) { const size_t h = slot(uniq[j]); keys[h] = uniq[j]; vals[h] = (int32_t)j; }
+    }
+    // code of p (a new one when unseen); -1 when that would exceed max_uniq
+    int32_t code(uintptr_t p, int64_t at, int64_t max_uniq) {
+        size_t h = slot(p);
         if (vals[h] < 0) {
             if ((int64_t)uniq.size() >= max_uniq) return -1;
+            if ((uniq.size() + 1) * 4 > cap) { grow(); h = slot(p); }
             keys[h] = p; vals[h] = (int32_t)uniq.size(); uniq.push_back(p); first.push_back(at);
         }
         return vals[h];
@@ -192,14 +205,11 @@ struct PtrTable {
 
 static int64_t pup_host_factorize_ptr_impl(const uintptr_t* ptrs, int64_t n, int32_t* codes, int64_t* first, int64_t max_uniq) {
     if (n < 0 || max_uniq < 1 || (n > 0 && (!ptrs || !codes || !first))) return -2;
-    size_t cap = 64;
-    while (cap < (size_t)max_uniq * 4) cap <<= 1;
     // every worker numbers the pointers of its share on its own (runs of one value — the usual case after a sort by chromosome —
     // skip the table); the shares' dictionaries are then merged in order, which keeps the numbering that of first appearance
     // over the whole array, and the shares' codes are renumbered.  (One thread: 7 ms per 10^6 pointers.)
     const int workers = n_workers(n);
-    std::vector<PtrTable> tabs; tabs.reserve((size_t)workers);
-    for (int k = 0; k < workers; ++k) tabs.emplace_back(cap);
+    std::vector<PtrTable> tabs((size_t)workers);
     std::vector<int> over((size_t)workers, 0);
     parallel_chunks(n, workers, [&](int k, int64_t a, int64_t b) {
         PtrTable& t = tabs[(size_t)k];
@@ -213,7 +223,7 @@ static int64_t pup_host_factorize_ptr_impl(const uintptr_t* ptrs, int64_t n, int
         }
     });
     for (int k = 0; k < workers; ++k) if (over[(size_t)k]) return -1;
-    PtrTable all(cap);
+    PtrTable all;
     std::vector<std::vector<int32_t>> remap((size_t)workers);
     bool changed = false;
     for (int k = 0; k < workers; ++k) {
@@ -394,8 +404,15 @@ void mt_twist(const uint32_t* __restrict__ old, uint32_t* __restrict__ nw) {
         const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
         return c ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
     };
-    for (int k = 0; k < kMtN - kMtM; ++k) nw[k] = mix(old[k], old[k + 1], old[k + kMtM]);
-    for (int k = kMtN - kMtM; k < kMtN - 1; ++k) nw[k] = mix(old[k], old[k + 1], nw[k - (kMtN - kMtM)]);
+    // three runs without a dependence inside: [0, 227) from old words only, [227, 454) from old words and new [0, 227), [454, 623) from
+    // old words and new [227, 396) — spelled as separate source / destination pointers so that the vectoriser sees it (one loop over
+    // [227, 623) with a dependence distance of 227: half the speed under clang)
+    constexpr int D = kMtN - kMtM;                    // 227
+    for (int k = 0; k < D; ++k) nw[k] = mix(old[k], old[k + 1], old[k + kMtM]);
+    { const uint32_t* __restrict__ src = nw; uint32_t* __restrict__ dst = nw + D;
+      for (int k = 0; k < D; ++k) dst[k] = mix(old[k + D], old[k + D + 1], src[k]); }
+    { const uint32_t* __restrict__ src = nw + D; uint32_t* __restrict__ dst = nw + 2 * D;
+      for (int k = 0; k < kMtN - 1 - 2 * D; ++k) dst[k] = mix(old[k + 2 * D], old[k + 2 * D + 1], src[k]); }
     nw[kMtN - 1] = mix(old[kMtN - 1], nw[0], nw[kMtM - 1]);
 }
 
@@ -413,7 +430,10 @@ int64_t mt_temper_count(const uint32_t* __restrict__ raw, int64_t a, int64_t b, 
 }
 
 // scratch for the raw words, kept between calls (a fresh 40 MB buffer costs its page faults every time)
-std::vector<uint32_t>& mt_scratch() { static thread_local std::vector<uint32_t> v; return v; }
+// (process-wide: the draws of a pile-up come from a helper thread that lives for that call only — a thread_local buffer was a fresh
+// 40 MB and its page faults every time.  The legacy generator is one sequence: its callers are serialised anyway; the mutex makes it so.)
+std::vector<uint32_t>& mt_scratch() { static std::vector<uint32_t> v; return v; }
+std::mutex& mt_mutex() { static std::mutex m; return m; }
 
 }  // namespace
 
@@ -437,6 +457,7 @@ static int pup_host_mt_randint_impl(uint32_t* key, int32_t* pos, int64_t low, in
     mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
     const bool all = rng == 0xffffffffull;               // (numpy takes the words as they come)
     // raw words: the unread tail of the current block, then freshly twisted blocks, in rounds until m candidates are accepted
+    std::lock_guard<std::mutex> guard(mt_mutex());
     std::vector<uint32_t>& raw = mt_scratch();
     const double p_accept = ((double)rng + 1.0) / ((double)mask + 1.0);
     int64_t done = 0;                                     // accepted so far

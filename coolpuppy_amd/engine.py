@@ -369,6 +369,10 @@ class PileupEngine:
         """Kernel family that served the last accumulate call (pup_last_kernel): 'staged', 'wide', 'wide_fact', 'regtile', 'band', ..."""
         return self._lib.pup_last_kernel(self._h).decode()
 
+    def last_prepass(self):
+        """How the last staged call got its block order (pup_last_prepass): 'binning', 'library_sort', or '' (not staged)."""
+        return self._lib.pup_last_prepass(self._h).decode()
+
     def clear_stats(self):
         self._check(self._lib.pup_clear_stats(self._h))
 
@@ -508,19 +512,28 @@ def host_windows_into(r0, c0, at, st1, st2, shift, sign, nshifts, resolution, of
     return int(kept)
 
 
-def legacy_randint(low, high, m, scale=1, offset=0, discard=False, dtype=np.int64):
+def legacy_randint(low, high, m, scale=1, offset=0, discard=False, dtype=np.int64, out=None):
     """offset + scale * np.random.randint(low, high, m) of numpy's LEGACY global generator, drawn by the library
     (pup_host_mt_randint: same numbers, same generator state afterwards, several threads instead of one call per number).
     discard=True only advances the generator.  Falls back to numpy itself for tiny requests, ranges wider than 2^32 or a
     global generator that is not MT19937."""
     m = int(m)
     st = np.random.get_state(legacy=True) if m >= 2048 and 0 < int(high) - int(low) <= (1 << 32) else None
+    if out is not None and (out.shape != (m,) or not out.flags.c_contiguous or out.dtype.itemsize not in (4, 8)):
+        raise ValueError("legacy_randint: out must be a contiguous int32 / int64 array of m entries")
     if st is None or st[0] != "MT19937":
         d = np.random.randint(low, high, m)
-        return None if discard else (d if (scale == 1 and offset == 0) else offset + scale * d).astype(dtype, copy=False)
+        if discard:
+            return None
+        d = (d if (scale == 1 and offset == 0) else offset + scale * d)
+        if out is not None:
+            out[:] = d
+            return out
+        return d.astype(dtype, copy=False)
     key = np.array(st[1], dtype=np.uint32, copy=True)
     pos = C.c_int32(int(st[2]))
-    out = None if discard else np.empty(m, dtype)
+    if out is None:
+        out = None if discard else np.empty(m, dtype)
     rc = _ffi.lib().pup_host_mt_randint(_ptr(key), C.byref(pos), int(low), int(high), m, int(scale), int(offset), _ptr(out),
                                         0 if out is None else out.dtype.itemsize)
     if rc != 0:

@@ -232,11 +232,13 @@ def _finalize_tiles(pu, acc, keys, gid, G, groupby, want_control):
             Sc = cov_normalised(Sc, csc, cec)
         elif pu.expected:
             warnings.warn("Expected can not be normalized to coverage", stacklevel=3)
+    # (in place: S / Sc are this function's own copies, or views of the fetched tiles nobody reads again — a by-window pile-up holds
+    # a tile per feature, and every temporary of that size is 130 MB of fresh pages)
     with np.errstate(divide="ignore", invalid="ignore"):
-        data = S / N
+        data = np.divide(S, N, out=S)
         if want_control:
-            data = data / (Sc / Nc)
-    data = np.where(data == np.inf, np.nan, data)
+            data = np.divide(data, np.divide(Sc, Nc, out=Sc), out=data)
+    np.putmask(data, data == np.inf, np.nan)
     if pu.local:
         with warnings.catch_warnings():
             warnings.simplefilter("ignore", category=RuntimeWarning)

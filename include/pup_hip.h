@@ -46,7 +46,8 @@
  *   pup_host_alloc / pup_host_free    <- (no counterpart: page-locked staging for asynchronous host-to-device copies)
  *   pup_rccl_path                     <- (no counterpart: which librccl the communicator of pup_allreduce must come from)
  *   pup_debug_timing                  <- (no counterpart: phase clocks of the staged kernel, development aid)
- *   pup_last_kernel                   <- (no counterpart: which kernel family served the last call, for tests / benchmarks)
+ *   pup_last_kernel / pup_last_prepass <- (no counterpart: which kernel family served the last call and how its windows were
+ *                                        put in block order, for tests / benchmarks)
  *
  * Conventions
  *   - plain C: pointers + sizes only; no C++/torch types cross this line.
@@ -307,6 +308,10 @@ int pup_debug_timing(pup_ctx* ctx, int64_t* out, int64_t cap);
  * "wide_fact" = K1w, "regtile" = K1r, "band" = K1b, "sparse" = K1s, "lds_tile", "expected_diag", "rescale"; "" before the first call).
  * Results never depend on it; tests and benchmarks assert through it that the kernel they mean to measure is the one that ran.  Never NULL. */
 const char* pup_last_kernel(const pup_ctx* ctx);
+/* How the last pile-up call served by a workgroup-staged kernel got its block order: "binning" (the hand-written passes of
+ * csrc/pup_bin.hpp) or "library_sort" (rocPRIM's radix sort: keys beyond 23 bits, or tuning bit 29); "" when the last call was not
+ * staged.  Tests pin the shapes that must stay on the binning. */
+const char* pup_last_prepass(const pup_ctx* ctx);
 /* generic stream timer: record slot (0..7) on the context's stream; elapsed between two slots */
 int pup_event_record(pup_ctx* ctx, int slot);
 int pup_event_elapsed_ms(pup_ctx* ctx, int slot_begin, int slot_end, float* ms);

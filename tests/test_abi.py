@@ -59,3 +59,22 @@ def test_missing_library_is_loud(monkeypatch, tmp_path):
     monkeypatch.setattr(_ffi, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="not found"):
         _ffi.lib()
+
+
+def test_every_source_under_csrc_makes_the_library_stale(monkeypatch):
+    """coolpuppy_amd.build.is_stale(): a newer file ANYWHERE under csrc/ (or the public header) must trigger a rebuild — round 4's
+    hand-kept header list missed pup_bin.hpp, so an edit of the binning alone left tests running yesterday's library."""
+    import os
+    from coolpuppy_amd import build
+    csrc = os.path.join(ROOT, "coolpuppy_amd", "csrc")
+    sources = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".cpp", ".hpp", ".h")))
+    assert len(sources) >= 9 and any(f.endswith("pup_bin.hpp") for f in sources)
+    for f in sources + [os.path.join(ROOT, "include", "pup_hip.h")]:
+        assert f in build.DEPS, f
+    real = os.path.getmtime
+    lib_time = real(build.OUT) if os.path.exists(build.OUT) else 0.0
+    for touched in sources:
+        monkeypatch.setattr(os.path, "getmtime", lambda p, t=touched: lib_time + 10 if p == t else (lib_time if p == build.OUT else min(real(p), lib_time)))
+        assert build.is_stale(), touched
+    monkeypatch.setattr(os.path, "getmtime", lambda p: lib_time if p == build.OUT else min(real(p), lib_time))
+    assert not build.is_stale() or not os.path.exists(build.OUT)

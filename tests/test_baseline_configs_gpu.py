@@ -239,6 +239,10 @@ def test_config3_by_distance_by_strand(hg38, oracle_mod):
                      modify=modify, cols=["distance"])
     assert plan["T"] >= 30
     acc = _run_calls(pu, plan, plan["calls"])
+    # the grouped call (tile sets: slot and segment bits in the key) must stay on the hand-written binning (csrc/pup_bin.hpp) — the
+    # library's radix sort is only for keys beyond 23 bits, and a change that silently pushed this shape there would cost 0.15 ms a call
+    eng = coolpup._engine_for(pu._aclr, 0)
+    assert eng.last_kernel() == "staged" and eng.last_prepass() == "binning", (eng.last_kernel(), eng.last_prepass())
     _check_every_window_vs_oracle(pu, plan, acc)
     _check_full_size(pu, plan, acc)
     with warnings.catch_warnings():

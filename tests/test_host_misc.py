@@ -190,6 +190,7 @@ def test_draw_ahead_thread_issues_the_serial_draws():
     class CC:
         minshift, maxshift, trans = 100_000, 1_000_000, False
         _draw_raw_now = coolpup.CoordCreator._draw_raw_now
+        _draw_dtype = coolpup.CoordCreator._draw_dtype
     sizes = [5000, 1, 70_000, 2048, 300_000, 12]
     for trans in (False, True):
         cc = CC()

@@ -102,6 +102,8 @@ def test_cis_parity(engine, small_clr, oracle_mod, pad, scenario):
     _compare(got, want)
     if engine._variant == 8 and pad >= 16 and scenario in ("balanced", "ooe", "flip_groups"):
         assert engine.last_kernel().startswith("wide"), engine.last_kernel()     # K1w really ran
+        if pad == 100:        # 201-bin windows = 16 sub-window groups: their keys must stay within the hand-written binning
+            assert engine.last_prepass() == "binning", engine.last_prepass()
     if scenario == "expected_only" and engine._variant != 2:
         assert engine.last_kernel() == "expected_diag"
     # running accumulation: a second identical call doubles everything exactly for integers
