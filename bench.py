@@ -91,6 +91,26 @@ def workload_key(a):
     return hashlib.sha1(f"w6|{a.chroms}|{a.lam}|{a.pairs}|{a.nshifts}|{a.pad}".encode()).hexdigest()[:12]
 
 
+def traffic_key(a):
+    """Key of a measured-traffic entry (profiles/traffic.json): the workload, the BASELINE configuration and the kernel variant."""
+    return hashlib.sha1(f"{workload_key(a)}|config{a.config}|variant{a.variant}|trans{a.trans_nnz if a.config == 4 else 0}".encode()).hexdigest()[:12]
+
+
+def measured_traffic(a):
+    """(HBM bytes per pile-up launch, source file) measured with rocprofv3 PMC passes on THESE kernel sources for this workload, or
+    (None, None): tools/profile_round.sh -> tools/summarize_profiles.py write profiles/traffic.json."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath) or a.gpus != 1:
+        return None, None
+    try:
+        tj = json.load(open(tpath)).get("entries", {}).get(traffic_key(a))
+        if tj and tj.get("source_key") == source_key():
+            return tj.get("hbm_bytes_per_launch"), tj.get("source")
+    except Exception:
+        pass
+    return None, None
+
+
 def source_key():
     """Hash of the kernel sources: measured HBM traffic (profiles/traffic.json) is only quoted for the kernels it was
     measured on."""
@@ -639,16 +659,7 @@ def main():
         idx_lines_all = float(sum((int(co[k + 1] - co[k]) * -(-int(co[k + 1] - co[k]) // 320)) for k in range(len(co) - 1)))
         table_pass = nnz_all * 8 + idx_lines_all * 64 + 8.0 * n_set
         # (3) measured HBM bytes (rocprofv3 PMC passes over this command; quoted only for these kernel sources)
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and a.gpus == 1 and a.variant == 0:
-            try:
-                tj = json.load(open(tpath))
-                tj = tj.get("entries", {}).get(workload_key(a), tj)       # one entry per measured workload (pad 10, pad 25, ...)
-                if tj.get("workload_key") == workload_key(a) and tj.get("source_key") == source_key():
-                    traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
-            except Exception:
-                traffic = None
+        traffic, traffic_src = measured_traffic(a)
         peak = HBM_PEAK_GBPS * a.gpus
         frac_comp = compulsory / (k1_ms * 1e-3) / 1e9 / peak if a.scaling != "weak" or a.gpus == 1 else None
         frac_traffic = None if traffic is None else traffic / (k1_ms * 1e-3) / 1e9 / peak

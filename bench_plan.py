@@ -187,6 +187,9 @@ def main_plan(a, rank, world, local_rank, bench):
     staged = int(st.get("staged_regions", 0)) > 0
     lds_bytes = (n_all // a.gpus) * W * W * 8
     lds_peak = 256 * 256 * 2.4
+    # measured HBM bytes of the step's pile-up launches (rocprofv3 PMC passes over this command on these sources: profiles/traffic.json)
+    traffic, traffic_src = bench.measured_traffic(a)
+    frac_traffic = None if traffic is None else traffic / (k1 * 1e-3) / 1e9 / peak
     roofline = {
         "bound": "lds" if staged else "hbm", "kernel_family": "+".join(families),
         "kernel": ("pup::pileup_staged_kernel (K1q, sets of four tile pairs per staging)" if staged else
@@ -195,10 +198,14 @@ def main_plan(a, rank, world, local_rank, bench):
         "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
         # trans windows share nothing (no reuse): the 8(d) bytes are what the kernel must move and frac is a real fraction;
         # the grouped cis pile-up serves its windows from LDS-staged regions: its own bound is the LDS read rate
-        "frac": round(lds_bytes / (k1 * 1e-3) / 1e9 / lds_peak, 4) if staged else round(achieved / peak, 4),
-        "frac_is": "lds_frac" if staged else "algorithmic_over_peak",
+        # frac = MEASURED HBM bytes / kernel time / peak — the same quantity as the headline line's — whenever a measurement of these
+        # sources is on file; else what round 4 printed (the kernel's own bound for the staged path, the 8(d) bytes for trans windows)
+        "frac": round(frac_traffic, 4) if frac_traffic is not None else
+                (round(lds_bytes / (k1 * 1e-3) / 1e9 / lds_peak, 4) if staged else round(achieved / peak, 4)),
+        "frac_is": "frac_traffic" if frac_traffic is not None else ("lds_frac" if staged else "algorithmic_over_peak"),
+        "frac_traffic": None if frac_traffic is None else round(frac_traffic, 4),
         "lds_frac": round(lds_bytes / (k1 * 1e-3) / 1e9 / lds_peak, 4) if staged else None,
-        "algorithmic_over_peak": round(achieved / peak, 4), "traffic": None,
+        "algorithmic_over_peak": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
         "kernel_ms_per_step": round(k1, 4), "prepass_ms_per_step": round(st.get("prepare_ms", 0.0) / launches * len(calls), 4),
         "reduce_ms_per_step": round(st.get("reduce_ms", 0.0) / launches * len(calls), 4),
         "algorithmic_bytes_per_step": round(alg / a.gpus), "nnz_win_mean": round(pix_all / max(n_all, 1), 1),

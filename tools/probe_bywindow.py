@@ -12,6 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--every", type=int, default=1, help="use every k-th site")
 ap.add_argument("--maxdist", type=int, default=1_000_000)
 ap.add_argument("--out", default="")
+ap.add_argument("--reps", type=int, default=3)
 a = ap.parse_args()
 warnings.simplefilter("ignore")
 clr = synth.make_cooler(synth.MM9, binsize=10_000, lam=120, seed=1000, name="mm9_like", parallel=True)
@@ -23,7 +24,7 @@ coolpup.pileup(clr, bed, **kw)
 eng = next(iter(coolpup._ENGINES.values()))[1]
 eng.set_profiling(3)
 res = []
-for rep in range(3):
+for rep in range(a.reps):
     eng.clear_stats()
     t = time.time(); df = coolpup.pileup(clr, bed, **kw); wall = time.time() - t
     st = eng.stats()

@@ -14,6 +14,8 @@ import sys
 import pandas as pd
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GENERIC = "--generic" in sys.argv          # any command under the profiler (no bench line): kernel stats + counter means only
+sys.argv = [x for x in sys.argv if x != "--generic"]
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 prof = os.path.join(ROOT, "gpurun_out", "prof")
 out = os.path.join(ROOT, "profiles")
@@ -21,8 +23,10 @@ os.makedirs(out, exist_ok=True)
 
 stats = glob.glob(os.path.join(prof, "stats", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(stats, os.path.join(out, f"{tag}_kernel_stats.csv"))
-bench = json.loads(open(os.path.join(prof, "stats_bench.json")).read().strip().splitlines()[-1])
-nnz = bench["config"]["nnz"]
+bench = None
+if not GENERIC:
+    bench = json.loads(open(os.path.join(prof, "stats_bench.json")).read().strip().splitlines()[-1])
+    nnz = bench["config"]["nnz"]
 
 summary = {}
 for d in sorted(glob.glob(os.path.join(prof, "pmc_*"))):
@@ -44,6 +48,26 @@ for d in sorted(glob.glob(os.path.join(prof, "pmc_*"))):
         e["ms_per_launch_under_pmc"] = float(tr[tr.Kernel_Name == kname].ms.mean())
         e["vgpr"] = int(g.VGPR_Count.iloc[0]); e["agpr"] = int(g.Accum_VGPR_Count.iloc[0])
         e["lds_bytes"] = int(g.LDS_Block_Size.iloc[0])
+
+if GENERIC:
+    def _mix(cs):
+        g = lambda n: cs.get(n, {}).get("mean_per_launch")      # noqa: E731
+        out = {}
+        if g("SQ_INSTS_VALU"):
+            out["salu_over_valu"] = round(g("SQ_INSTS_SALU") / g("SQ_INSTS_VALU"), 3) if g("SQ_INSTS_SALU") else None
+            out["wait_any_over_wave_cycles"] = round(g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), 3) if g("SQ_WAIT_ANY") and g("SQ_WAVE_CYCLES") else None
+        if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum"):
+            out["l2_hit"] = round(g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")), 3)
+        if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+            out["hbm_bytes_per_launch_x2_rule"] = g("FETCH_SIZE") * 1024 * 2.0 + g("WRITE_SIZE") * 1024      # (guide: gfx950 FETCH_SIZE counts wide reads at half)
+        return out
+    for k in summary:
+        summary[k]["derived"] = _mix(summary[k]["counters"])
+    note = open(os.path.join(prof, "stats_bench.json")).read()[-4000:] if os.path.exists(os.path.join(prof, "stats_bench.json")) else ""
+    json.dump({"command_output_tail": note, "kernels": summary, "units": "FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB"},
+              open(os.path.join(out, f"{tag}_pmc_summary.json"), "w"), indent=1)
+    print(json.dumps({k: v["derived"] for k, v in summary.items() if "pileup" in k or "reduce" in k}, indent=1))
+    sys.exit(0)
 
 # the pile-up step may be served by two kernels (block-staged for dense tiles + plain register tile for sparse ones):
 # traffic and time of "K1" are the sums over the pile-up kernels launched once per step
@@ -69,15 +93,29 @@ if cal:
                           "write_bytes_per_counted_byte": nnz * 8.0 / cal_write}
     factor = known_read / cal_fetch
 hbm = fetch_kib * 1024 * factor + write_kib * 1024
+rl = bench.get("roofline", {})
 doc["k1"] = {"kernel": k1, "FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib, "fetch_correction_factor": factor,
              "hbm_bytes_per_launch": hbm,
-             "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"]}
+             "algorithmic_bytes_per_launch": rl.get("algorithmic_bytes_per_launch", rl.get("algorithmic_bytes_per_step"))}
+# instruction mix and waiting of the pile-up kernel(s): what the verdicts quote (SALU / VALU, waves waiting, LDS conflicts)
+mix = {}
+for k in k1s:
+    cs = summary[k]["counters"]
+    g = lambda n: cs.get(n, {}).get("mean_per_launch")      # noqa: E731
+    if g("SQ_INSTS_VALU"):
+        mix[k] = {"salu_over_valu": round(g("SQ_INSTS_SALU") / g("SQ_INSTS_VALU"), 3) if g("SQ_INSTS_SALU") else None,
+                  "wait_any_over_wave_cycles": round(g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), 3) if g("SQ_WAIT_ANY") and g("SQ_WAVE_CYCLES") else None,
+                  "lds_bank_conflict_over_lds_active": round(g("SQ_LDS_BANK_CONFLICT") / g("SQ_ACTIVE_INST_LDS"), 4) if g("SQ_LDS_BANK_CONFLICT") is not None and g("SQ_ACTIVE_INST_LDS") else None,
+                  "l2_hit": round(g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")), 3) if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") else None}
+doc["k1"]["instruction_mix"] = mix
 json.dump(doc, open(os.path.join(out, f"{tag}_pmc_summary.json"), "w"), indent=1)
 sys.path.insert(0, ROOT)
 import bench as bench_mod                                     # workload / kernel-source keys exactly as bench.py computes them
 c = bench["config"]
-args = bench_mod.parse(["--pairs", str(c["pairs"]), "--nshifts", str(c["nshifts"]), "--pad", str(c["pad"])])
-entry = {"workload_key": bench_mod.workload_key(args), "source_key": bench_mod.source_key(),
+cfg = 3 if "configs[3]" in c["workload"] else (4 if "configs[4]" in c["workload"] else 2)
+args = bench_mod.parse(["--pairs", str(c["pairs"]), "--nshifts", str(c["nshifts"]), "--pad", str(c["pad"]), "--config", str(cfg),
+                        "--variant", str(c.get("variant", 0))] if cfg == 2 else ["--config", str(cfg), "--variant", str(c.get("variant", 0))])
+entry = {"workload_key": bench_mod.traffic_key(args), "workload": c["workload"], "variant": c.get("variant", 0), "source_key": bench_mod.source_key(),
          "hbm_bytes_per_launch": hbm, "kernel": k1, "source": f"profiles/{tag}_pmc_summary.json",
          "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB->bytes, FETCH_SIZE x calibration "
                    "factor measured on balance_pixels_kernel (known 8 B/pixel stream) in the same run; quoted by "
@@ -91,6 +129,7 @@ if os.path.exists(tpath):
         book = old if "entries" in old else {"entries": {old["workload_key"]: old}}
     except Exception:
         pass
+book["entries"] = {k: v for k, v in book["entries"].items() if v.get("source_key") == entry["source_key"]}      # (other sources: void)
 book["entries"][entry["workload_key"]] = entry
 json.dump(book, open(tpath, "w"), indent=1)
 print(json.dumps(doc["k1"], indent=1)); print(json.dumps(doc.get("calibration"), indent=1))
