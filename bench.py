@@ -523,6 +523,12 @@ def main():
             if native_comm is not None:
                 rccl_ranks = pdist.comm_ranks(native_comm)
                 exchange_used = "pup_allreduce (RCCL on the engine's stream, in place)"
+            # --exchange native is the path the line claims to measure: a communicator that is missing or spans fewer ranks than
+            # the job would time something else under that name — say so and stop (--exchange torch asks for the fallback openly)
+            if rccl_ranks != world:
+                raise SystemExit(f"[bench] rank {rank}: --exchange native on {world} ranks, but the engine's RCCL communicator spans "
+                                 f"{rccl_ranks} rank(s) — refusing to report a number for a path that did not run "
+                                 f"(--exchange torch times torch.distributed.all_reduce on exported buffers instead)")
 
     def make_step(p_r0, p_c0, n, tptr):
         def step():

@@ -147,9 +147,20 @@ def main_plan(a, rank, world, local_rank, bench):
         if world > 1:
             pdist.allreduce_engine(eng)      # pup_allreduce (RCCL on the engine's stream) with nccl, host memory with gloo
 
+    if a.exchange == "torch":
+        os.environ["COOLPUPPY_AMD_NATIVE_RCCL"] = "0"    # (dist.allreduce_engine: torch.distributed.all_reduce on exported buffers)
     # pixel statistics once, outside the timed region
     eng.set_profiling(1); eng.clear_stats()
     step(); eng.sync()
+    rccl_ranks = None
+    if world > 1 and a.backend == "nccl" and a.exchange == "native":
+        # the line below says "pup_allreduce": it must have been what ran — a communicator that could not be set up (the library then
+        # falls back with a warning) or that spans fewer ranks than the job is an error here, not a footnote
+        comm = pdist._NATIVE_COMMS.get((eng.device_id, world), (None, None))[0]
+        rccl_ranks = pdist.comm_ranks(comm) if comm else None
+        if rccl_ranks != world:
+            raise SystemExit(f"[bench] rank {rank}: --exchange native on {world} ranks, but the engine's RCCL communicator spans "
+                             f"{rccl_ranks} rank(s) — refusing to report a number for a path that did not run")
     pix_local = float(eng.stats()["pixels_in_windows"])
     families = sorted({eng.last_kernel()})
     eng.set_profiling(0)
@@ -243,6 +254,7 @@ def main_plan(a, rank, world, local_rank, bench):
                    "variant": a.variant},
         "exchange": "none" if world == 1 else ("pup_allreduce (RCCL on the engine's stream)" if a.backend == "nccl" and a.exchange == "native"
                                                 else "torch.distributed.all_reduce on exported buffers"),
+        "rccl_ranks": rccl_ranks,
         "host_coordinates_plan_s": round(t_host, 3),
         "check": {"n": [int(x) for x in out["n"]], "n_sum": int(out["n"].sum())},
         "roofline": roofline, "cpu_baseline": cpu,

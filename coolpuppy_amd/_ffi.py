@@ -54,6 +54,7 @@ _SIGNATURES = {
     "pup_version": (C.c_int, []),
     "pup_device_count": (C.c_int, []),
     "pup_load_pixels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64]),
+    "pup_load_pixel_values": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "pup_build_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64]),
     "pup_coverage": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "pup_load_bins": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

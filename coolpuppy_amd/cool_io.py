@@ -289,8 +289,15 @@ def stream_pixels_into(eng, clr, slab_pixels=0):
     g = src["group"]
     cdt = np.dtype(src["count_dtype"])
     if cdt.kind not in "iu":
-        f.close()
-        raise NotImplementedError("coolers with non-integer pixel counts are not supported by the GPU engine")
+        # a float pixels/count column: the whole table through host memory (PileupEngine.load_pixels takes float values — as int32
+        # when they are whole numbers, else as float64 beside the table: pup_load_pixel_values)
+        try:
+            bin2 = f.read(f"{g}/pixels/bin2_id")
+            vals = f.read(f"{g}/pixels/count")
+        finally:
+            f.close()
+        eng.load_pixels(clr.bin1_offset, bin2, vals)
+        return {"h2d_ms": None, "h2d_bytes": None, "h2d_GBps": None}
     b2dt = np.dtype(np.int64) if np.dtype(src["bin2_dtype"]).itemsize == 8 else np.dtype(np.int32)
 
     def fill(first, m, colv, cntv):
@@ -362,9 +369,10 @@ def read_cool(path, group="/", extra_bins=None, stream_pixels=False):
 
 
 def _counts32(count):
-    """pixels/count as the engine's int32 — refusing, not wrapping, what does not fit."""
-    if not np.issubdtype(count.dtype, np.integer):
-        raise NotImplementedError("coolers with non-integer pixel counts are not supported by the GPU engine")
+    """pixels/count as the engine's int32 — refusing, not wrapping, what does not fit.  A float column is kept as it is
+    (PileupEngine.load_pixels uploads it as float64 pixel values)."""
+    if count.dtype.kind == "f":
+        return count
     if count.dtype.itemsize > 4 and count.size and (int(count.max()) > 2**31 - 1 or int(count.min()) < 0):
         raise OverflowError("pixel counts outside 0 .. 2^31-1 do not fit the engine's int32 pixel table")
     return count.astype(np.int32)

@@ -58,6 +58,8 @@ struct pup_ctx {
     DevBuf<long long> indptr;
     DevBuf<int2> px;
     DevBuf<int> cnt32;
+    DevBuf<double> cntf;                     // pixel values of a float pixels/count column (pup_load_pixel_values); float_values says whether in use
+    bool float_values = false;
     DevBuf<double> bal;
     DevBuf<unsigned long long> badbits;
     DevBuf<unsigned long long> nf_keys;      // pixels with a non-finite balanced value (see collect_nonfinite_kernel), sorted
@@ -440,6 +442,28 @@ int pup_load_pixels(pup_ctx* c, const int64_t* bin1_offset, const void* bin2_id,
     if (status != PUP_OK) return status;
     c->nbins = nbins; c->nnz = nnz; c->have_px = true;
     c->have_weight = c->have_cov = false; c->have_bal = false;
+    c->float_values = false;
+    return PUP_OK;
+}
+
+// Float pixel values: cooler allows pixels/count to be a float column (merged / scaled / simulated maps) and the reference multiplies
+// whatever it finds (coolpuppy/coolpup.py:1053-1057).  The engine's own tables are integer counts — the dense band, the count
+// arrays the staged kernels balance at store time, the exact integer sums of the coverage kernel — so such a table is served by the
+// kernels that read the balanced VALUE table (`bal`, float64, built from these values by pup_load_bins): the per-window register
+// tile (K1r), the banded tile (K1b), the sparse trans kernel (K1s), rescaled windows, stripes and per-snippet windows.  Same
+// results as for counts; the staged kernels and pup_coverage decline (the latter with PUP_ENOTSUP).
+int pup_load_pixel_values(pup_ctx* c, const double* value, int64_t nnz) {
+    if (!c) return PUP_EINVAL;
+    if (!c->have_px) return fail(c, PUP_ESTATE, "pup_load_pixel_values: call pup_load_pixels first");
+    if (nnz != c->nnz || (nnz > 0 && !value)) return fail(c, PUP_EINVAL, "pup_load_pixel_values: %lld values for a table of %lld pixels", (long long)nnz, (long long)c->nnz);
+    int rc = bind(c); if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, c->cntf.reserve((size_t)std::max<int64_t>(nnz, 1)));
+    if (nnz > 0) HIPCHK(c, hipMemcpy(c->cntf.p, value, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
+    c->float_values = true;
+    c->band_w = 0;                                       // (a band built from the placeholder counts must not be staged from)
+    c->have_bal = false; c->have_weight = c->have_cov = false;       // pup_load_bins rebuilds the value table
+    c->forget_hints();
     return PUP_OK;
 }
 
@@ -610,7 +634,7 @@ int pup_build_index(pup_ctx* c, const int64_t* chrom_offset, int32_t n_chroms, i
             const long long v = atoll(e);
             if (v == 256 || v == 512 || v == 1024 || v == 2048 || v == 4096) widest = v;
         }
-        for (long long BWd = widest; BWd >= 256 && have_mem && !(c->variant & 256); BWd >>= 1) {
+        for (long long BWd = widest; BWd >= 256 && have_mem && !(c->variant & 256) && !c->float_values; BWd >>= 1) {
             const long long cells = pup::kBandFront + (c->nbins + 129) * BWd;
             if (!((size_t)cells * 4 <= fb / 4 + c->band.cap * sizeof(int))) continue;     // (64-bit addressed: no cell-count limit)
             HIPCHK(c, c->band.reserve((size_t)cells));
@@ -635,6 +659,7 @@ int pup_coverage(pup_ctx* c, const int64_t* chrom_offset, int32_t n_chroms, int3
     if (chrom_offset[0] != 0 || chrom_offset[n_chroms] != c->nbins)
         return fail(c, PUP_EINVAL, "pup_coverage: chrom_offset must run from 0 to nbins=%lld", c->nbins);
     if (ignore_diags < 0) return fail(c, PUP_EINVAL, "pup_coverage: ignore_diags must be >= 0");
+    if (c->float_values) return fail(c, PUP_ENOTSUP, "pup_coverage: the table holds float pixel values (pup_load_pixel_values); the coverage kernel sums integer counts exactly — supply cov_*_raw columns computed elsewhere");
     int rc = bind(c); if (rc) return rc;
     std::vector<pup::IdxChrom> tab((size_t)n_chroms);
     for (int k = 0; k < n_chroms; ++k) {
@@ -698,7 +723,7 @@ int pup_load_bins(pup_ctx* c, const double* weight, const double* cov) {
     const double* dw = c->have_weight ? c->weight.p : nullptr;
     const unsigned gb = (unsigned)std::min<long long>((c->nbins + 3) / 4, 1 << 20);
     hipLaunchKernelGGL(pup::balance_pixels_kernel, dim3(gb), dim3(256), 0, c->stream,
-                       c->indptr.p, c->px.p, dw, c->bal.p, c->nbins);
+                       c->indptr.p, c->px.p, dw, c->bal.p, c->nbins, c->float_values ? (const double*)c->cntf.p : (const double*)nullptr);
     hipLaunchKernelGGL(pup::badbits_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, c->stream,
                        dw, c->badbits.p, c->nbins, nwords);
     HIPCHK(c, hipGetLastError());
@@ -714,7 +739,7 @@ int pup_load_bins(pup_ctx* c, const double* weight, const double* cov) {
         for (int pass = 0; pass < 2; ++pass) {
             HIPCHK(c, hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), c->stream));
             hipLaunchKernelGGL(pup::collect_nonfinite_kernel, dim3(gb), dim3(256), 0, c->stream, c->indptr.p, c->px.p, dw, c->nbins,
-                               pass ? c->nf_keys.p : nullptr, total, cnt.p);
+                               pass ? c->nf_keys.p : nullptr, total, cnt.p, c->float_values ? (const double*)c->cntf.p : (const double*)nullptr);
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipMemcpyAsync(&total, cnt.p, sizeof(total), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -862,7 +887,7 @@ static void launch_key_kernel(pup_ctx* c, int BR, int BC, unsigned grid, const i
 }   // extern "C++"
 
 static void fill_k1_args(pup_ctx* c, pup::K1Args& a, int32_t ignore_diags, uint32_t mode) {
-    a.indptr = c->indptr.p; a.px = c->px.p; a.cnt32 = c->cnt32.p;
+    a.indptr = c->indptr.p; a.px = c->px.p; a.cnt32 = c->cnt32.p; a.cntf = c->float_values ? c->cntf.p : nullptr;
     a.bal = c->bal.p; a.badbits = c->badbits.p;
     const bool use_idx = c->have_idx && !(c->variant & 1);
     a.idx = use_idx ? c->idx.p : nullptr; a.idx_chrom = use_idx ? c->idx_chrom.p : nullptr;
@@ -975,7 +1000,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
                       int32_t ignore_diags, uint32_t mode, bool rescale, hipEvent_t* ev) {
     const int W = c->W, T = c->T;
     c->last_stagings = 0; c->last_staged = false;
-    const bool force = (c->variant & 8) != 0, forbid = (c->variant & 16) != 0;
+    const bool force = (c->variant & 8) != 0, forbid = (c->variant & 16) != 0 || c->float_values;     // (float pixel values: the kernels on the `bal` table)
     const bool use_idx_t = c->have_idx && !(c->variant & 1);
     if (c->n_chrom > pup::kKeyMaxChrom && !forbid && !rescale && ignore_diags >= 0 && n >= c->tiled_min)
         c->off_staged(8u, "the table has more chromosomes / scaffolds than the staged kernels' key pass keeps in LDS (3072)", (long long)n);
@@ -1315,7 +1340,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
 static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const int64_t* tile_ptr, const int64_t* flip_from,
                     int32_t ignore_diags, uint32_t mode, bool rescale, hipEvent_t* ev) {
     const int W = c->W, T = c->T;
-    const bool force = (c->variant & 8) != 0, forbid = (c->variant & 16) != 0;
+    const bool force = (c->variant & 8) != 0, forbid = (c->variant & 16) != 0 || c->float_values;
     const bool ooe = (mode & PUP_MODE_OOE) != 0;
     const bool cov_sep = (mode & PUP_MODE_COV) && c->have_cov;
     if (forbid || rescale || (mode & (PUP_MODE_EXPECTED | PUP_MODE_TRANSPOSE)) || (c->variant & (1 | 2 | 256)) || c->count_pixels ||
@@ -2038,7 +2063,7 @@ int pup_stripes(pup_ctx* c, const int32_t* r0, const int32_t* c0, int64_t n, int
     if (e == hipSuccess) e = hipMemcpy(c->d_c0.p, c0, (size_t)n * sizeof(int), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         pup::K1Args a{};
-        a.indptr = c->indptr.p; a.px = c->px.p;
+        a.indptr = c->indptr.p; a.px = c->px.p; a.cntf = c->float_values ? c->cntf.p : nullptr;
         a.weight = c->have_weight ? c->weight.p : nullptr;
         a.expv = (c->nexp > 0 || (c->n_exp_regions > 0 && !c->have_exp_pair)) ? c->expv.p : nullptr;
         a.nexp = c->nexp; a.nbins = c->nbins;
@@ -2096,7 +2121,7 @@ int pup_extract(pup_ctx* c, const int32_t* r0, const int32_t* c0, const int32_t*
     if (e == hipSuccess && cov_start) e = d_cov.reserve((size_t)n * 2 * W);
     if (e == hipSuccess) {
         pup::K1Args a{};
-        a.indptr = c->indptr.p; a.px = c->px.p; a.cnt32 = c->cnt32.p;
+        a.indptr = c->indptr.p; a.px = c->px.p; a.cnt32 = c->cnt32.p; a.cntf = c->float_values ? c->cntf.p : nullptr;
         a.bal = c->bal.p; a.badbits = c->badbits.p;
         const bool use_idx = c->have_idx && !(c->variant & 1);
         a.idx = use_idx ? c->idx.p : nullptr; a.idx_chrom = use_idx ? c->idx_chrom.p : nullptr;

@@ -75,6 +75,8 @@ struct K1Args {
     const long long* indptr;   // [nbins+1]
     const int2*      px;       // [nnz] {col, count}
     const int*       cnt32;    // [nnz+64] counts only (LDS-tile kernel, indexed path)
+    const double*    cntf;     // [nnz] pixel VALUES as float64 when the cooler's pixels/count is a float column (pup_load_pixel_values),
+                               //       else nullptr: the integer counts above are then placeholders and only kernels reading `bal` / this run
     const double*    bal;      // [nnz+64] balanced value of every pixel, count*w[row]*w[col] (0 where a weight is
                                //          NaN; plain count when raw) — what get_data() yields, computed once per
                                //          (table, weight column); read by the register-tile kernel
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(kWave) void pileup_chunk_kernel(K1Args a) {
                 if ((bits >> j) & 1ull) {
                     ++npix;
                     const long long pos = st[p] + __popcll(bits & ((1ull << j) - 1ull));
-                    double val = (double)a.cnt32[pos] * wrp * wcj;
+                    double val = (a.cntf ? a.cntf[pos] : (double)a.cnt32[pos]) * wrp * wcj;
                     bool okv = (val == val) && (igd < 0 || dj >= igd);
                     if (m_ooe) { val = val / ej; okv = okv && (val == val); }
                     if (okv) lds_add_f64(&tsum[cell], val);
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(kWave) void pileup_chunk_kernel(K1Args a) {
                     const int q = e2.x - c0s;              // >= 0 by lower_bound
                     if (q < W) {
                         ++npix;
-                        double val = (double)e2.y * wrp * wc[q];
+                        double val = (a.cntf ? a.cntf[pos] : (double)e2.y) * wrp * wc[q];
                         const int d = (c0s + q) - (r0s + p);
                         bool okv = (val == val) && (igd < 0 || d >= igd);
                         if (m_ooe) { val = val / (use_exp ? ex[q - p + W - 1] : __builtin_nan("")); okv = okv && (val == val); }
@@ -1222,7 +1224,7 @@ constexpr int kRescaleSepK = 64;                      // most zoom weights kept 
 // column holds +-inf: cooler multiplies such pixels out to +-inf or NaN (0 * inf) and the reference's windows carry exactly
 // that (coolpuppy/coolpup.py:1115-1123), while `bal` keeps NaN products as 0 for the accumulating kernels
 __device__ __forceinline__ double pixel_value(const K1Args& a, long long pos, int row, int col) {
-    if (a.nf_pixels && a.weight) return (double)a.cnt32[pos] * a.weight[row] * a.weight[col];
+    if (a.nf_pixels && a.weight) return (a.cntf ? a.cntf[pos] : (double)a.cnt32[pos]) * a.weight[row] * a.weight[col];
     return a.bal[pos];
 }
 
@@ -1528,7 +1530,7 @@ PUP_KERNEL __launch_bounds__(1024) void pileup_rescale_kernel(K1Args a, const in
 // (count * w[row]) * w[col]; NaN (masked bin) is stored as 0 and masked through badbits instead
 PUP_KERNEL __launch_bounds__(256) void balance_pixels_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
                                                              const double* __restrict__ weight, double* __restrict__ bal,
-                                                             long long nbins) {
+                                                             long long nbins, const double* __restrict__ cntf = nullptr) {
     const int lane = threadIdx.x & 63;
     long long r = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long stride = (long long)gridDim.x * (blockDim.x >> 6);
@@ -1537,7 +1539,7 @@ PUP_KERNEL __launch_bounds__(256) void balance_pixels_kernel(const long long* __
         const long long b = indptr[r], e = indptr[r + 1];
         for (long long k = b + lane; k < e; k += 64) {
             const int2 pc = px[k];
-            double v = (double)pc.y;
+            double v = cntf ? cntf[k] : (double)pc.y;        // (float pixel values: cooler multiplies them through the same way)
             if (weight) { v = v * wr * weight[pc.x]; if (!(v == v)) v = 0.0; }
             bal[k] = v;
         }
@@ -1552,7 +1554,7 @@ PUP_KERNEL __launch_bounds__(256) void balance_pixels_kernel(const long long* __
 PUP_KERNEL __launch_bounds__(256) void collect_nonfinite_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
                                                                 const double* __restrict__ weight, long long nbins,
                                                                 unsigned long long* __restrict__ keys, unsigned long long cap,
-                                                                unsigned long long* __restrict__ count) {
+                                                                unsigned long long* __restrict__ count, const double* __restrict__ cntf = nullptr) {
     const int lane = threadIdx.x & 63;
     long long r = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long stride = (long long)gridDim.x * (blockDim.x >> 6);
@@ -1564,7 +1566,7 @@ PUP_KERNEL __launch_bounds__(256) void collect_nonfinite_kernel(const long long*
             const int2 pc = px[k];
             const double wc = weight[pc.x];
             if (wc != wc) continue;
-            const double v = (double)pc.y * wr * wc;
+            const double v = (cntf ? cntf[k] : (double)pc.y) * wr * wc;
             if (v == v && !__builtin_isinf(v)) continue;
             const int both = (pc.x != (int)r) ? 2 : 1;
             const unsigned long long at = atomicAdd(count, (unsigned long long)both);
@@ -1807,12 +1809,12 @@ PUP_KERNEL __launch_bounds__(512) void coverage_kernel(const long long* __restri
 // (coolpup.py:1164-1169): horizontal = data[pad, :], vertical = data[:, pad][::-1].  Output is O(n*W), not a
 // reduction: one wave per snippet, lanes 0..W-1 look up the row cells, lanes W..2W-1 the column cells, each by a
 // binary search of its matrix row (2W cells per snippet: the index would save nothing worth its code here).
-__device__ __forceinline__ int find_count(const K1Args& a, int row, int col, bool& found) {
+__device__ __forceinline__ double find_count(const K1Args& a, int row, int col, bool& found) {
     long long lo = a.indptr[row], hi = a.indptr[row + 1];
     const long long end = hi;
     while (lo < hi) { const long long m = (lo + hi) >> 1; if (a.px[m].x < col) lo = m + 1; else hi = m; }
     found = lo < end && a.px[lo].x == col;
-    return found ? a.px[lo].y : 0;
+    return found ? (a.cntf ? a.cntf[lo] : (double)a.px[lo].y) : 0.0;      // (float pixel values: pup_load_pixel_values)
 }
 
 PUP_KERNEL __launch_bounds__(kWave) void stripes_kernel(K1Args a, long long n, double* __restrict__ h_out,
@@ -1841,7 +1843,7 @@ PUP_KERNEL __launch_bounds__(kWave) void stripes_kernel(K1Args a, long long n, d
             else       { p = horiz ? i : pad;           q = horiz ? pad : (W - 1 - i); }
             const int row = r0s + p, col = c0s + q;
             bool found;
-            double v = (double)find_count(a, row, col, found);
+            double v = find_count(a, row, col, found);
             if (a.weight) {
                 const double wr = a.weight[row], wc = a.weight[col];
                 // cooler multiplies stored pixels out (a stored 0 next to an infinite weight is NaN); cells without a

@@ -85,9 +85,21 @@ class PileupEngine:
         if bin2_id.dtype not in (np.dtype(np.int32), np.dtype(np.int64)):
             bin2_id = bin2_id.astype(np.int64)
         count = np.ascontiguousarray(count)
+        values = None
+        if count.dtype.kind == "f":
+            # a float pixels/count column (cooler allows it; the reference multiplies it through, coolpup.py:1053-1057): whole
+            # numbers in range ARE counts — every kernel serves them; anything else goes up as float64 pixel values beside the
+            # table (pup_load_pixel_values) and is piled up by the kernels on the balanced value table
+            whole = count.size == 0 or (bool(np.all(np.isfinite(count))) and bool(np.all(count == np.floor(count)))
+                                        and 0 <= float(count.min()) and float(count.max()) <= 2**31 - 1)
+            if whole:
+                count = count.astype(np.int32)
+            else:
+                values = np.ascontiguousarray(count, np.float64)
+                count = np.zeros(count.shape[0], np.int32)
         if count.dtype != np.int32:
             if not np.issubdtype(count.dtype, np.integer):
-                raise PupError(-6, f"pixel counts of dtype {count.dtype} are not supported (int32 expected)")
+                raise PupError(-6, f"pixel counts of dtype {count.dtype} are not supported (integers or floats expected)")
             if count.size and (int(count.max()) > 2**31 - 1 or int(count.min()) < 0):
                 raise PupError(-5, "pixel counts outside 0 .. 2^31-1 do not fit the engine's int32 pixel table")
             count = count.astype(np.int32)
@@ -97,7 +109,10 @@ class PileupEngine:
             raise ValueError("bin2_id and count differ in length")
         self._check(self._lib.pup_load_pixels(self._h, _ptr(bin1_offset), _ptr(bin2_id), bin2_id.dtype.itemsize,
                                               _ptr(count), nbins, nnz))
+        if values is not None:
+            self._check(self._lib.pup_load_pixel_values(self._h, _ptr(values), nnz))
         self.nbins, self.nnz = nbins, nnz
+        self.float_values = values is not None
 
     def load_pixels_stream(self, bin1_offset, nnz, bin2_dtype, fill, slab_pixels=0):
         """The pixel table streamed in (pup_load_pixels_stream): ``fill(first, m, bin2_view, count_view)`` writes pixels

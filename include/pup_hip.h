@@ -20,6 +20,7 @@
  *                                                                      coolpuppy/coolpup.py:1059-1191, 1236-1283
  *                                                                      coolpuppy/lib/puputils.py:12-41
  *                                        (flip bit: flip_snip_func     coolpuppy/coolpup.py:128-147)
+ *   pup_load_pixel_values             <- the same table when pixels/count is a float column   coolpuppy/coolpup.py:1053-1057
  *   pup_coverage                      <- cooltools.api.coverage.coverage(clr, ignore_diags=..., store=True), called by
  *                                        PileUpper.__init__ when cov_*_raw is missing     coolpuppy/coolpup.py:955-963
  *   pup_accumulate_rescaled           <- the same loop with _rescale_snip               coolpuppy/coolpup.py:1159-1162, 1193-1234
@@ -113,6 +114,17 @@ int  pup_device_count(void);
  */
 int pup_load_pixels(pup_ctx* ctx, const int64_t* bin1_offset, const void* bin2_id, int bin2_bytes,
                     const int32_t* count, int64_t nbins, int64_t nnz);
+
+/*
+ * pup_load_pixel_values: the pixel VALUES as float64, for coolers whose pixels/count is a float column (cooler allows it —
+ * merged, scaled or simulated maps — and the reference multiplies whatever matrix(balance=...) hands it,
+ * coolpuppy/coolpup.py:1053-1057).  Call after pup_load_pixels (whose integer counts are then placeholders; pass zeros) and
+ * before pup_load_bins.  The table is then piled up by the kernels that read the balanced value table (per-window register /
+ * banded tiles, the sparse trans kernel, rescaled windows, stripes, per-snippet windows): same results as for counts.  The
+ * workgroup-staged kernels (integer count tables, dense band) do not run on it, and pup_coverage — exact integer sums —
+ * returns PUP_ENOTSUP.  The next pup_load_pixels returns the context to integer counts.
+ */
+int pup_load_pixel_values(pup_ctx* ctx, const double* value, int64_t nnz);
 /*
  * The same table STREAMED in: the caller hands over a reader instead of whole arrays.  The library owns two page-locked slabs and
  * calls fill(user, first, m, bin2_id, count) to have pixels [first, first + m) written into one of them (bin2_id: m values of

@@ -329,6 +329,17 @@ def scenarios():
                 kw["store_stripes"] = True
             add(f"F{32 + k:02d}_rescale_{m}", "small", tads.iloc[frng.choice(len(tads), 9, replace=False)].sort_index(),
                 expected=expected, **kw)
+    # a FLOAT pixels/count column (cooler allows it; get_data multiplies whatever matrix(balance=...) returns, coolpup.py:1053-1057):
+    # every count of the small cooler times a factor in [0.25, 1.75) (synth.patched_cooler, "count_float_seed")
+    fl = {"count_float_seed": 7}
+    add("G15_float_counts_controls", "small", bedpe, patch=fl, nshifts=2, seed=4, **base)
+    add("G15b_float_counts_expected_ooe_by_strand", "small", bedpe, patch=fl, expected=exp_chrom, by_strand=True, **base)
+    add("G15c_float_counts_trans_expected", "small", trans_bedpe(clr), patch=fl, features_format="bedpe", trans=True,
+        view=view_chrom, expected=tr_exp, flank=100_000)
+    add("G15d_float_counts_raw_local_stripes", "small", bed, patch=fl, features_format="bed", local=True, store_stripes=True,
+        clr_weight_name=None, flank=100_000)
+    add("G15e_float_counts_rescale_local", "small", tads, patch=fl, features_format="bed", local=True, rescale=True, rescale_flank=1,
+        rescale_size=21)
     # the reference's own stripe test (tests/test_coolpup.py:143-172): raw counts, ignore_diags=0, first coordinates row
     # known-answer tests of the reference's own test-suite (tests/test_coolpup.py), n depends on coordinates only
     toy_kw = dict(features_format="bed", flank=2_000_000, mindist=0)

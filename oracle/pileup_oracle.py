@@ -47,6 +47,9 @@ def _load():
         _lib.oracle_pileup_mt.restype = C.c_int
         _lib.oracle_pileup_mt.argtypes = [C.c_void_p] * 3 + [C.c_int64] + [C.c_void_p] * 3 + [C.c_int64] + \
             [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_int32] + [C.c_void_p] * 5
+        for name in ("oracle_pileup", "oracle_pileup_mt"):          # the same restatement over float64 pixel values
+            f = getattr(_lib, name + "_f64")
+            f.restype, f.argtypes = C.c_int, getattr(_lib, name).argtypes
     return _lib
 
 
@@ -62,12 +65,20 @@ def empty_acc(n_tiles, pad):
     }
 
 
+def _counts(cnt, f_int, f_float):
+    """(contiguous pixel values, the entry point for their type): int32 counts, or float64 values for a float `pixels/count`."""
+    cnt = np.asarray(cnt)
+    if cnt.dtype.kind == "f":
+        return np.ascontiguousarray(cnt, np.float64), f_float
+    return np.ascontiguousarray(cnt, np.int32), f_int
+
+
 def pileup_c(indptr, col, cnt, weight, cov, expv, r0, c0, flip, tile, n_tiles, pad, ignore_diags, mode, acc=None):
     """Accumulate into ``acc`` (created when None) with the C restatement; returns acc."""
     lib = _load()
     indptr = np.ascontiguousarray(indptr, np.int64)
     col = np.ascontiguousarray(col, np.int32)
-    cnt = np.ascontiguousarray(cnt, np.int32)
+    cnt, fn = _counts(cnt, lib.oracle_pileup, lib.oracle_pileup_f64)
     weight = None if weight is None else np.ascontiguousarray(weight, np.float64)
     cov = None if cov is None else np.ascontiguousarray(cov, np.float64)
     expv = None if expv is None else np.atleast_1d(np.ascontiguousarray(expv, np.float64))
@@ -77,7 +88,7 @@ def pileup_c(indptr, col, cnt, weight, cov, expv, r0, c0, flip, tile, n_tiles, p
     tile = np.ascontiguousarray(tile, np.int32)
     if acc is None:
         acc = empty_acc(n_tiles, pad)
-    rc = lib.oracle_pileup(_p(indptr), _p(col), _p(cnt), indptr.shape[0] - 1, _p(weight), _p(cov), _p(expv),
+    rc = fn(_p(indptr), _p(col), _p(cnt), indptr.shape[0] - 1, _p(weight), _p(cov), _p(expv),
                            0 if expv is None else expv.shape[0], _p(r0), _p(c0), _p(flip), _p(tile), r0.shape[0],
                            pad, ignore_diags, mode, _p(acc["sum"]), _p(acc["num"]), _p(acc["n"]),
                            _p(acc["cov_start"]), _p(acc["cov_end"]))
@@ -93,7 +104,7 @@ def pileup_c_mt(indptr, col, cnt, weight, cov, expv, r0, c0, flip, tile, n_tiles
     lib = _load()
     indptr = np.ascontiguousarray(indptr, np.int64)
     col = np.ascontiguousarray(col, np.int32)
-    cnt = np.ascontiguousarray(cnt, np.int32)
+    cnt, fn = _counts(cnt, lib.oracle_pileup_mt, lib.oracle_pileup_mt_f64)
     weight = None if weight is None else np.ascontiguousarray(weight, np.float64)
     cov = None if cov is None else np.ascontiguousarray(cov, np.float64)
     expv = None if expv is None else np.atleast_1d(np.ascontiguousarray(expv, np.float64))
@@ -103,7 +114,7 @@ def pileup_c_mt(indptr, col, cnt, weight, cov, expv, r0, c0, flip, tile, n_tiles
     tile = np.ascontiguousarray(tile, np.int32)
     if acc is None:
         acc = empty_acc(n_tiles, pad)
-    rc = lib.oracle_pileup_mt(_p(indptr), _p(col), _p(cnt), indptr.shape[0] - 1, _p(weight), _p(cov), _p(expv),
+    rc = fn(_p(indptr), _p(col), _p(cnt), indptr.shape[0] - 1, _p(weight), _p(cov), _p(expv),
                               0 if expv is None else expv.shape[0], _p(r0), _p(c0), _p(flip), _p(tile), r0.shape[0],
                               n_tiles, pad, ignore_diags, mode, int(nthreads), _p(acc["sum"]), _p(acc["num"]),
                               _p(acc["n"]), _p(acc["cov_start"]), _p(acc["cov_end"]))

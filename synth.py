@@ -187,9 +187,14 @@ def patched_cooler(clr, patch):
             pass
     for name in (patch or {}).get("drop", []):          # {"drop": [columns]}: a cooler that lacks them
         cols.pop(name, None)
+    count = clr.count
     for col, edits in (patch or {}).items():
         if col == "drop":
             continue
+        if col == "count_float_seed":                    # {"count_float_seed": s}: a FLOAT pixels/count column — every count times a
+            # factor in [0.25, 1.75) drawn from PCG64(s): cooler allows float counts and coolpuppy multiplies them through
+            count = clr.count.astype(np.float64) * (0.25 + 1.5 * np.random.Generator(np.random.PCG64(int(edits))).random(clr.count.shape[0]))
+            continue
         for what, where in edits.items():
             cols[col][np.asarray(where, dtype=np.int64)] = vals[what]
-    return ArrayCooler(clr.chromsizes, clr.binsize, clr.bin1_offset, clr.bin2_id, clr.count, bins=cols, filename=clr.filename)
+    return ArrayCooler(clr.chromsizes, clr.binsize, clr.bin1_offset, clr.bin2_id, count, bins=cols, filename=clr.filename)
