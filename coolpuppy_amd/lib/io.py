@@ -64,6 +64,7 @@ def _lib():
     lib.H5Pcreate.restype = _hid; lib.H5Pcreate.argtypes = [_hid]
     lib.H5Pset_chunk.argtypes = [_hid, C.c_int, C.c_void_p]
     lib.H5Pset_deflate.argtypes = [_hid, C.c_uint]
+    lib.H5Pset_shuffle.argtypes = [_hid]
     lib.H5Pclose.argtypes = [_hid]
     lib.H5Dcreate2.restype = _hid; lib.H5Dcreate2.argtypes = [_hid, C.c_char_p, _hid, _hid, _hid, _hid, _hid]
     lib.H5Dwrite.restype = C.c_int; lib.H5Dwrite.argtypes = [_hid, _hid, _hid, _hid, _hid, C.c_void_p]
@@ -244,7 +245,7 @@ class _H5:
         finally:
             lib.H5Oclose(oid)
 
-    def write(self, name, arr, chunks=None, gzip=None):
+    def write(self, name, arr, chunks=None, gzip=None, shuffle=False):
         """Numeric array (dtype kept) or array of str (variable-length UTF-8), any rank."""
         lib = self.lib
         arr = np.asarray(arr)
@@ -254,6 +255,8 @@ class _H5:
         if chunks is not None and arr.size:
             dcpl = lib.H5Pcreate(_native(lib, "H5P_CLS_DATASET_CREATE_ID_g"))
             lib.H5Pset_chunk(dcpl, len(chunks), (C.c_uint64 * len(chunks))(*chunks))
+            if shuffle:                                      # (cooler's default pipeline: shuffle, then gzip)
+                lib.H5Pset_shuffle(dcpl)
             if gzip:
                 lib.H5Pset_deflate(dcpl, int(gzip))
         if strings:
@@ -512,12 +515,18 @@ class _ArrayUnpickler(pickle.Unpickler):
     """Unpickler for the object blocks of a pandas "fixed" store: a numpy object ndarray of plain Python values.  Only the
     numpy array / dtype / scalar reconstructors and the builtin value types resolve; anything else in the stream (a crafted
     file could name os.system) raises instead of being imported — pd.read_hdf, which the reference uses, offers no such guard."""
-    _NUMPY = {"_reconstruct", "ndarray", "dtype", "scalar", "_frombuffer"}
+    # exact (module, name) pairs — "any numpy submodule" would let a crafted file import numpy.distutils / numpy.f2py and friends
+    _NUMPY = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+              ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+              ("numpy", "ndarray"), ("numpy", "dtype"),
+              ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer")}
     _BUILTINS = {"list", "tuple", "dict", "set", "frozenset", "str", "bytes", "bytearray", "int", "float", "complex", "bool",
                  "slice", "range", "NoneType"}
 
     def find_class(self, module, name):
-        if module.split(".")[0] == "numpy" and name in self._NUMPY:
+        if (module, name) in self._NUMPY:
+            if module.startswith("numpy.core."):             # (numpy 2 renamed the package; old pickles still name the old one)
+                module = "numpy._core." + module[len("numpy.core."):] if hasattr(np, "_core") else module
             return super().find_class(module, name)
         if module == "builtins" and name in self._BUILTINS:
             return super().find_class(module, name)
@@ -527,8 +536,12 @@ class _ArrayUnpickler(pickle.Unpickler):
 
 
 def _restricted_loads(data):
+    """The object ndarray pickled in a block of a "fixed" store — and nothing else: the unpickled value must BE an ndarray."""
     import io as _io
-    return _ArrayUnpickler(_io.BytesIO(data)).load()
+    val = _ArrayUnpickler(_io.BytesIO(data)).load()
+    if not isinstance(val, np.ndarray):
+        raise pickle.UnpicklingError(f".clpy annotation: an object block unpickled to {type(val).__name__}, not to an array")
+    return val
 
 
 def _read_annotation_pytables(h5):

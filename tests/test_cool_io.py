@@ -330,6 +330,37 @@ def test_streamed_cooler_reads_row_range_chunks(tmp_path, group, gz):
     assert lazy.pixels_in_memory
 
 
+@pytest.mark.parametrize("chunks,gz,shuffle", [(None, None, False), (4096, None, False), (4096, 4, False), (5000, 6, True)])
+def test_direct_reader_equals_the_hyperslab_reads(tmp_path, chunks, gz, shuffle):
+    """cool_io._DirectReader (the streamed loader's data path: pread / inflate / un-shuffle on several threads, no libhdf5 call per
+    read) against the arrays themselves, for contiguous datasets and chunked ones with cooler's filters (gzip, shuffle + gzip), at
+    offsets inside / across chunks, into arrays of the file's width and narrower ones; a range-violating narrow copy raises."""
+    from coolpuppy_amd import cool_io
+    clr = synth.make_cooler({"chr1": 9_000_000, "chr2": 6_500_000}, lam=30, seed=5)
+    path = str(tmp_path / "d.cool")
+    cool_io.write_cool(path, clr, chunks=chunks, gzip=gz, shuffle=shuffle)
+    col, cnt = clr.pixel_table()[1], clr.pixel_table()[2]
+    f = cool_io._File(path)
+    lay = f.layout("/pixels/bin2_id")
+    assert lay is not None and lay["kind"] == ("contiguous" if chunks is None else "chunked") and lay["n"] == clr.nnz
+    if chunks is not None:
+        assert lay["filters"] == ([2] if shuffle else []) + ([1] if gz else [])
+    rc = cool_io._DirectReader(path, f, "/pixels/bin2_id", threads=4)
+    rn = cool_io._DirectReader(path, f, "/pixels/count", threads=4)
+    rc.PIECE = rn.PIECE = 4096                               # (several tasks per read even on this small table)
+    try:
+        for first, m in ((0, 1), (0, 5000), (4095, 3), (1234, clr.nnz - 5000), (clr.nnz - 7, 7), (0, clr.nnz)):
+            a64, a32, c32 = np.empty(m, np.int64), np.empty(m, np.int32), np.empty(m, np.int32)
+            rc.read_into(first, a64); rc.read_into(first, a32); rn.read_into(first, c32)
+            np.testing.assert_array_equal(a64, col[first:first + m])
+            np.testing.assert_array_equal(a32, col[first:first + m])
+            np.testing.assert_array_equal(c32, cnt[first:first + m])
+        with pytest.raises(OverflowError):
+            rc.read_into(0, np.empty(clr.nnz, np.int8))
+    finally:
+        rc.close(); rn.close(); f.close()
+
+
 @pytest.mark.gpu
 def test_streamed_cooler_upload_matches_the_eager_one(tmp_path, hip_lib):
     """The pixel table streamed file -> page-locked slabs -> HBM (pup_load_pixels_stream, several slabs) gives the same engine
@@ -338,7 +369,7 @@ def test_streamed_cooler_upload_matches_the_eager_one(tmp_path, hip_lib):
     from coolpuppy_amd.engine import PileupEngine
     clr = synth.make_cooler({"chr1": 90_000_000, "chr2": 65_000_000}, lam=150, seed=8)
     path = str(tmp_path / "s.cool")
-    cool_io.write_cool(path, clr, chunks=65536, gzip=1)
+    cool_io.write_cool(path, clr, chunks=65536, gzip=1, shuffle=True)
     lazy = cool_io.read_cool(path, stream_pixels=True)
     pairs = synth.random_cis_pairs(clr, 20_000, seed=2)
     kw = dict(features_format="bedpe", flank=100_000, nshifts=2, seed=1)
