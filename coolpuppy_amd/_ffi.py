@@ -106,6 +106,8 @@ _SIGNATURES = {
     "pup_host_sort_pairs": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                         C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
+    "pup_host_pair_region_counts": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_int32, C.c_void_p]),
     "pup_host_take_rows": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
     "pup_host_group_tiles_runs": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -140,6 +140,7 @@ def flip_snip_func(snip, groupby, ignore_group_order, extra_func=None):
     return snip
 
 
+_DRAW_AHEAD_MIN = 200_000      # control draws of a pile-up from which a helper thread draws them ahead of the window passes
 _DRAW_BUFFERS = {}      # dtype -> [shift buffer, sign buffer]: the draw-ahead's outputs, kept between pile-ups (80 MB of page faults per 10^7 draws otherwise)
 
 
@@ -224,12 +225,22 @@ class _DrawAhead:
             self._bufs, self._at = bufs, 0
         self._q = queue.Queue(maxsize=depth)
         self._err = None
+        self._stop = False
         self._th = threading.Thread(target=self._run, name="coolpuppy_amd-draws", daemon=True)
         self._th.start()
+
+    def cancel(self, state):
+        """Stop a helper nobody will consume (started early on sizes that turned out not to be the pile-up's, or before an error)
+        and put numpy's legacy generator back to `state`, where it stood before the helper's first draw."""
+        self._stop = True
+        self.close()
+        np.random.set_state(state)
 
     def _run(self):
         try:
             for m in self._sizes:
+                if self._stop:
+                    break
                 if self._bufs is not None:
                     a = self._at
                     self._at += m
@@ -267,7 +278,11 @@ class CoordCreator:
 
     def __init__(self, features, resolution, *, features_format="auto", flank=100000, rescale_flank=None,
                  chroms="all", minshift=10**5, maxshift=10**6, nshifts=10, mindist="auto", maxdist=None,
-                 local=False, subset=0, trans=False, seed=None):
+                 local=False, subset=0, trans=False, seed=None, _draw_hint=None):
+        # _draw_hint (pileup() only): {"regions": [(chrom, start, end), ...] in pile-up order} — the control draws of a plain
+        # pile-up start as soon as the rows per region are known, while the table is still being sorted (see _start_early_draws)
+        self._draw_hint = _draw_hint
+        self._early_ahead = None
         # (the caller's frame is only ever READ: the processed table is a column store of its own, intervals.py, and the frame
         # behind `.intervals` is assembled from it on first access — tests/test_host_misc.py checks the caller's frame stays as it was)
         self._src = features
@@ -356,8 +371,9 @@ class CoordCreator:
         from .intervals import build_table
         tbl = None
         if not os.environ.get("COOLPUPPY_AMD_FRAME_PATH"):
+            early = self._start_early_draws if (self._draw_hint and self.kind == "bedpe" and self.nshifts > 0 and not self.trans) else None
             tbl = build_table(src, self.kind, self.resolution, self.flank, self.rescale_flank, self.mindist, self.maxdist,
-                              tag_kind=self.nshifts > 0 and self.kind == "bedpe")
+                              tag_kind=self.nshifts > 0 and self.kind == "bedpe", early=early)
         if tbl is None:
             return self._process_frame(src)
         self._tbl, self._fc = tbl, None
@@ -370,6 +386,27 @@ class CoordCreator:
                 raise ValueError("Can't make local with both sides of loops defined")
             base = (present[0] | present[1]) if self.trans else (present[0] & present[1])
         self._finish_process(base)
+
+    def _start_early_draws(self, S, E, codes, names):
+        """Called by intervals.build_table before it sorts: the rows every region of the coming pile-up will hold (the distance
+        filter and the region filter on the unsorted columns, pup_host_pair_region_counts) are all the reference's control draws
+        depend on (coolpup.py:420-436: rows x nshifts numbers per region, in region order) — the helper thread of _DrawAhead starts
+        drawing NOW, 20 ms before the first window is asked for.  pileupsWithControl adopts it when its own sizes agree, else
+        cancels it (the generator is put back where it stood)."""
+        from .engine import pair_region_counts
+        regs = self._draw_hint.get("regions") or []
+        if len(regs) < 2 or os.environ.get("COOLPUPPY_AMD_NO_DRAW_AHEAD") or os.environ.get("COOLPUPPY_AMD_NO_EARLY_DRAWS"):
+            return
+        code_of = {nm: i for i, nm in enumerate(names)}
+        rc = [code_of.get(str(c), len(names)) for c, _, _ in regs]
+        counts = pair_region_counts(S[0], E[0], S[1], E[1], codes[0], codes[1], self.mindist, self.maxdist, rc,
+                                    [int(r[1]) for r in regs], [int(r[2]) for r in regs])
+        if counts is None:
+            return
+        sizes = [int(c) * int(self.nshifts) for c in counts if c > 0]
+        if sum(sizes) >= _DRAW_AHEAD_MIN:
+            state = np.random.get_state()
+            self._early_ahead = (_DrawAhead(self, sizes), sizes, state)
 
     def _finish_process(self, base):
         self.basechroms = natsorted(list(base))
@@ -1495,6 +1532,7 @@ class PileUpper:
         batches = []
         ahead = None
         nsh = self.nshifts if self.control else 0
+        early, self.CC._early_ahead = getattr(self.CC, "_early_ahead", None), None      # (draws started while the table was sorted)
         if owned is None and nsh > 0 and len(pairs) > 1 and not os.environ.get("COOLPUPPY_AMD_NO_DRAW_AHEAD") and \
                 self._plain_pairs(modify, _by_window, False, groupby):
             # every region takes _pair_snippets: the helper thread draws the regions' control shifts ahead (see _DrawAhead)
@@ -1505,8 +1543,15 @@ class PileUpper:
                 rows = CC._rows_trans_pairs(tuple(reg1), tuple(reg2)) if CC.trans else CC._rows_pairs_region(tuple(reg1))
                 if _nrows(rows):
                     sizes.append(_nrows(rows) * nsh)
-            if sum(sizes) >= 200_000:
+            if early is not None and early[1] == sizes:
+                ahead, early = early[0], None                 # the very sequence this pile-up needs: already under way
+                CC._draw_ahead = ahead
+            elif sum(sizes) >= _DRAW_AHEAD_MIN:
+                if early is not None:
+                    early[0].cancel(early[2]); early = None
                 ahead = CC._draw_ahead = _DrawAhead(CC, sizes)
+        if early is not None:                                 # started for a pile-up that is not this one: stop it, generator back
+            early[0].cancel(early[2])
         fused = (owned is None and nsh > 0 and not grouped and not self.expected and not self.trans and not self.rescale
                  and self._plain_pairs(modify, _by_window, False, groupby) and not os.environ.get("COOLPUPPY_AMD_NO_FUSED_WINDOWS"))
         plan = None
@@ -2598,10 +2643,32 @@ def pileup(clr, features, features_format="bed", view_df=None, expected_df=None,
         if local:
             raise ValueError("Can't make local by-window pileups")
 
+    # a plain pile-up with random-shift controls: its draws can start while the features are still being sorted (CoordCreator.
+    # _start_early_draws) — told here which regions, in which order, the pile-up will walk
+    hint = None
+    if control and expected_df is None and not trans and not rescale and not by_window and not flip_negative_strand \
+            and not ignore_group_order and not store_stripes and features_format == "bedpe":
+        from . import dist as _dist
+        if _dist.world()[1] == 1:
+            hint = {"regions": list(zip(view_df["chrom"].astype(str).tolist(), view_df["start"].tolist(), view_df["end"].tolist()))}
     CC = CoordCreator(features=features, resolution=clr.binsize, features_format=features_format, flank=flank,
                       rescale_flank=rescale_flank, chroms=chroms, minshift=minshift, maxshift=maxshift,
                       nshifts=nshifts, mindist=mindist, maxdist=maxdist, local=local, subset=subset, seed=seed,
-                      trans=trans)
+                      trans=trans, _draw_hint=hint)
+    try:
+        return _pileup_with(CC, clr, view_df, expected_df, expected_value_col, clr_weight_name, ooe, control, coverage_norm, rescale,
+                            rescale_size, flip_negative_strand, min_diag, store_stripes, nproc, by_window, by_strand, by_distance,
+                            distance_edges if by_distance else None, groupby, ignore_group_order)
+    finally:
+        early, CC._early_ahead = getattr(CC, "_early_ahead", None), None
+        if early is not None:          # (an error before the pile-up adopted the early draws: stop them, generator back)
+            early[0].cancel(early[2])
+
+
+def _pileup_with(CC, clr, view_df, expected_df, expected_value_col, clr_weight_name, ooe, control, coverage_norm, rescale, rescale_size,
+                 flip_negative_strand, min_diag, store_stripes, nproc, by_window, by_strand, by_distance, distance_edges, groupby,
+                 ignore_group_order):
+    """The second half of pileup() (reference coolpup.py:2210-2279): PileUpper, the by-X dispatch, the closing columns."""
     PU = PileUpper(clr=clr, CC=CC, view_df=view_df, clr_weight_name=clr_weight_name, expected=expected_df,
                    expected_value_col=expected_value_col, ooe=ooe, control=control, coverage_norm=coverage_norm,
                    rescale=rescale, rescale_size=rescale_size, flip_negative_strand=flip_negative_strand,

@@ -111,6 +111,7 @@ struct pup_ctx {
     // partition pass, the buckets' block lists, the packed block keys, the sorted low digits (sets of tile pairs)
     DevBuf<unsigned> d_binmeta, d_bindesc, d_blkkey, d_bkeys; DevBuf<unsigned short> d_low;
     DevBuf<double> rs_scratch;               // K5: one slab of window cells per workgroup (see pileup_rescale_kernel)
+    DevBuf<double> rs_tile;                  // K5: output tiles too large for LDS, one per workgroup
     DevBuf<double> cov_rec; DevBuf<unsigned> cov_owner;     // coverage-vector pass beside the staged kernels (cov_vectors_kernel)
     long long wide_min = 20000;              // calls of at least this many wide cis windows take the staged wide kernel
     const char* last_kernel = "";            // which pile-up kernel the last pup_accumulate ran (diagnostics)
@@ -1644,10 +1645,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         HIPCHK(c, c->d_h.reserve((size_t)n)); HIPCHK(c, c->d_w.reserve((size_t)n));
         HIPCHK(c, upload_snippets(c, c->d_h.p, hgt, (size_t)n * sizeof(int)));
         HIPCHK(c, upload_snippets(c, c->d_w.p, wid, (size_t)n * sizeof(int)));
-        const size_t need = (size_t)c->W * c->W * 12 + 16 * (size_t)c->W;
-        if (need > (size_t)c->max_lds)
-            return fail(c, PUP_ENOTSUP, "pup_accumulate_rescaled: a %dx%d output tile needs %zu B of LDS, device offers %d",
-                        c->W, c->W, need, c->max_lds);
+        // (an output tile that does not fit LDS — rescale_size beyond ~115 — lives in global memory: pileup_rescale_kernel, tile_g)
     }
 
     const int T = c->T;
@@ -1889,6 +1887,11 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
     }
     if (rescale) {
         size_t rs_lds = (size_t)W * W * 12 + 16 * (size_t)W;
+        const bool tile_global = rs_lds > (size_t)c->max_lds;                 // the S x S tile does not fit LDS: one per workgroup in HBM / L2
+        if (tile_global) {
+            rs_lds = 16 * (size_t)W;
+            HIPCHK(c, c->rs_tile.reserve((size_t)nblocks * ((size_t)W * W + ((size_t)W * W + 1) / 2)));
+        }
         // room for the separable zoom's weights: as many per output row and column as LDS has left, up to kRescaleSepK (a window
         // h times the output size needs h + 2; 99 x 99 outputs: 27, small outputs: 64)
         const int sep_k = rescale_sep_k(c, rs_lds, W);
@@ -1902,7 +1905,7 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
             c->rs_scratch.reserve((size_t)slab_cells * (size_t)nblocks) != hipSuccess) { slab_cells = 0; (void)hipGetLastError(); }
         hipLaunchKernelGGL(pup::pileup_rescale_kernel, dim3((unsigned)nblocks), dim3(rs_threads), rs_lds, c->stream, a,
                            (const int*)c->d_h.p, (const int*)c->d_w.p, (double*)nullptr, (double*)nullptr, 0LL,
-                           slab_cells ? c->rs_scratch.p : (double*)nullptr, slab_cells, sep_k);
+                           slab_cells ? c->rs_scratch.p : (double*)nullptr, slab_cells, sep_k, tile_global ? c->rs_tile.p : (double*)nullptr);
         launched = true; c->last_kernel = "rescale";
     }
     const bool sparse_launch = !lds_kernel2 && !rescale && ignore_diags < 0 && W <= 63 && !(c->variant & 32) &&
@@ -2140,6 +2143,11 @@ int pup_extract(pup_ctx* c, const int32_t* r0, const int32_t* c0, const int32_t*
         const unsigned grid = (unsigned)std::min<int64_t>(n, 16384);
         if (rescale) {
             size_t rs_lds = W2 * 12 + 16 * (size_t)W;
+            const bool tile_global = rs_lds > (size_t)c->max_lds;
+            if (tile_global) {
+                rs_lds = 16 * (size_t)W;
+                if (c->rs_tile.reserve((size_t)grid * (W2 + (W2 + 1) / 2)) != hipSuccess) return fail(c, PUP_ENOMEM, "pup_extract: tile scratch");
+            }
             const int sep_k = rescale_sep_k(c, rs_lds, W);
             if (sep_k) rs_lds += 8 + 2 * (size_t)W * ((size_t)sep_k * sizeof(double) + sizeof(int));
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pup::pileup_rescale_kernel),
@@ -2152,7 +2160,7 @@ int pup_extract(pup_ctx* c, const int32_t* r0, const int32_t* c0, const int32_t*
                 c->rs_scratch.reserve((size_t)slab_cells * grid) != hipSuccess) { slab_cells = 0; (void)hipGetLastError(); }
             hipLaunchKernelGGL(pup::pileup_rescale_kernel, dim3(grid), dim3(256), rs_lds, c->stream, a,
                                (const int*)c->d_h.p, (const int*)c->d_w.p, d_out.p, cov_start ? d_cov.p : (double*)nullptr,
-                               (long long)n, slab_cells ? c->rs_scratch.p : (double*)nullptr, slab_cells, sep_k);
+                               (long long)n, slab_cells ? c->rs_scratch.p : (double*)nullptr, slab_cells, sep_k, tile_global ? c->rs_tile.p : (double*)nullptr);
         } else {
             hipLaunchKernelGGL(pup::extract_windows_kernel, dim3(grid), dim3(256), 0, c->stream, a, (long long)n, d_out.p,
                                cov_start ? d_cov.p : (double*)nullptr);

@@ -289,6 +289,44 @@ static int pup_host_argsort_impl(const uint64_t* keys, int64_t n, int32_t bits, 
     return PUP_OK;
 }
 
+// How many BEDPE rows every view region will hand to the window pass — before anything is sorted: the rows that pass the distance
+// filter (centres in double, as pup_host_sort_pairs) and lie, both anchors, inside the region (start >= region start, end < region
+// end: the reference's region filter, coolpuppy/coolpup.py:549-562).  The random-shift draws of a pile-up (:420-436) only depend on
+// these counts, so they can start while the table is still being sorted.  Regions may overlap; counts[k] for region k of
+// chromosome code reg_code[k].
+static int pup_host_pair_region_counts_impl(const int64_t* s1, const int64_t* e1, const int64_t* s2, const int64_t* e2, const int32_t* c1,
+                                            const int32_t* c2, int64_t n, double mindist, double maxdist, const int32_t* reg_code,
+                                            const int64_t* reg_start, const int64_t* reg_end, int32_t n_regions, int64_t* counts) {
+    if (n < 0 || n_regions < 0 || (n > 0 && (!s1 || !e1 || !s2 || !e2 || !c1 || !c2)) || (n_regions > 0 && (!reg_code || !reg_start || !reg_end || !counts)))
+        return PUP_EINVAL;
+    for (int k = 0; k < n_regions; ++k) counts[k] = 0;
+    if (n == 0 || n_regions == 0) return PUP_OK;
+    int32_t max_code = 0;
+    for (int k = 0; k < n_regions; ++k) { if (reg_code[k] < 0) return PUP_EINVAL; max_code = std::max(max_code, reg_code[k]); }
+    // regions of a chromosome code: first[code] .. first[code + 1) in `by_code`
+    std::vector<int> first((size_t)max_code + 2, 0), by_code((size_t)n_regions);
+    for (int k = 0; k < n_regions; ++k) ++first[(size_t)reg_code[k] + 1];
+    for (size_t k = 1; k < first.size(); ++k) first[k] += first[k - 1];
+    { std::vector<int> at(first.begin(), first.end() - 1); for (int k = 0; k < n_regions; ++k) by_code[(size_t)at[(size_t)reg_code[k]]++] = k; }
+    const int workers = n_workers(n);
+    std::vector<int64_t> part((size_t)workers * (size_t)n_regions, 0);
+    parallel_chunks(n, workers, [&](int w, int64_t a, int64_t b) {
+        int64_t* cnt = part.data() + (size_t)w * (size_t)n_regions;
+        for (int64_t i = a; i < b; ++i) {
+            const int32_t code = c1[i];
+            if (code != c2[i] || code < 0 || code > max_code) continue;
+            const double ca = (double)(s1[i] + e1[i]) / 2.0, cb = (double)(s2[i] + e2[i]) / 2.0, d = std::fabs(cb - ca);
+            if (!(mindist <= d && d <= maxdist)) continue;
+            for (int j = first[(size_t)code]; j < first[(size_t)code + 1]; ++j) {
+                const int k = by_code[(size_t)j];
+                if (s1[i] >= reg_start[k] && e1[i] < reg_end[k] && s2[i] >= reg_start[k] && e2[i] < reg_end[k]) ++cnt[k];
+            }
+        }
+    });
+    for (int w = 0; w < workers; ++w) for (int k = 0; k < n_regions; ++k) counts[k] += part[(size_t)w * (size_t)n_regions + (size_t)k];
+    return PUP_OK;
+}
+
 // CoordCreator.process for BEDPE features in one call (coolpuppy/coolpup.py:296-321 centres and the mindist / maxdist filter,
 // :489-527 the sort by (chrom1, chrom2, start1, start2)): which rows stay, in which order, and the coordinate / chromosome-code
 // columns in that order.  The numpy form was ~20 passes over the 10^6 rows (two gcd reductions among them); here: one pass
@@ -609,4 +647,8 @@ PUP_EXPORT int pup_host_group_tiles_runs(int32_t n_parts, const int32_t* const* 
 
 PUP_EXPORT int64_t pup_host_control_windows(const int32_t* st1, const int32_t* st2, const int32_t* code, int64_t n, const int32_t* shift, const int32_t* sign, int32_t nshifts, double resolution, int64_t off1, int64_t off2, int64_t lo1, int64_t hi1, int64_t lo2, int64_t hi2, int32_t h, int32_t w, int32_t* r0, int32_t* c0, int32_t* code_out) {
     PUP_HOST_GUARD(pup_host_control_windows_impl(st1, st2, code, n, shift, sign, nshifts, resolution, off1, off2, lo1, hi1, lo2, hi2, h, w, r0, c0, code_out), PUP_ENOMEM);
+}
+
+PUP_EXPORT int pup_host_pair_region_counts(const int64_t* s1, const int64_t* e1, const int64_t* s2, const int64_t* e2, const int32_t* c1, const int32_t* c2, int64_t n, double mindist, double maxdist, const int32_t* reg_code, const int64_t* reg_start, const int64_t* reg_end, int32_t n_regions, int64_t* counts) {
+    PUP_HOST_GUARD(pup_host_pair_region_counts_impl(s1, e1, s2, e2, c1, c2, n, mindist, maxdist, reg_code, reg_start, reg_end, n_regions, counts), PUP_ENOMEM);
 }

@@ -1264,16 +1264,22 @@ __device__ __forceinline__ bool bin_bad(const K1Args& a, int bin) { return (a.ba
 PUP_KERNEL __launch_bounds__(1024) void pileup_rescale_kernel(K1Args a, const int* __restrict__ hs, const int* __restrict__ wsz,
                                                              double* __restrict__ emit, double* __restrict__ emit_cov,
                                                              long long emit_n, double* __restrict__ scratch, long long scratch_cells,
-                                                             int sep_k /* > 0: LDS holds room for sep_k zoom weights per output row / column */) {
+                                                             int sep_k /* > 0: LDS holds room for sep_k zoom weights per output row / column */,
+                                                             double* __restrict__ tile_g = nullptr /* output tiles too large for LDS (S > ~115): one
+                                                                 per workgroup in global memory, S2 doubles + S2 counts, 8-byte aligned stride */) {
 #pragma clang fp contract(off)      // zoom coordinates must be plain IEEE products (see below)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int S = a.W, S2 = S * S;
-    double*   tsum = reinterpret_cast<double*>(smem_raw);
-    double*   tcov = tsum + S2;                               // [2S]
-    unsigned* tnum = reinterpret_cast<unsigned*>(tcov + 2 * S);
+    // the S x S output tile: in LDS when it fits (thread-owned cells either way: no atomics) — the reference zooms to any odd size
+    // (coolpuppy/coolpup.py:1193-1234), so a larger tile lives in the workgroup's stretch of a global scratch buffer (L2-resident)
+    const bool tile_in_lds = tile_g == nullptr;
+    const size_t tile_stride = (size_t)S2 + ((size_t)S2 + 1) / 2;        // doubles per global tile: sums, then counts
+    double*   tsum = tile_in_lds ? reinterpret_cast<double*>(smem_raw) : tile_g + (size_t)blockIdx.x * tile_stride;
+    double*   tcov = tile_in_lds ? tsum + S2 : reinterpret_cast<double*>(smem_raw);                               // [2S]
+    unsigned* tnum = tile_in_lds ? reinterpret_cast<unsigned*>(tcov + 2 * S) : reinterpret_cast<unsigned*>(tsum + S2);
     // zoom weights of the current window (see below): Wy[S][sep_k] | Wx[S][sep_k] doubles, first input row / column of every output
     // row / column (2S ints)
-    double* const wsep = reinterpret_cast<double*>(smem_raw + (((size_t)S2 * 12 + 16 * (size_t)S + 7) & ~(size_t)7));
+    double* const wsep = reinterpret_cast<double*>(smem_raw + (tile_in_lds ? (((size_t)S2 * 12 + 16 * (size_t)S + 7) & ~(size_t)7) : 16 * (size_t)S));
     int* const wlo = reinterpret_cast<int*>(wsep + 2 * (size_t)S * (sep_k > 0 ? sep_k : 0));
     const bool emitting = emit != nullptr;
     const int ck = emitting ? (int)blockIdx.x : a.block_chunk[blockIdx.x];

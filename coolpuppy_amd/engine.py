@@ -589,6 +589,16 @@ def stable_argsort(keys, bits):
     return order
 
 
+def pair_region_counts(s1, e1, s2, e2, c1, c2, mindist, maxdist, reg_code, reg_start, reg_end):
+    """pup_host_pair_region_counts: kept BEDPE rows per view region, from the unsorted table (None when the library declines)."""
+    cols = [_as(v, np.int64) for v in (s1, e1, s2, e2)] + [_as(v, np.int32) for v in (c1, c2)]
+    rc_, rs_, re_ = _as(reg_code, np.int32), _as(reg_start, np.int64), _as(reg_end, np.int64)
+    out = np.zeros(rc_.shape[0], np.int64)
+    rc = _ffi.lib().pup_host_pair_region_counts(*[_ptr(v) for v in cols], cols[0].shape[0], float(mindist), float(maxdist),
+                                                _ptr(rc_), _ptr(rs_), _ptr(re_), rc_.shape[0], _ptr(out))
+    return out if rc == 0 else None
+
+
 def sort_pairs(s1, e1, s2, e2, c1, c2, rank, mindist, maxdist):
     """pup_host_sort_pairs: the distance filter and the (chrom1, chrom2, start1, start2) sort of a BEDPE table in one call.
     s1 .. e2: int64 columns, c1 / c2: int32 chromosome codes, rank[code]: the chromosome's place in sort order.  Returns None when

@@ -326,7 +326,7 @@ def _same_objects(a, b):
     return a.nbytes == 0 or memcmp(a.ctypes.data, b.ctypes.data, a.nbytes) == 0
 
 
-def build_table(src, kind, resolution, flank, rescale_flank, mindist, maxdist, tag_kind):
+def build_table(src, kind, resolution, flank, rescale_flank, mindist, maxdist, tag_kind, early=None):
     """The array path of CoordCreator.process for a feature frame `src` (reference :259-385, 489-527).  Returns an ArrayTable, or
     None when the input is not of the plain kind it handles (integer coordinates >= 0, integer resolution, chromosome names
     without missing values, keys that fit 63 bits) or is empty after the distance filter — the caller then takes the pandas path,
@@ -369,6 +369,8 @@ def build_table(src, kind, resolution, flank, rescale_flank, mindist, maxdist, t
         # the reference's filter and sort — (chrom1, chrom2, start1, start2), stable, chromosome names in string order — in one
         # call of the library
         from .engine import sort_pairs
+        if early is not None:          # (what only needs the unsorted columns — the control draws' sizes — starts before the sort)
+            early(S, E, codes, names)
         got = sort_pairs(S[0], E[0], S[1], E[1], codes[0], codes[1], rank, mindist, maxdist)
         if got is None or len(got[0]) == 0:
             return None

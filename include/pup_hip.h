@@ -39,6 +39,7 @@
  *   pup_host_control_windows             _stream_snips, as one host pass  coolpuppy/coolpup.py:387-453, 1105-1114
  *   pup_host_factorize_ptr            <- the same sort's chromosome codes (object columns factorised by identity)
  *   pup_host_argsort                  <- the same sort's order (one packed key per row)
+ *   pup_host_pair_region_counts       <- the rows per view region of the same table, before the sort (the draws' sizes)
  *   pup_host_sort_pairs               <- CoordCreator.process for BEDPE features: centres, mindist / maxdist filter and the sort
  *                                        by (chrom1, chrom2, start1, start2)          coolpuppy/coolpup.py:296-321, 489-527
  *   pup_host_take_rows                <- the sort of the feature frame in CoordCreator._binnify  coolpuppy/coolpup.py:489-527
@@ -431,6 +432,17 @@ int64_t pup_host_sort_pairs(const int64_t* s1, const int64_t* e1, const int64_t*
                             const int32_t* c2, int64_t n, const int64_t* rank, int32_t nu, double mindist, double maxdist,
                             int64_t* rows, int64_t* s1o, int64_t* e1o, int64_t* s2o, int64_t* e2o, int32_t* c1o, int32_t* c2o,
                             int32_t* flags);
+
+/*
+ * pup_host_pair_region_counts: the number of BEDPE rows every view region will pile up — rows that pass the distance filter
+ * (as pup_host_sort_pairs) with both anchors inside the region (start >= region start, end < region end: the reference's region
+ * filter, coolpuppy/coolpup.py:549-562), region k lying on chromosome code reg_code[k] — from the UNSORTED table.  The control
+ * shifts of a pile-up (coolpuppy/coolpup.py:420-436: rows x nshifts draws per region, in region order) depend on nothing else, so
+ * their drawing can start while the table is still being sorted.  PUP_OK / PUP_EINVAL.
+ */
+int pup_host_pair_region_counts(const int64_t* s1, const int64_t* e1, const int64_t* s2, const int64_t* e2, const int32_t* c1,
+                                const int32_t* c2, int64_t n, double mindist, double maxdist, const int32_t* reg_code,
+                                const int64_t* reg_start, const int64_t* reg_end, int32_t n_regions, int64_t* counts);
 
 /*
  * pup_host_group_tiles: the windows of several regions gathered into ONE pup_accumulate call — stable grouping by tile id

@@ -493,6 +493,50 @@ def test_rescaled_zoom_by_weights_equals_the_per_sample_zoom(hip_lib, S):
         assert a[0]["num"].sum() > 0 and np.isfinite(a[1]).any()
 
 
+def test_rescaled_output_tiles_beyond_lds(hip_lib, oracle_mod):
+    """rescale_size above ~115: the S x S output tile no longer fits LDS and lives in the workgroup's stretch of a global scratch
+    buffer (the reference zooms to any odd size, coolpup.py:1193-1234; round 4 returned PUP_ENOTSUP).  Against the scipy
+    restatement of _rescale_snip + zoom_array, windows above and below the output size, with and without expected."""
+    import synth
+    from coolpuppy_amd.engine import PileupEngine, MODE_OOE
+    po = oracle_mod
+    clr = synth.make_cooler({"chrA": 30_000_000, "chrB": 12_000_000}, lam=60, seed=71)
+    indptr, col, cnt = clr.pixel_table()
+    w = clr.bins()["weight"][:].values
+    e = synth.cis_expected(clr)
+    expv = e[e.region1 == "chrA"]["balanced.avg"].values.copy()
+    nb = indptr.shape[0] - 1
+    big = po.symmetric_csr(indptr, col, cnt, w, 0, nb, 0, nb)
+    rng = np.random.default_rng(4)
+    lo, hi = clr.extent("chrA")
+    for S in (131, 201):
+        pad = (S - 1) // 2
+        n = 24
+        hgt = rng.integers(20, 2 * S, n).astype(np.int32)
+        hgt[:4] = S
+        wid = hgt.copy()
+        r0 = rng.integers(lo + 5, hi - 2 * S - 600, n).astype(np.int32)
+        c0 = r0.copy()
+        tile = (np.arange(n) >= n // 2).astype(np.int32)
+        tile_ptr = np.array([0, n // 2, n], np.int64)
+        for mode, igd, ex in ((0x20, 2, None), (MODE_OOE | 0x20, 2, expv)):
+            with PileupEngine(0) as eng:
+                eng.load_pixels(indptr, col, cnt)
+                eng.build_index(clr.chrom_offset)
+                eng.load_bins(w, None)
+                eng.set_expected(ex)
+                eng.reset(2, pad)
+                eng.accumulate_rescaled(r0, c0, hgt, wid, tile_ptr, ignore_diags=igd, mode=mode)
+                got = eng.fetch()
+                snips = eng.extract(r0[:3], c0[:3], pad, height=hgt[:3], width=wid[:3], ignore_diags=igd, mode=mode)
+            want = po.pileup_rescaled(big, 0, 0, w, None, ex, r0, c0, hgt, wid, None, tile, 2, S, igd, mode)
+            np.testing.assert_array_equal(got["n"], want["n"])
+            np.testing.assert_array_equal(got["num"], want["num"])
+            np.testing.assert_allclose(got["sum"], want["sum"], rtol=1e-9, atol=1e-300)
+            one = po.windows_scipy(big, 0, 0, w, None, ex, r0[:3], c0[:3], pad, igd, mode, h=hgt[:3], w=wid[:3])[0]
+            np.testing.assert_allclose(snips, one, rtol=1e-9, atol=1e-300, equal_nan=True)
+
+
 def test_staged_kernel_with_an_empty_tile_of_a_pair(hip_lib):
     """A tile pair whose first or second tile has no window at all (a group without controls in this region, or the other way
     round): its team has no wave, its record stays invalid, the partner gets every wave."""
