@@ -13,9 +13,10 @@ ap.add_argument("--every", type=int, default=1, help="use every k-th site")
 ap.add_argument("--maxdist", type=int, default=1_000_000)
 ap.add_argument("--out", default="")
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--serial", action="store_true", help="build the table in this process (under rocprofv3: forked workers hang the profiler)")
 a = ap.parse_args()
 warnings.simplefilter("ignore")
-clr = synth.make_cooler(synth.MM9, binsize=10_000, lam=120, seed=1000, name="mm9_like", parallel=True)
+clr = synth.make_cooler(synth.MM9, binsize=10_000, lam=120, seed=1000, name="mm9_like", parallel=not a.serial)
 with gzip.open(os.path.join(ROOT, "tests", "golden", "ref_data", "Bonev_CTCF+.bed.gz"), "rt") as f:
     bed = pd.read_csv(f, sep="\t", header=None, names=["chrom", "start", "end"])
 bed = bed.iloc[::a.every].reset_index(drop=True)

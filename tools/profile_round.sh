@@ -23,8 +23,9 @@ for NAME in $SETS; do
   rm -rf "$REPO/gpurun_out/prof"
   T="${TAG}_${NAME}"
   if [ "$NAME" = "bywindow" ]; then
-    PROFILE_CMD="python $REPO/tools/probe_bywindow.py --reps 2" timeout 900 bash "$REPO/tools/profile_bench.sh" > /dev/null 2>&1
+    PROFILE_CMD="python $REPO/tools/probe_bywindow.py --reps 2 --serial" timeout 900 bash "$REPO/tools/profile_bench.sh" > /dev/null 2>&1
     (cd "$REPO" && timeout 300 python tools/summarize_profiles.py --generic "$T" > "gpurun_out/prof_out/${T}_summary.txt" 2>&1)
+    tail -c 2000 "$REPO/gpurun_out/prof/stats.err" > "$REPO/gpurun_out/prof_out/${T}_stats_err.txt" 2>/dev/null
   else
     BENCH_ARGS="--steps 10 --warmup 2 --cpu-sample 0 --no-end-to-end $EXTRA" timeout 900 bash "$REPO/tools/profile_bench.sh" > /dev/null 2>&1
     (cd "$REPO" && timeout 300 python tools/summarize_profiles.py "$T" > "gpurun_out/prof_out/${T}_summary.txt" 2>&1)
