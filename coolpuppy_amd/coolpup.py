@@ -236,8 +236,34 @@ class _DrawAhead:
         self.close()
         np.random.set_state(state)
 
+    def _run_plan(self):
+        """Every region's draws as one library job (engine.legacy_randint_plan: the raw stream produced a buffer ahead of a pool
+        of workers that lives for the whole sequence — the call-by-call form starts its threads twice per call and twists on one
+        thread while nobody else works).  False: the library declined, nothing was drawn."""
+        from .engine import legacy_randint_plan
+        cc, calls, parts, a = self._cc, [], [], 0
+        lo, hi = int(cc.minshift), int(cc.maxshift)
+        for m in self._sizes:
+            sh, sg = self._bufs[0][a:a + m], self._bufs[1][a:a + m]
+            a += m
+            calls.append((lo, hi, m, 1, 0, sh))
+            calls.append((0, 2, m, 2, -1, sg))
+            if cc.trans:                 # (the second pair of a trans pile-up only moves bp columns: drawn and dropped)
+                calls.append((lo, hi, m, 1, 0, None))
+                calls.append((0, 2, m, 1, 0, None))
+            parts.append((m, (sh, sg)))
+        if not legacy_randint_plan(calls):
+            return False
+        self._at = a
+        for part in parts:
+            self._q.put(part)
+        return True
+
     def _run(self):
         try:
+            if (self._bufs is not None and len(self._sizes) > 1 and not self._stop
+                    and not os.environ.get("COOLPUPPY_AMD_NO_DRAW_PLAN") and self._run_plan()):
+                return
             for m in self._sizes:
                 if self._stop:
                     break

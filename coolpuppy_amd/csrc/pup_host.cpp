@@ -9,6 +9,8 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -557,6 +559,236 @@ static int pup_host_mt_randint_impl(uint32_t* key, int32_t* pos, int64_t low, in
     return PUP_OK;
 }
 
+// ---- a whole pile-up's draws in one call ----------------------------------------------------------------------------------
+// The reference draws region after region (coolpuppy/coolpup.py:420-436): randint(minshift, maxshift, m_r), then choice([-1, 1], m_r)
+// — 46 calls for a 23-chromosome pile-up, every one of which twisted its raw words on ONE thread and then started sixteen
+// threads twice (count, place): of the 45 ms the 2 x 10^7 draws of the bench pile-up took, the sequential twist was ~14 and the
+// thread starts ~20.  The sizes of all calls are known before the first draw (pup_host_pair_region_counts), so the sequence is
+// drawn as ONE job: the raw stream is produced buffer by buffer (kPlanBlocks blocks of 624 words) by a twister thread that runs
+// one buffer ahead; a pool of workers that lives for the call takes each buffer in two passes — accepted candidates per chunk
+// under the rejection mask, then, once the calling thread has walked the calls over those counts (a call ends at its last
+// ACCEPTED word: the exact end is found by a scan inside one chunk), the tempered / masked / scaled numbers written to where
+// each call wants them.  Same stream, same numbers, same final state as the per-call form (tests/test_host_misc.py).
+// Calls that reject (range not a power of two) must share one range — true of a pile-up's draws; else PUP_ENOTSUP and the
+// caller draws call by call.
+namespace {
+
+struct PhasePool {                                   // n - 1 helper threads + the caller: run(f) = f(0) .. f(n - 1), back when all are done
+    int n;
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    std::function<void(int)> job;
+    long gen = 0;
+    int pending = 0;
+    bool stop = false, failed = false;
+    explicit PhasePool(int n_) : n(n_ < 1 ? 1 : n_) {
+        try {
+            for (int k = 1; k < n; ++k) th.emplace_back([this, k] { loop(k); });
+        } catch (...) { n = 1 + (int)th.size(); }      // fewer helpers than asked for: the shares are by n
+    }
+    ~PhasePool() {
+        { std::lock_guard<std::mutex> g(mu); stop = true; }
+        cv_go.notify_all();
+        for (auto& t : th) t.join();
+    }
+    void loop(int k) {
+        long seen = 0;
+        for (;;) {
+            std::function<void(int)> f;
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv_go.wait(g, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen; f = job;
+            }
+            bool bad = false;
+            try { f(k); } catch (...) { bad = true; }
+            {
+                std::lock_guard<std::mutex> g(mu);
+                if (bad) failed = true;
+                if (--pending == 0) cv_done.notify_one();
+            }
+        }
+    }
+    template <class F> void run(F&& f) {
+        if (n > 1) {
+            { std::lock_guard<std::mutex> g(mu); job = f; pending = n - 1; ++gen; }
+            cv_go.notify_all();
+        }
+        bool bad = false;
+        try { f(0); } catch (...) { bad = true; }
+        if (n > 1) { std::unique_lock<std::mutex> g(mu); cv_done.wait(g, [&] { return pending == 0; }); }
+        if (bad || failed) { failed = false; throw std::bad_alloc(); }
+    }
+};
+
+constexpr int kPlanChunkBlocks = 16;                  // blocks per chunk: the unit of the counts and of the workers' shares
+constexpr int64_t kPlanChunk = (int64_t)kPlanChunkBlocks * kMtN;
+std::vector<uint32_t>& mt_plan_buffer(int which) { static std::vector<uint32_t> v[2]; return v[which]; }
+
+struct PlanPiece { int32_t call; int64_t a, b, out_pos; };      // words [a, b) of the buffer belong to `call`; its accepted ones go to out[out_pos ...]
+
+template <class T>
+void plan_write(T* out, const uint32_t* __restrict__ raw, int64_t a, int64_t b, uint32_t mask, uint32_t rng, bool rej,
+                int64_t low, int64_t scale, int64_t offset) {
+    if (!rej) { for (int64_t i = a; i < b; ++i) *out++ = (T)(offset + scale * (low + (int64_t)(mt_temper(raw[i]) & mask))); return; }
+    for (int64_t i = a; i < b; ++i) {
+        const uint32_t v = mt_temper(raw[i]) & mask;
+        if (v <= rng) *out++ = (T)(offset + scale * (low + (int64_t)v));
+    }
+}
+
+}  // namespace
+
+static int pup_host_mt_randint_plan_impl(uint32_t* key, int32_t* pos, int32_t n_calls, const int64_t* low, const int64_t* high,
+                                        const int64_t* m, const int64_t* scale, const int64_t* offset, void* const* out,
+                                        const int32_t* out_bytes) {
+    if (!key || !pos || *pos < 0 || *pos > kMtN || n_calls < 0 || (n_calls > 0 && (!low || !high || !m || !scale || !offset || !out || !out_bytes)))
+        return PUP_EINVAL;
+    struct Call { uint32_t rng, mask; bool rej, none; };
+    std::vector<Call> calls((size_t)n_calls);
+    bool have_rej = false; uint32_t rng_rej = 0, mask_rej = 0;
+    double words_est = 0.0;
+    for (int k = 0; k < n_calls; ++k) {
+        if (m[k] < 0 || high[k] <= low[k] || (uint64_t)(high[k] - low[k] - 1) > 0xffffffffull) return PUP_EINVAL;
+        if (out[k] && out_bytes[k] != 4 && out_bytes[k] != 8) return PUP_EINVAL;
+        Call c;
+        c.rng = (uint32_t)(high[k] - low[k] - 1);
+        uint32_t mk = c.rng;
+        mk |= mk >> 1; mk |= mk >> 2; mk |= mk >> 4; mk |= mk >> 8; mk |= mk >> 16;
+        c.mask = mk; c.none = c.rng == 0; c.rej = c.rng != mk;
+        if (c.rej && m[k] > 0) {
+            if (have_rej && rng_rej != c.rng) return PUP_ENOTSUP;
+            have_rej = true; rng_rej = c.rng; mask_rej = mk;
+        }
+        if (!c.none) words_est += (double)m[k] * (((double)mk + 1.0) / ((double)c.rng + 1.0));
+        calls[(size_t)k] = c;
+    }
+    std::lock_guard<std::mutex> guard(mt_mutex());
+    // buffer size: an eighth of the job, between 256 and 4096 blocks (10 MB), whole chunks
+    int64_t NB = (int64_t)(words_est / kMtN / 8.0) + 1;
+    NB = std::max<int64_t>(256, std::min<int64_t>(4096, NB));
+    NB = (NB + kPlanChunkBlocks - 1) / kPlanChunkBlocks * kPlanChunkBlocks;
+    const int64_t NBW = NB * kMtN, n_chunks = NB / kPlanChunkBlocks;
+    for (int b = 0; b < 2; ++b) if (mt_plan_buffer(b).size() < (size_t)NBW) mt_plan_buffer(b).resize((size_t)NBW);
+    uint32_t* const buf[2] = {mt_plan_buffer(0).data(), mt_plan_buffer(1).data()};
+    std::atomic<bool> stop{false};
+    // buffer r = blocks [r NB, (r + 1) NB) of the stream whose block 0 is the incoming key
+    auto fill = [&](int64_t r) {
+        uint32_t* dst = buf[r & 1];
+        const uint32_t* prev;
+        int64_t b0 = 0;
+        if (r == 0) { std::memcpy(dst, key, (size_t)kMtN * 4); prev = dst; b0 = 1; }
+        else prev = buf[(r - 1) & 1] + (NB - 1) * kMtN;
+        for (int64_t b = b0; b < NB; ++b) {
+            if ((b & 63) == 0 && stop.load(std::memory_order_relaxed)) return;
+            mt_twist(prev, dst + b * kMtN);
+            prev = dst + b * kMtN;
+        }
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    PhasePool pool((int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(hw ? hw : 1, 16), (int64_t)(words_est / 200000.0) + 1)));
+    const int NWK = pool.n;
+    std::vector<int64_t> cnt((size_t)n_chunks + 1, 0);
+    std::vector<PlanPiece> pieces;
+    std::vector<uint32_t> carry((size_t)kMtN);           // last block of a buffer consumed to its end
+    bool have_carry = false;
+    int k = 0;
+    int64_t donek = 0;
+    int64_t i = *pos;                                     // next unread word of the current buffer
+    const int64_t i_start = i;
+    int64_t r = 0;
+    bool consumed_any = false;
+    fill(0);
+    auto accepted = [&](const uint32_t* raw, int64_t j) -> bool { return (mt_temper(raw[j]) & mask_rej) <= rng_rej; };
+    for (;; ++r) {
+        const uint32_t* raw = buf[r & 1];
+        std::thread tw;
+        bool tw_started = false;
+        try { tw = std::thread([&fill, r] { fill(r + 1); }); tw_started = true; } catch (...) {}
+        struct Join { std::thread& t; std::atomic<bool>& s; bool on; ~Join() { if (on) { s.store(true); t.join(); s.store(false); } } } joiner{tw, stop, tw_started};
+        // pass 1: accepted candidates per chunk under the rejection mask (only while a rejecting call is still to come)
+        bool rej_left = false;
+        for (int q = k; q < n_calls && !rej_left; ++q) rej_left = calls[(size_t)q].rej && m[q] > 0;
+        if (rej_left)
+            pool.run([&](int w) {
+                for (int64_t c = n_chunks * w / NWK; c < n_chunks * (w + 1) / NWK; ++c)
+                    cnt[(size_t)c] = mt_temper_count(raw, c * kPlanChunk, (c + 1) * kPlanChunk, mask_rej, rng_rej);
+            });
+        // the calls walked over the buffer
+        pieces.clear();
+        while (k < n_calls && i < NBW) {
+            const Call& cl = calls[(size_t)k];
+            if (cl.none || m[k] == donek) {
+                if (cl.none && out[k]) {
+                    const int64_t val = offset[k] + scale[k] * low[k];
+                    if (out_bytes[k] == 8) { int64_t* o = static_cast<int64_t*>(out[k]); for (int64_t t = 0; t < m[k]; ++t) o[t] = val; }
+                    else { int32_t* o = static_cast<int32_t*>(out[k]); for (int64_t t = 0; t < m[k]; ++t) o[t] = (int32_t)val; }
+                }
+                ++k; donek = 0; continue;
+            }
+            const int64_t need = m[k] - donek;
+            const int64_t cend = std::min<int64_t>((i / kPlanChunk + 1) * kPlanChunk, NBW);
+            if (!cl.rej) {
+                const int64_t take = std::min<int64_t>(need, cend - i);
+                pieces.push_back({k, i, i + take, donek});
+                donek += take; i += take;
+            } else if (i % kPlanChunk == 0 && cnt[(size_t)(i / kPlanChunk)] < need) {
+                pieces.push_back({k, i, cend, donek});
+                donek += cnt[(size_t)(i / kPlanChunk)]; i = cend;
+            } else {                                      // a partial chunk, or the chunk the call ends in: scan
+                int64_t got = 0, j = i;
+                while (j < cend && got < need) { got += accepted(raw, j) ? 1 : 0; ++j; }
+                pieces.push_back({k, i, j, donek});
+                donek += got; i = j;
+            }
+            consumed_any = true;
+            if (donek == m[k]) { ++k; donek = 0; }
+        }
+        while (k < n_calls && (calls[(size_t)k].none || m[k] == 0)) {      // trailing calls that take no words
+            const Call& cl = calls[(size_t)k];
+            if (cl.none && out[k]) {
+                const int64_t val = offset[k] + scale[k] * low[k];
+                if (out_bytes[k] == 8) { int64_t* o = static_cast<int64_t*>(out[k]); for (int64_t t = 0; t < m[k]; ++t) o[t] = val; }
+                else { int32_t* o = static_cast<int32_t*>(out[k]); for (int64_t t = 0; t < m[k]; ++t) o[t] = (int32_t)val; }
+            }
+            ++k;
+        }
+        // pass 2: the numbers
+        const int64_t np = (int64_t)pieces.size();
+        if (np > 0)
+            pool.run([&](int w) {
+                for (int64_t q = np * w / NWK; q < np * (w + 1) / NWK; ++q) {
+                    const PlanPiece& pc = pieces[(size_t)q];
+                    const Call& cl = calls[(size_t)pc.call];
+                    void* o = out[pc.call];
+                    if (!o) continue;
+                    if (out_bytes[pc.call] == 8) plan_write(static_cast<int64_t*>(o) + pc.out_pos, raw, pc.a, pc.b, cl.mask, cl.rng, cl.rej, low[pc.call], scale[pc.call], offset[pc.call]);
+                    else plan_write(static_cast<int32_t*>(o) + pc.out_pos, raw, pc.a, pc.b, cl.mask, cl.rng, cl.rej, low[pc.call], scale[pc.call], offset[pc.call]);
+                }
+            });
+        if (k >= n_calls) break;                          // (the twister is stopped and joined by `joiner`)
+        // the buffer is used up: the next one must be complete; keep this one's last block (the state if nothing more is read)
+        std::memcpy(carry.data(), raw + (NB - 1) * kMtN, (size_t)kMtN * 4); have_carry = true;
+        if (!tw_started) fill(r + 1);
+        else { joiner.on = false; tw.join(); }
+        i = 0;
+    }
+    // the generator's state: the block holding the last word read, and the place behind it
+    if (consumed_any) {
+        if (i > 0) {
+            const int64_t bl = (i - 1) / kMtN;
+            std::memcpy(key, buf[r & 1] + bl * kMtN, (size_t)kMtN * 4);
+            *pos = (int32_t)(i - bl * kMtN);
+        } else if (have_carry) {
+            std::memcpy(key, carry.data(), (size_t)kMtN * 4);
+            *pos = kMtN;
+        }
+    } else *pos = (int32_t)i_start;
+    return PUP_OK;
+}
+
 // Gather the windows of several regions into one engine call: stable counting sort by tile id over the concatenation of
 // the parts (part order, then order inside the part).  tile_ptr[T + 1] receives the tile boundaries.
 // Parts whose tile array is NULL are RUN-CODED: windows [0, split[p]) of part p belong to tile tile_a[p], the rest to tile_b[p] (an
@@ -639,6 +871,10 @@ PUP_EXPORT int64_t pup_host_sort_pairs(const int64_t* s1, const int64_t* e1, con
 
 PUP_EXPORT int pup_host_mt_randint(uint32_t* key, int32_t* pos, int64_t low, int64_t high, int64_t m, int64_t scale, int64_t offset, void* out_any, int32_t out_bytes) {
     PUP_HOST_GUARD(pup_host_mt_randint_impl(key, pos, low, high, m, scale, offset, out_any, out_bytes), PUP_ENOMEM);
+}
+
+PUP_EXPORT int pup_host_mt_randint_plan(uint32_t* key, int32_t* pos, int32_t n_calls, const int64_t* low, const int64_t* high, const int64_t* m, const int64_t* scale, const int64_t* offset, void* const* out, const int32_t* out_bytes) {
+    PUP_HOST_GUARD(pup_host_mt_randint_plan_impl(key, pos, n_calls, low, high, m, scale, offset, out, out_bytes), PUP_ENOMEM);
 }
 
 PUP_EXPORT int pup_host_group_tiles_runs(int32_t n_parts, const int32_t* const* r0, const int32_t* const* c0, const int32_t* const* tile, const int64_t* split, const int32_t* tile_a, const int32_t* tile_b, const int64_t* len, int32_t T, int32_t* r0_out, int32_t* c0_out, int64_t* tile_ptr) {

@@ -557,6 +557,40 @@ def legacy_randint(low, high, m, scale=1, offset=0, discard=False, dtype=np.int6
     return out
 
 
+def legacy_randint_plan(calls):
+    """A sequence of legacy_randint calls as ONE library job (pup_host_mt_randint_plan): `calls` = [(low, high, m, scale, offset,
+    out)], out a contiguous int32 / int64 array of m entries or None (draw and discard).  Same numbers, same generator state
+    afterwards as the calls made one by one.  Returns False — nothing drawn, generator untouched — when the library declines
+    (calls rejecting over different ranges, a range wider than 2^32, a global generator that is not MT19937): the caller then
+    makes the calls itself."""
+    if not calls:
+        return True
+    st = np.random.get_state(legacy=True)
+    if st[0] != "MT19937":
+        return False
+    n = len(calls)
+    low = np.empty(n, np.int64); high = np.empty(n, np.int64); m = np.empty(n, np.int64)
+    scale = np.empty(n, np.int64); offset = np.empty(n, np.int64); nbytes = np.zeros(n, np.int32)
+    outs = (C.c_void_p * n)()
+    for k, (lo, hi, mk, sc, of, out) in enumerate(calls):
+        if not 0 < int(hi) - int(lo) <= (1 << 32):
+            return False
+        if out is not None:
+            if out.shape != (int(mk),) or not out.flags.c_contiguous or out.dtype.itemsize not in (4, 8) or out.dtype.kind != "i":
+                raise ValueError("legacy_randint_plan: out must be a contiguous int32 / int64 array of m entries")
+            outs[k] = out.ctypes.data
+            nbytes[k] = out.dtype.itemsize
+        low[k], high[k], m[k], scale[k], offset[k] = int(lo), int(hi), int(mk), int(sc), int(of)
+    key = np.array(st[1], dtype=np.uint32, copy=True)
+    pos = C.c_int32(int(st[2]))
+    rc = _ffi.lib().pup_host_mt_randint_plan(_ptr(key), C.byref(pos), n, _ptr(low), _ptr(high), _ptr(m), _ptr(scale), _ptr(offset),
+                                             C.cast(outs, C.c_void_p), _ptr(nbytes))
+    if rc != 0:
+        return False
+    np.random.set_state(("MT19937", key, int(pos.value), st[3], st[4]))
+    return True
+
+
 def factorize_objects(a):
     """pd.factorize(a) (codes int64 with -1 for missing values, uniques in order of first appearance) for a 1-D object array whose
     entries point at few distinct objects: the pointers are factorised by identity in the library (pup_host_factorize_ptr), pandas

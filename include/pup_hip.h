@@ -33,7 +33,7 @@
  *   pup_fetch / pup_export / pup_import
  *                                     <- sum_pups cross-region merge   coolpuppy/lib/puputils.py:88-113
  *                                        and the reduce at             coolpuppy/coolpup.py:1511-1531
- *   pup_host_mt_randint               <- np.random.randint / np.random.choice draws of CoordCreator._control_regions
+ *   pup_host_mt_randint / _plan       <- np.random.randint / np.random.choice draws of CoordCreator._control_regions
  *                                                                      coolpuppy/coolpup.py:420-436
  *   pup_host_windows                  <- CoordCreator._control_regions (shifted control copies) + the bounds test of
  *   pup_host_control_windows             _stream_snips, as one host pass  coolpuppy/coolpup.py:387-453, 1105-1114
@@ -394,6 +394,19 @@ int64_t pup_host_control_windows(const int32_t* st1, const int32_t* st2, const i
  */
 int pup_host_mt_randint(uint32_t* key, int32_t* pos, int64_t low, int64_t high, int64_t m, int64_t scale, int64_t offset,
                         void* out, int32_t out_bytes);
+
+/*
+ * pup_host_mt_randint_plan: n_calls consecutive pup_host_mt_randint calls as ONE job — the draws of every region of a pile-up
+ * (coolpuppy/coolpup.py:420-436, region after region: randint(minshift, maxshift, m_r), then choice([-1, 1], m_r)), whose sizes
+ * are known before the first of them (pup_host_pair_region_counts).  Call k draws m[k] numbers of [low[k], high[k]) into out[k]
+ * (elements of out_bytes[k] = 4 or 8 bytes, as offset[k] + scale[k] * draw; NULL: draw and discard).  Numbers and final state are
+ * those of the calls made one by one; the raw MT19937 stream is produced a buffer ahead by one thread while a pool of workers
+ * counts / places the candidates of the buffer before (the per-call form starts its threads twice per call).
+ * Returns PUP_OK, PUP_EINVAL, or PUP_ENOTSUP when two calls reject over different ranges (make the calls one by one then).
+ */
+int pup_host_mt_randint_plan(uint32_t* key, int32_t* pos, int32_t n_calls, const int64_t* low, const int64_t* high,
+                             const int64_t* m, const int64_t* scale, const int64_t* offset, void* const* out,
+                             const int32_t* out_bytes);
 
 /*
  * pup_host_take_rows: frame.take(order) for the numeric columns of the feature frame CoordCreator sorts (the stable sort of

@@ -132,6 +132,52 @@ def test_library_draws_equal_the_legacy_generator():
     assert np.array_equal(E.legacy_randint(0, 2, 10_000, scale=2, offset=-1), want)
 
 
+def test_planned_draws_equal_the_calls_made_one_by_one():
+    """pup_host_mt_randint_plan (a pile-up's draws as one job: twister thread a buffer ahead of a worker pool) against
+    np.random.randint called in sequence: numbers of every call and the final generator state, for starting positions inside /
+    at the end of a block, int32 and int64 outputs, discarded calls, single-valued ranges, empty calls, a full 32-bit range,
+    sequences that end exactly on a block and on a buffer boundary; two calls rejecting over different ranges are declined
+    with the generator untouched."""
+    from coolpuppy_amd import engine as E
+
+    def check(calls, seed, burn, dtype):
+        np.random.seed(seed)
+        np.random.randint(0, 1000, burn)
+        st0 = np.random.get_state()
+        want = [of + sc * np.random.randint(lo, hi, m) for lo, hi, m, sc, of, _ in calls]
+        end = np.random.get_state()
+        np.random.set_state(st0)
+        mine = [(lo, hi, m, sc, of, np.empty(m, dtype) if keep else None) for lo, hi, m, sc, of, keep in calls]
+        assert E.legacy_randint_plan(mine)
+        now = np.random.get_state()
+        assert np.array_equal(now[1], end[1]) and now[2] == end[2], (seed, burn)
+        for w, c in zip(want, mine):
+            if c[5] is not None:
+                assert np.array_equal(w, c[5]), (seed, burn, c[:3])
+    rng = np.random.default_rng(1)
+    for seed in range(3):
+        for burn in (0, 1, 623, 624, 1000):
+            calls = []
+            for m in rng.integers(0, 5000, 5):
+                calls += [(100_000, 1_000_000, int(m), 1, 0, True), (0, 2, int(m), 2, -1, True)]
+            check(calls, seed, burn, np.int32)
+            check(calls, seed, burn, np.int64)
+    check([(5, 6, 10, 1, 0, True), (100_000, 1_000_000, 70_000, 1, 0, True), (0, 2, 70_000, 2, -1, False), (100_000, 1_000_000, 0, 1, 0, True),
+           (0, 2, 0, 1, 0, True), (100_000, 1_000_000, 300_001, 1, 0, False), (0, 1 << 32, 1000, 1, 0, True), (0, 16, 123_457, 3, 7, True),
+           (7, 8, 3, 2, 1, True)], 3, 17, np.int64)
+    calls = []
+    for m in rng.integers(100_000, 400_000, 6):                    # several buffers
+        calls += [(100_000, 1_000_000, int(m), 1, 0, True), (0, 2, int(m), 2, -1, True)]
+    check(calls, 11, 5, np.int32)
+    for burn in (0, 624):
+        check([(0, 2, 624 * 300 - burn, 1, 0, True)], 0, burn, np.int32)           # ends on a block boundary
+        check([(0, 2, 624 * 256 * 3 - burn, 1, 0, True)], 0, burn, np.int32)       # ... and on a buffer boundary (256 blocks)
+    np.random.seed(0)
+    st = np.random.get_state()
+    assert not E.legacy_randint_plan([(0, 3, 10, 1, 0, np.empty(10, np.int32)), (0, 5, 10, 1, 0, np.empty(10, np.int32))])
+    assert np.array_equal(np.random.get_state()[1], st[1]) and np.random.get_state()[2] == st[2]
+
+
 def test_library_window_pass_equals_numpy():
     """pup_host_windows (shift, bounds test, compaction; no GPU needed) against the numpy statement of the same rules —
     np.round's half-to-even included — for several shapes; pup_host_group_tiles against a stable argsort."""
@@ -181,7 +227,7 @@ def test_library_window_pass_equals_numpy():
         E.group_tiles([(r0[:5], c0[:5], E.RunTile(2, 5, 0, 11))], 11)
 
 
-def test_draw_ahead_thread_issues_the_serial_draws():
+def test_draw_ahead_thread_issues_the_serial_draws(monkeypatch):
     """_DrawAhead (control shifts drawn on a helper thread, a few regions ahead) hands out the numbers the main thread would
     have drawn itself, region by region, and leaves numpy's legacy generator in the same state; a consumer out of step is an
     error, and close() after an abandoned run still ends the sequence where a serial run would."""
@@ -192,7 +238,9 @@ def test_draw_ahead_thread_issues_the_serial_draws():
         _draw_raw_now = coolpup.CoordCreator._draw_raw_now
         _draw_dtype = coolpup.CoordCreator._draw_dtype
     sizes = [5000, 1, 70_000, 2048, 300_000, 12]
-    for trans in (False, True):
+    for trans, planned in ((False, True), (True, True), (False, False), (True, False)):
+        # (planned: the whole sequence as one library job, pup_host_mt_randint_plan; else call by call)
+        monkeypatch.setenv("COOLPUPPY_AMD_NO_DRAW_PLAN", "") if planned else monkeypatch.setenv("COOLPUPPY_AMD_NO_DRAW_PLAN", "1")
         cc = CC()
         cc.trans = trans
         np.random.seed(7)
