@@ -997,6 +997,30 @@ static int cov_pass(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, uint3
 
 // returns PUP_OK when the call was piled up here (K1q + reduction enqueued), 1 when the per-window kernels must take it,
 // a negative code on error.  ev[0..2]: optional timing events (prepass start, K1 start, K1 end).
+// shares of the sixteen waves of K1q's workgroup (StagedArgs::wgt, 1/1024 of an average wave's): the SIMD favours some of its four
+// waves whatever their priorities, the look-ahead work sits at a different place in every wave's slice, and the workgroup waits for its
+// slowest wave at the barrier behind the window loop — so a wave's slice is sized by its measured pace.  Rounds 3-5 had one weight per
+// AGE (wave >> 2: 0.89 / 1.02 / 1.0 / 0.83 = 911 / 1044 / 1024 / 850); the table below is the fixed point of tools/ab/tune_weights.py
+// (four rounds of "phase clocks -> shares towards equal time"; window-loop clocks per control wave 832-882 k -> 852-866 k, wait at the
+// barrier 111 k -> 104 k clocks: what is left of that wait is per-block scatter, not a standing imbalance; K1 -1.5 %,
+// profiles/r05_k1q_weights.txt).  COOLPUPPY_AMD_K1Q_WEIGHTS="w0,...,w15" (in 1/1024) replaces it (experiments).
+static void staged_wave_weights(unsigned short (&wgt)[16]) {
+    static const unsigned short kDefault[16] = {900, 922, 895, 899, 1085, 1062, 1023, 1027, 1062, 1068, 1039, 1041, 799, 858, 825, 839};
+    static unsigned short table[16];
+    static bool have = false;
+    if (!have) {
+        for (int w = 0; w < 16; ++w) table[w] = kDefault[w];
+        if (const char* e = getenv("COOLPUPPY_AMD_K1Q_WEIGHTS")) {
+            int v[16], n = 0;
+            const char* p = e;
+            while (n < 16 && *p) { char* q; const long x = strtol(p, &q, 10); if (q == p) break; v[n++] = (int)x; p = *q == ',' ? q + 1 : q; }
+            if (n == 16) { bool ok = true; for (int w = 0; w < 16; ++w) ok = ok && v[w] > 0 && v[w] < 65536; if (ok) for (int w = 0; w < 16; ++w) table[w] = (unsigned short)v[w]; }
+        }
+        have = true;
+    }
+    for (int w = 0; w < 16; ++w) wgt[w] = table[w];
+}
+
 static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const int64_t* tile_ptr, const int64_t* flip_from,
                       int32_t ignore_diags, uint32_t mode, bool rescale, hipEvent_t* ev) {
     const int W = c->W, T = c->T;
@@ -1257,6 +1281,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
         sa.blocks = c->d_blocks.p; sa.win = c->d_win2.p; sa.wg_first = c->d_wgfirst.p; sa.U = U; sa.PH = H; sa.rec_owner = d_recvalid; sa.T = T;
         sa.teams = ACC > 1 ? c->d_teams.p + (fact ? 0 : (size_t)U * 16) : nullptr;      // (StagedGeom: 16 waves only with factorised counts)
         sa.debug = c->debug_phases & 0x3;
+        staged_wave_weights(sa.wgt);
         sa.timing = nullptr;
         if (c->debug_phases & 4) {                       // phase clocks (diagnostics): [G][16][8] long long, read by pup_debug_timing
             HIPCHK(c, c->d_timing.reserve((size_t)G * 16 * 8));

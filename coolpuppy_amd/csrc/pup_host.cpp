@@ -14,6 +14,8 @@
 #include <mutex>
 #include <new>
 #include <thread>
+#include <pthread.h>
+#include <cstdlib>
 #include <atomic>
 #include <vector>
 
@@ -30,8 +32,91 @@ int n_workers(int64_t rows) {
     return (int)want;
 }
 
+struct PhasePool {                                   // n - 1 helper threads + the caller: run(f) = f(0) .. f(n - 1), back when all are done
+    int n;
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    std::function<void(int)> job;
+    long gen = 0;
+    int pending = 0;
+    bool stop = false, failed = false;
+    explicit PhasePool(int n_) : n(n_ < 1 ? 1 : n_) {
+        try {
+            for (int k = 1; k < n; ++k) th.emplace_back([this, k] { loop(k); });
+        } catch (...) { n = 1 + (int)th.size(); }      // fewer helpers than asked for: the shares are by n
+    }
+    ~PhasePool() {
+        { std::lock_guard<std::mutex> g(mu); stop = true; }
+        cv_go.notify_all();
+        for (auto& t : th) t.join();
+    }
+    void loop(int k) {
+        long seen = 0;
+        for (;;) {
+            std::function<void(int)> f;
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv_go.wait(g, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen; f = job;
+            }
+            bool bad = false;
+            try { f(k); } catch (...) { bad = true; }
+            {
+                std::lock_guard<std::mutex> g(mu);
+                if (bad) failed = true;
+                if (--pending == 0) cv_done.notify_one();
+            }
+        }
+    }
+    template <class F> void run(F&& f) {
+        if (n > 1) {
+            { std::lock_guard<std::mutex> g(mu); job = f; pending = n - 1; ++gen; }
+            cv_go.notify_all();
+        }
+        bool bad = false;
+        try { f(0); } catch (...) { bad = true; }
+        if (n > 1) { std::unique_lock<std::mutex> g(mu); cv_done.wait(g, [&] { return pending == 0; }); }
+        if (bad || failed) { failed = false; throw std::bad_alloc(); }
+    }
+};
+
+// the process's helper threads for the array passes below (lazily started, min(cores, 16) - 1 of them, asleep between passes).
+// Every pass used to start its own threads: ~15 us each, sixteen of them, twice per call — the 46 window passes of a 1e6-pair pile-up
+// spent 11 of their 15 ms starting threads (r05 host profile).  One pass at a time owns the pool (a second caller — the draw helper
+// runs beside the main thread — starts threads of its own as before); a forked child starts a pool of its own.
+PhasePool* g_pool = nullptr;
+std::mutex g_pool_busy, g_pool_make;
+bool g_pool_atfork = false;
+int pool_size() { const unsigned hw = std::thread::hardware_concurrency(); return (int)std::max(1u, std::min(hw ? hw : 1u, 16u)); }
+PhasePool* the_pool() {
+    std::lock_guard<std::mutex> g(g_pool_make);
+    if (!g_pool) {
+        if (!g_pool_atfork) {
+            g_pool_atfork = true;
+            // (the child of a fork has none of the helper threads: it leaves the parent's pool object alone and makes its own)
+            pthread_atfork(nullptr, nullptr, [] { g_pool = nullptr; new (&g_pool_busy) std::mutex(); new (&g_pool_make) std::mutex(); });
+        }
+        g_pool = new PhasePool(pool_size());
+    }
+    return g_pool;
+}
+
 template <class F> void parallel_chunks(int64_t n, int workers, F&& f) {
     if (workers <= 1) { f(0, (int64_t)0, n); return; }
+    if (!getenv("COOLPUPPY_AMD_NO_HOST_POOL")) {
+        std::unique_lock<std::mutex> own(g_pool_busy, std::try_to_lock);
+        if (own.owns_lock()) {
+            PhasePool* pool = nullptr;
+            try { pool = the_pool(); } catch (...) { pool = nullptr; }
+            if (pool && pool->n >= 2) {
+                const int w = std::min(workers, pool->n);
+                pool->run([&f, w, n](int k) { if (k < w) f(k, n * k / w, n * (k + 1) / w); });
+                return;
+            }
+        }
+    }
     std::vector<std::thread> th;
     std::atomic<int> failed{0};
     th.reserve((size_t)workers);
@@ -572,56 +657,6 @@ static int pup_host_mt_randint_impl(uint32_t* key, int32_t* pos, int64_t low, in
 // Calls that reject (range not a power of two) must share one range — true of a pile-up's draws; else PUP_ENOTSUP and the
 // caller draws call by call.
 namespace {
-
-struct PhasePool {                                   // n - 1 helper threads + the caller: run(f) = f(0) .. f(n - 1), back when all are done
-    int n;
-    std::vector<std::thread> th;
-    std::mutex mu;
-    std::condition_variable cv_go, cv_done;
-    std::function<void(int)> job;
-    long gen = 0;
-    int pending = 0;
-    bool stop = false, failed = false;
-    explicit PhasePool(int n_) : n(n_ < 1 ? 1 : n_) {
-        try {
-            for (int k = 1; k < n; ++k) th.emplace_back([this, k] { loop(k); });
-        } catch (...) { n = 1 + (int)th.size(); }      // fewer helpers than asked for: the shares are by n
-    }
-    ~PhasePool() {
-        { std::lock_guard<std::mutex> g(mu); stop = true; }
-        cv_go.notify_all();
-        for (auto& t : th) t.join();
-    }
-    void loop(int k) {
-        long seen = 0;
-        for (;;) {
-            std::function<void(int)> f;
-            {
-                std::unique_lock<std::mutex> g(mu);
-                cv_go.wait(g, [&] { return stop || gen != seen; });
-                if (stop) return;
-                seen = gen; f = job;
-            }
-            bool bad = false;
-            try { f(k); } catch (...) { bad = true; }
-            {
-                std::lock_guard<std::mutex> g(mu);
-                if (bad) failed = true;
-                if (--pending == 0) cv_done.notify_one();
-            }
-        }
-    }
-    template <class F> void run(F&& f) {
-        if (n > 1) {
-            { std::lock_guard<std::mutex> g(mu); job = f; pending = n - 1; ++gen; }
-            cv_go.notify_all();
-        }
-        bool bad = false;
-        try { f(0); } catch (...) { bad = true; }
-        if (n > 1) { std::unique_lock<std::mutex> g(mu); cv_done.wait(g, [&] { return pending == 0; }); }
-        if (bad || failed) { failed = false; throw std::bad_alloc(); }
-    }
-};
 
 constexpr int kPlanChunkBlocks = 16;                  // blocks per chunk: the unit of the counts and of the workers' shares
 constexpr int64_t kPlanChunk = (int64_t)kPlanChunkBlocks * kMtN;

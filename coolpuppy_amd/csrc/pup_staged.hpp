@@ -71,6 +71,7 @@ struct StagedArgs {
     const unsigned char*  teams;      // [U][16]: waves [teams[u][s], teams[u][s+1]) pile up the slot-s windows of unit u's blocks —
                                       // teams sized by the host in proportion to the tiles' window counts (none for an empty tile)
     int                   debug;      // timing experiments only (results are wrong): 1 = skip the window loop, 2 = skip the staging
+    unsigned short        wgt[16];    // sixteen-wave kernels: wave w's share of its team's windows, in 1/1024 of an average wave's (see wave_weight)
     long long*            timing;     // phase clocks per wave, [G][NW][8] (tools/k1_probe.py --phases), or nullptr
 };
 
@@ -192,8 +193,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     // youngest wave of a SIMD get through a window ~8 % slower than the two in between whatever the priorities (phase clocks,
     // round 3: the workgroup waited 14 % of its time for them at the barrier behind the window loop) — they get 7 % fewer
     auto wave_weight = [&](int w) __attribute__((always_inline)) -> float {
-        const int ag = w >> 2;
-        return NW != 16 ? 1.0f : (ag == 3 ? 0.83f : (ag == 0 ? 0.89f : (ag == 1 ? 1.02f : 1.0f)));     // (round 5: re-measured, phase clocks of profiles/r05_k1q_phases.json)
+        return NW != 16 ? 1.0f : (float)sa.wgt[w & 15] * (1.0f / 1024.0f);     // (the engine's table: staged_wave_weights, from the phase clocks of profiles/r05_k1q_phases.txt)
     };
     float f_lo = 0.0f, f_hi = 1.0f;
     auto set_shares = [&]() __attribute__((always_inline)) {

@@ -294,6 +294,48 @@ def test_coordcreator_leaves_the_callers_frame_alone_and_factorises_by_identity(
     assert np.array_equal(c1, c2) and list(u1) == list(u2)
 
 
+def test_host_pool_serves_threads_and_forked_children():
+    """The array passes of the library share one pool of helper threads (pup_host.cpp: parallel_chunks): two Python threads calling
+    at once both get the right answer (the second caller starts threads of its own), and a forked child — which inherits none of
+    the helpers — makes a pool of its own instead of waiting for threads that do not exist."""
+    import os
+    import threading
+    from coolpuppy_amd import engine as E
+    rng = np.random.default_rng(9)
+    keys = [rng.integers(0, 1 << 23, 400_000).astype(np.uint64) for _ in range(2)]
+    want = [np.argsort(k, kind="stable") for k in keys]
+    assert np.array_equal(E.stable_argsort(keys[0], 23), want[0])          # (the pool exists from here on)
+    got = [None, None]
+
+    def work(i):
+        for _ in range(5):
+            got[i] = E.stable_argsort(keys[i], 23)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    pid = os.fork()
+    if pid == 0:
+        ok = False
+        try:
+            ok = np.array_equal(E.stable_argsort(keys[1], 23), want[1])
+        finally:
+            os._exit(0 if ok else 1)
+    for _ in range(600):
+        done, status = os.waitpid(pid, os.WNOHANG)
+        if done:
+            break
+        import time
+        time.sleep(0.05)
+    else:
+        os.kill(pid, 9)
+        os.waitpid(pid, 0)
+        raise AssertionError("the forked child hung in a library pass")
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
+
+
 def test_library_argsort_equals_numpy_stable_argsort():
     from coolpuppy_amd import engine as E
     rng = np.random.default_rng(5)
