@@ -1198,6 +1198,8 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
         if (se != hipSuccess) return fail(c, PUP_EHIP, "pup_accumulate: block sort: %s", hipGetErrorString(se));
     }
 
+    int block_cost = pup::kBlockCost;
+    if (const char* e = getenv("COOLPUPPY_AMD_K1Q_COST")) { const int v = atoi(e); if (v > 0) block_cost = v; }     // experiments
     // ---- prepass, all on the stream -------------------------------------------------------------------------------------
     if (ev) HIPCHK(c, hipEventRecord(ev[0], c->stream));
     if (use_bin) { const int brc = bin_prepare(c, bp, (long long)n, slot_bits > 0); if (brc != PUP_OK) return brc; }
@@ -1237,7 +1239,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
         hipLaunchKernelGGL((pup::staged_table_kernel<unsigned>), dim3(gt), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
                            (const unsigned*)(c->d_cnt32.p + 3), (long long)n, (const unsigned*)nullptr,
                            (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
-                           c->n_chrom, W, W, geo.RSR, geo.RSC, 1, pup::kBlockCost, sh_br, sh_er, sh_seg, seg_shift, slot_bits, n_eregs, er_in_key ? 1 : 0, d_eregs,
+                           c->n_chrom, W, W, geo.RSR, geo.RSC, 1, block_cost, sh_br, sh_er, sh_seg, seg_shift, slot_bits, n_eregs, er_in_key ? 1 : 0, d_eregs,
                            (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G, (const unsigned*)c->d_bkeys.p,
                            slot_bits > 0 ? (const unsigned short*)c->d_low.p : (const unsigned short*)nullptr,
                            (volatile unsigned*)(c->d_flags + 4), ticket, rel_bc);
@@ -1252,7 +1254,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
         hipLaunchKernelGGL((pup::staged_table_kernel<unsigned>), dim3(gt), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
                            (const unsigned*)(c->d_cnt32.p + 3), (long long)n, (const unsigned*)c->d_k32b.p,
                            (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
-                           c->n_chrom, W, W, geo.RSR, geo.RSC, 1, pup::kBlockCost, sh_br, sh_er, sh_seg, seg_shift, slot_bits, n_eregs, er_in_key ? 1 : 0, d_eregs,
+                           c->n_chrom, W, W, geo.RSR, geo.RSC, 1, block_cost, sh_br, sh_er, sh_seg, seg_shift, slot_bits, n_eregs, er_in_key ? 1 : 0, d_eregs,
                            (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G, (const unsigned*)nullptr, (const unsigned short*)nullptr,
                            (volatile unsigned*)(c->d_flags + 4), ticket, rel_bc);
     } else {
@@ -1266,7 +1268,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
         hipLaunchKernelGGL((pup::staged_table_kernel<unsigned long long>), dim3(gt), dim3(256), 0, c->stream, (const unsigned*)c->d_starts.p,
                            (const unsigned*)(c->d_cnt32.p + 3), (long long)n, (const unsigned long long*)c->d_keys2.p,
                            (const unsigned short*)c->d_win2.p, (const int*)c->d_brow.p, (const pup::IdxChrom*)c->idx_chrom.p,
-                           c->n_chrom, W, W, geo.RSR, geo.RSC, 1, pup::kBlockCost, sh_br, sh_er, sh_seg, seg_shift, slot_bits, n_eregs, er_in_key ? 1 : 0, d_eregs,
+                           c->n_chrom, W, W, geo.RSR, geo.RSC, 1, block_cost, sh_br, sh_er, sh_seg, seg_shift, slot_bits, n_eregs, er_in_key ? 1 : 0, d_eregs,
                            (const unsigned long long*)c->badbits.p, c->d_blocks.p, c->d_wgfirst.p, G, (const unsigned*)nullptr, (const unsigned short*)nullptr,
                            (volatile unsigned*)(c->d_flags + 4), ticket, rel_bc);
     }
@@ -1480,7 +1482,12 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
     }
     const unsigned gk4 = use_bin ? (unsigned)bp.ntiles : (unsigned)((n_items + 1023) / 1024);
     const int wkey_threads = 256, wkey_per = use_bin ? pup::kBinTile / 256 : 4;
-    int wide_cost = pup::kWideBlockCost;
+    // what staging a block costs, in items' worth of time (the workgroups' block ranges are balanced on items + cost x blocks): an item is
+    // 4 x CH LDS reads, a block ~9 k clocks of store burst, barriers and look-ahead whatever the lane shape — measured (tools/ab/wide_cost.sh,
+    // K1 ms at cost 100 / 130 / 160 / 200 / 260): 51-bin windows (CH 11) 2.71 / 2.70 / 2.78 / 2.87 / 2.93, 81-bin (CH 7, four groups) 7.67 / 6.98 /
+    // 6.47 / 6.34 / 6.58, 201-bin (CH 11, sixteen groups) 22.2 / 20.5 / 20.9 / 21.5 / 22.5 — the fixed 100 of round 4 was right for the
+    // shape it was measured on only
+    int wide_cost = (pup::kWideBlockCostCells + geo.CH / 2) / geo.CH;
     if (const char* e = getenv("COOLPUPPY_AMD_WIDE_COST")) { const int v = atoi(e); if (v > 0) wide_cost = v; }     // experiments
 #define PUP_WKEY_ARGS dr0, dc0, (long long)n, n_items, (const long long*)c->d_segend.p, nseg2t, (const pup::IdxChrom*)c->idx_chrom.p, c->n_chrom, \
         (const unsigned short*)c->bin_chrom.p, (long long)c->nbins, (const int*)c->d_brow.p, W, NG, geo.NGc, geo.SH, geo.SW, BR, BC, sh_br, sh_seg, \
@@ -1555,7 +1562,8 @@ static int wide_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, const
     wa.rec_seg = c->wrec_seg.p; wa.rec_f64 = c->wrec_f64.p; wa.rec_num = c->wrec_num.p;
     wa.timing = nullptr;
     {   // shares of the four waves of a panel, oldest first (see slice_of); COOLPUPPY_AMD_WIDE_SHARES="a,b,c" (cumulative, of 256) for experiments
-        int sh3[3] = {80, 151, 211};               // measured, pad 25: equal shares 3.30 ms, 73/140/202 3.15, 78/148/208 2.92, 80/151/211 2.87, 82/154/213 2.90
+        int sh3[3] = {88, 161, 219};               // measured, pad 25: equal shares 3.30 ms, 73/140/202 3.15, 78/148/208 2.92, 80/151/211 2.87, 82/154/213 2.90;
+                                                   // round 5 (bookkeeping panel rotating): pad 25 80/151/211 2.71, 88/161/219 2.71, 92/166/222 2.81; pad 100 22.2 / 21.9 / 21.7
         if (const char* e = getenv("COOLPUPPY_AMD_WIDE_SHARES")) { int x, y, z; if (sscanf(e, "%d,%d,%d", &x, &y, &z) == 3 && 0 <= x && x <= y && y <= z && z <= 256) { sh3[0] = x; sh3[1] = y; sh3[2] = z; } }
         wa.share[0] = sh3[0]; wa.share[1] = sh3[1]; wa.share[2] = sh3[2];
     }

@@ -27,8 +27,8 @@
 namespace pup {
 
 constexpr int kWideRec = 64 * 64;                     // cells of a partial record: sub-window row p, column q at p * 64 + q
-constexpr int kWideBlockCost = 100;                   // staging one region, in (sub-)windows' worth of time (workgroup ranges): measured,
-                                                      // pad 25: ~12 k clocks per block (HBM round trip, store burst, two barriers) at 138 per window
+constexpr int kWideBlockCostCells = 1400;             // staging one region, in cells per lane of items' worth of time: a block costs 1400 / CH items
+                                                      // (workgroup ranges; wide_run: ~9 k clocks per block — store burst, two barriers, look-ahead)
 constexpr int kWideMaxRows = 64;                      // sub-window rows: a lane each
 constexpr int kWideMaxCH = 13;                        // cells per lane: register budget of 16 waves x 128 VGPRs
 
@@ -245,8 +245,11 @@ void pileup_wide_kernel(K1Args a, WideArgs wa) {
             const bool live = rr >= row_lo && rr < hi2;                           // (uniform)
             const int* rowp = live ? a.band + (long long)row * a.band_w + (C - row) : zeros;
             if constexpr (FACT) {
-#pragma unroll
-                for (int h = 0; h < NH; ++h) v[i * NH + h] = rowp[64 * h + lane];
+                // a lane takes the NEIGHBOURING columns 2 l and 2 l + 1 of the row — one 8-byte load per row and, at store time, one
+                // ds_write2_b64 — half the memory and LDS instructions of the staging (as K1q since round 5)
+                int2 two;
+                __builtin_memcpy(&two, rowp + 2 * lane, sizeof(two));      // (4-byte aligned: global_load_dwordx2)
+                v[i * NH] = two.x; v[i * NH + 1] = two.y;
             } else {
                 const bool row_bad = (fld64(ev, 16 + 2 * (rr >> 6)) >> (rr & 63)) & 1ull;
 #pragma unroll
@@ -264,7 +267,7 @@ void pileup_wide_kernel(K1Args a, WideArgs wa) {
         const double* wsrc = a.weight ? a.weight : reinterpret_cast<const double*>(a.indptr);
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-            const long long col = (long long)C + 64 * h + lane;
+            const long long col = FACT ? (long long)C + 2 * lane + h : (long long)C + 64 * h + lane;      // (FACT: columns 2 l, 2 l + 1)
             wc[h] = wsrc[col < a.nbins ? col : a.nbins - 1];      // raw: reads the row offsets, a table of the same length — never looked at
         }
         {   // row weights: lane i < RPW holds its row's, broadcast at store time
@@ -293,10 +296,11 @@ void pileup_wide_kernel(K1Args a, WideArgs wa) {
             const double wr = __longlong_as_double((long long)bcast64((unsigned long long)__double_as_longlong(wrs), i));
 #pragma unroll
             for (int hh = 0; hh < NH; ++hh) {
+                const int colx = FACT ? 2 * lane + hh : 64 * hh + lane;      // (band_issue: FACT lanes hold columns 2 l and 2 l + 1)
                 double val = (double)v[i * NH + hh] * wr * wcs[hh];
                 if (nf) val = (val == val) ? val : 0.0;
                 if (OOE) {
-                    const double e = exp_lds[64 * hh + lane - rr + (RSR - 1)];      // expected of |col - row|
+                    const double e = exp_lds[colx - rr + (RSR - 1)];      // expected of |col - row|
                     val = val / e;
                     val = (val == val) ? val : 0.0;         // NaN quotients are skipped, inf is kept
                     if constexpr (!FACT) {
@@ -306,7 +310,7 @@ void pileup_wide_kernel(K1Args a, WideArgs wa) {
                         if (lane == i) okn[hh] &= eok;
                     }
                 }
-                tile[rr * LS + 64 * hh + lane] = val;
+                tile[rr * LS + colx] = val;
             }
         }
         if constexpr (!FACT) {
@@ -402,11 +406,14 @@ void pileup_wide_kernel(K1Args a, WideArgs wa) {
             lo = (int)(((long long)n * cum_lo + 128) >> 8); hi = sub == 3 ? n : (int)(((long long)n * cum_hi + 128) >> 8);
         } else { lo = (int)(((long long)n * sub) / nsub); hi = (int)(((long long)n * (sub + 1)) / nsub); }
     };
-    auto windows = [&](const Cur& g, int wf, auto&& mid) __attribute__((always_inline)) {
+    auto windows = [&](const Cur& g, int wf, int rot, auto&& mid) __attribute__((always_inline)) {
         int lo, hi;
         slice_of(g.n, lo, hi);
         const bool cols_live = (panel * kWave) / NCH < sh;     // (uniform) a panel whose first slot lies past the group's last row has nothing to pile up
-        int t = 0;
+        // batch t's bookkeeping falls to panel (t + rot) % NPC, rot = the block's number: many-group calls (201-bin windows: ~80 items
+        // per block, ~20 per slice) have ONE batch per slice and block — without the rotation panel 0 did all of it and its four
+        // waves were the workgroup's slowest by 8-10 % (phase clocks, profiles/r05_k1w_phases.txt)
+        int t = rot;
         {
             const int drv = wf & ((1 << kWinShift) - 1), dcv = (wf >> kWinShift) & ((1 << kWinShift) - 1);
             const int offv = 8 * (drv * LS + dcv);
@@ -522,7 +529,7 @@ void pileup_wide_kernel(K1Args a, WideArgs wa) {
         };
         const Cur c0 = cur_of(ev0);
         const long long t1 = tick();
-        windows(c0, w0f, lookahead);
+        windows(c0, w0f, b & 3, lookahead);
         if constexpr (OOE) { if (has1 && tid < 256) exp_lds[tid] = e_next; }     // (last read when region b was stored; visible after the barrier below)
         const long long t2 = tick();
         const int seg0 = fld(ev0, 20), grp0 = fld(ev0, 30);
