@@ -11,6 +11,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <functional>
+#include <limits>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -880,6 +881,28 @@ PUP_EXPORT int pup_host_group_tiles(int32_t n_parts, const int32_t* const* r0, c
     return pup_host_group_tiles_runs(n_parts, r0, c0, tile, nullptr, nullptr, nullptr, len, T, r0_out, c0_out, tile_ptr);
 }
 
+// ---- the finaliser's arithmetic on whole tile arrays -----------------------------------------------------------------------
+// data = (sum / num) [/ (control_sum / control_num)], +inf -> NaN (coolpuppy/coolpup.py:1533-1545), element by element in place of
+// `sum`, in numpy's order of operations (so that the frame equals the per-row form bit for bit).  A by-window pile-up has a tile
+// per feature — 1.6e7 cells for 37 k CTCF sites: numpy's four single-threaded passes were 20 ms of a 90 ms call.
+static int pup_host_normalise_tiles_impl(double* sum, const int64_t* num, double* csum, const int64_t* cnum, int64_t count) {
+    if (count < 0 || (count > 0 && (!sum || !num)) || ((csum == nullptr) != (cnum == nullptr))) return PUP_EINVAL;
+    const double inf = std::numeric_limits<double>::infinity(), qnan = std::numeric_limits<double>::quiet_NaN();
+    parallel_chunks(count, n_workers(count / 4), [&](int, int64_t a, int64_t b) {
+        if (csum) {
+            for (int64_t i = a; i < b; ++i) {
+                const double c = csum[i] / (double)cnum[i];
+                csum[i] = c;                                 // (the caller's control array holds the quotient afterwards, as numpy's out=)
+                const double v = (sum[i] / (double)num[i]) / c;
+                sum[i] = v == inf ? qnan : v;
+            }
+        } else {
+            for (int64_t i = a; i < b; ++i) { const double v = sum[i] / (double)num[i]; sum[i] = v == inf ? qnan : v; }
+        }
+    });
+    return PUP_OK;
+}
+
 // No exception may cross the C boundary (a std::bad_alloc of the scratch vectors, a std::system_error of a thread that could not
 // be started inside a container's limits): the entry points catch everything and report an error code; the callers fall back to numpy.
 #define PUP_HOST_GUARD(call, err) try { return call; } catch (...) { return err; }
@@ -910,6 +933,10 @@ PUP_EXPORT int pup_host_mt_randint(uint32_t* key, int32_t* pos, int64_t low, int
 
 PUP_EXPORT int pup_host_mt_randint_plan(uint32_t* key, int32_t* pos, int32_t n_calls, const int64_t* low, const int64_t* high, const int64_t* m, const int64_t* scale, const int64_t* offset, void* const* out, const int32_t* out_bytes) {
     PUP_HOST_GUARD(pup_host_mt_randint_plan_impl(key, pos, n_calls, low, high, m, scale, offset, out, out_bytes), PUP_ENOMEM);
+}
+
+PUP_EXPORT int pup_host_normalise_tiles(double* sum, const int64_t* num, double* csum, const int64_t* cnum, int64_t count) {
+    PUP_HOST_GUARD(pup_host_normalise_tiles_impl(sum, num, csum, cnum, count), PUP_ENOMEM);
 }
 
 PUP_EXPORT int pup_host_group_tiles_runs(int32_t n_parts, const int32_t* const* r0, const int32_t* const* c0, const int32_t* const* tile, const int64_t* split, const int32_t* tile_a, const int32_t* tile_b, const int64_t* len, int32_t T, int32_t* r0_out, int32_t* c0_out, int64_t* tile_ptr) {

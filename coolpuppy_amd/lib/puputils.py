@@ -199,6 +199,26 @@ def _annotation(pu):
     return out
 
 
+def _normalise_tiles(S, N, Sc, Nc):
+    """data = S / N [/ (Sc / Nc)], +inf -> NaN (reference coolpup.py:1533-1545), in place of S (and Sc): big tile arrays (by-window: a
+    tile per feature) go through the library's multi-threaded pass (pup_host_normalise_tiles: same operations, same order),
+    small or unusual ones through numpy."""
+    arrs = [S, N] + ([Sc, Nc] if Sc is not None else [])
+    if S.size >= 200_000 and all(isinstance(a, np.ndarray) and a.flags.c_contiguous and a.flags.writeable for a in arrs) \
+            and S.dtype == np.float64 and N.dtype == np.int64 and N.shape == S.shape \
+            and (Sc is None or (Sc.dtype == np.float64 and Nc.dtype == np.int64 and Sc.shape == S.shape and Nc.shape == S.shape)):
+        from .. import _ffi
+        ptr = lambda a: None if a is None else a.ctypes.data      # noqa: E731
+        if _ffi.lib().pup_host_normalise_tiles(ptr(S), ptr(N), ptr(Sc), ptr(Nc), S.size) == 0:
+            return S
+    with np.errstate(divide="ignore", invalid="ignore"):
+        data = np.divide(S, N, out=S)
+        if Sc is not None:
+            data = np.divide(data, np.divide(Sc, Nc, out=Sc), out=data)
+    np.putmask(data, data == np.inf, np.nan)
+    return data
+
+
 def _finalize_tiles(pu, acc, keys, gid, G, groupby, want_control):
     """_finalize_frames for the usual case — no stripes, every group piled up for both kinds — on the [T][W][W] arrays at
     once instead of one pandas operation per step and row: the same frame (columns, order, dtypes, values; tests compare the
@@ -234,19 +254,13 @@ def _finalize_tiles(pu, acc, keys, gid, G, groupby, want_control):
             warnings.warn("Expected can not be normalized to coverage", stacklevel=3)
     # (in place: S / Sc are this function's own copies, or views of the fetched tiles nobody reads again — a by-window pile-up holds
     # a tile per feature, and every temporary of that size is 130 MB of fresh pages)
-    with np.errstate(divide="ignore", invalid="ignore"):
-        data = np.divide(S, N, out=S)
-        if want_control:
-            data = np.divide(data, np.divide(Sc, Nc, out=Sc), out=data)
-    np.putmask(data, data == np.inf, np.nan)
+    data = _normalise_tiles(S, N, Sc if want_control else None, Nc if want_control else None)
     if pu.local:
         with warnings.catch_warnings():
             warnings.simplefilter("ignore", category=RuntimeWarning)
             data = np.nanmean(np.stack((data, data.transpose(0, 2, 1)), axis=-1), axis=-1)
-    ints = lambda v: np.array([int(x) for x in v] + [None], dtype=object)[:-1]      # noqa: E731  Python ints in an object column
-    group = np.empty(n_rows, dtype=object)
-    for i, k in enumerate(keys):
-        group[i] = k
+    ints = lambda v: np.asarray(v, np.int64).astype(object)      # noqa: E731  Python ints in an object column
+    group = np.fromiter(keys, dtype=object, count=n_rows)       # (entry i IS keys[i]: tuples stay tuples)
     cols = {}
     if groupby:
         gdf = pd.DataFrame([("all",) * len(groupby) if (isinstance(k, str) and k == "all") else k for k in keys],

@@ -33,6 +33,8 @@
  *   pup_fetch / pup_export / pup_import
  *                                     <- sum_pups cross-region merge   coolpuppy/lib/puputils.py:88-113
  *                                        and the reduce at             coolpuppy/coolpup.py:1511-1531
+ *   pup_host_normalise_tiles          <- the ratio to the control and the inf -> NaN step of pileupsWithControl
+ *                                                                      coolpuppy/coolpup.py:1533-1545
  *   pup_host_mt_randint / _plan       <- np.random.randint / np.random.choice draws of CoordCreator._control_regions
  *                                                                      coolpuppy/coolpup.py:420-436
  *   pup_host_windows                  <- CoordCreator._control_regions (shifted control copies) + the bounds test of
@@ -394,6 +396,14 @@ int64_t pup_host_control_windows(const int32_t* st1, const int32_t* st2, const i
  */
 int pup_host_mt_randint(uint32_t* key, int32_t* pos, int64_t low, int64_t high, int64_t m, int64_t scale, int64_t offset,
                         void* out, int32_t out_bytes);
+
+/*
+ * pup_host_normalise_tiles: the finaliser's arithmetic (coolpuppy/coolpup.py:1533-1545: data / num, the ratio to the control's
+ * data / num, +inf -> NaN) on `count` cells at once, in place of `sum` (and of `csum`, which holds the control's quotient
+ * afterwards), on several threads; csum / cnum NULL: no control.  Same operations in the same order as the reference's numpy
+ * expressions.  Returns PUP_OK or PUP_EINVAL.
+ */
+int pup_host_normalise_tiles(double* sum, const int64_t* num, double* csum, const int64_t* cnum, int64_t count);
 
 /*
  * pup_host_mt_randint_plan: n_calls consecutive pup_host_mt_randint calls as ONE job — the draws of every region of a pile-up

@@ -336,6 +336,60 @@ def test_host_pool_serves_threads_and_forked_children():
     assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
 
 
+def test_sorted_combinations_equal_the_walk_over_offsets(monkeypatch):
+    """CoordCreator._combination_table_sorted (BED features, no control draws: the pairs of every feature by two bisections in the
+    order of the centres, brought into the reference's order by stable sorts) against the walk over the offsets the reference makes
+    (coolpup.py:682-700): same rows, same order, same columns and dtypes — for several densities, ties between centres, float and
+    automatic bounds, one- and two-feature chromosomes."""
+    import pandas as pd
+    from coolpuppy_amd import coolpup
+
+    def tables(feats, walk, **kw):
+        monkeypatch.setenv("COOLPUPPY_AMD_WALK_COMBINATIONS", "1") if walk else monkeypatch.delenv("COOLPUPPY_AMD_WALK_COMBINATIONS", raising=False)
+        cc = coolpup.CoordCreator(features=feats, resolution=10_000, features_format="bed", flank=100_000, **kw)
+        cc.process()
+        return [cc.region_table((ch, 0, 10 ** 9), None, control=False, columns=None) for ch in ("chr1", "chr2")]
+    rng = np.random.default_rng(0)
+    for trial, n in enumerate((50, 400, 1500, 3, 1, 2)):
+        rows = []
+        for ch in ("chr1", "chr2"):
+            st = np.sort(rng.integers(0, 30_000_000, n)) if trial != 2 else np.sort(rng.integers(0, 3_000_000, n) // 5000 * 5000)
+            # (odd trials: ends that make the centres leave the order of the starts)
+            rows.append(pd.DataFrame({"chrom": ch, "start": st, "end": st + rng.integers(1, 3 if trial % 2 == 0 else 400, n) * 1000}))
+        feats = pd.concat(rows, ignore_index=True)
+        for kw in (dict(mindist=300_000, maxdist=1_000_000), dict(mindist=0, maxdist=250_000.5), dict(mindist="auto"),
+                   dict(mindist=220_000.25, maxdist=3e6)):
+            for x, y in zip(tables(feats, True, **kw), tables(feats, False, **kw)):
+                assert (x is None) == (y is None), (trial, kw)
+                if x is not None:
+                    assert list(x.keys()) == list(y.keys())
+                    for k in x:
+                        assert x[k].dtype == y[k].dtype and np.array_equal(x[k], y[k]), (trial, kw, k)
+
+
+def test_library_tile_normalisation_equals_numpy():
+    """pup_host_normalise_tiles (data / num, the ratio to the control's, +inf -> NaN on whole tile arrays, several threads) against
+    the numpy expressions of the finaliser: same values, NaN where numpy has NaN, -inf kept, signs of zeros included."""
+    from coolpuppy_amd.lib import puputils as P
+    rng = np.random.default_rng(0)
+    for ctrl in (False, True):
+        S = rng.normal(size=(2000, 21, 21))
+        N = rng.integers(0, 5, S.shape).astype(np.int64)
+        S[N == 0] = 0.0
+        S[0, 0, 0], N[0, 0, 0] = 1.0, 0              # +inf -> NaN
+        S[0, 0, 1], N[0, 0, 1] = -1.0, 0             # -inf stays
+        Sc, Nc = rng.normal(size=S.shape), rng.integers(0, 3, S.shape).astype(np.int64)
+        with np.errstate(all="ignore"):
+            want = S / N
+            if ctrl:
+                want = want / (Sc / Nc)
+        want = np.where(want == np.inf, np.nan, want)
+        got = P._normalise_tiles(S.copy(), N, Sc.copy() if ctrl else None, Nc if ctrl else None)
+        assert np.array_equal(want, got, equal_nan=True)
+        fin = ~np.isnan(want)
+        assert np.array_equal(np.signbit(want[fin]), np.signbit(got[fin]))
+
+
 def test_library_argsort_equals_numpy_stable_argsort():
     from coolpuppy_amd import engine as E
     rng = np.random.default_rng(5)

@@ -13,6 +13,7 @@ ap.add_argument("--every", type=int, default=1, help="use every k-th site")
 ap.add_argument("--maxdist", type=int, default=1_000_000)
 ap.add_argument("--out", default="")
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--profile", type=int, default=0, help="cProfile of one more call: print the top N functions")
 ap.add_argument("--serial", action="store_true", help="build the table in this process (under rocprofv3: forked workers hang the profiler)")
 a = ap.parse_args()
 warnings.simplefilter("ignore")
@@ -42,6 +43,12 @@ for rep in range(a.reps):
                 "exchange_tiles_total_bytes": int(8 * sum(eng.tile_block_sizes(int(rows.shape[0])))),
                 "exchange_bytes_per_rank_of_8": int(8 * sum(eng.tile_block_sizes((int(rows.shape[0]) + 7) // 8)))})
     print(json.dumps(res[-1]), flush=True)
+if a.profile:
+    import cProfile, pstats
+    cProfile.runctx("coolpup.pileup(clr, bed, **kw)", globals(), locals(), "/tmp/bywindow.prof")
+    st = pstats.Stats("/tmp/bywindow.prof")
+    st.sort_stats("cumulative").print_stats(a.profile)
+    st.sort_stats("tottime").print_stats(a.profile)
 if a.out:
     json.dump({"what": "by-window pile-up, Bonev CTCF+ sites on the mm9-like synthetic 10 kb table (tools/probe_bywindow.py)", "runs": res},
               open(a.out, "w"), indent=1)
