@@ -23,7 +23,8 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "pup_hip.h")
 _KERNEL_HEADERS = sorted(os.path.join(_CSRC, h) for h in os.listdir(_CSRC) if h.endswith((".hpp", ".h")))
 DEPS = sorted(os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".cpp", ".hpp", ".h"))) + [HEADER]
 OUT = os.path.join(_HERE, "libpup_hip.so")
-_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-result", "-pthread"]
+_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-result", "-pthread"] \
+    + os.environ.get("COOLPUPPY_AMD_EXTRA_CXXFLAGS", "").split()       # (experiments: e.g. -DPUP_WIDE_NW=8)
 
 
 def hipcc_path():

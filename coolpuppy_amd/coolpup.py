@@ -1838,8 +1838,18 @@ class PileUpper:
             if b is None or b["n"] == 0:
                 continue
             run_tile = (not grouped) and ("n_roi" in b) and not exp_as_control and b.get("flip") is None and not rescale
+            tile_done = False
             if grouped:     # (a key none of the region's kept windows uses is not in the table: its code never occurs)
-                g = np.array([gid.get(k, -1) for k in b["group_keys"]], np.int32)[b["group_codes"]]
+                lut = np.array([gid.get(k, -1) for k in b["group_keys"]], np.int32)
+                if "n_roi" in b and not exp_as_control and len(lut):
+                    # ROI windows first, then the controls: tile = group, + G from there on — two gathers straight into the tile
+                    # array (a gather and an in-place add over the same 10^7 entries were 23 ms of a 1e6-pair call)
+                    g = np.empty(b["n"], np.int32)
+                    np.take(lut, b["group_codes"][:b["n_roi"]], out=g[:b["n_roi"]], mode="clip")      # (codes are in range; "raise" buffers out)
+                    np.take(lut + np.int32(G), b["group_codes"][b["n_roi"]:], out=g[b["n_roi"]:], mode="clip")
+                    tile_done = True
+                else:
+                    g = lut[b["group_codes"]]
             elif run_tile:
                 g = None    # (no per-window array at all: tile 0 for the ROI windows, G for the controls — engine.RunTile)
             else:
@@ -1862,6 +1872,8 @@ class PileUpper:
             if run_tile:
                 from .engine import RunTile
                 tile = RunTile(b["n_roi"], b["n"], 0, G)
+            elif tile_done:
+                tile = g
             elif "n_roi" in b:         # ROI windows first, then the controls: tile = group, + G from there on
                 tile = g if g.flags.writeable and g.base is None else g.copy()
                 tile[b["n_roi"]:] += np.int32(G)

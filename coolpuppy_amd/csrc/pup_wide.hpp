@@ -117,14 +117,18 @@ inline bool launch_wide(int shape, const K1Args& a, const WideArgs& wa, int G, b
     }
 }
 
+#ifndef PUP_WIDE_NW
+#define PUP_WIDE_NW 16
+#endif
+constexpr int kWideWaves = PUP_WIDE_NW;               // waves of K1w's workgroup (experiments: 8 — twice the registers per wave)
 template <int CH, int NCH, bool OOE, bool FACT>
-__global__ __launch_bounds__(kWave * 16, 1)
+__global__ __launch_bounds__(kWave * kWideWaves, 1)
 void pileup_wide_kernel(K1Args a, WideArgs wa) {
     static_assert(CH >= 1 && CH <= kWideMaxCH, "cells per lane");
     static_assert(NCH >= 1 && NCH <= 8 && NCH * (CH - 1) < 64, "column chunks per row; a lane's validity bits fit one 64-bit word");
     // row stride LS = RSC + NCH doubles: slot s reads double p * LS + k + NCH * i = s + NCH * i (mod 32 bank pairs) — the 32 lanes of
     // a half wave hit 32 different bank pairs
-    constexpr int RSR = 128, RSC = 128, NW = 16, LS = RSC + NCH, RPW = RSR / NW, NH = 2, NRH = RPW * NH, VBW = 3, NTHR = kWave * NW;
+    constexpr int RSR = 128, RSC = 128, NW = kWideWaves, LS = RSC + NCH, RPW = RSR / NW, NH = 2, NRH = RPW * NH, VBW = 3, NTHR = kWave * NW;
     static_assert((size_t)(NW / 2) * CH * kWave * 12 <= (size_t)RSR * LS * 8, "merge scratch must fit the region buffer");
     __shared__ double tile[RSR * LS + 16];                          // (+16: the last panel's unowned cells may run past the last row)
     __shared__ unsigned long long vbits[FACT ? 1 : RSR * VBW + 2];  // bit c of row r: cell (r, c) counts in num (+2: the four-dword read of the last row)

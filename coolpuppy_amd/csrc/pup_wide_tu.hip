@@ -15,7 +15,7 @@ namespace pup {
 #define PUP_PASTE(a, b) PUP_PASTE_(a, b)
 bool PUP_PASTE(launch_wide_part, PUP_TU_PART)(const K1Args& a, const WideArgs& wa, int G, bool ooe, bool fact, hipStream_t s) {
     constexpr int CH = wide_shape_ch(PUP_TU_PART), NCH = wide_shape_nch(PUP_TU_PART);
-    const dim3 grid((unsigned)G), block(kWave * 16);
+    const dim3 grid((unsigned)G), block(kWave * kWideWaves);
     if (ooe) {
         if (fact) hipLaunchKernelGGL((pileup_wide_kernel<CH, NCH, true, true>), grid, block, 0, s, a, wa);
         else      hipLaunchKernelGGL((pileup_wide_kernel<CH, NCH, true, false>), grid, block, 0, s, a, wa);
