@@ -129,6 +129,9 @@ template <int W, bool OOE, bool EXTRA, bool SMALL = false, bool FACT = true> str
 // inside its slice of windows — stores its rows of block b + 1 into the other (their counts were requested a block earlier) and
 // requests those of block b + 2: the store burst is hidden behind the other waves' LDS reads and ONE barrier per block is left
 // (with one buffer: barrier, store burst, barrier — 14 + 10 + 5 % of the kernel by the phase clocks of round 3).
+#ifndef PUP_K1Q_DUAL
+#define PUP_K1Q_DUAL 0
+#endif
 template <int W, bool OOE, int RSR, int RSC, int NW, int ACC, bool FACT, bool EXTRA, bool BAND = false, bool DB = false>
 __global__ __launch_bounds__(kWave * NW, 1)
 void pileup_staged_kernel(K1Args a, StagedArgs sa) {
@@ -142,6 +145,10 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     constexpr int NCH = kWave / W;
     constexpr int CH  = (W + NCH - 1) / NCH;
     constexpr int W2  = W * W;
+    // DUAL (experiment, -DPUP_K1Q_DUAL=1): a tile PAIR with BOTH register tiles in every wave — no teams: every wave takes its share of
+    // ALL the block's windows (the pair's first tile holds a tenth of them: two waves for it are 12.5 % of the workgroup for 9 % of
+    // the windows, the fourteen others carry 6.5 % each instead of 6.25)
+    constexpr bool DUAL = PUP_K1Q_DUAL && ACC == 2 && FACT && !EXTRA && !OOE && BAND && NW == 16 && !DB;
     constexpr int NH  = RSC / 64;                        // 64-column halves of a region row
     constexpr int LS  = RSC + ((NCH % 32) ? (NCH % 32) : 32);   // row stride in doubles, LS % 32 == NCH % 32 (see above)
     constexpr int RPW = RSR / NW;                        // region rows staged by each wave
@@ -214,6 +221,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
             team_w[0] = __builtin_amdgcn_readfirstlane(t.x); team_w[1] = __builtin_amdgcn_readfirstlane(t.y);
             team_w[2] = __builtin_amdgcn_readfirstlane(t.z); team_w[3] = __builtin_amdgcn_readfirstlane(t.w);
             my_slot = 0;
+            if constexpr (DUAL) { team_lo = 0; team_n = NW; set_shares(); return; }    // (the table still says which tiles have windows: flush)
 #pragma unroll
             for (int s = 1; s < ACC; ++s) my_slot += wave >= team_at(s) ? 1 : 0;     // (teams are contiguous, empty ones have equal ends)
             team_lo = team_at(my_slot); team_n = team_at(my_slot + 1) - team_lo;
@@ -222,6 +230,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     };
     double   sum[CH];
     unsigned num[CH];
+    double   sum1[DUAL ? CH : 1];                        // DUAL: the pair's second tile (slot 1); `sum` is its first
     // the SIMD favours its oldest wave; left alone the youngest of the four finishes its (equal) share of a block's windows
     // 40 % later than the oldest and everybody waits for it at the barrier (phase clocks, round 3): priorities against age
     // (uniform) 0 = the oldest wave of its SIMD.  The priorities are swapped half way through every block's windows (see
@@ -234,6 +243,10 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < CH; ++i) { sum[i] = 0.0; num[i] = 0u; }
+        if constexpr (DUAL) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) sum1[i] = 0.0;
+        }
         if (m_cov) for (int t = lane; t < 2 * W; t += kWave) cov_lds[wave][t] = 0.0;
         if constexpr (FACT) {                            // visible after the next barrier
             for (int t = tid; t < ACC * W2; t += NTHR) (&rc_lds[0][0])[t] = 0u;
@@ -552,7 +565,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     // of a pair come first in a block (stable sort), so at most one wave sees both slots.  (Round 2 dealt windows out
     // round robin from batches every wave held; with one workgroup per CU the per-batch fetch then stalled the whole CU,
     // and the factorised-count bookkeeping of a batch fell on one wave.)
-    struct Cur { int R, C, start, first, n; unsigned long long rowbad[2], colbad[2]; };   // first, n: the windows of this wave's slot
+    struct Cur { int R, C, start, first, n, split; unsigned long long rowbad[2], colbad[2]; };   // first, n: the windows of this wave's slot; split (DUAL): the block's first slot-1 window
     unsigned lane_off8 = (unsigned)(uintptr_t)tile + 8u * (unsigned)(p * LS + k);   // LDS byte address of the lane's first cell (DB: in the buffer being read)
     const unsigned vb_base = (unsigned)(uintptr_t)vbits;
     // window `at + lane` of the block, for the lanes below `end`
@@ -560,7 +573,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
         return at + lane < end ? (int)sa.win[start + at + lane] : 0;
     };
     // windows jb <= j < je of the wave's current batch (window j sits in lane j), all of accumulator slot S
-    auto run = [&](const Cur& g, int offv, int drv, int dcv, int jb, int je) __attribute__((always_inline)) {
+    auto run = [&](double (&acc)[CH], const Cur& g, int offv, int drv, int dcv, int jb, int je) __attribute__((always_inline)) {
         auto gather = [&](int jj, double (&v)[CH], unsigned long long& vraw, unsigned& ad0, unsigned& ad1) __attribute__((always_inline)) {
             // single ds_read_b64 each (see lds_read_b64); cells the lane does not own read padding, never flushed
             ad0 = lane_off8 + (unsigned)__builtin_amdgcn_readlane(offv, jj);
@@ -597,7 +610,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
         };
         auto add = [&](const double (&v)[CH], unsigned vw) __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < CH; ++i) { sum[i] += v[i]; if (!FACT) num[i] += (vw >> (NCH * i)) & 1u; }
+            for (int i = 0; i < CH; ++i) { acc[i] += v[i]; if (!FACT) num[i] += (vw >> (NCH * i)) & 1u; }
         };
         constexpr int NB = CH + (FACT ? 0 : 1);            // LDS operations of one window's gather
         if constexpr (!EXTRA && NB <= 15) {
@@ -660,14 +673,18 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     // reaches it): valid = !rowbad[p] & !colbad[q], so over the segment num[p][q] = N - R[p] - C[q] + RC[p][q].
     // fact_tot[slot] = {R[W], C[W], N}; rc_lds[slot] = RC (masked row meets masked column: rare).  Integer LDS atomics:
     // exact and order-independent.
-    auto fact_batch = [&](const Cur& g, int drv, int dcv, int nb) __attribute__((always_inline)) {
+    auto fact_batch = [&](const Cur& g, int drv, int dcv, int nb, int js = 0) __attribute__((always_inline)) {
       if constexpr (FACT) {
         constexpr unsigned WMASK = (1u << W) - 1u;
-        const int tb = my_slot * (2 * W + 1);
-        if (lane == 0) atomicAdd(&fact_tot[tb + 2 * W], (unsigned)nb);
+        // (DUAL: the batch's windows [0, js) belong to slot 0, the others to slot 1)
+        const int slot = DUAL ? (lane >= js ? 1 : 0) : my_slot;
+        const int tb = slot * (2 * W + 1);
+        if constexpr (DUAL) {
+            if (lane == 0 && js > 0) atomicAdd(&fact_tot[2 * W], (unsigned)js);
+            if (lane == 0 && nb > js) atomicAdd(&fact_tot[(2 * W + 1) + 2 * W], (unsigned)(nb - js));
+        } else if (lane == 0) atomicAdd(&fact_tot[tb + 2 * W], (unsigned)nb);
         if ((g.rowbad[0] | g.rowbad[1] | g.colbad[0] | g.colbad[1]) == 0ull) return;     // (uniform) no masked bin in the region
         const bool live = lane < nb;
-        const int slot = my_slot;
         unsigned rb = live ? mask_at(g.rowbad, drv) & WMASK : 0u;
         const unsigned cbm = live ? mask_at(g.colbad, dcv) & WMASK : 0u;
         unsigned cc = cbm;
@@ -684,6 +701,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     // slot-0 / slot-1 part of it); wf = its first batch, one window per lane, each as its corner inside the region (the
     // value the block sort carried)
     auto slot_range = [&](int ev, int& first, int& n) __attribute__((always_inline)) {
+        if constexpr (DUAL) { first = 0; n = fld(ev, 3); return; }
         first = (ACC > 1 && my_slot > 0) ? fld(ev, 22 + my_slot) : 0;
         n = ((ACC > 1 && my_slot < ACC - 1) ? fld(ev, 23 + my_slot) : fld(ev, 3)) - first;
     };
@@ -697,6 +715,13 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     // LDS): every wave does it once, INSIDE its first batch, after 0, 1/6, 2/6 or 3/6 of the batch's windows by its number
     // — so that of the four waves of a SIMD one at a time is busy with it while the others keep the LDS reading.  (All
     // sixteen doing it back to back before the window loop, as in round 2, cost 28 % of the kernel: phase clocks.)
+    // windows [jb, je) of a batch whose first js windows belong to slot 0 (DUAL; else everything goes to the wave's one tile)
+    auto run2 = [&](const Cur& g, int offv, int drv, int dcv, int jb, int je, int js) __attribute__((always_inline)) {
+        if constexpr (DUAL) {
+            run(sum, g, offv, drv, dcv, jb, je < js ? je : js);
+            run(sum1, g, offv, drv, dcv, jb > js ? jb : js, je);
+        } else run(sum, g, offv, drv, dcv, jb, je);
+    };
     auto windows = [&](const Cur& g, int wf, auto&& mid) __attribute__((always_inline)) {
         int lo, hi;
         slice_of(g.first, g.n, lo, hi);
@@ -706,24 +731,26 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
             const int offv = 8 * (drv * LS + dcv);
             if (lo + kWave < hi) wf = load_batch(g.start, lo + kWave, hi);
             const int nb = (hi - lo) < kWave ? (hi - lo) : kWave;
-            fact_batch(g, drv, dcv, nb);
+            int js = g.split - lo; js = js < 0 ? 0 : (js > nb ? nb : js);
+            fact_batch(g, drv, dcv, nb, js);
             // (measured: without the split and the priority flip the kernel is 5 % slower — tools/k1_probe.py history in DESIGN §4)
             const int cut = (nb * (wave & 3) * 43) >> 8;                           // ~ nb * (wave & 3) / 6
             const int half = nb >> 1;
             set_prio(age);
-            run(g, offv, drv, dcv, 0, cut);
+            run2(g, offv, drv, dcv, 0, cut, js);
             mid();
-            run(g, offv, drv, dcv, cut, cut > half ? cut : half);
+            run2(g, offv, drv, dcv, cut, cut > half ? cut : half, js);
             set_prio(3 - age);
-            run(g, offv, drv, dcv, cut > half ? cut : half, nb);
+            run2(g, offv, drv, dcv, cut > half ? cut : half, nb, js);
         }
         for (int s0 = lo + kWave; s0 < hi; s0 += kWave) {
             const int drv = wf & ((1 << kWinShift) - 1), dcv = (wf >> kWinShift) & ((1 << kWinShift) - 1);
             const int offv = 8 * (drv * LS + dcv);
             if (s0 + kWave < hi) wf = load_batch(g.start, s0 + kWave, hi);         // next batch of a long slice
             const int nb = (hi - s0) < kWave ? (hi - s0) : kWave;
-            fact_batch(g, drv, dcv, nb);
-            run(g, offv, drv, dcv, 0, nb);
+            int js = g.split - s0; js = js < 0 ? 0 : (js > nb ? nb : js);
+            fact_batch(g, drv, dcv, nb, js);
+            run2(g, offv, drv, dcv, 0, nb, js);
         }
     };
     auto first_coords = [&](int ev, int& wf) __attribute__((always_inline)) {
@@ -735,6 +762,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     auto cur_of = [&](int ev) __attribute__((always_inline)) -> Cur {
         Cur c;
         c.R = fld(ev, 0); c.C = fld(ev, 1); c.start = fld(ev, 2); slot_range(ev, c.first, c.n);
+        c.split = DUAL ? fld(ev, 4) : 0;
         c.rowbad[0] = fld64(ev, 16); c.rowbad[1] = fld64(ev, 18);
         c.colbad[0] = ~fld64(ev, 12); c.colbad[1] = ~fld64(ev, 14);     // (also set past the chromosome's end: no eligible window reaches there)
         return c;
@@ -751,41 +779,44 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
         __syncthreads();
         // every team merges its waves' tiles into its first wave: binary tree over the position inside the team (both teams
         // at once: their scratch slots are disjoint — the absolute wave number picks the slot)
-        const int r = wave - team_lo;
-        for (int step = 1; step < NW; step <<= 1) {
-            const int slot_w = wave >> 1;
-            if ((r & (2 * step - 1)) == step) {
+        auto merge = [&](double (&acc)[CH]) __attribute__((always_inline)) {
+            const int r = wave - team_lo;
+            for (int step = 1; step < NW; step <<= 1) {
+                const int slot_w = wave >> 1;
+                if ((r & (2 * step - 1)) == step) {
 #pragma unroll
-                for (int i = 0; i < CH; ++i) {
-                    mf[(slot_w * CH + i) * kWave + lane] = sum[i];
-                    if (!FACT) mn[(slot_w * CH + i) * kWave + lane] = num[i];
+                    for (int i = 0; i < CH; ++i) {
+                        mf[(slot_w * CH + i) * kWave + lane] = acc[i];
+                        if (!FACT) mn[(slot_w * CH + i) * kWave + lane] = num[i];
+                    }
                 }
-            }
-            __syncthreads();
-            if ((r & (2 * step - 1)) == 0 && r + step < team_n) {
-                const int from = (wave + step) >> 1;
+                __syncthreads();
+                if ((r & (2 * step - 1)) == 0 && r + step < team_n) {
+                    const int from = (wave + step) >> 1;
 #pragma unroll
-                for (int i = 0; i < CH; ++i) {
-                    sum[i] += mf[(from * CH + i) * kWave + lane];
-                    if (!FACT) num[i] += mn[(from * CH + i) * kWave + lane];
+                    for (int i = 0; i < CH; ++i) {
+                        acc[i] += mf[(from * CH + i) * kWave + lane];
+                        if (!FACT) num[i] += mn[(from * CH + i) * kWave + lane];
+                    }
                 }
+                __syncthreads();
             }
-            __syncthreads();
-        }
-#pragma unroll
-        for (int s = 0; s < ACC; ++s) {
+        };
+        merge(sum);
+        if constexpr (DUAL) merge(sum1);                 // (one team of sixteen: wave 0 ends up with both tiles)
+        auto write_rec = [&](int s, const double (&acc)[CH]) __attribute__((always_inline)) {
             const int tl = staged_tile<ACC>(unit, s, sa.PH);
             const int lead = ACC > 1 ? team_at(s) : 0, w_hi = ACC > 1 ? team_at(s + 1) : NW;   // the team's first wave holds its merged tile
-            if (tl < 0 || lead >= w_hi) continue;                         // (uniform) no such tile / none of its windows in this call
+            if (tl < 0 || lead >= w_hi) return;                           // (uniform) no such tile / none of its windows in this call
             const size_t rec = (size_t)s * (size_t)(2 * sa.T + G) + (size_t)tl * 2 + (size_t)fl + (size_t)g_id;
             double*   of = a.part_f64 + rec * L;
             unsigned* on = a.part_num + rec * W2;
-            if (wave == lead) {
+            if (wave == (DUAL ? 0 : lead)) {
 #pragma unroll
                 for (int i = 0; i < CH; ++i)
                     if ((chmask >> i) & 1u) {
                         const int cell = map_cell(p, k + NCH * i, W, false, fl);
-                        of[cell] = sum[i];
+                        of[cell] = acc[i];
                         if (!FACT) on[cell] = num[i];
                     }
             }
@@ -798,11 +829,16 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
                 }
             }
             for (int t = tid; t < 2 * W; t += NTHR) {
-                double acc = 0.0;
-                if (m_cov) for (int w = lead; w < w_hi; ++w) acc += cov_lds[w][t];
-                of[W2 + t] = acc;
+                double cacc = 0.0;
+                if (m_cov) for (int w = lead; w < w_hi; ++w) cacc += cov_lds[w][t];
+                of[W2 + t] = cacc;
             }
             if (tid == 0) sa.rec_owner[rec] = (unsigned short)(tl * 2 + fl + 1);
+        };
+        if constexpr (DUAL) { write_rec(0, sum); write_rec(1, sum1); }
+        else {
+#pragma unroll
+            for (int s = 0; s < ACC; ++s) write_rec(s, sum);
         }
         __syncthreads();                                 // fact_tot / rc_lds / cov_lds have been read
         zero_acc();
