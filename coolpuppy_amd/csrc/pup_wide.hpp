@@ -214,6 +214,7 @@ void pileup_wide_kernel(K1Args a, WideArgs wa) {
         if (er >= 0 && er < a.n_exp_regions) { const ExpRegion g = a.exp_regions[er]; es.base = a.expv + g.off; es.len = g.len; }
         return es;
     };
+    auto exp_entry = [&](double e) __attribute__((always_inline)) -> double { return FACT ? 1.0 / e : e; };     // (the reciprocal: see K1q)
     auto exp_fetch = [&](int ev) __attribute__((always_inline)) -> double {
         if (!use_exp || tid >= RSR + RSC - 1) return qnan;
         const ExpSel es = exp_of(ev);
@@ -305,7 +306,7 @@ void pileup_wide_kernel(K1Args a, WideArgs wa) {
                 if (nf) val = (val == val) ? val : 0.0;
                 if (OOE) {
                     const double e = exp_lds[colx - rr + (RSR - 1)];      // expected of |col - row|
-                    val = val / e;
+                    val = FACT ? val * e : val / e;         // (FACT: the entry is the reciprocal — exp_entry)
                     val = (val == val) ? val : 0.0;         // NaN quotients are skipped, inf is kept
                     if constexpr (!FACT) {
                         int e_ok = (e == e && e != 0.0) ? 1 : 0;     // (through a register the compiler cannot fold: see K1q's store_region)
@@ -512,7 +513,7 @@ void pileup_wide_kernel(K1Args a, WideArgs wa) {
         band_issue(ev0, v, wc, wrv);
         first_coords(ev0, w0f);
         if (bb + 1 < be) ev1 = entry_load(bb + 1);
-        if constexpr (OOE) { if (tid < 256) exp_lds[tid] = exp_fetch(ev0); }
+        if constexpr (OOE) { if (tid < 256) exp_lds[tid] = exp_entry(exp_fetch(ev0)); }
         __syncthreads();
         band_store(ev0, v, wc, wrv);
         __syncthreads();
@@ -534,7 +535,7 @@ void pileup_wide_kernel(K1Args a, WideArgs wa) {
         const Cur c0 = cur_of(ev0);
         const long long t1 = tick();
         windows(c0, w0f, b & 3, lookahead);
-        if constexpr (OOE) { if (has1 && tid < 256) exp_lds[tid] = e_next; }     // (last read when region b was stored; visible after the barrier below)
+        if constexpr (OOE) { if (has1 && tid < 256) exp_lds[tid] = exp_entry(e_next); }     // (last read when region b was stored; visible after the barrier below)
         const long long t2 = tick();
         const int seg0 = fld(ev0, 20), grp0 = fld(ev0, 30);
         if (!has1) { flush(seg0); break; }
