@@ -1282,7 +1282,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
         pup::StagedArgs sa{};
         sa.blocks = c->d_blocks.p; sa.win = c->d_win2.p; sa.wg_first = c->d_wgfirst.p; sa.U = U; sa.PH = H; sa.rec_owner = d_recvalid; sa.T = T;
         sa.teams = ACC > 1 ? c->d_teams.p + (fact ? 0 : (size_t)U * 16) : nullptr;      // (StagedGeom: 16 waves only with factorised counts)
-        sa.debug = c->debug_phases & 0x3;
+        sa.debug = c->debug_phases & 0xb;
         staged_wave_weights(sa.wgt);
         sa.timing = nullptr;
         if (c->debug_phases & 4) {                       // phase clocks (diagnostics): [G][16][8] long long, read by pup_debug_timing
@@ -2530,7 +2530,7 @@ int pup_set_tuning(pup_ctx* c, int32_t chunk_snippets, int32_t variant) {
     c->forget_hints();
     c->variant = (variant & 0xff) | ((variant >> 19) & 0x700);   // bit 27 -> 256: never stage from the dense band; bit 28 -> 512: tile pairs one by one; bit 29 -> 1024: library sort in the prepass
     c->group_waves = (variant >> 8) & 0xffff;
-    c->debug_phases = (variant >> 24) & 0x7;
+    c->debug_phases = ((variant >> 24) & 0x7) | ((variant >> 27) & 0x8);     // (bit 30 -> 8: K1q without its factorised-count bookkeeping, timing only)
     return PUP_OK;
 }
 

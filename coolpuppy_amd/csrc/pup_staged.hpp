@@ -70,7 +70,7 @@ struct StagedArgs {
     int                   T;          // tiles of the call
     const unsigned char*  teams;      // [U][16]: waves [teams[u][s], teams[u][s+1]) pile up the slot-s windows of unit u's blocks —
                                       // teams sized by the host in proportion to the tiles' window counts (none for an empty tile)
-    int                   debug;      // timing experiments only (results are wrong): 1 = skip the window loop, 2 = skip the staging
+    int                   debug;      // timing experiments only (results are wrong): 1 = skip the window loop, 2 = skip the staging, 8 = skip the factorised-count bookkeeping
     unsigned short        wgt[16];    // sixteen-wave kernels: wave w's share of its team's windows, in 1/1024 of an average wave's (see wave_weight)
     long long*            timing;     // phase clocks per wave, [G][NW][8] (tools/k1_probe.py --phases), or nullptr
 };
@@ -681,6 +681,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     // exact and order-independent.
     auto fact_batch = [&](const Cur& g, int drv, int dcv, int nb, int js = 0) __attribute__((always_inline)) {
       if constexpr (FACT) {
+        if (sa.debug & 8) return;                        // (timing experiments: what the bookkeeping costs; the counts are wrong then)
         constexpr unsigned WMASK = (1u << W) - 1u;
         // (DUAL: the batch's windows [0, js) belong to slot 0, the others to slot 1)
         const int slot = DUAL ? (lane >= js ? 1 : 0) : my_slot;
