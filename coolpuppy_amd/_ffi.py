@@ -101,6 +101,8 @@ _SIGNATURES = {
                                              C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pup_host_mt_randint": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                       C.c_void_p, C.c_int32]),
+    "pup_host_lut_i32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
+    "pup_host_count_le": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "pup_host_normalise_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "pup_host_mt_randint_plan": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int32] + [C.c_void_p] * 7),
     "pup_host_factorize_ptr": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]),

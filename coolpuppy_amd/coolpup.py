@@ -1515,7 +1515,7 @@ class PileUpper:
                     edges = kw.get("band_edges", "default")
                     if isinstance(edges, str) and edges == "default":
                         edges = _default_band_edges()
-                    keycols.append(np.searchsorted(edges, CC._col("distance")[rows], side="right"))
+                    keycols.append(_engine.count_le(edges, CC._col("distance")[rows]))
                     decs.append(lambda i, e=edges: tuple(e[i - 1:i + 1]))
                     continue
                 name, dec = self._group_source(g)
@@ -1529,7 +1529,7 @@ class PileUpper:
         lo1, hi1, off1 = self._global_extents[region1]
         lo2, hi2, off2 = self._global_extents[region2]
         r0, c0, code_out, n_roi = _engine.host_windows(st1, st2, codes, shift, sign, nshifts, self.resolution, off1, off2,
-                                                       lo1, hi1, lo2, hi2, W, W)
+                                                       lo1, hi1, lo2, hi2, W, W, arena=getattr(self, "_arena_ok", False))
         m = len(r0)
         kind = np.empty(m, np.int8)
         kind[:n_roi] = KIND_ROI
@@ -1737,6 +1737,15 @@ class PileUpper:
         return plan
 
     def _region_batches(self, pairs, owned, groupby, modify, columns, _by_window):
+        from . import engine as _engine
+        _engine._ARENA.reset()             # (the regions' window arrays of THIS pile-up: scratch kept between pile-ups)
+        self._arena_ok = True
+        try:
+            return self._region_batches_impl(pairs, owned, groupby, modify, columns, _by_window)
+        finally:
+            self._arena_ok = False
+
+    def _region_batches_impl(self, pairs, owned, groupby, modify, columns, _by_window):
         batches = []
         for i, (region1, region2) in enumerate(pairs):
             if owned is not None and i not in owned:
@@ -1844,9 +1853,8 @@ class PileUpper:
                 if "n_roi" in b and not exp_as_control and len(lut):
                     # ROI windows first, then the controls: tile = group, + G from there on — two gathers straight into the tile
                     # array (a gather and an in-place add over the same 10^7 entries were 23 ms of a 1e6-pair call)
-                    g = np.empty(b["n"], np.int32)
-                    np.take(lut, b["group_codes"][:b["n_roi"]], out=g[:b["n_roi"]], mode="clip")      # (codes are in range; "raise" buffers out)
-                    np.take(lut + np.int32(G), b["group_codes"][b["n_roi"]:], out=g[b["n_roi"]:], mode="clip")
+                    from .engine import lut_codes
+                    g = lut_codes(lut, b["group_codes"], add_from=b["n_roi"], add=G)
                     tile_done = True
                 else:
                     g = lut[b["group_codes"]]

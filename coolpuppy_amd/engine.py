@@ -6,6 +6,8 @@ inner part of ``PileUpper.pileup_region`` — ``get_data`` + ``_stream_snips`` +
 (reference coolpuppy/coolpup.py:1024-1057, 1059-1191, 1236-1283).
 """
 import ctypes as C
+import sys
+import threading
 import os
 import weakref
 
@@ -482,7 +484,35 @@ def pinned_empty(n, dtype=np.int32):
     return np.asarray(_PinnedBlock(ptr, size, nbytes)).view(dtype)[:int(n)]
 
 
-def host_windows(st1, st2, code, shift, sign, nshifts, resolution, off1, off2, lo1, hi1, lo2, hi2, h, w):
+class _WindowArena(threading.local):
+    """Per-thread scratch for the per-region window arrays of ONE pile-up (r0 / c0 / group codes of every region, alive until the plan
+    has gathered them): carved out of one buffer that is kept between pile-ups — three fresh arrays per region were 130 MB of new pages
+    (and their faults, inside the window pass) per 10^7 windows.  reset() at the start of a pile-up reuses the buffer only when no array
+    of an earlier pile-up is still alive."""
+
+    def __init__(self):
+        self.buf, self.at = np.empty(0, np.int32), 0
+
+    def reset(self):
+        # (every array handed out is a view whose .base is the buffer: while any of them is alive the buffer is left to them and a new
+        # one of the same size takes over — an earlier plan's windows are never overwritten under its feet)
+        if sys.getrefcount(self.buf) > 2:
+            self.buf = np.empty(self.buf.shape[0], np.int32)
+        self.at = 0
+
+    def take(self, n):
+        n = int(n)
+        if self.at + n > self.buf.shape[0]:
+            self.buf, self.at = np.empty(max(2 * self.buf.shape[0], self.at + n, 1 << 20), np.int32), 0
+        out = self.buf[self.at:self.at + n]
+        self.at += n
+        return out
+
+
+_ARENA = _WindowArena()
+
+
+def host_windows(st1, st2, code, shift, sign, nshifts, resolution, off1, off2, lo1, hi1, lo2, hi2, h, w, arena=False):
     """pup_host_windows: ROI windows + shifted control copies of one region, bounds-tested, as (r0, c0, code, n_roi_kept).  st1 / st2 / code: int32 per ROI row (code may be None); shift / sign: int32, n*nshifts each."""
     st1, st2 = _as(st1, np.int32), _as(st2, np.int32)
     n = st1.shape[0]
@@ -494,8 +524,9 @@ def host_windows(st1, st2, code, shift, sign, nshifts, resolution, off1, off2, l
         raise ValueError("control shifts beyond +-2^31 bp do not fit the int32 shifts of pup_host_windows")
     shift = None if shift is None else _as(shift, np.int32)
     sign = None if sign is None else _as(sign, np.int32)
-    r0, c0 = np.empty(cap, np.int32), np.empty(cap, np.int32)      # per-region intermediates: group_tiles makes the DMA source
-    code_out = np.empty(cap, np.int32) if code is not None else None
+    alloc = _ARENA.take if arena else (lambda m: np.empty(m, np.int32))
+    r0, c0 = alloc(cap), alloc(cap)                                 # per-region intermediates: group_tiles makes the DMA source
+    code_out = alloc(cap) if code is not None else None
     n_roi = C.c_int64(0)
     kept = _ffi.lib().pup_host_windows(_ptr(st1), _ptr(st2), _ptr(code), n, _ptr(shift), _ptr(sign), int(nshifts),
                                        float(resolution), int(off1), int(off2), int(lo1), int(hi1), int(lo2), int(hi2),
@@ -557,6 +588,33 @@ def legacy_randint(low, high, m, scale=1, offset=0, discard=False, dtype=np.int6
     return out
 
 
+def lut_codes(lut, codes, add_from=None, add=0):
+    """lut[codes] (+ add from entry add_from on) as int32, by the library's multi-threaded pass for long arrays (pup_host_lut_i32)."""
+    lut = _as(lut, np.int32)
+    n = len(codes)
+    add_from = n if add_from is None else int(add_from)
+    if n >= 200_000 and isinstance(codes, np.ndarray) and codes.dtype == np.int32 and codes.flags.c_contiguous and len(lut):
+        out = np.empty(n, np.int32)
+        if _ffi.lib().pup_host_lut_i32(_ptr(lut), len(lut), _ptr(codes), n, add_from, int(add), _ptr(out)) == 0:
+            return out
+    out = lut[codes]
+    if add and add_from < n:
+        out[add_from:] += np.int32(add)
+    return out
+
+
+def count_le(edges, values):
+    """np.searchsorted(edges, values, side="right") for a short sorted edge list and float64 values, by the library for long arrays."""
+    values = np.asarray(values)
+    e = np.asarray(edges, np.float64)
+    if len(values) >= 10_000 and values.dtype == np.float64 and values.flags.c_contiguous and 0 < len(e) <= 64 \
+            and np.array_equal(e, np.asarray(edges)) and not np.isnan(e).any():
+        out = np.empty(len(values), np.int32)
+        if _ffi.lib().pup_host_count_le(_ptr(e), len(e), _ptr(values), len(values), _ptr(out)) == 0:
+            return out
+    return np.searchsorted(edges, values, side="right")
+
+
 def legacy_randint_plan(calls):
     """A sequence of legacy_randint calls as ONE library job (pup_host_mt_randint_plan): `calls` = [(low, high, m, scale, offset,
     out)], out a contiguous int32 / int64 array of m entries or None (draw and discard).  Same numbers, same generator state
@@ -608,6 +666,8 @@ def factorize_objects(a):
         return pd.factorize(a)
     reps = a[first[:nu]]
     rcodes, uniq = pd.factorize(reps)                           # distinct objects that are equal strings share a code; missing: -1
+    if len(rcodes) == len(uniq) and np.array_equal(rcodes, np.arange(len(uniq))):
+        return codes32.astype(np.int64), uniq                   # (every distinct object its own value: the numbering stands as it is)
     return rcodes.astype(np.int64)[codes32], uniq
 
 

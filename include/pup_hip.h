@@ -33,6 +33,8 @@
  *   pup_fetch / pup_export / pup_import
  *                                     <- sum_pups cross-region merge   coolpuppy/lib/puputils.py:88-113
  *                                        and the reduce at             coolpuppy/coolpup.py:1511-1531
+ *   pup_host_lut_i32 / _count_le      <- group -> tile numbers and distance bands of a grouped pile-up's windows
+ *                                                                      coolpuppy/coolpup.py:28-51, 1757-1919
  *   pup_host_normalise_tiles          <- the ratio to the control and the inf -> NaN step of pileupsWithControl
  *                                                                      coolpuppy/coolpup.py:1533-1545
  *   pup_host_mt_randint / _plan       <- np.random.randint / np.random.choice draws of CoordCreator._control_regions
@@ -396,6 +398,16 @@ int64_t pup_host_control_windows(const int32_t* st1, const int32_t* st2, const i
  */
 int pup_host_mt_randint(uint32_t* key, int32_t* pos, int64_t low, int64_t high, int64_t m, int64_t scale, int64_t offset,
                         void* out, int32_t out_bytes);
+
+/*
+ * pup_host_lut_i32 / pup_host_count_le: two array passes of a GROUPED pile-up's plan (by distance band, strand, ...: coolpuppy/coolpup.py:
+ * 28-51, 1757-1919) on several threads.  pup_host_lut_i32: out[i] = lut[codes[i]] (+ add for i >= add_from) — the tile numbers of a region's
+ * windows from their group codes, the controls' half offset by the number of groups; PUP_ERANGE for a code outside [0, n_lut).
+ * pup_host_count_le: out[i] = number of edges <= values[i] = np.searchsorted(edges, values, side="right") for up to 64 sorted edges (the
+ * distance band of a pair).
+ */
+int pup_host_lut_i32(const int32_t* lut, int64_t n_lut, const int32_t* codes, int64_t n, int64_t add_from, int32_t add, int32_t* out);
+int pup_host_count_le(const double* edges, int32_t n_edges, const double* values, int64_t n, int32_t* out);
 
 /*
  * pup_host_normalise_tiles: the finaliser's arithmetic (coolpuppy/coolpup.py:1533-1545: data / num, the ratio to the control's

@@ -390,6 +390,51 @@ def test_library_tile_normalisation_equals_numpy():
         assert np.array_equal(np.signbit(want[fin]), np.signbit(got[fin]))
 
 
+def test_library_lut_and_band_passes_equal_numpy():
+    """pup_host_lut_i32 (tile numbers from group codes, the controls' half offset) and pup_host_count_le (distance bands =
+    searchsorted(edges, d, "right")) against numpy, values on and beside the edges included; short inputs take numpy itself."""
+    from coolpuppy_amd import engine as E
+    from coolpuppy_amd.coolpup import _default_band_edges
+    rng = np.random.default_rng(0)
+    lut = rng.integers(0, 40, 25).astype(np.int32)
+    for n, cut in ((500_000, 123_456), (500_000, 0), (500_000, 500_000), (1000, 500)):
+        codes = rng.integers(0, 25, n).astype(np.int32)
+        want = lut[codes].copy()
+        want[cut:] += 7
+        got = E.lut_codes(lut, codes, cut, 7)
+        assert got.dtype == np.int32 and np.array_equal(got, want)
+    edges = _default_band_edges()
+    for n in (400_000, 1000):
+        d = rng.integers(0, 6_000_000, n) + 0.5
+        d[:10] = edges[:10]
+        d[10:20] = edges[:10] - 0.5
+        assert np.array_equal(E.count_le(edges, d), np.searchsorted(edges, d, side="right"))
+    assert np.array_equal(E.count_le([10, 20, 30], np.full(200_000, 20.0)), np.full(200_000, 2))
+
+
+def test_window_arena_never_reuses_memory_somebody_still_holds():
+    """engine._ARENA (scratch for the per-region window arrays of a grouped pile-up, kept between pile-ups): reset() reuses the buffer
+    only when no array handed out earlier — or a view of one — is still alive."""
+    from coolpuppy_amd import engine as E
+    a = E._ARENA
+    a.reset()
+    x = a.take(10)
+    x[:] = 7
+    first = id(a.buf)
+    a.reset()                                  # x is alive: the buffer is left to it
+    assert id(a.buf) != first and (x == 7).all()
+    del x
+    second = id(a.buf)
+    a.reset()                                  # nobody holds anything: reused
+    assert id(a.buf) == second
+    y = a.take(5)
+    z = y[:2]
+    del y
+    a.reset()                                  # a view of a view still pins it
+    assert id(a.buf) != second
+    del z
+
+
 def test_library_argsort_equals_numpy_stable_argsort():
     from coolpuppy_amd import engine as E
     rng = np.random.default_rng(5)
