@@ -93,6 +93,20 @@ __device__ __forceinline__ void lds_read2_b32_23(unsigned long long& dst, unsign
     asm volatile("ds_read2_b32 %0, %1 offset0:2 offset1:3" : "=&v"(dst) : "v"(addr));
 }
 __device__ __forceinline__ void lds_pin_u64(unsigned long long& v) { asm volatile("" : "+v"(v)); }
+// (double)v for a 32-bit count, exactly, without v_cvt_f64_i32: the dword v ^ 2^31 under the exponent of 2^52 IS the double
+// 2^52 + 2^31 + v; one full-rate subtraction takes the bias off.  Same-box A/B against the conversion instruction (-DPUP_CVT_I32=1),
+// three alternations: K1q 0.582 / 0.583 / 0.574 against 0.590 / 0.595 / 0.588 ms (the store phase's clocks do not move: it is bound
+// by the LDS write path, the instruction mix of the look-ahead around it changes); K1w +1 %: kept here, not there.
+#ifndef PUP_CVT_I32
+#define PUP_CVT_I32 0
+#endif
+__device__ __forceinline__ double count_to_f64(int v) {
+#if PUP_CVT_I32
+    return (double)v;
+#else
+    return __hiloint2double(0x43300000, (int)((unsigned)v ^ 0x80000000u)) - 4503601774854144.0;      // 2^52 + 2^31
+#endif
+}
 // wait until at most N LDS operations of this wave are outstanding (they return in order: everything older is complete);
 // the address registers of the reads waited for stay untouched until here (see lds_wait_all in pup_kernels.hpp)
 template <int N>
@@ -419,7 +433,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
 #pragma unroll
             for (int hh = 0; hh < NH; ++hh) {
                 // balanced value (raw: both weights are 1.0; lanes with nothing to keep loaded a zero count)
-                double val = (double)v[i * NH + hh] * wr * wcs[hh];
+                double val = count_to_f64(v[i * NH + hh]) * wr * wcs[hh];
                 if (NFP) val = (val == val) ? val : 0.0;
                 if (OOE) {
                     const double e = exp_lds[64 * hh + lane - rr + (RSR - 1)];      // expected of |col - row|
@@ -537,7 +551,7 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
             for (int hh = 0; hh < NH; ++hh) {
                 constexpr bool PAIRS = FACT && NH == 2;      // (band_issue: the lane's two values are columns 2 l and 2 l + 1)
                 const int colx = PAIRS ? 2 * lane + hh : 64 * hh + lane;
-                double val = (double)v[i * NH + hh] * wr * wcs[hh];
+                double val = count_to_f64(v[i * NH + hh]) * wr * wcs[hh];
                 if (NFP) val = (val == val) ? val : 0.0;
                 if (OOE) {
                     const double e = exp_lds[colx - rr + (RSR - 1)];      // expected of |col - row|

@@ -302,7 +302,7 @@ void pileup_wide_kernel(K1Args a, WideArgs wa) {
 #pragma unroll
             for (int hh = 0; hh < NH; ++hh) {
                 const int colx = FACT ? 2 * lane + hh : 64 * hh + lane;      // (band_issue: FACT lanes hold columns 2 l and 2 l + 1)
-                double val = (double)v[i * NH + hh] * wr * wcs[hh];
+                double val = (double)v[i * NH + hh] * wr * wcs[hh];      // (count_to_f64, K1q's way round v_cvt_f64_i32: 1 % slower here, A/B)
                 if (nf) val = (val == val) ? val : 0.0;
                 if (OOE) {
                     const double e = exp_lds[colx - rr + (RSR - 1)];      // expected of |col - row|
