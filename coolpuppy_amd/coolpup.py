@@ -932,9 +932,13 @@ class CoordCreator:
             # features sorted by centre (the usual BED case): the separation at offset i only grows with i, so the first
             # offset at which every pair is beyond maxdist ends the walk (the reference keeps looping; it finds nothing there)
             ordered = m > 1 and bool(np.all(c1[1:] >= c1[:-1]))
-            if m > 1 and nshifts == 0 and right is left and not getattr(self, "_draw_only", False) and m < 65_536 \
+            if m > 1 and right is left and not getattr(self, "_draw_only", False) and m < 65_536 \
                     and not os.environ.get("COOLPUPPY_AMD_WALK_COMBINATIONS"):
-                return self._combination_table_sorted(L, R, c1, m)
+                if nshifts == 0:
+                    return self._combination_table_sorted(L, R, c1, m)
+                got = self._combination_table_sorted(L, R, c1, m, nshifts)
+                if got is not None:
+                    return got                     # (None: no pair at all, or the library declined the draws — nothing was drawn: the walk)
             for i in range(1, min(self._tbl.n, m)):
                 k = m - i
                 dist = c2[i:i + k] - c1[:k]
@@ -957,7 +961,7 @@ class CoordCreator:
         out = _Cols({k: np.concatenate([p[k] for p in parts]) for k in parts[0]})
         return out
 
-    def _combination_table_sorted(self, L, R, c, m):
+    def _combination_table_sorted(self, L, R, c, m, nshifts=0):
         """_combination_table's walk over the offsets (no control draws), without the walk: the pairs (k, j > k) whose centres lie
         mindist ... maxdist apart are found through the centres' sort order — for every feature the partners beyond it in centre
         are a contiguous stretch of that order (two bisections) — and the reference's order (offset i = j - k ascending, k
@@ -989,9 +993,55 @@ class CoordCreator:
         o2 = np.argsort((j - k)[o1].astype(np.uint16), kind="stable")
         order = o1[o2]
         a, b = k[order], j[order]
-        tbl = _Cols({**{kk: v[a] for kk, v in L.items()}, **{kk: v[b] for kk, v in R.items()}})
-        tbl["distance"] = dist[order]
-        return self._control_cols(tbl, 0)
+        if nshifts <= 0:
+            tbl = _Cols({**{kk: v[a] for kk, v in L.items()}, **{kk: v[b] for kk, v in R.items()}})
+            tbl["distance"] = dist[order]
+            return self._control_cols(tbl, 0)
+        return self._combination_controls(L, R, a, b, dist[order], (b - a), nshifts)
+
+    def _combination_controls(self, L, R, a, b, dist, off, nshifts):
+        """The control copies of _combination_table's walk, all offsets at once.  The walk hands every offset's table to _control_cols:
+        its ROI rows, then nshifts shifted copies of them, drawn with ONE randint + ONE choice per offset (coolpup.py:420-436 inside the
+        loop of :682-700) — thousands of small draws and small tables for a by-window pile-up with controls (0.18 of its 1.0 s).  Here the
+        draws of all offsets are one library job (engine.legacy_randint_plan: the same calls in the same order, so the same numbers and
+        generator state) and the output rows are gathered in one go: block i of the output = rows [s_i, s_i + n_i) of the pair table
+        once as they are, then nshifts times shifted.  None: the library declined the draws (the caller walks instead)."""
+        from .engine import legacy_randint_plan
+        P = len(a)
+        n_off = np.bincount(off)                                   # pairs per offset; the walk skips the empty ones (no draw)
+        n_off = n_off[n_off > 0]
+        s_off = np.cumsum(n_off) - n_off                            # first pair of every offset (the pairs are in offset order)
+        shift = np.empty(P * nshifts, np.int64)
+        sign = np.empty(P * nshifts, np.int64)
+        lo, hi = int(self.minshift), int(self.maxshift)
+        calls = []
+        for s, n in zip((s_off * nshifts).tolist(), (n_off * nshifts).tolist()):
+            calls.append((lo, hi, n, 1, 0, shift[s:s + n]))
+            calls.append((0, 2, n, 2, -1, sign[s:s + n]))
+        if not legacy_randint_plan(calls):
+            return None
+        shift *= sign
+        # output row o lies in block i = the offset whose rows it copies; inside the block: n_i ROI rows, then nshifts x n_i controls
+        blk = (1 + nshifts) * s_off
+        o = np.arange(P * (1 + nshifts))
+        i = np.repeat(np.arange(len(n_off)), n_off * (1 + nshifts))
+        within = o - blk[i]
+        ni = n_off[i]
+        src = s_off[i] + within % ni
+        ctrl = within >= ni
+        sh = np.where(ctrl, shift[np.where(ctrl, nshifts * s_off[i] + within - ni, 0)], 0)
+        rows_a, rows_b = a[src], b[src]
+        out = _Cols({**{kk: v[rows_a] for kk, v in L.items()}, **{kk: v[rows_b] for kk, v in R.items()}})
+        out["distance"] = dist[src]
+        for name in ("exp_start1", "exp_end1", "center1", "exp_start2", "exp_end2", "center2"):      # (cis: both sides move by `shift`)
+            if name in out:
+                out[name] = out[name] + sh
+        dbin = np.round(sh / self.resolution).astype(int)           # the BINS of both sides move by `shift` too (reference :442-445)
+        dbin32 = dbin.astype(np.int32)
+        for name in ("stBin1", "endBin1", "stBin2", "endBin2"):
+            out[name] = out[name] + (dbin32 if out[name].dtype == np.int32 else dbin)
+        out["kind"] = np.where(ctrl, np.int8(KIND_CONTROL), np.int8(KIND_ROI))
+        return out
 
     # -- dict-row streams kept for API compatibility (reference :598-749) -----------------------------------
     def get_intervals_stream(self, filter_func1, filter_func2=None, intervals=None, control=False, groupby=[],
@@ -1660,7 +1710,7 @@ class PileUpper:
             # the global group table needs every region's group keys in region order: the ranks swap them (a few keys each)
             got = _dist.merge_dicts({i: self.region_groups(batches[i][2], grouped) for i in owned})
             region_groups = [got[i] for i in range(len(pairs))]
-        return self._pile_and_finalize(batches, groupby, grouped=grouped, region_groups=region_groups)
+        return self._pile_and_finalize(batches, groupby, grouped=grouped, region_groups=region_groups, any_order=_by_window)
 
     def _fused_plan(self, pairs):
         """The plan of an UNGROUPED pile-up of plain feature pairs with random-shift controls (the headline shape: BEDPE features,
@@ -2014,14 +2064,17 @@ class PileUpper:
                     # groups numbered in output order (the usual case) and the whole kind present: the "all" tile itself still
                     # holds zeros, so the members' sum in their order IS the sum over the kind's slice — no gather of every tile
                     # (a by-window pile-up has one per feature)
-                    whole = len(members) == G - 1 and bool(np.all(np.diff(members) > 0)) and not acc["n"][a] \
-                        and not acc["sum"][a].any()
+                    # (the control groups of a by-window pile-up with random shifts come in another order than the ROI ones — a permutation
+                    # of the same slice: summed in tile order as well; gathering 37 k tiles five times was 0.3 s of such a call)
+                    # (... and, by-window, a kind may lack a few of the features altogether — their tiles of that kind hold zeros)
+                    whole = not acc["n"][a] and not acc["sum"][a].any() and \
+                        (plan.get("any_order", False) or (len(members) == G - 1 and bool(np.all(np.diff(members) > 0))))
                     for name in ("sum", "num", "n", "cov_start", "cov_end"):
                         acc[name][a] = acc[name][kind * G:(kind + 1) * G].sum(axis=0) if whole else acc[name][members].sum(axis=0)
         self._merge_inf_cells(plan, acc)
         stripes = _collect_stripes(plan, acc) if (plan.get("stripe_jobs") or acc.get("stripe_jobs")) else None
         return finalize_pileups(self, acc, order, gid, G, plan["groupby"], plan["want_control"],
-                                grouped=plan["grouped"], stripes=stripes)
+                                grouped=plan["grouped"], stripes=stripes, any_order=plan.get("any_order", False))
 
     def _merge_inf_cells(self, plan, acc):
         """Cells that hold +inf (a pixel over expected == 0) follow the reference's merge arithmetic instead of plain
@@ -2076,8 +2129,9 @@ class PileUpper:
                 fix = np.isinf(S[t]) | ~np.isfinite(d)
                 S[t][fix] = d[fix]
 
-    def _pile_and_finalize(self, batches, groupby, grouped=None, region_groups=None):
+    def _pile_and_finalize(self, batches, groupby, grouped=None, region_groups=None, any_order=False):
         plan = self.make_plan(batches, groupby, grouped=grouped, region_groups=region_groups)
+        plan["any_order"] = bool(any_order)        # (by-window: the caller sorts the rows itself — _by_window_frame)
         return self.finalize_plan(plan, self.run_plan(plan))
 
     def pileup_region(self, region1, region2=None, groupby=[], modify_2Dintervals_func=None, postprocess_func=None,

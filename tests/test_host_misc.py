@@ -390,6 +390,39 @@ def test_library_tile_normalisation_equals_numpy():
         assert np.array_equal(np.signbit(want[fin]), np.signbit(got[fin]))
 
 
+def test_sorted_combinations_with_controls_equal_the_walk(monkeypatch):
+    """The same with random-shift controls (nshifts > 0): the draws of all offsets as one library job and the rows gathered in one
+    go (CoordCreator._combination_controls) against the walk's one randint + one choice and one small table per offset — same
+    rows, columns, dtypes, and the legacy generator left in the same state."""
+    import pandas as pd
+    from coolpuppy_amd import coolpup
+
+    def tables(feats, walk, **kw):
+        monkeypatch.setenv("COOLPUPPY_AMD_WALK_COMBINATIONS", "1") if walk else monkeypatch.delenv("COOLPUPPY_AMD_WALK_COMBINATIONS", raising=False)
+        np.random.seed(3)
+        cc = coolpup.CoordCreator(features=feats, resolution=10_000, features_format="bed", flank=100_000, **kw)
+        cc.process()
+        out = [cc.region_table((ch, 0, 10 ** 9), None, control=True, columns=None) for ch in ("chr1", "chr2")]
+        return out, np.random.get_state()
+    rng = np.random.default_rng(1)
+    for trial, n in enumerate((60, 700, 2, 1)):
+        rows = []
+        for ch in ("chr1", "chr2"):
+            st = np.sort(rng.integers(0, 30_000_000, n))
+            rows.append(pd.DataFrame({"chrom": ch, "start": st, "end": st + rng.integers(1, 3 if trial % 2 == 0 else 300, n) * 1000}))
+        feats = pd.concat(rows, ignore_index=True)
+        for kw in (dict(mindist=300_000, maxdist=1_000_000, nshifts=3), dict(mindist="auto", maxdist=2_000_000, nshifts=1),
+                   dict(mindist=0, maxdist=250_000.5, nshifts=2, minshift=20_000, maxshift=77_777)):
+            (ta, sa), (tb, sb) = tables(feats, True, **kw), tables(feats, False, **kw)
+            assert sa[2] == sb[2] and np.array_equal(sa[1], sb[1]), (trial, kw)
+            for x, y in zip(ta, tb):
+                assert (x is None) == (y is None), (trial, kw)
+                if x is not None:
+                    assert list(x.keys()) == list(y.keys())
+                    for k in x:
+                        assert x[k].dtype == y[k].dtype and np.array_equal(x[k], y[k]), (trial, kw, k)
+
+
 def test_library_lut_and_band_passes_equal_numpy():
     """pup_host_lut_i32 (tile numbers from group codes, the controls' half offset) and pup_host_count_le (distance bands =
     searchsorted(edges, d, "right")) against numpy, values on and beside the edges included; short inputs take numpy itself."""
