@@ -86,6 +86,8 @@ def _hdf5():
     lib.H5Pget_filter2.restype = C.c_int
     lib.H5Pget_filter2.argtypes = [hid, C.c_uint, C.POINTER(C.c_uint), C.POINTER(C.c_size_t), C.POINTER(C.c_uint), C.c_size_t, C.c_char_p, C.POINTER(C.c_uint)]
     lib.H5Pclose.argtypes = [hid]
+    lib.H5Fget_create_plist.restype = hid; lib.H5Fget_create_plist.argtypes = [hid]
+    lib.H5Pget_userblock.restype = C.c_int; lib.H5Pget_userblock.argtypes = [hid, C.POINTER(C.c_uint64)]
     lib.H5Tget_order.restype = C.c_int; lib.H5Tget_order.argtypes = [hid]
     if hasattr(lib, "H5Dget_num_chunks"):
         lib.H5Dget_num_chunks.restype = C.c_int; lib.H5Dget_num_chunks.argtypes = [hid, hid, C.POINTER(C.c_uint64)]
@@ -232,12 +234,29 @@ class _File:
         finally:
             lib.H5Dclose(did)
 
+    def _userblock(self):
+        """Size of the file's user block (H5Pget_userblock on the file creation property list); -1 when it cannot be asked."""
+        lib = self.lib
+        pl = lib.H5Fget_create_plist(self.fid)
+        if pl < 0:
+            return -1
+        try:
+            size = C.c_uint64(0)
+            return int(size.value) if lib.H5Pget_userblock(pl, C.byref(size)) >= 0 else -1
+        finally:
+            lib.H5Pclose(pl)
+
     def layout(self, name):
         """Where the bytes of a 1-D numeric dataset sit in the file, for readers that fetch them without libhdf5 (whose calls are
         serialised by its global lock): {"dtype", "n", "kind": "contiguous", "offset"} or {"kind": "chunked", "chunk": elements per
         chunk, "chunks": [(first element, file offset, stored bytes, filter mask)], "filters": [1 = deflate | 2 = shuffle, in pipeline order]}.  None for
         anything else (other filters, big-endian or non-native types, no storage allocated yet): the caller uses H5Dread."""
         lib = self.lib
+        if self._userblock() != 0:
+            # (ADVICE r5) chunk addresses of H5Dget_chunk_info are relative to the file's base address in libhdf5 builds before
+            # 1.14.4 — behind a user block a pread at them fetches other bytes, and an unfiltered chunk would not even fail to
+            # inflate.  Such files (rare: cooler never writes one) go through H5Dread.
+            return None
         did = lib.H5Dopen2(self.fid, name.encode(), _H5P_DEFAULT)
         if did < 0:
             raise KeyError(f"dataset {name!r} not found")
@@ -432,6 +451,8 @@ class _DirectReader:
                     buf = zlib.decompress(buf)
                 else:
                     buf = np.frombuffer(buf, np.uint8, count=ce * item).reshape(item, ce).T.tobytes()     # byte planes back into elements
+            if len(buf) != ce * item:                               # (a chunk always holds `chunk` elements, edge chunks too)
+                raise OSError(f"{self.name!r}: a chunk unpacked to {len(buf)} bytes, expected {ce * item}")
             vals = np.frombuffer(buf, lay["dtype"], count=ce)[:n_el]
             a, b = max(start, int(first)), min(start + n_el, last)
             if b > a:
@@ -595,16 +616,16 @@ def _read_cool_h5py(path, group, extra_bins):
                            g["pixels/bin2_id"][:], _counts32(g["pixels/count"][:]), bins=cols, filename=path)
 
 
-def write_cool(path, clr, group="/", chunks=None, gzip=None, shuffle=False):
+def write_cool(path, clr, group="/", chunks=None, gzip=None, shuffle=False, userblock=0):
     """Write an ArrayCooler as a single-resolution ``.cool`` (the datasets read_cool consumes, cooler's schema: chroms/{name,length},
     bins/{chrom,start,end,<columns>}, pixels/{bin1_id,bin2_id,count}, indexes/{bin1_offset,chrom_offset}, attrs bin-size /
     format / nbins / nnz).  A utility for tests and benchmarks (the reference only ever reads coolers; `cooler` writes them):
-    chunks / gzip as cooler does when given, else contiguous datasets."""
+    chunks / gzip as cooler does when given, else contiguous datasets; userblock: bytes of HDF5 user block in front (tests)."""
     from .lib.io import _H5
     g = "/" + group.strip("/")
     g = "" if g == "/" else g
     indptr, col, cnt = clr.pixel_table()
-    with _H5(path, "w") as h5:
+    with _H5(path, "w", userblock=userblock) as h5:
         cur = ""
         for part in [p for p in g.split("/") if p]:
             cur += "/" + part

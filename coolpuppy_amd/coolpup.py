@@ -419,6 +419,18 @@ class CoordCreator:
 
         # the array path (intervals.build_table): same rows, order and columns as the pandas steps below, without the frame
         from .intervals import build_table
+        try:
+            self._process_table(src, build_table)
+        except BaseException:
+            #  the helper of _start_early_draws owns numpy's legacy generator from inside build_table on; an error
+            # between there and the end of the constructor would leave it drawing with nobody to adopt or cancel it — the
+            # constructor has no object to hand pileup()'s own guard
+            early, self._early_ahead = self._early_ahead, None
+            if early is not None:
+                early[0].cancel(early[2])
+            raise
+
+    def _process_table(self, src, build_table):
         tbl = None
         if not os.environ.get("COOLPUPPY_AMD_FRAME_PATH"):
             early = self._start_early_draws if (self._draw_hint and self.kind == "bedpe" and self.nshifts > 0 and not self.trans) else None
@@ -502,6 +514,8 @@ class CoordCreator:
             if not keep.all():
                 iv = iv[keep].reset_index(drop=True)
                 c1, c2 = c1[keep], c2[keep]
+            elif not (isinstance(iv.index, pd.RangeIndex) and iv.index.start == 0 and iv.index.step == 1):
+                iv = iv.reset_index(drop=True)          # (the reference renumbers whether or not the filter dropped a row, :321)
             iv["chrom1"] = iv["chrom1"].astype(str)
             iv["chrom2"] = iv["chrom2"].astype(str)
             iv["center1"] = c1

@@ -443,7 +443,7 @@ int pup_load_pixels(pup_ctx* c, const int64_t* bin1_offset, const void* bin2_id,
     if (status != PUP_OK) return status;
     c->nbins = nbins; c->nnz = nnz; c->have_px = true;
     c->have_weight = c->have_cov = false; c->have_bal = false;
-    c->float_values = false;
+    c->float_values = false; c->band_w = 0;              // (the band of the previous table, or none after float values: pup_build_index makes this table's)
     return PUP_OK;
 }
 
@@ -559,6 +559,8 @@ int pup_load_pixels_stream(pup_ctx* c, const int64_t* bin1_offset, int64_t nbins
     if (h2d_bytes) *h2d_bytes = bytes_total;
     c->nbins = nbins; c->nnz = nnz; c->have_px = true;
     c->have_weight = c->have_cov = false; c->have_bal = false;
+    c->float_values = false; c->band_w = 0;              // (as pup_load_pixels: a new table is a table of counts until pup_load_pixel_values says otherwise)
+    c->forget_hints();
     return PUP_OK;
 }
 
@@ -660,14 +662,15 @@ int pup_coverage(pup_ctx* c, const int64_t* chrom_offset, int32_t n_chroms, int3
     if (chrom_offset[0] != 0 || chrom_offset[n_chroms] != c->nbins)
         return fail(c, PUP_EINVAL, "pup_coverage: chrom_offset must run from 0 to nbins=%lld", c->nbins);
     if (ignore_diags < 0) return fail(c, PUP_EINVAL, "pup_coverage: ignore_diags must be >= 0");
-    if (c->float_values) return fail(c, PUP_ENOTSUP, "pup_coverage: the table holds float pixel values (pup_load_pixel_values); the coverage kernel sums integer counts exactly — supply cov_*_raw columns computed elsewhere");
     int rc = bind(c); if (rc) return rc;
     std::vector<pup::IdxChrom> tab((size_t)n_chroms);
     for (int k = 0; k < n_chroms; ++k) {
         if (chrom_offset[k + 1] < chrom_offset[k]) return fail(c, PUP_EINVAL, "pup_coverage: chrom_offset decreases at %d", k);
         tab[(size_t)k] = pup::IdxChrom{(int)chrom_offset[k], (int)chrom_offset[k + 1], 0, 0, 0};
     }
-    DevBuf<pup::IdxChrom> d_tab; DevBuf<unsigned long long> d_cov;
+    // counts: u64 sums (exact, order-independent); float pixel values (pup_load_pixel_values): f64 sums of the same pass
+    const bool flt = c->float_values;
+    DevBuf<pup::IdxChrom> d_tab; DevBuf<unsigned long long> d_cov;          // (2 x nbins 8-byte accumulators either way)
     const size_t nb = (size_t)c->nbins;
     hipError_t e = d_tab.reserve((size_t)n_chroms);
     if (e == hipSuccess) e = d_cov.reserve(2 * nb);
@@ -675,13 +678,18 @@ int pup_coverage(pup_ctx* c, const int64_t* chrom_offset, int32_t n_chroms, int3
     int status = PUP_OK;
     std::vector<unsigned long long> h(2 * nb);
     e = hipMemcpy(d_tab.p, tab.data(), tab.size() * sizeof(pup::IdxChrom), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemsetAsync(d_cov.p, 0, 2 * nb * sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_cov.p, 0, 2 * nb * sizeof(unsigned long long), c->stream);     // (all-zero bits are 0.0 too)
     if (e == hipSuccess) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         (void)hipEventRecord(e0, c->stream);
-        hipLaunchKernelGGL(pup::coverage_kernel, dim3((unsigned)((c->nbins + pup::kCovRows - 1) / pup::kCovRows)), dim3(512), 0,
-                           c->stream, c->indptr.p, c->px.p, d_tab.p, n_chroms, ignore_diags, d_cov.p, d_cov.p + nb, c->nbins);
+        const dim3 grid((unsigned)((c->nbins + pup::kCovRows - 1) / pup::kCovRows));
+        if (flt)
+            hipLaunchKernelGGL(pup::coverage_kernel<double>, grid, dim3(512), 0, c->stream, c->indptr.p, c->px.p, (const double*)c->cntf.p,
+                               d_tab.p, n_chroms, ignore_diags, reinterpret_cast<double*>(d_cov.p), reinterpret_cast<double*>(d_cov.p + nb), c->nbins);
+        else
+            hipLaunchKernelGGL(pup::coverage_kernel<unsigned long long>, grid, dim3(512), 0, c->stream, c->indptr.p, c->px.p, (const double*)nullptr,
+                               d_tab.p, n_chroms, ignore_diags, d_cov.p, d_cov.p + nb, c->nbins);
         (void)hipEventRecord(e1, c->stream);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -693,6 +701,14 @@ int pup_coverage(pup_ctx* c, const int64_t* chrom_offset, int32_t n_chroms, int3
     if (e != hipSuccess) status = fail(c, PUP_EHIP, "pup_coverage: %s", hipGetErrorString(e));
     d_tab.release(); d_cov.release();
     if (status != PUP_OK) return status;
+    if (flt) {
+        const double* hd = reinterpret_cast<const double*>(h.data());
+        for (size_t i = 0; i < nb; ++i) {
+            if (cov_cis) cov_cis[i] = hd[nb + i];
+            if (cov_tot) cov_tot[i] = hd[nb + i] + hd[i];
+        }
+        return PUP_OK;
+    }
     for (size_t i = 0; i < nb; ++i) {
         if (cov_cis) cov_cis[i] = (double)h[nb + i];
         if (cov_tot) cov_tot[i] = (double)(h[nb + i] + h[i]);      // intra- plus inter-chromosomal

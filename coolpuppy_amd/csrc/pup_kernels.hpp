@@ -1764,30 +1764,52 @@ constexpr int kCovCols = 4096;
 // the host forms cov_tot = cov_cis + cov_trans.  A wave streams its row with 16-byte loads (two pixels per lane), two
 // loads in flight per lane: the pass is bound by load latency, not by the LDS atomics (the distinct columns of one
 // row never collide; four loads in flight per lane and a 2048-column window were measured: 0.86 ms and 2.1 ms against 0.78).  Columns beyond the block's LDS window and all trans columns take global atomics.
+// Round 6: the same pass over FLOAT pixel values (a float pixels/count column, pup_load_pixel_values): Acc = double, the value of
+// pixel k comes from cntf[k], the sums are f64 atomics (LDS and global, hardware adds on gfx950) — the row sums stay a fixed-order
+// wave reduction, the column sums depend on arrival order in their last bits (cooltools sums floats in table order; 1e-6 is the bar).
+template <typename Acc>
+struct CovOps;
+template <>
+struct CovOps<unsigned long long> {
+    static constexpr bool kFloat = false;
+    static __device__ __forceinline__ void add(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
+    static __device__ __forceinline__ bool nonzero(unsigned long long v) { return v != 0ull; }
+};
+template <>
+struct CovOps<double> {
+    static constexpr bool kFloat = true;
+    static __device__ __forceinline__ void add(double* p, double v) { unsafeAtomicAdd(p, v); }
+    static __device__ __forceinline__ bool nonzero(double v) { return v != 0.0; }
+};
+
+template <typename Acc>
 PUP_KERNEL __launch_bounds__(512) void coverage_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
+                                                       const double* __restrict__ cntf,
                                                        const IdxChrom* __restrict__ chroms, int n_chrom, int ignore_diags,
-                                                       unsigned long long* cov_trans, unsigned long long* cov_cis,
-                                                       long long nbins) {
-    __shared__ unsigned long long h_cis[kCovCols];
+                                                       Acc* cov_trans, Acc* cov_cis, long long nbins) {
+    constexpr bool FLT = CovOps<Acc>::kFloat;
+    __shared__ Acc h_cis[kCovCols];
     const long long row0 = (long long)blockIdx.x * kCovRows;
-    for (int t = threadIdx.x; t < kCovCols; t += blockDim.x) h_cis[t] = 0ull;
+    for (int t = threadIdx.x; t < kCovCols; t += blockDim.x) h_cis[t] = Acc(0);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     for (long long r = row0 + wave; r < row0 + kCovRows && r < nbins; r += nwave) {
         int lo = 0, hi = n_chrom;
         while (lo < hi) { const int m = (lo + hi) >> 1; if (chroms[m].end <= r) lo = m + 1; else hi = m; }
         const long long chrom_end = lo < n_chrom ? chroms[lo].end : nbins;
-        unsigned long long s_trans = 0, s_cis = 0;
+        Acc s_trans = Acc(0), s_cis = Acc(0);
         const long long b = indptr[r], e = indptr[r + 1];
         auto add = [&](long long k, int col, int cnt) __attribute__((always_inline)) {
             if (k < b || k >= e) return;
             const long long d = (long long)col - r;
-            const unsigned long long w = ((d < 0 ? -d : d) < ignore_diags) ? 0ull : (unsigned long long)(unsigned)cnt;
-            if (col >= chrom_end) { s_trans += w; atomicAdd(&cov_trans[col], w); return; }
+            Acc w;
+            if constexpr (FLT) w = cntf[k]; else w = (Acc)(unsigned)cnt;
+            if ((d < 0 ? -d : d) < ignore_diags) w = Acc(0);
+            if (col >= chrom_end) { s_trans += w; CovOps<Acc>::add(&cov_trans[col], w); return; }
             s_cis += w;
             const long long rel = (long long)col - row0;
-            if (rel < kCovCols) atomicAdd(&h_cis[rel], w);
-            else atomicAdd(&cov_cis[col], w);
+            if (rel < kCovCols) CovOps<Acc>::add(&h_cis[rel], w);
+            else CovOps<Acc>::add(&cov_cis[col], w);
         };
         // pixel pairs at even offsets (16-byte aligned); the table is padded, so the pair straddling e is readable
         for (long long k = (b & ~1LL) + 2 * lane; k < e; k += 256) {
@@ -1799,14 +1821,14 @@ PUP_KERNEL __launch_bounds__(512) void coverage_kernel(const long long* __restri
         }
         for (int off = 32; off > 0; off >>= 1) { s_trans += __shfl_down(s_trans, off); s_cis += __shfl_down(s_cis, off); }
         if (lane == 0) {
-            atomicAdd(&h_cis[r - row0], s_cis);
-            if (s_trans) atomicAdd(&cov_trans[r], s_trans);
+            CovOps<Acc>::add(&h_cis[r - row0], s_cis);
+            if (CovOps<Acc>::nonzero(s_trans)) CovOps<Acc>::add(&cov_trans[r], s_trans);
         }
     }
     __syncthreads();
     for (int t = threadIdx.x; t < kCovCols; t += blockDim.x) {
         const long long c = row0 + t;
-        if (c < nbins && h_cis[t]) atomicAdd(&cov_cis[c], h_cis[t]);
+        if (c < nbins && CovOps<Acc>::nonzero(h_cis[t])) CovOps<Acc>::add(&cov_cis[c], h_cis[t]);
     }
 }
 

@@ -145,6 +145,7 @@ class PileupEngine:
             raise err[0]
         self._check(rc)
         self.nbins, self.nnz = nbins, int(nnz)
+        self.float_values = False             # (the streamed table is a table of counts: the library has dropped any float values too)
         return {"h2d_ms": ms.value, "h2d_bytes": nbytes.value,
                 "h2d_GBps": (nbytes.value / (ms.value * 1e-3) / 1e9) if ms.value > 0 else None}
 

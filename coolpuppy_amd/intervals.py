@@ -295,9 +295,12 @@ class ArrayTable:
         """The frame the reference's process() ends with: the caller's columns (chromosome names as str) filtered and sorted, the
         derived columns behind them — built once, in one construction."""
         if self._frame is None:
-            # index labels: the caller's, permuted — or, when the distance filter dropped rows, the kept rows renumbered from 0
-            # before the sort (the reference resets the index after its filter, coolpup.py:321)
-            if self.rows is None:
+            # index labels.  BED: the caller's, permuted.  BEDPE: the kept rows renumbered from 0 BEFORE the sort — the reference
+            # resets the index after its distance filter whether or not it dropped a row (coolpup.py:321), so a caller's own
+            # labels (a subset of a bigger frame, say) never survive
+            if self.kind == "bedpe" and not self.filtered:
+                index = pd.RangeIndex(self.n) if self.rows is None else pd.Index(np.asarray(self.rows, np.int64))
+            elif self.rows is None:
                 index = self.src.index
             elif not self.filtered:
                 index = self.src.index.take(self.rows)

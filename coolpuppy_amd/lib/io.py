@@ -98,11 +98,19 @@ _NP2H5 = {"float32": "H5T_NATIVE_FLOAT_g", "float64": "H5T_NATIVE_DOUBLE_g", "in
 class _H5:
     """The dozen libhdf5 calls a .clpy needs: groups, n-d numeric / string datasets, scalar and 1-d attributes."""
 
-    def __init__(self, path, mode):
+    def __init__(self, path, mode, userblock=0):
         self.lib = lib = _lib()
         p = os.fsencode(path)
         if mode == "w" or (mode == "a" and not os.path.exists(path)):
-            self.fid = lib.H5Fcreate(p, _H5F_ACC_TRUNC, 0, 0)
+            fcpl = 0
+            if userblock:                                     # (tests: a file whose HDF5 data starts behind a user block)
+                lib.H5Pset_userblock.argtypes = [_hid, C.c_uint64]
+                fcpl = lib.H5Pcreate(_native(lib, "H5P_CLS_FILE_CREATE_ID_g"))
+                if fcpl < 0 or lib.H5Pset_userblock(fcpl, int(userblock)) < 0:
+                    raise OSError(f"cannot set a user block of {userblock} bytes (a power of two >= 512)")
+            self.fid = lib.H5Fcreate(p, _H5F_ACC_TRUNC, fcpl, 0)
+            if fcpl:
+                lib.H5Pclose(fcpl)
         else:
             self.fid = lib.H5Fopen(p, _H5F_ACC_RDWR if mode == "a" else _H5F_ACC_RDONLY, 0)
         if self.fid < 0:

@@ -126,8 +126,9 @@ int pup_load_pixels(pup_ctx* ctx, const int64_t* bin1_offset, const void* bin2_i
  * coolpuppy/coolpup.py:1053-1057).  Call after pup_load_pixels (whose integer counts are then placeholders; pass zeros) and
  * before pup_load_bins.  The table is then piled up by the kernels that read the balanced value table (per-window register /
  * banded tiles, the sparse trans kernel, rescaled windows, stripes, per-snippet windows): same results as for counts.  The
- * workgroup-staged kernels (integer count tables, dense band) do not run on it, and pup_coverage — exact integer sums —
- * returns PUP_ENOTSUP.  The next pup_load_pixels returns the context to integer counts.
+ * workgroup-staged kernels (integer count tables, dense band) do not run on it; pup_coverage sums the values in float64
+ * (round 6; counts: exact integer sums).  The next pup_load_pixels / pup_load_pixels_stream returns the context to integer
+ * counts.
  */
 int pup_load_pixel_values(pup_ctx* ctx, const double* value, int64_t nnz);
 /*
@@ -184,7 +185,8 @@ int pup_set_expected_table(pup_ctx* ctx, const int32_t* start, const int32_t* en
  * Per-bin coverage of the loaded table (K3), cooltools semantics: every pixel adds its raw count to BOTH of its
  * bins (a main-diagonal pixel twice); pixels with |bin2 - bin1| < ignore_diags count as 0; cov_cis only uses
  * pixels whose two bins share a chromosome (chrom_offset = indexes/chrom_offset, int64[n_chroms+1]).
- * Outputs: host float64[nbins] (integers, exact); either may be NULL.  Synchronous.
+ * Outputs: host float64[nbins] (integers, exact; after pup_load_pixel_values: float64 sums of the pixel values, the column
+ * sums' last bits depend on the order the atomics arrive in); either may be NULL.  Synchronous.
  */
 int pup_coverage(pup_ctx* ctx, const int64_t* chrom_offset, int32_t n_chroms, int32_t ignore_diags,
                  double* cov_cis, double* cov_tot);

@@ -392,3 +392,31 @@ def test_streamed_cooler_upload_matches_the_eager_one(tmp_path, hip_lib):
     x, y = eng.fetch(), ref.fetch()
     np.testing.assert_array_equal(x["num"], y["num"]); np.testing.assert_array_equal(x["sum"], y["sum"])
     eng.close(); ref.close()
+
+
+@pytest.mark.parametrize("chunks", [None, 4096])
+def test_direct_reader_declines_a_file_with_a_user_block(tmp_path, chunks):
+    """behind an HDF5 user block the chunk addresses of older libhdf5 builds are relative to the base address — a pread
+    at them would fetch other bytes, silently for unfiltered chunks.  layout() says None for such a file and the reader takes
+    libhdf5's own path: same arrays."""
+    from coolpuppy_amd import cool_io
+    clr = synth.make_cooler({"chr1": 9_000_000, "chr2": 6_500_000}, lam=30, seed=5)
+    path = str(tmp_path / "u.cool")
+    cool_io.write_cool(path, clr, chunks=chunks, userblock=1024)
+    with open(path, "rb") as fh:
+        assert fh.read(8) != b"\x89HDF\r\n\x1a\n" and fh.seek(1024) == 1024 and fh.read(8) == b"\x89HDF\r\n\x1a\n"
+    col, cnt = clr.pixel_table()[1], clr.pixel_table()[2]
+    f = cool_io._File(path)
+    assert f._userblock() == 1024 and f.layout("/pixels/bin2_id") is None
+    rc = cool_io._DirectReader(path, f, "/pixels/bin2_id", threads=2)
+    rn = cool_io._DirectReader(path, f, "/pixels/count", threads=2)
+    try:
+        for first, m in ((0, 5000), (4095, 3), (0, clr.nnz)):
+            a64, c32 = np.empty(m, np.int64), np.empty(m, np.int32)
+            rc.read_into(first, a64); rn.read_into(first, c32)
+            np.testing.assert_array_equal(a64, col[first:first + m])
+            np.testing.assert_array_equal(c32, cnt[first:first + m])
+    finally:
+        rc.close(); rn.close(); f.close()
+    back = cool_io.read_cool(path)
+    np.testing.assert_array_equal(back.pixel_table()[1], col)

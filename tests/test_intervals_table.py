@@ -100,3 +100,24 @@ def test_array_path_declines_what_it_cannot_word_like_pandas(monkeypatch):
     cc.intervals = sub
     assert cc._tbl.n == 100 and cc.intervals is sub
     assert len(cc._col("stBin1")) == 100
+
+
+def test_bedpe_index_is_renumbered_even_when_the_filter_drops_nothing(monkeypatch):
+    """the reference resets the index after its distance filter unconditionally (coolpup.py:321) and only then sorts — the
+    labels of CoordCreator.intervals are the kept rows' POSITIONS in the input, whatever labels the caller's frame carried (here:
+    a subset of a bigger frame, shuffled).  Both paths; with and without rows dropped."""
+    clr = synth.make_cooler({"chr1": 30_000_000, "chr2": 20_000_000}, lam=3, seed=2)
+    big = synth.random_cis_pairs(clr, 20_000, seed=3)
+    pairs = big.iloc[5_000:15_000].sample(frac=1.0, random_state=1)            # labels 5000..14999, shuffled
+    for kw in (dict(mindist=0, maxdist=np.inf), dict(mindist=400_000, maxdist=900_000)):
+        fast, slow = _both(monkeypatch, pairs, clr.binsize, features_format="bedpe", flank=50_000, nshifts=0, **kw)
+        _same(fast, slow)
+        # the pandas statement of the reference's steps on the same frame: filter, reset_index, stable sort
+        c1 = (pairs["start1"] + pairs["end1"]) / 2
+        c2 = (pairs["start2"] + pairs["end2"]) / 2
+        ref = pairs[(kw["mindist"] <= (c2 - c1).abs()) & ((c2 - c1).abs() <= kw["maxdist"])].reset_index(drop=True)
+        ref = ref.sort_values(["chrom1", "chrom2", "start1", "start2"], kind="stable")
+        assert list(fast.intervals.index) == list(ref.index)
+        assert np.array_equal(fast.intervals["start1"].to_numpy(), ref["start1"].to_numpy())
+        if kw["mindist"] == 0:
+            assert len(ref) == len(pairs) and sorted(fast.intervals.index) == list(range(len(pairs)))
