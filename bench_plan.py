@@ -152,15 +152,22 @@ def main_plan(a, rank, world, local_rank, bench):
     # pixel statistics once, outside the timed region
     eng.set_profiling(1); eng.clear_stats()
     step(); eng.sync()
-    rccl_ranks = None
+    rccl_ranks, native_failed = None, False
     if world > 1 and a.backend == "nccl" and a.exchange == "native":
         # the line below says "pup_allreduce": it must have been what ran — a communicator that could not be set up (the library then
         # falls back with a warning) or that spans fewer ranks than the job is an error here, not a footnote
         comm = pdist._NATIVE_COMMS.get((eng.device_id, world), (None, None))[0]
         rccl_ranks = pdist.comm_ranks(comm) if comm else None
         if rccl_ranks != world:
-            raise SystemExit(f"[bench] rank {rank}: --exchange native on {world} ranks, but the engine's RCCL communicator spans "
-                             f"{rccl_ranks} rank(s) — refusing to report a number for a path that did not run")
+            msg = (f"[bench] rank {rank}: --exchange native on {world} ranks, but the engine's RCCL communicator spans "
+                   f"{rccl_ranks} rank(s)")
+            if getattr(a, "strict_exchange", False):
+                raise SystemExit(msg + " — refusing to report a number for a path that did not run")
+            # (round 6, as bench.py: dist.allreduce_engine has then fallen back to torch's RCCL all-reduce on exported buffers —
+            # measured and LABELLED instead of no line at all)
+            print(msg + " — the steps run dist.allreduce_engine's fallback (torch.distributed.all_reduce on exported buffers); "
+                  "the line says so", file=sys.stderr, flush=True)
+            native_failed = True
     pix_local = float(eng.stats()["pixels_in_windows"])
     families = sorted({eng.last_kernel()})
     eng.set_profiling(0)
@@ -204,7 +211,7 @@ def main_plan(a, rank, world, local_rank, bench):
     roofline = {
         "bound": "lds" if staged else "hbm", "kernel_family": "+".join(families),
         "kernel": ("pup::pileup_staged_kernel (K1q, sets of four tile pairs per staging)" if staged else
-                   ("pup::pileup_sparse_kernel<false> (K1s: O(W) per inter-chromosomal window, presence bitmap)" if "sparse" in families
+                   ("pup::pileup_sparse_queue_kernel<false> (K1s: O(W) per inter-chromosomal window, presence filter, per-lane hit queues)" if "sparse" in families
                     else "+".join(families))),
         "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
         # trans windows share nothing (no reuse): the 8(d) bytes are what the kernel must move and frac is a real fraction;
@@ -252,9 +259,9 @@ def main_plan(a, rank, world, local_rank, bench):
                                    ("chromosomes" if a.config == 3 else "chromosome pairs") + " dealt to the ranks longest first (dist.shard), own rows "
                                    "of the pixel table per rank, one all-reduce of the packed tiles every step")),
                    "variant": a.variant},
-        "exchange": "none" if world == 1 else ("pup_allreduce (RCCL on the engine's stream)" if a.backend == "nccl" and a.exchange == "native"
-                                                else "torch.distributed.all_reduce on exported buffers"),
-        "rccl_ranks": rccl_ranks,
+        "exchange": "none" if world == 1 else ("pup_allreduce (RCCL on the engine's stream)" if a.backend == "nccl" and a.exchange == "native" and not native_failed
+                                                else ("FALLBACK: " if native_failed else "") + "torch.distributed.all_reduce on exported buffers"),
+        "rccl_ranks": rccl_ranks, "native_exchange_failed": native_failed,
         "host_coordinates_plan_s": round(t_host, 3),
         "check": {"n": [int(x) for x in out["n"]], "n_sum": int(out["n"].sum())},
         "roofline": roofline, "cpu_baseline": cpu,

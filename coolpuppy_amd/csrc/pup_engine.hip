@@ -76,7 +76,7 @@ struct pup_ctx {
     DevBuf<int> d_brow;                     // [n_chrom] block rows before each chromosome (block-order prepass)
     DevBuf<unsigned> rowseg;               // [nbins][n_chrom+1] search bounds per (row, chromosome), see K1Args
     DevBuf<uint2> rowabs;                  // [n_chrom][nbins] the same as absolute positions, chromosome-major (sparse trans kernel)
-    DevBuf<unsigned long long> tbits;      // [ceil(nbins/64)][nbins] presence bitmap (sparse trans kernel), built on first use
+    DevBuf<unsigned long long> tbits;      // presence filter of the table as overlapping 32-bit words [column block][row] (sparse trans kernel, K1Args::tbits), built on first use
     int tbits_state = 0;                   // 0: not tried for this table, 1: built, -1: does not fit
     int tbits_shift = 0;                   // columns per bit of the bitmap = 1 << tbits_shift (a coarser filter when the exact one does not fit)
     DevBuf<int> band;                       // dense band of counts near the diagonal (staged kernel), [nbins][band_w] + zeros
@@ -1751,7 +1751,10 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
         // a sparse-kernel window is cheap, a chunk is not (zeroing and finishing a W^2 record, one more record for K2)
         // (measured on 4.9e5 51 x 51 windows, K1s + K2 ms: 100 per chunk 0.90, 200: 0.78, 300: 1.01 — fewer chunks than ~10
         // per CU leave the memory system idle, more pay their fixed cost and load the reduction)
-        const long long slots = (long long)c->n_cu * 10;
+        // (round 6, the queued form: 4.9e5 windows, K1s ms at 96 / 120 / 160 / 191 / 250 per chunk: 0.284 / 0.267 / 0.264-0.272 / 0.272-0.295 /
+        // 0.276-0.299 — twelve chunks per CU, all resident at the kernel's four waves per SIMD)
+        const bool queued = !(c->variant & 4096) && pup::k1sq_lds_bytes(c->W) <= (size_t)c->max_lds;
+        const long long slots = (long long)c->n_cu * (queued ? 12 : 10);
         C = std::max<long long>(96, (n + slots - 1) / slots);
     }
     const int S_plain = c->group_waves > 0 ? c->group_waves : 128;
@@ -1974,14 +1977,16 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
             // with no pixel has none in the 16-column blocks around it either), so 16 columns per bit is where the search starts:
             // 0.7 GB instead of 11.5 GB for a human 10 kb table, and a first call of ~3 ms instead of 22.
             int sh0 = 4;
-            if (const char* e = getenv("COOLPUPPY_AMD_TBITS_SHIFT")) sh0 = std::max(0, std::min(16, atoi(e)));
+            // (round 6: overlapping 32-bit filter words, a window of up to 63 bins inside one of them: at least 4 columns per bit)
+            if (const char* e = getenv("COOLPUPPY_AMD_TBITS_SHIFT")) sh0 = std::max(2, std::min(16, atoi(e)));
             for (int sh = sh0; have_mem && sh <= 16; ++sh) {
-                const unsigned long long words = (unsigned long long)((((c->nbins + (1LL << sh) - 1) >> sh) + 63) / 64 + 1) * (unsigned long long)c->nbins;
+                const unsigned long long w32 = (unsigned long long)((((c->nbins + (1LL << sh) - 1) >> sh) + 15) / 16 + 1) * (unsigned long long)c->nbins;
+                const unsigned long long words = (w32 + 1) / 2 + 1;      // 8-byte units of the buffer
                 if (words * 8ull > fb / 4 + c->tbits.cap * 8ull) continue;
                 if (c->tbits.reserve((size_t)words) != hipSuccess) { (void)hipGetLastError(); break; }
                 HIPCHK(c, hipMemsetAsync(c->tbits.p, 0, (size_t)words * 8, c->stream));
                 const unsigned gb3 = (unsigned)std::min<long long>((c->nbins + 3) / 4, 1 << 20);
-                hipLaunchKernelGGL(pup::tbits_fill_kernel, dim3(gb3), dim3(256), 0, c->stream, c->indptr.p, c->px.p, c->tbits.p, c->nbins, sh);
+                hipLaunchKernelGGL(pup::tbits_fill_kernel, dim3(gb3), dim3(256), 0, c->stream, c->indptr.p, c->px.p, reinterpret_cast<unsigned*>(c->tbits.p), c->nbins, sh);
                 c->tbits_state = 1; c->tbits_shift = sh;
                 if (sh > sh0 && !(c->warned & 4u) && !getenv("COOLPUPPY_AMD_QUIET")) {
                     c->warned |= 4u;
@@ -1996,15 +2001,16 @@ static int accumulate_impl(pup_ctx* c, const int32_t* r0, const int32_t* c0, con
                                 "window row instead (1.5x to 5x slower)\n", c->nbins);
             }
         }
-        a.tbits = c->tbits_state == 1 ? c->tbits.p : nullptr; a.tshift = c->tbits_state == 1 ? c->tbits_shift : 0;
-        const size_t sl = pup::k1s_lds_bytes(W);
-        if (mode & PUP_MODE_OOE) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pup::pileup_sparse_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl);
-            hipLaunchKernelGGL((pup::pileup_sparse_kernel<true>), dim3((unsigned)nblocks), dim3(pup::kWave), sl, c->stream, a);
-        } else {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pup::pileup_sparse_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl);
-            hipLaunchKernelGGL((pup::pileup_sparse_kernel<false>), dim3((unsigned)nblocks), dim3(pup::kWave), sl, c->stream, a);
-        }
+        a.tbits = c->tbits_state == 1 ? reinterpret_cast<const unsigned*>(c->tbits.p) : nullptr; a.tshift = c->tbits_state == 1 ? c->tbits_shift : 0;
+        // round 6: per-lane hit queues (pileup_sparse_queue_kernel); tuning bit 21 keeps the first form (same results bit for bit: tests)
+        const bool queued = !(c->variant & 4096) && pup::k1sq_lds_bytes(W) <= (size_t)c->max_lds;
+        const size_t sl = queued ? pup::k1sq_lds_bytes(W) : pup::k1s_lds_bytes(W);
+        auto launch_sparse = [&](auto kern) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl);
+            hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(pup::kWave), sl, c->stream, a);
+        };
+        if (mode & PUP_MODE_OOE) { if (queued) launch_sparse(pup::pileup_sparse_queue_kernel<true>); else launch_sparse(pup::pileup_sparse_kernel<true>); }
+        else { if (queued) launch_sparse(pup::pileup_sparse_queue_kernel<false>); else launch_sparse(pup::pileup_sparse_kernel<false>); }
         launched = true; c->last_kernel = "sparse";
     }
     if (!launched && !lds_kernel2 && W <= 31) { launched = launch_regtile(W, a, (int)nblocks, c->stream); if (launched) c->last_kernel = "regtile"; }
@@ -2545,7 +2551,8 @@ int pup_set_tuning(pup_ctx* c, int32_t chunk_snippets, int32_t variant) {
     c->chunk_snippets = chunk_snippets;
     c->forget_hints();
     c->variant = (variant & 0xff) | ((variant >> 19) & 0x700);   // bit 27 -> 256: never stage from the dense band; bit 28 -> 512: tile pairs one by one; bit 29 -> 1024: library sort in the prepass
-    c->group_waves = (variant >> 8) & 0xffff;
+    c->variant |= ((variant >> 20) & 0x3) << 11;                 // bit 20 -> 2048: rescaled windows zoomed sample by sample; bit 21 -> 4096: the sparse trans kernel without hit queues
+    c->group_waves = (variant >> 8) & 0xfff;
     c->debug_phases = ((variant >> 24) & 0x7) | ((variant >> 27) & 0x8);     // (bit 30 -> 8: K1q without its factorised-count bookkeeping, timing only)
     return PUP_OK;
 }

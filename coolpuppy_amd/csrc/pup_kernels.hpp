@@ -89,10 +89,11 @@ struct K1Args {
                                //          of a window that the rank-bitmap index does not cover (trans)
     const uint2*     rowabs;   // [n_chrom][nbins] or nullptr: {first, end} of the row's pixels in chromosome k as ABSOLUTE positions in
                                //          the pixel table, chromosome-major (the sparse trans kernel: one load per window row)
-    int              tshift;   // columns per bit of tbits = 1 << tshift (0: exact; > 0: a coarser FILTER for tables whose exact bitmap would not fit)
-    const unsigned long long* tbits;   // [ceil(nbins / 64)][nbins] or nullptr: bit j of word [cb][row] set <=> the table holds pixel
-                               //          (row, 64 cb + j).  COLUMN-block major: the 64-bit words of consecutive rows for one
-                               //          block of 64 columns are contiguous (the sparse trans kernel, see tbits_fill_kernel)
+    int              tshift;   // columns per bit of tbits = 1 << tshift (>= 2)
+    const unsigned* tbits;     // [ceil(ceil(nbins >> tshift) / 16) + 1][nbins] or nullptr: bit j of the 32-bit word [cb][row] set <=> the
+                               //          table holds a pixel of row `row` in columns [(16 cb + j) << tshift, (16 cb + j + 1) << tshift):
+                               //          the words OVERLAP by half.  COLUMN-block major: the words of consecutive rows for one block
+                               //          of columns are contiguous (the sparse trans kernel, see tbits_fill_kernel)
     const double*    weight;   // [nbins] or nullptr (raw)
     const double*    cov;      // [nbins] or nullptr
     const double*    expv;     // [nexp] or nullptr: ONE by-diagonal vector (nexp >= 2) or ONE scalar (nexp == 1) ...
@@ -478,8 +479,19 @@ PUP_KERNEL __launch_bounds__(256) void rowabs_kernel(const long long* __restrict
 // (1.2e6 bins: 180 GB; a 1 kb human map: 1.2 TB) a bit stands for 2^tshift consecutive columns: the memory shrinks by that factor, the
 // loads stay two per window, and at trans densities (1e-4 and below) a handful of extra columns per window row changes the hit rate
 // from 0.36 % to 0.4 %.
+// Round 6: the filter is kept as OVERLAPPING 32-bit words — word [cb][row] holds the bits of the filter columns [16 cb, 16 cb + 32) of
+// row `row` (tshift >= 2: a window of up to 63 bins spans at most 17 filter columns, so the window whose first filter column is
+// 16 cb + i, i < 16, lies inside word cb): ONE 4-byte load per window row, no second word for windows that straddle a boundary, and
+// a lane's state per window in flight is one register — the sparse kernel keeps the words of 32 windows in flight per wave (its
+// loads' latency, not their bytes, is what it waits for: phase clocks, round 6).  W consecutive words are 4 W bytes = 2-3 lines
+// (round 3's 8-byte words: 4.5 lines, a second load for windows across a 64-column boundary).  Twice the bits of a plain bitmap:
+// 1.4 GB for a human 10 kb table at 16 columns per bit.
+// One wave per matrix row; a row's pixels are sorted by column, so the lanes of a batch of 64 pixels that fall into one column block
+// are neighbours: their bits are ORed along the run first (six shuffle steps) and the run's last lane sends TWO atomics — an atomic
+// per pixel (the first form, and twice that with overlapping words) serialised on the few words a row's thousand cis pixels share:
+// 24 ms, then 44 ms, per 3.8e8-pixel table; now a few.
 PUP_KERNEL __launch_bounds__(256) void tbits_fill_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
-                                                         unsigned long long* __restrict__ tbits, long long nbins, int tshift) {
+                                                         unsigned* __restrict__ tbits, long long nbins, int tshift) {
     const int lane = threadIdx.x & 63;
     long long r = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long stride = (long long)gridDim.x * (blockDim.x >> 6);
@@ -487,12 +499,30 @@ PUP_KERNEL __launch_bounds__(256) void tbits_fill_kernel(const long long* __rest
         const long long b = indptr[r], e = indptr[r + 1];
         for (long long k0 = b; k0 < e; k0 += 64) {
             const long long k = k0 + lane;
-            if (k < e) {
-                const int col = px[k].x >> tshift;
-                atomicOr(&tbits[(long long)(col >> 6) * nbins + r], 1ull << (col & 63));
+            const bool live = k < e;
+            const int cc = live ? (px[k].x >> tshift) : -1;
+            int cb = live ? (cc >> 4) : -2 - lane;                  // (idle lanes: blocks of their own, never written)
+            unsigned bits = live ? (1u << (cc & 15)) : 0u;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned ob = __shfl_up(bits, d);
+                const int ocb = __shfl_up(cb, d);
+                if (lane >= d && ocb == cb) bits |= ob;
+            }
+            const int ncb = __shfl_down(cb, 1);
+            if (live && (lane == 63 || ncb != cb)) {                // the run's last lane holds the OR of the whole run
+                atomicOr(&tbits[(long long)cb * nbins + r], bits);
+                if (cb > 0) atomicOr(&tbits[(long long)(cb - 1) * nbins + r], bits << 16);
             }
         }
     }
+}
+// the word of a window's row: index of its column block
+__device__ __forceinline__ long long tbits_block(int c0, int tshift) { return (long long)((c0 >> tshift) >> 4); }
+// filter bits of a window's columns from its row's word: bit i <=> filter column (c0 >> tshift) + i may hold a pixel
+__device__ __forceinline__ unsigned tbits_window(unsigned w, int c0, int W, int tshift) {
+    const int cc0 = c0 >> tshift, span = ((c0 + W - 1) >> tshift) - cc0 + 1;      // span <= 17 for W <= 63, tshift >= 2
+    return (w >> (cc0 & 15)) & ((1u << span) - 1u);
 }
 
 // ---- K1r: register-tile variant for small windows (W <= 32) ----------------------------------------------
@@ -805,7 +835,7 @@ __global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
 
     // one window's state between its phases; four windows are in flight per wave (their load chains interleave)
     constexpr int LEAF = 4;                                          // pixels of a row looked at in registers (two 16-byte loads; 8: the same time)
-    struct Win { int r0, c0; bool valid, e_ok; unsigned long long rowmask, colmask, wa, wb; double e; long long lo, b, hi; int x[LEAF];
+    struct Win { int r0, c0; bool valid, e_ok; unsigned long long rowmask, colmask; unsigned wa, wb; double e; long long lo, b, hi; int x[LEAF];
                  int first, first_q; double first_v; };              // first pixel of the leaf inside the window (-1: none), its column, its value
     // masked-bin bits of bins [bin, bin + 64).  Worked out per BATCH, a lane per window (vector loads, all in flight together),
     // and handed to the window's turn by readlane: as scalar loads inside the window's turn they were sixteen dependent
@@ -836,28 +866,18 @@ __global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
             w.e = es.is_scalar ? es.scalar : qnan;
             w.e_ok = (w.e == w.e) && (w.e != 0.0);
         }
-        w.rowmask = rowmask; w.colmask = colmask; w.wa = ~0ull; w.wb = ~0ull;
-        if (rowlane && a.tbits != nullptr) {
-            // which columns of this lane's matrix row hold a pixel: the words of the one or two 64-column blocks under the
-            // window (consecutive lanes = consecutive rows = consecutive words: two coalesced loads per window)
-            const long long myrow = (long long)r0 + lane;
-            const int cc0 = c0 >> a.tshift, cc1 = (c0 + W - 1) >> a.tshift;       // the window's (coarse) filter columns
-            const long long cbk = cc0 >> 6;
-            w.wa = a.tbits[cbk * a.nbins + myrow];
-            w.wb = (cc1 >> 6) > cbk ? a.tbits[(cbk + 1) * a.nbins + myrow] : 0ull;
-        }
+        w.rowmask = rowmask; w.colmask = colmask; w.wa = ~0u; w.wb = 0u;
+        if (rowlane && a.tbits != nullptr)
+            // which columns of this lane's matrix row hold a pixel: the word of the column block under the window
+            // (consecutive lanes = consecutive rows = consecutive words: one coalesced load per window)
+            w.wa = a.tbits[tbits_block(c0, a.tshift) * a.nbins + (long long)r0 + lane];
     };
     // phase 2 (the bitmap words of every window in flight have been requested): the pixel range of the rows that hold a pixel
     // inside the window — three rows in a hundred; the others are done
     auto ranges = [&](Win& w, int kc) __attribute__((always_inline)) {
         if (!w.valid || !rowlane) return;
         if (a.tbits != nullptr) {
-            const int cc0 = w.c0 >> a.tshift, span = ((w.c0 + W - 1) >> a.tshift) - cc0 + 1;
-            const int sh = cc0 & 63;
-            unsigned long long bits = w.wa >> sh;
-            if (sh) bits |= w.wb << (64 - sh);
-            const unsigned long long fm = a.tshift ? (span >= 64 ? ~0ull : ((1ull << span) - 1ull)) : wmask;
-            if ((bits & fm) == 0ull) return;                          // no pixel of this row inside the window
+            if (tbits_window(w.wa, w.c0, W, a.tshift) == 0u) return;     // no pixel of this row inside the window
         }
         const long long myrow = (long long)w.r0 + lane;
         if (a.rowabs != nullptr) {
@@ -1002,6 +1022,353 @@ __global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
         on[cell] = n_e - trb[p] - tcb[q] + rc;
     }
     for (int t = lane; t < 2 * W; t += kWave) of[W2 + t] = m_cov ? tcov[t] : 0.0;
+    for (int off = 32; off > 0; off >>= 1) { npix += __shfl_down(npix, off); nprobe += __shfl_down(nprobe, off); }
+    if (lane == 0 && a.counters) { atomicAdd(&a.counters[0], npix); atomicAdd(&a.counters[1], nprobe); }
+}
+
+// ---- K1s, round 6: the same kernel around per-lane HIT QUEUES -------------------------------------------------------------
+// In pileup_sparse_kernel a window's turn — pixel range, bisection, leaf, value, add — is executed by the 64 lanes of the wave for
+// the three rows in a hundred that hold a pixel under the window: ~300 vector and ~160 scalar instructions per window, 97 % of
+// their lanes idle (counters, round 3 / 5: waves waiting 66 %, 0.11 of the HBM peak on the traffic).  Here the batch of 64
+// windows is walked TWICE:
+//   phase A: the factorised-count bookkeeping with a lane per WINDOW (its masked-row / masked-column words -> integer atomics), then
+//            per window (uniform) one coalesced load of the filter words of its rows and the hit test — a lane whose row MAY hold
+//            a pixel appends the window's number to ITS OWN queue (LDS, 64 entries x 64 lanes, slot-major: q[slot][lane]);
+//   phase B, per queue slot: lane p takes the slot-th window of its queue — its OWN window, coordinates by ds_bpermute from the
+//            lane that holds them — and runs the lookup chain for (that window, row p): every lane with a queued hit is busy.
+// A batch holds ~1.5 hits per window = ~2 per lane: phase B is one or two rounds of U = 4 chains instead of 64 / 8 rounds of 8.
+// Lane p still owns row p of the chunk's record and meets its windows in batch order, its pixels in column order: the adds of a
+// cell are the ones the first form makes, in the same order — the two forms agree bit for bit (tests run both: tuning bit 21).
+constexpr int kSparseLdsChroms = 256;                    // chromosome ends kept in LDS for the batch set-up (more: bisection in global memory)
+__host__ __device__ inline size_t k1sq_lds_bytes(int W) { return k1s_lds_bytes(W) + 64 * 64 + 8 + kSparseLdsChroms * sizeof(int); }
+
+#ifndef PUP_K1S_CLOCKS
+#define PUP_K1S_CLOCKS 0
+#endif
+#ifndef PUP_K1S_NA
+#define PUP_K1S_NA 16
+#endif
+#ifndef PUP_K1S_WAVES
+#define PUP_K1S_WAVES 4
+#endif
+#ifndef PUP_K1S_U
+#define PUP_K1S_U 4
+#endif
+template <bool OOE>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(PUP_K1S_WAVES, PUP_K1S_WAVES))) void pileup_sparse_queue_kernel(K1Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int W = a.W, W2 = W * W;
+    double*   tcov = reinterpret_cast<double*>(smem_raw);            // [2W]
+    unsigned* trb  = reinterpret_cast<unsigned*>(tcov + 2 * W);      // [W]   R
+    unsigned* tcb  = trb + W;                                        // [W]   C
+    unsigned char* queue = reinterpret_cast<unsigned char*>(tcb + W);               // [64 slots][64 lanes]: window numbers
+    int* s_cend = reinterpret_cast<int*>(queue + 64 * 64);           // [n_chrom <= kSparseLdsChroms] chromosome ends (24 W + 4096 bytes in: aligned)
+    const int lane = threadIdx.x;
+    const int ck = a.block_chunk[blockIdx.x];
+    if (ck < 0) return;
+#if PUP_K1S_CLOCKS
+    // (dev builds, -DPUP_K1S_CLOCKS=1: per-wave clocks of the phases leave through the two diagnostic counters, packed as
+    // clocks / 16 in 32-bit halves: [0] = total | phase A << 32, [1] = phase B | batch set-up << 32 — tools/probe_trans.py PHASES=1)
+    const long long tk0 = (long long)__builtin_readcyclecounter();
+    long long tkA = 0, tkB = 0, tkS = 0;
+#endif
+    unsigned* trc = a.part_num + (size_t)ck * W2;                    // [W2]  RC, accumulator frame, in the chunk's own record
+    double*   tsum = a.part_f64 + (size_t)ck * ((size_t)W2 + 2 * (size_t)W);   // [W2] the chunk's sums, accumulator frame (map_cell)
+    for (int t = lane; t < W2; t += kWave) { tsum[t] = 0.0; trc[t] = 0u; }
+    for (int t = lane; t < 2 * W; t += kWave) tcov[t] = 0.0;
+    for (int t = lane; t < W; t += kWave) { trb[t] = 0u; tcb[t] = 0u; }
+    const bool lds_chroms = a.rowabs != nullptr && a.n_chrom <= kSparseLdsChroms;
+    if (lds_chroms) for (int t = lane; t < a.n_chrom; t += kWave) s_cend[t] = a.idx_chrom[t].end;
+    // the zeros have reached L2 before any atomic of this wave gets there: the wave waits for its stores' acknowledgements
+    // (workgroup scope = s_waitcnt vmcnt(0); the record is this wave's alone and its atomics execute in the same XCD's L2 — the
+    // agent-scope release of the first form also wrote the whole L2 back, `buffer_wbl2 sc1`, once per wave)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+
+    const bool m_cov = (a.mode & 0x04u) && a.cov != nullptr;
+    const bool m_tr  = a.mode & 0x08u;
+    const bool use_exp = OOE && ((a.expv != nullptr && a.nexp > 0) || a.n_exp_regions > 0);
+    const double qnan = __builtin_nan("");
+    const long long cb = a.chunk_begin[ck], ce = a.chunk_end[ck], cstep = a.chunk_stride[ck];
+    const int fl = a.chunk_flip[ck];
+    ExpCache ecache;
+    unsigned n_e = 0;                                                // wave-uniform
+    double cov_s = 0.0, cov_e = 0.0;                                 // lane p: coverage sums of window row / column p
+    unsigned long long npix = 0, nprobe = 0;
+    const bool rowlane = lane < W;
+    const unsigned long long wmask = W >= 64 ? ~0ull : ((1ull << W) - 1ull);
+    const bool filt = a.tbits != nullptr;
+    const int tsh = a.tshift;
+    const bool from_counts = a.cntf == nullptr;                      // (uniform) pixel values formed from the leaf's counts and the weight vector
+
+    auto bits64 = [&](int bin) __attribute__((always_inline)) -> unsigned long long {
+        const unsigned long long* wd = a.badbits + (bin >> 6);
+        const int sh = bin & 63;
+        unsigned long long v = wd[0] >> sh;
+        if (sh) v |= wd[1] << (64 - sh);
+        return v;
+    };
+    // value of `v` in lane `src` (per lane: ds_bpermute goes through the LDS crossbar, no memory)
+    auto from32 = [&](int v, int src) __attribute__((always_inline)) -> int { return __builtin_amdgcn_ds_bpermute(src << 2, v); };
+    auto from64 = [&](unsigned long long v, int src) __attribute__((always_inline)) -> unsigned long long {
+        return ((unsigned long long)(unsigned)from32((int)(v >> 32), src) << 32) | (unsigned)from32((int)(unsigned)v, src);
+    };
+
+    constexpr int LEAF = 4;                                          // pixels of a row looked at in registers (two 16-byte loads)
+    constexpr int NA = PUP_K1S_NA;                                   // windows of phase A whose filter words are in flight together
+    constexpr int U = PUP_K1S_U;                                     // queue slots of phase B in flight per lane
+#if PUP_K1S_CLOCKS
+    const long long tkP = (long long)__builtin_readcyclecounter() - tk0;
+#endif
+    auto coord = [&](long long s0, const int* __restrict__ src) { const long long sl = s0 + (long long)lane * cstep; return sl < ce ? src[sl] : 0; };
+    int r0n = coord(cb, a.r0), c0n = coord(cb, a.c0);
+    for (long long s0 = cb; s0 < ce; s0 += (long long)kWave * cstep) {
+#if PUP_K1S_CLOCKS
+        const long long tkb0 = (long long)__builtin_readcyclecounter();
+#endif
+        const int r0v = r0n, c0v = c0n;
+        r0n = coord(s0 + (long long)kWave * cstep, a.r0); c0n = coord(s0 + (long long)kWave * cstep, a.c0);
+        const long long left = (ce - s0 + cstep - 1) / cstep;
+        const int nb = (int)(left < kWave ? left : kWave);
+        // per batch, a lane per window: is it inside the table, masked-bin words of its rows / columns, the chromosome of its columns
+        unsigned long long rmv = 0ull, cmv = 0ull;
+        int kcv = 0;
+        const bool okv = lane < nb && r0v >= 0 && c0v >= 0 && (long long)r0v + W <= a.nbins && (long long)c0v + W <= a.nbins;
+        if (okv) {
+            rmv = bits64(r0v) & wmask; cmv = bits64(c0v) & wmask;
+            if (a.rowabs != nullptr) {
+                // (the chromosome table in LDS: five dependent global loads per batch were a tenth of the kernel — phase clocks)
+                int lo = 0, hi = a.n_chrom;
+                if (lds_chroms) { while (lo < hi) { const int m = (lo + hi) >> 1; if (s_cend[m] <= c0v) lo = m + 1; else hi = m; } }
+                else { while (lo < hi) { const int m = (lo + hi) >> 1; if (a.idx_chrom[m].end <= c0v) lo = m + 1; else hi = m; } }
+                kcv = lo < a.n_chrom ? lo : a.n_chrom - 1;
+            }
+        }
+        const unsigned long long okm = __ballot(okv);                // (uniform) windows of the batch inside the table
+        if (okm != (nb >= 64 ? ~0ull : ((1ull << nb) - 1ull)) && lane == 0) atomicExch(a.err, 1);
+        unsigned long long evv = 0ull;                               // OOE: lane j holds the expected of window j (bits of the double)
+        int cnt = 0;                                                 // entries of this lane's queue
+
+#if PUP_K1S_CLOCKS
+        const long long tkb1 = (long long)__builtin_readcyclecounter();
+        tkS += tkb1 - tkb0;
+#endif
+        // ---- phase A ----------------------------------------------------------------------------------------------------------
+        // (1) the factorised counts, a LANE PER WINDOW (round 6, second pass: walked window by window with the whole wave — two
+        // 64-bit mask tests, two counters and a branch per window — this bookkeeping was most of the kernel's ~100 vector and ~85
+        // scalar instructions per window, and instruction issue is what the kernel is bound by once it no longer waits for
+        // memory: counters, SIMDs busy > 90 %).  Lane j walks the set bits of ITS window's masked-row / masked-column words:
+        // integer LDS atomics for R[p] and C[q], the record's own cells (L2 atomics) for the pairs — exact, order-free.
+        unsigned long long eokm = okm;                               // (uniform) windows that count: inside the table, usable expected
+        if (OOE) {
+            for (int ju = 0; ju < nb; ++ju) {
+                if (!((okm >> ju) & 1ull)) continue;
+                const int r0 = __builtin_amdgcn_readlane(r0v, ju), c0 = __builtin_amdgcn_readlane(c0v, ju);
+                ExpSel es; es.base = a.expv; es.len = 0; es.scalar = qnan; es.is_scalar = true;
+                if (use_exp) es = select_expected(a, ecache, r0, c0);
+                // trans expected is one scalar per region pair (the engine sends by-diagonal vectors to the dense kernels)
+                const double e = es.is_scalar ? es.scalar : qnan;
+                if (!((e == e) && (e != 0.0))) eokm &= ~(1ull << ju);
+                if (lane == ju) evv = (unsigned long long)__double_as_longlong(e);
+            }
+        }
+        n_e += (unsigned)__builtin_popcountll(eokm);
+        {
+            const bool mine = (eokm >> lane) & 1ull;
+            const unsigned long long rm = mine ? rmv : 0ull, cmk = mine ? cmv : 0ull;
+            for (unsigned long long x = rm; x; x &= x - 1) atomicAdd(&trb[__ffsll((long long)x) - 1], 1u);
+            for (unsigned long long y = cmk; y; y &= y - 1) atomicAdd(&tcb[__ffsll((long long)y) - 1], 1u);
+            if (cmk)
+                for (unsigned long long x = rm; x; x &= x - 1) {
+                    const int p = __ffsll((long long)x) - 1;
+                    for (unsigned long long y = cmk; y; y &= y - 1) atomicAdd(&trc[map_cell(p, __ffsll((long long)y) - 1, W, m_tr, fl)], 1u);
+                }
+        }
+        // (2) coverage vectors (coverage_norm): lane p adds its bins of every window, in batch order
+        if (m_cov) {
+            for (int j = 0; j < nb; j += 8) {
+                double cr[8], cv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int ju = j + u < nb ? j + u : j;
+                    const int r0 = __builtin_amdgcn_readlane(r0v, ju), c0 = __builtin_amdgcn_readlane(c0v, ju);
+                    const bool on = rowlane && j + u < nb && ((okm >> ju) & 1ull);
+                    cr[u] = on ? a.cov[r0 + lane] : qnan; cv[u] = on ? a.cov[c0 + lane] : qnan;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double vs = m_tr ? cv[u] : cr[u], ve = m_tr ? cr[u] : cv[u];
+                    if (vs == vs) cov_s += vs;
+                    if (ve == ve) cov_e += ve;
+                }
+            }
+        }
+        // (3) the filter: which rows of which windows may hold a pixel under the window -> the lanes' queues
+        for (int j = 0; j < nb; j += NA) {
+            unsigned wa[NA];
+#pragma unroll
+            for (int u = 0; u < NA; ++u) {
+                const int ju = j + u < nb ? j + u : j;
+                wa[u] = ~0u;
+                if (filt && rowlane && ((okm >> ju) & 1ull)) {
+                    // which columns of this lane's matrix row hold a pixel: the word of the column block under the window
+                    // (consecutive lanes = consecutive rows = consecutive words: 4 W bytes, two or three lines)
+                    const int r0 = __builtin_amdgcn_readlane(r0v, ju), c0 = __builtin_amdgcn_readlane(c0v, ju);
+                    wa[u] = a.tbits[tbits_block(c0, tsh) * a.nbins + (long long)r0 + lane];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NA; ++u) {
+                const int ju = j + u;
+                if (ju >= nb || !((okm >> ju) & 1ull)) continue;      // (uniform)
+                const int c0 = __builtin_amdgcn_readlane(c0v, ju);
+                const bool hit = rowlane && (!filt || tbits_window(wa[u], c0, W, tsh) != 0u);
+                if (hit) { queue[cnt * kWave + lane] = (unsigned char)ju; ++cnt; }
+            }
+        }
+
+#if PUP_K1S_CLOCKS
+        const long long tkb2 = (long long)__builtin_readcyclecounter();
+        tkA += tkb2 - tkb1;
+#endif
+        // ---- phase B: lane p and the windows of ITS queue, U at a time ----------------------------------------------------------
+        for (int t = 0; __ballot(t < cnt) != 0ull; t += U) {
+            bool live[U], rbad[U];
+            int r0[U], c0[U];
+            unsigned long long cm[U];
+            double ev[U];
+            long long lo[U], bnd[U], hi[U];
+            double wrow[U];                                           // weight of the lane's matrix row (values from counts: below)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                live[u] = t + u < cnt;
+                const int jw = live[u] ? (int)queue[(t + u) * kWave + lane] : 0;
+                rbad[u] = (from64(rmv, jw) >> lane) & 1ull;           // (bits past W are clear)
+                r0[u] = from32(r0v, jw); c0[u] = from32(c0v, jw);
+                cm[u] = from64(cmv, jw);
+                ev[u] = OOE ? __longlong_as_double((long long)from64(evv, jw)) : 1.0;
+                const int kc = from32(kcv, jw);
+                lo[u] = 0; hi[u] = 0; wrow[u] = 1.0;
+                if (live[u]) {
+                    const long long myrow = (long long)r0[u] + lane;
+                    if (a.rowabs != nullptr) { const uint2 sg = a.rowabs[(long long)kc * a.nbins + myrow]; lo[u] = sg.x; hi[u] = sg.y; }
+                    else { lo[u] = a.indptr[myrow]; hi[u] = a.indptr[myrow + 1]; }
+                    if (from_counts && a.weight) wrow[u] = a.weight[myrow];
+                }
+                bnd[u] = hi[u];
+            }
+            // the bisections in lockstep, until the lower bound is known to within LEAF - 1 pixels — the leaf [lo, lo + LEAF) then
+            // holds the first pixel at or after the window's first column; the probes of a step are independent loads
+            for (;;) {
+                bool any = false;
+#pragma unroll
+                for (int u = 0; u < U; ++u) any = any || (bnd[u] - lo[u] >= LEAF);
+                if (!__ballot(any)) break;
+                int x[U]; long long m[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) { m[u] = (lo[u] + bnd[u]) >> 1; x[u] = a.px[m[u]].x; }   // padded table: reading at a row's end is harmless
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (bnd[u] - lo[u] >= LEAF) { if (x[u] < c0[u]) lo[u] = m[u] + 1; else bnd[u] = m[u]; ++nprobe; }
+            }
+            int xs[U][LEAF], first[U], first_q[U], first_cnt[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool has = live[u] && lo[u] < hi[u];
+                const int2* src = a.px + (has ? lo[u] : 0);
+                first[u] = -1; first_q[u] = 0; first_cnt[u] = 0;
+#pragma unroll
+                for (int i = LEAF - 2; i >= 0; i -= 2) {              // (backwards: the FIRST pixel inside the window is what is kept)
+                    const int4 two = *reinterpret_cast<const int4*>(src + i);
+                    xs[u][i] = has ? two.x : 0x7fffffff; xs[u][i + 1] = has ? two.z : 0x7fffffff;
+                    const int q1 = xs[u][i + 1] - c0[u], q0 = xs[u][i] - c0[u];
+                    if (lo[u] + i + 1 < hi[u] && q1 >= 0 && q1 < W) { first[u] = i + 1; first_q[u] = q1; first_cnt[u] = two.w; }
+                    if (lo[u] + i < hi[u] && q0 >= 0 && q0 < W) { first[u] = i; first_q[u] = q0; first_cnt[u] = two.y; }
+                }
+            }
+            // value of pixel k = (row of the lane, column col, count cnt).  The leaf holds the COUNT beside the column, and the balanced
+            // value table is nothing but (count * w[row]) * w[col] with NaN products stored as 0 (balance_pixels_kernel): formed here, in
+            // that order, it is the same double — and the weights are a 2 MB vector that lives in L2, where `bal[k]` was one more random
+            // line from HBM per pixel found (a table of float pixel values keeps reading `bal`)
+            auto value_of = [&](int u, long long k, int col, int cnt_k, double wcol) __attribute__((always_inline)) -> double {
+                if (!from_counts) return a.bal[k];
+                double v = (double)cnt_k;
+                if (a.weight) { v = v * wrow[u] * wcol; if (!(v == v)) v = 0.0; }
+                return v;
+            };
+            double first_w[U];                                        // from_counts: the weight of the first pixel's column, else its value
+#pragma unroll
+            for (int u = 0; u < U; ++u) {                             // requested together for the U windows
+                first_w[u] = 0.0;
+                if (first[u] >= 0) first_w[u] = from_counts ? (a.weight ? a.weight[c0[u] + first_q[u]] : 1.0) : a.bal[lo[u] + first[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (first[u] < 0) continue;
+                // (no load on this path before the first add: see pileup_sparse_kernel)
+                auto add_value = [&](int q, double v) __attribute__((always_inline)) {
+                    ++npix;
+                    if (rbad[u] || ((cm[u] >> q) & 1ull)) return;     // masked bin: contributes nothing
+                    const double x = OOE ? v / ev[u] : v;
+                    if (x == x) unsafeAtomicAdd(&tsum[map_cell(lane, q, W, m_tr, fl)], x);
+                };
+                add_value(first_q[u], from_counts ? value_of(u, 0, 0, first_cnt[u], first_w[u]) : first_w[u]);
+                bool more = true;
+#pragma unroll
+                for (int i = 1; i < LEAF; ++i)
+                    if (i > first[u] && more) {
+                        const int q = xs[u][i] - c0[u];
+                        if (lo[u] + i < hi[u] && q < W)            // (a second pixel of the row inside the window: rare — its count comes from the table again)
+                            add_value(q, value_of(u, lo[u] + i, xs[u][i], from_counts ? a.px[lo[u] + i].y : 0, (from_counts && a.weight) ? a.weight[xs[u][i]] : 1.0));
+                        else more = false;
+                    }
+                if (more)
+                    for (long long k = lo[u] + LEAF; k < hi[u]; ++k) {
+                        const int2 pc = a.px[k];
+                        const int q = pc.x - c0[u];
+                        if (q >= W) break;
+                        add_value(q, value_of(u, k, pc.x, pc.y, (from_counts && a.weight) ? a.weight[pc.x] : 1.0));
+                    }
+            }
+        }
+#if PUP_K1S_CLOCKS
+        tkB += (long long)__builtin_readcyclecounter() - tkb2;
+#endif
+    }
+#if PUP_K1S_CLOCKS
+    const long long tkF0 = (long long)__builtin_readcyclecounter();
+#endif
+    if (m_cov && rowlane) { tcov[lane] = cov_s; tcov[W + lane] = cov_e; }
+    __syncthreads();
+    // ---- flush: num from the factorised counts; window frame -> accumulator frame ---------------------------
+    const size_t L = (size_t)W2 + 2 * (size_t)W;
+    double*   of = a.part_f64 + (size_t)ck * L;
+    unsigned* on = a.part_num + (size_t)ck * W2;
+    // RC was counted in place by L2 atomics; the rest of num joins it the same way — an atomic that returns nothing: reading RC
+    // back (past the L1) was a dependent round trip per cell and lane, 41 of them for a 51 x 51 record, 4-5 us each under this
+    // kernel's load (phase clocks, round 6).  u32 arithmetic wraps: the sum is what it would have been.
+    for (int t = lane; t < W2; t += kWave) {
+        const int p = t / W, q = t - p * W;
+        atomicAdd(&on[map_cell(p, q, W, m_tr, fl)], n_e - trb[p] - tcb[q]);
+    }
+    for (int t = lane; t < 2 * W; t += kWave) of[W2 + t] = m_cov ? tcov[t] : 0.0;
+#if PUP_K1S_CLOCKS
+    const long long tkF1 = (long long)__builtin_readcyclecounter();
+    __builtin_amdgcn_s_waitcnt(0);
+    if (lane == 0 && a.counters) {
+        const long long tkE = (long long)__builtin_readcyclecounter();
+        const unsigned long long tot = (unsigned long long)(tkE - tk0) >> 4;
+#if PUP_K1S_CLOCKS == 2
+        // (second set: prologue, flush issue, final drain)
+        atomicAdd(&a.counters[0], tot | ((unsigned long long)tkP >> 4) << 32);
+        atomicAdd(&a.counters[1], ((unsigned long long)(tkF1 - tkF0) >> 4) | ((unsigned long long)(tkE - tkF1) >> 4) << 32);
+#else
+        atomicAdd(&a.counters[0], tot | ((unsigned long long)tkA >> 4) << 32);
+        atomicAdd(&a.counters[1], ((unsigned long long)tkB >> 4) | ((unsigned long long)tkS >> 4) << 32);
+#endif
+    }
+    return;
+#endif
     for (int off = 32; off > 0; off >>= 1) { npix += __shfl_down(npix, off); nprobe += __shfl_down(nprobe, off); }
     if (lane == 0 && a.counters) { atomicAdd(&a.counters[0], npix); atomicAdd(&a.counters[1], nprobe); }
 }

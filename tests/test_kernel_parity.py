@@ -355,8 +355,13 @@ def test_trans_sparse_kernel_vs_oracle_and_dense(hip_lib, small_clr, oracle_mod,
     want = po.pileup_c(indptr, col, cnt, weight, covv, expv, r0, c0, flip, tile, T, pad, -1, mode)
     got = {}
     import os
-    for name, variant, shift in (("sparse", 0, None), ("sparse_exact_bitmap", 0, "0"), ("sparse_coarse_filter", 0, "7"), ("dense", 32, None)):
-        # (round 4: the presence bitmap is a filter of 2^k columns per bit — 16 by default, coarser when that does not fit; forced here)
+    # (round 6: the sparse kernel keeps per-lane hit queues; tuning bit 21 = its first form, walking every window with the whole
+    # wave — same adds in the same order: identical doubles; variant 1 = no presence filter at all: every row is a queued hit)
+    for name, variant, shift in (("sparse", 0, None), ("sparse_fine_filter", 0, "2"), ("sparse_coarse_filter", 0, "7"),
+                                 ("sparse_first_form", 1 << 21, None), ("sparse_no_filter", 1, None), ("sparse_first_form_no_filter", (1 << 21) | 1, None),
+                                 ("dense", 32, None)):
+        # (round 4: the presence bitmap is a filter of 2^k columns per bit — 16 by default, coarser when that does not fit; forced here.
+        # round 6: 16-bit words, k >= 2)
         if shift is None:
             os.environ.pop("COOLPUPPY_AMD_TBITS_SHIFT", None)
         else:
@@ -370,12 +375,12 @@ def test_trans_sparse_kernel_vs_oracle_and_dense(hip_lib, small_clr, oracle_mod,
         eng.reset(T, pad)
         eng.accumulate(r0, c0, tile_ptr, flip_from=ff, ignore_diags=-1, mode=mode)
         got[name] = eng.fetch()
-        if variant == 0:
+        if variant != 32:
             assert eng.last_kernel() == "sparse"
         eng.close()
         _compare(got[name], want)
     os.environ.pop("COOLPUPPY_AMD_TBITS_SHIFT", None)
     np.testing.assert_array_equal(got["sparse"]["num"], got["dense"]["num"])
-    for k in ("sparse_exact_bitmap", "sparse_coarse_filter"):
+    for k in ("sparse_fine_filter", "sparse_coarse_filter", "sparse_first_form", "sparse_no_filter", "sparse_first_form_no_filter"):
         np.testing.assert_array_equal(got[k]["num"], got["dense"]["num"])
         np.testing.assert_array_equal(got[k]["sum"], got["sparse"]["sum"])

@@ -448,7 +448,7 @@ def test_block_columns_renumbered_when_a_window_leaves_the_band(hip_lib):
 @pytest.mark.parametrize("S", [11, 33, 99])
 def test_rescaled_zoom_by_weights_equals_the_per_sample_zoom(hip_lib, S):
     """The rescaled pile-up's zoom as two sets of weights (separable bilinear interpolation + block mean) against the per-sample
-    loop it replaced (tuning bit 11 switches the weights off): windows smaller than the output (upsampling), equal, up to 9 x
+    loop it replaced (tuning bit 20 switches the weights off; until round 6 the test set bit 11, which pup_set_tuning reads as a group size: both runs took the weights): windows smaller than the output (upsampling), equal, up to 9 x
     larger, rectangular, local (symmetrised) and plain, with masked bins inside, observed over expected; accumulated tiles and
     per-window emission.  Same NaN pattern and counts; sums within rounding of the different addition order."""
     import synth
@@ -471,7 +471,7 @@ def test_rescaled_zoom_by_weights_equals_the_per_sample_zoom(hip_lib, S):
     pad = (S - 1) // 2
     for mode, igd in ((0x20, 2), (0, 0), (MODE_OOE | 0x20, 2)):
         res = {}
-        for variant in (0, 2048):
+        for variant in (0, 1 << 20):                     # tuning bit 20: the zoom sample by sample instead of by separable weights
             eng = PileupEngine(0)
             eng.load_pixels(*clr.pixel_table())
             eng.build_index(clr.chrom_offset)
@@ -484,7 +484,7 @@ def test_rescaled_zoom_by_weights_equals_the_per_sample_zoom(hip_lib, S):
             snips = eng.extract(r0[:60], c0[:60], pad, height=hgt[:60], width=wid[:60], ignore_diags=igd, mode=mode)
             res[variant] = (acc, snips[0] if isinstance(snips, tuple) else snips)
             eng.close()
-        a, b = res[0], res[2048]
+        a, b = res[0], res[1 << 20]
         np.testing.assert_array_equal(a[0]["num"], b[0]["num"])
         np.testing.assert_array_equal(a[0]["n"], b[0]["n"])
         np.testing.assert_allclose(a[0]["sum"], b[0]["sum"], rtol=1e-11, atol=0)

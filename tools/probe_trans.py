@@ -56,5 +56,9 @@ for C in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "0,100,70,50,35
         for c in plan["calls"]:
             eng.accumulate(c["r0"], c["c0"], c["tile_ptr"], flip_from=c["flip_from"], ignore_diags=c["ignore_diags"], mode=c["mode"])
         eng.sync(); st = eng.stats()
-        print("  clocks A, B summed over waves:", int(st["pixels_in_windows"]), int(st["probe_loads"]), flush=True)
+        # (a library built with COOLPUPPY_AMD_EXTRA_CXXFLAGS=-DPUP_K1S_CLOCKS=1: the sparse kernel's phase clocks, packed — see the kernel)
+        c0_, c1_ = int(st["pixels_in_windows"]), int(st["probe_loads"])
+        nw = -(-sum(len(c["r0"]) for c in plan["calls"]) // max(C, 1)) if C else None
+        print("  clocks summed over waves: total", (c0_ & 0xffffffff) << 4, "phase A", (c0_ >> 32) << 4, "phase B", (c1_ & 0xffffffff) << 4,
+              "batch set-up", (c1_ >> 32) << 4, "chunks (if C given)", nw, flush=True)
     print("chunk", C, "k1_ms, reduce_ms =", best, "same", bool(np.array_equal(out["num"], ref["num"]) and np.allclose(out["sum"], ref["sum"], rtol=1e-12)), flush=True)
