@@ -233,6 +233,7 @@ int check_async_error(pup_ctx* c) {
     if (h) {
         int zero = 0;
         HIPCHK(c, hipMemcpy(c->d_err.p, &zero, sizeof(int), hipMemcpyHostToDevice));
+        if (h == 2) return fail(c, PUP_EHIP, "the staged kernel gave up waiting for one of its own waves (progressive staging): results of this call are void — please report; it only runs with tuning bit 22");
         return fail(c, PUP_ERANGE, "a snippet window leaves the bin table [0, %lld)", c->nbins);
     }
     return PUP_OK;
@@ -1307,7 +1308,7 @@ static int staged_run(pup_ctx* c, const int* dr0, const int* dc0, int64_t n, con
             sa.timing = c->d_timing.p; c->timing_G = G;
         }
         if (ev) HIPCHK(c, hipEventRecord(ev[1], c->stream));
-        const pup::StagedLaunch sl{W, G, ACC, fact, extra, small21, band};
+        const pup::StagedLaunch sl{W, G, ACC, fact, extra, small21, band, (c->variant & 8192) != 0};
         if (!pup::launch_staged(sl, a, sa, c->stream))
             return fail(c, PUP_ENOTSUP, "pup_accumulate: staged kernel not built for W=%d", W);
         HIPCHK(c, hipGetLastError());
@@ -2551,7 +2552,7 @@ int pup_set_tuning(pup_ctx* c, int32_t chunk_snippets, int32_t variant) {
     c->chunk_snippets = chunk_snippets;
     c->forget_hints();
     c->variant = (variant & 0xff) | ((variant >> 19) & 0x700);   // bit 27 -> 256: never stage from the dense band; bit 28 -> 512: tile pairs one by one; bit 29 -> 1024: library sort in the prepass
-    c->variant |= ((variant >> 20) & 0x3) << 11;                 // bit 20 -> 2048: rescaled windows zoomed sample by sample; bit 21 -> 4096: the sparse trans kernel without hit queues
+    c->variant |= ((variant >> 20) & 0x7) << 11;                 // bit 20 -> 2048: rescaled windows zoomed sample by sample; bit 21 -> 4096: the sparse trans kernel without hit queues; bit 22 -> 8192: the staged kernel with progressive staging (no barrier between blocks: measured slower, round 6; 21-bin windows only)
     c->group_waves = (variant >> 8) & 0xfff;
     c->debug_phases = ((variant >> 24) & 0x7) | ((variant >> 27) & 0x8);     // (bit 30 -> 8: K1q without its factorised-count bookkeeping, timing only)
     return PUP_OK;

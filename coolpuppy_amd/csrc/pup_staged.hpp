@@ -81,6 +81,13 @@ constexpr int kSetPairs = 4;                          // tile pairs piled up tog
 constexpr int kSetSlotBits = 3;
 constexpr int kBandFront = 256;                       // cells in front of the band table's row 0 (see band_issue)
 constexpr int kMaxSegCount = 1024;                    // (tile, flip) runs one block-ordered call may have (key kernel LDS table)
+constexpr int kProgSpinLimit = 1 << 18;                 // polls (s_sleep 1 each: ~10 ms in all) a wave of the progressive kernel waits for another before it gives up
+// a waiting wave of the progressive kernel sleeps this long between polls (units of 64 clocks).  With s_sleep 1 a waiting wave — typically
+// the OLDEST of its SIMD, which the arbiter favours — spent most of its SIMD's issue slots polling: the waves still piling up ran 2.5 x slower
+#ifndef PUP_PROG_SLEEP
+#define PUP_PROG_SLEEP 8
+#endif
+constexpr int kProgSleep = PUP_PROG_SLEEP;
 constexpr int kBlockCost = 400;                       // staging one region, in windows' worth of time (workgroup ranges)
 constexpr int kMaxStagedTiles = kMaxSegCount / 2;     // (tile, flip) runs fit the key kernel's LDS table
 constexpr int kKeyMaxChrom = 3072;                    // chromosomes whose table (12 bytes each) the key kernels keep in LDS; assemblies of more
@@ -146,9 +153,10 @@ template <int W, bool OOE, bool EXTRA, bool SMALL = false, bool FACT = true> str
 #ifndef PUP_K1Q_DUAL
 #define PUP_K1Q_DUAL 0
 #endif
-template <int W, bool OOE, int RSR, int RSC, int NW, int ACC, bool FACT, bool EXTRA, bool BAND = false, bool DB = false>
+template <int W, bool OOE, int RSR, int RSC, int NW, int ACC, bool FACT, bool EXTRA, bool BAND = false, bool DB = false, bool PROG = false>
 __global__ __launch_bounds__(kWave * NW, 1)
 void pileup_staged_kernel(K1Args a, StagedArgs sa) {
+    static_assert(!PROG || (BAND && FACT && !OOE && !EXTRA && !DB && NW == 16 && RSR == 128 && RSC == 128), "progressive staging: band, factorised counts, 128 x 128 regions on sixteen waves");
     static_assert(!(BAND && EXTRA), "pixel statistics need the presence bits of the index: sparse staging");
     static_assert(!DB || (BAND && FACT && !OOE && !EXTRA), "double-buffered regions: band staging, factorised counts, no expected");
     static_assert(W >= 3 && W <= 31, "workgroup-staged kernel serves windows of 3..31 bins");
@@ -184,6 +192,9 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
     // FACT: num[p][q] = N - R[p] - C[q] + RC[p][q] (see fact_batch): the sparse both-masked pairs, and the totals
     __shared__ unsigned rc_lds[ACC][FACT ? W2 : 1];
     __shared__ unsigned fact_tot[FACT ? ACC * (2 * W + 1) : 1];     // per slot: R[W] | C[W] | N
+    // PROG: prog_p[w] = block * 32 + first 8-row bucket wave w may still read in that block (16: done with it) — monotone;
+    //       prog_s[w] = newest block whose rows [8 w, 8 w + 8) wave w has stored
+    __shared__ unsigned prog_p[PROG ? 16 : 1], prog_s[PROG ? 16 : 1];
     const int tid  = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -866,6 +877,215 @@ void pileup_staged_kernel(K1Args a, StagedArgs sa) {
         __syncthreads();
     };
 
+    // ---- the block loop, PROGRESSIVE staging (round 6): no barrier between blocks ------------------------------------------------
+    // One buffer, one region — but a region row is dead as soon as no window that is still to come reads it.  Every wave puts the
+    // windows of its slice into ROW order (buckets of eight rows: a counting sort over the lanes of a batch, ballots and one
+    // ds_permute), publishes the bucket of its next window, and owns eight region rows as before: wave w stores rows [8 w, 8 w + 8)
+    // of block b + 1 as soon as EVERY wave's next window of block b lies below them, and a window of block b + 1 is read once the
+    // waves owning its rows have stored them.  The store burst and both barriers of the barrier form (26 % of its clocks: phase
+    // clocks, round 5) dissolve into the window phase of the neighbouring blocks; a wave may run most of a block ahead of the
+    // slowest one.  A wave enters block b + 1 only after storing its own rows of it, so whoever waits for rows of b + 1 waits for
+    // waves still in block b, which wait for nobody ahead of them: no cycle.  A change of segment (the accumulators are flushed
+    // through the region buffer) falls back to the barrier form for that one block.  Same integers as every other kernel; the sums
+    // are added in (bucket, arrival) order — fixed, bit-reproducible.
+    if constexpr (PROG) {
+        constexpr int KMAX = (RSR - W) >> 3;                            // last bucket that holds a corner (W = 21: 13; W <= 7: 15)
+        constexpr int IDLE = 16;                                        // bucket of the lanes behind a batch's windows
+        constexpr int DONE = 17;                                        // progress value "no window of this block left"
+        if (tid < 16) { prog_p[tid] = 0u; prog_s[tid] = 0u; }
+        int ev0 = entry_load(bb), ev1 = ev0, evn = ev0;
+        int v[NRH];
+        double wc[NH], wrv = 1.0;
+        int w0f, w1f = 0;
+        const ExpSel es_none = exp_of(ev0);                            // (no expected in this instantiation)
+        {   // prologue: stage block bb without overlap, request the counts of bb + 1
+            band_issue(ev0, v, wc, wrv);
+            set_team(fld(ev0, 20) >> 1);
+            first_coords(ev0, w0f);
+            if (bb + 1 < be) ev1 = entry_load(bb + 1);
+            __syncthreads();
+            if (nf) band_store(std::true_type{}, ev0, v, wc, wrv, es_none); else band_store(std::false_type{}, ev0, v, wc, wrv, es_none);
+            if (bb + 1 < be) band_issue(ev1, v, wc, wrv);
+            __syncthreads();
+        }
+        long long tk[6] = {0, 0, 0, 0, 0, 0}, tmid = 0;
+        const bool timed = sa.timing != nullptr;
+        auto tick = [&]() __attribute__((always_inline)) -> long long { return timed ? (long long)__builtin_readcyclecounter() : 0; };
+        // all sixteen waves at or past `target` = block * 32 + bucket ?
+        auto all_past = [&](unsigned target) __attribute__((always_inline)) -> bool {
+            const unsigned pv = prog_p[lane & 15];
+            return (__ballot(pv >= target) & 0xffffull) == 0xffffull;
+        };
+        // waves 0 .. n-1 have stored their rows of block lb: n
+        auto stored_upto = [&](unsigned lb) __attribute__((always_inline)) -> int {
+            const unsigned sv = prog_s[lane & 15];
+            const unsigned long long okb = __ballot(sv >= lb) & 0xffffull;
+            return (int)__builtin_ctzll(~okb);
+        };
+        for (int b = bb; b < be; ++b) {
+            const unsigned lb = (unsigned)(b - bb);
+            const bool has1 = b + 1 < be, has2 = b + 2 < be;
+            const long long t0 = tick();
+            const int seg0 = fld(ev0, 20), seg1 = has1 ? fld(ev1, 20) : seg0;
+            const bool barrier_mode = has1 && seg1 != seg0;            // (uniform) another segment follows: the accumulators go out through
+                                                                       // the region buffer — the barrier form for this one block
+            if (has1) first_coords(ev1, w1f);                          // (same unit: same teams — a new unit reloads them below)
+            if (has2) evn = entry_load(b + 2);
+            const Cur g = cur_of(ev0);
+            bool todo_store = has1, force = false;
+            int spins = 0;
+            int avail = __builtin_amdgcn_readfirstlane(lb == 0 ? 16 : 0);                              // waves whose rows of THIS block are known to be stored
+            unsigned published = lb * 32u;
+            const unsigned my_target = lb * 32u + (unsigned)(wave + 1 <= KMAX ? wave + 1 : DONE);     // everybody past this: my rows are dead
+            auto publish = [&](int bucket) __attribute__((always_inline)) {
+                const unsigned val = (unsigned)__builtin_amdgcn_readfirstlane((int)(lb * 32u + (unsigned)bucket));
+                if (val != published) { published = val; if (lane == 0) prog_p[wave] = val; }
+            };
+            int lo, hi;
+            slice_of(g.first, g.n, lo, hi);
+            lo = __builtin_amdgcn_readfirstlane(lo); hi = __builtin_amdgcn_readfirstlane(hi);     // (float arithmetic: they come out of vector registers)
+            const long long t1 = tick();
+            long long t2 = t1;
+            int wf = w0f;
+            for (int s0 = lo; ; s0 += kWave) {
+                const int left = hi - s0;
+                const int nb = __builtin_amdgcn_readfirstlane(left < 0 ? 0 : (left < kWave ? left : kWave));
+                const bool last_batch = s0 + kWave >= hi;
+                // the batch in row-bucket order: rank = windows in lower buckets + lanes before this one in its bucket; lane k of
+                // `bstart` keeps the number of windows in buckets below k = where bucket k begins in the sorted batch
+                const long long ts0 = tick();
+                const int dr_u = wf & ((1 << kWinShift) - 1), dc_u = (wf >> kWinShift) & ((1 << kWinShift) - 1);
+                if (!last_batch) wf = load_batch(g.start, s0 + kWave, hi);             // next batch of a long slice
+                if (nb > 0) fact_batch(g, dr_u, dc_u, nb);
+                const int bk_u = lane < nb ? (dr_u >> 3) : IDLE;       // (idle lanes behind every window)
+                int rank = 0, base = 0, bstart = 0;
+#pragma unroll
+                for (int kb = 0; kb <= IDLE; ++kb) {
+                    const unsigned long long mk = __ballot(bk_u == kb);
+                    const int before = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                    rank = bk_u == kb ? base + before : rank;
+                    bstart = lane == kb ? base : bstart;
+                    base += (int)__builtin_popcountll(mk);
+                }
+                const int packed = __builtin_amdgcn_ds_permute(rank << 2, dr_u | (dc_u << 8));     // lane `rank` receives this window
+                const int drv = packed & 0xff;
+                int offv = 8 * (drv * LS + ((packed >> 8) & 0xff));
+                if (sa.debug & 8) offv = 8 * (dr_u * LS + dc_u);       // (timing experiment, wrong sums: the reads in the unsorted order)
+                tk[3] += tick() - ts0;
+                int next_check = 0;                                    // first window of the next bucket: where the slow path below runs again
+                // before the reads of window j, the first of its bucket, are issued: what this wave may still read is published (the
+                // window before it is still in flight: ITS bucket), the rows of the new bucket must have been stored
+                auto boundary = [&](int j) __attribute__((always_inline)) {
+                    const int kb = __builtin_amdgcn_readlane(drv, j) >> 3;
+                    if (last_batch) publish(j > 0 ? (__builtin_amdgcn_readlane(drv, j - 1) >> 3) : kb);
+                    int need = (8 * kb + 7 + W - 1) >> 3;              // owner of the last row a window of this bucket may read
+                    need = need < NW - 1 ? need : NW - 1;              // (corners stop at row RSR - W: the region's last row is wave 15's)
+                    if (need >= avail) {
+                        const long long e0 = tick();
+                        while (need >= avail) {
+                            avail = __builtin_amdgcn_readfirstlane(stored_upto(lb));
+                            if (need >= avail) {
+                                __builtin_amdgcn_s_sleep(kProgSleep);
+                                if (++spins > kProgSpinLimit) { if (lane == 0) atomicExch(a.err, 2); avail = 16; }     // (never seen: a wedged workgroup ends with an error instead of hanging the queue)
+                            }
+                        }
+                    }
+                    next_check = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_readlane(bstart, kb + 1));
+                };
+                auto gather = [&](int j, double (&vv)[CH], unsigned& ad) __attribute__((always_inline)) {
+                    ad = lane_off8 + (unsigned)__builtin_amdgcn_readlane(offv, j);
+                    LdsReadRow<0, CH, 8 * NCH>::go(vv, ad);
+                };
+                if (!last_batch) publish(0);
+                // The batch goes through in SEGMENTS: a segment ends where this wave may first be allowed to store its rows of the next
+                // block (the start of the bucket behind its rows; one bucket at a time while the others are not there yet) — the ONE
+                // place where block b + 1 is stored and b + 2 requested — else at the batch's end.  Inside a segment the window loop is
+                // K1q's (two windows in flight, no check but the bucket boundary).
+                int j0 = 0;
+                for (;;) {
+                    const bool tail = j0 >= nb && last_batch;
+                    if (tail) {
+                        publish(DONE);
+                        if (t2 == t1) t2 = tick();
+                        if (barrier_mode && !force) {
+                            flush(seg0);
+                            if (ACC > 1 && (seg1 >> 1) != (seg0 >> 1)) { set_team(seg1 >> 1); first_coords(ev1, w1f); }
+                            force = true;
+                        }
+                    }
+                    if (todo_store) {
+                        bool go = force;
+                        if (!force && !barrier_mode && published >= my_target) {
+                            const long long e0 = tick();
+                            go = all_past(my_target);
+                        }
+                        if (go) {
+                            const long long m0 = tick();
+                            if (!(sa.debug & 2)) { if (nf) band_store(std::true_type{}, ev1, v, wc, wrv, es_none); else band_store(std::false_type{}, ev1, v, wc, wrv, es_none); }
+                            if (lane == 0) prog_s[wave] = lb + 1u;     // (behind the row stores: LDS operations of a wave stay in order)
+                            if (force && barrier_mode) __syncthreads();
+                            if (has2 && !(sa.debug & 2)) band_issue(evn, v, wc, wrv);
+                            todo_store = false;
+                            tmid += tick() - m0;
+                        }
+                    }
+                    if (j0 >= nb) {
+                        if (!tail || !todo_store) break;
+                        __builtin_amdgcn_s_sleep(kProgSleep);
+                        if (++spins > kProgSpinLimit) { if (lane == 0) atomicExch(a.err, 2); force = true; }
+                        continue;
+                    }
+                    int j1 = nb;
+                    if (todo_store && !barrier_mode && last_batch && !(sa.debug & 1)) {      // (debug 1, timing experiments: one segment, the store behind the last window)
+                        const int kb0 = __builtin_amdgcn_readlane(drv, j0) >> 3;
+                        const int kt = kb0 + 1 > wave + 1 ? kb0 + 1 : wave + 1;
+                        j1 = kt <= KMAX ? __builtin_amdgcn_readlane(bstart, kt) : nb;
+                    }
+                    j1 = __builtin_amdgcn_readfirstlane(j1);
+                    {   // windows [j0, j1)
+                        const long long tl0 = tick();
+                        tk[5] += timed ? (j1 - j0) : 0;
+                        double va[CH], vb[CH]; unsigned a0, b0;
+                        int jj = __builtin_amdgcn_readfirstlane(j0);
+                        if (sa.debug & 1) next_check = nb;              // (timing experiment: no bucket boundaries)
+                        if (jj >= next_check) boundary(jj);
+                        gather(jj, va, a0);
+                        for (;;) {
+                            const bool n1 = jj + 1 < j1;
+                            if (n1 && jj + 1 >= next_check) boundary(jj + 1);
+                            gather(n1 ? jj + 1 : jj, vb, b0);
+                            lds_wait_but<CH>(a0, a0); lds_pin(va);
+#pragma unroll
+                            for (int i = 0; i < CH; ++i) sum[i] += va[i];
+                            if (!n1) break;
+                            const bool n2 = jj + 2 < j1;
+                            if (n2 && jj + 2 >= next_check) boundary(jj + 2);
+                            gather(n2 ? jj + 2 : jj + 1, va, a0);
+                            lds_wait_but<CH>(b0, b0); lds_pin(vb);
+#pragma unroll
+                            for (int i = 0; i < CH; ++i) sum[i] += vb[i];
+                            if (!n2) break;
+                            jj = __builtin_amdgcn_readfirstlane(jj + 2);
+                        }
+                        lds_wait_all(a0, b0, a0, b0); lds_pin(va); lds_pin(vb);      // the trailing read
+                        tk[4] += tick() - tl0;
+                    }
+                    j0 = j1;
+                    if (last_batch && j0 < nb) publish(__builtin_amdgcn_readlane(drv, j0) >> 3);   // (everything before j0 has landed)
+                }
+                if (last_batch) break;
+            }
+            if (!has1) { flush(seg0); if (timed) { tk[0] += t1 - t0; tk[1] += t2 - t1; } break; }
+            const long long t3 = tick();
+            ev0 = ev1; w0f = w1f; ev1 = evn;
+            if (timed) { tk[0] += t1 - t0; tk[1] += t2 - t1; tk[2] += t3 - t2; }
+        }
+        if (timed && lane == 0) {
+            long long* o = sa.timing + ((size_t)g_id * NW + wave) * 8;
+            for (int i = 0; i < 6; ++i) o[i] = tk[i];
+            o[6] = be - bb; o[7] = tmid;
+        }
+    } else
     // ---- the block loop, two buffers: region b is piled up from one buffer while b+1 is stored into the other (its counts were
     // requested while b-1 was piled up), b+2's counts are requested and b+3's table entry is on its way -------------------------
     if constexpr (DB) {

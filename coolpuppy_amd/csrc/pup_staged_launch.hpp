@@ -14,6 +14,7 @@ struct StagedLaunch {
     bool extra;          // coverage vectors and / or pixel statistics ride along
     bool small21;        // tuning probe: the plain 21-bin kernel on 64 x 128 regions
     bool band;           // regions staged from the dense band of counts
+    bool prog;           // progressive staging where the instantiation exists (band, factorised counts, no expected, 128 x 128 regions): no barrier between blocks
 };
 
 constexpr int kStagedParts = 8;

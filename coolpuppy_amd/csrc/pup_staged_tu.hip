@@ -14,6 +14,13 @@ namespace {
 template <int W, bool OOE, int ACC, bool FACT, bool EXTRA>
 void launch_kernel(const StagedLaunch& l, const K1Args& a, const StagedArgs& sa, hipStream_t s) {
     using Geo = StagedGeom<W, OOE, EXTRA, false, FACT>;
+    if constexpr (!EXTRA && FACT && !OOE && Geo::big && W == 21) {      // (an experiment kept for the record: instantiated for the bench's width only)
+        if (l.band && l.prog && !l.small21) {                // progressive staging (pup_staged.hpp: PROG), tuning bit 22
+            hipLaunchKernelGGL((pileup_staged_kernel<W, OOE, Geo::RSR, Geo::RSC, Geo::NW, ACC, FACT, EXTRA, true, false, true>), dim3(l.G),
+                               dim3(kWave * Geo::NW), 0, s, a, sa);
+            return;
+        }
+    }
     if constexpr (!EXTRA) {
         if (l.band && !(W == 21 && !OOE && l.small21)) {
             hipLaunchKernelGGL((pileup_staged_kernel<W, OOE, Geo::RSR, Geo::RSC, Geo::NW, ACC, FACT, EXTRA, true>), dim3(l.G),

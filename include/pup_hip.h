@@ -339,7 +339,8 @@ int pup_event_elapsed_ms(pup_ctx* ctx, int slot_begin, int slot_end, float* ms);
  * in the staged kernel, 8 = always use the staged kernel where it is eligible (tests), 16 = never use it, 32 = never use
  * the sparse trans kernel, 64 = no tile pairing in the staged kernel, 128 = the 21-bin staged kernel on 64 x 128 regions
  * (tuning probe), bits 8..19 = waves per interleaved group, bit 20 = rescaled windows zoomed sample by sample instead of by separable
- * weights, bit 21 = the sparse trans kernel without its per-lane hit queues (round 5's form), bit 26 = collect the staged kernel's phase clocks
+ * weights, bit 21 = the sparse trans kernel without its per-lane hit queues (round 5's form), bit 22 = the 21-bin staged kernel with
+ * progressive staging instead of a barrier between blocks (round 6 experiment, slower: DESIGN.md), bit 26 = collect the staged kernel's phase clocks
  * (pup_debug_timing), bit 27 = never stage from the dense band of counts, bit 28 = pile tile pairs up one by one instead of
  * four pairs per staging.
  * Staged kernel: a call of >= 4e5 cis windows (1.5e5 with observed over expected; W <= 31, every window inside one chromosome, index built, at most 64 tiles) is

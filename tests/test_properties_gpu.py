@@ -253,7 +253,11 @@ def test_staged_kernel_sets_of_tile_pairs(hip_lib, pad, T):
             if what != "plain" and (T, pad) not in ((10, 10), (16, 7)):
                 continue
             res = {}
-            for name, variant in (("plain", 16), ("sets", 8), ("pairs", 8 | (1 << 28)), ("sets again", 8), ("sets sparse", 8 | (1 << 27))):
+            # (round 6: tuning bit 22 = the progressive staging experiment — no barrier between blocks, windows of a wave in row-bucket
+            # order; instantiated for 21-bin windows: elsewhere the bit changes nothing)
+            for name, variant in (("plain", 16), ("sets", 8), ("pairs", 8 | (1 << 28)), ("sets again", 8), ("sets sparse", 8 | (1 << 27)),
+                                  ("sets progressive", 8 | (1 << 22)), ("pairs progressive", 8 | (1 << 28) | (1 << 22)),
+                                  ("sets progressive again", 8 | (1 << 22))):
                 eng.set_tuning(0, variant)
                 eng.set_expected(expv)
                 eng.reset(T, pad)
@@ -261,12 +265,13 @@ def test_staged_kernel_sets_of_tile_pairs(hip_lib, pad, T):
                 res[name] = (eng.fetch(), eng.stats()["staged_regions"])
             assert res["plain"][1] == 0
             assert 0 < res["sets"][1] < res["pairs"][1] or H < 2, (res["sets"][1], res["pairs"][1])
-            for name in ("sets", "pairs", "sets sparse"):
+            for name in ("sets", "pairs", "sets sparse", "sets progressive", "pairs progressive"):
                 for k in ("n", "num"):
                     np.testing.assert_array_equal(res[name][0][k], res["plain"][0][k], err_msg=f"{label} {what} {name} {k}")
                 np.testing.assert_allclose(res[name][0]["sum"], res["plain"][0]["sum"], rtol=1e-11, atol=0, equal_nan=True,
                                            err_msg=f"{label} {what} {name}")
             np.testing.assert_array_equal(res["sets again"][0]["sum"], res["sets"][0]["sum"])
+            np.testing.assert_array_equal(res["sets progressive again"][0]["sum"], res["sets progressive"][0]["sum"])
     eng.close()
 
 
