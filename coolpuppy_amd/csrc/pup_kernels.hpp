@@ -827,7 +827,6 @@ __global__ __launch_bounds__(kWave) void pileup_sparse_kernel(K1Args a) {
     const long long cb = a.chunk_begin[ck], ce = a.chunk_end[ck], cstep = a.chunk_stride[ck];
     const int fl = a.chunk_flip[ck];
     ExpCache ecache;
-    ChromOf colchrom;
     unsigned n_e = 0;                                                // wave-uniform
     unsigned long long npix = 0, nprobe = 0;
     const bool rowlane = lane < W;

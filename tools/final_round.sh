@@ -4,7 +4,7 @@
 # the per-config table, by-window / coverage / host-layer / phase-clock probes.  Everything lands under gpurun_out/prof_out/.
 # Usage: bash tools/final_round.sh <tag>
 set -u
-REPO="${GRAFT_REPO_ROOT:-/root/repo}"; TAG="${1:-r05}"; OUT="$REPO/gpurun_out/prof_out"
+REPO="${GRAFT_REPO_ROOT:-/root/repo}"; TAG="${1:-r06}"; OUT="$REPO/gpurun_out/prof_out"
 mkdir -p "$OUT"; cd "$REPO"
 timeout 1200 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3 > "$OUT/${TAG}_gputests.txt"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 >> "$OUT/${TAG}_gputests.txt"

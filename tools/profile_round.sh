@@ -6,7 +6,7 @@
 # copied under gpurun_out/prof_out/ (what gpurun brings back).  Usage: bash tools/profile_round.sh <tag> [set ...]   e.g. r05 k1q k1w_pad25
 set -u
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"
-TAG="${1:-r05}"; shift || true
+TAG="${1:-r06}"; shift || true
 SETS="${*:-k1q k1w_pad25 k1w_pad100 k1q_grouped k1s k1r bywindow}"
 mkdir -p "$REPO/gpurun_out/prof_out"
 for NAME in $SETS; do
