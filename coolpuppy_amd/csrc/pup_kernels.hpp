@@ -469,27 +469,21 @@ PUP_KERNEL __launch_bounds__(256) void rowabs_kernel(const long long* __restrict
     rowabs[t] = make_uint2(first_at(chroms[k].start), k + 1 < n_chrom ? first_at(chroms[k + 1].start) : (unsigned)end);
 }
 
-// Presence bitmap of the whole table for the sparse trans kernel: one wave per matrix row ORs a bit per pixel into
-// tbits[col / 64][row].  nbins^2 / 8 bytes — 11.5 GB for a human genome at 10 kb: this is what 288 GB of HBM are for.  A
-// trans window's W rows then need TWO coalesced loads (the words of W consecutive rows for the one or two 64-column blocks
-// the window's columns fall into) to learn which of its rows hold a pixel inside it and in which columns; without it every
-// (window, row) pair fetched a cache line of the pixel table — 2.5e7 random lines, 3 GB, per 4.9e5 windows — to find, 97 times
-// out of 100, nothing.  Built on the first call that uses the sparse kernel (pup_engine.hip: ensure_tbits).
-// Round 4: the bitmap is a FILTER — a set bit only sends the row to the real lookup — so for tables whose exact bitmap does not fit
-// (1.2e6 bins: 180 GB; a 1 kb human map: 1.2 TB) a bit stands for 2^tshift consecutive columns: the memory shrinks by that factor, the
-// loads stay two per window, and at trans densities (1e-4 and below) a handful of extra columns per window row changes the hit rate
-// from 0.36 % to 0.4 %.
-// Round 6: the filter is kept as OVERLAPPING 32-bit words — word [cb][row] holds the bits of the filter columns [16 cb, 16 cb + 32) of
-// row `row` (tshift >= 2: a window of up to 63 bins spans at most 17 filter columns, so the window whose first filter column is
-// 16 cb + i, i < 16, lies inside word cb): ONE 4-byte load per window row, no second word for windows that straddle a boundary, and
-// a lane's state per window in flight is one register — the sparse kernel keeps the words of 32 windows in flight per wave (its
-// loads' latency, not their bytes, is what it waits for: phase clocks, round 6).  W consecutive words are 4 W bytes = 2-3 lines
-// (round 3's 8-byte words: 4.5 lines, a second load for windows across a 64-column boundary).  Twice the bits of a plain bitmap:
-// 1.4 GB for a human 10 kb table at 16 columns per bit.
-// One wave per matrix row; a row's pixels are sorted by column, so the lanes of a batch of 64 pixels that fall into one column block
-// are neighbours: their bits are ORed along the run first (six shuffle steps) and the run's last lane sends TWO atomics — an atomic
-// per pixel (the first form, and twice that with overlapping words) serialised on the few words a row's thousand cis pixels share:
-// 24 ms, then 44 ms, per 3.8e8-pixel table; now a few.
+// Presence FILTER of the whole table for the sparse trans kernel: bit j of the 32-bit word tbits[cb][row] says that row `row` holds a
+// pixel in columns [(16 cb + j) << tshift, (16 cb + j + 1) << tshift).  Without it every (window, row) pair of a trans pile-up
+// fetched a cache line of the pixel table — 2.5e7 random lines, 3 GB, per 4.9e5 windows of 51 x 51 — to find, 97 times out of 100,
+// nothing; with it the W consecutive words of a window's rows are one coalesced load, and only the rows whose bits meet the window's
+// columns look the table up.  History: round 3 an exact bitmap of 64-bit words (nbins^2 / 8 bytes: 11.5 GB for a human 10 kb table);
+// round 4 a bit per 2^tshift columns (a set bit only SENDS the row to the real lookup, and at trans densities a handful of extra
+// columns changes the hit rate from 0.36 % to 0.4 %: 0.7 GB at 16 columns per bit; tables whose filter does not fit get a coarser one).
+// Round 6: OVERLAPPING 32-bit words — word cb covers the filter columns [16 cb, 16 cb + 32), so the window whose first filter column
+// is 16 cb + i, i < 16, lies inside word cb (tshift >= 2: a window of up to 63 bins spans at most 17 filter columns): ONE 4-byte load
+// per window row, never a second word for windows across a boundary, one register per window in flight, 4 W bytes = 2-3 lines (the
+// 8-byte words: 4.5 lines + the second load).  Twice the bits of a plain bitmap: 1.4 GB for a human 10 kb table at 16 columns per bit.
+// Built on the first call that uses the sparse kernel (pup_engine.hip), one wave per matrix row: a row's pixels are sorted by column,
+// so the lanes of a batch of 64 pixels that fall into one column block are neighbours — their bits are ORed along the run (six shuffle
+// steps) and the run's last lane sends TWO atomics.  An atomic per pixel serialised on the few words a row's thousand cis pixels
+// share: 24 ms per 3.8e8-pixel table (44 with the overlap); now 4.
 PUP_KERNEL __launch_bounds__(256) void tbits_fill_kernel(const long long* __restrict__ indptr, const int2* __restrict__ px,
                                                          unsigned* __restrict__ tbits, long long nbins, int tshift) {
     const int lane = threadIdx.x & 63;

@@ -384,3 +384,54 @@ def test_trans_sparse_kernel_vs_oracle_and_dense(hip_lib, small_clr, oracle_mod,
     for k in ("sparse_fine_filter", "sparse_coarse_filter", "sparse_first_form", "sparse_no_filter", "sparse_first_form_no_filter"):
         np.testing.assert_array_equal(got[k]["num"], got["dense"]["num"])
         np.testing.assert_array_equal(got[k]["sum"], got["sparse"]["sum"])
+
+
+@pytest.mark.parametrize("pad", [1, 7, 19, 31])
+def test_trans_sparse_queue_kernel_chunk_shapes(hip_lib, small_clr, oracle_mod, pad):
+    """The queued sparse kernel (round 6) over the shapes its batches can take: chunk sizes that leave one window, a full batch, a
+    batch + 1 and several batches to a wave; filters of 4 / 16 / 512 columns per bit; coverage vectors, flips, a scalar expected;
+    windows touching the table's last bins.  Against the C oracle, and bit for bit against the kernel's first form (tuning bit 21)."""
+    import os
+    from coolpuppy_amd.engine import PileupEngine
+    po = oracle_mod
+    clr = small_clr
+    indptr, col, cnt = clr.pixel_table()
+    w = clr.bins()["weight"][:].values
+    cov = clr.bins()["cov_tot_raw"][:].values
+    W, T, n = 2 * pad + 1, 2, 2500
+    rng = np.random.default_rng(600 + pad)
+    loA, hiA = clr.extent("chrA")
+    loC, hiC = clr.extent("chrC")
+    r0 = rng.integers(loA, hiA - W, n).astype(np.int32)
+    c0 = rng.integers(loC, hiC - W + 1, n).astype(np.int32)
+    c0[:40] = hiC - W                                       # windows ending on the table's last bin
+    tile = rng.integers(0, T, n).astype(np.int32)
+    flip = (rng.random(n) < 0.3).astype(np.uint8)
+    r0, c0, flip, tile, tile_ptr = _group(r0, c0, flip, tile, T)
+    ff = _flip_from(flip, tile, tile_ptr)
+    try:
+        for shift, chunk in (("2", 1), ("4", 64), ("4", 65), ("9", 333), (None, 0)):
+            if shift is None:
+                os.environ.pop("COOLPUPPY_AMD_TBITS_SHIFT", None)
+            else:
+                os.environ["COOLPUPPY_AMD_TBITS_SHIFT"] = shift
+            for mode, weight, covv, expv in ((0, w, None, None), (po.MODE_COV, None, cov, None), (po.MODE_OOE, w, None, np.array([0.37]))):
+                want = po.pileup_c(indptr, col, cnt, weight, covv, expv, r0, c0, flip, tile, T, pad, -1, mode)
+                got = {}
+                for form, variant in (("queued", 0), ("first", 1 << 21)):
+                    eng = PileupEngine(0)
+                    eng.load_pixels(indptr, col, cnt)
+                    eng.build_index(clr.chrom_offset)
+                    eng.set_tuning(chunk, variant)
+                    eng.load_bins(weight, covv)
+                    eng.set_expected(expv)
+                    eng.reset(T, pad)
+                    eng.accumulate(r0, c0, tile_ptr, flip_from=ff, ignore_diags=-1, mode=mode)
+                    got[form] = eng.fetch()
+                    assert eng.last_kernel() == "sparse"
+                    eng.close()
+                    _compare(got[form], want)
+                for k in ("sum", "num", "cov_start", "cov_end"):
+                    np.testing.assert_array_equal(got["queued"][k], got["first"][k], err_msg=f"{k} shift {shift} chunk {chunk} mode {mode}")
+    finally:
+        os.environ.pop("COOLPUPPY_AMD_TBITS_SHIFT", None)
