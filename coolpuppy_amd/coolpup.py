@@ -1111,14 +1111,40 @@ class CoordCreator:
 # ------------------------------------------------------------------------------------------------------
 # PileUpper
 # ------------------------------------------------------------------------------------------------------
-def _make_cooler_view(clr):
-    """cooltools.lib.common.make_cooler_view: one whole-chromosome region per chromosome."""
-    return pd.DataFrame({"chrom": list(clr.chromnames), "start": 0,
-                         "end": [int(clr.chromsizes[c]) for c in clr.chromnames], "name": list(clr.chromnames)})
+def _view_signature(chromsizes):
+    """What a validated view frame was validated against: the chromosome names and sizes."""
+    return (tuple(str(c) for c in chromsizes.index), tuple(int(v) for v in chromsizes.values))
+
+
+# frames _make_cooler_view / _make_viewframe have produced, by identity (weak references): pileup() validates the view and hands the
+# SAME object to PileUpper, which would validate it again — a third of a small call's set-up.  (Not DataFrame.attrs: pandas deep-copies
+# them into every derived frame.)
+_VALID_VIEWS = []
+
+
+def _remember_view(df, sig):
+    import weakref
+    _VALID_VIEWS[:] = [(r, s) for r, s in _VALID_VIEWS[-3:] if r() is not None] + [(weakref.ref(df), sig)]
+    return df
+
+
+def _make_cooler_view(clr, remember=False):
+    """cooltools.lib.common.make_cooler_view: one whole-chromosome region per chromosome.  remember: pileup()'s own local frame —
+    valid by construction, seen by nobody else — need not be validated again by the PileUpper it is handed to."""
+    names = [str(c) for c in clr.chromnames]
+    df = pd.DataFrame({"chrom": names, "start": 0, "end": [int(clr.chromsizes[c]) for c in clr.chromnames], "name": list(names)})
+    return _remember_view(df, _view_signature(clr.chromsizes)) if remember else df
 
 
 def _make_viewframe(view_df, chromsizes):
-    """bioframe.make_viewframe for the DataFrame case: chrom/start/end[/name], bounds-checked."""
+    """bioframe.make_viewframe for the DataFrame case: chrom/start/end[/name], bounds-checked.  A frame pileup() has just made or
+    validated for the same chromosomes (_remember_view: the very object, a local of pileup() nobody else holds) is handed back as a
+    copy; frames that become public attributes are never remembered — their owner may edit them."""
+    sig = _view_signature(chromsizes)
+    for ref, s in _VALID_VIEWS:
+        if ref() is view_df and s == sig and list(view_df.columns) == ["chrom", "start", "end", "name"] \
+                and isinstance(view_df.index, pd.RangeIndex):
+            return view_df.copy()
     df = pd.DataFrame(view_df).copy()
     if "chrom" not in df.columns:
         df.columns = ["chrom", "start", "end", "name"][: df.shape[1]] + list(df.columns[4:])
@@ -1128,7 +1154,7 @@ def _make_viewframe(view_df, chromsizes):
     df = df[["chrom", "start", "end", "name"]].reset_index(drop=True)
     if df["name"].duplicated().any():
         raise ValueError("view_df is not a valid viewframe: region names are not unique")
-    sizes = {str(c): int(v) for c, v in zip(chromsizes.index, chromsizes.values)}
+    sizes = dict(zip(*sig))
     for r in zip(df["chrom"].tolist(), df["start"].tolist(), df["end"].tolist(), df["name"].tolist()):
         if r[0] not in sizes or r[1] < 0 or r[2] > sizes[r[0]] or r[1] >= r[2]:
             raise ValueError(f"view_df is not a valid viewframe or incompatible: region {r} out of bounds")
@@ -1705,7 +1731,9 @@ class PileUpper:
                 ahead = CC._draw_ahead = _DrawAhead(CC, sizes)
         if early is not None:                                 # started for a pile-up that is not this one: stop it, generator back
             early[0].cancel(early[2])
-        fused = (owned is None and nsh > 0 and not grouped and not self.expected and not self.trans and not self.rescale
+        # (round 6: also without controls — a loop list piled up as it is, nshifts = 0: the per-region window tables and the pass that
+        # gathers them were half of such a call's host time at twenty regions)
+        fused = (owned is None and (nsh > 0 or not self.control) and not grouped and not self.expected and not self.trans and not self.rescale
                  and self._plain_pairs(modify, _by_window, False, groupby) and not os.environ.get("COOLPUPPY_AMD_NO_FUSED_WINDOWS"))
         plan = None
         try:
@@ -1738,7 +1766,8 @@ class PileUpper:
         from .engine import MODE_COV
         CC = self.CC
         W = 2 * self.pad_bins + 1
-        nsh = int(self.nshifts)
+        nsh = int(self.nshifts) if self.control else 0               # (0: no controls at all — ROI windows only)
+        want_control = nsh > 0
         regs = []
         for bi, (region1, region2) in enumerate(pairs):
             rows = CC._rows_pairs_region(tuple(self._region_tuple(region1)))
@@ -1760,7 +1789,9 @@ class PileUpper:
             pos += k
         roi_total = pos
         for bi, region1, rows, n in regs:
-            if n == 0:
+            if n == 0 or not want_control:
+                if n and not want_control:
+                    logger.info(f"{region1, region1}: {spans[bi][1] - spans[bi][0]}")
                 continue
             shift, sign = CC._draw_raw(n * nsh)
             lo, hi, off = self._global_extents[region1]
@@ -1790,7 +1821,8 @@ class PileUpper:
                               None, RunTile(b - a, m, 0, G), igd, mode, size(m), size(m), bi))
             return items
 
-        plan = _Plan({"T": T, "G": G, "gid": {"all": 0}, "order": {KIND_ROI: ["all"], KIND_CONTROL: ["all"]}, "want_control": True,
+        plan = _Plan({"T": T, "G": G, "gid": {"all": 0}, "order": {KIND_ROI: ["all"], KIND_CONTROL: ["all"] if want_control else []},
+                      "want_control": want_control,
                       "groupby": [], "grouped": False, "calls": calls, "pad": self.pad_bins, "rescale": False,
                       "n_regions": len(pairs),
                       "region_groups": [({KIND_ROI: [], KIND_CONTROL: []} if bi in live else None) for bi in range(len(pairs))],
@@ -2786,7 +2818,7 @@ def pileup(clr, features, features_format="bed", view_df=None, expected_df=None,
     if nproc == 0:
         nproc = -1
     if view_df is None:
-        view_df = _make_cooler_view(clr)
+        view_df = _make_cooler_view(clr, remember=True)
     else:
         try:
             view_df = _make_viewframe(view_df, clr.chromsizes).reset_index(drop=True)
@@ -2796,6 +2828,7 @@ def pileup(clr, features, features_format="bed", view_df=None, expected_df=None,
                 raise ValueError("view is not sorted by chromosome order and start")
         except Exception as e:
             raise ValueError("view_df is not a valid viewframe or incompatible") from e
+        _remember_view(view_df, _view_signature(clr.chromsizes))
     control = nshifts > 0
     if expected_df is None:
         expected_value_col = None
