@@ -86,6 +86,26 @@ def parse(argv=None):
 # ----------------------------------------------------------------------------------------------------
 # workload (cached under $TMPDIR so that back-to-back runs at N = 1, 2, 4, 8 do not regenerate it)
 # ----------------------------------------------------------------------------------------------------
+def exchange_verdict(world, rccl_ranks, strict, rank=0):
+    """What an N > 1 line may call its exchange when `--exchange native` was asked for (pure: tests/test_bench_sharding.py).
+    `--exchange native` is the path the line claims to measure: a communicator that is missing (rccl_ranks None) or spans fewer
+    ranks than the job would time something else under that name.  strict: say so and stop.  Else (round 6: the engine-side path had
+    never run on more than one rank before the driver's scaling run — a curve over torch's own RCCL all-reduce, LABELLED as such,
+    says more than no curve): fall back, loudly, and say so in the line (`exchange`, `native_exchange_failed`)."""
+    if rccl_ranks == world:
+        return {"fallback": False, "message": "", "exchange": "pup_allreduce (RCCL on the engine's stream, in place)"}
+    msg = (f"[bench] rank {rank}: --exchange native on {world} ranks, but the engine's RCCL communicator spans "
+           f"{rccl_ranks} rank(s)")
+    if strict:
+        raise SystemExit(msg + " — refusing to report a number for a path that did not run "
+                         "(--exchange torch times torch.distributed.all_reduce on exported buffers instead)")
+    return {"fallback": True,
+            "message": msg + " — FALLING BACK to torch.distributed.all_reduce (nccl backend = RCCL) on exported buffers; the "
+                             "line says so in `exchange` and `native_exchange_failed`",
+            "exchange": (f"FALLBACK: torch.distributed.all_reduce (RCCL) on exported buffers + a host synchronisation per step "
+                         f"— the engine's own communicator spanned {rccl_ranks} of {world} ranks")}
+
+
 def _tmp(name):
     return os.path.join(os.environ.get("TMPDIR", "/tmp"), name)
 
@@ -526,22 +546,13 @@ def main():
             if native_comm is not None:
                 rccl_ranks = pdist.comm_ranks(native_comm)
                 exchange_used = "pup_allreduce (RCCL on the engine's stream, in place)"
-            # --exchange native is the path the line claims to measure: a communicator that is missing or spans fewer ranks than
-            # the job would time something else under that name — say so and stop (--exchange torch asks for the fallback openly)
-            if rccl_ranks != world:
-                msg = (f"[bench] rank {rank}: --exchange native on {world} ranks, but the engine's RCCL communicator spans "
-                       f"{rccl_ranks} rank(s)")
-                if a.strict_exchange:
-                    raise SystemExit(msg + " — refusing to report a number for a path that did not run "
-                                     "(--exchange torch times torch.distributed.all_reduce on exported buffers instead)")
-                # round 6: the engine-side path has never run on more than one rank before the driver's scaling run; a curve
-                # measured over torch's own RCCL all-reduce and LABELLED as such says more than no curve.  Loud, and in the line.
-                print(msg + " — FALLING BACK to torch.distributed.all_reduce (nccl backend = RCCL) on exported buffers; the "
-                      "line says so in `exchange` and `native_exchange_failed`", file=sys.stderr, flush=True)
+            verdict = exchange_verdict(world, rccl_ranks, a.strict_exchange, rank)
+            if verdict["message"]:
+                print(verdict["message"], file=sys.stderr, flush=True)
+            if verdict["fallback"]:
                 native_comm = None
                 native_failed = True
-                exchange_used = (f"FALLBACK: torch.distributed.all_reduce (RCCL) on exported buffers + a host synchronisation per step "
-                                 f"— the engine's own communicator spanned {rccl_ranks} of {world} ranks")
+                exchange_used = verdict["exchange"]
 
     def make_step(p_r0, p_c0, n, tptr):
         def step():

@@ -158,16 +158,12 @@ def main_plan(a, rank, world, local_rank, bench):
         # falls back with a warning) or that spans fewer ranks than the job is an error here, not a footnote
         comm = pdist._NATIVE_COMMS.get((eng.device_id, world), (None, None))[0]
         rccl_ranks = pdist.comm_ranks(comm) if comm else None
-        if rccl_ranks != world:
-            msg = (f"[bench] rank {rank}: --exchange native on {world} ranks, but the engine's RCCL communicator spans "
-                   f"{rccl_ranks} rank(s)")
-            if getattr(a, "strict_exchange", False):
-                raise SystemExit(msg + " — refusing to report a number for a path that did not run")
-            # (round 6, as bench.py: dist.allreduce_engine has then fallen back to torch's RCCL all-reduce on exported buffers —
-            # measured and LABELLED instead of no line at all)
-            print(msg + " — the steps run dist.allreduce_engine's fallback (torch.distributed.all_reduce on exported buffers); "
-                  "the line says so", file=sys.stderr, flush=True)
-            native_failed = True
+        # (as bench.py: strict -> exit; else dist.allreduce_engine has fallen back to torch's RCCL all-reduce on exported buffers and the
+        # line is measured and LABELLED instead of missing)
+        verdict = bench.exchange_verdict(world, rccl_ranks, getattr(a, "strict_exchange", False), rank)
+        if verdict["message"]:
+            print(verdict["message"], file=sys.stderr, flush=True)
+        native_failed = verdict["fallback"]
     pix_local = float(eng.stats()["pixels_in_windows"])
     families = sorted({eng.last_kernel()})
     eng.set_profiling(0)

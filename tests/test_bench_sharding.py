@@ -94,3 +94,21 @@ def test_bench_config_3_and_4_two_ranks_on_one_gpu_match_one_rank(hip_lib, tmp_p
     assert two["config"]["snippets_per_step"] == one["config"]["snippets_per_step"] == one["check"]["n_sum"]
     assert one["config"]["tiles"] == two["config"]["tiles"] and (one["config"]["tiles"] >= 30 if config == 3 else one["config"]["tiles"] <= 2)
     assert one["roofline"]["kernel_family"] and one["cpu_baseline"] is None
+
+
+def test_exchange_verdict_labels_a_fallback_and_refuses_when_strict():
+    """bench.py --gpus N with --exchange native: a communicator spanning the job -> the engine's own all-reduce under its name; a
+    missing or smaller one -> the torch fallback, LABELLED and flagged (round 6), or — --strict-exchange — no line at all."""
+    import bench
+    ok = bench.exchange_verdict(8, 8, False)
+    assert ok == {"fallback": False, "message": "", "exchange": "pup_allreduce (RCCL on the engine's stream, in place)"}
+    assert bench.exchange_verdict(8, 8, True) == ok
+    for spans in (None, 1, 4):
+        v = bench.exchange_verdict(8, spans, False, rank=3)
+        assert v["fallback"] and v["exchange"].startswith("FALLBACK: torch.distributed.all_reduce") and f"{spans} of 8" in v["exchange"]
+        assert "rank 3" in v["message"] and "FALLING BACK" in v["message"]
+        with pytest.raises(SystemExit, match="refusing to report"):
+            bench.exchange_verdict(8, spans, True)
+    a = bench.parse(["--gpus", "8"])
+    assert a.exchange == "native" and a.strict_exchange is False
+    assert bench.parse(["--gpus", "8", "--strict-exchange"]).strict_exchange is True
